@@ -1,0 +1,336 @@
+#!/usr/bin/env python
+"""TEST INFRASTRUCTURE ONLY.  Generates tests/golden/*.json.gz by calling the REFERENCE's
+own Python (imported from /root/reference via oracle/ref_harness.py) on seeded synthetic
+inputs from tests/casegen.py.  Run in the build container only:
+
+    PYTHONHASHSEED=0 python oracle/gen_golden.py
+
+The fixtures hold inputs and the reference's outputs (data only; no reference source).
+fuzzysearch / Levenshtein are the documented restatements of oracle/stubs.py
+("parity unpinned" at that third-party boundary, see that file).
+"""
+import gzip
+import json
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+import casegen  # noqa: E402
+import ref_harness  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def dump(name, obj):
+    path = os.path.join(GOLD, name + ".json.gz")
+    with gzip.GzipFile(path, "wb", mtime=0) as f:
+        f.write(json.dumps(obj, separators=(",", ":"), sort_keys=True).encode())
+    print("wrote", path, os.path.getsize(path), "bytes")
+
+
+def write_fasta(path, names, seqs):
+    with open(path, "w") as f:
+        for n, s in zip(names, seqs):
+            f.write(">" + n + "\n" + s + "\n")
+
+
+def gen_fmea(U, tmp):
+    cases = []
+    specs = [
+        dict(seed=1, n_seg=2, n_fam=3, noise=5, frag=(1, 1)),
+        dict(seed=2, n_seg=3, n_fam=6, noise=20, frag=(1, 4)),
+        dict(seed=3, n_seg=2, n_fam=4, noise=10, frag=(2, 5), dup=15),
+        dict(seed=4, n_seg=4, n_fam=10, noise=40, frag=(1, 3), chroms=("chrX",)),
+        dict(seed=5, n_seg=1, n_fam=5, noise=0, frag=(3, 6), copies=(5, 14)),
+        dict(seed=6, n_seg=3, n_fam=8, noise=100, frag=(1, 2)),
+    ]
+    for sp in specs:
+        for skip_gap, max_len in ((2000, 30000), (150, 5000)):
+            rows = casegen.make_hsp_table(**sp)
+            p = os.path.join(tmp, "fmea_%d_%d.out" % (sp["seed"], skip_gap))
+            with open(p, "w") as f:
+                f.writelines(casegen.hsp_to_blast6_lines(rows))
+            pkl = U.get_longest_repeats_v4(p, skip_gap, max_len, 0)
+            res = U.load_from_file(pkl)
+            cases.append(dict(rows=rows, skip_gap=skip_gap, max_len=max_len, expected=list(res.keys())))
+    # hand-made edge cases: chain break at skip_gap +-1, 10-bp rounding collisions
+    q, s = "chr1$0", "chr1$1000000"
+    hand = []
+    for gap in (1999, 2000, 2001):
+        hand.append([(q, s, 100, 400, 5000, 5300), (q, s, 400 + gap, 800 + gap, 5300 + 10, 5700 + 10)])
+        hand.append([(q, s, 100, 400, 5000, 5300), (q, s, 410, 800, 5300 + gap, 5700 + gap)])
+        hand.append([(q, s, 100, 400, 9000, 8700), (q, s, 410, 800, 8700 - gap, 8300 - gap)])
+    hand.append([(q, s, 101, 400, 5001, 5300), (q, "chr2$0", 105, 398, 77001, 77294), (q, "chr2$0", 2105, 2398, 97001, 97294),
+                 (q, "chr2$0", 2111, 2391, 197001, 197281)])
+    hand.append([(q, s, 100, 100 + 78, 5000, 5078), (q, s, 1000, 1000 + 79, 15000, 15079), (q, s, 3000, 3000 + 80, 25000, 25080)])
+    hand.append([(q, q, 100, 900, 20100, 20900), (q, q, 20100, 20900, 100, 900), (q, q, 150, 880, 50150, 50880),
+                 (q, q, 100, 900, 100, 900)])
+    for rows in hand:
+        p = os.path.join(tmp, "fmea_hand.out")
+        with open(p, "w") as f:
+            f.writelines(casegen.hsp_to_blast6_lines(rows))
+        pkl = U.get_longest_repeats_v4(p, 2000, 30000, 0)
+        cases.append(dict(rows=rows, skip_gap=2000, max_len=30000, expected=list(U.load_from_file(pkl).keys())))
+    dump("fmea", cases)
+
+
+def run_msa_case(U, tmp, case):
+    raw = os.path.join(tmp, "aln.fa")
+    write_fasta(raw, case["names"], case["seqs"])
+    clean = U.remove_sparse_col_in_align_file(raw)
+    cn, cc = U.read_fasta(clean)
+    out = dict(case)
+    out["clean"] = [cc[n] for n in cn]
+    fn = {"tir": U.judge_boundary_v5, "helitron": U.judge_boundary_v6, "non_ltr": U.judge_boundary_v9}[case["te_type"]]
+    try:
+        is_te, info, cons, rn = fn(case["cand"], clean, 0, case["te_type"], case["plant"], "cons")
+        out["expected"] = [bool(is_te), info, cons, int(rn)]
+    except Exception as e:  # the reference raises on a few degenerate inputs
+        out["expected"] = ["EXC", type(e).__name__]
+    return out
+
+
+def gen_judge(U, tmp):
+    for te_type, n, seed0 in (("tir", 60, 11), ("non_ltr", 40, 12), ("helitron", 40, 13)):
+        cases = []
+        for p in casegen.msa_param_grid(te_type, n, seed0):
+            c = casegen.make_msa_case(**p)
+            for plant in ((1, 0) if te_type == "tir" and p["seed"] % 3 == 0 else (1,)):
+                c2 = dict(c)
+                c2["plant"] = plant
+                cases.append(run_msa_case(U, tmp, c2))
+        # large ones: 101-row cap and wide matrices
+        big = casegen.make_msa_case(seed=seed0 * 7, te_type=te_type, rows=110, te_len=900, div=0.1, ins_cols=10,
+                                    trunc_rows=4, shift_l=6, shift_r=-4, tsd_len=8, tsd_frac=0.9)
+        cases.append(run_msa_case(U, tmp, big))
+        stats = {}
+        for c in cases:
+            k = str(c["expected"][:2])
+            stats[k] = stats.get(k, 0) + 1
+        print(te_type, "outcomes:", stats)
+        dump("judge_" + te_type, cases)
+
+
+def gen_boundary_search(U):
+    """search_boundary_homo_v3 / v4 and calculate_window_homology called directly."""
+    rng = np.random.default_rng(77)
+    cases = []
+    for i, p in enumerate(casegen.msa_param_grid("tir", 40, 21)):
+        c = casegen.make_msa_case(**p)
+        mat = [list(s) for s in c["seqs"]]
+        R, C = len(mat), len(mat[0])
+        thr = 0.95 if R <= 2 else (0.9 if R <= 5 else float(rng.choice([0.7, 0.8])))
+        for side in ("start", "end"):
+            base = 50 if side == "start" else C - 51
+            pos = int(np.clip(base + int(rng.integers(-30, 31)), 0, C - 1))
+            v3 = U.search_boundary_homo_v3(int(R / 2), pos, mat, R, C, side, thr, 0, 20, 10)
+            v4 = U.search_boundary_homo_v4(int(R / 2), pos, mat, R, C, side, thr, thr - 0.05, thr, 0, 20, 10)
+            cases.append(dict(seqs=c["seqs"], pos=pos, side=side, thr=thr, v3=int(v3), v4=[bool(v4[0]), int(v4[1])]))
+    dump("boundary_search", cases)
+
+    # threshold ties: R=10 / 20 rows with columns at exactly 6/10, 7/10, 8/10, 17/20
+    ties = []
+    for R, k, thr in ((10, 6, 0.7), (10, 7, 0.7), (10, 7, 0.8), (10, 8, 0.8), (20, 17, 0.95), (20, 14, 0.8),
+                      (20, 14, 0.7), (10, 9, 0.9), (10, 8, 0.9), (3, 2, 0.7)):
+        W = 12
+        rows = []
+        for r in range(R):
+            rows.append("".join("A" if r < k else "CGT"[(r + c) % 3] for c in range(W)))
+        mat = [list(s) for s in rows]
+        res = U.calculate_window_homology(mat, list(range(0, W)), thr)
+        res2 = U.calculate_window_homology(mat, list(range(W - 1, 1, -1)), thr)
+        ties.append(dict(seqs=rows, thr=thr, fwd=int(res), rev=int(res2)))
+    dump("thr_ties", ties)
+
+
+def gen_tsd(U):
+    rng = np.random.default_rng(5)
+    cases = []
+    for i in range(300):
+        k = int(rng.choice([0, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12]))
+        L = int(rng.integers(30, 90))
+        core = casegen.rand_seq(rng, L)
+        mode = rng.random()
+        if k == 2 and mode < 0.5:
+            tsd = "TA"
+        elif k == 2:
+            tsd = casegen.rand_seq(rng, 2)
+            core = "CCC" + core[3:-3] + "GGG"
+        elif k == 3:
+            tsd = str(rng.choice(["TAA", "TTA", casegen.rand_seq(rng, 3)]))
+            if mode < 0.4:
+                core = "CACTA" + core[5:-5] + "TAGTG"
+            elif mode < 0.6:
+                core = "CACTG" + core[5:-5] + "CAGTG"
+        elif k == 4:
+            tsd = str(rng.choice(["TTAA", casegen.rand_seq(rng, 4)]))
+        else:
+            tsd = casegen.rand_seq(rng, k)
+        rt = tsd
+        if k >= 8 and mode < 0.3:
+            j = int(rng.integers(0, k))
+            rt = tsd[:j] + casegen.BASES[(casegen.BASES.index(tsd[j]) + 1) % 4] + tsd[j + 1:]
+        left = casegen.rand_seq(rng, int(rng.integers(0, 15))) + tsd
+        right = rt + casegen.rand_seq(rng, int(rng.integers(0, 15)))
+        s = list(left + core + right)
+        # sprinkle gaps
+        for _ in range(int(rng.integers(0, 8))):
+            p = int(rng.integers(0, len(s) + 1))
+            s[p:p] = ["-"] * int(rng.integers(1, 4))
+        s = "".join(s)
+        # boundary columns = first / last base of core in gapped coordinates
+        ung = -1
+        bs = be = None
+        for col, ch in enumerate(s):
+            if ch != "-":
+                ung += 1
+                if ung == len(left):
+                    bs = col
+                if ung == len(left) + L - 1:
+                    be = col
+        bs += int(rng.choice([0, 0, 0, 1, -1]))
+        be += int(rng.choice([0, 0, 0, 1, -1]))
+        bs = max(0, bs)
+        be = min(len(s) - 1, be)
+        for plant in (0, 1):
+            l, r = U.TSDsearch_v5(s, bs, be, plant)
+            cases.append(dict(seq=s, start=bs, end=be, plant=plant, left=l, right=r))
+    dump("tsd_search", cases)
+
+
+def gen_tir_kmer(U):
+    cases = []
+    i = 0
+    for te_len in (120, 300, 1500):
+        for tsd_len in (2, 3, 4, 5, 6, 8, 9, 10, 11):
+            for off_l, off_r in ((0, 0), (7, -3), (-20, 25), (40, 40)):
+                i += 1
+                seq, flank = casegen.make_tir_candidate(1000 + i, te_len=te_len, tsd_len=tsd_len, off_l=off_l,
+                                                        off_r=off_r, with_n=(i % 7 == 0))
+                for plant in (0, 1):
+                    res = U.search_confident_tir_v4(seq, flank + 1, len(seq) - flank, flank, "q%d" % i, plant)
+                    # canonical order: the reference's order among equal distances depends on
+                    # PYTHONHASHSEED, and its -C_{i} index is the rank in that order; fixtures keep the multiset
+                    # {(tsd, distance, sequence)} sorted canonically.
+                    items = []
+                    for name, s in res.items():
+                        parts = name.split("-")
+                        tsd = [p for p in parts if p.startswith("tsd_")][0][4:]
+                        dist = int([p for p in parts if p.startswith("distance_")][0][9:])
+                        items.append([dist, tsd, s])
+                    items.sort()
+                    cases.append(dict(seq=seq, flank=flank, plant=plant, name="q%d" % i, n=len(res), items=items))
+    dump("tir_kmer", cases)
+
+
+def gen_gather(U, tmp):
+    cases = []
+    for seed in (1, 2, 3):
+        names, seqs = casegen.make_genome(seed)
+        ref = os.path.join(tmp, "genome_%d.fa" % seed)
+        write_fasta(ref, names, seqs)
+        copies = casegen.make_copies(seed, names, seqs)
+        cand = os.path.join(tmp, "cand_%d.fa" % seed)
+        write_fasta(cand, list(copies.keys()), ["ACGT" * 30 for _ in copies])
+        captured = {}
+
+        def fake_copies(query_path, reference, temp_dir, max_copy_num, threads, _c=copies):
+            os.makedirs(temp_dir, exist_ok=True)
+            return _c
+
+        def fake_members(task, temp_dir, subset_script_path, plant, TE_type, debug, result_type, _cap=captured):
+            (query_name, cur_seq, trunc_member_file, extend_member_file) = task
+            ent = {}
+            n, c = U.read_fasta(extend_member_file)
+            ent["extend"] = [[x, c[x]] for x in n]
+            if trunc_member_file is not None:
+                n, c = U.read_fasta(trunc_member_file)
+                ent["trunc"] = [[x, c[x]] for x in n]
+            else:
+                ent["trunc"] = None
+            _cap[query_name] = ent
+            return (None, None, "", 0, extend_member_file)
+
+        saved = (U.get_full_length_copies_minimap2, U.run_find_members_v8, U.ProcessPoolExecutor, U.as_completed)
+        U.get_full_length_copies_minimap2 = fake_copies
+        U.run_find_members_v8 = fake_members
+        U.ProcessPoolExecutor = ref_harness.SyncExecutor
+        U.as_completed = lambda fs: fs
+        try:
+            log = type("L", (), {"logger": type("LL", (), {"info": staticmethod(lambda *a: None)})})()
+            U.flank_region_align_v5(cand, os.path.join(tmp, "real.fa"), 50, ref, None, "other", tmp, 1, 0, log,
+                                    "", 1, 0, 0, os.path.join(tmp, "low.fa"))
+        finally:
+            (U.get_full_length_copies_minimap2, U.run_find_members_v8, U.ProcessPoolExecutor, U.as_completed) = saved
+        cases.append(dict(names=names, seqs=seqs, flank=50,
+                          copies={k: [list(t) for t in v] for k, v in copies.items()}, expected=captured))
+
+        # flanking_seq (a-6)
+        rng = np.random.default_rng(seed)
+        rep_names = []
+        for _ in range(40):
+            ci = int(rng.integers(0, len(names)))
+            n = len(seqs[ci])
+            L = int(rng.integers(80, 3000))
+            st = int(rng.choice([0, 5, 49, 50, 51, n - L - 60, n - L - 50, n - L - 10, n - L, int(rng.integers(0, n - L))]))
+            st = max(0, st)
+            rep_names.append("%s:%d-%d" % (names[ci], st, st + L))
+        rep_names = list(dict.fromkeys(rep_names))
+        lr = os.path.join(tmp, "lr.fa")
+        write_fasta(lr, rep_names, [seqs[names.index(x.split(":")[0])][int(x.split(":")[1].split("-")[0]):int(x.split("-")[1])] for x in rep_names])
+        out = os.path.join(tmp, "lr.flanked.fa")
+        U.flanking_seq(lr, out, ref, 50)
+        n, c = U.read_fasta(out)
+        cases[-1]["flanking_in"] = rep_names
+        cases[-1]["flanking_out"] = [[x, c[x]] for x in n]
+    dump("gather", cases)
+
+
+def gen_tails(U):
+    rng = np.random.default_rng(9)
+    cases = []
+    for i in range(200):
+        L = int(rng.integers(5, 80))
+        s = casegen.rand_seq(rng, L)
+        m = rng.random()
+        if m < 0.3:
+            s = s + "A" * int(rng.integers(4, 12)) + casegen.rand_seq(rng, int(rng.integers(0, 6)))
+        elif m < 0.6:
+            u = casegen.rand_seq(rng, int(rng.integers(2, 7)))
+            s = s + u * int(rng.integers(3, 7)) + casegen.rand_seq(rng, int(rng.integers(0, 4)))
+        a = U.find_tail_polyA(s)
+        b = U.find_longest_tandem_repeat_tail(s)
+        cases.append(dict(seq=s, polyA=int(a[0]), tandem=int(b[0])))
+    dump("tails", cases)
+
+
+def main():
+    assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
+    U = ref_harness.load_reference_util()
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails"]
+    with tempfile.TemporaryDirectory() as tmp:
+        if "fmea" in which:
+            gen_fmea(U, tmp)
+        if "judge" in which:
+            gen_judge(U, tmp)
+        if "search" in which:
+            gen_boundary_search(U)
+        if "tsd" in which:
+            gen_tsd(U)
+        if "kmer" in which:
+            gen_tir_kmer(U)
+        if "gather" in which:
+            gen_gather(U, tmp)
+        if "tails" in which:
+            gen_tails(U)
+
+
+if __name__ == "__main__":
+    main()

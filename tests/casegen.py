@@ -1,0 +1,315 @@
+"""Seeded synthetic case generators shared by oracle/gen_golden.py (which feeds them to
+the reference's Python) and by the parity tests (which feed the same generators, at
+other seeds/sizes, to the C oracle and the HIP path).
+
+Pure numpy/python; no reference code, no oracle code.
+"""
+import numpy as np
+
+BASES = "ACGT"
+_COMP = {"A": "T", "C": "G", "G": "C", "T": "A"}
+
+
+def revcomp(s):
+    return "".join(_COMP.get(c, "N") for c in reversed(s))
+
+
+def rand_seq(rng, n):
+    return "".join(BASES[i] for i in rng.integers(0, 4, size=n))
+
+
+def mutate(rng, s, sub_rate):
+    out = list(s)
+    for i in range(len(out)):
+        if rng.random() < sub_rate:
+            out[i] = BASES[(BASES.index(out[i]) + 1 + int(rng.integers(0, 3))) % 4] if out[i] in BASES else "A"
+    return "".join(out)
+
+
+# ----------------------------------------------------------------------------------
+# multiple-alignment matrices (input of remove_sparse_col / judge_boundary_v5/v6/v9)
+# ----------------------------------------------------------------------------------
+def make_msa_case(seed, te_type="tir", rows=12, te_len=200, flank=50, div=0.08,
+                  row_gap_rate=0.01, ins_cols=3, trunc_rows=1, shift_l=0, shift_r=0,
+                  tsd_len=8, tsd_frac=0.8, noise_rows=0, homolog_flank_l=0,
+                  homolog_flank_r=0, long_gap_rows=0):
+    """Build a gapped rows x cols alignment of `rows` copies of one synthetic TE family
+    with +-`flank` bp of (mostly) non-homologous flanks, plus the candidate sequence
+    (row 0's element, boundaries shifted by shift_l/shift_r: positive = candidate longer).
+
+    Returns dict(names, seqs (gapped, equal length), cand, te_type, plant).
+    """
+    rng = np.random.default_rng(seed)
+    cons = rand_seq(rng, te_len)
+    if te_type == "tir":
+        tir = rand_seq(rng, 12)
+        # avoid TG..CA and TATATATA starts
+        if tir.startswith("TG"):
+            tir = "CA" + tir[2:]
+        cons = tir + cons[12:-12] + revcomp(tir)
+    elif te_type == "helitron":
+        cons = "TC" + cons[2:-4] + str(rng.choice(["CTAG", "CTAA", "CTGG", "CTGA"]))
+    elif te_type == "non_ltr":
+        cons = cons[:-14] + "A" * 14
+    L = len(cons)
+    hom_l = rand_seq(rng, homolog_flank_l)
+    hom_r = rand_seq(rng, homolog_flank_r)
+    # per-row ungapped pieces: left flank, element (with deletions marked), right flank
+    row_left, row_te, row_right = [], [], []
+    for r in range(rows):
+        te = mutate(rng, cons, div if r > 0 else 0.0)
+        lf = rand_seq(rng, flank)
+        rf = rand_seq(rng, flank)
+        if homolog_flank_l:
+            lf = lf[: flank - homolog_flank_l] + mutate(rng, hom_l, div)
+        if homolog_flank_r:
+            rf = mutate(rng, hom_r, div) + rf[homolog_flank_r:]
+        if te_type == "tir" and rng.random() < tsd_frac and tsd_len > 0:
+            if tsd_len == 2:
+                tsd = "TA"
+            elif tsd_len == 4:
+                tsd = "TTAA"
+            elif tsd_len == 3:
+                tsd = "TAA"
+            else:
+                tsd = rand_seq(rng, tsd_len)
+            lf = lf[: flank - tsd_len] + tsd
+            rf = tsd + rf[tsd_len:]
+        elif te_type == "helitron":
+            lf = lf[:-1] + ("A" if rng.random() < 0.9 else "C")
+            rf = ("T" if rng.random() < 0.9 else "G") + rf[1:]
+        elif te_type == "non_ltr" and rng.random() < tsd_frac:
+            k = int(rng.integers(8, 21))
+            tsd = rand_seq(rng, k)
+            while tsd.endswith("A") or tsd.startswith("A"):
+                tsd = rand_seq(rng, k)
+            lf = lf[: flank - k] + tsd
+            rf = tsd + rf[k:]
+        row_left.append(lf)
+        row_te.append(te)
+        row_right.append(rf)
+    # column model: every ungapped position of [left|te|right] is a column; add
+    # insertion columns (bases present in a single row) and per-row deletions.
+    total = flank + L + flank
+    ins_after = sorted(set(int(x) for x in rng.integers(5, total - 5, size=ins_cols))) if ins_cols else []
+    mat = []
+    for r in range(rows):
+        s = row_left[r] + row_te[r] + row_right[r]
+        s = list(s)
+        # deletions inside the element
+        i = flank + 25
+        while i < flank + L - 25:
+            if r > 0 and rng.random() < row_gap_rate:
+                glen = int(rng.integers(1, 6))
+                for j in range(i, min(i + glen, flank + L - 25)):
+                    s[j] = "-"
+                i += glen
+            i += 1
+        mat.append(s)
+    # truncated rows: leading part missing (gaps) through the left boundary
+    for t in range(trunc_rows):
+        r = rows - 1 - t
+        if r <= 0:
+            break
+        cut = flank + int(rng.integers(15, max(16, L // 3)))
+        for j in range(cut):
+            mat[r][j] = "-"
+    for t in range(long_gap_rows):
+        r = 1 + t
+        if r >= rows:
+            break
+        a = flank + L // 3
+        b = flank + 2 * L // 3
+        for j in range(a, b):
+            mat[r][j] = "-"
+    # insertion columns
+    for pos in reversed(ins_after):
+        owner = int(rng.integers(0, rows))
+        ilen = int(rng.integers(1, 4))
+        for r in range(rows):
+            ins = list(rand_seq(rng, ilen)) if r == owner else ["-"] * ilen
+            mat[r][pos:pos] = ins
+    seqs = ["".join(m) for m in mat]
+    # noise rows: unrelated sequence, same width
+    width = len(seqs[0])
+    for t in range(noise_rows):
+        seqs.append(rand_seq(rng, width))
+    names = ["chr%d:%d-%d(%s)" % (i % 5, 1000 + 37 * i, 1000 + 37 * i + L - 1, "+-"[i % 2])
+             for i in range(len(seqs))]
+    # candidate = row-0 element with shifted boundaries (ungapped coordinates of row 0)
+    row0 = row_left[0] + row_te[0] + row_right[0]
+    cs = max(0, flank - shift_l)
+    ce = min(len(row0), flank + L + shift_r)
+    cand = row0[cs:ce]
+    return {"names": names, "seqs": seqs, "cand": cand, "te_type": te_type, "plant": 1,
+            "true_start_col_ungapped": flank, "true_len": L}
+
+
+def msa_param_grid(te_type, n, seed0):
+    """n varied parameter sets for make_msa_case (deterministic)."""
+    rng = np.random.default_rng(seed0)
+    out = []
+    for i in range(n):
+        rows = int(rng.choice([2, 3, 5, 6, 8, 12, 20, 30, 60, 104]))
+        p = dict(seed=seed0 * 1000 + i, te_type=te_type, rows=rows,
+                 te_len=int(rng.choice([90, 120, 200, 350, 600, 900])),
+                 div=float(rng.choice([0.0, 0.03, 0.08, 0.15, 0.25])),
+                 row_gap_rate=float(rng.choice([0.0, 0.005, 0.02])),
+                 ins_cols=int(rng.choice([0, 2, 6])),
+                 trunc_rows=int(rng.choice([0, 1, 3])) if rows > 4 else 0,
+                 shift_l=int(rng.choice([0, 0, 7, -5, 20, -12, 3])),
+                 shift_r=int(rng.choice([0, 0, 7, -5, 20, -12, 3])),
+                 tsd_len=int(rng.choice([0, 2, 3, 4, 5, 8, 9, 11])),
+                 tsd_frac=float(rng.choice([0.0, 0.5, 1.0])),
+                 noise_rows=int(rng.choice([0, 0, 1, 4])),
+                 homolog_flank_l=int(rng.choice([0, 0, 0, 15, 45])),
+                 homolog_flank_r=int(rng.choice([0, 0, 0, 15, 45])),
+                 long_gap_rows=int(rng.choice([0, 0, 2])))
+        out.append(p)
+    return out
+
+
+# ----------------------------------------------------------------------------------
+# blast6-style HSP tables (input of get_longest_repeats_v4)
+# ----------------------------------------------------------------------------------
+def make_hsp_table(seed, n_seg=4, n_fam=6, copies=(2, 9), seg_len=1_000_000, noise=20,
+                   frag=(1, 4), dup=0, chroms=("chr1", "chr2")):
+    """HSP tuples (qname, sname, qs, qe, ss, se) resembling blastn -outfmt 6 between
+    1 Mbp genome segments named chr$offset, 1-based inclusive, reverse hits have ss>se."""
+    rng = np.random.default_rng(seed)
+    segs = []
+    for c in chroms:
+        for k in range(n_seg):
+            segs.append((c, k * seg_len))
+    copies_by_fam = []
+    for f in range(n_fam):
+        flen = int(rng.integers(150, 9000))
+        nc = int(rng.integers(copies[0], copies[1] + 1))
+        cl = []
+        for _ in range(nc):
+            sg = segs[int(rng.integers(0, len(segs)))]
+            pos = int(rng.integers(1000, seg_len - flen - 1000))
+            strand = int(rng.integers(0, 2))
+            cl.append((sg, pos, strand))
+        copies_by_fam.append((flen, cl))
+    rows = []
+    for flen, cl in copies_by_fam:
+        for a in range(len(cl)):
+            for b in range(len(cl)):
+                if a == b:
+                    continue
+                (sa, pa, sta), (sb, pb, stb) = cl[a], cl[b]
+                nfr = int(rng.integers(frag[0], frag[1] + 1))
+                cuts = sorted(set([0, flen] + [int(x) for x in rng.integers(30, flen - 30, size=nfr - 1)])) if flen > 80 else [0, flen]
+                for i in range(len(cuts) - 1):
+                    x0, x1 = cuts[i], cuts[i + 1]
+                    g0 = int(rng.integers(0, 12))
+                    g1 = int(rng.integers(0, 12))
+                    if x1 - g1 - (x0 + g0) < 20:
+                        continue
+                    # copy A forward coordinates of the fragment
+                    if sta == 0:
+                        qs, qe = pa + x0 + g0, pa + x1 - g1 - 1
+                    else:
+                        qs, qe = pa + (flen - x1) + g1, pa + (flen - x0) - g0 - 1
+                    if stb == 0:
+                        ts, te = pb + x0 + g0, pb + x1 - g1 - 1
+                    else:
+                        ts, te = pb + (flen - x1) + g1, pb + (flen - x0) - g0 - 1
+                    jitter = int(rng.integers(-3, 4))
+                    ts += jitter
+                    te += jitter
+                    if sta != stb:
+                        ss, se = te, ts
+                    else:
+                        ss, se = ts, te
+                    rows.append(("%s$%d" % sa, "%s$%d" % sb, qs, qe, ss, se))
+    for _ in range(noise):
+        sa = segs[int(rng.integers(0, len(segs)))]
+        sb = segs[int(rng.integers(0, len(segs)))]
+        ln = int(rng.integers(30, 400))
+        qs = int(rng.integers(1, seg_len - ln))
+        ss = int(rng.integers(1, seg_len - ln))
+        if rng.random() < 0.5:
+            rows.append(("%s$%d" % sa, "%s$%d" % sb, qs, qs + ln, ss, ss + ln + int(rng.integers(-2, 3))))
+        else:
+            rows.append(("%s$%d" % sa, "%s$%d" % sb, qs, qs + ln, ss + ln, ss))
+    # exact self hits (skipped by the reference) and duplicates
+    for sg in segs[:2]:
+        rows.append(("%s$%d" % sg, "%s$%d" % sg, 1, seg_len, 1, seg_len))
+    for _ in range(dup):
+        rows.append(rows[int(rng.integers(0, len(rows)))])
+    perm = rng.permutation(len(rows))
+    return [rows[i] for i in perm]
+
+
+def hsp_to_blast6_lines(rows):
+    return ["%s\t%s\t%.3f\t%d\t0\t0\t%d\t%d\t%d\t%d\t1e-50\t%.1f\n" %
+            (q, s, 95.0, abs(qe - qs) + 1, qs, qe, ss, se, 2.0 * (abs(qe - qs) + 1))
+            for (q, s, qs, qe, ss, se) in rows]
+
+
+# ----------------------------------------------------------------------------------
+# flanked candidates (input of search_confident_tir_v4) and genomes/copies (gather)
+# ----------------------------------------------------------------------------------
+def make_tir_candidate(seed, te_len=300, flank=50, tsd_len=8, off_l=0, off_r=0, with_n=False):
+    rng = np.random.default_rng(seed)
+    tsd = {2: "TA", 4: "TTAA"}.get(tsd_len, rand_seq(rng, tsd_len))
+    tir = rand_seq(rng, 15)
+    te = tir + rand_seq(rng, te_len - 30) + revcomp(tir)
+    left = rand_seq(rng, flank + 30)
+    right = rand_seq(rng, flank + 30)
+    seq = left + tsd + te + tsd + right
+    if with_n:
+        seq = seq[:20] + "NNNN" + seq[24:]
+    true_start = len(left) + len(tsd)  # 0-based first base of the element
+    true_end = true_start + te_len - 1
+    # the flanked candidate is cut so that the raw boundaries sit `flank` from each end
+    cs = true_start + off_l - flank
+    ce = true_end + off_r + flank + 1
+    cs = max(0, cs)
+    ce = min(len(seq), ce)
+    return seq[cs:ce], flank
+
+
+def make_genome(seed, n_chr=3, chr_len=(20000, 60000), n_frac=0.002, other_frac=0.0005):
+    rng = np.random.default_rng(seed)
+    names, seqs = [], []
+    for i in range(n_chr):
+        n = int(rng.integers(chr_len[0], chr_len[1]))
+        a = rng.integers(0, 4, size=n)
+        s = np.frombuffer(b"ACGT", dtype=np.uint8)[a].copy()
+        # runs of N and a few IUPAC codes
+        for _ in range(max(1, int(n * n_frac / 20))):
+            p = int(rng.integers(0, n - 40))
+            s[p:p + int(rng.integers(1, 40))] = ord("N")
+        for _ in range(int(n * other_frac)):
+            s[int(rng.integers(0, n))] = ord("RYKM"[int(rng.integers(0, 4))])
+        names.append("chr%d" % (i + 1))
+        seqs.append(s.tobytes().decode())
+    return names, seqs
+
+
+def make_copies(seed, names, seqs, n_cand=6, per_cand=(1, 12), length=(60, 2500), flank=50):
+    """{query: [(chr, start1, end1, aln_len, strand)]} as get_copies_minimap2 returns them
+    (1-based inclusive), including copies that run off the contig ends."""
+    rng = np.random.default_rng(seed)
+    out = {}
+    for q in range(n_cand):
+        lst = []
+        for _ in range(int(rng.integers(per_cand[0], per_cand[1] + 1))):
+            ci = int(rng.integers(0, len(names)))
+            L = int(rng.integers(length[0], length[1]))
+            n = len(seqs[ci])
+            mode = rng.random()
+            if mode < 0.08:
+                st = int(rng.integers(1, flank + 2))
+            elif mode < 0.16:
+                st = n - L - int(rng.integers(0, flank + 1))
+            else:
+                st = int(rng.integers(1, max(2, n - L)))
+            st = max(1, st)
+            en = min(n, st + L - 1)
+            lst.append((names[ci], st, en, en - st + 1, "+-"[int(rng.integers(0, 2))]))
+        out["cand_%d" % q] = lst
+    return out

@@ -1,0 +1,187 @@
+"""ctypes binding of oracle/libhite_oracle.so -- the CHECKER.  Imported only by tests,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg (never by hite_amd/)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+SO = os.path.join(ORACLE_DIR, "libhite_oracle.so")
+
+ORC_EXC = -1000
+_lib = None
+
+u8p = C.POINTER(C.c_uint8)
+i32p = C.POINTER(C.c_int32)
+i64p = C.POINTER(C.c_int64)
+ip = C.POINTER(C.c_int)
+
+
+def build():
+    subprocess.run(["make", "-s", "-C", ORACLE_DIR], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("hite_oracle.c", "hite_oracle_coarse.c")]
+        if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
+            build()
+        _lib = C.CDLL(SO)
+        _lib.orc_flank_window.restype = C.c_int64
+    return _lib
+
+
+def _u8(b):
+    a = np.frombuffer(b if isinstance(b, (bytes, bytearray)) else b.encode(), dtype=np.uint8)
+    return np.ascontiguousarray(a)
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def msa_array(seqs):
+    R = len(seqs)
+    Cn = len(seqs[0])
+    assert all(len(s) == Cn for s in seqs)
+    return np.frombuffer("".join(seqs).encode(), dtype=np.uint8).reshape(R, Cn).copy()
+
+
+def sparse_cols(msa):
+    R, Cn = msa.shape
+    keep = np.zeros(Cn, dtype=np.uint8)
+    rc = lib().orc_sparse_cols(_ptr(msa, u8p), R, Cn, _ptr(keep, u8p))
+    assert rc == 0
+    return keep
+
+
+def search_v3(msa, pos, side, thr, win_in=20, win_out=10):
+    R, Cn = msa.shape
+    return lib().orc_search_v3(_ptr(msa, u8p), R, Cn, int(pos), 0 if side == "start" else 1, C.c_double(thr), win_in, win_out)
+
+
+def search_v4(msa, pos, side, thr, int_thr, out_thr, win_in=20, win_out=10):
+    R, Cn = msa.shape
+    valid = C.c_int(0)
+    b = lib().orc_search_v4(_ptr(msa, u8p), R, Cn, int(pos), 0 if side == "start" else 1, C.c_double(thr),
+                            C.c_double(int_thr), C.c_double(out_thr), win_in, win_out, C.byref(valid))
+    return bool(valid.value), b
+
+
+def window_homology(msa, first, n, step, thr):
+    R, Cn = msa.shape
+    return lib().orc_window_homology(_ptr(msa, u8p), R, Cn, first, n, step, C.c_double(thr))
+
+
+INFO = {0: "", 1: "nb", 2: "fl1"}
+
+
+def judge(te_type, msa, cand, plant):
+    """-> [is_TE, info, cons, row_num] or ['EXC'] ; plus (bstart, bend)"""
+    R, Cn = msa.shape
+    fn = {"tir": lib().orc_judge_v5, "helitron": lib().orc_judge_v6, "non_ltr": lib().orc_judge_v9}[te_type]
+    cb = _u8(cand)
+    cons = np.zeros(Cn + 8, dtype=np.uint8)
+    clen = C.c_int(0)
+    info = C.c_int(0)
+    rn = C.c_int(0)
+    bounds = (C.c_int * 2)(-1, -1)
+    rc = fn(_ptr(msa, u8p), R, Cn, _ptr(cb, u8p), len(cb), int(plant), _ptr(cons, u8p), Cn + 8, C.byref(clen),
+            C.byref(info), C.byref(rn), bounds)
+    if rc < 0:
+        return ["EXC", rc], (-1, -1)
+    return [bool(rc), INFO[info.value], cons[:clen.value].tobytes().decode(), rn.value], (bounds[0], bounds[1])
+
+
+def tsd_search_v5(row, bs, be, plant):
+    rb = _u8(row)
+    l = np.zeros(16, dtype=np.uint8)
+    r = np.zeros(16, dtype=np.uint8)
+    k = lib().orc_tsd_search_v5(_ptr(rb, u8p), len(rb), bs, be, plant, _ptr(l, u8p), _ptr(r, u8p))
+    if k < 0:
+        return None
+    return l[:k].tobytes().decode(), r[:k].tobytes().decode()
+
+
+def find_tail_polyA(s):
+    b = _u8(s)
+    return lib().orc_find_tail_polyA(_ptr(b, u8p), len(b))
+
+
+def find_tandem_tail(s):
+    b = _u8(s)
+    return lib().orc_find_tandem_tail(_ptr(b, u8p), len(b))
+
+
+def hsp_arrays(rows):
+    """rows of (qname, sname, qs, qe, ss, se) -> dict of numpy arrays + segment tables"""
+    segs = {}
+    chroms = {}
+    seg_chrom, seg_off = [], []
+
+    def seg_id(name):
+        if name not in segs:
+            c, off = name.split("$")
+            if c not in chroms:
+                chroms[c] = len(chroms)
+            segs[name] = len(segs)
+            seg_chrom.append(chroms[c])
+            seg_off.append(int(off))
+        return segs[name]
+
+    q = np.array([seg_id(r[0]) for r in rows], dtype=np.int32)
+    s = np.array([seg_id(r[1]) for r in rows], dtype=np.int32)
+    arr = lambda k: np.array([r[k] for r in rows], dtype=np.int64)  # noqa: E731
+    return dict(qseg=q, sseg=s, qs=arr(2), qe=arr(3), ss=arr(4), se=arr(5),
+                seg_chrom=np.array(seg_chrom, dtype=np.int32), seg_off=np.array(seg_off, dtype=np.int64),
+                chrom_names=list(chroms.keys()))
+
+
+def fmea(h, skip_gap, max_len):
+    n = len(h["qseg"])
+    cap = max(16, n + 16)
+    oc = np.zeros(cap, dtype=np.int32)
+    os_ = np.zeros(cap, dtype=np.int64)
+    oe = np.zeros(cap, dtype=np.int64)
+    rc = lib().orc_fmea(n, _ptr(h["qseg"], i32p), _ptr(h["sseg"], i32p), _ptr(h["qs"], i64p), _ptr(h["qe"], i64p),
+                        _ptr(h["ss"], i64p), _ptr(h["se"], i64p), len(h["seg_chrom"]), _ptr(h["seg_chrom"], i32p),
+                        _ptr(h["seg_off"], i64p), C.c_int64(skip_gap), C.c_int64(max_len), cap, _ptr(oc, i32p),
+                        _ptr(os_, i64p), _ptr(oe, i64p))
+    assert rc >= 0, rc
+    return ["%s:%d-%d" % (h["chrom_names"][oc[i]], os_[i], oe[i]) for i in range(rc)]
+
+
+def flank_window(contig_bytes, start1, end1, strand, flank=50):
+    cb = _u8(contig_bytes)
+    n = max(0, end1 - start1 + 1 + 2 * flank)
+    out = np.zeros(n + 8, dtype=np.uint8)
+    tr = np.zeros(1000, dtype=np.uint8)
+    tl = C.c_int64(0)
+    L = lib().orc_flank_window(_ptr(cb, u8p), C.c_int64(len(cb)), C.c_int64(start1), C.c_int64(end1),
+                               1 if strand == "-" else 0, C.c_int64(flank), _ptr(out, u8p), _ptr(tr, u8p), C.byref(tl))
+    if L == 0:
+        return None, None
+    return out[:L].tobytes().decode(), (tr[:tl.value].tobytes().decode() if tl.value else None)
+
+
+def flanking_seq(s, e, clen, flank=50):
+    lo, hi, ns, ne = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+    lib().orc_flanking_seq(C.c_int64(s), C.c_int64(e), C.c_int64(clen), C.c_int64(flank), C.byref(lo), C.byref(hi),
+                           C.byref(ns), C.byref(ne))
+    return lo.value, hi.value, ns.value, ne.value
+
+
+def tir_kmer(seq, raw_start, raw_end, dist, plant):
+    b = _u8(seq)
+    cap = 128
+    k = np.zeros(cap, dtype=np.int32)
+    ts = np.zeros(cap, dtype=np.int64)
+    te = np.zeros(cap, dtype=np.int64)
+    d = np.zeros(cap, dtype=np.int64)
+    m = lib().orc_tir_kmer(_ptr(b, u8p), C.c_int64(len(b)), C.c_int64(raw_start), C.c_int64(raw_end), C.c_int64(dist),
+                           int(plant), cap, _ptr(k, i32p), _ptr(ts, i64p), _ptr(te, i64p), _ptr(d, i64p))
+    assert m >= 0, m
+    return [(int(k[i]), int(ts[i]), int(te[i]), int(d[i])) for i in range(m)]

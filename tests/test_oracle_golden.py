@@ -1,0 +1,121 @@
+"""The CPU oracle (oracle/*.c) must reproduce every golden vector generated from the
+reference's own Python (oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from conftest import load_golden
+
+
+def test_fmea_golden():
+    for case in load_golden("fmea"):
+        h = O.hsp_arrays([tuple(r) for r in case["rows"]])
+        got = O.fmea(h, case["skip_gap"], case["max_len"])
+        assert got == case["expected"]
+
+
+def test_sparse_cols_golden():
+    n = 0
+    for name in ("judge_tir", "judge_non_ltr", "judge_helitron"):
+        for case in load_golden(name):
+            msa = O.msa_array(case["seqs"])
+            keep = O.sparse_cols(msa).astype(bool)
+            clean = ["".join(chr(c) for c in row[keep]) for row in msa]
+            assert clean == case["clean"]
+            n += 1
+    assert n > 100
+
+
+@pytest.mark.parametrize("name,te_type", [("judge_tir", "tir"), ("judge_non_ltr", "non_ltr"), ("judge_helitron", "helitron")])
+def test_judge_golden(name, te_type):
+    ntrue = 0
+    for i, case in enumerate(load_golden(name)):
+        msa = O.msa_array(case["clean"])
+        got, _ = O.judge(te_type, msa, case["cand"], case["plant"])
+        exp = case["expected"]
+        if exp[0] == "EXC":
+            assert got[0] == "EXC", (i, got, exp)
+        else:
+            assert got == exp, (i, got, exp)
+            ntrue += bool(exp[0])
+    assert ntrue >= 2
+
+
+def test_boundary_search_golden():
+    for i, case in enumerate(load_golden("boundary_search")):
+        msa = O.msa_array(case["seqs"])
+        thr = case["thr"]
+        assert O.search_v3(msa, case["pos"], case["side"], thr) == case["v3"], i
+        v, b = O.search_v4(msa, case["pos"], case["side"], thr, thr - 0.05, thr)
+        assert [v, b] == case["v4"], i
+
+
+def test_threshold_ties_golden():
+    for case in load_golden("thr_ties"):
+        msa = O.msa_array(case["seqs"])
+        W = msa.shape[1]
+        assert O.window_homology(msa, 0, W, 1, case["thr"]) == case["fwd"]
+        assert O.window_homology(msa, W - 1, W - 2, -1, case["thr"]) == case["rev"]
+
+
+def test_tsd_search_golden():
+    for case in load_golden("tsd_search"):
+        got = O.tsd_search_v5(case["seq"], case["start"], case["end"], case["plant"])
+        assert got == (case["left"], case["right"])
+
+
+def test_tails_golden():
+    for case in load_golden("tails"):
+        assert O.find_tail_polyA(case["seq"]) == case["polyA"]
+        assert O.find_tandem_tail(case["seq"]) == case["tandem"]
+
+
+def check_tir_items(items, case):
+    """The reference keeps the top 100 by distance; which of the candidates tied at the cut
+    distance survive depends on PYTHONHASHSEED (set iteration, Util.py:7741/:7807), so at a
+    full cut only the strictly-closer part is pinned."""
+    exp = case["items"]
+    assert len(items) == len(exp) == case["n"]
+    if case["n"] < 100:
+        assert items == exp
+    else:
+        dcut = exp[-1][0]
+        assert [x for x in items if x[0] < dcut] == [x for x in exp if x[0] < dcut]
+        assert all(x[0] == dcut for x in items if x[0] >= dcut)
+
+
+def test_tir_kmer_golden():
+    for case in load_golden("tir_kmer"):
+        seq, flank = case["seq"], case["flank"]
+        recs = O.tir_kmer(seq, flank + 1, len(seq) - flank, flank, case["plant"])
+        items = sorted([d, seq[ts - k:ts], seq[ts:te + 1]] for (k, ts, te, d) in recs)
+        check_tir_items(items, case)
+
+
+def test_gather_golden():
+    for case in load_golden("gather"):
+        contigs = dict(zip(case["names"], case["seqs"]))
+        for q, copies in case["copies"].items():
+            ext, trunc = [], []
+            seen = {}
+            for (chrom, s, e, _alen, strand) in copies:
+                w, t = O.flank_window(contigs[chrom], s, e, strand, case["flank"])
+                if w is None:
+                    continue
+                name = "%s:%d-%d(%s)" % (chrom, s, e, strand)
+                seen[name] = (w, t)  # dict semantics: later duplicate names overwrite in place
+            ext = [[k, v[0]] for k, v in seen.items()]
+            trunc = [[k, v[1]] for k, v in seen.items() if v[1] is not None]
+            exp = case["expected"].get(q)
+            if exp is None:
+                assert ext == []
+                continue
+            assert ext == exp["extend"]
+            assert (trunc or None) == exp["trunc"]
+        # flanking_seq
+        for name, (oname, oseq) in zip(case["flanking_in"], case["flanking_out"]):
+            chrom, pos = name.split(":")
+            s, e = map(int, pos.split("-"))
+            lo, hi, ns, ne = O.flanking_seq(s, e, len(contigs[chrom]), 50)
+            assert "%s:%d-%d" % (chrom, ns, ne) == oname
+            assert contigs[chrom][lo:hi] == oseq
