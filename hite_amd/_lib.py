@@ -1,0 +1,201 @@
+"""ctypes binding of libhite_gpu.so (include/hite_gpu.h).  This is the stub a HiTE maintainer
+would add next to module/Util.py.  There is NO CPU fallback: if the HIP
+library is missing or no GPU is present every call raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libhite_gpu.so")
+
+HITE_TE = {"tir": 0, "helitron": 1, "non_ltr": 2}
+INFO = {0: "", 1: "nb", 2: "fl1", 3: "EXC"}
+
+
+class HiteError(RuntimeError):
+    pass
+
+
+class HiteCall(C.Structure):
+    _fields_ = [("is_te", C.c_int32), ("info", C.c_int32), ("row_num", C.c_int32), ("bstart", C.c_int32),
+                ("bend", C.c_int32), ("cons_len", C.c_int32), ("cons_off", C.c_int64)]
+
+
+CALL_DTYPE = np.dtype([("is_te", "<i4"), ("info", "<i4"), ("row_num", "<i4"), ("bstart", "<i4"), ("bend", "<i4"),
+                       ("cons_len", "<i4"), ("cons_off", "<i8")])
+assert CALL_DTYPE.itemsize == 32 and C.sizeof(HiteCall) == 32
+
+_lib = None
+
+
+def load():
+    """Load libhite_gpu.so; raises HiteError (never falls back) when it is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise HiteError("libhite_gpu.so not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                            "(or make -C hite_amd/csrc); there is no CPU fallback")
+        lib = C.CDLL(SO_PATH)
+        lib.hite_last_error.restype = C.c_char_p
+        lib.hite_genome_bases.restype = C.c_int64
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _arr(x, dtype):
+    return np.ascontiguousarray(x, dtype=dtype)
+
+
+class Context:
+    """One per process/GPU.  Owns the resident 2-bit genome and device scratch."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.hite_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise HiteError("hite_ctx_create(device=%d) failed: %d (no usable GPU?)" % (device, rc))
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.hite_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.hite_last_error(self.h)
+            raise HiteError("%s failed: %d %s" % (what, rc, (msg or b"").decode(errors="replace")))
+
+    # ---- genome ---------------------------------------------------------------------------
+    def genome_pack(self, seqs):
+        """seqs: list of str/bytes contigs (upper-case)."""
+        bs = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        off = np.zeros(len(bs) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in bs], out=off[1:])
+        buf = np.frombuffer(b"".join(bs), dtype=np.uint8)
+        self._check(self.lib.hite_genome_pack(self.h, _p(buf), _p(off), len(bs)), "hite_genome_pack")
+        self.contig_len = np.diff(off)
+
+    def genome_pack_dev(self, d_ptr, contig_off, stream=0):
+        off = _arr(contig_off, np.int64)
+        self._check(self.lib.hite_genome_pack_dev(self.h, C.c_void_p(d_ptr), _p(off), len(off) - 1, C.c_void_p(stream)),
+                    "hite_genome_pack_dev")
+        self.contig_len = np.diff(off)
+
+    # ---- flank windows --------------------------------------------------------------------
+    def flank_gather(self, contig, start1, end1, minus, flank=50):
+        """-> (windows: list[bytes|None], trunc: list[bytes|None]) following Util.py:8095-8124"""
+        n = len(contig)
+        contig = _arr(contig, np.int32)
+        start1 = _arr(start1, np.int64)
+        end1 = _arr(end1, np.int64)
+        minus = _arr(minus, np.uint8)
+        ln = np.zeros(n, dtype=np.int64)
+        tl = np.zeros(n, dtype=np.int64)
+        self._check(self.lib.hite_flank_sizes(self.h, C.c_int64(n), _p(contig), _p(start1), _p(end1), int(flank), _p(ln), _p(tl)),
+                    "hite_flank_sizes")
+        pad = (ln + 15) // 16 * 16
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(pad, out=off[1:])
+        tpad = (tl + 15) // 16 * 16
+        toff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(tpad, out=toff[1:])
+        out = np.zeros(int(off[-1]) + 16, dtype=np.uint8)
+        tout = np.zeros(int(toff[-1]) + 16, dtype=np.uint8)
+        self._check(self.lib.hite_flank_gather(self.h, C.c_int64(n), _p(contig), _p(start1), _p(end1), _p(minus), int(flank),
+                                               _p(off), _p(out), _p(toff), _p(tout)), "hite_flank_gather")
+        wins = [out[off[i]:off[i] + ln[i]].tobytes() if ln[i] else None for i in range(n)]
+        tr = [tout[toff[i]:toff[i] + tl[i]].tobytes() if tl[i] else None for i in range(n)]
+        return wins, tr
+
+    # ---- alignments -----------------------------------------------------------------------
+    @staticmethod
+    def pack_msas(msas):
+        """msas: list of 2-D uint8 arrays -> (bytes, msa_off, rows, cols)"""
+        rows = np.array([m.shape[0] for m in msas], dtype=np.int32)
+        cols = np.array([m.shape[1] for m in msas], dtype=np.int32)
+        sizes = rows.astype(np.int64) * cols
+        pad = (sizes + 15) // 16 * 16
+        off = np.zeros(len(msas) + 1, dtype=np.int64)
+        np.cumsum(pad, out=off[1:])
+        buf = np.full(int(off[-1]) + 16, ord("-"), dtype=np.uint8)
+        for i, m in enumerate(msas):
+            buf[off[i]:off[i] + sizes[i]] = np.ascontiguousarray(m, dtype=np.uint8).reshape(-1)
+        return buf, off[:-1].copy(), rows, cols
+
+    def sparse_cols(self, msas):
+        buf, off, rows, cols = self.pack_msas(msas)
+        out = np.zeros_like(buf)
+        nc = np.zeros(len(msas), dtype=np.int32)
+        self._check(self.lib.hite_sparse_cols(self.h, len(msas), _p(buf), _p(off), _p(rows), _p(cols), _p(out), _p(nc)),
+                    "hite_sparse_cols")
+        return [out[off[i]:off[i] + int(rows[i]) * int(nc[i])].reshape(int(rows[i]), int(nc[i])).copy() for i in range(len(msas))]
+
+    def column_vote(self, msas):
+        buf, off, rows, cols = self.pack_msas(msas)
+        coff = np.zeros(len(msas) + 1, dtype=np.int64)
+        np.cumsum(cols, out=coff[1:])
+        counts = np.zeros((int(coff[-1]), 6), dtype=np.int32)
+        self._check(self.lib.hite_column_vote(self.h, len(msas), _p(buf), _p(off), _p(rows), _p(cols), _p(coff), _p(counts)),
+                    "hite_column_vote")
+        return [counts[coff[i]:coff[i + 1]] for i in range(len(msas))]
+
+    def boundary_search(self, msas, pos, side, thr, variant=3, int_thr=None, out_thr=None, win_in=20, win_out=10):
+        buf, off, rows, cols = self.pack_msas(msas)
+        n = len(msas)
+        pos = _arr(pos, np.int32)
+        side = _arr([0 if s in (0, "start") else 1 for s in side], np.int32)
+        thr = _arr(thr, np.float64)
+        it = _arr(int_thr, np.float64) if int_thr is not None else None
+        ot = _arr(out_thr, np.float64) if out_thr is not None else None
+        b = np.zeros(n, dtype=np.int32)
+        v = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.hite_boundary_search(self.h, n, _p(buf), _p(off), _p(rows), _p(cols), _p(pos), _p(side), _p(thr),
+                                                  _p(it), _p(ot), int(variant), win_in, win_out, _p(b), _p(v)),
+                    "hite_boundary_search")
+        return b, v
+
+    def judge(self, te_type, msas, cands, plant=1):
+        """-> list of (is_TE, info, cons, row_num, bstart, bend) -- the tuple judge_boundary_v5/v6/v9 return"""
+        buf, off, rows, cols = self.pack_msas(msas)
+        n = len(msas)
+        cb = [c.encode() if isinstance(c, str) else bytes(c) for c in cands]
+        coff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in cb], out=coff[1:])
+        cbuf = np.frombuffer(b"".join(cb) + b"\0" * 16, dtype=np.uint8)
+        calls = np.zeros(n, dtype=CALL_DTYPE)
+        cons = np.zeros(int(cols.astype(np.int64).sum()) + 8 * n + 16, dtype=np.uint8)
+        self._check(self.lib.hite_judge(self.h, HITE_TE[te_type], int(plant), n, _p(buf), _p(off), _p(rows), _p(cols),
+                                        _p(cbuf), _p(coff), _p(calls), _p(cons)), "hite_judge")
+        out = []
+        for i in range(n):
+            c = calls[i]
+            s = cons[c["cons_off"]:c["cons_off"] + c["cons_len"]].tobytes().decode() if c["is_te"] else ""
+            out.append((bool(c["is_te"]), INFO[int(c["info"])], s, int(c["row_num"]), int(c["bstart"]), int(c["bend"])))
+        return out
+
+    def tsd_search(self, rows_, bstart, bend, plant=1):
+        rb = [r.encode() if isinstance(r, str) else bytes(r) for r in rows_]
+        n = len(rb)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(r) for r in rb], out=off[1:])
+        buf = np.frombuffer(b"".join(rb) + b"\0" * 16, dtype=np.uint8)
+        ln = np.zeros(n, dtype=np.int32)
+        lo = np.zeros((n, 16), dtype=np.uint8)
+        ro = np.zeros((n, 16), dtype=np.uint8)
+        self._check(self.lib.hite_tsd_search(self.h, n, _p(buf), _p(off), _p(_arr(bstart, np.int32)), _p(_arr(bend, np.int32)),
+                                             int(plant), _p(ln), _p(lo), _p(ro)), "hite_tsd_search")
+        return [(lo[i, :max(ln[i], 0)].tobytes().decode(), ro[i, :max(ln[i], 0)].tobytes().decode(), int(ln[i])) for i in range(n)]

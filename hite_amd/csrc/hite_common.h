@@ -1,0 +1,104 @@
+// hite_common.h -- shared host/device helpers of libhite_gpu.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <stdlib.h>
+#include "../../include/hite_gpu.h"
+
+#define HITE_WAVE 64
+#define HITE_BLOCK 256
+
+struct hite_ctx {
+    int device;
+    char err[512];
+    // resident genome: 2-bit bases (16 per u32), 1-bit non-ACGT mask (32 per u32)
+    uint32_t *d_bases;
+    uint32_t *d_nmask;
+    int64_t *d_contig_off;  // n_contigs + 1 (base index of each contig in the packed arrays)
+    int64_t *h_contig_off;
+    int32_t n_contigs;
+    int64_t n_bases;
+    // grow-only scratch
+    void *d_scratch;
+    size_t scratch_bytes;
+    void *d_scratch2;
+    size_t scratch2_bytes;
+};
+
+#define HITE_CHECK(ctx, call)                                                                         \
+    do {                                                                                              \
+        hipError_t e__ = (call);                                                                      \
+        if (e__ != hipSuccess) {                                                                      \
+            if (ctx) snprintf((ctx)->err, sizeof((ctx)->err), "%s:%d %s: %s", __FILE__, __LINE__, #call, \
+                              hipGetErrorString(e__));                                                \
+            return HITE_EHIP;                                                                         \
+        }                                                                                             \
+    } while (0)
+
+int hite_scratch_reserve(hite_ctx *ctx, size_t bytes, void **out);
+int hite_scratch2_reserve(hite_ctx *ctx, size_t bytes, void **out);
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+// symbol classes: 0..3 = ACGT, 4 = N (and every other non-gap byte), 5 = '-'
+__device__ __forceinline__ int sym_class(uint8_t c) {
+    switch (c) {
+        case 'A': return 0;
+        case 'C': return 1;
+        case 'G': return 2;
+        case 'T': return 3;
+        case '-': return 5;
+        default: return 4;
+    }
+}
+__device__ __forceinline__ uint8_t class_sym(int k) { return (uint8_t)("ACGTN-"[k]); }
+__device__ __forceinline__ uint8_t fold_sym(uint8_t c) { return class_sym(sym_class(c)); }
+__device__ __forceinline__ uint8_t comp_sym(uint8_t c) {
+    switch (c) {
+        case 'A': return 'T';
+        case 'T': return 'A';
+        case 'C': return 'G';
+        case 'G': return 'C';
+        default: return 'N';
+    }
+}
+
+// exclusive scan over the 256 threads of a block (s_tmp: >= 8 ints of LDS); returns the
+// exclusive prefix of v and the block total in *total.  Contains __syncthreads().
+__device__ __forceinline__ int block_excl_scan(int v, int *s_tmp, int *total) {
+    int lane = lane_id(), w = wave_id();
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int y = __shfl_up(x, d, 64);
+        if (lane >= d) x += y;
+    }
+    __syncthreads();
+    if (lane == 63) s_tmp[w] = x;
+    __syncthreads();
+    int base = 0, tot = 0;
+    int nw = (blockDim.x + 63) >> 6;
+    for (int i = 0; i < nw; i++) {
+        int t = s_tmp[i];
+        if (i < w) base += t;
+        tot += t;
+    }
+    *total = tot;
+    return base + x - v;
+}
+
+// Python s[a:b] normalisation on a length-n sequence
+__device__ __forceinline__ void py_slice(int64_t a, int64_t b, int64_t n, int *lo, int *hi) {
+    if (a < 0) { a += n; if (a < 0) a = 0; }
+    if (b < 0) { b += n; if (b < 0) b = 0; }
+    if (a > n) a = n;
+    if (b > n) b = n;
+    if (b < a) b = a;
+    *lo = (int)a; *hi = (int)b;
+}

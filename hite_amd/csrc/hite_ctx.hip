@@ -1,0 +1,398 @@
+// hite_ctx.hip -- context, resident 2-bit genome, flank-window gather.
+//
+// Data layout in HBM
+//   d_bases : 2 bits per base, 16 bases per u32, A=0 C=1 G=2 T=3, contigs concatenated
+//   d_nmask : 1 bit per base, 32 per u32, set where the input byte is not A/C/G/T
+//   d_contig_off : int64 base index of each contig (+ total)
+// Algorithmic bytes: pack reads G bytes, writes G/4 + G/8; gather reads W/4 + W/8 per window
+// and writes W (+1000 for the first500+last500 form).  Both are HBM-bound streaming kernels.
+#include "hite_common.h"
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+extern "C" int hite_version(void) { return 1; }
+
+extern "C" int hite_ctx_create(int device_id, hite_ctx **out) {
+    if (!out) return HITE_EINVAL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return HITE_ENODEV;
+    if (device_id < 0 || device_id >= ndev) return HITE_EINVAL;
+    hite_ctx *c = (hite_ctx *)calloc(1, sizeof(hite_ctx));
+    if (!c) return HITE_ENOMEM;
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess) { free(c); return HITE_EHIP; }
+    *out = c;
+    return HITE_OK;
+}
+
+static void free_genome(hite_ctx *c) {
+    if (c->d_bases) (void)hipFree(c->d_bases);
+    if (c->d_nmask) (void)hipFree(c->d_nmask);
+    if (c->d_contig_off) (void)hipFree(c->d_contig_off);
+    free(c->h_contig_off);
+    c->d_bases = c->d_nmask = nullptr;
+    c->d_contig_off = nullptr;
+    c->h_contig_off = nullptr;
+    c->n_contigs = 0;
+    c->n_bases = 0;
+}
+
+extern "C" void hite_ctx_destroy(hite_ctx *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_genome(c);
+    if (c->d_scratch) (void)hipFree(c->d_scratch);
+    if (c->d_scratch2) (void)hipFree(c->d_scratch2);
+    free(c);
+}
+
+extern "C" const char *hite_last_error(hite_ctx *c) { return c ? c->err : "null ctx"; }
+
+int hite_scratch_reserve(hite_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch_bytes) {
+        if (ctx->d_scratch) HITE_CHECK(ctx, hipFree(ctx->d_scratch));
+        ctx->d_scratch = nullptr;
+        ctx->scratch_bytes = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        HITE_CHECK(ctx, hipMalloc(&ctx->d_scratch, want));
+        ctx->scratch_bytes = want;
+    }
+    *out = ctx->d_scratch;
+    return HITE_OK;
+}
+int hite_scratch2_reserve(hite_ctx *ctx, size_t bytes, void **out) {
+    if (bytes > ctx->scratch2_bytes) {
+        if (ctx->d_scratch2) HITE_CHECK(ctx, hipFree(ctx->d_scratch2));
+        ctx->d_scratch2 = nullptr;
+        ctx->scratch2_bytes = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        HITE_CHECK(ctx, hipMalloc(&ctx->d_scratch2, want));
+        ctx->scratch2_bytes = want;
+    }
+    *out = ctx->d_scratch2;
+    return HITE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// genome pack: each thread converts 32 bases (two 16-byte loads) -> 2 x u32 bases + 1 x u32 mask
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void pack4(uint32_t w, uint32_t &bits, uint32_t &mask, int shift) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t c = (w >> (8 * i)) & 0xffu;
+        uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+        bits |= (code & 3u) << (2 * (shift + i));
+        mask |= (code >> 2) << (shift + i);
+    }
+}
+
+__global__ void __launch_bounds__(256) pack_genome_kernel(const uint8_t *__restrict__ seq, int64_t n,
+                                                          uint32_t *__restrict__ bases, uint32_t *__restrict__ nmask) {
+    int64_t nw = (n + 31) >> 5;  // mask words
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < nw; w += (int64_t)gridDim.x * blockDim.x) {
+        int64_t g = w << 5;
+        uint32_t b0 = 0, b1 = 0, m0 = 0, m1 = 0;
+        if (g + 32 <= n) {
+            const uint4 *p = reinterpret_cast<const uint4 *>(seq + g);
+            uint4 x = p[0], y = p[1];
+            pack4(x.x, b0, m0, 0); pack4(x.y, b0, m0, 4); pack4(x.z, b0, m0, 8); pack4(x.w, b0, m0, 12);
+            pack4(y.x, b1, m1, 0); pack4(y.y, b1, m1, 4); pack4(y.z, b1, m1, 8); pack4(y.w, b1, m1, 12);
+        } else {
+            for (int i = 0; i < 32 && g + i < n; i++) {
+                uint32_t c = seq[g + i];
+                uint32_t code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+                if (i < 16) { b0 |= (code & 3u) << (2 * i); m0 |= (code >> 2) << i; }
+                else { b1 |= (code & 3u) << (2 * (i - 16)); m1 |= (code >> 2) << (i - 16); }
+            }
+        }
+        reinterpret_cast<uint2 *>(bases)[w] = make_uint2(b0, b1);
+        nmask[w] = m0 | (m1 << 16);
+    }
+}
+
+static int genome_alloc(hite_ctx *ctx, const int64_t *contig_off, int32_t n_contigs) {
+    if (n_contigs <= 0 || !contig_off || contig_off[0] != 0) return HITE_EINVAL;
+    for (int i = 0; i < n_contigs; i++) if (contig_off[i + 1] < contig_off[i]) return HITE_EINVAL;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    free_genome(ctx);
+    int64_t n = contig_off[n_contigs];
+    int64_t nw = (n + 31) >> 5;
+    HITE_CHECK(ctx, hipMalloc((void **)&ctx->d_bases, (size_t)(nw * 2 + 8) * 4));
+    HITE_CHECK(ctx, hipMalloc((void **)&ctx->d_nmask, (size_t)(nw + 8) * 4));
+    HITE_CHECK(ctx, hipMemset(ctx->d_bases, 0, (size_t)(nw * 2 + 8) * 4));
+    HITE_CHECK(ctx, hipMemset(ctx->d_nmask, 0, (size_t)(nw + 8) * 4));
+    HITE_CHECK(ctx, hipMalloc((void **)&ctx->d_contig_off, sizeof(int64_t) * (n_contigs + 1)));
+    HITE_CHECK(ctx, hipMemcpy(ctx->d_contig_off, contig_off, sizeof(int64_t) * (n_contigs + 1), hipMemcpyHostToDevice));
+    ctx->h_contig_off = (int64_t *)malloc(sizeof(int64_t) * (n_contigs + 1));
+    if (!ctx->h_contig_off) return HITE_ENOMEM;
+    memcpy(ctx->h_contig_off, contig_off, sizeof(int64_t) * (n_contigs + 1));
+    ctx->n_contigs = n_contigs;
+    ctx->n_bases = n;
+    return HITE_OK;
+}
+
+extern "C" int hite_genome_pack_dev(hite_ctx *ctx, const uint8_t *d_seq, const int64_t *contig_off_host,
+                                    int32_t n_contigs, void *stream) {
+    if (!ctx || !d_seq) return HITE_EINVAL;
+    if (((uintptr_t)d_seq) & 15) return HITE_EINVAL;
+    int rc = genome_alloc(ctx, contig_off_host, n_contigs);
+    if (rc) return rc;
+    int64_t nw = (ctx->n_bases + 31) >> 5;
+    if (nw == 0) return HITE_OK;
+    int64_t blocks = (nw + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(pack_genome_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, d_seq,
+                       ctx->n_bases, ctx->d_bases, ctx->d_nmask);
+    HITE_CHECK(ctx, hipGetLastError());
+    return HITE_OK;
+}
+
+extern "C" int hite_genome_pack(hite_ctx *ctx, const uint8_t *seq, const int64_t *contig_off, int32_t n_contigs) {
+    if (!ctx || !seq || !contig_off || n_contigs <= 0) return HITE_EINVAL;
+    int64_t n = contig_off[n_contigs];
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    uint8_t *d = nullptr;
+    HITE_CHECK(ctx, hipMalloc((void **)&d, (size_t)n + 64));
+    hipError_t e = hipMemcpy(d, seq, (size_t)n, hipMemcpyHostToDevice);
+    int rc = e == hipSuccess ? hite_genome_pack_dev(ctx, d, contig_off, n_contigs, nullptr) : HITE_EHIP;
+    if (rc == HITE_OK && hipDeviceSynchronize() != hipSuccess) rc = HITE_EHIP;
+    (void)hipFree(d);
+    return rc;
+}
+
+extern "C" int64_t hite_genome_bases(hite_ctx *ctx) { return ctx ? ctx->n_bases : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// flank-window gather
+// ---------------------------------------------------------------------------------------------
+// window length rules  Util.py:8102-8109, 8117
+__device__ __forceinline__ void window_rule(const int64_t *__restrict__ coff, int32_t ncontig, int32_t c, int64_t s1,
+                                            int64_t e1, int32_t flank, int64_t &len, int64_t &tlen, int64_t &g_lo) {
+    len = 0; tlen = 0; g_lo = 0;
+    if (c < 0 || c >= ncontig) return;
+    int64_t clen = coff[c + 1] - coff[c];
+    if (s1 - 1 - flank < 0 || e1 + flank > clen) return;
+    int64_t lo = s1 - 1 - flank, hi = e1 + flank;
+    if (hi < lo) hi = lo;
+    int64_t n = hi - lo;
+    if (n < 100) return;
+    len = n;
+    tlen = n > 1000 ? 1000 : 0;
+    g_lo = coff[c] + lo;
+}
+
+__global__ void flank_sizes_kernel(const int64_t *__restrict__ coff, int32_t ncontig, int64_t n,
+                                   const int32_t *__restrict__ contig, const int64_t *__restrict__ s1,
+                                   const int64_t *__restrict__ e1, int32_t flank, int64_t *__restrict__ out_len,
+                                   int64_t *__restrict__ trunc_len) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int64_t len, tlen, g;
+    window_rule(coff, ncontig, contig[i], s1[i], e1[i], flank, len, tlen, g);
+    out_len[i] = len;
+    if (trunc_len) trunc_len[i] = tlen;
+}
+
+// 4 consecutive bases starting at packed index g -> 4 ASCII bytes (little endian in a u32)
+__device__ __forceinline__ uint32_t fetch4(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                           int64_t g) {
+    int64_t w = g >> 4;
+    int sh = (int)(g & 15) * 2;
+    uint64_t two = (uint64_t)bases[w] | ((uint64_t)bases[w + 1] << 32);
+    uint32_t bits = (uint32_t)(two >> sh) & 0xffu;
+    int64_t mw = g >> 5;
+    int msh = (int)(g & 31);
+    uint64_t mtwo = (uint64_t)nmask[mw] | ((uint64_t)nmask[mw + 1] << 32);
+    uint32_t m = (uint32_t)(mtwo >> msh) & 0xfu;
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t code = (bits >> (2 * i)) & 3u;
+        uint32_t ch = (0x54474341u >> (8 * code)) & 0xffu;  // "ACGT"
+        if ((m >> i) & 1u) ch = 'N';
+        out |= ch << (8 * i);
+    }
+    return out;
+}
+// reverse-complement of 4 ASCII bytes packed in a u32 (byte order reversed, bases complemented)
+__device__ __forceinline__ uint32_t revcomp4(uint32_t x) {
+    uint32_t out = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint32_t c = (x >> (8 * i)) & 0xffu;
+        uint32_t r = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'N';
+        out |= r << (8 * (3 - i));
+    }
+    return out;
+}
+
+// write window[ws .. ws+cnt) to dst (4-byte aligned) using the lanes of one wave
+__device__ __forceinline__ void emit_span(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                          int64_t g_lo, int64_t wlen, bool minus, int64_t ws, int64_t cnt,
+                                          uint8_t *__restrict__ dst, int lane) {
+    int64_t groups = (cnt + 3) >> 2;
+    bool aligned = (((uintptr_t)dst) & 3) == 0;
+    for (int64_t j = lane; j < groups; j += 64) {
+        int64_t p = ws + 4 * j;  // window position of the first byte of this group
+        int rem = (int)((cnt - 4 * j) < 4 ? (cnt - 4 * j) : 4);
+        uint32_t v;
+        if (!minus) {
+            v = fetch4(bases, nmask, g_lo + p);
+        } else {
+            // window[p+i] = comp(genome[g_lo + wlen-1-p-i]); fetch ascending from g_lo + wlen - 4 - p
+            int64_t g = g_lo + wlen - 4 - p;
+            if (g >= 0) v = revcomp4(fetch4(bases, nmask, g));
+            else {  // only possible in a partial tail group at the very start of the genome
+                v = 0;
+                for (int i = 0; i < rem; i++) {
+                    uint32_t c = fetch4(bases, nmask, g_lo + wlen - 1 - p - i) & 0xffu;
+                    uint32_t r = c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'N';
+                    v |= r << (8 * i);
+                }
+            }
+        }
+        if (rem == 4 && aligned) *reinterpret_cast<uint32_t *>(dst + 4 * j) = v;
+        else for (int i = 0; i < rem; i++) dst[4 * j + i] = (uint8_t)(v >> (8 * i));
+    }
+}
+
+// one wavefront per copy
+__global__ void __launch_bounds__(256) flank_gather_kernel(const uint32_t *__restrict__ bases,
+                                                           const uint32_t *__restrict__ nmask,
+                                                           const int64_t *__restrict__ coff, int32_t ncontig, int64_t n,
+                                                           const int32_t *__restrict__ contig,
+                                                           const int64_t *__restrict__ s1, const int64_t *__restrict__ e1,
+                                                           const uint8_t *__restrict__ minus, int32_t flank,
+                                                           const int64_t *__restrict__ out_off, uint8_t *__restrict__ out,
+                                                           const int64_t *__restrict__ trunc_off,
+                                                           uint8_t *__restrict__ trunc_out) {
+    int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    int lane = threadIdx.x & 63;
+    int64_t len, tlen, g_lo;
+    window_rule(coff, ncontig, contig[i], s1[i], e1[i], flank, len, tlen, g_lo);
+    if (len == 0) return;
+    bool mn = minus[i] != 0;
+    emit_span(bases, nmask, g_lo, len, mn, 0, len, out + out_off[i], lane);
+    if (tlen && trunc_out) {
+        uint8_t *t = trunc_out + trunc_off[i];
+        emit_span(bases, nmask, g_lo, len, mn, 0, 500, t, lane);
+        emit_span(bases, nmask, g_lo, len, mn, len - 500, 500, t + 500, lane);
+    }
+}
+
+extern "C" int hite_flank_gather_dev(hite_ctx *ctx, int64_t n, const int32_t *d_contig, const int64_t *d_start1,
+                                     const int64_t *d_end1, const uint8_t *d_minus, int32_t flank,
+                                     const int64_t *d_out_off, uint8_t *d_out, const int64_t *d_trunc_off,
+                                     uint8_t *d_trunc_out, void *stream) {
+    if (!ctx || !ctx->d_bases) return HITE_EINVAL;
+    if (n <= 0) return HITE_OK;
+    int64_t blocks = (n + 3) / 4;
+    hipLaunchKernelGGL(flank_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ctx->d_bases,
+                       ctx->d_nmask, ctx->d_contig_off, ctx->n_contigs, n, d_contig, d_start1, d_end1, d_minus, flank,
+                       d_out_off, d_out, d_trunc_off, d_trunc_out);
+    HITE_CHECK(ctx, hipGetLastError());
+    return HITE_OK;
+}
+
+extern "C" int hite_flank_sizes_dev(hite_ctx *ctx, int64_t n, const int32_t *d_contig, const int64_t *d_start1,
+                                    const int64_t *d_end1, int32_t flank, int64_t *d_out_len, int64_t *d_trunc_len,
+                                    void *stream) {
+    if (!ctx || !ctx->d_bases) return HITE_EINVAL;
+    if (n <= 0) return HITE_OK;
+    hipLaunchKernelGGL(flank_sizes_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       ctx->d_contig_off, ctx->n_contigs, n, d_contig, d_start1, d_end1, flank, d_out_len, d_trunc_len);
+    HITE_CHECK(ctx, hipGetLastError());
+    return HITE_OK;
+}
+
+// host-buffer wrappers -------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    hipError_t up(const void *h, size_t n) {
+        hipError_t e = alloc(n);
+        if (e != hipSuccess) return e;
+        return n ? hipMemcpy(p, h, n, hipMemcpyHostToDevice) : hipSuccess;
+    }
+};
+
+extern "C" int hite_flank_sizes(hite_ctx *ctx, int64_t n, const int32_t *contig, const int64_t *start1,
+                                const int64_t *end1, int32_t flank, int64_t *out_len, int64_t *trunc_len) {
+    if (!ctx || !ctx->d_bases || n < 0) return HITE_EINVAL;
+    if (n == 0) return HITE_OK;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    DevBuf c, s, e, ol, tl;
+    HITE_CHECK(ctx, c.up(contig, n * 4));
+    HITE_CHECK(ctx, s.up(start1, n * 8));
+    HITE_CHECK(ctx, e.up(end1, n * 8));
+    HITE_CHECK(ctx, ol.alloc(n * 8));
+    HITE_CHECK(ctx, tl.alloc(n * 8));
+    int rc = hite_flank_sizes_dev(ctx, n, (int32_t *)c.p, (int64_t *)s.p, (int64_t *)e.p, flank, (int64_t *)ol.p,
+                                  (int64_t *)tl.p, nullptr);
+    if (rc) return rc;
+    HITE_CHECK(ctx, hipMemcpy(out_len, ol.p, n * 8, hipMemcpyDeviceToHost));
+    if (trunc_len) HITE_CHECK(ctx, hipMemcpy(trunc_len, tl.p, n * 8, hipMemcpyDeviceToHost));
+    return HITE_OK;
+}
+
+extern "C" int hite_flank_gather(hite_ctx *ctx, int64_t n, const int32_t *contig, const int64_t *start1,
+                                 const int64_t *end1, const uint8_t *minus, int32_t flank, const int64_t *out_off,
+                                 uint8_t *out, const int64_t *trunc_off, uint8_t *trunc_out) {
+    if (!ctx || !ctx->d_bases || n < 0 || !out_off || !out) return HITE_EINVAL;
+    if (n == 0) return HITE_OK;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    // sizes of the output pools = last offset + last length (recomputed on the host side from the rules)
+    int64_t *len = (int64_t *)malloc(sizeof(int64_t) * n * 2);
+    if (!len) return HITE_ENOMEM;
+    int rc = hite_flank_sizes(ctx, n, contig, start1, end1, flank, len, len + n);
+    if (rc) { free(len); return rc; }
+    int64_t tot = 0, ttot = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (len[i] && out_off[i] + len[i] > tot) tot = out_off[i] + len[i];
+        if (trunc_off && len[n + i] && trunc_off[i] + len[n + i] > ttot) ttot = trunc_off[i] + len[n + i];
+    }
+    free(len);
+    DevBuf c, s, e, m, oo, o, to, t;
+    HITE_CHECK(ctx, c.up(contig, n * 4));
+    HITE_CHECK(ctx, s.up(start1, n * 8));
+    HITE_CHECK(ctx, e.up(end1, n * 8));
+    HITE_CHECK(ctx, m.up(minus, n));
+    HITE_CHECK(ctx, oo.up(out_off, n * 8));
+    HITE_CHECK(ctx, o.alloc(tot + 16));
+    bool do_t = trunc_off && trunc_out && ttot > 0;
+    if (do_t) {
+        HITE_CHECK(ctx, to.up(trunc_off, n * 8));
+        HITE_CHECK(ctx, t.alloc(ttot + 16));
+    }
+    rc = hite_flank_gather_dev(ctx, n, (int32_t *)c.p, (int64_t *)s.p, (int64_t *)e.p, (uint8_t *)m.p, flank,
+                               (int64_t *)oo.p, (uint8_t *)o.p, do_t ? (int64_t *)to.p : nullptr,
+                               do_t ? (uint8_t *)t.p : nullptr, nullptr);
+    if (rc) return rc;
+    HITE_CHECK(ctx, hipDeviceSynchronize());
+    if (tot) HITE_CHECK(ctx, hipMemcpy(out, o.p, tot, hipMemcpyDeviceToHost));
+    if (do_t) HITE_CHECK(ctx, hipMemcpy(trunc_out, t.p, ttot, hipMemcpyDeviceToHost));
+    return HITE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// HIP-event timing helpers (bench.py times kernels on the stream they are launched on)
+// ---------------------------------------------------------------------------------------------
+extern "C" int hite_event_create(void **ev) {
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return HITE_EHIP;
+    *ev = (void *)e;
+    return HITE_OK;
+}
+extern "C" int hite_event_record(void *ev, void *stream) {
+    return hipEventRecord((hipEvent_t)ev, (hipStream_t)stream) == hipSuccess ? HITE_OK : HITE_EHIP;
+}
+extern "C" int hite_event_elapsed_ms(void *a, void *b, float *ms) {
+    if (hipEventSynchronize((hipEvent_t)b) != hipSuccess) return HITE_EHIP;
+    return hipEventElapsedTime(ms, (hipEvent_t)a, (hipEvent_t)b) == hipSuccess ? HITE_OK : HITE_EHIP;
+}
+extern "C" int hite_event_destroy(void *ev) {
+    return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? HITE_OK : HITE_EHIP;
+}

@@ -1,0 +1,143 @@
+/*
+ * hite_gpu.h -- C ABI of libhite_gpu.so: the MI355X-native (gfx950, HIP) implementation of
+ * HiTE's dynamic-boundary-adjustment hot path.  Plain pointers and sizes only.
+ *
+ * HiTE is pure Python: it has no FFI today.  Each entry point below replaces the inside of
+ * one Python function of /root/reference/module/Util.py (cited per function); the binding a
+ * maintainer adds is the ctypes stub shown in INTEGRATION.md (hite_amd/_lib.py is that stub).
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative HITE_E* code; nothing aborts.
+ *  - "host" entry points take host pointers (numpy buffers) and copy in/out;
+ *    "_dev" entry points take DEVICE pointers and a hipStream_t (as void*), launch
+ *    asynchronously on that stream and never synchronise (bench / pipelines / torch tensors).
+ *  - strings cross the boundary as uint8 arrays + int64 CSR offsets, never char**.
+ *  - an alignment ("msa") is rows x cols bytes, row-major, alphabet ACGTN and '-' (any other
+ *    byte is folded to 'N' on entry, the same folding getReverseSequence applies, Util.py:1635).
+ *  - thread-safety: one hite_ctx per thread / per GPU; no global HIP state before the first call.
+ */
+#ifndef HITE_GPU_H
+#define HITE_GPU_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HITE_OK 0
+#define HITE_EINVAL (-1)   /* bad argument */
+#define HITE_ENOMEM (-2)   /* host or device allocation failed */
+#define HITE_EHIP (-3)     /* HIP runtime error (hite_last_error() has the text) */
+#define HITE_ECAP (-4)     /* caller-provided output capacity too small */
+#define HITE_ENODEV (-5)   /* no usable GPU */
+
+#define HITE_TE_TIR 0      /* judge_boundary_v5  Util.py:9145 */
+#define HITE_TE_HELITRON 1 /* judge_boundary_v6  Util.py:9821 */
+#define HITE_TE_NON_LTR 2  /* judge_boundary_v9  Util.py:9483 */
+
+#define HITE_INFO_NONE 0   /* ''    */
+#define HITE_INFO_NB 1     /* 'nb'  : anchor not found */
+#define HITE_INFO_FL1 2    /* 'fl1' : <= 1 full-length row */
+#define HITE_INFO_EXC 3    /* the reference would raise a Python exception on this input */
+
+typedef struct hite_ctx hite_ctx;
+
+/* One boundary call = the tuple judge_boundary_v5/v6/v9 return (is_TE, info, cons_seq, row_num)
+ * plus the final boundary columns the reference only prints in debug mode.  32 bytes; this is also
+ * the record all-gathered between GPUs. */
+typedef struct hite_call {
+    int32_t is_te;
+    int32_t info;
+    int32_t row_num;
+    int32_t bstart;   /* final_boundary_start column (-1 if none) */
+    int32_t bend;     /* final_boundary_end column   (-1 if none) */
+    int32_t cons_len; /* consensus length */
+    int64_t cons_off; /* offset of the consensus inside the caller's cons pool */
+} hite_call;
+
+/* ---- context ------------------------------------------------------------------------- */
+int hite_ctx_create(int device_id, hite_ctx **out);
+void hite_ctx_destroy(hite_ctx *ctx);
+const char *hite_last_error(hite_ctx *ctx);
+int hite_version(void);
+
+/* ---- genome residency (2-bit bases + 1-bit non-ACGT mask in HBM) ------------------------
+ * Replaces the per-stage `read_fasta(reference)` (Util.py:1650, called at :8073, :4616, :4788).
+ * seq = all contigs concatenated (upper-cased ASCII), contig_off[n_contigs+1] CSR. */
+int hite_genome_pack(hite_ctx *ctx, const uint8_t *seq, const int64_t *contig_off, int32_t n_contigs);
+/* same, from an ASCII buffer already in device memory (async on `stream`) */
+int hite_genome_pack_dev(hite_ctx *ctx, const uint8_t *d_seq, const int64_t *contig_off_host, int32_t n_contigs,
+                         void *stream);
+int64_t hite_genome_bases(hite_ctx *ctx);
+
+/* ---- flank-window gather --- Util.py:8095-8124 (inside flank_region_align_v5) -------------
+ * copy i = (contig[i], start1[i], end1[i]) 1-based inclusive, minus[i] = strand '-'.
+ * Pass 1 (sizes): out_len[i] = window length, 0 if the reference skips the copy (off-contig
+ *   :8103 or shorter than 100 :8108); trunc_len[i] = 1000 if window > 1000 (:8117) else 0.
+ * Pass 2 (fill): windows written at out_off[i] (caller's exclusive scan of out_len), the
+ *   first500+last500 form at trunc_off[i] when trunc_len[i] != 0 (trunc_* may be NULL). */
+int hite_flank_sizes(hite_ctx *ctx, int64_t n, const int32_t *contig, const int64_t *start1, const int64_t *end1,
+                     int32_t flank, int64_t *out_len, int64_t *trunc_len);
+int hite_flank_sizes_dev(hite_ctx *ctx, int64_t n, const int32_t *d_contig, const int64_t *d_start1,
+                         const int64_t *d_end1, int32_t flank, int64_t *d_out_len, int64_t *d_trunc_len, void *stream);
+int hite_flank_gather(hite_ctx *ctx, int64_t n, const int32_t *contig, const int64_t *start1, const int64_t *end1,
+                      const uint8_t *minus, int32_t flank, const int64_t *out_off, uint8_t *out,
+                      const int64_t *trunc_off, uint8_t *trunc_out);
+int hite_flank_gather_dev(hite_ctx *ctx, int64_t n, const int32_t *d_contig, const int64_t *d_start1,
+                          const int64_t *d_end1, const uint8_t *d_minus, int32_t flank, const int64_t *d_out_off,
+                          uint8_t *d_out, const int64_t *d_trunc_off, uint8_t *d_trunc_out, void *stream);
+
+/* ---- sparse-column removal --- remove_sparse_col_in_align_file  Util.py:10344-10405 --------
+ * batch of n alignments: msa_off[i] = byte offset of alignment i, rows[i] x cols[i].
+ * Writes the cleaned alignment IN THE SAME SLOT of `out` (offset msa_off[i], row stride
+ * new_cols[i]) and new_cols[i]. */
+int hite_sparse_cols(hite_ctx *ctx, int32_t n, const uint8_t *msa, const int64_t *msa_off, const int32_t *rows,
+                     const int32_t *cols, uint8_t *out, int32_t *new_cols);
+/* device-resident: d_col_off = exclusive scan of cols (n+1), total_cols = its last element;
+ * d_out must not alias d_msa. */
+int hite_sparse_cols_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_msa, const int64_t *d_msa_off,
+                         const int32_t *d_rows, const int32_t *d_cols, const int64_t *d_col_off, int64_t total_cols,
+                         uint8_t *d_out, int32_t *d_new_cols, void *stream);
+
+/* ---- column vote --- col_base_map  Util.py:9251-9266 (a-15) --------------------------------
+ * counts_out[col_off[i] + c][6] = per-column counts of A,C,G,T,N,'-' over ALL rows of
+ * alignment i, with col_off[i] = caller's exclusive scan of cols. */
+int hite_column_vote(hite_ctx *ctx, int32_t n, const uint8_t *msa, const int64_t *msa_off, const int32_t *rows,
+                     const int32_t *cols, const int64_t *col_off, int32_t *counts_out);
+
+/* ---- boundary search --- search_boundary_homo_v3 / _v4  Util.py:8887-9143 / 8556-8824 --------
+ * One search per alignment: pos[i], side[i] (0 'start', 1 'end'), thr[i]; variant 3 or 4.
+ * For v4 int_thr/out_thr as the caller passes them; valid_out (v4's first tuple element)
+ * may be NULL for v3.  win_in = 20, win_out = 10 in every reference call. */
+int hite_boundary_search(hite_ctx *ctx, int32_t n, const uint8_t *msa, const int64_t *msa_off, const int32_t *rows,
+                         const int32_t *cols, const int32_t *pos, const int32_t *side, const double *thr,
+                         const double *int_thr, const double *out_thr, int32_t variant, int32_t win_in,
+                         int32_t win_out, int32_t *boundary_out, int32_t *valid_out);
+
+/* ---- judge --- judge_boundary_v5 / v6 / v9 (result_type 'cons') ------------------------------
+ * te_type selects the variant for the whole batch.  cand = candidate sequences (cur_seq), CSR
+ * cand_off[n+1].  calls[i].cons_off = msa col prefix: cons pool must hold sum(cols[i] + 8) bytes
+ * and candidate i's consensus is written at cons_off = sum_{j<i}(cols[j] + 8). */
+int hite_judge(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n, const uint8_t *msa, const int64_t *msa_off,
+               const int32_t *rows, const int32_t *cols, const uint8_t *cand, const int64_t *cand_off,
+               hite_call *calls, uint8_t *cons);
+int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n, const uint8_t *d_msa,
+                   const int64_t *d_msa_off, const int32_t *d_rows, const int32_t *d_cols, const uint8_t *d_cand,
+                   const int64_t *d_cand_off, const int64_t *d_col_off, int32_t max_cols, int32_t max_rows,
+                   hite_call *d_calls, uint8_t *d_cons, void *stream);
+
+/* ---- TSDsearch_v5  Util.py:2460-2492 (batch of rows) --------------------------------------- */
+int hite_tsd_search(hite_ctx *ctx, int32_t n, const uint8_t *rows_bytes, const int64_t *row_off,
+                    const int32_t *bstart, const int32_t *bend, int32_t plant, int32_t *tsd_len_out,
+                    uint8_t *left_out /* n x 16 */, uint8_t *right_out /* n x 16 */);
+
+/* ---- timing helper: HIP-event elapsed ms around work already enqueued on `stream` ---------- */
+int hite_event_create(void **ev);
+int hite_event_record(void *ev, void *stream);
+int hite_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms);
+int hite_event_destroy(void *ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HITE_GPU_H */
