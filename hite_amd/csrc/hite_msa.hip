@@ -1,0 +1,350 @@
+// hite_msa.hip -- star alignment of the copy windows of each candidate: this build's GPU-native
+// stage at the point where the reference shells out to `mafft` (Util.py:10416, third-party,
+// unpinned, absent -> parity unpinned; the pinned twin is oracle/hite_oracle_msa.c, byte-exact).
+//
+// Definition: see the header comment of oracle/hite_oracle_msa.c (identical scoring, band
+// rule and tie-breaks).  Mapping to CDNA4:
+//   * one wavefront per (row, centre) pair; the 64 lanes ARE the adaptive band: lane k owns
+//     the cell i = t + k of anti-diagonal s = i + j, so one step of the recurrence is a
+//     handful of wave64 VALU ops + three cross-lane reads, no LDS, no divergence;
+//   * the per-cell direction (2 bits) leaves the wave as two 64-bit __ballot masks
+//     (16 B per anti-diagonal, written by one lane), the band moves as one bit per step;
+//   * the traceback replays those masks; it emits per centre position "gap?" + "bases inserted
+//     before", 2 B per position;
+//   * a second kernel takes the per-position maximum insertion over the rows (column layout)
+//     and a third writes the rows x cols matrix, every output byte written exactly once.
+// The DP is integer-ALU / latency bound (report cells/s); layout+fill are HBM streaming.
+#include "hite_common.h"
+
+#define MW 64
+#define MNEG (-(1 << 28))
+#define SC_MATCH 2
+#define SC_MIS (-2)
+#define SC_GAP (-4)
+
+struct MsaParams {
+    int n;                     // candidates
+    int64_t total_rows;
+    const uint8_t *win;
+    const int64_t *win_off;    // total_rows + 1
+    const int32_t *row_first;  // n + 1
+    const int64_t *ops_base;   // n + 1 : exclusive scan of (R_c + 1) * (m_c + 1)
+    uint16_t *ops;
+    int32_t *cols_out;         // n
+    int32_t *status;           // n : 0 ok, 1 failed (path left the band / too wide)
+    uint8_t *tb;               // traceback scratch, per wave slot
+    size_t tb_slot;            // bytes per slot
+    int max_steps;
+    unsigned int *counter;
+};
+
+__device__ __forceinline__ int find_cand(const int32_t *__restrict__ row_first, int n, int64_t g) {
+    int lo = 0, hi = n;  // largest c with row_first[c] <= g
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if ((int64_t)row_first[mid] <= g) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
+    const int lane = threadIdx.x & 63;
+    const int wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
+    uint8_t *slot = P.tb + (size_t)wslot * P.tb_slot;
+    ulonglong2 *tbd = reinterpret_cast<ulonglong2 *>(slot);                          // [max_steps + 1]
+    unsigned long long *tbm = reinterpret_cast<unsigned long long *>(slot + (size_t)(P.max_steps + 1) * 16);  // move bits
+    for (;;) {
+        unsigned int gq = 0;
+        if (lane == 0) gq = atomicAdd(P.counter, 1u);
+        gq = __builtin_amdgcn_readfirstlane(gq);
+        if ((int64_t)gq >= P.total_rows) break;
+        const int64_t g = gq;
+        const int c = find_cand(P.row_first, P.n, g);
+        const int64_t g0 = P.row_first[c];
+        if (g == g0) continue;  // the centre itself
+        const uint8_t *a = P.win + P.win_off[g0];
+        const int m = (int)(P.win_off[g0 + 1] - P.win_off[g0]);
+        const uint8_t *b = P.win + P.win_off[g];
+        const int n = (int)(P.win_off[g + 1] - P.win_off[g]);
+        uint16_t *ops = P.ops + P.ops_base[c] + (int64_t)(g - g0) * (m + 1);
+        const int steps = m + n;
+        if (m <= 0 || n <= 0 || steps > P.max_steps) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
+
+        // ---------------- forward: anti-diagonal adaptive band ----------------
+        int t = -32, tp = -32;  // origins of anti-diagonals s-1 and s-2
+        int prev = lane == 32 ? 0 : MNEG, pprev = MNEG;
+        unsigned long long mvbits = 0;
+        for (int s = 1; s <= steps; s++) {
+            int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);
+            int move = h0 > h63 ? 0 : (h0 < h63 ? 1 : ((((s - 1) & 1) == 0) ? 1 : 0));
+            int lo = s - n > 0 ? s - n : 0, hi = m < s ? m : s;
+            int tn = t + move;
+            if (tn > hi - 31) tn = t;
+            if (tn < lo - 32) tn = t + 1;
+            const int dt1 = tn - t, dt2 = tn - tp;
+            const int i = tn + lane, j = s - i;
+            int lu = lane + dt1 - 1, ll = lane + dt1, ld = lane + dt2 - 1;
+            int hu = __shfl(prev, lu & 63, 64), hl = __shfl(prev, ll & 63, 64), hd = __shfl(pprev, ld & 63, 64);
+            if (lu < 0 || lu > 63) hu = MNEG;
+            if (ll < 0 || ll > 63) hl = MNEG;
+            if (ld < 0 || ld > 63) hd = MNEG;
+            int v = MNEG, d = 0;
+            if (i >= 0 && i <= m && j >= 0 && j <= n) {
+                int cd = MNEG, cu = MNEG, cl = MNEG;
+                if (i >= 1 && j >= 1) {
+                    uint8_t x = a[i - 1], y = b[j - 1];
+                    cd = hd + ((x == y && x != 'N') ? SC_MATCH : SC_MIS);
+                }
+                if (i >= 1) cu = hu + SC_GAP;
+                if (j >= 1) cl = hl + SC_GAP;
+                if (cd >= cu && cd >= cl) { v = cd; d = 0; }
+                else if (cu >= cl) { v = cu; d = 1; }
+                else { v = cl; d = 2; }
+            }
+            unsigned long long b0 = __ballot(d & 1), b1 = __ballot(d >> 1);
+            if (lane == 0) tbd[s] = make_ulonglong2(b0, b1);
+            mvbits |= (unsigned long long)(tn - t) << (s & 63);
+            if ((s & 63) == 63 || s == steps) { if (lane == 0) tbm[s >> 6] = mvbits; mvbits = 0; }
+            pprev = prev; prev = v; tp = t; t = tn;
+        }
+        // make lane 0's stores visible to the whole wave before the traceback loads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        // ---------------- traceback (wave-uniform) ----------------
+        int i = m, j = n, cur_ins = 0, pend_gap = 0, fail = 0;
+        int tcur = t;  // origin of anti-diagonal `steps`
+        int scur = steps;
+        while (i > 0 || j > 0) {
+            // bring tcur to anti-diagonal s = i + j
+            int s = i + j;
+            while (scur > s) {
+                unsigned long long mb = tbm[scur >> 6];
+                tcur -= (int)((mb >> (scur & 63)) & 1ull);
+                scur--;
+            }
+            int k = i - tcur;
+            if (k < 0 || k > 63) { fail = 1; break; }
+            ulonglong2 w = tbd[s];
+            int d = (int)((w.x >> k) & 1ull) | ((int)((w.y >> k) & 1ull) << 1);
+            if (i == 0) d = 2; else if (j == 0) d = 1;
+            if (d == 2) { cur_ins++; j--; }
+            else {
+                if (lane == 0) ops[i] = (uint16_t)((cur_ins > 0x7fff ? 0x7fff : cur_ins) | (pend_gap << 15));
+                pend_gap = d == 1;
+                cur_ins = 0;
+                i--;
+                if (d == 0) j--;
+            }
+        }
+        if (lane == 0) {
+            if (fail) atomicExch(&P.status[c], 1);
+            else ops[0] = (uint16_t)((cur_ins > 0x7fff ? 0x7fff : cur_ins) | (pend_gap << 15));
+        }
+    }
+}
+
+// column layout: one block per candidate.  insmax -> row-0 slot of ops, block starts -> slot R.
+__global__ void __launch_bounds__(256) star_layout_kernel(MsaParams P) {
+    __shared__ int s_scan[8];
+    const int c = blockIdx.x;
+    if (c >= P.n) return;
+    const int64_t g0 = P.row_first[c];
+    const int R = P.row_first[c + 1] - P.row_first[c];
+    const int m = (int)(P.win_off[g0 + 1] - P.win_off[g0]);
+    uint16_t *ops = P.ops + P.ops_base[c];
+    uint16_t *insmax = ops;                              // centre row slot (its own ops are all zero)
+    uint16_t *bstart = ops + (int64_t)R * (m + 1);       // extra slot
+    if (P.status[c]) { if (threadIdx.x == 0) P.cols_out[c] = 0; return; }
+    int running = 0;
+    for (int base = 0; base <= m; base += 256) {
+        int p = base + threadIdx.x;
+        int mx = 0;
+        if (p <= m) for (int r = 1; r < R; r++) { int v = ops[(int64_t)r * (m + 1) + p] & 0x7fff; mx = v > mx ? v : mx; }
+        int width = p <= m ? mx + (p < m ? 1 : 0) : 0;
+        int tot;
+        int pre = block_excl_scan(width, s_scan, &tot);
+        if (p <= m) {
+            int bs = running + pre;
+            insmax[p] = (uint16_t)mx;
+            bstart[p] = (uint16_t)(bs > 65535 ? 65535 : bs);
+        }
+        running += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        if (running > 65535) { P.status[c] = 1; P.cols_out[c] = 0; }
+        else P.cols_out[c] = running;
+    }
+}
+
+struct FillParams {
+    int n;
+    const uint8_t *win;
+    const int64_t *win_off;
+    const int32_t *row_first;
+    const int64_t *ops_base;
+    const uint16_t *ops;
+    const int32_t *cols;
+    const int64_t *msa_off;
+    uint8_t *msa;
+};
+
+// fill: one block per candidate, rows in turn; thread p owns insertion block p + centre column p
+__global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
+    __shared__ int s_scan[8];
+    const int c = blockIdx.x;
+    if (c >= P.n) return;
+    const int C = P.cols[c];
+    if (C <= 0) return;
+    const int64_t g0 = P.row_first[c];
+    const int R = P.row_first[c + 1] - P.row_first[c];
+    const int m = (int)(P.win_off[g0 + 1] - P.win_off[g0]);
+    const uint16_t *ops = P.ops + P.ops_base[c];
+    const uint16_t *insmax = ops;
+    const uint16_t *bstart = ops + (int64_t)R * (m + 1);
+    uint8_t *out = P.msa + P.msa_off[c];
+    for (int r = 0; r < R; r++) {
+        const uint8_t *b = P.win + P.win_off[g0 + r];
+        uint8_t *row = out + (int64_t)r * C;
+        const uint16_t *rop = ops + (int64_t)r * (m + 1);
+        int running = 0;
+        for (int base = 0; base <= m; base += 256) {
+            int p = base + threadIdx.x;
+            int ins = 0, gap = 0, adv = 0;
+            if (p <= m) {
+                if (r > 0) { uint16_t o = rop[p]; ins = o & 0x7fff; gap = o >> 15; }
+                adv = ins + ((p < m && !gap) ? 1 : 0);
+            }
+            int tot;
+            int pre = block_excl_scan(adv, s_scan, &tot);
+            if (p <= m) {
+                int rp = running + pre;
+                int bs = bstart[p], im = insmax[p];
+                for (int q = 0; q < im; q++) row[bs + q] = q < ins ? b[rp + q] : (uint8_t)'-';
+                if (p < m) row[bs + im] = gap ? (uint8_t)'-' : b[rp + ins];
+            }
+            running += tot;
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                                 const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base,
+                                 int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status,
+                                 void *stream) {
+    if (!ctx || n < 0 || total_rows < 0 || max_win_len <= 0) return HITE_EINVAL;
+    if (n == 0) return HITE_OK;
+    const int max_steps = 2 * max_win_len;
+    size_t tb_slot = (size_t)(max_steps + 1) * 16 + ((size_t)(max_steps >> 6) + 2) * 8;
+    tb_slot = (tb_slot + 63) & ~(size_t)63;
+    int64_t pairs = total_rows - n;
+    int grid = (int)((pairs + 3) / 4);
+    if (grid < 1) grid = 1;
+    if (grid > 2048) grid = 2048;
+    while (grid > 64 && (size_t)grid * 4 * tb_slot > ((size_t)3 << 30)) grid /= 2;
+    void *scr = nullptr, *opsb = nullptr;
+    int rc = hite_scratch_reserve(ctx, (size_t)grid * 4 * tb_slot + 256, &scr);
+    if (rc) return rc;
+    rc = hite_scratch2_reserve(ctx, (size_t)ops_elems * 2 + 256, &opsb);
+    if (rc) return rc;
+    unsigned int *counter = (unsigned int *)((uint8_t *)scr + (size_t)grid * 4 * tb_slot);
+    hipStream_t st = (hipStream_t)stream;
+    HITE_CHECK(ctx, hipMemsetAsync(counter, 0, 4, st));
+    HITE_CHECK(ctx, hipMemsetAsync(d_status, 0, (size_t)n * 4, st));
+    MsaParams P;
+    P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = d_win_off; P.row_first = d_row_first;
+    P.ops_base = d_ops_base; P.ops = (uint16_t *)opsb; P.cols_out = d_cols_out; P.status = d_status;
+    P.tb = (uint8_t *)scr; P.tb_slot = tb_slot; P.max_steps = max_steps; P.counter = counter;
+    hipLaunchKernelGGL(star_align_kernel, dim3(grid), dim3(256), 0, st, P);
+    HITE_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(star_layout_kernel, dim3(n), dim3(256), 0, st, P);
+    HITE_CHECK(ctx, hipGetLastError());
+    return HITE_OK;
+}
+
+extern "C" int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                                      const int32_t *d_row_first, const int64_t *d_ops_base, const int32_t *d_cols,
+                                      const int64_t *d_msa_off, uint8_t *d_msa, void *stream) {
+    if (!ctx || n < 0 || !ctx->d_scratch2) return HITE_EINVAL;
+    if (n == 0) return HITE_OK;
+    FillParams P;
+    P.n = n; P.win = d_win; P.win_off = d_win_off; P.row_first = d_row_first; P.ops_base = d_ops_base;
+    P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_cols; P.msa_off = d_msa_off; P.msa = d_msa;
+    hipLaunchKernelGGL(star_fill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, P);
+    HITE_CHECK(ctx, hipGetLastError());
+    return HITE_OK;
+}
+
+struct MBuf {
+    void *p = nullptr;
+    ~MBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    hipError_t up(const void *h, size_t n) {
+        hipError_t e = alloc(n);
+        if (e != hipSuccess) return e;
+        return n ? hipMemcpy(p, h, n, hipMemcpyHostToDevice) : hipSuccess;
+    }
+};
+
+// host-buffer convenience: pass 1 (msa_out == NULL) returns cols_out only; otherwise also the
+// alignments at msa_off_out[i] (16-byte aligned slots), msa_cap bytes available.
+extern "C" int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off,
+                             const int32_t *row_first, int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out,
+                             int64_t *msa_off_out) {
+    if (!ctx || n < 0 || !win || !win_off || !row_first || !cols_out) return HITE_EINVAL;
+    if (n == 0) return HITE_OK;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    int64_t total_rows = row_first[n];
+    int64_t *ops_base = (int64_t *)malloc(sizeof(int64_t) * (n + 1));
+    if (!ops_base) return HITE_ENOMEM;
+    int64_t acc = 0;
+    int maxlen = 1;
+    for (int c = 0; c < n; c++) {
+        int R = row_first[c + 1] - row_first[c];
+        if (R <= 0) { free(ops_base); return HITE_EINVAL; }
+        int64_t m = win_off[row_first[c] + 1] - win_off[row_first[c]];
+        ops_base[c] = acc;
+        acc += (int64_t)(R + 1) * (m + 1);
+        for (int r = 0; r < R; r++) {
+            int64_t L = win_off[row_first[c] + r + 1] - win_off[row_first[c] + r];
+            if (L <= 0 || L > 32767) { free(ops_base); return HITE_EINVAL; }
+            if (L > maxlen) maxlen = (int)L;
+        }
+    }
+    ops_base[n] = acc;
+    MBuf dw, dwo, drf, dob, dcols, dst, dmo, dmsa;
+    hipError_t e;
+    e = dw.up(win, win_off[total_rows]); if (e == hipSuccess) e = dwo.up(win_off, (total_rows + 1) * 8);
+    if (e == hipSuccess) e = drf.up(row_first, (n + 1) * 4); if (e == hipSuccess) e = dob.up(ops_base, (n + 1) * 8);
+    if (e == hipSuccess) e = dcols.alloc(n * 4); if (e == hipSuccess) e = dst.alloc(n * 4);
+    free(ops_base);
+    HITE_CHECK(ctx, e);
+    int rc = hite_star_msa_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)drf.p, total_rows, (int64_t *)dob.p, acc,
+                               maxlen, (int32_t *)dcols.p, (int32_t *)dst.p, nullptr);
+    if (rc) return rc;
+    HITE_CHECK(ctx, hipDeviceSynchronize());
+    HITE_CHECK(ctx, hipMemcpy(cols_out, dcols.p, n * 4, hipMemcpyDeviceToHost));
+    if (!msa_out) return HITE_OK;
+    if (!msa_off_out) return HITE_EINVAL;
+    int64_t off = 0;
+    for (int c = 0; c < n; c++) {
+        int R = row_first[c + 1] - row_first[c];
+        msa_off_out[c] = off;
+        off += ((int64_t)R * cols_out[c] + 15) / 16 * 16;
+    }
+    if (off > msa_cap) return HITE_ECAP;
+    e = dmo.up(msa_off_out, n * 8); if (e == hipSuccess) e = dmsa.alloc(off + 16);
+    HITE_CHECK(ctx, e);
+    rc = hite_star_msa_fill_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)drf.p, (int64_t *)dob.p,
+                                (int32_t *)dcols.p, (int64_t *)dmo.p, (uint8_t *)dmsa.p, nullptr);
+    if (rc) return rc;
+    HITE_CHECK(ctx, hipDeviceSynchronize());
+    HITE_CHECK(ctx, hipMemcpy(msa_out, dmsa.p, off, hipMemcpyDeviceToHost));
+    return HITE_OK;
+}

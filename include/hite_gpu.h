@@ -131,6 +131,25 @@ int hite_tsd_search(hite_ctx *ctx, int32_t n, const uint8_t *rows_bytes, const i
                     const int32_t *bstart, const int32_t *bend, int32_t plant, int32_t *tsd_len_out,
                     uint8_t *left_out /* n x 16 */, uint8_t *right_out /* n x 16 */);
 
+/* ---- star alignment: this build's GPU-native stage where the reference runs the external
+ * `mafft --preservecase --quiet --thread 1` (Util.py:10416; third-party, unpinned -> parity is
+ * pinned against the build's own CPU twin, oracle/hite_oracle_msa.c).
+ * windows of candidate c = rows row_first[c] .. row_first[c+1]-1 of the CSR (win, win_off);
+ * the first row of each candidate is the centre.  Window length <= 32767.
+ * hite_star_msa: pass msa_out = NULL to get cols_out only; otherwise the rows x cols matrices are
+ * written at msa_off_out[c] (16-byte aligned slots) and msa_cap is checked.
+ * _dev: d_ops_base[n+1] = exclusive scan of (R_c + 1) * (m_c + 1) (m_c = centre length),
+ * ops_elems its last element; d_status[c] != 0 marks a candidate whose alignment failed
+ * (cols_out[c] = 0).  The fill call must follow the align call on the same ctx/stream. */
+int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
+                  int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out, int64_t *msa_off_out);
+int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                      const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base, int64_t ops_elems,
+                      int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status, void *stream);
+int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                           const int32_t *d_row_first, const int64_t *d_ops_base, const int32_t *d_cols,
+                           const int64_t *d_msa_off, uint8_t *d_msa, void *stream);
+
 /* ---- timing helper: HIP-event elapsed ms around work already enqueued on `stream` ---------- */
 int hite_event_create(void **ev);
 int hite_event_record(void *ev, void *stream);

@@ -1,0 +1,155 @@
+/*
+ * hite_oracle_msa.c -- TEST INFRASTRUCTURE ONLY (see hite_oracle.c header).
+ *
+ * CPU twin of the build's OWN star-alignment stage (hite_amd/csrc/hite_msa.hip), which stands
+ * where the reference shells out to `mafft --preservecase --quiet --thread 1`
+ * (/root/reference/module/Util.py:10416).  mafft is third-party, unpinned
+ * (environment.yml:30) and absent from this image: PARITY UNPINNED at that boundary
+ * (SURVEY.md 8c).  What is pinned is: HIP output == this twin, byte for byte, and everything
+ * downstream of the gapped matrix == the reference (hite_oracle.c).
+ *
+ * Definition (shared with the HIP kernels)
+ *   centre = row 0 of the candidate; every other row is aligned to it by global
+ *   Needleman-Wunsch, match +2 (equal, not 'N'), mismatch -2, linear gap -4, restricted to an
+ *   adaptive band of W=64 cells per anti-diagonal s=i+j (rows i in [t, t+63]):
+ *     - t(0) = -32; after anti-diagonal s the band moves right (t same) if H[lane0] > H[lane63],
+ *       down (t+1) if H[lane0] < H[lane63], on a tie down when s is even else right;
+ *     - then forced: t+1 only if t+1 <= min(m,s+1)-31, and t+1 if t < max(0,s+1-n)-32;
+ *   cells outside the band or the matrix hold NEG.  Ties in the recurrence: diag >= up >= left.
+ *   Traceback from (m,n) gives per centre position p: gap flag (row has '-') and the number of
+ *   row bases inserted before p.  Columns: for p = 0..m an insertion block of
+ *   max_r ins[r][p] columns (bases left-justified, '-' padded) followed (p < m) by the centre
+ *   column.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_EINVAL (-1002)
+#define ORC_ECAP (-1001)
+#define W 64
+#define NEG (-(1 << 28))
+#define SC_MATCH 2
+#define SC_MIS (-2)
+#define SC_GAP (-4)
+
+/* align row b[0..n) to centre a[0..m); ops[p] (p = 0..m): low 15 bits = insertions before p,
+ * bit 15 = row has a gap at centre position p.  returns 0 or <0. */
+static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t *ops) {
+    int steps = m + n;
+    /* direction codes per (s, lane) and the band origin t per s */
+    uint8_t *dir = (uint8_t *)malloc((size_t)(steps + 1) * W);
+    int *ts = (int *)malloc(sizeof(int) * (steps + 1));
+    int prev[W], pprev[W], cur[W];
+    if (!dir || !ts) { free(dir); free(ts); return ORC_EINVAL; }
+    int t = -32, tp = -32, tpp = -32;
+    for (int k = 0; k < W; k++) { prev[k] = NEG; pprev[k] = NEG; }
+    prev[32] = 0; /* H(0,0) */
+    ts[0] = t;
+    for (int s = 1; s <= steps; s++) {
+        /* choose the move from anti-diagonal s-1 (held in prev, origin tp == t) */
+        int h0 = prev[0], h63 = prev[W - 1];
+        int move;
+        if (h0 > h63) move = 0; else if (h0 < h63) move = 1; else move = (((s - 1) & 1) == 0) ? 1 : 0;
+        int lo = s - n > 0 ? s - n : 0, hi = m < s ? m : s;
+        int tn = t + move;
+        if (tn > hi - 31) tn = t;
+        if (tn < lo - 32) tn = t + 1;
+        tpp = tp; tp = t; t = tn;
+        /* after the shuffle of names: t = origin of s, tp = origin of s-1, tpp = origin of s-2 */
+        for (int k = 0; k < W; k++) {
+            int i = t + k, j = s - i;
+            int v = NEG, d = 0;
+            if (i >= 0 && i <= m && j >= 0 && j <= n) {
+                int lu = i - 1 - tp, ll = i - tp, ld = i - 1 - tpp;
+                int hu = (lu >= 0 && lu < W) ? prev[lu] : NEG;
+                int hl = (ll >= 0 && ll < W) ? prev[ll] : NEG;
+                int hd = (ld >= 0 && ld < W) ? pprev[ld] : NEG;
+                int cd = NEG, cu = NEG, cl = NEG;
+                if (i >= 1 && j >= 1) {
+                    uint8_t x = a[i - 1], y = b[j - 1];
+                    cd = hd + ((x == y && x != 'N') ? SC_MATCH : SC_MIS);
+                }
+                if (i >= 1) cu = hu + SC_GAP;
+                if (j >= 1) cl = hl + SC_GAP;
+                if (cd >= cu && cd >= cl) { v = cd; d = 0; }
+                else if (cu >= cl) { v = cu; d = 1; }
+                else { v = cl; d = 2; }
+            }
+            cur[k] = v;
+            dir[(size_t)s * W + k] = (uint8_t)d;
+        }
+        memcpy(pprev, prev, sizeof prev);
+        memcpy(prev, cur, sizeof cur);
+        ts[s] = t;
+    }
+    /* traceback */
+    int i = m, j = n, cur_ins = 0, pend_gap = 0;
+    while (i > 0 || j > 0) {
+        int s = i + j;
+        int k = i - ts[s];
+        int d;
+        if (k < 0 || k >= W) { free(dir); free(ts); return ORC_EINVAL; }
+        d = dir[(size_t)s * W + k];
+        if (i == 0) d = 2; else if (j == 0) d = 1; /* only possible moves on the borders */
+        if (d == 2) { cur_ins++; j--; }
+        else {
+            ops[i] = (uint16_t)((cur_ins > 0x7fff ? 0x7fff : cur_ins) | (pend_gap << 15));
+            pend_gap = d == 1;
+            cur_ins = 0;
+            i--;
+            if (d == 0) j--;
+        }
+    }
+    ops[0] = (uint16_t)((cur_ins > 0x7fff ? 0x7fff : cur_ins) | (pend_gap << 15));
+    free(dir); free(ts);
+    return 0;
+}
+
+/*
+ * One candidate: R windows (win + win_off[R+1]); writes cols and, if msa != NULL and cap suffices,
+ * the R x cols alignment (row-major).  Returns 0 or <0.
+ */
+int orc_star_msa(const uint8_t *win, const int64_t *win_off, int R, int *cols_out, uint8_t *msa, int64_t cap) {
+    if (R <= 0) return ORC_EINVAL;
+    const uint8_t *a = win + win_off[0];
+    int m = (int)(win_off[1] - win_off[0]);
+    if (m <= 0) return ORC_EINVAL;
+    uint16_t *ops = (uint16_t *)calloc((size_t)R * (m + 1), sizeof(uint16_t));
+    if (!ops) return ORC_EINVAL;
+    for (int r = 1; r < R; r++) {
+        int n = (int)(win_off[r + 1] - win_off[r]);
+        if (n <= 0) { free(ops); return ORC_EINVAL; }
+        int rc = pair_align(a, m, win + win_off[r], n, ops + (size_t)r * (m + 1));
+        if (rc) { free(ops); return rc; }
+    }
+    int *insmax = (int *)calloc(m + 1, sizeof(int));
+    int *bstart = (int *)calloc(m + 2, sizeof(int));
+    for (int r = 0; r < R; r++)
+        for (int p = 0; p <= m; p++) {
+            int v = ops[(size_t)r * (m + 1) + p] & 0x7fff;
+            if (v > insmax[p]) insmax[p] = v;
+        }
+    int c = 0;
+    for (int p = 0; p <= m; p++) { bstart[p] = c; c += insmax[p] + (p < m ? 1 : 0); }
+    int C = c;
+    *cols_out = C;
+    if (msa) {
+        if ((int64_t)R * C > cap) { free(ops); free(insmax); free(bstart); return ORC_ECAP; }
+        memset(msa, '-', (size_t)R * C);
+        for (int r = 0; r < R; r++) {
+            const uint8_t *b = win + win_off[r];
+            uint8_t *row = msa + (size_t)r * C;
+            int rp = 0;
+            for (int p = 0; p <= m; p++) {
+                uint16_t o = ops[(size_t)r * (m + 1) + p];
+                int ins = o & 0x7fff, gap = o >> 15;
+                for (int q = 0; q < ins; q++) row[bstart[p] + q] = b[rp + q];
+                rp += ins;
+                if (p < m && !gap) { row[bstart[p] + insmax[p]] = b[rp]; rp++; }
+            }
+        }
+    }
+    free(ops); free(insmax); free(bstart);
+    return 0;
+}

@@ -26,7 +26,7 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("hite_oracle.c", "hite_oracle_coarse.c")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("hite_oracle.c", "hite_oracle_coarse.c", "hite_oracle_msa.c")]
         if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
             build()
         _lib = C.CDLL(SO)
@@ -185,3 +185,18 @@ def tir_kmer(seq, raw_start, raw_end, dist, plant):
                            int(plant), cap, _ptr(k, i32p), _ptr(ts, i64p), _ptr(te, i64p), _ptr(d, i64p))
     assert m >= 0, m
     return [(int(k[i]), int(ts[i]), int(te[i]), int(d[i])) for i in range(m)]
+
+
+def star_msa(windows):
+    """windows: list of bytes/str (row 0 = centre) -> 2-D uint8 alignment (this build's mafft stand-in)"""
+    wb = [w.encode() if isinstance(w, str) else bytes(w) for w in windows]
+    off = np.zeros(len(wb) + 1, dtype=np.int64)
+    np.cumsum([len(w) for w in wb], out=off[1:])
+    buf = np.frombuffer(b"".join(wb), dtype=np.uint8)
+    cols = C.c_int(0)
+    rc = lib().orc_star_msa(_ptr(buf, u8p), _ptr(off, i64p), len(wb), C.byref(cols), None, C.c_int64(0))
+    assert rc == 0, rc
+    out = np.zeros((len(wb), cols.value), dtype=np.uint8)
+    rc = lib().orc_star_msa(_ptr(buf, u8p), _ptr(off, i64p), len(wb), C.byref(cols), _ptr(out, u8p), C.c_int64(out.size))
+    assert rc == 0, rc
+    return out

@@ -39,8 +39,12 @@ def test_no_cpu_fallback_without_gpu():
 
 
 def test_product_does_not_import_oracle():
+    """only tests/, smoke() and bench.py's cpu_baseline leg may import / link / load the oracle"""
+    bad = re.compile(r"^\s*(import|from)\s+\S*oracle|#\s*include\s+\S*oracle|oracle_lib|libhite_oracle|dlopen|CDLL\(.*oracle", re.M)
     for dirpath, _, files in os.walk(os.path.join(ROOT, "hite_amd")):
         for f in files:
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
-                assert "oracle_lib" not in txt and "libhite_oracle" not in txt and "hite_oracle" not in txt, f
+                assert not bad.search(txt), f
+    mk = open(os.path.join(ROOT, "hite_amd", "csrc", "Makefile")).read()
+    assert "oracle" not in mk

@@ -153,3 +153,60 @@ def test_judge_wide_alignment(ctx):
     keep = O.sparse_cols(m).astype(bool)
     exp, _ = O.judge("tir", np.ascontiguousarray(m[:, keep]), c["cand"], 1)
     assert [g[0], g[1], g[2], g[3]] == exp
+
+
+def _families(seed, n_fam, rows_choices=(2, 8, 30, 60), lens=(150, 400, 800, 1400)):
+    rng = np.random.default_rng(seed)
+    groups = []
+    for f in range(n_fam):
+        L = int(rng.choice(lens))
+        R = int(rng.choice(rows_choices))
+        div = float(rng.choice([0.0, 0.05, 0.12, 0.2]))
+        indel = float(rng.choice([0.0, 0.01, 0.03]))
+        cons = casegen.rand_seq(rng, L)
+        wins = []
+        for r in range(R):
+            s = casegen.mutate(rng, cons, div if r else 0.0)
+            out = []
+            for ch in s:
+                x = rng.random()
+                if r and x < indel / 2:
+                    continue
+                out.append(ch)
+                if r and x > 1 - indel / 2:
+                    out.append(casegen.rand_seq(rng, int(rng.integers(1, 4))))
+            te = "".join(out)
+            if r and rng.random() < 0.1:
+                te = te[: len(te) // 2] + te[len(te) // 2 + int(rng.integers(5, 60)):]  # a larger deletion
+            w = casegen.rand_seq(rng, 50) + te + casegen.rand_seq(rng, 50)
+            if rng.random() < 0.05:
+                w = w[:30] + "NNNNN" + w[35:]
+            wins.append(w)
+        groups.append(wins)
+    return groups
+
+
+def test_star_msa_vs_twin(ctx):
+    groups = _families(2024, 40)
+    got = ctx.star_msa(groups)
+    for g, m in zip(groups, got):
+        exp = O.star_msa(g)
+        assert m is not None and m.shape == exp.shape
+        assert np.array_equal(m, exp)
+        # every row, ungapped, is the input window
+        for r, w in enumerate(g):
+            assert bytes(m[r][m[r] != ord("-")]) == w.encode()
+
+
+def test_star_msa_to_judge_chain(ctx):
+    """windows -> star alignment -> sparse columns -> judge, all on the GPU, vs the oracle chain"""
+    groups = _families(777, 24, rows_choices=(8, 30, 60), lens=(200, 500, 900))
+    cands = [g[0][50 - 6: len(g[0]) - 50 + 4] for g in groups]
+    msas = ctx.star_msa(groups)
+    clean = ctx.sparse_cols(msas)
+    got = ctx.judge("tir", clean, cands, plant=1)
+    for g, cand, res in zip(groups, cands, got):
+        m = O.star_msa(g)
+        keep = O.sparse_cols(m).astype(bool)
+        exp, _ = O.judge("tir", np.ascontiguousarray(m[:, keep]), cand, 1)
+        assert [res[0], res[1], res[2], res[3]] == exp
