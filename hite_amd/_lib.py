@@ -227,3 +227,34 @@ class Context:
             else:
                 res.append(out[moff[i]:moff[i] + rows[i] * cols[i]].reshape(int(rows[i]), int(cols[i])).copy())
         return res
+
+    # ---- the fine stage in one call (body of flank_region_align_v5 after copy finding) -----------
+    def flank_region_align(self, te_type, cands, copies, plant=1, flank=50):
+        """cands: list of candidate sequences; copies: list (per candidate) of
+        (contig_index, start1, end1, minus) tuples.  Needs genome_pack() first.
+        -> (list of (is_TE, info, cons, row_num, bstart, bend), stats)"""
+        n = len(cands)
+        cb = [c.encode() if isinstance(c, str) else bytes(c) for c in cands]
+        coff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in cb], out=coff[1:])
+        cbuf = np.frombuffer(b"".join(cb) + b"\0" * 16, dtype=np.uint8)
+        cf = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum([len(c) for c in copies], out=cf[1:])
+        flat = [t for c in copies for t in c]
+        contig = _arr([t[0] for t in flat], np.int32)
+        s1 = _arr([t[1] for t in flat], np.int64)
+        e1 = _arr([t[2] for t in flat], np.int64)
+        mn = _arr([t[3] for t in flat], np.uint8)
+        calls = np.zeros(n, dtype=CALL_DTYPE)
+        cap = int(coff[-1]) + (2 * flank + 64) * n + 4096
+        cons = np.zeros(cap + 16, dtype=np.uint8)
+        stats = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.hite_flank_region_align(self.h, HITE_TE[te_type], int(plant), n, _p(cbuf), _p(coff), _p(cf),
+                                                     C.c_int64(len(flat)), _p(contig), _p(s1), _p(e1), _p(mn), int(flank),
+                                                     _p(calls), _p(cons), C.c_int64(cap), _p(stats)), "hite_flank_region_align")
+        out = []
+        for i in range(n):
+            c = calls[i]
+            s = cons[c["cons_off"]:c["cons_off"] + c["cons_len"]].tobytes().decode() if c["is_te"] else ""
+            out.append((bool(c["is_te"]), INFO[int(c["info"])], s, int(c["row_num"]), int(c["bstart"]), int(c["bend"])))
+        return out, stats

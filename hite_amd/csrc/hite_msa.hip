@@ -26,7 +26,8 @@ struct MsaParams {
     int n;                     // candidates
     int64_t total_rows;
     const uint8_t *win;
-    const int64_t *win_off;    // total_rows + 1
+    const int64_t *win_off;    // total_rows : start of each window
+    const int32_t *win_len;    // total_rows : length of each window
     const int32_t *row_first;  // n + 1
     const int64_t *ops_base;   // n + 1 : exclusive scan of (R_c + 1) * (m_c + 1)
     uint16_t *ops;
@@ -63,9 +64,9 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         const int64_t g0 = P.row_first[c];
         if (g == g0) continue;  // the centre itself
         const uint8_t *a = P.win + P.win_off[g0];
-        const int m = (int)(P.win_off[g0 + 1] - P.win_off[g0]);
+        const int m = P.win_len[g0];
         const uint8_t *b = P.win + P.win_off[g];
-        const int n = (int)(P.win_off[g + 1] - P.win_off[g]);
+        const int n = P.win_len[g];
         uint16_t *ops = P.ops + P.ops_base[c] + (int64_t)(g - g0) * (m + 1);
         const int steps = m + n;
         if (m <= 0 || n <= 0 || steps > P.max_steps) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
@@ -152,7 +153,7 @@ __global__ void __launch_bounds__(256) star_layout_kernel(MsaParams P) {
     if (c >= P.n) return;
     const int64_t g0 = P.row_first[c];
     const int R = P.row_first[c + 1] - P.row_first[c];
-    const int m = (int)(P.win_off[g0 + 1] - P.win_off[g0]);
+    const int m = P.win_len[g0];
     uint16_t *ops = P.ops + P.ops_base[c];
     uint16_t *insmax = ops;                              // centre row slot (its own ops are all zero)
     uint16_t *bstart = ops + (int64_t)R * (m + 1);       // extra slot
@@ -183,6 +184,7 @@ struct FillParams {
     int n;
     const uint8_t *win;
     const int64_t *win_off;
+    const int32_t *win_len;
     const int32_t *row_first;
     const int64_t *ops_base;
     const uint16_t *ops;
@@ -200,7 +202,7 @@ __global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
     if (C <= 0) return;
     const int64_t g0 = P.row_first[c];
     const int R = P.row_first[c + 1] - P.row_first[c];
-    const int m = (int)(P.win_off[g0 + 1] - P.win_off[g0]);
+    const int m = P.win_len[g0];
     const uint16_t *ops = P.ops + P.ops_base[c];
     const uint16_t *insmax = ops;
     const uint16_t *bstart = ops + (int64_t)R * (m + 1);
@@ -235,7 +237,7 @@ __global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
 // host side
 // ---------------------------------------------------------------------------------------------
 extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
-                                 const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base,
+                                 const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base,
                                  int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status,
                                  void *stream) {
     if (!ctx || n < 0 || total_rows < 0 || max_win_len <= 0) return HITE_EINVAL;
@@ -258,7 +260,7 @@ extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win,
     HITE_CHECK(ctx, hipMemsetAsync(counter, 0, 4, st));
     HITE_CHECK(ctx, hipMemsetAsync(d_status, 0, (size_t)n * 4, st));
     MsaParams P;
-    P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = d_win_off; P.row_first = d_row_first;
+    P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first;
     P.ops_base = d_ops_base; P.ops = (uint16_t *)opsb; P.cols_out = d_cols_out; P.status = d_status;
     P.tb = (uint8_t *)scr; P.tb_slot = tb_slot; P.max_steps = max_steps; P.counter = counter;
     hipLaunchKernelGGL(star_align_kernel, dim3(grid), dim3(256), 0, st, P);
@@ -269,12 +271,12 @@ extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win,
 }
 
 extern "C" int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
-                                      const int32_t *d_row_first, const int64_t *d_ops_base, const int32_t *d_cols,
+                                      const int32_t *d_win_len, const int32_t *d_row_first, const int64_t *d_ops_base, const int32_t *d_cols,
                                       const int64_t *d_msa_off, uint8_t *d_msa, void *stream) {
     if (!ctx || n < 0 || !ctx->d_scratch2) return HITE_EINVAL;
     if (n == 0) return HITE_OK;
     FillParams P;
-    P.n = n; P.win = d_win; P.win_off = d_win_off; P.row_first = d_row_first; P.ops_base = d_ops_base;
+    P.n = n; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first; P.ops_base = d_ops_base;
     P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_cols; P.msa_off = d_msa_off; P.msa = d_msa;
     hipLaunchKernelGGL(star_fill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, P);
     HITE_CHECK(ctx, hipGetLastError());
@@ -318,14 +320,19 @@ extern "C" int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const
         }
     }
     ops_base[n] = acc;
-    MBuf dw, dwo, drf, dob, dcols, dst, dmo, dmsa;
+    int32_t *wl = (int32_t *)malloc(sizeof(int32_t) * (total_rows + 1));
+    if (!wl) { free(ops_base); return HITE_ENOMEM; }
+    for (int64_t g = 0; g < total_rows; g++) wl[g] = (int32_t)(win_off[g + 1] - win_off[g]);
+    MBuf dw, dwo, dwl, drf, dob, dcols, dst, dmo, dmsa;
     hipError_t e;
     e = dw.up(win, win_off[total_rows]); if (e == hipSuccess) e = dwo.up(win_off, (total_rows + 1) * 8);
+    if (e == hipSuccess) e = dwl.up(wl, total_rows * 4);
+    free(wl);
     if (e == hipSuccess) e = drf.up(row_first, (n + 1) * 4); if (e == hipSuccess) e = dob.up(ops_base, (n + 1) * 8);
     if (e == hipSuccess) e = dcols.alloc(n * 4); if (e == hipSuccess) e = dst.alloc(n * 4);
     free(ops_base);
     HITE_CHECK(ctx, e);
-    int rc = hite_star_msa_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)drf.p, total_rows, (int64_t *)dob.p, acc,
+    int rc = hite_star_msa_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)dwl.p, (int32_t *)drf.p, total_rows, (int64_t *)dob.p, acc,
                                maxlen, (int32_t *)dcols.p, (int32_t *)dst.p, nullptr);
     if (rc) return rc;
     HITE_CHECK(ctx, hipDeviceSynchronize());
@@ -341,7 +348,7 @@ extern "C" int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const
     if (off > msa_cap) return HITE_ECAP;
     e = dmo.up(msa_off_out, n * 8); if (e == hipSuccess) e = dmsa.alloc(off + 16);
     HITE_CHECK(ctx, e);
-    rc = hite_star_msa_fill_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)drf.p, (int64_t *)dob.p,
+    rc = hite_star_msa_fill_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)dwl.p, (int32_t *)drf.p, (int64_t *)dob.p,
                                 (int32_t *)dcols.p, (int64_t *)dmo.p, (uint8_t *)dmsa.p, nullptr);
     if (rc) return rc;
     HITE_CHECK(ctx, hipDeviceSynchronize());

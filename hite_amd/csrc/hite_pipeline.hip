@@ -1,0 +1,556 @@
+// hite_pipeline.hip -- device-resident driver of the fine (dynamic-boundary) stage: the body of
+// flank_region_align_v5 (/root/reference/module/Util.py:8032-8194) from the copy table onwards,
+// one batched call per stage instead of one forked process per candidate:
+//
+//   copies --window rules--> rows (<=100 longest per candidate, Util.py:10409 / ready_for_MSA.sh)
+//          --flank gather (2-bit genome, revcomp in registers)--> windows
+//          --star alignment (hite_msa.hip)--> rows x cols matrices
+//          --remove_sparse_col--> cleaned matrices --judge_boundary_v5/v6/v9--> calls
+//
+// Candidates that have a copy window > 1000 bp are judged first on the first500+last500 form of
+// those copies only, and on the full windows only if that passed (run_find_members_v8,
+// Util.py:10439-10449).  Everything stays in HBM; the host reads back a handful of totals per
+// pass to size the next allocation.
+#include "hite_common.h"
+#include "hite_genome.h"
+#include <vector>
+
+extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n, const uint8_t *d_msa,
+                              const int64_t *d_msa_off, const int32_t *d_rows, const int32_t *d_cols,
+                              const uint8_t *d_cand, const int64_t *d_cand_off, const int64_t *d_col_off,
+                              int32_t max_cols, int32_t max_rows, hite_call *d_calls, uint8_t *d_cons, void *stream);
+
+#define MAXROWS 100
+
+// ---------------------------------------------------------------------------------------------
+// arenas (grow-only, reset per call; no hipMalloc on the steady-state path)
+// ---------------------------------------------------------------------------------------------
+struct Arena {
+    std::vector<void *> chunks;
+    std::vector<size_t> caps;
+    size_t off = 0;
+    size_t high = 0;  // bytes handed out since the last reset
+};
+struct PipeState {
+    Arena keep, tmp;
+    int64_t *h_pin = nullptr;  // pinned scalars for read-backs
+    int64_t *d_scal = nullptr;
+};
+
+static int arena_alloc(hite_ctx *ctx, Arena &a, size_t bytes, void **out) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (bytes == 0) bytes = 256;
+    if (a.chunks.empty() || a.off + bytes > a.caps.back()) {
+        size_t want = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
+        void *p = nullptr;
+        HITE_CHECK(ctx, hipMalloc(&p, want));
+        a.chunks.push_back(p);
+        a.caps.push_back(want);
+        a.off = 0;
+    }
+    *out = (uint8_t *)a.chunks.back() + a.off;
+    a.off += bytes;
+    a.high += bytes;
+    return HITE_OK;
+}
+// after use: if the arena fragmented into several chunks, replace them by one of the total size
+static int arena_reset(hite_ctx *ctx, Arena &a, bool may_sync) {
+    if (a.chunks.size() > 1 && may_sync) {
+        HITE_CHECK(ctx, hipDeviceSynchronize());
+        for (void *p : a.chunks) (void)hipFree(p);
+        a.chunks.clear();
+        a.caps.clear();
+        size_t want = a.high + a.high / 8 + ((size_t)16 << 20);
+        void *p = nullptr;
+        HITE_CHECK(ctx, hipMalloc(&p, want));
+        a.chunks.push_back(p);
+        a.caps.push_back(want);
+    }
+    a.off = 0;
+    a.high = 0;
+    return HITE_OK;
+}
+static void arena_free(Arena &a) {
+    for (void *p : a.chunks) (void)hipFree(p);
+    a.chunks.clear();
+    a.caps.clear();
+    a.off = a.high = 0;
+}
+
+extern "C" void hite_pipeline_release(void *state) {
+    PipeState *s = (PipeState *)state;
+    if (!s) return;
+    arena_free(s->keep);
+    arena_free(s->tmp);
+    if (s->h_pin) (void)hipHostFree(s->h_pin);
+    if (s->d_scal) (void)hipFree(s->d_scal);
+    delete s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exclusive scan (int64 out, out[n] = total), three phases; TIn = int32_t or int64_t
+// ---------------------------------------------------------------------------------------------
+#define SCAN_TILE 4096
+template <typename TIn>
+__global__ void __launch_bounds__(256) scan_sums_kernel(const TIn *__restrict__ in, int64_t n, int64_t *__restrict__ bsum) {
+    __shared__ long long s_w[4];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    long long acc = 0;
+    for (int i = threadIdx.x; i < SCAN_TILE; i += 256) {
+        int64_t k = base + i;
+        if (k < n) acc += (long long)in[k];
+    }
+    for (int d = 32; d >= 1; d >>= 1) acc += __shfl_down(acc, d, 64);
+    if ((threadIdx.x & 63) == 0) s_w[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) bsum[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+}
+__global__ void scan_bsums_kernel(int64_t *__restrict__ bsum, int64_t nb, int64_t *__restrict__ total) {
+    // single thread block, serial over the (few thousand) tile sums
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        long long acc = 0;
+        for (int64_t b = 0; b < nb; b++) { long long v = bsum[b]; bsum[b] = acc; acc += v; }
+        *total = acc;
+    }
+}
+template <typename TIn>
+__global__ void __launch_bounds__(256) scan_apply_kernel(const TIn *__restrict__ in, int64_t n, const int64_t *__restrict__ bsum,
+                                                         int64_t *__restrict__ out) {
+    __shared__ long long s_w[4];
+    int64_t base = (int64_t)blockIdx.x * SCAN_TILE;
+    long long running = bsum[blockIdx.x];
+    for (int i0 = 0; i0 < SCAN_TILE; i0 += 256) {
+        int64_t k = base + i0 + threadIdx.x;
+        long long v = k < n ? (long long)in[k] : 0;
+        long long x = v;
+        int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        for (int d = 1; d < 64; d <<= 1) { long long y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        __syncthreads();
+        if (lane == 63) s_w[w] = x;
+        __syncthreads();
+        long long pre = 0, tot = 0;
+        for (int q = 0; q < 4; q++) { if (q < w) pre += s_w[q]; tot += s_w[q]; }
+        if (k < n) out[k] = running + pre + x - v;
+        running += tot;
+    }
+}
+template <typename TIn>
+static int scan_excl(hite_ctx *ctx, Arena &tmp, const TIn *d_in, int64_t n, int64_t *d_out /* n+1 */, hipStream_t st) {
+    int64_t nb = (n + SCAN_TILE - 1) / SCAN_TILE;
+    if (nb < 1) nb = 1;
+    void *bs = nullptr;
+    int rc = arena_alloc(ctx, tmp, (size_t)nb * 8, &bs);
+    if (rc) return rc;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_sums_kernel<TIn>), dim3((unsigned)nb), dim3(256), 0, st, d_in, n, (int64_t *)bs);
+    hipLaunchKernelGGL(scan_bsums_kernel, dim3(1), dim3(64), 0, st, (int64_t *)bs, nb, d_out + n);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_apply_kernel<TIn>), dim3((unsigned)nb), dim3(256), 0, st, d_in, n, (int64_t *)bs, d_out);
+    HITE_CHECK(ctx, hipGetLastError());
+    return HITE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// stage kernels
+// ---------------------------------------------------------------------------------------------
+// mode of pass A: 2 = judge first on first500+last500 of the >1000 windows, 1 = full windows, 0 = no copy
+__global__ void mode_a_kernel(int n, const int32_t *__restrict__ copy_first, const int64_t *__restrict__ len,
+                              int32_t *__restrict__ mode) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    int any = 0, big = 0;
+    for (int i = copy_first[c]; i < copy_first[c + 1]; i++) { any |= len[i] > 0; big |= len[i] > 1000; }
+    mode[c] = big ? 2 : (any ? 1 : 0);
+}
+// mode of pass B: full windows for the candidates whose truncated form passed
+__global__ void mode_b_kernel(int n, const int32_t *__restrict__ mode_a, const hite_call *__restrict__ calls_a,
+                              int32_t *__restrict__ mode) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    mode[c] = (mode_a[c] == 2 && calls_a[c].is_te) ? 1 : 0;
+}
+
+// rows of each candidate: eligible copies, at most the 100 longest (ties: input order), input order kept
+__global__ void __launch_bounds__(256) select_rows_kernel(int n, const int32_t *__restrict__ copy_first,
+                                                          const int64_t *__restrict__ len,
+                                                          const int32_t *__restrict__ mode, int32_t *__restrict__ nrows,
+                                                          int32_t *__restrict__ sel /* n x 100 */) {
+    __shared__ int s_scan[8];
+    __shared__ int s_cnt;
+    int c = blockIdx.x;
+    if (c >= n) return;
+    const int md = mode[c];
+    const int f = copy_first[c], k = copy_first[c + 1] - f;
+    if (md == 0 || k <= 0) { if (threadIdx.x == 0) nrows[c] = 0; return; }
+    // count eligible
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    int local = 0;
+    for (int i = threadIdx.x; i < k; i += 256) { int64_t L = len[f + i]; local += md == 2 ? (L > 1000) : (L > 0); }
+    atomicAdd(&s_cnt, local);
+    __syncthreads();
+    const int E = s_cnt;
+    int running = 0;
+    for (int base = 0; base < k; base += 256) {
+        int i = base + threadIdx.x;
+        int keep = 0;
+        if (i < k) {
+            int64_t L = len[f + i];
+            bool el = md == 2 ? (L > 1000) : (L > 0);
+            if (el) {
+                if (E <= MAXROWS) keep = 1;
+                else {
+                    int64_t Li = md == 2 ? 1000 : L;
+                    int rank = 0;
+                    for (int j = 0; j < k; j++) {
+                        int64_t Lj = len[f + j];
+                        bool ej = md == 2 ? (Lj > 1000) : (Lj > 0);
+                        if (!ej) continue;
+                        if (md == 2) Lj = 1000;
+                        rank += (Lj > Li) || (Lj == Li && j < i);
+                    }
+                    keep = rank < MAXROWS;
+                }
+            }
+        }
+        int tot;
+        int pre = block_excl_scan(keep, s_scan, &tot);
+        if (keep) sel[(int64_t)c * MAXROWS + running + pre] = f + i;
+        running += tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) nrows[c] = running;
+}
+
+__global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, const int32_t *__restrict__ nrows,
+                                const int32_t *__restrict__ sel, const int32_t *__restrict__ mode,
+                                const int64_t *__restrict__ len, int32_t *__restrict__ row_first32,
+                                int32_t *__restrict__ row_copy, int32_t *__restrict__ row_len,
+                                int32_t *__restrict__ row_pad, uint8_t *__restrict__ row_trunc,
+                                int32_t *__restrict__ maxlen) {
+    int c = blockIdx.x;
+    if (c >= n) return;
+    if (threadIdx.x == 0) { row_first32[c] = (int32_t)row_first[c]; if (c == n - 1) row_first32[n] = (int32_t)row_first[n]; }
+    int R = nrows[c];
+    int md = mode[c];
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        int64_t g = row_first[c] + r;
+        int cp = sel[(int64_t)c * MAXROWS + r];
+        int L = md == 2 ? 1000 : (int)len[cp];
+        row_copy[g] = cp;
+        row_len[g] = L;
+        row_pad[g] = (L + 15) & ~15;
+        row_trunc[g] = md == 2;
+        atomicMax(maxlen, L);
+    }
+}
+
+// one wavefront per row: window (or its first500+last500 form) from the packed genome
+__global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restrict__ bases,
+                                                         const uint32_t *__restrict__ nmask,
+                                                         const int64_t *__restrict__ coff, int32_t ncontig,
+                                                         int64_t nrows_total, const int32_t *__restrict__ row_copy,
+                                                         const uint8_t *__restrict__ row_trunc,
+                                                         const int32_t *__restrict__ contig,
+                                                         const int64_t *__restrict__ s1, const int64_t *__restrict__ e1,
+                                                         const uint8_t *__restrict__ minus, int32_t flank,
+                                                         const int64_t *__restrict__ win_off, uint8_t *__restrict__ win) {
+    int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= nrows_total) return;
+    int lane = threadIdx.x & 63;
+    int cp = row_copy[g];
+    int64_t len, tlen, g_lo;
+    window_rule(coff, ncontig, contig[cp], s1[cp], e1[cp], flank, len, tlen, g_lo);
+    if (len == 0) return;
+    bool mn = minus[cp] != 0;
+    uint8_t *dst = win + win_off[g];
+    if (row_trunc[g]) {
+        emit_span(bases, nmask, g_lo, len, mn, 0, 500, dst, lane);
+        emit_span(bases, nmask, g_lo, len, mn, len - 500, 500, dst + 500, lane);
+    } else {
+        emit_span(bases, nmask, g_lo, len, mn, 0, len, dst, lane);
+    }
+}
+
+__global__ void ops_count_kernel(int n, const int64_t *__restrict__ row_first, const int32_t *__restrict__ nrows,
+                                 const int32_t *__restrict__ row_len, int64_t *__restrict__ cnt) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    int R = nrows[c];
+    cnt[c] = R > 0 ? (int64_t)(R + 1) * (row_len[row_first[c]] + 1) : 0;
+}
+
+__global__ void msa_size_kernel(int n, const int32_t *__restrict__ nrows, const int32_t *__restrict__ cols,
+                                int64_t *__restrict__ bytes, int32_t *__restrict__ maxcols) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    int64_t b = (int64_t)nrows[c] * cols[c];
+    bytes[c] = (b + 15) & ~(int64_t)15;
+    atomicMax(maxcols, cols[c]);
+}
+
+// rows visible to sparse-col / judge: 0 rows where the alignment failed
+__global__ void eff_rows_kernel(int n, const int32_t *__restrict__ nrows, const int32_t *__restrict__ cols,
+                                int32_t *__restrict__ eff) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    eff[c] = cols[c] > 0 ? nrows[c] : 0;
+}
+
+// remove_sparse_col on a batch where some slots are empty
+extern "C" int hite_sparse_cols_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_msa, const int64_t *d_msa_off,
+                                    const int32_t *d_rows, const int32_t *d_cols, const int64_t *d_col_off,
+                                    int64_t total_cols, uint8_t *d_out, int32_t *d_new_cols, void *stream);
+
+// final record per candidate + length of the consensus to keep
+__global__ void merge_calls_kernel(int n, const int32_t *__restrict__ mode_a, const hite_call *__restrict__ ca,
+                                   const hite_call *__restrict__ cb, hite_call *__restrict__ out,
+                                   int32_t *__restrict__ src_pass, int64_t *__restrict__ keep_len) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    hite_call r;
+    r.is_te = 0; r.info = 0; r.row_num = 0; r.bstart = -1; r.bend = -1; r.cons_len = 0; r.cons_off = 0;
+    int src = 0;
+    if (mode_a[c] == 1) { r = ca[c]; src = 1; }
+    else if (mode_a[c] == 2) {
+        if (ca[c].is_te && cb) { r = cb[c]; src = 2; }
+        else { r = ca[c]; src = 1; }
+    }
+    if (!r.is_te) r.cons_len = 0;
+    out[c] = r;
+    src_pass[c] = r.is_te ? src : 0;
+    keep_len[c] = r.is_te ? r.cons_len : 0;
+}
+__global__ void __launch_bounds__(256) copy_cons_kernel(int n, hite_call *__restrict__ calls,
+                                                        const int32_t *__restrict__ src_pass,
+                                                        const uint8_t *__restrict__ cons_a,
+                                                        const uint8_t *__restrict__ cons_b,
+                                                        const int64_t *__restrict__ out_off, uint8_t *__restrict__ out,
+                                                        int64_t out_cap) {
+    int c = blockIdx.x;
+    if (c >= n) return;
+    int sp = src_pass[c];
+    if (!sp) { if (threadIdx.x == 0) calls[c].cons_off = out_off[c]; return; }
+    const uint8_t *src = (sp == 1 ? cons_a : cons_b) + calls[c].cons_off;
+    int L = calls[c].cons_len;
+    int64_t o = out_off[c];
+    if (o + L <= out_cap) for (int i = threadIdx.x; i < L; i += 256) out[o + i] = src[i];
+    __syncthreads();
+    if (threadIdx.x == 0) calls[c].cons_off = o;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one pass over all candidates with the given per-candidate mode
+// ---------------------------------------------------------------------------------------------
+struct PassOut {
+    hite_call *calls = nullptr;  // keep arena
+    uint8_t *cons = nullptr;     // keep arena
+};
+struct StageTimes;  // (events are recorded by bench.py around the whole call; per-kernel via rocprof)
+
+extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                                 const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows,
+                                 const int64_t *d_ops_base, int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out,
+                                 int32_t *d_status, void *stream);
+extern "C" int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                                      const int32_t *d_win_len, const int32_t *d_row_first, const int64_t *d_ops_base,
+                                      const int32_t *d_cols, const int64_t *d_msa_off, uint8_t *d_msa, void *stream);
+
+static int read_scalars(hite_ctx *ctx, PipeState *S, hipStream_t st, int count) {
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, sizeof(int64_t) * count, hipMemcpyDeviceToHost, st));
+    HITE_CHECK(ctx, hipStreamSynchronize(st));
+    return HITE_OK;
+}
+
+#define ACHK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, const uint8_t *d_cand,
+                    const int64_t *d_cand_off, const int32_t *d_copy_first, const int32_t *d_contig,
+                    const int64_t *d_s1, const int64_t *d_e1, const uint8_t *d_minus, int flank, const int64_t *d_len,
+                    const int32_t *d_mode, PassOut *out, int64_t *stats /* rows, win_bytes, msa_bytes, cells */,
+                    hipStream_t st) {
+    Arena &T = S->tmp, &K = S->keep;
+    int32_t *nrows, *sel, *row_first32, *row_copy, *row_len, *row_pad, *cols, *status, *eff, *new_cols;
+    int64_t *row_first, *win_off, *ops_cnt, *ops_base, *msa_bytes, *msa_off, *col_off, *col_off2;
+    uint8_t *row_trunc, *win, *msa, *clean;
+    void *p;
+    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); nrows = (int32_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)n * MAXROWS * 4, &p)); sel = (int32_t *)p;
+    hipLaunchKernelGGL(select_rows_kernel, dim3(n), dim3(256), 0, st, n, d_copy_first, d_len, d_mode, nrows, sel);
+    ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); row_first = (int64_t *)p;
+    ACHK(scan_excl<int32_t>(ctx, T, nrows, n, row_first, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, row_first + n, 8, hipMemcpyDeviceToDevice, st));
+    ACHK(read_scalars(ctx, S, st, 1));
+    const int64_t total_rows = S->h_pin[0];
+    stats[0] += total_rows;
+    ACHK(arena_alloc(ctx, K, sizeof(hite_call) * (size_t)n, &p)); out->calls = (hite_call *)p;
+    HITE_CHECK(ctx, hipMemsetAsync(out->calls, 0, sizeof(hite_call) * (size_t)n, st));
+    if (total_rows == 0) { ACHK(arena_alloc(ctx, K, 256, &p)); out->cons = (uint8_t *)p; return HITE_OK; }
+    if (total_rows > 0x7fffffff) return HITE_EINVAL;
+
+    ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 4, &p)); row_first32 = (int32_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)total_rows * 4, &p)); row_copy = (int32_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)total_rows * 4, &p)); row_len = (int32_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)total_rows * 4, &p)); row_pad = (int32_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)total_rows, &p)); row_trunc = (uint8_t *)p;
+    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    hipLaunchKernelGGL(row_meta_kernel, dim3(n), dim3(128), 0, st, n, row_first, nrows, sel, d_mode, d_len, row_first32,
+                       row_copy, row_len, row_pad, row_trunc, (int32_t *)(S->d_scal + 2));
+    ACHK(arena_alloc(ctx, T, (size_t)(total_rows + 1) * 8, &p)); win_off = (int64_t *)p;
+    ACHK(scan_excl<int32_t>(ctx, T, row_pad, total_rows, win_off, st));
+    ACHK(arena_alloc(ctx, T, (size_t)n * 8, &p)); ops_cnt = (int64_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); ops_base = (int64_t *)p;
+    hipLaunchKernelGGL(ops_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, row_first, nrows, row_len, ops_cnt);
+    ACHK(scan_excl<int64_t>(ctx, T, ops_cnt, n, ops_base, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, win_off + total_rows, 8, hipMemcpyDeviceToDevice, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, ops_base + n, 8, hipMemcpyDeviceToDevice, st));
+    ACHK(read_scalars(ctx, S, st, 3));
+    const int64_t win_bytes = S->h_pin[0], ops_elems = S->h_pin[1];
+    const int max_len = (int)(((int32_t *)(S->h_pin + 2))[0]);
+    stats[1] += win_bytes;
+
+    ACHK(arena_alloc(ctx, T, (size_t)win_bytes + 64, &p)); win = (uint8_t *)p;
+    hipLaunchKernelGGL(row_gather_kernel, dim3((unsigned)((total_rows + 3) / 4)), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask,
+                       ctx->d_contig_off, ctx->n_contigs, total_rows, row_copy, row_trunc, d_contig, d_s1, d_e1, d_minus,
+                       flank, win_off, win);
+    HITE_CHECK(ctx, hipGetLastError());
+
+    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); cols = (int32_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); status = (int32_t *)p;
+    ACHK(hite_star_msa_dev(ctx, n, win, win_off, row_len, row_first32, total_rows, ops_base, ops_elems, max_len > 0 ? max_len : 1,
+                           cols, status, st));
+    ACHK(arena_alloc(ctx, T, (size_t)n * 8, &p)); msa_bytes = (int64_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); msa_off = (int64_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); col_off = (int64_t *)p;
+    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    hipLaunchKernelGGL(msa_size_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nrows, cols, msa_bytes, (int32_t *)(S->d_scal + 2));
+    ACHK(scan_excl<int64_t>(ctx, T, msa_bytes, n, msa_off, st));
+    ACHK(scan_excl<int32_t>(ctx, T, cols, n, col_off, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, msa_off + n, 8, hipMemcpyDeviceToDevice, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, col_off + n, 8, hipMemcpyDeviceToDevice, st));
+    ACHK(read_scalars(ctx, S, st, 3));
+    const int64_t msa_total = S->h_pin[0], total_cols = S->h_pin[1];
+    stats[2] += msa_total;
+    ACHK(arena_alloc(ctx, T, (size_t)msa_total + 64, &p)); msa = (uint8_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)msa_total + 64, &p)); clean = (uint8_t *)p;
+    ACHK(hite_star_msa_fill_dev(ctx, n, win, win_off, row_len, row_first32, ops_base, cols, msa_off, msa, st));
+    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); eff = (int32_t *)p;
+    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); new_cols = (int32_t *)p;
+    hipLaunchKernelGGL(eff_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nrows, cols, eff);
+    ACHK(hite_sparse_cols_dev(ctx, n, msa, msa_off, eff, cols, col_off, total_cols, clean, new_cols, st));
+    ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); col_off2 = (int64_t *)p;
+    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    ACHK(scan_excl<int32_t>(ctx, T, new_cols, n, col_off2, st));
+    hipLaunchKernelGGL(msa_size_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, eff, new_cols, msa_bytes, (int32_t *)(S->d_scal + 2));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, col_off2 + n, 8, hipMemcpyDeviceToDevice, st));
+    ACHK(read_scalars(ctx, S, st, 3));
+    const int64_t total_cols2 = S->h_pin[0];
+    const int max_cols2 = (int)(((int32_t *)(S->h_pin + 2))[0]);
+    ACHK(arena_alloc(ctx, K, (size_t)total_cols2 + 8 * (size_t)n + 64, &p)); out->cons = (uint8_t *)p;
+    if (max_cols2 > 0)
+        ACHK(hite_judge_dev(ctx, te_type, plant, n, clean, msa_off, eff, new_cols, d_cand, d_cand_off, col_off2, max_cols2,
+                            MAXROWS + 1, out->calls, out->cons, st));
+    return HITE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// public entry: the fine stage for one batch of candidates
+// ---------------------------------------------------------------------------------------------
+extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32_t te_type, int32_t plant, int32_t n_cand,
+                                           const uint8_t *d_cand, const int64_t *d_cand_off, const int32_t *d_copy_first,
+                                           int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1,
+                                           const int64_t *d_end1, const uint8_t *d_minus, int32_t flank, hite_call *d_calls,
+                                           uint8_t *d_cons, int64_t cons_cap, int64_t *stats_out /* 8 x int64, host, may be NULL */,
+                                           void *stream) {
+    if (!ctx || !ctx->d_bases || !state_io || n_cand < 0 || n_copies < 0 || te_type < 0 || te_type > 2) return HITE_EINVAL;
+    if (n_cand == 0) return HITE_OK;
+    hipStream_t st = (hipStream_t)stream;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    PipeState *S = (PipeState *)*state_io;
+    if (!S) {
+        S = new PipeState();
+        HITE_CHECK(ctx, hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)));
+        HITE_CHECK(ctx, hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)));
+        *state_io = S;
+    }
+    ACHK(arena_reset(ctx, S->keep, true));
+    ACHK(arena_reset(ctx, S->tmp, true));
+    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void *p;
+    int64_t *len;
+    int32_t *mode_a, *mode_b, *src_pass;
+    int64_t *keep_len, *out_off;
+    ACHK(arena_alloc(ctx, S->keep, (size_t)(n_copies + 1) * 8, &p)); len = (int64_t *)p;
+    ACHK(arena_alloc(ctx, S->keep, (size_t)n_cand * 4, &p)); mode_a = (int32_t *)p;
+    ACHK(arena_alloc(ctx, S->keep, (size_t)n_cand * 4, &p)); mode_b = (int32_t *)p;
+    ACHK(arena_alloc(ctx, S->keep, (size_t)n_cand * 4, &p)); src_pass = (int32_t *)p;
+    ACHK(arena_alloc(ctx, S->keep, (size_t)n_cand * 8, &p)); keep_len = (int64_t *)p;
+    ACHK(arena_alloc(ctx, S->keep, (size_t)(n_cand + 1) * 8, &p)); out_off = (int64_t *)p;
+    if (n_copies > 0)
+        hipLaunchKernelGGL(flank_sizes_kernel, dim3((unsigned)((n_copies + 255) / 256)), dim3(256), 0, st, ctx->d_contig_off,
+                           ctx->n_contigs, n_copies, d_contig, d_start1, d_end1, flank, len, (int64_t *)nullptr);
+    hipLaunchKernelGGL(mode_a_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, d_copy_first, len, mode_a);
+    HITE_CHECK(ctx, hipGetLastError());
+    PassOut A, B;
+    ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, flank,
+                  len, mode_a, &A, stats, st));
+    ACHK(arena_reset(ctx, S->tmp, false));
+    hipLaunchKernelGGL(mode_b_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, mode_a, A.calls, mode_b);
+    ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, flank,
+                  len, mode_b, &B, stats + 4, st));
+    hipLaunchKernelGGL(merge_calls_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, mode_a, A.calls, B.calls, d_calls,
+                       src_pass, keep_len);
+    ACHK(scan_excl<int64_t>(ctx, S->tmp, keep_len, n_cand, out_off, st));
+    hipLaunchKernelGGL(copy_cons_kernel, dim3(n_cand), dim3(256), 0, st, n_cand, d_calls, src_pass, A.cons, B.cons, out_off, d_cons,
+                       cons_cap);
+    HITE_CHECK(ctx, hipGetLastError());
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, out_off + n_cand, 8, hipMemcpyDeviceToDevice, st));
+    ACHK(read_scalars(ctx, S, st, 1));
+    if (stats_out) { memcpy(stats_out, stats, sizeof stats); stats_out[3] = S->h_pin[0]; }
+    if (S->h_pin[0] > cons_cap) return HITE_ECAP;
+    return HITE_OK;
+}
+
+// host-buffer wrapper (numpy callers / the drop-in scripts): uploads, runs, downloads
+struct PBuf {
+    void *p = nullptr;
+    ~PBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    hipError_t up(const void *h, size_t n) {
+        hipError_t e = alloc(n + 16);
+        if (e != hipSuccess) return e;
+        return n ? hipMemcpy(p, h, n, hipMemcpyHostToDevice) : hipSuccess;
+    }
+};
+__global__ void fold_bytes_kernel(uint8_t *__restrict__ p, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = fold_sym(p[i]);
+}
+
+extern "C" int hite_flank_region_align(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
+                                       const int64_t *cand_off, const int32_t *copy_first, int64_t n_copies,
+                                       const int32_t *contig, const int64_t *start1, const int64_t *end1,
+                                       const uint8_t *minus, int32_t flank, hite_call *calls, uint8_t *cons, int64_t cons_cap,
+                                       int64_t *stats_out) {
+    if (!ctx || n_cand < 0 || !cand || !cand_off || !copy_first || !calls || !cons) return HITE_EINVAL;
+    if (n_cand == 0) return HITE_OK;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    PBuf dc, dco, dcf, dct, ds, de, dm, dcalls, dcons;
+    hipError_t e;
+    e = dc.up(cand, cand_off[n_cand]); if (e == hipSuccess) e = dco.up(cand_off, (n_cand + 1) * 8);
+    if (e == hipSuccess) e = dcf.up(copy_first, (n_cand + 1) * 4); if (e == hipSuccess) e = dct.up(contig, n_copies * 4);
+    if (e == hipSuccess) e = ds.up(start1, n_copies * 8); if (e == hipSuccess) e = de.up(end1, n_copies * 8);
+    if (e == hipSuccess) e = dm.up(minus, n_copies); if (e == hipSuccess) e = dcalls.alloc(sizeof(hite_call) * n_cand);
+    if (e == hipSuccess) e = dcons.alloc(cons_cap + 16);
+    HITE_CHECK(ctx, e);
+    hipLaunchKernelGGL(fold_bytes_kernel, dim3(256), dim3(256), 0, nullptr, (uint8_t *)dc.p, cand_off[n_cand]);
+    void *state = nullptr;
+    int rc = hite_flank_region_align_dev(ctx, &state, te_type, plant, n_cand, (uint8_t *)dc.p, (int64_t *)dco.p, (int32_t *)dcf.p,
+                                         n_copies, (int32_t *)dct.p, (int64_t *)ds.p, (int64_t *)de.p, (uint8_t *)dm.p, flank,
+                                         (hite_call *)dcalls.p, (uint8_t *)dcons.p, cons_cap, stats_out, nullptr);
+    hipError_t es = hipDeviceSynchronize();
+    if (rc == HITE_OK || rc == HITE_ECAP) {
+        if (es == hipSuccess) es = hipMemcpy(calls, dcalls.p, sizeof(hite_call) * n_cand, hipMemcpyDeviceToHost);
+        if (es == hipSuccess && rc == HITE_OK) es = hipMemcpy(cons, dcons.p, cons_cap, hipMemcpyDeviceToHost);
+    }
+    hite_pipeline_release(state);
+    if (es != hipSuccess) return HITE_EHIP;
+    return rc;
+}

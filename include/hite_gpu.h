@@ -138,17 +138,39 @@ int hite_tsd_search(hite_ctx *ctx, int32_t n, const uint8_t *rows_bytes, const i
  * the first row of each candidate is the centre.  Window length <= 32767.
  * hite_star_msa: pass msa_out = NULL to get cols_out only; otherwise the rows x cols matrices are
  * written at msa_off_out[c] (16-byte aligned slots) and msa_cap is checked.
- * _dev: d_ops_base[n+1] = exclusive scan of (R_c + 1) * (m_c + 1) (m_c = centre length),
+ * _dev: window g starts at d_win_off[g] and is d_win_len[g] long; d_ops_base[n+1] = exclusive scan of (R_c + 1) * (m_c + 1) (m_c = centre length),
  * ops_elems its last element; d_status[c] != 0 marks a candidate whose alignment failed
  * (cols_out[c] = 0).  The fill call must follow the align call on the same ctx/stream. */
 int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
                   int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out, int64_t *msa_off_out);
 int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
-                      const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base, int64_t ops_elems,
+                      const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base, int64_t ops_elems,
                       int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status, void *stream);
 int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
-                           const int32_t *d_row_first, const int64_t *d_ops_base, const int32_t *d_cols,
+                           const int32_t *d_win_len, const int32_t *d_row_first, const int64_t *d_ops_base, const int32_t *d_cols,
                            const int64_t *d_msa_off, uint8_t *d_msa, void *stream);
+
+/* ---- the fine stage in one call --- body of flank_region_align_v5 from the copy table on ----------
+ * (Util.py:8095-8194 + run_find_members_v8 :10439 + is_TE_from_align_file :10407).
+ * Candidates: cand/cand_off CSR (cur_seq of each candidate).  Copies of candidate c are entries
+ * copy_first[c] .. copy_first[c+1]-1 of (contig, start1, end1, minus) -- what
+ * get_full_length_copies_minimap2 (:7933) returns, 1-based inclusive.  Needs a packed genome.
+ * calls[c] = the tuple is_TE_from_align_file returns for candidate c; consensus bytes are packed
+ * into cons (cons_off/cons_len in the record); HITE_ECAP if cons_cap is too small.
+ * stats_out (8 x int64, host, optional): pass A rows, window bytes, matrix bytes, cons bytes,
+ * pass B rows, window bytes, matrix bytes, 0.
+ * _dev: all pointers are device pointers; *state_io (initially NULL) keeps the arenas between
+ * calls so the steady state performs no allocation; free it with hite_pipeline_release. */
+int hite_flank_region_align(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
+                            const int64_t *cand_off, const int32_t *copy_first, int64_t n_copies, const int32_t *contig,
+                            const int64_t *start1, const int64_t *end1, const uint8_t *minus, int32_t flank,
+                            hite_call *calls, uint8_t *cons, int64_t cons_cap, int64_t *stats_out);
+int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32_t te_type, int32_t plant, int32_t n_cand,
+                                const uint8_t *d_cand, const int64_t *d_cand_off, const int32_t *d_copy_first,
+                                int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1, const int64_t *d_end1,
+                                const uint8_t *d_minus, int32_t flank, hite_call *d_calls, uint8_t *d_cons,
+                                int64_t cons_cap, int64_t *stats_out, void *stream);
+void hite_pipeline_release(void *state);
 
 /* ---- timing helper: HIP-event elapsed ms around work already enqueued on `stream` ---------- */
 int hite_event_create(void **ev);

@@ -210,3 +210,26 @@ def test_star_msa_to_judge_chain(ctx):
         keep = O.sparse_cols(m).astype(bool)
         exp, _ = O.judge("tir", np.ascontiguousarray(m[:, keep]), cand, 1)
         assert [res[0], res[1], res[2], res[3]] == exp
+
+
+def _synthetic_fine_inputs(seed, n_fam=14, te_types=("tir",)):
+    """small genome with planted TE families + the copy table a copy finder would return"""
+    import synth_small
+
+    return synth_small.make(seed, n_fam)
+
+
+def test_fine_stage_vs_oracle_chain(ctx):
+    import oracle_pipeline as OP
+    import synth_small
+
+    g = synth_small.make(11, n_fam=16)
+    ctx.genome_pack(g["contigs"])
+    got, stats = ctx.flank_region_align("tir", g["cands"], g["copies"], plant=1)
+    n_te = 0
+    for cand, copies, res in zip(g["cands"], g["copies"], got):
+        exp = OP.fine_stage_candidate("tir", cand, copies, g["contigs"], plant=1)
+        assert [res[0], res[1], res[2], res[3]] == exp, (res, exp)
+        n_te += res[0]
+    assert n_te >= 4
+    assert stats[0] > 0 and stats[4] > 0  # both the truncated-first and the full pass ran
