@@ -64,6 +64,9 @@ class Context:
         self.device = device
 
     def close(self):
+        if getattr(self, "_pipe_state", None) is not None and getattr(self, "h", None):
+            self.lib.hite_pipeline_release(self._pipe_state)
+            self._pipe_state = C.c_void_p(None)
         if getattr(self, "h", None):
             self.lib.hite_ctx_destroy(self.h)
             self.h = None
@@ -248,7 +251,7 @@ class Context:
         calls = np.zeros(n, dtype=CALL_DTYPE)
         cap = int(coff[-1]) + (2 * flank + 64) * n + 4096
         cons = np.zeros(cap + 16, dtype=np.uint8)
-        stats = np.zeros(8, dtype=np.int64)
+        stats = np.zeros(12, dtype=np.int64)
         self._check(self.lib.hite_flank_region_align(self.h, HITE_TE[te_type], int(plant), n, _p(cbuf), _p(coff), _p(cf),
                                                      C.c_int64(len(flat)), _p(contig), _p(s1), _p(e1), _p(mn), int(flank),
                                                      _p(calls), _p(cons), C.c_int64(cap), _p(stats)), "hite_flank_region_align")
@@ -258,3 +261,32 @@ class Context:
             s = cons[c["cons_off"]:c["cons_off"] + c["cons_len"]].tobytes().decode() if c["is_te"] else ""
             out.append((bool(c["is_te"]), INFO[int(c["info"])], s, int(c["row_num"]), int(c["bstart"]), int(c["bend"])))
         return out, stats
+
+    # device-resident variant: every argument is a raw device pointer (e.g. torch tensor .data_ptr())
+    def flank_region_align_dev(self, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, n_copies, d_contig, d_start1,
+                               d_end1, d_minus, flank, d_calls, d_cons, cons_cap, stream=0):
+        if not hasattr(self, "_pipe_state"):
+            self._pipe_state = C.c_void_p(None)
+        stats = np.zeros(12, dtype=np.int64)
+        v = C.c_void_p
+        rc = self.lib.hite_flank_region_align_dev(self.h, C.byref(self._pipe_state), HITE_TE[te_type], int(plant), int(n_cand),
+                                                  v(d_cand), v(d_cand_off), v(d_copy_first), C.c_int64(n_copies), v(d_contig),
+                                                  v(d_start1), v(d_end1), v(d_minus), int(flank), v(d_calls), v(d_cons),
+                                                  C.c_int64(cons_cap), _p(stats), v(stream))
+        self._check(rc, "hite_flank_region_align_dev")
+        return stats
+
+    def profile(self, on=None, reset=False):
+        """per-stage HIP-event timings recorded by the library on its launch stream"""
+        if reset:
+            self.lib.hite_profile_reset(self.h)
+        if on is not None:
+            self.lib.hite_profile_enable(self.h, 1 if on else 0)
+        out = {}
+        name = C.create_string_buffer(32)
+        ms = C.c_double(0)
+        cnt = C.c_int64(0)
+        for i in range(self.lib.hite_profile_count(self.h)):
+            if self.lib.hite_profile_get(self.h, i, name, C.byref(ms), C.byref(cnt)) == 0:
+                out[name.value.decode()] = (ms.value, cnt.value)
+        return out

@@ -25,7 +25,21 @@ struct hite_ctx {
     size_t scratch_bytes;
     void *d_scratch2;
     size_t scratch2_bytes;
+    // optional per-stage HIP-event profiling (hite_profile_*)
+    int prof_on;
+    int prof_n;                 // stages seen
+    char prof_name[32][32];
+    double prof_ms[32];
+    int64_t prof_count[32];
+    int prof_pending;           // event pairs recorded and not yet resolved
+    void *prof_ev[512][2];
+    int prof_stage[512];
 };
+
+// record the time of everything enqueued on `st` between begin and end as stage `name`
+int hite_prof_begin(hite_ctx *ctx, const char *name, hipStream_t st);
+void hite_prof_end(hite_ctx *ctx, int token, hipStream_t st);
+void hite_prof_resolve(hite_ctx *ctx);
 
 #define HITE_CHECK(ctx, call)                                                                         \
     do {                                                                                              \

@@ -306,3 +306,74 @@ extern "C" int hite_event_elapsed_ms(void *a, void *b, float *ms) {
 extern "C" int hite_event_destroy(void *ev) {
     return hipEventDestroy((hipEvent_t)ev) == hipSuccess ? HITE_OK : HITE_EHIP;
 }
+
+// ---------------------------------------------------------------------------------------------
+// per-stage profiling with HIP events on the launch stream (bench.py reads these live)
+// ---------------------------------------------------------------------------------------------
+int hite_prof_begin(hite_ctx *ctx, const char *name, hipStream_t st) {
+    if (!ctx || !ctx->prof_on) return -1;
+    if (ctx->prof_pending >= 512) hite_prof_resolve(ctx);
+    int sidx = -1;
+    for (int i = 0; i < ctx->prof_n; i++) if (strcmp(ctx->prof_name[i], name) == 0) { sidx = i; break; }
+    if (sidx < 0) {
+        if (ctx->prof_n >= 32) return -1;
+        sidx = ctx->prof_n++;
+        strncpy(ctx->prof_name[sidx], name, 31);
+        ctx->prof_name[sidx][31] = 0;
+        ctx->prof_ms[sidx] = 0.0;
+        ctx->prof_count[sidx] = 0;
+    }
+    int t = ctx->prof_pending;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess) return -1;
+    if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return -1; }
+    ctx->prof_ev[t][0] = (void *)a;
+    ctx->prof_ev[t][1] = (void *)b;
+    ctx->prof_stage[t] = sidx;
+    ctx->prof_pending++;
+    (void)hipEventRecord(a, st);
+    return t;
+}
+void hite_prof_end(hite_ctx *ctx, int token, hipStream_t st) {
+    if (!ctx || token < 0) return;
+    (void)hipEventRecord((hipEvent_t)ctx->prof_ev[token][1], st);
+}
+void hite_prof_resolve(hite_ctx *ctx) {
+    if (!ctx) return;
+    for (int t = 0; t < ctx->prof_pending; t++) {
+        hipEvent_t a = (hipEvent_t)ctx->prof_ev[t][0], b = (hipEvent_t)ctx->prof_ev[t][1];
+        float ms = 0.f;
+        if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess) {
+            ctx->prof_ms[ctx->prof_stage[t]] += ms;
+            ctx->prof_count[ctx->prof_stage[t]] += 1;
+        }
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
+    ctx->prof_pending = 0;
+}
+extern "C" int hite_profile_enable(hite_ctx *ctx, int on) {
+    if (!ctx) return HITE_EINVAL;
+    hite_prof_resolve(ctx);
+    ctx->prof_on = on;
+    return HITE_OK;
+}
+extern "C" int hite_profile_reset(hite_ctx *ctx) {
+    if (!ctx) return HITE_EINVAL;
+    hite_prof_resolve(ctx);
+    ctx->prof_n = 0;
+    return HITE_OK;
+}
+extern "C" int hite_profile_count(hite_ctx *ctx) {
+    if (!ctx) return 0;
+    hite_prof_resolve(ctx);
+    return ctx->prof_n;
+}
+extern "C" int hite_profile_get(hite_ctx *ctx, int idx, char *name_out /* >= 32 */, double *ms_total, int64_t *launches) {
+    if (!ctx || idx < 0 || idx >= ctx->prof_n) return HITE_EINVAL;
+    hite_prof_resolve(ctx);
+    strncpy(name_out, ctx->prof_name[idx], 32);
+    *ms_total = ctx->prof_ms[idx];
+    *launches = ctx->prof_count[idx];
+    return HITE_OK;
+}

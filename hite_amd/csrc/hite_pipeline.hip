@@ -270,12 +270,25 @@ __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restr
     }
 }
 
+// also accumulates the alignment stage's algorithmic bytes (windows read per pair + ops written) and
+// its anti-diagonal steps (x64 = DP cells) into acc[0], acc[1]
 __global__ void ops_count_kernel(int n, const int64_t *__restrict__ row_first, const int32_t *__restrict__ nrows,
-                                 const int32_t *__restrict__ row_len, int64_t *__restrict__ cnt) {
+                                 const int32_t *__restrict__ row_len, int64_t *__restrict__ cnt,
+                                 unsigned long long *__restrict__ acc) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
     int R = nrows[c];
-    cnt[c] = R > 0 ? (int64_t)(R + 1) * (row_len[row_first[c]] + 1) : 0;
+    if (R <= 0) { cnt[c] = 0; return; }
+    int64_t g0 = row_first[c];
+    int64_t m = row_len[g0];
+    cnt[c] = (int64_t)(R + 1) * (m + 1);
+    unsigned long long bytes = 0, steps = 0;
+    for (int r = 1; r < R; r++) {
+        int64_t nn = row_len[g0 + r];
+        bytes += (unsigned long long)(m + nn + 2 * (m + 1));
+        steps += (unsigned long long)(m + nn);
+    }
+    if (bytes) { atomicAdd(&acc[0], bytes); atomicAdd(&acc[1], steps); }
 }
 
 __global__ void msa_size_kernel(int n, const int32_t *__restrict__ nrows, const int32_t *__restrict__ cols,
@@ -365,8 +378,8 @@ static int read_scalars(hite_ctx *ctx, PipeState *S, hipStream_t st, int count) 
 static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, const uint8_t *d_cand,
                     const int64_t *d_cand_off, const int32_t *d_copy_first, const int32_t *d_contig,
                     const int64_t *d_s1, const int64_t *d_e1, const uint8_t *d_minus, int flank, const int64_t *d_len,
-                    const int32_t *d_mode, PassOut *out, int64_t *stats /* rows, win_bytes, msa_bytes, cells */,
-                    hipStream_t st) {
+                    const int32_t *d_mode, PassOut *out, int64_t *stats /* rows, win_bytes, msa_bytes, align_bytes */,
+                    int64_t *extra /* steps */, hipStream_t st) {
     Arena &T = S->tmp, &K = S->keep;
     int32_t *nrows, *sel, *row_first32, *row_copy, *row_len, *row_pad, *cols, *status, *eff, *new_cols;
     int64_t *row_first, *win_off, *ops_cnt, *ops_base, *msa_bytes, *msa_off, *col_off, *col_off2;
@@ -374,7 +387,9 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     void *p;
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); nrows = (int32_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)n * MAXROWS * 4, &p)); sel = (int32_t *)p;
+    int tk = hite_prof_begin(ctx, "select_rows_kernel", st);
     hipLaunchKernelGGL(select_rows_kernel, dim3(n), dim3(256), 0, st, n, d_copy_first, d_len, d_mode, nrows, sel);
+    hite_prof_end(ctx, tk, st);
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); row_first = (int64_t *)p;
     ACHK(scan_excl<int32_t>(ctx, T, nrows, n, row_first, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, row_first + n, 8, hipMemcpyDeviceToDevice, st));
@@ -398,19 +413,24 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     ACHK(scan_excl<int32_t>(ctx, T, row_pad, total_rows, win_off, st));
     ACHK(arena_alloc(ctx, T, (size_t)n * 8, &p)); ops_cnt = (int64_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); ops_base = (int64_t *)p;
-    hipLaunchKernelGGL(ops_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, row_first, nrows, row_len, ops_cnt);
+    hipLaunchKernelGGL(ops_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, row_first, nrows, row_len, ops_cnt,
+                       (unsigned long long *)(S->d_scal + 4));
     ACHK(scan_excl<int64_t>(ctx, T, ops_cnt, n, ops_base, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, win_off + total_rows, 8, hipMemcpyDeviceToDevice, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, ops_base + n, 8, hipMemcpyDeviceToDevice, st));
-    ACHK(read_scalars(ctx, S, st, 3));
+    ACHK(read_scalars(ctx, S, st, 6));
     const int64_t win_bytes = S->h_pin[0], ops_elems = S->h_pin[1];
     const int max_len = (int)(((int32_t *)(S->h_pin + 2))[0]);
     stats[1] += win_bytes;
+    stats[3] += S->h_pin[4];  // alignment algorithmic bytes
+    extra[0] += S->h_pin[5];  // anti-diagonal steps
 
     ACHK(arena_alloc(ctx, T, (size_t)win_bytes + 64, &p)); win = (uint8_t *)p;
+    tk = hite_prof_begin(ctx, "row_gather_kernel", st);
     hipLaunchKernelGGL(row_gather_kernel, dim3((unsigned)((total_rows + 3) / 4)), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask,
                        ctx->d_contig_off, ctx->n_contigs, total_rows, row_copy, row_trunc, d_contig, d_s1, d_e1, d_minus,
                        flank, win_off, win);
+    hite_prof_end(ctx, tk, st);
     HITE_CHECK(ctx, hipGetLastError());
 
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); cols = (int32_t *)p;
@@ -431,11 +451,15 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     stats[2] += msa_total;
     ACHK(arena_alloc(ctx, T, (size_t)msa_total + 64, &p)); msa = (uint8_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)msa_total + 64, &p)); clean = (uint8_t *)p;
+    tk = hite_prof_begin(ctx, "star_fill_kernel", st);
     ACHK(hite_star_msa_fill_dev(ctx, n, win, win_off, row_len, row_first32, ops_base, cols, msa_off, msa, st));
+    hite_prof_end(ctx, tk, st);
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); eff = (int32_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); new_cols = (int32_t *)p;
     hipLaunchKernelGGL(eff_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nrows, cols, eff);
+    tk = hite_prof_begin(ctx, "sparse_cols_kernel", st);
     ACHK(hite_sparse_cols_dev(ctx, n, msa, msa_off, eff, cols, col_off, total_cols, clean, new_cols, st));
+    hite_prof_end(ctx, tk, st);
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); col_off2 = (int64_t *)p;
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
     ACHK(scan_excl<int32_t>(ctx, T, new_cols, n, col_off2, st));
@@ -445,9 +469,11 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     const int64_t total_cols2 = S->h_pin[0];
     const int max_cols2 = (int)(((int32_t *)(S->h_pin + 2))[0]);
     ACHK(arena_alloc(ctx, K, (size_t)total_cols2 + 8 * (size_t)n + 64, &p)); out->cons = (uint8_t *)p;
+    tk = hite_prof_begin(ctx, "judge_kernel", st);
     if (max_cols2 > 0)
         ACHK(hite_judge_dev(ctx, te_type, plant, n, clean, msa_off, eff, new_cols, d_cand, d_cand_off, col_off2, max_cols2,
                             MAXROWS + 1, out->calls, out->cons, st));
+    hite_prof_end(ctx, tk, st);
     return HITE_OK;
 }
 
@@ -458,7 +484,7 @@ extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32
                                            const uint8_t *d_cand, const int64_t *d_cand_off, const int32_t *d_copy_first,
                                            int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1,
                                            const int64_t *d_end1, const uint8_t *d_minus, int32_t flank, hite_call *d_calls,
-                                           uint8_t *d_cons, int64_t cons_cap, int64_t *stats_out /* 8 x int64, host, may be NULL */,
+                                           uint8_t *d_cons, int64_t cons_cap, int64_t *stats_out /* 12 x int64, host, may be NULL */,
                                            void *stream) {
     if (!ctx || !ctx->d_bases || !state_io || n_cand < 0 || n_copies < 0 || te_type < 0 || te_type > 2) return HITE_EINVAL;
     if (n_cand == 0) return HITE_OK;
@@ -473,7 +499,7 @@ extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32
     }
     ACHK(arena_reset(ctx, S->keep, true));
     ACHK(arena_reset(ctx, S->tmp, true));
-    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t stats[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     void *p;
     int64_t *len;
     int32_t *mode_a, *mode_b, *src_pass;
@@ -491,11 +517,11 @@ extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32
     HITE_CHECK(ctx, hipGetLastError());
     PassOut A, B;
     ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, flank,
-                  len, mode_a, &A, stats, st));
+                  len, mode_a, &A, stats, stats + 8, st));
     ACHK(arena_reset(ctx, S->tmp, false));
     hipLaunchKernelGGL(mode_b_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, mode_a, A.calls, mode_b);
     ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, flank,
-                  len, mode_b, &B, stats + 4, st));
+                  len, mode_b, &B, stats + 4, stats + 9, st));
     hipLaunchKernelGGL(merge_calls_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, mode_a, A.calls, B.calls, d_calls,
                        src_pass, keep_len);
     ACHK(scan_excl<int64_t>(ctx, S->tmp, keep_len, n_cand, out_off, st));
@@ -504,7 +530,7 @@ extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32
     HITE_CHECK(ctx, hipGetLastError());
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, out_off + n_cand, 8, hipMemcpyDeviceToDevice, st));
     ACHK(read_scalars(ctx, S, st, 1));
-    if (stats_out) { memcpy(stats_out, stats, sizeof stats); stats_out[3] = S->h_pin[0]; }
+    if (stats_out) { memcpy(stats_out, stats, sizeof stats); stats_out[10] = S->h_pin[0]; }
     if (S->h_pin[0] > cons_cap) return HITE_ECAP;
     return HITE_OK;
 }

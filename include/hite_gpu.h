@@ -157,8 +157,9 @@ int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
  * get_full_length_copies_minimap2 (:7933) returns, 1-based inclusive.  Needs a packed genome.
  * calls[c] = the tuple is_TE_from_align_file returns for candidate c; consensus bytes are packed
  * into cons (cons_off/cons_len in the record); HITE_ECAP if cons_cap is too small.
- * stats_out (8 x int64, host, optional): pass A rows, window bytes, matrix bytes, cons bytes,
- * pass B rows, window bytes, matrix bytes, 0.
+ * stats_out (12 x int64, host, optional): [0..3] pass A rows, window bytes, matrix bytes, alignment
+ * algorithmic bytes; [4..7] the same for pass B; [8],[9] anti-diagonal steps of pass A / B (x64 = DP
+ * cells); [10] consensus bytes kept; [11] 0.
  * _dev: all pointers are device pointers; *state_io (initially NULL) keeps the arenas between
  * calls so the steady state performs no allocation; free it with hite_pipeline_release. */
 int hite_flank_region_align(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
@@ -171,6 +172,13 @@ int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32_t te_type,
                                 const uint8_t *d_minus, int32_t flank, hite_call *d_calls, uint8_t *d_cons,
                                 int64_t cons_cap, int64_t *stats_out, void *stream);
 void hite_pipeline_release(void *state);
+
+/* ---- per-stage profiling: HIP events recorded on the launch stream around each kernel of the
+ * pipeline (stage names = kernel names).  ms_total / launches accumulate since the last reset. */
+int hite_profile_enable(hite_ctx *ctx, int on);
+int hite_profile_reset(hite_ctx *ctx);
+int hite_profile_count(hite_ctx *ctx);
+int hite_profile_get(hite_ctx *ctx, int idx, char *name_out, double *ms_total, int64_t *launches);
 
 /* ---- timing helper: HIP-event elapsed ms around work already enqueued on `stream` ---------- */
 int hite_event_create(void **ev);
