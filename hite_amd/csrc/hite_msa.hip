@@ -48,12 +48,31 @@ __device__ __forceinline__ int find_cand(const int32_t *__restrict__ row_first, 
     return lo;
 }
 
+// cross-lane helpers (wave64).  wave_shl:1 -> lane i reads lane i+1, wave_shr:1 -> lane i reads lane i-1;
+// lanes without a source keep `fill`.
+__device__ __forceinline__ int from_next_lane(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
+__device__ __forceinline__ int from_prev_lane(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
+    unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
+    unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// One wavefront per (row, centre) pair.
+//  forward : lane k owns cell i = t + k of anti-diagonal s.  Per step: one DPP shift of `prev`, at most one
+//            of `pprev`, one DPP shift of the resident base register (the band moved down -> centre bases
+//            slide, moved right -> row bases slide) with the single new base taken from a 64-base chunk
+//            register by v_readlane; no LDS, no per-step memory load.  The 2-bit directions of 64
+//            consecutive anti-diagonals are parked one step per lane and stored as one coalesced 1 KiB write.
+//  backward: the same 1 KiB chunks are re-loaded one per 64 steps, the walk itself is scalar
+//            (v_readlane + bit tests); results leave as coalesced 128-B chunks of u16
+//            (row position aligned to centre position p | gap flag << 15).
 __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
     const int lane = threadIdx.x & 63;
     const int wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
     uint8_t *slot = P.tb + (size_t)wslot * P.tb_slot;
-    ulonglong2 *tbd = reinterpret_cast<ulonglong2 *>(slot);                          // [max_steps + 1]
-    unsigned long long *tbm = reinterpret_cast<unsigned long long *>(slot + (size_t)(P.max_steps + 1) * 16);  // move bits
+    ulonglong2 *tbd = reinterpret_cast<ulonglong2 *>(slot);                                              // [max_steps + 64]
+    unsigned long long *tbm = reinterpret_cast<unsigned long long *>(slot + (size_t)(P.max_steps + 64) * 16);  // move bits
     for (;;) {
         unsigned int gq = 0;
         if (lane == 0) gq = atomicAdd(P.counter, 1u);
@@ -71,10 +90,19 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         const int steps = m + n;
         if (m <= 0 || n <= 0 || steps > P.max_steps) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
 
-        // ---------------- forward: anti-diagonal adaptive band ----------------
+        // ---------------- forward ----------------
         int t = -32, tp = -32;  // origins of anti-diagonals s-1 and s-2
         int prev = lane == 32 ? 0 : MNEG, pprev = MNEG;
-        unsigned long long mvbits = 0;
+        // resident bases for anti-diagonal s-1: areg = a[i-1], breg = b[j-1] with i = t + lane, j = (s-1) - i
+        int areg, breg;
+        {
+            int ia = t + lane - 1, jb = -(t + lane) - 1;
+            areg = (ia >= 0 && ia < m) ? a[ia] : 0xFF;
+            breg = (jb >= 0 && jb < n) ? b[jb] : 0xFE;
+        }
+        int abase = -64, bbase = -64;  // chunk registers: achunk = a[abase + lane], bchunk = b[bbase + lane]
+        int achunk = 0xFF, bchunk = 0xFE;
+        unsigned long long mvbits = 0, r0 = 0, r1 = 0;
         for (int s = 1; s <= steps; s++) {
             int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);
             int move = h0 > h63 ? 0 : (h0 < h63 ? 1 : ((((s - 1) & 1) == 0) ? 1 : 0));
@@ -83,19 +111,32 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             if (tn > hi - 31) tn = t;
             if (tn < lo - 32) tn = t + 1;
             const int dt1 = tn - t, dt2 = tn - tp;
+            int hu, hl, hd;
+            if (dt1) {  // moved down: centre bases slide towards lane 0
+                hl = from_next_lane(prev, MNEG); hu = prev;
+                int ai = tn + 63 - 1;  // base needed by lane 63: a[i-1], i = tn + 63
+                int nv = 0xFF;
+                if (ai >= 0 && ai < m) {
+                    if ((ai & ~63) != abase) { abase = ai & ~63; achunk = (abase + lane < m) ? a[abase + lane] : 0xFF; }
+                    nv = __builtin_amdgcn_readlane(achunk, ai & 63);
+                }
+                areg = from_next_lane(areg, nv);
+            } else {    // moved right: row bases slide towards lane 63
+                hl = prev; hu = from_prev_lane(prev, MNEG);
+                int bj = s - tn - 1;  // base needed by lane 0: b[j-1], j = s - tn
+                int nv = 0xFE;
+                if (bj >= 0 && bj < n) {
+                    if ((bj & ~63) != bbase) { bbase = bj & ~63; bchunk = (bbase + lane < n) ? b[bbase + lane] : 0xFE; }
+                    nv = __builtin_amdgcn_readlane(bchunk, bj & 63);
+                }
+                breg = from_prev_lane(breg, nv);
+            }
+            hd = dt2 == 1 ? pprev : (dt2 == 0 ? from_prev_lane(pprev, MNEG) : from_next_lane(pprev, MNEG));
             const int i = tn + lane, j = s - i;
-            int lu = lane + dt1 - 1, ll = lane + dt1, ld = lane + dt2 - 1;
-            int hu = __shfl(prev, lu & 63, 64), hl = __shfl(prev, ll & 63, 64), hd = __shfl(pprev, ld & 63, 64);
-            if (lu < 0 || lu > 63) hu = MNEG;
-            if (ll < 0 || ll > 63) hl = MNEG;
-            if (ld < 0 || ld > 63) hd = MNEG;
             int v = MNEG, d = 0;
             if (i >= 0 && i <= m && j >= 0 && j <= n) {
                 int cd = MNEG, cu = MNEG, cl = MNEG;
-                if (i >= 1 && j >= 1) {
-                    uint8_t x = a[i - 1], y = b[j - 1];
-                    cd = hd + ((x == y && x != 'N') ? SC_MATCH : SC_MIS);
-                }
+                if (i >= 1 && j >= 1) cd = hd + ((areg == breg && areg != 'N') ? SC_MATCH : SC_MIS);
                 if (i >= 1) cu = hu + SC_GAP;
                 if (j >= 1) cl = hl + SC_GAP;
                 if (cd >= cu && cd >= cl) { v = cd; d = 0; }
@@ -103,47 +144,57 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
                 else { v = cl; d = 2; }
             }
             unsigned long long b0 = __ballot(d & 1), b1 = __ballot(d >> 1);
-            if (lane == 0) tbd[s] = make_ulonglong2(b0, b1);
-            mvbits |= (unsigned long long)(tn - t) << (s & 63);
-            if ((s & 63) == 63 || s == steps) { if (lane == 0) tbm[s >> 6] = mvbits; mvbits = 0; }
+            if (lane == (s & 63)) { r0 = b0; r1 = b1; }
+            mvbits |= (unsigned long long)dt1 << (s & 63);
+            if ((s & 63) == 63 || s == steps) {
+                tbd[(s & ~63) + lane] = make_ulonglong2(r0, r1);
+                if (lane == 0) tbm[s >> 6] = mvbits;
+                mvbits = 0;
+            }
             pprev = prev; prev = v; tp = t; t = tn;
         }
-        // make lane 0's stores visible to the whole wave before the traceback loads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-        // ---------------- traceback (wave-uniform) ----------------
-        int i = m, j = n, cur_ins = 0, pend_gap = 0, fail = 0;
-        int tcur = t;  // origin of anti-diagonal `steps`
-        int scur = steps;
-        while (i > 0 || j > 0) {
-            // bring tcur to anti-diagonal s = i + j
-            int s = i + j;
+        // ---------------- traceback (wave-uniform control flow) ----------------
+        int i = m, j = n, fail = 0;
+        int tcur = t, scur = steps;
+        int chunk = -1;
+        unsigned long long w0 = 0, w1 = 0, mv = 0;
+        int oreg = 0;
+        while (i > 0) {
+            const int s = i + j;
             while (scur > s) {
-                unsigned long long mb = tbm[scur >> 6];
-                tcur -= (int)((mb >> (scur & 63)) & 1ull);
+                if ((scur >> 6) != chunk) { chunk = scur >> 6; ulonglong2 w = tbd[chunk * 64 + lane]; w0 = w.x; w1 = w.y; mv = tbm[chunk]; }
+                tcur -= (int)((mv >> (scur & 63)) & 1ull);
                 scur--;
             }
-            int k = i - tcur;
+            if ((s >> 6) != chunk) { chunk = s >> 6; ulonglong2 w = tbd[chunk * 64 + lane]; w0 = w.x; w1 = w.y; mv = tbm[chunk]; }
+            const int k = i - tcur;
             if (k < 0 || k > 63) { fail = 1; break; }
-            ulonglong2 w = tbd[s];
-            int d = (int)((w.x >> k) & 1ull) | ((int)((w.y >> k) & 1ull) << 1);
-            if (i == 0) d = 2; else if (j == 0) d = 1;
-            if (d == 2) { cur_ins++; j--; }
-            else {
-                if (lane == 0) ops[i] = (uint16_t)((cur_ins > 0x7fff ? 0x7fff : cur_ins) | (pend_gap << 15));
-                pend_gap = d == 1;
-                cur_ins = 0;
-                i--;
-                if (d == 0) j--;
-            }
+            unsigned long long x0 = readlane64(w0, s & 63), x1 = readlane64(w1, s & 63);
+            int d = (int)((x0 >> k) & 1ull) | ((int)((x1 >> k) & 1ull) << 1);
+            if (j == 0) d = 1;
+            if (d == 2) { j--; continue; }
+            // centre position p = i-1: aligned to row position j-1 (diag) or to a gap before row position j (up)
+            const int p = i - 1;
+            const int val = d == 0 ? (j - 1) : (j | 0x8000);
+            if (lane == (p & 63)) oreg = val;
+            if ((p & 63) == 0) { if (p + lane < m) ops[p + lane] = (uint16_t)oreg; }
+            i--;
+            if (d == 0) j--;
         }
-        if (lane == 0) {
-            if (fail) atomicExch(&P.status[c], 1);
-            else ops[0] = (uint16_t)((cur_ins > 0x7fff ? 0x7fff : cur_ins) | (pend_gap << 15));
-        }
+        if (fail && lane == 0) atomicExch(&P.status[c], 1);
     }
+}
+
+// insertions of row r before centre position p (p = 0..m), from two neighbouring ops entries
+__device__ __forceinline__ int row_ins(const uint16_t *__restrict__ rop, int p, int m, int nrow) {
+    int prev_end = 0;
+    if (p > 0) { unsigned o = rop[p - 1]; prev_end = (int)(o & 0x7fff) + ((o >> 15) ? 0 : 1); }
+    int q = p < m ? (int)(rop[p] & 0x7fff) : nrow;
+    return q - prev_end;
 }
 
 // column layout: one block per candidate.  insmax -> row-0 slot of ops, block starts -> slot R.
@@ -153,22 +204,23 @@ __global__ void __launch_bounds__(256) star_layout_kernel(MsaParams P) {
     if (c >= P.n) return;
     const int64_t g0 = P.row_first[c];
     const int R = P.row_first[c + 1] - P.row_first[c];
+    if (R <= 0) { if (threadIdx.x == 0) P.cols_out[c] = 0; return; }
     const int m = P.win_len[g0];
     uint16_t *ops = P.ops + P.ops_base[c];
-    uint16_t *insmax = ops;                              // centre row slot (its own ops are all zero)
+    uint16_t *insmax = ops;                              // centre row slot (the centre has no ops of its own)
     uint16_t *bstart = ops + (int64_t)R * (m + 1);       // extra slot
     if (P.status[c]) { if (threadIdx.x == 0) P.cols_out[c] = 0; return; }
     int running = 0;
     for (int base = 0; base <= m; base += 256) {
         int p = base + threadIdx.x;
         int mx = 0;
-        if (p <= m) for (int r = 1; r < R; r++) { int v = ops[(int64_t)r * (m + 1) + p] & 0x7fff; mx = v > mx ? v : mx; }
+        if (p <= m) for (int r = 1; r < R; r++) { int v = row_ins(ops + (int64_t)r * (m + 1), p, m, P.win_len[g0 + r]); mx = v > mx ? v : mx; }
         int width = p <= m ? mx + (p < m ? 1 : 0) : 0;
         int tot;
         int pre = block_excl_scan(width, s_scan, &tot);
         if (p <= m) {
             int bs = running + pre;
-            insmax[p] = (uint16_t)mx;
+            insmax[p] = (uint16_t)(mx > 65535 ? 65535 : mx);
             bstart[p] = (uint16_t)(bs > 65535 ? 65535 : bs);
         }
         running += tot;
@@ -193,9 +245,9 @@ struct FillParams {
     uint8_t *msa;
 };
 
-// fill: one block per candidate, rows in turn; thread p owns insertion block p + centre column p
+// fill: grid (candidate, row slice); item (r, p) owns insertion block p + centre column p of row r,
+// so every output byte is written exactly once and no scan is needed.
 __global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
-    __shared__ int s_scan[8];
     const int c = blockIdx.x;
     if (c >= P.n) return;
     const int C = P.cols[c];
@@ -207,28 +259,22 @@ __global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
     const uint16_t *insmax = ops;
     const uint16_t *bstart = ops + (int64_t)R * (m + 1);
     uint8_t *out = P.msa + P.msa_off[c];
-    for (int r = 0; r < R; r++) {
+    for (int r = blockIdx.y; r < R; r += gridDim.y) {
         const uint8_t *b = P.win + P.win_off[g0 + r];
+        const int nrow = P.win_len[g0 + r];
         uint8_t *row = out + (int64_t)r * C;
         const uint16_t *rop = ops + (int64_t)r * (m + 1);
-        int running = 0;
-        for (int base = 0; base <= m; base += 256) {
-            int p = base + threadIdx.x;
-            int ins = 0, gap = 0, adv = 0;
-            if (p <= m) {
-                if (r > 0) { uint16_t o = rop[p]; ins = o & 0x7fff; gap = o >> 15; }
-                adv = ins + ((p < m && !gap) ? 1 : 0);
+        for (int p = threadIdx.x; p <= m; p += 256) {
+            int ins, gap = 0, q;
+            if (r == 0) { ins = 0; q = p; }
+            else {
+                ins = row_ins(rop, p, m, nrow);
+                if (p < m) { unsigned o = rop[p]; q = (int)(o & 0x7fff); gap = (int)(o >> 15); } else q = nrow;
             }
-            int tot;
-            int pre = block_excl_scan(adv, s_scan, &tot);
-            if (p <= m) {
-                int rp = running + pre;
-                int bs = bstart[p], im = insmax[p];
-                for (int q = 0; q < im; q++) row[bs + q] = q < ins ? b[rp + q] : (uint8_t)'-';
-                if (p < m) row[bs + im] = gap ? (uint8_t)'-' : b[rp + ins];
-            }
-            running += tot;
-            __syncthreads();
+            const int bs = bstart[p], im = insmax[p];
+            const int rp = q - ins;  // first inserted base
+            for (int k = 0; k < im; k++) row[bs + k] = k < ins ? b[rp + k] : (uint8_t)'-';
+            if (p < m) row[bs + im] = gap ? (uint8_t)'-' : b[q];
         }
     }
 }
@@ -243,7 +289,7 @@ extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win,
     if (!ctx || n < 0 || total_rows < 0 || max_win_len <= 0) return HITE_EINVAL;
     if (n == 0) return HITE_OK;
     const int max_steps = 2 * max_win_len;
-    size_t tb_slot = (size_t)(max_steps + 1) * 16 + ((size_t)(max_steps >> 6) + 2) * 8;
+    size_t tb_slot = (size_t)(max_steps + 64) * 16 + ((size_t)(max_steps >> 6) + 2) * 8;
     tb_slot = (tb_slot + 63) & ~(size_t)63;
     int64_t pairs = total_rows - n;
     int grid = (int)((pairs + 3) / 4);
@@ -282,7 +328,7 @@ extern "C" int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d
     FillParams P;
     P.n = n; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first; P.ops_base = d_ops_base;
     P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_cols; P.msa_off = d_msa_off; P.msa = d_msa;
-    hipLaunchKernelGGL(star_fill_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, P);
+    hipLaunchKernelGGL(star_fill_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, P);
     HITE_CHECK(ctx, hipGetLastError());
     return HITE_OK;
 }
