@@ -17,7 +17,7 @@
 #include "hite_common.h"
 
 #define MW 64
-#define MNEG (-(1 << 28))
+#define MBIAS (1 << 28)
 #define SC_MATCH 2
 #define SC_MIS (-2)
 #define SC_GAP (-4)
@@ -52,21 +52,36 @@ __device__ __forceinline__ int find_cand(const int32_t *__restrict__ row_first, 
 // lanes without a source keep `fill`.
 __device__ __forceinline__ int from_next_lane(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x130, 0xf, 0xf, false); }
 __device__ __forceinline__ int from_prev_lane(int v, int fill) { return __builtin_amdgcn_update_dpp(fill, v, 0x138, 0xf, 0xf, false); }
+// same with 0 shifted in (bound_ctrl): scores are biased by 2^28 so that 0 is "minus infinity"
+__device__ __forceinline__ int from_next_lane0(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }
+__device__ __forceinline__ int from_prev_lane0(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }
 __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int l) {
     unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, l);
     unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), l);
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// pin a wave-uniform value into an SGPR (the compiler otherwise keeps loop-carried uniform values in VGPRs)
+__device__ __forceinline__ int to_sgpr(int v) {
+    int r;
+    asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(__builtin_amdgcn_readfirstlane(v)));
+    return r;
+}
+__device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
+    unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
+    unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
 // One wavefront per (row, centre) pair.
-//  forward : lane k owns cell i = t + k of anti-diagonal s.  Per step: one DPP shift of `prev`, at most one
-//            of `pprev`, one DPP shift of the resident base register (the band moved down -> centre bases
-//            slide, moved right -> row bases slide) with the single new base taken from a 64-base chunk
-//            register by v_readlane; no LDS, no per-step memory load.  The 2-bit directions of 64
-//            consecutive anti-diagonals are parked one step per lane and stored as one coalesced 1 KiB write.
-//  backward: the same 1 KiB chunks are re-loaded one per 64 steps, the walk itself is scalar
-//            (v_readlane + bit tests); results leave as coalesced 128-B chunks of u16
-//            (row position aligned to centre position p | gap flag << 15).
+//  forward : lane k owns cell i = t + k of anti-diagonal s.  Everything about the band (s, t, moves, bounds,
+//            which base enters) lives in SGPRs; per step the vector work is one DPP shift of `prev`, at most
+//            one of `pprev`, one DPP shift of the resident base register (band moved down -> centre bases
+//            slide, moved right -> row bases slide; the one new base comes from a 64-base chunk register by
+//            v_readlane), a dozen compares/selects, two ballots.  No LDS, no per-step memory access.  The
+//            2-bit directions of 64 consecutive anti-diagonals are parked one step per lane and
+//            leave as one coalesced 1 KiB store.
+//  backward: the same 1 KiB chunks come back one load per 64 steps; the walk itself is scalar; results leave as
+//            coalesced 128-B chunks of u16 (row position aligned to centre position p | gap flag << 15).
 __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
     const int lane = threadIdx.x & 63;
     const int wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -79,73 +94,78 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         gq = __builtin_amdgcn_readfirstlane(gq);
         if ((int64_t)gq >= P.total_rows) break;
         const int64_t g = gq;
-        const int c = find_cand(P.row_first, P.n, g);
-        const int64_t g0 = P.row_first[c];
+        const int c = __builtin_amdgcn_readfirstlane(find_cand(P.row_first, P.n, g));
+        const int64_t g0 = __builtin_amdgcn_readfirstlane(P.row_first[c]);
         if (g == g0) continue;  // the centre itself
-        const uint8_t *a = P.win + P.win_off[g0];
-        const int m = P.win_len[g0];
-        const uint8_t *b = P.win + P.win_off[g];
-        const int n = P.win_len[g];
-        uint16_t *ops = P.ops + P.ops_base[c] + (int64_t)(g - g0) * (m + 1);
+        const uint8_t *a = (const uint8_t *)rfl64((unsigned long long)(P.win + P.win_off[g0]));
+        const int m = to_sgpr(P.win_len[g0]);
+        const uint8_t *b = (const uint8_t *)rfl64((unsigned long long)(P.win + P.win_off[g]));
+        const int n = to_sgpr(P.win_len[g]);
+        uint16_t *ops = (uint16_t *)rfl64((unsigned long long)(P.ops + P.ops_base[c] + (int64_t)(g - g0) * (m + 1)));
         const int steps = m + n;
         if (m <= 0 || n <= 0 || steps > P.max_steps) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
 
         // ---------------- forward ----------------
-        int t = -32, tp = -32;  // origins of anti-diagonals s-1 and s-2
-        int prev = lane == 32 ? 0 : MNEG, pprev = MNEG;
-        // resident bases for anti-diagonal s-1: areg = a[i-1], breg = b[j-1] with i = t + lane, j = (s-1) - i
+        int t = -32, tp = -32;  // origins of anti-diagonals s-1 and s-2 (scalar)
+        int prev = lane == 32 ? MBIAS : 0, pprev = 0;
+        // resident bases for anti-diagonal s-1: areg = a[i-1], breg = b[j-1] with i = t + lane, j = (s-1) - i;
+        // outside the sequences: sentinels that never match; a centre 'N' never matches either
         int areg, breg;
         {
             int ia = t + lane - 1, jb = -(t + lane) - 1;
             areg = (ia >= 0 && ia < m) ? a[ia] : 0xFF;
+            if (areg == 'N') areg = 0xFD;
             breg = (jb >= 0 && jb < n) ? b[jb] : 0xFE;
         }
         int abase = -64, bbase = -64;  // chunk registers: achunk = a[abase + lane], bchunk = b[bbase + lane]
         int achunk = 0xFF, bchunk = 0xFE;
         unsigned long long mvbits = 0, r0 = 0, r1 = 0;
         for (int s = 1; s <= steps; s++) {
-            int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);
-            int move = h0 > h63 ? 0 : (h0 < h63 ? 1 : ((((s - 1) & 1) == 0) ? 1 : 0));
-            int lo = s - n > 0 ? s - n : 0, hi = m < s ? m : s;
+            const int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);
+            const int move = h0 > h63 ? 0 : (h0 < h63 ? 1 : (s & 1));
+            const int lo = s - n > 0 ? s - n : 0, hi = m < s ? m : s;
             int tn = t + move;
             if (tn > hi - 31) tn = t;
             if (tn < lo - 32) tn = t + 1;
-            const int dt1 = tn - t, dt2 = tn - tp;
-            int hu, hl, hd;
-            if (dt1) {  // moved down: centre bases slide towards lane 0
-                hl = from_next_lane(prev, MNEG); hu = prev;
-                int ai = tn + 63 - 1;  // base needed by lane 63: a[i-1], i = tn + 63
+            tn = to_sgpr(tn);  // keep the band bookkeeping in SGPRs
+            const int dt2 = tn - tp;
+            int hu, hl;
+            if (tn != t) {  // moved down: centre bases slide towards lane 0
+                hl = from_next_lane0(prev); hu = prev;
+                const int ai = tn + 62;  // base needed by lane 63: a[i-1], i = tn + 63
                 int nv = 0xFF;
                 if (ai >= 0 && ai < m) {
-                    if ((ai & ~63) != abase) { abase = ai & ~63; achunk = (abase + lane < m) ? a[abase + lane] : 0xFF; }
+                    if ((ai & ~63) != abase) {
+                        abase = to_sgpr(ai & ~63);
+                        achunk = (abase + lane < m) ? a[abase + lane] : 0xFF;
+                        if (achunk == 'N') achunk = 0xFD;
+                    }
                     nv = __builtin_amdgcn_readlane(achunk, ai & 63);
                 }
                 areg = from_next_lane(areg, nv);
-            } else {    // moved right: row bases slide towards lane 63
-                hl = prev; hu = from_prev_lane(prev, MNEG);
-                int bj = s - tn - 1;  // base needed by lane 0: b[j-1], j = s - tn
+            } else {        // moved right: row bases slide towards lane 63
+                hl = prev; hu = from_prev_lane0(prev);
+                const int bj = s - tn - 1;  // base needed by lane 0: b[j-1], j = s - tn
                 int nv = 0xFE;
                 if (bj >= 0 && bj < n) {
-                    if ((bj & ~63) != bbase) { bbase = bj & ~63; bchunk = (bbase + lane < n) ? b[bbase + lane] : 0xFE; }
+                    if ((bj & ~63) != bbase) { bbase = to_sgpr(bj & ~63); bchunk = (bbase + lane < n) ? b[bbase + lane] : 0xFE; }
                     nv = __builtin_amdgcn_readlane(bchunk, bj & 63);
                 }
                 breg = from_prev_lane(breg, nv);
             }
-            hd = dt2 == 1 ? pprev : (dt2 == 0 ? from_prev_lane(pprev, MNEG) : from_next_lane(pprev, MNEG));
-            const int i = tn + lane, j = s - i;
-            int v = MNEG, d = 0;
-            if (i >= 0 && i <= m && j >= 0 && j <= n) {
-                int cd = MNEG, cu = MNEG, cl = MNEG;
-                if (i >= 1 && j >= 1) cd = hd + ((areg == breg && areg != 'N') ? SC_MATCH : SC_MIS);
-                if (i >= 1) cu = hu + SC_GAP;
-                if (j >= 1) cl = hl + SC_GAP;
-                if (cd >= cu && cd >= cl) { v = cd; d = 0; }
-                else if (cu >= cl) { v = cu; d = 1; }
-                else { v = cl; d = 2; }
-            }
-            unsigned long long b0 = __ballot(d & 1), b1 = __ballot(d >> 1);
+            int hd;
+            if (dt2 == 1) hd = pprev;
+            else if (dt2 == 0) hd = from_prev_lane0(pprev);
+            else hd = from_next_lane0(pprev);
+            const int cd = hd + (areg == breg ? SC_MATCH : SC_MIS);
+            const int cu = hu + SC_GAP, cl = hl + SC_GAP;
+            const int mx = cu > cl ? cu : cl;
+            const int v = cd > mx ? cd : mx;
+            // direction: 0 diag (cd is the max), else 1 up (cu >= cl), else 2 left
+            const unsigned long long nd = __ballot(cd != v), ug = __ballot(cu >= cl);
+            const unsigned long long b0 = nd & ug, b1 = nd & ~ug;
             if (lane == (s & 63)) { r0 = b0; r1 = b1; }
-            mvbits |= (unsigned long long)dt1 << (s & 63);
+            mvbits |= (unsigned long long)(tn - t) << (s & 63);
             if ((s & 63) == 63 || s == steps) {
                 tbd[(s & ~63) + lane] = make_ulonglong2(r0, r1);
                 if (lane == 0) tbm[s >> 6] = mvbits;
@@ -153,11 +173,16 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             }
             pprev = prev; prev = v; tp = t; t = tn;
         }
+        {
+            const int kf = m - t;
+            const int hf = (kf >= 0 && kf < 64) ? __builtin_amdgcn_readlane(prev, kf & 63) : 0;
+            if (hf <= MBIAS / 2) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-        // ---------------- traceback (wave-uniform control flow) ----------------
+        // ---------------- traceback (scalar walk) ----------------
         int i = m, j = n, fail = 0;
         int tcur = t, scur = steps;
         int chunk = -1;
@@ -166,14 +191,14 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         while (i > 0) {
             const int s = i + j;
             while (scur > s) {
-                if ((scur >> 6) != chunk) { chunk = scur >> 6; ulonglong2 w = tbd[chunk * 64 + lane]; w0 = w.x; w1 = w.y; mv = tbm[chunk]; }
+                if ((scur >> 6) != chunk) { chunk = scur >> 6; ulonglong2 w = tbd[chunk * 64 + lane]; w0 = w.x; w1 = w.y; mv = rfl64(tbm[chunk]); }
                 tcur -= (int)((mv >> (scur & 63)) & 1ull);
                 scur--;
             }
-            if ((s >> 6) != chunk) { chunk = s >> 6; ulonglong2 w = tbd[chunk * 64 + lane]; w0 = w.x; w1 = w.y; mv = tbm[chunk]; }
+            if ((s >> 6) != chunk) { chunk = s >> 6; ulonglong2 w = tbd[chunk * 64 + lane]; w0 = w.x; w1 = w.y; mv = rfl64(tbm[chunk]); }
             const int k = i - tcur;
             if (k < 0 || k > 63) { fail = 1; break; }
-            unsigned long long x0 = readlane64(w0, s & 63), x1 = readlane64(w1, s & 63);
+            const unsigned long long x0 = readlane64(w0, s & 63), x1 = readlane64(w1, s & 63);
             int d = (int)((x0 >> k) & 1ull) | ((int)((x1 >> k) & 1ull) << 1);
             if (j == 0) d = 1;
             if (d == 2) { j--; continue; }

@@ -15,7 +15,12 @@
  *     - t(0) = -32; after anti-diagonal s the band moves right (t same) if H[lane0] > H[lane63],
  *       down (t+1) if H[lane0] < H[lane63], on a tie down when s is even else right;
  *     - then forced: t+1 only if t+1 <= min(m,s+1)-31, and t+1 if t < max(0,s+1-n)-32;
- *   cells outside the band or the matrix hold NEG.  Ties in the recurrence: diag >= up >= left.
+ *   every lane of the band evaluates the same recurrence every step: bases outside the sequences
+ *   are sentinels that never match (so cells outside the matrix only ever hold "junk" that
+ *   cannot beat a real score), values shifted in from outside the band are 0 and real scores
+ *   are biased by 2^28 (H(0,0) = 2^28); an 'N' in the centre never matches.  The alignment
+ *   fails if H(m,n) <= 2^27 (end cell not reachable inside the band).
+ *   Ties in the recurrence: diag >= up >= left.
  *   Traceback from (m,n) gives per centre position p: gap flag (row has '-') and the number of
  *   row bases inserted before p.  Columns: for p = 0..m an insertion block of
  *   max_r ins[r][p] columns (bases left-justified, '-' padded) followed (p < m) by the centre
@@ -28,7 +33,7 @@
 #define ORC_EINVAL (-1002)
 #define ORC_ECAP (-1001)
 #define W 64
-#define NEG (-(1 << 28))
+#define BIAS (1 << 28)
 #define SC_MATCH 2
 #define SC_MIS (-2)
 #define SC_GAP (-4)
@@ -43,45 +48,45 @@ static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t
     int prev[W], pprev[W], cur[W];
     if (!dir || !ts) { free(dir); free(ts); return ORC_EINVAL; }
     int t = -32, tp = -32, tpp = -32;
-    for (int k = 0; k < W; k++) { prev[k] = NEG; pprev[k] = NEG; }
-    prev[32] = 0; /* H(0,0) */
+    for (int k = 0; k < W; k++) { prev[k] = 0; pprev[k] = 0; }
+    prev[32] = BIAS; /* H(0,0) */
     ts[0] = t;
     for (int s = 1; s <= steps; s++) {
-        /* choose the move from anti-diagonal s-1 (held in prev, origin tp == t) */
+        /* choose the move from anti-diagonal s-1 (held in prev, origin t) */
         int h0 = prev[0], h63 = prev[W - 1];
         int move;
-        if (h0 > h63) move = 0; else if (h0 < h63) move = 1; else move = (((s - 1) & 1) == 0) ? 1 : 0;
+        if (h0 > h63) move = 0; else if (h0 < h63) move = 1; else move = (s & 1) ? 1 : 0;
         int lo = s - n > 0 ? s - n : 0, hi = m < s ? m : s;
         int tn = t + move;
         if (tn > hi - 31) tn = t;
         if (tn < lo - 32) tn = t + 1;
         tpp = tp; tp = t; t = tn;
-        /* after the shuffle of names: t = origin of s, tp = origin of s-1, tpp = origin of s-2 */
+        /* now t = origin of s, tp = origin of s-1, tpp = origin of s-2 */
         for (int k = 0; k < W; k++) {
             int i = t + k, j = s - i;
-            int v = NEG, d = 0;
-            if (i >= 0 && i <= m && j >= 0 && j <= n) {
-                int lu = i - 1 - tp, ll = i - tp, ld = i - 1 - tpp;
-                int hu = (lu >= 0 && lu < W) ? prev[lu] : NEG;
-                int hl = (ll >= 0 && ll < W) ? prev[ll] : NEG;
-                int hd = (ld >= 0 && ld < W) ? pprev[ld] : NEG;
-                int cd = NEG, cu = NEG, cl = NEG;
-                if (i >= 1 && j >= 1) {
-                    uint8_t x = a[i - 1], y = b[j - 1];
-                    cd = hd + ((x == y && x != 'N') ? SC_MATCH : SC_MIS);
-                }
-                if (i >= 1) cu = hu + SC_GAP;
-                if (j >= 1) cl = hl + SC_GAP;
-                if (cd >= cu && cd >= cl) { v = cd; d = 0; }
-                else if (cu >= cl) { v = cu; d = 1; }
-                else { v = cl; d = 2; }
-            }
+            int lu = i - 1 - tp, ll = i - tp, ld = i - 1 - tpp;
+            int hu = (lu >= 0 && lu < W) ? prev[lu] : 0;
+            int hl = (ll >= 0 && ll < W) ? prev[ll] : 0;
+            int hd = (ld >= 0 && ld < W) ? pprev[ld] : 0;
+            int x = (i >= 1 && i <= m) ? a[i - 1] : 0xFF;
+            int y = (j >= 1 && j <= n) ? b[j - 1] : 0xFE;
+            if (x == 'N') x = 0xFD;
+            int cd = hd + (x == y ? SC_MATCH : SC_MIS);
+            int cu = hu + SC_GAP, cl = hl + SC_GAP;
+            int v, d;
+            if (cd >= cu && cd >= cl) { v = cd; d = 0; }
+            else if (cu >= cl) { v = cu; d = 1; }
+            else { v = cl; d = 2; }
             cur[k] = v;
             dir[(size_t)s * W + k] = (uint8_t)d;
         }
         memcpy(pprev, prev, sizeof prev);
         memcpy(prev, cur, sizeof cur);
         ts[s] = t;
+    }
+    {
+        int kf = m - t;
+        if (kf < 0 || kf >= W || prev[kf] <= BIAS / 2) { free(dir); free(ts); return ORC_EINVAL; }
     }
     /* traceback */
     int i = m, j = n, cur_ins = 0, pend_gap = 0;

@@ -195,7 +195,8 @@ def star_msa(windows):
     buf = np.frombuffer(b"".join(wb), dtype=np.uint8)
     cols = C.c_int(0)
     rc = lib().orc_star_msa(_ptr(buf, u8p), _ptr(off, i64p), len(wb), C.byref(cols), None, C.c_int64(0))
-    assert rc == 0, rc
+    if rc != 0:
+        return None  # an alignment left the band: the candidate is not judged (GPU: cols = 0)
     out = np.zeros((len(wb), cols.value), dtype=np.uint8)
     rc = lib().orc_star_msa(_ptr(buf, u8p), _ptr(off, i64p), len(wb), C.byref(cols), _ptr(out, u8p), C.c_int64(out.size))
     assert rc == 0, rc

@@ -22,6 +22,8 @@ def judge_windows(te_type, cand, windows, plant):
     keep = select_rows([len(w) for w in windows])
     wins = [windows[i] for i in keep]
     m = O.star_msa(wins)
+    if m is None:
+        return ["EXC", 0], (-1, -1)
     kc = O.sparse_cols(m).astype(bool)
     res, b = O.judge(te_type, np.ascontiguousarray(m[:, kc]), cand, plant)
     return res, b
