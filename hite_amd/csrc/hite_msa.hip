@@ -67,6 +67,25 @@ __device__ __forceinline__ int to_sgpr(int v) {
     asm volatile("s_mov_b32 %0, %1" : "=s"(r) : "s"(__builtin_amdgcn_readfirstlane(v)));
     return r;
 }
+// one wave-uniform grab from a global work counter without a divergent branch: lane 0 alone issues the
+// atomic (exec = 1), the old value comes back in an SGPR.  Keeping the queue pop branch-free lets the
+// compiler see the whole pair loop as uniform control flow (band bookkeeping stays on the scalar unit).
+__device__ __forceinline__ unsigned wave_grab(unsigned *counter) {
+    unsigned vret, sret, one = 1;
+    unsigned long long saved;
+    asm volatile(
+        "s_mov_b64 %1, exec\n\t"
+        "s_mov_b64 exec, 1\n\t"
+        "global_atomic_add %0, %3, %4, off sc0\n\t"
+        "s_waitcnt vmcnt(0)\n\t"
+        "s_mov_b64 exec, %1\n\t"
+        "s_nop 4\n\t"
+        "v_readfirstlane_b32 %2, %0"
+        : "=&v"(vret), "=&s"(saved), "=s"(sret)
+        : "v"(counter), "v"(one)
+        : "memory");
+    return sret;
+}
 __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
     unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v);
     unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
@@ -86,12 +105,10 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
     const int lane = threadIdx.x & 63;
     const int wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
     uint8_t *slot = P.tb + (size_t)wslot * P.tb_slot;
-    ulonglong2 *tbd = reinterpret_cast<ulonglong2 *>(slot);                                              // [max_steps + 64]
+    uint4 *tbd = reinterpret_cast<uint4 *>(slot);                                              // [max_steps + 64]
     unsigned long long *tbm = reinterpret_cast<unsigned long long *>(slot + (size_t)(P.max_steps + 64) * 16);  // move bits
     for (;;) {
-        unsigned int gq = 0;
-        if (lane == 0) gq = atomicAdd(P.counter, 1u);
-        gq = __builtin_amdgcn_readfirstlane(gq);
+        const unsigned int gq = wave_grab(P.counter);
         if ((int64_t)gq >= P.total_rows) break;
         const int64_t g = gq;
         const int c = __builtin_amdgcn_readfirstlane(find_cand(P.row_first, P.n, g));
@@ -119,15 +136,34 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         }
         int abase = -64, bbase = -64;  // chunk registers: achunk = a[abase + lane], bchunk = b[bbase + lane]
         int achunk = 0xFF, bchunk = 0xFE;
-        unsigned long long mvbits = 0, r0 = 0, r1 = 0;
+        unsigned long long mvbits = 0;
+        unsigned dreg = 0, wx = 0, wy = 0, wz = 0, ww = 0;  // 2-bit directions: 16 steps per register
         for (int s = 1; s <= steps; s++) {
             const int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);
-            const int move = h0 > h63 ? 0 : (h0 < h63 ? 1 : (s & 1));
-            const int lo = s - n > 0 ? s - n : 0, hi = m < s ? m : s;
-            int tn = t + move;
-            if (tn > hi - 31) tn = t;
-            if (tn < lo - 32) tn = t + 1;
-            tn = to_sgpr(tn);  // keep the band bookkeeping in SGPRs
+            int tn, sc0, sc1, sc2;
+            // band bookkeeping, pinned to the scalar unit:
+            //   move = h0 > h63 ? 0 : (h0 < h63 ? 1 : s & 1);  tn = t + move
+            //   if (tn > min(m, s) - 31) tn = t;  if (tn < max(0, s - n) - 32) tn = t + 1
+            asm volatile(
+                "s_and_b32 %1, %5, 1\n\t"
+                "s_cmp_ge_i32 %6, %7\n\t"
+                "s_cselect_b32 %1, %1, 1\n\t"
+                "s_cmp_gt_i32 %6, %7\n\t"
+                "s_cselect_b32 %1, 0, %1\n\t"
+                "s_add_i32 %0, %4, %1\n\t"
+                "s_min_i32 %2, %8, %5\n\t"
+                "s_sub_i32 %2, %2, 31\n\t"
+                "s_cmp_gt_i32 %0, %2\n\t"
+                "s_cselect_b32 %0, %4, %0\n\t"
+                "s_sub_i32 %3, %5, %9\n\t"
+                "s_max_i32 %3, %3, 0\n\t"
+                "s_sub_i32 %3, %3, 32\n\t"
+                "s_add_i32 %2, %4, 1\n\t"
+                "s_cmp_lt_i32 %0, %3\n\t"
+                "s_cselect_b32 %0, %2, %0"
+                : "=&s"(tn), "=&s"(sc0), "=&s"(sc1), "=&s"(sc2)
+                : "s"(t), "s"(s), "s"(h0), "s"(h63), "s"(m), "s"(n)
+                : "scc");
             const int dt2 = tn - tp;
             int hu, hl;
             if (tn != t) {  // moved down: centre bases slide towards lane 0
@@ -162,12 +198,17 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             const int mx = cu > cl ? cu : cl;
             const int v = cd > mx ? cd : mx;
             // direction: 0 diag (cd is the max), else 1 up (cu >= cl), else 2 left
-            const unsigned long long nd = __ballot(cd != v), ug = __ballot(cu >= cl);
-            const unsigned long long b0 = nd & ug, b1 = nd & ~ug;
-            if (lane == (s & 63)) { r0 = b0; r1 = b1; }
+            const unsigned d = cd == v ? 0u : (cu >= cl ? 1u : 2u);
+            dreg = (dreg << 2) | d;
+            if ((s & 15) == 15 || s == steps) {
+                const unsigned dv = dreg << (2 * (15 - (s & 15)));
+                const int q = (s >> 4) & 3;
+                if (q == 0) wx = dv; else if (q == 1) wy = dv; else if (q == 2) wz = dv; else ww = dv;
+                dreg = 0;
+            }
             mvbits |= (unsigned long long)(tn - t) << (s & 63);
             if ((s & 63) == 63 || s == steps) {
-                tbd[(s & ~63) + lane] = make_ulonglong2(r0, r1);
+                tbd[(s & ~63) + lane] = make_uint4(wx, wy, wz, ww);
                 if (lane == 0) tbm[s >> 6] = mvbits;
                 mvbits = 0;
             }
@@ -186,20 +227,26 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         int i = m, j = n, fail = 0;
         int tcur = t, scur = steps;
         int chunk = -1;
-        unsigned long long w0 = 0, w1 = 0, mv = 0;
+        unsigned long long mv = 0;
         int oreg = 0;
+        wx = wy = wz = ww = 0;
         while (i > 0) {
             const int s = i + j;
             while (scur > s) {
-                if ((scur >> 6) != chunk) { chunk = scur >> 6; ulonglong2 w = tbd[chunk * 64 + lane]; w0 = w.x; w1 = w.y; mv = rfl64(tbm[chunk]); }
+                if ((scur >> 6) != chunk) { chunk = scur >> 6; uint4 w = tbd[chunk * 64 + lane]; wx = w.x; wy = w.y; wz = w.z; ww = w.w; mv = rfl64(tbm[chunk]); }
                 tcur -= (int)((mv >> (scur & 63)) & 1ull);
                 scur--;
             }
-            if ((s >> 6) != chunk) { chunk = s >> 6; ulonglong2 w = tbd[chunk * 64 + lane]; w0 = w.x; w1 = w.y; mv = rfl64(tbm[chunk]); }
+            if ((s >> 6) != chunk) { chunk = s >> 6; uint4 w = tbd[chunk * 64 + lane]; wx = w.x; wy = w.y; wz = w.z; ww = w.w; mv = rfl64(tbm[chunk]); }
             const int k = i - tcur;
             if (k < 0 || k > 63) { fail = 1; break; }
-            const unsigned long long x0 = readlane64(w0, s & 63), x1 = readlane64(w1, s & 63);
-            int d = (int)((x0 >> k) & 1ull) | ((int)((x1 >> k) & 1ull) << 1);
+            const int q = (s >> 4) & 3;
+            unsigned wsel;
+            if (q == 0) wsel = (unsigned)__builtin_amdgcn_readlane((int)wx, k);
+            else if (q == 1) wsel = (unsigned)__builtin_amdgcn_readlane((int)wy, k);
+            else if (q == 2) wsel = (unsigned)__builtin_amdgcn_readlane((int)wz, k);
+            else wsel = (unsigned)__builtin_amdgcn_readlane((int)ww, k);
+            int d = (int)((wsel >> (2 * (15 - (s & 15)))) & 3u);
             if (j == 0) d = 1;
             if (d == 2) { j--; continue; }
             // centre position p = i-1: aligned to row position j-1 (diag) or to a gap before row position j (up)
