@@ -91,22 +91,25 @@ __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
     unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
-// One wavefront per (row, centre) pair.
-//  forward : lane k owns cell i = t + k of anti-diagonal s.  Everything about the band (s, t, moves, bounds,
-//            which base enters) lives in SGPRs; per step the vector work is one DPP shift of `prev`, at most
-//            one of `pprev`, one DPP shift of the resident base register (band moved down -> centre bases
-//            slide, moved right -> row bases slide; the one new base comes from a 64-base chunk register by
-//            v_readlane), a dozen compares/selects, two ballots.  No LDS, no per-step memory access.  The
-//            2-bit directions of 64 consecutive anti-diagonals are parked one step per lane and
-//            leave as one coalesced 1 KiB store.
-//  backward: the same 1 KiB chunks come back one load per 64 steps; the walk itself is scalar; results leave as
-//            coalesced 128-B chunks of u16 (row position aligned to centre position p | gap flag << 15).
+// One wavefront per (row, centre) pair.  Issue budget: a CU has ONE scalar unit for its 32 waves but four
+// vector units, so the per-step work is split on purpose: the band steering (16 dependent integer ops on
+// wave-uniform values) runs on the scalar unit, everything else is branch-free vector code.
+//  forward : lane k owns cell i = t + k of anti-diagonal s.  Per step: three DPP shifts + selects give the up /
+//            left / diagonal neighbours (the diagonal operand of the next step is this step's "left" operand,
+//            so no second history register has to be re-aligned), one DPP shift + select slides the resident
+//            centre or row bases, the one base that enters the band was fetched one step earlier by a uniform
+//            (broadcast) load.  Directions are packed 2 bits per step into a per-lane register (v_lshl_or) and
+//            leave as one coalesced 256-B store per 16 steps; the band origin t(s) is parked one step per
+//            lane and leaves as a 256-B store per 64 steps.  No LDS, no atomics, no per-step branches.
+//  backward: wave-uniform walk in vector registers: origin and direction word of the current cell come from
+//            ds_bpermute on the re-loaded chunks; results leave as coalesced 128-B chunks of u16
+//            (row position aligned to centre position p | gap flag << 15).
 __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
     const int lane = threadIdx.x & 63;
     const int wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
     uint8_t *slot = P.tb + (size_t)wslot * P.tb_slot;
-    uint4 *tbd = reinterpret_cast<uint4 *>(slot);                                              // [max_steps + 64]
-    unsigned long long *tbm = reinterpret_cast<unsigned long long *>(slot + (size_t)(P.max_steps + 64) * 16);  // move bits
+    unsigned *tbd = reinterpret_cast<unsigned *>(slot);                                   // [(max_steps/16 + 2) * 64] direction words
+    int *tbt = reinterpret_cast<int *>(slot + (size_t)((P.max_steps >> 4) + 2) * 256);    // [max_steps + 64] band origins
     for (;;) {
         const unsigned int gq = wave_grab(P.counter);
         if ((int64_t)gq >= P.total_rows) break;
@@ -123,96 +126,89 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         if (m <= 0 || n <= 0 || steps > P.max_steps) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
 
         // ---------------- forward ----------------
-        int t = -32, tp = -32;  // origins of anti-diagonals s-1 and s-2 (scalar)
-        int prev = lane == 32 ? MBIAS : 0, pprev = 0;
-        // resident bases for anti-diagonal s-1: areg = a[i-1], breg = b[j-1] with i = t + lane, j = (s-1) - i;
-        // outside the sequences: sentinels that never match; a centre 'N' never matches either
-        int areg, breg;
+        int t = -32;                                   // origin of anti-diagonal s-1 (scalar)
+        int prev = lane == 32 ? MBIAS : 0, ppal = 0;   // H(s-1) at origin t;  H(s-2) re-aligned to origin t
+        int areg, breg;                                // a[i-1], b[j-1] of this lane's cell on anti-diagonal s-1
         {
             int ia = t + lane - 1, jb = -(t + lane) - 1;
             areg = (ia >= 0 && ia < m) ? a[ia] : 0xFF;
             if (areg == 'N') areg = 0xFD;
             breg = (jb >= 0 && jb < n) ? b[jb] : 0xFE;
         }
-        int abase = -64, bbase = -64;  // chunk registers: achunk = a[abase + lane], bchunk = b[bbase + lane]
-        int achunk = 0xFF, bchunk = 0xFE;
-        unsigned long long mvbits = 0;
-        unsigned dreg = 0, wx = 0, wy = 0, wz = 0, ww = 0;  // 2-bit directions: 16 steps per register
-        for (int s = 1; s <= steps; s++) {
-            const int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);
-            int tn, sc0, sc1, sc2;
-            // band bookkeeping, pinned to the scalar unit:
-            //   move = h0 > h63 ? 0 : (h0 < h63 ? 1 : s & 1);  tn = t + move
-            //   if (tn > min(m, s) - 31) tn = t;  if (tn < max(0, s - n) - 32) tn = t + 1
-            asm volatile(
-                "s_and_b32 %1, %5, 1\n\t"
-                "s_cmp_ge_i32 %6, %7\n\t"
-                "s_cselect_b32 %1, %1, 1\n\t"
-                "s_cmp_gt_i32 %6, %7\n\t"
-                "s_cselect_b32 %1, 0, %1\n\t"
-                "s_add_i32 %0, %4, %1\n\t"
-                "s_min_i32 %2, %8, %5\n\t"
-                "s_sub_i32 %2, %2, 31\n\t"
-                "s_cmp_gt_i32 %0, %2\n\t"
-                "s_cselect_b32 %0, %4, %0\n\t"
-                "s_sub_i32 %3, %5, %9\n\t"
-                "s_max_i32 %3, %3, 0\n\t"
-                "s_sub_i32 %3, %3, 32\n\t"
-                "s_add_i32 %2, %4, 1\n\t"
-                "s_cmp_lt_i32 %0, %3\n\t"
-                "s_cselect_b32 %0, %2, %0"
-                : "=&s"(tn), "=&s"(sc0), "=&s"(sc1), "=&s"(sc2)
-                : "s"(t), "s"(s), "s"(h0), "s"(h63), "s"(m), "s"(n)
-                : "scc");
-            const int dt2 = tn - tp;
-            int hu, hl;
-            if (tn != t) {  // moved down: centre bases slide towards lane 0
-                hl = from_next_lane0(prev); hu = prev;
-                const int ai = tn + 62;  // base needed by lane 63: a[i-1], i = tn + 63
-                int nv = 0xFF;
-                if (ai >= 0 && ai < m) {
-                    if ((ai & ~63) != abase) {
-                        abase = to_sgpr(ai & ~63);
-                        achunk = (abase + lane < m) ? a[abase + lane] : 0xFF;
-                        if (achunk == 'N') achunk = 0xFD;
-                    }
-                    nv = __builtin_amdgcn_readlane(achunk, ai & 63);
+        // bases that would enter the band at step 1: a[t + 63] on a down move, b[0 - t] on a right move
+        int na, nb;
+        {
+            int ia = t + 63, jb = -t;
+            na = (ia >= 0 && ia < m) ? a[ia] : 0xFF;
+            if (na == 'N') na = 0xFD;
+            nb = (jb >= 0 && jb < n) ? b[jb] : 0xFE;
+        }
+        unsigned dreg = 0;
+        int treg = 0;
+        int vz;  // an opaque vector zero: keeps the prefetch addressing on the vector unit (the scalar unit is the scarce one)
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+        const int nchunk = steps >> 4;
+        for (int ch = 0; ch <= nchunk; ch++) {
+            const int s_lo = ch == 0 ? 1 : ch << 4;
+            const int s_hi = (ch << 4) + 15 < steps ? (ch << 4) + 15 : steps;
+            for (int s = s_lo; s <= s_hi; s++) {
+                const int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);
+                int tn, sc0, sc1, sc2;
+                // band steering, pinned to the scalar unit:
+                //   move = h0 > h63 ? 0 : (h0 < h63 ? 1 : s & 1);  tn = t + move
+                //   if (tn > min(m, s) - 31) tn = t;  if (tn < max(0, s - n) - 32) tn = t + 1
+                asm volatile(
+                    "s_and_b32 %1, %5, 1\n\t"
+                    "s_cmp_ge_i32 %6, %7\n\t"
+                    "s_cselect_b32 %1, %1, 1\n\t"
+                    "s_cmp_gt_i32 %6, %7\n\t"
+                    "s_cselect_b32 %1, 0, %1\n\t"
+                    "s_add_i32 %0, %4, %1\n\t"
+                    "s_min_i32 %2, %8, %5\n\t"
+                    "s_sub_i32 %2, %2, 31\n\t"
+                    "s_cmp_gt_i32 %0, %2\n\t"
+                    "s_cselect_b32 %0, %4, %0\n\t"
+                    "s_sub_i32 %3, %5, %9\n\t"
+                    "s_max_i32 %3, %3, 0\n\t"
+                    "s_sub_i32 %3, %3, 32\n\t"
+                    "s_add_i32 %2, %4, 1\n\t"
+                    "s_cmp_lt_i32 %0, %3\n\t"
+                    "s_cselect_b32 %0, %2, %0"
+                    : "=&s"(tn), "=&s"(sc0), "=&s"(sc1), "=&s"(sc2)
+                    : "s"(t), "s"(s), "s"(h0), "s"(h63), "s"(m), "s"(n)
+                    : "scc");
+                const bool down = tn != t;  // wave-uniform
+                // neighbours: down -> (left, up) = (H(s-1)[k+1], H(s-1)[k]);  right -> (H(s-1)[k], H(s-1)[k-1])
+                const int nxt = from_next_lane0(prev), prv = from_prev_lane0(prev), pps = from_prev_lane0(ppal);
+                const int hl = down ? nxt : prev;
+                const int hu = down ? prev : prv;
+                const int hd = down ? ppal : pps;
+                // resident bases: down -> centre bases slide towards lane 0, right -> row bases towards lane 63
+                const int an = from_next_lane(areg, na), bn = from_prev_lane(breg, nb);
+                areg = down ? an : areg;
+                breg = down ? breg : bn;
+                // prefetch the bases that can enter at step s+1 (same address in every lane -> broadcast load)
+                {
+                    const int ia = tn + 63 + vz, jb = s - tn + vz;
+                    const bool oka = (unsigned)ia < (unsigned)m, okb = (unsigned)jb < (unsigned)n;
+                    int xa = a[oka ? ia : 0], xb = b[okb ? jb : 0];
+                    xa = oka ? xa : 0xFF;
+                    na = xa == 'N' ? 0xFD : xa;
+                    nb = okb ? xb : 0xFE;
                 }
-                areg = from_next_lane(areg, nv);
-            } else {        // moved right: row bases slide towards lane 63
-                hl = prev; hu = from_prev_lane0(prev);
-                const int bj = s - tn - 1;  // base needed by lane 0: b[j-1], j = s - tn
-                int nv = 0xFE;
-                if (bj >= 0 && bj < n) {
-                    if ((bj & ~63) != bbase) { bbase = to_sgpr(bj & ~63); bchunk = (bbase + lane < n) ? b[bbase + lane] : 0xFE; }
-                    nv = __builtin_amdgcn_readlane(bchunk, bj & 63);
-                }
-                breg = from_prev_lane(breg, nv);
+                const int cd = hd + (areg == breg ? SC_MATCH : SC_MIS);
+                const int cu = hu + SC_GAP, cl = hl + SC_GAP;
+                const int mx = cu > cl ? cu : cl;
+                const int v = cd > mx ? cd : mx;
+                // direction: 0 diag (cd is the max), else 1 up (cu >= cl), else 2 left
+                const unsigned d = cd == v ? 0u : (cu >= cl ? 1u : 2u);
+                dreg = (dreg << 2) | d;
+                if (lane == (s & 63)) treg = tn;
+                ppal = hl; prev = v; t = tn;
             }
-            int hd;
-            if (dt2 == 1) hd = pprev;
-            else if (dt2 == 0) hd = from_prev_lane0(pprev);
-            else hd = from_next_lane0(pprev);
-            const int cd = hd + (areg == breg ? SC_MATCH : SC_MIS);
-            const int cu = hu + SC_GAP, cl = hl + SC_GAP;
-            const int mx = cu > cl ? cu : cl;
-            const int v = cd > mx ? cd : mx;
-            // direction: 0 diag (cd is the max), else 1 up (cu >= cl), else 2 left
-            const unsigned d = cd == v ? 0u : (cu >= cl ? 1u : 2u);
-            dreg = (dreg << 2) | d;
-            if ((s & 15) == 15 || s == steps) {
-                const unsigned dv = dreg << (2 * (15 - (s & 15)));
-                const int q = (s >> 4) & 3;
-                if (q == 0) wx = dv; else if (q == 1) wy = dv; else if (q == 2) wz = dv; else ww = dv;
-                dreg = 0;
-            }
-            mvbits |= (unsigned long long)(tn - t) << (s & 63);
-            if ((s & 63) == 63 || s == steps) {
-                tbd[(s & ~63) + lane] = make_uint4(wx, wy, wz, ww);
-                if (lane == 0) tbm[s >> 6] = mvbits;
-                mvbits = 0;
-            }
-            pprev = prev; prev = v; tp = t; t = tn;
+            tbd[ch * 64 + lane] = dreg << (2 * (15 - (s_hi & 15)));
+            dreg = 0;
+            if ((ch & 3) == 3 || ch == nchunk) tbt[(ch >> 2) * 64 + lane] = treg;
         }
         {
             const int kf = m - t;
@@ -223,39 +219,31 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-        // ---------------- traceback (scalar walk) ----------------
-        int i = m, j = n, fail = 0;
-        int tcur = t, scur = steps;
-        int chunk = -1;
-        unsigned long long mv = 0;
-        int oreg = 0;
-        wx = wy = wz = ww = 0;
+        // ---------------- traceback: wave-uniform walk kept in vector registers ----------------
+        int i = m, j = n;                 // every lane carries the same (i, j)
+        int dchunk = -1, tchunk = -1;     // loaded chunks (scalar)
+        unsigned wcur = 0;                // this lane's direction word of the 16-step chunk
+        int tcur = 0;                     // this lane's band origin of step (tchunk*64 + lane)
+        int oreg = 0, fail = 0;
         while (i > 0) {
             const int s = i + j;
-            while (scur > s) {
-                if ((scur >> 6) != chunk) { chunk = scur >> 6; uint4 w = tbd[chunk * 64 + lane]; wx = w.x; wy = w.y; wz = w.z; ww = w.w; mv = rfl64(tbm[chunk]); }
-                tcur -= (int)((mv >> (scur & 63)) & 1ull);
-                scur--;
-            }
-            if ((s >> 6) != chunk) { chunk = s >> 6; uint4 w = tbd[chunk * 64 + lane]; wx = w.x; wy = w.y; wz = w.z; ww = w.w; mv = rfl64(tbm[chunk]); }
-            const int k = i - tcur;
-            if (k < 0 || k > 63) { fail = 1; break; }
-            const int q = (s >> 4) & 3;
-            unsigned wsel;
-            if (q == 0) wsel = (unsigned)__builtin_amdgcn_readlane((int)wx, k);
-            else if (q == 1) wsel = (unsigned)__builtin_amdgcn_readlane((int)wy, k);
-            else if (q == 2) wsel = (unsigned)__builtin_amdgcn_readlane((int)wz, k);
-            else wsel = (unsigned)__builtin_amdgcn_readlane((int)ww, k);
+            const int sq = __builtin_amdgcn_readfirstlane(s);
+            if ((sq >> 4) != dchunk) { dchunk = sq >> 4; wcur = tbd[dchunk * 64 + lane]; }
+            if ((sq >> 6) != tchunk) { tchunk = sq >> 6; tcur = tbt[tchunk * 64 + lane]; }
+            const int ts = __builtin_amdgcn_ds_bpermute((s & 63) << 2, tcur);   // origin of anti-diagonal s
+            const int k = i - ts;
+            if (__builtin_amdgcn_readfirstlane((unsigned)k > 63u)) { fail = 1; break; }
+            const unsigned wsel = (unsigned)__builtin_amdgcn_ds_bpermute(k << 2, (int)wcur);
             int d = (int)((wsel >> (2 * (15 - (s & 15)))) & 3u);
-            if (j == 0) d = 1;
-            if (d == 2) { j--; continue; }
+            d = j == 0 ? 1 : d;
+            const bool isleft = d == 2, isdiag = d == 0;
             // centre position p = i-1: aligned to row position j-1 (diag) or to a gap before row position j (up)
             const int p = i - 1;
-            const int val = d == 0 ? (j - 1) : (j | 0x8000);
-            if (lane == (p & 63)) oreg = val;
-            if ((p & 63) == 0) { if (p + lane < m) ops[p + lane] = (uint16_t)oreg; }
-            i--;
-            if (d == 0) j--;
+            const int val = isdiag ? (j - 1) : (j | 0x8000);
+            if (!isleft && lane == (p & 63)) oreg = val;
+            if (__builtin_amdgcn_readfirstlane((!isleft && (p & 63) == 0) ? 1 : 0)) { if (p + lane < m) ops[p + lane] = (uint16_t)oreg; }
+            i -= isleft ? 0 : 1;
+            j -= d == 1 ? 0 : 1;
         }
         if (fail && lane == 0) atomicExch(&P.status[c], 1);
     }
@@ -361,7 +349,7 @@ extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win,
     if (!ctx || n < 0 || total_rows < 0 || max_win_len <= 0) return HITE_EINVAL;
     if (n == 0) return HITE_OK;
     const int max_steps = 2 * max_win_len;
-    size_t tb_slot = (size_t)(max_steps + 64) * 16 + ((size_t)(max_steps >> 6) + 2) * 8;
+    size_t tb_slot = (size_t)((max_steps >> 4) + 2) * 256 + (size_t)(max_steps + 64) * 4;
     tb_slot = (tb_slot + 63) & ~(size_t)63;
     int64_t pairs = total_rows - n;
     int grid = (int)((pairs + 3) / 4);
