@@ -92,24 +92,25 @@ __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
     return ((unsigned long long)hi << 32) | lo;
 }
 // One wavefront per (row, centre) pair.  Issue budget: a CU has ONE scalar unit for its 32 waves but four
-// vector units, so the per-step work is split on purpose: the band steering (16 dependent integer ops on
-// wave-uniform values) runs on the scalar unit, everything else is branch-free vector code.
-//  forward : lane k owns cell i = t + k of anti-diagonal s.  Per step: three DPP shifts + selects give the up /
-//            left / diagonal neighbours (the diagonal operand of the next step is this step's "left" operand,
-//            so no second history register has to be re-aligned), one DPP shift + select slides the resident
-//            centre or row bases, the one base that enters the band was fetched one step earlier by a uniform
-//            (broadcast) load.  Directions are packed 2 bits per step into a per-lane register (v_lshl_or) and
-//            leave as one coalesced 256-B store per 16 steps; the band origin t(s) is parked one step per
-//            lane and leaves as a 256-B store per 64 steps.  No LDS, no atomics, no per-step branches.
-//  backward: wave-uniform walk in vector registers: origin and direction word of the current cell come from
-//            ds_bpermute on the re-loaded chunks; results leave as coalesced 128-B chunks of u16
-//            (row position aligned to centre position p | gap flag << 15).
+// vector units, so the per-step work is split on purpose: the band steering (11 dependent integer ops on
+// wave-uniform values) runs on the scalar unit, everything else is vector code under one uniform branch.
+//  forward : lane k owns cell i = t + k of anti-diagonal s.  Per step, depending on the (uniform) move: two
+//            DPP shifts give the up / left / diagonal neighbours (the diagonal operand of the next step is this
+//            step's "left" operand, so no second history register has to be re-aligned), one DPP shift slides
+//            the resident centre or row bases and takes in the one base that enters the band, fetched one
+//            step earlier by a broadcast load.  Directions are packed 2 bits per step into a per-lane register
+//            and leave as one coalesced 256-B store per 16 steps, the moves as 16 bits per 16 steps.
+//            No LDS, no atomics.
+//  backward: wave-uniform walk kept in vector registers; the walk tracks the lane index k of the current cell
+//            (k changes by the stored moves), the direction word comes from ds_bpermute on the re-loaded chunk;
+//            results leave as coalesced 128-B chunks of u16 (row position aligned to centre position p |
+//            gap flag << 15).
 __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
     const int lane = threadIdx.x & 63;
     const int wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
     uint8_t *slot = P.tb + (size_t)wslot * P.tb_slot;
-    unsigned *tbd = reinterpret_cast<unsigned *>(slot);                                   // [(max_steps/16 + 2) * 64] direction words
-    int *tbt = reinterpret_cast<int *>(slot + (size_t)((P.max_steps >> 4) + 2) * 256);    // [max_steps + 64] band origins
+    unsigned *tbd = reinterpret_cast<unsigned *>(slot);                                     // [(max_steps/16 + 2) * 64] direction words
+    unsigned *tbm = reinterpret_cast<unsigned *>(slot + (size_t)((P.max_steps >> 4) + 2) * 256);  // [max_steps/16 + 2] move bits
     for (;;) {
         const unsigned int gq = wave_grab(P.counter);
         if ((int64_t)gq >= P.total_rows) break;
@@ -135,66 +136,65 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             if (areg == 'N') areg = 0xFD;
             breg = (jb >= 0 && jb < n) ? b[jb] : 0xFE;
         }
-        // bases that would enter the band at step 1: a[t + 63] on a down move, b[0 - t] on a right move
-        int na, nb;
+        // bases that would enter the band at step 1: a[t + 63] on a down move, b[0 - t] on a right move.
+        // Kept raw (+ in-range flag) and only turned into base-or-sentinel at the point of use, so that the
+        // broadcast load issued at step s is not waited for before the next move of the same kind.
+        int na_raw, nb_raw;
+        bool na_ok, nb_ok;
         {
             int ia = t + 63, jb = -t;
-            na = (ia >= 0 && ia < m) ? a[ia] : 0xFF;
-            if (na == 'N') na = 0xFD;
-            nb = (jb >= 0 && jb < n) ? b[jb] : 0xFE;
+            na_ok = ia >= 0 && ia < m; nb_ok = jb >= 0 && jb < n;
+            na_raw = a[na_ok ? ia : 0];
+            nb_raw = b[nb_ok ? jb : 0];
         }
-        unsigned dreg = 0;
-        int treg = 0;
+        unsigned dreg = 0, mreg = 0;
         int vz;  // an opaque vector zero: keeps the prefetch addressing on the vector unit (the scalar unit is the scarce one)
         asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+        const int m31 = m - 31, n1 = n + 1;
         const int nchunk = steps >> 4;
         for (int ch = 0; ch <= nchunk; ch++) {
             const int s_lo = ch == 0 ? 1 : ch << 4;
             const int s_hi = (ch << 4) + 15 < steps ? (ch << 4) + 15 : steps;
             for (int s = s_lo; s <= s_hi; s++) {
                 const int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);
-                int tn, sc0, sc1, sc2;
-                // band steering, pinned to the scalar unit:
-                //   move = h0 > h63 ? 0 : (h0 < h63 ? 1 : s & 1);  tn = t + move
-                //   if (tn > min(m, s) - 31) tn = t;  if (tn < max(0, s - n) - 32) tn = t + 1
+                int tn, sc0, sc1;
+                // band steering on the scalar unit (s31 = s - 31):
+                //   move = h0 > h63 ? 0 : (h0 < h63 ? 1 : s & 1)   ==  (h63 - h0 + (s & 1)) > 0
+                //   tn = max(min(t + move, min(m, s) - 31), max(0, s - n) - 32)      [t <= hi', lo' <= t + 1 always]
+                const int s31 = s - 31;
                 asm volatile(
-                    "s_and_b32 %1, %5, 1\n\t"
-                    "s_cmp_ge_i32 %6, %7\n\t"
-                    "s_cselect_b32 %1, %1, 1\n\t"
-                    "s_cmp_gt_i32 %6, %7\n\t"
-                    "s_cselect_b32 %1, 0, %1\n\t"
-                    "s_add_i32 %0, %4, %1\n\t"
-                    "s_min_i32 %2, %8, %5\n\t"
-                    "s_sub_i32 %2, %2, 31\n\t"
-                    "s_cmp_gt_i32 %0, %2\n\t"
-                    "s_cselect_b32 %0, %4, %0\n\t"
-                    "s_sub_i32 %3, %5, %9\n\t"
-                    "s_max_i32 %3, %3, 0\n\t"
-                    "s_sub_i32 %3, %3, 32\n\t"
-                    "s_add_i32 %2, %4, 1\n\t"
-                    "s_cmp_lt_i32 %0, %3\n\t"
-                    "s_cselect_b32 %0, %2, %0"
-                    : "=&s"(tn), "=&s"(sc0), "=&s"(sc1), "=&s"(sc2)
-                    : "s"(t), "s"(s), "s"(h0), "s"(h63), "s"(m), "s"(n)
+                    "s_and_b32 %1, %4, 1\n\t"
+                    "s_sub_i32 %2, %6, %5\n\t"
+                    "s_add_i32 %2, %2, %1\n\t"
+                    "s_cmp_gt_i32 %2, 0\n\t"
+                    "s_addc_u32 %0, %3, 0\n\t"
+                    "s_min_i32 %1, %7, %8\n\t"
+                    "s_min_i32 %0, %0, %1\n\t"
+                    "s_sub_i32 %2, %8, %9\n\t"
+                    "s_max_i32 %2, %2, -32\n\t"
+                    "s_max_i32 %0, %0, %2"
+                    : "=&s"(tn), "=&s"(sc0), "=&s"(sc1)
+                    : "s"(t), "s"(s), "s"(h0), "s"(h63), "s"(m31), "s"(s31), "s"(n1)
                     : "scc");
-                const bool down = tn != t;  // wave-uniform
-                // neighbours: down -> (left, up) = (H(s-1)[k+1], H(s-1)[k]);  right -> (H(s-1)[k], H(s-1)[k-1])
-                const int nxt = from_next_lane0(prev), prv = from_prev_lane0(prev), pps = from_prev_lane0(ppal);
-                const int hl = down ? nxt : prev;
-                const int hu = down ? prev : prv;
-                const int hd = down ? ppal : pps;
-                // resident bases: down -> centre bases slide towards lane 0, right -> row bases towards lane 63
-                const int an = from_next_lane(areg, na), bn = from_prev_lane(breg, nb);
-                areg = down ? an : areg;
-                breg = down ? breg : bn;
-                // prefetch the bases that can enter at step s+1 (same address in every lane -> broadcast load)
-                {
-                    const int ia = tn + 63 + vz, jb = s - tn + vz;
-                    const bool oka = (unsigned)ia < (unsigned)m, okb = (unsigned)jb < (unsigned)n;
-                    int xa = a[oka ? ia : 0], xb = b[okb ? jb : 0];
-                    xa = oka ? xa : 0xFF;
-                    na = xa == 'N' ? 0xFD : xa;
-                    nb = okb ? xb : 0xFE;
+                int hl, hu, hd;
+                if (tn != t) {
+                    // down: (left, up, diag) = (H(s-1)[k+1], H(s-1)[k], H(s-2)[k]); centre bases slide towards lane 0
+                    hl = from_next_lane0(prev); hu = prev; hd = ppal;
+                    const int na = na_ok ? (na_raw == 'N' ? 0xFD : na_raw) : 0xFF;
+                    areg = from_next_lane(areg, na);
+                    const int ia = tn + 63 + vz;
+                    na_ok = (unsigned)ia < (unsigned)m;
+                    na_raw = a[na_ok ? ia : 0];
+                    mreg = (mreg << 1) | 1u;
+                } else {
+                    // right: (left, up, diag) = (H(s-1)[k], H(s-1)[k-1], H(s-2)[k-1]); row bases slide towards lane 63
+                    hl = prev; hu = from_prev_lane0(prev); hd = from_prev_lane0(ppal);
+                    const int nb = nb_ok ? nb_raw : 0xFE;
+                    breg = from_prev_lane(breg, nb);
+                    const int jb = s - tn + vz;
+                    nb_ok = (unsigned)jb < (unsigned)n;
+                    nb_raw = b[nb_ok ? jb : 0];
+                    mreg = mreg << 1;
                 }
                 const int cd = hd + (areg == breg ? SC_MATCH : SC_MIS);
                 const int cu = hu + SC_GAP, cl = hl + SC_GAP;
@@ -203,12 +203,12 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
                 // direction: 0 diag (cd is the max), else 1 up (cu >= cl), else 2 left
                 const unsigned d = cd == v ? 0u : (cu >= cl ? 1u : 2u);
                 dreg = (dreg << 2) | d;
-                if (lane == (s & 63)) treg = tn;
                 ppal = hl; prev = v; t = tn;
             }
-            tbd[ch * 64 + lane] = dreg << (2 * (15 - (s_hi & 15)));
-            dreg = 0;
-            if ((ch & 3) == 3 || ch == nchunk) tbt[(ch >> 2) * 64 + lane] = treg;
+            const int sh = 15 - (s_hi & 15);
+            tbd[ch * 64 + lane] = dreg << (2 * sh);
+            if (lane == 0) tbm[ch] = (mreg << sh) & 0xffffu;   // bit (15 - (s & 15)) = move of step s
+            dreg = 0; mreg = 0;
         }
         {
             const int kf = m - t;
@@ -220,31 +220,40 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         // ---------------- traceback: wave-uniform walk kept in vector registers ----------------
-        int i = m, j = n;                 // every lane carries the same (i, j)
-        int dchunk = -1, tchunk = -1;     // loaded chunks (scalar)
+        int i = m + vz, j = n + vz;       // every lane carries the same (i, j)
+        int k = m - t + vz;               // lane that owns cell (i, j) on anti-diagonal i + j
+        int dchunk = -1;                  // loaded chunk (scalar)
         unsigned wcur = 0;                // this lane's direction word of the 16-step chunk
-        int tcur = 0;                     // this lane's band origin of step (tchunk*64 + lane)
-        int oreg = 0, fail = 0;
-        while (i > 0) {
+        unsigned mm = 0;                  // moves: chunk of s in bits 16..31, the chunk below in bits 0..15
+        int oreg = 0, fail = 0, bad = 0;
+        while (__builtin_amdgcn_readfirstlane(i) > 0) {
             const int s = i + j;
             const int sq = __builtin_amdgcn_readfirstlane(s);
-            if ((sq >> 4) != dchunk) { dchunk = sq >> 4; wcur = tbd[dchunk * 64 + lane]; }
-            if ((sq >> 6) != tchunk) { tchunk = sq >> 6; tcur = tbt[tchunk * 64 + lane]; }
-            const int ts = __builtin_amdgcn_ds_bpermute((s & 63) << 2, tcur);   // origin of anti-diagonal s
-            const int k = i - ts;
-            if (__builtin_amdgcn_readfirstlane((unsigned)k > 63u)) { fail = 1; break; }
-            const unsigned wsel = (unsigned)__builtin_amdgcn_ds_bpermute(k << 2, (int)wcur);
-            int d = (int)((wsel >> (2 * (15 - (s & 15)))) & 3u);
+            if ((sq >> 4) != dchunk) {
+                dchunk = sq >> 4;
+                wcur = tbd[dchunk * 64 + lane];
+                const unsigned mc = tbm[dchunk], mp = dchunk > 0 ? tbm[dchunk - 1] : 0u;
+                mm = (mc << 16) | mp;
+            }
+            bad |= (unsigned)k > 63u;
+            const unsigned wsel = (unsigned)__builtin_amdgcn_ds_bpermute((k & 63) << 2, (int)wcur);
+            const int r = s & 15;
+            int d = (int)((wsel >> (2 * (15 - r))) & 3u);
             d = j == 0 ? 1 : d;
+            // moves of steps s (bit 31 - r) and s-1 (bit 30 - r; falls into the lower chunk when r == 0)
+            const int mv_s = (int)((mm >> (31 - r)) & 1u), mv_s1 = (int)((mm >> (30 - r)) & 1u);
             const bool isleft = d == 2, isdiag = d == 0;
             // centre position p = i-1: aligned to row position j-1 (diag) or to a gap before row position j (up)
             const int p = i - 1;
             const int val = isdiag ? (j - 1) : (j | 0x8000);
             if (!isleft && lane == (p & 63)) oreg = val;
             if (__builtin_amdgcn_readfirstlane((!isleft && (p & 63) == 0) ? 1 : 0)) { if (p + lane < m) ops[p + lane] = (uint16_t)oreg; }
+            // predecessor cell: left (i, j-1): k + mv_s; up (i-1, j): k - 1 + mv_s; diag (i-1, j-1): k - 1 + mv_s + mv_s1
+            k += mv_s - (isleft ? 0 : 1) + (isdiag ? mv_s1 : 0);
             i -= isleft ? 0 : 1;
             j -= d == 1 ? 0 : 1;
         }
+        fail = __builtin_amdgcn_readfirstlane(bad);
         if (fail && lane == 0) atomicExch(&P.status[c], 1);
     }
 }
@@ -349,7 +358,7 @@ extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win,
     if (!ctx || n < 0 || total_rows < 0 || max_win_len <= 0) return HITE_EINVAL;
     if (n == 0) return HITE_OK;
     const int max_steps = 2 * max_win_len;
-    size_t tb_slot = (size_t)((max_steps >> 4) + 2) * 256 + (size_t)(max_steps + 64) * 4;
+    size_t tb_slot = (size_t)((max_steps >> 4) + 2) * 256 + (size_t)((max_steps >> 4) + 4) * 4;
     tb_slot = (tb_slot + 63) & ~(size_t)63;
     int64_t pairs = total_rows - n;
     int grid = (int)((pairs + 3) / 4);
