@@ -224,7 +224,7 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         int k = m - t + vz;               // lane that owns cell (i, j) on anti-diagonal i + j
         int dchunk = -1;                  // loaded chunk (scalar)
         unsigned wcur = 0;                // this lane's direction word of the 16-step chunk
-        unsigned mm = 0;                  // moves: chunk of s in bits 16..31, the chunk below in bits 0..15
+        unsigned mm = 0;                  // moves: chunk of s in bits 0..15, the chunk below in bits 16..31
         int oreg = 0, fail = 0, bad = 0;
         while (__builtin_amdgcn_readfirstlane(i) > 0) {
             const int s = i + j;
@@ -233,15 +233,15 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
                 dchunk = sq >> 4;
                 wcur = tbd[dchunk * 64 + lane];
                 const unsigned mc = tbm[dchunk], mp = dchunk > 0 ? tbm[dchunk - 1] : 0u;
-                mm = (mc << 16) | mp;
+                mm = (mp << 16) | mc;
             }
             bad |= (unsigned)k > 63u;
             const unsigned wsel = (unsigned)__builtin_amdgcn_ds_bpermute((k & 63) << 2, (int)wcur);
             const int r = s & 15;
             int d = (int)((wsel >> (2 * (15 - r))) & 3u);
             d = j == 0 ? 1 : d;
-            // moves of steps s (bit 31 - r) and s-1 (bit 30 - r; falls into the lower chunk when r == 0)
-            const int mv_s = (int)((mm >> (31 - r)) & 1u), mv_s1 = (int)((mm >> (30 - r)) & 1u);
+            // moves of steps s (bit 15 - r) and s-1 (bit 16 - r: bit 0 of the lower chunk when r == 0)
+            const int mv_s = (int)((mm >> (15 - r)) & 1u), mv_s1 = (int)((mm >> (16 - r)) & 1u);
             const bool isleft = d == 2, isdiag = d == 0;
             // centre position p = i-1: aligned to row position j-1 (diag) or to a gap before row position j (up)
             const int p = i - 1;
