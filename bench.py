@@ -30,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--genome-mbp", type=int, default=int(os.environ.get("HITE_BENCH_MBP", 1000)))
     ap.add_argument("--tir-families", type=int, default=None)
     ap.add_argument("--ltr-families", type=int, default=None)
@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20250927 + 3)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify", type=int, default=0, help="re-judge this many random candidates with the CPU oracle chain and compare")
     args = ap.parse_args()
 
     import torch
@@ -171,9 +172,38 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+        if args.verify > 0:
+            out["verify"] = verify(w, calls, d_cons.cpu().numpy(), args.verify)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
+
+
+def verify(w, calls, cons, count):
+    """full-size parity spot check: the oracle chain on random candidates of THIS workload vs the GPU calls"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_pipeline as OP
+
+    co = w["contig_off"]
+    g = w["genome"]
+    host = g.cpu().numpy() if hasattr(g, "cpu") else g
+    contigs = {ci: host[co[ci]:co[ci + 1]].tobytes() for ci in range(len(co) - 1)}
+    n_cand = len(w["cand_off"]) - 1
+    rng = np.random.default_rng(12345)
+    bad = []
+    info_names = {0: "", 1: "nb", 2: "fl1", 3: "EXC"}
+    picks = rng.permutation(n_cand)[:count]
+    for c in picks:
+        a, b = int(w["copy_first"][c]), int(w["copy_first"][c + 1])
+        copies = [(int(w["contig"][i]), int(w["start1"][i]), int(w["end1"][i]), int(w["minus"][i])) for i in range(a, b)]
+        cand = w["cands"][w["cand_off"][c]:w["cand_off"][c + 1]].tobytes().decode()
+        exp = OP.fine_stage_candidate("tir", cand, copies, contigs, plant=1)
+        r = calls[c]
+        got = [bool(r["is_te"]), info_names[int(r["info"])],
+               cons[r["cons_off"]:r["cons_off"] + r["cons_len"]].tobytes().decode() if r["is_te"] else "", int(r["row_num"])]
+        if got != exp:
+            bad.append(int(c))
+    return {"checked": int(len(picks)), "mismatches": len(bad), "bad_candidates": bad[:10]}
 
 
 def cpu_baseline(w, budget_s):

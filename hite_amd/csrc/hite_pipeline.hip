@@ -28,8 +28,8 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
 struct Arena {
     std::vector<void *> chunks;
     std::vector<size_t> caps;
-    size_t off = 0;
-    size_t high = 0;  // bytes handed out since the last reset
+    size_t cur = 0;   // chunk being filled
+    size_t off = 0;   // bytes used in it
 };
 struct PipeState {
     Arena keep, tmp;
@@ -40,41 +40,46 @@ struct PipeState {
 static int arena_alloc(hite_ctx *ctx, Arena &a, size_t bytes, void **out) {
     bytes = (bytes + 255) & ~(size_t)255;
     if (bytes == 0) bytes = 256;
-    if (a.chunks.empty() || a.off + bytes > a.caps.back()) {
+    // first chunk (from the current one on) that still has room
+    while (a.cur < a.chunks.size() && a.off + bytes > a.caps[a.cur]) { a.cur++; a.off = 0; }
+    if (a.cur >= a.chunks.size()) {
         size_t want = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
         void *p = nullptr;
         HITE_CHECK(ctx, hipMalloc(&p, want));
         a.chunks.push_back(p);
         a.caps.push_back(want);
+        a.cur = a.chunks.size() - 1;
         a.off = 0;
     }
-    *out = (uint8_t *)a.chunks.back() + a.off;
+    *out = (uint8_t *)a.chunks[a.cur] + a.off;
     a.off += bytes;
-    a.high += bytes;
     return HITE_OK;
 }
-// after use: if the arena fragmented into several chunks, replace them by one of the total size
-static int arena_reset(hite_ctx *ctx, Arena &a, bool may_sync) {
-    if (a.chunks.size() > 1 && may_sync) {
+// soft reset: hand the same memory out again (stream order protects the reuse).
+// hard reset (start of a call): if the arena grew into several chunks, replace them by one chunk of
+// the total capacity, so that the steady state never calls hipMalloc.
+static int arena_reset(hite_ctx *ctx, Arena &a, bool hard) {
+    if (hard && a.chunks.size() > 1) {
         HITE_CHECK(ctx, hipDeviceSynchronize());
+        size_t total = 0;
+        for (size_t c : a.caps) total += c;
         for (void *p : a.chunks) (void)hipFree(p);
         a.chunks.clear();
         a.caps.clear();
-        size_t want = a.high + a.high / 8 + ((size_t)16 << 20);
         void *p = nullptr;
-        HITE_CHECK(ctx, hipMalloc(&p, want));
+        HITE_CHECK(ctx, hipMalloc(&p, total));
         a.chunks.push_back(p);
-        a.caps.push_back(want);
+        a.caps.push_back(total);
     }
+    a.cur = 0;
     a.off = 0;
-    a.high = 0;
     return HITE_OK;
 }
 static void arena_free(Arena &a) {
     for (void *p : a.chunks) (void)hipFree(p);
     a.chunks.clear();
     a.caps.clear();
-    a.off = a.high = 0;
+    a.cur = a.off = 0;
 }
 
 extern "C" void hite_pipeline_release(void *state) {
