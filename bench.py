@@ -136,6 +136,13 @@ def main():
         kern = {}
         for k, (ms, cnt) in prof.items():
             kern[k] = {"ms_per_step": ms / args.steps, "launches_per_step": cnt / args.steps}
+        # the library times the two passes of a step separately; fold them per kernel for the roofline
+        merged = {}
+        for k, (ms, cnt) in prof.items():
+            base = k.replace("_passA", "").replace("_passB", "").replace("_long", "").replace("_short", "")
+            a, b = merged.get(base, (0.0, 0))
+            merged[base] = (a + ms, b + cnt)
+        prof = merged
         dom = max(prof.items(), key=lambda kv: kv[1][0])[0] if prof else None
         roof = None
         if dom:

@@ -378,7 +378,7 @@ extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win,
     P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first;
     P.ops_base = d_ops_base; P.ops = (uint16_t *)opsb; P.cols_out = d_cols_out; P.status = d_status;
     P.tb = (uint8_t *)scr; P.tb_slot = tb_slot; P.max_steps = max_steps; P.counter = counter;
-    int tk = hite_prof_begin(ctx, "star_align_kernel", st);
+    int tk = hite_prof_begin(ctx, max_win_len > 1000 ? "star_align_kernel_long" : "star_align_kernel_short", st);
     hipLaunchKernelGGL(star_align_kernel, dim3(grid), dim3(256), 0, st, P);
     hite_prof_end(ctx, tk, st);
     HITE_CHECK(ctx, hipGetLastError());

@@ -20,6 +20,10 @@
  *   cannot beat a real score), values shifted in from outside the band are 0 and real scores
  *   are biased by 2^28 (H(0,0) = 2^28); an 'N' in the centre never matches.  The alignment
  *   fails if H(m,n) <= 2^27 (end cell not reachable inside the band).
+ *   The diagonal operand is carried in ONE history register H(s-2)' = H(s-2) re-aligned to the
+ *   origin of anti-diagonal s-1, which is simply the previous step's "left" operand; an element
+ *   that was shifted out of the band by that re-alignment is gone (0) even if a later move
+ *   would shift it back in.
  *   Ties in the recurrence: diag >= up >= left.
  *   Traceback from (m,n) gives per centre position p: gap flag (row has '-') and the number of
  *   row bases inserted before p.  Columns: for p = 0..m an insertion block of
@@ -45,10 +49,11 @@ static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t
     /* direction codes per (s, lane) and the band origin t per s */
     uint8_t *dir = (uint8_t *)malloc((size_t)(steps + 1) * W);
     int *ts = (int *)malloc(sizeof(int) * (steps + 1));
-    int prev[W], pprev[W], cur[W];
+    int prev[W], cur[W];
     if (!dir || !ts) { free(dir); free(ts); return ORC_EINVAL; }
-    int t = -32, tp = -32, tpp = -32;
-    for (int k = 0; k < W; k++) { prev[k] = 0; pprev[k] = 0; }
+    int t = -32;
+    int ppal[W]; /* H(s-2) re-aligned to the origin of anti-diagonal s-1 (see header) */
+    for (int k = 0; k < W; k++) { prev[k] = 0; ppal[k] = 0; }
     prev[32] = BIAS; /* H(0,0) */
     ts[0] = t;
     for (int s = 1; s <= steps; s++) {
@@ -60,14 +65,15 @@ static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t
         int tn = t + move;
         if (tn > hi - 31) tn = t;
         if (tn < lo - 32) tn = t + 1;
-        tpp = tp; tp = t; t = tn;
-        /* now t = origin of s, tp = origin of s-1, tpp = origin of s-2 */
+        int down = tn != t;
+        int hlv[W];
         for (int k = 0; k < W; k++) {
-            int i = t + k, j = s - i;
-            int lu = i - 1 - tp, ll = i - tp, ld = i - 1 - tpp;
-            int hu = (lu >= 0 && lu < W) ? prev[lu] : 0;
-            int hl = (ll >= 0 && ll < W) ? prev[ll] : 0;
-            int hd = (ld >= 0 && ld < W) ? pprev[ld] : 0;
+            int i = tn + k, j = s - i;
+            /* down : (left, up, diag) = (H(s-1)[k+1], H(s-1)[k],   H(s-2)'[k])
+             * right: (left, up, diag) = (H(s-1)[k],   H(s-1)[k-1], H(s-2)'[k-1])   0 from outside the band */
+            int hl = down ? (k + 1 < W ? prev[k + 1] : 0) : prev[k];
+            int hu = down ? prev[k] : (k >= 1 ? prev[k - 1] : 0);
+            int hd = down ? ppal[k] : (k >= 1 ? ppal[k - 1] : 0);
             int x = (i >= 1 && i <= m) ? a[i - 1] : 0xFF;
             int y = (j >= 1 && j <= n) ? b[j - 1] : 0xFE;
             if (x == 'N') x = 0xFD;
@@ -78,10 +84,12 @@ static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t
             else if (cu >= cl) { v = cu; d = 1; }
             else { v = cl; d = 2; }
             cur[k] = v;
+            hlv[k] = hl;
             dir[(size_t)s * W + k] = (uint8_t)d;
         }
-        memcpy(pprev, prev, sizeof prev);
+        memcpy(ppal, hlv, sizeof hlv); /* this step's "left" operand is the next step's re-aligned H(s-2) */
         memcpy(prev, cur, sizeof cur);
+        t = tn;
         ts[s] = t;
     }
     {
