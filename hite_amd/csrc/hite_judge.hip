@@ -34,6 +34,7 @@ struct JShared {
     int res[4];            // per-wave window results
     uint8_t flag[JB];
     uint8_t pat[2][24];    // anchor patterns
+    unsigned peq[8];       // Myers match masks per symbol class
     int tsd[25];
     int fo[5], eo[5];
 };
@@ -117,26 +118,61 @@ __device__ int blk_ungap_row(const uint8_t *__restrict__ row, int C, uint8_t *__
 // ---------------------------------------------------------------------------------------------
 __device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ ung, int n, int k,
                        uint8_t *__restrict__ minfo, int side, JShared &S) {
-    for (int s = threadIdx.x; s < n; s += JB) {
-        int w = (m + k) < (n - s) ? (m + k) : (n - s);
-        uint8_t maxL = 0, best = 0;
-        if (!(w < m - k || w <= 0)) {
-            int d[5];
-            banded_dist(pat, m, ung + s, w, k, d);
-            int bd = 3, bL = 0;
-            int L0 = m - k > 1 ? m - k : 1;
-            for (int L = L0; L <= w && L <= m + k; L++) {
-                int dd = d[L - (m - 2)];
-                if (dd <= k) {
-                    maxL = (uint8_t)L;
-                    if (dd < bd || (dd == bd && L > bL)) { bd = dd; bL = L; }
+    // Phase 1 (filter): Myers' bit-parallel approximate search.  Each thread scans a chunk of end positions
+    // (plus m+k characters of warm-up, which makes every distance <= k exact) and flags the ends where
+    // the pattern matches within k edits; 17 word operations per character instead of one banded DP per start.
+    // Phase 2: the exact per-start banded DP runs only for the <= 2k+1 starts that can end at a flagged position.
+    for (int i = threadIdx.x; i < 2 * n; i += JB) minfo[i] = 0;
+    if (threadIdx.x < 8) {
+        unsigned mk = 0;
+        for (int i = 0; i < m; i++) if (sym_class(pat[i]) == (int)threadIdx.x) mk |= 1u << i;
+        S.peq[threadIdx.x] = mk;
+    }
+    __syncthreads();
+    {
+        int L = (n + JB - 1) / JB;
+        if (L < 16) L = 16;
+        const int cs = threadIdx.x * L;            // ends [cs, cs + L) belong to this thread (end = index of last char)
+        if (cs < n) {
+            const int ce = cs + L < n ? cs + L : n;
+            int j0 = cs - (m + k); if (j0 < 0) j0 = 0;
+            unsigned Pv = 0xffffffffu, Mv = 0;
+            int score = m;
+            const unsigned top = 1u << (m - 1);
+            for (int j = j0; j < ce; j++) {
+                const unsigned Eq = S.peq[sym_class(ung[j])];
+                const unsigned Xv = Eq | Mv;
+                const unsigned Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                unsigned Ph = Mv | ~(Xh | Pv);
+                unsigned Mh = Pv & Xh;
+                score += (Ph & top) ? 1 : 0;
+                score -= (Mh & top) ? 1 : 0;
+                Ph <<= 1; Mh <<= 1;
+                Pv = Mh | ~(Xv | Ph);
+                Mv = Ph & Xv;
+                if (j >= cs && score <= k) {
+                    // a match ends at character j (exclusive end e = j + 1): starts e-(m+k) .. e-(m-k)
+                    const int e = j + 1;
+                    int s0 = e - (m + k); if (s0 < 0) s0 = 0;
+                    int s1 = e - (m - k); if (s1 < 0) s1 = 0;
+                    for (int st = s0; st <= s1 && st < n; st++) {
+                        int w = (m + k) < (n - st) ? (m + k) : (n - st);
+                        if (w < m - k || w <= 0) continue;
+                        int d[5];
+                        banded_dist(pat, m, ung + st, w, k, d);
+                        int bd = 3, bL = 0, maxL = 0;
+                        int L0 = m - k > 1 ? m - k : 1;
+                        for (int LL = L0; LL <= w && LL <= m + k; LL++) {
+                            int dd = d[LL - (m - 2)];
+                            if (dd <= k) { maxL = LL; if (dd < bd || (dd == bd && LL > bL)) { bd = dd; bL = LL; } }
+                        }
+                        if (maxL) { minfo[2 * st] = (uint8_t)maxL; minfo[2 * st + 1] = (uint8_t)((bd << 5) | bL); }
+                    }
                 }
             }
-            best = (uint8_t)((bd << 5) | bL);
         }
-        minfo[2 * s] = maxL;
-        minfo[2 * s + 1] = best;
     }
+    __syncthreads();
     if (threadIdx.x == 0) { S.red[0] = 0xffffffffu; S.red[1] = 0u; S.red[2] = 0xffffffffu; S.red[3] = 0xffffffffu; }
     __syncthreads();
     // group starts: a start with a match that no earlier match overlaps
@@ -721,8 +757,12 @@ __device__ void judge_tir_tail(const JudgeParams &P, const uint8_t *msa, int R, 
     __syncthreads();
     if (threadIdx.x == 0) { S.red[4] = 0xffffffffu; S.red[5] = 0u; }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += JB)
-        if (2 * (int)cstat[(size_t)c * CS + 5] <= rn) { atomicMin(&S.red[4], (unsigned)c); atomicMax(&S.red[5], (unsigned)c + 1u); }
+    {
+        unsigned lmin = 0xffffffffu, lmax = 0u;
+        for (int c = threadIdx.x; c < C; c += JB)
+            if (2 * (int)cstat[(size_t)c * CS + 5] <= rn) { if ((unsigned)c < lmin) lmin = (unsigned)c; lmax = (unsigned)c + 1u; }
+        if (lmax) { atomicMin(&S.red[4], lmin); atomicMax(&S.red[5], lmax); }
+    }
     __syncthreads();
     int vl = S.red[4] == 0xffffffffu ? -1 : (int)S.red[4];
     int vr = (int)S.red[5] - 1;
