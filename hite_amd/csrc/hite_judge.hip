@@ -35,6 +35,8 @@ struct JShared {
     uint8_t flag[JB];
     uint8_t pat[2][24];    // anchor patterns
     unsigned peq[8];       // Myers match masks per symbol class
+    int nflag;             // flagged match ends of the current anchor search
+    int flagged[64];
     int tsd[25];
     int fo[5], eo[5];
 };
@@ -127,11 +129,12 @@ __device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ un
         unsigned mk = 0;
         for (int i = 0; i < m; i++) if (sym_class(pat[i]) == (int)threadIdx.x) mk |= 1u << i;
         S.peq[threadIdx.x] = mk;
+        if (threadIdx.x == 0) S.nflag = 0;
     }
     __syncthreads();
     {
         int L = (n + JB - 1) / JB;
-        if (L < 16) L = 16;
+        if (L < 6) L = 6;
         const int cs = threadIdx.x * L;            // ends [cs, cs + L) belong to this thread (end = index of last char)
         if (cs < n) {
             const int ce = cs + L < n ? cs + L : n;
@@ -151,25 +154,36 @@ __device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ un
                 Pv = Mh | ~(Xv | Ph);
                 Mv = Ph & Xv;
                 if (j >= cs && score <= k) {
-                    // a match ends at character j (exclusive end e = j + 1): starts e-(m+k) .. e-(m-k)
-                    const int e = j + 1;
-                    int s0 = e - (m + k); if (s0 < 0) s0 = 0;
-                    int s1 = e - (m - k); if (s1 < 0) s1 = 0;
-                    for (int st = s0; st <= s1 && st < n; st++) {
-                        int w = (m + k) < (n - st) ? (m + k) : (n - st);
-                        if (w < m - k || w <= 0) continue;
-                        int d[5];
-                        banded_dist(pat, m, ung + st, w, k, d);
-                        int bd = 3, bL = 0, maxL = 0;
-                        int L0 = m - k > 1 ? m - k : 1;
-                        for (int LL = L0; LL <= w && LL <= m + k; LL++) {
-                            int dd = d[LL - (m - 2)];
-                            if (dd <= k) { maxL = LL; if (dd < bd || (dd == bd && LL > bL)) { bd = dd; bL = LL; } }
-                        }
-                        if (maxL) { minfo[2 * st] = (uint8_t)maxL; minfo[2 * st + 1] = (uint8_t)((bd << 5) | bL); }
-                    }
+                    // a match ends at character j: remember the exclusive end e = j + 1
+                    const int q = atomicAdd(&S.nflag, 1);
+                    if (q < 64) S.flagged[q] = j + 1;
                 }
             }
+        }
+    }
+    __syncthreads();
+    {
+        // Phase 2: exact banded DP for the starts e-(m+k) .. e-(m-k) of every flagged end, one (end, start)
+        // pair per thread; if the list overflowed (repetitive text) fall back to every start.
+        const int nf = S.nflag;
+        const int span = 2 * k + 1;
+        const int ntask = nf <= 64 ? nf * span : n;
+        for (int tsk = threadIdx.x; tsk < ntask; tsk += JB) {
+            int st;
+            if (nf <= 64) { st = S.flagged[tsk / span] - (m + k) + (tsk % span); if (st < 0) continue; }
+            else st = tsk;
+            if (st >= n) continue;
+            int w = (m + k) < (n - st) ? (m + k) : (n - st);
+            if (w < m - k || w <= 0) continue;
+            int d[5];
+            banded_dist(pat, m, ung + st, w, k, d);
+            int bd = 3, bL = 0, maxL = 0;
+            int L0 = m - k > 1 ? m - k : 1;
+            for (int LL = L0; LL <= w && LL <= m + k; LL++) {
+                int dd = d[LL - (m - 2)];
+                if (dd <= k) { maxL = LL; if (dd < bd || (dd == bd && LL > bL)) { bd = dd; bL = LL; } }
+            }
+            if (maxL) { minfo[2 * st] = (uint8_t)maxL; minfo[2 * st + 1] = (uint8_t)((bd << 5) | bL); }
         }
     }
     __syncthreads();
