@@ -1,0 +1,224 @@
+"""Host-side mirror of the reference's function interface for the dynamic-boundary path
+(/root/reference/module/Util.py).  Same names, argument meaning and file contracts; the
+arithmetic runs in libhite_gpu.so through `hite_amd._lib` (no CPU fallback).
+
+What is NOT reproduced here (third-party tools the reference shells out to, outside this build):
+`minimap2` copy finding (pass `all_copies=` or a `copy_finder=` callable to flank_region_align_v5),
+and the low-copy rescue by trf / itrsearch / blastx (Util.py:8196-8281): low-copy elements are
+written to `all_low_copy` exactly like the reference does, nothing is rescued.
+"""
+import os
+import re
+
+import numpy as np
+
+from ._lib import Context
+
+_CTX = None
+_PACKED = {"path": None, "names": None, "lens": None}
+
+
+def get_ctx(device=0):
+    global _CTX
+    if _CTX is None:
+        _CTX = Context(device)
+    return _CTX
+
+
+# ---- FASTA (Util.py:1650-1670, 1983-1988) ---------------------------------------------------------
+def read_fasta(fasta_path):
+    contignames, contigs = [], {}
+    if os.path.exists(fasta_path):
+        name, chunks = "", []
+        with open(fasta_path, "r") as rf:
+            for line in rf:
+                if line.startswith(">"):
+                    if name != "" and chunks:
+                        contigs[name] = "".join(chunks)
+                        contignames.append(name)
+                    name = line.strip()[1:].split(" ")[0].split("\t")[0]
+                    chunks = []
+                else:
+                    chunks.append(line.strip().upper())
+            if name != "" and chunks:
+                contigs[name] = "".join(chunks)
+                contignames.append(name)
+    return contignames, contigs
+
+
+def store_fasta(contigs, file_path):
+    with open(file_path, "w") as f:
+        for name, seq in contigs.items():
+            f.write(">" + name + "\n" + seq + "\n")
+
+
+def set_reference(reference, device=0):
+    """pack the genome into HBM once per process (replaces the per-stage read_fasta(reference))"""
+    ctx = get_ctx(device)
+    if _PACKED["path"] != os.path.abspath(reference):
+        names, contigs = read_fasta(reference)
+        ctx.genome_pack([contigs[n] for n in names])
+        _PACKED.update(path=os.path.abspath(reference), names={n: i for i, n in enumerate(names)},
+                       lens=[len(contigs[n]) for n in names])
+    return ctx
+
+
+def _read_alignment(align_file):
+    names, contigs = read_fasta(align_file)
+    if not names:
+        return names, None
+    rows = [contigs[n] for n in names]
+    width = len(rows[0])
+    if any(len(r) != width for r in rows):
+        raise ValueError("alignment rows differ in length: " + align_file)
+    return names, np.frombuffer("".join(rows).encode(), dtype=np.uint8).reshape(len(rows), width).copy()
+
+
+# ---- a-14 .. a-21 ------------------------------------------------------------------------------------
+def remove_sparse_col_in_align_file(align_file):
+    """Util.py:10344-10405: writes <align_file>.clean.fa and returns its path"""
+    names, m = _read_alignment(align_file)
+    clean = get_ctx().sparse_cols([m])[0]
+    out = align_file + ".clean.fa"
+    with open(out, "w") as f:
+        for n, r in zip(names, clean):
+            f.write(">" + n + "\n" + r.tobytes().decode() + "\n")
+    return out
+
+
+def _judge(te_type, cur_seq, align_file, plant, result_type):
+    if result_type != "cons":
+        raise NotImplementedError("only result_type='cons' (the only value the reference's callers pass)")
+    names, m = _read_alignment(align_file)
+    if m is None:
+        return False, "nb", "", 0
+    r = get_ctx().judge(te_type, [m], [cur_seq], plant=int(plant))[0]
+    if r[1] == "EXC":
+        raise RuntimeError("the reference raises on this input (empty candidate / no full-length row / index error)")
+    return r[0], r[1], r[2], r[3]
+
+
+def judge_boundary_v5(cur_seq, align_file, debug, TE_type, plant, result_type):
+    """Util.py:9145-9480 (TIR)"""
+    return _judge("tir", cur_seq, align_file, plant, result_type)
+
+
+def judge_boundary_v6(cur_seq, align_file, debug, TE_type, plant, result_type):
+    """Util.py:9821-10159 (Helitron)"""
+    return _judge("helitron", cur_seq, align_file, plant, result_type)
+
+
+def judge_boundary_v9(cur_seq, align_file, debug, TE_type, plant, result_type):
+    """Util.py:9483-9720 (non-LTR)"""
+    return _judge("non_ltr", cur_seq, align_file, plant, result_type)
+
+
+def TSDsearch_v5(raw_align_seq, cur_boundary_start, cur_boundary_end, plant):
+    """Util.py:2460-2492"""
+    l, r, _k = get_ctx().tsd_search([raw_align_seq], [cur_boundary_start], [cur_boundary_end], int(plant))[0]
+    return l, r
+
+
+def search_boundary_homo_v3(valid_col_threshold, pos, matrix, row_num, col_num, type, homo_threshold, debug,
+                            int_sliding_window_size, out_sliding_window_size):
+    """Util.py:8887-9143; `matrix` = list of rows (lists/strings of single characters)"""
+    m = np.frombuffer("".join("".join(r) for r in matrix).encode(), dtype=np.uint8).reshape(row_num, col_num).copy()
+    b, _ = get_ctx().boundary_search([m], [pos], [type], [homo_threshold], variant=3, win_in=int_sliding_window_size,
+                                     win_out=out_sliding_window_size)
+    return int(b[0])
+
+
+def search_boundary_homo_v4(valid_col_threshold, pos, matrix, row_num, col_num, type, homo_threshold, int_homo_threshold,
+                            out_homo_threshold, debug, int_sliding_window_size, out_sliding_window_size):
+    """Util.py:8556-8824"""
+    m = np.frombuffer("".join("".join(r) for r in matrix).encode(), dtype=np.uint8).reshape(row_num, col_num).copy()
+    b, v = get_ctx().boundary_search([m], [pos], [type], [homo_threshold], variant=4, int_thr=[int_homo_threshold],
+                                     out_thr=[out_homo_threshold], win_in=int_sliding_window_size,
+                                     win_out=out_sliding_window_size)
+    return bool(v[0]), int(b[0])
+
+
+# ---- a-6 ---------------------------------------------------------------------------------------------
+def flanking_seq(longest_repeats_path, longest_repeats_flanked_path, reference, flanking_len):
+    """Util.py:4614-4634: `chr:start-end` (0-based half-open) -> `chr:(s+1-flank)-(e+flank)` with the
+    window clamped into the contig; bases come from the packed genome."""
+    seq_names, _ = read_fasta(longest_repeats_path)
+    ctx = set_reference(reference)
+    idx, lens = _PACKED["names"], _PACKED["lens"]
+    contig, s1, e1, new_names = [], [], [], []
+    for name in seq_names:
+        ref_name, pos = name.split(":")
+        a, b = pos.split("-")
+        ref_start, ref_end = int(a) + 1, int(b)
+        clen = lens[idx[ref_name]]
+        if ref_start - 1 - flanking_len < 0:
+            ref_start = flanking_len + 1
+        if ref_end + flanking_len > clen:
+            ref_end = clen - flanking_len
+        new_names.append(ref_name + ":" + str(ref_start - flanking_len) + "-" + str(ref_end + flanking_len))
+        contig.append(idx[ref_name])
+        s1.append(ref_start - flanking_len)       # 1-based inclusive window, gathered with flank 0
+        e1.append(ref_end + flanking_len)
+    wins, _ = ctx.flank_gather(contig, s1, e1, [0] * len(contig), flank=0)
+    flanked = {}
+    for n, w, (c, a, b) in zip(new_names, wins, zip(contig, s1, e1)):
+        flanked[n] = w.decode() if w is not None else ""
+    store_fasta(flanked, longest_repeats_flanked_path)
+
+
+# ---- the fine stage (Util.py:8032-8287) -----------------------------------------------------------------
+def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, reference, split_ref_dir, TE_type, tmp_output_dir,
+                          threads, ref_index, log, subset_script_path, plant, debug, iter_num, all_low_copy,
+                          result_type="cons", all_copies=None, copy_finder=None):
+    """Same contract as the reference: reads the candidate FASTA, writes `real_TEs` and appends the low-copy
+    elements to `all_low_copy`.  `all_copies` = what get_full_length_copies_minimap2 returns
+    ({query: [(chr, start1, end1, aligned_len, '+'/'-'), ...]}) or `copy_finder(candidate_path, reference)`
+    producing it; one batched GPU call replaces the per-candidate process pool."""
+    if result_type != "cons":
+        raise NotImplementedError("only result_type='cons'")
+    names, contigs = read_fasta(candidate_sequence_path)
+    if all_copies is None:
+        if copy_finder is None:
+            raise ValueError("copy finding (minimap2 in the reference, Util.py:7933) is outside this build: "
+                             "pass all_copies= or copy_finder=")
+        all_copies = copy_finder(candidate_sequence_path, reference)
+    ctx = set_reference(reference)
+    idx = _PACKED["names"]
+    qnames = [q for q in all_copies.keys() if q in contigs]  # reference iterates all_copies (Util.py:8095)
+    cands = [contigs[q] for q in qnames]
+    copies = []
+    for q in qnames:
+        seen, lst = {}, []
+        for cp in all_copies[q]:
+            key = (cp[0], int(cp[1]), int(cp[2]), cp[4])  # dict semantics of copy_contigs[new_name] (Util.py:8110-8114)
+            if key in seen:
+                continue
+            seen[key] = 1
+            lst.append((idx[cp[0]], int(cp[1]), int(cp[2]), 1 if cp[4] == "-" else 0))
+        copies.append(lst)
+    res, _stats = ctx.flank_region_align(TE_type, cands, copies, plant=int(plant), flank=int(flanking_len)) if qnames else ([], None)
+    # result bucketing  Util.py:8159-8194, 8282-8287
+    true_tes, low_copy = {}, {}
+    thr = 5 if TE_type in ("tir", "non_ltr") else 2
+    for q, (is_te, info, cons, copy_count, _bs, _be) in zip(qnames, res):
+        if not is_te:
+            continue
+        if TE_type in ("tir", "helitron", "non_ltr"):
+            if cons.startswith("TG") and cons.endswith("CA"):
+                continue
+            if copy_count <= thr:
+                low_copy[q] = cons
+            else:
+                true_tes[q] = cons
+        else:
+            true_tes[q] = cons
+    store_fasta(true_tes, real_TEs)
+    with open(all_low_copy, "a") as f:
+        for q, s in low_copy.items():
+            f.write(">" + q + "\n" + s + "\n")
+    return true_tes, low_copy
+
+
+def valid_filename(query_name):
+    """Util.py:8127"""
+    return re.sub(r'[<>:"/\\|?*]', "-", query_name)

@@ -233,3 +233,45 @@ def test_fine_stage_vs_oracle_chain(ctx):
         n_te += res[0]
     assert n_te >= 4
     assert stats[0] > 0 and stats[4] > 0  # both the truncated-first and the full pass ran
+
+
+def test_util_mirror_file_contracts(ctx, tmp_path):
+    """the host-side mirror keeps the reference's file contracts (FASTA in, FASTA out)"""
+    from hite_amd import util
+
+    util._CTX = ctx
+    # flanking_seq against the golden produced by the reference (Util.py:4614)
+    case = load_golden("gather")[0]
+    ref = tmp_path / "genome.fa"
+    fold = lambda s: "".join(ch if ch in "ACGTN" else "N" for ch in s)  # noqa: E731
+    ref.write_text("".join(">%s\n%s\n" % (n, s) for n, s in zip(case["names"], case["seqs"])))
+    lr = tmp_path / "lr.fa"
+    lr.write_text("".join(">%s\nACGT\n" % n for n in case["flanking_in"]))
+    out = tmp_path / "lr.flanked.fa"
+    util.flanking_seq(str(lr), str(out), str(ref), 50)
+    names, contigs = util.read_fasta(str(out))
+    assert [[n, contigs[n]] for n in names] == [[n, fold(s)] for n, s in case["flanking_out"]]
+    # remove_sparse_col + judge through files
+    jc = [c for c in load_golden("judge_tir") if c["expected"][0] is True][0]
+    aln = tmp_path / "x.maf.fa"
+    aln.write_text("".join(">%s\n%s\n" % (n, s) for n, s in zip(jc["names"], jc["seqs"])))
+    clean = util.remove_sparse_col_in_align_file(str(aln))
+    cn, cc = util.read_fasta(clean)
+    assert [cc[n] for n in cn] == jc["clean"]
+    got = util.judge_boundary_v5(jc["cand"], clean, 0, "tir", jc["plant"], "cons")
+    assert list(got) == jc["expected"]
+    # flank_region_align_v5: candidates + copy table -> real_TEs / low-copy files
+    import synth_small
+
+    g = synth_small.make(5, n_fam=10)
+    gref = tmp_path / "g.fa"
+    gref.write_text("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(g["contigs"])))
+    cand = tmp_path / "cand.fa"
+    cand.write_text("".join(">q%d\n%s\n" % (i, s) for i, s in enumerate(g["cands"])))
+    copies = {"q%d" % i: [("c%d" % c, a, b, b - a + 1, "-" if m else "+") for (c, a, b, m) in cp] for i, cp in enumerate(g["copies"])}
+    real, low = tmp_path / "real.fa", tmp_path / "low.fa"
+    t, l = util.flank_region_align_v5(str(cand), str(real), 50, str(gref), None, "tir", str(tmp_path), 1, 0, None, "", 1, 0, 0,
+                                      str(low), all_copies=copies)
+    rn, rc = util.read_fasta(str(real))
+    assert set(rn) == set(t.keys()) and len(t) + len(l) >= 3
+    assert all(len(s) >= 80 for s in rc.values())
