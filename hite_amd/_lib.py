@@ -290,3 +290,35 @@ class Context:
             if self.lib.hite_profile_get(self.h, i, name, C.byref(ms), C.byref(cnt)) == 0:
                 out[name.value.decode()] = (ms.value, cnt.value)
         return out
+
+    # ---- k-mer TSD seed matching (search_confident_tir_v4, Util.py:7734) -----------------------------
+    def tsd_kmer(self, seqs, flank=50, plant=1):
+        """-> per candidate list of (tsd_len, tir_start, tir_end, distance), canonical order, <= 100"""
+        sb = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        n = len(sb)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in sb], out=off[1:])
+        buf = np.frombuffer(b"".join(sb) + b"\0" * 16, dtype=np.uint8)
+        rec = np.zeros((n, 100, 4), dtype=np.int32)
+        cnt = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.hite_tsd_kmer(self.h, n, _p(buf), _p(off), int(flank), int(plant), _p(rec), _p(cnt)), "hite_tsd_kmer")
+        return [[tuple(int(x) for x in rec[i, j]) for j in range(max(cnt[i], 0))] for i in range(n)]
+
+    # ---- FMEA (get_longest_repeats_v4 + process_all_seqs, Util.py:4122) --------------------------------
+    def fmea_chain(self, qseg, sseg, qs, qe, ss, se, seg_chrom, seg_off, skip_gap, max_len):
+        """-> (chrom ids, starts, ends) of the longest_repeats keys, in the reference's insertion order"""
+        n = len(qseg)
+        a = lambda x, t: _arr(x, t)  # noqa: E731
+        qseg, sseg = a(qseg, np.int32), a(sseg, np.int32)
+        qs, qe, ss, se = a(qs, np.int64), a(qe, np.int64), a(ss, np.int64), a(se, np.int64)
+        seg_chrom, seg_off = a(seg_chrom, np.int32), a(seg_off, np.int64)
+        cap = max(16, n + 16)
+        oc = np.zeros(cap, dtype=np.int32)
+        os_ = np.zeros(cap, dtype=np.int64)
+        oe = np.zeros(cap, dtype=np.int64)
+        nout = C.c_int64(0)
+        self._check(self.lib.hite_fmea_chain(self.h, C.c_int64(n), _p(qseg), _p(sseg), _p(qs), _p(qe), _p(ss), _p(se), len(seg_chrom),
+                                             _p(seg_chrom), _p(seg_off), C.c_int64(skip_gap), C.c_int64(max_len), C.c_int64(cap),
+                                             _p(oc), _p(os_), _p(oe), C.byref(nout)), "hite_fmea_chain")
+        k = nout.value
+        return oc[:k].copy(), os_[:k].copy(), oe[:k].copy()

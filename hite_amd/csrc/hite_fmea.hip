@@ -1,0 +1,652 @@
+// hite_fmea.hip -- FMEA: HSP chaining + interval de-duplication of the coarse stage.
+// get_longest_repeats_v4 + process_all_seqs (/root/reference/module/Util.py:4122-4400, 4529-4569).
+//
+// The reference walks nested Python dicts {query: {subject: [HSP]}}.  Here the same result comes out
+// of a sort / scan / segment pipeline on the GPU; every step is order-exact:
+//   1  first-appearance ranks of queries and of subjects within a query (atomicMin + block bitonic)
+//      -> group slot = (query order, subject order, strand)
+//   2  stable LSD radix sort of the HSPs by (slot | strand-aware s_start, s_end)            [:4166-4174]
+//   3  cluster sweep, one wavefront per group, lanes test the open cluster's members       [:4176-4227]
+//   4  stable radix sort by (cluster | q_start, q_end)                                      [:4231]
+//   5  greedy chain extension, one thread per cluster (visited aliasing of equal tuples)   [:4235-4319]
+//   6  first-come de-duplication on 10-bp rounded keys: a chain is new iff, for each of its 8 keys,
+//      it is the earliest chain carrying that key -> lock-free hash table with atomicMin    [:4344-4390]
+//   7  per query: stable sort by length (desc) and greedy 95 % containment filter          [:4529-4563]
+// Integer work only.  Algorithmic bytes: 24 B per HSP in, 20 B per interval out; the sorts move
+// 12 B x 2 per pass (HBM streaming).
+#include "hite_common.h"
+#include "hite_scan.h"
+
+#define FM_MAXSEG 4096
+
+// ---------------------------------------------------------------------------------------------
+// stable LSD radix sort of (u64 key, u32 value), 8 bits per pass, tile = 256 threads x 8 items
+// ---------------------------------------------------------------------------------------------
+#define RS_ITEMS 8
+#define RS_TILE (256 * RS_ITEMS)
+
+__global__ void __launch_bounds__(256) rs_hist_kernel(const unsigned long long *__restrict__ keys, int64_t n, int shift,
+                                                      int nblocks, int32_t *__restrict__ hist /* [256][nblocks] */) {
+    __shared__ int h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    int64_t base = (int64_t)blockIdx.x * RS_TILE;
+    for (int it = 0; it < RS_ITEMS; it++) {
+        int64_t i = base + it * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & 255ull)], 1);
+    }
+    __syncthreads();
+    hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+__global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned long long *__restrict__ kin, const unsigned *__restrict__ vin,
+                                                         unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
+                                                         int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
+    __shared__ long long base[256];
+    __shared__ int cnt[4][256];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    base[threadIdx.x] = offs[(int64_t)threadIdx.x * nblocks + blockIdx.x];
+    int64_t tile = (int64_t)blockIdx.x * RS_TILE;
+    for (int it = 0; it < RS_ITEMS; it++) {
+        for (int q = 0; q < 4; q++) cnt[q][threadIdx.x] = 0;
+        __syncthreads();
+        int64_t i = tile + it * 256 + threadIdx.x;
+        bool act = i < n;
+        unsigned long long k = act ? kin[i] : 0;
+        unsigned v = act ? vin[i] : 0;
+        int d = (int)((k >> shift) & 255ull);
+        // lanes of this wave with the same digit (inactive lanes match nothing)
+        unsigned long long peers = __ballot(act);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            unsigned long long bal = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        if (act && rank == 0) cnt[w][d] = __popcll(peers);
+        __syncthreads();
+        if (act) {
+            long long pos = base[d];
+            for (int q = 0; q < w; q++) pos += cnt[q][d];
+            pos += rank;
+            kout[pos] = k; vout[pos] = v;
+        }
+        __syncthreads();
+        base[threadIdx.x] += cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
+        __syncthreads();
+    }
+}
+
+struct Sorter {
+    hite_ctx *ctx;
+    hipStream_t st;
+    int64_t cap = 0;
+    unsigned long long *k2 = nullptr;
+    unsigned *v2 = nullptr;
+    int32_t *hist = nullptr;
+    int64_t *offs = nullptr, *bs = nullptr;
+    int64_t hist_n = 0;
+};
+
+static int sorter_init(Sorter &S, hite_ctx *ctx, hipStream_t st, int64_t n) {
+    S.ctx = ctx; S.st = st; S.cap = n;
+    int64_t nblocks = (n + RS_TILE - 1) / RS_TILE; if (nblocks < 1) nblocks = 1;
+    S.hist_n = 256 * nblocks;
+    HITE_CHECK(ctx, hipMalloc((void **)&S.k2, (size_t)(n + 1) * 8));
+    HITE_CHECK(ctx, hipMalloc((void **)&S.v2, (size_t)(n + 1) * 4));
+    HITE_CHECK(ctx, hipMalloc((void **)&S.hist, (size_t)S.hist_n * 4));
+    HITE_CHECK(ctx, hipMalloc((void **)&S.offs, (size_t)(S.hist_n + 1) * 8));
+    HITE_CHECK(ctx, hipMalloc((void **)&S.bs, (size_t)scan_tmp_elems(S.hist_n) * 8));
+    return HITE_OK;
+}
+static void sorter_free(Sorter &S) {
+    if (S.k2) (void)hipFree(S.k2);
+    if (S.v2) (void)hipFree(S.v2);
+    if (S.hist) (void)hipFree(S.hist);
+    if (S.offs) (void)hipFree(S.offs);
+    if (S.bs) (void)hipFree(S.bs);
+}
+// sorts (keys, vals) in place (ping-pong through the sorter's buffers), bits [0, nbits)
+static int sorter_sort(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int nbits) {
+    if (n <= 1) return HITE_OK;
+    int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
+    unsigned long long *ka = keys, *kb = S.k2;
+    unsigned *va = vals, *vb = S.v2;
+    int passes = (nbits + 7) / 8;
+    for (int p = 0; p < passes; p++) {
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(256), 0, S.st, ka, n, p * 8, nblocks, S.hist);
+        int rc = scan_excl_buf<int32_t>(S.ctx, S.bs, S.hist, (int64_t)256 * nblocks, S.offs, S.st);
+        if (rc) return rc;
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, p * 8, nblocks, S.offs);
+        unsigned long long *tk = ka; ka = kb; kb = tk;
+        unsigned *tv = va; va = vb; vb = tv;
+    }
+    if (ka != keys) {
+        HITE_CHECK(S.ctx, hipMemcpyAsync(keys, ka, (size_t)n * 8, hipMemcpyDeviceToDevice, S.st));
+        HITE_CHECK(S.ctx, hipMemcpyAsync(vals, va, (size_t)n * 4, hipMemcpyDeviceToDevice, S.st));
+    }
+    HITE_CHECK(S.ctx, hipGetLastError());
+    return HITE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 1: ranks
+// ---------------------------------------------------------------------------------------------
+struct Hsp { int qs, qe, ss, se; };
+
+__global__ void fm_first_kernel(int64_t n, const int32_t *__restrict__ qseg, const int32_t *__restrict__ sseg,
+                                const int64_t *__restrict__ qs, const int64_t *__restrict__ qe, const int64_t *__restrict__ ss,
+                                const int64_t *__restrict__ se, int nseg, int *__restrict__ first_q, int *__restrict__ first_pair,
+                                uint8_t *__restrict__ keep, int *__restrict__ err) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int q = qseg[i], s = sseg[i];
+    bool bad = q < 0 || q >= nseg || s < 0 || s >= nseg || qs[i] == qe[i] || ss[i] == se[i] || qs[i] < 0 || qe[i] < 0 || ss[i] < 0 ||
+               se[i] < 0 || qs[i] >= 0x7fffffff || qe[i] >= 0x7fffffff || ss[i] >= 0x7fffffff || se[i] >= 0x7fffffff;
+    if (bad) { atomicExch(err, 1); keep[i] = 0; return; }
+    bool self = q == s && qs[i] == ss[i] && qe[i] == se[i];  // :4138
+    keep[i] = !self;
+    if (self) return;
+    atomicMin(&first_q[q], (int)i);
+    atomicMin(&first_pair[(int64_t)q * nseg + s], (int)i);
+}
+
+// block bitonic sort of up to FM_MAXSEG (key, id) pairs in LDS; rank_out[id] = position, order_out[pos] = id
+__device__ void block_bitonic(unsigned *key, unsigned short *id, int np2) {
+    for (int k = 2; k <= np2; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < np2; i += blockDim.x) {
+                int ixj = i ^ j;
+                if (ixj > i) {
+                    bool up = (i & k) == 0;
+                    unsigned a = key[i], b = key[ixj];
+                    unsigned short ia = id[i], ib = id[ixj];
+                    bool gt = a > b || (a == b && ia > ib);
+                    if (gt == up) { key[i] = b; key[ixj] = a; id[i] = ib; id[ixj] = ia; }
+                }
+            }
+            __syncthreads();
+        }
+}
+
+__global__ void __launch_bounds__(256) fm_qrank_kernel(int nseg, int np2, const int *__restrict__ first_q, int *__restrict__ qrank,
+                                                       int *__restrict__ qorder, int *__restrict__ nq) {
+    __shared__ unsigned key[FM_MAXSEG];
+    __shared__ unsigned short id[FM_MAXSEG];
+    for (int i = threadIdx.x; i < np2; i += 256) { key[i] = i < nseg ? (unsigned)first_q[i] : 0xffffffffu; id[i] = (unsigned short)i; }
+    __syncthreads();
+    block_bitonic(key, id, np2);
+    for (int i = threadIdx.x; i < nseg; i += 256) { int q = id[i]; if (q < nseg) { qrank[q] = i; qorder[i] = q; } }
+    if (threadIdx.x == 0) { int c = 0; for (int i = 0; i < nseg; i++) c += key[i] != 0x7fffffffu && key[i] != 0xffffffffu; *nq = c; }
+}
+
+// one block per query: rank of each used subject by first appearance
+__global__ void __launch_bounds__(256) fm_srank_kernel(int nseg, int np2, const int *__restrict__ first_pair,
+                                                       int *__restrict__ srank, int *__restrict__ npairs) {
+    __shared__ unsigned key[FM_MAXSEG];
+    __shared__ unsigned short id[FM_MAXSEG];
+    const int q = blockIdx.x;
+    for (int i = threadIdx.x; i < np2; i += 256) { key[i] = i < nseg ? (unsigned)first_pair[(int64_t)q * nseg + i] : 0xffffffffu; id[i] = (unsigned short)i; }
+    __syncthreads();
+    block_bitonic(key, id, np2);
+    for (int i = threadIdx.x; i < nseg; i += 256) { int s = id[i]; if (s < nseg) srank[(int64_t)q * nseg + s] = i; }
+    if (threadIdx.x == 0) { int c = 0; for (int i = 0; i < nseg; i++) c += key[i] < 0x7fffffffu; npairs[q] = c; }
+}
+
+// gbase over queries in rank order (single thread; nseg is small)
+__global__ void fm_gbase_kernel(int nseg, const int *__restrict__ qorder, const int *__restrict__ npairs, int64_t *__restrict__ gbase,
+                                int64_t *__restrict__ total) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        int64_t acc = 0;
+        for (int r = 0; r < nseg; r++) { gbase[r] = acc; acc += npairs[qorder[r]]; }
+        *total = acc;
+    }
+}
+
+// keys of the first sort pair: key1 = s_end key (32 bit), key2 = slot << 31 | s_start key; value = HSP index
+__global__ void fm_keys_kernel(int64_t n, const uint8_t *__restrict__ keep, const int64_t *__restrict__ kpos,
+                               const int32_t *__restrict__ qseg, const int32_t *__restrict__ sseg, const int64_t *__restrict__ ss,
+                               const int64_t *__restrict__ se, int nseg, const int *__restrict__ qrank, const int *__restrict__ srank,
+                               const int64_t *__restrict__ gbase, unsigned long long *__restrict__ key_se,
+                               unsigned long long *__restrict__ key_slot, unsigned *__restrict__ val, int32_t *__restrict__ slot_cnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    int64_t o = kpos[i];
+    int q = qseg[i], s = sseg[i];
+    bool rev = ss[i] > se[i];                                                     // :4169
+    long long slot = 2 * (gbase[qrank[q]] + srank[(int64_t)q * nseg + s]) + (rev ? 1 : 0);
+    unsigned sk = rev ? (unsigned)(0x7fffffff - (int)ss[i]) : (unsigned)ss[i];    // (-ss, -se) order for reverse  :4174
+    unsigned ek = rev ? (unsigned)(0x7fffffff - (int)se[i]) : (unsigned)se[i];
+    key_se[o] = ek;
+    key_slot[o] = ((unsigned long long)slot << 31) | sk;
+    val[o] = (unsigned)i;
+    atomicAdd(&slot_cnt[slot], 1);
+}
+
+// after the first sort the value order is "by s_end"; gather key_slot in that order for the second sort
+__global__ void fm_gather_key_kernel(int64_t m, const unsigned *__restrict__ val, const int64_t *__restrict__ kpos,
+                                     const unsigned long long *__restrict__ key_by_pos, unsigned long long *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    out[i] = key_by_pos[kpos[val[i]]];
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 3: cluster sweep, one wavefront per group
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fm_cluster_kernel(int64_t nslots, const int64_t *__restrict__ slot_start,
+                                                         const unsigned *__restrict__ order /* HSP idx, sorted */,
+                                                         const int64_t *__restrict__ qe, const int64_t *__restrict__ ss,
+                                                         const int64_t *__restrict__ se, int64_t gap, int32_t *__restrict__ clid,
+                                                         int32_t *__restrict__ ncl) {
+    const int lane = threadIdx.x & 63;
+    for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < nslots; g += (int64_t)gridDim.x * 4) {
+        const int64_t b = slot_start[g], e = slot_start[g + 1];
+        if (e <= b) { if (lane == 0) ncl[g] = 0; continue; }
+        const bool rev = g & 1;
+        int cl = 0;
+        int64_t cstart = b;
+        if (lane == 0) clid[b] = 0;
+        for (int64_t k = b + 1; k < e; k++) {
+            const unsigned hk = order[k];
+            const long long ssk = ss[hk], qek = qe[hk];
+            bool closed = false;
+            for (int64_t top = k - 1; top >= cstart && !closed; top -= 64) {
+                int64_t m = top - lane;
+                bool hit = false;
+                if (m >= cstart) {
+                    const unsigned hm = order[m];
+                    long long d = rev ? (se[hm] - ssk) : (ssk - se[hm]);
+                    hit = d < gap && qek > qe[hm];
+                }
+                closed = __ballot(hit) != 0ull;
+            }
+            if (!closed) { cl++; cstart = k; }
+            if (lane == 0) clid[k] = cl;
+        }
+        if (lane == 0) ncl[g] = cl + 1;
+    }
+}
+
+// keys of the second sort pair: key1 = q_end, key2 = q_start, key3 = global cluster id; value = HSP index
+__global__ void fm_ckeys_kernel(int64_t m, const unsigned *__restrict__ order, const int64_t *__restrict__ slot_start,
+                                const unsigned long long *__restrict__ key_slot_sorted, const int32_t *__restrict__ clid,
+                                const int64_t *__restrict__ cl_base, const int64_t *__restrict__ qs, const int64_t *__restrict__ qe,
+                                unsigned long long *__restrict__ k_qe, unsigned long long *__restrict__ k_qs,
+                                unsigned long long *__restrict__ k_cl, int32_t *__restrict__ cl_cnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    unsigned h = order[i];
+    long long slot = (long long)(key_slot_sorted[i] >> 31);
+    long long g = cl_base[slot] + clid[i];
+    k_qe[i] = (unsigned long long)qe[h];
+    k_qs[i] = (unsigned long long)qs[h];
+    k_cl[i] = (unsigned long long)g;
+    atomicAdd(&cl_cnt[g], 1);
+}
+
+// generic: out[i] = src[perm_from[i]] where the current order lists positions of a previous order
+__global__ void fm_permute_u64_kernel(int64_t m, const unsigned *__restrict__ pos, const unsigned long long *__restrict__ src,
+                                      unsigned long long *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) out[i] = src[pos[i]];
+}
+__global__ void fm_iota_kernel(int64_t m, unsigned *__restrict__ v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) v[i] = (unsigned)i;
+}
+__global__ void fm_compose_kernel(int64_t m, const unsigned *__restrict__ pos, const unsigned *__restrict__ order_in,
+                                  unsigned *__restrict__ order_out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m) order_out[i] = order_in[pos[i]];
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 5: chaining, one thread per cluster  (Util.py:4235-4319)
+// ---------------------------------------------------------------------------------------------
+struct Chain { int qs, qe, ss, se; int sseg; int qseg; };
+
+__global__ void fm_chain_kernel(int64_t ncl, const int64_t *__restrict__ cl_start, const unsigned *__restrict__ order,
+                                const int32_t *__restrict__ qseg, const int32_t *__restrict__ sseg, const int64_t *__restrict__ qs,
+                                const int64_t *__restrict__ qe, const int64_t *__restrict__ ss, const int64_t *__restrict__ se,
+                                int64_t gap, uint8_t *__restrict__ vis, int32_t *__restrict__ canon, Chain *__restrict__ chains,
+                                int32_t *__restrict__ is_chain) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncl) return;
+    const int64_t b = cl_start[c], e = cl_start[c + 1];
+    // visited is keyed by the HSP tuple: identical tuples alias (adjacent after the stable sorts)
+    for (int64_t i = b; i < e; i++) {
+        vis[i] = 0; is_chain[i] = 0;
+        int32_t cn = (int32_t)(i - b);  // index relative to the cluster start
+        unsigned hi = order[i];
+        for (int64_t j = i - 1; j >= b; j--) {
+            unsigned hj = order[j];
+            if (qs[hj] != qs[hi] || qe[hj] != qe[hi]) break;
+            if (ss[hj] == ss[hi] && se[hj] == se[hi]) cn = canon[j];
+        }
+        canon[i] = cn;
+    }
+    for (int64_t i = b; i < e; i++) {
+        if (vis[b + canon[i]]) continue;
+        unsigned hi = order[i];
+        long long pqs = qs[hi], pqe = qe[hi], pss = ss[hi], pse = se[hi];
+        vis[b + canon[i]] = 1;
+        for (int64_t j = i + 1; j < e; j++) {
+            if (vis[b + canon[j]]) continue;
+            unsigned hj = order[j];
+            long long cqs = qs[hj], cqe = qe[hj], css = ss[hj], cse = se[hj];
+            if (cqe > pqe) {
+                if (pss < pse && css < cse) {
+                    if (cse > pse) {
+                        if (cqs - pqe < gap && cqe > pqe && css - pse < gap) { pqe = cqe; pss = pss < css ? pss : css; pse = cse; vis[b + canon[j]] = 1; }
+                        else if (cqs - pqe >= gap) break;
+                    }
+                } else if (pss > pse && css > cse) {
+                    if (cse < pse) {
+                        if (cqs - pqe < gap && cqe > pqe && pse - css < gap) { pqe = cqe; pss = pss > css ? pss : css; pse = cse; vis[b + canon[j]] = 1; }
+                        else if (cqs - pqe >= gap) break;
+                    }
+                }
+            }
+        }
+        Chain ch; ch.qs = (int)pqs; ch.qe = (int)pqe; ch.ss = (int)pss; ch.se = (int)pse; ch.sseg = sseg[hi]; ch.qseg = qseg[hi];
+        chains[i] = ch;
+        is_chain[i] = 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 6: de-duplication keys
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ long long fl10(long long x) { long long q = x / 10; if (x % 10 != 0 && x < 0) q--; return q * 10; }
+// (chrom:18 | a/10:28 | (b-a)/10 + 2^17 : 18) -- lossless for chrom < 2^18, 0 <= a < 2^28*10, |b-a| < 2^17*10
+__device__ __forceinline__ bool pack_key(int chrom, long long a, long long b, unsigned long long *out) {
+    long long d = (b - a) / 10 + (1 << 17);
+    if (chrom < 0 || chrom >= (1 << 18) || a < 0 || a / 10 >= (1ll << 28) || d < 0 || d >= (1 << 18)) return false;
+    *out = ((unsigned long long)chrom << 46) | ((unsigned long long)(a / 10) << 18) | (unsigned long long)d;
+    return true;
+}
+__device__ __forceinline__ unsigned long long mixhash(unsigned long long x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdull; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ull; x ^= x >> 33;
+    return x;
+}
+#define HT_EMPTY 0xffffffffffffffffull
+
+__device__ void chain_keys(const Chain &c, const int32_t *seg_chrom, const int64_t *seg_off, unsigned long long *k8, bool *ok) {
+    int schr = seg_chrom[c.sseg], qchr = seg_chrom[c.qseg];
+    long long sst = seg_off[c.sseg] + c.ss - 1, sen = seg_off[c.sseg] + c.se;
+    long long qst = seg_off[c.qseg] + c.qs - 1, qen = seg_off[c.qseg] + c.qe;
+    long long s1 = fl10(sst), s2 = s1 + 10, e1 = fl10(sen), e2 = e1 + 10;
+    long long a1 = fl10(qst), a2 = a1 + 10, b1 = fl10(qen), b2 = b1 + 10;
+    bool good = true;
+    good &= pack_key(schr, s1, e1, &k8[0]); good &= pack_key(schr, s1, e2, &k8[1]);
+    good &= pack_key(schr, s2, e1, &k8[2]); good &= pack_key(schr, s2, e2, &k8[3]);
+    good &= pack_key(qchr, a1, b1, &k8[4]); good &= pack_key(qchr, a1, b2, &k8[5]);
+    good &= pack_key(qchr, a2, b1, &k8[6]); good &= pack_key(qchr, a2, b2, &k8[7]);
+    *ok = good;
+}
+
+__global__ void fm_ht_insert_kernel(int64_t nch, const Chain *__restrict__ chains, const int32_t *__restrict__ seg_chrom,
+                                    const int64_t *__restrict__ seg_off, unsigned long long *__restrict__ ht_key,
+                                    unsigned *__restrict__ ht_val, unsigned long long mask, int *__restrict__ err) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch) return;
+    unsigned long long k8[8];
+    bool ok;
+    chain_keys(chains[c], seg_chrom, seg_off, k8, &ok);
+    if (!ok) { atomicExch(err, 2); return; }
+    for (int t = 0; t < 8; t++) {
+        unsigned long long key = k8[t];
+        unsigned long long h = mixhash(key) & mask;
+        for (;;) {
+            unsigned long long old = atomicCAS(&ht_key[h], HT_EMPTY, key);
+            if (old == HT_EMPTY || old == key) { atomicMin(&ht_val[h], (unsigned)c); break; }
+            h = (h + 1) & mask;
+        }
+    }
+}
+
+__global__ void fm_ht_query_kernel(int64_t nch, const Chain *__restrict__ chains, const int32_t *__restrict__ seg_chrom,
+                                   const int64_t *__restrict__ seg_off, const unsigned long long *__restrict__ ht_key,
+                                   const unsigned *__restrict__ ht_val, unsigned long long mask, int64_t max_len,
+                                   const int *__restrict__ qrank, unsigned long long *__restrict__ cand_key,
+                                   int32_t *__restrict__ is_cand) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch) return;
+    Chain ch = chains[c];
+    unsigned long long k8[8];
+    bool ok;
+    chain_keys(ch, seg_chrom, seg_off, k8, &ok);
+    bool isnew = ok;
+    for (int t = 0; t < 8 && isnew; t++) {
+        unsigned long long key = k8[t];
+        unsigned long long h = mixhash(key) & mask;
+        while (ht_key[h] != key) h = (h + 1) & mask;
+        if (ht_val[h] != (unsigned)c) isnew = false;      // an earlier chain already carried this key
+    }
+    long long qlen = (long long)ch.qe - ((long long)ch.qs - 1);
+    if (qlen < 0) qlen = -qlen;
+    bool cand = isnew && qlen >= 80 && qlen < max_len;      // :4379
+    is_cand[c] = cand;
+    // sort key for process_seq_group: (query order | length descending); stable => chain order among equals
+    long long len = ((long long)ch.qe) - ((long long)ch.qs - 1);
+    cand_key[c] = ((unsigned long long)qrank[ch.qseg] << 32) | (unsigned long long)(0x7fffffff - (unsigned)(len & 0x7fffffff));
+}
+
+__global__ void fm_compact_chains_kernel(int64_t m, const int32_t *__restrict__ flag, const int64_t *__restrict__ pos,
+                                         const Chain *__restrict__ in, Chain *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < m && flag[i]) out[pos[i]] = in[i];
+}
+__global__ void fm_compact_cand_kernel(int64_t nch, const int32_t *__restrict__ flag, const int64_t *__restrict__ pos,
+                                       const unsigned long long *__restrict__ key_in, unsigned long long *__restrict__ key_out,
+                                       unsigned *__restrict__ val_out, int32_t *__restrict__ qcount, const Chain *__restrict__ chains,
+                                       const int *__restrict__ qrank) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= nch || !flag[c]) return;
+    key_out[pos[c]] = key_in[c];
+    val_out[pos[c]] = (unsigned)c;
+    atomicAdd(&qcount[qrank[chains[c].qseg]], 1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// step 7: per query greedy containment filter on the length-sorted candidates (Util.py:4529-4549)
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) fm_filter_kernel(int nq, const int64_t *__restrict__ qstart, const unsigned *__restrict__ cidx,
+                                                        const Chain *__restrict__ chains, const int64_t *__restrict__ seg_off,
+                                                        uint8_t *__restrict__ keepf) {
+    const int r = blockIdx.x;
+    if (r >= nq) return;
+    const int64_t b = qstart[r], e = qstart[r + 1];
+    for (int64_t i = b + threadIdx.x; i < e; i += 256) keepf[i] = 1;
+    __syncthreads();
+    for (int64_t i = b; i < e; i++) {
+        if (!keepf[i]) { continue; }   // uniform: keepf[i] is final once all j < i have been processed
+        const Chain ci = chains[cidx[i]];
+        const long long s1 = seg_off[ci.qseg] + ci.qs - 1, e1 = seg_off[ci.qseg] + ci.qe;
+        for (int64_t j = i + 1 + threadIdx.x; j < e; j += 256) {
+            if (!keepf[j]) continue;
+            const Chain cj = chains[cidx[j]];
+            const long long s2 = seg_off[cj.qseg] + cj.qs - 1, e2 = seg_off[cj.qseg] + cj.qe;
+            long long lo = s1 > s2 ? s1 : s2, hi = e1 < e2 ? e1 : e2;
+            long long ov = hi - lo; if (ov < 0) ov = 0;
+            if ((double)ov / (double)(e2 - s2) >= 0.95) keepf[j] = 0;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void fm_emit_kernel(int64_t ncand, const uint8_t *__restrict__ keepf, const int64_t *__restrict__ pos,
+                               const unsigned *__restrict__ cidx, const Chain *__restrict__ chains,
+                               const int32_t *__restrict__ seg_chrom, const int64_t *__restrict__ seg_off, int64_t cap,
+                               int32_t *__restrict__ out_chrom, int64_t *__restrict__ out_start, int64_t *__restrict__ out_end) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncand || !keepf[i]) return;
+    int64_t o = pos[i];
+    if (o >= cap) return;
+    const Chain c = chains[cidx[i]];
+    out_chrom[o] = seg_chrom[c.qseg];
+    out_start[o] = seg_off[c.qseg] + c.qs - 1;
+    out_end[o] = seg_off[c.qseg] + c.qe;
+}
+
+__global__ void fm_u8_to_i32_kernel(int64_t n, const uint8_t *__restrict__ in, int32_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i];
+}
+__global__ void fm_fill_i32_kernel(int64_t n, int *__restrict__ p, int v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host orchestration
+// ---------------------------------------------------------------------------------------------
+struct FBuf {
+    void *p = nullptr;
+    ~FBuf() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    hipError_t up(const void *h, size_t n) {
+        hipError_t e = alloc(n + 16);
+        if (e != hipSuccess) return e;
+        return n ? hipMemcpy(p, h, n, hipMemcpyHostToDevice) : hipSuccess;
+    }
+};
+#define FCHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e__)); sorter_free(S); return HITE_EHIP; } } while (0)
+#define GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
+
+extern "C" int hite_fmea_chain(hite_ctx *ctx, int64_t n, const int32_t *qseg, const int32_t *sseg, const int64_t *qs,
+                               const int64_t *qe, const int64_t *ss, const int64_t *se, int32_t nseg, const int32_t *seg_chrom,
+                               const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
+                               int64_t *out_start, int64_t *out_end, int64_t *n_out) {
+    if (!ctx || n < 0 || nseg <= 0 || nseg > FM_MAXSEG || !n_out || n >= 0x7fffffff) return HITE_EINVAL;
+    *n_out = 0;
+    if (n == 0) return HITE_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HITE_EHIP;
+    hipStream_t st = nullptr;
+    Sorter S;
+    int np2 = 1; while (np2 < nseg) np2 <<= 1;
+    FBuf dq, dsg, dqs, dqe, dss, dse, dchr, doff, dfirstq, dfirstp, dkeep, dkeep32, dkpos, dqrank, dqorder, dnq, dsrank, dnpairs, dgbase,
+        dtot, derr, dk1, dk2, dval, dslotcnt, dslotstart, dbs, dk2s, dclid, dncl, dclbase, dkqe, dkqs, dkcl, dclcnt, dclstart, dpos,
+        dorder2, dvis, dcanon, dchains, dischain, dchpos, dchains2, dhtk, dhtv, dckey, discand, dcpos, dckey2, dcidx, dqcount, dqstart,
+        dkeepf, dkeepf32, dopos, doc, dos, doe, dtmpk;
+    FCHK(dq.up(qseg, n * 4)); FCHK(dsg.up(sseg, n * 4)); FCHK(dqs.up(qs, n * 8)); FCHK(dqe.up(qe, n * 8)); FCHK(dss.up(ss, n * 8));
+    FCHK(dse.up(se, n * 8)); FCHK(dchr.up(seg_chrom, nseg * 4)); FCHK(doff.up(seg_off, nseg * 8));
+    FCHK(dfirstq.alloc((size_t)nseg * 4)); FCHK(dfirstp.alloc((size_t)nseg * nseg * 4)); FCHK(dkeep.alloc(n)); FCHK(dkeep32.alloc(n * 4));
+    FCHK(dkpos.alloc((n + 1) * 8)); FCHK(dqrank.alloc(nseg * 4)); FCHK(dqorder.alloc(nseg * 4)); FCHK(dnq.alloc(16));
+    FCHK(dsrank.alloc((size_t)nseg * nseg * 4)); FCHK(dnpairs.alloc(nseg * 4)); FCHK(dgbase.alloc((nseg + 1) * 8)); FCHK(dtot.alloc(64));
+    FCHK(derr.alloc(16)); FCHK(dbs.alloc((size_t)scan_tmp_elems((int64_t)nseg * nseg * 2 + n + 16) * 8));
+    FCHK(hipMemset(derr.p, 0, 16));
+    hipLaunchKernelGGL(fm_fill_i32_kernel, GRID(nseg), 0, st, (int64_t)nseg, (int *)dfirstq.p, 0x7fffffff);
+    hipLaunchKernelGGL(fm_fill_i32_kernel, GRID((int64_t)nseg * nseg), 0, st, (int64_t)nseg * nseg, (int *)dfirstp.p, 0x7fffffff);
+    hipLaunchKernelGGL(fm_first_kernel, GRID(n), 0, st, n, (int32_t *)dq.p, (int32_t *)dsg.p, (int64_t *)dqs.p, (int64_t *)dqe.p,
+                       (int64_t *)dss.p, (int64_t *)dse.p, nseg, (int *)dfirstq.p, (int *)dfirstp.p, (uint8_t *)dkeep.p, (int *)derr.p);
+    int herr = 0;
+    FCHK(hipMemcpy(&herr, derr.p, 4, hipMemcpyDeviceToHost));
+    if (herr) return HITE_EINVAL;  // zero-length HSP (the reference divides by its length, :4270) or coordinate out of range
+    hipLaunchKernelGGL(fm_u8_to_i32_kernel, GRID(n), 0, st, n, (uint8_t *)dkeep.p, (int32_t *)dkeep32.p);
+    if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)dkeep32.p, n, (int64_t *)dkpos.p, st)) return HITE_EHIP;
+    int64_t m = 0;
+    FCHK(hipMemcpy(&m, (int64_t *)dkpos.p + n, 8, hipMemcpyDeviceToHost));
+    if (m == 0) return HITE_OK;
+    hipLaunchKernelGGL(fm_qrank_kernel, dim3(1), dim3(256), 0, st, nseg, np2, (int *)dfirstq.p, (int *)dqrank.p, (int *)dqorder.p, (int *)dnq.p);
+    hipLaunchKernelGGL(fm_srank_kernel, dim3(nseg), dim3(256), 0, st, nseg, np2, (int *)dfirstp.p, (int *)dsrank.p, (int *)dnpairs.p);
+    hipLaunchKernelGGL(fm_gbase_kernel, dim3(1), dim3(64), 0, st, nseg, (int *)dqorder.p, (int *)dnpairs.p, (int64_t *)dgbase.p, (int64_t *)dtot.p);
+    int64_t npairs_total = 0;
+    int nq = 0;
+    FCHK(hipMemcpy(&npairs_total, dtot.p, 8, hipMemcpyDeviceToHost));
+    FCHK(hipMemcpy(&nq, dnq.p, 4, hipMemcpyDeviceToHost));
+    const int64_t nslots = 2 * npairs_total;
+    FCHK(dk1.alloc((m + 1) * 8)); FCHK(dk2.alloc((m + 1) * 8)); FCHK(dval.alloc((m + 1) * 4)); FCHK(dslotcnt.alloc((nslots + 1) * 4));
+    FCHK(dslotstart.alloc((nslots + 2) * 8)); FCHK(dk2s.alloc((m + 1) * 8)); FCHK(dtmpk.alloc((m + 1) * 8));
+    FCHK(hipMemset(dslotcnt.p, 0, (nslots + 1) * 4));
+    if (sorter_init(S, ctx, st, m)) { sorter_free(S); return HITE_EHIP; }
+    hipLaunchKernelGGL(fm_keys_kernel, GRID(n), 0, st, n, (uint8_t *)dkeep.p, (int64_t *)dkpos.p, (int32_t *)dq.p, (int32_t *)dsg.p,
+                       (int64_t *)dss.p, (int64_t *)dse.p, nseg, (int *)dqrank.p, (int *)dsrank.p, (int64_t *)dgbase.p,
+                       (unsigned long long *)dk1.p, (unsigned long long *)dk2.p, (unsigned *)dval.p, (int32_t *)dslotcnt.p);
+    // sort 1: by s_end key, then (stable) by slot | s_start key.  dval holds original HSP indices.
+    if (sorter_sort(S, (unsigned long long *)dk1.p, (unsigned *)dval.p, m, 32)) { sorter_free(S); return HITE_EHIP; }
+    hipLaunchKernelGGL(fm_gather_key_kernel, GRID(m), 0, st, m, (unsigned *)dval.p, (int64_t *)dkpos.p, (unsigned long long *)dk2.p,
+                       (unsigned long long *)dk2s.p);
+    int slot_bits = 1; while ((1ll << slot_bits) < nslots + 1) slot_bits++;
+    if (sorter_sort(S, (unsigned long long *)dk2s.p, (unsigned *)dval.p, m, 31 + slot_bits)) { sorter_free(S); return HITE_EHIP; }
+    if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)dslotcnt.p, nslots, (int64_t *)dslotstart.p, st)) { sorter_free(S); return HITE_EHIP; }
+    // clusters
+    FCHK(dclid.alloc((m + 1) * 4)); FCHK(dncl.alloc((nslots + 1) * 4)); FCHK(dclbase.alloc((nslots + 2) * 8));
+    {
+        int64_t blocks = (nslots + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(fm_cluster_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nslots, (int64_t *)dslotstart.p, (unsigned *)dval.p,
+                           (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, skip_gap, (int32_t *)dclid.p, (int32_t *)dncl.p);
+    }
+    if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)dncl.p, nslots, (int64_t *)dclbase.p, st)) { sorter_free(S); return HITE_EHIP; }
+    int64_t ncl = 0;
+    FCHK(hipMemcpy(&ncl, (int64_t *)dclbase.p + nslots, 8, hipMemcpyDeviceToHost));
+    FCHK(dkqe.alloc((m + 1) * 8)); FCHK(dkqs.alloc((m + 1) * 8)); FCHK(dkcl.alloc((m + 1) * 8)); FCHK(dclcnt.alloc((ncl + 1) * 4));
+    FCHK(dclstart.alloc((ncl + 2) * 8)); FCHK(dpos.alloc((m + 1) * 4)); FCHK(dorder2.alloc((m + 1) * 4));
+    FCHK(hipMemset(dclcnt.p, 0, (ncl + 1) * 4));
+    hipLaunchKernelGGL(fm_ckeys_kernel, GRID(m), 0, st, m, (unsigned *)dval.p, (int64_t *)dslotstart.p, (unsigned long long *)dk2s.p,
+                       (int32_t *)dclid.p, (int64_t *)dclbase.p, (int64_t *)dqs.p, (int64_t *)dqe.p, (unsigned long long *)dkqe.p,
+                       (unsigned long long *)dkqs.p, (unsigned long long *)dkcl.p, (int32_t *)dclcnt.p);
+    // sort 2: positions of the current order by q_end, then q_start, then cluster (each stable)
+    hipLaunchKernelGGL(fm_iota_kernel, GRID(m), 0, st, m, (unsigned *)dpos.p);
+    if (sorter_sort(S, (unsigned long long *)dkqe.p, (unsigned *)dpos.p, m, 32)) { sorter_free(S); return HITE_EHIP; }
+    hipLaunchKernelGGL(fm_permute_u64_kernel, GRID(m), 0, st, m, (unsigned *)dpos.p, (unsigned long long *)dkqs.p, (unsigned long long *)dtmpk.p);
+    if (sorter_sort(S, (unsigned long long *)dtmpk.p, (unsigned *)dpos.p, m, 32)) { sorter_free(S); return HITE_EHIP; }
+    hipLaunchKernelGGL(fm_permute_u64_kernel, GRID(m), 0, st, m, (unsigned *)dpos.p, (unsigned long long *)dkcl.p, (unsigned long long *)dtmpk.p);
+    int cl_bits = 1; while ((1ll << cl_bits) < ncl + 1) cl_bits++;
+    if (sorter_sort(S, (unsigned long long *)dtmpk.p, (unsigned *)dpos.p, m, cl_bits)) { sorter_free(S); return HITE_EHIP; }
+    hipLaunchKernelGGL(fm_compose_kernel, GRID(m), 0, st, m, (unsigned *)dpos.p, (unsigned *)dval.p, (unsigned *)dorder2.p);
+    if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)dclcnt.p, ncl, (int64_t *)dclstart.p, st)) { sorter_free(S); return HITE_EHIP; }
+    // chains
+    FCHK(dvis.alloc(m + 16)); FCHK(dcanon.alloc((m + 1) * 4)); FCHK(dchains.alloc((m + 1) * sizeof(Chain))); FCHK(dischain.alloc((m + 1) * 4));
+    FCHK(dchpos.alloc((m + 2) * 8)); FCHK(dchains2.alloc((m + 1) * sizeof(Chain)));
+    hipLaunchKernelGGL(fm_chain_kernel, GRID(ncl), 0, st, ncl, (int64_t *)dclstart.p, (unsigned *)dorder2.p, (int32_t *)dq.p, (int32_t *)dsg.p,
+                       (int64_t *)dqs.p, (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, skip_gap, (uint8_t *)dvis.p, (int32_t *)dcanon.p,
+                       (Chain *)dchains.p, (int32_t *)dischain.p);
+    if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)dischain.p, m, (int64_t *)dchpos.p, st)) { sorter_free(S); return HITE_EHIP; }
+    int64_t nch = 0;
+    FCHK(hipMemcpy(&nch, (int64_t *)dchpos.p + m, 8, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(fm_compact_chains_kernel, GRID(m), 0, st, m, (int32_t *)dischain.p, (int64_t *)dchpos.p, (Chain *)dchains.p, (Chain *)dchains2.p);
+    // de-duplication
+    unsigned long long htsize = 64; while (htsize < (unsigned long long)nch * 16 + 64) htsize <<= 1;
+    FCHK(dhtk.alloc(htsize * 8)); FCHK(dhtv.alloc(htsize * 4));
+    FCHK(hipMemset(dhtk.p, 0xff, htsize * 8)); FCHK(hipMemset(dhtv.p, 0xff, htsize * 4));
+    FCHK(dckey.alloc((nch + 1) * 8)); FCHK(discand.alloc((nch + 1) * 4)); FCHK(dcpos.alloc((nch + 2) * 8));
+    hipLaunchKernelGGL(fm_ht_insert_kernel, GRID(nch), 0, st, nch, (Chain *)dchains2.p, (int32_t *)dchr.p, (int64_t *)doff.p,
+                       (unsigned long long *)dhtk.p, (unsigned *)dhtv.p, htsize - 1, (int *)derr.p);
+    FCHK(hipMemcpy(&herr, derr.p, 4, hipMemcpyDeviceToHost));
+    if (herr) { sorter_free(S); return HITE_EINVAL; }  // interval outside the 64-bit key packing range
+    hipLaunchKernelGGL(fm_ht_query_kernel, GRID(nch), 0, st, nch, (Chain *)dchains2.p, (int32_t *)dchr.p, (int64_t *)doff.p,
+                       (unsigned long long *)dhtk.p, (unsigned *)dhtv.p, htsize - 1, max_len, (int *)dqrank.p,
+                       (unsigned long long *)dckey.p, (int32_t *)discand.p);
+    if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)discand.p, nch, (int64_t *)dcpos.p, st)) { sorter_free(S); return HITE_EHIP; }
+    int64_t ncand = 0;
+    FCHK(hipMemcpy(&ncand, (int64_t *)dcpos.p + nch, 8, hipMemcpyDeviceToHost));
+    if (ncand == 0) { sorter_free(S); return HITE_OK; }
+    FCHK(dckey2.alloc((ncand + 1) * 8)); FCHK(dcidx.alloc((ncand + 1) * 4)); FCHK(dqcount.alloc((nseg + 1) * 4)); FCHK(dqstart.alloc((nseg + 2) * 8));
+    FCHK(dkeepf.alloc(ncand + 16)); FCHK(dkeepf32.alloc((ncand + 1) * 4)); FCHK(dopos.alloc((ncand + 2) * 8));
+    FCHK(hipMemset(dqcount.p, 0, (nseg + 1) * 4));
+    hipLaunchKernelGGL(fm_compact_cand_kernel, GRID(nch), 0, st, nch, (int32_t *)discand.p, (int64_t *)dcpos.p, (unsigned long long *)dckey.p,
+                       (unsigned long long *)dckey2.p, (unsigned *)dcidx.p, (int32_t *)dqcount.p, (Chain *)dchains2.p, (int *)dqrank.p);
+    // process_seq_group: stable sort by (query order | length desc)  -- ncand <= m, the sorter is large enough
+    if (sorter_sort(S, (unsigned long long *)dckey2.p, (unsigned *)dcidx.p, ncand, 44)) { sorter_free(S); return HITE_EHIP; }
+    if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)dqcount.p, nseg, (int64_t *)dqstart.p, st)) { sorter_free(S); return HITE_EHIP; }
+    hipLaunchKernelGGL(fm_filter_kernel, dim3(nseg), dim3(256), 0, st, nseg, (int64_t *)dqstart.p, (unsigned *)dcidx.p, (Chain *)dchains2.p,
+                       (int64_t *)doff.p, (uint8_t *)dkeepf.p);
+    hipLaunchKernelGGL(fm_u8_to_i32_kernel, GRID(ncand), 0, st, ncand, (uint8_t *)dkeepf.p, (int32_t *)dkeepf32.p);
+    if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)dkeepf32.p, ncand, (int64_t *)dopos.p, st)) { sorter_free(S); return HITE_EHIP; }
+    int64_t nout = 0;
+    FCHK(hipMemcpy(&nout, (int64_t *)dopos.p + ncand, 8, hipMemcpyDeviceToHost));
+    *n_out = nout;
+    if (nout > cap) { sorter_free(S); return HITE_ECAP; }
+    FCHK(doc.alloc((nout + 1) * 4)); FCHK(dos.alloc((nout + 1) * 8)); FCHK(doe.alloc((nout + 1) * 8));
+    hipLaunchKernelGGL(fm_emit_kernel, GRID(ncand), 0, st, ncand, (uint8_t *)dkeepf.p, (int64_t *)dopos.p, (unsigned *)dcidx.p, (Chain *)dchains2.p,
+                       (int32_t *)dchr.p, (int64_t *)doff.p, cap, (int32_t *)doc.p, (int64_t *)dos.p, (int64_t *)doe.p);
+    FCHK(hipGetLastError());
+    FCHK(hipDeviceSynchronize());
+    FCHK(hipMemcpy(out_chrom, doc.p, nout * 4, hipMemcpyDeviceToHost));
+    FCHK(hipMemcpy(out_start, dos.p, nout * 8, hipMemcpyDeviceToHost));
+    FCHK(hipMemcpy(out_end, doe.p, nout * 8, hipMemcpyDeviceToHost));
+    sorter_free(S);
+    return HITE_OK;
+}

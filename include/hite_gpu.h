@@ -131,6 +131,30 @@ int hite_tsd_search(hite_ctx *ctx, int32_t n, const uint8_t *rows_bytes, const i
                     const int32_t *bstart, const int32_t *bend, int32_t plant, int32_t *tsd_len_out,
                     uint8_t *left_out /* n x 16 */, uint8_t *right_out /* n x 16 */);
 
+/* ---- FMEA --- get_longest_repeats_v4 + process_all_seqs  Util.py:4122-4400, 4529-4569 -------------
+ * n HSPs in blast6 file order (cols 0,1,6,7,8,9 of -outfmt 6): qseg/sseg = ids of the 'chr$offset'
+ * segment names, 1-based inclusive coordinates (reverse hits have ss > se); seg_chrom/seg_off give the
+ * chromosome id and the offset of each segment (nseg <= 4096).  skip_gap = fixed_extend_base_threshold.
+ * Output = the keys 'chr:start-end' of the reference's longest_repeats dict, in insertion order, as
+ * (chrom id, start, end); *n_out is set even when HITE_ECAP is returned.
+ * HITE_EINVAL for a zero-length HSP (the reference raises ZeroDivisionError, :4270) or coordinates
+ * outside [0, 2^31) / chain spans >= 1.31 Mbp (the de-duplication key is packed into 64 bits). */
+int hite_fmea_chain(hite_ctx *ctx, int64_t n, const int32_t *qseg, const int32_t *sseg, const int64_t *qs,
+                    const int64_t *qe, const int64_t *ss, const int64_t *se, int32_t nseg, const int32_t *seg_chrom,
+                    const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
+                    int64_t *out_start, int64_t *out_end, int64_t *n_out);
+
+/* ---- k-mer TSD seed matching --- search_confident_tir_v4  Util.py:7734-7845 -------------------------
+ * batch of flanked candidates (CSR); the raw boundaries are (flank+1, len-flank), 1-based, as
+ * search_confident_tir_batch_v1 passes them (Util.py:6550), tsd_search_distance = flank (<= 63).
+ * Per candidate up to 100 records (tsd_len, tir_start, tir_end, distance), 0-based inclusive, in the
+ * canonical order (distance, tir_start, tir_end, tsd_len) that replaces the reference's
+ * PYTHONHASHSEED-dependent tie order; rec_out is n x 100 x 4 int32, cnt_out[n] (-1: window too long). */
+int hite_tsd_kmer(hite_ctx *ctx, int32_t n, const uint8_t *seqs, const int64_t *seq_off, int32_t flank, int32_t plant,
+                  int32_t *rec_out, int32_t *cnt_out);
+int hite_tsd_kmer_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_seqs, const int64_t *d_seq_off, int32_t flank,
+                      int32_t plant, int32_t *d_rec_out, int32_t *d_cnt_out, void *stream);
+
 /* ---- star alignment: this build's GPU-native stage where the reference runs the external
  * `mafft --preservecase --quiet --thread 1` (Util.py:10416; third-party, unpinned -> parity is
  * pinned against the build's own CPU twin, oracle/hite_oracle_msa.c).

@@ -275,3 +275,51 @@ def test_util_mirror_file_contracts(ctx, tmp_path):
     rn, rc = util.read_fasta(str(real))
     assert set(rn) == set(t.keys()) and len(t) + len(l) >= 3
     assert all(len(s) >= 80 for s in rc.values())
+
+
+def test_tsd_kmer_golden_and_oracle(ctx):
+    from test_oracle_golden import check_tir_items
+
+    cases = load_golden("tir_kmer")
+    for plant in (0, 1):
+        sub = [c for c in cases if c["plant"] == plant]
+        got = ctx.tsd_kmer([c["seq"] for c in sub], flank=50, plant=plant)
+        for c, recs in zip(sub, got):
+            seq = c["seq"]
+            assert recs == O.tir_kmer(seq, c["flank"] + 1, len(seq) - c["flank"], c["flank"], plant)
+            items = sorted([d, seq[ts - k:ts], seq[ts:te + 1]] for (k, ts, te, d) in recs)
+            check_tir_items(items, c)
+    # fresh seeds vs the oracle
+    seqs = []
+    for i in range(200):
+        s, fl = casegen.make_tir_candidate(90000 + i, te_len=int(100 + 37 * (i % 40)), tsd_len=[2, 3, 4, 5, 6, 8, 9, 10, 11][i % 9],
+                                           off_l=(i * 7) % 45 - 20, off_r=(i * 11) % 45 - 20, with_n=(i % 9 == 0))
+        seqs.append(s)
+    got = ctx.tsd_kmer(seqs, flank=50, plant=1)
+    for s, recs in zip(seqs, got):
+        assert recs == O.tir_kmer(s, 51, len(s) - 50, 50, 1)
+
+
+def _fmea_gpu(ctx, rows, skip_gap, max_len):
+    h = O.hsp_arrays([tuple(r) for r in rows])
+    oc, os_, oe = ctx.fmea_chain(h["qseg"], h["sseg"], h["qs"], h["qe"], h["ss"], h["se"], h["seg_chrom"], h["seg_off"], skip_gap, max_len)
+    return ["%s:%d-%d" % (h["chrom_names"][c], s, e) for c, s, e in zip(oc, os_, oe)], h
+
+
+def test_fmea_golden(ctx):
+    for case in load_golden("fmea"):
+        got, _ = _fmea_gpu(ctx, case["rows"], case["skip_gap"], case["max_len"])
+        assert got == case["expected"]
+
+
+def test_fmea_random_vs_oracle(ctx):
+    for seed in range(40, 52):
+        rows = casegen.make_hsp_table(seed, n_seg=3 + seed % 3, n_fam=8 + seed % 7, noise=60, frag=(1, 5), dup=seed % 4 * 10,
+                                      copies=(2, 10 + seed % 9))
+        for gap, mx in ((2000, 30000), (300, 8000)):
+            got, h = _fmea_gpu(ctx, rows, gap, mx)
+            assert got == O.fmea(h, gap, mx)
+    # a larger stress table: ~60k HSPs
+    rows = casegen.make_hsp_table(7, n_seg=6, n_fam=60, noise=2000, frag=(1, 4), copies=(4, 22))
+    got, h = _fmea_gpu(ctx, rows, 2000, 30000)
+    assert len(rows) > 20000 and got == O.fmea(h, 2000, 30000)
