@@ -64,6 +64,9 @@ class Context:
         self.device = device
 
     def close(self):
+        if getattr(self, "_copy_state", None) is not None and getattr(self, "h", None):
+            self.lib.hite_copy_index_release(self._copy_state)
+            self._copy_state = None
         if getattr(self, "_pipe_state", None) is not None and getattr(self, "h", None):
             self.lib.hite_pipeline_release(self._pipe_state)
             self._pipe_state = C.c_void_p(None)
@@ -322,3 +325,41 @@ class Context:
                                              _p(oc), _p(os_), _p(oe), C.byref(nout)), "hite_fmea_chain")
         k = nout.value
         return oc[:k].copy(), os_[:k].copy(), oe[:k].copy()
+
+    # ---- copy finding (stage where the reference calls minimap2, Util.py:7933) ---------------------------
+    def find_copies(self, cands):
+        """-> per candidate list of (contig, start1, end1, minus, anchors); needs genome_pack() first"""
+        if getattr(self, "_copy_state", None) is None:
+            self._copy_state = C.c_void_p(None)
+        cb = [c.encode() if isinstance(c, str) else bytes(c) for c in cands]
+        n = len(cb)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in cb], out=off[1:])
+        buf = np.frombuffer(b"".join(cb) + b"\0" * 16, dtype=np.uint8)
+        cap = 300 * n + 16
+        cf = np.zeros(n + 1, dtype=np.int32)
+        ct = np.zeros(cap, dtype=np.int32)
+        s1 = np.zeros(cap, dtype=np.int64)
+        e1 = np.zeros(cap, dtype=np.int64)
+        mn = np.zeros(cap, dtype=np.uint8)
+        an = np.zeros(cap, dtype=np.int32)
+        nout = C.c_int64(0)
+        self._check(self.lib.hite_find_copies(self.h, C.byref(self._copy_state), n, _p(buf), _p(off), C.c_int64(cap), _p(cf), _p(ct),
+                                              _p(s1), _p(e1), _p(mn), _p(an), C.byref(nout)), "hite_find_copies")
+        return [[(int(ct[i]), int(s1[i]), int(e1[i]), int(mn[i]), int(an[i])) for i in range(cf[c], cf[c + 1])] for c in range(n)]
+
+    def copy_index_build(self, stream=0):
+        if getattr(self, "_copy_state", None) is None:
+            self._copy_state = C.c_void_p(None)
+        self._check(self.lib.hite_copy_index_build(self.h, C.byref(self._copy_state), C.c_void_p(stream)), "hite_copy_index_build")
+
+    def find_copies_dev(self, n_cand, d_cand, d_cand_off, cand_bytes, stream=0):
+        """device-resident: -> (n_copies, d_copy_first, d_contig, d_start1, d_end1, d_minus, d_anchors) raw device pointers"""
+        v = C.c_void_p
+        outs = [v() for _ in range(6)]
+        n = C.c_int64(0)
+        rc = self.lib.hite_find_copies_dev(self.h, self._copy_state, int(n_cand), v(d_cand), v(d_cand_off), C.c_int64(cand_bytes),
+                                           C.byref(outs[0]), C.byref(n), C.byref(outs[1]), C.byref(outs[2]), C.byref(outs[3]),
+                                           C.byref(outs[4]), C.byref(outs[5]), v(stream))
+        self._check(rc, "hite_find_copies_dev")
+        return (n.value,) + tuple(o.value or 0 for o in outs)

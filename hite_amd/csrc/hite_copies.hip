@@ -1,0 +1,539 @@
+// hite_copies.hip -- candidate x genome copy finding: this build's GPU-native stage where the reference
+// shells out to `minimap2 -ax map-ont -N 300 -p 0.2` and filters the SAM records
+// (get_full_length_copies_minimap2 / get_copies_minimap2, /root/reference/module/Util.py:7933-8030).
+// minimap2 is third-party and absent: parity is pinned against the build's own CPU twin
+// (oracle/hite_oracle_copies.c, whose header holds the definition), record for record.
+//
+// Pipeline (sort / scan / segment, everything resident in HBM):
+//   index (once per genome): (w=10, k=15) minimizers straight from the 2-bit genome, one thread per
+//     window start, wave-aggregated append, radix sort by (hash|strand, position), 2^22-bucket directory;
+//   query: candidate minimizers -> directory lookup -> occurrence counts -> scan -> hit expansion
+//     (key = candidate | relative strand | diagonal) -> radix sort -> cluster flags where the diagonal
+//     jumps -> per-cluster anchor count and extreme anchors by 64-bit atomicMin/Max -> coverage
+//     filter + boundary extrapolation -> radix sort by (candidate | anchors desc | start) -> top 300.
+// Bound: HBM streaming for the sorts (12 B in + 12 B out per element per pass) and L2-latency for the
+// directory lookups; integer work only.
+#include "hite_common.h"
+#include "hite_scan.h"
+#include "hite_sort.h"
+#include "hite_arena.h"
+
+#define CK 15
+#define CW 10
+#define C_MAXOCC 2000
+#define C_TD 64
+#define C_MINANCH 3
+#define C_MAXCOPY 300
+#define HS_INVALID 0xffffffffu
+#define DIRBITS 22
+#define DBIAS 65536ll
+
+struct CopyState {
+    unsigned *idx_hs = nullptr, *idx_pos = nullptr, *dir = nullptr;
+    int64_t M = 0;
+    Arena arena;
+    int64_t *h_pin = nullptr;
+    int64_t *d_scal = nullptr;
+};
+
+__device__ __forceinline__ unsigned lowbias32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+__device__ __forceinline__ unsigned rev2_30(unsigned x) {  // reverse the order of the 15 2-bit groups
+    unsigned y = __brev(x) >> 2;
+    return ((y & 0x15555555u) << 1) | ((y >> 1) & 0x15555555u);
+}
+__device__ __forceinline__ unsigned hs_from_code(unsigned x) {
+    unsigned rc = rev2_30(x ^ 0x3fffffffu);
+    unsigned can = x < rc ? x : rc;
+    unsigned hs = (lowbias32(can) & ~1u) | (rc < x ? 1u : 0u);
+    if (hs >= 0xfffffffeu) hs -= 2;
+    return hs;
+}
+__device__ __forceinline__ int contig_of(const int64_t *__restrict__ coff, int nc, int64_t g) {
+    int lo = 0, hi = nc;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (coff[mid] <= g) lo = mid; else hi = mid; }
+    return lo;
+}
+// hs of the genome k-mer starting at global position g (contig [cb, ce))
+__device__ __forceinline__ unsigned genome_hs(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g,
+                                              int64_t ce) {
+    if (g + CK > ce) return HS_INVALID;
+    int64_t w = g >> 4; int sh = (int)(g & 15) * 2;
+    unsigned long long two = (unsigned long long)bases[w] | ((unsigned long long)bases[w + 1] << 32);
+    unsigned x = (unsigned)(two >> sh) & 0x3fffffffu;
+    int64_t mw = g >> 5; int msh = (int)(g & 31);
+    unsigned long long mt = (unsigned long long)nmask[mw] | ((unsigned long long)nmask[mw + 1] << 32);
+    if ((unsigned)(mt >> msh) & 0x7fffu) return HS_INVALID;
+    return hs_from_code(x);
+}
+__device__ __forceinline__ unsigned ascii_hs(const uint8_t *__restrict__ s, int64_t p, int64_t L) {
+    if (p < 0 || p + CK > L) return HS_INVALID;
+    unsigned x = 0;
+#pragma unroll
+    for (int i = 0; i < CK; i++) {
+        uint8_t c = s[p + i];
+        unsigned code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
+        if (code > 3u) return HS_INVALID;
+        x |= code << (2 * i);
+    }
+    return hs_from_code(x);
+}
+
+// minimizer of the window starting at k-mer start p of a sequence whose k-mer starts are [b, b+nk):
+// index of the valid k-mer with the smallest (hs >> 1, position) in [p, min(p+W, b+nk)), -1 if none
+template <typename HsFn>
+__device__ __forceinline__ int64_t window_min(int64_t p, int64_t b, int64_t nk, HsFn hs_at, unsigned *hs_out) {
+    int64_t hi = p + CW < b + nk ? p + CW : b + nk;
+    int64_t best = -1; unsigned bh = 0;
+    for (int64_t i = p; i < hi; i++) {
+        unsigned h = hs_at(i);
+        if (h == HS_INVALID) continue;
+        if (best < 0 || (h >> 1) < (bh >> 1)) { best = i; bh = h; }
+    }
+    *hs_out = bh;
+    return best;
+}
+
+// genome minimizers: thread = window start (global position).  key = hs << 32 | pos
+__global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                                               const int64_t *__restrict__ coff, int nc, int64_t G,
+                                                               unsigned long long *__restrict__ out, unsigned long long cap,
+                                                               unsigned long long *__restrict__ counter) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < G; p += (int64_t)gridDim.x * blockDim.x) {
+        int c = contig_of(coff, nc, p);
+        int64_t cb = coff[c], ce = coff[c + 1];
+        int64_t nk = ce - cb - CK + 1;
+        if (nk <= 0) continue;
+        int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
+        if (p - cb >= nwin) continue;
+        auto hs_at = [&](int64_t i) { return genome_hs(bases, nmask, i, ce); };
+        unsigned h, hp;
+        int64_t m = window_min(p, cb, nk, hs_at, &h);
+        if (m < 0) continue;
+        if (p > cb) { int64_t mp = window_min(p - 1, cb, nk, hs_at, &hp); if (mp == m) continue; }
+        unsigned long long slot = atomicAdd(counter, 1ull);
+        if (slot < cap) out[slot] = ((unsigned long long)h << 32) | (unsigned long long)(unsigned)m;
+    }
+}
+
+__global__ void split_index_kernel(int64_t M, const unsigned long long *__restrict__ keys, unsigned *__restrict__ hs,
+                                   unsigned *__restrict__ pos, unsigned *__restrict__ dircnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    unsigned h = (unsigned)(keys[i] >> 32);
+    hs[i] = h; pos[i] = (unsigned)keys[i];
+    atomicAdd(&dircnt[h >> (32 - DIRBITS)], 1u);
+}
+__global__ void i64_to_u32_kernel(int64_t n, const int64_t *__restrict__ in, unsigned *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (unsigned)in[i];
+}
+
+// candidate minimizers: thread = position in the concatenated candidate buffer
+__global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const uint8_t *__restrict__ cand,
+                                                             const int64_t *__restrict__ cand_off, int64_t total,
+                                                             unsigned *__restrict__ q_c, unsigned *__restrict__ q_pos,
+                                                             unsigned *__restrict__ q_hs, unsigned long long cap,
+                                                             unsigned long long *__restrict__ counter) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        int c = contig_of(cand_off, ncand, p);
+        int64_t cb = cand_off[c], L = cand_off[c + 1] - cb;
+        int64_t nk = L - CK + 1;
+        if (nk <= 0) continue;
+        int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
+        int64_t lp = p - cb;
+        if (lp >= nwin) continue;
+        const uint8_t *s = cand + cb;
+        auto hs_at = [&](int64_t i) { return ascii_hs(s, i, L); };
+        unsigned h, hp;
+        int64_t m = window_min(lp, 0, nk, hs_at, &h);
+        if (m < 0) continue;
+        if (lp > 0) { int64_t mp = window_min(lp - 1, 0, nk, hs_at, &hp); if (mp == m) continue; }
+        unsigned long long slot = atomicAdd(counter, 1ull);
+        if (slot < cap) { q_c[slot] = (unsigned)c; q_pos[slot] = (unsigned)m; q_hs[slot] = h; }
+    }
+}
+
+// occurrences of each candidate minimizer in the index (same hs >> 1)
+__global__ void occ_kernel(int64_t nq, const unsigned *__restrict__ q_hs, const unsigned *__restrict__ idx_hs,
+                           const unsigned *__restrict__ dir, unsigned *__restrict__ occ_lo, int32_t *__restrict__ occ_n) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq) return;
+    unsigned h31 = q_hs[t] >> 1;
+    unsigned b = q_hs[t] >> (32 - DIRBITS);
+    unsigned lo = dir[b], hi = dir[b + 1];
+    while (lo < hi) { unsigned mid = (lo + hi) >> 1; if ((idx_hs[mid] >> 1) < h31) lo = mid + 1; else hi = mid; }
+    unsigned e = lo, end = dir[b + 1];
+    while (e < end && (idx_hs[e] >> 1) == h31) e++;
+    int n = (int)(e - lo);
+    occ_lo[t] = lo;
+    occ_n[t] = n > C_MAXOCC ? 0 : n;
+}
+
+// hits: key = candidate << 34 | rel << 33 | (d + DBIAS), value = qo
+__global__ void hit_kernel(int64_t nq, const unsigned *__restrict__ q_c, const unsigned *__restrict__ q_pos,
+                           const unsigned *__restrict__ q_hs, const int64_t *__restrict__ cand_off,
+                           const unsigned *__restrict__ idx_hs, const unsigned *__restrict__ idx_pos,
+                           const unsigned *__restrict__ occ_lo, const int32_t *__restrict__ occ_n,
+                           const int64_t *__restrict__ hit_off, unsigned long long *__restrict__ hkey, unsigned *__restrict__ hval) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nq) return;
+    int n = occ_n[t];
+    if (n <= 0) return;
+    unsigned c = q_c[t];
+    long long Lq = cand_off[c + 1] - cand_off[c];
+    long long qp = q_pos[t];
+    unsigned qh = q_hs[t];
+    int64_t o = hit_off[t];
+    unsigned lo = occ_lo[t];
+    for (int i = 0; i < n; i++) {
+        unsigned gh = idx_hs[lo + i];
+        long long gpos = idx_pos[lo + i];
+        unsigned rel = (qh ^ gh) & 1u;
+        long long qo = rel ? (Lq - qp - CK) : qp;
+        long long d = gpos - qo + DBIAS;
+        hkey[o + i] = ((unsigned long long)c << 34) | ((unsigned long long)rel << 33) | (unsigned long long)d;
+        hval[o + i] = (unsigned)qo;
+    }
+}
+
+__global__ void cluster_flag_kernel(int64_t nh, const unsigned long long *__restrict__ hkey, const unsigned *__restrict__ hval,
+                                    const int64_t *__restrict__ coff, int nc, int32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nh) return;
+    int f = 1;
+    if (i > 0) {
+        unsigned long long a = hkey[i - 1], b = hkey[i];
+        long long da = (long long)(a & 0x1ffffffffull), db = (long long)(b & 0x1ffffffffull);
+        long long ga = da - DBIAS + hval[i - 1], gb = db - DBIAS + hval[i];
+        f = (a >> 33) != (b >> 33) || db - da > C_TD || contig_of(coff, nc, ga) != contig_of(coff, nc, gb);
+    }
+    flag[i] = f;
+}
+
+struct ClusterAcc { unsigned long long lo, hi; int cnt; int first; };
+
+__global__ void cluster_acc_kernel(int64_t nh, const unsigned long long *__restrict__ hkey, const unsigned *__restrict__ hval,
+                                   const int32_t *__restrict__ flag, const int64_t *__restrict__ cid_excl,
+                                   unsigned long long *__restrict__ c_lo, unsigned long long *__restrict__ c_hi,
+                                   int32_t *__restrict__ c_cnt, unsigned *__restrict__ c_first) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nh) return;
+    int64_t cid = cid_excl[i] + flag[i] - 1;
+    long long d = (long long)(hkey[i] & 0x1ffffffffull) - DBIAS;
+    unsigned qo = hval[i];
+    unsigned long long gpos = (unsigned long long)(d + qo);
+    unsigned long long v = ((unsigned long long)qo << 32) | (gpos & 0xffffffffull);
+    atomicMin(&c_lo[cid], v);
+    atomicMax(&c_hi[cid], v);
+    atomicAdd(&c_cnt[cid], 1);
+    if (flag[i]) c_first[cid] = (unsigned)i;
+}
+
+// accepted clusters -> copy records (appended) + sort key (candidate:19 | 4095-anchors:12 | start:32 | minus:1)
+__global__ void cluster_copy_kernel(int64_t ncl, const unsigned long long *__restrict__ hkey, const unsigned *__restrict__ c_first,
+                                    const unsigned long long *__restrict__ c_lo, const unsigned long long *__restrict__ c_hi,
+                                    const int32_t *__restrict__ c_cnt, const int64_t *__restrict__ cand_off,
+                                    const int64_t *__restrict__ coff, int nc, unsigned long long *__restrict__ ckey,
+                                    unsigned *__restrict__ cval, int32_t *__restrict__ r_contig, int64_t *__restrict__ r_s1,
+                                    int64_t *__restrict__ r_e1, uint8_t *__restrict__ r_minus, int32_t *__restrict__ r_anch,
+                                    int32_t *__restrict__ per_cand, unsigned long long *__restrict__ counter) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncl) return;
+    int na = c_cnt[k];
+    if (na < C_MINANCH) return;
+    unsigned long long key = hkey[c_first[k]];
+    unsigned c = (unsigned)(key >> 34);
+    unsigned rel = (unsigned)(key >> 33) & 1u;
+    long long Lq = cand_off[c + 1] - cand_off[c];
+    long long qlo = (long long)(c_lo[k] >> 32), glo = (long long)(c_lo[k] & 0xffffffffull);
+    long long qhi = (long long)(c_hi[k] >> 32), ghi = (long long)(c_hi[k] & 0xffffffffull);
+    if ((qhi + CK - qlo) * 100 < 80 * Lq) return;
+    int ctg = contig_of(coff, nc, glo);
+    long long s0 = glo - qlo, e0 = ghi + CK + (Lq - (qhi + CK));
+    long long cb = coff[ctg], ce = coff[ctg + 1];
+    if (s0 < cb) s0 = cb;
+    if (e0 > ce) e0 = ce;
+    if (e0 <= s0) return;
+    unsigned long long slot = atomicAdd(counter, 1ull);
+    r_contig[slot] = ctg; r_s1[slot] = s0 - cb + 1; r_e1[slot] = e0 - cb; r_minus[slot] = (uint8_t)rel; r_anch[slot] = na;
+    int ac = na > 4095 ? 4095 : na;
+    ckey[slot] = ((unsigned long long)c << 45) | ((unsigned long long)(4095 - ac) << 33) | ((unsigned long long)(unsigned)s0 << 1) | rel;
+    cval[slot] = (unsigned)slot;
+    atomicAdd(&per_cand[c], 1);
+}
+
+__global__ void cap300_kernel(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] > C_MAXCOPY ? C_MAXCOPY : in[i];
+}
+
+__global__ void emit_copies_kernel(int64_t ncp, const unsigned long long *__restrict__ ckey, const unsigned *__restrict__ cval,
+                                   const int64_t *__restrict__ cstart /* per candidate, all accepted */,
+                                   const int64_t *__restrict__ ofirst /* per candidate, kept */, const int32_t *__restrict__ r_contig,
+                                   const int64_t *__restrict__ r_s1, const int64_t *__restrict__ r_e1, const uint8_t *__restrict__ r_minus,
+                                   const int32_t *__restrict__ r_anch, int32_t *__restrict__ o_contig, int64_t *__restrict__ o_s1,
+                                   int64_t *__restrict__ o_e1, uint8_t *__restrict__ o_minus, int32_t *__restrict__ o_anch) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ncp) return;
+    unsigned c = (unsigned)(ckey[i] >> 45);
+    int64_t rank = i - cstart[c];
+    if (rank >= C_MAXCOPY) return;
+    int64_t o = ofirst[c] + rank;
+    unsigned s = cval[i];
+    o_contig[o] = r_contig[s]; o_s1[o] = r_s1[s]; o_e1[o] = r_e1[s]; o_minus[o] = r_minus[s]; o_anch[o] = r_anch[s];
+}
+__global__ void i64_to_i32_kernel(int64_t n, const int64_t *__restrict__ in, int32_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)in[i];
+}
+__global__ void fill_u64_kernel(int64_t n, unsigned long long *__restrict__ p, unsigned long long v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+#define CGRID(n) dim3((unsigned)((((n) > 0 ? (n) : 1) + 255) / 256)), dim3(256)
+#define CCHK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+static int sorter_from_arena(Sorter &S, hite_ctx *ctx, Arena &A, hipStream_t st, int64_t n) {
+    S.ctx = ctx; S.st = st; S.cap = n;
+    int64_t nblocks = (n + RS_TILE - 1) / RS_TILE; if (nblocks < 1) nblocks = 1;
+    S.hist_n = 256 * nblocks;
+    void *p;
+    CCHK(arena_alloc(ctx, A, (size_t)(n + 1) * 8, &p)); S.k2 = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(n + 1) * 4, &p)); S.v2 = (unsigned *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)S.hist_n * 4, &p)); S.hist = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(S.hist_n + 1) * 8, &p)); S.offs = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(S.hist_n) * 8, &p)); S.bs = (int64_t *)p;
+    return HITE_OK;
+}
+
+extern "C" void hite_copy_index_release(void *state) {
+    CopyState *S = (CopyState *)state;
+    if (!S) return;
+    if (S->idx_hs) (void)hipFree(S->idx_hs);
+    if (S->idx_pos) (void)hipFree(S->idx_pos);
+    if (S->dir) (void)hipFree(S->dir);
+    arena_free(S->arena);
+    if (S->h_pin) (void)hipHostFree(S->h_pin);
+    if (S->d_scal) (void)hipFree(S->d_scal);
+    delete S;
+}
+
+static int read_back(hite_ctx *ctx, CopyState *S, hipStream_t st, int count) {
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, sizeof(int64_t) * count, hipMemcpyDeviceToHost, st));
+    HITE_CHECK(ctx, hipStreamSynchronize(st));
+    return HITE_OK;
+}
+
+// builds the minimizer index of the packed genome; *state_io receives the index handle
+extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream) {
+    if (!ctx || !ctx->d_bases || !state_io) return HITE_EINVAL;
+    if (ctx->n_bases >= 0xfffe0000ll) return HITE_EINVAL;  // positions are 32-bit
+    hipStream_t st = (hipStream_t)stream;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    if (*state_io) hite_copy_index_release(*state_io);
+    CopyState *S = new CopyState();
+    *state_io = S;
+    HITE_CHECK(ctx, hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)));
+    HITE_CHECK(ctx, hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)));
+    const int64_t G = ctx->n_bases;
+    unsigned long long cap = (unsigned long long)(G * 0.32) + 4096;
+    unsigned long long *keys = nullptr;
+    unsigned *vals = nullptr;
+    HITE_CHECK(ctx, hipMalloc((void **)&keys, cap * 8));
+    HITE_CHECK(ctx, hipMalloc((void **)&vals, cap * 4));
+    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    int64_t blocks = (G + 255) / 256; if (blocks > 256 * 64) blocks = 256 * 64;
+    hipLaunchKernelGGL(genome_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
+                       ctx->n_contigs, G, keys, cap, (unsigned long long *)S->d_scal);
+    HITE_CHECK(ctx, hipGetLastError());
+    CCHK(read_back(ctx, S, st, 1));
+    const int64_t M = S->h_pin[0];
+    if ((unsigned long long)M > cap) { (void)hipFree(keys); (void)hipFree(vals); return HITE_ECAP; }
+    S->M = M;
+    Sorter so;
+    if (sorter_init(so, ctx, st, M > 0 ? M : 1)) { (void)hipFree(keys); (void)hipFree(vals); return HITE_EHIP; }
+    int rc = sorter_sort(so, keys, vals, M, 64);
+    if (rc) { sorter_free(so); (void)hipFree(keys); (void)hipFree(vals); return rc; }
+    HITE_CHECK(ctx, hipMalloc((void **)&S->idx_hs, (size_t)(M + 16) * 4));
+    HITE_CHECK(ctx, hipMalloc((void **)&S->idx_pos, (size_t)(M + 16) * 4));
+    HITE_CHECK(ctx, hipMalloc((void **)&S->dir, (size_t)((1 << DIRBITS) + 2) * 4));
+    unsigned *dircnt = nullptr;
+    int64_t *diroff = nullptr, *bs = nullptr;
+    HITE_CHECK(ctx, hipMalloc((void **)&dircnt, (size_t)((1 << DIRBITS) + 2) * 4));
+    HITE_CHECK(ctx, hipMalloc((void **)&diroff, (size_t)((1 << DIRBITS) + 2) * 8));
+    HITE_CHECK(ctx, hipMalloc((void **)&bs, (size_t)scan_tmp_elems((1 << DIRBITS) + 1) * 8));
+    HITE_CHECK(ctx, hipMemsetAsync(dircnt, 0, (size_t)((1 << DIRBITS) + 2) * 4, st));
+    hipLaunchKernelGGL(split_index_kernel, CGRID(M), 0, st, M, keys, S->idx_hs, S->idx_pos, dircnt);
+    rc = scan_excl_buf<int32_t>(ctx, bs, (int32_t *)dircnt, (int64_t)(1 << DIRBITS), diroff, st);
+    hipLaunchKernelGGL(i64_to_u32_kernel, CGRID((int64_t)(1 << DIRBITS) + 1), 0, st, (int64_t)(1 << DIRBITS) + 1, diroff, S->dir);
+    HITE_CHECK(ctx, hipStreamSynchronize(st));
+    sorter_free(so);
+    (void)hipFree(keys); (void)hipFree(vals); (void)hipFree(dircnt); (void)hipFree(diroff); (void)hipFree(bs);
+    return rc;
+}
+
+// candidates (device) -> copy table (device arrays owned by the index state's arena; valid until the next call)
+extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8_t *d_cand, const int64_t *d_cand_off,
+                                    int64_t cand_bytes, int32_t **d_copy_first, int64_t *n_copies, int32_t **d_contig,
+                                    int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus, int32_t **d_anchors, void *stream) {
+    CopyState *S = (CopyState *)state;
+    if (!ctx || !S || !ctx->d_bases || n_cand < 0 || n_cand >= (1 << 19) || !n_copies) return HITE_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    CCHK(arena_reset(ctx, S->arena, true));
+    Arena &A = S->arena;
+    void *p;
+    int32_t *ofirst32;
+    CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 4, &p)); ofirst32 = (int32_t *)p;
+    *d_copy_first = ofirst32; *n_copies = 0;
+    HITE_CHECK(ctx, hipMemsetAsync(ofirst32, 0, (size_t)(n_cand + 2) * 4, st));
+    *d_contig = nullptr; *d_start1 = nullptr; *d_end1 = nullptr; *d_minus = nullptr; *d_anchors = nullptr;
+    if (n_cand == 0 || cand_bytes <= 0 || S->M == 0) return HITE_OK;
+    // candidate minimizers
+    unsigned long long qcap = (unsigned long long)(cand_bytes * 0.32) + 4096 + (unsigned long long)n_cand;
+    unsigned *q_c, *q_pos, *q_hs, *occ_lo, *hval, *c_first, *cval;
+    int32_t *occ_n, *flag, *c_cnt, *per_cand, *per_cand300;
+    int64_t *hit_off, *cid, *bs, *cstart, *ofirst;
+    unsigned long long *hkey, *c_lo, *c_hi, *ckey;
+    CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_c = (unsigned *)p;
+    CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_pos = (unsigned *)p;
+    CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_hs = (unsigned *)p;
+    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    {
+        int64_t blocks = (cand_bytes + 255) / 256; if (blocks > 256 * 64) blocks = 256 * 64;
+        hipLaunchKernelGGL(cand_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, cand_bytes, q_c,
+                           q_pos, q_hs, qcap, (unsigned long long *)S->d_scal);
+    }
+    CCHK(read_back(ctx, S, st, 1));
+    const int64_t nq = S->h_pin[0];
+    if ((unsigned long long)nq > qcap) return HITE_ECAP;
+    if (nq == 0) return HITE_OK;
+    CCHK(arena_alloc(ctx, A, (size_t)nq * 4, &p)); occ_lo = (unsigned *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)nq * 4, &p)); occ_n = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(nq + 1) * 8, &p)); hit_off = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(nq) * 8, &p)); bs = (int64_t *)p;
+    hipLaunchKernelGGL(occ_kernel, CGRID(nq), 0, st, nq, q_hs, S->idx_hs, S->dir, occ_lo, occ_n);
+    CCHK(scan_excl_buf<int32_t>(ctx, bs, occ_n, nq, hit_off, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, hit_off + nq, 8, hipMemcpyDeviceToDevice, st));
+    CCHK(read_back(ctx, S, st, 1));
+    const int64_t nh = S->h_pin[0];
+    if (nh == 0) return HITE_OK;
+    if (nh >= 0xffffffffll) return HITE_ECAP;
+    CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 8, &p)); hkey = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 4, &p)); hval = (unsigned *)p;
+    hipLaunchKernelGGL(hit_kernel, CGRID(nq), 0, st, nq, q_c, q_pos, q_hs, d_cand_off, S->idx_hs, S->idx_pos, occ_lo, occ_n, hit_off, hkey, hval);
+    Sorter so;
+    CCHK(sorter_from_arena(so, ctx, A, st, nh));
+    int cbits = 1; while ((1ll << cbits) < n_cand) cbits++;
+    CCHK(sorter_sort(so, hkey, hval, nh, 34 + cbits));
+    // clusters
+    CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 4, &p)); flag = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(nh + 2) * 8, &p)); cid = (int64_t *)p;
+    int64_t *bs2;
+    CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(nh) * 8, &p)); bs2 = (int64_t *)p;
+    hipLaunchKernelGGL(cluster_flag_kernel, CGRID(nh), 0, st, nh, hkey, hval, ctx->d_contig_off, ctx->n_contigs, flag);
+    CCHK(scan_excl_buf<int32_t>(ctx, bs2, flag, nh, cid, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cid + nh, 8, hipMemcpyDeviceToDevice, st));
+    CCHK(read_back(ctx, S, st, 1));
+    const int64_t ncl = S->h_pin[0];
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); c_lo = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); c_hi = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); c_cnt = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); c_first = (unsigned *)p;
+    hipLaunchKernelGGL(fill_u64_kernel, CGRID(ncl), 0, st, ncl, c_lo, 0xffffffffffffffffull);
+    HITE_CHECK(ctx, hipMemsetAsync(c_hi, 0, (size_t)(ncl + 1) * 8, st));
+    HITE_CHECK(ctx, hipMemsetAsync(c_cnt, 0, (size_t)(ncl + 1) * 4, st));
+    hipLaunchKernelGGL(cluster_acc_kernel, CGRID(nh), 0, st, nh, hkey, hval, flag, cid, c_lo, c_hi, c_cnt, c_first);
+    // clusters -> copies
+    int32_t *r_contig, *r_anch;
+    int64_t *r_s1, *r_e1;
+    uint8_t *r_minus;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); ckey = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); cval = (unsigned *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); r_contig = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); r_s1 = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); r_e1 = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 16), &p)); r_minus = (uint8_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); r_anch = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); per_cand = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); per_cand300 = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); cstart = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); ofirst = (int64_t *)p;
+    HITE_CHECK(ctx, hipMemsetAsync(per_cand, 0, (size_t)(n_cand + 1) * 4, st));
+    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    hipLaunchKernelGGL(cluster_copy_kernel, CGRID(ncl), 0, st, ncl, hkey, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
+                       ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, per_cand, (unsigned long long *)S->d_scal);
+    hipLaunchKernelGGL(cap300_kernel, CGRID((int64_t)n_cand), 0, st, n_cand, per_cand, per_cand300);
+    int64_t *bs3;
+    CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(n_cand) * 8, &p)); bs3 = (int64_t *)p;
+    CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand, n_cand, cstart, st));
+    CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand300, n_cand, ofirst, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, ofirst + n_cand, 8, hipMemcpyDeviceToDevice, st));
+    CCHK(read_back(ctx, S, st, 2));
+    const int64_t ncp = S->h_pin[0], nout = S->h_pin[1];
+    *n_copies = nout;
+    hipLaunchKernelGGL(i64_to_i32_kernel, CGRID((int64_t)n_cand + 1), 0, st, (int64_t)n_cand + 1, ofirst, ofirst32);
+    if (ncp == 0) return HITE_OK;
+    Sorter so2;
+    CCHK(sorter_from_arena(so2, ctx, A, st, ncp));
+    CCHK(sorter_sort(so2, ckey, cval, ncp, 64));
+    int32_t *o_contig, *o_anch;
+    int64_t *o_s1, *o_e1;
+    uint8_t *o_minus;
+    CCHK(arena_alloc(ctx, A, (size_t)(nout + 1) * 4, &p)); o_contig = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(nout + 1) * 8, &p)); o_s1 = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(nout + 1) * 8, &p)); o_e1 = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(nout + 16), &p)); o_minus = (uint8_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(nout + 1) * 4, &p)); o_anch = (int32_t *)p;
+    hipLaunchKernelGGL(emit_copies_kernel, CGRID(ncp), 0, st, ncp, ckey, cval, cstart, ofirst, r_contig, r_s1, r_e1, r_minus, r_anch,
+                       o_contig, o_s1, o_e1, o_minus, o_anch);
+    HITE_CHECK(ctx, hipGetLastError());
+    *d_contig = o_contig; *d_start1 = o_s1; *d_end1 = o_e1; *d_minus = o_minus; *d_anchors = o_anch;
+    return HITE_OK;
+}
+
+// host-buffer wrapper: builds the index if *state_io is NULL, uploads the candidates, downloads the table
+extern "C" int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
+                                int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
+                                int32_t *anchors, int64_t *n_out) {
+    if (!ctx || !state_io || !cand || !cand_off || !copy_first || !n_out) return HITE_EINVAL;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    if (!*state_io) CCHK(hite_copy_index_build(ctx, state_io, nullptr));
+    uint8_t *dc = nullptr;
+    int64_t *dco = nullptr;
+    int64_t bytes = cand_off[n_cand];
+    HITE_CHECK(ctx, hipMalloc((void **)&dc, (size_t)bytes + 64));
+    HITE_CHECK(ctx, hipMalloc((void **)&dco, (size_t)(n_cand + 1) * 8));
+    HITE_CHECK(ctx, hipMemcpy(dc, cand, (size_t)bytes, hipMemcpyHostToDevice));
+    HITE_CHECK(ctx, hipMemcpy(dco, cand_off, (size_t)(n_cand + 1) * 8, hipMemcpyHostToDevice));
+    int32_t *dcf, *dct, *dan;
+    int64_t *ds1, *de1;
+    uint8_t *dmn;
+    int64_t n = 0;
+    int rc = hite_find_copies_dev(ctx, *state_io, n_cand, dc, dco, bytes, &dcf, &n, &dct, &ds1, &de1, &dmn, &dan, nullptr);
+    if (rc == HITE_OK) {
+        *n_out = n;
+        if (hipDeviceSynchronize() != hipSuccess) rc = HITE_EHIP;
+        else if (n > cap) rc = HITE_ECAP;
+        else {
+            hipError_t e = hipMemcpy(copy_first, dcf, (size_t)(n_cand + 1) * 4, hipMemcpyDeviceToHost);
+            if (n > 0) {
+                if (e == hipSuccess) e = hipMemcpy(contig, dct, (size_t)n * 4, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(start1, ds1, (size_t)n * 8, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(end1, de1, (size_t)n * 8, hipMemcpyDeviceToHost);
+                if (e == hipSuccess) e = hipMemcpy(minus, dmn, (size_t)n, hipMemcpyDeviceToHost);
+                if (e == hipSuccess && anchors) e = hipMemcpy(anchors, dan, (size_t)n * 4, hipMemcpyDeviceToHost);
+            }
+            if (e != hipSuccess) rc = HITE_EHIP;
+        }
+    }
+    (void)hipFree(dc); (void)hipFree(dco);
+    return rc;
+}

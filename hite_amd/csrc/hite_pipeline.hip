@@ -14,6 +14,7 @@
 #include "hite_common.h"
 #include "hite_genome.h"
 #include "hite_scan.h"
+#include "hite_arena.h"
 #include <vector>
 
 extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n, const uint8_t *d_msa,
@@ -23,65 +24,11 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
 
 #define MAXROWS 100
 
-// ---------------------------------------------------------------------------------------------
-// arenas (grow-only, reset per call; no hipMalloc on the steady-state path)
-// ---------------------------------------------------------------------------------------------
-struct Arena {
-    std::vector<void *> chunks;
-    std::vector<size_t> caps;
-    size_t cur = 0;   // chunk being filled
-    size_t off = 0;   // bytes used in it
-};
 struct PipeState {
     Arena keep, tmp;
     int64_t *h_pin = nullptr;  // pinned scalars for read-backs
     int64_t *d_scal = nullptr;
 };
-
-static int arena_alloc(hite_ctx *ctx, Arena &a, size_t bytes, void **out) {
-    bytes = (bytes + 255) & ~(size_t)255;
-    if (bytes == 0) bytes = 256;
-    // first chunk (from the current one on) that still has room
-    while (a.cur < a.chunks.size() && a.off + bytes > a.caps[a.cur]) { a.cur++; a.off = 0; }
-    if (a.cur >= a.chunks.size()) {
-        size_t want = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
-        void *p = nullptr;
-        HITE_CHECK(ctx, hipMalloc(&p, want));
-        a.chunks.push_back(p);
-        a.caps.push_back(want);
-        a.cur = a.chunks.size() - 1;
-        a.off = 0;
-    }
-    *out = (uint8_t *)a.chunks[a.cur] + a.off;
-    a.off += bytes;
-    return HITE_OK;
-}
-// soft reset: hand the same memory out again (stream order protects the reuse).
-// hard reset (start of a call): if the arena grew into several chunks, replace them by one chunk of
-// the total capacity, so that the steady state never calls hipMalloc.
-static int arena_reset(hite_ctx *ctx, Arena &a, bool hard) {
-    if (hard && a.chunks.size() > 1) {
-        HITE_CHECK(ctx, hipDeviceSynchronize());
-        size_t total = 0;
-        for (size_t c : a.caps) total += c;
-        for (void *p : a.chunks) (void)hipFree(p);
-        a.chunks.clear();
-        a.caps.clear();
-        void *p = nullptr;
-        HITE_CHECK(ctx, hipMalloc(&p, total));
-        a.chunks.push_back(p);
-        a.caps.push_back(total);
-    }
-    a.cur = 0;
-    a.off = 0;
-    return HITE_OK;
-}
-static void arena_free(Arena &a) {
-    for (void *p : a.chunks) (void)hipFree(p);
-    a.chunks.clear();
-    a.caps.clear();
-    a.cur = a.off = 0;
-}
 
 extern "C" void hite_pipeline_release(void *state) {
     PipeState *s = (PipeState *)state;

@@ -155,6 +155,25 @@ int hite_tsd_kmer(hite_ctx *ctx, int32_t n, const uint8_t *seqs, const int64_t *
 int hite_tsd_kmer_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_seqs, const int64_t *d_seq_off, int32_t flank,
                       int32_t plant, int32_t *d_rec_out, int32_t *d_cnt_out, void *stream);
 
+/* ---- copy finding: this build's GPU-native stage where the reference runs the external
+ * `minimap2 -ax map-ont -N 300 -p 0.2` + SAM filtering (get_full_length_copies_minimap2, Util.py:7933-8030;
+ * third-party, unpinned -> parity is pinned against the build's own CPU twin, oracle/hite_oracle_copies.c,
+ * whose header holds the definition: (w=10,k=15) minimizers, diagonal clustering, >= 3 anchors spanning
+ * >= 80 % of the candidate, boundaries extrapolated from the extreme anchors, <= 300 copies per candidate
+ * ordered by anchors).  Needs a packed genome (< 4 Gbp).  The index handle (*state_io, initially NULL)
+ * is built once per genome; free it with hite_copy_index_release.
+ * Output = the copy table get_full_length_copies_minimap2 returns, as the CSR that
+ * hite_flank_region_align consumes (1-based inclusive coordinates).  n_cand < 2^19 per call.
+ * _dev: the returned device arrays live in the index state's arena until the next call. */
+int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream);
+void hite_copy_index_release(void *state);
+int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
+                     int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
+                     int32_t *anchors, int64_t *n_out);
+int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8_t *d_cand, const int64_t *d_cand_off,
+                         int64_t cand_bytes, int32_t **d_copy_first, int64_t *n_copies, int32_t **d_contig,
+                         int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus, int32_t **d_anchors, void *stream);
+
 /* ---- star alignment: this build's GPU-native stage where the reference runs the external
  * `mafft --preservecase --quiet --thread 1` (Util.py:10416; third-party, unpinned -> parity is
  * pinned against the build's own CPU twin, oracle/hite_oracle_msa.c).

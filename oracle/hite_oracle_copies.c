@@ -1,0 +1,224 @@
+/*
+ * hite_oracle_copies.c -- TEST INFRASTRUCTURE ONLY (see hite_oracle.c header).
+ *
+ * CPU twin of the build's OWN copy-finding stage (hite_amd/csrc/hite_copies.hip), which stands where
+ * the reference shells out to `minimap2 -ax map-ont -N 300 -p 0.2` and filters the SAM records
+ * (get_full_length_copies_minimap2 / get_copies_minimap2, /root/reference/module/Util.py:7933-8030).
+ * minimap2 2.28 is third-party and absent from this image: PARITY UNPINNED at that boundary; what is
+ * pinned is HIP output == this twin, record for record.
+ *
+ * Definition (shared with the HIP kernels)
+ *   k-mer code (K=15): x = sum code(base_i) << 2i, A0 C1 G2 T3; rc = rev2(x ^ 0x3fffffff);
+ *   canonical = min(x, rc), strand = rc < x; hs = (lowbias32(canonical) & ~1) | strand, values
+ *   >= 0xfffffffe lowered by 2; a k-mer with a non-ACGT base or crossing a sequence end is invalid.
+ *   Minimizer of a window of W=10 consecutive k-mer starts = the valid k-mer with the smallest
+ *   (hs >> 1, position); the minimizers of a sequence are the distinct window minimizers
+ *   (sequences with fewer than W k-mers form one window).
+ *   Index = genome minimizers sorted by (hs, position).  For every candidate minimizer the index
+ *   entries with the same hs >> 1 are its occurrences (skipped when more than MAXOCC = 2000);
+ *   an occurrence gives a hit: rel = strand_q ^ strand_g, qo = rel ? Lq - qpos - K : qpos,
+ *   d = gpos - qo.  Hits are sorted by (candidate, rel, d); a new cluster starts when candidate, rel
+ *   or the contig of gpos changes or d jumps by more than TD = 64.  A cluster with >= 3 anchors whose
+ *   anchor span (max qo + K - min qo) covers >= 80 % of the candidate becomes a copy:
+ *   start0 = gpos(min qo) - min qo, end0 = gpos(max qo) + K + (Lq - (max qo + K)), clamped to the
+ *   contig (ties: min qo -> smallest gpos, max qo -> largest gpos).  Per candidate the copies are
+ *   ordered by (anchors descending (capped at 4095), start ascending) and the first 300 are kept.
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_EINVAL (-1002)
+#define ORC_ECAP (-1001)
+#define CK 15
+#define CW 10
+#define MAXOCC 2000
+#define TD 64
+#define MINANCH 3
+#define MAXCOPY 300
+#define HS_INVALID 0xffffffffu
+
+static uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+static uint32_t rev2_30(uint32_t x) { /* reverse the order of the 15 2-bit groups of a 30-bit value */
+    uint32_t y = 0;
+    for (int i = 0; i < 15; i++) y |= ((x >> (2 * i)) & 3u) << (2 * (14 - i));
+    return y;
+}
+static int code_of(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
+
+/* hs of the k-mer starting at p of seq[0..L) */
+static uint32_t kmer_hs(const uint8_t *seq, int64_t L, int64_t p) {
+    if (p < 0 || p + CK > L) return HS_INVALID;
+    uint32_t x = 0;
+    for (int i = 0; i < CK; i++) {
+        int c = code_of(seq[p + i]);
+        if (c < 0) return HS_INVALID;
+        x |= (uint32_t)c << (2 * i);
+    }
+    uint32_t rc = rev2_30(x ^ 0x3fffffffu);
+    uint32_t can = x < rc ? x : rc;
+    uint32_t strand = rc < x ? 1u : 0u;
+    uint32_t hs = (lowbias32(can) & ~1u) | strand;
+    if (hs >= 0xfffffffeu) hs -= 2;
+    return hs;
+}
+
+typedef struct { uint32_t hs; int64_t pos; } mini_t;
+
+/* minimizers of seq[0..L); pos offset added; returns count (out may be NULL to count) */
+static int64_t minimizers(const uint8_t *seq, int64_t L, int64_t pos_off, mini_t *out) {
+    int64_t nk = L - CK + 1;
+    if (nk <= 0) return 0;
+    uint32_t *hs = (uint32_t *)malloc(sizeof(uint32_t) * nk);
+    for (int64_t p = 0; p < nk; p++) hs[p] = kmer_hs(seq, L, p);
+    int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
+    int64_t n = 0, last = -1;
+    for (int64_t p = 0; p < nwin; p++) {
+        int64_t hi = p + CW < nk ? p + CW : nk;
+        int64_t best = -1;
+        for (int64_t i = p; i < hi; i++) {
+            if (hs[i] == HS_INVALID) continue;
+            if (best < 0 || (hs[i] >> 1) < (hs[best] >> 1)) best = i;
+        }
+        if (best >= 0 && best != last) {
+            if (out) { out[n].hs = hs[best]; out[n].pos = pos_off + best; }
+            n++;
+            last = best;
+        }
+    }
+    free(hs);
+    return n;
+}
+
+static int cmp_mini(const void *a, const void *b) {
+    const mini_t *x = (const mini_t *)a, *y = (const mini_t *)b;
+    if (x->hs != y->hs) return x->hs < y->hs ? -1 : 1;
+    if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+    return 0;
+}
+
+typedef struct { int32_t c, rel; int64_t d; int32_t qo; int64_t gpos; } hit_t;
+static int cmp_hit(const void *a, const void *b) {
+    const hit_t *x = (const hit_t *)a, *y = (const hit_t *)b;
+    if (x->c != y->c) return x->c < y->c ? -1 : 1;
+    if (x->rel != y->rel) return x->rel < y->rel ? -1 : 1;
+    if (x->d != y->d) return x->d < y->d ? -1 : 1;
+    return 0; /* order among equal (c, rel, d) does not influence the result */
+}
+typedef struct { int32_t c, contig, minus, anch; int64_t start1, end1, gstart; } copy_t;
+static int cmp_copy(const void *a, const void *b) {
+    const copy_t *x = (const copy_t *)a, *y = (const copy_t *)b;
+    if (x->c != y->c) return x->c < y->c ? -1 : 1;
+    int ax = x->anch > 4095 ? 4095 : x->anch, ay = y->anch > 4095 ? 4095 : y->anch;
+    if (ax != ay) return ax > ay ? -1 : 1;
+    if (x->gstart != y->gstart) return x->gstart < y->gstart ? -1 : 1;
+    if (x->minus != y->minus) return x->minus < y->minus ? -1 : 1;
+    return 0;
+}
+static int contig_of(const int64_t *coff, int nc, int64_t g) {
+    int lo = 0, hi = nc;
+    while (hi - lo > 1) { int mid = (lo + hi) / 2; if (coff[mid] <= g) lo = mid; else hi = mid; }
+    return lo;
+}
+
+/*
+ * genome: contigs concatenated (upper-case ASCII), contig_off[ncontig+1].  Candidates: cand + cand_off.
+ * Output: CSR copy_first[ncand+1] into (contig, start1, end1 (1-based inclusive), minus, anchors).
+ * Returns total copies or <0.
+ */
+int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int ncontig, const uint8_t *cand,
+                        const int64_t *cand_off, int ncand, int64_t cap, int32_t *copy_first, int32_t *contig,
+                        int64_t *start1, int64_t *end1, uint8_t *minus, int32_t *anchors) {
+    if (ncontig <= 0 || ncand < 0) return ORC_EINVAL;
+    /* index */
+    int64_t M = 0;
+    for (int c = 0; c < ncontig; c++) M += minimizers(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], NULL);
+    mini_t *idx = (mini_t *)malloc(sizeof(mini_t) * (M + 1));
+    int64_t k = 0;
+    for (int c = 0; c < ncontig; c++) k += minimizers(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], idx + k);
+    qsort(idx, M, sizeof(mini_t), cmp_mini);
+    /* hits */
+    int64_t hcap = 1 << 16, nh = 0;
+    hit_t *hits = (hit_t *)malloc(sizeof(hit_t) * hcap);
+    for (int c = 0; c < ncand; c++) {
+        const uint8_t *q = cand + cand_off[c];
+        int64_t Lq = cand_off[c + 1] - cand_off[c];
+        int64_t nm = minimizers(q, Lq, 0, NULL);
+        if (nm <= 0) continue;
+        mini_t *qm = (mini_t *)malloc(sizeof(mini_t) * nm);
+        minimizers(q, Lq, 0, qm);
+        for (int64_t t = 0; t < nm; t++) {
+            uint32_t h31 = qm[t].hs >> 1;
+            /* lower bound of hs >= h31 << 1 */
+            int64_t lo = 0, hi = M;
+            while (lo < hi) { int64_t mid = (lo + hi) / 2; if ((idx[mid].hs >> 1) < h31) lo = mid + 1; else hi = mid; }
+            int64_t e = lo;
+            while (e < M && (idx[e].hs >> 1) == h31) e++;
+            if (e - lo > MAXOCC) continue;
+            for (int64_t i = lo; i < e; i++) {
+                if (nh == hcap) { hcap *= 2; hits = (hit_t *)realloc(hits, sizeof(hit_t) * hcap); }
+                int rel = (int)((qm[t].hs ^ idx[i].hs) & 1u);
+                int64_t qo = rel ? (Lq - qm[t].pos - CK) : qm[t].pos;
+                hits[nh].c = c; hits[nh].rel = rel; hits[nh].qo = (int32_t)qo; hits[nh].gpos = idx[i].pos;
+                hits[nh].d = idx[i].pos - qo;
+                nh++;
+            }
+        }
+        free(qm);
+    }
+    qsort(hits, nh, sizeof(hit_t), cmp_hit);
+    /* clusters -> copies */
+    int64_t ccap = 1 << 12, ncp = 0;
+    copy_t *cps = (copy_t *)malloc(sizeof(copy_t) * ccap);
+    int64_t i = 0;
+    while (i < nh) {
+        int64_t j = i + 1;
+        int ctg = contig_of(contig_off, ncontig, hits[i].gpos);
+        while (j < nh && hits[j].c == hits[i].c && hits[j].rel == hits[i].rel &&
+               contig_of(contig_off, ncontig, hits[j].gpos) == ctg && hits[j].d - hits[j - 1].d <= TD) j++;
+        int64_t Lq = cand_off[hits[i].c + 1] - cand_off[hits[i].c];
+        int64_t qlo = hits[i].qo, glo = hits[i].gpos, qhi = hits[i].qo, ghi = hits[i].gpos;
+        for (int64_t t = i; t < j; t++) {
+            if (hits[t].qo < qlo || (hits[t].qo == qlo && hits[t].gpos < glo)) { qlo = hits[t].qo; glo = hits[t].gpos; }
+            if (hits[t].qo > qhi || (hits[t].qo == qhi && hits[t].gpos > ghi)) { qhi = hits[t].qo; ghi = hits[t].gpos; }
+        }
+        int64_t na = j - i;
+        if (na >= MINANCH && (qhi + CK - qlo) * 100 >= 80 * Lq) {
+            int64_t s0 = glo - qlo, e0 = ghi + CK + (Lq - (qhi + CK));
+            int64_t cb = contig_off[ctg], ce = contig_off[ctg + 1];
+            if (s0 < cb) s0 = cb;
+            if (e0 > ce) e0 = ce;
+            if (e0 > s0) {
+                if (ncp == ccap) { ccap *= 2; cps = (copy_t *)realloc(cps, sizeof(copy_t) * ccap); }
+                cps[ncp].c = hits[i].c; cps[ncp].contig = ctg; cps[ncp].minus = hits[i].rel; cps[ncp].anch = (int32_t)na;
+                cps[ncp].start1 = s0 - cb + 1; cps[ncp].end1 = e0 - cb; cps[ncp].gstart = s0;
+                ncp++;
+            }
+        }
+        i = j;
+    }
+    qsort(cps, ncp, sizeof(copy_t), cmp_copy);
+    int64_t nout = 0;
+    int cur = 0;
+    copy_first[0] = 0;
+    int64_t p = 0;
+    for (int c = 0; c < ncand; c++) {
+        int kept = 0;
+        while (p < ncp && cps[p].c == c) {
+            if (kept < MAXCOPY) {
+                if (nout >= cap) { free(idx); free(hits); free(cps); return ORC_ECAP; }
+                contig[nout] = cps[p].contig; start1[nout] = cps[p].start1; end1[nout] = cps[p].end1;
+                minus[nout] = (uint8_t)cps[p].minus; anchors[nout] = cps[p].anch;
+                nout++; kept++;
+            }
+            p++;
+        }
+        copy_first[c + 1] = (int32_t)nout;
+    }
+    (void)cur;
+    free(idx); free(hits); free(cps);
+    return nout;
+}

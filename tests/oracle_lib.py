@@ -26,11 +26,12 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("hite_oracle.c", "hite_oracle_coarse.c", "hite_oracle_msa.c")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in ("hite_oracle.c", "hite_oracle_coarse.c", "hite_oracle_msa.c", "hite_oracle_copies.c")]
         if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
             build()
         _lib = C.CDLL(SO)
         _lib.orc_flank_window.restype = C.c_int64
+        _lib.orc_find_copies.restype = C.c_int64
     return _lib
 
 
@@ -201,3 +202,26 @@ def star_msa(windows):
     rc = lib().orc_star_msa(_ptr(buf, u8p), _ptr(off, i64p), len(wb), C.byref(cols), _ptr(out, u8p), C.c_int64(out.size))
     assert rc == 0, rc
     return out
+
+
+def find_copies(contigs, cands):
+    """this build's minimap2 stand-in: -> per candidate list of (contig, start1, end1, minus, anchors)"""
+    gb = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]
+    coff = np.zeros(len(gb) + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in gb], out=coff[1:])
+    gbuf = np.frombuffer(b"".join(gb), dtype=np.uint8)
+    cb = [c.encode() if isinstance(c, str) else bytes(c) for c in cands]
+    qoff = np.zeros(len(cb) + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in cb], out=qoff[1:])
+    qbuf = np.frombuffer(b"".join(cb) + b"\0", dtype=np.uint8)
+    cap = 300 * len(cb) + 16
+    cf = np.zeros(len(cb) + 1, dtype=np.int32)
+    ct = np.zeros(cap, dtype=np.int32)
+    s1 = np.zeros(cap, dtype=np.int64)
+    e1 = np.zeros(cap, dtype=np.int64)
+    mn = np.zeros(cap, dtype=np.uint8)
+    an = np.zeros(cap, dtype=np.int32)
+    n = lib().orc_find_copies(_ptr(gbuf, u8p), _ptr(coff, i64p), len(gb), _ptr(qbuf, u8p), _ptr(qoff, i64p), len(cb), C.c_int64(cap),
+                              _ptr(cf, i32p), _ptr(ct, i32p), _ptr(s1, i64p), _ptr(e1, i64p), _ptr(mn, u8p), _ptr(an, i32p))
+    assert n >= 0, n
+    return [[(int(ct[i]), int(s1[i]), int(e1[i]), int(mn[i]), int(an[i])) for i in range(cf[c], cf[c + 1])] for c in range(len(cb))]

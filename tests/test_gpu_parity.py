@@ -323,3 +323,28 @@ def test_fmea_random_vs_oracle(ctx):
     rows = casegen.make_hsp_table(7, n_seg=6, n_fam=60, noise=2000, frag=(1, 4), copies=(4, 22))
     got, h = _fmea_gpu(ctx, rows, 2000, 30000)
     assert len(rows) > 20000 and got == O.fmea(h, 2000, 30000)
+
+
+def test_find_copies_vs_twin(ctx):
+    import synth_small
+
+    for seed, nf in ((11, 16), (23, 24), (5, 10)):
+        g = synth_small.make(seed, n_fam=nf)
+        ctx.genome_pack(g["contigs"])
+        ctx._copy_state = None  # new genome -> new index
+        cands = list(g["cands"]) + ["ACGT" * 3, "A" * 40, g["contigs"][0][5000:5400]]  # too short / low complexity / unique region
+        got = ctx.find_copies(cands)
+        exp = O.find_copies(g["contigs"], cands)
+        assert got == exp
+        assert sum(len(x) for x in got) > 20
+    # the found copies drive the fine stage to the same calls as the oracle chain on the same table
+    import oracle_pipeline as OP
+
+    g = synth_small.make(11, n_fam=16)
+    ctx.genome_pack(g["contigs"])
+    ctx._copy_state = None
+    tab = ctx.find_copies(g["cands"])
+    copies = [[x[:4] for x in t] for t in tab]
+    res, _ = ctx.flank_region_align("tir", g["cands"], copies, plant=1)
+    for cand, cp, r in zip(g["cands"], copies, res):
+        assert [r[0], r[1], r[2], r[3]] == OP.fine_stage_candidate("tir", cand, cp, g["contigs"], plant=1)
