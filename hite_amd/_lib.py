@@ -363,3 +363,10 @@ class Context:
                                            C.byref(outs[4]), C.byref(outs[5]), v(stream))
         self._check(rc, "hite_find_copies_dev")
         return (n.value,) + tuple(o.value or 0 for o in outs)
+
+    def download(self, d_ptr, count, dtype):
+        """numpy copy of `count` elements of `dtype` at raw device pointer d_ptr"""
+        out = np.zeros(int(count), dtype=dtype)
+        if count:
+            self._check(self.lib.hite_memcpy_d2h(_p(out), C.c_void_p(d_ptr), C.c_int64(out.nbytes)), "hite_memcpy_d2h")
+        return out

@@ -406,11 +406,13 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_pos = (unsigned *)p;
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_hs = (unsigned *)p;
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    int tk_cm = hite_prof_begin(ctx, "cand_minimizer_kernel", st);
     {
         int64_t blocks = (cand_bytes + 255) / 256; if (blocks > 256 * 64) blocks = 256 * 64;
         hipLaunchKernelGGL(cand_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, cand_bytes, q_c,
                            q_pos, q_hs, qcap, (unsigned long long *)S->d_scal);
     }
+    hite_prof_end(ctx, tk_cm, st);
     CCHK(read_back(ctx, S, st, 1));
     const int64_t nq = S->h_pin[0];
     if ((unsigned long long)nq > qcap) return HITE_ECAP;
@@ -419,7 +421,9 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, (size_t)nq * 4, &p)); occ_n = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(nq + 1) * 8, &p)); hit_off = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(nq) * 8, &p)); bs = (int64_t *)p;
+    int tk_occ_kernel = hite_prof_begin(ctx, "occ_kernel", st);
     hipLaunchKernelGGL(occ_kernel, CGRID(nq), 0, st, nq, q_hs, S->idx_hs, S->dir, occ_lo, occ_n);
+    hite_prof_end(ctx, tk_occ_kernel, st);
     CCHK(scan_excl_buf<int32_t>(ctx, bs, occ_n, nq, hit_off, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, hit_off + nq, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
@@ -428,17 +432,23 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     if (nh >= 0xffffffffll) return HITE_ECAP;
     CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 8, &p)); hkey = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 4, &p)); hval = (unsigned *)p;
+    int tk_hit_kernel = hite_prof_begin(ctx, "hit_kernel", st);
     hipLaunchKernelGGL(hit_kernel, CGRID(nq), 0, st, nq, q_c, q_pos, q_hs, d_cand_off, S->idx_hs, S->idx_pos, occ_lo, occ_n, hit_off, hkey, hval);
+    hite_prof_end(ctx, tk_hit_kernel, st);
     Sorter so;
     CCHK(sorter_from_arena(so, ctx, A, st, nh));
     int cbits = 1; while ((1ll << cbits) < n_cand) cbits++;
+    int tk_sh = hite_prof_begin(ctx, "radix_sort_hits", st);
     CCHK(sorter_sort(so, hkey, hval, nh, 34 + cbits));
+    hite_prof_end(ctx, tk_sh, st);
     // clusters
     CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 4, &p)); flag = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(nh + 2) * 8, &p)); cid = (int64_t *)p;
     int64_t *bs2;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(nh) * 8, &p)); bs2 = (int64_t *)p;
+    int tk_cluster_flag_kernel = hite_prof_begin(ctx, "cluster_flag_kernel", st);
     hipLaunchKernelGGL(cluster_flag_kernel, CGRID(nh), 0, st, nh, hkey, hval, ctx->d_contig_off, ctx->n_contigs, flag);
+    hite_prof_end(ctx, tk_cluster_flag_kernel, st);
     CCHK(scan_excl_buf<int32_t>(ctx, bs2, flag, nh, cid, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cid + nh, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
@@ -450,7 +460,9 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     hipLaunchKernelGGL(fill_u64_kernel, CGRID(ncl), 0, st, ncl, c_lo, 0xffffffffffffffffull);
     HITE_CHECK(ctx, hipMemsetAsync(c_hi, 0, (size_t)(ncl + 1) * 8, st));
     HITE_CHECK(ctx, hipMemsetAsync(c_cnt, 0, (size_t)(ncl + 1) * 4, st));
+    int tk_cluster_acc_kernel = hite_prof_begin(ctx, "cluster_acc_kernel", st);
     hipLaunchKernelGGL(cluster_acc_kernel, CGRID(nh), 0, st, nh, hkey, hval, flag, cid, c_lo, c_hi, c_cnt, c_first);
+    hite_prof_end(ctx, tk_cluster_acc_kernel, st);
     // clusters -> copies
     int32_t *r_contig, *r_anch;
     int64_t *r_s1, *r_e1;
@@ -468,8 +480,10 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); ofirst = (int64_t *)p;
     HITE_CHECK(ctx, hipMemsetAsync(per_cand, 0, (size_t)(n_cand + 1) * 4, st));
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    int tk_cluster_copy_kernel = hite_prof_begin(ctx, "cluster_copy_kernel", st);
     hipLaunchKernelGGL(cluster_copy_kernel, CGRID(ncl), 0, st, ncl, hkey, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
                        ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, per_cand, (unsigned long long *)S->d_scal);
+    hite_prof_end(ctx, tk_cluster_copy_kernel, st);
     hipLaunchKernelGGL(cap300_kernel, CGRID((int64_t)n_cand), 0, st, n_cand, per_cand, per_cand300);
     int64_t *bs3;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(n_cand) * 8, &p)); bs3 = (int64_t *)p;
@@ -483,7 +497,9 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     if (ncp == 0) return HITE_OK;
     Sorter so2;
     CCHK(sorter_from_arena(so2, ctx, A, st, ncp));
+    int tk_sc = hite_prof_begin(ctx, "radix_sort_copies", st);
     CCHK(sorter_sort(so2, ckey, cval, ncp, 64));
+    hite_prof_end(ctx, tk_sc, st);
     int32_t *o_contig, *o_anch;
     int64_t *o_s1, *o_e1;
     uint8_t *o_minus;

@@ -377,3 +377,10 @@ extern "C" int hite_profile_get(hite_ctx *ctx, int idx, char *name_out /* >= 32 
     *launches = ctx->prof_count[idx];
     return HITE_OK;
 }
+
+// utility for host mirrors / tests: copy a device range returned by a _dev entry point to the host
+extern "C" int hite_memcpy_d2h(void *dst, const void *d_src, int64_t bytes) {
+    if (bytes <= 0) return HITE_OK;
+    if (hipDeviceSynchronize() != hipSuccess) return HITE_EHIP;
+    return hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost) == hipSuccess ? HITE_OK : HITE_EHIP;
+}

@@ -223,6 +223,9 @@ int hite_profile_reset(hite_ctx *ctx);
 int hite_profile_count(hite_ctx *ctx);
 int hite_profile_get(hite_ctx *ctx, int idx, char *name_out, double *ms_total, int64_t *launches);
 
+/* copy a device range returned by a _dev entry point to the host (synchronises the device) */
+int hite_memcpy_d2h(void *dst, const void *d_src, int64_t bytes);
+
 /* ---- timing helper: HIP-event elapsed ms around work already enqueued on `stream` ---------- */
 int hite_event_create(void **ev);
 int hite_event_record(void *ev, void *stream);
