@@ -139,77 +139,84 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         // bases that would enter the band at step 1: a[t + 63] on a down move, b[0 - t] on a right move.
         // Kept raw (+ in-range flag) and only turned into base-or-sentinel at the point of use, so that the
         // broadcast load issued at step s is not waited for before the next move of the same kind.
-        int na_raw, nb_raw;
-        bool na_ok, nb_ok;
+        int na_raw, nb_raw, na_i, nb_i;   // the in-range test is redone from the index at the point of use (no loop-carried masks)
         {
-            int ia = t + 63, jb = -t;
-            na_ok = ia >= 0 && ia < m; nb_ok = jb >= 0 && jb < n;
-            na_raw = a[na_ok ? ia : 0];
-            nb_raw = b[nb_ok ? jb : 0];
+            na_i = t + 63; nb_i = -t;
+            na_raw = a[(unsigned)na_i < (unsigned)m ? na_i : 0];
+            nb_raw = b[(unsigned)nb_i < (unsigned)n ? nb_i : 0];
         }
         unsigned dreg = 0, mreg = 0;
         int vz;  // an opaque vector zero: keeps the prefetch addressing on the vector unit (the scalar unit is the scarce one)
         asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
         const int m31 = m - 31, n1 = n + 1;
         const int nchunk = steps >> 4;
+        // one anti-diagonal; the move is wave-uniform, the two arms are complete (no re-merge before the DP math)
+#define ALIGN_STEP(SS)                                                                                                   \
+        {                                                                                                                \
+            const int s_ = (SS);                                                                                         \
+            const int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);                \
+            int tn, sc0, sc1;                                                                                            \
+            const int s31 = s_ - 31;                                                                                     \
+            /* band steering on the scalar unit:  move = (h63 - h0 + (s & 1)) > 0;                                  */   \
+            /* tn = max(min(t + move, min(m, s) - 31), max(0, s - n) - 32)                                           */   \
+            asm volatile(                                                                                                \
+                "s_and_b32 %1, %4, 1\n\t"                                                                                \
+                "s_sub_i32 %2, %6, %5\n\t"                                                                               \
+                "s_add_i32 %2, %2, %1\n\t"                                                                               \
+                "s_cmp_gt_i32 %2, 0\n\t"                                                                                 \
+                "s_addc_u32 %0, %3, 0\n\t"                                                                               \
+                "s_min_i32 %1, %7, %8\n\t"                                                                               \
+                "s_min_i32 %0, %0, %1\n\t"                                                                               \
+                "s_sub_i32 %2, %8, %9\n\t"                                                                               \
+                "s_max_i32 %2, %2, -32\n\t"                                                                              \
+                "s_max_i32 %0, %0, %2"                                                                                   \
+                : "=&s"(tn), "=&s"(sc0), "=&s"(sc1)                                                                      \
+                : "s"(t), "s"(s_), "s"(h0), "s"(h63), "s"(m31), "s"(s31), "s"(n1)                                        \
+                : "scc");                                                                                                \
+            int hl, hu, hd;                                                                                              \
+            if (tn != t) {                                                                                               \
+                /* down: (left, up, diag) = (H(s-1)[k+1], H(s-1)[k], H(s-2)'[k]); centre bases slide to lane 0 */        \
+                hl = from_next_lane0(prev); hu = prev; hd = ppal;                                                        \
+                const int na = (unsigned)na_i < (unsigned)m ? (na_raw == 'N' ? 0xFD : na_raw) : 0xFF;                     \
+                areg = from_next_lane(areg, na);                                                                         \
+                na_i = tn + 63 + vz;                                                                                     \
+                na_raw = a[(unsigned)na_i < (unsigned)m ? na_i : 0];                                                     \
+                mreg = (mreg << 1) | 1u;                                                                                 \
+                const int cd = hd + (areg == breg ? SC_MATCH : SC_MIS);                                                  \
+                const int cu = hu + SC_GAP, cl = hl + SC_GAP;                                                            \
+                const int mx = cu > cl ? cu : cl;                                                                        \
+                const int v = cd > mx ? cd : mx;                                                                         \
+                dreg = (dreg << 2) | (cd == v ? 0u : (cu >= cl ? 1u : 2u));                                              \
+                ppal = hl; prev = v;                                                                                     \
+            } else {                                                                                                     \
+                /* right: (left, up, diag) = (H(s-1)[k], H(s-1)[k-1], H(s-2)'[k-1]); row bases slide to lane 63 */       \
+                hl = prev; hu = from_prev_lane0(prev); hd = from_prev_lane0(ppal);                                       \
+                const int nb = (unsigned)nb_i < (unsigned)n ? nb_raw : 0xFE;                                             \
+                breg = from_prev_lane(breg, nb);                                                                         \
+                nb_i = s_ - tn + vz;                                                                                     \
+                nb_raw = b[(unsigned)nb_i < (unsigned)n ? nb_i : 0];                                                     \
+                mreg = mreg << 1;                                                                                        \
+                const int cd = hd + (areg == breg ? SC_MATCH : SC_MIS);                                                  \
+                const int cu = hu + SC_GAP, cl = hl + SC_GAP;                                                            \
+                const int mx = cu > cl ? cu : cl;                                                                        \
+                const int v = cd > mx ? cd : mx;                                                                         \
+                dreg = (dreg << 2) | (cd == v ? 0u : (cu >= cl ? 1u : 2u));                                              \
+                ppal = hl; prev = v;                                                                                     \
+            }                                                                                                            \
+            t = tn;                                                                                                      \
+        }
         for (int ch = 0; ch <= nchunk; ch++) {
             const int s_lo = ch == 0 ? 1 : ch << 4;
             const int s_hi = (ch << 4) + 15 < steps ? (ch << 4) + 15 : steps;
-            for (int s = s_lo; s <= s_hi; s++) {
-                const int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);
-                int tn, sc0, sc1;
-                // band steering on the scalar unit (s31 = s - 31):
-                //   move = h0 > h63 ? 0 : (h0 < h63 ? 1 : s & 1)   ==  (h63 - h0 + (s & 1)) > 0
-                //   tn = max(min(t + move, min(m, s) - 31), max(0, s - n) - 32)      [t <= hi', lo' <= t + 1 always]
-                const int s31 = s - 31;
-                asm volatile(
-                    "s_and_b32 %1, %4, 1\n\t"
-                    "s_sub_i32 %2, %6, %5\n\t"
-                    "s_add_i32 %2, %2, %1\n\t"
-                    "s_cmp_gt_i32 %2, 0\n\t"
-                    "s_addc_u32 %0, %3, 0\n\t"
-                    "s_min_i32 %1, %7, %8\n\t"
-                    "s_min_i32 %0, %0, %1\n\t"
-                    "s_sub_i32 %2, %8, %9\n\t"
-                    "s_max_i32 %2, %2, -32\n\t"
-                    "s_max_i32 %0, %0, %2"
-                    : "=&s"(tn), "=&s"(sc0), "=&s"(sc1)
-                    : "s"(t), "s"(s), "s"(h0), "s"(h63), "s"(m31), "s"(s31), "s"(n1)
-                    : "scc");
-                int hl, hu, hd;
-                if (tn != t) {
-                    // down: (left, up, diag) = (H(s-1)[k+1], H(s-1)[k], H(s-2)[k]); centre bases slide towards lane 0
-                    hl = from_next_lane0(prev); hu = prev; hd = ppal;
-                    const int na = na_ok ? (na_raw == 'N' ? 0xFD : na_raw) : 0xFF;
-                    areg = from_next_lane(areg, na);
-                    const int ia = tn + 63 + vz;
-                    na_ok = (unsigned)ia < (unsigned)m;
-                    na_raw = a[na_ok ? ia : 0];
-                    mreg = (mreg << 1) | 1u;
-                } else {
-                    // right: (left, up, diag) = (H(s-1)[k], H(s-1)[k-1], H(s-2)[k-1]); row bases slide towards lane 63
-                    hl = prev; hu = from_prev_lane0(prev); hd = from_prev_lane0(ppal);
-                    const int nb = nb_ok ? nb_raw : 0xFE;
-                    breg = from_prev_lane(breg, nb);
-                    const int jb = s - tn + vz;
-                    nb_ok = (unsigned)jb < (unsigned)n;
-                    nb_raw = b[nb_ok ? jb : 0];
-                    mreg = mreg << 1;
-                }
-                const int cd = hd + (areg == breg ? SC_MATCH : SC_MIS);
-                const int cu = hu + SC_GAP, cl = hl + SC_GAP;
-                const int mx = cu > cl ? cu : cl;
-                const int v = cd > mx ? cd : mx;
-                // direction: 0 diag (cd is the max), else 1 up (cu >= cl), else 2 left
-                const unsigned d = cd == v ? 0u : (cu >= cl ? 1u : 2u);
-                dreg = (dreg << 2) | d;
-                ppal = hl; prev = v; t = tn;
-            }
+            int s = s_lo;
+            for (; s + 1 <= s_hi; s += 2) { ALIGN_STEP(s) ALIGN_STEP(s + 1) }
+            if (s <= s_hi) ALIGN_STEP(s)
             const int sh = 15 - (s_hi & 15);
             tbd[ch * 64 + lane] = dreg << (2 * sh);
             if (lane == 0) tbm[ch] = (mreg << sh) & 0xffffu;   // bit (15 - (s & 15)) = move of step s
             dreg = 0; mreg = 0;
         }
+#undef ALIGN_STEP
         {
             const int kf = m - t;
             const int hf = (kf >= 0 && kf < 64) ? __builtin_amdgcn_readlane(prev, kf & 63) : 0;
@@ -222,17 +229,17 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         // ---------------- traceback: wave-uniform walk kept in vector registers ----------------
         int i = m + vz, j = n + vz;       // every lane carries the same (i, j)
         int k = m - t + vz;               // lane that owns cell (i, j) on anti-diagonal i + j
-        int dchunk = -1;                  // loaded chunk (scalar)
         unsigned wcur = 0;                // this lane's direction word of the 16-step chunk
         unsigned mm = 0;                  // moves: chunk of s in bits 0..15, the chunk below in bits 16..31
         int oreg = 0, fail = 0, bad = 0;
+        int dchunk_v = -1 + vz;           // loaded chunk, kept as a (uniform) vector value: the compares stay on the vector unit
         while (__builtin_amdgcn_readfirstlane(i) > 0) {
             const int s = i + j;
-            const int sq = __builtin_amdgcn_readfirstlane(s);
-            if ((sq >> 4) != dchunk) {
-                dchunk = sq >> 4;
-                wcur = tbd[dchunk * 64 + lane];
-                const unsigned mc = tbm[dchunk], mp = dchunk > 0 ? tbm[dchunk - 1] : 0u;
+            if ((s >> 4) != dchunk_v) {   // uniform
+                dchunk_v = s >> 4;
+                const int dc = __builtin_amdgcn_readfirstlane(dchunk_v);
+                wcur = tbd[dc * 64 + lane];
+                const unsigned mc = tbm[dc], mp = dc > 0 ? tbm[dc - 1] : 0u;
                 mm = (mp << 16) | mc;
             }
             bad |= (unsigned)k > 63u;
@@ -247,7 +254,10 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             const int p = i - 1;
             const int val = isdiag ? (j - 1) : (j | 0x8000);
             if (!isleft && lane == (p & 63)) oreg = val;
-            if (__builtin_amdgcn_readfirstlane((!isleft && (p & 63) == 0) ? 1 : 0)) { if (p + lane < m) ops[p + lane] = (uint16_t)oreg; }
+            if (!isleft && (p & 63) == 0) {   // uniform
+                const int pb = __builtin_amdgcn_readfirstlane(p);
+                if (pb + lane < m) ops[pb + lane] = (uint16_t)oreg;
+            }
             // predecessor cell: left (i, j-1): k + mv_s; up (i-1, j): k - 1 + mv_s; diag (i-1, j-1): k - 1 + mv_s + mv_s1
             k += mv_s - (isleft ? 0 : 1) + (isdiag ? mv_s1 : 0);
             i -= isleft ? 0 : 1;
