@@ -131,8 +131,17 @@ __global__ void i64_to_u32_kernel(int64_t n, const int64_t *__restrict__ in, uns
     if (i < n) out[i] = (unsigned)in[i];
 }
 
-// candidate minimizers: thread = position in the concatenated candidate buffer
-__global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const uint8_t *__restrict__ cand,
+// candidate k-mer hashes: thread = position in the concatenated candidate buffer (a k-mer never crosses a candidate end)
+__global__ void __launch_bounds__(256) cand_hs_kernel(int ncand, const uint8_t *__restrict__ cand, const int64_t *__restrict__ cand_off,
+                                                      int64_t total, unsigned *__restrict__ hs) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
+        int c = contig_of(cand_off, ncand, p);
+        int64_t cb = cand_off[c], L = cand_off[c + 1] - cb;
+        hs[p] = ascii_hs(cand + cb, p - cb, L);
+    }
+}
+// candidate minimizers: thread = window start; window minima over the precomputed hashes
+__global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const unsigned *__restrict__ hs,
                                                              const int64_t *__restrict__ cand_off, int64_t total,
                                                              unsigned *__restrict__ q_c, unsigned *__restrict__ q_pos,
                                                              unsigned *__restrict__ q_hs, unsigned long long cap,
@@ -145,8 +154,8 @@ __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const ui
         int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
         int64_t lp = p - cb;
         if (lp >= nwin) continue;
-        const uint8_t *s = cand + cb;
-        auto hs_at = [&](int64_t i) { return ascii_hs(s, i, L); };
+        const unsigned *h0 = hs + cb;
+        auto hs_at = [&](int64_t i) { return h0[i]; };
         unsigned h, hp;
         int64_t m = window_min(lp, 0, nk, hs_at, &h);
         if (m < 0) continue;
@@ -215,21 +224,30 @@ __global__ void cluster_flag_kernel(int64_t nh, const unsigned long long *__rest
 
 struct ClusterAcc { unsigned long long lo, hi; int cnt; int first; };
 
-__global__ void cluster_acc_kernel(int64_t nh, const unsigned long long *__restrict__ hkey, const unsigned *__restrict__ hval,
-                                   const int32_t *__restrict__ flag, const int64_t *__restrict__ cid_excl,
-                                   unsigned long long *__restrict__ c_lo, unsigned long long *__restrict__ c_hi,
-                                   int32_t *__restrict__ c_cnt, unsigned *__restrict__ c_first) {
+// first hit of every cluster (+ sentinel)
+__global__ void cluster_first_kernel(int64_t nh, const int32_t *__restrict__ flag, const int64_t *__restrict__ cid_excl,
+                                     unsigned *__restrict__ c_first, int64_t ncl) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nh) return;
-    int64_t cid = cid_excl[i] + flag[i] - 1;
-    long long d = (long long)(hkey[i] & 0x1ffffffffull) - DBIAS;
-    unsigned qo = hval[i];
-    unsigned long long gpos = (unsigned long long)(d + qo);
-    unsigned long long v = ((unsigned long long)qo << 32) | (gpos & 0xffffffffull);
-    atomicMin(&c_lo[cid], v);
-    atomicMax(&c_hi[cid], v);
-    atomicAdd(&c_cnt[cid], 1);
-    if (flag[i]) c_first[cid] = (unsigned)i;
+    if (flag[i]) c_first[cid_excl[i]] = (unsigned)i;
+    if (i == 0) c_first[ncl] = (unsigned)nh;
+}
+// per cluster: anchor count and the extreme anchors (min qo -> smallest gpos, max qo -> largest gpos)
+__global__ void cluster_acc_kernel(int64_t ncl, const unsigned long long *__restrict__ hkey, const unsigned *__restrict__ hval,
+                                   const unsigned *__restrict__ c_first, unsigned long long *__restrict__ c_lo,
+                                   unsigned long long *__restrict__ c_hi, int32_t *__restrict__ c_cnt) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncl) return;
+    unsigned b = c_first[k], e = c_first[k + 1];
+    unsigned long long lo = 0xffffffffffffffffull, hi = 0;
+    for (unsigned i = b; i < e; i++) {
+        long long d = (long long)(hkey[i] & 0x1ffffffffull) - DBIAS;
+        unsigned qo = hval[i];
+        unsigned long long v = ((unsigned long long)qo << 32) | ((unsigned long long)(d + qo) & 0xffffffffull);
+        lo = v < lo ? v : lo;
+        hi = v > hi ? v : hi;
+    }
+    c_lo[k] = lo; c_hi[k] = hi; c_cnt[k] = (int)(e - b);
 }
 
 // accepted clusters -> copy records (appended) + sort key (candidate:19 | 4095-anchors:12 | start:32 | minus:1)
@@ -409,7 +427,10 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     int tk_cm = hite_prof_begin(ctx, "cand_minimizer_kernel", st);
     {
         int64_t blocks = (cand_bytes + 255) / 256; if (blocks > 256 * 64) blocks = 256 * 64;
-        hipLaunchKernelGGL(cand_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, cand_bytes, q_c,
+        unsigned *chs;
+        CCHK(arena_alloc(ctx, A, (size_t)(cand_bytes + 16) * 4, &p)); chs = (unsigned *)p;
+        hipLaunchKernelGGL(cand_hs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, cand_bytes, chs);
+        hipLaunchKernelGGL(cand_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_cand, chs, d_cand_off, cand_bytes, q_c,
                            q_pos, q_hs, qcap, (unsigned long long *)S->d_scal);
     }
     hite_prof_end(ctx, tk_cm, st);
@@ -456,12 +477,10 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); c_lo = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); c_hi = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); c_cnt = (int32_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); c_first = (unsigned *)p;
-    hipLaunchKernelGGL(fill_u64_kernel, CGRID(ncl), 0, st, ncl, c_lo, 0xffffffffffffffffull);
-    HITE_CHECK(ctx, hipMemsetAsync(c_hi, 0, (size_t)(ncl + 1) * 8, st));
-    HITE_CHECK(ctx, hipMemsetAsync(c_cnt, 0, (size_t)(ncl + 1) * 4, st));
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 4, &p)); c_first = (unsigned *)p;
+    hipLaunchKernelGGL(cluster_first_kernel, CGRID(nh), 0, st, nh, flag, cid, c_first, ncl);
     int tk_cluster_acc_kernel = hite_prof_begin(ctx, "cluster_acc_kernel", st);
-    hipLaunchKernelGGL(cluster_acc_kernel, CGRID(nh), 0, st, nh, hkey, hval, flag, cid, c_lo, c_hi, c_cnt, c_first);
+    hipLaunchKernelGGL(cluster_acc_kernel, CGRID(ncl), 0, st, ncl, hkey, hval, c_first, c_lo, c_hi, c_cnt);
     hite_prof_end(ctx, tk_cluster_acc_kernel, st);
     // clusters -> copies
     int32_t *r_contig, *r_anch;
