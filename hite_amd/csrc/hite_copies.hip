@@ -131,37 +131,38 @@ __global__ void i64_to_u32_kernel(int64_t n, const int64_t *__restrict__ in, uns
     if (i < n) out[i] = (unsigned)in[i];
 }
 
-// candidate k-mer hashes: thread = position in the concatenated candidate buffer (a k-mer never crosses a candidate end)
+// candidate k-mer hashes: one wavefront per candidate (no per-position search for the owning candidate)
 __global__ void __launch_bounds__(256) cand_hs_kernel(int ncand, const uint8_t *__restrict__ cand, const int64_t *__restrict__ cand_off,
-                                                      int64_t total, unsigned *__restrict__ hs) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
-        int c = contig_of(cand_off, ncand, p);
-        int64_t cb = cand_off[c], L = cand_off[c + 1] - cb;
-        hs[p] = ascii_hs(cand + cb, p - cb, L);
+                                                      unsigned *__restrict__ hs) {
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < ncand; c += gridDim.x * 4) {
+        const int64_t cb = cand_off[c], L = cand_off[c + 1] - cb;
+        const uint8_t *s = cand + cb;
+        for (int64_t p = lane; p < L; p += 64) hs[cb + p] = ascii_hs(s, p, L);
     }
 }
-// candidate minimizers: thread = window start; window minima over the precomputed hashes
+// candidate minimizers: one wavefront per candidate, lane = window start; window minima over the precomputed hashes
 __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const unsigned *__restrict__ hs,
-                                                             const int64_t *__restrict__ cand_off, int64_t total,
+                                                             const int64_t *__restrict__ cand_off,
                                                              unsigned *__restrict__ q_c, unsigned *__restrict__ q_pos,
                                                              unsigned *__restrict__ q_hs, unsigned long long cap,
                                                              unsigned long long *__restrict__ counter) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
-        int c = contig_of(cand_off, ncand, p);
-        int64_t cb = cand_off[c], L = cand_off[c + 1] - cb;
-        int64_t nk = L - CK + 1;
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < ncand; c += gridDim.x * 4) {
+        const int64_t cb = cand_off[c], L = cand_off[c + 1] - cb;
+        const int64_t nk = L - CK + 1;
         if (nk <= 0) continue;
-        int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
-        int64_t lp = p - cb;
-        if (lp >= nwin) continue;
+        const int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
         const unsigned *h0 = hs + cb;
         auto hs_at = [&](int64_t i) { return h0[i]; };
-        unsigned h, hp;
-        int64_t m = window_min(lp, 0, nk, hs_at, &h);
-        if (m < 0) continue;
-        if (lp > 0) { int64_t mp = window_min(lp - 1, 0, nk, hs_at, &hp); if (mp == m) continue; }
-        unsigned long long slot = atomicAdd(counter, 1ull);
-        if (slot < cap) { q_c[slot] = (unsigned)c; q_pos[slot] = (unsigned)m; q_hs[slot] = h; }
+        for (int64_t lp = lane; lp < nwin; lp += 64) {
+            unsigned h, hp;
+            int64_t m = window_min(lp, 0, nk, hs_at, &h);
+            if (m < 0) continue;
+            if (lp > 0) { int64_t mp = window_min(lp - 1, 0, nk, hs_at, &hp); if (mp == m) continue; }
+            unsigned long long slot = atomicAdd(counter, 1ull);
+            if (slot < cap) { q_c[slot] = (unsigned)c; q_pos[slot] = (unsigned)m; q_hs[slot] = h; }
+        }
     }
 }
 
@@ -429,9 +430,11 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
         int64_t blocks = (cand_bytes + 255) / 256; if (blocks > 256 * 64) blocks = 256 * 64;
         unsigned *chs;
         CCHK(arena_alloc(ctx, A, (size_t)(cand_bytes + 16) * 4, &p)); chs = (unsigned *)p;
-        hipLaunchKernelGGL(cand_hs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, cand_bytes, chs);
-        hipLaunchKernelGGL(cand_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, n_cand, chs, d_cand_off, cand_bytes, q_c,
-                           q_pos, q_hs, qcap, (unsigned long long *)S->d_scal);
+        int wblocks = (n_cand + 3) / 4; if (wblocks > 8192) wblocks = 8192;
+        (void)blocks;
+        hipLaunchKernelGGL(cand_hs_kernel, dim3(wblocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, chs);
+        hipLaunchKernelGGL(cand_minimizer_kernel, dim3(wblocks), dim3(256), 0, st, n_cand, chs, d_cand_off, q_c, q_pos, q_hs, qcap,
+                           (unsigned long long *)S->d_scal);
     }
     hite_prof_end(ctx, tk_cm, st);
     CCHK(read_back(ctx, S, st, 1));

@@ -1,0 +1,103 @@
+#!/usr/bin/env python
+"""Drop-in for HiTE's module/judge_TIR_transposons.py (stage 3.2): same argv, same files
+(/root/reference/module/judge_TIR_transposons.py:114-143, 63-111, 16-61).
+
+  --seqs longest_repeats_{i}.flanked.fa  ->  <tmp_output_dir>/confident_tir_{i}.fa   (+ tir_low_copy.fa, prev_TE append)
+
+What runs on the GPU: the k-mer TSD seed search (search_confident_tir_v4), copy finding, flank-window
+gather, star alignment, sparse-column removal and judge_boundary_v5, three refinement iterations.
+External tools are used exactly where the reference uses them and only if they are installed:
+`itrsearch` (TIR length / structure filter, Util.py:216) and `cd-hit-est` (judge_TIR_transposons.py:87);
+when one is missing the step is skipped with a warning (the candidates are passed through)."""
+import argparse
+import os
+import shutil
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+from hite_amd import util  # noqa: E402
+
+
+def tsd_variants(flanked_path, flanking_len, plant):
+    """multi_process_tsd_v1 (Util.py:6630) without the per-file process pool: one batched GPU call, then the
+    min-distance variant per candidate (filter_dup_itr_v3, Util.py:2791) named <query>-tir_<len>-tsd_<seq>."""
+    names, contigs = util.read_fasta(flanked_path)
+    names = [n for n in names if "NNNNNNNNNN" not in contigs[n]]  # Util.py:6543
+    ctx = util.get_ctx()
+    recs = ctx.tsd_kmer([contigs[n] for n in names], flank=flanking_len, plant=plant)
+    out = {}
+    for n, rr in zip(names, recs):
+        if not rr:
+            continue
+        k, ts, te, d = rr[0]  # canonical order: smallest distance first
+        seq = contigs[n][ts:te + 1]
+        if len(seq) < 30000:
+            out["%s-tir_%d-tsd_%s" % (n, 0, contigs[n][ts - k:ts])] = seq
+    return out
+
+
+def run_cd_hit(inp, outp, threads):
+    if shutil.which("cd-hit-est") is None:
+        sys.stderr.write("[hite_amd] cd-hit-est not found: redundancy removal skipped\n")
+        shutil.copyfile(inp, outp)
+        return
+    subprocess.run("cd-hit-est -aS 0.95 -aL 0.95 -c 0.8 -G 0 -g 1 -A 80 -i %s -o %s -T %d -M 0 > /dev/null 2>&1" % (inp, outp, threads),
+                   shell=True, check=False)
+
+
+def main():
+    p = argparse.ArgumentParser(description="run HiTE TIR module on the MI355X path")
+    p.add_argument("--seqs"); p.add_argument("-t", type=int, default=1); p.add_argument("--tmp_output_dir")
+    p.add_argument("--tandem_region_cutoff", default="0.5"); p.add_argument("--ref_index", default="0")
+    p.add_argument("--plant", type=int, default=1); p.add_argument("--flanking_len", type=int, default=50)
+    p.add_argument("--recover", type=int, default=0); p.add_argument("--debug", type=int, default=0)
+    p.add_argument("-r"); p.add_argument("--split_ref_dir", default=None); p.add_argument("--prev_TE", default=None)
+    p.add_argument("--all_low_copy_tir", default=None); p.add_argument("--min_TE_len", type=int, default=80)
+    p.add_argument("-w", "--work_dir", default="/tmp")
+    a = p.parse_args()
+    out_dir = os.path.abspath(a.tmp_output_dir or os.getcwd())
+    os.makedirs(out_dir, exist_ok=True)
+    ref_index, flank = a.ref_index, 50  # the reference pins flanking_len to 50 here (judge_TIR_transposons.py:21)
+    final = os.path.join(out_dir, "confident_tir_%s.fa" % ref_index)
+    if a.recover and os.path.exists(final) and util.read_fasta(final)[0]:
+        return 0
+    low = a.all_low_copy_tir or os.path.join(out_dir, "tir_low_copy.fa")
+    util.set_reference(a.r)
+    ctx = util.get_ctx()
+    tsd_path = os.path.join(out_dir, "tir_tsd_%s.fa" % ref_index)
+    util.store_fasta(tsd_variants(a.seqs, flank, a.plant), tsd_path)
+    cons_path = tsd_path + ".cons"
+    run_cd_hit(tsd_path, cons_path, a.t)
+
+    def finder(cand_path, reference):
+        names, contigs = util.read_fasta(cand_path)
+        tab = ctx.find_copies([contigs[n] for n in names])
+        rev = {v: k for k, v in util._PACKED["names"].items()}
+        return {n: [(rev[c], s, e, e - s + 1, "-" if m else "+") for (c, s, e, m, _an) in t] for n, t in zip(names, tab) if t}
+
+    cur = cons_path
+    for it in range(3):  # judge_TIR_transposons.py:27
+        nxt = os.path.join(out_dir, "confident_tir_%s.r%d.fa" % (ref_index, it))
+        util.flank_region_align_v5(cur, nxt, flank, a.r, a.split_ref_dir, "tir", out_dir, a.t, ref_index, None, "", a.plant, a.debug,
+                                   it, low, copy_finder=finder)
+        cur = nxt
+    names, contigs = util.read_fasta(cur)
+    prefix = os.path.basename(a.r).split(".")[0]
+    kept = {}
+    for n in names:
+        if len(contigs[n]) >= a.min_TE_len:
+            kept["%s-TIR_%s_%d" % (prefix, ref_index, len(kept))] = contigs[n]
+    tmp = final + ".tmp"
+    util.store_fasta(kept, tmp)
+    os.replace(tmp, final)  # success == "the output file exists" (Util.py:2831): never leave a partial file
+    if a.prev_TE:
+        with open(a.prev_TE, "a") as f:
+            for n, s in kept.items():
+                f.write(">" + n + "\n" + s + "\n")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

@@ -348,3 +348,115 @@ def test_find_copies_vs_twin(ctx):
     res, _ = ctx.flank_region_align("tir", g["cands"], copies, plant=1)
     for cand, cp, r in zip(g["cands"], copies, res):
         assert [r[0], r[1], r[2], r[3]] == OP.fine_stage_candidate("tir", cand, cp, g["contigs"], plant=1)
+
+
+def test_edge_cases(ctx):
+    """empty / ragged / degenerate inputs the reference also meets: empty batches, single-row and
+    two-row alignments, candidates without copies, candidates shorter than the 20-bp anchor, copies at contig ends"""
+    # empty batches
+    assert ctx.sparse_cols([]) == []
+    assert ctx.judge("tir", [], [], plant=1) == []
+    assert ctx.tsd_kmer([], 50, 1) == []
+    oc, os_, oe = ctx.fmea_chain([], [], [], [], [], [], [0], [0], 2000, 30000)
+    assert len(oc) == 0
+    # FMEA: only self hits / a single HSP
+    rows = [("chr1$0", "chr1$0", 1, 1000000, 1, 1000000)]
+    got, h = _fmea_gpu(ctx, rows, 2000, 30000)
+    assert got == O.fmea(h, 2000, 30000) == []
+    rows = [("chr1$0", "chr1$1000000", 100, 500, 7000, 7400)]
+    got, h = _fmea_gpu(ctx, rows, 2000, 30000)
+    assert got == O.fmea(h, 2000, 30000) and len(got) == 1
+    # single-row / two-row alignments and a short candidate
+    base = casegen.make_msa_case(seed=4, te_type="tir", rows=6, te_len=150, tsd_len=8, tsd_frac=1.0)
+    m = O.msa_array(base["seqs"])
+    for sub, cand in ((m[:1], base["cand"]), (m[:2], base["cand"]), (m, base["cand"][:12]), (m, "ACGTACGTAC")):
+        for te in ("tir", "helitron", "non_ltr"):
+            g = ctx.judge(te, [np.ascontiguousarray(sub)], [cand], plant=1)[0]
+            e, _ = O.judge(te, np.ascontiguousarray(sub), cand, 1)
+            if e[0] == "EXC":
+                assert g[1] == "EXC"
+            else:
+                assert [g[0], g[1], g[2], g[3]] == e
+    # candidates without any usable copy, copies hanging over contig ends
+    names, seqs = casegen.make_genome(3, n_chr=2, chr_len=(5000, 6000), other_frac=0.0)
+    ctx.genome_pack(seqs)
+    cands = [seqs[0][1000:1300], seqs[1][200:700], "ACGT" * 40]
+    copies = [[], [(1, 1, 40, 0), (1, len(seqs[1]) - 30, len(seqs[1]), 1), (1, 201, 700, 0)], [(0, 10, 20, 0)]]
+    res, _ = ctx.flank_region_align("tir", cands, copies, plant=1)
+    import oracle_pipeline as OP
+
+    for cand, cp, r in zip(cands, copies, res):
+        assert [r[0], r[1], r[2], r[3]] == OP.fine_stage_candidate("tir", cand, cp, seqs, plant=1)
+    assert ctx.flank_region_align("tir", [], [], plant=1)[0] == []
+
+
+def test_max_size_alignment(ctx):
+    """the full-length pass at max_single_repeat_len: 30 kb windows (C-ABI limit 32767) through alignment and judge"""
+    rng = np.random.default_rng(99)
+    L = 30000
+    cons = casegen.rand_seq(rng, 14)
+    cons = cons + casegen.rand_seq(rng, L - 28) + casegen.revcomp(cons[:14])
+    wins = []
+    for r in range(4):
+        s = casegen.mutate(rng, cons, 0.04 if r else 0.0)
+        if r == 2:
+            s = s[:12000] + s[12040:]          # a 40-bp deletion
+        if r == 3:
+            s = s[:20000] + casegen.rand_seq(rng, 25) + s[20000:]  # a 25-bp insertion
+        t = casegen.rand_seq(rng, 9)
+        wins.append(casegen.rand_seq(rng, 41) + t + s + t + casegen.rand_seq(rng, 41))
+    got = ctx.star_msa([wins])[0]
+    exp = O.star_msa(wins)
+    assert got is not None and exp is not None and np.array_equal(got, exp)
+    clean = ctx.sparse_cols([got])[0]
+    kc = O.sparse_cols(exp).astype(bool)
+    assert np.array_equal(clean, exp[:, kc])
+    cand = wins[0][50 - 3: 50 + L + 2]
+    g = ctx.judge("tir", [clean], [cand], plant=1)[0]
+    e, _ = O.judge("tir", np.ascontiguousarray(exp[:, kc]), cand, 1)
+    assert [g[0], g[1], g[2], g[3]] == e
+
+
+def test_dropin_scripts(ctx, tmp_path):
+    """argv-compatible stage scripts: coarse_boundary (HSP table -> FMEA -> flanks) and judge_TIR (flanked
+    candidates -> confident_tir_{i}.fa) keep the reference's file contract"""
+    import subprocess
+    import sys as _sys
+
+    import synth_small
+
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    g = synth_small.make(21, n_fam=10, n_chr=2, chr_len=150_000)
+    ref = tmp_path / "genome.fa"
+    ref.write_text("".join(">chr%d\n%s\n" % (i + 1, s) for i, s in enumerate(g["contigs"])))
+    # coarse stage from an HSP table
+    rows = casegen.make_hsp_table(3, n_seg=1, n_fam=6, seg_len=140_000, noise=10, chroms=("chr1", "chr2"))
+    hsp = tmp_path / "0.fa.final.out"
+    hsp.write_text("".join(casegen.hsp_to_blast6_lines(rows)))
+    out = tmp_path / "out"
+    rc = subprocess.run([_sys.executable, root + "/hite_amd/scripts/coarse_boundary.py", "-g", str(ref), "-r", str(ref),
+                         "--tmp_output_dir", str(out), "--ref_index", "0", "--fixed_extend_base_threshold", "2000",
+                         "--max_repeat_len", "30000", "--thread", "1", "--flanking_len", "50", "--recover", "0",
+                         "--hsp", str(hsp)], capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stderr
+    from hite_amd import util
+
+    names, _ = util.read_fasta(str(out / "longest_repeats_0.fa"))
+    h = O.hsp_arrays([tuple(r) for r in rows])
+    assert names == O.fmea(h, 2000, 30000)
+    fn, fc = util.read_fasta(str(out / "longest_repeats_0.flanked.fa"))
+    assert len(fn) == len(names) and all(len(fc[n]) >= 180 for n in fn)
+    # fine stage: flanked candidates of the planted families
+    flanked = tmp_path / "cand.flanked.fa"
+    recs = []
+    for i, (cand, cps) in enumerate(zip(g["cands"], g["copies"])):
+        c, a, b, m = cps[0]
+        s = g["contigs"][c][a - 1 - 50:b + 50]
+        recs.append(">chr%d:%d-%d\n%s\n" % (c + 1, a - 50, b + 50, s))
+    flanked.write_text("".join(recs))
+    rc = subprocess.run([_sys.executable, root + "/hite_amd/scripts/judge_TIR_transposons.py", "--seqs", str(flanked), "-t", "1",
+                         "--tmp_output_dir", str(out), "--ref_index", "0", "--plant", "1", "--flanking_len", "50", "--recover", "0",
+                         "-r", str(ref), "--min_TE_len", "80"], capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stderr
+    tn, tc = util.read_fasta(str(out / "confident_tir_0.fa"))
+    assert len(tn) >= 2 and all(n.startswith("genome-TIR_0_") for n in tn)
