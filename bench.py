@@ -191,7 +191,7 @@ def main():
                                    "(%s)" % (args.genome_mbp, n_tir, n_ltr, n_cand,
                                          "copy finding by minimizer-index lookup inside the timed step; index build %.1f s untimed" % index_s
                                          if args.copies == "found" else "copy table = generator truth; copy finding not in the timed path"),
-                       "genome_bp": G, "candidates_per_gpu": n_cand, "copies": int(found["n"]), "copy_table": args.copies, "rows_aligned_per_step": rows,
+                       "genome_bp": G, "candidates_per_gpu": n_cand, "candidate_bases": cand_bytes, "copies": int(found["n"]), "copy_table": args.copies, "rows_aligned_per_step": rows,
                        "is_te": n_te, "parallelism": "replicated genome, candidates sharded x%d, all-gather of 32-B calls" % world,
                        "setup_s": round(setup_s, 1)},
             "roofline": roof,

@@ -96,25 +96,42 @@ __device__ __forceinline__ int64_t window_min(int64_t p, int64_t b, int64_t nk, 
     return best;
 }
 
+// wave-aggregated append: one atomic per wavefront instead of one per lane (a single hot counter serialises in L2)
+__device__ __forceinline__ unsigned long long wave_append(bool want, unsigned long long *counter) {
+    const unsigned long long m = __ballot(want);
+    if (m == 0) return 0;
+    const int lane = threadIdx.x & 63;
+    const int leader = __ffsll((long long)m) - 1;
+    unsigned long long base = 0;
+    if (lane == leader) base = atomicAdd(counter, (unsigned long long)__popcll(m));
+    base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader) << 32) | (unsigned)__shfl((int)base, leader);
+    return base + __popcll(m & ((1ull << lane) - 1ull));
+}
+
 // genome minimizers: thread = window start (global position).  key = hs << 32 | pos
 __global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
                                                                const int64_t *__restrict__ coff, int nc, int64_t G,
                                                                unsigned long long *__restrict__ out, unsigned long long cap,
                                                                unsigned long long *__restrict__ counter) {
-    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < G; p += (int64_t)gridDim.x * blockDim.x) {
-        int c = contig_of(coff, nc, p);
-        int64_t cb = coff[c], ce = coff[c + 1];
-        int64_t nk = ce - cb - CK + 1;
-        if (nk <= 0) continue;
-        int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
-        if (p - cb >= nwin) continue;
-        auto hs_at = [&](int64_t i) { return genome_hs(bases, nmask, i, ce); };
-        unsigned h, hp;
-        int64_t m = window_min(p, cb, nk, hs_at, &h);
-        if (m < 0) continue;
-        if (p > cb) { int64_t mp = window_min(p - 1, cb, nk, hs_at, &hp); if (mp == m) continue; }
-        unsigned long long slot = atomicAdd(counter, 1ull);
-        if (slot < cap) out[slot] = ((unsigned long long)h << 32) | (unsigned long long)(unsigned)m;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < G; p0 += stride) {   // block-uniform trip count (wave_append)
+        const int64_t p = p0 + threadIdx.x;
+        bool want = false; unsigned h = 0; int64_t m = -1;
+        if (p < G) {
+            int c = contig_of(coff, nc, p);
+            int64_t cb = coff[c], ce = coff[c + 1];
+            int64_t nk = ce - cb - CK + 1;
+            int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
+            if (nk > 0 && p - cb < nwin) {
+                auto hs_at = [&](int64_t i) { return genome_hs(bases, nmask, i, ce); };
+                unsigned hp;
+                m = window_min(p, cb, nk, hs_at, &h);
+                want = m >= 0;
+                if (want && p > cb) { int64_t mp = window_min(p - 1, cb, nk, hs_at, &hp); if (mp == m) want = false; }
+            }
+        }
+        unsigned long long slot = wave_append(want, counter);
+        if (want && slot < cap) out[slot] = ((unsigned long long)h << 32) | (unsigned long long)(unsigned)m;
     }
 }
 
@@ -155,13 +172,16 @@ __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const un
         const int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
         const unsigned *h0 = hs + cb;
         auto hs_at = [&](int64_t i) { return h0[i]; };
-        for (int64_t lp = lane; lp < nwin; lp += 64) {
-            unsigned h, hp;
-            int64_t m = window_min(lp, 0, nk, hs_at, &h);
-            if (m < 0) continue;
-            if (lp > 0) { int64_t mp = window_min(lp - 1, 0, nk, hs_at, &hp); if (mp == m) continue; }
-            unsigned long long slot = atomicAdd(counter, 1ull);
-            if (slot < cap) { q_c[slot] = (unsigned)c; q_pos[slot] = (unsigned)m; q_hs[slot] = h; }
+        for (int64_t l0 = 0; l0 < nwin; l0 += 64) {
+            const int64_t lp = l0 + lane;
+            unsigned h = 0, hp; int64_t m = -1; bool want = false;
+            if (lp < nwin) {
+                m = window_min(lp, 0, nk, hs_at, &h);
+                want = m >= 0;
+                if (want && lp > 0) { int64_t mp = window_min(lp - 1, 0, nk, hs_at, &hp); if (mp == m) want = false; }
+            }
+            unsigned long long slot = wave_append(want, counter);
+            if (want && slot < cap) { q_c[slot] = (unsigned)c; q_pos[slot] = (unsigned)m; q_hs[slot] = h; }
         }
     }
 }
@@ -425,18 +445,18 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_pos = (unsigned *)p;
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_hs = (unsigned *)p;
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
-    int tk_cm = hite_prof_begin(ctx, "cand_minimizer_kernel", st);
     {
-        int64_t blocks = (cand_bytes + 255) / 256; if (blocks > 256 * 64) blocks = 256 * 64;
         unsigned *chs;
         CCHK(arena_alloc(ctx, A, (size_t)(cand_bytes + 16) * 4, &p)); chs = (unsigned *)p;
         int wblocks = (n_cand + 3) / 4; if (wblocks > 8192) wblocks = 8192;
-        (void)blocks;
+        int tk_ch = hite_prof_begin(ctx, "cand_hs_kernel", st);
         hipLaunchKernelGGL(cand_hs_kernel, dim3(wblocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, chs);
+        hite_prof_end(ctx, tk_ch, st);
+        int tk_cm = hite_prof_begin(ctx, "cand_minimizer_kernel", st);
         hipLaunchKernelGGL(cand_minimizer_kernel, dim3(wblocks), dim3(256), 0, st, n_cand, chs, d_cand_off, q_c, q_pos, q_hs, qcap,
                            (unsigned long long *)S->d_scal);
+        hite_prof_end(ctx, tk_cm, st);
     }
-    hite_prof_end(ctx, tk_cm, st);
     CCHK(read_back(ctx, S, st, 1));
     const int64_t nq = S->h_pin[0];
     if ((unsigned long long)nq > qcap) return HITE_ECAP;

@@ -127,8 +127,10 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         if (m <= 0 || n <= 0 || steps > P.max_steps) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
 
         // ---------------- forward ----------------
+        // Scores are kept shifted by +4 per anti-diagonal (gap 0, mismatch +6, match +10): every real cell
+        // compares exactly as with +2 / -2 / -4, and the recurrence is one add and one v_max3 per cell.
         int t = -32;                                   // origin of anti-diagonal s-1 (scalar)
-        int prev = lane == 32 ? MBIAS : 0, ppal = 0;   // H(s-1) at origin t;  H(s-2) re-aligned to origin t
+        int prev = lane == 32 ? MBIAS : 0, pp = 0;     // H(s-1) at origin t;  H(s-2) re-aligned to origin t
         int areg, breg;                                // a[i-1], b[j-1] of this lane's cell on anti-diagonal s-1
         {
             int ia = t + lane - 1, jb = -(t + lane) - 1;
@@ -136,87 +138,112 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             if (areg == 'N') areg = 0xFD;
             breg = (jb >= 0 && jb < n) ? b[jb] : 0xFE;
         }
-        // bases that would enter the band at step 1: a[t + 63] on a down move, b[0 - t] on a right move.
-        // Kept raw (+ in-range flag) and only turned into base-or-sentinel at the point of use, so that the
-        // broadcast load issued at step s is not waited for before the next move of the same kind.
-        int na_raw, nb_raw, na_i, nb_i;   // the in-range test is redone from the index at the point of use (no loop-carried masks)
-        {
-            na_i = t + 63; nb_i = -t;
-            na_raw = a[(unsigned)na_i < (unsigned)m ? na_i : 0];
-            nb_raw = b[(unsigned)nb_i < (unsigned)n ? nb_i : 0];
-        }
-        unsigned dreg = 0, mreg = 0;
-        int vz;  // an opaque vector zero: keeps the prefetch addressing on the vector unit (the scalar unit is the scarce one)
-        asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
         const int m31 = m - 31, n1 = n + 1;
-        const int nchunk = steps >> 4;
-        // one anti-diagonal; the move is wave-uniform, the two arms are complete (no re-merge before the DP math)
-#define ALIGN_STEP(SS)                                                                                                   \
-        {                                                                                                                \
-            const int s_ = (SS);                                                                                         \
-            const int h0 = __builtin_amdgcn_readlane(prev, 0), h63 = __builtin_amdgcn_readlane(prev, 63);                \
-            int tn, sc0, sc1;                                                                                            \
-            const int s31 = s_ - 31;                                                                                     \
-            /* band steering on the scalar unit:  move = (h63 - h0 + (s & 1)) > 0;                                  */   \
-            /* tn = max(min(t + move, min(m, s) - 31), max(0, s - n) - 32)                                           */   \
-            asm volatile(                                                                                                \
-                "s_and_b32 %1, %4, 1\n\t"                                                                                \
-                "s_sub_i32 %2, %6, %5\n\t"                                                                               \
-                "s_add_i32 %2, %2, %1\n\t"                                                                               \
-                "s_cmp_gt_i32 %2, 0\n\t"                                                                                 \
-                "s_addc_u32 %0, %3, 0\n\t"                                                                               \
-                "s_min_i32 %1, %7, %8\n\t"                                                                               \
-                "s_min_i32 %0, %0, %1\n\t"                                                                               \
-                "s_sub_i32 %2, %8, %9\n\t"                                                                               \
-                "s_max_i32 %2, %2, -32\n\t"                                                                              \
-                "s_max_i32 %0, %0, %2"                                                                                   \
-                : "=&s"(tn), "=&s"(sc0), "=&s"(sc1)                                                                      \
-                : "s"(t), "s"(s_), "s"(h0), "s"(h63), "s"(m31), "s"(s31), "s"(n1)                                        \
-                : "scc");                                                                                                \
-            int hl, hu, hd;                                                                                              \
-            if (tn != t) {                                                                                               \
-                /* down: (left, up, diag) = (H(s-1)[k+1], H(s-1)[k], H(s-2)'[k]); centre bases slide to lane 0 */        \
-                hl = from_next_lane0(prev); hu = prev; hd = ppal;                                                        \
-                const int na = (unsigned)na_i < (unsigned)m ? (na_raw == 'N' ? 0xFD : na_raw) : 0xFF;                     \
-                areg = from_next_lane(areg, na);                                                                         \
-                na_i = tn + 63 + vz;                                                                                     \
-                na_raw = a[(unsigned)na_i < (unsigned)m ? na_i : 0];                                                     \
-                mreg = (mreg << 1) | 1u;                                                                                 \
-                const int cd = hd + (areg == breg ? SC_MATCH : SC_MIS);                                                  \
-                const int cu = hu + SC_GAP, cl = hl + SC_GAP;                                                            \
-                const int mx = cu > cl ? cu : cl;                                                                        \
-                const int v = cd > mx ? cd : mx;                                                                         \
-                dreg = (dreg << 2) | (cd == v ? 0u : (cu >= cl ? 1u : 2u));                                              \
-                ppal = hl; prev = v;                                                                                     \
-            } else {                                                                                                     \
-                /* right: (left, up, diag) = (H(s-1)[k], H(s-1)[k-1], H(s-2)'[k-1]); row bases slide to lane 63 */       \
-                hl = prev; hu = from_prev_lane0(prev); hd = from_prev_lane0(ppal);                                       \
-                const int nb = (unsigned)nb_i < (unsigned)n ? nb_raw : 0xFE;                                             \
-                breg = from_prev_lane(breg, nb);                                                                         \
-                nb_i = s_ - tn + vz;                                                                                     \
-                nb_raw = b[(unsigned)nb_i < (unsigned)n ? nb_i : 0];                                                     \
-                mreg = mreg << 1;                                                                                        \
-                const int cd = hd + (areg == breg ? SC_MATCH : SC_MIS);                                                  \
-                const int cu = hu + SC_GAP, cl = hl + SC_GAP;                                                            \
-                const int mx = cu > cl ? cu : cl;                                                                        \
-                const int v = cd > mx ? cd : mx;                                                                         \
-                dreg = (dreg << 2) | (cd == v ? 0u : (cu >= cl ? 1u : 2u));                                              \
-                ppal = hl; prev = v;                                                                                     \
-            }                                                                                                            \
-            t = tn;                                                                                                      \
+        const int nchunk = (steps + 15) >> 4;          // chunk ch = anti-diagonals 16 ch + 1 .. 16 ch + 16
+        int s31 = to_sgpr(1 - 31);                     // (s - 31) of the next step
+        const int neg32 = to_sgpr(-32);
+        // One anti-diagonal, hand-scheduled (the compiler's version of the same step re-merges the two arms through
+        // lane masks and spends ~45 issue slots; this one is 14-15 vector + 13 scalar and needs no s_nop):
+        //   steering (scalar): move = h63 > h0 (even s) / h63 >= h0 (odd s); tn = max(min(t + move, min(m,s) - 31), max(0,s-n) - 32)
+        //   down : bases of the centre slide one lane down (DPP wave_shl), lanes 60..63 are refilled from the rotating
+        //          window `ach` (DPP wave_rol, row/bank-masked); left = shl(prev) lands in pp (it is the next diagonal)
+        //   right: same with the row bases / wave_shr / `bch`; diagonal = shr(pp) folded into the add (v_add_u32_dpp)
+        //   direction bits: carry-in adds (d = 2 d + bit) into two planes, du: up >= left, dd: diagonal wins;
+        //   the dd compare of step s is consumed by the add in step s+1 (fills the VALU->SGPR->VALU wait states).
+#define STEP_ASM(CMP, L)                                                                          \
+            "v_readlane_b32 %[h0], %[prev], 0\n\t"                                                \
+            "v_readlane_b32 %[h63], %[prev], 63\n\t"                                              \
+            CMP " %[h63], %[h0]\n\t"                                                              \
+            "s_addc_u32 %[tn], %[t], 0\n\t"                                                       \
+            "s_min_i32 %[x], %[m31], %[s31]\n\t"                                                  \
+            "s_min_i32 %[tn], %[tn], %[x]\n\t"                                                    \
+            "s_sub_i32 %[y], %[s31], %[n1]\n\t"                                                   \
+            "s_max_i32 %[y], %[y], %[neg32]\n\t"                                                  \
+            "s_max_i32 %[tn], %[tn], %[y]\n\t"                                                    \
+            "s_add_i32 %[s31], %[s31], 1\n\t"                                                     \
+            "s_cmp_lg_u32 %[tn], %[t]\n\t"                                                        \
+            "s_mov_b32 %[t], %[tn]\n\t"                                                           \
+            "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
+            "s_lshl1_add_u32 %[mreg], %[mreg], 1\n\t"                                             \
+            "v_mov_b32_dpp %[areg], %[areg] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"            \
+            "v_mov_b32_dpp %[areg], %[ach] wave_rol:1 row_mask:0x8 bank_mask:0x8\n\t"             \
+            "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
+            "v_mov_b32_dpp %[ach], %[ach] wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"              \
+            "v_addc_co_u32 %[dd], %[jk], %[dd], %[dd], %[e]\n\t"                                  \
+            "v_cndmask_b32_e64 %[tsc], 6, 10, vcc\n\t"                                            \
+            "v_add_u32 %[tcd], %[pp], %[tsc]\n\t"                                                 \
+            "v_mov_b32_dpp %[pp], %[prev] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            "v_cmp_ge_i32 vcc, %[prev], %[pp]\n\t"                                                \
+            "v_max3_i32 %[prev], %[tcd], %[prev], %[pp]\n\t"                                      \
+            "v_cmp_eq_u32 %[e], %[tcd], %[prev]\n\t"                                              \
+            "v_addc_co_u32 %[du], %[jk], %[du], %[du], vcc\n\t"                                   \
+            "s_branch J" L "_%=\n"                                                                \
+            "R" L "_%=:\n\t"                                                                      \
+            "s_lshl_b32 %[mreg], %[mreg], 1\n\t"                                                  \
+            "v_mov_b32_dpp %[breg], %[breg] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
+            "v_mov_b32_dpp %[breg], %[bch] wave_ror:1 row_mask:0x1 bank_mask:0x1\n\t"             \
+            "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
+            "v_mov_b32_dpp %[bch], %[bch] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"              \
+            "v_addc_co_u32 %[dd], %[jk], %[dd], %[dd], %[e]\n\t"                                  \
+            "v_cndmask_b32_e64 %[tsc], 6, 10, vcc\n\t"                                            \
+            "v_mov_b32_dpp %[thx], %[prev] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            "v_add_u32_dpp %[tcd], %[pp], %[tsc] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            "v_cmp_ge_i32 vcc, %[thx], %[prev]\n\t"                                               \
+            "v_mov_b32 %[pp], %[prev]\n\t"                                                        \
+            "v_max3_i32 %[prev], %[tcd], %[thx], %[pp]\n\t"                                       \
+            "v_cmp_eq_u32 %[e], %[tcd], %[prev]\n\t"                                              \
+            "v_addc_co_u32 %[du], %[jk], %[du], %[du], vcc\n"                                     \
+            "J" L "_%=:\n\t"
+#define STEP_OPERANDS                                                                                                      \
+            : [prev] "+v"(prev), [pp] "+v"(pp), [areg] "+v"(areg), [breg] "+v"(breg), [ach] "+v"(ach), [bch] "+v"(bch),   \
+              [du] "+v"(du), [dd] "+v"(dd), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [t] "+s"(t),            \
+              [mreg] "+s"(mreg), [s31] "+s"(s31), [cnt] "+s"(cnt), [h0] "=&s"(h0), [h63] "=&s"(h63), [x] "=&s"(sx),       \
+              [y] "=&s"(sy), [tn] "=&s"(tn), [e] "+s"(epair), [jk] "=&s"(jpair)                                          \
+            : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32)                                                             \
+            : "vcc", "scc"
+        for (int ch = 0; ch < nchunk; ch++) {
+            const int s_lo = (ch << 4) + 1;
+            const int left = steps - (ch << 4);
+            const int nst = left < 16 ? left : 16;
+            // rotating windows of the bases that can enter the band during this chunk (<= 16 of each):
+            //   ach[l] = a'[t + 63 + o(l)], o = -3 .. 60 (lane 0 is the next base in, lanes 61..63 the last three in)
+            //   bch[l] = b'[s_lo - t - 1 + p(l)], p(63) = 0 the next base in, lanes 0..2 the last three in
+            int ach, bch;
+            {
+                const int ia = t + 63 + (((lane + 3) & 63) - 3);
+                const int ra = a[(unsigned)ia < (unsigned)m ? ia : 0];
+                ach = (unsigned)ia < (unsigned)m ? (ra == 'N' ? 0xFD : ra) : 0xFF;
+                const int ib = s_lo - t - 1 + (((66 - lane) & 63) - 3);
+                const int rb = b[(unsigned)ib < (unsigned)n ? ib : 0];
+                bch = (unsigned)ib < (unsigned)n ? rb : 0xFE;
+            }
+            int du = 0, dd = 0, tsc, tcd, thx;
+            int mreg = to_sgpr(0), h0, h63, sx, sy, tn;
+            unsigned long long epair = 0, jpair;   // epair: the "diagonal wins" mask of the last step, not yet added into dd
+            if (nst >= 2) {
+                int cnt = to_sgpr((nst >> 1) - 1);
+                asm volatile(
+                    "L_%=:\n\t"
+                    STEP_ASM("s_cmp_ge_i32", "a")
+                    STEP_ASM("s_cmp_gt_i32", "b")
+                    "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                    "s_cbranch_scc0 L_%=\n\t"
+                    STEP_OPERANDS);
+            }
+            if (nst & 1) {
+                int cnt = 0;
+                asm volatile(
+                    STEP_ASM("s_cmp_ge_i32", "c")
+                    STEP_OPERANDS);
+            }
+            asm volatile("s_nop 1\n\tv_addc_co_u32 %[dd], %[jk], %[dd], %[dd], %[e]"
+                         : [dd] "+v"(dd), [jk] "=&s"(jpair) : [e] "s"(epair) : "vcc");
+            const int sh = 16 - nst;
+            tbd[ch * 64 + lane] = ((unsigned)(dd << sh) << 16) | ((unsigned)(du << sh) & 0xffffu);
+            if (lane == 0) tbm[ch] = ((unsigned)mreg << sh) & 0xffffu;   // bit (15 - ((s - 1) & 15)) = move of step s
         }
-        for (int ch = 0; ch <= nchunk; ch++) {
-            const int s_lo = ch == 0 ? 1 : ch << 4;
-            const int s_hi = (ch << 4) + 15 < steps ? (ch << 4) + 15 : steps;
-            int s = s_lo;
-            for (; s + 1 <= s_hi; s += 2) { ALIGN_STEP(s) ALIGN_STEP(s + 1) }
-            if (s <= s_hi) ALIGN_STEP(s)
-            const int sh = 15 - (s_hi & 15);
-            tbd[ch * 64 + lane] = dreg << (2 * sh);
-            if (lane == 0) tbm[ch] = (mreg << sh) & 0xffffu;   // bit (15 - (s & 15)) = move of step s
-            dreg = 0; mreg = 0;
-        }
-#undef ALIGN_STEP
+#undef STEP_ASM
+#undef STEP_OPERANDS
         {
             const int kf = m - t;
             const int hf = (kf >= 0 && kf < 64) ? __builtin_amdgcn_readlane(prev, kf & 63) : 0;
@@ -227,6 +254,8 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         // ---------------- traceback: wave-uniform walk kept in vector registers ----------------
+        int vz;  // an opaque vector zero: keeps the walk's bookkeeping on the vector unit (the scalar unit is the scarce one)
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
         int i = m + vz, j = n + vz;       // every lane carries the same (i, j)
         int k = m - t + vz;               // lane that owns cell (i, j) on anti-diagonal i + j
         unsigned wcur = 0;                // this lane's direction word of the 16-step chunk
@@ -234,7 +263,7 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         int oreg = 0, fail = 0, bad = 0;
         int dchunk_v = -1 + vz;           // loaded chunk, kept as a (uniform) vector value: the compares stay on the vector unit
         while (__builtin_amdgcn_readfirstlane(i) > 0) {
-            const int s = i + j;
+            const int s = i + j - 1;      // chunk / bit index of anti-diagonal i + j
             if ((s >> 4) != dchunk_v) {   // uniform
                 dchunk_v = s >> 4;
                 const int dc = __builtin_amdgcn_readfirstlane(dchunk_v);
@@ -245,7 +274,7 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             bad |= (unsigned)k > 63u;
             const unsigned wsel = (unsigned)__builtin_amdgcn_ds_bpermute((k & 63) << 2, (int)wcur);
             const int r = s & 15;
-            int d = (int)((wsel >> (2 * (15 - r))) & 3u);
+            int d = ((wsel >> (31 - r)) & 1u) ? 0 : (((wsel >> (15 - r)) & 1u) ? 1 : 2);
             d = j == 0 ? 1 : d;
             // moves of steps s (bit 15 - r) and s-1 (bit 16 - r: bit 0 of the lower chunk when r == 0)
             const int mv_s = (int)((mm >> (15 - r)) & 1u), mv_s1 = (int)((mm >> (16 - r)) & 1u);

@@ -18,7 +18,10 @@
  *   every lane of the band evaluates the same recurrence every step: bases outside the sequences
  *   are sentinels that never match (so cells outside the matrix only ever hold "junk" that
  *   cannot beat a real score), values shifted in from outside the band are 0 and real scores
- *   are biased by 2^28 (H(0,0) = 2^28); an 'N' in the centre never matches.  The alignment
+ *   are biased by 2^28 (H(0,0) = 2^28); an 'N' in the centre never matches.  H is STORED shifted
+ *   by +4 per anti-diagonal, i.e. the recurrence adds +10 / +6 / 0 for match / mismatch / gap
+ *   (identical comparisons for every cell derived from H(0,0); the 0 that enters at the band
+ *   edges is not shifted, which is part of this definition).  The alignment
  *   fails if H(m,n) <= 2^27 (end cell not reachable inside the band).
  *   The diagonal operand is carried in ONE history register H(s-2)' = H(s-2) re-aligned to the
  *   origin of anti-diagonal s-1, which is simply the previous step's "left" operand; an element
@@ -38,9 +41,10 @@
 #define ORC_ECAP (-1001)
 #define W 64
 #define BIAS (1 << 28)
-#define SC_MATCH 2
-#define SC_MIS (-2)
-#define SC_GAP (-4)
+/* stored scores are shifted by +4 per anti-diagonal: (match, mismatch, gap) = (+2, -2, -4) + (8, 8, 4) */
+#define SC_MATCH 10
+#define SC_MIS 6
+#define SC_GAP 0
 
 /* align row b[0..n) to centre a[0..m); ops[p] (p = 0..m): low 15 bits = insertions before p,
  * bit 15 = row has a gap at centre position p.  returns 0 or <0. */
