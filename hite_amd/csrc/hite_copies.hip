@@ -148,41 +148,66 @@ __global__ void i64_to_u32_kernel(int64_t n, const int64_t *__restrict__ in, uns
     if (i < n) out[i] = (unsigned)in[i];
 }
 
-// candidate k-mer hashes: one wavefront per candidate (no per-position search for the owning candidate)
-__global__ void __launch_bounds__(256) cand_hs_kernel(int ncand, const uint8_t *__restrict__ cand, const int64_t *__restrict__ cand_off,
-                                                      unsigned *__restrict__ hs) {
-    const int lane = threadIdx.x & 63;
-    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < ncand; c += gridDim.x * 4) {
-        const int64_t cb = cand_off[c], L = cand_off[c + 1] - cb;
+// candidate minimizers: one wavefront per candidate, 64 window starts per tile.  The tile's bases are staged in LDS
+// once (coalesced), the 75 k-mer hashes it needs are built from LDS and stay there; every lane then scans its own
+// window and the previous one (11 LDS reads).  Nothing but the minimizers themselves goes to HBM.
+// Two passes (WRITE = false: per-candidate counts; an exclusive scan; WRITE = true: the records, ordered by
+// (candidate, position)): a single append counter would serialise ~3 M device-scope atomics (~12 ns each).
+template <bool WRITE>
+__global__ void __launch_bounds__(64) cand_minimizer_kernel(int ncand, const uint8_t *__restrict__ cand,
+                                                            const int64_t *__restrict__ cand_off,
+                                                            unsigned *__restrict__ q_c, unsigned *__restrict__ q_pos,
+                                                            unsigned *__restrict__ q_hs, int32_t *__restrict__ q_cnt,
+                                                            const int64_t *__restrict__ q_first) {
+    __shared__ uint8_t sb[96];
+    __shared__ unsigned sh[80];
+    const int lane = threadIdx.x;
+    for (int c = blockIdx.x; c < ncand; c += gridDim.x) {
+        const int64_t cb = cand_off[c];
+        const int L = (int)(cand_off[c + 1] - cb);
+        const int nk = L - CK + 1;
+        if (nk <= 0) { if (!WRITE && lane == 0) q_cnt[c] = 0; continue; }
+        const int nwin = nk >= CW ? nk - CW + 1 : 1;
         const uint8_t *s = cand + cb;
-        for (int64_t p = lane; p < L; p += 64) hs[cb + p] = ascii_hs(s, p, L);
-    }
-}
-// candidate minimizers: one wavefront per candidate, lane = window start; window minima over the precomputed hashes
-__global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const unsigned *__restrict__ hs,
-                                                             const int64_t *__restrict__ cand_off,
-                                                             unsigned *__restrict__ q_c, unsigned *__restrict__ q_pos,
-                                                             unsigned *__restrict__ q_hs, unsigned long long cap,
-                                                             unsigned long long *__restrict__ counter) {
-    const int lane = threadIdx.x & 63;
-    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < ncand; c += gridDim.x * 4) {
-        const int64_t cb = cand_off[c], L = cand_off[c + 1] - cb;
-        const int64_t nk = L - CK + 1;
-        if (nk <= 0) continue;
-        const int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
-        const unsigned *h0 = hs + cb;
-        auto hs_at = [&](int64_t i) { return h0[i]; };
-        for (int64_t l0 = 0; l0 < nwin; l0 += 64) {
-            const int64_t lp = l0 + lane;
-            unsigned h = 0, hp; int64_t m = -1; bool want = false;
-            if (lp < nwin) {
-                m = window_min(lp, 0, nk, hs_at, &h);
-                want = m >= 0;
-                if (want && lp > 0) { int64_t mp = window_min(lp - 1, 0, nk, hs_at, &hp); if (mp == m) want = false; }
+        int64_t run = WRITE ? q_first[c] : 0;   // wave-uniform running offset
+        for (int base = 0; base < nwin; base += 64) {
+            __syncthreads();
+            for (int q = lane; q < 96; q += 64) { const int pos = base - 1 + q; sb[q] = (pos >= 0 && pos < L) ? s[pos] : 0; }
+            __syncthreads();
+            for (int q = lane; q < 75; q += 64) {   // k-mer start base - 1 + q
+                unsigned x = 0; bool ok = true;
+#pragma unroll
+                for (int i = 0; i < CK; i++) {
+                    const uint8_t ch = sb[q + i];
+                    const unsigned code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+                    ok = ok && code < 4u;
+                    x |= (code & 3u) << (2 * i);
+                }
+                sh[q] = ok ? hs_from_code(x) : HS_INVALID;
             }
-            unsigned long long slot = wave_append(want, counter);
-            if (want && slot < cap) { q_c[slot] = (unsigned)c; q_pos[slot] = (unsigned)m; q_hs[slot] = h; }
+            __syncthreads();
+            const int lp = base + lane;
+            bool want = false; unsigned h = 0; int m = -1;
+            if (lp < nwin) {
+                // window [lp, lp + CW) = sh[lane + 1 .. lane + CW]; previous window = sh[lane .. lane + CW - 1]
+                int mprev = -1; unsigned hprev = 0;
+#pragma unroll
+                for (int i = 0; i < CW; i++) {
+                    const unsigned v = sh[lane + 1 + i];
+                    if (v != HS_INVALID && (m < 0 || (v >> 1) < (h >> 1))) { m = lp + i; h = v; }
+                    const unsigned u = sh[lane + i];
+                    if (u != HS_INVALID && (mprev < 0 || (u >> 1) < (hprev >> 1))) { mprev = lp - 1 + i; hprev = u; }
+                }
+                want = m >= 0 && !(lp > 0 && mprev == m);
+            }
+            const unsigned long long bm = __ballot(want);
+            if (WRITE && want) {
+                const int64_t slot = run + __popcll(bm & ((1ull << lane) - 1ull));
+                q_c[slot] = (unsigned)c; q_pos[slot] = (unsigned)m; q_hs[slot] = h;
+            }
+            run += __popcll(bm);
         }
+        if (!WRITE && lane == 0) q_cnt[c] = (int32_t)run;
     }
 }
 
@@ -445,21 +470,25 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_pos = (unsigned *)p;
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_hs = (unsigned *)p;
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    int64_t nq;
     {
-        unsigned *chs;
-        CCHK(arena_alloc(ctx, A, (size_t)(cand_bytes + 16) * 4, &p)); chs = (unsigned *)p;
-        int wblocks = (n_cand + 3) / 4; if (wblocks > 8192) wblocks = 8192;
-        int tk_ch = hite_prof_begin(ctx, "cand_hs_kernel", st);
-        hipLaunchKernelGGL(cand_hs_kernel, dim3(wblocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, chs);
-        hite_prof_end(ctx, tk_ch, st);
+        int32_t *q_cnt; int64_t *q_first, *qbs;
+        CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); q_cnt = (int32_t *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); q_first = (int64_t *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(n_cand) * 8, &p)); qbs = (int64_t *)p;
+        int wblocks = n_cand < 65536 ? n_cand : 65536;
         int tk_cm = hite_prof_begin(ctx, "cand_minimizer_kernel", st);
-        hipLaunchKernelGGL(cand_minimizer_kernel, dim3(wblocks), dim3(256), 0, st, n_cand, chs, d_cand_off, q_c, q_pos, q_hs, qcap,
-                           (unsigned long long *)S->d_scal);
+        hipLaunchKernelGGL(cand_minimizer_kernel<false>, dim3(wblocks), dim3(64), 0, st, n_cand, d_cand, d_cand_off, q_c, q_pos, q_hs,
+                           q_cnt, (const int64_t *)nullptr);
+        CCHK(scan_excl_buf<int32_t>(ctx, qbs, q_cnt, n_cand, q_first, st));
+        HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, q_first + n_cand, 8, hipMemcpyDeviceToDevice, st));
+        CCHK(read_back(ctx, S, st, 1));
+        nq = S->h_pin[0];
+        if ((unsigned long long)nq > qcap) return HITE_ECAP;
+        hipLaunchKernelGGL(cand_minimizer_kernel<true>, dim3(wblocks), dim3(64), 0, st, n_cand, d_cand, d_cand_off, q_c, q_pos, q_hs,
+                           q_cnt, (const int64_t *)q_first);
         hite_prof_end(ctx, tk_cm, st);
     }
-    CCHK(read_back(ctx, S, st, 1));
-    const int64_t nq = S->h_pin[0];
-    if ((unsigned long long)nq > qcap) return HITE_ECAP;
     if (nq == 0) return HITE_OK;
     CCHK(arena_alloc(ctx, A, (size_t)nq * 4, &p)); occ_lo = (unsigned *)p;
     CCHK(arena_alloc(ctx, A, (size_t)nq * 4, &p)); occ_n = (int32_t *)p;

@@ -239,8 +239,9 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             asm volatile("s_nop 1\n\tv_addc_co_u32 %[dd], %[jk], %[dd], %[dd], %[e]"
                          : [dd] "+v"(dd), [jk] "=&s"(jpair) : [e] "s"(epair) : "vcc");
             const int sh = 16 - nst;
-            tbd[ch * 64 + lane] = ((unsigned)(dd << sh) << 16) | ((unsigned)(du << sh) & 0xffffu);
-            if (lane == 0) tbm[ch] = ((unsigned)mreg << sh) & 0xffffu;   // bit (15 - ((s - 1) & 15)) = move of step s
+            // bit-reversed so that step r of the chunk sits at bit r (diagonal plane), 16 + r (up plane), r (moves)
+            tbd[ch * 64 + lane] = __brev(((unsigned)(dd << sh) << 16) | ((unsigned)(du << sh) & 0xffffu));
+            if (lane == 0) tbm[ch] = __brev(((unsigned)mreg << sh) & 0xffffu) >> 16;
         }
 #undef STEP_ASM
 #undef STEP_OPERANDS
@@ -253,46 +254,85 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
-        // ---------------- traceback: wave-uniform walk kept in vector registers ----------------
-        int vz;  // an opaque vector zero: keeps the walk's bookkeeping on the vector unit (the scalar unit is the scarce one)
-        asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-        int i = m + vz, j = n + vz;       // every lane carries the same (i, j)
-        int k = m - t + vz;               // lane that owns cell (i, j) on anti-diagonal i + j
-        unsigned wcur = 0;                // this lane's direction word of the 16-step chunk
-        unsigned mm = 0;                  // moves: chunk of s in bits 0..15, the chunk below in bits 16..31
-        int oreg = 0, fail = 0, bad = 0;
-        int dchunk_v = -1 + vz;           // loaded chunk, kept as a (uniform) vector value: the compares stay on the vector unit
-        while (__builtin_amdgcn_readfirstlane(i) > 0) {
-            const int s = i + j - 1;      // chunk / bit index of anti-diagonal i + j
-            if ((s >> 4) != dchunk_v) {   // uniform
-                dchunk_v = s >> 4;
-                const int dc = __builtin_amdgcn_readfirstlane(dchunk_v);
-                wcur = tbd[dc * 64 + lane];
-                const unsigned mc = tbm[dc], mp = dc > 0 ? tbm[dc - 1] : 0u;
-                mm = (mp << 16) | mc;
-            }
+        // ---------------- traceback: scalar walk ----------------
+        // (i-1, j-1, k), the bit index r of the anti-diagonal inside its chunk and the move bits live in SGPRs (i-1 in
+        // M0: it is the lane select of the v_writelane that drops each result into `oreg`); the direction word of the
+        // current cell is one v_readlane of the chunk's per-lane words.  One asm loop per 16-step chunk, then the <= 16
+        // centre positions it produced leave as one masked store.  A cell on the path is always inside the band (its
+        // score derives from H(0,0), checked above; band-edge fills are 2^28 lower), so k is only checked per chunk.
+        int ip = m - 1, jp = n - 1;
+        int k = m - t;                    // lane that owns cell (i, j) on anti-diagonal i + j
+        int oreg = 0, bad = 0, fail;
+        while (ip >= 0 && jp >= 0) {
+            const int sp = ip + jp + 1;   // chunk / bit index of anti-diagonal i + j
+            const int dch = sp >> 4;
+            int r = to_sgpr(sp & 15);
+            const unsigned wcur = tbd[dch * 64 + lane];   // bit r: diagonal wins at step r of the chunk; bit 16 + r: up >= left
+            const unsigned mc = tbm[dch], mp = dch > 0 ? tbm[dch - 1] : 0u;
+            // bit r + 1: move of step r, bit 0: last move of the chunk below
+            const int mm = to_sgpr((int)((mc << 1) | ((mp >> 15) & 1u)));
             bad |= (unsigned)k > 63u;
-            const unsigned wsel = (unsigned)__builtin_amdgcn_ds_bpermute((k & 63) << 2, (int)wcur);
-            const int r = s & 15;
-            int d = ((wsel >> (31 - r)) & 1u) ? 0 : (((wsel >> (15 - r)) & 1u) ? 1 : 2);
-            d = j == 0 ? 1 : d;
-            // moves of steps s (bit 15 - r) and s-1 (bit 16 - r: bit 0 of the lower chunk when r == 0)
-            const int mv_s = (int)((mm >> (15 - r)) & 1u), mv_s1 = (int)((mm >> (16 - r)) & 1u);
-            const bool isleft = d == 2, isdiag = d == 0;
-            // centre position p = i-1: aligned to row position j-1 (diag) or to a gap before row position j (up)
-            const int p = i - 1;
-            const int val = isdiag ? (j - 1) : (j | 0x8000);
-            if (!isleft && lane == (p & 63)) oreg = val;
-            if (!isleft && (p & 63) == 0) {   // uniform
-                const int pb = __builtin_amdgcn_readfirstlane(p);
-                if (pb + lane < m) ops[pb + lane] = (uint16_t)oreg;
-            }
-            // predecessor cell: left (i, j-1): k + mv_s; up (i-1, j): k - 1 + mv_s; diag (i-1, j-1): k - 1 + mv_s + mv_s1
-            k += mv_s - (isleft ? 0 : 1) + (isdiag ? mv_s1 : 0);
-            i -= isleft ? 0 : 1;
-            j -= d == 1 ? 0 : 1;
+            const int ip0 = ip;
+            int sw, sx, sy;
+            asm volatile(
+                "s_mov_b32 m0, %[ip]\n"
+                "L_%=:\n\t"
+                "v_readlane_b32 %[w], %[wcur], %[k]\n\t"
+                "s_lshr_b32 %[y], %[mm], %[r]\n\t"
+                "s_lshr_b32 %[x], %[w], %[r]\n\t"
+                "s_bitcmp1_b32 %[x], 0\n\t"
+                "s_cbranch_scc0 N_%=\n\t"
+                /* diagonal: centre position i-1 <-> row position j-1 */
+                "v_writelane_b32 %[oreg], %[jp], m0\n\t"
+                "s_and_b32 %[y], %[y], 3\n\t"
+                "s_bcnt1_i32_b32 %[y], %[y]\n\t"
+                "s_add_i32 %[k], %[k], %[y]\n\t"
+                "s_addk_i32 %[k], -1\n\t"
+                "s_sub_i32 m0, m0, 1\n\t"
+                "s_sub_i32 %[jp], %[jp], 1\n\t"
+                "s_sub_i32 %[r], %[r], 2\n\t"
+                "s_or_b32 %[x], %[jp], m0\n\t"
+                "s_or_b32 %[x], %[x], %[r]\n\t"
+                "s_cmp_lt_i32 %[x], 0\n\t"
+                "s_cbranch_scc0 L_%=\n\t"
+                "s_branch E_%=\n"
+                "N_%=:\n\t"
+                "s_bitcmp1_b32 %[x], 16\n\t"
+                "s_cbranch_scc0 F_%=\n\t"
+                /* up: centre position i-1 faces a gap before row position j */
+                "s_add_i32 %[x], %[jp], 0x8001\n\t"
+                "v_writelane_b32 %[oreg], %[x], m0\n\t"
+                "s_bfe_u32 %[y], %[y], 0x10001\n\t"
+                "s_add_i32 %[k], %[k], %[y]\n\t"
+                "s_addk_i32 %[k], -1\n\t"
+                "s_sub_i32 m0, m0, 1\n\t"
+                "s_sub_i32 %[r], %[r], 1\n\t"
+                "s_or_b32 %[x], %[jp], m0\n\t"
+                "s_or_b32 %[x], %[x], %[r]\n\t"
+                "s_cmp_lt_i32 %[x], 0\n\t"
+                "s_cbranch_scc0 L_%=\n\t"
+                "s_branch E_%=\n"
+                "F_%=:\n\t"
+                /* left: a row base inserted */
+                "s_bfe_u32 %[y], %[y], 0x10001\n\t"
+                "s_add_i32 %[k], %[k], %[y]\n\t"
+                "s_sub_i32 %[jp], %[jp], 1\n\t"
+                "s_sub_i32 %[r], %[r], 1\n\t"
+                "s_or_b32 %[x], %[jp], %[r]\n\t"
+                "s_cmp_lt_i32 %[x], 0\n\t"
+                "s_cbranch_scc0 L_%=\n"
+                "E_%=:\n\t"
+                "s_mov_b32 %[ip], m0"
+                : [ip] "+s"(ip), [jp] "+s"(jp), [k] "+s"(k), [r] "+s"(r), [oreg] "+v"(oreg), [w] "=&s"(sw), [x] "=&s"(sx),
+                  [y] "=&s"(sy)
+                : [wcur] "v"(wcur), [mm] "s"(mm)
+                : "scc");
+            // positions (ip, ip0] were produced by this chunk: lane l holds the one with p mod 64 == l
+            const int pl = ip0 - ((ip0 - lane) & 63);
+            if (pl > ip) ops[pl] = (uint16_t)oreg;
         }
-        fail = __builtin_amdgcn_readfirstlane(bad);
+        for (int q = lane; q <= ip; q += 64) ops[q] = (uint16_t)0x8000;   // j == 0: gaps before row position 0
+        fail = bad;
         if (fail && lane == 0) atomicExch(&P.status[c], 1);
     }
 }
