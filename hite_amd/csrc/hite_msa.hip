@@ -127,10 +127,12 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         if (m <= 0 || n <= 0 || steps > P.max_steps) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
 
         // ---------------- forward ----------------
-        // Scores are kept shifted by +4 per anti-diagonal (gap 0, mismatch +6, match +10): every real cell
-        // compares exactly as with +2 / -2 / -4, and the recurrence is one add and one v_max3 per cell.
+        // Stored form of a score (see oracle/hite_oracle_msa.c): shifted by +4 per anti-diagonal (gap 0, mismatch +6,
+        // match +10), times 4, low two bits = tag of the operand that won (2 diagonal, 1 up, 0 left).  With the up
+        // operand stored with tag 1 and the left operand taken as "- 1", ONE v_max3 yields value, tie-break
+        // (diag >= up >= left) and direction; v_alignbit shifts the two direction bits into the per-lane chunk word.
         int t = -32;                                   // origin of anti-diagonal s-1 (scalar)
-        int prev = lane == 32 ? MBIAS : 0, pp = 0;     // H(s-1) at origin t;  H(s-2) re-aligned to origin t
+        int prev = lane == 32 ? ((MBIAS << 2) | 1) : 0, pp = 0;   // H(s-1) at origin t (tag 1);  left operand of step s-1
         int areg, breg;                                // a[i-1], b[j-1] of this lane's cell on anti-diagonal s-1
         {
             int ia = t + lane - 1, jb = -(t + lane) - 1;
@@ -140,66 +142,77 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         }
         const int m31 = m - 31, n1 = n + 1;
         const int nchunk = (steps + 15) >> 4;          // chunk ch = anti-diagonals 16 ch + 1 .. 16 ch + 16
-        int s31 = to_sgpr(1 - 31);                     // (s - 31) of the next step
         const int neg32 = to_sgpr(-32);
-        // One anti-diagonal, hand-scheduled (the compiler's version of the same step re-merges the two arms through
-        // lane masks and spends ~45 issue slots; this one is 14-15 vector + 13 scalar and needs no s_nop):
-        //   steering (scalar): move = h63 > h0 (even s) / h63 >= h0 (odd s); tn = max(min(t + move, min(m,s) - 31), max(0,s-n) - 32)
-        //   down : bases of the centre slide one lane down (DPP wave_shl), lanes 60..63 are refilled from the rotating
-        //          window `ach` (DPP wave_rol, row/bank-masked); left = shl(prev) lands in pp (it is the next diagonal)
-        //   right: same with the row bases / wave_shr / `bch`; diagonal = shr(pp) folded into the add (v_add_u32_dpp)
-        //   direction bits: carry-in adds (d = 2 d + bit) into two planes, du: up >= left, dd: diagonal wins;
-        //   the dd compare of step s is consumed by the add in step s+1 (fills the VALU->SGPR->VALU wait states).
-#define STEP_ASM(CMP, L)                                                                          \
-            "v_readlane_b32 %[h0], %[prev], 0\n\t"                                                \
-            "v_readlane_b32 %[h63], %[prev], 63\n\t"                                              \
-            CMP " %[h63], %[h0]\n\t"                                                              \
-            "s_addc_u32 %[tn], %[t], 0\n\t"                                                       \
-            "s_min_i32 %[x], %[m31], %[s31]\n\t"                                                  \
-            "s_min_i32 %[tn], %[tn], %[x]\n\t"                                                    \
-            "s_sub_i32 %[y], %[s31], %[n1]\n\t"                                                   \
-            "s_max_i32 %[y], %[y], %[neg32]\n\t"                                                  \
-            "s_max_i32 %[tn], %[tn], %[y]\n\t"                                                    \
-            "s_add_i32 %[s31], %[s31], 1\n\t"                                                     \
-            "s_cmp_lg_u32 %[tn], %[t]\n\t"                                                        \
-            "s_mov_b32 %[t], %[tn]\n\t"                                                           \
-            "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
-            "s_lshl1_add_u32 %[mreg], %[mreg], 1\n\t"                                             \
+        const int mn = m < n ? m : n;
+        int vm1;                                       // DPP forms take no constant operand
+        asm volatile("v_mov_b32 %0, -1" : "=v"(vm1));
+        // One anti-diagonal, hand-scheduled: 11-12 vector instructions, no s_nop (scalar instructions fill the wait states:
+        // v_cmp -> v_cndmask needs 2, a VALU write -> DPP read of the same register needs 2).
+        //   steering : two v_readlane; move = prev[63] >= prev[0] (odd s) / > (even s)
+        //              general step: tn = max(min(t + move, min(m,s) - 31), max(0,s-n) - 32) on the scalar unit;
+        //              fast step (s <= min(m,n): neither clamp can bind): tn = t + move
+        //   down     : centre bases slide one lane down (wave_shl), lanes 60..63 refilled from the rotating window `ach`
+        //              (wave_rol, row/bank-masked); left = shl(prev) - 1 lands in pp (next step's diagonal operand)
+        //   right    : same with the row bases / wave_shr / `bch`; diagonal = shr(pp) folded into the add
+#define ARM_DOWN(TAIL)                                                                            \
             "v_mov_b32_dpp %[areg], %[areg] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"            \
             "v_mov_b32_dpp %[areg], %[ach] wave_rol:1 row_mask:0x8 bank_mask:0x8\n\t"             \
             "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
             "v_mov_b32_dpp %[ach], %[ach] wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"              \
-            "v_addc_co_u32 %[dd], %[jk], %[dd], %[dd], %[e]\n\t"                                  \
-            "v_cndmask_b32_e64 %[tsc], 6, 10, vcc\n\t"                                            \
+            "s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t"                                             \
+            "v_cndmask_b32_e64 %[tsc], 26, 42, vcc\n\t"                                           \
             "v_add_u32 %[tcd], %[pp], %[tsc]\n\t"                                                 \
-            "v_mov_b32_dpp %[pp], %[prev] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-            "v_cmp_ge_i32 vcc, %[prev], %[pp]\n\t"                                                \
-            "v_max3_i32 %[prev], %[tcd], %[prev], %[pp]\n\t"                                      \
-            "v_cmp_eq_u32 %[e], %[tcd], %[prev]\n\t"                                              \
-            "v_addc_co_u32 %[du], %[jk], %[du], %[du], vcc\n\t"                                   \
-            "s_branch J" L "_%=\n"                                                                \
-            "R" L "_%=:\n\t"                                                                      \
-            "s_lshl_b32 %[mreg], %[mreg], 1\n\t"                                                  \
+            "v_add_u32_dpp %[pp], %[prev], %[vm1] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            "v_max3_i32 %[tv], %[tcd], %[prev], %[pp]\n\t"                                        \
+            "v_and_or_b32 %[prev], %[tv], -4, 1\n\t"                                              \
+            "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"                                           \
+            TAIL
+#define ARM_RIGHT(TAIL)                                                                           \
             "v_mov_b32_dpp %[breg], %[breg] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
             "v_mov_b32_dpp %[breg], %[bch] wave_ror:1 row_mask:0x1 bank_mask:0x1\n\t"             \
             "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
             "v_mov_b32_dpp %[bch], %[bch] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"              \
-            "v_addc_co_u32 %[dd], %[jk], %[dd], %[dd], %[e]\n\t"                                  \
-            "v_cndmask_b32_e64 %[tsc], 6, 10, vcc\n\t"                                            \
             "v_mov_b32_dpp %[thx], %[prev] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            "v_cndmask_b32_e64 %[tsc], 26, 42, vcc\n\t"                                           \
             "v_add_u32_dpp %[tcd], %[pp], %[tsc] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-            "v_cmp_ge_i32 vcc, %[thx], %[prev]\n\t"                                               \
-            "v_mov_b32 %[pp], %[prev]\n\t"                                                        \
-            "v_max3_i32 %[prev], %[tcd], %[thx], %[pp]\n\t"                                       \
-            "v_cmp_eq_u32 %[e], %[tcd], %[prev]\n\t"                                              \
-            "v_addc_co_u32 %[du], %[jk], %[du], %[du], vcc\n"                                     \
+            "v_add_u32 %[pp], -1, %[prev]\n\t"                                                    \
+            "v_max3_i32 %[tv], %[tcd], %[thx], %[pp]\n\t"                                         \
+            "v_and_or_b32 %[prev], %[tv], -4, 1\n\t"                                              \
+            "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"                                           \
+            TAIL
+#define STEP_GEN(CMP, L)                                                                          \
+            "v_readlane_b32 %[h0], %[prev], 0\n\t"                                                \
+            "v_readlane_b32 %[h63], %[prev], 63\n\t"                                              \
+            "s_add_i32 %[s31], %[s31], 1\n\t"                                                     \
+            "s_min_i32 %[x], %[m31], %[s31]\n\t"                                                  \
+            "s_sub_i32 %[y], %[s31], %[n1]\n\t"                                                   \
+            "s_max_i32 %[y], %[y], %[neg32]\n\t"                                                  \
+            CMP " %[h63], %[h0]\n\t"                                                              \
+            "s_addc_u32 %[tn], %[t], 0\n\t"                                                       \
+            "s_min_i32 %[tn], %[tn], %[x]\n\t"                                                    \
+            "s_max_i32 %[tn], %[tn], %[y]\n\t"                                                    \
+            "s_cmp_lg_u32 %[tn], %[t]\n\t"                                                        \
+            "s_mov_b32 %[t], %[tn]\n\t"                                                           \
+            "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
+            ARM_DOWN("s_branch J" L "_%=\n")                                                      \
+            "R" L "_%=:\n\t"                                                                      \
+            ARM_RIGHT("s_lshl_b32 %[mreg], %[mreg], 2\n")                                         \
+            "J" L "_%=:\n\t"
+#define STEP_FAST(CMP, L)                                                                         \
+            "v_readlane_b32 %[h0], %[prev], 0\n\t"                                                \
+            "v_readlane_b32 %[h63], %[prev], 63\n\t"                                              \
+            CMP " %[h63], %[h0]\n\t"                                                              \
+            "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
+            ARM_DOWN("s_add_i32 %[t], %[t], 1\n\ts_branch J" L "_%=\n")                           \
+            "R" L "_%=:\n\t"                                                                      \
+            ARM_RIGHT("s_lshl_b32 %[mreg], %[mreg], 2\n")                                         \
             "J" L "_%=:\n\t"
 #define STEP_OPERANDS                                                                                                      \
             : [prev] "+v"(prev), [pp] "+v"(pp), [areg] "+v"(areg), [breg] "+v"(breg), [ach] "+v"(ach), [bch] "+v"(bch),   \
-              [du] "+v"(du), [dd] "+v"(dd), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [t] "+s"(t),            \
-              [mreg] "+s"(mreg), [s31] "+s"(s31), [cnt] "+s"(cnt), [h0] "=&s"(h0), [h63] "=&s"(h63), [x] "=&s"(sx),       \
-              [y] "=&s"(sy), [tn] "=&s"(tn), [e] "+s"(epair), [jk] "=&s"(jpair)                                          \
-            : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32)                                                             \
+              [d2] "+v"(d2), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv), [t] "+s"(t),           \
+              [mreg] "+s"(mreg), [s31] "+s"(s31), [cnt] "+s"(cnt), [x] "=&s"(sx), [y] "=&s"(sy), [tn] "=&s"(tn),          \
+              [h0] "=&s"(h0), [h63] "=&s"(h63)                                                                             \
+            : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32), [vm1] "v"(vm1)                                             \
             : "vcc", "scc"
         for (int ch = 0; ch < nchunk; ch++) {
             const int s_lo = (ch << 4) + 1;
@@ -217,38 +230,53 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
                 const int rb = b[(unsigned)ib < (unsigned)n ? ib : 0];
                 bch = (unsigned)ib < (unsigned)n ? rb : 0xFE;
             }
-            int du = 0, dd = 0, tsc, tcd, thx;
-            int mreg = to_sgpr(0), h0, h63, sx, sy, tn;
-            unsigned long long epair = 0, jpair;   // epair: the "diagonal wins" mask of the last step, not yet added into dd
-            if (nst >= 2) {
-                int cnt = to_sgpr((nst >> 1) - 1);
-                asm volatile(
-                    "L_%=:\n\t"
-                    STEP_ASM("s_cmp_ge_i32", "a")
-                    STEP_ASM("s_cmp_gt_i32", "b")
-                    "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-                    "s_cbranch_scc0 L_%=\n\t"
-                    STEP_OPERANDS);
+            int d2 = 0, tsc, tcd, thx, tv;
+            int mreg = to_sgpr(0), sx, sy, tn, h0, h63;
+            int s31 = to_sgpr(s_lo - 32);              // (s - 31) of the step before the next one
+            if (s_lo + nst - 1 <= mn) {
+                if (nst >= 2) {
+                    int cnt = to_sgpr((nst >> 1) - 1);
+                    asm volatile(
+                        "L_%=:\n\t"
+                        STEP_FAST("s_cmp_ge_i32", "a")
+                        STEP_FAST("s_cmp_gt_i32", "b")
+                        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                        "s_cbranch_scc0 L_%=\n\t"
+                        STEP_OPERANDS);
+                }
+                if (nst & 1) {
+                    int cnt = 0;
+                    asm volatile(STEP_FAST("s_cmp_ge_i32", "c") STEP_OPERANDS);
+                }
+            } else {
+                if (nst >= 2) {
+                    int cnt = to_sgpr((nst >> 1) - 1);
+                    asm volatile(
+                        "L_%=:\n\t"
+                        STEP_GEN("s_cmp_ge_i32", "a")
+                        STEP_GEN("s_cmp_gt_i32", "b")
+                        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                        "s_cbranch_scc0 L_%=\n\t"
+                        STEP_OPERANDS);
+                }
+                if (nst & 1) {
+                    int cnt = 0;
+                    asm volatile(STEP_GEN("s_cmp_ge_i32", "c") STEP_OPERANDS);
+                }
             }
-            if (nst & 1) {
-                int cnt = 0;
-                asm volatile(
-                    STEP_ASM("s_cmp_ge_i32", "c")
-                    STEP_OPERANDS);
-            }
-            asm volatile("s_nop 1\n\tv_addc_co_u32 %[dd], %[jk], %[dd], %[dd], %[e]"
-                         : [dd] "+v"(dd), [jk] "=&s"(jpair) : [e] "s"(epair) : "vcc");
-            const int sh = 16 - nst;
-            // bit-reversed so that step r of the chunk sits at bit r (diagonal plane), 16 + r (up plane), r (moves)
-            tbd[ch * 64 + lane] = __brev(((unsigned)(dd << sh) << 16) | ((unsigned)(du << sh) & 0xffffu));
-            if (lane == 0) tbm[ch] = __brev(((unsigned)mreg << sh) & 0xffffu) >> 16;
+            // two bits per step, step r of the chunk at bits 2r+1 : 2r (directions), the move at bit 30 - 2r
+            tbd[ch * 64 + lane] = (unsigned)d2 >> (2 * (16 - nst));
+            if (lane == 0) tbm[ch] = (unsigned)mreg << (2 * (16 - nst));
         }
-#undef STEP_ASM
+#undef STEP_GEN
+#undef STEP_FAST
+#undef ARM_DOWN
+#undef ARM_RIGHT
 #undef STEP_OPERANDS
         {
             const int kf = m - t;
             const int hf = (kf >= 0 && kf < 64) ? __builtin_amdgcn_readlane(prev, kf & 63) : 0;
-            if (hf <= MBIAS / 2) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
+            if (hf <= (MBIAS / 2) * 4) { if (lane == 0) atomicExch(&P.status[c], 1); continue; }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -266,66 +294,63 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         while (ip >= 0 && jp >= 0) {
             const int sp = ip + jp + 1;   // chunk / bit index of anti-diagonal i + j
             const int dch = sp >> 4;
-            int r = to_sgpr(sp & 15);
-            const unsigned wcur = tbd[dch * 64 + lane];   // bit r: diagonal wins at step r of the chunk; bit 16 + r: up >= left
+            int q = to_sgpr(((sp & 15) << 1) + 1);        // 2 x (step inside the chunk) + 1
+            const unsigned wcur = tbd[dch * 64 + lane];   // step r: bit 2r+1 diagonal wins, else bit 2r up, else left
             const unsigned mc = tbm[dch], mp = dch > 0 ? tbm[dch - 1] : 0u;
-            // bit r + 1: move of step r, bit 0: last move of the chunk below
-            const int mm = to_sgpr((int)((mc << 1) | ((mp >> 15) & 1u)));
+            const int mma = to_sgpr((int)__brev(mc));                                  // bit 2r+1: move of step r
+            const int mmb = to_sgpr((int)((__brev(mc) << 2) | ((mp & 1u) << 1)));      // bit 2r+1: move of step r-1
             bad |= (unsigned)k > 63u;
             const int ip0 = ip;
-            int sw, sx, sy;
+            int sw, sx;
             asm volatile(
                 "s_mov_b32 m0, %[ip]\n"
                 "L_%=:\n\t"
                 "v_readlane_b32 %[w], %[wcur], %[k]\n\t"
-                "s_lshr_b32 %[y], %[mm], %[r]\n\t"
-                "s_lshr_b32 %[x], %[w], %[r]\n\t"
-                "s_bitcmp1_b32 %[x], 0\n\t"
+                "s_bitcmp1_b32 %[w], %[q]\n\t"
                 "s_cbranch_scc0 N_%=\n\t"
-                /* diagonal: centre position i-1 <-> row position j-1 */
+                /* diagonal: centre position i-1 <-> row position j-1;  k += move(s) + move(s-1) - 1 */
                 "v_writelane_b32 %[oreg], %[jp], m0\n\t"
-                "s_and_b32 %[y], %[y], 3\n\t"
-                "s_bcnt1_i32_b32 %[y], %[y]\n\t"
-                "s_add_i32 %[k], %[k], %[y]\n\t"
-                "s_addk_i32 %[k], -1\n\t"
+                "s_bitcmp0_b32 %[mma], %[q]\n\t"
+                "s_subb_u32 %[k], %[k], 0\n\t"
+                "s_bitcmp1_b32 %[mmb], %[q]\n\t"
+                "s_addc_u32 %[k], %[k], 0\n\t"
                 "s_sub_i32 m0, m0, 1\n\t"
                 "s_sub_i32 %[jp], %[jp], 1\n\t"
-                "s_sub_i32 %[r], %[r], 2\n\t"
+                "s_sub_i32 %[q], %[q], 4\n\t"
                 "s_or_b32 %[x], %[jp], m0\n\t"
-                "s_or_b32 %[x], %[x], %[r]\n\t"
+                "s_or_b32 %[x], %[x], %[q]\n\t"
                 "s_cmp_lt_i32 %[x], 0\n\t"
                 "s_cbranch_scc0 L_%=\n\t"
                 "s_branch E_%=\n"
                 "N_%=:\n\t"
-                "s_bitcmp1_b32 %[x], 16\n\t"
+                "s_lshl_b32 %[w], %[w], 1\n\t"
+                "s_bitcmp1_b32 %[w], %[q]\n\t"
                 "s_cbranch_scc0 F_%=\n\t"
-                /* up: centre position i-1 faces a gap before row position j */
+                /* up: centre position i-1 faces a gap before row position j;  k += move(s) - 1 */
                 "s_add_i32 %[x], %[jp], 0x8001\n\t"
                 "v_writelane_b32 %[oreg], %[x], m0\n\t"
-                "s_bfe_u32 %[y], %[y], 0x10001\n\t"
-                "s_add_i32 %[k], %[k], %[y]\n\t"
-                "s_addk_i32 %[k], -1\n\t"
+                "s_bitcmp0_b32 %[mma], %[q]\n\t"
+                "s_subb_u32 %[k], %[k], 0\n\t"
                 "s_sub_i32 m0, m0, 1\n\t"
-                "s_sub_i32 %[r], %[r], 1\n\t"
+                "s_sub_i32 %[q], %[q], 2\n\t"
                 "s_or_b32 %[x], %[jp], m0\n\t"
-                "s_or_b32 %[x], %[x], %[r]\n\t"
+                "s_or_b32 %[x], %[x], %[q]\n\t"
                 "s_cmp_lt_i32 %[x], 0\n\t"
                 "s_cbranch_scc0 L_%=\n\t"
                 "s_branch E_%=\n"
                 "F_%=:\n\t"
-                /* left: a row base inserted */
-                "s_bfe_u32 %[y], %[y], 0x10001\n\t"
-                "s_add_i32 %[k], %[k], %[y]\n\t"
+                /* left: a row base inserted;  k += move(s) */
+                "s_bitcmp1_b32 %[mma], %[q]\n\t"
+                "s_addc_u32 %[k], %[k], 0\n\t"
                 "s_sub_i32 %[jp], %[jp], 1\n\t"
-                "s_sub_i32 %[r], %[r], 1\n\t"
-                "s_or_b32 %[x], %[jp], %[r]\n\t"
+                "s_sub_i32 %[q], %[q], 2\n\t"
+                "s_or_b32 %[x], %[jp], %[q]\n\t"
                 "s_cmp_lt_i32 %[x], 0\n\t"
                 "s_cbranch_scc0 L_%=\n"
                 "E_%=:\n\t"
                 "s_mov_b32 %[ip], m0"
-                : [ip] "+s"(ip), [jp] "+s"(jp), [k] "+s"(k), [r] "+s"(r), [oreg] "+v"(oreg), [w] "=&s"(sw), [x] "=&s"(sx),
-                  [y] "=&s"(sy)
-                : [wcur] "v"(wcur), [mm] "s"(mm)
+                : [ip] "+s"(ip), [jp] "+s"(jp), [k] "+s"(k), [q] "+s"(q), [oreg] "+v"(oreg), [w] "=&s"(sw), [x] "=&s"(sx)
+                : [wcur] "v"(wcur), [mma] "s"(mma), [mmb] "s"(mmb)
                 : "scc");
             // positions (ip, ip0] were produced by this chunk: lane l holds the one with p mod 64 == l
             const int pl = ip0 - ((ip0 - lane) & 63);

@@ -18,10 +18,13 @@
  *   every lane of the band evaluates the same recurrence every step: bases outside the sequences
  *   are sentinels that never match (so cells outside the matrix only ever hold "junk" that
  *   cannot beat a real score), values shifted in from outside the band are 0 and real scores
- *   are biased by 2^28 (H(0,0) = 2^28); an 'N' in the centre never matches.  H is STORED shifted
- *   by +4 per anti-diagonal, i.e. the recurrence adds +10 / +6 / 0 for match / mismatch / gap
- *   (identical comparisons for every cell derived from H(0,0); the 0 that enters at the band
- *   edges is not shifted, which is part of this definition).  The alignment
+ *   are biased by 2^28 (H(0,0) = 2^28); an 'N' in the centre never matches.
+ *   Stored form (part of the definition, it fixes what the junk cells hold): H is shifted by +4
+ *   per anti-diagonal (the recurrence adds +10 / +6 / 0 for match / mismatch / gap), scaled by 4,
+ *   and the low two bits carry the winning operand: V = 4 H + tag, candidates
+ *   diag = D + 4*score + 2, up = U (stored with tag 1), left = L - 1 (tag 0), V = max of the
+ *   three (so ties go diag >= up >= left), direction = V & 3, and (V & ~3) | 1 is stored.  The 0
+ *   that enters at a band edge is not transformed (left operand: 0 - 1).  The alignment
  *   fails if H(m,n) <= 2^27 (end cell not reachable inside the band).
  *   The diagonal operand is carried in ONE history register H(s-2)' = H(s-2) re-aligned to the
  *   origin of anti-diagonal s-1, which is simply the previous step's "left" operand; an element
@@ -41,10 +44,9 @@
 #define ORC_ECAP (-1001)
 #define W 64
 #define BIAS (1 << 28)
-/* stored scores are shifted by +4 per anti-diagonal: (match, mismatch, gap) = (+2, -2, -4) + (8, 8, 4) */
-#define SC_MATCH 10
-#define SC_MIS 6
-#define SC_GAP 0
+/* stored scores: shifted by +4 per anti-diagonal ((+2, -2, -4) + (8, 8, 4) = 10, 6, 0), times 4, + tag 2 */
+#define SC_MATCH 42
+#define SC_MIS 26
 
 /* align row b[0..n) to centre a[0..m); ops[p] (p = 0..m): low 15 bits = insertions before p,
  * bit 15 = row has a gap at centre position p.  returns 0 or <0. */
@@ -58,7 +60,7 @@ static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t
     int t = -32;
     int ppal[W]; /* H(s-2) re-aligned to the origin of anti-diagonal s-1 (see header) */
     for (int k = 0; k < W; k++) { prev[k] = 0; ppal[k] = 0; }
-    prev[32] = BIAS; /* H(0,0) */
+    prev[32] = (BIAS << 2) | 1; /* H(0,0), stored form */
     ts[0] = t;
     for (int s = 1; s <= steps; s++) {
         /* choose the move from anti-diagonal s-1 (held in prev, origin t) */
@@ -75,18 +77,17 @@ static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t
             int i = tn + k, j = s - i;
             /* down : (left, up, diag) = (H(s-1)[k+1], H(s-1)[k],   H(s-2)'[k])
              * right: (left, up, diag) = (H(s-1)[k],   H(s-1)[k-1], H(s-2)'[k-1])   0 from outside the band */
-            int hl = down ? (k + 1 < W ? prev[k + 1] : 0) : prev[k];
+            int hl = (down ? (k + 1 < W ? prev[k + 1] : 0) : prev[k]) - 1;
             int hu = down ? prev[k] : (k >= 1 ? prev[k - 1] : 0);
             int hd = down ? ppal[k] : (k >= 1 ? ppal[k - 1] : 0);
             int x = (i >= 1 && i <= m) ? a[i - 1] : 0xFF;
             int y = (j >= 1 && j <= n) ? b[j - 1] : 0xFE;
             if (x == 'N') x = 0xFD;
             int cd = hd + (x == y ? SC_MATCH : SC_MIS);
-            int cu = hu + SC_GAP, cl = hl + SC_GAP;
-            int v, d;
-            if (cd >= cu && cd >= cl) { v = cd; d = 0; }
-            else if (cu >= cl) { v = cu; d = 1; }
-            else { v = cl; d = 2; }
+            int v4 = cd > hu ? cd : hu, v, d;
+            if (hl > v4) v4 = hl;
+            d = (v4 & 2) ? 0 : ((v4 & 1) ? 1 : 2);   /* junk cells may carry any tag; they are never on the path */
+            v = (v4 & ~3) | 1;
             cur[k] = v;
             hlv[k] = hl;
             dir[(size_t)s * W + k] = (uint8_t)d;
@@ -98,7 +99,7 @@ static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t
     }
     {
         int kf = m - t;
-        if (kf < 0 || kf >= W || prev[kf] <= BIAS / 2) { free(dir); free(ts); return ORC_EINVAL; }
+        if (kf < 0 || kf >= W || prev[kf] <= (BIAS / 2) * 4) { free(dir); free(ts); return ORC_EINVAL; }
     }
     /* traceback */
     int i = m, j = n, cur_ins = 0, pend_gap = 0;
