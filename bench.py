@@ -192,11 +192,17 @@ def main():
                                          "copy finding by minimizer-index lookup inside the timed step; index build %.1f s untimed" % index_s
                                          if args.copies == "found" else "copy table = generator truth; copy finding not in the timed path"),
                        "genome_bp": G, "candidates_per_gpu": n_cand, "candidate_bases": cand_bytes, "copies": int(found["n"]), "copy_table": args.copies, "rows_aligned_per_step": rows,
+                       "pipeline_stats": [int(x) for x in stats], "copy_stats": list(ctx.copy_stats()) if args.copies == "found" else None,
                        "is_te": n_te, "parallelism": "replicated genome, candidates sharded x%d, all-gather of 32-B calls" % world,
                        "setup_s": round(setup_s, 1)},
             "roofline": roof,
             "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kern.items())},
         }
+        if hasattr(ctx.lib, "hite_debug_judge_clocks"):   # only in a -DJUDGE_CLOCKS development build
+            import ctypes
+            buf = (ctypes.c_ulonglong * 16)()
+            ctx.lib.hite_debug_judge_clocks(buf, 1)
+            out["judge_phase_ticks"] = [int(x) for x in buf[:6]]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         if args.verify > 0:

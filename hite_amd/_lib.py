@@ -364,6 +364,12 @@ class Context:
         self._check(rc, "hite_find_copies_dev")
         return (n.value,) + tuple(o.value or 0 for o in outs)
 
+    def copy_stats(self):
+        """sizes of the last find_copies call: (candidate minimizers, index hits, diagonal clusters, copies before the cap)"""
+        out = (C.c_int64 * 4)()
+        self._check(self.lib.hite_copy_stats(self._copy_state, out), "hite_copy_stats")
+        return tuple(int(x) for x in out)
+
     def download(self, d_ptr, count, dtype):
         """numpy copy of `count` elements of `dtype` at raw device pointer d_ptr"""
         out = np.zeros(int(count), dtype=dtype)

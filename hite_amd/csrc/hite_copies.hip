@@ -34,6 +34,7 @@ struct CopyState {
     Arena arena;
     int64_t *h_pin = nullptr;
     int64_t *d_scal = nullptr;
+    int64_t last[4] = {0, 0, 0, 0};   // last call: candidate minimizers, hits, clusters, copies (before the 300 cap)
 };
 
 __device__ __forceinline__ unsigned lowbias32(unsigned x) {
@@ -485,6 +486,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
         CCHK(read_back(ctx, S, st, 1));
         nq = S->h_pin[0];
         if ((unsigned long long)nq > qcap) return HITE_ECAP;
+        S->last[0] = nq; S->last[1] = S->last[2] = S->last[3] = 0;
         hipLaunchKernelGGL(cand_minimizer_kernel<true>, dim3(wblocks), dim3(64), 0, st, n_cand, d_cand, d_cand_off, q_c, q_pos, q_hs,
                            q_cnt, (const int64_t *)q_first);
         hite_prof_end(ctx, tk_cm, st);
@@ -501,6 +503,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, hit_off + nq, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
     const int64_t nh = S->h_pin[0];
+    S->last[1] = nh;
     if (nh == 0) return HITE_OK;
     if (nh >= 0xffffffffll) return HITE_ECAP;
     CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 8, &p)); hkey = (unsigned long long *)p;
@@ -526,6 +529,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cid + nh, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
     const int64_t ncl = S->h_pin[0];
+    S->last[2] = ncl;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); c_lo = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); c_hi = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); c_cnt = (int32_t *)p;
@@ -564,6 +568,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(read_back(ctx, S, st, 2));
     const int64_t ncp = S->h_pin[0], nout = S->h_pin[1];
     *n_copies = nout;
+    S->last[3] = ncp;
     hipLaunchKernelGGL(i64_to_i32_kernel, CGRID((int64_t)n_cand + 1), 0, st, (int64_t)n_cand + 1, ofirst, ofirst32);
     if (ncp == 0) return HITE_OK;
     Sorter so2;
@@ -623,4 +628,12 @@ extern "C" int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, 
     }
     (void)hipFree(dc); (void)hipFree(dco);
     return rc;
+}
+
+// sizes of the last hite_find_copies[_dev] call on this index: {candidate minimizers, index hits, diagonal clusters, copies before the cap}
+extern "C" int hite_copy_stats(void *state, int64_t out[4]) {
+    CopyState *S = (CopyState *)state;
+    if (!S || !out) return HITE_EINVAL;
+    for (int i = 0; i < 4; i++) out[i] = S->last[i];
+    return HITE_OK;
 }

@@ -24,6 +24,7 @@
 #define MAXSEL 128      // capacity of the selected-row list (the reference keeps <= 101)
 #define CS 12           // bytes of column statistics per column: cnt[6], first[6]
 #define SCR_PER_COL 32  // scratch bytes per column per block slot
+#define TILE_COLS 160   // widest column span staged in LDS for the window scans (wider spans read the alignment directly)
 
 struct JShared {
     int scan[8];
@@ -39,6 +40,7 @@ struct JShared {
     int flagged[64];
     int tsd[25];
     int fo[5], eo[5];
+    uint8_t tile[TILE_COLS * MAXSEL];   // symbol classes of the selected rows over the column span of the current scan
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -300,6 +302,40 @@ __device__ int wave_window_homology(const uint8_t *__restrict__ msa, int C, cons
     return avg >= thr ? first_cand : -1;
 }
 
+// the same window evaluated on the LDS tile (column-major: tile[(c - lo) * MAXSEL + rank]); identical arithmetic
+__device__ int wave_window_homology_tile(const uint8_t *tile, int lo, int rn, int first, int n, int step, double thr) {
+    const int lane = lane_id();
+    const bool h0 = lane < rn, h1 = lane + 64 < rn;
+    const uint8_t *t0 = tile + lane, *t1 = tile + lane + 64;
+    int g0 = 0, g1 = 0;
+    for (int i = 0, c = first - lo; i < n; i++, c += step) {
+        if (h0) g0 += t0[c * MAXSEL] == 5;
+        if (h1) g1 += t1[c * MAXSEL] == 5;
+    }
+    const bool v0 = h0 && 2 * g0 <= n;
+    const bool v1 = h1 && 2 * g1 <= n;
+    const int nv = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
+    if (nv < 2) return -1;
+    double total = 0.0;
+    const double lim = thr - 0.1;
+    int first_cand = -1;
+    for (int i = 0, c = first - lo; i < n; i++, c += step) {
+        const int k0 = v0 ? t0[c * MAXSEL] : 7;
+        const int k1 = v1 ? t1[c * MAXSEL] : 7;
+        int best = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int cnt = __popcll(__ballot(k0 == k)) + __popcll(__ballot(k1 == k));
+            best = cnt > best ? cnt : best;
+        }
+        double ratio = best ? (double)best / (double)nv : 0.0;
+        if (ratio >= lim && first_cand == -1) first_cand = c + lo;
+        total += ratio;
+    }
+    double avg = total / (double)n;
+    return avg >= thr ? first_cand : -1;
+}
+
 // collect up to 100 valid columns into S.cols; mode as in the oracle's scan_valid
 __device__ int blk_scan_valid(const uint8_t *__restrict__ cstat, int C, int vthr, int from, int dir, int mode,
                               JShared &S) {
@@ -341,13 +377,28 @@ __device__ int blk_first_window(const uint8_t *__restrict__ msa, int C, const ui
     int nwin = n - ws + 1;
     int w = wave_id();
     int found = -1;
+    // every window is a contiguous column range inside [lo, hi]: stage that span once (rows = selected rows)
+    const int e0 = S.cols[0], e1 = S.cols[n - 1];   // the list is monotonic (either direction)
+    const int lo = e0 < e1 ? e0 : e1, hi = e0 < e1 ? e1 : e0;
+    const int span = hi - lo + 1;
+    const bool tiled = span <= TILE_COLS && rn <= MAXSEL;
+    if (tiled) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < rn * span; idx += JB) {
+            const int r = idx / span, c = idx - r * span;
+            S.tile[c * MAXSEL + r] = (uint8_t)sym_class(msa[(size_t)sel[r] * C + lo + c]);
+        }
+        __syncthreads();
+    }
     for (int base = 0; base < nwin; base += 4) {
         int i = base + w;
         int r = -1;
         if (i < nwin) {
             int a = rev_list ? S.cols[n - 1 - i] : S.cols[i];
             int b = rev_list ? S.cols[n - 1 - (i + ws - 1)] : S.cols[i + ws - 1];
-            if (!desc) r = wave_window_homology(msa, C, sel, rn, a, b - a + 1, +1, thr);
+            if (tiled) r = !desc ? wave_window_homology_tile(S.tile, lo, rn, a, b - a + 1, +1, thr)
+                                 : wave_window_homology_tile(S.tile, lo, rn, a, a - b - 1, -1, thr);
+            else if (!desc) r = wave_window_homology(msa, C, sel, rn, a, b - a + 1, +1, thr);
             else r = wave_window_homology(msa, C, sel, rn, a, a - b - 1, -1, thr);
         }
         __syncthreads();
@@ -661,8 +712,24 @@ __device__ void judge_v9_tail(const JudgeParams &P, const uint8_t *msa, int R, i
 __device__ void judge_v6_body(const JudgeParams &P, const uint8_t *msa, int R, int C, int astart, int aend,
                               uint8_t *cstat, uint8_t *model, hite_call &out, JShared &S);
 
-__global__ void __launch_bounds__(JB) judge_kernel(JudgeParams P) {
+#ifdef JUDGE_CLOCKS
+// development aid (-DJUDGE_CLOCKS): wall-clock ticks per phase, summed over blocks by thread 0
+__device__ unsigned long long g_jclk[16];
+#define JCLK(i) do { if (threadIdx.x == 0) { unsigned long long now_ = wall_clock64(); atomicAdd(&g_jclk[i], now_ - jt_); jt_ = now_; } } while (0)
+extern "C" int hite_debug_judge_clocks(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jclk), sizeof(g_jclk)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jclk), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define JCLK(i) do { } while (0)
+#endif
+
+__global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 8))) judge_kernel(JudgeParams P) {
     __shared__ JShared S;
+#ifdef JUDGE_CLOCKS
+    unsigned long long jt_ = wall_clock64();
+#endif
     uint8_t *slot = P.scratch + (size_t)blockIdx.x * P.slot_bytes;
     for (;;) {
         __syncthreads();
@@ -733,17 +800,21 @@ __global__ void __launch_bounds__(JB) judge_kernel(JudgeParams P) {
             }
             if (astart == -1 || aend == -1) { call.info = HITE_INFO_NB; done = true; }
         }
+        JCLK(0);   // anchors
         if (!done && P.te_type != HITE_TE_HELITRON) {
             int rn = blk_select_rows(msa, R, C, astart, aend, 10, true, true, S.sel, S);
+            JCLK(1);   // select rows
             if (rn == 0) { call.info = HITE_INFO_EXC; done = true; }
             else if (rn <= 1) { call.info = HITE_INFO_FL1; call.row_num = (P.te_type == HITE_TE_TIR) ? 1 : rn; done = true; }
             if (!done) {
                 call.row_num = rn;
                 blk_colstats(msa, C, S.sel, rn, cstat);
+                JCLK(2);   // column statistics
                 double thr = homo_thr(rn, P.te_type == HITE_TE_TIR ? 0.7 : 0.8);
                 int hs = blk_search_v3(msa, cstat, C, S.sel, rn, astart, 0, thr, 20, 10, S);
                 int he = -1;
                 if (hs != -1) he = blk_search_v3(msa, cstat, C, S.sel, rn, aend, 1, thr, 20, 10, S);
+                JCLK(3);   // boundary search
                 if (hs != -1 && he != -1) {
                     if (P.te_type == HITE_TE_TIR) {
                         judge_tir_tail(P, msa, R, C, cstat, rn, hs, he, model, cons_base, call, S);
@@ -757,6 +828,7 @@ __global__ void __launch_bounds__(JB) judge_kernel(JudgeParams P) {
             judge_v6_body(P, msa, R, C, astart, aend, cstat, model, call, S);
         }
         __syncthreads();
+        JCLK(4);   // tail
         if (threadIdx.x == 0) P.calls[ci] = call;
     }
 }

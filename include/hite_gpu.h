@@ -167,6 +167,9 @@ int hite_tsd_kmer_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_seqs, const int
  * _dev: the returned device arrays live in the index state's arena until the next call. */
 int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream);
 void hite_copy_index_release(void *state);
+/* sizes of the last hite_find_copies[_dev] call on this index (diagnostics / roofline accounting):
+ * out = {candidate minimizers, index hits, diagonal clusters, copies before the 300-per-candidate cap} */
+int hite_copy_stats(void *state, int64_t out[4]);
 int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
                      int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
                      int32_t *anchors, int64_t *n_out);
