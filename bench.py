@@ -146,8 +146,7 @@ def main():
             "star_align_kernel": float(stats[3] + stats[7]),
             "row_gather_kernel": float((stats[1] + stats[5]) * (1 + 0.375)),
             "star_layout_kernel": float(2 * 0.5 * (stats[3] + stats[7]) / 3.0),
-            "star_fill_kernel": float((stats[1] + stats[5]) + (stats[2] + stats[6])),
-            "sparse_cols_kernel": float(2 * (stats[2] + stats[6])),
+            "star_fill_sparse_kernel": float((stats[1] + stats[5]) + (stats[2] + stats[6])),
             "judge_kernel": float((stats[2] + stats[6]) * (1 + 13.0 / 32.0)),
             "select_rows_kernel": float(8 * n_copies + 4 * rows),
         }

@@ -207,9 +207,11 @@ class Context:
         return [(lo[i, :max(ln[i], 0)].tobytes().decode(), ro[i, :max(ln[i], 0)].tobytes().decode(), int(ln[i])) for i in range(n)]
 
     # ---- star alignment (stage where the reference calls mafft) -------------------------------
-    def star_msa(self, groups):
+    def star_msa(self, groups, sparse=False):
         """groups: list of lists of windows (bytes/str), first window of each group = centre.
-        -> list of 2-D uint8 alignments (None where the alignment failed)."""
+        -> list of 2-D uint8 alignments (None where the alignment failed).
+        sparse=True: the fused path, sparse columns (remove_sparse_col_in_align_file) already removed."""
+        fn = self.lib.hite_star_msa_sparse if sparse else self.lib.hite_star_msa
         flat = [w.encode() if isinstance(w, str) else bytes(w) for g in groups for w in g]
         n = len(groups)
         row_first = np.zeros(n + 1, dtype=np.int32)
@@ -218,14 +220,12 @@ class Context:
         np.cumsum([len(w) for w in flat], out=off[1:])
         buf = np.frombuffer(b"".join(flat) + b"\0" * 16, dtype=np.uint8)
         cols = np.zeros(n, dtype=np.int32)
-        self._check(self.lib.hite_star_msa(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), C.c_int64(0), None, None),
-                    "hite_star_msa(sizes)")
+        self._check(fn(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), C.c_int64(0), None, None), "hite_star_msa(sizes)")
         rows = np.diff(row_first).astype(np.int64)
         cap = int(((rows * cols + 15) // 16 * 16).sum()) + 16
         out = np.zeros(cap, dtype=np.uint8)
         moff = np.zeros(n, dtype=np.int64)
-        self._check(self.lib.hite_star_msa(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), C.c_int64(cap), _p(out), _p(moff)),
-                    "hite_star_msa(fill)")
+        self._check(fn(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), C.c_int64(cap), _p(out), _p(moff)), "hite_star_msa(fill)")
         res = []
         for i in range(n):
             if cols[i] <= 0:

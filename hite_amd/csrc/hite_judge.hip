@@ -725,7 +725,7 @@ extern "C" int hite_debug_judge_clocks(unsigned long long *out, int reset) {
 #define JCLK(i) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(4, 8))) judge_kernel(JudgeParams P) {
+__global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(5, 8))) judge_kernel(JudgeParams P) {
     __shared__ JShared S;
 #ifdef JUDGE_CLOCKS
     unsigned long long jt_ = wall_clock64();

@@ -453,12 +453,139 @@ __global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// fused column layout + remove_sparse_col_in_align_file (Util.py:10344-10405) for the fine-stage pipeline: the full
+// alignment is never materialised.  Column c of the full alignment is kept iff c == 0 or c == C-1 or gaps(c) <= R/2:
+//   * centre column p: gaps = rows whose op carries the gap flag;
+//   * column j of the insertion block before p: a base in every row with ins_r > j, a gap elsewhere (centre included),
+//     so the kept columns of a block are a PREFIX of length kw = the ceil(R/2)-th largest ins_r;
+//   * the first / last column of the alignment are kept regardless (the last one may be a non-prefix column of block m).
+// Per position p: ops row-0 slot = kw | keep_centre << 15, extra slot = first kept column of the block.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, int32_t *__restrict__ new_cols,
+                                                                 int32_t *__restrict__ last_extra) {
+    __shared__ int s_scan[8];
+    __shared__ int s_mxm;
+    const int c = blockIdx.x;
+    if (c >= P.n) return;
+    const int64_t g0 = P.row_first[c];
+    const int R = P.row_first[c + 1] - P.row_first[c];
+    if (R <= 0 || P.status[c]) { if (threadIdx.x == 0) { P.cols_out[c] = 0; new_cols[c] = 0; last_extra[c] = -1; } return; }
+    const int m = P.win_len[g0];
+    uint16_t *ops = P.ops + P.ops_base[c];
+    uint16_t *kwslot = ops;                              // centre row slot
+    uint16_t *nstart = ops + (int64_t)R * (m + 1);       // extra slot
+    const int h = (R + 1) >> 1;                          // fewest rows with a base for a column to survive
+    if (threadIdx.x == 0) s_mxm = 0;
+    __syncthreads();
+    {   // widest insertion after the last centre position: decides which column is the last one
+        int mxm = 0;
+        for (int r = 1 + threadIdx.x; r < R; r += 256) { int v = row_ins(ops + (int64_t)r * (m + 1), m, m, P.win_len[g0 + r]); mxm = v > mxm ? v : mxm; }
+        if (mxm > 0) atomicMax(&s_mxm, mxm);
+    }
+    __syncthreads();
+    const int mxm = s_mxm;
+    int run_new = 0, run_full = 0, extra = -1;
+    for (int base = 0; base <= m; base += 256) {
+        const int p = base + threadIdx.x;
+        int mx = 0, npos = 0, gapc = 0;
+        if (p <= m) {
+            for (int r = 1; r < R; r++) {
+                const uint16_t *rop = ops + (int64_t)r * (m + 1);
+                const int v = row_ins(rop, p, m, P.win_len[g0 + r]);
+                mx = v > mx ? v : mx;
+                npos += v > 0;
+                if (p < m) gapc += rop[p] >> 15;
+            }
+        }
+        int kw = 0;
+        if (npos >= h) {
+            kw = 1;
+            for (;;) {
+                int cnt = 0;
+                for (int r = 1; r < R; r++) cnt += row_ins(ops + (int64_t)r * (m + 1), p, m, P.win_len[g0 + r]) > kw;
+                if (cnt >= h) kw++; else break;
+            }
+        }
+        int keepc = (p < m && 2 * gapc <= R) ? 1 : 0;
+        int ex = 0;
+        if (p == 0) { if (mx > 0) kw = kw > 1 ? kw : 1; else if (m > 0) keepc = 1; }     // first column
+        if (p == m - 1 && mxm == 0) keepc = 1;                                            // last column = centre column m-1
+        if (p == m && mx > 0 && kw < mx) { ex = 1; extra = mx - 1; }                       // last column = block m, j = mx-1
+        if (kw > 0x7fff) kw = 0x7fff;
+        const int wnew = p <= m ? kw + keepc + ex : 0;
+        const int wfull = p <= m ? mx + (p < m ? 1 : 0) : 0;
+        int tot_new, tot_full;
+        const int pre = block_excl_scan(wnew, s_scan, &tot_new);
+        __syncthreads();
+        (void)block_excl_scan(wfull, s_scan, &tot_full);
+        if (p <= m) {
+            const int bs = run_new + pre;
+            kwslot[p] = (uint16_t)(kw | (keepc << 15));
+            nstart[p] = (uint16_t)(bs > 65535 ? 65535 : bs);
+        }
+        run_new += tot_new; run_full += tot_full;
+        __syncthreads();
+    }
+    if (threadIdx.x == (m & 255)) last_extra[c] = extra;   // the thread that owned p == m
+    if (threadIdx.x == 0) {
+        if (run_full > 65535) { P.status[c] = 1; P.cols_out[c] = 0; new_cols[c] = 0; }
+        else { P.cols_out[c] = run_full; new_cols[c] = run_new; }
+    }
+}
+
+struct FillSparseParams {
+    FillParams F;              // cols = kept columns per candidate, msa = compacted output
+    const int32_t *last_extra;
+};
+
+// fill of the kept columns only: item (r, p) owns the kept prefix of insertion block p, the centre column p if kept
+// and (p == m) the extra last column; every output byte is written exactly once.
+__global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams Q) {
+    const FillParams &P = Q.F;
+    const int c = blockIdx.x;
+    if (c >= P.n) return;
+    const int C = P.cols[c];
+    if (C <= 0) return;
+    const int64_t g0 = P.row_first[c];
+    const int R = P.row_first[c + 1] - P.row_first[c];
+    const int m = P.win_len[g0];
+    const uint16_t *ops = P.ops + P.ops_base[c];
+    const uint16_t *kwslot = ops;
+    const uint16_t *nstart = ops + (int64_t)R * (m + 1);
+    const int le = Q.last_extra[c];
+    uint8_t *out = P.msa + P.msa_off[c];
+    for (int r = blockIdx.y; r < R; r += gridDim.y) {
+        const uint8_t *b = P.win + P.win_off[g0 + r];
+        const int nrow = P.win_len[g0 + r];
+        uint8_t *row = out + (int64_t)r * C;
+        const uint16_t *rop = ops + (int64_t)r * (m + 1);
+        for (int p = threadIdx.x; p <= m; p += 256) {
+            const unsigned ks = kwslot[p];
+            const int kw = (int)(ks & 0x7fff), kc = (int)(ks >> 15);
+            const bool ex = p == m && le >= 0;
+            if (kw == 0 && !kc && !ex) continue;
+            int ins, gap = 0, q;
+            if (r == 0) { ins = 0; q = p; }
+            else {
+                ins = row_ins(rop, p, m, nrow);
+                if (p < m) { unsigned o = rop[p]; q = (int)(o & 0x7fff); gap = (int)(o >> 15); } else q = nrow;
+            }
+            const int bs = nstart[p];
+            const int rp = q - ins;  // first inserted base
+            for (int k = 0; k < kw; k++) row[bs + k] = k < ins ? b[rp + k] : (uint8_t)'-';
+            if (kc) row[bs + kw] = gap ? (uint8_t)'-' : b[q];
+            if (ex) row[bs + kw] = le < ins ? b[rp + le] : (uint8_t)'-';
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
-extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
-                                 const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base,
-                                 int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status,
-                                 void *stream) {
+static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                           const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base,
+                           int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status,
+                           int32_t *d_new_cols, int32_t *d_last_extra, void *stream) {
     if (!ctx || n < 0 || total_rows < 0 || max_win_len <= 0) return HITE_EINVAL;
     if (n == 0) return HITE_OK;
     const int max_steps = 2 * max_win_len;
@@ -486,9 +613,50 @@ extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win,
     hipLaunchKernelGGL(star_align_kernel, dim3(grid), dim3(256), 0, st, P);
     hite_prof_end(ctx, tk, st);
     HITE_CHECK(ctx, hipGetLastError());
-    tk = hite_prof_begin(ctx, "star_layout_kernel", st);
-    hipLaunchKernelGGL(star_layout_kernel, dim3(n), dim3(256), 0, st, P);
+    if (d_new_cols) {
+        tk = hite_prof_begin(ctx, "star_layout_sparse_kernel", st);
+        hipLaunchKernelGGL(star_layout_sparse_kernel, dim3(n), dim3(256), 0, st, P, d_new_cols, d_last_extra);
+    } else {
+        tk = hite_prof_begin(ctx, "star_layout_kernel", st);
+        hipLaunchKernelGGL(star_layout_kernel, dim3(n), dim3(256), 0, st, P);
+    }
     hite_prof_end(ctx, tk, st);
+    HITE_CHECK(ctx, hipGetLastError());
+    return HITE_OK;
+}
+
+extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                                 const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base,
+                                 int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status,
+                                 void *stream) {
+    return star_msa_launch(ctx, n, d_win, d_win_off, d_win_len, d_row_first, total_rows, d_ops_base, ops_elems, max_win_len,
+                           d_cols_out, d_status, nullptr, nullptr, stream);
+}
+
+// align + fused layout / sparse-column selection: d_cols_out = columns of the full alignment (0 = failed),
+// d_new_cols = columns that survive remove_sparse_col_in_align_file, d_last_extra = per-candidate fill hint
+extern "C" int hite_star_msa_sparse_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                                        const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows,
+                                        const int64_t *d_ops_base, int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out,
+                                        int32_t *d_status, int32_t *d_new_cols, int32_t *d_last_extra, void *stream) {
+    if (!d_new_cols || !d_last_extra) return HITE_EINVAL;
+    return star_msa_launch(ctx, n, d_win, d_win_off, d_win_len, d_row_first, total_rows, d_ops_base, ops_elems, max_win_len,
+                           d_cols_out, d_status, d_new_cols, d_last_extra, stream);
+}
+
+// compacted alignments (rows x d_new_cols[i] at d_msa_off[i]) from the ops of the last hite_star_msa_sparse_dev call
+extern "C" int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                                             const int32_t *d_win_len, const int32_t *d_row_first, const int64_t *d_ops_base,
+                                             const int32_t *d_new_cols, const int32_t *d_last_extra, const int64_t *d_msa_off,
+                                             uint8_t *d_msa, void *stream) {
+    if (!ctx || n < 0 || !ctx->d_scratch2 || !d_new_cols || !d_last_extra) return HITE_EINVAL;
+    if (n == 0) return HITE_OK;
+    FillSparseParams Q;
+    FillParams &P = Q.F;
+    P.n = n; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first; P.ops_base = d_ops_base;
+    P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_new_cols; P.msa_off = d_msa_off; P.msa = d_msa;
+    Q.last_extra = d_last_extra;
+    hipLaunchKernelGGL(star_fill_sparse_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
     HITE_CHECK(ctx, hipGetLastError());
     return HITE_OK;
 }
@@ -519,9 +687,9 @@ struct MBuf {
 
 // host-buffer convenience: pass 1 (msa_out == NULL) returns cols_out only; otherwise also the
 // alignments at msa_off_out[i] (16-byte aligned slots), msa_cap bytes available.
-extern "C" int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off,
-                             const int32_t *row_first, int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out,
-                             int64_t *msa_off_out) {
+static int star_msa_host(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off,
+                         const int32_t *row_first, int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out,
+                         int64_t *msa_off_out, bool sparse) {
     if (!ctx || n < 0 || !win || !win_off || !row_first || !cols_out) return HITE_EINVAL;
     if (n == 0) return HITE_OK;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
@@ -546,20 +714,22 @@ extern "C" int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const
     int32_t *wl = (int32_t *)malloc(sizeof(int32_t) * (total_rows + 1));
     if (!wl) { free(ops_base); return HITE_ENOMEM; }
     for (int64_t g = 0; g < total_rows; g++) wl[g] = (int32_t)(win_off[g + 1] - win_off[g]);
-    MBuf dw, dwo, dwl, drf, dob, dcols, dst, dmo, dmsa;
+    MBuf dw, dwo, dwl, drf, dob, dcols, dst, dmo, dmsa, dnew, dlast;
     hipError_t e;
     e = dw.up(win, win_off[total_rows]); if (e == hipSuccess) e = dwo.up(win_off, (total_rows + 1) * 8);
     if (e == hipSuccess) e = dwl.up(wl, total_rows * 4);
     free(wl);
     if (e == hipSuccess) e = drf.up(row_first, (n + 1) * 4); if (e == hipSuccess) e = dob.up(ops_base, (n + 1) * 8);
     if (e == hipSuccess) e = dcols.alloc(n * 4); if (e == hipSuccess) e = dst.alloc(n * 4);
+    if (e == hipSuccess) e = dnew.alloc(n * 4); if (e == hipSuccess) e = dlast.alloc(n * 4);
     free(ops_base);
     HITE_CHECK(ctx, e);
-    int rc = hite_star_msa_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)dwl.p, (int32_t *)drf.p, total_rows, (int64_t *)dob.p, acc,
-                               maxlen, (int32_t *)dcols.p, (int32_t *)dst.p, nullptr);
+    int rc = star_msa_launch(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)dwl.p, (int32_t *)drf.p, total_rows, (int64_t *)dob.p, acc,
+                             maxlen, (int32_t *)dcols.p, (int32_t *)dst.p, sparse ? (int32_t *)dnew.p : nullptr,
+                             sparse ? (int32_t *)dlast.p : nullptr, nullptr);
     if (rc) return rc;
     HITE_CHECK(ctx, hipDeviceSynchronize());
-    HITE_CHECK(ctx, hipMemcpy(cols_out, dcols.p, n * 4, hipMemcpyDeviceToHost));
+    HITE_CHECK(ctx, hipMemcpy(cols_out, sparse ? dnew.p : dcols.p, n * 4, hipMemcpyDeviceToHost));
     if (!msa_out) return HITE_OK;
     if (!msa_off_out) return HITE_EINVAL;
     int64_t off = 0;
@@ -571,10 +741,26 @@ extern "C" int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const
     if (off > msa_cap) return HITE_ECAP;
     e = dmo.up(msa_off_out, n * 8); if (e == hipSuccess) e = dmsa.alloc(off + 16);
     HITE_CHECK(ctx, e);
-    rc = hite_star_msa_fill_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)dwl.p, (int32_t *)drf.p, (int64_t *)dob.p,
-                                (int32_t *)dcols.p, (int64_t *)dmo.p, (uint8_t *)dmsa.p, nullptr);
+    if (sparse)
+        rc = hite_star_msa_fill_sparse_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)dwl.p, (int32_t *)drf.p, (int64_t *)dob.p,
+                                           (int32_t *)dnew.p, (int32_t *)dlast.p, (int64_t *)dmo.p, (uint8_t *)dmsa.p, nullptr);
+    else
+        rc = hite_star_msa_fill_dev(ctx, n, (uint8_t *)dw.p, (int64_t *)dwo.p, (int32_t *)dwl.p, (int32_t *)drf.p, (int64_t *)dob.p,
+                                    (int32_t *)dcols.p, (int64_t *)dmo.p, (uint8_t *)dmsa.p, nullptr);
     if (rc) return rc;
     HITE_CHECK(ctx, hipDeviceSynchronize());
     HITE_CHECK(ctx, hipMemcpy(msa_out, dmsa.p, off, hipMemcpyDeviceToHost));
     return HITE_OK;
+}
+
+extern "C" int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off,
+                             const int32_t *row_first, int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out,
+                             int64_t *msa_off_out) {
+    return star_msa_host(ctx, n, win, win_off, row_first, cols_out, msa_cap, msa_out, msa_off_out, false);
+}
+// same call protocol; the alignments come back with the sparse columns already removed (cols_out = surviving columns)
+extern "C" int hite_star_msa_sparse(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off,
+                                    const int32_t *row_first, int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out,
+                                    int64_t *msa_off_out) {
+    return star_msa_host(ctx, n, win, win_off, row_first, cols_out, msa_cap, msa_out, msa_off_out, true);
 }

@@ -282,8 +282,8 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
                     int64_t *extra /* steps */, bool pass_b, hipStream_t st) {
     Arena &T = S->tmp, &K = S->keep;
     int32_t *nrows, *sel, *row_first32, *row_copy, *row_len, *row_pad, *cols, *status, *eff, *new_cols;
-    int64_t *row_first, *win_off, *ops_cnt, *ops_base, *msa_bytes, *msa_off, *col_off, *col_off2;
-    uint8_t *row_trunc, *win, *msa, *clean;
+    int64_t *row_first, *win_off, *ops_cnt, *ops_base, *msa_bytes, *msa_off, *col_off2;
+    uint8_t *row_trunc, *win, *clean;
     void *p;
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); nrows = (int32_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)n * MAXROWS * 4, &p)); sel = (int32_t *)p;
@@ -335,37 +335,30 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
 
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); cols = (int32_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); status = (int32_t *)p;
-    ACHK(hite_star_msa_dev(ctx, n, win, win_off, row_len, row_first32, total_rows, ops_base, ops_elems, max_len > 0 ? max_len : 1,
-                           cols, status, st));
+    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); new_cols = (int32_t *)p;
+    int32_t *last_extra;
+    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); last_extra = (int32_t *)p;
+    // alignment + layout + sparse-column selection: the full alignment is never written
+    ACHK(hite_star_msa_sparse_dev(ctx, n, win, win_off, row_len, row_first32, total_rows, ops_base, ops_elems, max_len > 0 ? max_len : 1,
+                                  cols, status, new_cols, last_extra, st));
+    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); eff = (int32_t *)p;
+    hipLaunchKernelGGL(eff_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nrows, cols, eff);
     ACHK(arena_alloc(ctx, T, (size_t)n * 8, &p)); msa_bytes = (int64_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); msa_off = (int64_t *)p;
-    ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); col_off = (int64_t *)p;
-    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
-    hipLaunchKernelGGL(msa_size_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nrows, cols, msa_bytes, (int32_t *)(S->d_scal + 2));
-    ACHK(scan_excl<int64_t>(ctx, T, msa_bytes, n, msa_off, st));
-    ACHK(scan_excl<int32_t>(ctx, T, cols, n, col_off, st));
-    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, msa_off + n, 8, hipMemcpyDeviceToDevice, st));
-    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, col_off + n, 8, hipMemcpyDeviceToDevice, st));
-    ACHK(read_scalars(ctx, S, st, 3));
-    const int64_t msa_total = S->h_pin[0], total_cols = S->h_pin[1];
-    stats[2] += msa_total;
-    ACHK(arena_alloc(ctx, T, (size_t)msa_total + 64, &p)); msa = (uint8_t *)p;
-    ACHK(arena_alloc(ctx, T, (size_t)msa_total + 64, &p)); clean = (uint8_t *)p;
-    tk = hite_prof_begin(ctx, "star_fill_kernel", st);
-    ACHK(hite_star_msa_fill_dev(ctx, n, win, win_off, row_len, row_first32, ops_base, cols, msa_off, msa, st));
-    hite_prof_end(ctx, tk, st);
-    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); eff = (int32_t *)p;
-    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); new_cols = (int32_t *)p;
-    hipLaunchKernelGGL(eff_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nrows, cols, eff);
-    tk = hite_prof_begin(ctx, "sparse_cols_kernel", st);
-    ACHK(hite_sparse_cols_dev(ctx, n, msa, msa_off, eff, cols, col_off, total_cols, clean, new_cols, st));
-    hite_prof_end(ctx, tk, st);
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); col_off2 = (int64_t *)p;
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
-    ACHK(scan_excl<int32_t>(ctx, T, new_cols, n, col_off2, st));
     hipLaunchKernelGGL(msa_size_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, eff, new_cols, msa_bytes, (int32_t *)(S->d_scal + 2));
+    ACHK(scan_excl<int64_t>(ctx, T, msa_bytes, n, msa_off, st));
+    ACHK(scan_excl<int32_t>(ctx, T, new_cols, n, col_off2, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, col_off2 + n, 8, hipMemcpyDeviceToDevice, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, msa_off + n, 8, hipMemcpyDeviceToDevice, st));
     ACHK(read_scalars(ctx, S, st, 3));
+    const int64_t msa_total = S->h_pin[1];
+    stats[2] += msa_total;
+    ACHK(arena_alloc(ctx, T, (size_t)msa_total + 64, &p)); clean = (uint8_t *)p;
+    tk = hite_prof_begin(ctx, "star_fill_sparse_kernel", st);
+    ACHK(hite_star_msa_fill_sparse_dev(ctx, n, win, win_off, row_len, row_first32, ops_base, new_cols, last_extra, msa_off, clean, st));
+    hite_prof_end(ctx, tk, st);
     const int64_t total_cols2 = S->h_pin[0];
     const int max_cols2 = (int)(((int32_t *)(S->h_pin + 2))[0]);
     ACHK(arena_alloc(ctx, K, (size_t)total_cols2 + 8 * (size_t)n + 64, &p)); out->cons = (uint8_t *)p;

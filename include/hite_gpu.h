@@ -189,12 +189,28 @@ int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8
  * (cols_out[c] = 0).  The fill call must follow the align call on the same ctx/stream. */
 int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
                   int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out, int64_t *msa_off_out);
+/* hite_star_msa followed by remove_sparse_col_in_align_file in one step (same two-call protocol; cols_out = surviving columns) */
+int hite_star_msa_sparse(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
+                         int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out, int64_t *msa_off_out);
 int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
                       const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base, int64_t ops_elems,
                       int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status, void *stream);
 int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
                            const int32_t *d_win_len, const int32_t *d_row_first, const int64_t *d_ops_base, const int32_t *d_cols,
                            const int64_t *d_msa_off, uint8_t *d_msa, void *stream);
+/* Fused variant used by hite_flank_region_align: alignment + column layout + the column selection of
+ * remove_sparse_col_in_align_file (Util.py:10344-10405) in one step, so that only the surviving columns are ever written.
+ * d_cols_out = columns of the full alignment (0 = failed), d_new_cols = surviving columns, d_last_extra = fill hint.
+ * hite_star_msa_fill_sparse_dev then writes rows x d_new_cols[i] bytes at d_msa_off[i]; the result is byte-identical to
+ * hite_star_msa_fill_dev followed by hite_sparse_cols_dev. */
+int hite_star_msa_sparse_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                             const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows,
+                             const int64_t *d_ops_base, int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out,
+                             int32_t *d_status, int32_t *d_new_cols, int32_t *d_last_extra, void *stream);
+int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
+                                  const int32_t *d_win_len, const int32_t *d_row_first, const int64_t *d_ops_base,
+                                  const int32_t *d_new_cols, const int32_t *d_last_extra, const int64_t *d_msa_off,
+                                  uint8_t *d_msa, void *stream);
 
 /* ---- the fine stage in one call --- body of flank_region_align_v5 from the copy table on ----------
  * (Util.py:8095-8194 + run_find_members_v8 :10439 + is_TE_from_align_file :10407).

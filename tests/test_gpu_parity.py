@@ -460,3 +460,31 @@ def test_dropin_scripts(ctx, tmp_path):
     assert rc.returncode == 0, rc.stderr
     tn, tc = util.read_fasta(str(out / "confident_tir_0.fa"))
     assert len(tn) >= 2 and all(n.startswith("genome-TIR_0_") for n in tn)
+
+
+def test_star_msa_sparse_fused(ctx):
+    """fused alignment + sparse-column removal == twin alignment followed by the oracle's remove_sparse_col
+    (first / last column rules, insertion blocks that survive as prefixes, few-row groups)"""
+    groups = _families(4242, 60, rows_choices=(1, 2, 3, 4, 7, 30, 101), lens=(60, 200, 700))
+    rng = np.random.default_rng(5)
+    # groups whose rows all carry the same leading / trailing insertions (the first / last column is an insertion column)
+    for _ in range(12):
+        L = int(rng.integers(40, 200))
+        centre = "".join("ACGT"[i] for i in rng.integers(0, 4, L))
+        rows = [centre]
+        for _r in range(int(rng.integers(1, 9))):
+            pre = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(0, 4))))
+            suf = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(0, 4))))
+            mid = int(rng.integers(5, L - 5))
+            ins = "".join("ACGT"[i] for i in rng.integers(0, 4, int(rng.integers(0, 3))))
+            rows.append(pre + centre[:mid] + ins + centre[mid:] + suf)
+        groups.append(rows)
+    got = ctx.star_msa(groups, sparse=True)
+    full = ctx.star_msa(groups)
+    for g, m, f in zip(groups, got, full):
+        exp_full = O.star_msa(g)
+        assert f is not None and np.array_equal(f, exp_full)
+        keep = O.sparse_cols(exp_full).astype(bool)
+        exp = np.ascontiguousarray(exp_full[:, keep])
+        assert m is not None and m.shape == exp.shape, (m.shape if m is not None else None, exp.shape, len(g))
+        assert np.array_equal(m, exp)
