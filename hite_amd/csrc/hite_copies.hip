@@ -152,14 +152,13 @@ __global__ void i64_to_u32_kernel(int64_t n, const int64_t *__restrict__ in, uns
 // candidate minimizers: one wavefront per candidate, 64 window starts per tile.  The tile's bases are staged in LDS
 // once (coalesced), the 75 k-mer hashes it needs are built from LDS and stay there; every lane then scans its own
 // window and the previous one (11 LDS reads).  Nothing but the minimizers themselves goes to HBM.
-// Two passes (WRITE = false: per-candidate counts; an exclusive scan; WRITE = true: the records, ordered by
-// (candidate, position)): a single append counter would serialise ~3 M device-scope atomics (~12 ns each).
-template <bool WRITE>
+// The records of candidate c first go to a private region (start = its byte offset: a candidate of L bases has < L
+// windows), with the count; after an exclusive scan of the counts a second kernel packs the regions.  Order = (candidate,
+// position), no atomics (a single append counter would serialise ~3 M device-scope atomics at ~12 ns each).
 __global__ void __launch_bounds__(64) cand_minimizer_kernel(int ncand, const uint8_t *__restrict__ cand,
                                                             const int64_t *__restrict__ cand_off,
-                                                            unsigned *__restrict__ q_c, unsigned *__restrict__ q_pos,
-                                                            unsigned *__restrict__ q_hs, int32_t *__restrict__ q_cnt,
-                                                            const int64_t *__restrict__ q_first) {
+                                                            unsigned *__restrict__ r_pos, unsigned *__restrict__ r_hs,
+                                                            int32_t *__restrict__ q_cnt) {
     __shared__ uint8_t sb[96];
     __shared__ unsigned sh[80];
     const int lane = threadIdx.x;
@@ -167,10 +166,10 @@ __global__ void __launch_bounds__(64) cand_minimizer_kernel(int ncand, const uin
         const int64_t cb = cand_off[c];
         const int L = (int)(cand_off[c + 1] - cb);
         const int nk = L - CK + 1;
-        if (nk <= 0) { if (!WRITE && lane == 0) q_cnt[c] = 0; continue; }
+        if (nk <= 0) { if (lane == 0) q_cnt[c] = 0; continue; }
         const int nwin = nk >= CW ? nk - CW + 1 : 1;
         const uint8_t *s = cand + cb;
-        int64_t run = WRITE ? q_first[c] : 0;   // wave-uniform running offset
+        int64_t run = cb;   // wave-uniform running offset
         for (int base = 0; base < nwin; base += 64) {
             __syncthreads();
             for (int q = lane; q < 96; q += 64) { const int pos = base - 1 + q; sb[q] = (pos >= 0 && pos < L) ? s[pos] : 0; }
@@ -202,13 +201,24 @@ __global__ void __launch_bounds__(64) cand_minimizer_kernel(int ncand, const uin
                 want = m >= 0 && !(lp > 0 && mprev == m);
             }
             const unsigned long long bm = __ballot(want);
-            if (WRITE && want) {
+            if (want) {
                 const int64_t slot = run + __popcll(bm & ((1ull << lane) - 1ull));
-                q_c[slot] = (unsigned)c; q_pos[slot] = (unsigned)m; q_hs[slot] = h;
+                r_pos[slot] = (unsigned)m; r_hs[slot] = h;
             }
             run += __popcll(bm);
         }
-        if (!WRITE && lane == 0) q_cnt[c] = (int32_t)run;
+        if (lane == 0) q_cnt[c] = (int32_t)(run - cb);
+    }
+}
+__global__ void __launch_bounds__(256) cand_minimizer_pack_kernel(int ncand, const int64_t *__restrict__ cand_off,
+                                                                  const unsigned *__restrict__ r_pos, const unsigned *__restrict__ r_hs,
+                                                                  const int64_t *__restrict__ q_first, unsigned *__restrict__ q_c,
+                                                                  unsigned *__restrict__ q_pos, unsigned *__restrict__ q_hs) {
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < ncand; c += gridDim.x * 4) {
+        const int64_t src = cand_off[c], dst = q_first[c];
+        const int cnt = (int)(q_first[c + 1] - dst);
+        for (int i = lane; i < cnt; i += 64) { q_c[dst + i] = (unsigned)c; q_pos[dst + i] = r_pos[src + i]; q_hs[dst + i] = r_hs[src + i]; }
     }
 }
 
@@ -473,22 +483,23 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
     int64_t nq;
     {
-        int32_t *q_cnt; int64_t *q_first, *qbs;
+        int32_t *q_cnt; int64_t *q_first, *qbs; unsigned *r_pos, *r_hs;
         CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); q_cnt = (int32_t *)p;
         CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); q_first = (int64_t *)p;
         CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(n_cand) * 8, &p)); qbs = (int64_t *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(cand_bytes + 64) * 4, &p)); r_pos = (unsigned *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(cand_bytes + 64) * 4, &p)); r_hs = (unsigned *)p;
         int wblocks = n_cand < 65536 ? n_cand : 65536;
         int tk_cm = hite_prof_begin(ctx, "cand_minimizer_kernel", st);
-        hipLaunchKernelGGL(cand_minimizer_kernel<false>, dim3(wblocks), dim3(64), 0, st, n_cand, d_cand, d_cand_off, q_c, q_pos, q_hs,
-                           q_cnt, (const int64_t *)nullptr);
+        hipLaunchKernelGGL(cand_minimizer_kernel, dim3(wblocks), dim3(64), 0, st, n_cand, d_cand, d_cand_off, r_pos, r_hs, q_cnt);
         CCHK(scan_excl_buf<int32_t>(ctx, qbs, q_cnt, n_cand, q_first, st));
         HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, q_first + n_cand, 8, hipMemcpyDeviceToDevice, st));
         CCHK(read_back(ctx, S, st, 1));
         nq = S->h_pin[0];
         if ((unsigned long long)nq > qcap) return HITE_ECAP;
         S->last[0] = nq; S->last[1] = S->last[2] = S->last[3] = 0;
-        hipLaunchKernelGGL(cand_minimizer_kernel<true>, dim3(wblocks), dim3(64), 0, st, n_cand, d_cand, d_cand_off, q_c, q_pos, q_hs,
-                           q_cnt, (const int64_t *)q_first);
+        hipLaunchKernelGGL(cand_minimizer_pack_kernel, dim3((n_cand + 3) / 4 < 8192 ? (n_cand + 3) / 4 : 8192), dim3(256), 0, st, n_cand,
+                           d_cand_off, r_pos, r_hs, q_first, q_c, q_pos, q_hs);
         hite_prof_end(ctx, tk_cm, st);
     }
     if (nq == 0) return HITE_OK;

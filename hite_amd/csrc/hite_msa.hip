@@ -17,6 +17,7 @@
 #include "hite_common.h"
 
 #define MW 64
+#define MSA_MAXR 128   // rows whose lengths are cached in LDS by the layout / fill kernels
 #define MBIAS (1 << 28)
 #define SC_MATCH 2
 #define SC_MIS (-2)
@@ -154,12 +155,12 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         //   down     : centre bases slide one lane down (wave_shl), lanes 60..63 refilled from the rotating window `ach`
         //              (wave_rol, row/bank-masked); left = shl(prev) - 1 lands in pp (next step's diagonal operand)
         //   right    : same with the row bases / wave_shr / `bch`; diagonal = shr(pp) folded into the add
-#define ARM_DOWN(TAIL)                                                                            \
+#define ARM_DOWN(MOVE, TAIL)                                                                            \
             "v_mov_b32_dpp %[areg], %[areg] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"            \
             "v_mov_b32_dpp %[areg], %[ach] wave_rol:1 row_mask:0x8 bank_mask:0x8\n\t"             \
             "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
             "v_mov_b32_dpp %[ach], %[ach] wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"              \
-            "s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t"                                             \
+            MOVE                                                                                  \
             "v_cndmask_b32_e64 %[tsc], 26, 42, vcc\n\t"                                           \
             "v_add_u32 %[tcd], %[pp], %[tsc]\n\t"                                                 \
             "v_add_u32_dpp %[pp], %[prev], %[vm1] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
@@ -167,12 +168,13 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             "v_and_or_b32 %[prev], %[tv], -4, 1\n\t"                                              \
             "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"                                           \
             TAIL
-#define ARM_RIGHT(TAIL)                                                                           \
+#define ARM_RIGHT(MOVE, TAIL)                                                                           \
             "v_mov_b32_dpp %[breg], %[breg] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
             "v_mov_b32_dpp %[breg], %[bch] wave_ror:1 row_mask:0x1 bank_mask:0x1\n\t"             \
             "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
             "v_mov_b32_dpp %[bch], %[bch] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"              \
             "v_mov_b32_dpp %[thx], %[prev] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            MOVE                                                                                  \
             "v_cndmask_b32_e64 %[tsc], 26, 42, vcc\n\t"                                           \
             "v_add_u32_dpp %[tcd], %[pp], %[tsc] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
             "v_add_u32 %[pp], -1, %[prev]\n\t"                                                    \
@@ -194,19 +196,20 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             "s_cmp_lg_u32 %[tn], %[t]\n\t"                                                        \
             "s_mov_b32 %[t], %[tn]\n\t"                                                           \
             "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
-            ARM_DOWN("s_branch J" L "_%=\n")                                                      \
+            ARM_DOWN("s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t", "s_branch J" L "_%=\n")            \
             "R" L "_%=:\n\t"                                                                      \
-            ARM_RIGHT("s_lshl_b32 %[mreg], %[mreg], 2\n")                                         \
+            ARM_RIGHT("s_lshl_b32 %[mreg], %[mreg], 2\n\t", "\n")                                 \
             "J" L "_%=:\n\t"
 #define STEP_FAST(CMP, L)                                                                         \
             "v_readlane_b32 %[h0], %[prev], 0\n\t"                                                \
             "v_readlane_b32 %[h63], %[prev], 63\n\t"                                              \
             CMP " %[h63], %[h0]\n\t"                                                              \
             "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
-            ARM_DOWN("s_add_i32 %[t], %[t], 1\n\ts_branch J" L "_%=\n")                           \
+            ARM_DOWN("v_lshl_or_b32 %[vm], %[vm], 2, 1\n\t", "s_branch J" L "_%=\n")               \
             "R" L "_%=:\n\t"                                                                      \
-            ARM_RIGHT("s_lshl_b32 %[mreg], %[mreg], 2\n")                                         \
+            ARM_RIGHT("v_lshlrev_b32 %[vm], 2, %[vm]\n\t", "\n")                                   \
             "J" L "_%=:\n\t"
+#define STEP_FAST2(L) STEP_FAST("s_cmp_ge_i32", L "o") STEP_FAST("s_cmp_gt_i32", L "e")
 #define STEP_OPERANDS                                                                                                      \
             : [prev] "+v"(prev), [pp] "+v"(pp), [areg] "+v"(areg), [breg] "+v"(breg), [ach] "+v"(ach), [bch] "+v"(bch),   \
               [d2] "+v"(d2), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv), [t] "+s"(t),           \
@@ -233,21 +236,22 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             int d2 = 0, tsc, tcd, thx, tv;
             int mreg = to_sgpr(0), sx, sy, tn, h0, h63;
             int s31 = to_sgpr(s_lo - 32);              // (s - 31) of the step before the next one
-            if (s_lo + nst - 1 <= mn) {
-                if (nst >= 2) {
-                    int cnt = to_sgpr((nst >> 1) - 1);
-                    asm volatile(
-                        "L_%=:\n\t"
-                        STEP_FAST("s_cmp_ge_i32", "a")
-                        STEP_FAST("s_cmp_gt_i32", "b")
-                        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-                        "s_cbranch_scc0 L_%=\n\t"
-                        STEP_OPERANDS);
-                }
-                if (nst & 1) {
-                    int cnt = 0;
-                    asm volatile(STEP_FAST("s_cmp_ge_i32", "c") STEP_OPERANDS);
-                }
+            // neither clamp can bind during a full chunk that starts with t + 16 <= m - 31 and t >= max(0, s_hi - n) - 32
+            // (t only grows, by at most one per step; t <= s - 32 always): such chunks run the 16 steps unrolled with the
+            // moves recorded on the vector side -- the scalar unit (one per CU, shared by 32 waves) is the scarce resource.
+            const int s_hi = s_lo + 15;
+            if (nst == 16 && t + 16 <= m31 && t >= (s_hi > n ? s_hi - n : 0) - 32) {
+                int vm = 0;
+                asm volatile(
+                    STEP_FAST2("0") STEP_FAST2("1") STEP_FAST2("2") STEP_FAST2("3")
+                    STEP_FAST2("4") STEP_FAST2("5") STEP_FAST2("6") STEP_FAST2("7")
+                    : [prev] "+v"(prev), [pp] "+v"(pp), [areg] "+v"(areg), [breg] "+v"(breg), [ach] "+v"(ach), [bch] "+v"(bch),
+                      [d2] "+v"(d2), [vm] "+v"(vm), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv),
+                      [h0] "=&s"(h0), [h63] "=&s"(h63)
+                    : [vm1] "v"(vm1)
+                    : "vcc", "scc");
+                mreg = to_sgpr(vm);
+                t += __builtin_popcount((unsigned)mreg & 0x55555555u);
             } else {
                 if (nst >= 2) {
                     int cnt = to_sgpr((nst >> 1) - 1);
@@ -270,6 +274,7 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         }
 #undef STEP_GEN
 #undef STEP_FAST
+#undef STEP_FAST2
 #undef ARM_DOWN
 #undef ARM_RIGHT
 #undef STEP_OPERANDS
@@ -475,11 +480,14 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
     uint16_t *kwslot = ops;                              // centre row slot
     uint16_t *nstart = ops + (int64_t)R * (m + 1);       // extra slot
     const int h = (R + 1) >> 1;                          // fewest rows with a base for a column to survive
+    __shared__ int s_wl[MSA_MAXR];
+    for (int r = threadIdx.x; r < R && r < MSA_MAXR; r += 256) s_wl[r] = P.win_len[g0 + r];
     if (threadIdx.x == 0) s_mxm = 0;
     __syncthreads();
+    const int64_t rs = m + 1;                            // ops row stride
     {   // widest insertion after the last centre position: decides which column is the last one
         int mxm = 0;
-        for (int r = 1 + threadIdx.x; r < R; r += 256) { int v = row_ins(ops + (int64_t)r * (m + 1), m, m, P.win_len[g0 + r]); mxm = v > mxm ? v : mxm; }
+        for (int r = 1 + threadIdx.x; r < R; r += 256) { int v = row_ins(ops + r * rs, m, m, P.win_len[g0 + r]); mxm = v > mxm ? v : mxm; }
         if (mxm > 0) atomicMax(&s_mxm, mxm);
     }
     __syncthreads();
@@ -489,9 +497,24 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
         const int p = base + threadIdx.x;
         int mx = 0, npos = 0, gapc = 0;
         if (p <= m) {
-            for (int r = 1; r < R; r++) {
-                const uint16_t *rop = ops + (int64_t)r * (m + 1);
-                const int v = row_ins(rop, p, m, P.win_len[g0 + r]);
+            // ins_r(p) = q_r(p) - end_r(p-1): two u16 per row, four rows in flight
+            const uint16_t *col = ops + p;
+            int r = 1;
+            for (; r + 3 < R; r += 4) {
+                unsigned oc[4], op[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) { oc[u] = p < m ? col[(r + u) * rs] : 0u; op[u] = p > 0 ? col[(r + u) * rs - 1] : 0u; }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const int pe = p > 0 ? (int)(op[u] & 0x7fff) + ((op[u] >> 15) ? 0 : 1) : 0;
+                    const int q = p < m ? (int)(oc[u] & 0x7fff) : (r + u < MSA_MAXR ? s_wl[r + u] : P.win_len[g0 + r + u]);
+                    const int v = q - pe;
+                    mx = v > mx ? v : mx; npos += v > 0; gapc += (int)(oc[u] >> 15);
+                }
+            }
+            for (; r < R; r++) {
+                const uint16_t *rop = ops + r * rs;
+                const int v = row_ins(rop, p, m, r < MSA_MAXR ? s_wl[r] : P.win_len[g0 + r]);
                 mx = v > mx ? v : mx;
                 npos += v > 0;
                 if (p < m) gapc += rop[p] >> 15;
@@ -554,28 +577,30 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
     const uint16_t *nstart = ops + (int64_t)R * (m + 1);
     const int le = Q.last_extra[c];
     uint8_t *out = P.msa + P.msa_off[c];
-    for (int r = blockIdx.y; r < R; r += gridDim.y) {
+    // items (r, p) flattened over the whole candidate: short centres still fill every lane, many loads in flight
+    const int rs = m + 1;
+    const unsigned items = (unsigned)R * (unsigned)rs;   // < 2^31: R <= a few hundred rows, rs <= 32768
+    for (unsigned it = blockIdx.y * 256u + threadIdx.x; it < items; it += gridDim.y * 256u) {
+        const int r = (int)(it / (unsigned)rs), p = (int)(it - (unsigned)r * (unsigned)rs);
+        const unsigned ks = kwslot[p];
+        const int kw = (int)(ks & 0x7fff), kc = (int)(ks >> 15);
+        const bool ex = p == m && le >= 0;
+        if (kw == 0 && !kc && !ex) continue;
         const uint8_t *b = P.win + P.win_off[g0 + r];
-        const int nrow = P.win_len[g0 + r];
-        uint8_t *row = out + (int64_t)r * C;
-        const uint16_t *rop = ops + (int64_t)r * (m + 1);
-        for (int p = threadIdx.x; p <= m; p += 256) {
-            const unsigned ks = kwslot[p];
-            const int kw = (int)(ks & 0x7fff), kc = (int)(ks >> 15);
-            const bool ex = p == m && le >= 0;
-            if (kw == 0 && !kc && !ex) continue;
-            int ins, gap = 0, q;
-            if (r == 0) { ins = 0; q = p; }
-            else {
-                ins = row_ins(rop, p, m, nrow);
-                if (p < m) { unsigned o = rop[p]; q = (int)(o & 0x7fff); gap = (int)(o >> 15); } else q = nrow;
-            }
-            const int bs = nstart[p];
-            const int rp = q - ins;  // first inserted base
-            for (int k = 0; k < kw; k++) row[bs + k] = k < ins ? b[rp + k] : (uint8_t)'-';
-            if (kc) row[bs + kw] = gap ? (uint8_t)'-' : b[q];
-            if (ex) row[bs + kw] = le < ins ? b[rp + le] : (uint8_t)'-';
+        const uint16_t *rop = ops + (int64_t)r * rs;
+        int ins, gap = 0, q;
+        if (r == 0) { ins = 0; q = p; }
+        else {
+            const int nrow = P.win_len[g0 + r];
+            ins = row_ins(rop, p, m, nrow);
+            if (p < m) { unsigned o = rop[p]; q = (int)(o & 0x7fff); gap = (int)(o >> 15); } else q = nrow;
         }
+        uint8_t *row = out + (int64_t)r * C;
+        const int bs = nstart[p];
+        const int rp = q - ins;  // first inserted base
+        for (int k = 0; k < kw; k++) row[bs + k] = k < ins ? b[rp + k] : (uint8_t)'-';
+        if (kc) row[bs + kw] = gap ? (uint8_t)'-' : b[q];
+        if (ex) row[bs + kw] = le < ins ? b[rp + le] : (uint8_t)'-';
     }
 }
 
@@ -614,7 +639,7 @@ static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
     hite_prof_end(ctx, tk, st);
     HITE_CHECK(ctx, hipGetLastError());
     if (d_new_cols) {
-        tk = hite_prof_begin(ctx, "star_layout_sparse_kernel", st);
+        tk = hite_prof_begin(ctx, max_win_len > 1000 ? "star_layout_sparse_kernel_long" : "star_layout_sparse_kernel_short", st);
         hipLaunchKernelGGL(star_layout_sparse_kernel, dim3(n), dim3(256), 0, st, P, d_new_cols, d_last_extra);
     } else {
         tk = hite_prof_begin(ctx, "star_layout_kernel", st);

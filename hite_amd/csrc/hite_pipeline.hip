@@ -356,7 +356,7 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     const int64_t msa_total = S->h_pin[1];
     stats[2] += msa_total;
     ACHK(arena_alloc(ctx, T, (size_t)msa_total + 64, &p)); clean = (uint8_t *)p;
-    tk = hite_prof_begin(ctx, "star_fill_sparse_kernel", st);
+    tk = hite_prof_begin(ctx, extra == nullptr ? "star_fill_sparse_kernel" : (pass_b ? "star_fill_sparse_kernel_passB" : "star_fill_sparse_kernel_passA"), st);
     ACHK(hite_star_msa_fill_sparse_dev(ctx, n, win, win_off, row_len, row_first32, ops_base, new_cols, last_extra, msa_off, clean, st));
     hite_prof_end(ctx, tk, st);
     const int64_t total_cols2 = S->h_pin[0];
