@@ -107,6 +107,7 @@ __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
 //            results leave as coalesced 128-B chunks of u16 (row position aligned to centre position p |
 //            gap flag << 15).
 __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
+    __shared__ uint8_t s_bases[4][2][96];   // per wave: windows of centre / row bases for the current chunk
     const int lane = threadIdx.x & 63;
     const int wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
     uint8_t *slot = P.tb + (size_t)wslot * P.tb_slot;
@@ -144,45 +145,50 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         const int m31 = m - 31, n1 = n + 1;
         const int nchunk = (steps + 15) >> 4;          // chunk ch = anti-diagonals 16 ch + 1 .. 16 ch + 16
         const int neg32 = to_sgpr(-32);
-        const int mn = m < n ? m : n;
         int vm1;                                       // DPP forms take no constant operand
         asm volatile("v_mov_b32 %0, -1" : "=v"(vm1));
-        // One anti-diagonal, hand-scheduled: 11-12 vector instructions, no s_nop (scalar instructions fill the wait states:
+        // per-wave LDS windows of the bases that can enter the band during one chunk (the vector unit is the bottleneck
+        // of this kernel: 4 cycles per instruction, ~100 % busy; LDS reads issue on their own port):
+        //   A[x] = a'[t0 - 1 + x]   lane k reads A[k + downs]   (x = 1 .. 79)
+        //   B[y] = b'[e0 - 64 + y]  lane k reads B[63 - k + rights],  e0 = s_lo - t0 - 1
+        uint8_t *winA = &s_bases[threadIdx.x >> 6][0][0], *winB = &s_bases[threadIdx.x >> 6][1][0];
+        const unsigned ldsA = (unsigned)(uintptr_t)winA, ldsB = (unsigned)(uintptr_t)winB;
+        // One anti-diagonal, hand-scheduled: 10-11 vector instructions, no s_nop (scalar instructions fill the wait states:
         // v_cmp -> v_cndmask needs 2, a VALU write -> DPP read of the same register needs 2).
         //   steering : two v_readlane; move = prev[63] >= prev[0] (odd s) / > (even s)
         //              general step: tn = max(min(t + move, min(m,s) - 31), max(0,s-n) - 32) on the scalar unit;
-        //              fast step (s <= min(m,n): neither clamp can bind): tn = t + move
-        //   down     : centre bases slide one lane down (wave_shl), lanes 60..63 refilled from the rotating window `ach`
-        //              (wave_rol, row/bank-masked); left = shl(prev) - 1 lands in pp (next step's diagonal operand)
-        //   right    : same with the row bases / wave_shr / `bch`; diagonal = shr(pp) folded into the add
-#define ARM_DOWN(MOVE, TAIL)                                                                            \
-            "v_mov_b32_dpp %[areg], %[areg] wave_shl:1 row_mask:0xf bank_mask:0xf\n\t"            \
-            "v_mov_b32_dpp %[areg], %[ach] wave_rol:1 row_mask:0x8 bank_mask:0x8\n\t"             \
+        //              clamp-free step (see the chunk test below): tn = t + move
+        //   down     : the centre base of every lane is re-read one entry further in A; left = shl(prev) - 1 becomes the
+        //              next step's diagonal operand (the two pp registers swap roles every step: no copy)
+        //   right    : same with the row bases / B; diagonal = shr(pp) folded into the add
+#define ARM_DOWN(PO, PN, MOVE, TAIL)                                                                    \
+            "v_add_u32 %[aaddr], 1, %[aaddr]\n\t"                                                 \
+            "ds_read_u8 %[areg], %[aaddr]\n\t"                                                    \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                            \
             "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
-            "v_mov_b32_dpp %[ach], %[ach] wave_rol:1 row_mask:0xf bank_mask:0xf\n\t"              \
+            "v_add_u32_dpp %[" PN "], %[prev], %[vm1] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
             MOVE                                                                                  \
             "v_cndmask_b32_e64 %[tsc], 26, 42, vcc\n\t"                                           \
-            "v_add_u32 %[tcd], %[pp], %[tsc]\n\t"                                                 \
-            "v_add_u32_dpp %[pp], %[prev], %[vm1] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-            "v_max3_i32 %[tv], %[tcd], %[prev], %[pp]\n\t"                                        \
+            "v_add_u32 %[tcd], %[" PO "], %[tsc]\n\t"                                             \
+            "v_max3_i32 %[tv], %[tcd], %[prev], %[" PN "]\n\t"                                    \
             "v_and_or_b32 %[prev], %[tv], -4, 1\n\t"                                              \
             "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"                                           \
             TAIL
-#define ARM_RIGHT(MOVE, TAIL)                                                                           \
-            "v_mov_b32_dpp %[breg], %[breg] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"            \
-            "v_mov_b32_dpp %[breg], %[bch] wave_ror:1 row_mask:0x1 bank_mask:0x1\n\t"             \
+#define ARM_RIGHT(PO, PN, MOVE, TAIL)                                                                   \
+            "v_add_u32 %[baddr], 1, %[baddr]\n\t"                                                 \
+            "ds_read_u8 %[breg], %[baddr]\n\t"                                                    \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                            \
             "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
-            "v_mov_b32_dpp %[bch], %[bch] wave_ror:1 row_mask:0xf bank_mask:0xf\n\t"              \
             "v_mov_b32_dpp %[thx], %[prev] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
             MOVE                                                                                  \
             "v_cndmask_b32_e64 %[tsc], 26, 42, vcc\n\t"                                           \
-            "v_add_u32_dpp %[tcd], %[pp], %[tsc] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-            "v_add_u32 %[pp], -1, %[prev]\n\t"                                                    \
-            "v_max3_i32 %[tv], %[tcd], %[thx], %[pp]\n\t"                                         \
+            "v_add_u32_dpp %[tcd], %[" PO "], %[tsc] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            "v_add_u32 %[" PN "], -1, %[prev]\n\t"                                                \
+            "v_max3_i32 %[tv], %[tcd], %[thx], %[" PN "]\n\t"                                     \
             "v_and_or_b32 %[prev], %[tv], -4, 1\n\t"                                              \
             "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"                                           \
             TAIL
-#define STEP_GEN(CMP, L)                                                                          \
+#define STEP_GEN(CMP, L, PO, PN)                                                                  \
             "v_readlane_b32 %[h0], %[prev], 0\n\t"                                                \
             "v_readlane_b32 %[h63], %[prev], 63\n\t"                                              \
             "s_add_i32 %[s31], %[s31], 1\n\t"                                                     \
@@ -196,78 +202,78 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             "s_cmp_lg_u32 %[tn], %[t]\n\t"                                                        \
             "s_mov_b32 %[t], %[tn]\n\t"                                                           \
             "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
-            ARM_DOWN("s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t", "s_branch J" L "_%=\n")            \
+            ARM_DOWN(PO, PN, "s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t", "s_branch J" L "_%=\n")   \
             "R" L "_%=:\n\t"                                                                      \
-            ARM_RIGHT("s_lshl_b32 %[mreg], %[mreg], 2\n\t", "\n")                                 \
+            ARM_RIGHT(PO, PN, "s_lshl_b32 %[mreg], %[mreg], 2\n\t", "\n")                         \
             "J" L "_%=:\n\t"
-#define STEP_FAST(CMP, L)                                                                         \
+#define STEP_FAST(CMP, L, PO, PN)                                                                 \
             "v_readlane_b32 %[h0], %[prev], 0\n\t"                                                \
             "v_readlane_b32 %[h63], %[prev], 63\n\t"                                              \
             CMP " %[h63], %[h0]\n\t"                                                              \
             "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
-            ARM_DOWN("v_lshl_or_b32 %[vm], %[vm], 2, 1\n\t", "s_branch J" L "_%=\n")               \
+            ARM_DOWN(PO, PN, "s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t", "s_branch J" L "_%=\n")   \
             "R" L "_%=:\n\t"                                                                      \
-            ARM_RIGHT("v_lshlrev_b32 %[vm], 2, %[vm]\n\t", "\n")                                   \
+            ARM_RIGHT(PO, PN, "s_lshl_b32 %[mreg], %[mreg], 2\n\t", "\n")                         \
             "J" L "_%=:\n\t"
-#define STEP_FAST2(L) STEP_FAST("s_cmp_ge_i32", L "o") STEP_FAST("s_cmp_gt_i32", L "e")
-#define STEP_OPERANDS                                                                                                      \
-            : [prev] "+v"(prev), [pp] "+v"(pp), [areg] "+v"(areg), [breg] "+v"(breg), [ach] "+v"(ach), [bch] "+v"(bch),   \
-              [d2] "+v"(d2), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv), [t] "+s"(t),           \
-              [mreg] "+s"(mreg), [s31] "+s"(s31), [cnt] "+s"(cnt), [x] "=&s"(sx), [y] "=&s"(sy), [tn] "=&s"(tn),          \
-              [h0] "=&s"(h0), [h63] "=&s"(h63)                                                                             \
-            : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32), [vm1] "v"(vm1)                                             \
-            : "vcc", "scc"
+#define STEP_FAST2(L) STEP_FAST("s_cmp_ge_i32", L "o", "p0", "p1") STEP_FAST("s_cmp_gt_i32", L "e", "p1", "p0")
+#define STEP_VREGS                                                                                                         \
+              [prev] "+v"(prev), [p0] "+v"(p0), [p1] "+v"(p1), [areg] "+v"(areg), [breg] "+v"(breg), [aaddr] "+v"(aaddr), \
+              [baddr] "+v"(baddr), [d2] "+v"(d2), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv)
+        int p0 = pp, p1 = 0;                           // the diagonal operand lives in p0 at the start of every chunk
         for (int ch = 0; ch < nchunk; ch++) {
             const int s_lo = (ch << 4) + 1;
             const int left = steps - (ch << 4);
             const int nst = left < 16 ? left : 16;
-            // rotating windows of the bases that can enter the band during this chunk (<= 16 of each):
-            //   ach[l] = a'[t + 63 + o(l)], o = -3 .. 60 (lane 0 is the next base in, lanes 61..63 the last three in)
-            //   bch[l] = b'[s_lo - t - 1 + p(l)], p(63) = 0 the next base in, lanes 0..2 the last three in
-            int ach, bch;
-            {
-                const int ia = t + 63 + (((lane + 3) & 63) - 3);
-                const int ra = a[(unsigned)ia < (unsigned)m ? ia : 0];
-                ach = (unsigned)ia < (unsigned)m ? (ra == 'N' ? 0xFD : ra) : 0xFF;
-                const int ib = s_lo - t - 1 + (((66 - lane) & 63) - 3);
-                const int rb = b[(unsigned)ib < (unsigned)n ? ib : 0];
-                bch = (unsigned)ib < (unsigned)n ? rb : 0xFE;
+            {   // windows of this chunk: entries 1..63 are the bases the lanes hold now, 64..79 the (<= 16) that can enter
+                winA[lane] = (uint8_t)areg;
+                winB[63 - lane] = (uint8_t)breg;
+                const bool isb = lane >= 16;
+                const int idx = isb ? s_lo - t - 1 + (lane - 16) : t + 63 + lane;
+                const int lim = isb ? n : m;
+                const uint8_t *src = isb ? b : a;
+                if (lane < 32) {
+                    const int raw = src[(unsigned)idx < (unsigned)lim ? idx : 0];
+                    const int v = (unsigned)idx < (unsigned)lim ? ((!isb && raw == 'N') ? 0xFD : raw) : (isb ? 0xFE : 0xFF);
+                    (isb ? winB : winA)[64 + (lane & 15)] = (uint8_t)v;
+                }
             }
+            int aaddr = (int)(ldsA + lane), baddr = (int)(ldsB + 63 - lane);
             int d2 = 0, tsc, tcd, thx, tv;
             int mreg = to_sgpr(0), sx, sy, tn, h0, h63;
             int s31 = to_sgpr(s_lo - 32);              // (s - 31) of the step before the next one
             // neither clamp can bind during a full chunk that starts with t + 16 <= m - 31 and t >= max(0, s_hi - n) - 32
-            // (t only grows, by at most one per step; t <= s - 32 always): such chunks run the 16 steps unrolled with the
-            // moves recorded on the vector side -- the scalar unit (one per CU, shared by 32 waves) is the scarce resource.
+            // (t only grows, by at most one per step; t <= s - 32 always): such chunks run the 16 steps unrolled and
+            // recover t from the recorded moves.  Both forms live in ONE asm statement (same registers: no copies).
             const int s_hi = s_lo + 15;
-            if (nst == 16 && t + 16 <= m31 && t >= (s_hi > n ? s_hi - n : 0) - 32) {
-                int vm = 0;
-                asm volatile(
-                    STEP_FAST2("0") STEP_FAST2("1") STEP_FAST2("2") STEP_FAST2("3")
-                    STEP_FAST2("4") STEP_FAST2("5") STEP_FAST2("6") STEP_FAST2("7")
-                    : [prev] "+v"(prev), [pp] "+v"(pp), [areg] "+v"(areg), [breg] "+v"(breg), [ach] "+v"(ach), [bch] "+v"(bch),
-                      [d2] "+v"(d2), [vm] "+v"(vm), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv),
-                      [h0] "=&s"(h0), [h63] "=&s"(h63)
-                    : [vm1] "v"(vm1)
-                    : "vcc", "scc");
-                mreg = to_sgpr(vm);
-                t += __builtin_popcount((unsigned)mreg & 0x55555555u);
-            } else {
-                if (nst >= 2) {
-                    int cnt = to_sgpr((nst >> 1) - 1);
-                    asm volatile(
-                        "L_%=:\n\t"
-                        STEP_GEN("s_cmp_ge_i32", "a")
-                        STEP_GEN("s_cmp_gt_i32", "b")
-                        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-                        "s_cbranch_scc0 L_%=\n\t"
-                        STEP_OPERANDS);
-                }
-                if (nst & 1) {
-                    int cnt = 0;
-                    asm volatile(STEP_GEN("s_cmp_ge_i32", "c") STEP_OPERANDS);
-                }
-            }
+            const int fast = to_sgpr((nst == 16 && t + 16 <= m31 && t >= (s_hi > n ? s_hi - n : 0) - 32) ? 1 : 0);
+            int cnt = to_sgpr((nst >> 1) - 1);         // pairs - 1 (general form)
+            const int odd = to_sgpr(nst & 1);          // only the last chunk can be odd: p1 is never read again
+            asm volatile(
+                "s_cmp_lg_u32 %[fast], 0\n\t"
+                "s_cbranch_scc1 F_%=\n\t"
+                "s_cmp_lt_i32 %[cnt], 0\n\t"
+                "s_cbranch_scc1 S_%=\n"
+                "L_%=:\n\t"
+                STEP_GEN("s_cmp_ge_i32", "a", "p0", "p1")
+                STEP_GEN("s_cmp_gt_i32", "b", "p1", "p0")
+                "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                "s_cbranch_scc0 L_%=\n"
+                "S_%=:\n\t"
+                "s_cmp_eq_u32 %[odd], 0\n\t"
+                "s_cbranch_scc1 E_%=\n\t"
+                STEP_GEN("s_cmp_ge_i32", "c", "p0", "p1")
+                "s_branch E_%=\n"
+                "F_%=:\n\t"
+                STEP_FAST2("0") STEP_FAST2("1") STEP_FAST2("2") STEP_FAST2("3")
+                STEP_FAST2("4") STEP_FAST2("5") STEP_FAST2("6") STEP_FAST2("7")
+                "s_and_b32 %[x], %[mreg], 0x55555555\n\t"
+                "s_bcnt1_i32_b32 %[x], %[x]\n\t"
+                "s_add_i32 %[t], %[t], %[x]\n"
+                "E_%=:\n\t"
+                : STEP_VREGS, [t] "+s"(t), [mreg] "+s"(mreg), [s31] "+s"(s31), [cnt] "+s"(cnt), [x] "=&s"(sx), [y] "=&s"(sy),
+                  [tn] "=&s"(tn), [h0] "=&s"(h0), [h63] "=&s"(h63)
+                : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32), [vm1] "v"(vm1), [fast] "s"(fast), [odd] "s"(odd)
+                : "vcc", "scc", "memory");
             // two bits per step, step r of the chunk at bits 2r+1 : 2r (directions), the move at bit 30 - 2r
             tbd[ch * 64 + lane] = (unsigned)d2 >> (2 * (16 - nst));
             if (lane == 0) tbm[ch] = (unsigned)mreg << (2 * (16 - nst));
@@ -277,7 +283,7 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
 #undef STEP_FAST2
 #undef ARM_DOWN
 #undef ARM_RIGHT
-#undef STEP_OPERANDS
+#undef STEP_VREGS
         {
             const int kf = m - t;
             const int hf = (kf >= 0 && kf < 64) ? __builtin_amdgcn_readlane(prev, kf & 63) : 0;
