@@ -252,7 +252,19 @@ __device__ void blk_colstats(const uint8_t *__restrict__ msa, int C, const uint1
                              uint8_t *__restrict__ cstat) {
     for (int c = threadIdx.x; c < C; c += JB) {
         uint8_t cnt[6] = {0, 0, 0, 0, 0, 0}, fst[6] = {255, 255, 255, 255, 255, 255};
-        for (int r = 0; r < rn; r++) {
+        int r = 0;
+        for (; r + 3 < rn; r += 4) {   // four rows in flight (the loop is load-latency bound otherwise)
+            uint8_t sy[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) sy[u] = msa[(size_t)sel[r + u] * C + c];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                int k = sym_class(sy[u]);
+                if (cnt[k] == 0) fst[k] = (uint8_t)(r + u);
+                cnt[k]++;
+            }
+        }
+        for (; r < rn; r++) {
             int k = sym_class(msa[(size_t)sel[r] * C + c]);
             if (cnt[k] == 0) fst[k] = (uint8_t)r;
             cnt[k]++;

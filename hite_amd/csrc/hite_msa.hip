@@ -607,27 +607,58 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
     // items (r, p) flattened over the whole candidate: short centres still fill every lane, many loads in flight
     const int rs = m + 1;
     const unsigned items = (unsigned)R * (unsigned)rs;   // < 2^31: R <= a few hundred rows, rs <= 32768
-    for (unsigned it = blockIdx.y * 256u + threadIdx.x; it < items; it += gridDim.y * 256u) {
-        const int r = (int)(it / (unsigned)rs), p = (int)(it - (unsigned)r * (unsigned)rs);
-        const unsigned ks = kwslot[p];
-        const int kw = (int)(ks & 0x7fff), kc = (int)(ks >> 15);
-        const bool ex = p == m && le >= 0;
-        if (kw == 0 && !kc && !ex) continue;
-        const uint8_t *b = P.win + P.win_off[g0 + r];
-        const uint16_t *rop = ops + (int64_t)r * rs;
-        int ins, gap = 0, q;
-        if (r == 0) { ins = 0; q = p; }
-        else {
-            const int nrow = P.win_len[g0 + r];
-            ins = row_ins(rop, p, m, nrow);
-            if (p < m) { unsigned o = rop[p]; q = (int)(o & 0x7fff); gap = (int)(o >> 15); } else q = nrow;
+    const unsigned stride = gridDim.y * 256u;
+    // four items per thread and trip: the loads of each dependency level are issued together (the chain kwslot -> ops ->
+    // base is three loads deep and the kernel is latency bound otherwise)
+    for (unsigned it0 = blockIdx.y * 256u + threadIdx.x; it0 < items; it0 += 4 * stride) {
+        int r[4], p[4], kw[4], kc[4], ins[4], gap[4], q[4], bs[4];
+        bool live[4], ex[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const unsigned it = it0 + u * stride;
+            live[u] = it < items;
+            r[u] = live[u] ? (int)(it / (unsigned)rs) : 0;
+            p[u] = live[u] ? (int)(it - (unsigned)r[u] * (unsigned)rs) : 0;
         }
-        uint8_t *row = out + (int64_t)r * C;
-        const int bs = nstart[p];
-        const int rp = q - ins;  // first inserted base
-        for (int k = 0; k < kw; k++) row[bs + k] = k < ins ? b[rp + k] : (uint8_t)'-';
-        if (kc) row[bs + kw] = gap ? (uint8_t)'-' : b[q];
-        if (ex) row[bs + kw] = le < ins ? b[rp + le] : (uint8_t)'-';
+        unsigned ks[4], oc[4], op[4];
+        int nrow[4];
+        int64_t woff[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            ks[u] = kwslot[p[u]];
+            const uint16_t *rop = ops + (int64_t)r[u] * rs;
+            oc[u] = (r[u] > 0 && p[u] < m) ? rop[p[u]] : 0u;
+            op[u] = (r[u] > 0 && p[u] > 0) ? rop[p[u] - 1] : 0u;
+            nrow[u] = P.win_len[g0 + r[u]];
+            woff[u] = P.win_off[g0 + r[u]];
+            bs[u] = nstart[p[u]];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            kw[u] = (int)(ks[u] & 0x7fff); kc[u] = (int)(ks[u] >> 15);
+            ex[u] = p[u] == m && le >= 0;
+            live[u] = live[u] && (kw[u] != 0 || kc[u] || ex[u]);
+            if (r[u] == 0) { ins[u] = 0; q[u] = p[u]; gap[u] = 0; }
+            else {
+                const int pe = p[u] > 0 ? (int)(op[u] & 0x7fff) + ((op[u] >> 15) ? 0 : 1) : 0;
+                q[u] = p[u] < m ? (int)(oc[u] & 0x7fff) : nrow[u];
+                gap[u] = (int)(oc[u] >> 15);
+                ins[u] = q[u] - pe;
+            }
+        }
+        uint8_t cb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) cb[u] = (live[u] && kc[u] && !gap[u]) ? P.win[woff[u] + q[u]] : (uint8_t)'-';
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (!live[u]) continue;
+            const uint8_t *b = P.win + woff[u];
+            uint8_t *row = out + (int64_t)r[u] * C;
+            const int rp = q[u] - ins[u];  // first inserted base
+            for (int k = 0; k < kw[u]; k++) row[bs[u] + k] = k < ins[u] ? b[rp + k] : (uint8_t)'-';
+            if (kc[u]) row[bs[u] + kw[u]] = cb[u];
+            if (ex[u]) row[bs[u] + kw[u]] = le < ins[u] ? b[rp + le] : (uint8_t)'-';
+        }
     }
 }
 
