@@ -364,6 +364,37 @@ class Context:
         self._check(rc, "hite_find_copies_dev")
         return (n.value,) + tuple(o.value or 0 for o in outs)
 
+    def seed_segments(self, seg_len=1_000_000):
+        """-> (seg_chrom int32[nseg], seg_off int64[nseg]): the 'chr$offset' segment table of the packed genome"""
+        n = C.c_int32(0)
+        self._check(self.lib.hite_seed_segments(self.h, C.c_int64(seg_len), 0, None, None, C.byref(n)), "hite_seed_segments")
+        sc = np.zeros(max(1, n.value), dtype=np.int32)
+        so = np.zeros(max(1, n.value), dtype=np.int64)
+        self._check(self.lib.hite_seed_segments(self.h, C.c_int64(seg_len), n.value, _p(sc), _p(so), C.byref(n)), "hite_seed_segments")
+        return sc[:n.value], so[:n.value]
+
+    def seed_allvsall(self, seg_len=1_000_000, max_anchors=2_000_000_000, cap=None):
+        """all-vs-all seeding of the packed genome -> dict(qseg, sseg, qs, qe, ss, se, stats): the HSP table fmea_chain takes"""
+        if getattr(self, "_copy_state", None) is None:
+            self._copy_state = C.c_void_p(None)
+        stats = (C.c_int64 * 4)()
+        n = C.c_int64(0)
+        cap = int(cap) if cap is not None else 1 << 20
+        while True:
+            qseg = np.zeros(cap, dtype=np.int32); sseg = np.zeros(cap, dtype=np.int32)
+            qs = np.zeros(cap, dtype=np.int64); qe = np.zeros(cap, dtype=np.int64)
+            ss = np.zeros(cap, dtype=np.int64); se = np.zeros(cap, dtype=np.int64)
+            rc = self.lib.hite_seed_allvsall(self.h, C.byref(self._copy_state), C.c_int64(seg_len), C.c_int64(max_anchors), C.c_int64(cap),
+                                             _p(qseg), _p(sseg), _p(qs), _p(qe), _p(ss), _p(se), C.byref(n), stats)
+            if rc == -4 and n.value > cap:   # HITE_ECAP with the needed size known: retry once with room
+                cap = n.value + 16
+                continue
+            self._check(rc, "hite_seed_allvsall")
+            break
+        k = n.value
+        return {"qseg": qseg[:k].copy(), "sseg": sseg[:k].copy(), "qs": qs[:k].copy(), "qe": qe[:k].copy(), "ss": ss[:k].copy(),
+                "se": se[:k].copy(), "stats": tuple(int(x) for x in stats)}
+
     def copy_stats(self):
         """sizes of the last find_copies call: (candidate minimizers, index hits, diagonal clusters, copies before the cap)"""
         out = (C.c_int64 * 4)()

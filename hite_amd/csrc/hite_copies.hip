@@ -648,3 +648,295 @@ extern "C" int hite_copy_stats(void *state, int64_t out[4]) {
     for (int i = 0; i < 4; i++) out[i] = S->last[i];
     return HITE_OK;
 }
+
+// =====================================================================================================
+// All-vs-all seeding (stage 3.1): this build's GPU-native stage where the reference runs `blastn` of every
+// 1 Mbp segment file against every file (process_blast_alignments / sequence2sequenceBlastn,
+// /root/reference/module/Util.py:4724-4780, 4068-4091).  Definition: header of the twin in
+// oracle/hite_oracle_copies.c (orc_seed_allvsall), HIP == twin record for record.
+//   minimizers in position order (one radix sort of the index positions) -> run of equal hs >> 1 per seed ->
+//   anchor counts -> scan -> anchors (key = strand | diagonal, value = query position) -> stable radix sort on
+//   (strand, diagonal >> 6) -> cluster flags -> HSPs from the first / last anchor of each cluster -> cut at the
+//   1 Mbp segment borders -> stable sort by (query segment, subject segment).
+// Everything is sort / scan / segment work on 12-byte records: HBM streaming.
+// =====================================================================================================
+#define SEED_MAXOCC 1000
+#define SEED_GAP 300
+#define SEED_MINANCH 3
+#define SEED_MINSPAN 60
+
+__global__ void seed_posrank_kernel(int64_t M, const unsigned *__restrict__ idx_pos, unsigned long long *__restrict__ keys,
+                                    unsigned *__restrict__ vals) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) { keys[i] = idx_pos[i]; vals[i] = (unsigned)i; }
+}
+__global__ void seed_runflag_kernel(int64_t M, const unsigned *__restrict__ idx_hs, int32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) flag[i] = (i == 0 || (idx_hs[i] >> 1) != (idx_hs[i - 1] >> 1)) ? 1 : 0;
+}
+__global__ void seed_rid_fix_kernel(int64_t M, const int32_t *__restrict__ flag, int64_t *__restrict__ rid) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) rid[i] = rid[i] + flag[i] - 1;
+}
+// per seed (position order): partners = run size - 1 (0 when the run is too large)
+__global__ void seed_count_kernel(int64_t M, const unsigned *__restrict__ rank, const int64_t *__restrict__ rid,
+                                  const unsigned *__restrict__ run_first, int32_t *__restrict__ cnt) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M) return;
+    const unsigned i = rank[t];
+    const int64_t r = rid[i];
+    const unsigned occ = run_first[r + 1] - run_first[r];
+    cnt[t] = occ > SEED_MAXOCC ? 0 : (int32_t)(occ - 1);
+}
+__global__ void seed_anchor_kernel(int64_t M, int64_t G, const unsigned *__restrict__ rank, const int64_t *__restrict__ rid,
+                                   const unsigned *__restrict__ run_first, const unsigned *__restrict__ idx_hs,
+                                   const unsigned *__restrict__ idx_pos, const int32_t *__restrict__ cnt,
+                                   const int64_t *__restrict__ aoff, unsigned long long *__restrict__ akey, unsigned *__restrict__ aval) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= M || cnt[t] <= 0) return;
+    const unsigned i = rank[t];
+    const int64_t r = rid[i];
+    const unsigned lo = run_first[r], hi = run_first[r + 1];
+    const unsigned hq = idx_hs[i];
+    const long long pi = idx_pos[i];
+    int64_t o = aoff[t];
+    for (unsigned j = lo; j < hi; j++) {
+        if (j == i) continue;
+        const unsigned long long rel = (hq ^ idx_hs[j]) & 1u;
+        const long long pj = idx_pos[j];
+        const unsigned long long d = rel ? (unsigned long long)(pi + pj) : (unsigned long long)(pj - pi + G);
+        akey[o] = (rel << 34) | d;
+        aval[o] = (unsigned)pi;
+        o++;
+    }
+}
+__device__ __forceinline__ long long seed_pj(unsigned long long key, unsigned pi, long long G) {
+    const long long d = (long long)(key & 0x3ffffffffull);
+    return (key >> 34) ? d - (long long)pi : d - G + (long long)pi;
+}
+__global__ void seed_flag_kernel(int64_t na, int64_t G, const unsigned long long *__restrict__ akey, const unsigned *__restrict__ aval,
+                                 const int64_t *__restrict__ coff, int nc, int32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= na) return;
+    int f = 1;
+    if (i > 0) {
+        const unsigned long long a = akey[i - 1], b = akey[i];
+        const unsigned pa = aval[i - 1], pb = aval[i];
+        f = (a >> 6) != (b >> 6) || (long long)pb - (long long)pa > SEED_GAP || contig_of(coff, nc, pa) != contig_of(coff, nc, pb) ||
+            contig_of(coff, nc, seed_pj(a, pa, G)) != contig_of(coff, nc, seed_pj(b, pb, G));
+    }
+    flag[i] = f;
+}
+// one thread per cluster; EMIT = false counts the pieces, EMIT = true writes them at pfirst[cluster]
+template <bool EMIT>
+__global__ void seed_piece_kernel(int64_t ncl, int64_t G, int64_t seg_len, const unsigned long long *__restrict__ akey,
+                                  const unsigned *__restrict__ aval, const unsigned *__restrict__ c_first,
+                                  const int64_t *__restrict__ coff, int nc, const int32_t *__restrict__ seg_base,
+                                  int32_t *__restrict__ pcnt, const int64_t *__restrict__ pfirst,
+                                  unsigned long long *__restrict__ okey, unsigned *__restrict__ oval, int32_t *__restrict__ o_qseg,
+                                  int32_t *__restrict__ o_sseg, int64_t *__restrict__ o_qs, int64_t *__restrict__ o_qe,
+                                  int64_t *__restrict__ o_ss, int64_t *__restrict__ o_se) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= ncl) return;
+    const unsigned b = c_first[k], e = c_first[k + 1];
+    int n = 0;
+    const long long q0 = aval[b], q1 = (long long)aval[e - 1] + CK;
+    if (e - b >= SEED_MINANCH && q1 - q0 >= SEED_MINSPAN) {
+        const int rel = (int)(akey[b] >> 34);
+        const long long pf = seed_pj(akey[b], aval[b], G), pl = seed_pj(akey[e - 1], aval[e - 1], G);
+        const long long s0 = pf < pl ? pf : pl, s1 = (pf < pl ? pl : pf) + CK;
+        const int cq = contig_of(coff, nc, q0), cs = contig_of(coff, nc, pf);
+        const long long qb = coff[cq], sb = coff[cs];
+        int64_t o = EMIT ? pfirst[k] : 0;
+        for (long long a = q0; a < q1;) {
+            const long long qsegi = (a - qb) / seg_len;
+            long long bnd = qb + (qsegi + 1) * seg_len;
+            if (bnd > q1) bnd = q1;
+            long long u0, u1;
+            if (!rel) { u0 = s0 + (a - q0); u1 = s0 + (bnd - q0); } else { u0 = s1 - (bnd - q0); u1 = s1 - (a - q0); }
+            if (u0 < s0) u0 = s0;
+            if (u1 > s1) u1 = s1;
+            for (long long x = u0; x < u1;) {
+                const long long ssegi = (x - sb) / seg_len;
+                long long y = sb + (ssegi + 1) * seg_len;
+                if (y > u1) y = u1;
+                long long a2, b2;
+                if (!rel) { a2 = a + (x - u0); b2 = a + (y - u0); } else { a2 = a + (u1 - y); b2 = a + (u1 - x); }
+                if (a2 < a) a2 = a;
+                if (b2 > bnd) b2 = bnd;
+                if (b2 > a2) {
+                    if (EMIT) {
+                        const int32_t qsg = seg_base[cq] + (int32_t)qsegi, ssg = seg_base[cs] + (int32_t)ssegi;
+                        const long long qo = qb + qsegi * seg_len, so = sb + ssegi * seg_len;
+                        o_qseg[o] = qsg; o_sseg[o] = ssg; o_qs[o] = a2 - qo + 1; o_qe[o] = b2 - qo;
+                        if (!rel) { o_ss[o] = x - so + 1; o_se[o] = y - so; } else { o_ss[o] = y - so; o_se[o] = x - so + 1; }
+                        okey[o] = ((unsigned long long)(unsigned)qsg << 16) | (unsigned long long)(unsigned)ssg;
+                        oval[o] = (unsigned)o;
+                        o++;
+                    }
+                    n++;
+                }
+                x = y;
+            }
+            a = bnd;
+        }
+    }
+    if (!EMIT) pcnt[k] = n;
+}
+__global__ void seed_gather_kernel(int64_t n, const unsigned *__restrict__ perm, const int32_t *__restrict__ i_qseg,
+                                   const int32_t *__restrict__ i_sseg, const int64_t *__restrict__ i_qs, const int64_t *__restrict__ i_qe,
+                                   const int64_t *__restrict__ i_ss, const int64_t *__restrict__ i_se, int32_t *__restrict__ o_qseg,
+                                   int32_t *__restrict__ o_sseg, int64_t *__restrict__ o_qs, int64_t *__restrict__ o_qe,
+                                   int64_t *__restrict__ o_ss, int64_t *__restrict__ o_se) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const unsigned s = perm[i];
+    o_qseg[i] = i_qseg[s]; o_sseg[i] = i_sseg[s]; o_qs[i] = i_qs[s]; o_qe[i] = i_qe[s]; o_ss[i] = i_ss[s]; o_se[i] = i_se[s];
+}
+
+// segment table of the packed genome (host side): per contig ceil(len / seg_len) segments, ids in contig order
+extern "C" int hite_seed_segments(hite_ctx *ctx, int64_t seg_len, int32_t cap, int32_t *seg_chrom, int64_t *seg_off, int32_t *nseg_out) {
+    if (!ctx || !ctx->h_contig_off || seg_len <= 0 || !nseg_out) return HITE_EINVAL;
+    int n = 0;
+    for (int c = 0; c < ctx->n_contigs; c++) {
+        const int64_t L = ctx->h_contig_off[c + 1] - ctx->h_contig_off[c];
+        int64_t o = 0;
+        do {
+            if (seg_chrom && seg_off && n < cap) { seg_chrom[n] = c; seg_off[n] = o; }
+            n++;
+            o += seg_len;
+        } while (o < L);
+    }
+    *nseg_out = n;
+    return (seg_chrom && n > cap) ? HITE_ECAP : HITE_OK;
+}
+
+extern "C" int hite_seed_allvsall(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int64_t cap,
+                                  int32_t *qseg, int32_t *sseg, int64_t *qs, int64_t *qe, int64_t *ss, int64_t *se,
+                                  int64_t *n_out, int64_t *stats_out /* 4 x int64 or NULL: seeds, anchors, clusters, records */) {
+    if (!ctx || !ctx->d_bases || !state_io || seg_len <= 0 || !n_out || cap < 0) return HITE_EINVAL;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = nullptr;
+    if (!*state_io) CCHK(hite_copy_index_build(ctx, state_io, nullptr));
+    CopyState *S = (CopyState *)*state_io;
+    *n_out = 0;
+    const int64_t M = S->M, G = ctx->n_bases;
+    if (stats_out) { stats_out[0] = M; stats_out[1] = stats_out[2] = stats_out[3] = 0; }
+    if (M == 0) return HITE_OK;
+    CCHK(arena_reset(ctx, S->arena, true));
+    Arena &A = S->arena;
+    void *p;
+    // segment bases per contig
+    std::vector<int32_t> hbase(ctx->n_contigs + 1);
+    hbase[0] = 0;
+    for (int c = 0; c < ctx->n_contigs; c++) {
+        const int64_t L = ctx->h_contig_off[c + 1] - ctx->h_contig_off[c];
+        hbase[c + 1] = hbase[c] + (int32_t)(L > 0 ? (L + seg_len - 1) / seg_len : 1);
+    }
+    if (hbase[ctx->n_contigs] >= 65536) return HITE_EINVAL;   // segment ids are packed into 16 bits of the final sort key
+    int32_t *seg_base;
+    CCHK(arena_alloc(ctx, A, (size_t)(ctx->n_contigs + 1) * 4, &p)); seg_base = (int32_t *)p;
+    HITE_CHECK(ctx, hipMemcpyAsync(seg_base, hbase.data(), (size_t)(ctx->n_contigs + 1) * 4, hipMemcpyHostToDevice, st));
+    // seeds in position order
+    unsigned long long *pk; unsigned *rank;
+    CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 8, &p)); pk = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); rank = (unsigned *)p;
+    hipLaunchKernelGGL(seed_posrank_kernel, CGRID(M), 0, st, M, S->idx_pos, pk, rank);
+    {
+        Sorter so;
+        CCHK(sorter_from_arena(so, ctx, A, st, M));
+        CCHK(sorter_sort(so, pk, rank, M, 32));
+    }
+    // runs of equal hs >> 1 in the index
+    int32_t *rflag, *cnt; int64_t *rid, *bs, *aoff; unsigned *run_first;
+    CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); rflag = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 8, &p)); rid = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(M) * 8, &p)); bs = (int64_t *)p;
+    hipLaunchKernelGGL(seed_runflag_kernel, CGRID(M), 0, st, M, S->idx_hs, rflag);
+    CCHK(scan_excl_buf<int32_t>(ctx, bs, rflag, M, rid, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, rid + M, 8, hipMemcpyDeviceToDevice, st));
+    CCHK(read_back(ctx, S, st, 1));
+    const int64_t nrun = S->h_pin[0];
+    CCHK(arena_alloc(ctx, A, (size_t)(nrun + 2) * 4, &p)); run_first = (unsigned *)p;
+    hipLaunchKernelGGL(cluster_first_kernel, CGRID(M), 0, st, M, rflag, rid, run_first, nrun);
+    // rid is an EXCLUSIVE scan of the flags: the run of entry i is rid[i] + flag[i] - 1
+    hipLaunchKernelGGL(seed_rid_fix_kernel, CGRID(M), 0, st, M, rflag, rid);
+    CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); cnt = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 8, &p)); aoff = (int64_t *)p;
+    hipLaunchKernelGGL(seed_count_kernel, CGRID(M), 0, st, M, rank, rid, run_first, cnt);
+    CCHK(scan_excl_buf<int32_t>(ctx, bs, cnt, M, aoff, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, aoff + M, 8, hipMemcpyDeviceToDevice, st));
+    CCHK(read_back(ctx, S, st, 1));
+    const int64_t na = S->h_pin[0];
+    if (stats_out) stats_out[1] = na;
+    if (na == 0) return HITE_OK;
+    if (na > max_anchors || na >= 0xffffffffll) return HITE_ECAP;
+    unsigned long long *akey; unsigned *aval;
+    CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 8, &p)); akey = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 4, &p)); aval = (unsigned *)p;
+    hipLaunchKernelGGL(seed_anchor_kernel, CGRID(M), 0, st, M, G, rank, rid, run_first, S->idx_hs, S->idx_pos, cnt, aoff, akey, aval);
+    {
+        Sorter so;
+        CCHK(sorter_from_arena(so, ctx, A, st, na));
+        CCHK(sorter_sort_bits(so, akey, aval, na, 6, 35));
+    }
+    // clusters
+    int32_t *cflag; int64_t *cid, *bs2; unsigned *c_first;
+    CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 4, &p)); cflag = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(na + 2) * 8, &p)); cid = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(na) * 8, &p)); bs2 = (int64_t *)p;
+    hipLaunchKernelGGL(seed_flag_kernel, CGRID(na), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, cflag);
+    CCHK(scan_excl_buf<int32_t>(ctx, bs2, cflag, na, cid, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cid + na, 8, hipMemcpyDeviceToDevice, st));
+    CCHK(read_back(ctx, S, st, 1));
+    const int64_t ncl = S->h_pin[0];
+    if (stats_out) stats_out[2] = ncl;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 4, &p)); c_first = (unsigned *)p;
+    hipLaunchKernelGGL(cluster_first_kernel, CGRID(na), 0, st, na, cflag, cid, c_first, ncl);
+    // pieces: count, scan, emit
+    int32_t *pcnt; int64_t *pfirst, *bs3;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); pcnt = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 8, &p)); pfirst = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(ncl) * 8, &p)); bs3 = (int64_t *)p;
+    hipLaunchKernelGGL(seed_piece_kernel<false>, CGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs,
+                       seg_base, pcnt, (const int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr, (int32_t *)nullptr,
+                       (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
+    CCHK(scan_excl_buf<int32_t>(ctx, bs3, pcnt, ncl, pfirst, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, pfirst + ncl, 8, hipMemcpyDeviceToDevice, st));
+    CCHK(read_back(ctx, S, st, 1));
+    const int64_t np = S->h_pin[0];
+    *n_out = np;
+    if (stats_out) stats_out[3] = np;
+    if (np == 0) return HITE_OK;
+    if (np > cap) return HITE_ECAP;
+    if (np >= 0xffffffffll) return HITE_ECAP;
+    unsigned long long *okey; unsigned *oval; int32_t *t_qseg, *t_sseg, *f_qseg, *f_sseg; int64_t *t_q[4], *f_q[4];
+    CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); okey = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 4, &p)); oval = (unsigned *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 4, &p)); t_qseg = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 4, &p)); t_sseg = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 4, &p)); f_qseg = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 4, &p)); f_sseg = (int32_t *)p;
+    for (int i = 0; i < 4; i++) {
+        CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); t_q[i] = (int64_t *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); f_q[i] = (int64_t *)p;
+    }
+    hipLaunchKernelGGL(seed_piece_kernel<true>, CGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs,
+                       seg_base, pcnt, (const int64_t *)pfirst, okey, oval, t_qseg, t_sseg, t_q[0], t_q[1], t_q[2], t_q[3]);
+    {
+        Sorter so;
+        CCHK(sorter_from_arena(so, ctx, A, st, np));
+        CCHK(sorter_sort(so, okey, oval, np, 32));
+    }
+    hipLaunchKernelGGL(seed_gather_kernel, CGRID(np), 0, st, np, oval, t_qseg, t_sseg, t_q[0], t_q[1], t_q[2], t_q[3], f_qseg, f_sseg, f_q[0],
+                       f_q[1], f_q[2], f_q[3]);
+    HITE_CHECK(ctx, hipGetLastError());
+    HITE_CHECK(ctx, hipStreamSynchronize(st));
+    HITE_CHECK(ctx, hipMemcpy(qseg, f_qseg, (size_t)np * 4, hipMemcpyDeviceToHost));
+    HITE_CHECK(ctx, hipMemcpy(sseg, f_sseg, (size_t)np * 4, hipMemcpyDeviceToHost));
+    HITE_CHECK(ctx, hipMemcpy(qs, f_q[0], (size_t)np * 8, hipMemcpyDeviceToHost));
+    HITE_CHECK(ctx, hipMemcpy(qe, f_q[1], (size_t)np * 8, hipMemcpyDeviceToHost));
+    HITE_CHECK(ctx, hipMemcpy(ss, f_q[2], (size_t)np * 8, hipMemcpyDeviceToHost));
+    HITE_CHECK(ctx, hipMemcpy(se, f_q[3], (size_t)np * 8, hipMemcpyDeviceToHost));
+    return HITE_OK;
+}

@@ -93,18 +93,19 @@ static void sorter_free(Sorter &S) {
     if (S.offs) (void)hipFree(S.offs);
     if (S.bs) (void)hipFree(S.bs);
 }
-// sorts (keys, vals) in place (ping-pong through the sorter's buffers), bits [0, nbits)
-static int sorter_sort(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int nbits) {
+// sorts (keys, vals) in place (ping-pong through the sorter's buffers) on the key bits [lo_bit, hi_bit), stable
+static int sorter_sort_bits(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int lo_bit, int hi_bit) {
     if (n <= 1) return HITE_OK;
     int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
     unsigned long long *ka = keys, *kb = S.k2;
     unsigned *va = vals, *vb = S.v2;
-    int passes = (nbits + 7) / 8;
+    int passes = (hi_bit - lo_bit + 7) / 8;
     for (int p = 0; p < passes; p++) {
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(256), 0, S.st, ka, n, p * 8, nblocks, S.hist);
+        const int sh = lo_bit + p * 8;
+        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
         int rc = scan_excl_buf<int32_t>(S.ctx, S.bs, S.hist, (int64_t)256 * nblocks, S.offs, S.st);
         if (rc) return rc;
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, p * 8, nblocks, S.offs);
+        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         unsigned long long *tk = ka; ka = kb; kb = tk;
         unsigned *tv = va; va = vb; vb = tv;
     }
@@ -115,4 +116,7 @@ static int sorter_sort(Sorter &S, unsigned long long *keys, unsigned *vals, int6
     HITE_CHECK(S.ctx, hipGetLastError());
     return HITE_OK;
 }
-
+// bits [0, nbits)
+static int sorter_sort(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int nbits) {
+    return sorter_sort_bits(S, keys, vals, n, 0, nbits);
+}

@@ -4,10 +4,12 @@
 
   <tmp_output_dir>/longest_repeats_{i}.fa, longest_repeats_{i}.flanked.fa
 
-GPU: FMEA chaining + de-duplication (get_longest_repeats_v4) and the flank gather.  The all-vs-all
-seed-and-extend that feeds FMEA is `blastn` in the reference (Util.py:4068) and is NOT part of this build
-yet: pass the HSP table with `--hsp <blast6 file(s)>` (what sequence2sequenceBlastn writes, one file per
-query FASTA as process_blast_alignments concatenates them, Util.py:4750-4769)."""
+GPU: the all-vs-all search of the chunk's 1 Mbp segments against each other (the build's own stage where the
+reference runs `blastn`, Util.py:4068 -- hite_seed_allvsall), FMEA chaining + de-duplication
+(get_longest_repeats_v4) and the flank gather.  `--hsp <blast6 file(s)>` (an extension of this build) takes
+the HSP tables from real blastn runs instead (what sequence2sequenceBlastn writes, one file per query FASTA as
+process_blast_alignments concatenates them, Util.py:4750-4769).  Tandem-repeat masking (`trf`, Util.py:2855)
+stays an external pre-step: run it on the chunk first if wanted."""
 import argparse
 import os
 import sys
@@ -61,10 +63,15 @@ def main():
     os.makedirs(out_dir, exist_ok=True)
     lr = os.path.join(out_dir, "longest_repeats_%s.fa" % a.ref_index)
     fl = os.path.join(out_dir, "longest_repeats_%s.flanked.fa" % a.ref_index)
+    if a.recover and os.path.exists(lr) and os.path.exists(fl) and util.read_fasta(fl)[0]:
+        return 0
     if not a.hsp:
-        sys.stderr.write("coarse_boundary (MI355X path): the all-vs-all seeding stage (blastn in the reference) is not built yet; "
-                         "pass the HSP tables with --hsp\n")
-        return 2
+        tmp = lr + ".tmp"
+        util.determine_repeat_boundary_v5(a.g, tmp, a.fixed_extend_base_threshold, a.max_repeat_len, a.r)
+        os.replace(tmp, lr)
+        util.flanking_seq(lr, fl + ".tmp", a.r, a.flanking_len)
+        os.replace(fl + ".tmp", fl)
+        return 0
     ctx = util.set_reference(a.r)
     _names, ref = util.read_fasta(a.r)
     final = {}

@@ -139,6 +139,68 @@ def search_boundary_homo_v4(valid_col_threshold, pos, matrix, row_num, col_num, 
 
 
 # ---- a-6 ---------------------------------------------------------------------------------------------
+def split_and_store_sequences(names, contigs, base_threshold):
+    """grouping rule of split_and_store_sequences (/root/reference/module/Util.py:4987-5012) without the files:
+    consecutive sequences are collected until their total reaches base_threshold -> list of name lists (the reference's
+    {i}_target.fa query / target files)."""
+    groups, cur, count = [], [], 0
+    for name in names:
+        cur.append(name)
+        count += len(contigs[name])
+        if count >= base_threshold:
+            groups.append(cur)
+            cur, count = [], 0
+    if cur:
+        groups.append(cur)
+    return groups
+
+
+def determine_repeat_boundary_v5(repeats_path, longest_repeats_path, fixed_extend_base_threshold, max_single_repeat_len, reference,
+                                 device=0):
+    """determine_repeat_boundary_v5 (Util.py:4637) from the all-vs-all search on: process_blast_alignments (:4724) +
+    get_longest_repeats_v4 per query file + generate_final_result (:4783).  repeats_path = the chunk FASTA of
+    'chr$offset' segments; the all-vs-all stage is hite_seed_allvsall (the build's blastn stand-in), FMEA runs per
+    query file as in the reference (each call has its own first-come de-duplication), results are unioned by name in
+    query-file order (the canonical replacement of the reference's as_completed order)."""
+    ctx = get_ctx(device)
+    names, contigs = read_fasta(repeats_path)
+    if not names:
+        store_fasta({}, longest_repeats_path)
+        return longest_repeats_path
+    ctx.genome_pack([contigs[n] for n in names])
+    ctx._copy_state = None
+    _PACKED["path"] = None   # the reference genome has to be packed again by whoever needs it next
+    seg_len = max(len(contigs[n]) for n in names)
+    tab = ctx.seed_allvsall(seg_len=max(seg_len, 1))
+    chroms, seg_chrom, seg_off = {}, [], []
+    for n in names:
+        c, off = n.split("$")
+        chroms.setdefault(c, len(chroms))
+        seg_chrom.append(chroms[c])
+        seg_off.append(int(off))
+    inv = {v: k for k, v in chroms.items()}
+    index_of = {n: i for i, n in enumerate(names)}
+    qseg = tab["qseg"]
+    final = []
+    seen = set()
+    for group in split_and_store_sequences(names, contigs, 1_000_000):
+        ids = np.array([index_of[n] for n in group], dtype=np.int64)
+        sel = np.isin(qseg, ids)
+        if not sel.any():
+            continue
+        oc, os_, oe = ctx.fmea_chain(tab["qseg"][sel], tab["sseg"][sel], tab["qs"][sel], tab["qe"][sel], tab["ss"][sel], tab["se"][sel],
+                                     seg_chrom, seg_off, fixed_extend_base_threshold, max_single_repeat_len)
+        for c, a, b in zip(oc, os_, oe):
+            name = "%s:%d-%d" % (inv[int(c)], a, b)
+            if name not in seen:
+                seen.add(name)
+                final.append((name, inv[int(c)], int(a), int(b)))
+    _rn, ref = read_fasta(reference)
+    out = {name: ref[c][a:b] for name, c, a, b in final}
+    store_fasta(out, longest_repeats_path)
+    return longest_repeats_path
+
+
 def flanking_seq(longest_repeats_path, longest_repeats_flanked_path, reference, flanking_len):
     """Util.py:4614-4634: `chr:start-end` (0-based half-open) -> `chr:(s+1-flank)-(e+flank)` with the
     window clamped into the contig; bases come from the packed genome."""

@@ -170,6 +170,19 @@ void hite_copy_index_release(void *state);
 /* sizes of the last hite_find_copies[_dev] call on this index (diagnostics / roofline accounting):
  * out = {candidate minimizers, index hits, diagonal clusters, copies before the 300-per-candidate cap} */
 int hite_copy_stats(void *state, int64_t out[4]);
+
+/* ---- all-vs-all seeding (stage 3.1) --- where the reference runs blastn of every 1 Mbp segment file against every
+ * file: process_blast_alignments / sequence2sequenceBlastn  Util.py:4724-4780, 4068-4091 (rmblast is third-party and
+ * absent: this is the build's own stage, pinned against its CPU twin orc_seed_allvsall) ---------------------------------
+ * Uses the minimizer index of the packed genome (*state_io as for hite_find_copies; built on demand).  Output = the HSP
+ * table hite_fmea_chain consumes (cols 0,1,6,7,8,9 of -outfmt 6): ids of the 'chr$offset' segments of seg_len bases
+ * (hite_seed_segments gives the table, split_genome_chunks.py:41-52), 1-based inclusive coordinates inside the segment,
+ * ss > se for reverse-strand hits; ordered by (query segment, subject segment).  *n_out is set even on HITE_ECAP.
+ * max_anchors bounds the device memory of the anchor sort (24 B per anchor).  stats_out (may be NULL) =
+ * {seeds, anchors, clusters, records}. */
+int hite_seed_segments(hite_ctx *ctx, int64_t seg_len, int32_t cap, int32_t *seg_chrom, int64_t *seg_off, int32_t *nseg_out);
+int hite_seed_allvsall(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int64_t cap, int32_t *qseg,
+                       int32_t *sseg, int64_t *qs, int64_t *qe, int64_t *ss, int64_t *se, int64_t *n_out, int64_t *stats_out);
 int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
                      int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
                      int32_t *anchors, int64_t *n_out);

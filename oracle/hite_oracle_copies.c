@@ -222,3 +222,163 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
     free(idx); free(hits); free(cps);
     return nout;
 }
+
+/* ======================================================================================================
+ * All-vs-all seeding: CPU twin of hite_seed_allvsall (hite_amd/csrc/hite_copies.hip), the build's OWN stage
+ * where the reference runs `blastn -evalue 1e-20 -outfmt 6` of every 1 Mbp segment file against every file
+ * (process_blast_alignments / sequence2sequenceBlastn, /root/reference/module/Util.py:4724-4780, 4068-4091).
+ * rmblast 2.14.0 is third-party and absent: PARITY UNPINNED at that boundary; pinned is HIP == this twin.
+ *
+ * Definition (shared with the HIP kernels; index and minimizers as above)
+ *   Every genome minimizer, taken in position order, is a query seed; its partners are the index entries
+ *   with the same hs >> 1 at another position, in index order (skipped when the run holds more than
+ *   SEED_MAXOCC = 1000 entries).  A pair is an anchor (pi, pj, rel = strand_i ^ strand_j) on the diagonal
+ *   d = pj - pi + G (rel 0) or pi + pj (rel 1).  Anchors are ordered by (rel, d >> 6), ties in generation
+ *   order (a stable sort), and cut into clusters where rel, d >> 6, the contig of pi or of pj changes or pi
+ *   advances by more than SEED_GAP = 300.  A cluster with >= 3 anchors and a query span
+ *   (last pi + K - first pi) >= 60 is an HSP: query [first pi, last pi + K), subject
+ *   [min(pj_first, pj_last), max(pj_first, pj_last) + K).  HSPs are cut at the borders of the seg_len
+ *   segments ('chr$offset' naming of split_genome_chunks.py:41-52) of the query, then of the subject, the
+ *   other side following linearly (reversed for rel 1) and clamped; records = (qseg, sseg, qs, qe, ss, se),
+ *   1-based inclusive inside the segment, ss > se for rel 1; output order = (qseg, sseg), ties in cluster
+ *   order (stable).
+ * ====================================================================================================== */
+#define SEED_MAXOCC 1000
+#define SEED_GAP 300
+#define SEED_MINANCH 3
+#define SEED_MINSPAN 60
+
+typedef struct { uint64_t key; uint32_t pi; int64_t ord; } anchor_t;
+static int cmp_anchor(const void *a, const void *b) {
+    const anchor_t *x = (const anchor_t *)a, *y = (const anchor_t *)b;
+    uint64_t kx = x->key >> 6, ky = y->key >> 6;
+    if (kx != ky) return kx < ky ? -1 : 1;
+    if (x->ord != y->ord) return x->ord < y->ord ? -1 : 1;
+    return 0;
+}
+static int cmp_mini_pos(const void *a, const void *b) {
+    const mini_t *x = (const mini_t *)a, *y = (const mini_t *)b;
+    if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
+    return 0;
+}
+typedef struct { int32_t qseg, sseg; int64_t qs, qe, ss, se; int64_t ord; } hsp_t;
+static int cmp_hsp(const void *a, const void *b) {
+    const hsp_t *x = (const hsp_t *)a, *y = (const hsp_t *)b;
+    if (x->qseg != y->qseg) return x->qseg < y->qseg ? -1 : 1;
+    if (x->sseg != y->sseg) return x->sseg < y->sseg ? -1 : 1;
+    if (x->ord != y->ord) return x->ord < y->ord ? -1 : 1;
+    return 0;
+}
+
+/* segment table of a genome: per contig ceil(len / seg_len) segments; returns nseg (seg_chrom / seg_off may be NULL) */
+int orc_seed_segments(const int64_t *contig_off, int ncontig, int64_t seg_len, int32_t *seg_chrom, int64_t *seg_off, int cap) {
+    int n = 0;
+    for (int c = 0; c < ncontig; c++) {
+        int64_t L = contig_off[c + 1] - contig_off[c];
+        for (int64_t o = 0; o < L || (L == 0 && o == 0); o += seg_len) {
+            if (seg_chrom && n < cap) { seg_chrom[n] = c; seg_off[n] = o; }
+            n++;
+            if (L == 0) break;
+        }
+    }
+    return n;
+}
+
+int64_t orc_seed_allvsall(const uint8_t *genome, const int64_t *contig_off, int ncontig, int64_t seg_len, int64_t cap,
+                          int32_t *qseg, int32_t *sseg, int64_t *qs, int64_t *qe, int64_t *ss, int64_t *se) {
+    if (ncontig <= 0 || seg_len <= 0) return ORC_EINVAL;
+    const int64_t G = contig_off[ncontig];
+    int64_t M = 0;
+    for (int c = 0; c < ncontig; c++) M += minimizers(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], NULL);
+    mini_t *idx = (mini_t *)malloc(sizeof(mini_t) * (M + 1)), *byp = (mini_t *)malloc(sizeof(mini_t) * (M + 1));
+    int64_t k = 0;
+    for (int c = 0; c < ncontig; c++) k += minimizers(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], idx + k);
+    memcpy(byp, idx, sizeof(mini_t) * M);
+    qsort(idx, M, sizeof(mini_t), cmp_mini);
+    qsort(byp, M, sizeof(mini_t), cmp_mini_pos);
+    int *seg_base = (int *)malloc(sizeof(int) * (ncontig + 1));
+    seg_base[0] = 0;
+    for (int c = 0; c < ncontig; c++) {
+        int64_t L = contig_off[c + 1] - contig_off[c];
+        seg_base[c + 1] = seg_base[c] + (int)(L > 0 ? (L + seg_len - 1) / seg_len : 1);
+    }
+    /* anchors */
+    int64_t acap = 1 << 16, na = 0;
+    anchor_t *an = (anchor_t *)malloc(sizeof(anchor_t) * acap);
+    for (int64_t t = 0; t < M; t++) {
+        uint32_t h31 = byp[t].hs >> 1;
+        int64_t lo = 0, hi = M;
+        while (lo < hi) { int64_t mid = (lo + hi) / 2; if ((idx[mid].hs >> 1) < h31) lo = mid + 1; else hi = mid; }
+        int64_t e = lo;
+        while (e < M && (idx[e].hs >> 1) == h31) e++;
+        if (e - lo > SEED_MAXOCC) continue;
+        for (int64_t i = lo; i < e; i++) {
+            if (idx[i].pos == byp[t].pos) continue;
+            if (na == acap) { acap *= 2; an = (anchor_t *)realloc(an, sizeof(anchor_t) * acap); }
+            uint64_t rel = (byp[t].hs ^ idx[i].hs) & 1u;
+            uint64_t d = rel ? (uint64_t)(byp[t].pos + idx[i].pos) : (uint64_t)(idx[i].pos - byp[t].pos + G);
+            an[na].key = (rel << 34) | d; an[na].pi = (uint32_t)byp[t].pos; an[na].ord = na;
+            na++;
+        }
+    }
+    qsort(an, na, sizeof(anchor_t), cmp_anchor);
+    /* clusters -> HSP pieces */
+    int64_t hcap = 1 << 12, nh = 0;
+    hsp_t *hs = (hsp_t *)malloc(sizeof(hsp_t) * hcap);
+    int64_t i = 0;
+    while (i < na) {
+#define AN_PJ(a) ((int64_t)(((a).key >> 34) ? (int64_t)((a).key & 0x3ffffffffull) - (int64_t)(a).pi : (int64_t)((a).key & 0x3ffffffffull) - G + (int64_t)(a).pi))
+        int64_t j = i + 1;
+        int cq = contig_of(contig_off, ncontig, an[i].pi), cs = contig_of(contig_off, ncontig, AN_PJ(an[i]));
+        while (j < na && (an[j].key >> 6) == (an[i].key >> 6) && (int64_t)an[j].pi - (int64_t)an[j - 1].pi <= SEED_GAP &&
+               contig_of(contig_off, ncontig, an[j].pi) == cq && contig_of(contig_off, ncontig, AN_PJ(an[j])) == cs) j++;
+        int64_t cnt = j - i;
+        int64_t q0 = an[i].pi, q1 = (int64_t)an[j - 1].pi + CK;
+        if (cnt >= SEED_MINANCH && q1 - q0 >= SEED_MINSPAN) {
+            int rel = (int)(an[i].key >> 34);
+            int64_t pf = AN_PJ(an[i]), pl = AN_PJ(an[j - 1]);
+            int64_t s0 = pf < pl ? pf : pl, s1 = (pf < pl ? pl : pf) + CK;
+            int64_t qb = contig_off[cq], sb = contig_off[cs];
+            /* query pieces */
+            for (int64_t a = q0; a < q1;) {
+                int64_t qsegi = (a - qb) / seg_len;
+                int64_t b = qb + (qsegi + 1) * seg_len;
+                if (b > q1) b = q1;
+                /* subject range of [a, b) */
+                int64_t u0, u1;
+                if (!rel) { u0 = s0 + (a - q0); u1 = s0 + (b - q0); } else { u0 = s1 - (b - q0); u1 = s1 - (a - q0); }
+                if (u0 < s0) u0 = s0;
+                if (u1 > s1) u1 = s1;
+                for (int64_t x = u0; x < u1;) {
+                    int64_t ssegi = (x - sb) / seg_len;
+                    int64_t y = sb + (ssegi + 1) * seg_len;
+                    if (y > u1) y = u1;
+                    /* query sub-range of subject piece [x, y) */
+                    int64_t a2, b2;
+                    if (!rel) { a2 = a + (x - u0); b2 = a + (y - u0); } else { a2 = a + (u1 - y); b2 = a + (u1 - x); }
+                    if (a2 < a) a2 = a;
+                    if (b2 > b) b2 = b;
+                    if (b2 > a2) {
+                        if (nh == hcap) { hcap *= 2; hs = (hsp_t *)realloc(hs, sizeof(hsp_t) * hcap); }
+                        hsp_t *o = &hs[nh];
+                        o->qseg = seg_base[cq] + (int32_t)qsegi; o->sseg = seg_base[cs] + (int32_t)ssegi;
+                        int64_t qo = qb + qsegi * seg_len, so = sb + ssegi * seg_len;
+                        o->qs = a2 - qo + 1; o->qe = b2 - qo;
+                        if (!rel) { o->ss = x - so + 1; o->se = y - so; } else { o->ss = y - so; o->se = x - so + 1; }
+                        o->ord = nh;
+                        nh++;
+                    }
+                    x = y;
+                }
+                a = b;
+            }
+        }
+        i = j;
+    }
+    qsort(hs, nh, sizeof(hsp_t), cmp_hsp);
+    int64_t rc = nh;
+    if (nh > cap) rc = ORC_ECAP;
+    else for (int64_t t = 0; t < nh; t++) { qseg[t] = hs[t].qseg; sseg[t] = hs[t].sseg; qs[t] = hs[t].qs; qe[t] = hs[t].qe; ss[t] = hs[t].ss; se[t] = hs[t].se; }
+    free(idx); free(byp); free(seg_base); free(an); free(hs);
+    return rc;
+}

@@ -225,3 +225,31 @@ def find_copies(contigs, cands):
                               _ptr(cf, i32p), _ptr(ct, i32p), _ptr(s1, i64p), _ptr(e1, i64p), _ptr(mn, u8p), _ptr(an, i32p))
     assert n >= 0, n
     return [[(int(ct[i]), int(s1[i]), int(e1[i]), int(mn[i]), int(an[i])) for i in range(cf[c], cf[c + 1])] for c in range(len(cb))]
+
+
+def seed_allvsall(contigs, seg_len=1_000_000):
+    """this build's blastn stand-in (twin): -> dict(qseg, sseg, qs, qe, ss, se) + the segment table"""
+    gb = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]
+    coff = np.zeros(len(gb) + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in gb], out=coff[1:])
+    gbuf = np.frombuffer(b"".join(gb) + b"\0", dtype=np.uint8)
+    L = lib()
+    L.orc_seed_allvsall.restype = C.c_int64
+    cap = 1 << 16
+    while True:
+        qseg = np.zeros(cap, dtype=np.int32); sseg = np.zeros(cap, dtype=np.int32)
+        qs = np.zeros(cap, dtype=np.int64); qe = np.zeros(cap, dtype=np.int64)
+        ss = np.zeros(cap, dtype=np.int64); se = np.zeros(cap, dtype=np.int64)
+        n = L.orc_seed_allvsall(_ptr(gbuf, u8p), _ptr(coff, i64p), len(gb), C.c_int64(seg_len), C.c_int64(cap), _ptr(qseg, i32p),
+                                _ptr(sseg, i32p), _ptr(qs, i64p), _ptr(qe, i64p), _ptr(ss, i64p), _ptr(se, i64p))
+        if n == -1001:
+            cap *= 4
+            continue
+        assert n >= 0, n
+        break
+    nseg = L.orc_seed_segments(_ptr(coff, i64p), len(gb), C.c_int64(seg_len), None, None, 0)
+    sc = np.zeros(nseg, dtype=np.int32)
+    so = np.zeros(nseg, dtype=np.int64)
+    L.orc_seed_segments(_ptr(coff, i64p), len(gb), C.c_int64(seg_len), _ptr(sc, i32p), _ptr(so, i64p), nseg)
+    return {"qseg": qseg[:n].copy(), "sseg": sseg[:n].copy(), "qs": qs[:n].copy(), "qe": qe[:n].copy(), "ss": ss[:n].copy(),
+            "se": se[:n].copy(), "seg_chrom": sc, "seg_off": so}

@@ -8,7 +8,7 @@ def make(seed, n_fam=12, n_chr=3, chr_len=120_000, flank_ok=60):
     rng = np.random.default_rng(seed)
     chroms = [list(casegen.rand_seq(rng, chr_len)) for _ in range(n_chr)]
     used = [np.zeros(chr_len, dtype=bool) for _ in range(n_chr)]
-    cands, copies = [], []
+    cands, copies, truth, divs = [], [], [], []
     for f in range(n_fam):
         L = int(rng.choice([160, 420, 900, 1500, 2600]))
         ncopy = int(rng.choice([1, 3, 8, 25, 60, 130]))
@@ -54,6 +54,8 @@ def make(seed, n_fam=12, n_chr=3, chr_len=120_000, flank_ok=60):
         if mn:
             seq = casegen.revcomp(seq)
         cands.append(seq)
+        truth.append(list(fam))
+        divs.append(div)
         # a copy finder reports slightly fuzzy ends; keep a few off-contig / too-short entries as well
         cp = []
         for (c2, a, b, m2) in fam:
@@ -62,4 +64,4 @@ def make(seed, n_fam=12, n_chr=3, chr_len=120_000, flank_ok=60):
             cp.append((0, 5, 5 + L, 0))  # runs off the contig start -> skipped (Util.py:8103)
         copies.append(cp)
     contigs = ["".join(c) for c in chroms]
-    return {"contigs": contigs, "cands": cands, "copies": copies}
+    return {"contigs": contigs, "cands": cands, "copies": copies, "truth": truth, "divs": divs}

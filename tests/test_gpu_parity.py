@@ -488,3 +488,72 @@ def test_star_msa_sparse_fused(ctx):
         exp = np.ascontiguousarray(exp_full[:, keep])
         assert m is not None and m.shape == exp.shape, (m.shape if m is not None else None, exp.shape, len(g))
         assert np.array_equal(m, exp)
+
+
+def test_seed_allvsall_vs_twin(ctx):
+    """all-vs-all seeding (stage 3.1, the build's blastn stand-in): HIP == twin, record for record, incl. segment splits;
+    the table drives FMEA to the same intervals as the oracle's FMEA on the twin's table"""
+    import synth_small
+
+    for seed, nf, seg in ((31, 10, 100_000), (7, 14, 37_000), (19, 6, 1_000_000)):
+        g = synth_small.make(seed, n_fam=nf, n_chr=2, chr_len=260_000)
+        ctx.genome_pack(g["contigs"])
+        ctx._copy_state = None
+        got = ctx.seed_allvsall(seg_len=seg)
+        exp = O.seed_allvsall(g["contigs"], seg_len=seg)
+        sc, so = ctx.seed_segments(seg)
+        assert np.array_equal(sc, exp["seg_chrom"]) and np.array_equal(so, exp["seg_off"])
+        for k in ("qseg", "sseg", "qs", "qe", "ss", "se"):
+            assert np.array_equal(got[k], exp[k]), (seed, k, len(got[k]), len(exp[k]))
+        assert len(got["qseg"]) > 50 and got["stats"][3] == len(got["qseg"])
+    # seeding -> FMEA on the GPU == oracle FMEA on the same table
+    oc, os_, oe = ctx.fmea_chain(got["qseg"], got["sseg"], got["qs"], got["qe"], got["ss"], got["se"], sc, so, 2000, 30000)
+    h = dict(got)
+    h["seg_chrom"], h["seg_off"], h["chrom_names"] = sc, so, ["chr%d" % (i + 1) for i in range(2)]
+    exp_names = O.fmea(h, 2000, 30000)
+    assert ["chr%d:%d-%d" % (c + 1, a, b) for c, a, b in zip(oc, os_, oe)] == exp_names and len(exp_names) > 3
+
+
+def test_coarse_boundary_script_end_to_end(ctx, tmp_path):
+    """stage 3.1 without external tools: chunk of 'chr$offset' segments -> all-vs-all seeding -> FMEA -> longest_repeats +
+    flanked FASTA; the planted multi-copy families come out as candidate repeats"""
+    import os
+    import subprocess
+    import sys as _sys
+
+    import synth_small
+    from hite_amd import util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = synth_small.make(43, n_fam=10, n_chr=2, chr_len=300_000)
+    ref = tmp_path / "genome.fa"
+    ref.write_text("".join(">chr%d\n%s\n" % (i + 1, s) for i, s in enumerate(g["contigs"])))
+    cut = tmp_path / "genome.cut0.fa"
+    seg = 100_000
+    with open(cut, "w") as f:
+        for i, s in enumerate(g["contigs"]):
+            for o in range(0, len(s), seg):
+                f.write(">chr%d$%d\n%s\n" % (i + 1, o, s[o:o + seg]))
+    out = tmp_path / "out"
+    rc = subprocess.run([_sys.executable, root + "/hite_amd/scripts/coarse_boundary.py", "-g", str(cut), "-r", str(ref),
+                         "--tmp_output_dir", str(out), "--ref_index", "0", "--fixed_extend_base_threshold", "1000",
+                         "--max_repeat_len", "30000", "--thread", "1", "--flanking_len", "50", "--recover", "0"],
+                        capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stderr[-2000:]
+    names, seqs = util.read_fasta(str(out / "longest_repeats_0.fa"))
+    fn, _fc = util.read_fasta(str(out / "longest_repeats_0.flanked.fa"))
+    assert len(names) == len(fn) and len(names) > 5
+    iv = []
+    for n in names:
+        c, pos = n.split(":")
+        a, b = map(int, pos.split("-"))
+        assert seqs[n] == g["contigs"][int(c[3:]) - 1][a:b] and 80 <= b - a < 30000
+        iv.append((int(c[3:]) - 1, a, b))
+    hit = tot = 0
+    for fam, div in zip(g["truth"], g["divs"]):
+        if len(fam) < 3 or div > 0.08:
+            continue
+        tot += 1
+        c0, a0, b0, _m = fam[0]
+        hit += any(c == c0 and min(b, b0) - max(a, a0) > 0.7 * (b0 - a0) for c, a, b in iv)
+    assert tot >= 3 and hit >= tot - 1, (hit, tot)

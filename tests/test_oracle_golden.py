@@ -119,3 +119,41 @@ def test_gather_golden():
             lo, hi, ns, ne = O.flanking_seq(s, e, len(contigs[chrom]), 50)
             assert "%s:%d-%d" % (chrom, ns, ne) == oname
             assert contigs[chrom][lo:hi] == oseq
+
+
+def test_seed_allvsall_twin_recovers_planted_pairs():
+    """own-design stage (blastn stand-in): planted copies that differ by <= ~8 % (any two copies of a 2 % family, the
+    unmutated copy against the others of an 8 % family) are joined by HSPs that cover most of the query copy, on the right
+    strand; records respect the blast6 conventions and segment borders"""
+    import synth_small
+
+    g = synth_small.make(31, n_fam=10, n_chr=2, chr_len=260_000)
+    seg_len = 100_000
+    h = O.seed_allvsall(g["contigs"], seg_len=seg_len)
+    n = len(h["qseg"])
+    assert n > 50
+    assert (h["qs"] >= 1).all() and (h["qe"] <= seg_len).all() and (h["qs"] <= h["qe"]).all()
+    assert (np.minimum(h["ss"], h["se"]) >= 1).all() and (np.maximum(h["ss"], h["se"]) <= seg_len).all()
+    key = h["qseg"].astype(np.int64) * 65536 + h["sseg"]
+    assert (np.diff(key) >= 0).all()
+    # genome coordinates of every record
+    qchr, schr = h["seg_chrom"][h["qseg"]], h["seg_chrom"][h["sseg"]]
+    qa, qb = h["seg_off"][h["qseg"]] + h["qs"], h["seg_off"][h["qseg"]] + h["qe"]
+    sa = h["seg_off"][h["sseg"]] + np.minimum(h["ss"], h["se"])
+    sb = h["seg_off"][h["sseg"]] + np.maximum(h["ss"], h["se"])
+    minus = h["ss"] > h["se"]
+    found = total = 0
+    for fam, div in zip(g["truth"], g["divs"]):
+        if div > 0.08 or len(fam) < 2:
+            continue
+        for i, (c1, a1, b1, m1) in enumerate(fam[:6]):
+            for j, (c2, a2, b2, m2) in enumerate(fam[:6]):
+                if i == j or (div > 0.02 and i != 0 and j != 0):
+                    continue
+                total += 1
+                sel = (qchr == c1) & (schr == c2) & (qa < b1) & (qb > a1) & (sa < b2) & (sb > a2) & (minus == (m1 != m2))
+                cov = 0
+                if sel.any():
+                    cov = int((np.minimum(qb[sel], b1) - np.maximum(qa[sel], a1) + 1).sum())
+                found += cov >= 0.6 * (b1 - a1 + 1)
+    assert total > 20 and found >= 0.9 * total, (found, total)
