@@ -664,6 +664,7 @@ extern "C" int hite_copy_stats(void *state, int64_t out[4]) {
 #define SEED_GAP 300
 #define SEED_MINANCH 3
 #define SEED_MINSPAN 60
+#define SEED_MINPIECE 20
 
 __global__ void seed_posrank_kernel(int64_t M, const unsigned *__restrict__ idx_pos, unsigned long long *__restrict__ keys,
                                     unsigned *__restrict__ vals) {
@@ -764,7 +765,7 @@ __global__ void seed_piece_kernel(int64_t ncl, int64_t G, int64_t seg_len, const
                 if (!rel) { a2 = a + (x - u0); b2 = a + (y - u0); } else { a2 = a + (u1 - y); b2 = a + (u1 - x); }
                 if (a2 < a) a2 = a;
                 if (b2 > bnd) b2 = bnd;
-                if (b2 > a2) {
+                if (b2 - a2 >= SEED_MINPIECE && y - x >= SEED_MINPIECE) {
                     if (EMIT) {
                         const int32_t qsg = seg_base[cq] + (int32_t)qsegi, ssg = seg_base[cs] + (int32_t)ssegi;
                         const long long qo = qb + qsegi * seg_len, so = sb + ssegi * seg_len;

@@ -239,7 +239,8 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
  *   (last pi + K - first pi) >= 60 is an HSP: query [first pi, last pi + K), subject
  *   [min(pj_first, pj_last), max(pj_first, pj_last) + K).  HSPs are cut at the borders of the seg_len
  *   segments ('chr$offset' naming of split_genome_chunks.py:41-52) of the query, then of the subject, the
- *   other side following linearly (reversed for rel 1) and clamped; records = (qseg, sseg, qs, qe, ss, se),
+ *   other side following linearly (reversed for rel 1) and clamped, pieces shorter than 20 bases on either side are
+ *   dropped; records = (qseg, sseg, qs, qe, ss, se),
  *   1-based inclusive inside the segment, ss > se for rel 1; output order = (qseg, sseg), ties in cluster
  *   order (stable).
  * ====================================================================================================== */
@@ -247,6 +248,7 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
 #define SEED_GAP 300
 #define SEED_MINANCH 3
 #define SEED_MINSPAN 60
+#define SEED_MINPIECE 20
 
 typedef struct { uint64_t key; uint32_t pi; int64_t ord; } anchor_t;
 static int cmp_anchor(const void *a, const void *b) {
@@ -358,7 +360,7 @@ int64_t orc_seed_allvsall(const uint8_t *genome, const int64_t *contig_off, int 
                     if (!rel) { a2 = a + (x - u0); b2 = a + (y - u0); } else { a2 = a + (u1 - y); b2 = a + (u1 - x); }
                     if (a2 < a) a2 = a;
                     if (b2 > b) b2 = b;
-                    if (b2 > a2) {
+                    if (b2 - a2 >= SEED_MINPIECE && y - x >= SEED_MINPIECE) {
                         if (nh == hcap) { hcap *= 2; hs = (hsp_t *)realloc(hs, sizeof(hsp_t) * hcap); }
                         hsp_t *o = &hs[nh];
                         o->qseg = seg_base[cq] + (int32_t)qsegi; o->sseg = seg_base[cs] + (int32_t)ssegi;
