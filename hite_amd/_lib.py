@@ -364,6 +364,11 @@ class Context:
         self._check(rc, "hite_find_copies_dev")
         return (n.value,) + tuple(o.value or 0 for o in outs)
 
+    def genome_mask(self, contig, start1, end1):
+        """N-mask the 1-based inclusive intervals of the resident genome (mask_genome_intactTE)"""
+        c, a, b = _arr(contig, np.int32), _arr(start1, np.int64), _arr(end1, np.int64)
+        self._check(self.lib.hite_genome_mask(self.h, C.c_int64(len(c)), _p(c), _p(a), _p(b)), "hite_genome_mask")
+
     def seed_segments(self, seg_len=1_000_000):
         """-> (seg_chrom int32[nseg], seg_off int64[nseg]): the 'chr$offset' segment table of the packed genome"""
         n = C.c_int32(0)

@@ -165,6 +165,53 @@ extern "C" int hite_genome_pack(hite_ctx *ctx, const uint8_t *seq, const int64_t
 extern "C" int64_t hite_genome_bases(hite_ctx *ctx) { return ctx ? ctx->n_bases : 0; }
 
 // ---------------------------------------------------------------------------------------------
+// N-masking of intervals of the resident genome (mask_genome_intactTE, Util.py:6389-6431: the copies of already
+// found TEs are replaced by N before the next chunk is searched).  One block per interval, threads over mask words.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) genome_mask_kernel(int64_t n, const int32_t *__restrict__ contig, const int64_t *__restrict__ s1,
+                                                          const int64_t *__restrict__ e1, const int64_t *__restrict__ coff, int nc,
+                                                          uint32_t *__restrict__ nmask) {
+    const int64_t k = blockIdx.x;
+    if (k >= n) return;
+    const int c = contig[k];
+    if (c < 0 || c >= nc) return;
+    int64_t a = s1[k] - 1, b = e1[k];          // 0-based half open inside the contig (python slice semantics: clamped)
+    const int64_t L = coff[c + 1] - coff[c];
+    if (a < 0) a = 0;
+    if (b > L) b = L;
+    if (b <= a) return;
+    a += coff[c]; b += coff[c];
+    for (int64_t w = (a >> 5) + threadIdx.x; w <= ((b - 1) >> 5); w += 256) {
+        const int64_t g = w << 5;
+        const int lo = a > g ? (int)(a - g) : 0, hi = b < g + 32 ? (int)(b - g) : 32;
+        const uint32_t m = (hi - lo == 32) ? 0xffffffffu : (((1u << (hi - lo)) - 1u) << lo);
+        atomicOr(&nmask[w], m);
+    }
+}
+extern "C" int hite_genome_mask(hite_ctx *ctx, int64_t n, const int32_t *contig, const int64_t *start1, const int64_t *end1) {
+    if (!ctx || !ctx->d_bases || n < 0 || (n > 0 && (!contig || !start1 || !end1))) return HITE_EINVAL;
+    if (n == 0) return HITE_OK;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    int32_t *dc = nullptr; int64_t *ds = nullptr, *de = nullptr;
+    hipError_t e = hipMalloc((void **)&dc, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMalloc((void **)&ds, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMalloc((void **)&de, (size_t)n * 8);
+    if (e == hipSuccess) e = hipMemcpy(dc, contig, (size_t)n * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(ds, start1, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(de, end1, (size_t)n * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(genome_mask_kernel, dim3((unsigned)n), dim3(256), 0, nullptr, n, dc, ds, de, ctx->d_contig_off, ctx->n_contigs,
+                           ctx->d_nmask);
+        e = hipDeviceSynchronize();
+    }
+    if (dc) (void)hipFree(dc);
+    if (ds) (void)hipFree(ds);
+    if (de) (void)hipFree(de);
+    HITE_CHECK(ctx, e);
+    return HITE_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // flank-window gather
 // ---------------------------------------------------------------------------------------------
 // one wavefront per copy

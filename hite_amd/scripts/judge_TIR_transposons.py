@@ -20,22 +20,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from hite_amd import util  # noqa: E402
 
 
-def tsd_variants(flanked_path, flanking_len, plant):
-    """multi_process_tsd_v1 (Util.py:6630) without the per-file process pool: one batched GPU call, then the
-    min-distance variant per candidate (filter_dup_itr_v3, Util.py:2791) named <query>-tir_<len>-tsd_<seq>."""
+def tsd_variants(flanked_path, flanking_len, plant, work_dir):
+    """multi_process_tsd_v1 (Util.py:6630) without the per-file process pool: one batched call"""
     names, contigs = util.read_fasta(flanked_path)
-    names = [n for n in names if "NNNNNNNNNN" not in contigs[n]]  # Util.py:6543
-    ctx = util.get_ctx()
-    recs = ctx.tsd_kmer([contigs[n] for n in names], flank=flanking_len, plant=plant)
-    out = {}
-    for n, rr in zip(names, recs):
-        if not rr:
-            continue
-        k, ts, te, d = rr[0]  # canonical order: smallest distance first
-        seq = contigs[n][ts:te + 1]
-        if len(seq) < 30000:
-            out["%s-tir_%d-tsd_%s" % (n, 0, contigs[n][ts - k:ts])] = seq
-    return out
+    return util.search_confident_tir_batch_v1(names, contigs, flanking_len, plant, work_dir)
 
 
 def run_cd_hit(inp, outp, threads):
@@ -67,7 +55,7 @@ def main():
     util.set_reference(a.r)
     ctx = util.get_ctx()
     tsd_path = os.path.join(out_dir, "tir_tsd_%s.fa" % ref_index)
-    util.store_fasta(tsd_variants(a.seqs, flank, a.plant), tsd_path)
+    util.store_fasta(tsd_variants(a.seqs, flank, a.plant, out_dir), tsd_path)
     cons_path = tsd_path + ".cons"
     run_cd_hit(tsd_path, cons_path, a.t)
 

@@ -8,6 +8,7 @@ and the low-copy rescue by trf / itrsearch / blastx (Util.py:8196-8281): low-cop
 written to `all_low_copy` exactly like the reference does, nothing is rescued.
 """
 import os
+import sys
 import re
 
 import numpy as np
@@ -139,6 +140,138 @@ def search_boundary_homo_v4(valid_col_threshold, pos, matrix, row_num, col_num, 
 
 
 # ---- a-6 ---------------------------------------------------------------------------------------------
+_COMP = {"A": "T", "T": "A", "C": "G", "G": "C"}
+
+
+def getReverseSequence(sequence):
+    """reverse complement, every non-ACGT symbol -> N (Util.py:1635)"""
+    return "".join(_COMP.get(b, "N") for b in reversed(sequence))
+
+
+def get_short_tir_contigs(cur_itr_contigs, plant):
+    """terminal-structure shortcuts of Util.py:7297-7334: variants whose first 5 bases equal the reverse complement of
+    their last 5 are kept without itrsearch when the TSD length in the name says hAT (8, < 4 kb), Mutator (9-11) or --
+    plants, CACTA/CACTG start -- CACTA (3); so are variants framed by CCC ... GGG."""
+    keep = {}
+    for name, seq in cur_itr_contigs.items():
+        tsd_len = len(name.split("-tsd_")[1].split("-")[0]) if "-tsd_" in name else 0
+        head5, tail5 = seq[:5], getReverseSequence(seq[len(seq) - 5:])
+        head3, tail3 = seq[:3], getReverseSequence(seq[len(seq) - 3:])
+        if head5 == tail5:
+            if (tsd_len == 8 and len(seq) < 4000) or 9 <= tsd_len <= 11 or \
+                    (plant == 1 and tsd_len == 3 and head5 in ("CACTA", "CACTG")):
+                keep[name] = seq
+        elif head3 == tail3 == "CCC":
+            keep[name] = seq
+    return keep
+
+
+def filter_dup_itr_v3(cur_copies_out_contigs, TIR_len_dict):
+    """Util.py:2791-2812: of the variants of one query keep the one with the smallest '-distance_' (first wins ties),
+    renamed '<query>-tir_<len>-tsd_<seq>'; >= 30 kb is dropped."""
+    best, best_d = "", 100000
+    for name in cur_copies_out_contigs:
+        d = int(name.split("-distance_")[1])
+        if d < best_d:
+            best, best_d = name, d
+    if not best:
+        return {}
+    query, rest = best.split("-C_")[0], best.split("-C_")[1]
+    tsd = rest.split("-tsd_")[1].split("-")[0]
+    seq = cur_copies_out_contigs[best]
+    return {"%s-tir_%d-tsd_%s" % (query, TIR_len_dict.get(best, 0), tsd): seq} if len(seq) < 30000 else {}
+
+
+def run_itrsearch(contigs, work_dir, tag):
+    """itrsearch -i 0.7 -l 7 on first40+last40 (Util.py:216-224, 6556-6572) if the binary is installed:
+    -> (names with a TIR, {name: TIR length}); None when the tool is absent."""
+    import shutil
+    import subprocess
+
+    exe = shutil.which("itrsearch")
+    if exe is None:
+        return None
+    path = os.path.join(work_dir, tag + ".fa")
+    store_fasta({n: s[:40] + s[-40:] for n, s in contigs.items()}, path)
+    subprocess.run("cd %s && %s -i 0.7 -l 7 %s > /dev/null 2>&1" % (work_dir, exe, path), shell=True, check=False)
+    out = path + ".itr"
+    names, lens = [], {}
+    if os.path.exists(out):
+        with open(out) as f:
+            for line in f:
+                if line.startswith(">"):
+                    q = line[1:].split(" ")[0].strip()
+                    names.append(q)
+                    if "Length itr=" in line:
+                        lens[q] = int(line.split("Length itr=")[1].split()[0])
+    return names, lens
+
+
+def search_confident_tir_batch_v1(names, contigs, flanking_len, plant, work_dir, device=0):
+    """search_confident_tir_batch_v1 (Util.py:6533-6628) for one batch: k-mer TSD variants on the GPU
+    (search_confident_tir_v4, names '<q>-C_<i>-tsd_<kmer>-distance_<d>' in the canonical order (distance, start, end, k)),
+    terminal-structure shortcuts, itrsearch for the rest when it is installed (otherwise every variant stays a
+    candidate), then one variant per query (filter_dup_itr_v3)."""
+    ctx = get_ctx(device)
+    names = [n for n in names if "NNNNNNNNNN" not in contigs[n]]
+    recs = ctx.tsd_kmer([contigs[n] for n in names], flank=flanking_len, plant=plant)
+    variants = {}
+    for n, rr in zip(names, recs):
+        seq = contigs[n]
+        for i, (k, ts, te, d) in enumerate(rr):
+            variants["%s-C_%d-tsd_%s-distance_%d" % (n, i, seq[ts - k:ts], d)] = seq[ts:te + 1]
+    short = get_short_tir_contigs(variants, plant)
+    rest = {n: s for n, s in variants.items() if n not in short}
+    tir_len = {}
+    itr_short = run_itrsearch(short, work_dir, "short_tir") if short else ([], {})
+    itr_rest = run_itrsearch(rest, work_dir, "all_tir") if rest else ([], {})
+    if itr_rest is None:
+        sys.stderr.write("[hite_amd] itrsearch not found: every TSD variant stays a TIR candidate\n")
+        kept = dict(rest)
+    else:
+        kept = {n: rest[n] for n in itr_rest[0] if n in rest}
+        tir_len.update(itr_rest[1])
+    if itr_short is not None:
+        tir_len.update(itr_short[1])
+    kept.update(short)
+    groups = {}
+    for n, s in kept.items():
+        groups.setdefault(n.split("-C_")[0], {})[n] = s
+    out = {}
+    for q in groups:
+        out.update(filter_dup_itr_v3(groups[q], tir_len))
+    return out
+
+
+def mask_genome_intactTE(TE_lib, genome_path, work_dir=None, thread=1, ref_index=0, debug=0, device=0):
+    """mask_genome_intactTE (Util.py:6389-6431): the full-length copies (coverage >= 0.95 of the library sequence) of the
+    TEs found so far are replaced by N in the chunk, written to <genome_path>.masked.  The copies come from the build's
+    copy finder (where the reference runs minimap2, :6318) and the resident genome is masked as well."""
+    masked = genome_path + ".masked"
+    names, contigs = read_fasta(genome_path)
+    te_names, tes = read_fasta(TE_lib) if TE_lib is not None and os.path.exists(TE_lib) else ([], {})
+    if not te_names:
+        store_fasta(contigs, masked)
+        return masked
+    ctx = get_ctx(device)
+    ctx.genome_pack([contigs[n] for n in names])
+    ctx._copy_state = None
+    _PACKED["path"] = None
+    tab = ctx.find_copies([tes[n] for n in te_names])
+    cc, ss, ee = [], [], []
+    for n, copies in zip(te_names, tab):
+        L = len(tes[n])
+        for (c, s1, e1, _minus, _anch) in copies:
+            if (e1 - s1 + 1) >= 0.95 * L:
+                cc.append(c); ss.append(s1); ee.append(e1)
+    ctx.genome_mask(cc, ss, ee)
+    arrs = [np.frombuffer(contigs[n].encode(), dtype=np.uint8).copy() for n in names]
+    for c, s1, e1 in zip(cc, ss, ee):
+        arrs[c][max(0, s1 - 1):e1] = ord("N")
+    store_fasta({n: a.tobytes().decode() for n, a in zip(names, arrs)}, masked)
+    return masked
+
+
 def split_and_store_sequences(names, contigs, base_threshold):
     """grouping rule of split_and_store_sequences (/root/reference/module/Util.py:4987-5012) without the files:
     consecutive sequences are collected until their total reaches base_threshold -> list of name lists (the reference's

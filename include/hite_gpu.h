@@ -69,6 +69,9 @@ int hite_genome_pack(hite_ctx *ctx, const uint8_t *seq, const int64_t *contig_of
 int hite_genome_pack_dev(hite_ctx *ctx, const uint8_t *d_seq, const int64_t *contig_off_host, int32_t n_contigs,
                          void *stream);
 int64_t hite_genome_bases(hite_ctx *ctx);
+/* N-mask intervals (contig id, 1-based inclusive, clamped into the contig) of the resident genome: the masking step of
+ * mask_genome_intactTE (Util.py:6389-6431).  A minimizer index built before the call does not see the mask. */
+int hite_genome_mask(hite_ctx *ctx, int64_t n, const int32_t *contig, const int64_t *start1, const int64_t *end1);
 
 /* ---- flank-window gather --- Util.py:8095-8124 (inside flank_region_align_v5) -------------
  * copy i = (contig[i], start1[i], end1[i]) 1-based inclusive, minus[i] = strand '-'.

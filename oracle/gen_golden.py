@@ -310,11 +310,65 @@ def gen_tails(U):
     dump("tails", cases)
 
 
+def gen_host(U):
+    """host-side glue of the stage wrappers: get_short_tir_contigs (Util.py:7297), filter_dup_itr_v3 (:2791),
+    split_and_store_sequences grouping (:4987), getReverseSequence (:1635)"""
+    rng = np.random.default_rng(909)
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    short_cases = []
+    for plant in (0, 1):
+        contigs = {}
+        for q in range(60):
+            body = casegen.rand_seq(rng, int(rng.integers(40, 300)))
+            kind = int(rng.integers(0, 6))
+            head = casegen.rand_seq(rng, 5)
+            if kind == 0:
+                head = "CACTA" if rng.random() < 0.5 else "CACTG"
+            if kind == 1:
+                head = "CCC" + casegen.rand_seq(rng, 2)
+            tail = "".join(comp[c] for c in reversed(head)) if kind != 5 else casegen.rand_seq(rng, 5)
+            if kind == 4:
+                body = body + casegen.rand_seq(rng, 4000)   # hAT length limit
+            if kind == 3:
+                tail = casegen.rand_seq(rng, 2) + "GGG"      # CCC ... GGG with different inner bases
+                head = "CCC" + head[3:]
+            seq = head + body + tail
+            if rng.random() < 0.1:
+                seq = seq[:2] + "N" + seq[3:]
+            tsd = casegen.rand_seq(rng, int(rng.choice([2, 3, 4, 8, 9, 10, 11, 12])))
+            contigs["chr1:%d-%d-C_%d-tsd_%s-distance_%d" % (q * 100, q * 100 + len(seq), q % 7, tsd, int(rng.integers(0, 40)))] = seq
+        got = U.get_short_tir_contigs(dict(contigs), plant)
+        short_cases.append({"plant": plant, "names": list(contigs.keys()), "seqs": list(contigs.values()), "kept": list(got.keys())})
+    dup_cases = []
+    for q in range(40):
+        n = int(rng.integers(1, 8))
+        names, seqs, lens = [], [], {}
+        for i in range(n):
+            nm = "chr2:%d-%d-C_%d-tsd_%s-distance_%d" % (q, q + 500, i, casegen.rand_seq(rng, int(rng.integers(2, 12))), int(rng.integers(0, 6)))
+            names.append(nm)
+            seqs.append(casegen.rand_seq(rng, int(rng.choice([120, 400, 29999, 30000], p=[0.48, 0.48, 0.02, 0.02]))))
+            if rng.random() < 0.6:
+                lens[nm] = int(rng.integers(5, 40))
+        res = U.filter_dup_itr_v3(dict(zip(names, seqs)), dict(lens))
+        dup_cases.append({"names": names, "seqs": seqs, "tir_len": lens, "out_names": list(res.keys()), "out_seqs": list(res.values())})
+    split_cases = []
+    for thr in (100, 1000, 5000):
+        names = ["s%d" % i for i in range(int(rng.integers(1, 30)))]
+        lens = [int(rng.integers(1, 1500)) for _ in names]
+        with tempfile.TemporaryDirectory() as d:
+            files = U.split_and_store_sequences(names, {n: "A" * l for n, l in zip(names, lens)}, d, thr)
+            groups = [U.read_fasta(f[0])[0] for f in files]
+        split_cases.append({"names": names, "lens": lens, "thr": thr, "groups": groups})
+    rev = [casegen.rand_seq(rng, 30) for _ in range(5)] + ["ACGTNRYacgt-", ""]
+    dump("host_glue", {"short_tir": short_cases, "filter_dup": dup_cases, "split": split_cases,
+                       "revcomp": [[s, U.getReverseSequence(s)] for s in rev]})
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -330,6 +384,8 @@ def main():
             gen_gather(U, tmp)
         if "tails" in which:
             gen_tails(U)
+        if "host" in which:
+            gen_host(U)
 
 
 if __name__ == "__main__":

@@ -557,3 +557,34 @@ def test_coarse_boundary_script_end_to_end(ctx, tmp_path):
         c0, a0, b0, _m = fam[0]
         hit += any(c == c0 and min(b, b0) - max(a, a0) > 0.7 * (b0 - a0) for c, a, b in iv)
     assert tot >= 3 and hit >= tot - 1, (hit, tot)
+
+
+def test_mask_genome_intactTE(ctx, tmp_path):
+    """N-masking of the full-length copies of a TE library: file output and the resident genome agree"""
+    import synth_small
+    from hite_amd import util
+
+    g = synth_small.make(11, n_fam=16)
+    gp = tmp_path / "genome.cut1.fa"
+    gp.write_text("".join(">chr%d$0\n%s\n" % (i + 1, s) for i, s in enumerate(g["contigs"])))
+    lib = tmp_path / "prev_TE.fa"
+    lib.write_text("".join(">TE_%d\n%s\n" % (i, s) for i, s in enumerate(g["cands"][:6])))
+    out = util.mask_genome_intactTE(str(lib), str(gp))
+    names, masked = util.read_fasta(out)
+    assert names == ["chr%d$0" % (i + 1) for i in range(len(g["contigs"]))]
+    # expectation from the twin's copy table
+    tab = O.find_copies(g["contigs"], g["cands"][:6])
+    exp = [np.frombuffer(s.encode(), dtype=np.uint8).copy() for s in g["contigs"]]
+    nmask = 0
+    for cand, copies in zip(g["cands"][:6], tab):
+        for (c, s1, e1, _m, _a) in copies:
+            if e1 - s1 + 1 >= 0.95 * len(cand):
+                exp[c][s1 - 1:e1] = ord("N")
+                nmask += 1
+    assert nmask >= 6
+    for n, e in zip(names, exp):
+        assert masked[n] == e.tobytes().decode()
+    # the resident genome carries the same mask (gather of a masked interval gives N)
+    c, s1, e1, _m, _a = tab[0][0]
+    wins, _ = util.get_ctx().flank_gather([c], [s1], [e1], [0], flank=0)
+    assert set(wins[0].decode()) == {"N"}

@@ -157,3 +157,25 @@ def test_seed_allvsall_twin_recovers_planted_pairs():
                     cov = int((np.minimum(qb[sel], b1) - np.maximum(qa[sel], a1) + 1).sum())
                 found += cov >= 0.6 * (b1 - a1 + 1)
     assert total > 20 and found >= 0.9 * total, (found, total)
+
+
+def test_host_glue_golden():
+    """host-side glue of the stage wrappers against the reference's outputs: terminal-structure shortcuts,
+    min-distance variant, query-file grouping, reverse complement"""
+    import sys
+
+    sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+    from hite_amd import util
+
+    g = load_golden("host_glue")
+    for c in g["short_tir"]:
+        got = util.get_short_tir_contigs(dict(zip(c["names"], c["seqs"])), c["plant"])
+        assert list(got.keys()) == c["kept"]
+    assert sum(len(c["kept"]) for c in g["short_tir"]) > 10
+    for c in g["filter_dup"]:
+        got = util.filter_dup_itr_v3(dict(zip(c["names"], c["seqs"])), c["tir_len"])
+        assert list(got.keys()) == c["out_names"] and list(got.values()) == c["out_seqs"]
+    for c in g["split"]:
+        assert util.split_and_store_sequences(c["names"], {n: "A" * l for n, l in zip(c["names"], c["lens"])}, c["thr"]) == c["groups"]
+    for s, r in g["revcomp"]:
+        assert util.getReverseSequence(s) == r
