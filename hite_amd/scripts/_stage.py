@@ -1,0 +1,65 @@
+"""Shared plumbing of the drop-in stage scripts (judge_TIR / judge_Helitron / judge_Non_LTR_transposons.py):
+copy finder on the resident genome, cd-hit-est if installed, the refinement loop around flank_region_align_v5,
+the final rename / prefix / prev_TE update (rename_fasta Util.py:7500, lib_add_prefix :11559, update_prev_TE)."""
+import os
+import shutil
+import subprocess
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+
+from hite_amd import util  # noqa: E402
+
+
+def copy_finder():
+    """copy finder with the signature util.flank_region_align_v5 expects (stands where the reference calls minimap2)"""
+    ctx = util.get_ctx()
+
+    def finder(cand_path, reference):
+        names, contigs = util.read_fasta(cand_path)
+        tab = ctx.find_copies([contigs[n] for n in names])
+        rev = {v: k for k, v in util._PACKED["names"].items()}
+        return {n: [(rev[c], s, e, e - s + 1, "-" if m else "+") for (c, s, e, m, _an) in t] for n, t in zip(names, tab) if t}
+
+    return finder
+
+
+def run_cd_hit(inp, outp, threads):
+    """cd-hit-est -aS .95 -aL .95 -c .8 -G 0 -g 1 -A 80 (judge_TIR_transposons.py:87); pass-through when not installed"""
+    if shutil.which("cd-hit-est") is None:
+        sys.stderr.write("[hite_amd] cd-hit-est not found: redundancy removal skipped\n")
+        shutil.copyfile(inp, outp)
+        return
+    subprocess.run("cd-hit-est -aS 0.95 -aL 0.95 -c 0.8 -G 0 -g 1 -A 80 -i %s -o %s -T %d -M 0 > /dev/null 2>&1" % (inp, outp, threads),
+                   shell=True, check=False)
+
+
+def refine(te_type, first_input, out_dir, stem, ref_index, reference, split_ref_dir, threads, plant, debug, low_copy, iters, flank=50):
+    """iters rounds of flank_region_align_v5, each fed with the consensus of the previous one -> path of the last output"""
+    finder = copy_finder()
+    cur = first_input
+    for it in range(iters):
+        nxt = os.path.join(out_dir, "%s_%s.r%d.fa" % (stem, ref_index, it))
+        util.flank_region_align_v5(cur, nxt, flank, reference, split_ref_dir, te_type, out_dir, threads, ref_index, None, "", plant, debug,
+                                   it, low_copy, copy_finder=finder)
+        cur = nxt
+    return cur
+
+
+def finish(result_path, final_path, label, ref_index, reference, min_len, prev_TE, strip_hash=False):
+    """length filter, rename to <genomeprefix>-<label>_<i>_<n>, atomic publish (success == the file exists, Util.py:2831),
+    append to prev_TE"""
+    names, contigs = util.read_fasta(result_path)
+    prefix = os.path.basename(reference).split(".")[0]
+    kept = {}
+    for n in names:
+        if len(contigs[n]) >= min_len:
+            kept["%s-%s_%s_%d" % (prefix, label, ref_index, len(kept))] = contigs[n]
+    tmp = final_path + ".tmp"
+    util.store_fasta(kept, tmp)
+    os.replace(tmp, final_path)
+    if prev_TE:
+        with open(prev_TE, "a") as f:
+            for n, s in kept.items():
+                f.write(">" + n + "\n" + s + "\n")
+    return kept

@@ -11,28 +11,18 @@ External tools are used exactly where the reference uses them and only if they a
 when one is missing the step is skipped with a warning (the candidates are passed through)."""
 import argparse
 import os
-import shutil
-import subprocess
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
-from hite_amd import util  # noqa: E402
+import _stage  # noqa: E402
+from _stage import util  # noqa: E402
 
 
 def tsd_variants(flanked_path, flanking_len, plant, work_dir):
     """multi_process_tsd_v1 (Util.py:6630) without the per-file process pool: one batched call"""
     names, contigs = util.read_fasta(flanked_path)
     return util.search_confident_tir_batch_v1(names, contigs, flanking_len, plant, work_dir)
-
-
-def run_cd_hit(inp, outp, threads):
-    if shutil.which("cd-hit-est") is None:
-        sys.stderr.write("[hite_amd] cd-hit-est not found: redundancy removal skipped\n")
-        shutil.copyfile(inp, outp)
-        return
-    subprocess.run("cd-hit-est -aS 0.95 -aL 0.95 -c 0.8 -G 0 -g 1 -A 80 -i %s -o %s -T %d -M 0 > /dev/null 2>&1" % (inp, outp, threads),
-                   shell=True, check=False)
 
 
 def main():
@@ -53,37 +43,12 @@ def main():
         return 0
     low = a.all_low_copy_tir or os.path.join(out_dir, "tir_low_copy.fa")
     util.set_reference(a.r)
-    ctx = util.get_ctx()
     tsd_path = os.path.join(out_dir, "tir_tsd_%s.fa" % ref_index)
     util.store_fasta(tsd_variants(a.seqs, flank, a.plant, out_dir), tsd_path)
     cons_path = tsd_path + ".cons"
-    run_cd_hit(tsd_path, cons_path, a.t)
-
-    def finder(cand_path, reference):
-        names, contigs = util.read_fasta(cand_path)
-        tab = ctx.find_copies([contigs[n] for n in names])
-        rev = {v: k for k, v in util._PACKED["names"].items()}
-        return {n: [(rev[c], s, e, e - s + 1, "-" if m else "+") for (c, s, e, m, _an) in t] for n, t in zip(names, tab) if t}
-
-    cur = cons_path
-    for it in range(3):  # judge_TIR_transposons.py:27
-        nxt = os.path.join(out_dir, "confident_tir_%s.r%d.fa" % (ref_index, it))
-        util.flank_region_align_v5(cur, nxt, flank, a.r, a.split_ref_dir, "tir", out_dir, a.t, ref_index, None, "", a.plant, a.debug,
-                                   it, low, copy_finder=finder)
-        cur = nxt
-    names, contigs = util.read_fasta(cur)
-    prefix = os.path.basename(a.r).split(".")[0]
-    kept = {}
-    for n in names:
-        if len(contigs[n]) >= a.min_TE_len:
-            kept["%s-TIR_%s_%d" % (prefix, ref_index, len(kept))] = contigs[n]
-    tmp = final + ".tmp"
-    util.store_fasta(kept, tmp)
-    os.replace(tmp, final)  # success == "the output file exists" (Util.py:2831): never leave a partial file
-    if a.prev_TE:
-        with open(a.prev_TE, "a") as f:
-            for n, s in kept.items():
-                f.write(">" + n + "\n" + s + "\n")
+    _stage.run_cd_hit(tsd_path, cons_path, a.t)
+    last = _stage.refine("tir", cons_path, out_dir, "confident_tir", ref_index, a.r, a.split_ref_dir, a.t, a.plant, a.debug, low, 3)
+    _stage.finish(last, final, "TIR", ref_index, a.r, a.min_TE_len, a.prev_TE)
     return 0
 
 

@@ -460,6 +460,15 @@ def test_dropin_scripts(ctx, tmp_path):
     assert rc.returncode == 0, rc.stderr
     tn, tc = util.read_fasta(str(out / "confident_tir_0.fa"))
     assert len(tn) >= 2 and all(n.startswith("genome-TIR_0_") for n in tn)
+    # Helitron / non-LTR wrappers: same file contract (the synthetic TIR families are not expected to pass their rules)
+    candf = tmp_path / "cand.fa"
+    candf.write_text("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(g["cands"])))
+    for script, outname in (("judge_Helitron_transposons.py", "confident_helitron_0.fa"), ("judge_Non_LTR_transposons.py", "confident_non_ltr_0.fa")):
+        rc = subprocess.run([_sys.executable, root + "/hite_amd/scripts/" + script, "--seqs", str(flanked), "-t", "1", "--tmp_output_dir", str(out),
+                             "--ref_index", "0", "--flanking_len", "50", "--recover", "0", "-r", str(ref), "--min_TE_len", "80",
+                             "--candidates", str(candf)], capture_output=True, text=True)
+        assert rc.returncode == 0, rc.stderr[-2000:]
+        assert (out / outname).exists()
 
 
 def test_star_msa_sparse_fused(ctx):
