@@ -31,7 +31,8 @@
 struct CopyState {
     unsigned *idx_hs = nullptr, *idx_pos = nullptr, *dir = nullptr;
     int64_t M = 0;
-    Arena arena;
+    Arena arena;      // temporaries of one call
+    Arena out;        // copy table handed to the caller (valid until the next call)
     int64_t *h_pin = nullptr;
     int64_t *d_scal = nullptr;
     int64_t last[4] = {0, 0, 0, 0};   // last call: candidate minimizers, hits, clusters, copies (before the 300 cap)
@@ -395,6 +396,7 @@ extern "C" void hite_copy_index_release(void *state) {
     if (S->idx_pos) (void)hipFree(S->idx_pos);
     if (S->dir) (void)hipFree(S->dir);
     arena_free(S->arena);
+    arena_free(S->out);
     if (S->h_pin) (void)hipHostFree(S->h_pin);
     if (S->d_scal) (void)hipFree(S->d_scal);
     delete S;
@@ -463,10 +465,11 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     hipStream_t st = (hipStream_t)stream;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
     CCHK(arena_reset(ctx, S->arena, true));
+    CCHK(arena_reset(ctx, S->out, true));
     Arena &A = S->arena;
     void *p;
     int32_t *ofirst32;
-    CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 4, &p)); ofirst32 = (int32_t *)p;
+    CCHK(arena_alloc(ctx, S->out, (size_t)(n_cand + 2) * 4, &p)); ofirst32 = (int32_t *)p;
     *d_copy_first = ofirst32; *n_copies = 0;
     HITE_CHECK(ctx, hipMemsetAsync(ofirst32, 0, (size_t)(n_cand + 2) * 4, st));
     *d_contig = nullptr; *d_start1 = nullptr; *d_end1 = nullptr; *d_minus = nullptr; *d_anchors = nullptr;
@@ -590,15 +593,18 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     int32_t *o_contig, *o_anch;
     int64_t *o_s1, *o_e1;
     uint8_t *o_minus;
-    CCHK(arena_alloc(ctx, A, (size_t)(nout + 1) * 4, &p)); o_contig = (int32_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(nout + 1) * 8, &p)); o_s1 = (int64_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(nout + 1) * 8, &p)); o_e1 = (int64_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(nout + 16), &p)); o_minus = (uint8_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(nout + 1) * 4, &p)); o_anch = (int32_t *)p;
+    CCHK(arena_alloc(ctx, S->out, (size_t)(nout + 1) * 4, &p)); o_contig = (int32_t *)p;
+    CCHK(arena_alloc(ctx, S->out, (size_t)(nout + 1) * 8, &p)); o_s1 = (int64_t *)p;
+    CCHK(arena_alloc(ctx, S->out, (size_t)(nout + 1) * 8, &p)); o_e1 = (int64_t *)p;
+    CCHK(arena_alloc(ctx, S->out, (size_t)(nout + 16), &p)); o_minus = (uint8_t *)p;
+    CCHK(arena_alloc(ctx, S->out, (size_t)(nout + 1) * 4, &p)); o_anch = (int32_t *)p;
     hipLaunchKernelGGL(emit_copies_kernel, CGRID(ncp), 0, st, ncp, ckey, cval, cstart, ofirst, r_contig, r_s1, r_e1, r_minus, r_anch,
                        o_contig, o_s1, o_e1, o_minus, o_anch);
     HITE_CHECK(ctx, hipGetLastError());
     *d_contig = o_contig; *d_start1 = o_s1; *d_end1 = o_e1; *d_minus = o_minus; *d_anchors = o_anch;
+    // if the temporaries grew into several chunks during this call, merge them NOW (they are dead; the copy table lives in
+    // S->out): the next call then starts on one chunk and performs no hipMalloc
+    CCHK(arena_reset(ctx, S->arena, true));
     return HITE_OK;
 }
 

@@ -424,7 +424,12 @@ extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, out_off + n_cand, 8, hipMemcpyDeviceToDevice, st));
     ACHK(read_scalars(ctx, S, st, 1));
     if (stats_out) { memcpy(stats_out, stats, sizeof stats); stats_out[10] = S->h_pin[0]; }
-    if (S->h_pin[0] > cons_cap) return HITE_ECAP;
+    const int64_t cons_need = S->h_pin[0];
+    // everything in the two arenas is dead now (the stream is drained): if they grew into several chunks, merge them so that
+    // the next call performs no hipMalloc
+    ACHK(arena_reset(ctx, S->keep, true));
+    ACHK(arena_reset(ctx, S->tmp, true));
+    if (cons_need > cons_cap) return HITE_ECAP;
     return HITE_OK;
 }
 
