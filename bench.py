@@ -41,7 +41,11 @@ def main():
     ap.add_argument("--copies", choices=["found", "truth"], default="found",
                     help="found: copy finding (minimizer index lookup) runs inside the timed step; truth: the generator's copy table is the input")
     ap.add_argument("--verify", type=int, default=0, help="re-judge this many random candidates with the CPU oracle chain and compare")
+    ap.add_argument("--stage", choices=["fine", "coarse"], default="fine",
+                    help="fine (default): BASELINE.json's metric; coarse: the companion line of stage 3.1 (all-vs-all seeding + FMEA)")
     args = ap.parse_args()
+    if args.stage == "coarse":
+        return coarse_stage(args)
 
     import torch
     import torch.distributed as dist
@@ -247,6 +251,98 @@ def verify(w, calls, cons, count):
         if got != exp:
             bad.append(int(c))
     return {"checked": int(len(picks)), "mismatches": len(bad), "bad_candidates": bad[:10]}
+
+
+def coarse_stage(args):
+    """companion measurement of stage 3.1 (coarse_boundary.py: all-vs-all search of the 1 Mbp segments + FMEA) on the same
+    synthetic genome; one JSON line in the same shape as the main line.  A step = index + hite_seed_allvsall + hite_fmea_chain
+    over the whole genome (one chunk).  cpu_baseline = the CPU twins of the same stages (orc_seed_allvsall + orc_fmea, single
+    thread) on a bounded sub-genome (the all-vs-all stage is super-linear in the genome, so Mbp/s on the sample flatters
+    the CPU)."""
+    import torch
+
+    import hite_amd
+    from hite_amd import synth
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    G = args.genome_mbp * 1_000_000
+    n_tir = args.tir_families if args.tir_families is not None else max(1, int(2.5 * args.genome_mbp))
+    n_ltr = args.ltr_families if args.ltr_families is not None else max(0, int(2.5 * args.genome_mbp))
+    # replicas: every rank searches its own genome (config 5 of BASELINE.json: one genome per GPU); no collective on the data path
+    w = synth.make_workload(genome_bp=G, n_tir=n_tir, n_ltr=n_ltr, cands_per_family=1, seed=args.seed + 977 * rank, device=dev)
+    ctx = hite_amd.Context(local_rank)
+    ctx.genome_pack_dev(w["genome"].data_ptr(), w["contig_off"])
+    sc, so = ctx.seed_segments(1_000_000)
+
+    def step():
+        ctx._copy_state = None                      # the index is part of the step here
+        ctx.copy_index_build()
+        (oc, _os, _oe), st = ctx.coarse_stage_dev(1_000_000, sc, so, 4000, 30000)   # the HSP table never leaves the device
+        return st, len(oc)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    for _ in range(args.steps):
+        stats, n_iv = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    if rank == 0:
+        ms = 1000.0 * elapsed / max(1, args.steps)
+        out = {"metric": "coarse_boundary step (stage 3.1: all-vs-all seeding + FMEA) on the 1 Gbp synthetic genome",
+               "value": round(world * args.genome_mbp * args.steps / elapsed, 2), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "u8", "data": "synthetic",
+               "config": {"workload": "C3 genome: %d Mbp, %d TIR + %d LTR families, 1 Mbp segments, one chunk%s" %
+                                      (args.genome_mbp, n_tir, n_ltr, "; one genome per GPU (replicas)" if world > 1 else ""),
+                          "seeds": stats[0], "anchors": stats[1], "clusters": stats[2], "hsp_records": stats[3], "repeat_intervals": n_iv},
+               "roofline": {"bound": "hbm", "achieved": round((12.0 * stats[0] * 9 + 24.0 * stats[1] * 5 + 48.0 * stats[3] * 5) / (elapsed / args.steps) / 1e9, 2),
+                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                            "note": "algorithmic bytes = radix passes x 2 x record size over seeds / anchors / HSP records (whole step, not one kernel)"}}
+        out["roofline"]["frac"] = round(out["roofline"]["achieved"] / PEAK_HBM_GBS, 5)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = coarse_cpu_baseline(args, min(args.genome_mbp, 20))
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def coarse_cpu_baseline(args, mbp):
+    """the CPU twins of the coarse stage (oracle/hite_oracle_copies.c: orc_seed_allvsall, oracle/hite_oracle_coarse.c: orc_fmea),
+    single thread, on a sub-genome of `mbp` Mbp generated with the same family density"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from hite_amd import synth
+
+    w = synth.make_workload(genome_bp=mbp * 1_000_000, n_tir=max(1, int(2.5 * mbp)), n_ltr=int(2.5 * mbp), cands_per_family=1, seed=args.seed)
+    co = w["contig_off"]
+    contigs = [w["genome"][co[i]:co[i + 1]].tobytes() for i in range(len(co) - 1)]
+    t0 = time.perf_counter()
+    h = O.seed_allvsall(contigs, seg_len=1_000_000)
+    h["chrom_names"] = ["c%d" % i for i in range(len(contigs))]
+    names = O.fmea(h, 4000, 30000)
+    dt = time.perf_counter() - t0
+    return {"value": round(mbp / dt, 3), "unit": "Mbp/s", "cores": 1, "kind": "port",
+            "sample": "%d Mbp sub-genome, same family density (%.1f s): %d HSP records -> %d intervals; CPU twins of the same stages, single thread"
+                      % (mbp, dt, len(h["qseg"]), len(names))}
 
 
 def cpu_baseline(w, budget_s):

@@ -386,9 +386,9 @@ class Context:
         n = C.c_int64(0)
         cap = int(cap) if cap is not None else 1 << 20
         while True:
-            qseg = np.zeros(cap, dtype=np.int32); sseg = np.zeros(cap, dtype=np.int32)
-            qs = np.zeros(cap, dtype=np.int64); qe = np.zeros(cap, dtype=np.int64)
-            ss = np.zeros(cap, dtype=np.int64); se = np.zeros(cap, dtype=np.int64)
+            qseg = np.empty(cap, dtype=np.int32); sseg = np.empty(cap, dtype=np.int32)
+            qs = np.empty(cap, dtype=np.int64); qe = np.empty(cap, dtype=np.int64)
+            ss = np.empty(cap, dtype=np.int64); se = np.empty(cap, dtype=np.int64)
             rc = self.lib.hite_seed_allvsall(self.h, C.byref(self._copy_state), C.c_int64(seg_len), C.c_int64(max_anchors), C.c_int64(cap),
                                              _p(qseg), _p(sseg), _p(qs), _p(qe), _p(ss), _p(se), C.byref(n), stats)
             if rc == -4 and n.value > cap:   # HITE_ECAP with the needed size known: retry once with room
@@ -399,6 +399,26 @@ class Context:
         k = n.value
         return {"qseg": qseg[:k].copy(), "sseg": sseg[:k].copy(), "qs": qs[:k].copy(), "qe": qe[:k].copy(), "ss": ss[:k].copy(),
                 "se": se[:k].copy(), "stats": tuple(int(x) for x in stats)}
+
+    def coarse_stage_dev(self, seg_len, seg_chrom, seg_off, skip_gap, max_len, max_anchors=8_000_000_000):
+        """all-vs-all seeding + FMEA with the HSP table kept on the device -> ((chrom ids, starts, ends), seeding stats)"""
+        if getattr(self, "_copy_state", None) is None:
+            self._copy_state = C.c_void_p(None)
+        v = C.c_void_p
+        ptr = [v() for _ in range(6)]
+        stats = (C.c_int64 * 4)()
+        n = C.c_int64(0)
+        self._check(self.lib.hite_seed_allvsall_dev(self.h, C.byref(self._copy_state), C.c_int64(seg_len), C.c_int64(max_anchors),
+                                                    *[C.byref(x) for x in ptr], C.byref(n), stats), "hite_seed_allvsall_dev")
+        sc, so = _arr(seg_chrom, np.int32), _arr(seg_off, np.int64)
+        cap = max(16, n.value + 16)
+        oc = np.empty(cap, dtype=np.int32); os_ = np.empty(cap, dtype=np.int64); oe = np.empty(cap, dtype=np.int64)
+        nout = C.c_int64(0)
+        if n.value:
+            self._check(self.lib.hite_fmea_chain_dev(self.h, n, *ptr, len(sc), _p(sc), _p(so), C.c_int64(skip_gap), C.c_int64(max_len),
+                                                     C.c_int64(cap), _p(oc), _p(os_), _p(oe), C.byref(nout)), "hite_fmea_chain_dev")
+        k = nout.value
+        return (oc[:k].copy(), os_[:k].copy(), oe[:k].copy()), tuple(int(x) for x in stats)
 
     def copy_stats(self):
         """sizes of the last find_copies call: (candidate minimizers, index hits, diagonal clusters, copies before the cap)"""

@@ -818,10 +818,31 @@ extern "C" int hite_seed_segments(hite_ctx *ctx, int64_t seg_len, int32_t cap, i
     return (seg_chrom && n > cap) ? HITE_ECAP : HITE_OK;
 }
 
+static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int64_t cap,
+                              int32_t *qseg, int32_t *sseg, int64_t *qs, int64_t *qe, int64_t *ss, int64_t *se,
+                              int64_t *n_out, int64_t *stats_out, void **dev_out);
+// device-resident form: the six arrays stay in the index state's arena (valid until the next call that uses the state)
+extern "C" int hite_seed_allvsall_dev(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int32_t **d_qseg,
+                                      int32_t **d_sseg, int64_t **d_qs, int64_t **d_qe, int64_t **d_ss, int64_t **d_se, int64_t *n_out,
+                                      int64_t *stats_out) {
+    if (!d_qseg || !d_sseg || !d_qs || !d_qe || !d_ss || !d_se) return HITE_EINVAL;
+    void *ptrs[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int rc = seed_allvsall_impl(ctx, state_io, seg_len, max_anchors, -1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n_out,
+                                stats_out, ptrs);
+    *d_qseg = (int32_t *)ptrs[0]; *d_sseg = (int32_t *)ptrs[1]; *d_qs = (int64_t *)ptrs[2]; *d_qe = (int64_t *)ptrs[3];
+    *d_ss = (int64_t *)ptrs[4]; *d_se = (int64_t *)ptrs[5];
+    return rc;
+}
 extern "C" int hite_seed_allvsall(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int64_t cap,
                                   int32_t *qseg, int32_t *sseg, int64_t *qs, int64_t *qe, int64_t *ss, int64_t *se,
                                   int64_t *n_out, int64_t *stats_out /* 4 x int64 or NULL: seeds, anchors, clusters, records */) {
-    if (!ctx || !ctx->d_bases || !state_io || seg_len <= 0 || !n_out || cap < 0) return HITE_EINVAL;
+    if (cap < 0) return HITE_EINVAL;
+    return seed_allvsall_impl(ctx, state_io, seg_len, max_anchors, cap, qseg, sseg, qs, qe, ss, se, n_out, stats_out, nullptr);
+}
+static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int64_t cap,
+                              int32_t *qseg, int32_t *sseg, int64_t *qs, int64_t *qe, int64_t *ss, int64_t *se,
+                              int64_t *n_out, int64_t *stats_out, void **dev_out /* 6 pointers, or NULL: copy to the host arrays */) {
+    if (!ctx || !ctx->d_bases || !state_io || seg_len <= 0 || !n_out) return HITE_EINVAL;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = nullptr;
     if (!*state_io) CCHK(hite_copy_index_build(ctx, state_io, nullptr));
@@ -915,7 +936,7 @@ extern "C" int hite_seed_allvsall(hite_ctx *ctx, void **state_io, int64_t seg_le
     *n_out = np;
     if (stats_out) stats_out[3] = np;
     if (np == 0) return HITE_OK;
-    if (np > cap) return HITE_ECAP;
+    if (!dev_out && np > cap) return HITE_ECAP;
     if (np >= 0xffffffffll) return HITE_ECAP;
     unsigned long long *okey; unsigned *oval; int32_t *t_qseg, *t_sseg, *f_qseg, *f_sseg; int64_t *t_q[4], *f_q[4];
     CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); okey = (unsigned long long *)p;
@@ -939,6 +960,10 @@ extern "C" int hite_seed_allvsall(hite_ctx *ctx, void **state_io, int64_t seg_le
                        f_q[1], f_q[2], f_q[3]);
     HITE_CHECK(ctx, hipGetLastError());
     HITE_CHECK(ctx, hipStreamSynchronize(st));
+    if (dev_out) {
+        dev_out[0] = f_qseg; dev_out[1] = f_sseg; dev_out[2] = f_q[0]; dev_out[3] = f_q[1]; dev_out[4] = f_q[2]; dev_out[5] = f_q[3];
+        return HITE_OK;
+    }
     HITE_CHECK(ctx, hipMemcpy(qseg, f_qseg, (size_t)np * 4, hipMemcpyDeviceToHost));
     HITE_CHECK(ctx, hipMemcpy(sseg, f_sseg, (size_t)np * 4, hipMemcpyDeviceToHost));
     HITE_CHECK(ctx, hipMemcpy(qs, f_q[0], (size_t)np * 8, hipMemcpyDeviceToHost));

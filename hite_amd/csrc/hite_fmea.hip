@@ -395,7 +395,12 @@ __global__ void fm_fill_i32_kernel(int64_t n, int *__restrict__ p, int v) {
 // ---------------------------------------------------------------------------------------------
 struct FBuf {
     void *p = nullptr;
-    ~FBuf() { if (p) (void)hipFree(p); }
+    bool owned = true;
+    ~FBuf() { if (p && owned) (void)hipFree(p); }
+    hipError_t up_or_borrow(const void *src, size_t n, bool on_device) {
+        if (on_device) { p = const_cast<void *>(src); owned = false; return hipSuccess; }
+        return up(src, n);
+    }
     hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
     hipError_t up(const void *h, size_t n) {
         hipError_t e = alloc(n + 16);
@@ -406,10 +411,10 @@ struct FBuf {
 #define FCHK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { snprintf(ctx->err, sizeof ctx->err, "%s:%d %s", __FILE__, __LINE__, hipGetErrorString(e__)); sorter_free(S); return HITE_EHIP; } } while (0)
 #define GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256)
 
-extern "C" int hite_fmea_chain(hite_ctx *ctx, int64_t n, const int32_t *qseg, const int32_t *sseg, const int64_t *qs,
-                               const int64_t *qe, const int64_t *ss, const int64_t *se, int32_t nseg, const int32_t *seg_chrom,
-                               const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
-                               int64_t *out_start, int64_t *out_end, int64_t *n_out) {
+static int fmea_impl(hite_ctx *ctx, int64_t n, const int32_t *qseg, const int32_t *sseg, const int64_t *qs,
+                     const int64_t *qe, const int64_t *ss, const int64_t *se, bool hsp_on_device, int32_t nseg, const int32_t *seg_chrom,
+                     const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
+                     int64_t *out_start, int64_t *out_end, int64_t *n_out) {
     if (!ctx || n < 0 || nseg <= 0 || nseg > FM_MAXSEG || !n_out || n >= 0x7fffffff) return HITE_EINVAL;
     *n_out = 0;
     if (n == 0) return HITE_OK;
@@ -421,8 +426,10 @@ extern "C" int hite_fmea_chain(hite_ctx *ctx, int64_t n, const int32_t *qseg, co
         dtot, derr, dk1, dk2, dval, dslotcnt, dslotstart, dbs, dk2s, dclid, dncl, dclbase, dkqe, dkqs, dkcl, dclcnt, dclstart, dpos,
         dorder2, dvis, dcanon, dchains, dischain, dchpos, dchains2, dhtk, dhtv, dckey, discand, dcpos, dckey2, dcidx, dqcount, dqstart,
         dkeepf, dkeepf32, dopos, doc, dos, doe, dtmpk;
-    FCHK(dq.up(qseg, n * 4)); FCHK(dsg.up(sseg, n * 4)); FCHK(dqs.up(qs, n * 8)); FCHK(dqe.up(qe, n * 8)); FCHK(dss.up(ss, n * 8));
-    FCHK(dse.up(se, n * 8)); FCHK(dchr.up(seg_chrom, nseg * 4)); FCHK(doff.up(seg_off, nseg * 8));
+    FCHK(dq.up_or_borrow(qseg, n * 4, hsp_on_device)); FCHK(dsg.up_or_borrow(sseg, n * 4, hsp_on_device));
+    FCHK(dqs.up_or_borrow(qs, n * 8, hsp_on_device)); FCHK(dqe.up_or_borrow(qe, n * 8, hsp_on_device));
+    FCHK(dss.up_or_borrow(ss, n * 8, hsp_on_device)); FCHK(dse.up_or_borrow(se, n * 8, hsp_on_device));
+    FCHK(dchr.up(seg_chrom, nseg * 4)); FCHK(doff.up(seg_off, nseg * 8));
     FCHK(dfirstq.alloc((size_t)nseg * 4)); FCHK(dfirstp.alloc((size_t)nseg * nseg * 4)); FCHK(dkeep.alloc(n)); FCHK(dkeep32.alloc(n * 4));
     FCHK(dkpos.alloc((n + 1) * 8)); FCHK(dqrank.alloc(nseg * 4)); FCHK(dqorder.alloc(nseg * 4)); FCHK(dnq.alloc(16));
     FCHK(dsrank.alloc((size_t)nseg * nseg * 4)); FCHK(dnpairs.alloc(nseg * 4)); FCHK(dgbase.alloc((nseg + 1) * 8)); FCHK(dtot.alloc(64));
@@ -540,4 +547,20 @@ extern "C" int hite_fmea_chain(hite_ctx *ctx, int64_t n, const int32_t *qseg, co
     FCHK(hipMemcpy(out_end, doe.p, nout * 8, hipMemcpyDeviceToHost));
     sorter_free(S);
     return HITE_OK;
+}
+
+extern "C" int hite_fmea_chain(hite_ctx *ctx, int64_t n, const int32_t *qseg, const int32_t *sseg, const int64_t *qs,
+                               const int64_t *qe, const int64_t *ss, const int64_t *se, int32_t nseg, const int32_t *seg_chrom,
+                               const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
+                               int64_t *out_start, int64_t *out_end, int64_t *n_out) {
+    return fmea_impl(ctx, n, qseg, sseg, qs, qe, ss, se, false, nseg, seg_chrom, seg_off, skip_gap, max_len, cap, out_chrom, out_start,
+                     out_end, n_out);
+}
+// same with the HSP table resident on the device (what hite_seed_allvsall_dev leaves there); the HSP arrays are not modified
+extern "C" int hite_fmea_chain_dev(hite_ctx *ctx, int64_t n, const int32_t *d_qseg, const int32_t *d_sseg, const int64_t *d_qs,
+                                   const int64_t *d_qe, const int64_t *d_ss, const int64_t *d_se, int32_t nseg, const int32_t *seg_chrom,
+                                   const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
+                                   int64_t *out_start, int64_t *out_end, int64_t *n_out) {
+    return fmea_impl(ctx, n, d_qseg, d_sseg, d_qs, d_qe, d_ss, d_se, true, nseg, seg_chrom, seg_off, skip_gap, max_len, cap, out_chrom,
+                     out_start, out_end, n_out);
 }

@@ -146,6 +146,11 @@ int hite_fmea_chain(hite_ctx *ctx, int64_t n, const int32_t *qseg, const int32_t
                     const int64_t *qe, const int64_t *ss, const int64_t *se, int32_t nseg, const int32_t *seg_chrom,
                     const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
                     int64_t *out_start, int64_t *out_end, int64_t *n_out);
+/* same, HSP arrays resident on the device (e.g. straight from hite_seed_allvsall_dev: no PCIe round trip of the table) */
+int hite_fmea_chain_dev(hite_ctx *ctx, int64_t n, const int32_t *d_qseg, const int32_t *d_sseg, const int64_t *d_qs,
+                        const int64_t *d_qe, const int64_t *d_ss, const int64_t *d_se, int32_t nseg, const int32_t *seg_chrom,
+                        const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
+                        int64_t *out_start, int64_t *out_end, int64_t *n_out);
 
 /* ---- k-mer TSD seed matching --- search_confident_tir_v4  Util.py:7734-7845 -------------------------
  * batch of flanked candidates (CSR); the raw boundaries are (flank+1, len-flank), 1-based, as
@@ -183,6 +188,8 @@ int hite_copy_stats(void *state, int64_t out[4]);
  * ss > se for reverse-strand hits; ordered by (query segment, subject segment).  *n_out is set even on HITE_ECAP.
  * max_anchors bounds the device memory of the anchor sort (24 B per anchor).  stats_out (may be NULL) =
  * {seeds, anchors, clusters, records}. */
+int hite_seed_allvsall_dev(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int32_t **d_qseg, int32_t **d_sseg,
+                           int64_t **d_qs, int64_t **d_qe, int64_t **d_ss, int64_t **d_se, int64_t *n_out, int64_t *stats_out);
 int hite_seed_segments(hite_ctx *ctx, int64_t seg_len, int32_t cap, int32_t *seg_chrom, int64_t *seg_off, int32_t *nseg_out);
 int hite_seed_allvsall(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int64_t cap, int32_t *qseg,
                        int32_t *sseg, int64_t *qs, int64_t *qe, int64_t *ss, int64_t *se, int64_t *n_out, int64_t *stats_out);

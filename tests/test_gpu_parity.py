@@ -521,6 +521,9 @@ def test_seed_allvsall_vs_twin(ctx):
     h["seg_chrom"], h["seg_off"], h["chrom_names"] = sc, so, ["chr%d" % (i + 1) for i in range(2)]
     exp_names = O.fmea(h, 2000, 30000)
     assert ["chr%d:%d-%d" % (c + 1, a, b) for c, a, b in zip(oc, os_, oe)] == exp_names and len(exp_names) > 3
+    # device-resident form (the HSP table never crosses PCIe): same intervals
+    (oc2, os2, oe2), st2 = ctx.coarse_stage_dev(seg, sc, so, 2000, 30000)
+    assert np.array_equal(oc, oc2) and np.array_equal(os_, os2) and np.array_equal(oe, oe2) and st2 == got["stats"]
 
 
 def test_coarse_boundary_script_end_to_end(ctx, tmp_path):
