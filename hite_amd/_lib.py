@@ -364,6 +364,20 @@ class Context:
         self._check(rc, "hite_find_copies_dev")
         return (n.value,) + tuple(o.value or 0 for o in outs)
 
+    def ltr_frame(self, matrices, flank, window=20, side="left"):
+        """FiLTR flank-frame vote on a batch: matrices = list of lists of equal-length frame strings -> [(is_ltr, boundary)]"""
+        n = len(matrices)
+        rows = np.array([len(m) for m in matrices], dtype=np.int32)
+        cols = np.array([len(m[0]) if m else 0 for m in matrices], dtype=np.int32)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(rows.astype(np.int64) * cols, out=off[1:])
+        buf = np.frombuffer(("".join("".join(m) for m in matrices)).encode() + b"\0" * 16, dtype=np.uint8)
+        ok = np.zeros(n, dtype=np.int32)
+        b = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.hite_ltr_frame(self.h, n, _p(buf), _p(off), _p(rows), _p(cols), int(flank), int(window),
+                                            0 if side == "left" else 1, _p(ok), _p(b)), "hite_ltr_frame")
+        return [(bool(o), int(x)) for o, x in zip(ok, b)]
+
     def genome_mask(self, contig, start1, end1):
         """N-mask the 1-based inclusive intervals of the resident genome (mask_genome_intactTE)"""
         c, a, b = _arr(contig, np.int32), _arr(start1, np.int64), _arr(end1, np.int64)

@@ -140,6 +140,26 @@ def search_boundary_homo_v4(valid_col_threshold, pos, matrix, row_num, col_num, 
 
 
 # ---- a-6 ---------------------------------------------------------------------------------------------
+def _read_matrix(matrix_file, column):
+    rows = []
+    with open(matrix_file) as f:
+        for line in f:
+            rows.append(line.replace("\n", "").split("\t")[column])
+    return rows
+
+
+def judge_left_frame_LTR(matrix_file, flanking_len, sliding_window_size=20):
+    """bin/FiLTR-main/src/Util.py:9327: (is_ltr, new_boundary_start) from the left frames of the '.matrix' file"""
+    rows = _read_matrix(matrix_file, 0)
+    return (True, -1) if len(rows) <= 1 else get_ctx().ltr_frame([rows], flanking_len, sliding_window_size, "left")[0]
+
+
+def judge_right_frame_LTR(matrix_file, flanking_len, sliding_window_size=20):
+    """bin/FiLTR-main/src/Util.py:9175: (is_ltr, new_boundary_end) from the right frames of the '.matrix' file"""
+    rows = _read_matrix(matrix_file, 1)
+    return (True, -1) if len(rows) <= 1 else get_ctx().ltr_frame([rows], flanking_len, sliding_window_size, "right")[0]
+
+
 _COMP = {"A": "T", "T": "A", "C": "G", "G": "C"}
 
 

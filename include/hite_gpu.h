@@ -134,6 +134,15 @@ int hite_tsd_search(hite_ctx *ctx, int32_t n, const uint8_t *rows_bytes, const i
                     const int32_t *bstart, const int32_t *bend, int32_t plant, int32_t *tsd_len_out,
                     uint8_t *left_out /* n x 16 */, uint8_t *right_out /* n x 16 */);
 
+/* ---- LTR flank-frame vote (vendored FiLTR) --- judge_left_frame_LTR / judge_right_frame_LTR
+ * bin/FiLTR-main/src/Util.py:9327 / :9175 -----------------------------------------------------------------------------
+ * n matrices of rows[i] x cols[i] bytes at off[i] (the left OR right frames of the copies of one LTR candidate, what the
+ * reference reads from the '.matrix' file, one column of the tab-separated pair), side 0 = left frames (start column
+ * flank-1, walk left, tolerance 5), side 1 = right frames (start column 0, walk right, tolerance 20).
+ * ok_out[i] = 1 / 0 (is the candidate kept), boundary_out[i] = new boundary column or -1.  cols[i] <= 1024, flank <= cols[i]. */
+int hite_ltr_frame(hite_ctx *ctx, int32_t n, const uint8_t *frames, const int64_t *off, const int32_t *rows,
+                   const int32_t *cols, int32_t flank, int32_t window, int32_t side, int32_t *ok_out, int32_t *boundary_out);
+
 /* ---- FMEA --- get_longest_repeats_v4 + process_all_seqs  Util.py:4122-4400, 4529-4569 -------------
  * n HSPs in blast6 file order (cols 0,1,6,7,8,9 of -outfmt 6): qseg/sseg = ids of the 'chr$offset'
  * segment names, 1-based inclusive coordinates (reverse hits have ss > se); seg_chrom/seg_off give the

@@ -364,11 +364,60 @@ def gen_host(U):
                        "revcomp": [[s, U.getReverseSequence(s)] for s in rev]})
 
 
+def gen_ltr_frame(tmp):
+    """FiLTR flank-frame voting (bin/FiLTR-main/src/Util.py:9175 judge_right_frame_LTR, :9327 judge_left_frame_LTR):
+    matrix file rows 'left_frame\tright_frame' -> (is_ltr, new_boundary) for both sides"""
+    F = ref_harness.load_filtr_util()
+    rng = np.random.default_rng(4242)
+    cases = []
+    for ci in range(140):
+        R = int(rng.choice([1, 2, 3, 5, 6, 10, 11, 24, 51, 80]))
+        flank = int(rng.choice([30, 50, 100]))
+        # the homologous region reaches `hl` columns into the left frame (from its right end) and `hr` into the right frame
+        hl = int(rng.choice([0, 0, 3, 6, 15, 25, flank]))
+        hr = int(rng.choice([0, 0, 5, 19, 22, 30, flank]))
+        div = float(rng.choice([0.0, 0.05, 0.12, 0.3]))
+        cons_l, cons_r = casegen.rand_seq(rng, flank), casegen.rand_seq(rng, flank)
+        rows = []
+        for r in range(R):
+            L = list(casegen.rand_seq(rng, flank))
+            Rr = list(casegen.rand_seq(rng, flank))
+            for k in range(hl):
+                if rng.random() >= div:
+                    L[flank - 1 - k] = cons_l[flank - 1 - k]
+            for k in range(hr):
+                if rng.random() >= div:
+                    Rr[k] = cons_r[k]
+            L, Rr = "".join(L), "".join(Rr)
+            x = rng.random()
+            if x < 0.08:
+                L = "-" * flank
+            elif x < 0.16:
+                Rr = "-" * flank
+            elif x < 0.22:
+                cut = int(rng.integers(1, flank))
+                L = "-" * cut + L[cut:]
+                Rr = Rr[:flank - cut] + "-" * cut
+            elif x < 0.26:
+                L = L[:5] + "N" + L[6:]
+            rows.append((L, Rr))
+        path = os.path.join(tmp, "m%d.matrix" % ci)
+        with open(path, "w") as f:
+            for L, Rr in rows:
+                f.write(L + "\t" + Rr + "\n")
+        win = int(rng.choice([20, 20, 20, 10]))
+        lt = F.judge_left_frame_LTR(path, flank, sliding_window_size=win)
+        rt = F.judge_right_frame_LTR(path, flank, sliding_window_size=win)
+        cases.append({"left": [r[0] for r in rows], "right": [r[1] for r in rows], "flank": flank, "window": win,
+                      "left_out": [bool(lt[0]), int(lt[1])], "right_out": [bool(rt[0]), int(rt[1])]})
+    dump("ltr_frame", cases)
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -386,6 +435,8 @@ def main():
             gen_tails(U)
         if "host" in which:
             gen_host(U)
+        if "ltr" in which:
+            gen_ltr_frame(tmp)
 
 
 if __name__ == "__main__":

@@ -47,6 +47,21 @@ def load_reference_util():
     return Util
 
 
+def load_filtr_util():
+    """the vendored FiLTR's src/Util.py (bin/FiLTR-main, LTR flank-frame voting); needs the same stubs + intervaltree"""
+    import importlib.util
+
+    load_reference_util()
+    if "intervaltree" not in sys.modules:
+        it = types.ModuleType("intervaltree")
+        it.IntervalTree = object
+        sys.modules["intervaltree"] = it
+    spec = importlib.util.spec_from_file_location("filtr_util", os.path.join(REFERENCE_ROOT, "bin", "FiLTR-main", "src", "Util.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 class SyncExecutor:
     """Drop-in for ProcessPoolExecutor that runs submissions inline (deterministic,
     lets monkeypatched callables be used without pickling)."""

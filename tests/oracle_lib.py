@@ -253,3 +253,13 @@ def seed_allvsall(contigs, seg_len=1_000_000):
     L.orc_seed_segments(_ptr(coff, i64p), len(gb), C.c_int64(seg_len), _ptr(sc, i32p), _ptr(so, i64p), nseg)
     return {"qseg": qseg[:n].copy(), "sseg": sseg[:n].copy(), "qs": qs[:n].copy(), "qe": qe[:n].copy(), "ss": ss[:n].copy(),
             "se": se[:n].copy(), "seg_chrom": sc, "seg_off": so}
+
+
+def ltr_frame(rows, flank, window, side):
+    """FiLTR flank-frame vote: rows = frames of one side -> (is_ltr, boundary)"""
+    R = len(rows)
+    Cn = len(rows[0]) if R else 0
+    m = np.frombuffer("".join(rows).encode(), dtype=np.uint8).copy() if R else np.zeros(1, np.uint8)
+    b = C.c_int(-1)
+    ok = lib().orc_ltr_frame(_ptr(m, u8p), R, Cn, int(flank), int(window), 0 if side == "left" else 1, C.byref(b))
+    return bool(ok), int(b.value)

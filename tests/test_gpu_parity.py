@@ -600,3 +600,44 @@ def test_mask_genome_intactTE(ctx, tmp_path):
     c, s1, e1, _m, _a = tab[0][0]
     wins, _ = util.get_ctx().flank_gather([c], [s1], [e1], [0], flank=0)
     assert set(wins[0].decode()) == {"N"}
+
+
+def test_ltr_frame(ctx, tmp_path):
+    """FiLTR flank-frame vote: golden vectors (reference outputs) and fresh random matrices vs the oracle, batched"""
+    from hite_amd import util
+
+    g = load_golden("ltr_frame")
+    by = {}
+    for c in g:
+        by.setdefault((c["flank"], c["window"]), []).append(c)
+    for (flank, win), cs in by.items():
+        got_l = ctx.ltr_frame([c["left"] for c in cs], flank, win, "left")
+        got_r = ctx.ltr_frame([c["right"] for c in cs], flank, win, "right")
+        for c, a, b in zip(cs, got_l, got_r):
+            assert list(a) == c["left_out"] and list(b) == c["right_out"]
+    rng = np.random.default_rng(77)
+    mats = []
+    for _ in range(200):
+        R, flank = int(rng.integers(2, 120)), 60
+        cons = casegen.rand_seq(rng, flank)
+        h = int(rng.integers(0, flank + 1))
+        rows = []
+        for _r in range(R):
+            s = list(casegen.rand_seq(rng, flank))
+            for k in range(h):
+                if rng.random() > 0.1:
+                    s[k] = cons[k]
+            if rng.random() < 0.1:
+                s = ["-"] * flank
+            rows.append("".join(s))
+        mats.append(rows)
+    got = ctx.ltr_frame(mats, 60, 20, "right")
+    assert [tuple(x) for x in got] == [O.ltr_frame(m, 60, 20, "right") for m in mats]
+    got = ctx.ltr_frame([[r[::-1] for r in m] for m in mats], 60, 20, "left")
+    assert [tuple(x) for x in got] == [O.ltr_frame([r[::-1] for r in m], 60, 20, "left") for m in mats]
+    # file-level mirror
+    c = g[5]
+    mf = tmp_path / "x.matrix"
+    mf.write_text("".join(a + "\t" + b + "\n" for a, b in zip(c["left"], c["right"])))
+    assert list(util.judge_left_frame_LTR(str(mf), c["flank"], c["window"])) == c["left_out"]
+    assert list(util.judge_right_frame_LTR(str(mf), c["flank"], c["window"])) == c["right_out"]

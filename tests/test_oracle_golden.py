@@ -179,3 +179,14 @@ def test_host_glue_golden():
         assert util.split_and_store_sequences(c["names"], {n: "A" * l for n, l in zip(c["names"], c["lens"])}, c["thr"]) == c["groups"]
     for s, r in g["revcomp"]:
         assert util.getReverseSequence(s) == r
+
+
+def test_ltr_frame_golden():
+    """FiLTR flank-frame vote (judge_left/right_frame_LTR) restatement vs the reference's outputs"""
+    g = load_golden("ltr_frame")
+    seen = set()
+    for c in g:
+        assert list(O.ltr_frame(c["left"], c["flank"], c["window"], "left")) == c["left_out"]
+        assert list(O.ltr_frame(c["right"], c["flank"], c["window"], "right")) == c["right_out"]
+        seen.add((tuple(c["left_out"])[0], c["left_out"][1] >= 0, c["right_out"][0], c["right_out"][1] >= 0))
+    assert len(seen) >= 5
