@@ -143,7 +143,6 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             breg = (jb >= 0 && jb < n) ? b[jb] : 0xFE;
         }
         const int m31 = m - 31, n1 = n + 1;
-        const int nchunk = (steps + 15) >> 4;          // chunk ch = anti-diagonals 16 ch + 1 .. 16 ch + 16
         const int neg32 = to_sgpr(-32);
         int vm1;                                       // DPP forms take no constant operand
         asm volatile("v_mov_b32 %0, -1" : "=v"(vm1));
@@ -220,63 +219,89 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
               [prev] "+v"(prev), [p0] "+v"(p0), [p1] "+v"(p1), [areg] "+v"(areg), [breg] "+v"(breg), [aaddr] "+v"(aaddr), \
               [baddr] "+v"(baddr), [d2] "+v"(d2), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv)
         int p0 = pp, p1 = 0;                           // the diagonal operand lives in p0 at the start of every chunk
-        for (int ch = 0; ch < nchunk; ch++) {
-            const int s_lo = (ch << 4) + 1;
-            const int left = steps - (ch << 4);
-            const int nst = left < 16 ? left : 16;
-            {   // windows of this chunk: entries 1..63 are the bases the lanes hold now, 64..79 the (<= 16) that can enter
+        const int nchunk32 = (steps + 31) >> 5;        // chunk = 32 anti-diagonals (two 16-step direction words per lane)
+        for (int ch = 0; ch < nchunk32; ch++) {
+            const int s_lo = (ch << 5) + 1;
+            const int left = steps - (ch << 5);
+            const int nst = left < 32 ? left : 32;
+            const int nst1 = nst < 16 ? nst : 16, nst2 = nst - nst1;
+            {   // windows of this chunk: entries 1..63 are the bases the lanes hold now, 64..95 the (<= 32) that can enter
                 winA[lane] = (uint8_t)areg;
                 winB[63 - lane] = (uint8_t)breg;
-                const bool isb = lane >= 16;
-                const int idx = isb ? s_lo - t - 1 + (lane - 16) : t + 63 + lane;
+                const bool isb = lane >= 32;
+                const int idx = isb ? s_lo - t - 1 + (lane - 32) : t + 63 + lane;
                 const int lim = isb ? n : m;
                 const uint8_t *src = isb ? b : a;
-                if (lane < 32) {
-                    const int raw = src[(unsigned)idx < (unsigned)lim ? idx : 0];
-                    const int v = (unsigned)idx < (unsigned)lim ? ((!isb && raw == 'N') ? 0xFD : raw) : (isb ? 0xFE : 0xFF);
-                    (isb ? winB : winA)[64 + (lane & 15)] = (uint8_t)v;
-                }
+                const int raw = src[(unsigned)idx < (unsigned)lim ? idx : 0];
+                const int v = (unsigned)idx < (unsigned)lim ? ((!isb && raw == 'N') ? 0xFD : raw) : (isb ? 0xFE : 0xFF);
+                (isb ? winB : winA)[64 + (lane & 31)] = (uint8_t)v;
             }
             int aaddr = (int)(ldsA + lane), baddr = (int)(ldsB + 63 - lane);
-            int d2 = 0, tsc, tcd, thx, tv;
-            int mreg = to_sgpr(0), sx, sy, tn, h0, h63;
+            int d2 = 0, d2a = 0, tsc, tcd, thx, tv;
+            int mreg = to_sgpr(0), mrega = to_sgpr(0), sx, sy, tn, h0, h63;
             int s31 = to_sgpr(s_lo - 32);              // (s - 31) of the step before the next one
-            // neither clamp can bind during a full chunk that starts with t + 16 <= m - 31 and t >= max(0, s_hi - n) - 32
-            // (t only grows, by at most one per step; t <= s - 32 always): such chunks run the 16 steps unrolled and
+            // neither clamp can bind during a full chunk that starts with t + 32 <= m - 31 and t >= max(0, s_hi - n) - 32
+            // (t only grows, by at most one per step; t <= s - 32 always): such chunks run the 32 steps unrolled and
             // recover t from the recorded moves.  Both forms live in ONE asm statement (same registers: no copies).
-            const int s_hi = s_lo + 15;
-            const int fast = to_sgpr((nst == 16 && t + 16 <= m31 && t >= (s_hi > n ? s_hi - n : 0) - 32) ? 1 : 0);
-            int cnt = to_sgpr((nst >> 1) - 1);         // pairs - 1 (general form)
-            const int odd = to_sgpr(nst & 1);          // only the last chunk can be odd: p1 is never read again
+            // After 16 steps the direction word and the move word are full: they are parked in d2a / mrega.
+            const int s_hi = s_lo + 31;
+            const int fast = to_sgpr((nst == 32 && t + 32 <= m31 && t >= (s_hi > n ? s_hi - n : 0) - 32) ? 1 : 0);
+            int cnt1 = to_sgpr((nst1 >> 1) - 1), cnt2 = to_sgpr((nst2 >> 1) - 1);   // pairs - 1 of each half (general form)
+            const int odd1 = to_sgpr(nst1 & 1), odd2 = to_sgpr(nst2 & 1);           // only the last chunk can be odd
             asm volatile(
                 "s_cmp_lg_u32 %[fast], 0\n\t"
                 "s_cbranch_scc1 F_%=\n\t"
-                "s_cmp_lt_i32 %[cnt], 0\n\t"
-                "s_cbranch_scc1 S_%=\n"
-                "L_%=:\n\t"
+                "s_cmp_lt_i32 %[cnt1], 0\n\t"
+                "s_cbranch_scc1 S1_%=\n"
+                "L1_%=:\n\t"
                 STEP_GEN("s_cmp_ge_i32", "a", "p0", "p1")
                 STEP_GEN("s_cmp_gt_i32", "b", "p1", "p0")
-                "s_sub_u32 %[cnt], %[cnt], 1\n\t"
-                "s_cbranch_scc0 L_%=\n"
-                "S_%=:\n\t"
-                "s_cmp_eq_u32 %[odd], 0\n\t"
-                "s_cbranch_scc1 E_%=\n\t"
+                "s_sub_u32 %[cnt1], %[cnt1], 1\n\t"
+                "s_cbranch_scc0 L1_%=\n"
+                "S1_%=:\n\t"
+                "s_cmp_eq_u32 %[odd1], 0\n\t"
+                "s_cbranch_scc1 H_%=\n\t"
                 STEP_GEN("s_cmp_ge_i32", "c", "p0", "p1")
+                "H_%=:\n\t"
+                "v_mov_b32 %[d2a], %[d2]\n\t"
+                "s_mov_b32 %[mrega], %[mreg]\n\t"
+                "s_cmp_lt_i32 %[cnt2], 0\n\t"
+                "s_cbranch_scc1 S2_%=\n"
+                "L2_%=:\n\t"
+                STEP_GEN("s_cmp_ge_i32", "d", "p0", "p1")
+                STEP_GEN("s_cmp_gt_i32", "e", "p1", "p0")
+                "s_sub_u32 %[cnt2], %[cnt2], 1\n\t"
+                "s_cbranch_scc0 L2_%=\n"
+                "S2_%=:\n\t"
+                "s_cmp_eq_u32 %[odd2], 0\n\t"
+                "s_cbranch_scc1 E_%=\n\t"
+                STEP_GEN("s_cmp_ge_i32", "f", "p0", "p1")
                 "s_branch E_%=\n"
                 "F_%=:\n\t"
                 STEP_FAST2("0") STEP_FAST2("1") STEP_FAST2("2") STEP_FAST2("3")
                 STEP_FAST2("4") STEP_FAST2("5") STEP_FAST2("6") STEP_FAST2("7")
+                "v_mov_b32 %[d2a], %[d2]\n\t"
+                "s_mov_b32 %[mrega], %[mreg]\n\t"
+                STEP_FAST2("8") STEP_FAST2("9") STEP_FAST2("10") STEP_FAST2("11")
+                STEP_FAST2("12") STEP_FAST2("13") STEP_FAST2("14") STEP_FAST2("15")
                 "s_and_b32 %[x], %[mreg], 0x55555555\n\t"
+                "s_and_b32 %[y], %[mrega], 0x55555555\n\t"
                 "s_bcnt1_i32_b32 %[x], %[x]\n\t"
-                "s_add_i32 %[t], %[t], %[x]\n"
+                "s_bcnt1_i32_b32 %[y], %[y]\n\t"
+                "s_add_i32 %[t], %[t], %[x]\n\t"
+                "s_add_i32 %[t], %[t], %[y]\n"
                 "E_%=:\n\t"
-                : STEP_VREGS, [t] "+s"(t), [mreg] "+s"(mreg), [s31] "+s"(s31), [cnt] "+s"(cnt), [x] "=&s"(sx), [y] "=&s"(sy),
-                  [tn] "=&s"(tn), [h0] "=&s"(h0), [h63] "=&s"(h63)
-                : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32), [vm1] "v"(vm1), [fast] "s"(fast), [odd] "s"(odd)
+                : STEP_VREGS, [d2a] "+v"(d2a), [t] "+s"(t), [mreg] "+s"(mreg), [mrega] "+s"(mrega), [s31] "+s"(s31), [cnt1] "+s"(cnt1),
+                  [cnt2] "+s"(cnt2), [x] "=&s"(sx), [y] "=&s"(sy), [tn] "=&s"(tn), [h0] "=&s"(h0), [h63] "=&s"(h63)
+                : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32), [vm1] "v"(vm1), [fast] "s"(fast), [odd1] "s"(odd1), [odd2] "s"(odd2)
                 : "vcc", "scc", "memory");
-            // two bits per step, step r of the chunk at bits 2r+1 : 2r (directions), the move at bit 30 - 2r
-            tbd[ch * 64 + lane] = (unsigned)d2 >> (2 * (16 - nst));
-            if (lane == 0) tbm[ch] = (unsigned)mreg << (2 * (16 - nst));
+            // two bits per step, step r of a 16-step word at bits 2r+1 : 2r (directions), the move at bit 30 - 2r
+            tbd[(2 * ch) * 64 + lane] = (unsigned)d2a >> (2 * (16 - nst1));
+            if (lane == 0) tbm[2 * ch] = (unsigned)mrega << (2 * (16 - nst1));
+            if (nst2 > 0) {
+                tbd[(2 * ch + 1) * 64 + lane] = (unsigned)d2 >> (2 * (16 - nst2));
+                if (lane == 0) tbm[2 * ch + 1] = (unsigned)mreg << (2 * (16 - nst2));
+            }
         }
 #undef STEP_GEN
 #undef STEP_FAST
