@@ -690,6 +690,17 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
 // ---------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------
+// resident workgroups of the alignment kernel.  256 CUs x 8 = 2048 fills every wave slot; a caller that drives several
+// contexts on one GPU leaves room for the other context's memory-bound kernels with fewer (HITE_ALIGN_BLOCKS).
+static int align_max_blocks() {
+    static int v = 0;
+    if (!v) {
+        const char *e = getenv("HITE_ALIGN_BLOCKS");
+        v = e ? atoi(e) : 2048;
+        if (v < 64 || v > 4096) v = 2048;
+    }
+    return v;
+}
 static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
                            const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base,
                            int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status,
@@ -702,7 +713,7 @@ static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
     int64_t pairs = total_rows - n;
     int grid = (int)((pairs + 3) / 4);
     if (grid < 1) grid = 1;
-    if (grid > 2048) grid = 2048;
+    if (grid > align_max_blocks()) grid = align_max_blocks();
     while (grid > 64 && (size_t)grid * 4 * tb_slot > ((size_t)3 << 30)) grid /= 2;
     void *scr = nullptr, *opsb = nullptr;
     int rc = hite_scratch_reserve(ctx, (size_t)grid * 4 * tb_slot + 256, &scr);
