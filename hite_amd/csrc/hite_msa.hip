@@ -245,7 +245,9 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             // recover t from the recorded moves.  Both forms live in ONE asm statement (same registers: no copies).
             // After 16 steps the direction word and the move word are full: they are parked in d2a / mrega.
             const int s_hi = s_lo + 31;
-            const int fast = to_sgpr((nst == 32 && t + 32 <= m31 && t >= (s_hi > n ? s_hi - n : 0) - 32) ? 1 : 0);
+            // sign-bit form (no booleans: the compiler would route them through a VGPR)
+            const int lo_t = (s_hi > n ? s_hi - n : 0) - 32;
+            const int fast = (int)(~(unsigned)((m31 - t - 32) | (t - lo_t) | (nst - 32)) >> 31);
             int cnt1 = to_sgpr((nst1 >> 1) - 1), cnt2 = to_sgpr((nst2 >> 1) - 1);   // pairs - 1 of each half (general form)
             const int odd1 = to_sgpr(nst1 & 1), odd2 = to_sgpr(nst2 & 1);           // only the last chunk can be odd
             asm volatile(
@@ -319,58 +321,55 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 
         // ---------------- traceback: scalar walk ----------------
-        // i-1 (in M0: it is the lane select of the v_writelane that drops each result into `oreg`), the difference
-        // d = (i-1) - (j-1), k, and the bit index q of the anti-diagonal inside its chunk live in SGPRs; the direction word
-        // of the current cell is one v_readlane of the chunk's per-lane words.  What is dropped per centre position is d
-        // (the lane knows its own position; bit 20 marks "gap"), so a diagonal step costs 2 vector + 7 scalar
-        // instructions.  One asm loop per 16-step chunk, then the <= 16 centre positions it produced leave as one masked
-        // store.  A cell on the path is always inside the band (its score derives from H(0,0), checked above; band-edge
-        // fills are 2^28 lower), so k is only checked per chunk.
-#define TB_LOOP(V, EXIT4, EXIT2U, EXIT2L)                                                            \
+        // i-1 (in M0: it is the lane select of the v_writelane that drops each result into `oreg`), j-1, k and the bit index
+        // q of the anti-diagonal inside its 16-step word live in SGPRs; the direction word of the current cell is one
+        // v_readlane of the word's per-lane values.  A diagonal step costs 2 vector + 8 scalar instructions.  One asm loop
+        // per 16-step word, then the <= 16 centre positions it produced leave as one masked store.  A cell on the path is
+        // always inside the band (its score derives from H(0,0), checked above; band-edge fills are 2^28 lower), so k is
+        // only checked per word.
+#define TB_LOOP(V, EXIT4, EXIT2U, EXIT2L)                                                         \
                 "s_mov_b32 m0, %[ip]\n\t"                                                         \
-                "s_branch L" V "_%=\n"                                                                 \
-                "N" V "_%=:\n\t"                                                                       \
+                "s_branch L" V "_%=\n"                                                            \
+                "N" V "_%=:\n\t"                                                                  \
                 "s_lshl_b32 %[w], %[w], 1\n\t"                                                    \
                 "s_bitcmp1_b32 %[w], %[q]\n\t"                                                    \
-                "s_cbranch_scc0 F" V "_%=\n\t"                                                         \
+                "s_cbranch_scc0 F" V "_%=\n\t"                                                    \
                 /* up: centre position i-1 faces a gap before row position j;  k += move(s) - 1 */ \
-                "s_xor_b32 %[x], %[dc], 0x100000\n\t"                                             \
+                "s_add_i32 %[x], %[jp], 0x8001\n\t"                                               \
                 "v_writelane_b32 %[oreg], %[x], m0\n\t"                                           \
                 "s_bitcmp0_b32 %[mma], %[q]\n\t"                                                  \
                 "s_subb_u32 %[k], %[k], 0\n\t"                                                    \
                 "s_sub_i32 m0, m0, 1\n\t"                                                         \
-                "s_sub_i32 %[dc], %[dc], 1\n\t"                                                   \
                 EXIT2U                                                                            \
-                "s_branch E" V "_%=\n"                                                                 \
-                "F" V "_%=:\n\t"                                                                       \
+                "s_branch E" V "_%=\n"                                                            \
+                "F" V "_%=:\n\t"                                                                  \
                 /* left: a row base inserted;  k += move(s) */                                    \
                 "s_bitcmp1_b32 %[mma], %[q]\n\t"                                                  \
                 "s_addc_u32 %[k], %[k], 0\n\t"                                                    \
-                "s_add_i32 %[dc], %[dc], 1\n\t"                                                   \
+                "s_sub_i32 %[jp], %[jp], 1\n\t"                                                   \
                 EXIT2L                                                                            \
-                "s_branch E" V "_%=\n"                                                                 \
-                "L" V "_%=:\n\t"                                                                       \
+                "s_branch E" V "_%=\n"                                                            \
+                "L" V "_%=:\n\t"                                                                  \
                 "v_readlane_b32 %[w], %[wcur], %[k]\n\t"                                          \
                 "s_bitcmp1_b32 %[w], %[q]\n\t"                                                    \
-                "s_cbranch_scc0 N" V "_%=\n\t"                                                         \
+                "s_cbranch_scc0 N" V "_%=\n\t"                                                    \
                 /* diagonal: centre position i-1 <-> row position j-1;  k += move(s) + move(s-1) - 1 */ \
-                "v_writelane_b32 %[oreg], %[dc], m0\n\t"                                          \
+                "v_writelane_b32 %[oreg], %[jp], m0\n\t"                                          \
                 "s_bitcmp0_b32 %[mma], %[q]\n\t"                                                  \
                 "s_subb_u32 %[k], %[k], 0\n\t"                                                    \
                 "s_bitcmp1_b32 %[mmb], %[q]\n\t"                                                  \
                 "s_addc_u32 %[k], %[k], 0\n\t"                                                    \
                 "s_sub_i32 m0, m0, 1\n\t"                                                         \
+                "s_sub_i32 %[jp], %[jp], 1\n\t"                                                   \
                 EXIT4                                                                             \
-                "E" V "_%=:\n\t"                                                                       \
+                "E" V "_%=:\n\t"                                                                  \
                 "s_mov_b32 %[ip], m0"
-        // exit tests.  plain: the chunk cannot reach row / column 0 (i-1, j-1 >= 16 on entry): only q can run out (q is
-        // odd: the subtraction borrows exactly when the chunk is finished).  careful: also i-1 < 0 or j-1 < 0.
+        // exit tests.  plain: the word cannot reach row / column 0 (i-1, j-1 >= 16 on entry): only q can run out (q is
+        // odd: the subtraction borrows exactly when the word is finished).  careful: also i-1 < 0 or j-1 < 0.
 #define TB_PLAIN(N, V) "s_sub_u32 %[q], %[q], " N "\n\ts_cbranch_scc0 L" V "_%=\n\t"
-#define TB_CAREFUL(N, V, WITH_I)                                                                     \
+#define TB_CAREFUL(N, V)                                                                          \
                 "s_sub_i32 %[q], %[q], " N "\n\t"                                                 \
-                "s_sub_i32 %[x], m0, %[dc]\n\t"                                                   \
-                "s_add_i32 %[x], %[x], 0x10000\n\t"                                               \
-                WITH_I                                                                            \
+                "s_or_b32 %[x], %[jp], m0\n\t"                                                    \
                 "s_or_b32 %[x], %[x], %[q]\n\t"                                                   \
                 "s_cmp_lt_i32 %[x], 0\n\t"                                                        \
                 "s_cbranch_scc0 L" V "_%=\n\t"
@@ -378,37 +377,31 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         int k = m - t;                    // lane that owns cell (i, j) on anti-diagonal i + j
         int oreg = 0, bad = 0, fail;
         while (ip >= 0 && jp >= 0) {
-            const int sp = ip + jp + 1;   // chunk / bit index of anti-diagonal i + j
+            const int sp = ip + jp + 1;   // word / bit index of anti-diagonal i + j
             const int dch = sp >> 4;
-            int q = to_sgpr(((sp & 15) << 1) + 1);        // 2 x (step inside the chunk) + 1
+            int q = to_sgpr(((sp & 15) << 1) + 1);        // 2 x (step inside the word) + 1
             const unsigned wcur = tbd[dch * 64 + lane];   // step r: bit 2r+1 diagonal wins, else bit 2r up, else left
             const unsigned mc = tbm[dch], mp = dch > 0 ? tbm[dch - 1] : 0u;
             const int mma = to_sgpr((int)__brev(mc));                                  // bit 2r+1: move of step r
             const int mmb = to_sgpr((int)((__brev(mc) << 2) | ((mp & 1u) << 1)));      // bit 2r+1: move of step r-1
             bad |= (unsigned)k > 63u;
             const int ip0 = ip;
-            int dc = to_sgpr(ip - jp + 0x10000);          // d + 2^16
+            const int plain = (ip < jp ? ip : jp) >> 4;   // != 0: both >= 16 (integer form: stays on the scalar unit)
             int sw, sx;
-            const int plain = to_sgpr((ip >= 16 && jp >= 16) ? 1 : 0);
             asm volatile(
                 "s_cmp_lg_u32 %[plain], 0\n\t"
                 "s_cbranch_scc1 P_%=\n\t"
-                TB_LOOP("c", TB_CAREFUL("4", "c", "s_or_b32 %[x], %[x], m0\n\t"), TB_CAREFUL("2", "c", "s_or_b32 %[x], %[x], m0\n\t"),
-                        TB_CAREFUL("2", "c", ""))
+                TB_LOOP("c", TB_CAREFUL("4", "c"), TB_CAREFUL("2", "c"), TB_CAREFUL("2", "c"))
                 "\n\ts_branch X_%=\n"
                 "P_%=:\n\t"
                 TB_LOOP("p", TB_PLAIN("4", "p"), TB_PLAIN("2", "p"), TB_PLAIN("2", "p"))
                 "\nX_%=:\n\t"
-                : [ip] "+s"(ip), [dc] "+s"(dc), [k] "+s"(k), [q] "+s"(q), [oreg] "+v"(oreg), [w] "=&s"(sw), [x] "=&s"(sx)
+                : [ip] "+s"(ip), [jp] "+s"(jp), [k] "+s"(k), [q] "+s"(q), [oreg] "+v"(oreg), [w] "=&s"(sw), [x] "=&s"(sx)
                 : [wcur] "v"(wcur), [mma] "s"(mma), [mmb] "s"(mmb), [plain] "s"(plain)
                 : "scc");
-            jp = ip - (dc - 0x10000);
-            // positions (ip, ip0] were produced by this chunk: lane l holds the one with p mod 64 == l
+            // positions (ip, ip0] were produced by this word: lane l holds the one with p mod 64 == l
             const int pl = ip0 - ((ip0 - lane) & 63);
-            if (pl > ip) {
-                const int jv = pl - ((oreg & 0xfffff) - 0x10000);   // j - 1 of the cell that left row i = pl + 1
-                ops[pl] = (uint16_t)(((oreg >> 20) & 1) ? ((jv + 1) | 0x8000) : jv);
-            }
+            if (pl > ip) ops[pl] = (uint16_t)oreg;
         }
         for (int q = lane; q <= ip; q += 64) ops[q] = (uint16_t)0x8000;   // j == 0: gaps before row position 0
 #undef TB_LOOP
