@@ -327,7 +327,7 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         // per 16-step word, then the <= 16 centre positions it produced leave as one masked store.  A cell on the path is
         // always inside the band (its score derives from H(0,0), checked above; band-edge fills are 2^28 lower), so k is
         // only checked per word.
-#define TB_LOOP(V, EXIT4, EXIT2U, EXIT2L)                                                         \
+#define TB_LOOP(V, WCUR, MMA, MMB, EXIT4, EXIT2U, EXIT2L)                                          \
                 "s_mov_b32 m0, %[ip]\n\t"                                                         \
                 "s_branch L" V "_%=\n"                                                            \
                 "N" V "_%=:\n\t"                                                                  \
@@ -337,34 +337,34 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
                 /* up: centre position i-1 faces a gap before row position j;  k += move(s) - 1 */ \
                 "s_add_i32 %[x], %[jp], 0x8001\n\t"                                               \
                 "v_writelane_b32 %[oreg], %[x], m0\n\t"                                           \
-                "s_bitcmp0_b32 %[mma], %[q]\n\t"                                                  \
+                "s_bitcmp0_b32 %[" MMA "], %[q]\n\t"                                              \
                 "s_subb_u32 %[k], %[k], 0\n\t"                                                    \
                 "s_sub_i32 m0, m0, 1\n\t"                                                         \
                 EXIT2U                                                                            \
                 "s_branch E" V "_%=\n"                                                            \
                 "F" V "_%=:\n\t"                                                                  \
                 /* left: a row base inserted;  k += move(s) */                                    \
-                "s_bitcmp1_b32 %[mma], %[q]\n\t"                                                  \
+                "s_bitcmp1_b32 %[" MMA "], %[q]\n\t"                                              \
                 "s_addc_u32 %[k], %[k], 0\n\t"                                                    \
                 "s_sub_i32 %[jp], %[jp], 1\n\t"                                                   \
                 EXIT2L                                                                            \
                 "s_branch E" V "_%=\n"                                                            \
                 "L" V "_%=:\n\t"                                                                  \
-                "v_readlane_b32 %[w], %[wcur], %[k]\n\t"                                          \
+                "v_readlane_b32 %[w], %[" WCUR "], %[k]\n\t"                                      \
                 "s_bitcmp1_b32 %[w], %[q]\n\t"                                                    \
                 "s_cbranch_scc0 N" V "_%=\n\t"                                                    \
                 /* diagonal: centre position i-1 <-> row position j-1;  k += move(s) + move(s-1) - 1 */ \
                 "v_writelane_b32 %[oreg], %[jp], m0\n\t"                                          \
-                "s_bitcmp0_b32 %[mma], %[q]\n\t"                                                  \
+                "s_bitcmp0_b32 %[" MMA "], %[q]\n\t"                                              \
                 "s_subb_u32 %[k], %[k], 0\n\t"                                                    \
-                "s_bitcmp1_b32 %[mmb], %[q]\n\t"                                                  \
+                "s_bitcmp1_b32 %[" MMB "], %[q]\n\t"                                              \
                 "s_addc_u32 %[k], %[k], 0\n\t"                                                    \
                 "s_sub_i32 m0, m0, 1\n\t"                                                         \
                 "s_sub_i32 %[jp], %[jp], 1\n\t"                                                   \
                 EXIT4                                                                             \
                 "E" V "_%=:\n\t"                                                                  \
-                "s_mov_b32 %[ip], m0"
-        // exit tests.  plain: the word cannot reach row / column 0 (i-1, j-1 >= 16 on entry): only q can run out (q is
+                "s_mov_b32 %[ip], m0\n\t"
+        // exit tests.  plain: the two words cannot reach row / column 0 (i-1, j-1 >= 32 on entry): only q can run out (q is
         // odd: the subtraction borrows exactly when the word is finished).  careful: also i-1 < 0 or j-1 < 0.
 #define TB_PLAIN(N, V) "s_sub_u32 %[q], %[q], " N "\n\ts_cbranch_scc0 L" V "_%=\n\t"
 #define TB_CAREFUL(N, V)                                                                          \
@@ -380,26 +380,42 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             const int sp = ip + jp + 1;   // word / bit index of anti-diagonal i + j
             const int dch = sp >> 4;
             int q = to_sgpr(((sp & 15) << 1) + 1);        // 2 x (step inside the word) + 1
-            const unsigned wcur = tbd[dch * 64 + lane];   // step r: bit 2r+1 diagonal wins, else bit 2r up, else left
-            const unsigned mc = tbm[dch], mp = dch > 0 ? tbm[dch - 1] : 0u;
-            const int mma = to_sgpr((int)__brev(mc));                                  // bit 2r+1: move of step r
-            const int mmb = to_sgpr((int)((__brev(mc) << 2) | ((mp & 1u) << 1)));      // bit 2r+1: move of step r-1
+            // two 16-step words per trip (the one that holds anti-diagonal i + j and the one below): step r of a word has
+            // bit 2r+1 "diagonal wins", else bit 2r "up", else left
+            const int dlo = dch > 0 ? dch - 1 : 0;
+            const unsigned wcur1 = tbd[dch * 64 + lane], wcur0 = tbd[dlo * 64 + lane];
+            const unsigned m2 = tbm[dch], m1 = dch > 0 ? tbm[dch - 1] : 0u, m0w = dch > 1 ? tbm[dch - 2] : 0u;
+            const int mma1 = to_sgpr((int)__brev(m2));                                   // bit 2r+1: move of step r
+            const int mmb1 = to_sgpr((int)((__brev(m2) << 2) | ((m1 & 1u) << 1)));       // bit 2r+1: move of step r-1
+            const int mma0 = to_sgpr((int)__brev(m1));
+            const int mmb0 = to_sgpr((int)((__brev(m1) << 2) | ((m0w & 1u) << 1)));
+            const int two = dch < 1 ? dch : 1;           // integer form (a boolean would be routed through a VGPR)
             bad |= (unsigned)k > 63u;
             const int ip0 = ip;
-            const int plain = (ip < jp ? ip : jp) >> 4;   // != 0: both >= 16 (integer form: stays on the scalar unit)
+            const int plain = (ip < jp ? ip : jp) >> 5;   // != 0: both >= 32 (integer form: stays on the scalar unit)
             int sw, sx;
             asm volatile(
                 "s_cmp_lg_u32 %[plain], 0\n\t"
                 "s_cbranch_scc1 P_%=\n\t"
-                TB_LOOP("c", TB_CAREFUL("4", "c"), TB_CAREFUL("2", "c"), TB_CAREFUL("2", "c"))
-                "\n\ts_branch X_%=\n"
+                TB_LOOP("c1", "wcur1", "mma1", "mmb1", TB_CAREFUL("4", "c1"), TB_CAREFUL("2", "c1"), TB_CAREFUL("2", "c1"))
+                "s_or_b32 %[x], %[jp], %[ip]\n\t"        /* left the word because row / column 0 was reached? */
+                "s_cmp_lt_i32 %[x], 0\n\t"
+                "s_cbranch_scc1 X_%=\n\t"
+                "s_cmp_eq_u32 %[two], 0\n\t"
+                "s_cbranch_scc1 X_%=\n\t"
+                "s_add_i32 %[q], %[q], 32\n\t"
+                TB_LOOP("c0", "wcur0", "mma0", "mmb0", TB_CAREFUL("4", "c0"), TB_CAREFUL("2", "c0"), TB_CAREFUL("2", "c0"))
+                "s_branch X_%=\n"
                 "P_%=:\n\t"
-                TB_LOOP("p", TB_PLAIN("4", "p"), TB_PLAIN("2", "p"), TB_PLAIN("2", "p"))
+                TB_LOOP("p1", "wcur1", "mma1", "mmb1", TB_PLAIN("4", "p1"), TB_PLAIN("2", "p1"), TB_PLAIN("2", "p1"))
+                "s_add_i32 %[q], %[q], 32\n\t"
+                TB_LOOP("p0", "wcur0", "mma0", "mmb0", TB_PLAIN("4", "p0"), TB_PLAIN("2", "p0"), TB_PLAIN("2", "p0"))
                 "\nX_%=:\n\t"
                 : [ip] "+s"(ip), [jp] "+s"(jp), [k] "+s"(k), [q] "+s"(q), [oreg] "+v"(oreg), [w] "=&s"(sw), [x] "=&s"(sx)
-                : [wcur] "v"(wcur), [mma] "s"(mma), [mmb] "s"(mmb), [plain] "s"(plain)
+                : [wcur1] "v"(wcur1), [wcur0] "v"(wcur0), [mma1] "s"(mma1), [mmb1] "s"(mmb1), [mma0] "s"(mma0), [mmb0] "s"(mmb0),
+                  [plain] "s"(plain), [two] "s"(two)
                 : "scc");
-            // positions (ip, ip0] were produced by this word: lane l holds the one with p mod 64 == l
+            // positions (ip, ip0] were produced by this trip (<= 32): lane l holds the one with p mod 64 == l
             const int pl = ip0 - ((ip0 - lane) & 63);
             if (pl > ip) ops[pl] = (uint16_t)oreg;
         }
