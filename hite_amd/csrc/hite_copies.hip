@@ -239,30 +239,49 @@ __global__ void occ_kernel(int64_t nq, const unsigned *__restrict__ q_hs, const 
     occ_n[t] = n > C_MAXOCC ? 0 : n;
 }
 
-// hits: key = candidate << 34 | rel << 33 | (d + DBIAS), value = qo
-__global__ void hit_kernel(int64_t nq, const unsigned *__restrict__ q_c, const unsigned *__restrict__ q_pos,
-                           const unsigned *__restrict__ q_hs, const int64_t *__restrict__ cand_off,
-                           const unsigned *__restrict__ idx_hs, const unsigned *__restrict__ idx_pos,
-                           const unsigned *__restrict__ occ_lo, const int32_t *__restrict__ occ_n,
-                           const int64_t *__restrict__ hit_off, unsigned long long *__restrict__ hkey, unsigned *__restrict__ hval) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nq) return;
-    int n = occ_n[t];
-    if (n <= 0) return;
-    unsigned c = q_c[t];
-    long long Lq = cand_off[c + 1] - cand_off[c];
-    long long qp = q_pos[t];
-    unsigned qh = q_hs[t];
-    int64_t o = hit_off[t];
-    unsigned lo = occ_lo[t];
-    for (int i = 0; i < n; i++) {
-        unsigned gh = idx_hs[lo + i];
-        long long gpos = idx_pos[lo + i];
-        unsigned rel = (qh ^ gh) & 1u;
-        long long qo = rel ? (Lq - qp - CK) : qp;
-        long long d = gpos - qo + DBIAS;
-        hkey[o + i] = ((unsigned long long)c << 34) | ((unsigned long long)rel << 33) | (unsigned long long)d;
-        hval[o + i] = (unsigned)qo;
+// hits: key = candidate << 34 | rel << 33 | (d + DBIAS), value = qo.
+// One wavefront expands 64 consecutive candidate minimizers: their hits are a contiguous output range (hit_off is the
+// exclusive scan of the counts), lanes walk that range 64 at a time and find the owning minimizer by a 6-step search
+// over the lanes' prefix sums (shuffles): balanced work and coalesced 12-byte stores whatever the occurrence counts are.
+__global__ void __launch_bounds__(256) hit_kernel(int64_t nq, const unsigned *__restrict__ q_c, const unsigned *__restrict__ q_pos,
+                                                  const unsigned *__restrict__ q_hs, const int64_t *__restrict__ cand_off,
+                                                  const unsigned *__restrict__ idx_hs, const unsigned *__restrict__ idx_pos,
+                                                  const unsigned *__restrict__ occ_lo, const int32_t *__restrict__ occ_n,
+                                                  const int64_t *__restrict__ hit_off, unsigned long long *__restrict__ hkey,
+                                                  unsigned *__restrict__ hval) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
+    if (t0 >= nq) return;
+    const int64_t t = t0 + lane;
+    const bool have = t < nq;
+    const int64_t o0 = hit_off[t0];
+    const int pre = have ? (int)(hit_off[t] - o0) : 0x7fffffff;           // first output of this lane's minimizer
+    const int64_t tend = t0 + 64 < nq ? t0 + 64 : nq;
+    const int T = (int)(hit_off[tend] - o0);
+    const unsigned c = have ? q_c[t] : 0u, qh = have ? q_hs[t] : 0u, lo = have ? occ_lo[t] : 0u;
+    const int qp = have ? (int)q_pos[t] : 0;
+    const int Lq = have ? (int)(cand_off[c + 1] - cand_off[c]) : 0;
+    for (int j0 = 0; j0 < T; j0 += 64) {   // wave-uniform trip count: the shuffles below read lanes that own no output themselves
+        const int j = j0 + lane;
+        // largest u with pre[u] <= j (minimizers without hits share their successor's prefix and are skipped by "largest")
+        int u = 0;
+#pragma unroll
+        for (int step = 32; step >= 1; step >>= 1) {
+            const int v = u + step;
+            const int pv = __shfl(pre, v < 64 ? v : 63);
+            if (v < 64 && pv <= j) u = v;
+        }
+        const int i = j - __shfl(pre, u);
+        const unsigned uc = (unsigned)__shfl((int)c, u), uqh = (unsigned)__shfl((int)qh, u), ulo = (unsigned)__shfl((int)lo, u);
+        const long long uqp = __shfl(qp, u), uL = __shfl(Lq, u);
+        if (j >= T) continue;
+        const unsigned gh = idx_hs[ulo + i];
+        const long long gpos = idx_pos[ulo + i];
+        const unsigned rel = (uqh ^ gh) & 1u;
+        const long long qo = rel ? (uL - uqp - CK) : uqp;
+        const long long d = gpos - qo + DBIAS;
+        hkey[o0 + j] = ((unsigned long long)uc << 34) | ((unsigned long long)rel << 33) | (unsigned long long)d;
+        hval[o0 + j] = (unsigned)qo;
     }
 }
 
@@ -290,35 +309,61 @@ __global__ void cluster_first_kernel(int64_t nh, const int32_t *__restrict__ fla
     if (flag[i]) c_first[cid_excl[i]] = (unsigned)i;
     if (i == 0) c_first[ncl] = (unsigned)nh;
 }
-// per cluster: anchor count and the extreme anchors (min qo -> smallest gpos, max qo -> largest gpos)
-__global__ void cluster_acc_kernel(int64_t ncl, const unsigned long long *__restrict__ hkey, const unsigned *__restrict__ hval,
-                                   const unsigned *__restrict__ c_first, unsigned long long *__restrict__ c_lo,
-                                   unsigned long long *__restrict__ c_hi, int32_t *__restrict__ c_cnt) {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ncl) return;
-    unsigned b = c_first[k], e = c_first[k + 1];
+// per cluster: the extreme anchors (min qo -> smallest gpos, max qo -> largest gpos).  Thread per HIT: segmented min / max
+// scan over the lanes of a wavefront (segments = clusters), the last lane of each segment holds the wave's partial result:
+// stored directly when the whole cluster sits in this wave, merged with 64-bit atomics otherwise (c_lo / c_hi preset).
+__global__ void __launch_bounds__(256) cluster_acc_kernel(int64_t nh, const unsigned long long *__restrict__ hkey,
+                                                          const unsigned *__restrict__ hval, const int32_t *__restrict__ flag,
+                                                          const int64_t *__restrict__ cid_excl, unsigned long long *__restrict__ c_lo,
+                                                          unsigned long long *__restrict__ c_hi) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool have = i < nh;
+    long long k = -1 - lane;   // lanes past the end: distinct fake clusters
     unsigned long long lo = 0xffffffffffffffffull, hi = 0;
-    for (unsigned i = b; i < e; i++) {
-        long long d = (long long)(hkey[i] & 0x1ffffffffull) - DBIAS;
-        unsigned qo = hval[i];
-        unsigned long long v = ((unsigned long long)qo << 32) | ((unsigned long long)(d + qo) & 0xffffffffull);
-        lo = v < lo ? v : lo;
-        hi = v > hi ? v : hi;
+    int head = 0;
+    if (have) {
+        head = flag[i];
+        k = cid_excl[i] + head - 1;
+        const long long d = (long long)(hkey[i] & 0x1ffffffffull) - DBIAS;
+        const unsigned qo = hval[i];
+        lo = hi = ((unsigned long long)qo << 32) | ((unsigned long long)(d + qo) & 0xffffffffull);
     }
-    c_lo[k] = lo; c_hi[k] = hi; c_cnt[k] = (int)(e - b);
+    int has_head = head;       // does the run of this cluster inside the wave include the cluster's first hit?
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) {
+        const long long ok = __shfl_up(k, dd);
+        const unsigned long long olo = __shfl_up(lo, dd), ohi = __shfl_up(hi, dd);
+        const int oh = __shfl_up(has_head, dd);
+        if (lane >= dd && ok == k) { lo = olo < lo ? olo : lo; hi = ohi > hi ? ohi : hi; has_head |= oh; }
+    }
+    const long long nk = __shfl_down(k, 1);
+    const bool last_in_wave = lane == 63 || nk != k;
+    if (have && last_in_wave) {
+        const bool ends_here = i + 1 >= nh || flag[i + 1] != 0;   // the cluster's last hit
+        if (has_head && ends_here) { c_lo[k] = lo; c_hi[k] = hi; }
+        else { atomicMin(&c_lo[k], lo); atomicMax(&c_hi[k], hi); }
+    }
+}
+__global__ void cluster_acc_init_kernel(int64_t ncl, unsigned long long *__restrict__ c_lo, unsigned long long *__restrict__ c_hi) {
+    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < ncl) { c_lo[k] = 0xffffffffffffffffull; c_hi[k] = 0; }
 }
 
-// accepted clusters -> copy records (appended) + sort key (candidate:19 | 4095-anchors:12 | start:32 | minus:1)
+// accepted clusters -> copy records + sort key (candidate:19 | 4095-anchors:12 | start:32 | minus:1).  Two passes:
+// WRITE = false counts the accepted clusters per candidate, WRITE = true places each record at
+// cstart[candidate] + (a per-candidate atomic counter): no single hot append counter (740 k same-address atomics cost 5 ms).
+template <bool WRITE>
 __global__ void cluster_copy_kernel(int64_t ncl, const unsigned long long *__restrict__ hkey, const unsigned *__restrict__ c_first,
                                     const unsigned long long *__restrict__ c_lo, const unsigned long long *__restrict__ c_hi,
                                     const int32_t *__restrict__ c_cnt, const int64_t *__restrict__ cand_off,
                                     const int64_t *__restrict__ coff, int nc, unsigned long long *__restrict__ ckey,
                                     unsigned *__restrict__ cval, int32_t *__restrict__ r_contig, int64_t *__restrict__ r_s1,
                                     int64_t *__restrict__ r_e1, uint8_t *__restrict__ r_minus, int32_t *__restrict__ r_anch,
-                                    int32_t *__restrict__ per_cand, unsigned long long *__restrict__ counter) {
+                                    int32_t *__restrict__ per_cand, const int64_t *__restrict__ cstart) {
     int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= ncl) return;
-    int na = c_cnt[k];
+    int na = (int)(c_first[k + 1] - c_first[k]);
     if (na < C_MINANCH) return;
     unsigned long long key = hkey[c_first[k]];
     unsigned c = (unsigned)(key >> 34);
@@ -333,12 +378,12 @@ __global__ void cluster_copy_kernel(int64_t ncl, const unsigned long long *__res
     if (s0 < cb) s0 = cb;
     if (e0 > ce) e0 = ce;
     if (e0 <= s0) return;
-    unsigned long long slot = atomicAdd(counter, 1ull);
+    if (!WRITE) { atomicAdd(&per_cand[c], 1); return; }
+    const int64_t slot = cstart[c] + atomicAdd(&per_cand[c], 1);
     r_contig[slot] = ctg; r_s1[slot] = s0 - cb + 1; r_e1[slot] = e0 - cb; r_minus[slot] = (uint8_t)rel; r_anch[slot] = na;
     int ac = na > 4095 ? 4095 : na;
     ckey[slot] = ((unsigned long long)c << 45) | ((unsigned long long)(4095 - ac) << 33) | ((unsigned long long)(unsigned)s0 << 1) | rel;
     cval[slot] = (unsigned)slot;
-    atomicAdd(&per_cand[c], 1);
 }
 
 __global__ void cap300_kernel(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out) {
@@ -550,7 +595,8 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 4, &p)); c_first = (unsigned *)p;
     hipLaunchKernelGGL(cluster_first_kernel, CGRID(nh), 0, st, nh, flag, cid, c_first, ncl);
     int tk_cluster_acc_kernel = hite_prof_begin(ctx, "cluster_acc_kernel", st);
-    hipLaunchKernelGGL(cluster_acc_kernel, CGRID(ncl), 0, st, ncl, hkey, hval, c_first, c_lo, c_hi, c_cnt);
+    hipLaunchKernelGGL(cluster_acc_init_kernel, CGRID(ncl), 0, st, ncl, c_lo, c_hi);
+    hipLaunchKernelGGL(cluster_acc_kernel, CGRID(nh), 0, st, nh, hkey, hval, flag, cid, c_lo, c_hi);
     hite_prof_end(ctx, tk_cluster_acc_kernel, st);
     // clusters -> copies
     int32_t *r_contig, *r_anch;
@@ -567,16 +613,22 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); per_cand300 = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); cstart = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); ofirst = (int64_t *)p;
+    int32_t *fill;
+    CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); fill = (int32_t *)p;
     HITE_CHECK(ctx, hipMemsetAsync(per_cand, 0, (size_t)(n_cand + 1) * 4, st));
+    HITE_CHECK(ctx, hipMemsetAsync(fill, 0, (size_t)(n_cand + 1) * 4, st));
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
-    int tk_cluster_copy_kernel = hite_prof_begin(ctx, "cluster_copy_kernel", st);
-    hipLaunchKernelGGL(cluster_copy_kernel, CGRID(ncl), 0, st, ncl, hkey, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
-                       ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, per_cand, (unsigned long long *)S->d_scal);
-    hite_prof_end(ctx, tk_cluster_copy_kernel, st);
-    hipLaunchKernelGGL(cap300_kernel, CGRID((int64_t)n_cand), 0, st, n_cand, per_cand, per_cand300);
     int64_t *bs3;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(n_cand) * 8, &p)); bs3 = (int64_t *)p;
+    int tk_cluster_copy_kernel = hite_prof_begin(ctx, "cluster_copy_kernel", st);
+    hipLaunchKernelGGL(cluster_copy_kernel<false>, CGRID(ncl), 0, st, ncl, hkey, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
+                       ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, per_cand, (const int64_t *)nullptr);
     CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand, n_cand, cstart, st));
+    hipLaunchKernelGGL(cluster_copy_kernel<true>, CGRID(ncl), 0, st, ncl, hkey, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
+                       ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, fill, (const int64_t *)cstart);
+    hite_prof_end(ctx, tk_cluster_copy_kernel, st);
+    hipLaunchKernelGGL(cap300_kernel, CGRID((int64_t)n_cand), 0, st, n_cand, per_cand, per_cand300);
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cstart + n_cand, 8, hipMemcpyDeviceToDevice, st));
     CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand300, n_cand, ofirst, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, ofirst + n_cand, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 2));
