@@ -423,8 +423,7 @@ __global__ void fill_u64_kernel(int64_t n, unsigned long long *__restrict__ p, u
 
 static int sorter_from_arena(Sorter &S, hite_ctx *ctx, Arena &A, hipStream_t st, int64_t n) {
     S.ctx = ctx; S.st = st; S.cap = n;
-    int64_t nblocks = (n + RS_TILE - 1) / RS_TILE; if (nblocks < 1) nblocks = 1;
-    S.hist_n = 256 * nblocks;
+    S.hist_n = sorter_hist_elems(n);
     void *p;
     CCHK(arena_alloc(ctx, A, (size_t)(n + 1) * 8, &p)); S.k2 = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(n + 1) * 4, &p)); S.v2 = (unsigned *)p;

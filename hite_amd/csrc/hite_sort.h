@@ -7,50 +7,60 @@
 #include "hite_scan.h"
 
 // ---------------------------------------------------------------------------------------------
-// stable LSD radix sort of (u64 key, u32 value), 8 bits per pass, tile = 256 threads x 8 items
+// stable LSD radix sort of (u64 key, u32 value).  Two digit widths: 8 bits (tile = 256 threads x 8 items) for small
+// inputs, 10 bits (tile = 256 threads x 32 items, 1024 bins) for large ones: a 50-bit key takes 5 passes instead of 7.
 // ---------------------------------------------------------------------------------------------
 #define RS_ITEMS 8
 #define RS_TILE (256 * RS_ITEMS)
+#define RS_WIDE_MIN (1 << 22)   // element count from which the 10-bit form is used
 
+template <int BITS, int ITEMS>
 static __global__ void __launch_bounds__(256) rs_hist_kernel(const unsigned long long *__restrict__ keys, int64_t n, int shift,
-                                                      int nblocks, int32_t *__restrict__ hist /* [256][nblocks] */) {
-    __shared__ int h[256];
-    h[threadIdx.x] = 0;
+                                                             int nblocks, int32_t *__restrict__ hist /* [bins][nblocks] */) {
+    constexpr int BINS = 1 << BITS;
+    __shared__ int h[BINS];
+    for (int b = threadIdx.x; b < BINS; b += 256) h[b] = 0;
     __syncthreads();
-    int64_t base = (int64_t)blockIdx.x * RS_TILE;
-    for (int it = 0; it < RS_ITEMS; it++) {
+    int64_t base = (int64_t)blockIdx.x * (256 * ITEMS);
+    for (int it = 0; it < ITEMS; it++) {
         int64_t i = base + it * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & 255ull)], 1);
+        if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & (unsigned long long)(BINS - 1))], 1);
     }
     __syncthreads();
-    hist[(int64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (int b = threadIdx.x; b < BINS; b += 256) hist[(int64_t)b * nblocks + blockIdx.x] = h[b];
 }
 
+template <int BITS, int ITEMS>
 static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned long long *__restrict__ kin, const unsigned *__restrict__ vin,
-                                                         unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
-                                                         int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
-    __shared__ long long base[256];
-    __shared__ int cnt[4][256];
+                                                                unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
+                                                                int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
+    constexpr int BINS = 1 << BITS;
+    __shared__ long long base[BINS];
+    __shared__ int cnt[4][BINS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    base[threadIdx.x] = offs[(int64_t)threadIdx.x * nblocks + blockIdx.x];
-    int64_t tile = (int64_t)blockIdx.x * RS_TILE;
-    for (int it = 0; it < RS_ITEMS; it++) {
-        for (int q = 0; q < 4; q++) cnt[q][threadIdx.x] = 0;
-        __syncthreads();
+    for (int b = threadIdx.x; b < BINS; b += 256) {
+        base[b] = offs[(int64_t)b * nblocks + blockIdx.x];
+        cnt[0][b] = 0; cnt[1][b] = 0; cnt[2][b] = 0; cnt[3][b] = 0;
+    }
+    __syncthreads();
+    int64_t tile = (int64_t)blockIdx.x * (256 * ITEMS);
+    for (int it = 0; it < ITEMS; it++) {
+        // invariant: cnt is all zero here.  Only the entries of digits present in this round are touched (and reset).
         int64_t i = tile + it * 256 + threadIdx.x;
         bool act = i < n;
         unsigned long long k = act ? kin[i] : 0;
         unsigned v = act ? vin[i] : 0;
-        int d = (int)((k >> shift) & 255ull);
+        int d = (int)((k >> shift) & (unsigned long long)(BINS - 1));
         // lanes of this wave with the same digit (inactive lanes match nothing)
         unsigned long long peers = __ballot(act);
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < BITS; b++) {
             unsigned long long bal = __ballot((d >> b) & 1);
             peers &= ((d >> b) & 1) ? bal : ~bal;
         }
-        int rank = __popcll(peers & ((1ull << lane) - 1ull));
-        if (act && rank == 0) cnt[w][d] = __popcll(peers);
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        const int mine = __popcll(peers);
+        if (act && rank == 0) cnt[w][d] = mine;
         __syncthreads();
         if (act) {
             long long pos = base[d];
@@ -59,7 +69,7 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
             kout[pos] = k; vout[pos] = v;
         }
         __syncthreads();
-        base[threadIdx.x] += cnt[0][threadIdx.x] + cnt[1][threadIdx.x] + cnt[2][threadIdx.x] + cnt[3][threadIdx.x];
+        if (act && rank == 0) { atomicAdd((unsigned long long *)&base[d], (unsigned long long)mine); cnt[w][d] = 0; }
         __syncthreads();
     }
 }
@@ -74,11 +84,17 @@ struct Sorter {
     int64_t *offs = nullptr, *bs = nullptr;
     int64_t hist_n = 0;
 };
+// histogram entries a sort of n elements needs (the larger of the two forms)
+static inline int64_t sorter_hist_elems(int64_t n) {
+    int64_t nb8 = (n + RS_TILE - 1) / RS_TILE; if (nb8 < 1) nb8 = 1;
+    int64_t nb10 = (n + 8191) / 8192; if (nb10 < 1) nb10 = 1;
+    int64_t a = 256 * nb8, b = 1024 * nb10;
+    return a > b ? a : b;
+}
 
 static int sorter_init(Sorter &S, hite_ctx *ctx, hipStream_t st, int64_t n) {
     S.ctx = ctx; S.st = st; S.cap = n;
-    int64_t nblocks = (n + RS_TILE - 1) / RS_TILE; if (nblocks < 1) nblocks = 1;
-    S.hist_n = 256 * nblocks;
+    S.hist_n = sorter_hist_elems(n);
     HITE_CHECK(ctx, hipMalloc((void **)&S.k2, (size_t)(n + 1) * 8));
     HITE_CHECK(ctx, hipMalloc((void **)&S.v2, (size_t)(n + 1) * 4));
     HITE_CHECK(ctx, hipMalloc((void **)&S.hist, (size_t)S.hist_n * 4));
@@ -96,16 +112,21 @@ static void sorter_free(Sorter &S) {
 // sorts (keys, vals) in place (ping-pong through the sorter's buffers) on the key bits [lo_bit, hi_bit), stable
 static int sorter_sort_bits(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int lo_bit, int hi_bit) {
     if (n <= 1) return HITE_OK;
-    int nblocks = (int)((n + RS_TILE - 1) / RS_TILE);
+    const bool wide = n >= RS_WIDE_MIN;
+    const int bits = wide ? 10 : 8;
+    const int tile = wide ? 8192 : RS_TILE;
+    int nblocks = (int)((n + tile - 1) / tile);
     unsigned long long *ka = keys, *kb = S.k2;
     unsigned *va = vals, *vb = S.v2;
-    int passes = (hi_bit - lo_bit + 7) / 8;
+    int passes = (hi_bit - lo_bit + bits - 1) / bits;
     for (int p = 0; p < passes; p++) {
-        const int sh = lo_bit + p * 8;
-        hipLaunchKernelGGL(rs_hist_kernel, dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
-        int rc = scan_excl_buf<int32_t>(S.ctx, S.bs, S.hist, (int64_t)256 * nblocks, S.offs, S.st);
+        const int sh = lo_bit + p * bits;
+        if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<10, 32>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
+        int rc = scan_excl_buf<int32_t>(S.ctx, S.bs, S.hist, (int64_t)(1 << bits) * nblocks, S.offs, S.st);
         if (rc) return rc;
-        hipLaunchKernelGGL(rs_scatter_kernel, dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
+        if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_kernel<10, 32>), dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
+        else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         unsigned long long *tk = ka; ka = kb; kb = tk;
         unsigned *tv = va; va = vb; vb = tv;
     }
