@@ -107,7 +107,7 @@ __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
 //            results leave as coalesced 128-B chunks of u16 (row position aligned to centre position p |
 //            gap flag << 15).
 __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
-    __shared__ uint8_t s_bases[4][2][96];   // per wave: windows of centre / row bases for the current chunk
+    __shared__ uint8_t s_bases[4][2][128];  // per wave: windows of centre / row bases for the current chunk
     const int lane = threadIdx.x & 63;
     const int wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
     uint8_t *slot = P.tb + (size_t)wslot * P.tb_slot;
@@ -219,90 +219,86 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
               [prev] "+v"(prev), [p0] "+v"(p0), [p1] "+v"(p1), [areg] "+v"(areg), [breg] "+v"(breg), [aaddr] "+v"(aaddr), \
               [baddr] "+v"(baddr), [d2] "+v"(d2), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv)
         int p0 = pp, p1 = 0;                           // the diagonal operand lives in p0 at the start of every chunk
-        const int nchunk32 = (steps + 31) >> 5;        // chunk = 32 anti-diagonals (two 16-step direction words per lane)
-        for (int ch = 0; ch < nchunk32; ch++) {
-            const int s_lo = (ch << 5) + 1;
-            const int left = steps - (ch << 5);
-            const int nst = left < 32 ? left : 32;
-            const int nst1 = nst < 16 ? nst : 16, nst2 = nst - nst1;
-            {   // windows of this chunk: entries 1..63 are the bases the lanes hold now, 64..95 the (<= 32) that can enter
+        // chunk = 64 anti-diagonals = four 16-step direction words per lane.  Words 0..2 are parked in d2a/d2b/d2c (moves in
+        // mrega/b/c) as they fill up; the general form walks the four words in a small loop inside the same asm statement.
+        const int nchunk64 = (steps + 63) >> 6;
+        for (int ch = 0; ch < nchunk64; ch++) {
+            const int s_lo = (ch << 6) + 1;
+            const int left = steps - (ch << 6);
+            const int nst = left < 64 ? left : 64;
+            {   // windows of this chunk: entries 1..63 are the bases the lanes hold now, 64..127 the (<= 64) that can enter
                 winA[lane] = (uint8_t)areg;
                 winB[63 - lane] = (uint8_t)breg;
-                const bool isb = lane >= 32;
-                const int idx = isb ? s_lo - t - 1 + (lane - 32) : t + 63 + lane;
-                const int lim = isb ? n : m;
-                const uint8_t *src = isb ? b : a;
-                const int raw = src[(unsigned)idx < (unsigned)lim ? idx : 0];
-                const int v = (unsigned)idx < (unsigned)lim ? ((!isb && raw == 'N') ? 0xFD : raw) : (isb ? 0xFE : 0xFF);
-                (isb ? winB : winA)[64 + (lane & 31)] = (uint8_t)v;
+                const int ia = t + 63 + lane, ib = s_lo - t - 1 + lane;
+                const int ra = a[(unsigned)ia < (unsigned)m ? ia : 0], rb = b[(unsigned)ib < (unsigned)n ? ib : 0];
+                winA[64 + lane] = (uint8_t)((unsigned)ia < (unsigned)m ? (ra == 'N' ? 0xFD : ra) : 0xFF);
+                winB[64 + lane] = (uint8_t)((unsigned)ib < (unsigned)n ? rb : 0xFE);
             }
             int aaddr = (int)(ldsA + lane), baddr = (int)(ldsB + 63 - lane);
-            int d2 = 0, d2a = 0, tsc, tcd, thx, tv;
-            int mreg = to_sgpr(0), mrega = to_sgpr(0), sx, sy, tn, h0, h63;
-            int s31 = to_sgpr(s_lo - 32);              // (s - 31) of the step before the next one
-            // neither clamp can bind during a full chunk that starts with t + 32 <= m - 31 and t >= max(0, s_hi - n) - 32
-            // (t only grows, by at most one per step; t <= s - 32 always): such chunks run the 32 steps unrolled and
-            // recover t from the recorded moves.  Both forms live in ONE asm statement (same registers: no copies).
-            // After 16 steps the direction word and the move word are full: they are parked in d2a / mrega.
-            const int s_hi = s_lo + 31;
+            int tsc, tcd, thx, tv, sx, sy, tn, h0, h63;
+            // neither clamp can bind during a full chunk that starts with t + 64 <= m - 31 and t >= max(0, s_hi - n) - 32
+            // (t only grows, by at most one per step; t <= s - 32 always): such chunks run the 64 steps unrolled and
+            // recover t from the recorded moves; the other chunks run word by word through the general loop.
+            const int s_hi = s_lo + 63;
             // sign-bit form (no booleans: the compiler would route them through a VGPR)
             const int lo_t = (s_hi > n ? s_hi - n : 0) - 32;
-            const int fast = (int)(~(unsigned)((m31 - t - 32) | (t - lo_t) | (nst - 32)) >> 31);
-            int cnt1 = to_sgpr((nst1 >> 1) - 1), cnt2 = to_sgpr((nst2 >> 1) - 1);   // pairs - 1 of each half (general form)
-            const int odd1 = to_sgpr(nst1 & 1), odd2 = to_sgpr(nst2 & 1);           // only the last chunk can be odd
-            asm volatile(
-                "s_cmp_lg_u32 %[fast], 0\n\t"
-                "s_cbranch_scc1 F_%=\n\t"
-                "s_cmp_lt_i32 %[cnt1], 0\n\t"
-                "s_cbranch_scc1 S1_%=\n"
-                "L1_%=:\n\t"
-                STEP_GEN("s_cmp_ge_i32", "a", "p0", "p1")
-                STEP_GEN("s_cmp_gt_i32", "b", "p1", "p0")
-                "s_sub_u32 %[cnt1], %[cnt1], 1\n\t"
-                "s_cbranch_scc0 L1_%=\n"
-                "S1_%=:\n\t"
-                "s_cmp_eq_u32 %[odd1], 0\n\t"
-                "s_cbranch_scc1 H_%=\n\t"
-                STEP_GEN("s_cmp_ge_i32", "c", "p0", "p1")
-                "H_%=:\n\t"
-                "v_mov_b32 %[d2a], %[d2]\n\t"
-                "s_mov_b32 %[mrega], %[mreg]\n\t"
-                "s_cmp_lt_i32 %[cnt2], 0\n\t"
-                "s_cbranch_scc1 S2_%=\n"
-                "L2_%=:\n\t"
-                STEP_GEN("s_cmp_ge_i32", "d", "p0", "p1")
-                STEP_GEN("s_cmp_gt_i32", "e", "p1", "p0")
-                "s_sub_u32 %[cnt2], %[cnt2], 1\n\t"
-                "s_cbranch_scc0 L2_%=\n"
-                "S2_%=:\n\t"
-                "s_cmp_eq_u32 %[odd2], 0\n\t"
-                "s_cbranch_scc1 E_%=\n\t"
-                STEP_GEN("s_cmp_ge_i32", "f", "p0", "p1")
-                "s_branch E_%=\n"
-                "F_%=:\n\t"
-                STEP_FAST2("0") STEP_FAST2("1") STEP_FAST2("2") STEP_FAST2("3")
-                STEP_FAST2("4") STEP_FAST2("5") STEP_FAST2("6") STEP_FAST2("7")
-                "v_mov_b32 %[d2a], %[d2]\n\t"
-                "s_mov_b32 %[mrega], %[mreg]\n\t"
-                STEP_FAST2("8") STEP_FAST2("9") STEP_FAST2("10") STEP_FAST2("11")
-                STEP_FAST2("12") STEP_FAST2("13") STEP_FAST2("14") STEP_FAST2("15")
-                "s_and_b32 %[x], %[mreg], 0x55555555\n\t"
-                "s_and_b32 %[y], %[mrega], 0x55555555\n\t"
-                "s_bcnt1_i32_b32 %[x], %[x]\n\t"
-                "s_bcnt1_i32_b32 %[y], %[y]\n\t"
-                "s_add_i32 %[t], %[t], %[x]\n\t"
-                "s_add_i32 %[t], %[t], %[y]\n"
-                "E_%=:\n\t"
-                : STEP_VREGS, [d2a] "+v"(d2a), [t] "+s"(t), [mreg] "+s"(mreg), [mrega] "+s"(mrega), [s31] "+s"(s31), [cnt1] "+s"(cnt1),
-                  [cnt2] "+s"(cnt2), [x] "=&s"(sx), [y] "=&s"(sy), [tn] "=&s"(tn), [h0] "=&s"(h0), [h63] "=&s"(h63)
-                : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32), [vm1] "v"(vm1), [fast] "s"(fast), [odd1] "s"(odd1), [odd2] "s"(odd2)
-                : "vcc", "scc", "memory");
+            const int fast = (int)(~(unsigned)((m31 - t - 64) | (t - lo_t) | (nst - 64)) >> 31);
             // two bits per step, step r of a 16-step word at bits 2r+1 : 2r (directions), the move at bit 30 - 2r
-            tbd[(2 * ch) * 64 + lane] = (unsigned)d2a >> (2 * (16 - nst1));
-            if (lane == 0) tbm[2 * ch] = (unsigned)mrega << (2 * (16 - nst1));
-            if (nst2 > 0) {
-                tbd[(2 * ch + 1) * 64 + lane] = (unsigned)d2 >> (2 * (16 - nst2));
-                if (lane == 0) tbm[2 * ch + 1] = (unsigned)mreg << (2 * (16 - nst2));
+            if (fast) {
+                int d2 = 0, d2a, d2b, d2c;
+                int mreg = to_sgpr(0), mrega, mregb, mregc;
+                asm volatile(
+                    STEP_FAST2("0") STEP_FAST2("1") STEP_FAST2("2") STEP_FAST2("3")
+                    STEP_FAST2("4") STEP_FAST2("5") STEP_FAST2("6") STEP_FAST2("7")
+                    "v_mov_b32 %[d2a], %[d2]\n\t"
+                    "s_mov_b32 %[mrega], %[mreg]\n\t"
+                    STEP_FAST2("8") STEP_FAST2("9") STEP_FAST2("10") STEP_FAST2("11")
+                    STEP_FAST2("12") STEP_FAST2("13") STEP_FAST2("14") STEP_FAST2("15")
+                    "v_mov_b32 %[d2b], %[d2]\n\t"
+                    "s_mov_b32 %[mregb], %[mreg]\n\t"
+                    STEP_FAST2("16") STEP_FAST2("17") STEP_FAST2("18") STEP_FAST2("19")
+                    STEP_FAST2("20") STEP_FAST2("21") STEP_FAST2("22") STEP_FAST2("23")
+                    "v_mov_b32 %[d2c], %[d2]\n\t"
+                    "s_mov_b32 %[mregc], %[mreg]\n\t"
+                    STEP_FAST2("24") STEP_FAST2("25") STEP_FAST2("26") STEP_FAST2("27")
+                    STEP_FAST2("28") STEP_FAST2("29") STEP_FAST2("30") STEP_FAST2("31")
+                    : STEP_VREGS, [d2a] "=&v"(d2a), [d2b] "=&v"(d2b), [d2c] "=&v"(d2c), [mreg] "+s"(mreg), [mrega] "=&s"(mrega),
+                      [mregb] "=&s"(mregb), [mregc] "=&s"(mregc), [h0] "=&s"(h0), [h63] "=&s"(h63)
+                    : [vm1] "v"(vm1)
+                    : "vcc", "scc", "memory");
+                t += __builtin_popcount((unsigned)mrega & 0x55555555u) + __builtin_popcount((unsigned)mregb & 0x55555555u) +
+                     __builtin_popcount((unsigned)mregc & 0x55555555u) + __builtin_popcount((unsigned)mreg & 0x55555555u);
+                unsigned *wp = tbd + (4 * ch) * 64 + lane;
+                wp[0] = (unsigned)d2a; wp[64] = (unsigned)d2b; wp[128] = (unsigned)d2c; wp[192] = (unsigned)d2;
+                if (lane == 0) { tbm[4 * ch] = (unsigned)mrega; tbm[4 * ch + 1] = (unsigned)mregb; tbm[4 * ch + 2] = (unsigned)mregc; tbm[4 * ch + 3] = (unsigned)mreg; }
+            } else {
+                int s31 = to_sgpr(s_lo - 32);          // (s - 31) of the step before the next one
+                for (int w_ = 0; (w_ << 4) < nst; w_++) {
+                    const int nsw = nst - (w_ << 4) < 16 ? nst - (w_ << 4) : 16;
+                    int d2 = 0;
+                    int mreg = to_sgpr(0);
+                    int cnt = to_sgpr((nsw >> 1) - 1);         // pairs - 1
+                    const int odd = to_sgpr(nsw & 1);          // only the last word of the last chunk can be odd
+                    asm volatile(
+                        "s_cmp_lt_i32 %[cnt], 0\n\t"
+                        "s_cbranch_scc1 S_%=\n"
+                        "L_%=:\n\t"
+                        STEP_GEN("s_cmp_ge_i32", "a", "p0", "p1")
+                        STEP_GEN("s_cmp_gt_i32", "b", "p1", "p0")
+                        "s_sub_u32 %[cnt], %[cnt], 1\n\t"
+                        "s_cbranch_scc0 L_%=\n"
+                        "S_%=:\n\t"
+                        "s_cmp_eq_u32 %[odd], 0\n\t"
+                        "s_cbranch_scc1 E_%=\n\t"
+                        STEP_GEN("s_cmp_ge_i32", "c", "p0", "p1")
+                        "E_%=:\n\t"
+                        : STEP_VREGS, [t] "+s"(t), [mreg] "+s"(mreg), [s31] "+s"(s31), [cnt] "+s"(cnt), [x] "=&s"(sx), [y] "=&s"(sy),
+                          [tn] "=&s"(tn), [h0] "=&s"(h0), [h63] "=&s"(h63)
+                        : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32), [vm1] "v"(vm1), [odd] "s"(odd)
+                        : "vcc", "scc", "memory");
+                    tbd[(4 * ch + w_) * 64 + lane] = (unsigned)d2 >> (2 * (16 - nsw));
+                    if (lane == 0) tbm[4 * ch + w_] = (unsigned)mreg << (2 * (16 - nsw));
+                }
             }
         }
 #undef STEP_GEN
