@@ -372,50 +372,66 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         int ip = m - 1, jp = n - 1;
         int k = m - t;                    // lane that owns cell (i, j) on anti-diagonal i + j
         int oreg = 0, bad = 0, fail;
+        // between two words of a trip: careful form -- stop if row / column 0 was reached or no word is left
+#define TB_NEXT_CAREFUL(HAVE)                                                                     \
+                "s_or_b32 %[x], %[jp], %[ip]\n\t"                                                 \
+                "s_cmp_lt_i32 %[x], 0\n\t"                                                        \
+                "s_cbranch_scc1 X_%=\n\t"                                                         \
+                "s_cmp_lt_u32 %[nw], " HAVE "\n\t"                                                \
+                "s_cbranch_scc1 X_%=\n\t"                                                         \
+                "s_add_i32 %[q], %[q], 32\n\t"
         while (ip >= 0 && jp >= 0) {
             const int sp = ip + jp + 1;   // word / bit index of anti-diagonal i + j
             const int dch = sp >> 4;
             int q = to_sgpr(((sp & 15) << 1) + 1);        // 2 x (step inside the word) + 1
-            // two 16-step words per trip (the one that holds anti-diagonal i + j and the one below): step r of a word has
-            // bit 2r+1 "diagonal wins", else bit 2r "up", else left
-            const int dlo = dch > 0 ? dch - 1 : 0;
-            const unsigned wcur1 = tbd[dch * 64 + lane], wcur0 = tbd[dlo * 64 + lane];
-            const unsigned m2 = tbm[dch], m1 = dch > 0 ? tbm[dch - 1] : 0u, m0w = dch > 1 ? tbm[dch - 2] : 0u;
-            const int mma1 = to_sgpr((int)__brev(m2));                                   // bit 2r+1: move of step r
-            const int mmb1 = to_sgpr((int)((__brev(m2) << 2) | ((m1 & 1u) << 1)));       // bit 2r+1: move of step r-1
-            const int mma0 = to_sgpr((int)__brev(m1));
-            const int mmb0 = to_sgpr((int)((__brev(m1) << 2) | ((m0w & 1u) << 1)));
-            const int two = dch < 1 ? dch : 1;           // integer form (a boolean would be routed through a VGPR)
+            // up to four 16-step words per trip (the one that holds anti-diagonal i + j and the three below): step r of a
+            // word has bit 2r+1 "diagonal wins", else bit 2r "up", else left
+            const int nw = dch < 3 ? dch + 1 : 4;         // words available from dch downwards (integer form)
+            const unsigned *wp = tbd + lane;
+            const unsigned wcur3 = wp[dch * 64], wcur2 = wp[(dch > 0 ? dch - 1 : 0) * 64], wcur1 = wp[(dch > 1 ? dch - 2 : 0) * 64],
+                           wcur0 = wp[(dch > 2 ? dch - 3 : 0) * 64];
+            const unsigned mv4 = tbm[dch], mv3 = dch > 0 ? tbm[dch - 1] : 0u, mv2 = dch > 1 ? tbm[dch - 2] : 0u,
+                           mv1 = dch > 2 ? tbm[dch - 3] : 0u, mv0 = dch > 3 ? tbm[dch - 4] : 0u;
+            // per word: mma bit 2r+1 = move of step r, mmb bit 2r+1 = move of step r-1 (bit 1: last move of the word below)
+            const int mma3 = to_sgpr((int)__brev(mv4)), mmb3 = to_sgpr((int)((__brev(mv4) << 2) | ((mv3 & 1u) << 1)));
+            const int mma2 = to_sgpr((int)__brev(mv3)), mmb2 = to_sgpr((int)((__brev(mv3) << 2) | ((mv2 & 1u) << 1)));
+            const int mma1 = to_sgpr((int)__brev(mv2)), mmb1 = to_sgpr((int)((__brev(mv2) << 2) | ((mv1 & 1u) << 1)));
+            const int mma0 = to_sgpr((int)__brev(mv1)), mmb0 = to_sgpr((int)((__brev(mv1) << 2) | ((mv0 & 1u) << 1)));
             bad |= (unsigned)k > 63u;
             const int ip0 = ip;
-            const int plain = (ip < jp ? ip : jp) >> 5;   // != 0: both >= 32 (integer form: stays on the scalar unit)
+            const int plain = (ip < jp ? ip : jp) >> 6;   // != 0: both >= 64 (integer form: stays on the scalar unit)
             int sw, sx;
             asm volatile(
                 "s_cmp_lg_u32 %[plain], 0\n\t"
                 "s_cbranch_scc1 P_%=\n\t"
+                TB_LOOP("c3", "wcur3", "mma3", "mmb3", TB_CAREFUL("4", "c3"), TB_CAREFUL("2", "c3"), TB_CAREFUL("2", "c3"))
+                TB_NEXT_CAREFUL("2")
+                TB_LOOP("c2", "wcur2", "mma2", "mmb2", TB_CAREFUL("4", "c2"), TB_CAREFUL("2", "c2"), TB_CAREFUL("2", "c2"))
+                TB_NEXT_CAREFUL("3")
                 TB_LOOP("c1", "wcur1", "mma1", "mmb1", TB_CAREFUL("4", "c1"), TB_CAREFUL("2", "c1"), TB_CAREFUL("2", "c1"))
-                "s_or_b32 %[x], %[jp], %[ip]\n\t"        /* left the word because row / column 0 was reached? */
-                "s_cmp_lt_i32 %[x], 0\n\t"
-                "s_cbranch_scc1 X_%=\n\t"
-                "s_cmp_eq_u32 %[two], 0\n\t"
-                "s_cbranch_scc1 X_%=\n\t"
-                "s_add_i32 %[q], %[q], 32\n\t"
+                TB_NEXT_CAREFUL("4")
                 TB_LOOP("c0", "wcur0", "mma0", "mmb0", TB_CAREFUL("4", "c0"), TB_CAREFUL("2", "c0"), TB_CAREFUL("2", "c0"))
                 "s_branch X_%=\n"
                 "P_%=:\n\t"
+                TB_LOOP("p3", "wcur3", "mma3", "mmb3", TB_PLAIN("4", "p3"), TB_PLAIN("2", "p3"), TB_PLAIN("2", "p3"))
+                "s_add_i32 %[q], %[q], 32\n\t"
+                TB_LOOP("p2", "wcur2", "mma2", "mmb2", TB_PLAIN("4", "p2"), TB_PLAIN("2", "p2"), TB_PLAIN("2", "p2"))
+                "s_add_i32 %[q], %[q], 32\n\t"
                 TB_LOOP("p1", "wcur1", "mma1", "mmb1", TB_PLAIN("4", "p1"), TB_PLAIN("2", "p1"), TB_PLAIN("2", "p1"))
                 "s_add_i32 %[q], %[q], 32\n\t"
                 TB_LOOP("p0", "wcur0", "mma0", "mmb0", TB_PLAIN("4", "p0"), TB_PLAIN("2", "p0"), TB_PLAIN("2", "p0"))
                 "\nX_%=:\n\t"
                 : [ip] "+s"(ip), [jp] "+s"(jp), [k] "+s"(k), [q] "+s"(q), [oreg] "+v"(oreg), [w] "=&s"(sw), [x] "=&s"(sx)
-                : [wcur1] "v"(wcur1), [wcur0] "v"(wcur0), [mma1] "s"(mma1), [mmb1] "s"(mmb1), [mma0] "s"(mma0), [mmb0] "s"(mmb0),
-                  [plain] "s"(plain), [two] "s"(two)
+                : [wcur3] "v"(wcur3), [wcur2] "v"(wcur2), [wcur1] "v"(wcur1), [wcur0] "v"(wcur0), [mma3] "s"(mma3), [mmb3] "s"(mmb3),
+                  [mma2] "s"(mma2), [mmb2] "s"(mmb2), [mma1] "s"(mma1), [mmb1] "s"(mmb1), [mma0] "s"(mma0), [mmb0] "s"(mmb0),
+                  [plain] "s"(plain), [nw] "s"(nw)
                 : "scc");
-            // positions (ip, ip0] were produced by this trip (<= 32): lane l holds the one with p mod 64 == l
+            // positions (ip, ip0] were produced by this trip (<= 64): lane l holds the one with p mod 64 == l
             const int pl = ip0 - ((ip0 - lane) & 63);
             if (pl > ip) ops[pl] = (uint16_t)oreg;
         }
         for (int q = lane; q <= ip; q += 64) ops[q] = (uint16_t)0x8000;   // j == 0: gaps before row position 0
+#undef TB_NEXT_CAREFUL
 #undef TB_LOOP
 #undef TB_PLAIN
 #undef TB_CAREFUL
