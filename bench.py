@@ -259,7 +259,7 @@ def main():
             import ctypes
             buf = (ctypes.c_ulonglong * 16)()
             ctx.lib.hite_debug_judge_clocks(buf, 1)
-            out["judge_phase_ticks"] = [int(x) for x in buf[:6]]
+            out["judge_phase_ticks"] = [int(x) for x in buf[:12]]
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
         if args.verify > 0:

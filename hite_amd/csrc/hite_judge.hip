@@ -41,7 +41,24 @@ struct JShared {
     int tsd[25];
     int fo[5], eo[5];
     uint8_t tile[TILE_COLS * MAXSEL];   // symbol classes of the selected rows over the column span of the current scan
+#ifdef JUDGE_CLOCKS
+    unsigned long long jt;
+#endif
 };
+
+#ifdef JUDGE_CLOCKS
+// development aid (-DJUDGE_CLOCKS): wall-clock ticks per phase, summed over blocks by thread 0
+__device__ unsigned long long g_jclk[16];
+#define JCLK(i) do { if (threadIdx.x == 0) { unsigned long long now_ = wall_clock64(); atomicAdd(&g_jclk[i], now_ - S.jt); S.jt = now_; } } while (0)
+extern "C" int hite_debug_judge_clocks(unsigned long long *out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jclk), sizeof(g_jclk)) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jclk), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define JCLK(i) do { } while (0)
+#endif
+
 
 // ---------------------------------------------------------------------------------------------
 // banded (k<=2) edit distance of pattern p[0..m) against prefixes of text t[0..w):
@@ -432,8 +449,10 @@ __device__ int blk_search_v3(const uint8_t *__restrict__ msa, const uint8_t *__r
     if (side == 0) {
         n = blk_scan_valid(cstat, C, vthr, pos, +1, 0, S);
         ws = n < win_in ? n : win_in;
+        JCLK(5);   // (search) valid-column scans
         if (ws < 10) cur = -1;
         else cur = blk_first_window(msa, C, sel, rn, n, ws, false, false, thr, S);
+        JCLK(6);   // (search) windows
         n = blk_scan_valid(cstat, C, vthr, cur, -1, 1, S);
         ws = n < win_out ? n : win_out;
         if (ws < 10) cur = -1;
@@ -596,23 +615,28 @@ __device__ __forceinline__ bool eqs(const uint8_t *a, const char *b, int n) {
     return true;
 }
 
-// TSDsearch_v5 (Util.py:2460-2492): returns TSD length (0 none, -1 exception); left/right optional
+// TSDsearch_v5 (Util.py:2460-2492): returns TSD length (0 none, -1 exception); left/right optional.
+// The reference ungaps the two flanks once per length; the k characters it gets are the nearest k bases, i.e. the
+// suffix (left flank) / prefix (right flank) of the 11-base strings, so both flanks are walked ONCE (the walks are chains
+// of dependent byte loads: this is what the TSD votes of the judge spend their time on).
 __device__ int tsd_search_v5(const uint8_t *row, int C, int bs, int be, int plant, uint8_t *left, uint8_t *right) {
     const int lens[9] = {11, 10, 9, 8, 6, 5, 4, 3, 2};
-    uint8_t f5[5], f3[3], l5[5], l3[3], lt[12], rt[12];
+    uint8_t f5[5], l5[5], L11[12], R11[12];
     bool exc = false;
-    int nf5 = ungap_str(row, C, bs, 5, true, f5, &exc);
-    int nf3 = ungap_str(row, C, bs, 3, true, f3, &exc);
-    int nl5 = ungap_str(row, C, be, 5, false, l5, &exc);
-    int nl3 = ungap_str(row, C, be, 3, false, l3, &exc);
+    const int nf5 = ungap_str(row, C, bs, 5, true, f5, &exc);
+    const int nl5 = ungap_str(row, C, be, 5, false, l5, &exc);
+    // first 3 = prefix of the first 5; last 3 (walking left from be) = suffix of the last 5
+    const int nf3 = nf5 < 3 ? nf5 : 3, nl3 = nl5 < 3 ? nl5 : 3;
+    const uint8_t *f3 = f5, *l3 = l5 + (nl5 - nl3);
+    if (exc) return -1;
+    const int nL = ungap_str(row, C, bs - 1, 11, false, L11, &exc);   // nearest <= 11 bases left of bs, in sequence order
+    const int nR = ungap_str(row, C, be + 1, 11, true, R11, &exc);    // nearest <= 11 bases right of be
     if (exc) return -1;
     int found = 0;
     for (int t = 0; t < 9; t++) {
-        int k = lens[t];
-        int nl = ungap_str(row, C, bs - 1, k, false, lt, &exc);
-        int nr = ungap_str(row, C, be + 1, k, true, rt, &exc);
-        if (exc) return -1;
-        if (nl != nr || nl != k) continue;
+        const int k = lens[t];
+        if (nL < k || nR < k) continue;        // the reference gets fewer than k characters on one side
+        const uint8_t *lt = L11 + (nL - k), *rt = R11;
         bool same = true;
         int mm = 0;
         for (int i = 0; i < k; i++) if (lt[i] != rt[i]) { same = false; mm++; }
@@ -627,11 +651,10 @@ __device__ int tsd_search_v5(const uint8_t *row, int C, int bs, int be, int plan
                      (plant == 1 && nf5 == 5 && nl5 == 5 &&
                       ((eqs(f5, "CACTA", 5) && eqs(l5, "TAGTG", 5)) || (eqs(f5, "CACTG", 5) && eqs(l5, "CAGTG", 5))));
         } else if (k >= 8) ok = mm <= 1;
-        if (ok) {
-            found = k;
-            if (left) for (int i = 0; i < k; i++) { left[i] = lt[i]; right[i] = rt[i]; }
-        }
+        if (ok) found = k;   // the last (shortest) accepted length wins
     }
+    if (left && found > 0)
+        for (int i = 0; i < found; i++) { left[i] = L11[nL - found + i]; right[i] = R11[i]; }
     return found;
 }
 
@@ -724,23 +747,10 @@ __device__ void judge_v9_tail(const JudgeParams &P, const uint8_t *msa, int R, i
 __device__ void judge_v6_body(const JudgeParams &P, const uint8_t *msa, int R, int C, int astart, int aend,
                               uint8_t *cstat, uint8_t *model, hite_call &out, JShared &S);
 
-#ifdef JUDGE_CLOCKS
-// development aid (-DJUDGE_CLOCKS): wall-clock ticks per phase, summed over blocks by thread 0
-__device__ unsigned long long g_jclk[16];
-#define JCLK(i) do { if (threadIdx.x == 0) { unsigned long long now_ = wall_clock64(); atomicAdd(&g_jclk[i], now_ - jt_); jt_ = now_; } } while (0)
-extern "C" int hite_debug_judge_clocks(unsigned long long *out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_jclk), sizeof(g_jclk)) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_jclk), z, sizeof(z)); }
-    return 0;
-}
-#else
-#define JCLK(i) do { } while (0)
-#endif
-
 __global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(5, 8))) judge_kernel(JudgeParams P) {
     __shared__ JShared S;
 #ifdef JUDGE_CLOCKS
-    unsigned long long jt_ = wall_clock64();
+    if (threadIdx.x == 0) S.jt = wall_clock64();
 #endif
     uint8_t *slot = P.scratch + (size_t)blockIdx.x * P.slot_bytes;
     for (;;) {
@@ -865,8 +875,10 @@ __device__ void judge_tir_tail(const JudgeParams &P, const uint8_t *msa, int R, 
     int vl = S.red[4] == 0xffffffffu ? -1 : (int)S.red[4];
     int vr = (int)S.red[5] - 1;
     if (!(vl != -1 && vr != -1 && vl < vr)) { vl = -1; vr = -1; }
+    JCLK(7);   // (tail) valid range
     int ml = blk_consensus(cstat, rn, hs, he, 0, model, S);
     __syncthreads();
+    JCLK(8);   // (tail) consensus
     if (hs <= vl || he >= vr) return;  // :9353  final_cons_seq = ''
     if (threadIdx.x == 0) {
         int nfo = 0, neo = 0;
@@ -898,6 +910,7 @@ __device__ void judge_tir_tail(const JudgeParams &P, const uint8_t *msa, int R, 
         else if (k > 0) atomicAdd(&S.tsd[a * 5 + b], 1);
     }
     __syncthreads();
+    JCLK(9);   // (tail) TSD votes
     if (S.iv[6]) { out.info = HITE_INFO_EXC; return; }
     if (threadIdx.x == 0) {
         int have = 0, b_ed = 0, b_tc = 0, b_f = 0, b_e = 0;
