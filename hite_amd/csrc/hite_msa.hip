@@ -17,6 +17,7 @@
 #include "hite_common.h"
 
 #define MW 64
+#define FILL_U 4        // items in flight per thread in the fill kernel
 #define MSA_MAXR 128   // rows whose lengths are cached in LDS by the layout / fill kernels
 #define MBIAS (1 << 28)
 #define SC_MATCH 2
@@ -573,6 +574,18 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
             // ins_r(p) = q_r(p) - end_r(p-1): two u16 per row, four rows in flight
             const uint16_t *col = ops + p;
             int r = 1;
+            for (; r + 7 < R; r += 8) {
+                unsigned oc[8], op[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) { oc[u] = p < m ? col[(r + u) * rs] : 0u; op[u] = p > 0 ? col[(r + u) * rs - 1] : 0u; }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const int pe = p > 0 ? (int)(op[u] & 0x7fff) + ((op[u] >> 15) ? 0 : 1) : 0;
+                    const int q = p < m ? (int)(oc[u] & 0x7fff) : (r + u < MSA_MAXR ? s_wl[r + u] : P.win_len[g0 + r + u]);
+                    const int v = q - pe;
+                    mx = v > mx ? v : mx; npos += v > 0; gapc += (int)(oc[u] >> 15);
+                }
+            }
             for (; r + 3 < R; r += 4) {
                 unsigned oc[4], op[4];
 #pragma unroll
@@ -654,23 +667,23 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
     const int rs = m + 1;
     const unsigned items = (unsigned)R * (unsigned)rs;   // < 2^31: R <= a few hundred rows, rs <= 32768
     const unsigned stride = gridDim.y * 256u;
-    // four items per thread and trip: the loads of each dependency level are issued together (the chain kwslot -> ops ->
+    // FILL_U items per thread and trip: the loads of each dependency level are issued together (the chain kwslot -> ops ->
     // base is three loads deep and the kernel is latency bound otherwise)
-    for (unsigned it0 = blockIdx.y * 256u + threadIdx.x; it0 < items; it0 += 4 * stride) {
-        int r[4], p[4], kw[4], kc[4], ins[4], gap[4], q[4], bs[4];
-        bool live[4], ex[4];
+    for (unsigned it0 = blockIdx.y * 256u + threadIdx.x; it0 < items; it0 += FILL_U * stride) {
+        int r[FILL_U], p[FILL_U], kw[FILL_U], kc[FILL_U], ins[FILL_U], gap[FILL_U], q[FILL_U], bs[FILL_U];
+        bool live[FILL_U], ex[FILL_U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < FILL_U; u++) {
             const unsigned it = it0 + u * stride;
             live[u] = it < items;
             r[u] = live[u] ? (int)(it / (unsigned)rs) : 0;
             p[u] = live[u] ? (int)(it - (unsigned)r[u] * (unsigned)rs) : 0;
         }
-        unsigned ks[4], oc[4], op[4];
-        int nrow[4];
-        int64_t woff[4];
+        unsigned ks[FILL_U], oc[FILL_U], op[FILL_U];
+        int nrow[FILL_U];
+        int64_t woff[FILL_U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < FILL_U; u++) {
             ks[u] = kwslot[p[u]];
             const uint16_t *rop = ops + (int64_t)r[u] * rs;
             oc[u] = (r[u] > 0 && p[u] < m) ? rop[p[u]] : 0u;
@@ -680,7 +693,7 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
             bs[u] = nstart[p[u]];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < FILL_U; u++) {
             kw[u] = (int)(ks[u] & 0x7fff); kc[u] = (int)(ks[u] >> 15);
             ex[u] = p[u] == m && le >= 0;
             live[u] = live[u] && (kw[u] != 0 || kc[u] || ex[u]);
@@ -692,11 +705,11 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
                 ins[u] = q[u] - pe;
             }
         }
-        uint8_t cb[4];
+        uint8_t cb[FILL_U];
 #pragma unroll
-        for (int u = 0; u < 4; u++) cb[u] = (live[u] && kc[u] && !gap[u]) ? P.win[woff[u] + q[u]] : (uint8_t)'-';
+        for (int u = 0; u < FILL_U; u++) cb[u] = (live[u] && kc[u] && !gap[u]) ? P.win[woff[u] + q[u]] : (uint8_t)'-';
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < FILL_U; u++) {
             if (!live[u]) continue;
             const uint8_t *b = P.win + woff[u];
             uint8_t *row = out + (int64_t)r[u] * C;
