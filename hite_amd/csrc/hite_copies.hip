@@ -6,7 +6,7 @@
 //
 // Pipeline (sort / scan / segment, everything resident in HBM):
 //   index (once per genome): (w=10, k=15) minimizers straight from the 2-bit genome, one thread per
-//     window start, wave-aggregated append, radix sort by (hash|strand, position), 2^22-bucket directory;
+//     window start, wave-aggregated append, radix sort by (hash|strand, position), 2^26-bucket directory;
 //   query: candidate minimizers -> directory lookup -> occurrence counts -> scan -> hit expansion
 //     (key = candidate | relative strand | diagonal) -> radix sort -> cluster flags where the diagonal
 //     jumps -> per-cluster anchor count and extreme anchors by 64-bit atomicMin/Max -> coverage
@@ -25,7 +25,7 @@
 #define C_MINANCH 3
 #define C_MAXCOPY 300
 #define HS_INVALID 0xffffffffu
-#define DIRBITS 22
+#define DIRBITS 26
 #define DBIAS 65536ll
 
 struct CopyState {
