@@ -106,7 +106,11 @@ def main():
     d_cons = torch.zeros(cons_cap + 64 * K, dtype=torch.uint8, device=dev)
     gathered = torch.zeros(world * n_cand * 32, dtype=torch.uint8, device=dev) if world > 1 else None
     cand_bytes = int(w["cand_off"][-1])
-    bounds = [n_cand * i // K for i in range(K + 1)]
+    # uneven shares on purpose when K > 1: identical shares would march through their phases in lockstep and never overlap a
+    # vector-bound phase of one with a memory-bound phase of the other
+    wts = [1.0 + 0.35 * i for i in range(K)]
+    acc = np.cumsum([0.0] + wts) / sum(wts)
+    bounds = [int(round(n_cand * a_)) for a_ in acc]
     parts = []
     for i in range(K):
         lo, hi = bounds[i], bounds[i + 1]
@@ -172,8 +176,34 @@ def main():
         dist.barrier()
     t1 = time.perf_counter()
     stats = None
-    for _ in range(args.steps):
-        stats = step()
+    if K == 1:
+        for _ in range(args.steps):
+            stats = step()
+    else:
+        # the shares run their K steps back to back on their own stream / host thread (no join between steps: a step of a
+        # share is an independent unit of work); the boundary calls of every step are gathered afterwards
+        def run_steps(i):
+            for _ in range(args.steps):
+                run_part(i)
+                if parts[i]["err"] is not None:
+                    return
+
+        th = [threading.Thread(target=run_steps, args=(i,)) for i in range(K)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        for P in parts:
+            if P["err"] is not None:
+                raise P["err"]
+        for st_ in streams:
+            st_.synchronize()
+        if args.copies == "found":
+            found["n"] = sum(P["found"][0] for P in parts if P["found"])
+        if world > 1:
+            for _ in range(args.steps):
+                dist.all_gather_into_tensor(gathered, d_calls)
+        stats = sum(P["stats"] for P in parts)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
