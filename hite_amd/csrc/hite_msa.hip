@@ -663,60 +663,53 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
     const uint16_t *nstart = ops + (int64_t)R * (m + 1);
     const int le = Q.last_extra[c];
     uint8_t *out = P.msa + P.msa_off[c];
-    // items (r, p) flattened over the whole candidate: short centres still fill every lane, many loads in flight
+    // rows of the candidate are spread over blockIdx.y, positions over the threads: FILL_U positions per thread and trip, the
+    // loads of each dependency level issued together (the chain kwslot -> ops -> base is three loads deep and the kernel is
+    // latency bound otherwise); per-row values (window, length, output row) are wave-uniform: no division, little address math
     const int rs = m + 1;
-    const unsigned items = (unsigned)R * (unsigned)rs;   // < 2^31: R <= a few hundred rows, rs <= 32768
-    const unsigned stride = gridDim.y * 256u;
-    // FILL_U items per thread and trip: the loads of each dependency level are issued together (the chain kwslot -> ops ->
-    // base is three loads deep and the kernel is latency bound otherwise)
-    for (unsigned it0 = blockIdx.y * 256u + threadIdx.x; it0 < items; it0 += FILL_U * stride) {
-        int r[FILL_U], p[FILL_U], kw[FILL_U], kc[FILL_U], ins[FILL_U], gap[FILL_U], q[FILL_U], bs[FILL_U];
-        bool live[FILL_U], ex[FILL_U];
+    for (int r = blockIdx.y; r < R; r += gridDim.y) {
+        const uint8_t *b = P.win + P.win_off[g0 + r];
+        const int nrow = P.win_len[g0 + r];
+        const uint16_t *rop = ops + (int64_t)r * rs;
+        uint8_t *row = out + (int64_t)r * C;
+        for (int p0 = threadIdx.x; p0 <= m; p0 += FILL_U * 256) {
+            int p[FILL_U], kw[FILL_U], kc[FILL_U], ins[FILL_U], gap[FILL_U], q[FILL_U], bs[FILL_U];
+            bool live[FILL_U], ex[FILL_U];
+            unsigned ks[FILL_U], oc[FILL_U], op[FILL_U];
 #pragma unroll
-        for (int u = 0; u < FILL_U; u++) {
-            const unsigned it = it0 + u * stride;
-            live[u] = it < items;
-            r[u] = live[u] ? (int)(it / (unsigned)rs) : 0;
-            p[u] = live[u] ? (int)(it - (unsigned)r[u] * (unsigned)rs) : 0;
-        }
-        unsigned ks[FILL_U], oc[FILL_U], op[FILL_U];
-        int nrow[FILL_U];
-        int64_t woff[FILL_U];
-#pragma unroll
-        for (int u = 0; u < FILL_U; u++) {
-            ks[u] = kwslot[p[u]];
-            const uint16_t *rop = ops + (int64_t)r[u] * rs;
-            oc[u] = (r[u] > 0 && p[u] < m) ? rop[p[u]] : 0u;
-            op[u] = (r[u] > 0 && p[u] > 0) ? rop[p[u] - 1] : 0u;
-            nrow[u] = P.win_len[g0 + r[u]];
-            woff[u] = P.win_off[g0 + r[u]];
-            bs[u] = nstart[p[u]];
-        }
-#pragma unroll
-        for (int u = 0; u < FILL_U; u++) {
-            kw[u] = (int)(ks[u] & 0x7fff); kc[u] = (int)(ks[u] >> 15);
-            ex[u] = p[u] == m && le >= 0;
-            live[u] = live[u] && (kw[u] != 0 || kc[u] || ex[u]);
-            if (r[u] == 0) { ins[u] = 0; q[u] = p[u]; gap[u] = 0; }
-            else {
-                const int pe = p[u] > 0 ? (int)(op[u] & 0x7fff) + ((op[u] >> 15) ? 0 : 1) : 0;
-                q[u] = p[u] < m ? (int)(oc[u] & 0x7fff) : nrow[u];
-                gap[u] = (int)(oc[u] >> 15);
-                ins[u] = q[u] - pe;
+            for (int u = 0; u < FILL_U; u++) {
+                p[u] = p0 + u * 256;
+                live[u] = p[u] <= m;
+                if (!live[u]) p[u] = 0;
+                ks[u] = kwslot[p[u]];
+                oc[u] = (r > 0 && p[u] < m) ? rop[p[u]] : 0u;
+                op[u] = (r > 0 && p[u] > 0) ? rop[p[u] - 1] : 0u;
+                bs[u] = nstart[p[u]];
             }
-        }
-        uint8_t cb[FILL_U];
 #pragma unroll
-        for (int u = 0; u < FILL_U; u++) cb[u] = (live[u] && kc[u] && !gap[u]) ? P.win[woff[u] + q[u]] : (uint8_t)'-';
+            for (int u = 0; u < FILL_U; u++) {
+                kw[u] = (int)(ks[u] & 0x7fff); kc[u] = (int)(ks[u] >> 15);
+                ex[u] = p[u] == m && le >= 0;
+                live[u] = live[u] && (kw[u] != 0 || kc[u] || ex[u]);
+                if (r == 0) { ins[u] = 0; q[u] = p[u]; gap[u] = 0; }
+                else {
+                    const int pe = p[u] > 0 ? (int)(op[u] & 0x7fff) + ((op[u] >> 15) ? 0 : 1) : 0;
+                    q[u] = p[u] < m ? (int)(oc[u] & 0x7fff) : nrow;
+                    gap[u] = (int)(oc[u] >> 15);
+                    ins[u] = q[u] - pe;
+                }
+            }
+            uint8_t cb[FILL_U];
 #pragma unroll
-        for (int u = 0; u < FILL_U; u++) {
-            if (!live[u]) continue;
-            const uint8_t *b = P.win + woff[u];
-            uint8_t *row = out + (int64_t)r[u] * C;
-            const int rp = q[u] - ins[u];  // first inserted base
-            for (int k = 0; k < kw[u]; k++) row[bs[u] + k] = k < ins[u] ? b[rp + k] : (uint8_t)'-';
-            if (kc[u]) row[bs[u] + kw[u]] = cb[u];
-            if (ex[u]) row[bs[u] + kw[u]] = le < ins[u] ? b[rp + le] : (uint8_t)'-';
+            for (int u = 0; u < FILL_U; u++) cb[u] = (live[u] && kc[u] && !gap[u]) ? b[q[u]] : (uint8_t)'-';
+#pragma unroll
+            for (int u = 0; u < FILL_U; u++) {
+                if (!live[u]) continue;
+                const int rp = q[u] - ins[u];  // first inserted base
+                for (int k = 0; k < kw[u]; k++) row[bs[u] + k] = k < ins[u] ? b[rp + k] : (uint8_t)'-';
+                if (kc[u]) row[bs[u] + kw[u]] = cb[u];
+                if (ex[u]) row[bs[u] + kw[u]] = le < ins[u] ? b[rp + le] : (uint8_t)'-';
+            }
         }
     }
 }
