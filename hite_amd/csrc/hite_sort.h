@@ -35,11 +35,11 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
                                                                 unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
                                                                 int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
     constexpr int BINS = 1 << BITS;
-    __shared__ long long base[BINS];
+    __shared__ unsigned base[BINS];   // global positions fit 32 bits (every caller sorts < 2^32 elements)
     __shared__ int cnt[4][BINS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int b = threadIdx.x; b < BINS; b += 256) {
-        base[b] = offs[(int64_t)b * nblocks + blockIdx.x];
+        base[b] = (unsigned)offs[(int64_t)b * nblocks + blockIdx.x];
         cnt[0][b] = 0; cnt[1][b] = 0; cnt[2][b] = 0; cnt[3][b] = 0;
     }
     __syncthreads();
@@ -63,13 +63,12 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
         if (act && rank == 0) cnt[w][d] = mine;
         __syncthreads();
         if (act) {
-            long long pos = base[d];
-            for (int q = 0; q < w; q++) pos += cnt[q][d];
-            pos += rank;
+            unsigned pos = base[d] + (unsigned)rank;
+            for (int q = 0; q < w; q++) pos += (unsigned)cnt[q][d];
             kout[pos] = k; vout[pos] = v;
         }
         __syncthreads();
-        if (act && rank == 0) { atomicAdd((unsigned long long *)&base[d], (unsigned long long)mine); cnt[w][d] = 0; }
+        if (act && rank == 0) { atomicAdd(&base[d], (unsigned)mine); cnt[w][d] = 0; }
         __syncthreads();
     }
 }
@@ -112,6 +111,7 @@ static void sorter_free(Sorter &S) {
 // sorts (keys, vals) in place (ping-pong through the sorter's buffers) on the key bits [lo_bit, hi_bit), stable
 static int sorter_sort_bits(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int lo_bit, int hi_bit) {
     if (n <= 1) return HITE_OK;
+    if (n >= 0xffffffffll) return HITE_EINVAL;   // 32-bit positions inside the scatter kernel
     const bool wide = n >= RS_WIDE_MIN;
     const int bits = wide ? 10 : 8;
     const int tile = wide ? 8192 : RS_TILE;
