@@ -641,3 +641,29 @@ def test_ltr_frame(ctx, tmp_path):
     mf.write_text("".join(a + "\t" + b + "\n" for a, b in zip(c["left"], c["right"])))
     assert list(util.judge_left_frame_LTR(str(mf), c["flank"], c["window"])) == c["left_out"]
     assert list(util.judge_right_frame_LTR(str(mf), c["flank"], c["window"])) == c["right_out"]
+
+
+def test_seed_allvsall_edge_cases(ctx):
+    """all-vs-all seeding on degenerate genomes: no repeats, contigs shorter than a k-mer, N blocks, a repeat across a
+    segment border, an inverted repeat, a tandem array -- always equal to the twin"""
+    rng = np.random.default_rng(99)
+    unit = casegen.rand_seq(rng, 900)
+    fam = casegen.rand_seq(rng, 1500)
+    g1 = [casegen.rand_seq(rng, 30_000)]                                                   # unique sequence
+    g2 = ["ACGT", casegen.rand_seq(rng, 14), casegen.rand_seq(rng, 5000)]                    # tiny contigs
+    base = casegen.rand_seq(rng, 60_000)
+    g3 = [base[:10_000] + fam + base[10_000:29_400] + fam[:700] + "N" * 50 + fam[750:] + base[29_400:45_000] +
+          casegen.revcomp(fam) + base[45_000:]]                                             # direct, N-broken and inverted copies
+    g4 = [casegen.rand_seq(rng, 3000) + unit * 6 + casegen.rand_seq(rng, 3000), "N" * 2000 + casegen.rand_seq(rng, 4000)]  # tandem array
+    for contigs, seg in ((g1, 10_000), (g2, 1000), (g3, 20_000), (g3, 1_000_000), (g4, 2_500)):
+        ctx.genome_pack(contigs)
+        ctx._copy_state = None
+        got = ctx.seed_allvsall(seg_len=seg)
+        exp = O.seed_allvsall(contigs, seg_len=seg)
+        for k in ("qseg", "sseg", "qs", "qe", "ss", "se"):
+            assert np.array_equal(got[k], exp[k]), (len(contigs), seg, k, len(got[k]), len(exp[k]))
+    assert len(got["qseg"]) > 0
+    ctx.genome_pack(g3)
+    ctx._copy_state = None
+    h = ctx.seed_allvsall(seg_len=1_000_000)
+    assert (h["ss"] > h["se"]).any() and (h["ss"] < h["se"]).any()   # both strands reported
