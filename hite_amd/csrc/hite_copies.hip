@@ -7,10 +7,12 @@
 // Pipeline (sort / scan / segment, everything resident in HBM):
 //   index (once per genome): (w=10, k=15) minimizers straight from the 2-bit genome, one thread per
 //     window start, wave-aggregated append, radix sort by (hash|strand, position), 2^26-bucket directory;
-//   query: candidate minimizers -> directory lookup -> occurrence counts -> scan -> hit expansion
-//     (key = candidate | relative strand | diagonal) -> radix sort -> cluster flags where the diagonal
-//     jumps -> per-cluster anchor count and extreme anchors by 64-bit atomicMin/Max -> coverage
-//     filter + boundary extrapolation -> radix sort by (candidate | anchors desc | start) -> top 300.
+//   query: candidate minimizers (wave per candidate, LDS tile of 64 windows, private regions + pack) -> directory
+//     lookup -> occurrence counts -> scan -> wave-cooperative hit expansion (key = candidate | relative strand |
+//     diagonal) -> radix sort (10-bit digits) -> cluster flags where the diagonal jumps -> extreme anchors per
+//     cluster by a wave-level segmented min / max scan -> coverage filter + boundary extrapolation (two passes,
+//     per-candidate counters) -> radix sort by (candidate | anchors desc | start) -> top 300.
+//   The second half of the file is the all-vs-all seeding of stage 3.1 on the same index (hite_seed_allvsall).
 // Bound: HBM streaming for the sorts (12 B in + 12 B out per element per pass) and L2-latency for the
 // directory lookups; integer work only.
 #include "hite_common.h"
@@ -70,19 +72,6 @@ __device__ __forceinline__ unsigned genome_hs(const uint32_t *__restrict__ bases
     if ((unsigned)(mt >> msh) & 0x7fffu) return HS_INVALID;
     return hs_from_code(x);
 }
-__device__ __forceinline__ unsigned ascii_hs(const uint8_t *__restrict__ s, int64_t p, int64_t L) {
-    if (p < 0 || p + CK > L) return HS_INVALID;
-    unsigned x = 0;
-#pragma unroll
-    for (int i = 0; i < CK; i++) {
-        uint8_t c = s[p + i];
-        unsigned code = c == 'A' ? 0u : c == 'C' ? 1u : c == 'G' ? 2u : c == 'T' ? 3u : 4u;
-        if (code > 3u) return HS_INVALID;
-        x |= code << (2 * i);
-    }
-    return hs_from_code(x);
-}
-
 // minimizer of the window starting at k-mer start p of a sequence whose k-mer starts are [b, b+nk):
 // index of the valid k-mer with the smallest (hs >> 1, position) in [p, min(p+W, b+nk)), -1 if none
 template <typename HsFn>

@@ -2,18 +2,19 @@
 // stage at the point where the reference shells out to `mafft` (Util.py:10416, third-party,
 // unpinned, absent -> parity unpinned; the pinned twin is oracle/hite_oracle_msa.c, byte-exact).
 //
-// Definition: see the header comment of oracle/hite_oracle_msa.c (identical scoring, band
-// rule and tie-breaks).  Mapping to CDNA4:
-//   * one wavefront per (row, centre) pair; the 64 lanes ARE the adaptive band: lane k owns
-//     the cell i = t + k of anti-diagonal s = i + j, so one step of the recurrence is a
-//     handful of wave64 VALU ops + three cross-lane reads, no LDS, no divergence;
-//   * the per-cell direction (2 bits) leaves the wave as two 64-bit __ballot masks
-//     (16 B per anti-diagonal, written by one lane), the band moves as one bit per step;
-//   * the traceback replays those masks; it emits per centre position "gap?" + "bases inserted
-//     before", 2 B per position;
-//   * a second kernel takes the per-position maximum insertion over the rows (column layout)
-//     and a third writes the rows x cols matrix, every output byte written exactly once.
-// The DP is integer-ALU / latency bound (report cells/s); layout+fill are HBM streaming.
+// Definition: see the header comment of oracle/hite_oracle_msa.c (identical scoring, stored form,
+// band rule and tie-breaks).  Mapping to CDNA4:
+//   * one wavefront per (row, centre) pair from a dynamic queue; the 64 lanes ARE the adaptive band:
+//     lane k owns the cell i = t + k of anti-diagonal s = i + j.  The step is hand-scheduled inline
+//     asm (10-11 vector instructions): neighbours by DPP wave_shl / wave_shr, the bases of a chunk in
+//     per-wave LDS windows, one v_max3 on tagged scores for value + tie-break + direction;
+//   * the per-cell direction (2 bits) is packed per lane by v_alignbit: one dword per lane per 16
+//     anti-diagonals (256 B per wave, coalesced), the band moves as 2 bits per step in an SGPR;
+//   * the traceback is a scalar walk (v_readlane of the direction word, bit tests, v_writelane); it
+//     emits per centre position the aligned row position | gap flag << 15, 2 B per position;
+//   * layout / fill kernels turn those ops into the rows x cols matrix -- in the pipeline fused with
+//     remove_sparse_col_in_align_file, so that only the surviving columns are ever written.
+// The DP is bound by vector-instruction issue (report cells/s); layout + fill are HBM / latency bound.
 #include "hite_common.h"
 
 #define MW 64
@@ -93,20 +94,16 @@ __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
     unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
     return ((unsigned long long)hi << 32) | lo;
 }
-// One wavefront per (row, centre) pair.  Issue budget: a CU has ONE scalar unit for its 32 waves but four
-// vector units, so the per-step work is split on purpose: the band steering (11 dependent integer ops on
-// wave-uniform values) runs on the scalar unit, everything else is vector code under one uniform branch.
-//  forward : lane k owns cell i = t + k of anti-diagonal s.  Per step, depending on the (uniform) move: two
-//            DPP shifts give the up / left / diagonal neighbours (the diagonal operand of the next step is this
-//            step's "left" operand, so no second history register has to be re-aligned), one DPP shift slides
-//            the resident centre or row bases and takes in the one base that enters the band, fetched one
-//            step earlier by a broadcast load.  Directions are packed 2 bits per step into a per-lane register
-//            and leave as one coalesced 256-B store per 16 steps, the moves as 16 bits per 16 steps.
-//            No LDS, no atomics.
-//  backward: wave-uniform walk kept in vector registers; the walk tracks the lane index k of the current cell
-//            (k changes by the stored moves), the direction word comes from ds_bpermute on the re-loaded chunk;
-//            results leave as coalesced 128-B chunks of u16 (row position aligned to centre position p |
-//            gap flag << 15).
+// One wavefront per (row, centre) pair.  Issue budget (SQ counters, profiles/r01_sq_counters.txt): the vector unit is
+// ~96 % busy at 4 cycles per wave64 integer / DPP instruction, so the code below is written to the vector-instruction count.
+//  forward : lane k owns cell i = t + k of anti-diagonal s; 64 anti-diagonals per chunk.  Per step, depending on the
+//            (uniform) move: one DPP shift gives the left / up neighbour (the diagonal operand of the next step is this
+//            step's "left" operand: the two registers swap roles, no copy), the base that changes is re-read from the
+//            per-wave LDS window, one v_max3 on the tagged scores gives value, tie-break and direction, v_alignbit packs
+//            the direction.  Chunks that cannot touch the band clamps run 64 steps unrolled; the others go word by word
+//            through a general loop with the clamps on the scalar unit.
+//  backward: scalar walk (i-1 in M0, j-1, k, bit index in SGPRs), four 16-step words per trip; results leave as one
+//            masked store of <= 64 u16 per trip (row position aligned to centre position p | gap flag << 15).
 __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
     __shared__ uint8_t s_bases[4][2][128];  // per wave: windows of centre / row bases for the current chunk
     const int lane = threadIdx.x & 63;
