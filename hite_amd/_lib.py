@@ -364,6 +364,17 @@ class Context:
         self._check(rc, "hite_find_copies_dev")
         return (n.value,) + tuple(o.value or 0 for o in outs)
 
+    def nonltr_prep(self, seqs, flank=50, win5=25):
+        """search_polyA_TSD on a batch -> [(found_TSD, direct, tsd_start, tsd_len, lo, hi)]"""
+        sb = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        n = len(sb)
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in sb], out=off[1:])
+        buf = np.frombuffer(b"".join(sb) + b"\0" * 16, dtype=np.uint8)
+        out = np.zeros(6 * max(1, n), dtype=np.int64)
+        self._check(self.lib.hite_nonltr_prep(self.h, n, _p(buf), _p(off), int(flank), int(win5), _p(out)), "hite_nonltr_prep")
+        return [tuple(int(x) for x in out[6 * i:6 * i + 6]) for i in range(n)]
+
     def ltr_frame(self, matrices, flank, window=20, side="left"):
         """FiLTR flank-frame vote on a batch: matrices = list of lists of equal-length frame strings -> [(is_ltr, boundary)]"""
         n = len(matrices)

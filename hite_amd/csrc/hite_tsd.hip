@@ -183,3 +183,164 @@ extern "C" int hite_tsd_kmer(hite_ctx *ctx, int32_t n, const uint8_t *seqs, cons
     HITE_CHECK(ctx, hipMemcpy(cnt_out, dc.p, (size_t)n * 4, hipMemcpyDeviceToHost));
     return HITE_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// non-LTR candidate preparation: search_polyA_TSD  Util.py:10915-11007
+// (find_nearest_polyA / polyT :10865 / :10903, find_nearest_tandem :9772).  One wavefront per flanked repeat:
+// lanes own window positions for the poly-A / poly-T runs, the tandem units and the TSD k-mers.
+// find_near_matches(TSD, kmer, max_l_dist = 1) on two strings of the SAME length k has a closed form: a substring of
+// kmer within one edit of TSD is either kmer itself (<= 1 substitution) or kmer without its last / first character
+// (TSD with one character deleted); all three reduce to "common prefix + common suffix >= k - 1".
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void np_slice(long long a, long long b, long long n, long long *lo, long long *hi) {
+    if (a < 0) { a += n; if (a < 0) a = 0; }
+    if (b < 0) { b += n; if (b < 0) b = 0; }
+    if (a > n) a = n;
+    if (b > n) b = n;
+    if (b < a) b = a;
+    *lo = a; *hi = b;
+}
+// wave-wide arg-max of key (0 = nothing); returns the winning lane or -1
+__device__ __forceinline__ int wave_argmax(unsigned long long key) {
+    unsigned long long best = key;
+    for (int d = 32; d >= 1; d >>= 1) { unsigned long long o = __shfl_xor(best, d); best = o > best ? o : best; }
+    if (best == 0) return -1;
+    return __ffsll((long long)__ballot(key == best)) - 1;
+}
+// longest run of `base` (>= 6, first among equals) in seq[lo, hi), hi - lo <= 50: window coordinates [*s, *e)
+__device__ bool np_longest_run(const uint8_t *seq, long long lo, long long hi, uint8_t base, long long *s, long long *e) {
+    const int lane = threadIdx.x & 63;
+    const long long i = lo + lane;
+    int len = 0;
+    if (i < hi && seq[i] == base && (i == lo || seq[i - 1] != base))
+        for (long long q = i; q < hi && seq[q] == base; q++) len++;
+    const unsigned long long key = len >= 6 ? ((unsigned long long)len << 8) | (unsigned long long)(63 - lane) : 0ull;
+    const int w = wave_argmax(key);
+    if (w < 0) return false;
+    *s = w; *e = w + __shfl(len, w);
+    return true;
+}
+__device__ bool np_nearest_poly(const uint8_t *seq, long long n, long long pos, uint8_t base, long long *s, long long *e) {
+    long long lo, hi, ws, we;
+    np_slice(pos - 25 > 0 ? pos - 25 : 0, pos + 25 < n ? pos + 25 : n, n, &lo, &hi);
+    if (!np_longest_run(seq, lo, hi, base, &ws, &we)) return false;
+    const long long a = pos - 25 + ws, b = pos - 25 + we;
+    *s = a > 0 ? a : 0; *e = b > 0 ? b : 0;
+    return true;
+}
+__device__ bool np_nearest_tandem(const uint8_t *seq, long long n, long long pos, long long *s, long long *e) {
+    const int lane = threadIdx.x & 63;
+    const long long start = pos - 25 > 0 ? pos - 25 : 0, end = pos + 25 < n ? pos + 25 : n;
+    unsigned long long key = 0;
+    for (int m = 2; m <= 6; m++) {
+        const long long i = start + lane;
+        if (i < end - (long long)m * 4 + 1) {
+            long long lo, hi;
+            np_slice(i, i + (long long)m * 4, n, &lo, &hi);
+            const long long L = hi - lo;
+            bool ok = L > 0 && L % m == 0;
+            for (long long q = 0; ok && q < L; q++) ok = seq[lo + q] == seq[lo + q % m];
+            // first in (m ascending, i ascending) order among the longest
+            const unsigned long long k2 = ok ? ((unsigned long long)L << 16) | (unsigned long long)((7 - m) << 8) | (unsigned long long)(63 - lane) : 0ull;
+            key = k2 > key ? k2 : key;
+        }
+    }
+    const int w = wave_argmax(key);
+    if (w < 0) return false;
+    const unsigned long long kw = ((unsigned long long)(unsigned)__shfl((int)(key >> 32), w) << 32) | (unsigned)__shfl((int)key, w);
+    const long long L = (long long)(kw >> 16);
+    *s = start + w; *e = start + w + L;
+    return true;
+}
+// two strings of length k: is some substring of t within one edit of p?
+__device__ __forceinline__ bool np_near1(const uint8_t *p, const uint8_t *t, int k) {
+    int lp = 0, ls = 0, lp1 = 0, ls1 = 0;
+    while (lp < k && p[lp] == t[lp]) lp++;
+    if (lp == k) return true;
+    while (ls < k && p[k - 1 - ls] == t[k - 1 - ls]) ls++;
+    if (lp + ls >= k - 1) return true;                                  // <= 1 substitution
+    while (ls1 < k - 1 && p[k - 1 - ls1] == t[k - 2 - ls1]) ls1++;      // p without one character == t[0 : k-1]
+    if (lp + ls1 >= k - 1) return true;
+    while (lp1 < k - 1 && p[lp1] == t[1 + lp1]) lp1++;                  // p without one character == t[1 : k]
+    return lp1 + ls >= k - 1;
+}
+
+__global__ void __launch_bounds__(256) nonltr_prep_kernel(int n, const uint8_t *__restrict__ seqs, const int64_t *__restrict__ seq_off,
+                                                          int flank, int win5, int64_t *__restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n) return;
+    const uint8_t *seq = seqs + seq_off[c];
+    const long long L = seq_off[c + 1] - seq_off[c];
+    const long long raw_start = flank + 1, raw_end = L - flank;
+    long long end_3 = -1, end_5 = -1;
+    int direct = 0;
+    long long ps = 0, pe = 0, ts = 0, te = 0;
+    for (int side = 0; side < 2; side++) {
+        const long long pos = side == 0 ? raw_end : raw_start;
+        const bool hp = np_nearest_poly(seq, L, pos, side == 0 ? 'A' : 'T', &ps, &pe);
+        const bool ht = np_nearest_tandem(seq, L, pos, &ts, &te);
+        long long plen = 0, tlen = 0, lo, hi;
+        if (hp) { np_slice(ps, pe, L, &lo, &hi); plen = hi - lo; }
+        if (ht) tlen = te - ts;
+        if ((plen < tlen ? plen : tlen) > 0) {
+            if (side == 0) { end_3 = plen > tlen ? pe : te; end_5 = raw_start; direct = 1; }
+            else { end_3 = plen > tlen ? ps : ts; end_5 = raw_end; direct = 2; }
+        }
+    }
+    int found = 0;
+    long long tsd_s = 0, tsd_n = 0;
+    if (end_3 != -1 && end_5 != -1 && direct) {
+        long long wlo, whi;
+        np_slice(end_5 - win5 > 0 ? end_5 - win5 : 0, end_5 + win5, L, &wlo, &whi);
+        for (int k = 20; k >= 8 && !found; k--) {
+            long long tlo, thi;
+            if (direct == 2) np_slice(end_3 - k, end_3, L, &tlo, &thi); else np_slice(end_3, end_3 + k, L, &tlo, &thi);
+            if (thi - tlo != k) continue;
+            bool hasN = false;
+            for (int q = 0; q < k; q++) hasN = hasN || seq[tlo + q] == 'N';
+            if (hasN) continue;                      // a TSD with N never counts (:10971), whatever matches
+            unsigned long long hit = 0;
+            int first = -1;
+            for (long long i0 = 0; i0 + k <= whi - wlo && first < 0; i0 += 64) {
+                const long long i = i0 + lane;
+                const bool ok = i + k <= whi - wlo && np_near1(seq + tlo, seq + wlo + i, k);
+                hit = __ballot(ok);
+                if (hit) first = (int)i0 + __ffsll((long long)hit) - 1;
+            }
+            if (first >= 0) {
+                end_5 = (end_5 - win5 > 0 ? end_5 - win5 : 0) + first + (direct == 1 ? k : 0);
+                found = 1; tsd_s = tlo; tsd_n = k;
+            }
+        }
+    }
+    if (lane == 0) {
+        int64_t *o = out + (int64_t)c * 6;
+        o[0] = found; o[1] = direct; o[2] = tsd_s; o[3] = tsd_n;
+        if (!direct) { o[4] = 0; o[5] = 0; }
+        else {
+            long long lo, hi;
+            np_slice(end_5 < end_3 ? end_5 : end_3, end_5 > end_3 ? end_5 : end_3, L, &lo, &hi);
+            o[4] = lo; o[5] = hi;
+        }
+    }
+}
+
+// out: 6 x int64 per sequence = {found_TSD, direct (0 none, 1 '+', 2 '-'), TSD start, TSD length, lo, hi of non_ltr_seq}
+extern "C" int hite_nonltr_prep(hite_ctx *ctx, int32_t n, const uint8_t *seqs, const int64_t *seq_off, int32_t flank, int32_t win5,
+                                int64_t *out) {
+    if (!ctx || n < 0 || (n > 0 && (!seqs || !seq_off || !out)) || flank < 0 || win5 < 0 || win5 > 25) return HITE_EINVAL;
+    if (n == 0) return HITE_OK;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    TBuf ds, dof, dout;
+    hipError_t e = ds.up(seqs, seq_off[n]);
+    if (e == hipSuccess) e = dof.up(seq_off, (size_t)(n + 1) * 8);
+    if (e == hipSuccess) e = dout.alloc((size_t)n * 48);
+    HITE_CHECK(ctx, e);
+    hipLaunchKernelGGL(nonltr_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, nullptr, n, (const uint8_t *)ds.p, (const int64_t *)dof.p, flank,
+                       win5, (int64_t *)dout.p);
+    HITE_CHECK(ctx, hipGetLastError());
+    HITE_CHECK(ctx, hipDeviceSynchronize());
+    HITE_CHECK(ctx, hipMemcpy(out, dout.p, (size_t)n * 48, hipMemcpyDeviceToHost));
+    return HITE_OK;
+}

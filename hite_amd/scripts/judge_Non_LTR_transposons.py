@@ -2,9 +2,10 @@
 """Drop-in for HiTE's module/judge_Non_LTR_transposons.py (same argv and output files,
 /root/reference/module/judge_Non_LTR_transposons.py:16-144): <tmp_output_dir>/confident_non_ltr_{i}.fa.
 
-Candidates: the reference scans the flanked repeats for polyA/T + TSD structures (get_candidate_non_ltr_parallel, f-4 of
-SURVEY.md section 8 -- not built) and rescues LINEs by protein-domain search (blastx, external).  `--candidates <fa>`
-(extension of this build) passes the candidate file; without it <tmp_output_dir>/candidate_non_ltr_{i}.fa is used.
+Candidates: as in the reference they come from the flanked repeats (`--seqs`): polyA/T or tandem tail + TSD structures
+(get_candidate_non_LTR -> search_polyA_TSD, on the GPU), SINE class first, then LINE.  The rescue of LINEs without a TSD by
+protein-domain search (blastx, external) is not part of this build.  `--candidates <fa>` (extension) passes a ready
+candidate file instead.
 GPU: one pass of flank_region_align_v5 with judge_boundary_v9 (homology boundaries, polyA / tandem tail within 10 columns
 of the 3' boundary, 8-20 bp TSD with <= 1 edit upstream of the 5' boundary)."""
 import argparse
@@ -33,13 +34,16 @@ def main():
     final = os.path.join(out_dir, "confident_non_ltr_%s.fa" % a.ref_index)
     if a.recover and os.path.exists(final) and util.read_fasta(final)[0]:
         return 0
-    cand = a.candidates or os.path.join(out_dir, "candidate_non_ltr_%s.fa" % a.ref_index)
-    if not a.is_denovo_nonltr or not os.path.exists(cand):
-        if a.is_denovo_nonltr:
-            sys.stderr.write("judge_Non_LTR_transposons (MI355X path): no candidate file (%s)\n" % cand)
-            return 2
+    if not a.is_denovo_nonltr:
         util.store_fasta({}, final)
         return 0
+    cand = a.candidates
+    if cand is None:
+        cand = os.path.join(out_dir, "candidate_non_ltr_%s.fa" % a.ref_index)
+        sine, line = util.get_candidate_non_LTR(a.seqs, a.flanking_len)
+        merged = dict(sine)
+        merged.update(line)          # `cat SINE > candidates; cat LINE >> candidates` (judge_Non_LTR_transposons.py:37-38)
+        util.store_fasta(merged, cand)
     low = a.all_low_copy_non_ltr or os.path.join(out_dir, "non_ltr_low_copy.fa")
     util.set_reference(a.r)
     cons_in = cand + ".cons"

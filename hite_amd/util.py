@@ -263,6 +263,37 @@ def search_confident_tir_batch_v1(names, contigs, flanking_len, plant, work_dir,
     return out
 
 
+def search_polyA_TSD_batch(seqs, flanking_len=50, end_5_window_size=25, device=0):
+    """search_polyA_TSD (Util.py:10915) for a batch of flanked repeats -> [(found_TSD, TSD_seq, non_ltr_seq)]"""
+    res = get_ctx(device).nonltr_prep(seqs, flanking_len, end_5_window_size)
+    out = []
+    for s, (found, direct, ts, tn, lo, hi) in zip(seqs, res):
+        nl = s[lo:hi] if direct else ""
+        if direct == 2:
+            nl = getReverseSequence(nl)
+        out.append((bool(found), s[ts:ts + tn] if found else "", nl))
+    return out
+
+
+def get_candidate_non_LTR(longest_repeats_flanked_path, flanking_len=50, device=0):
+    """get_candidate_non_LTR (Util.py:11009-11045): flanked repeats of 100-700 bp (SINE) / 700-8000 bp (LINE) with a polyA/T
+    or tandem tail and a TSD -> ({name\tTSD:seq: element}, {...}); the element must fall into the same length class."""
+    names, contigs = read_fasta(longest_repeats_flanked_path)
+    sine = [n for n in names if 100 <= len(contigs[n]) - 2 * flanking_len <= 700]
+    line = [n for n in names if 700 < len(contigs[n]) - 2 * flanking_len <= 8000]
+    res = search_polyA_TSD_batch([contigs[n] for n in sine + line], flanking_len, 25, device)
+    cand_sine, cand_line = {}, {}
+    for i, n in enumerate(sine + line):
+        found, tsd, seq = res[i]
+        if not found:
+            continue
+        if i < len(sine) and 100 <= len(seq) <= 700:
+            cand_sine[n + "\tTSD:" + tsd] = seq
+        elif i >= len(sine) and 700 < len(seq) <= 8000:
+            cand_line[n + "\tTSD:" + tsd] = seq
+    return cand_sine, cand_line
+
+
 def mask_genome_intactTE(TE_lib, genome_path, work_dir=None, thread=1, ref_index=0, debug=0, device=0):
     """mask_genome_intactTE (Util.py:6389-6431): the full-length copies (coverage >= 0.95 of the library sequence) of the
     TEs found so far are replaced by N in the chunk, written to <genome_path>.masked.  The copies come from the build's

@@ -134,6 +134,13 @@ int hite_tsd_search(hite_ctx *ctx, int32_t n, const uint8_t *rows_bytes, const i
                     const int32_t *bstart, const int32_t *bend, int32_t plant, int32_t *tsd_len_out,
                     uint8_t *left_out /* n x 16 */, uint8_t *right_out /* n x 16 */);
 
+/* ---- non-LTR candidate preparation --- search_polyA_TSD  Util.py:10915-11007 (get_candidate_non_LTR :11009) -------------
+ * batch of flanked repeats (CSR): polyA / tandem tail near the 3' end (or polyT / tandem head), then an 8-20 bp TSD
+ * (<= 1 edit) within win5 (<= 25) of the 5' end.  out: 6 x int64 per sequence = {found_TSD, direct (0 none, 1 '+', 2 '-'),
+ * TSD start, TSD length, lo, hi}: non_ltr_seq = seq[lo:hi], reverse-complemented by the caller when direct == 2. */
+int hite_nonltr_prep(hite_ctx *ctx, int32_t n, const uint8_t *seqs, const int64_t *seq_off, int32_t flank, int32_t win5,
+                     int64_t *out);
+
 /* ---- LTR flank-frame vote (vendored FiLTR) --- judge_left_frame_LTR / judge_right_frame_LTR
  * bin/FiLTR-main/src/Util.py:9327 / :9175 -----------------------------------------------------------------------------
  * n matrices of rows[i] x cols[i] bytes at off[i] (the left OR right frames of the copies of one LTR candidate, what the

@@ -413,11 +413,44 @@ def gen_ltr_frame(tmp):
     dump("ltr_frame", cases)
 
 
+def gen_nonltr_prep(U):
+    """search_polyA_TSD (Util.py:10915): flanked repeat -> (found_TSD, TSD_seq, non_ltr_seq)"""
+    rng = np.random.default_rng(515)
+    cases = []
+    for ci in range(260):
+        flank = 50
+        L = int(rng.choice([60, 150, 400, 900, 3000]))
+        body = casegen.rand_seq(rng, L)
+        kind = int(rng.integers(0, 8))
+        tsd = casegen.rand_seq(rng, int(rng.integers(8, 21)))
+        left, right = casegen.rand_seq(rng, flank), casegen.rand_seq(rng, flank)
+        if kind in (0, 1, 2):                      # polyA tail at the 3' end, TSD on both sides
+            tail = "A" * int(rng.integers(5, 18)) if kind != 2 else "".join(["CA", "TTG", "GAAT"][int(rng.integers(0, 3))] for _ in range(6))
+            t2 = tsd if rng.random() < 0.7 else casegen.mutate(rng, tsd, 0.08)
+            left = left[:flank - len(tsd) - int(rng.integers(0, 6))] + tsd
+            left = (casegen.rand_seq(rng, flank) + left)[-flank:]
+            seq = left + body + tail + t2 + right
+            seq = seq[:flank + L + len(tail) + flank]
+        elif kind in (3, 4):                       # polyT head (minus strand element)
+            head = "T" * int(rng.integers(5, 18))
+            seq = (left + tsd)[-flank:] + head + body + tsd + right
+            seq = seq[:len(seq) - len(tsd)] if rng.random() < 0.3 else seq
+        elif kind == 5:
+            seq = left + body + right
+        elif kind == 6:                            # short sequence: windows clamp at both ends
+            seq = casegen.rand_seq(rng, int(rng.integers(20, 90)))[:40] + "A" * 9 + casegen.rand_seq(rng, 12)
+        else:
+            seq = left + body[:L // 2] + "N" * 3 + "AAAAAAAA" + body[L // 2:] + "AAAAAAAAAA" + tsd[:4] + "N" + tsd[5:] + right
+        found, tsd_seq, nl = U.search_polyA_TSD(seq, flank, 25, list(range(8, 21)))
+        cases.append({"seq": seq, "flank": flank, "found": bool(found), "tsd": tsd_seq, "non_ltr": nl})
+    dump("nonltr_prep", cases)
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -437,6 +470,8 @@ def main():
             gen_host(U)
         if "ltr" in which:
             gen_ltr_frame(tmp)
+        if "nonltr" in which:
+            gen_nonltr_prep(U)
 
 
 if __name__ == "__main__":

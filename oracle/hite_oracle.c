@@ -955,3 +955,101 @@ done:
     free(model); free(cm); free(srows); free(erows); free(frows); free(as); free(ae); free(ung); free(reflex);
     return is_te;
 }
+
+/* ------------------------------------------------------------------------------- */
+/* non-LTR candidate preparation                            */
+/* search_polyA_TSD  Util.py:10915-11007; find_nearest_polyA / polyT :10865 / :10903 */
+/* (find_longest_polyA / polyT :10840 / :10878), find_nearest_tandem :9772-9820      */
+/* ------------------------------------------------------------------------------- */
+/* longest run of `base` (>= min_len, first among equals) in seq[lo, hi): returns run as absolute [*s, *e) or 0 */
+static int longest_run(const uint8_t *seq, int64_t lo, int64_t hi, uint8_t base, int min_len, int64_t *s, int64_t *e) {
+    int64_t best = 0, cur = 0, start = 0, bs = -1, be = -1;
+    for (int64_t i = lo; i < hi; i++) {
+        if (seq[i] == base) { cur++; if (cur == 1) start = i; }
+        else { if (cur >= min_len && cur > best) { best = cur; bs = start; be = i; } cur = 0; }
+    }
+    if (cur >= min_len && cur > best) { bs = start; be = hi; }
+    if (bs < 0) return 0;
+    *s = bs - lo; *e = be - lo;   /* coordinates inside the window, as the reference returns them */
+    return 1;
+}
+/* find_nearest_polyA / find_nearest_polyT: -> 1 and absolute [*s, *e), or 0 */
+static int nearest_poly(const uint8_t *seq, int64_t n, int64_t pos, uint8_t base, int64_t *s, int64_t *e) {
+    int64_t lo, hi, ws, we;
+    py_slice(i64max(0, pos - 25), i64min(n, pos + 25), n, &lo, &hi);
+    if (!longest_run(seq, lo, hi, base, 6, &ws, &we)) return 0;
+    *s = i64max(0, pos - 25 + ws);   /* the offset is pos - 25 even when the window was clamped at 0 (:10872) */
+    *e = i64max(0, pos - 25 + we);
+    return 1;
+}
+/* find_nearest_tandem: -> 1 and absolute [*s, *e), or 0 */
+static int nearest_tandem(const uint8_t *seq, int64_t n, int64_t pos, int64_t *s, int64_t *e) {
+    const int64_t start = i64max(0, pos - 25), end = i64min(n, pos + 25);
+    int64_t best = 0;
+    int found = 0;
+    for (int m = 2; m <= 6; m++)
+        for (int64_t i = start; i < end - (int64_t)m * 4 + 1; i++) {
+            int64_t lo, hi;
+            py_slice(i, i + (int64_t)m * 4, n, &lo, &hi);
+            const int64_t L = hi - lo;
+            if (L % m != 0) continue;                 /* is_tandem_repeat: length must be a multiple of the motif */
+            int ok = 1;
+            for (int64_t q = 0; q < L && ok; q += m)
+                for (int r = 0; r < m; r++) if (seq[lo + q + r] != seq[lo + r]) { ok = 0; break; }
+            if (ok && L > best) { best = L; *s = lo; *e = lo + L; found = 1; }
+        }
+    return found && best > 0;
+}
+
+/*
+ * search_polyA_TSD(seq, flanking_len, end_5_window_size, TSD_sizes = 8..20).
+ * out[0] = found_TSD, out[1] = direct (0 none, 1 '+', 2 '-'), out[2] = TSD start, out[3] = TSD length (0 if none),
+ * out[4], out[5] = [lo, hi) of non_ltr_seq in seq (reverse-complemented by the caller when direct == '-').
+ */
+void orc_search_polyA_TSD(const uint8_t *seq, int64_t n, int flank, int win5, int64_t *out) {
+    const int64_t raw_start = flank + 1, raw_end = n - flank;
+    int64_t end_3 = -1, end_5 = -1;
+    int direct = 0;
+    int64_t ps, pe, ts, te;
+    int hp = nearest_poly(seq, n, raw_end, 'A', &ps, &pe), ht = nearest_tandem(seq, n, raw_end, &ts, &te);
+    /* sequence[max_start:max_end] can be empty after the clamps: the reference tests the STRING lengths */
+    {
+        int64_t plen = 0, tlen = 0, lo, hi;
+        if (hp) { py_slice(ps, pe, n, &lo, &hi); plen = hi - lo; }
+        if (ht) tlen = te - ts;
+        if ((plen < tlen ? plen : tlen) > 0) { end_3 = plen > tlen ? pe : te; end_5 = raw_start; direct = 1; }
+    }
+    hp = nearest_poly(seq, n, raw_start, 'T', &ps, &pe);
+    ht = nearest_tandem(seq, n, raw_start, &ts, &te);
+    {
+        int64_t plen = 0, tlen = 0, lo, hi;
+        if (hp) { py_slice(ps, pe, n, &lo, &hi); plen = hi - lo; }
+        if (ht) tlen = te - ts;
+        if ((plen < tlen ? plen : tlen) > 0) { end_3 = plen > tlen ? ps : ts; end_5 = raw_end; direct = 2; }
+    }
+    int found = 0;
+    int64_t tsd_s = 0, tsd_n = 0;
+    if (end_3 != -1 && end_5 != -1 && direct) {
+        int64_t wlo, whi;
+        py_slice(i64max(0, end_5 - win5), end_5 + win5, n, &wlo, &whi);
+        for (int k = 20; k >= 8 && !found; k--) {           /* reversed(TSD_list) */
+            int64_t tlo, thi;
+            if (direct == 2) py_slice(end_3 - k, end_3, n, &tlo, &thi); else py_slice(end_3, end_3 + k, n, &tlo, &thi);
+            if (thi - tlo != k) continue;                    /* k == len(TSD) */
+            int hasN = 0;
+            for (int64_t q = tlo; q < thi; q++) if (seq[q] == 'N') hasN = 1;
+            for (int64_t i = 0; i + k <= whi - wlo; i++) {
+                int o4[4];
+                /* len(kmer) == k >= 8 -> max_l_dist 1 */
+                if (orc_find_near_matches(seq + tlo, k, seq + wlo + i, k, 1, o4) > 0 && !hasN) {
+                    end_5 = i64max(0, end_5 - win5) + i + (direct == 1 ? k : 0);
+                    found = 1; tsd_s = tlo; tsd_n = k;
+                    break;
+                }
+            }
+        }
+    }
+    out[0] = found; out[1] = direct; out[2] = tsd_s; out[3] = tsd_n;
+    if (!direct) { out[4] = 0; out[5] = 0; }
+    else { int64_t lo, hi; py_slice(i64min(end_5, end_3), i64max(end_5, end_3), n, &lo, &hi); out[4] = lo; out[5] = hi; }
+}

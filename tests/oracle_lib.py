@@ -263,3 +263,20 @@ def ltr_frame(rows, flank, window, side):
     b = C.c_int(-1)
     ok = lib().orc_ltr_frame(_ptr(m, u8p), R, Cn, int(flank), int(window), 0 if side == "left" else 1, C.byref(b))
     return bool(ok), int(b.value)
+
+
+def search_polyA_TSD(seq, flank=50, win5=25):
+    """non-LTR candidate preparation (search_polyA_TSD, Util.py:10915) -> (found_TSD, TSD_seq, non_ltr_seq)"""
+    b = seq.encode() if isinstance(seq, str) else bytes(seq)
+    buf = np.frombuffer(b + b"\0", dtype=np.uint8)
+    out = np.zeros(6, dtype=np.int64)
+    L = lib()
+    L.orc_search_polyA_TSD.restype = None
+    L.orc_search_polyA_TSD(_ptr(buf, u8p), C.c_int64(len(b)), int(flank), int(win5), _ptr(out, i64p))
+    found, direct, ts, tn, lo, hi = (int(x) for x in out)
+    s = b.decode()
+    nl = s[lo:hi] if direct else ""
+    if direct == 2:
+        comp = {"A": "T", "T": "A", "C": "G", "G": "C"}
+        nl = "".join(comp.get(c, "N") for c in reversed(nl))
+    return bool(found), s[ts:ts + tn] if found else "", nl

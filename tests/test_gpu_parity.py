@@ -667,3 +667,49 @@ def test_seed_allvsall_edge_cases(ctx):
     ctx._copy_state = None
     h = ctx.seed_allvsall(seg_len=1_000_000)
     assert (h["ss"] > h["se"]).any() and (h["ss"] < h["se"]).any()   # both strands reported
+
+
+def test_nonltr_prep(ctx, tmp_path):
+    """non-LTR candidate preparation (search_polyA_TSD): golden vectors (reference outputs) + random tails vs the oracle"""
+    from hite_amd import util
+
+    g = load_golden("nonltr_prep")
+    got = util.search_polyA_TSD_batch([c["seq"] for c in g], 50, 25)
+    for c, r in zip(g, got):
+        assert list(r) == [c["found"], c["tsd"], c["non_ltr"]], (c["seq"][:50], r[:2])
+    rng = np.random.default_rng(8)
+    seqs = []
+    for _ in range(400):
+        L = int(rng.integers(30, 1200))
+        s = list(casegen.rand_seq(rng, L + 100))
+        for _k in range(int(rng.integers(0, 4))):
+            p = int(rng.integers(0, len(s) - 20))
+            unit = ["A", "T", "AC", "TTG", "GATA", "AAAAG"][int(rng.integers(0, 6))]
+            rep = (unit * 12)[:int(rng.integers(6, 24))]
+            s[p:p + len(rep)] = list(rep)
+        if rng.random() < 0.5:
+            t = casegen.rand_seq(rng, int(rng.integers(8, 21)))
+            a, b = int(rng.integers(20, 60)), len(s) - int(rng.integers(30, 70))
+            s[a:a + len(t)] = list(t)
+            s[b:b + len(t)] = list(t if rng.random() < 0.6 else casegen.mutate(rng, t, 0.07))
+        seqs.append("".join(s)[:L + 100])
+    for _ in range(150):   # constructed elements: TSD + body + polyA / tandem tail + TSD (or the reverse-strand form)
+        body = casegen.rand_seq(rng, int(rng.integers(90, 900)))
+        t = casegen.rand_seq(rng, int(rng.integers(8, 21)))
+        t2 = t if rng.random() < 0.6 else casegen.mutate(rng, t, 0.06)
+        tail = "A" * int(rng.integers(6, 20)) if rng.random() < 0.7 else "CA" * int(rng.integers(4, 9))
+        el = body + tail
+        if rng.random() < 0.4:
+            el = casegen.revcomp(el)
+        seqs.append((casegen.rand_seq(rng, 50) + t)[-50:] + el + (t2 + casegen.rand_seq(rng, 50))[:50])
+    got = util.search_polyA_TSD_batch(seqs, 50, 25)
+    assert [tuple(x) for x in got] == [O.search_polyA_TSD(s, 50, 25) for s in seqs]
+    assert sum(x[0] for x in got) > 20
+    # file-level mirror: length classes and names
+    fa = tmp_path / "lr.flanked.fa"
+    fa.write_text("".join(">r%d\n%s\n" % (i, c["seq"]) for i, c in enumerate(g)))
+    sine, line = util.get_candidate_non_LTR(str(fa), 50)
+    for name, seq in list(sine.items()) + list(line.items()):
+        i = int(name.split("\t")[0][1:])
+        assert g[i]["found"] and name.endswith("TSD:" + g[i]["tsd"]) and seq == g[i]["non_ltr"]
+    assert len(sine) + len(line) > 10

@@ -190,3 +190,14 @@ def test_ltr_frame_golden():
         assert list(O.ltr_frame(c["right"], c["flank"], c["window"], "right")) == c["right_out"]
         seen.add((tuple(c["left_out"])[0], c["left_out"][1] >= 0, c["right_out"][0], c["right_out"][1] >= 0))
     assert len(seen) >= 5
+
+
+def test_nonltr_prep_golden():
+    """search_polyA_TSD restatement (polyA / polyT / tandem tails + 8-20 bp TSD near the 5' end) vs the reference"""
+    g = load_golden("nonltr_prep")
+    kinds = set()
+    for c in g:
+        got = O.search_polyA_TSD(c["seq"], c["flank"], 25)
+        assert list(got) == [c["found"], c["tsd"], c["non_ltr"]], (c["seq"][:60], got, (c["found"], c["tsd"], c["non_ltr"][:40]))
+        kinds.add((c["found"], bool(c["non_ltr"])))
+    assert len(kinds) == 3
