@@ -446,11 +446,72 @@ def gen_nonltr_prep(U):
     dump("nonltr_prep", cases)
 
 
+def gen_query_copies(U, tmp):
+    """get_query_copies (Util.py:6828) on synthetic blast6-like HSP tables of TE queries against chromosomes"""
+    rng = np.random.default_rng(6828)
+    cases = []
+    for ci in range(40):
+        nq, ns = int(rng.integers(1, 6)), int(rng.integers(1, 4))
+        qlen = [int(rng.integers(200, 3000)) for _ in range(nq)]
+        slen = [int(rng.integers(20_000, 200_000)) for _ in range(ns)]
+        rows = []
+        many = ci % 13 == 5
+        scov = 0.02 if ci % 7 == 3 else 0.0
+        for q in range(nq):
+            for _copy in range(int(rng.integers(105, 140)) if (many and q == 0) else int(rng.integers(1, 14))):
+                s = int(rng.integers(0, ns))
+                rev = rng.random() < 0.5
+                pos = int(rng.integers(100, slen[s] - 2 * qlen[q] - 100))
+                cov = float(rng.choice([1.0, 1.0, 0.97, 0.6]))
+                span = int(qlen[q] * cov)
+                q0 = int(rng.integers(1, qlen[q] - span + 2))
+                nfr = int(rng.integers(1, 5))
+                cuts = sorted(set([0, span] + [int(x) for x in rng.integers(20, max(21, span - 20), size=nfr - 1)]))
+                shift = 0
+                for i in range(len(cuts) - 1):
+                    a, b = cuts[i], cuts[i + 1]
+                    gapq = int(rng.choice([0, 0, 5, 150, 199, 200, 260])) if i else 0
+                    shift += int(rng.choice([0, 0, 3, -3, 120, 199, 200, 230])) if i else 0
+                    fs, fe = q0 + a + (5 if gapq else 0), q0 + b - 1
+                    if fe <= fs:
+                        continue
+                    if not rev:
+                        ss_, se_ = pos + a + shift, pos + b - 1 + shift
+                    else:
+                        ss_, se_ = pos + span - a + shift, pos + span - b + 1 + shift
+                    ident = float(rng.choice([100.0, 98.5, 91.25]))
+                    rows.append((q, s, fs, fe, ss_, se_, ident))
+                    if rng.random() < 0.08:
+                        rows.append((q, s, fs, fe, ss_, se_, ident))              # exact duplicate line
+                    if rng.random() < 0.08:
+                        rows.append((q, s, fs + 3, fe, ss_ + (3 if not rev else -3), se_, 97.0))   # overlapping HSP
+        order = rng.permutation(len(rows))
+        rows = [rows[i] for i in order]
+        qnames = ["TE_%d" % q for q in range(nq)]
+        snames = ["chr%d" % s for s in range(ns)]
+        recs = {}
+        for (q, s, a, b, c, d, idt) in rows:
+            recs.setdefault(qnames[q], {}).setdefault(snames[s], []).append((a, b, c, d, idt))
+        qcov = float(rng.choice([0.95, 0.8, 0.5]))
+        qc = {qnames[q]: "A" * qlen[q] for q in range(nq)}
+        if scov > 0:        # the reference's subject coverage divides by the length of the SUBJECT contig (Util.py:7010)
+            spath = os.path.join(tmp, "qc_subj_%d.fa" % ci)
+            with open(spath, "w") as fh:
+                for s_ in range(ns):
+                    fh.write(">%s\n%s\n" % (snames[s_], "A" * slen[s_]))
+        else:
+            spath = None
+        res = U.get_query_copies(list(recs.items()), qc, spath, qcov, scov)
+        cases.append({"rows": [[int(x) for x in r[:6]] + [float(r[6])] for r in rows], "qlen": qlen, "slen": slen, "qcov": qcov, "scov": scov,
+                      "out": {k: [[c[0], int(c[1]), int(c[2]), int(c[3]), c[4]] for c in v] for k, v in res.items()}})
+    dump("query_copies", cases)
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -472,6 +533,8 @@ def main():
             gen_ltr_frame(tmp)
         if "nonltr" in which:
             gen_nonltr_prep(U)
+        if "qcopies" in which:
+            gen_query_copies(U, tmp)
 
 
 if __name__ == "__main__":

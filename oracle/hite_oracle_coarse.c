@@ -453,3 +453,158 @@ int orc_tir_kmer(const uint8_t *seq, int64_t n, int64_t raw_start, int64_t raw_e
     free(rec);
     return m;
 }
+
+/* ===================================================================================================
+ * get_query_copies  /root/reference/module/Util.py:6828-7030 (input built by get_copies_v1 :7032-7060):
+ * copy clustering on a blast6 HSP table (the blastn route of copy finding).
+ * HSPs arrive in file order with dense ids: qid = rank of first appearance of the query name, sid = id of the
+ * subject name; the subject dict of a query iterates in first-appearance order.
+ * =================================================================================================== */
+typedef struct { int64_t qs, qe, ss, se; double id; int64_t ord; } qc_frag;
+static int qc_cmp_fwd(const void *a, const void *b) {   /* sort(key = (x[2], x[3])), stable */
+    const qc_frag *x = (const qc_frag *)a, *y = (const qc_frag *)b;
+    if (x->ss != y->ss) return x->ss < y->ss ? -1 : 1;
+    if (x->se != y->se) return x->se < y->se ? -1 : 1;
+    return x->ord < y->ord ? -1 : (x->ord > y->ord);
+}
+static int qc_cmp_rev(const void *a, const void *b) {   /* sort(key = (-x[2], -x[3])), stable */
+    const qc_frag *x = (const qc_frag *)a, *y = (const qc_frag *)b;
+    if (x->ss != y->ss) return x->ss > y->ss ? -1 : 1;
+    if (x->se != y->se) return x->se > y->se ? -1 : 1;
+    return x->ord < y->ord ? -1 : (x->ord > y->ord);
+}
+static int qc_cmp_q(const void *a, const void *b) {     /* sort(key = (x[0], x[1])), stable */
+    const qc_frag *x = (const qc_frag *)a, *y = (const qc_frag *)b;
+    if (x->qs != y->qs) return x->qs < y->qs ? -1 : 1;
+    if (x->qe != y->qe) return x->qe < y->qe ? -1 : 1;
+    return x->ord < y->ord ? -1 : (x->ord > y->ord);
+}
+static int qc_same(const qc_frag *a, const qc_frag *b) {
+    return a->qs == b->qs && a->qe == b->qe && a->ss == b->ss && a->se == b->se && a->id == b->id;
+}
+typedef struct { int64_t qstart, qend, qlen, sstart, send, slen; int32_t sid; int64_t ord; } qc_long;
+static int qc_cmp_long(const void *a, const void *b) {  /* sort(key = -x[2]), stable */
+    const qc_long *x = (const qc_long *)a, *y = (const qc_long *)b;
+    if (x->qlen != y->qlen) return x->qlen > y->qlen ? -1 : 1;
+    return x->ord < y->ord ? -1 : (x->ord > y->ord);
+}
+
+/* one cluster (already sorted by (qs, qe)): the longest chain, Util.py:6900-6990.  returns 0 if the cluster is empty */
+static int qc_cluster_best(qc_frag *cl, int n, int rev, int64_t qthr, int64_t sthr, qc_long *out) {
+    if (n <= 0) return 0;
+    uint8_t *vis = (uint8_t *)calloc(n, 1);
+    int64_t best_len = -1;
+    for (int i = 0; i < n; i++) {
+        /* visited_frag is keyed by the tuple VALUE: a duplicate of a visited fragment is visited */
+        int v = vis[i];
+        for (int t = 0; !v && t < n; t++) if (vis[t] && qc_same(&cl[t], &cl[i])) v = 1;
+        if (v) continue;
+        int64_t cur_len = cl[i].qe - cl[i].qs + 1, lqs = cl[i].qs, lqe = cl[i].qe, lss = cl[i].ss, lse = cl[i].se;
+        vis[i] = 1;
+        for (int j = i + 1; j < n; j++) {
+            int vj = vis[j];
+            for (int t = 0; !vj && t < n; t++) if (vis[t] && qc_same(&cl[t], &cl[j])) vj = 1;
+            if (vj) continue;
+            const qc_frag *e = &cl[j];
+            if (e->qe > lqe) {
+                if (lss < lse && e->ss < e->se) {                     /* forward */
+                    if (e->se > lse) {
+                        if (e->qs - lqe < qthr && e->ss - lse < sthr) {
+                            lqe = e->qe; lss = lss < e->ss ? lss : e->ss; lse = e->se; cur_len = lqe - lqs; vis[j] = 1;
+                        } else if (e->qs - lqe >= qthr) break;
+                    }
+                } else if (lss > lse && e->ss > e->se) {              /* reverse */
+                    if (e->se < lse) {
+                        if (e->qs - lqe < qthr && lse - e->ss < sthr) {
+                            lqe = e->qe; lss = lss > e->ss ? lss : e->ss; lse = e->se; cur_len = lqe - lqs; vis[j] = 1;
+                        } else if (e->qs - lqe >= qthr) break;
+                    }
+                }
+            }
+        }
+        if (cur_len > best_len) {
+            best_len = cur_len;
+            out->qstart = lqs; out->qend = lqe; out->qlen = cur_len; out->sstart = lss; out->send = lse;
+            out->slen = (lse > lss ? lse - lss : lss - lse) + 1;
+        }
+    }
+    free(vis);
+    (void)rev;
+    return best_len != -1;
+}
+
+/*
+ * n HSPs in file order; qid / sid dense ids; qlen[nq], slen[ns] (slen may be NULL when scov <= 0).
+ * Output CSR copy_first[nq + 1] into (sid, start, end (start <= end), chain length, minus); returns total or -1001 (cap).
+ */
+int64_t orc_query_copies(int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe, const int64_t *ss,
+                         const int64_t *se, const double *ident, int nq, const int64_t *qlen, int ns, const int64_t *slen,
+                         double qcov, double scov, int64_t qthr, int64_t sthr, int max_copy, int64_t cap, int32_t *copy_first,
+                         int32_t *o_sid, int64_t *o_s, int64_t *o_e, int64_t *o_len, uint8_t *o_minus) {
+    int64_t nout = 0;
+    int64_t *idx = (int64_t *)malloc(sizeof(int64_t) * (n + 1));
+    qc_frag *fr = (qc_frag *)malloc(sizeof(qc_frag) * (n + 1));
+    qc_long *lq = (qc_long *)malloc(sizeof(qc_long) * (n + 1));
+    int32_t *sorder = (int32_t *)malloc(sizeof(int32_t) * (ns + 1));
+    uint8_t *sseen = (uint8_t *)malloc(ns + 1);
+    copy_first[0] = 0;
+    for (int q = 0; q < nq; q++) {
+        /* HSPs of this query in file order, subjects in first-appearance order */
+        int64_t m = 0;
+        for (int64_t i = 0; i < n; i++) if (qid[i] == q) idx[m++] = i;
+        int nso = 0;
+        for (int s = 0; s < ns; s++) sseen[s] = 0;
+        for (int64_t t = 0; t < m; t++) { int s = sid[idx[t]]; if (!sseen[s]) { sseen[s] = 1; sorder[nso++] = s; } }
+        int64_t nl = 0;
+        for (int so = 0; so < nso; so++) {
+            const int s = sorder[so];
+            for (int rev = 0; rev < 2; rev++) {
+                int64_t k = 0;
+                for (int64_t t = 0; t < m; t++) {
+                    const int64_t i = idx[t];
+                    if (sid[i] != s) continue;
+                    if ((ss[i] > se[i]) != rev) continue;          /* pos_item[2] > pos_item[3] -> reverse */
+                    fr[k].qs = qs[i]; fr[k].qe = qe[i]; fr[k].ss = ss[i]; fr[k].se = se[i]; fr[k].id = ident[i]; fr[k].ord = k; k++;
+                }
+                if (k == 0) continue;
+                qsort(fr, k, sizeof(qc_frag), rev ? qc_cmp_rev : qc_cmp_fwd);
+                /* closed clusters: a fragment joins the current cluster if ANY member is close on the subject and ends
+                 * earlier on the query (:6856-6893) */
+                int64_t cs = 0;   /* start of the current cluster */
+                for (int64_t t = 0; t <= k; t++) {
+                    int close_ = 0;
+                    if (t < k && t > cs)
+                        for (int64_t u = t - 1; u >= cs && !close_; u--)
+                            close_ = rev ? (fr[u].se - fr[t].ss < sthr && fr[t].qe > fr[u].qe) : (fr[t].ss - fr[u].se < sthr && fr[t].qe > fr[u].qe);
+                    if (t == k || (t > cs && !close_)) {
+                        /* cluster [cs, t): sort by (qs, qe), pick the longest chain */
+                        for (int64_t u = cs; u < t; u++) fr[u].ord = u;
+                        qsort(fr + cs, t - cs, sizeof(qc_frag), qc_cmp_q);
+                        qc_long L;
+                        if (qc_cluster_best(fr + cs, (int)(t - cs), rev, qthr, sthr, &L)) { L.sid = s; L.ord = nl; lq[nl++] = L; }
+                        cs = t;
+                    }
+                }
+            }
+        }
+        qsort(lq, nl, sizeof(qc_long), qc_cmp_long);
+        int64_t first = nout;
+        for (int64_t t = 0; t < nl; t++) {
+            if (nout - first > max_copy) break;                       /* len(copies) > max_copy_num */
+            int64_t a = lq[t].sstart, b = lq[t].send;
+            int minus = 0;
+            if (a > b) { int64_t x = a; a = b; b = x; minus = 1; }
+            int dup = 0;
+            for (int64_t u = first; u < nout && !dup; u++) dup = o_sid[u] == lq[t].sid && o_s[u] == a && o_e[u] == b;
+            int ok = (double)lq[t].qlen / (double)qlen[q] >= qcov && !dup;
+            if (scov > 0) ok = ok && (double)lq[t].slen / (double)slen[lq[t].sid] >= scov;
+            if (!ok) continue;
+            if (nout >= cap) { free(idx); free(fr); free(lq); free(sorder); free(sseen); return -1001; }
+            o_sid[nout] = lq[t].sid; o_s[nout] = a; o_e[nout] = b; o_len[nout] = lq[t].qlen; o_minus[nout] = (uint8_t)minus;
+            nout++;
+        }
+        copy_first[q + 1] = (int32_t)nout;
+    }
+    free(idx); free(fr); free(lq); free(sorder); free(sseen);
+    return nout;
+}

@@ -280,3 +280,28 @@ def search_polyA_TSD(seq, flank=50, win5=25):
         comp = {"A": "T", "T": "A", "C": "G", "G": "C"}
         nl = "".join(comp.get(c, "N") for c in reversed(nl))
     return bool(found), s[ts:ts + tn] if found else "", nl
+
+
+def query_copies(rows, qlen, slen, qcov, scov=0.0, qthr=200, sthr=200, max_copy=100):
+    """get_query_copies: rows = (query id, subject id, qs, qe, ss, se, identity) in file order, query ids dense by first
+    appearance -> per query list of (subject id, start, end, chain length, '+'/'-')"""
+    n = len(rows)
+    qid = np.array([r[0] for r in rows], dtype=np.int32); sid = np.array([r[1] for r in rows], dtype=np.int32)
+    a = lambda k: np.array([r[k] for r in rows], dtype=np.int64)  # noqa: E731
+    qs, qe, ss, se = a(2), a(3), a(4), a(5)
+    idt = np.array([r[6] for r in rows], dtype=np.float64)
+    ql = np.array(qlen, dtype=np.int64); sl = np.array(slen, dtype=np.int64)
+    nq = len(qlen)
+    cap = n + 16
+    cf = np.zeros(nq + 1, dtype=np.int32)
+    osid = np.zeros(cap, dtype=np.int32); os_ = np.zeros(cap, dtype=np.int64); oe = np.zeros(cap, dtype=np.int64)
+    ol = np.zeros(cap, dtype=np.int64); om = np.zeros(cap, dtype=np.uint8)
+    L = lib()
+    L.orc_query_copies.restype = C.c_int64
+    dp = C.POINTER(C.c_double)
+    tot = L.orc_query_copies(C.c_int64(n), _ptr(qid, i32p), _ptr(sid, i32p), _ptr(qs, i64p), _ptr(qe, i64p), _ptr(ss, i64p), _ptr(se, i64p),
+                             idt.ctypes.data_as(dp), nq, _ptr(ql, i64p), len(slen), _ptr(sl, i64p), C.c_double(qcov), C.c_double(scov),
+                             C.c_int64(qthr), C.c_int64(sthr), int(max_copy), C.c_int64(cap), _ptr(cf, i32p), _ptr(osid, i32p),
+                             _ptr(os_, i64p), _ptr(oe, i64p), _ptr(ol, i64p), _ptr(om, u8p))
+    assert tot >= 0, tot
+    return [[(int(osid[i]), int(os_[i]), int(oe[i]), int(ol[i]), "-" if om[i] else "+") for i in range(cf[q], cf[q + 1])] for q in range(nq)]

@@ -201,3 +201,27 @@ def test_nonltr_prep_golden():
         assert list(got) == [c["found"], c["tsd"], c["non_ltr"]], (c["seq"][:60], got, (c["found"], c["tsd"], c["non_ltr"][:40]))
         kinds.add((c["found"], bool(c["non_ltr"])))
     assert len(kinds) == 3
+
+
+def _query_copies_case(c):
+    """golden case -> (rows with dense first-appearance query ids, qlen in that order, expected per query)"""
+    order, rows = {}, []
+    for r in c["rows"]:
+        q = order.setdefault(r[0], len(order))
+        rows.append((q, r[1], r[2], r[3], r[4], r[5], r[6]))
+    qlen = [0] * len(order)
+    for orig, q in order.items():
+        qlen[q] = c["qlen"][orig]
+    exp = [[(int(x[0][3:]), x[1], x[2], x[3], x[4]) for x in c["out"].get("TE_%d" % orig, [])] for orig, q in sorted(order.items(), key=lambda kv: kv[1])]
+    return rows, qlen, exp
+
+
+def test_query_copies_golden():
+    """get_query_copies restatement (blastn-route copy clustering) vs the reference's outputs"""
+    g = load_golden("query_copies")
+    total = 0
+    for c in g:
+        rows, qlen, exp = _query_copies_case(c)
+        assert O.query_copies(rows, qlen, c["slen"], c["qcov"], c["scov"]) == exp
+        total += sum(len(e) for e in exp)
+    assert total > 100
