@@ -364,6 +364,32 @@ class Context:
         self._check(rc, "hite_find_copies_dev")
         return (n.value,) + tuple(o.value or 0 for o in outs)
 
+    def query_copies(self, qid, sid, qs, qe, ss, se, ident, qlen, slen=None, ns=None, qcov=0.95, scov=0.0, qthr=200, sthr=200, max_copy=100):
+        """get_query_copies on an HSP table in file order -> per query list of (subject id, start, end, chain length, '+'/'-')"""
+        n = len(qid)
+        a = lambda x, t: _arr(x, t)  # noqa: E731
+        qid, sid = a(qid, np.int32), a(sid, np.int32)
+        qs, qe, ss, se = a(qs, np.int64), a(qe, np.int64), a(ss, np.int64), a(se, np.int64)
+        ident = a(ident, np.float64) if ident is not None else None
+        qlen = a(qlen, np.int64)
+        nq = len(qlen)
+        slen = a(slen, np.int64) if slen is not None else None
+        if ns is None:
+            ns = len(slen) if slen is not None else (int(sid.max()) + 1 if n else 1)
+        cap = (max_copy + 1) * nq + 16
+        cf = np.zeros(nq + 1, dtype=np.int64)
+        osid = np.zeros(cap, dtype=np.int32)
+        os_, oe, ol = (np.zeros(cap, dtype=np.int64) for _ in range(3))
+        om = np.zeros(cap, dtype=np.uint8)
+        nout = C.c_int64(0)
+        self._check(self.lib.hite_query_copies(self.h, C.c_int64(n), _p(qid), _p(sid), _p(qs), _p(qe), _p(ss), _p(se),
+                                               _p(ident) if ident is not None else None, nq, _p(qlen), int(ns),
+                                               _p(slen) if slen is not None else None, C.c_double(qcov), C.c_double(scov), C.c_int64(qthr),
+                                               C.c_int64(sthr), int(max_copy), C.c_int64(cap), _p(cf), _p(osid), _p(os_), _p(oe), _p(ol),
+                                               _p(om), C.byref(nout)), "hite_query_copies")
+        return [[(int(osid[i]), int(os_[i]), int(oe[i]), int(ol[i]), "-" if om[i] else "+") for i in range(cf[q], cf[q + 1])]
+                for q in range(nq)]
+
     def nonltr_prep(self, seqs, flank=50, win5=25):
         """search_polyA_TSD on a batch -> [(found_TSD, direct, tsd_start, tsd_len, lo, hi)]"""
         sb = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]

@@ -128,13 +128,13 @@ __global__ void fm_gather_key_kernel(int64_t m, const unsigned *__restrict__ val
 __global__ void __launch_bounds__(256) fm_cluster_kernel(int64_t nslots, const int64_t *__restrict__ slot_start,
                                                          const unsigned *__restrict__ order /* HSP idx, sorted */,
                                                          const int64_t *__restrict__ qe, const int64_t *__restrict__ ss,
-                                                         const int64_t *__restrict__ se, int64_t gap, int32_t *__restrict__ clid,
-                                                         int32_t *__restrict__ ncl) {
+                                                         const int64_t *__restrict__ se, int64_t gap, int parity_rev,
+                                                         int32_t *__restrict__ clid, int32_t *__restrict__ ncl) {
     const int lane = threadIdx.x & 63;
     for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < nslots; g += (int64_t)gridDim.x * 4) {
         const int64_t b = slot_start[g], e = slot_start[g + 1];
         if (e <= b) { if (lane == 0) ncl[g] = 0; continue; }
-        const bool rev = g & 1;
+        const bool rev = parity_rev ? (bool)(g & 1) : (ss[order[b]] > se[order[b]]);
         int cl = 0;
         int64_t cstart = b;
         if (lane == 0) clid[b] = 0;
@@ -474,7 +474,7 @@ static int fmea_impl(hite_ctx *ctx, int64_t n, const int32_t *qseg, const int32_
     {
         int64_t blocks = (nslots + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(fm_cluster_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nslots, (int64_t *)dslotstart.p, (unsigned *)dval.p,
-                           (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, skip_gap, (int32_t *)dclid.p, (int32_t *)dncl.p);
+                           (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, skip_gap, 1, (int32_t *)dclid.p, (int32_t *)dncl.p);
     }
     if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)dncl.p, nslots, (int64_t *)dclbase.p, st)) { sorter_free(S); return HITE_EHIP; }
     int64_t ncl = 0;
@@ -563,4 +563,320 @@ extern "C" int hite_fmea_chain_dev(hite_ctx *ctx, int64_t n, const int32_t *d_qs
                                    int64_t *out_start, int64_t *out_end, int64_t *n_out) {
     return fmea_impl(ctx, n, d_qseg, d_sseg, d_qs, d_qe, d_ss, d_se, true, nseg, seg_chrom, seg_off, skip_gap, max_len, cap, out_chrom,
                      out_start, out_end, n_out);
+}
+
+
+// =============================================================================================
+// get_query_copies (/root/reference/module/Util.py:6828-7030): copy clustering of a blast6 HSP table, the
+// blastn route of copy finding.  Same sort / sweep / chain shape as FMEA above:
+//   1  first appearance of every (query, subject) pair: stable sort by pair, head of each run        [:6836-6848]
+//   2  stable LSD sorts by s_end key, strand | s_start key, (query | first appearance)  -> slots      [:6850-6854]
+//   3  cluster sweep, one wavefront per slot (fm_cluster_kernel, strand read from the data)          [:6856-6893]
+//   4  stable sorts by q_end, q_start, cluster                                                        [:6900]
+//   5  one thread per cluster: greedy chains, keep the longest (first on ties)                        [:6902-6990]
+//   6  stable sort of the cluster bests by (query | length desc)                                      [:7000]
+//   7  one wavefront per query: coverage test on 64 bests at a time, then in order: stop after
+//      max_copy + 1, de-duplicate on (subject, start, end) against the kept ones held in LDS          [:7005-7028]
+// =============================================================================================
+#define QC_MAXKEEP 256
+
+struct QBest { long long qlen, ss, se; int sid, qid; };
+
+__global__ void qc_check_kernel(int64_t n, const int32_t *__restrict__ qid, const int32_t *__restrict__ sid,
+                                const int64_t *__restrict__ qs, const int64_t *__restrict__ qe, const int64_t *__restrict__ ss,
+                                const int64_t *__restrict__ se, int nq, int ns, unsigned long long *__restrict__ gk,
+                                unsigned *__restrict__ val, int *__restrict__ err) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int q = qid[i], s = sid[i];
+    bool bad = q < 0 || q >= nq || s < 0 || s >= ns || qs[i] < 0 || qe[i] < 0 || ss[i] < 0 || se[i] < 0 || qs[i] >= 0x7fffffff ||
+               qe[i] >= 0x7fffffff || ss[i] >= 0x7fffffff || se[i] >= 0x7fffffff;
+    if (bad) { atomicExch(err, 1); q = 0; s = 0; }
+    gk[i] = (unsigned long long)q * (unsigned long long)ns + (unsigned long long)s;
+    val[i] = (unsigned)i;
+}
+__global__ void qc_head_kernel(int64_t n, const unsigned long long *__restrict__ k, int32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = i == 0 || k[i] != k[i - 1];
+}
+// f[hsp] = original index of the first HSP of its (query, subject) run (run id = exclusive scan of the head flags)
+__global__ void qc_run_first_kernel(int64_t n, const int32_t *__restrict__ flag, const int64_t *__restrict__ pos,
+                                    const unsigned *__restrict__ val, unsigned *__restrict__ gfirst) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) gfirst[pos[i]] = val[i];
+}
+__global__ void qc_first_kernel(int64_t n, const int32_t *__restrict__ flag, const int64_t *__restrict__ pos,
+                                const unsigned *__restrict__ val, const unsigned *__restrict__ gfirst, unsigned *__restrict__ f) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) f[val[i]] = gfirst[pos[i] + flag[i] - 1];
+}
+__global__ void qc_keys_kernel(int64_t n, const int32_t *__restrict__ qid, const int64_t *__restrict__ ss, const int64_t *__restrict__ se,
+                               const unsigned *__restrict__ f, unsigned long long *__restrict__ k_e, unsigned long long *__restrict__ k_s,
+                               unsigned long long *__restrict__ k_g, unsigned *__restrict__ val) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool rev = ss[i] > se[i];                                                // :6851
+    unsigned sk = rev ? (unsigned)(0x7fffffff - (int)ss[i]) : (unsigned)ss[i];     // (-ss, -se) order for reverse  :6854
+    unsigned ek = rev ? (unsigned)(0x7fffffff - (int)se[i]) : (unsigned)se[i];
+    k_e[i] = ek;
+    k_s[i] = ((unsigned long long)(rev ? 1 : 0) << 31) | sk;
+    k_g[i] = ((unsigned long long)qid[i] << 31) | f[i];
+    val[i] = (unsigned)i;
+}
+// slot heads in the fully sorted order: (query | first appearance) or the strand changes
+__global__ void qc_slot_head_kernel(int64_t n, const unsigned long long *__restrict__ kg, const unsigned *__restrict__ order,
+                                    const int64_t *__restrict__ ss, const int64_t *__restrict__ se, int32_t *__restrict__ flag) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool h = i == 0 || kg[i] != kg[i - 1];
+    if (!h) { unsigned a = order[i], b = order[i - 1]; h = (ss[a] > se[a]) != (ss[b] > se[b]); }
+    flag[i] = h;
+}
+// starts[id] = i for every head; id = exclusive scan of the flags
+__global__ void qc_starts_kernel(int64_t n, const int32_t *__restrict__ flag, const int64_t *__restrict__ pos, int64_t *__restrict__ starts) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (flag[i]) starts[pos[i]] = i;
+    if (i == n - 1) starts[pos[n]] = n;
+}
+__global__ void qc_ckeys_kernel(int64_t m, const unsigned *__restrict__ order, const int32_t *__restrict__ sflag,
+                                const int64_t *__restrict__ spos, const int32_t *__restrict__ clid, const int64_t *__restrict__ cl_base,
+                                const int64_t *__restrict__ qs, const int64_t *__restrict__ qe, unsigned long long *__restrict__ k_qe,
+                                unsigned long long *__restrict__ k_qs, unsigned long long *__restrict__ k_cl, int32_t *__restrict__ cl_cnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    unsigned h = order[i];
+    long long slot = spos[i] + sflag[i] - 1;
+    long long g = cl_base[slot] + clid[i];
+    k_qe[i] = (unsigned long long)qe[h];
+    k_qs[i] = (unsigned long long)qs[h];
+    k_cl[i] = (unsigned long long)g;
+    atomicAdd(&cl_cnt[g], 1);
+}
+
+// step 5: one thread per cluster, the longest chain  (Util.py:6902-6990)
+__global__ void qc_chain_kernel(int64_t ncl, const int64_t *__restrict__ cl_start, const unsigned *__restrict__ order,
+                                const int32_t *__restrict__ qid, const int32_t *__restrict__ sid, const int64_t *__restrict__ qs,
+                                const int64_t *__restrict__ qe, const int64_t *__restrict__ ss, const int64_t *__restrict__ se,
+                                const double *__restrict__ ident, int64_t qthr, int64_t sthr, uint8_t *__restrict__ vis,
+                                int32_t *__restrict__ canon, QBest *__restrict__ best, unsigned long long *__restrict__ lkey,
+                                unsigned *__restrict__ lval, int32_t *__restrict__ qcount) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncl) return;
+    const int64_t b = cl_start[c], e = cl_start[c + 1];
+    // visited_frag is keyed by the tuple value (q_start, q_end, s_start, s_end, identity): equal tuples alias
+    for (int64_t i = b; i < e; i++) {
+        vis[i] = 0;
+        int32_t cn = (int32_t)(i - b);
+        unsigned hi = order[i];
+        for (int64_t j = i - 1; j >= b; j--) {
+            unsigned hj = order[j];
+            if (qs[hj] != qs[hi] || qe[hj] != qe[hi]) break;
+            if (ss[hj] == ss[hi] && se[hj] == se[hi] && (!ident || ident[hj] == ident[hi])) cn = canon[j];
+        }
+        canon[i] = cn;
+    }
+    long long best_len = -1, bss = 0, bse = 0;
+    for (int64_t i = b; i < e; i++) {
+        if (vis[b + canon[i]]) continue;
+        unsigned hi = order[i];
+        long long lqs = qs[hi], lqe = qe[hi], lss = ss[hi], lse = se[hi];
+        long long cur = lqe - lqs + 1;                                                             // :6909
+        vis[b + canon[i]] = 1;
+        for (int64_t j = i + 1; j < e; j++) {
+            if (vis[b + canon[j]]) continue;
+            unsigned hj = order[j];
+            long long cqs = qs[hj], cqe = qe[hj], css = ss[hj], cse = se[hj];
+            if (cqe > lqe) {
+                if (lss < lse && css < cse) {
+                    if (cse > lse) {
+                        if (cqs - lqe < qthr && css - lse < sthr) { lqe = cqe; lss = lss < css ? lss : css; lse = cse; cur = lqe - lqs; vis[b + canon[j]] = 1; }
+                        else if (cqs - lqe >= qthr) break;
+                    }
+                } else if (lss > lse && css > cse) {
+                    if (cse < lse) {
+                        if (cqs - lqe < qthr && lse - css < sthr) { lqe = cqe; lss = lss > css ? lss : css; lse = cse; cur = lqe - lqs; vis[b + canon[j]] = 1; }
+                        else if (cqs - lqe >= qthr) break;
+                    }
+                }
+            }
+        }
+        if (cur > best_len) { best_len = cur; bss = lss; bse = lse; }
+    }
+    const unsigned h0 = order[b];
+    QBest r; r.qlen = best_len; r.ss = bss; r.se = bse; r.sid = sid[h0]; r.qid = qid[h0];
+    best[c] = r;
+    lkey[c] = ((unsigned long long)r.qid << 32) | (unsigned long long)(0x7fffffffll - best_len);    // sort(key = -x[2]) per query  :7000; |len| < 2^31
+    lval[c] = (unsigned)c;
+    atomicAdd(&qcount[r.qid], 1);
+}
+
+// step 7: one wavefront per query
+template <bool WRITE>
+__global__ void __launch_bounds__(256) qc_select_kernel(int nq, const int64_t *__restrict__ qstart, const unsigned *__restrict__ cidx,
+                                                        const QBest *__restrict__ best, const int64_t *__restrict__ qlen,
+                                                        const int64_t *__restrict__ slen, double qcov, double scov, int max_copy,
+                                                        int32_t *__restrict__ count, const int64_t *__restrict__ first,
+                                                        int32_t *__restrict__ o_sid, int64_t *__restrict__ o_s, int64_t *__restrict__ o_e,
+                                                        int64_t *__restrict__ o_len, uint8_t *__restrict__ o_minus) {
+    __shared__ int s_sid[4][QC_MAXKEEP];
+    __shared__ long long s_a[4][QC_MAXKEEP], s_b[4][QC_MAXKEEP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int q = blockIdx.x * 4 + w;
+    if (q >= nq) return;
+    const int64_t b = qstart[q], e = qstart[q + 1];
+    const double ql = (double)qlen[q];
+    const int64_t o0 = WRITE ? first[q] : 0;
+    int cnt = 0;
+    for (int64_t base = b; base < e && cnt <= max_copy; base += 64) {
+        const int64_t i = base + lane;
+        bool pass = false;
+        int rsid = 0; long long ra = 0, rb = 0, rl = 0; int rminus = 0;
+        if (i < e) {
+            const QBest r = best[cidx[i]];
+            rsid = r.sid; rl = r.qlen;
+            rminus = r.ss > r.se;                                                                  // :7012
+            ra = rminus ? r.se : r.ss; rb = rminus ? r.ss : r.se;
+            pass = (double)r.qlen / ql >= qcov;                                                    // :7021 / :7025
+            if (scov > 0) pass = pass && (double)(rb - ra + 1) / (double)slen[rsid] >= scov;      // :7019-7021
+        }
+        unsigned long long mask = __ballot(pass);
+        while (mask && cnt <= max_copy) {                                                          // len(copies) > max_copy_num: break  :7006
+            const int l = __ffsll((long long)mask) - 1;
+            mask &= mask - 1;
+            const int xs = __shfl(rsid, l); const long long xa = __shfl(ra, l), xb = __shfl(rb, l), xl = __shfl(rl, l);
+            const int xm = __shfl(rminus, l);
+            bool dup = false;
+            for (int t = lane; t < cnt; t += 64) dup |= s_sid[w][t] == xs && s_a[w][t] == xa && s_b[w][t] == xb;
+            if (__ballot(dup)) continue;                                                           // item in keeped_copies
+            if (lane == 0) {
+                s_sid[w][cnt] = xs; s_a[w][cnt] = xa; s_b[w][cnt] = xb;
+                if (WRITE) { o_sid[o0 + cnt] = xs; o_s[o0 + cnt] = xa; o_e[o0 + cnt] = xb; o_len[o0 + cnt] = xl; o_minus[o0 + cnt] = (uint8_t)xm; }
+            }
+            cnt++;
+        }
+    }
+    if (!WRITE && lane == 0) count[q] = cnt;
+}
+
+#define QSORT(k, v, cnt, bits) do { if (sorter_sort(S, (unsigned long long *)(k), (unsigned *)(v), (cnt), (bits))) { sorter_free(S); return HITE_EHIP; } } while (0)
+#define QSCAN(in, cnt, out) do { if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)(in), (cnt), (int64_t *)(out), st)) { sorter_free(S); return HITE_EHIP; } } while (0)
+
+extern "C" int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe,
+                                 const int64_t *ss, const int64_t *se, const double *ident, int32_t nq, const int64_t *qlen, int32_t ns,
+                                 const int64_t *slen, double qcov, double scov, int64_t qthr, int64_t sthr, int32_t max_copy, int64_t cap,
+                                 int64_t *copy_first, int32_t *o_sid, int64_t *o_s, int64_t *o_e, int64_t *o_len, uint8_t *o_minus,
+                                 int64_t *n_out) {
+    if (!ctx || n < 0 || n >= 0x7fffffff || nq <= 0 || ns <= 0 || !qlen || !copy_first || !n_out || max_copy < 0 || max_copy > QC_MAXKEEP - 2 ||
+        (scov > 0 && !slen) || (double)nq * (double)ns >= 1e12)
+        return HITE_EINVAL;
+    *n_out = 0;
+    for (int q = 0; q <= nq; q++) copy_first[q] = 0;
+    if (n == 0) return HITE_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HITE_EHIP;
+    hipStream_t st = nullptr;
+    Sorter S;
+    FBuf dq, dsg, dqs, dqe, dss, dse, did, dql, dsl, derr, dbs, dgk, dval, dflag, dpos, df, dke, dks, dkg, dtmpk, dslotstart, dclid, dncl, dclbase,
+        dkqe, dkqs, dkcl, dclcnt, dclstart, dp2, dorder2, dvis, dcanon, dbest, dlkey, dlval, dqcount, dqstart, dcount, dfirst, dos, doa, dob, dol, dom, dgf;
+    FCHK(dq.up(qid, n * 4)); FCHK(dsg.up(sid, n * 4)); FCHK(dqs.up(qs, n * 8)); FCHK(dqe.up(qe, n * 8)); FCHK(dss.up(ss, n * 8));
+    FCHK(dse.up(se, n * 8)); FCHK(dql.up(qlen, (size_t)nq * 8));
+    if (ident) FCHK(did.up(ident, n * 8));
+    if (slen) FCHK(dsl.up(slen, (size_t)ns * 8));
+    const int64_t scan_n = (n > nq ? n : nq) + 16;
+    FCHK(derr.alloc(16)); FCHK(dbs.alloc((size_t)scan_tmp_elems(scan_n) * 8)); FCHK(dgk.alloc((n + 1) * 8)); FCHK(dval.alloc((n + 1) * 4));
+    FCHK(dflag.alloc((n + 1) * 4)); FCHK(dpos.alloc((n + 2) * 8)); FCHK(df.alloc((n + 1) * 4)); FCHK(dke.alloc((n + 1) * 8));
+    FCHK(dks.alloc((n + 1) * 8)); FCHK(dkg.alloc((n + 1) * 8)); FCHK(dtmpk.alloc((n + 1) * 8)); FCHK(dgf.alloc((n + 1) * 4));
+    FCHK(hipMemset(derr.p, 0, 16));
+    if (sorter_init(S, ctx, st, n)) { sorter_free(S); return HITE_EHIP; }
+    // 1: first appearance of every (query, subject) pair
+    hipLaunchKernelGGL(qc_check_kernel, GRID(n), 0, st, n, (int32_t *)dq.p, (int32_t *)dsg.p, (int64_t *)dqs.p, (int64_t *)dqe.p, (int64_t *)dss.p,
+                       (int64_t *)dse.p, nq, ns, (unsigned long long *)dgk.p, (unsigned *)dval.p, (int *)derr.p);
+    int herr = 0;
+    FCHK(hipMemcpy(&herr, derr.p, 4, hipMemcpyDeviceToHost));
+    if (herr) { sorter_free(S); return HITE_EINVAL; }   // id or coordinate out of range
+    int pair_bits = 1; while ((1ull << pair_bits) < (unsigned long long)nq * (unsigned long long)ns + 1) pair_bits++;
+    QSORT(dgk.p, dval.p, n, pair_bits);
+    hipLaunchKernelGGL(qc_head_kernel, GRID(n), 0, st, n, (unsigned long long *)dgk.p, (int32_t *)dflag.p);
+    QSCAN(dflag.p, n, dpos.p);
+    hipLaunchKernelGGL(qc_run_first_kernel, GRID(n), 0, st, n, (int32_t *)dflag.p, (int64_t *)dpos.p, (unsigned *)dval.p, (unsigned *)dgf.p);
+    hipLaunchKernelGGL(qc_first_kernel, GRID(n), 0, st, n, (int32_t *)dflag.p, (int64_t *)dpos.p, (unsigned *)dval.p, (unsigned *)dgf.p,
+                       (unsigned *)df.p);
+    // 2: slots = (query, subject by first appearance, strand), sorted by strand-aware (s_start, s_end)
+    hipLaunchKernelGGL(qc_keys_kernel, GRID(n), 0, st, n, (int32_t *)dq.p, (int64_t *)dss.p, (int64_t *)dse.p, (unsigned *)df.p,
+                       (unsigned long long *)dke.p, (unsigned long long *)dks.p, (unsigned long long *)dkg.p, (unsigned *)dval.p);
+    QSORT(dke.p, dval.p, n, 32);
+    hipLaunchKernelGGL(fm_permute_u64_kernel, GRID(n), 0, st, n, (unsigned *)dval.p, (unsigned long long *)dks.p, (unsigned long long *)dtmpk.p);
+    QSORT(dtmpk.p, dval.p, n, 32);
+    hipLaunchKernelGGL(fm_permute_u64_kernel, GRID(n), 0, st, n, (unsigned *)dval.p, (unsigned long long *)dkg.p, (unsigned long long *)dtmpk.p);
+    int q_bits = 1; while ((1ll << q_bits) < (long long)nq + 1) q_bits++;
+    QSORT(dtmpk.p, dval.p, n, 31 + q_bits);
+    hipLaunchKernelGGL(qc_slot_head_kernel, GRID(n), 0, st, n, (unsigned long long *)dtmpk.p, (unsigned *)dval.p, (int64_t *)dss.p,
+                       (int64_t *)dse.p, (int32_t *)dflag.p);
+    QSCAN(dflag.p, n, dpos.p);
+    int64_t nslots = 0;
+    FCHK(hipMemcpy(&nslots, (int64_t *)dpos.p + n, 8, hipMemcpyDeviceToHost));
+    FCHK(dslotstart.alloc((nslots + 2) * 8)); FCHK(dclid.alloc((n + 1) * 4)); FCHK(dncl.alloc((nslots + 1) * 4)); FCHK(dclbase.alloc((nslots + 2) * 8));
+    hipLaunchKernelGGL(qc_starts_kernel, GRID(n), 0, st, n, (int32_t *)dflag.p, (int64_t *)dpos.p, (int64_t *)dslotstart.p);
+    // 3: clusters
+    {
+        int64_t blocks = (nslots + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(fm_cluster_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nslots, (int64_t *)dslotstart.p, (unsigned *)dval.p,
+                           (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, sthr, 0, (int32_t *)dclid.p, (int32_t *)dncl.p);
+    }
+    {   // the scan scratch must cover nslots too (nslots <= n)
+        QSCAN(dncl.p, nslots, dclbase.p);
+    }
+    int64_t ncl = 0;
+    FCHK(hipMemcpy(&ncl, (int64_t *)dclbase.p + nslots, 8, hipMemcpyDeviceToHost));
+    FCHK(dkqe.alloc((n + 1) * 8)); FCHK(dkqs.alloc((n + 1) * 8)); FCHK(dkcl.alloc((n + 1) * 8)); FCHK(dclcnt.alloc((ncl + 1) * 4));
+    FCHK(dclstart.alloc((ncl + 2) * 8)); FCHK(dp2.alloc((n + 1) * 4)); FCHK(dorder2.alloc((n + 1) * 4));
+    FCHK(hipMemset(dclcnt.p, 0, (ncl + 1) * 4));
+    hipLaunchKernelGGL(qc_ckeys_kernel, GRID(n), 0, st, n, (unsigned *)dval.p, (int32_t *)dflag.p, (int64_t *)dpos.p, (int32_t *)dclid.p,
+                       (int64_t *)dclbase.p, (int64_t *)dqs.p, (int64_t *)dqe.p, (unsigned long long *)dkqe.p, (unsigned long long *)dkqs.p,
+                       (unsigned long long *)dkcl.p, (int32_t *)dclcnt.p);
+    // 4: order inside the clusters by (q_start, q_end)
+    hipLaunchKernelGGL(fm_iota_kernel, GRID(n), 0, st, n, (unsigned *)dp2.p);
+    QSORT(dkqe.p, dp2.p, n, 32);
+    hipLaunchKernelGGL(fm_permute_u64_kernel, GRID(n), 0, st, n, (unsigned *)dp2.p, (unsigned long long *)dkqs.p, (unsigned long long *)dtmpk.p);
+    QSORT(dtmpk.p, dp2.p, n, 32);
+    hipLaunchKernelGGL(fm_permute_u64_kernel, GRID(n), 0, st, n, (unsigned *)dp2.p, (unsigned long long *)dkcl.p, (unsigned long long *)dtmpk.p);
+    int cl_bits = 1; while ((1ll << cl_bits) < ncl + 1) cl_bits++;
+    QSORT(dtmpk.p, dp2.p, n, cl_bits);
+    hipLaunchKernelGGL(fm_compose_kernel, GRID(n), 0, st, n, (unsigned *)dp2.p, (unsigned *)dval.p, (unsigned *)dorder2.p);
+    QSCAN(dclcnt.p, ncl, dclstart.p);
+    // 5: best chain per cluster
+    FCHK(dvis.alloc(n + 16)); FCHK(dcanon.alloc((n + 1) * 4)); FCHK(dbest.alloc((ncl + 1) * sizeof(QBest))); FCHK(dlkey.alloc((ncl + 1) * 8));
+    FCHK(dlval.alloc((ncl + 1) * 4)); FCHK(dqcount.alloc(((size_t)nq + 1) * 4)); FCHK(dqstart.alloc(((size_t)nq + 2) * 8));
+    FCHK(dcount.alloc(((size_t)nq + 1) * 4)); FCHK(dfirst.alloc(((size_t)nq + 2) * 8));
+    FCHK(hipMemset(dqcount.p, 0, ((size_t)nq + 1) * 4));
+    hipLaunchKernelGGL(qc_chain_kernel, GRID(ncl), 0, st, ncl, (int64_t *)dclstart.p, (unsigned *)dorder2.p, (int32_t *)dq.p, (int32_t *)dsg.p,
+                       (int64_t *)dqs.p, (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, (const double *)did.p, qthr, sthr,
+                       (uint8_t *)dvis.p, (int32_t *)dcanon.p, (QBest *)dbest.p, (unsigned long long *)dlkey.p, (unsigned *)dlval.p,
+                       (int32_t *)dqcount.p);
+    // 6: per query, longest first (stable)
+    QSORT(dlkey.p, dlval.p, ncl, 32 + q_bits);
+    QSCAN(dqcount.p, (int64_t)nq, dqstart.p);
+    // 7: selection -- count, scan, write
+    const unsigned sblocks = (unsigned)((nq + 3) / 4);
+    hipLaunchKernelGGL(qc_select_kernel<false>, dim3(sblocks), dim3(256), 0, st, (int)nq, (int64_t *)dqstart.p, (unsigned *)dlval.p, (QBest *)dbest.p,
+                       (int64_t *)dql.p, (int64_t *)dsl.p, qcov, scov, (int)max_copy, (int32_t *)dcount.p, (int64_t *)nullptr, (int32_t *)nullptr,
+                       (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (uint8_t *)nullptr);
+    QSCAN(dcount.p, (int64_t)nq, dfirst.p);
+    FCHK(hipMemcpy(copy_first, dfirst.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost));
+    const int64_t nout = copy_first[nq];
+    *n_out = nout;
+    if (nout > cap) { sorter_free(S); return HITE_ECAP; }
+    if (nout > 0) {
+        if (!o_sid || !o_s || !o_e || !o_len || !o_minus) { sorter_free(S); return HITE_EINVAL; }
+        FCHK(dos.alloc(nout * 4)); FCHK(doa.alloc(nout * 8)); FCHK(dob.alloc(nout * 8)); FCHK(dol.alloc(nout * 8)); FCHK(dom.alloc(nout));
+        hipLaunchKernelGGL(qc_select_kernel<true>, dim3(sblocks), dim3(256), 0, st, (int)nq, (int64_t *)dqstart.p, (unsigned *)dlval.p,
+                           (QBest *)dbest.p, (int64_t *)dql.p, (int64_t *)dsl.p, qcov, scov, (int)max_copy, (int32_t *)dcount.p,
+                           (int64_t *)dfirst.p, (int32_t *)dos.p, (int64_t *)doa.p, (int64_t *)dob.p, (int64_t *)dol.p, (uint8_t *)dom.p);
+        FCHK(hipGetLastError());
+        FCHK(hipMemcpy(o_sid, dos.p, nout * 4, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(o_s, doa.p, nout * 8, hipMemcpyDeviceToHost));
+        FCHK(hipMemcpy(o_e, dob.p, nout * 8, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(o_len, dol.p, nout * 8, hipMemcpyDeviceToHost));
+        FCHK(hipMemcpy(o_minus, dom.p, nout, hipMemcpyDeviceToHost));
+    }
+    sorter_free(S);
+    return HITE_OK;
 }

@@ -294,6 +294,49 @@ def get_candidate_non_LTR(longest_repeats_flanked_path, flanking_len=50, device=
     return cand_sine, cand_line
 
 
+def get_query_copies(cur_segments, query_contigs, subject_path, query_coverage, subject_coverage, query_fixed_extend_base_threshold=200,
+                     subject_fixed_extend_base_threshold=200, max_copy_num=100, device=0):
+    """Util.py:6828 -- cur_segments = [(query_name, {subject_name: [(q_start, q_end, s_start, s_end, identity)]})] ->
+    {query_name: [(subject_name, start, end, chain_len, '+'/'-')]}.  One device call for all queries."""
+    subject_contigs = read_fasta(subject_path)[1] if subject_coverage > 0 else {}
+    qnames, snames, sidx = [], [], {}
+    qid, sid, qs, qe, ss, se, ident = [], [], [], [], [], [], []
+    for query_name, subject_dict in cur_segments:
+        q = len(qnames)
+        qnames.append(query_name)
+        for subject_name, subject_pos in subject_dict.items():
+            s = sidx.setdefault(subject_name, len(snames))
+            if s == len(snames):
+                snames.append(subject_name)
+            for (a, b, c, d, idt) in subject_pos:
+                qid.append(q); sid.append(s); qs.append(a); qe.append(b); ss.append(c); se.append(d); ident.append(idt)
+    all_copies = {}
+    if not qnames:
+        return all_copies
+    qlen = [len(query_contigs[name]) for name in qnames]
+    slen = [len(subject_contigs[name]) for name in snames] if subject_coverage > 0 else None
+    res = get_ctx(device).query_copies(qid, sid, qs, qe, ss, se, ident, qlen, slen, ns=max(1, len(snames)), qcov=query_coverage,
+                                       scov=subject_coverage, qthr=query_fixed_extend_base_threshold,
+                                       sthr=subject_fixed_extend_base_threshold, max_copy=max_copy_num)
+    for q, name in enumerate(qnames):
+        all_copies[name] = [(snames[c[0]], c[1], c[2], c[3], c[4]) for c in res[q]]
+    return all_copies
+
+
+def get_copies_v1(blastnResults_path, query_path, subject_path, query_coverage=0.95, subject_coverage=0, device=0):
+    """Util.py:7032 -- blast6 table -> {query: copies}; lines with query == subject name are skipped"""
+    query_records = {}
+    with open(blastnResults_path) as f_r:
+        for line in f_r:
+            parts = line.split("\t")
+            if len(parts) < 10 or parts[0] == parts[1]:
+                continue
+            query_records.setdefault(parts[0], {}).setdefault(parts[1], []).append(
+                (int(parts[6]), int(parts[7]), int(parts[8]), int(parts[9]), float(parts[2])))
+    _names, query_contigs = read_fasta(query_path)
+    return get_query_copies(list(query_records.items()), query_contigs, subject_path, query_coverage, subject_coverage, device=device)
+
+
 def mask_genome_intactTE(TE_lib, genome_path, work_dir=None, thread=1, ref_index=0, debug=0, device=0):
     """mask_genome_intactTE (Util.py:6389-6431): the full-length copies (coverage >= 0.95 of the library sequence) of the
     TEs found so far are replaced by N in the chunk, written to <genome_path>.masked.  The copies come from the build's

@@ -168,6 +168,20 @@ int hite_fmea_chain_dev(hite_ctx *ctx, int64_t n, const int32_t *d_qseg, const i
                         const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
                         int64_t *out_start, int64_t *out_end, int64_t *n_out);
 
+/* ---- copy clustering of a blast6 HSP table --- get_query_copies  Util.py:6828-7030 (+ get_copies_v1 :7032-7060) -----
+ * n HSPs in file order (host arrays): query id in [0, nq), subject id in [0, ns), 1-based inclusive coordinates
+ * (s_start > s_end = minus strand), identity column (may be NULL: only its equality between otherwise identical
+ * lines matters).  Per query: cluster per (subject in order of first appearance, strand), longest chain per cluster
+ * with the 200 bp gap rules (qthr / sthr), longest first, keep chain_len / qlen >= qcov (and, if scov > 0,
+ * subject_span / slen[sid] >= scov), de-duplicate on (subject, start, end), stop after max_copy + 1 (<= 254).
+ * Output CSR copy_first[nq + 1] into (o_sid, o_s <= o_e, o_len, o_minus); *n_out = total; HITE_ECAP if total > cap.
+ * HITE_EINVAL on ids / coordinates out of range. */
+int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe,
+                      const int64_t *ss, const int64_t *se, const double *ident, int32_t nq, const int64_t *qlen, int32_t ns,
+                      const int64_t *slen, double qcov, double scov, int64_t qthr, int64_t sthr, int32_t max_copy, int64_t cap,
+                      int64_t *copy_first, int32_t *o_sid, int64_t *o_s, int64_t *o_e, int64_t *o_len, uint8_t *o_minus,
+                      int64_t *n_out);
+
 /* ---- k-mer TSD seed matching --- search_confident_tir_v4  Util.py:7734-7845 -------------------------
  * batch of flanked candidates (CSR); the raw boundaries are (flank+1, len-flank), 1-based, as
  * search_confident_tir_batch_v1 passes them (Util.py:6550), tsd_search_distance = flank (<= 63).

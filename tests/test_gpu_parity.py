@@ -713,3 +713,100 @@ def test_nonltr_prep(ctx, tmp_path):
         i = int(name.split("\t")[0][1:])
         assert g[i]["found"] and name.endswith("TSD:" + g[i]["tsd"]) and seq == g[i]["non_ltr"]
     assert len(sine) + len(line) > 10
+
+
+def _random_hsp_table(rng, nq, ns, n_copies, dup=0.05):
+    """blast6-like rows (q, s, qs, qe, ss, se, identity) of TE queries hitting chromosomes, fragmented and shuffled"""
+    qlen = [int(rng.integers(150, 4000)) for _ in range(nq)]
+    slen = [int(rng.integers(50_000, 3_000_000)) for _ in range(ns)]
+    rows = []
+    for _ in range(n_copies):
+        q, s = int(rng.integers(0, nq)), int(rng.integers(0, ns))
+        rev = rng.random() < 0.5
+        span = max(40, int(qlen[q] * float(rng.choice([1.0, 1.0, 0.96, 0.7, 0.3]))))
+        span = min(span, qlen[q])
+        q0 = int(rng.integers(1, qlen[q] - span + 2))
+        pos = int(rng.integers(1000, slen[s] - 3 * qlen[q] - 1000)) if rng.random() < 0.9 else 5000 + 37 * q   # piled-up copies
+        cuts = sorted(set([0, span] + [int(x) for x in rng.integers(10, max(11, span - 10), size=int(rng.integers(0, 4)))]))
+        shift = 0
+        for i in range(len(cuts) - 1):
+            a, b = cuts[i], cuts[i + 1]
+            if i:
+                shift += int(rng.choice([0, 0, 2, -2, 150, 199, 200, 201, 400]))
+            fs, fe = q0 + a + (int(rng.choice([0, 0, 4, 180, 199, 200])) if i else 0), q0 + b - 1
+            if fe < fs:
+                continue
+            ss_, se_ = (pos + a + shift, pos + b - 1 + shift) if not rev else (pos + span - a + shift, pos + span - b + 1 + shift)
+            idt = float(rng.choice([100.0, 99.2, 87.5]))
+            rows.append((q, s, fs, fe, ss_, se_, idt))
+            if rng.random() < dup:
+                rows.append((q, s, fs, fe, ss_, se_, idt if rng.random() < 0.5 else 80.0))
+    rows = [rows[i] for i in rng.permutation(len(rows))]
+    return rows, qlen, slen
+
+
+def test_query_copies(ctx, tmp_path):
+    """get_query_copies (blastn-route copy clustering): reference goldens through the util mirror, random tables vs the oracle"""
+    from hite_amd import util
+    for ci, c in enumerate(load_golden("query_copies")):
+        recs = {}
+        for (q, s, a, b, cc, d, idt) in c["rows"]:
+            recs.setdefault("TE_%d" % q, {}).setdefault("chr%d" % s, []).append((a, b, cc, d, idt))
+        qc = {"TE_%d" % q: "A" * L for q, L in enumerate(c["qlen"])}
+        spath = None
+        if c["scov"] > 0:
+            spath = str(tmp_path / ("subj_%d.fa" % ci))
+            with open(spath, "w") as fh:
+                for s, L in enumerate(c["slen"]):
+                    fh.write(">chr%d\n%s\n" % (s, "A" * L))
+        got = util.get_query_copies(list(recs.items()), qc, spath, c["qcov"], c["scov"])
+        exp = {k: [tuple(x) for x in v] for k, v in c["out"].items()}
+        assert got == exp, ci
+    rng = np.random.default_rng(6828)
+    for (nq, ns, ncp, kw) in [(1, 1, 1, {}), (3, 2, 40, {}), (200, 5, 6000, {}), (2000, 20, 60000, {"qcov": 0.8}),
+                              (50, 3, 30000, {"qcov": 0.5, "max_copy": 30}), (300, 4, 8000, {"scov": 0.0005, "qthr": 150, "sthr": 250})]:
+        rows, qlen, slen = _random_hsp_table(rng, nq, ns, ncp)
+        cols = list(zip(*rows))
+        exp = O.query_copies(rows, qlen, slen, kw.get("qcov", 0.95), kw.get("scov", 0.0), kw.get("qthr", 200), kw.get("sthr", 200),
+                             kw.get("max_copy", 100))
+        got = ctx.query_copies(cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], cols[6], qlen, slen, **kw)
+        assert got == exp, (nq, ns, ncp)
+        assert ncp < 100 or sum(len(x) for x in got) > 0
+    # no identity column, empty table, bad input
+    rows, qlen, slen = _random_hsp_table(rng, 20, 2, 500, dup=0.0)
+    cols = list(zip(*rows))
+    assert ctx.query_copies(cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], None, qlen, slen) == O.query_copies(rows, qlen, slen, 0.95)
+    assert ctx.query_copies([], [], [], [], [], [], [], [100, 200], [1000]) == [[], []]
+    with pytest.raises(RuntimeError):
+        ctx.query_copies([0], [0], [10], [50], [-1, ], [50], [99.0], [100], [1000])    # negative coordinate
+    with pytest.raises(RuntimeError):
+        ctx.query_copies([3], [0], [1], [50], [1, ], [50], [99.0], [100], [1000])      # query id out of range
+
+
+def test_get_copies_v1_file(ctx, tmp_path):
+    """get_copies_v1: blast6 file + query fasta -> copies; self hits skipped; equals the oracle on the parsed table"""
+    from hite_amd import util
+
+    rng = np.random.default_rng(7032)
+    rows, qlen, slen = _random_hsp_table(rng, 30, 3, 900)
+    bl = tmp_path / "hits.out"
+    with open(bl, "w") as fh:
+        fh.write("TE_0\tTE_0\t100.0\t50\t0\t0\t1\t50\t1\t50\t0.0\t90\n")         # self hit
+        for (q, s, a, b, c, d, idt) in rows:
+            fh.write("TE_%d\tchr%d\t%.3f\t%d\t0\t0\t%d\t%d\t%d\t%d\t1e-50\t500\n" % (q, s, idt, b - a + 1, a, b, c, d))
+    qf = tmp_path / "q.fa"
+    with open(qf, "w") as fh:
+        for q, L in enumerate(qlen):
+            fh.write(">TE_%d\n%s\n" % (q, "ACGT" * (L // 4) + "A" * (L % 4)))
+    got = util.get_copies_v1(str(bl), str(qf), "", query_coverage=0.9)
+    order = {}
+    dense = []
+    for r in rows:
+        dense.append((order.setdefault(r[0], len(order)),) + tuple(r[1:6]) + (float("%.3f" % r[6]),))
+    ql = [0] * len(order)
+    for orig, q in order.items():
+        ql[q] = qlen[orig]
+    exp = O.query_copies(dense, ql, slen, 0.9)
+    assert set(got) == {"TE_%d" % o for o in order}
+    for orig, q in order.items():
+        assert got["TE_%d" % orig] == [("chr%d" % c[0],) + c[1:] for c in exp[q]]
