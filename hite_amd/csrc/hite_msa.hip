@@ -64,6 +64,11 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
     return ((unsigned long long)hi << 32) | lo;
 }
 
+// base words of the aligner (see star_align_kernel): the centre base as a v_perm_b32 byte selector, the row base as its
+// 4-entry score row.  code = (c >> 1) & 3 is distinct for A, C, G, T; every other byte scores "mismatch" against anything.
+__device__ __forceinline__ bool base_acgt(unsigned c) { return c - 0x41u < 32u && ((0x00080045u >> (c - 0x41u)) & 1u); }
+__device__ __forceinline__ unsigned base_sel(unsigned c) { return 0x0c0c0c00u | (base_acgt(c) ? ((c >> 1) & 3u) : 4u); }
+__device__ __forceinline__ unsigned base_row(unsigned c) { return 0x1a1a1a1au + (base_acgt(c) ? (0x10u << (8u * ((c >> 1) & 3u))) : 0u); }
 // pin a wave-uniform value into an SGPR (the compiler otherwise keeps loop-carried uniform values in VGPRs)
 __device__ __forceinline__ int to_sgpr(int v) {
     int r;
@@ -105,7 +110,7 @@ __device__ __forceinline__ unsigned long long rfl64(unsigned long long v) {
 //  backward: scalar walk (i-1 in M0, j-1, k, bit index in SGPRs), four 16-step words per trip; results leave as one
 //            masked store of <= 64 u16 per trip (row position aligned to centre position p | gap flag << 15).
 __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
-    __shared__ uint8_t s_bases[4][2][128];  // per wave: windows of centre / row bases for the current chunk
+    __shared__ unsigned s_bases[4][2][128];  // per wave: windows of centre / row base words for the current chunk
     const int lane = threadIdx.x & 63;
     const int wslot = blockIdx.x * 4 + (threadIdx.x >> 6);
     uint8_t *slot = P.tb + (size_t)wslot * P.tb_slot;
@@ -131,91 +136,125 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
         // match +10), times 4, low two bits = tag of the operand that won (2 diagonal, 1 up, 0 left).  With the up
         // operand stored with tag 1 and the left operand taken as "- 1", ONE v_max3 yields value, tie-break
         // (diag >= up >= left) and direction; v_alignbit shifts the two direction bits into the per-lane chunk word.
+        // Bases are held as words that make the substitution score ONE v_perm_b32: the centre base is a byte selector
+        // (A, C, G, T -> 0..3 picks a byte of the row word, anything else -> 4 picks the constant), the row base is the
+        // 4-entry score row (42 in its own byte, 26 elsewhere; 26 everywhere for a non-ACGT byte).
         int t = -32;                                   // origin of anti-diagonal s-1 (scalar)
         int prev = lane == 32 ? ((MBIAS << 2) | 1) : 0, pp = 0;   // H(s-1) at origin t (tag 1);  left operand of step s-1
-        int areg, breg;                                // a[i-1], b[j-1] of this lane's cell on anti-diagonal s-1
+        int areg, breg;                                // selector of a[i-1], score row of b[j-1] of this lane's cell on anti-diagonal s-1
         {
             int ia = t + lane - 1, jb = -(t + lane) - 1;
-            areg = (ia >= 0 && ia < m) ? a[ia] : 0xFF;
-            if (areg == 'N') areg = 0xFD;
-            breg = (jb >= 0 && jb < n) ? b[jb] : 0xFE;
+            areg = (int)base_sel((ia >= 0 && ia < m) ? a[ia] : 0xFF);
+            breg = (int)base_row((jb >= 0 && jb < n) ? b[jb] : 0xFE);
         }
         const int m31 = m - 31, n1 = n + 1;
         const int neg32 = to_sgpr(-32);
-        int vm1;                                       // DPP forms take no constant operand
+        const int c26 = to_sgpr(0x1a1a1a1a);
+        int vm1, a252;                                 // DPP forms take no constant operand; ds_bpermute address of lane 63
         asm volatile("v_mov_b32 %0, -1" : "=v"(vm1));
-        // per-wave LDS windows of the bases that can enter the band during one chunk (the vector unit is the bottleneck
-        // of this kernel: 4 cycles per instruction, ~100 % busy; LDS reads issue on their own port):
-        //   A[x] = a'[t0 - 1 + x]   lane k reads A[k + downs]   (x = 1 .. 79)
-        //   B[y] = b'[e0 - 64 + y]  lane k reads B[63 - k + rights],  e0 = s_lo - t0 - 1
-        uint8_t *winA = &s_bases[threadIdx.x >> 6][0][0], *winB = &s_bases[threadIdx.x >> 6][1][0];
+        asm volatile("v_mov_b32 %0, 0xfc" : "=v"(a252));
+        // per-wave LDS windows of the base words that can enter the band during one chunk (the vector unit is the
+        // bottleneck of this kernel: 4 cycles per instruction, ~100 % busy; LDS instructions issue on their own port):
+        //   A[x]  = sel(a'[t0 - 1 + x])         lane k reads A[k + downs]
+        //   B'[z] = row(b'[e0 + 63 - z])        lane k reads B'[64 + k - rights],  e0 = s_lo - t0 - 1   (B' is stored mirrored
+        //           so that both reads are "R + constant" with ONE address register R = &A[k + downs] in the unrolled form:
+        //           &B'[64 + k - rights] = R + 512 + 4 (64 - j) at step j of the chunk)
+        unsigned *winA = &s_bases[threadIdx.x >> 6][0][0], *winB = &s_bases[threadIdx.x >> 6][1][0];
         const unsigned ldsA = (unsigned)(uintptr_t)winA, ldsB = (unsigned)(uintptr_t)winB;
-        // One anti-diagonal, hand-scheduled: 10-11 vector instructions, no s_nop (scalar instructions fill the wait states:
-        // v_cmp -> v_cndmask needs 2, a VALU write -> DPP read of the same register needs 2).
-        //   steering : two v_readlane; move = prev[63] >= prev[0] (odd s) / > (even s)
+        // One anti-diagonal, hand-scheduled: 8 vector instructions.
+        //   steering : prev[63] comes to lane 0 through ds_bpermute (LDS port, issued as soon as prev exists), one v_cmp,
+        //              s_bitcmp on bit 0 of vcc: move = prev[63] >= prev[0] (odd s) / > (even s)
         //              general step: tn = max(min(t + move, min(m,s) - 31), max(0,s-n) - 32) on the scalar unit;
         //              clamp-free step (see the chunk test below): tn = t + move
-        //   down     : the centre base of every lane is re-read one entry further in A; left = shl(prev) - 1 becomes the
+        //   down     : the centre word of every lane is re-read one entry further in A; left = shl(prev) - 1 becomes the
         //              next step's diagonal operand (the two pp registers swap roles every step: no copy)
-        //   right    : same with the row bases / B; diagonal = shr(pp) folded into the add
-#define ARM_DOWN(PO, PN, MOVE, TAIL)                                                                    \
-            "v_add_u32 %[aaddr], 1, %[aaddr]\n\t"                                                 \
-            "ds_read_u8 %[areg], %[aaddr]\n\t"                                                    \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                            \
-            "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
+        //   right    : same with the row words / B'; diagonal = shr(pp) folded into the add
+#define ARM_CORE_DOWN(PO, PN, MOVE)                                                                     \
             "v_add_u32_dpp %[" PN "], %[prev], %[vm1] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
             MOVE                                                                                  \
-            "v_cndmask_b32_e64 %[tsc], 26, 42, vcc\n\t"                                           \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                            \
+            "v_perm_b32 %[tsc], %[c26], %[breg], %[areg]\n\t"                                     \
             "v_add_u32 %[tcd], %[" PO "], %[tsc]\n\t"                                             \
             "v_max3_i32 %[tv], %[tcd], %[prev], %[" PN "]\n\t"                                    \
             "v_and_or_b32 %[prev], %[tv], -4, 1\n\t"                                              \
-            "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"                                           \
-            TAIL
-#define ARM_RIGHT(PO, PN, MOVE, TAIL)                                                                   \
-            "v_add_u32 %[baddr], 1, %[baddr]\n\t"                                                 \
-            "ds_read_u8 %[breg], %[baddr]\n\t"                                                    \
-            "s_waitcnt lgkmcnt(0)\n\t"                                                            \
-            "v_cmp_eq_u32 vcc, %[areg], %[breg]\n\t"                                              \
+            "ds_bpermute_b32 %[rot], %[a252], %[prev]\n\t"                                        \
+            "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"
+#define ARM_CORE_RIGHT(PO, PN, MOVE)                                                                    \
             "v_mov_b32_dpp %[thx], %[prev] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
-            MOVE                                                                                  \
-            "v_cndmask_b32_e64 %[tsc], 26, 42, vcc\n\t"                                           \
-            "v_add_u32_dpp %[tcd], %[" PO "], %[tsc] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
             "v_add_u32 %[" PN "], -1, %[prev]\n\t"                                                \
+            MOVE                                                                                  \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                            \
+            "v_perm_b32 %[tsc], %[c26], %[breg], %[areg]\n\t"                                     \
+            "v_add_u32_dpp %[tcd], %[" PO "], %[tsc] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
             "v_max3_i32 %[tv], %[tcd], %[thx], %[" PN "]\n\t"                                     \
             "v_and_or_b32 %[prev], %[tv], -4, 1\n\t"                                              \
-            "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"                                           \
-            TAIL
+            "ds_bpermute_b32 %[rot], %[a252], %[prev]\n\t"                                        \
+            "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"
 #define STEP_GEN(CMP, L, PO, PN)                                                                  \
-            "v_readlane_b32 %[h0], %[prev], 0\n\t"                                                \
-            "v_readlane_b32 %[h63], %[prev], 63\n\t"                                              \
             "s_add_i32 %[s31], %[s31], 1\n\t"                                                     \
             "s_min_i32 %[x], %[m31], %[s31]\n\t"                                                  \
             "s_sub_i32 %[y], %[s31], %[n1]\n\t"                                                   \
             "s_max_i32 %[y], %[y], %[neg32]\n\t"                                                  \
-            CMP " %[h63], %[h0]\n\t"                                                              \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                            \
+            CMP " vcc, %[rot], %[prev]\n\t"                                                       \
+            "s_bitcmp1_b32 vcc_lo, 0\n\t"                                                         \
             "s_addc_u32 %[tn], %[t], 0\n\t"                                                       \
             "s_min_i32 %[tn], %[tn], %[x]\n\t"                                                    \
             "s_max_i32 %[tn], %[tn], %[y]\n\t"                                                    \
             "s_cmp_lg_u32 %[tn], %[t]\n\t"                                                        \
             "s_mov_b32 %[t], %[tn]\n\t"                                                           \
             "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
-            ARM_DOWN(PO, PN, "s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t", "s_branch J" L "_%=\n")   \
+            "v_add_u32 %[aaddr], 4, %[aaddr]\n\t"                                                 \
+            "ds_read_b32 %[areg], %[aaddr]\n\t"                                                   \
+            ARM_CORE_DOWN(PO, PN, "s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t")                      \
+            "s_branch J" L "_%=\n"                                                                \
             "R" L "_%=:\n\t"                                                                      \
-            ARM_RIGHT(PO, PN, "s_lshl_b32 %[mreg], %[mreg], 2\n\t", "\n")                         \
+            "v_add_u32 %[baddr], -4, %[baddr]\n\t"                                                \
+            "ds_read_b32 %[breg], %[baddr]\n\t"                                                   \
+            ARM_CORE_RIGHT(PO, PN, "s_lshl_b32 %[mreg], %[mreg], 2\n\t")                          \
             "J" L "_%=:\n\t"
-#define STEP_FAST(CMP, L, PO, PN)                                                                 \
-            "v_readlane_b32 %[h0], %[prev], 0\n\t"                                                \
-            "v_readlane_b32 %[h63], %[prev], 63\n\t"                                              \
-            CMP " %[h63], %[h0]\n\t"                                                              \
+        // unrolled form: step J (1..64) of the chunk is a literal, the row word of a right move sits at R + 768 - 4 J.  Both
+        // words that can enter at step J are fetched speculatively together with the steering value (one LDS round trip per
+        // step); the arm taken copies its word into the resident register and re-fetches only its own side (after a down
+        // move the row word that a right move would bring in is still the same entry of B', and vice versa).  Measured
+        // cost model on MI355X: a wave64 vector instruction occupies its SIMD for 4 cycles (1 CU-cycle with the 4 SIMDs in
+        // parallel), a wave64 LDS instruction occupies the CU's LDS pipe for ~4 cycles: 9 vector + 2 LDS per step is
+        // vector-bound (11.6 vs 8 CU-cycles with the traceback's share); re-reading through LDS instead of the two copies
+        // (8 vector + 3 LDS) turns it LDS-bound and is slower.
+#define STEP_FAST(CMP, L, J, PO, PN)                                                              \
+            "s_waitcnt lgkmcnt(0)\n\t"                                                            \
+            CMP " vcc, %[rot], %[prev]\n\t"                                                       \
+            "s_bitcmp1_b32 vcc_lo, 0\n\t"                                                         \
             "s_cbranch_scc0 R" L "_%=\n\t"                                                        \
-            ARM_DOWN(PO, PN, "s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t", "s_branch J" L "_%=\n")   \
+            "v_add_u32_dpp %[" PN "], %[prev], %[vm1] wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            "v_perm_b32 %[tsc], %[c26], %[breg], %[an]\n\t"                                       \
+            "v_add_u32 %[tcd], %[" PO "], %[tsc]\n\t"                                             \
+            "v_max3_i32 %[tv], %[tcd], %[prev], %[" PN "]\n\t"                                    \
+            "v_and_or_b32 %[prev], %[tv], -4, 1\n\t"                                              \
+            "ds_bpermute_b32 %[rot], %[a252], %[prev]\n\t"                                        \
+            "v_add_u32 %[aaddr], 4, %[aaddr]\n\t"                                                 \
+            "v_mov_b32 %[areg], %[an]\n\t"                                                        \
+            "s_lshl2_add_u32 %[mreg], %[mreg], 1\n\t"                                             \
+            "ds_read_b32 %[an], %[aaddr] offset:4\n\t"                                            \
+            "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"                                           \
+            "s_branch J" L "_%=\n"                                                                \
             "R" L "_%=:\n\t"                                                                      \
-            ARM_RIGHT(PO, PN, "s_lshl_b32 %[mreg], %[mreg], 2\n\t", "\n")                         \
+            "v_mov_b32_dpp %[thx], %[prev] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            "v_add_u32 %[" PN "], -1, %[prev]\n\t"                                                \
+            "v_perm_b32 %[tsc], %[c26], %[bn], %[areg]\n\t"                                       \
+            "v_add_u32_dpp %[tcd], %[" PO "], %[tsc] wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+            "v_max3_i32 %[tv], %[tcd], %[thx], %[" PN "]\n\t"                                     \
+            "v_and_or_b32 %[prev], %[tv], -4, 1\n\t"                                              \
+            "ds_bpermute_b32 %[rot], %[a252], %[prev]\n\t"                                        \
+            "v_mov_b32 %[breg], %[bn]\n\t"                                                        \
+            "s_lshl_b32 %[mreg], %[mreg], 2\n\t"                                                  \
+            "ds_read_b32 %[bn], %[aaddr] offset:764-4*(" J ")\n\t"                                \
+            "v_alignbit_b32 %[d2], %[tv], %[d2], 2\n\t"                                           \
             "J" L "_%=:\n\t"
-#define STEP_FAST2(L) STEP_FAST("s_cmp_ge_i32", L "o", "p0", "p1") STEP_FAST("s_cmp_gt_i32", L "e", "p1", "p0")
+#define STEP_FAST2(L) STEP_FAST("v_cmp_ge_i32", L "o", "2*" L "+1", "p0", "p1") STEP_FAST("v_cmp_gt_i32", L "e", "2*" L "+2", "p1", "p0")
 #define STEP_VREGS                                                                                                         \
               [prev] "+v"(prev), [p0] "+v"(p0), [p1] "+v"(p1), [areg] "+v"(areg), [breg] "+v"(breg), [aaddr] "+v"(aaddr), \
-              [baddr] "+v"(baddr), [d2] "+v"(d2), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv)
+              [d2] "+v"(d2), [tsc] "=&v"(tsc), [tcd] "=&v"(tcd), [thx] "=&v"(thx), [tv] "=&v"(tv), [rot] "=&v"(rot)
         int p0 = pp, p1 = 0;                           // the diagonal operand lives in p0 at the start of every chunk
         // chunk = 64 anti-diagonals = four 16-step direction words per lane.  Words 0..2 are parked in d2a/d2b/d2c (moves in
         // mrega/b/c) as they fill up; the general form walks the four words in a small loop inside the same asm statement.
@@ -224,16 +263,16 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             const int s_lo = (ch << 6) + 1;
             const int left = steps - (ch << 6);
             const int nst = left < 64 ? left : 64;
-            {   // windows of this chunk: entries 1..63 are the bases the lanes hold now, 64..127 the (<= 64) that can enter
-                winA[lane] = (uint8_t)areg;
-                winB[63 - lane] = (uint8_t)breg;
+            {   // windows of this chunk: the words the lanes hold now, then the (<= 64) that can enter on either side
+                winA[lane] = (unsigned)areg;
+                winB[64 + lane] = (unsigned)breg;
                 const int ia = t + 63 + lane, ib = s_lo - t - 1 + lane;
                 const int ra = a[(unsigned)ia < (unsigned)m ? ia : 0], rb = b[(unsigned)ib < (unsigned)n ? ib : 0];
-                winA[64 + lane] = (uint8_t)((unsigned)ia < (unsigned)m ? (ra == 'N' ? 0xFD : ra) : 0xFF);
-                winB[64 + lane] = (uint8_t)((unsigned)ib < (unsigned)n ? rb : 0xFE);
+                winA[64 + lane] = base_sel((unsigned)ia < (unsigned)m ? ra : 0xFF);
+                winB[63 - lane] = base_row((unsigned)ib < (unsigned)n ? rb : 0xFE);
             }
-            int aaddr = (int)(ldsA + lane), baddr = (int)(ldsB + 63 - lane);
-            int tsc, tcd, thx, tv, sx, sy, tn, h0, h63;
+            int aaddr = (int)(ldsA + 4 * lane);
+            int tsc, tcd, thx, tv, rot, sx, sy, tn;
             // neither clamp can bind during a full chunk that starts with t + 64 <= m - 31 and t >= max(0, s_hi - n) - 32
             // (t only grows, by at most one per step; t <= s - 32 always): such chunks run the 64 steps unrolled and
             // recover t from the recorded moves; the other chunks run word by word through the general loop.
@@ -245,7 +284,11 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
             if (fast) {
                 int d2 = 0, d2a, d2b, d2c;
                 int mreg = to_sgpr(0), mrega, mregb, mregc;
+                int an, bn;
                 asm volatile(
+                    "ds_bpermute_b32 %[rot], %[a252], %[prev]\n\t"
+                    "ds_read_b32 %[an], %[aaddr] offset:4\n\t"
+                    "ds_read_b32 %[bn], %[aaddr] offset:764\n\t"
                     STEP_FAST2("0") STEP_FAST2("1") STEP_FAST2("2") STEP_FAST2("3")
                     STEP_FAST2("4") STEP_FAST2("5") STEP_FAST2("6") STEP_FAST2("7")
                     "v_mov_b32 %[d2a], %[d2]\n\t"
@@ -260,9 +303,10 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
                     "s_mov_b32 %[mregc], %[mreg]\n\t"
                     STEP_FAST2("24") STEP_FAST2("25") STEP_FAST2("26") STEP_FAST2("27")
                     STEP_FAST2("28") STEP_FAST2("29") STEP_FAST2("30") STEP_FAST2("31")
+                    "s_waitcnt lgkmcnt(0)\n\t"
                     : STEP_VREGS, [d2a] "=&v"(d2a), [d2b] "=&v"(d2b), [d2c] "=&v"(d2c), [mreg] "+s"(mreg), [mrega] "=&s"(mrega),
-                      [mregb] "=&s"(mregb), [mregc] "=&s"(mregc), [h0] "=&s"(h0), [h63] "=&s"(h63)
-                    : [vm1] "v"(vm1)
+                      [mregb] "=&s"(mregb), [mregc] "=&s"(mregc), [an] "=&v"(an), [bn] "=&v"(bn)
+                    : [vm1] "v"(vm1), [a252] "v"(a252), [c26] "s"(c26)
                     : "vcc", "scc", "memory");
                 t += __builtin_popcount((unsigned)mrega & 0x55555555u) + __builtin_popcount((unsigned)mregb & 0x55555555u) +
                      __builtin_popcount((unsigned)mregc & 0x55555555u) + __builtin_popcount((unsigned)mreg & 0x55555555u);
@@ -271,6 +315,7 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
                 if (lane == 0) { tbm[4 * ch] = (unsigned)mrega; tbm[4 * ch + 1] = (unsigned)mregb; tbm[4 * ch + 2] = (unsigned)mregc; tbm[4 * ch + 3] = (unsigned)mreg; }
             } else {
                 int s31 = to_sgpr(s_lo - 32);          // (s - 31) of the step before the next one
+                int baddr = (int)(ldsB + 4 * (64 + lane));
                 for (int w_ = 0; (w_ << 4) < nst; w_++) {
                     const int nsw = nst - (w_ << 4) < 16 ? nst - (w_ << 4) : 16;
                     int d2 = 0;
@@ -278,21 +323,23 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
                     int cnt = to_sgpr((nsw >> 1) - 1);         // pairs - 1
                     const int odd = to_sgpr(nsw & 1);          // only the last word of the last chunk can be odd
                     asm volatile(
+                        "ds_bpermute_b32 %[rot], %[a252], %[prev]\n\t"
                         "s_cmp_lt_i32 %[cnt], 0\n\t"
                         "s_cbranch_scc1 S_%=\n"
                         "L_%=:\n\t"
-                        STEP_GEN("s_cmp_ge_i32", "a", "p0", "p1")
-                        STEP_GEN("s_cmp_gt_i32", "b", "p1", "p0")
+                        STEP_GEN("v_cmp_ge_i32", "a", "p0", "p1")
+                        STEP_GEN("v_cmp_gt_i32", "b", "p1", "p0")
                         "s_sub_u32 %[cnt], %[cnt], 1\n\t"
                         "s_cbranch_scc0 L_%=\n"
                         "S_%=:\n\t"
                         "s_cmp_eq_u32 %[odd], 0\n\t"
                         "s_cbranch_scc1 E_%=\n\t"
-                        STEP_GEN("s_cmp_ge_i32", "c", "p0", "p1")
+                        STEP_GEN("v_cmp_ge_i32", "c", "p0", "p1")
                         "E_%=:\n\t"
-                        : STEP_VREGS, [t] "+s"(t), [mreg] "+s"(mreg), [s31] "+s"(s31), [cnt] "+s"(cnt), [x] "=&s"(sx), [y] "=&s"(sy),
-                          [tn] "=&s"(tn), [h0] "=&s"(h0), [h63] "=&s"(h63)
-                        : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32), [vm1] "v"(vm1), [odd] "s"(odd)
+                        "s_waitcnt lgkmcnt(0)\n\t"
+                        : STEP_VREGS, [baddr] "+v"(baddr), [t] "+s"(t), [mreg] "+s"(mreg), [s31] "+s"(s31), [cnt] "+s"(cnt), [x] "=&s"(sx),
+                          [y] "=&s"(sy), [tn] "=&s"(tn)
+                        : [m31] "s"(m31), [n1] "s"(n1), [neg32] "s"(neg32), [vm1] "v"(vm1), [a252] "v"(a252), [c26] "s"(c26), [odd] "s"(odd)
                         : "vcc", "scc", "memory");
                     tbd[(4 * ch + w_) * 64 + lane] = (unsigned)d2 >> (2 * (16 - nsw));
                     if (lane == 0) tbm[4 * ch + w_] = (unsigned)mreg << (2 * (16 - nsw));
@@ -302,8 +349,8 @@ __global__ void __launch_bounds__(256) star_align_kernel(MsaParams P) {
 #undef STEP_GEN
 #undef STEP_FAST
 #undef STEP_FAST2
-#undef ARM_DOWN
-#undef ARM_RIGHT
+#undef ARM_CORE_DOWN
+#undef ARM_CORE_RIGHT
 #undef STEP_VREGS
         {
             const int kf = m - t;

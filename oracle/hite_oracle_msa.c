@@ -10,7 +10,7 @@
  *
  * Definition (shared with the HIP kernels)
  *   centre = row 0 of the candidate; every other row is aligned to it by global
- *   Needleman-Wunsch, match +2 (equal, not 'N'), mismatch -2, linear gap -4, restricted to an
+ *   Needleman-Wunsch, match +2 (equal and one of A, C, G, T), mismatch -2, linear gap -4, restricted to an
  *   adaptive band of W=64 cells per anti-diagonal s=i+j (rows i in [t, t+63]):
  *     - t(0) = -32; after anti-diagonal s the band moves right (t same) if H[lane0] > H[lane63],
  *       down (t+1) if H[lane0] < H[lane63], on a tie down when s is even else right;
@@ -18,7 +18,7 @@
  *   every lane of the band evaluates the same recurrence every step: bases outside the sequences
  *   are sentinels that never match (so cells outside the matrix only ever hold "junk" that
  *   cannot beat a real score), values shifted in from outside the band are 0 and real scores
- *   are biased by 2^28 (H(0,0) = 2^28); an 'N' in the centre never matches.
+ *   are biased by 2^28 (H(0,0) = 2^28); 'N' (any byte other than A, C, G, T) never matches.
  *   Stored form (part of the definition, it fixes what the junk cells hold): H is shifted by +4
  *   per anti-diagonal (the recurrence adds +10 / +6 / 0 for match / mismatch / gap), scaled by 4,
  *   and the low two bits carry the winning operand: V = 4 H + tag, candidates
@@ -82,8 +82,7 @@ static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t
             int hd = down ? ppal[k] : (k >= 1 ? ppal[k - 1] : 0);
             int x = (i >= 1 && i <= m) ? a[i - 1] : 0xFF;
             int y = (j >= 1 && j <= n) ? b[j - 1] : 0xFE;
-            if (x == 'N') x = 0xFD;
-            int cd = hd + (x == y ? SC_MATCH : SC_MIS);
+            int cd = hd + ((x == y && (x == 'A' || x == 'C' || x == 'G' || x == 'T')) ? SC_MATCH : SC_MIS);
             int v4 = cd > hu ? cd : hu, v, d;
             if (hl > v4) v4 = hl;
             d = (v4 & 2) ? 0 : ((v4 & 1) ? 1 : 2);   /* junk cells may carry any tag; they are never on the path */
