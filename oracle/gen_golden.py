@@ -507,11 +507,96 @@ def gen_query_copies(U, tmp):
     dump("query_copies", cases)
 
 
+def gen_lib_dedup(U, tmp):
+    """panHiTE library de-duplication: process_blast_results_in_chunks -> process_chunk (extend_fragments) ->
+    cluster_sequences_from_chunks, and cons_from_mafft_v1, run through the reference on synthetic all-vs-all tables"""
+    import shutil
+    rng = np.random.default_rng(12202)
+    cases = []
+    for ci in range(36):
+        nseq = int(rng.integers(2, 12))
+        lens = [int(rng.integers(150, 2500)) for _ in range(nseq)]
+        thr = float(rng.choice([0.95, 0.8, 0.9]))
+        rows = []
+        for _ in range(int(rng.integers(1, 60))):
+            q, s = int(rng.integers(0, nseq)), int(rng.integers(0, nseq))
+            rev = rng.random() < 0.4
+            span = max(30, int(min(lens[q], lens[s]) * float(rng.choice([1.0, 0.97, 0.9, 0.5, 0.2]))))
+            span = min(span, lens[q], lens[s])
+            q0 = int(rng.integers(1, lens[q] - span + 2)); s0 = int(rng.integers(1, lens[s] - span + 2))
+            cuts = sorted(set([0, span] + [int(x) for x in rng.integers(5, max(6, span - 5), size=int(rng.integers(0, 4)))]))
+            for i in range(len(cuts) - 1):
+                a, b = cuts[i], cuts[i + 1]
+                jq = int(rng.choice([0, 0, 3, 20, 60])) if i else 0
+                js = int(rng.choice([0, 0, -2, 4, 30, 90])) if i else 0
+                fs, fe = q0 + a + jq, q0 + b - 1
+                if fe < fs:
+                    continue
+                if not rev:
+                    ss_, se_ = s0 + a + js, s0 + b - 1
+                else:
+                    ss_, se_ = s0 + span - a - 1 - js, s0 + span - b
+                if ss_ < 1 or se_ < 1:
+                    continue
+                rows.append((q, s, fs, fe, ss_, se_))
+                if rng.random() < 0.06:
+                    rows.append((q, s, fs, fe, ss_, se_))
+            if rng.random() < 0.3:
+                rows.append((q, q, 1, lens[q], 1, lens[q]))                      # self hit (skipped, counts for chunking)
+            if rng.random() < 0.1:
+                rows.append((q, q, 1, 80, lens[q] - 79, lens[q]))               # internal repeat of the same sequence
+        rows = [rows[i] for i in rng.permutation(len(rows))]
+        chunk_size = int(rng.choice([5_000_000, 7, 13])) if ci % 3 else 5_000_000
+        names = ["seq_%d" % i for i in range(nseq)]
+        work = os.path.join(tmp, "lib_%d" % ci)
+        os.makedirs(work, exist_ok=True)
+        bl = os.path.join(work, "all.out")
+        with open(bl, "w") as fh:
+            for (q, s, a, b, c, d) in rows:
+                fh.write("%s\t%s\t95.0\t%d\t0\t0\t%d\t%d\t%d\t%d\t1e-20\t200\n" % (names[q], names[s], b - a + 1, a, b, c, d))
+        files = U.process_blast_results_in_chunks(bl, work, "t", chunk_size=chunk_size)
+        qlens = {names[i]: lens[i] for i in range(nseq)}
+        lr_dir = os.path.join(work, "lr")
+        os.makedirs(lr_dir, exist_ok=True)
+        lr_files, recs = [], []
+        for k, f in enumerate(files):                                            # FMEA_new1_parallel_large, one job per file, in order
+            idx, res = U.process_chunk(qlens, [f], thr, k)
+            lr_files.append(U.save_data_in_chunks(res, lr_dir, idx))
+            for qn, lst in res.items():
+                for r in lst:
+                    recs.append([k, int(r[0][4:]), int(r[1]), int(r[2]), int(r[3][4:]), int(r[4]), int(r[5])])
+        contigs = {names[i]: "A" * lens[i] for i in range(nseq)}
+        clusters = U.cluster_sequences_from_chunks(lr_files, contigs, thr)
+        cases.append({"rows": [list(map(int, r)) for r in rows], "lens": lens, "thr": thr, "chunk_size": chunk_size, "recs": recs,
+                      "clusters": [sorted(int(x[4:]) for x in cl) for cl in clusters]})
+        shutil.rmtree(work)
+    cons = []
+    for ci in range(30):
+        R = int(rng.integers(1, 14)); L = int(rng.integers(5, 300))
+        base = casegen.rand_seq(rng, L)
+        mat = []
+        for r in range(R):
+            row = list(base if rng.random() < 0.8 else casegen.rand_seq(rng, L))
+            for c in range(L):
+                x = rng.random()
+                if x < 0.25:
+                    row[c] = "-"
+                elif x < 0.32:
+                    row[c] = "ACGTNacgt"[int(rng.integers(0, 9))]
+            mat.append("".join(row))
+        af = os.path.join(tmp, "cons_%d.maf.fa" % ci)
+        with open(af, "w") as fh:
+            for r, row in enumerate(mat):
+                fh.write(">r%d\n%s\n" % (r, row))
+        cons.append({"rows": mat, "cons": U.cons_from_mafft_v1(af)})
+    dump("lib_dedup", {"chain": cases, "cons": cons})
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -535,6 +620,8 @@ def main():
             gen_nonltr_prep(U)
         if "qcopies" in which:
             gen_query_copies(U, tmp)
+        if "libdedup" in which:
+            gen_lib_dedup(U, tmp)
 
 
 if __name__ == "__main__":

@@ -305,3 +305,52 @@ def query_copies(rows, qlen, slen, qcov, scov=0.0, qthr=200, sthr=200, max_copy=
                              _ptr(os_, i64p), _ptr(oe, i64p), _ptr(ol, i64p), _ptr(om, u8p))
     assert tot >= 0, tot
     return [[(int(osid[i]), int(os_[i]), int(oe[i]), int(ol[i]), "-" if om[i] else "+") for i in range(cf[q], cf[q + 1])] for q in range(nq)]
+
+
+def lib_chain(rows, lens, thr, chunk_size=0):
+    """process_blast_results_in_chunks + process_chunk: rows (q, s, qs, qe, ss, se) -> records [chunk, q, qs-1, qe, s, ss-1, se]"""
+    n = len(rows)
+    a32 = lambda k: np.array([r[k] for r in rows], dtype=np.int32)  # noqa: E731
+    a64 = lambda k: np.array([r[k] for r in rows], dtype=np.int64)  # noqa: E731
+    qid, sid, qs, qe, ss, se = a32(0), a32(1), a64(2), a64(3), a64(4), a64(5)
+    sl = np.array(lens, dtype=np.int64)
+    cap = n + 16
+    oc, oq, os_ = (np.zeros(cap, dtype=np.int32) for _ in range(3))
+    oqs, oqe, oss, ose = (np.zeros(cap, dtype=np.int64) for _ in range(4))
+    L = lib()
+    L.orc_lib_chain.restype = C.c_int64
+    k = L.orc_lib_chain(C.c_int64(n), _ptr(qid, i32p), _ptr(sid, i32p), _ptr(qs, i64p), _ptr(qe, i64p), _ptr(ss, i64p), _ptr(se, i64p),
+                        len(lens), _ptr(sl, i64p), C.c_double(thr), C.c_int64(chunk_size), C.c_int64(cap), _ptr(oc, i32p), _ptr(oq, i32p),
+                        _ptr(oqs, i64p), _ptr(oqe, i64p), _ptr(os_, i32p), _ptr(oss, i64p), _ptr(ose, i64p))
+    assert k >= 0, k
+    return [[int(oc[i]), int(oq[i]), int(oqs[i]), int(oqe[i]), int(os_[i]), int(oss[i]), int(ose[i])] for i in range(k)]
+
+
+def lib_cluster(recs, lens, thr):
+    """cluster_sequences_from_chunks on lib_chain records -> list of clusters (query first, then subjects in order added)"""
+    n = len(recs)
+    a32 = lambda k: np.array([r[k] for r in recs], dtype=np.int32)  # noqa: E731
+    a64 = lambda k: np.array([r[k] for r in recs], dtype=np.int64)  # noqa: E731
+    ch, q, qs, qe, s, ss, se = a32(0), a32(1), a64(2), a64(3), a32(4), a64(5), a64(6)
+    sl = np.array(lens, dtype=np.int64)
+    capc, capm = n + 2, 2 * n + 2
+    cf = np.zeros(capc + 1, dtype=np.int64)
+    mem = np.zeros(capm, dtype=np.int32)
+    L = lib()
+    L.orc_lib_cluster.restype = C.c_int64
+    k = L.orc_lib_cluster(C.c_int64(n), _ptr(ch, i32p), _ptr(q, i32p), _ptr(qs, i64p), _ptr(qe, i64p), _ptr(s, i32p), _ptr(ss, i64p),
+                          _ptr(se, i64p), len(lens), _ptr(sl, i64p), C.c_double(thr), C.c_int64(capc), C.c_int64(capm), _ptr(cf, i64p),
+                          _ptr(mem, i32p))
+    assert k >= 0, k
+    return [[int(x) for x in mem[cf[c]:cf[c + 1]]] for c in range(k)]
+
+
+def cons_majority(rows):
+    """cons_from_mafft_v1 on equal-length aligned rows -> consensus string"""
+    R, cols = len(rows), len(rows[0])
+    mat = np.frombuffer("".join(rows).encode(), dtype=np.uint8).copy()
+    out = np.zeros(cols + 1, dtype=np.uint8)
+    L = lib()
+    L.orc_cons_majority.restype = C.c_int64
+    k = L.orc_cons_majority(R, C.c_int64(cols), _ptr(mat, u8p), _ptr(out, u8p))
+    return out[:k].tobytes().decode()

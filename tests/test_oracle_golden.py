@@ -225,3 +225,18 @@ def test_query_copies_golden():
         assert O.query_copies(rows, qlen, c["slen"], c["qcov"], c["scov"]) == exp
         total += sum(len(e) for e in exp)
     assert total > 100
+
+
+def test_lib_dedup_golden():
+    """panHiTE library de-duplication (f-3): chain records, greedy clusters and majority consensus vs the reference's outputs"""
+    g = load_golden("lib_dedup")
+    nrec = ncl = 0
+    for c in g["chain"]:
+        recs = O.lib_chain(c["rows"], c["lens"], c["thr"], c["chunk_size"])
+        assert recs == c["recs"]
+        cl = O.lib_cluster(recs, c["lens"], c["thr"])
+        assert [sorted(x) for x in cl] == c["clusters"]
+        nrec += len(recs); ncl += len(cl)
+    assert nrec > 300 and ncl > 50
+    for c in g["cons"]:
+        assert O.cons_majority([r.upper() for r in c["rows"]]) == c["cons"]
