@@ -390,6 +390,63 @@ class Context:
         return [[(int(osid[i]), int(os_[i]), int(oe[i]), int(ol[i]), "-" if om[i] else "+") for i in range(cf[q], cf[q + 1])]
                 for q in range(nq)]
 
+    def lib_chain(self, qid, sid, qs, qe, ss, se, seq_len, threshold, chunk_size=0):
+        """library-vs-itself HSP table -> chain records [chunk, q, qs-1, qe, s, ss-1, se] in the reference's chunk-file order"""
+        n = len(qid)
+        a = lambda x, t: _arr(x, t)  # noqa: E731
+        qid, sid = a(qid, np.int32), a(sid, np.int32)
+        qs, qe, ss, se = a(qs, np.int64), a(qe, np.int64), a(ss, np.int64), a(se, np.int64)
+        sl = a(seq_len, np.int64)
+        cap = n + 16
+        oc, oq, os_ = (np.zeros(cap, dtype=np.int32) for _ in range(3))
+        oqs, oqe, oss, ose = (np.zeros(cap, dtype=np.int64) for _ in range(4))
+        nout = C.c_int64(0)
+        self._check(self.lib.hite_lib_chain(self.h, C.c_int64(n), _p(qid), _p(sid), _p(qs), _p(qe), _p(ss), _p(se), len(sl), _p(sl),
+                                            C.c_double(threshold), C.c_int64(chunk_size), C.c_int64(cap), _p(oc), _p(oq), _p(oqs), _p(oqe),
+                                            _p(os_), _p(oss), _p(ose), C.byref(nout)), "hite_lib_chain")
+        k = nout.value
+        return [[int(oc[i]), int(oq[i]), int(oqs[i]), int(oqe[i]), int(os_[i]), int(oss[i]), int(ose[i])] for i in range(k)]
+
+    def lib_cluster(self, recs, seq_len, threshold):
+        """chain records -> clusters (lists of sequence ids: the query, then the subjects in the order they joined)"""
+        n = len(recs)
+        col = lambda k, t: _arr([r[k] for r in recs], t)  # noqa: E731
+        ch, q, qs, qe, s, ss, se = col(0, np.int32), col(1, np.int32), col(2, np.int64), col(3, np.int64), col(4, np.int32), col(5, np.int64), col(6, np.int64)
+        sl = _arr(seq_len, np.int64)
+        capc, capm = n + 2, 2 * n + 2
+        cf = np.zeros(capc + 1, dtype=np.int64)
+        mem = np.zeros(capm, dtype=np.int32)
+        ncl = C.c_int64(0)
+        self._check(self.lib.hite_lib_cluster(C.c_int64(n), _p(ch), _p(q), _p(qs), _p(qe), _p(s), _p(ss), _p(se), len(sl), _p(sl),
+                                              C.c_double(threshold), C.c_int64(capc), C.c_int64(capm), _p(cf), _p(mem), C.byref(ncl)),
+                    "hite_lib_cluster")
+        return [[int(x) for x in mem[cf[c]:cf[c + 1]]] for c in range(ncl.value)]
+
+    def msa_consensus(self, alignments):
+        """batch of alignments (each a list of equal-length byte strings) -> list of consensus strings (cons_from_mafft_v1)"""
+        nmat = len(alignments)
+        if nmat == 0:
+            return []
+        rows = np.array([len(al) for al in alignments], dtype=np.int32)
+        cols = np.array([len(al[0]) for al in alignments], dtype=np.int64)
+        flat = []
+        for al in alignments:
+            for r in al:
+                rb = r.encode() if isinstance(r, str) else bytes(r)
+                if len(rb) != len(al[0]):
+                    raise ValueError("ragged alignment")
+                flat.append(rb)
+        buf = np.frombuffer(b"".join(flat) + b"\0" * 16, dtype=np.uint8)
+        moff = np.zeros(nmat + 1, dtype=np.int64)
+        np.cumsum(rows.astype(np.int64) * cols, out=moff[1:])
+        ooff = np.zeros(nmat + 1, dtype=np.int64)
+        np.cumsum(cols, out=ooff[1:])
+        cons = np.zeros(int(ooff[-1]) + 16, dtype=np.uint8)
+        clen = np.zeros(nmat, dtype=np.int64)
+        self._check(self.lib.hite_msa_consensus(self.h, nmat, _p(rows), _p(cols), _p(moff), _p(buf), _p(ooff), _p(cons), _p(clen)),
+                    "hite_msa_consensus")
+        return [cons[ooff[a]:ooff[a] + clen[a]].tobytes().decode("latin-1") for a in range(nmat)]
+
     def nonltr_prep(self, seqs, flank=50, win5=25):
         """search_polyA_TSD on a batch -> [(found_TSD, direct, tsd_start, tsd_len, lo, hi)]"""
         sb = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]

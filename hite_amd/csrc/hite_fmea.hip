@@ -17,6 +17,7 @@
 #include "hite_common.h"
 #include "hite_scan.h"
 #include "hite_sort.h"
+#include <vector>
 
 #define FM_MAXSEG 4096
 
@@ -878,5 +879,334 @@ extern "C" int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, c
         FCHK(hipMemcpy(o_minus, dom.p, nout, hipMemcpyDeviceToHost));
     }
     sorter_free(S);
+    return HITE_OK;
+}
+
+// =============================================================================================
+// Library de-duplication (panHiTE merge): the arithmetic HiTE owns between its external tools.
+//   hite_lib_chain      process_blast_results_in_chunks + process_chunk + extend_fragments
+//                       (/root/reference/module/Util.py:12146-12200, 11958-12003, 11869-11944)
+//   hite_lib_cluster    cluster_sequences_from_chunks (:12067-12115)  -- sequential by definition, host code
+//   hite_msa_consensus  cons_from_mafft_v1 (:12515-12566), batch of alignments
+// hite_lib_chain has the shape of the copy clustering above: chunk ids by a scan over the closing lines, first appearance
+// of (chunk, query) and (chunk, query, subject) by stable sorts, slots ordered by those, one thread per slot for the
+// extension sweep (every open fragment within reach is extended, the scan stops at the first one out of reach).
+// =============================================================================================
+struct LFrag { int qs, qe, ss, se; };
+
+__global__ void lc_check_kernel(int64_t n, const int32_t *__restrict__ qid, const int32_t *__restrict__ sid, const int64_t *__restrict__ qs,
+                                const int64_t *__restrict__ qe, const int64_t *__restrict__ ss, const int64_t *__restrict__ se, int nseq,
+                                int64_t chunk_size, int32_t *__restrict__ keep, int32_t *__restrict__ bnd, int *__restrict__ err) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int q = qid[i], s = sid[i];
+    bool bad = q < 0 || q >= nseq || s < 0 || s >= nseq || qs[i] < 0 || qe[i] < 0 || ss[i] < 0 || se[i] < 0 || qs[i] >= 0x7fffffff ||
+               qe[i] >= 0x7fffffff || ss[i] >= 0x7fffffff || se[i] >= 0x7fffffff;
+    if (bad) atomicExch(err, 1);
+    const bool self = q == s && qs[i] == ss[i] && qe[i] == se[i];               // :12186
+    keep[i] = !self && !bad;
+    bnd[i] = !self && !bad && (i + 1) % chunk_size == 0;                         // :12193 (skipped lines `continue` past it)
+}
+// kept lines in file order: val = original index, key = (chunk, query)
+__global__ void lc_qkey_kernel(int64_t n, const int32_t *__restrict__ keep, const int64_t *__restrict__ kpos, const int64_t *__restrict__ chunk,
+                               const int32_t *__restrict__ qid, int q_bits, unsigned long long *__restrict__ key, unsigned *__restrict__ val) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    key[kpos[i]] = ((unsigned long long)chunk[i] << q_bits) | (unsigned)qid[i];
+    val[kpos[i]] = (unsigned)i;
+}
+// second round: key = (first line of the (chunk, query) run, subject)
+__global__ void lc_pkey_kernel(int64_t n, const int32_t *__restrict__ keep, const int64_t *__restrict__ kpos, const unsigned *__restrict__ fq,
+                               const int32_t *__restrict__ sid, int q_bits, unsigned long long *__restrict__ key, unsigned *__restrict__ val) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !keep[i]) return;
+    key[kpos[i]] = ((unsigned long long)fq[i] << q_bits) | (unsigned)sid[i];
+    val[kpos[i]] = (unsigned)i;
+}
+__global__ void lc_keys_kernel(int64_t m, const unsigned *__restrict__ lines, const int64_t *__restrict__ ss, const int64_t *__restrict__ se,
+                               const unsigned *__restrict__ fq, const unsigned *__restrict__ fp, unsigned long long *__restrict__ k_e,
+                               unsigned long long *__restrict__ k_s, unsigned long long *__restrict__ k_g, unsigned *__restrict__ val) {
+    int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const unsigned i = lines[j];
+    const bool rev = ss[i] > se[i];                                                // forward: s_start <= s_end  :11985
+    unsigned sk = rev ? (unsigned)(0x7fffffff - (int)ss[i]) : (unsigned)ss[i];
+    unsigned ek = rev ? (unsigned)(0x7fffffff - (int)se[i]) : (unsigned)se[i];
+    k_e[j] = ek;
+    k_s[j] = ((unsigned long long)(rev ? 1 : 0) << 31) | sk;
+    k_g[j] = ((unsigned long long)fq[i] << 31) | fp[i];
+    val[j] = i;
+}
+// one thread per slot: extend_fragments (:11886-11944).  Long fragments are built in place at lf[slot_start ...].
+__global__ void lc_extend_kernel(int64_t nslots, const int64_t *__restrict__ slot_start, const unsigned *__restrict__ order,
+                                 const int32_t *__restrict__ qid, const int64_t *__restrict__ qs, const int64_t *__restrict__ qe,
+                                 const int64_t *__restrict__ ss, const int64_t *__restrict__ se, const int64_t *__restrict__ seq_len,
+                                 double one_minus_thr, LFrag *__restrict__ lf, int32_t *__restrict__ isrec) {
+    int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nslots) return;
+    const int64_t b = slot_start[g], e = slot_start[g + 1];
+    const unsigned h0 = order[b];
+    const bool fwd = ss[h0] <= se[h0];
+    const double skip_gap = (double)seq_len[qid[h0]] * one_minus_thr;              // :11978
+    int64_t nl = 0;
+    for (int64_t t = b; t < e; t++) {
+        const unsigned h = order[t];
+        const int cqs = (int)qs[h], cqe = (int)qe[h], css = (int)ss[h], cse = (int)se[h];
+        bool upd = false;
+        for (int64_t u = nl - 1; u >= 0; u--) {
+            LFrag p = lf[b + u];
+            if (fwd) {
+                if ((double)(css - p.se) >= skip_gap) break;
+                if ((double)(cqs - p.qe) < skip_gap && cqe > p.qe && cse > p.se) {
+                    p.qs = p.qs < cqs ? p.qs : cqs; p.qe = cqe; p.ss = p.ss < css ? p.ss : css; p.se = cse;
+                    lf[b + u] = p; upd = true;
+                }
+            } else {
+                if ((double)(p.se - css) >= skip_gap) break;
+                if ((double)(cqs - p.qe) < skip_gap && cqe > p.qe && cse < p.se) {
+                    p.qe = cqe; p.ss = p.ss > css ? p.ss : css; p.se = cse;
+                    lf[b + u] = p; upd = true;
+                }
+            }
+        }
+        if (!upd) { LFrag p; p.qs = cqs; p.qe = cqe; p.ss = css; p.se = cse; lf[b + nl] = p; nl++; }
+    }
+    for (int64_t u = b; u < e; u++) isrec[u] = u - b < nl;
+}
+__global__ void lc_emit_kernel(int64_t m, const int32_t *__restrict__ isrec, const int64_t *__restrict__ pos, const int32_t *__restrict__ sflag,
+                               const int64_t *__restrict__ spos, const int64_t *__restrict__ slot_start, const unsigned *__restrict__ order,
+                               const LFrag *__restrict__ lf, const int64_t *__restrict__ chunk, const int32_t *__restrict__ qid,
+                               const int32_t *__restrict__ sid, int64_t cap, int32_t *__restrict__ o_chunk, int32_t *__restrict__ o_q,
+                               int64_t *__restrict__ o_qs, int64_t *__restrict__ o_qe, int32_t *__restrict__ o_s, int64_t *__restrict__ o_ss,
+                               int64_t *__restrict__ o_se) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || !isrec[i]) return;
+    const int64_t o = pos[i];
+    if (o >= cap) return;
+    const int64_t slot = spos[i] + sflag[i] - 1;
+    const unsigned h0 = order[slot_start[slot]];
+    const LFrag p = lf[i];
+    o_chunk[o] = (int32_t)chunk[h0]; o_q[o] = qid[h0]; o_s[o] = sid[h0];
+    o_qs[o] = (int64_t)p.qs - 1; o_qe[o] = p.qe; o_ss[o] = (int64_t)p.ss - 1; o_se[o] = p.se;     // :11996-11999
+}
+
+extern "C" int hite_lib_chain(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe,
+                              const int64_t *ss, const int64_t *se, int32_t nseq, const int64_t *seq_len, double threshold,
+                              int64_t chunk_size, int64_t cap, int32_t *o_chunk, int32_t *o_q, int64_t *o_qs, int64_t *o_qe, int32_t *o_s,
+                              int64_t *o_ss, int64_t *o_se, int64_t *n_out) {
+    if (!ctx || n < 0 || n >= 0x7fffffff || nseq <= 0 || !seq_len || !n_out) return HITE_EINVAL;
+    *n_out = 0;
+    if (n == 0) return HITE_OK;
+    if (chunk_size <= 0) chunk_size = n;
+    int q_bits = 1; while ((1ll << q_bits) < (long long)nseq + 1) q_bits++;
+    int c_bits = 1; while ((1ll << c_bits) < n / chunk_size + 2) c_bits++;
+    if (c_bits + q_bits > 63 || 31 + q_bits > 63) return HITE_EINVAL;
+    if (hipSetDevice(ctx->device) != hipSuccess) return HITE_EHIP;
+    hipStream_t st = nullptr;
+    Sorter S;
+    FBuf dq, dsg, dqs, dqe, dss, dse, dsl, derr, dbs, dkeep, dbnd, dkpos, dchunk, dkey, dval, dflag, dpos, dgf, dfq, dfp, dke, dks, dkg, dtmpk,
+        dslotstart, dlf, disrec, dopos, doc, doq, dos, doqs, doqe, doss, dose;
+    FCHK(dq.up(qid, n * 4)); FCHK(dsg.up(sid, n * 4)); FCHK(dqs.up(qs, n * 8)); FCHK(dqe.up(qe, n * 8)); FCHK(dss.up(ss, n * 8));
+    FCHK(dse.up(se, n * 8)); FCHK(dsl.up(seq_len, (size_t)nseq * 8));
+    FCHK(derr.alloc(16)); FCHK(dbs.alloc((size_t)scan_tmp_elems(n + 16) * 8)); FCHK(dkeep.alloc((n + 1) * 4)); FCHK(dbnd.alloc((n + 1) * 4));
+    FCHK(dkpos.alloc((n + 2) * 8)); FCHK(dchunk.alloc((n + 2) * 8));
+    FCHK(hipMemset(derr.p, 0, 16));
+    hipLaunchKernelGGL(lc_check_kernel, GRID(n), 0, st, n, (int32_t *)dq.p, (int32_t *)dsg.p, (int64_t *)dqs.p, (int64_t *)dqe.p, (int64_t *)dss.p,
+                       (int64_t *)dse.p, (int)nseq, chunk_size, (int32_t *)dkeep.p, (int32_t *)dbnd.p, (int *)derr.p);
+    int herr = 0;
+    FCHK(hipMemcpy(&herr, derr.p, 4, hipMemcpyDeviceToHost));
+    if (herr) return HITE_EINVAL;   // id or coordinate out of range
+    QSCAN(dkeep.p, n, dkpos.p);
+    QSCAN(dbnd.p, n, dchunk.p);     // chunk of line i = closing lines before it
+    int64_t m = 0;
+    FCHK(hipMemcpy(&m, (int64_t *)dkpos.p + n, 8, hipMemcpyDeviceToHost));
+    if (m == 0) return HITE_OK;
+    FCHK(dkey.alloc((m + 1) * 8)); FCHK(dval.alloc((m + 1) * 4)); FCHK(dflag.alloc((m + 1) * 4)); FCHK(dpos.alloc((m + 2) * 8));
+    FCHK(dgf.alloc((m + 1) * 4)); FCHK(dfq.alloc((n + 1) * 4)); FCHK(dfp.alloc((n + 1) * 4)); FCHK(dke.alloc((m + 1) * 8));
+    FCHK(dks.alloc((m + 1) * 8)); FCHK(dkg.alloc((m + 1) * 8)); FCHK(dtmpk.alloc((m + 1) * 8));
+    if (sorter_init(S, ctx, st, m)) { sorter_free(S); return HITE_EHIP; }
+    // first appearance of every (chunk, query), then of every (chunk, query, subject)
+    hipLaunchKernelGGL(lc_qkey_kernel, GRID(n), 0, st, n, (int32_t *)dkeep.p, (int64_t *)dkpos.p, (int64_t *)dchunk.p, (int32_t *)dq.p, q_bits,
+                       (unsigned long long *)dkey.p, (unsigned *)dval.p);
+    QSORT(dkey.p, dval.p, m, c_bits + q_bits);
+    hipLaunchKernelGGL(qc_head_kernel, GRID(m), 0, st, m, (unsigned long long *)dkey.p, (int32_t *)dflag.p);
+    QSCAN(dflag.p, m, dpos.p);
+    hipLaunchKernelGGL(qc_run_first_kernel, GRID(m), 0, st, m, (int32_t *)dflag.p, (int64_t *)dpos.p, (unsigned *)dval.p, (unsigned *)dgf.p);
+    hipLaunchKernelGGL(qc_first_kernel, GRID(m), 0, st, m, (int32_t *)dflag.p, (int64_t *)dpos.p, (unsigned *)dval.p, (unsigned *)dgf.p,
+                       (unsigned *)dfq.p);
+    hipLaunchKernelGGL(lc_pkey_kernel, GRID(n), 0, st, n, (int32_t *)dkeep.p, (int64_t *)dkpos.p, (unsigned *)dfq.p, (int32_t *)dsg.p, q_bits,
+                       (unsigned long long *)dkey.p, (unsigned *)dval.p);
+    QSORT(dkey.p, dval.p, m, 31 + q_bits);
+    hipLaunchKernelGGL(qc_head_kernel, GRID(m), 0, st, m, (unsigned long long *)dkey.p, (int32_t *)dflag.p);
+    QSCAN(dflag.p, m, dpos.p);
+    hipLaunchKernelGGL(qc_run_first_kernel, GRID(m), 0, st, m, (int32_t *)dflag.p, (int64_t *)dpos.p, (unsigned *)dval.p, (unsigned *)dgf.p);
+    hipLaunchKernelGGL(qc_first_kernel, GRID(m), 0, st, m, (int32_t *)dflag.p, (int64_t *)dpos.p, (unsigned *)dval.p, (unsigned *)dgf.p,
+                       (unsigned *)dfp.p);
+    // slots = ((chunk, query) by first line, subject by first line, strand), sorted by strand-aware (s_start, s_end).
+    // dval currently lists the kept lines (some order): rebuild it in file order through kpos for stable sorts.
+    hipLaunchKernelGGL(lc_qkey_kernel, GRID(n), 0, st, n, (int32_t *)dkeep.p, (int64_t *)dkpos.p, (int64_t *)dchunk.p, (int32_t *)dq.p, q_bits,
+                       (unsigned long long *)dkey.p, (unsigned *)dgf.p);          // dgf = kept lines in file order (dkey is scratch here)
+    hipLaunchKernelGGL(lc_keys_kernel, GRID(m), 0, st, m, (unsigned *)dgf.p, (int64_t *)dss.p, (int64_t *)dse.p, (unsigned *)dfq.p,
+                       (unsigned *)dfp.p, (unsigned long long *)dke.p, (unsigned long long *)dks.p, (unsigned long long *)dkg.p,
+                       (unsigned *)dval.p);
+    // the keys are indexed by compacted position j; sort positions, compose with the line list at the end
+    hipLaunchKernelGGL(fm_iota_kernel, GRID(m), 0, st, m, (unsigned *)dval.p);
+    QSORT(dke.p, dval.p, m, 32);
+    hipLaunchKernelGGL(fm_permute_u64_kernel, GRID(m), 0, st, m, (unsigned *)dval.p, (unsigned long long *)dks.p, (unsigned long long *)dtmpk.p);
+    QSORT(dtmpk.p, dval.p, m, 32);
+    hipLaunchKernelGGL(fm_permute_u64_kernel, GRID(m), 0, st, m, (unsigned *)dval.p, (unsigned long long *)dkg.p, (unsigned long long *)dtmpk.p);
+    QSORT(dtmpk.p, dval.p, m, 62);
+    FCHK(dslotstart.alloc((m + 2) * 8));   // order = lines[val]
+    {
+        FBuf dorder;
+        FCHK(dorder.alloc((m + 1) * 4));
+        hipLaunchKernelGGL(fm_compose_kernel, GRID(m), 0, st, m, (unsigned *)dval.p, (unsigned *)dgf.p, (unsigned *)dorder.p);
+        FCHK(hipMemcpyAsync(dval.p, dorder.p, (size_t)m * 4, hipMemcpyDeviceToDevice, st));
+        FCHK(hipStreamSynchronize(st));
+    }
+    hipLaunchKernelGGL(qc_slot_head_kernel, GRID(m), 0, st, m, (unsigned long long *)dtmpk.p, (unsigned *)dval.p, (int64_t *)dss.p,
+                       (int64_t *)dse.p, (int32_t *)dflag.p);
+    QSCAN(dflag.p, m, dpos.p);
+    int64_t nslots = 0;
+    FCHK(hipMemcpy(&nslots, (int64_t *)dpos.p + m, 8, hipMemcpyDeviceToHost));
+    hipLaunchKernelGGL(qc_starts_kernel, GRID(m), 0, st, m, (int32_t *)dflag.p, (int64_t *)dpos.p, (int64_t *)dslotstart.p);
+    FCHK(dlf.alloc((m + 1) * sizeof(LFrag))); FCHK(disrec.alloc((m + 1) * 4)); FCHK(dopos.alloc((m + 2) * 8));
+    hipLaunchKernelGGL(lc_extend_kernel, GRID(nslots), 0, st, nslots, (int64_t *)dslotstart.p, (unsigned *)dval.p, (int32_t *)dq.p,
+                       (int64_t *)dqs.p, (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, (int64_t *)dsl.p, 1 - threshold,
+                       (LFrag *)dlf.p, (int32_t *)disrec.p);
+    QSCAN(disrec.p, m, dopos.p);
+    int64_t nout = 0;
+    FCHK(hipMemcpy(&nout, (int64_t *)dopos.p + m, 8, hipMemcpyDeviceToHost));
+    *n_out = nout;
+    if (nout > cap) { sorter_free(S); return HITE_ECAP; }
+    if (nout > 0) {
+        if (!o_chunk || !o_q || !o_qs || !o_qe || !o_s || !o_ss || !o_se) { sorter_free(S); return HITE_EINVAL; }
+        FCHK(doc.alloc(nout * 4)); FCHK(doq.alloc(nout * 4)); FCHK(dos.alloc(nout * 4)); FCHK(doqs.alloc(nout * 8)); FCHK(doqe.alloc(nout * 8));
+        FCHK(doss.alloc(nout * 8)); FCHK(dose.alloc(nout * 8));
+        hipLaunchKernelGGL(lc_emit_kernel, GRID(m), 0, st, m, (int32_t *)disrec.p, (int64_t *)dopos.p, (int32_t *)dflag.p, (int64_t *)dpos.p,
+                           (int64_t *)dslotstart.p, (unsigned *)dval.p, (LFrag *)dlf.p, (int64_t *)dchunk.p, (int32_t *)dq.p, (int32_t *)dsg.p,
+                           nout, (int32_t *)doc.p, (int32_t *)doq.p, (int64_t *)doqs.p, (int64_t *)doqe.p, (int32_t *)dos.p, (int64_t *)doss.p,
+                           (int64_t *)dose.p);
+        FCHK(hipGetLastError());
+        FCHK(hipMemcpy(o_chunk, doc.p, nout * 4, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(o_q, doq.p, nout * 4, hipMemcpyDeviceToHost));
+        FCHK(hipMemcpy(o_s, dos.p, nout * 4, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(o_qs, doqs.p, nout * 8, hipMemcpyDeviceToHost));
+        FCHK(hipMemcpy(o_qe, doqe.p, nout * 8, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(o_ss, doss.p, nout * 8, hipMemcpyDeviceToHost));
+        FCHK(hipMemcpy(o_se, dose.p, nout * 8, hipMemcpyDeviceToHost));
+    }
+    sorter_free(S);
+    return HITE_OK;
+}
+
+// cluster_sequences_from_chunks (:12067-12115): greedy, every decision depends on the set built so far -> host loop.
+// Records as hite_lib_chain emits them; a (chunk, query) run is a maximal stretch of equal (chunk, q).
+extern "C" int hite_lib_cluster(int64_t nrec, const int32_t *chunk, const int32_t *q, const int64_t *qs, const int64_t *qe, const int32_t *s,
+                                const int64_t *ss, const int64_t *se, int32_t nseq, const int64_t *seq_len, double threshold, int64_t cap_cl,
+                                int64_t cap_mem, int64_t *cl_first, int32_t *members, int64_t *n_cl) {
+    if (nrec < 0 || nseq <= 0 || !seq_len || !cl_first || !n_cl || (nrec > 0 && (!chunk || !q || !qs || !qe || !s || !ss || !se || !members)))
+        return HITE_EINVAL;
+    std::vector<uint8_t> redundant((size_t)nseq, 0);
+    int64_t ncl = 0, nm = 0;
+    cl_first[0] = 0;
+    *n_cl = 0;
+    for (int64_t i = 0; i < nrec;) {
+        int64_t j = i;
+        while (j < nrec && chunk[j] == chunk[i] && q[j] == q[i]) j++;
+        const int query = q[i];
+        if (query < 0 || query >= nseq) return HITE_EINVAL;
+        if (!redundant[query]) {                                                          // :12084
+            if (ncl >= cap_cl || nm >= cap_mem) return HITE_ECAP;
+            members[nm++] = query;
+            for (int64_t t = i; t < j; t++) {
+                const int sub = s[t];
+                if (sub < 0 || sub >= nseq) return HITE_EINVAL;
+                if (redundant[sub]) continue;                                             // :12098
+                const int64_t ql = qe[t] > qs[t] ? qe[t] - qs[t] : qs[t] - qe[t], sl = se[t] > ss[t] ? se[t] - ss[t] : ss[t] - se[t];
+                if ((double)ql / (double)seq_len[query] >= threshold || (double)sl / (double)seq_len[sub] >= threshold) {   // :12064
+                    redundant[sub] = 1;
+                    if (sub != query) {
+                        if (nm >= cap_mem) return HITE_ECAP;
+                        members[nm++] = sub;
+                    }
+                }
+            }
+            cl_first[++ncl] = nm;
+        }
+        i = j;
+    }
+    *n_cl = ncl;
+    return HITE_OK;
+}
+
+// cons_from_mafft_v1 (:12515-12566): one block per alignment; a column keeps its most frequent non-gap character if that
+// count exceeds R / 2.  A strict majority over all R entries is the Boyer-Moore candidate of the column ('-' voting as an
+// ordinary symbol); a second pass over the rows counts it.  Kept columns are compacted in order with a block scan.
+__global__ void __launch_bounds__(256) msa_consensus_kernel(int nmat, const int32_t *__restrict__ rows, const int64_t *__restrict__ cols,
+                                                            const int64_t *__restrict__ mat_off, const uint8_t *__restrict__ mats,
+                                                            const int64_t *__restrict__ out_off, uint8_t *__restrict__ cons,
+                                                            int64_t *__restrict__ cons_len) {
+    __shared__ int s_scan[256];
+    __shared__ int64_t s_base;
+    const int a = blockIdx.x;
+    const int R = rows[a];
+    const int64_t C = cols[a];
+    const uint8_t *mat = mats + mat_off[a];
+    uint8_t *out = cons + out_off[a];
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int64_t c0 = 0; c0 < C; c0 += 256) {
+        const int64_t c = c0 + threadIdx.x;
+        int keep = 0;
+        uint8_t ch = 0;
+        if (c < C) {
+            int cand = -1, cnt = 0;
+            for (int r = 0; r < R; r++) {
+                const int x = mat[(int64_t)r * C + c];
+                if (cnt == 0) { cand = x; cnt = 1; } else if (x == cand) cnt++; else cnt--;
+            }
+            if (cand >= 0 && cand != '-') {
+                int tot = 0;
+                for (int r = 0; r < R; r++) tot += mat[(int64_t)r * C + c] == cand;
+                keep = tot > R / 2;                                                      // :12559
+                ch = (uint8_t)cand;
+            }
+        }
+        s_scan[threadIdx.x] = keep;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            int v = threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+            __syncthreads();
+            s_scan[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int64_t base = s_base;
+        if (keep) out[base + s_scan[threadIdx.x] - 1] = ch;
+        __syncthreads();
+        if (threadIdx.x == 255) s_base = base + s_scan[255];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cons_len[a] = s_base;
+}
+
+extern "C" int hite_msa_consensus(hite_ctx *ctx, int32_t nmat, const int32_t *rows, const int64_t *cols, const int64_t *mat_off,
+                                  const uint8_t *mats, const int64_t *out_off, uint8_t *cons, int64_t *cons_len) {
+    if (!ctx || nmat < 0 || (nmat > 0 && (!rows || !cols || !mat_off || !mats || !out_off || !cons || !cons_len))) return HITE_EINVAL;
+    if (nmat == 0) return HITE_OK;
+    int64_t total_out = 0;
+    for (int a = 0; a < nmat; a++) {
+        if (rows[a] <= 0 || cols[a] < 0 || mat_off[a + 1] - mat_off[a] != (int64_t)rows[a] * cols[a] || out_off[a] < 0) return HITE_EINVAL;
+        if (out_off[a] + cols[a] > total_out) total_out = out_off[a] + cols[a];
+    }
+    if (hipSetDevice(ctx->device) != hipSuccess) return HITE_EHIP;
+    hipStream_t st = nullptr;
+    Sorter S;   // (FCHK frees it)
+    FBuf dr, dc, dmo, dm, doo, dcons, dlen;
+    FCHK(dr.up(rows, (size_t)nmat * 4)); FCHK(dc.up(cols, (size_t)nmat * 8)); FCHK(dmo.up(mat_off, ((size_t)nmat + 1) * 8));
+    FCHK(dm.up(mats, (size_t)mat_off[nmat])); FCHK(doo.up(out_off, (size_t)nmat * 8)); FCHK(dcons.alloc((size_t)total_out + 16));
+    FCHK(dlen.alloc((size_t)nmat * 8));
+    hipLaunchKernelGGL(msa_consensus_kernel, dim3((unsigned)nmat), dim3(256), 0, st, (int)nmat, (int32_t *)dr.p, (int64_t *)dc.p, (int64_t *)dmo.p,
+                       (uint8_t *)dm.p, (int64_t *)doo.p, (uint8_t *)dcons.p, (int64_t *)dlen.p);
+    FCHK(hipGetLastError());
+    FCHK(hipMemcpy(cons_len, dlen.p, (size_t)nmat * 8, hipMemcpyDeviceToHost));
+    if (total_out > 0) FCHK(hipMemcpy(cons, dcons.p, (size_t)total_out, hipMemcpyDeviceToHost));
     return HITE_OK;
 }

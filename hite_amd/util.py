@@ -337,6 +337,49 @@ def get_copies_v1(blastnResults_path, query_path, subject_path, query_coverage=0
     return get_query_copies(list(query_records.items()), query_contigs, subject_path, query_coverage, subject_coverage, device=device)
 
 
+def lib_longest_repeats(blastnResults_path, redundant_ltr, coverage_threshold, chunk_size=5_000_000, device=0):
+    """process_blast_results_in_chunks + FMEA_new1_parallel_large (Util.py:12146, 12006) in one device call ->
+    [{query_name: [(query_name, q_start-1, q_end, subject_name, s_start-1, s_end)]}] one dict per chunk, in chunk order"""
+    names, contigs = read_fasta(redundant_ltr)
+    idx = {name: i for i, name in enumerate(names)}
+    qid, sid, qs, qe, ss, se = [], [], [], [], [], []
+    with open(blastnResults_path) as f_r:
+        for line in f_r:
+            parts = line.rstrip("\n").split("\t")
+            qid.append(idx[parts[0]]); sid.append(idx[parts[1]])
+            qs.append(int(parts[6])); qe.append(int(parts[7])); ss.append(int(parts[8])); se.append(int(parts[9]))
+    lens = [len(contigs[name]) for name in names]
+    recs = get_ctx(device).lib_chain(qid, sid, qs, qe, ss, se, lens, coverage_threshold, chunk_size)
+    chunks = []
+    for (ch, q, a, b, s, c, d) in recs:
+        while len(chunks) <= ch:
+            chunks.append({})
+        chunks[ch].setdefault(names[q], []).append((names[q], a, b, names[s], c, d))
+    return chunks
+
+
+def cluster_sequences_from_chunks(longest_repeats_chunks, contigs, coverage_threshold, device=0):
+    """Util.py:12067 -- chunks as lib_longest_repeats returns them (the reference reads the same dicts from JSON files) ->
+    list of clusters; each cluster is a list (query first) where the reference builds a set"""
+    names = list(contigs.keys())
+    idx = {name: i for i, name in enumerate(names)}
+    recs = []
+    for ch, chunk in enumerate(longest_repeats_chunks):
+        for query_name, lst in chunk.items():
+            for r in lst:
+                recs.append((ch, idx[query_name], r[1], r[2], idx[r[3]], r[4], r[5]))
+    lens = [len(contigs[name]) for name in names]
+    return [[names[i] for i in cl] for cl in get_ctx(device).lib_cluster(recs, lens, coverage_threshold)]
+
+
+def cons_from_mafft_v1(align_file, device=0):
+    """Util.py:12515 -- strict-majority consensus of an aligned FASTA (None for an empty file)"""
+    align_names, align_contigs = read_fasta(align_file)
+    if len(align_names) <= 0:
+        return None
+    return get_ctx(device).msa_consensus([[align_contigs[name] for name in align_names]])[0]
+
+
 def mask_genome_intactTE(TE_lib, genome_path, work_dir=None, thread=1, ref_index=0, debug=0, device=0):
     """mask_genome_intactTE (Util.py:6389-6431): the full-length copies (coverage >= 0.95 of the library sequence) of the
     TEs found so far are replaced by N in the chunk, written to <genome_path>.masked.  The copies come from the build's

@@ -182,6 +182,30 @@ int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_
                       int64_t *copy_first, int32_t *o_sid, int64_t *o_s, int64_t *o_e, int64_t *o_len, uint8_t *o_minus,
                       int64_t *n_out);
 
+/* ---- library de-duplication (panHiTE merge) --- the arithmetic between the external tools of deredundant_for_LTR_v5 -----
+ * hite_lib_chain: process_blast_results_in_chunks + process_chunk + extend_fragments (Util.py:12146-12200, 11958-12003,
+ * 11869-11944).  n blast6 lines of a library-vs-itself search in file order (host arrays), ids into seq_len[nseq],
+ * 1-based inclusive coordinates; a line with qid == sid, qs == ss, qe == se is skipped.  chunk_size as in the reference
+ * (<= 0: one chunk): a chunk is closed by a kept line whose 1-based number is a multiple of chunk_size, chains never
+ * cross chunks.  skip_gap = seq_len[query] * (1 - threshold).  Output records in the order of the reference's chunk
+ * files (chunk, query by first appearance, subject by first appearance, forward then reverse, creation order):
+ * (o_chunk, o_q, o_qs = q_start - 1, o_qe, o_s, o_ss = s_start - 1, o_se); *n_out records, HITE_ECAP if > cap. */
+int hite_lib_chain(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe,
+                   const int64_t *ss, const int64_t *se, int32_t nseq, const int64_t *seq_len, double threshold, int64_t chunk_size,
+                   int64_t cap, int32_t *o_chunk, int32_t *o_q, int64_t *o_qs, int64_t *o_qe, int32_t *o_s, int64_t *o_ss,
+                   int64_t *o_se, int64_t *n_out);
+/* hite_lib_cluster: cluster_sequences_from_chunks (Util.py:12067-12115) on the records above (host code: the greedy
+ * pass is sequential by definition).  Cluster c = members[cl_first[c] .. cl_first[c+1]): its query, then the subjects in
+ * the order they joined (the reference keeps a Python set: membership is the contract).  *n_cl clusters. */
+int hite_lib_cluster(int64_t nrec, const int32_t *chunk, const int32_t *q, const int64_t *qs, const int64_t *qe, const int32_t *s,
+                     const int64_t *ss, const int64_t *se, int32_t nseq, const int64_t *seq_len, double threshold, int64_t cap_cl,
+                     int64_t cap_mem, int64_t *cl_first, int32_t *members, int64_t *n_cl);
+/* hite_msa_consensus: cons_from_mafft_v1 (Util.py:12515-12566) for a batch of alignments.  Alignment a = rows[a] x cols[a]
+ * bytes, row-major, at mats + mat_off[a] (mat_off[nmat] = total); a column contributes its most frequent non-gap byte if
+ * that count > rows[a] / 2.  Consensus a is written at cons + out_off[a] (reserve cols[a] bytes), length cons_len[a]. */
+int hite_msa_consensus(hite_ctx *ctx, int32_t nmat, const int32_t *rows, const int64_t *cols, const int64_t *mat_off,
+                       const uint8_t *mats, const int64_t *out_off, uint8_t *cons, int64_t *cons_len);
+
 /* ---- k-mer TSD seed matching --- search_confident_tir_v4  Util.py:7734-7845 -------------------------
  * batch of flanked candidates (CSR); the raw boundaries are (flank+1, len-flank), 1-based, as
  * search_confident_tir_batch_v1 passes them (Util.py:6550), tsd_search_distance = flank (<= 63).

@@ -810,3 +810,92 @@ def test_get_copies_v1_file(ctx, tmp_path):
     assert set(got) == {"TE_%d" % o for o in order}
     for orig, q in order.items():
         assert got["TE_%d" % orig] == [("chr%d" % c[0],) + c[1:] for c in exp[q]]
+
+
+def _random_lib_table(rng, nseq, nhits):
+    lens = [int(rng.integers(120, 6000)) for _ in range(nseq)]
+    rows = []
+    for _ in range(nhits):
+        q, s = int(rng.integers(0, nseq)), int(rng.integers(0, nseq))
+        rev = rng.random() < 0.4
+        span = max(25, int(min(lens[q], lens[s]) * float(rng.choice([1.0, 0.97, 0.9, 0.5, 0.1]))))
+        span = min(span, lens[q], lens[s])
+        q0, s0 = int(rng.integers(1, lens[q] - span + 2)), int(rng.integers(1, lens[s] - span + 2))
+        cuts = sorted(set([0, span] + [int(x) for x in rng.integers(5, max(6, span - 5), size=int(rng.integers(0, 5)))]))
+        for i in range(len(cuts) - 1):
+            a, b = cuts[i], cuts[i + 1]
+            jq = int(rng.choice([0, 0, 3, 20, 60, 200])) if i else 0
+            js = int(rng.choice([0, 0, -2, 4, 30, 90, 300])) if i else 0
+            fs, fe = q0 + a + jq, q0 + b - 1
+            ss_, se_ = (s0 + a + js, s0 + b - 1) if not rev else (s0 + span - a - 1 - js, s0 + span - b)
+            if fe < fs or ss_ < 1 or se_ < 1:
+                continue
+            rows.append((q, s, fs, fe, ss_, se_))
+            if rng.random() < 0.05:
+                rows.append((q, s, fs, fe, ss_, se_))
+        if rng.random() < 0.2:
+            rows.append((q, q, 1, lens[q], 1, lens[q]))
+    return [rows[i] for i in rng.permutation(len(rows))], lens
+
+
+def test_lib_dedup(ctx, tmp_path):
+    """panHiTE library de-duplication pieces (f-3): chain records / clusters / consensus vs reference goldens and the oracle"""
+    from hite_amd import util
+
+    g = load_golden("lib_dedup")
+    for ci, c in enumerate(g["chain"]):
+        cols = list(zip(*c["rows"])) if c["rows"] else [[]] * 6
+        recs = ctx.lib_chain(cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], c["lens"], c["thr"], c["chunk_size"])
+        assert recs == c["recs"], ci
+        assert [sorted(x) for x in ctx.lib_cluster(recs, c["lens"], c["thr"])] == c["clusters"]
+    # file-level mirrors on one golden case
+    c = g["chain"][3]
+    names = ["seq_%d" % i for i in range(len(c["lens"]))]
+    fa, bl = tmp_path / "lib.fa", tmp_path / "lib.out"
+    with open(fa, "w") as fh:
+        for nme, L in zip(names, c["lens"]):
+            fh.write(">%s\n%s\n" % (nme, "A" * L))
+    with open(bl, "w") as fh:
+        for (q, s, a, b, cc, d) in c["rows"]:
+            fh.write("%s\t%s\t95.0\t%d\t0\t0\t%d\t%d\t%d\t%d\t1e-20\t200\n" % (names[q], names[s], b - a + 1, a, b, cc, d))
+    chunks = util.lib_longest_repeats(str(bl), str(fa), c["thr"], chunk_size=c["chunk_size"])
+    flat = [[ch, int(r[0][4:]), r[1], r[2], int(r[3][4:]), r[4], r[5]] for ch, d in enumerate(chunks) for lst in d.values() for r in lst]
+    assert flat == c["recs"]
+    cl = util.cluster_sequences_from_chunks(chunks, util.read_fasta(str(fa))[1], c["thr"])
+    assert [sorted(int(x[4:]) for x in k) for k in cl] == c["clusters"]
+    # random tables vs the oracle, chunked and not
+    rng = np.random.default_rng(12202)
+    for (nseq, nhits, cs) in [(1, 3, 0), (40, 800, 0), (300, 20000, 0), (300, 20000, 997), (2000, 60000, 5000)]:
+        rows, lens = _random_lib_table(rng, nseq, nhits)
+        thr = float(rng.choice([0.95, 0.8]))
+        cols = list(zip(*rows))
+        recs = ctx.lib_chain(cols[0], cols[1], cols[2], cols[3], cols[4], cols[5], lens, thr, cs)
+        assert recs == O.lib_chain(rows, lens, thr, cs), (nseq, nhits, cs)
+        assert ctx.lib_cluster(recs, lens, thr) == O.lib_cluster(recs, lens, thr)
+    assert ctx.lib_chain([], [], [], [], [], [], [100], 0.95) == []
+    with pytest.raises(RuntimeError):
+        ctx.lib_chain([0], [5], [1], [10], [1], [10], [100], 0.95)       # subject id out of range
+    # consensus: goldens through the file mirror, random batch vs the oracle
+    for ci, c in enumerate(g["cons"]):
+        af = tmp_path / ("c%d.maf.fa" % ci)
+        with open(af, "w") as fh:
+            for r, row in enumerate(c["rows"]):
+                fh.write(">r%d\n%s\n" % (r, row))
+        assert util.cons_from_mafft_v1(str(af)) == c["cons"], ci
+    als = []
+    for _ in range(60):
+        R, L = int(rng.integers(1, 40)), int(rng.integers(1, 1500))
+        base = casegen.rand_seq(rng, L)
+        al = []
+        for _r in range(R):
+            row = np.frombuffer(base.encode(), dtype=np.uint8).copy()
+            m = rng.random(L)
+            row[m < 0.3] = ord("-")
+            sub = (m >= 0.3) & (m < 0.4)
+            row[sub] = np.frombuffer(b"ACGTN", dtype=np.uint8)[rng.integers(0, 5, size=int(sub.sum()))]
+            al.append(row.tobytes().decode())
+        als.append(al)
+    got = ctx.msa_consensus(als)
+    for al, gc in zip(als, got):
+        assert gc == O.cons_majority(al)
+    assert ctx.msa_consensus([]) == []
