@@ -469,6 +469,20 @@ def test_dropin_scripts(ctx, tmp_path):
                              "--candidates", str(candf)], capture_output=True, text=True)
         assert rc.returncode == 0, rc.stderr[-2000:]
         assert (out / outname).exists()
+    # homology module: library entries = planted families (one mutated, one absent from the genome) -> longest genomic copy each
+    lib = tmp_path / "non_LTR.lib"
+    rng = np.random.default_rng(3)
+    ent = [(">fam%d#LINE/L1\n" % i) + (s if i != 1 else casegen.mutate(rng, s, 0.02)) + "\n" for i, s in enumerate(g["cands"][:5])]
+    ent.append(">absent#SINE/tRNA\n" + casegen.rand_seq(rng, 400) + "\n")
+    lib.write_text("".join(ent))
+    rc = subprocess.run([_sys.executable, root + "/hite_amd/scripts/judge_Other_transposons.py", "-t", "1", "--tmp_output_dir", str(out),
+                         "--recover", "0", "-r", str(ref), "--min_TE_len", "80", "--lib", str(lib)], capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stderr[-2000:]
+    on, oc_ = util.read_fasta(str(out / "confident_other.fa"))
+    assert 3 <= len(on) <= 5 and all(n.startswith("Homology_Non_LTR_") and n.endswith("#LINE/L1") for n in on)
+    genome_text = "".join(g["contigs"])
+    for n in on:
+        assert oc_[n] in genome_text or util.getReverseSequence(oc_[n]) in genome_text   # a genomic copy, verbatim
 
 
 def test_star_msa_sparse_fused(ctx):
