@@ -413,6 +413,61 @@ def gen_ltr_frame(tmp):
     dump("ltr_frame", cases)
 
 
+def gen_ltr_both_ends(tmp):
+    """FiLTR get_both_ends_frame (bin/FiLTR-main/src/Util.py:1401): aligned copies + terminal sequence -> `.matrix` frames and
+    full-length rows (anchor search with the harness' find_near_matches, its own sparse-column rule)"""
+    F = ref_harness.load_filtr_util()
+    rng = np.random.default_rng(1401)
+    cases = []
+    for ci in range(70):
+        R = int(rng.choice([1, 2, 3, 4, 7, 12, 30]))
+        L = int(rng.choice([45, 120, 400, 900]))
+        flank = int(rng.choice([20, 50, 100]))
+        outer = int(rng.choice([0, 10, flank, flank + 30]))
+        elem = casegen.rand_seq(rng, L)
+        consensus = casegen.rand_seq(rng, outer) + elem + casegen.rand_seq(rng, outer)
+        # column plan: every consensus position is a column; sparse insertion columns are sprinkled in
+        plan = []
+        for i in range(len(consensus)):
+            if rng.random() < 0.06:
+                plan.extend([("ins", None)] * int(rng.integers(1, 4)))
+            plan.append(("pos", i))
+        kind = ci % 10
+        rows = []
+        for r in range(R):
+            lo = 0 if rng.random() < 0.7 else int(rng.integers(0, outer + 25))
+            hi = len(consensus) if rng.random() < 0.7 else len(consensus) - int(rng.integers(0, outer + 25))
+            div = float(rng.choice([0.0, 0.02, 0.08]))
+            if kind == 3 and r == 0:
+                div = 0.5                                         # the first row loses its anchors: the second one decides
+            if kind == 7:
+                div = 0.6                                         # nobody has the anchors
+            row = []
+            for (k, i) in plan:
+                if k == "ins":
+                    row.append(casegen.rand_seq(rng, 1) if rng.random() < (0.15 if kind != 5 else 0.55) else "-")
+                elif i < lo or i >= hi or rng.random() < 0.04:
+                    row.append("-")
+                else:
+                    row.append(consensus[i] if rng.random() >= div else casegen.rand_seq(rng, 1))
+            rows.append("".join(row))
+        cur = elem if kind != 2 else casegen.mutate(rng, elem, 0.01)
+        af = os.path.join(tmp, "be_%d.maf.fa" % ci)
+        with open(af, "w") as fh:
+            for r, row in enumerate(rows):
+                fh.write(">copy%d\n%s\n" % (r, row))
+        od, fd = os.path.join(tmp, "be_out_%d" % ci), os.path.join(tmp, "be_full_%d" % ci)
+        os.makedirs(od, exist_ok=True); os.makedirs(fd, exist_ok=True)
+        m1, m2 = F.get_both_ends_frame("q", cur, af, od, fd, flank, 0)
+        if m1 is None:
+            cases.append({"rows": rows, "cur": cur, "flank": flank, "frames": None, "full": None})
+        else:
+            frames = [ln.rstrip("\n").split("\t") for ln in open(m1)]
+            full = [ln.rstrip("\n") for ln in open(m2)]
+            cases.append({"rows": rows, "cur": cur, "flank": flank, "frames": frames, "full": full})
+    dump("ltr_both_ends", cases)
+
+
 def gen_nonltr_prep(U):
     """search_polyA_TSD (Util.py:10915): flanked repeat -> (found_TSD, TSD_seq, non_ltr_seq)"""
     rng = np.random.default_rng(515)
@@ -596,7 +651,7 @@ def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -622,6 +677,8 @@ def main():
             gen_query_copies(U, tmp)
         if "libdedup" in which:
             gen_lib_dedup(U, tmp)
+        if "bothends" in which:
+            gen_ltr_both_ends(tmp)
 
 
 if __name__ == "__main__":

@@ -1053,3 +1053,50 @@ void orc_search_polyA_TSD(const uint8_t *seq, int64_t n, int flank, int win5, in
     if (!direct) { out[4] = 0; out[5] = 0; }
     else { int64_t lo, hi; py_slice(i64min(end_5, end_3), i64max(end_5, end_3), n, &lo, &hi); out[4] = lo; out[5] = hi; }
 }
+
+/* ------------------------------------------------------------------------------- */
+/* FiLTR get_both_ends_frame + its remove_sparse_col_in_align_file                  */
+/* /root/reference/bin/FiLTR-main/src/Util.py:1401-1497, 1341-1399   */
+/* ------------------------------------------------------------------------------- */
+/* msa R x C (upper-cased rows); cand = the LTR terminal sequence.  frames: R rows of 2*flank bytes (left frame, right
+ * frame: the `.matrix` line without its tab); full: R rows with stride 2*flank + C, *full_cols bytes used per row
+ * (left frame + cleaned[new_start:new_end] + right frame).  returns 0 ok, 1 boundary not found (None, None),
+ * 2 align_start == align_end (the reference then slices with -1: not restated), <0 error. */
+int orc_ltr_both_ends(const uint8_t *msa, int R, int C, const uint8_t *cand, int clen, int flank, uint8_t *frames, uint8_t *full,
+                      int *full_cols, int *new_start, int *new_end) {
+    int astart, aend;
+    *full_cols = 0; *new_start = -1; *new_end = -1;
+    if (R <= 0 || C <= 0 || clen <= 0) return 1;
+    int rc = find_anchor_first_row(msa, R, C, cand, clen, &astart, &aend);
+    if (rc < 0) return rc;
+    if (rc != 0 || astart == -1 || aend == -1) return 1;
+    if (astart == aend) return 2;
+    int *inv = (int *)malloc(sizeof(int) * (size_t)(C + 1));
+    int K = 0, ns = -1, ne = -1;
+    for (int c = 0; c < C; c++) {
+        int gap = 0;
+        for (int r = 0; r < R; r++) gap += msa[(size_t)r * C + c] == '-';
+        if (c == astart) ns = K;                                   /* :1378 */
+        else if (c == aend) ne = K;                                /* :1380 */
+        else if (2 * gap > R) continue;                            /* gap_num > row_num / 2  :1383 */
+        inv[K++] = c;
+    }
+    const int mid = ne > ns ? ne - ns : 0;
+    const int stride = 2 * flank + C;
+    for (int r = 0; r < R; r++) {
+        const uint8_t *row = msa + (size_t)r * C;
+        uint8_t *fr = frames + (size_t)r * 2 * flank, *fu = full + (size_t)r * stride;
+        for (int j = 0; j < flank; j++) {
+            int k = ns - flank + j;                                /* '-' * (F - len) + row[max(0, ns - F) : ns] */
+            fr[j] = k >= 0 ? row[inv[k]] : (uint8_t)'-';
+            int k2 = ne + j;                                       /* row[ne : min(len, ne + F)] + '-' * (F - len) */
+            fr[flank + j] = k2 < K ? row[inv[k2]] : (uint8_t)'-';
+        }
+        for (int j = 0; j < flank; j++) fu[j] = fr[j];
+        for (int j = 0; j < mid; j++) fu[flank + j] = row[inv[ns + j]];
+        for (int j = 0; j < flank; j++) fu[flank + mid + j] = fr[flank + j];
+    }
+    *full_cols = 2 * flank + mid; *new_start = ns; *new_end = ne;
+    free(inv);
+    return 0;
+}

@@ -354,3 +354,22 @@ def cons_majority(rows):
     L.orc_cons_majority.restype = C.c_int64
     k = L.orc_cons_majority(R, C.c_int64(cols), _ptr(mat, u8p), _ptr(out, u8p))
     return out[:k].tobytes().decode()
+
+
+def ltr_both_ends(rows, cur, flank):
+    """FiLTR get_both_ends_frame on aligned rows -> (frames [(left, right)], full rows, new_start, new_end) or None"""
+    R, Cc = len(rows), len(rows[0])
+    mat = np.frombuffer("".join(rows).encode(), dtype=np.uint8).copy()
+    cb = np.frombuffer(cur.encode(), dtype=np.uint8).copy()
+    fr = np.zeros(R * 2 * flank + 16, dtype=np.uint8)
+    stride = 2 * flank + Cc
+    fu = np.zeros(R * stride + 16, dtype=np.uint8)
+    fc, ns, ne = C.c_int(0), C.c_int(0), C.c_int(0)
+    rc = lib().orc_ltr_both_ends(_ptr(mat, u8p), R, Cc, _ptr(cb, u8p), len(cur), flank, _ptr(fr, u8p), _ptr(fu, u8p), C.byref(fc),
+                                 C.byref(ns), C.byref(ne))
+    if rc != 0:
+        return None if rc == 1 else rc
+    frames = [[fr[r * 2 * flank:r * 2 * flank + flank].tobytes().decode(), fr[r * 2 * flank + flank:(r + 1) * 2 * flank].tobytes().decode()]
+              for r in range(R)]
+    full = [fu[r * stride:r * stride + fc.value].tobytes().decode() for r in range(R)]
+    return frames, full, ns.value, ne.value

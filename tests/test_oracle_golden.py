@@ -240,3 +240,19 @@ def test_lib_dedup_golden():
     assert nrec > 300 and ncl > 50
     for c in g["cons"]:
         assert O.cons_majority([r.upper() for r in c["rows"]]) == c["cons"]
+
+
+def test_ltr_both_ends_golden():
+    """FiLTR get_both_ends_frame (anchors, its sparse-column rule, `.matrix` frames, full-length rows) vs the reference"""
+    g = load_golden("ltr_both_ends")
+    found = 0
+    for c in g:
+        rows = [r.upper() for r in c["rows"]]
+        got = O.ltr_both_ends(rows, c["cur"], c["flank"])
+        if c["frames"] is None:
+            assert got is None
+            continue
+        assert got is not None and not isinstance(got, int)
+        assert got[0] == c["frames"] and got[1] == c["full"]
+        found += 1
+    assert found > 40 and found < len(g)
