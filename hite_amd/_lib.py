@@ -447,6 +447,51 @@ class Context:
                     "hite_msa_consensus")
         return [cons[ooff[a]:ooff[a] + clen[a]].tobytes().decode("latin-1") for a in range(nmat)]
 
+    def ltr_both_ends(self, alignments, cur_seqs, flank):
+        """FiLTR get_both_ends_frame on a batch: alignments = lists of equal-length rows, cur_seqs = terminal sequences ->
+        per alignment None (boundary not found) or (frames [(left, right)], full rows, new_start, new_end)"""
+        n = len(alignments)
+        if n == 0:
+            return []
+        rows = np.array([len(al) for al in alignments], dtype=np.int32)
+        cols = np.array([len(al[0]) if al else 0 for al in alignments], dtype=np.int32)
+        flat = []
+        for al in alignments:
+            for r in al:
+                rb = r.encode() if isinstance(r, str) else bytes(r)
+                if len(rb) != len(al[0]):
+                    raise ValueError("ragged alignment")
+                flat.append(rb)
+        buf = np.frombuffer(b"".join(flat) + b"\0" * 16, dtype=np.uint8)
+        moff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(rows.astype(np.int64) * cols, out=moff[1:])
+        cb = [c.encode() if isinstance(c, str) else bytes(c) for c in cur_seqs]
+        coff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in cb], out=coff[1:])
+        cbuf = np.frombuffer(b"".join(cb) + b"\0" * 16, dtype=np.uint8)
+        froff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(rows.astype(np.int64) * 2 * flank, out=froff[1:])
+        fuoff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(rows.astype(np.int64) * (2 * flank + cols.astype(np.int64)), out=fuoff[1:])
+        frames = np.zeros(int(froff[-1]) + 16, dtype=np.uint8)
+        full = np.zeros(int(fuoff[-1]) + 16, dtype=np.uint8)
+        fcols = np.zeros(n, dtype=np.int32)
+        npos = np.zeros(2 * n, dtype=np.int32)
+        status = np.zeros(n, dtype=np.int32)
+        self._check(self.lib.hite_ltr_both_ends(self.h, n, _p(buf), _p(moff), _p(rows), _p(cols), _p(cbuf), _p(coff), int(flank), _p(frames),
+                                                _p(froff), _p(full), _p(fuoff), _p(fcols), _p(npos), _p(status)), "hite_ltr_both_ends")
+        out = []
+        for a in range(n):
+            if status[a] != 0:
+                out.append(None)
+                continue
+            R, stride = int(rows[a]), 2 * flank + int(cols[a])
+            fr = [(frames[froff[a] + r * 2 * flank:froff[a] + r * 2 * flank + flank].tobytes().decode("latin-1"),
+                   frames[froff[a] + r * 2 * flank + flank:froff[a] + (r + 1) * 2 * flank].tobytes().decode("latin-1")) for r in range(R)]
+            fu = [full[fuoff[a] + r * stride:fuoff[a] + r * stride + fcols[a]].tobytes().decode("latin-1") for r in range(R)]
+            out.append((fr, fu, int(npos[2 * a]), int(npos[2 * a + 1])))
+        return out
+
     def nonltr_prep(self, seqs, flank=50, win5=25):
         """search_polyA_TSD on a batch -> [(found_TSD, direct, tsd_start, tsd_len, lo, hi)]"""
         sb = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]

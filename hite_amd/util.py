@@ -148,6 +148,27 @@ def _read_matrix(matrix_file, column):
     return rows
 
 
+def get_both_ends_frame(query_name, cur_seq, align_file, output_dir, full_length_output_dir, flanking_len, debug, device=0):
+    """bin/FiLTR-main/src/Util.py:1401 -- aligned copies of one LTR terminal -> <output_dir>/<query>.matrix
+    ('left_frame\\tright_frame' per copy) and <full_length_output_dir>/<query>.matrix; (None, None) without a boundary"""
+    align_names, align_contigs = read_fasta(align_file)
+    if not align_names:
+        return None, None
+    res = get_ctx(device).ltr_both_ends([[align_contigs[n] for n in align_names]], [cur_seq], flanking_len)[0]
+    if res is None:
+        return None, None
+    frames, full, _ns, _ne = res
+    start_align_file = os.path.join(output_dir, query_name + ".matrix")
+    with open(start_align_file, "w") as f_save:
+        for left, right in frames:
+            f_save.write(left + "\t" + right + "\n")
+    full_length_align_file = os.path.join(full_length_output_dir, query_name + ".matrix")
+    with open(full_length_align_file, "w") as f_save:
+        for row in full:
+            f_save.write(row + "\n")
+    return start_align_file, full_length_align_file
+
+
 def judge_left_frame_LTR(matrix_file, flanking_len, sliding_window_size=20):
     """bin/FiLTR-main/src/Util.py:9327: (is_ltr, new_boundary_start) from the left frames of the '.matrix' file"""
     rows = _read_matrix(matrix_file, 0)

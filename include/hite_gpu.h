@@ -206,6 +206,18 @@ int hite_lib_cluster(int64_t nrec, const int32_t *chunk, const int32_t *q, const
 int hite_msa_consensus(hite_ctx *ctx, int32_t nmat, const int32_t *rows, const int64_t *cols, const int64_t *mat_off,
                        const uint8_t *mats, const int64_t *out_off, uint8_t *cons, int64_t *cons_len);
 
+/* ---- LTR frames of the vendored FiLTR --- get_both_ends_frame  bin/FiLTR-main/src/Util.py:1401-1497 (+ :1341-1399) -----
+ * Batch of alignments (rows[a] x cols[a] bytes at msa + msa_off[a], upper case) with the terminal sequence of each
+ * (cand + cand_off[a] .. cand_off[a+1]).  Per alignment: anchors from the first row carrying both 20-mers within two
+ * edits, FiLTR's sparse-column rule (more than R/2 gaps, anchor columns always kept), then per row the `.matrix` line
+ * (left frame | right frame, 2 * flank bytes at frames + frame_off[a] + r * 2 * flank, '-' padded) and the full-length row
+ * (left frame + cleaned[new_start:new_end] + right frame at full + full_off[a] + r * (2 * flank + cols[a]), full_cols[a]
+ * bytes used).  new_pos[2a], new_pos[2a+1] = anchor columns in cleaned coordinates.  status[a]: 0 ok, 1 boundary not
+ * found (the reference returns None, None), 2 both anchors on the same column (not restated). */
+int hite_ltr_both_ends(hite_ctx *ctx, int32_t n, const uint8_t *msa, const int64_t *msa_off, const int32_t *rows, const int32_t *cols,
+                       const uint8_t *cand, const int64_t *cand_off, int32_t flank, uint8_t *frames, const int64_t *frame_off,
+                       uint8_t *full, const int64_t *full_off, int32_t *full_cols, int32_t *new_pos, int32_t *status);
+
 /* ---- k-mer TSD seed matching --- search_confident_tir_v4  Util.py:7734-7845 -------------------------
  * batch of flanked candidates (CSR); the raw boundaries are (flank+1, len-flank), 1-based, as
  * search_confident_tir_batch_v1 passes them (Util.py:6550), tsd_search_distance = flank (<= 63).

@@ -913,3 +913,37 @@ def test_lib_dedup(ctx, tmp_path):
     for al, gc in zip(als, got):
         assert gc == O.cons_majority(al)
     assert ctx.msa_consensus([]) == []
+
+
+def test_ltr_both_ends(ctx, tmp_path):
+    """FiLTR get_both_ends_frame: reference goldens through the file mirror (batch call for the rest) + frames feed the vote"""
+    from hite_amd import util
+
+    g = load_golden("ltr_both_ends")
+    als = [[r.upper() for r in c["rows"]] for c in g]
+    flanks = sorted({c["flank"] for c in g})
+    nfound = 0
+    for F in flanks:
+        idx = [i for i, c in enumerate(g) if c["flank"] == F]
+        got = ctx.ltr_both_ends([als[i] for i in idx], [g[i]["cur"] for i in idx], F)
+        for i, res in zip(idx, got):
+            c = g[i]
+            exp = O.ltr_both_ends(als[i], c["cur"], F)
+            if c["frames"] is None:
+                assert res is None and exp is None
+                continue
+            assert res is not None
+            assert [list(x) for x in res[0]] == c["frames"] and res[1] == c["full"], i
+            assert (res[2], res[3]) == (exp[2], exp[3])
+            nfound += 1
+    assert nfound > 40
+    # file-level mirror and hand-over to the frame vote
+    c = next(c for c in g if c["frames"] is not None and len(c["rows"]) >= 4)
+    af = tmp_path / "q.maf.fa"
+    af.write_text("".join(">copy%d\n%s\n" % (r, row) for r, row in enumerate(c["rows"])))
+    (tmp_path / "o").mkdir(); (tmp_path / "f").mkdir()
+    m1, m2 = util.get_both_ends_frame("q", c["cur"], str(af), str(tmp_path / "o"), str(tmp_path / "f"), c["flank"], 0)
+    assert [ln.rstrip("\n").split("\t") for ln in open(m1)] == c["frames"]
+    assert [ln.rstrip("\n") for ln in open(m2)] == c["full"]
+    lt = util.judge_left_frame_LTR(m1, c["flank"])
+    assert isinstance(lt[0], (bool, np.bool_, int))
