@@ -20,7 +20,11 @@ static int arena_alloc(hite_ctx *ctx, Arena &a, size_t bytes, void **out) {
     // first chunk (from the current one on) that still has room
     while (a.cur < a.chunks.size() && a.off + bytes > a.caps[a.cur]) { a.cur++; a.off = 0; }
     if (a.cur >= a.chunks.size()) {
+        // geometric growth: a new chunk is at least as large as everything allocated so far (few chunks to consolidate)
+        size_t total = 0;
+        for (size_t c : a.caps) total += c;
         size_t want = bytes > ((size_t)256 << 20) ? bytes : ((size_t)256 << 20);
+        if (want < total) want = total;
         void *p = nullptr;
         HITE_CHECK(ctx, hipMalloc(&p, want));
         a.chunks.push_back(p);

@@ -447,11 +447,19 @@ extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *strea
     if (ctx->n_bases >= 0xfffe0000ll) return HITE_EINVAL;  // positions are 32-bit
     hipStream_t st = (hipStream_t)stream;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
-    if (*state_io) hite_copy_index_release(*state_io);
-    CopyState *S = new CopyState();
-    *state_io = S;
-    HITE_CHECK(ctx, hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)));
-    HITE_CHECK(ctx, hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)));
+    // rebuilding on an existing handle (next genome / chunk) keeps its arenas: their growth is the expensive part of a cold call
+    CopyState *S = (CopyState *)*state_io;
+    if (S) {
+        if (S->idx_hs) (void)hipFree(S->idx_hs);
+        if (S->idx_pos) (void)hipFree(S->idx_pos);
+        if (S->dir) (void)hipFree(S->dir);
+        S->idx_hs = nullptr; S->idx_pos = nullptr; S->dir = nullptr; S->M = 0;
+    } else {
+        S = new CopyState();
+        *state_io = S;
+        HITE_CHECK(ctx, hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)));
+        HITE_CHECK(ctx, hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)));
+    }
     const int64_t G = ctx->n_bases;
     unsigned long long cap = (unsigned long long)(G * 0.32) + 4096;
     unsigned long long *keys = nullptr;
