@@ -99,30 +99,72 @@ __device__ __forceinline__ unsigned long long wave_append(bool want, unsigned lo
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
-// genome minimizers: thread = window start (global position).  key = hs << 32 | pos
+// genome minimizers.  key = hs << 32 | pos (the index is sorted afterwards: the emission order is free).
+// One block per tile of GM_TILE window starts: the k-mer hashes the tile needs are computed once into LDS (each from its
+// own contig: a k-mer that crosses the contig end or touches an N is invalid), every thread then scans the windows of
+// GM_TILE / 256 starts (interleaved: conflict-free LDS reads) and their predecessors, and the tile's minimizers leave
+// with ONE atomic on the global counter (one per wavefront -- 15 M same-address atomics at ~12 ns -- was the whole cost).
+#define GM_TILE 2048
 __global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
                                                                const int64_t *__restrict__ coff, int nc, int64_t G,
                                                                unsigned long long *__restrict__ out, unsigned long long cap,
                                                                unsigned long long *__restrict__ counter) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t p0 = (int64_t)blockIdx.x * blockDim.x; p0 < G; p0 += stride) {   // block-uniform trip count (wave_append)
-        const int64_t p = p0 + threadIdx.x;
-        bool want = false; unsigned h = 0; int64_t m = -1;
-        if (p < G) {
-            int c = contig_of(coff, nc, p);
-            int64_t cb = coff[c], ce = coff[c + 1];
-            int64_t nk = ce - cb - CK + 1;
-            int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
-            if (nk > 0 && p - cb < nwin) {
-                auto hs_at = [&](int64_t i) { return genome_hs(bases, nmask, i, ce); };
-                unsigned hp;
-                m = window_min(p, cb, nk, hs_at, &h);
-                want = m >= 0;
-                if (want && p > cb) { int64_t mp = window_min(p - 1, cb, nk, hs_at, &hp); if (mp == m) want = false; }
-            }
+    __shared__ unsigned sh[GM_TILE + CW + 8];   // sh[q] = hs of the k-mer starting at p0 - 1 + q
+    __shared__ int s_wcnt[4];
+    __shared__ unsigned long long s_base;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    constexpr int PER = GM_TILE / 256;
+    for (int64_t p0 = (int64_t)blockIdx.x * GM_TILE; p0 < G; p0 += (int64_t)gridDim.x * GM_TILE) {
+        __syncthreads();
+        for (int q = threadIdx.x; q < GM_TILE + CW + 1; q += 256) {
+            const int64_t g = p0 - 1 + q;
+            unsigned h = HS_INVALID;
+            if (g >= 0 && g < G) { const int c = contig_of(coff, nc, g); h = genome_hs(bases, nmask, g, coff[c + 1]); }
+            sh[q] = h;
         }
-        unsigned long long slot = wave_append(want, counter);
-        if (want && slot < cap) out[slot] = ((unsigned long long)h << 32) | (unsigned long long)(unsigned)m;
+        __syncthreads();
+        unsigned hh[PER]; unsigned mm[PER];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int o = j * 256 + threadIdx.x;          // window start p = p0 + o, its k-mers sit at sh[o + 1 ...]
+            const int64_t p = p0 + o;
+            bool want = false; unsigned h = 0; int m = -1;
+            if (p < G) {
+                const int c = contig_of(coff, nc, p);
+                const int64_t cb = coff[c], ce = coff[c + 1];
+                const int64_t nk = ce - cb - CK + 1;
+                const int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
+                if (nk > 0 && p - cb < nwin) {
+                    const int lim = (int)((cb + nk - p) < CW ? (cb + nk - p) : CW);          // k-mers [p, min(p + W, cb + nk))
+                    const int limp = (int)((cb + nk - (p - 1)) < CW ? (cb + nk - (p - 1)) : CW);
+                    int mprev = 0; unsigned hprev = 0; bool fprev = false;
+#pragma unroll
+                    for (int i = 0; i < CW; i++) {
+                        const unsigned v = sh[o + 1 + i];
+                        if (i < lim && v != HS_INVALID && (m < 0 || (v >> 1) < (h >> 1))) { m = i; h = v; }
+                        const unsigned u = sh[o + i];
+                        if (i < limp && u != HS_INVALID && (!fprev || (u >> 1) < (hprev >> 1))) { mprev = i - 1; hprev = u; fprev = true; }
+                    }
+                    want = m >= 0 && !(p > cb && fprev && mprev == m);
+                }
+            }
+            if (want) { hh[cnt] = h; mm[cnt] = (unsigned)(p + m); cnt++; }
+        }
+        // block compaction: wave prefix by shuffles, wave totals through LDS, one atomic per tile
+        int incl = cnt;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
+        if (lane == 63) s_wcnt[w] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long slot = s_base + (unsigned long long)(incl - cnt);
+        for (int i = 0; i < w; i++) slot += (unsigned long long)s_wcnt[i];
+        for (int i = 0; i < cnt; i++, slot++) if (slot < cap) out[slot] = ((unsigned long long)hh[i] << 32) | (unsigned long long)mm[i];
     }
 }
 
@@ -467,7 +509,7 @@ extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *strea
     HITE_CHECK(ctx, hipMalloc((void **)&keys, cap * 8));
     HITE_CHECK(ctx, hipMalloc((void **)&vals, cap * 4));
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
-    int64_t blocks = (G + 255) / 256; if (blocks > 256 * 64) blocks = 256 * 64;
+    int64_t blocks = (G + GM_TILE - 1) / GM_TILE; if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(genome_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
                        ctx->n_contigs, G, keys, cap, (unsigned long long *)S->d_scal);
     HITE_CHECK(ctx, hipGetLastError());
