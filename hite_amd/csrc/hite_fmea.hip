@@ -39,8 +39,16 @@ __global__ void fm_first_kernel(int64_t n, const int32_t *__restrict__ qseg, con
     bool self = q == s && qs[i] == ss[i] && qe[i] == se[i];  // :4138
     keep[i] = !self;
     if (self) return;
-    atomicMin(&first_q[q], (int)i);
-    atomicMin(&first_pair[(int64_t)q * nseg + s], (int)i);
+    // an HSP whose predecessor in the table is kept and carries the same query (pair) cannot be the first of it: on a table
+    // grouped by (query, subject) -- what blastn and the seeding stage emit -- this removes nearly every same-address atomic
+    bool same_q = false, same_p = false;
+    if (i > 0) {
+        const int q1 = qseg[i - 1], s1 = sseg[i - 1];
+        const bool self1 = q1 == s1 && qs[i - 1] == ss[i - 1] && qe[i - 1] == se[i - 1];
+        if (!self1) { same_q = q1 == q; same_p = same_q && s1 == s; }
+    }
+    if (!same_q) atomicMin(&first_q[q], (int)i);
+    if (!same_p) atomicMin(&first_pair[(int64_t)q * nseg + s], (int)i);
 }
 
 // block bitonic sort of up to FM_MAXSEG (key, id) pairs in LDS; rank_out[id] = position, order_out[pos] = id
