@@ -24,6 +24,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+PEAK_VALU_GINST = 256 * 4 * 2.4 / 4      # G wave64 vector instructions per second (MI355X_MICROARCH.md: 4 cycles per wave64 VALU op)
+VALU_PER_DP_STEP = 11.6                  # measured: SQ_INSTS_VALU / (launch steps), profiles/r01_sq_counters.txt
 
 
 def main():
@@ -266,8 +268,16 @@ def main():
                     "avg_launch_ms": round(avg_launch_ms, 4), "alg_bytes_per_launch": int(bytes_per_launch)}
             if dom == "star_align_kernel":
                 cells = 64.0 * float(stats[8] + stats[9])
-                roof["note"] = "integer-ALU/latency-bound banded DP: cells/s is the meaningful rate"
+                # the kernel is bound by vector-instruction issue (profiles/r01_sq_counters.txt: SQ_INSTS_VALU per anti-diagonal
+                # step of a wave = 11.6 incl. traceback, SIMD busy ~98 %): report that rate beside the HBM figure.
+                # peak = 256 CU x 4 SIMD x 2.4 GHz / 4 cycles per wave64 instruction
+                steps_done = float(stats[8] + stats[9]) * args.steps
+                valu_rate = VALU_PER_DP_STEP * steps_done / (ms_tot * 1e-3) / 1e9
+                roof["note"] = ("vector-issue-bound banded DP (not HBM): traffic is the traceback's 2 direction bits per cell, "
+                                "written once, read once (16 B per wave-step)")
                 roof["dp_gcells_per_s"] = round(cells * args.steps / (ms_tot * 1e-3) / 1e9, 2)
+                roof["valu_issue"] = {"achieved": round(valu_rate, 1), "peak": PEAK_VALU_GINST, "unit": "G wave64-inst/s",
+                                      "frac": round(valu_rate / PEAK_VALU_GINST, 4), "inst_per_dp_step": VALU_PER_DP_STEP}
         out = {
             "metric": "candidate TE boundaries/sec on 1 Gbp synthetic genome (fine stage: copy finding+gather+align+vote+judge)",
             "value": round(value, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
