@@ -73,6 +73,102 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
     }
 }
 
+// 10-bit scatter with the tile staged in LDS in output order.  The direct form above writes every element to its final
+// position as it is ranked: 256 elements per round land in up to 256 different bins and HBM sees partial-line writes
+// (PMC: 3x the algorithmic write bytes).  Here a block of 8 wavefronts owns a tile of 8192 elements (wave w: the contiguous
+// chunk [1024 w, 1024 w + 1024), 16 coalesced rounds, keys / values held in registers), ranks them stably inside the tile
+// (per-wave digit counts -> offsets; ballots for the rank inside a round), writes them to LDS in digit order and streams
+// the runs out: the average run of a digit is 8 consecutive elements (64 B of keys).
+// LDS: keys 64 KB | values 32 KB | per-wave digit offsets u16 [8][1024] 16 KB | run shift u32 [1024] 4 KB | scan 64 B.
+#define RSS_TILE 8192
+#define RSS_LDS_BYTES (RSS_TILE * 12 + 8 * 1024 * 2 + 1024 * 4 + 64)
+static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const unsigned long long *__restrict__ kin, const unsigned *__restrict__ vin,
+                                                                       unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
+                                                                       int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
+    extern __shared__ unsigned char rss_lds[];
+    unsigned long long *skey = reinterpret_cast<unsigned long long *>(rss_lds);
+    unsigned *sval = reinterpret_cast<unsigned *>(rss_lds + RSS_TILE * 8);
+    unsigned short *woff = reinterpret_cast<unsigned short *>(rss_lds + RSS_TILE * 12);           // [8][1024]
+    unsigned *delta = reinterpret_cast<unsigned *>(rss_lds + RSS_TILE * 12 + 8 * 1024 * 2);       // [1024]
+    int *wsum = reinterpret_cast<int *>(rss_lds + RSS_TILE * 12 + 8 * 1024 * 2 + 1024 * 4);      // [8] + total
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * RSS_TILE;
+    unsigned long long k[16];
+    unsigned v[16];
+    unsigned info[16];   // rank inside the round (low 8 bits) | lanes with the same digit (next 8 bits) | digit << 16
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const int64_t i = tile + w * 1024 + r * 64 + lane;
+        const bool act = i < n;
+        k[r] = act ? kin[i] : 0ull;
+        v[r] = act ? vin[i] : 0u;
+    }
+    for (int b = threadIdx.x; b < 8 * 1024; b += 512) woff[b] = 0;
+    __syncthreads();
+    unsigned short *myoff = woff + w * 1024;
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const bool act = tile + w * 1024 + r * 64 + lane < n;
+        const int d = (int)((k[r] >> shift) & 1023ull);
+        unsigned long long peers = __ballot(act);
+#pragma unroll
+        for (int b = 0; b < 10; b++) {
+            const unsigned long long bal = __ballot((d >> b) & 1);
+            peers &= ((d >> b) & 1) ? bal : ~bal;
+        }
+        const int rank = __popcll(peers & ((1ull << lane) - 1ull));
+        const int mine = __popcll(peers);
+        info[r] = (unsigned)rank | ((unsigned)(mine - 1) << 8) | ((unsigned)d << 16) | (act ? 0x80000000u : 0u);
+        if (act && rank == 0) myoff[d] = (unsigned short)(myoff[d] + mine);      // wave-private row, one writer per digit and round
+    }
+    __syncthreads();
+    // digit totals -> exclusive scan over the 1024 digits -> per-wave start offsets; delta = global run start - local run start
+    {
+        const int d0 = threadIdx.x * 2;
+        int c0 = 0, c1 = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { c0 += woff[q * 1024 + d0]; c1 += woff[q * 1024 + d0 + 1]; }
+        int incl = c0 + c1;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const int t = __shfl_up(incl, dd); if (lane >= dd) incl += t; }
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        int pre = incl - (c0 + c1);
+        for (int q = 0; q < w; q++) pre += wsum[q];
+        // pre = local start of digit d0, pre + c0 = local start of digit d0 + 1
+        int s0 = pre, s1 = pre + c0;
+        delta[d0] = (unsigned)offs[(int64_t)d0 * nblocks + blockIdx.x] - (unsigned)s0;
+        delta[d0 + 1] = (unsigned)offs[(int64_t)(d0 + 1) * nblocks + blockIdx.x] - (unsigned)s1;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int a0 = woff[q * 1024 + d0], a1 = woff[q * 1024 + d0 + 1];
+            woff[q * 1024 + d0] = (unsigned short)s0; woff[q * 1024 + d0 + 1] = (unsigned short)s1;
+            s0 += a0; s1 += a1;
+        }
+        if (threadIdx.x == 511) wsum[8] = pre + c0 + c1;   // elements in the tile
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 16; r++) {
+        const unsigned inf = info[r];
+        const bool act = inf >> 31;
+        const int d = (int)((inf >> 16) & 1023u), rank = (int)(inf & 255u), mine = (int)((inf >> 8) & 255u) + 1;
+        int pos = 0;
+        if (act) pos = myoff[d] + rank;
+        __builtin_amdgcn_wave_barrier();
+        if (act) { skey[pos] = k[r]; sval[pos] = v[r]; if (rank == 0) myoff[d] = (unsigned short)(myoff[d] + mine); }
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+    const int total = wsum[8];
+    for (int j = threadIdx.x; j < total; j += 512) {
+        const unsigned long long key = skey[j];
+        const unsigned pos = (unsigned)j + delta[(int)((key >> shift) & 1023ull)];
+        kout[pos] = key;
+        vout[pos] = sval[j];
+    }
+}
+
 struct Sorter {
     hite_ctx *ctx;
     hipStream_t st;
@@ -93,6 +189,8 @@ static inline int64_t sorter_hist_elems(int64_t n) {
 
 static int sorter_init(Sorter &S, hite_ctx *ctx, hipStream_t st, int64_t n) {
     S.ctx = ctx; S.st = st; S.cap = n;
+    HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        RSS_LDS_BYTES));
     S.hist_n = sorter_hist_elems(n);
     HITE_CHECK(ctx, hipMalloc((void **)&S.k2, (size_t)(n + 1) * 8));
     HITE_CHECK(ctx, hipMalloc((void **)&S.v2, (size_t)(n + 1) * 4));
@@ -125,7 +223,7 @@ static int sorter_sort_bits(Sorter &S, unsigned long long *keys, unsigned *vals,
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
         int rc = scan_excl_buf<int32_t>(S.ctx, S.bs, S.hist, (int64_t)(1 << bits) * nblocks, S.offs, S.st);
         if (rc) return rc;
-        if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_kernel<10, 32>), dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
+        if (wide) hipLaunchKernelGGL(rs_scatter_staged_kernel, dim3(nblocks), dim3(512), RSS_LDS_BYTES, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         unsigned long long *tk = ka; ka = kb; kb = tk;
         unsigned *tv = va; va = vb; vb = tv;
