@@ -118,7 +118,7 @@ static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const uns
         }
         const int rank = __popcll(peers & ((1ull << lane) - 1ull));
         const int mine = __popcll(peers);
-        info[r] = (unsigned)rank | ((unsigned)(mine - 1) << 8) | ((unsigned)d << 16) | (act ? 0x80000000u : 0u);
+        info[r] = act ? ((unsigned)rank | ((unsigned)(mine - 1) << 8) | ((unsigned)d << 16) | 0x80000000u) : 0u;
         if (act && rank == 0) myoff[d] = (unsigned short)(myoff[d] + mine);      // wave-private row, one writer per digit and round
     }
     __syncthreads();
@@ -210,7 +210,9 @@ static void sorter_free(Sorter &S) {
 static int sorter_sort_bits(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int lo_bit, int hi_bit) {
     if (n <= 1) return HITE_OK;
     if (n >= 0xffffffffll) return HITE_EINVAL;   // 32-bit positions inside the scatter kernel
-    const bool wide = n >= RS_WIDE_MIN;
+    // HITE_SORT_WIDE_MIN (tests): element count from which the 10-bit staged form is used, default RS_WIDE_MIN
+    static const long long wide_min = [] { const char *e = getenv("HITE_SORT_WIDE_MIN"); return e && *e ? atoll(e) : (long long)RS_WIDE_MIN; }();
+    const bool wide = n >= wide_min;
     const int bits = wide ? 10 : 8;
     const int tile = wide ? 8192 : RS_TILE;
     int nblocks = (int)((n + tile - 1) / tile);

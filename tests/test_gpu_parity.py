@@ -947,3 +947,18 @@ def test_ltr_both_ends(ctx, tmp_path):
     assert [ln.rstrip("\n") for ln in open(m2)] == c["full"]
     lt = util.judge_left_frame_LTR(m1, c["flank"])
     assert isinstance(lt[0], (bool, np.bool_, int))
+
+
+def test_wide_radix_sort_on_small_inputs(tmp_path):
+    """the 10-bit LDS-staged scatter (normally used from 4 M elements on) forced onto the small parity cases: FMEA, copy
+    clustering, library chaining and the copy finder must give the same answers (ragged last tiles, empty digits)"""
+    import os
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HITE_SORT_WIDE_MIN="2")
+    rc = subprocess.run([_sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                         "fmea or query_copies or lib_dedup or find_copies or seed_allvsall"], env=env, capture_output=True, text=True, cwd=root)
+    assert rc.returncode == 0, rc.stdout[-3000:] + rc.stderr[-2000:]
+    assert " passed" in rc.stdout
