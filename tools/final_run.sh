@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 R=$PWD
 mkdir -p gpurun_out/final
-timeout 300 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/final/pytest_gpu.txt
+timeout 400 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 > gpurun_out/final/pytest_gpu.txt
 timeout 120 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 > gpurun_out/final/smoke.txt
 timeout 400 python bench.py 2>gpurun_out/final/bench_default.err | tail -1 > gpurun_out/final/bench_default.json
 cd /tmp
