@@ -181,65 +181,82 @@ __global__ void i64_to_u32_kernel(int64_t n, const int64_t *__restrict__ in, uns
     if (i < n) out[i] = (unsigned)in[i];
 }
 
-// candidate minimizers: one wavefront per candidate, 64 window starts per tile.  The tile's bases are staged in LDS
-// once (coalesced), the 75 k-mer hashes it needs are built from LDS and stay there; every lane then scans its own
-// window and the previous one (11 LDS reads).  Nothing but the minimizers themselves goes to HBM.
+// candidate minimizers: one block per candidate, CM_TILE window starts per tile.  The tile's bases are staged in LDS once
+// (coalesced) as 2-bit codes, every thread rolls the hashes of five consecutive k-mers out of them (19 byte reads for five
+// 15-mers), every window then scans its own k-mers and the previous window's from LDS (11 word reads), and the minimizers
+// leave in position order (rounds of 256 consecutive starts, ballots + wave counts).  Nothing but the minimizers goes to HBM.
 // The records of candidate c first go to a private region (start = its byte offset: a candidate of L bases has < L
 // windows), with the count; after an exclusive scan of the counts a second kernel packs the regions.  Order = (candidate,
 // position), no atomics (a single append counter would serialise ~3 M device-scope atomics at ~12 ns each).
-__global__ void __launch_bounds__(64) cand_minimizer_kernel(int ncand, const uint8_t *__restrict__ cand,
-                                                            const int64_t *__restrict__ cand_off,
-                                                            unsigned *__restrict__ r_pos, unsigned *__restrict__ r_hs,
-                                                            int32_t *__restrict__ q_cnt) {
-    __shared__ uint8_t sb[96];
-    __shared__ unsigned sh[80];
-    const int lane = threadIdx.x;
+#define CM_TILE 1024
+#define CM_KPT 5       // k-mers per thread in the hash phase (256 x 5 >= CM_TILE + CW + 1)
+__global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const uint8_t *__restrict__ cand,
+                                                             const int64_t *__restrict__ cand_off,
+                                                             unsigned *__restrict__ r_pos, unsigned *__restrict__ r_hs,
+                                                             int32_t *__restrict__ q_cnt) {
+    __shared__ uint8_t sb[256 * CM_KPT + CK + 8];     // sb[q] = code of base (tile - 1 + q): 0..3, 4 = not A/C/G/T or outside
+    __shared__ unsigned sh[256 * CM_KPT];             // sh[q] = hs of the k-mer starting at base (tile - 1 + q)
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int c = blockIdx.x; c < ncand; c += gridDim.x) {
         const int64_t cb = cand_off[c];
         const int L = (int)(cand_off[c + 1] - cb);
         const int nk = L - CK + 1;
-        if (nk <= 0) { if (lane == 0) q_cnt[c] = 0; continue; }
+        if (nk <= 0) { if (threadIdx.x == 0) q_cnt[c] = 0; continue; }
         const int nwin = nk >= CW ? nk - CW + 1 : 1;
         const uint8_t *s = cand + cb;
-        int64_t run = cb;   // wave-uniform running offset
-        for (int base = 0; base < nwin; base += 64) {
+        int run = 0;   // block-uniform count so far
+        for (int base = 0; base < nwin; base += CM_TILE) {
             __syncthreads();
-            for (int q = lane; q < 96; q += 64) { const int pos = base - 1 + q; sb[q] = (pos >= 0 && pos < L) ? s[pos] : 0; }
+            for (int q = threadIdx.x; q < 256 * CM_KPT + CK; q += 256) {
+                const int pos = base - 1 + q;
+                const uint8_t ch = (pos >= 0 && pos < L) ? s[pos] : 0;
+                sb[q] = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4;
+            }
             __syncthreads();
-            for (int q = lane; q < 75; q += 64) {   // k-mer start base - 1 + q
-                unsigned x = 0; bool ok = true;
+            {
+                const int q0 = threadIdx.x * CM_KPT;
+                unsigned x = 0, bad = 0;
 #pragma unroll
-                for (int i = 0; i < CK; i++) {
-                    const uint8_t ch = sb[q + i];
-                    const unsigned code = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
-                    ok = ok && code < 4u;
-                    x |= (code & 3u) << (2 * i);
+                for (int i = 0; i < CK; i++) { const unsigned cd = sb[q0 + i]; x |= (cd & 3u) << (2 * i); bad |= (cd >> 2) << i; }
+#pragma unroll
+                for (int j = 0; j < CM_KPT; j++) {
+                    sh[q0 + j] = bad ? HS_INVALID : hs_from_code(x);
+                    const unsigned cd = sb[q0 + j + CK];
+                    x = (x >> 2) | ((cd & 3u) << (2 * (CK - 1)));
+                    bad = (bad >> 1) | ((cd >> 2) << (CK - 1));
                 }
-                sh[q] = ok ? hs_from_code(x) : HS_INVALID;
             }
             __syncthreads();
-            const int lp = base + lane;
-            bool want = false; unsigned h = 0; int m = -1;
-            if (lp < nwin) {
-                // window [lp, lp + CW) = sh[lane + 1 .. lane + CW]; previous window = sh[lane .. lane + CW - 1]
-                int mprev = -1; unsigned hprev = 0;
+#pragma unroll 1
+            for (int j = 0; j < CM_TILE / 256; j++) {
+                const int o = j * 256 + threadIdx.x;
+                const int lp = base + o;
+                bool want = false; unsigned h = 0; int m = -1;
+                if (lp < nwin) {
+                    // window [lp, lp + CW) = sh[o + 1 .. o + CW]; previous window = sh[o .. o + CW - 1]
+                    int mprev = -1; unsigned hprev = 0;
 #pragma unroll
-                for (int i = 0; i < CW; i++) {
-                    const unsigned v = sh[lane + 1 + i];
-                    if (v != HS_INVALID && (m < 0 || (v >> 1) < (h >> 1))) { m = lp + i; h = v; }
-                    const unsigned u = sh[lane + i];
-                    if (u != HS_INVALID && (mprev < 0 || (u >> 1) < (hprev >> 1))) { mprev = lp - 1 + i; hprev = u; }
+                    for (int i = 0; i < CW; i++) {
+                        const unsigned v = sh[o + 1 + i];
+                        if (v != HS_INVALID && (m < 0 || (v >> 1) < (h >> 1))) { m = lp + i; h = v; }
+                        const unsigned u = sh[o + i];
+                        if (u != HS_INVALID && (mprev < 0 || (u >> 1) < (hprev >> 1))) { mprev = lp - 1 + i; hprev = u; }
+                    }
+                    want = m >= 0 && !(lp > 0 && mprev == m);
                 }
-                want = m >= 0 && !(lp > 0 && mprev == m);
+                const unsigned long long bm = __ballot(want);
+                if (lane == 0) s_cnt[w] = __popcll(bm);
+                __syncthreads();
+                int off = run + __popcll(bm & ((1ull << lane) - 1ull));
+                for (int q = 0; q < w; q++) off += s_cnt[q];
+                if (want) { r_pos[cb + off] = (unsigned)m; r_hs[cb + off] = h; }
+                run += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+                __syncthreads();
+                if (base + (j + 1) * 256 >= nwin) break;   // block-uniform
             }
-            const unsigned long long bm = __ballot(want);
-            if (want) {
-                const int64_t slot = run + __popcll(bm & ((1ull << lane) - 1ull));
-                r_pos[slot] = (unsigned)m; r_hs[slot] = h;
-            }
-            run += __popcll(bm);
         }
-        if (lane == 0) q_cnt[c] = (int32_t)(run - cb);
+        if (threadIdx.x == 0) q_cnt[c] = run;
     }
 }
 __global__ void __launch_bounds__(256) cand_minimizer_pack_kernel(int ncand, const int64_t *__restrict__ cand_off,
@@ -577,7 +594,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
         CCHK(arena_alloc(ctx, A, (size_t)(cand_bytes + 64) * 4, &p)); r_hs = (unsigned *)p;
         int wblocks = n_cand < 65536 ? n_cand : 65536;
         int tk_cm = hite_prof_begin(ctx, "cand_minimizer_kernel", st);
-        hipLaunchKernelGGL(cand_minimizer_kernel, dim3(wblocks), dim3(64), 0, st, n_cand, d_cand, d_cand_off, r_pos, r_hs, q_cnt);
+        hipLaunchKernelGGL(cand_minimizer_kernel, dim3(wblocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, r_pos, r_hs, q_cnt);
         CCHK(scan_excl_buf<int32_t>(ctx, qbs, q_cnt, n_cand, q_first, st));
         HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, q_first + n_cand, 8, hipMemcpyDeviceToDevice, st));
         CCHK(read_back(ctx, S, st, 1));
