@@ -267,28 +267,38 @@ __device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ un
 // ---------------------------------------------------------------------------------------------
 __device__ void blk_colstats(const uint8_t *__restrict__ msa, int C, const uint16_t *sel, int rn,
                              uint8_t *__restrict__ cstat) {
+    // the six counters and the six first-appearance ranks live in two 64-bit registers (one byte per symbol class): a
+    // dynamically indexed register array costs a compare-select chain per access.  rn <= MAXSEL (128) fits a byte.
     for (int c = threadIdx.x; c < C; c += JB) {
-        uint8_t cnt[6] = {0, 0, 0, 0, 0, 0}, fst[6] = {255, 255, 255, 255, 255, 255};
+        unsigned long long cnt = 0, fst = 0;
+        unsigned seen = 0;
         int r = 0;
-        for (; r + 3 < rn; r += 4) {   // four rows in flight (the loop is load-latency bound otherwise)
-            uint8_t sy[4];
+        for (; r + 7 < rn; r += 8) {   // eight rows in flight (the loop is load-latency bound otherwise)
+            uint8_t sy[8];
 #pragma unroll
-            for (int u = 0; u < 4; u++) sy[u] = msa[(size_t)sel[r + u] * C + c];
+            for (int u = 0; u < 8; u++) sy[u] = msa[(size_t)sel[r + u] * C + c];
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                int k = sym_class(sy[u]);
-                if (cnt[k] == 0) fst[k] = (uint8_t)(r + u);
-                cnt[k]++;
+            for (int u = 0; u < 8; u++) {
+                const int k8 = sym_class(sy[u]) * 8;
+                const unsigned fresh = ((seen >> k8 / 8) & 1u) ^ 1u;
+                cnt += 1ull << k8;
+                fst |= (unsigned long long)((unsigned)(r + u) & (0u - fresh)) << k8;
+                seen |= 1u << (k8 / 8);
             }
         }
         for (; r < rn; r++) {
-            int k = sym_class(msa[(size_t)sel[r] * C + c]);
-            if (cnt[k] == 0) fst[k] = (uint8_t)r;
-            cnt[k]++;
+            const int k8 = sym_class(msa[(size_t)sel[r] * C + c]) * 8;
+            const unsigned fresh = ((seen >> k8 / 8) & 1u) ^ 1u;
+            cnt += 1ull << k8;
+            fst |= (unsigned long long)((unsigned)r & (0u - fresh)) << k8;
+            seen |= 1u << (k8 / 8);
         }
         uint8_t *o = cstat + (size_t)c * CS;
 #pragma unroll
-        for (int k = 0; k < 6; k++) { o[k] = cnt[k]; o[6 + k] = fst[k]; }
+        for (int k = 0; k < 6; k++) {
+            o[k] = (uint8_t)(cnt >> (8 * k));
+            o[6 + k] = ((seen >> k) & 1u) ? (uint8_t)(fst >> (8 * k)) : (uint8_t)255;
+        }
     }
     __syncthreads();
 }
