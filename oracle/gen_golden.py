@@ -78,6 +78,16 @@ def gen_fmea(U, tmp):
         pkl = U.get_longest_repeats_v4(p, 2000, 30000, 0)
         cases.append(dict(rows=rows, skip_gap=2000, max_len=30000, expected=list(U.load_from_file(pkl).keys())))
     dump("fmea", cases)
+    # stress case: ~30 k lines; stored as the generator parameters + sha256 of the ordered interval names
+    import hashlib
+    sp = dict(seed=77, n_seg=4, n_fam=220, noise=1800, frag=(1, 4), copies=(2, 12))
+    rows = casegen.make_hsp_table(**sp)
+    p = os.path.join(tmp, "fmea_stress.out")
+    with open(p, "w") as f:
+        f.writelines(casegen.hsp_to_blast6_lines(rows))
+    names = list(U.load_from_file(U.get_longest_repeats_v4(p, 2000, 30000, 0)).keys())
+    dump("fmea_stress", dict(params=sp, lines=len(rows), intervals=len(names), skip_gap=2000, max_len=30000,
+                             sha256=hashlib.sha256("\n".join(names).encode()).hexdigest()))
 
 
 def run_msa_case(U, tmp, case):

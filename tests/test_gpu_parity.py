@@ -962,3 +962,14 @@ def test_wide_radix_sort_on_small_inputs(tmp_path):
                          "fmea or query_copies or lib_dedup or find_copies or seed_allvsall"], env=env, capture_output=True, text=True, cwd=root)
     assert rc.returncode == 0, rc.stdout[-3000:] + rc.stderr[-2000:]
     assert " passed" in rc.stdout
+
+
+def test_fmea_stress_hash(ctx):
+    """30 k-line HSP table: the GPU's ordered interval names hash to the reference's sha256 (fixture holds parameters + hash)"""
+    import hashlib
+
+    g = load_golden("fmea_stress")
+    rows = casegen.make_hsp_table(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in g["params"].items()})
+    got, _h = _fmea_gpu(ctx, rows, g["skip_gap"], g["max_len"])
+    assert len(rows) == g["lines"] and len(got) == g["intervals"]
+    assert hashlib.sha256("\n".join(got).encode()).hexdigest() == g["sha256"]

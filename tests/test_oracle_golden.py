@@ -3,6 +3,7 @@ reference's own Python (oracle/gen_golden.py).  CPU only."""
 import numpy as np
 import pytest
 
+import casegen
 import oracle_lib as O
 from conftest import load_golden
 
@@ -256,3 +257,15 @@ def test_ltr_both_ends_golden():
         assert got[0] == c["frames"] and got[1] == c["full"]
         found += 1
     assert found > 40 and found < len(g)
+
+
+def test_fmea_stress_hash():
+    """30 k-line HSP table: the ordered interval names of the reference are pinned by their sha256"""
+    import hashlib
+
+    g = load_golden("fmea_stress")
+    rows = casegen.make_hsp_table(**{k: (tuple(v) if isinstance(v, list) else v) for k, v in g["params"].items()})
+    assert len(rows) == g["lines"]
+    names = O.fmea(O.hsp_arrays([tuple(r) for r in rows]), g["skip_gap"], g["max_len"])
+    assert len(names) == g["intervals"]
+    assert hashlib.sha256("\n".join(names).encode()).hexdigest() == g["sha256"]
