@@ -63,10 +63,14 @@ class Context:
         self.h = h
         self.device = device
 
-    def close(self):
+    def release_copy_index(self):
+        """drops the minimizer index of the packed genome (device memory is freed); the next copy / seeding call rebuilds it"""
         if getattr(self, "_copy_state", None) is not None and getattr(self, "h", None):
             self.lib.hite_copy_index_release(self._copy_state)
-            self._copy_state = None
+        self._copy_state = None
+
+    def close(self):
+        self.release_copy_index()
         if getattr(self, "_pipe_state", None) is not None and getattr(self, "h", None):
             self.lib.hite_pipeline_release(self._pipe_state)
             self._pipe_state = C.c_void_p(None)

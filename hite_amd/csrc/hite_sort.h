@@ -1,7 +1,8 @@
-// hite_sort.h -- hand-written stable LSD radix sort of (u64 key, u32 value) pairs, shared by FMEA and the
-// copy finder.  8 bits per pass; per pass: per-tile digit histogram (LDS atomics), three-phase scan of the
-// [digit][tile] matrix, stable scatter whose in-tile rank comes from wave ballots (lanes with the same digit)
-// plus per-wave digit counts in LDS.  HBM streaming: 12 B read + 12 B written per element per pass.
+// hite_sort.h -- hand-written stable LSD radix sort of (u64 key, u32 value) pairs, shared by FMEA, the copy finder and the
+// seeding stage.  Per pass: per-tile digit histogram (LDS atomics), three-phase scan of the [digit][tile] matrix, stable
+// scatter.  Two forms: 8-bit digits with a direct scatter (rank from wave ballots + per-wave digit counts) for small
+// inputs; 10-bit digits with the tile ranked and staged in LDS in output order (rs_scatter_staged_kernel) from 4 M elements
+// on.  HBM streaming: 8 B (histogram) + 12 B read and 12 B written per element per pass.
 #pragma once
 #include "hite_common.h"
 #include "hite_scan.h"

@@ -413,7 +413,7 @@ def mask_genome_intactTE(TE_lib, genome_path, work_dir=None, thread=1, ref_index
         return masked
     ctx = get_ctx(device)
     ctx.genome_pack([contigs[n] for n in names])
-    ctx._copy_state = None
+    ctx.release_copy_index()
     _PACKED["path"] = None
     tab = ctx.find_copies([tes[n] for n in te_names])
     cc, ss, ee = [], [], []
@@ -459,7 +459,7 @@ def determine_repeat_boundary_v5(repeats_path, longest_repeats_path, fixed_exten
         store_fasta({}, longest_repeats_path)
         return longest_repeats_path
     ctx.genome_pack([contigs[n] for n in names])
-    ctx._copy_state = None
+    ctx.release_copy_index()
     _PACKED["path"] = None   # the reference genome has to be packed again by whoever needs it next
     seg_len = max(len(contigs[n]) for n in names)
     tab = ctx.seed_allvsall(seg_len=max(seg_len, 1))

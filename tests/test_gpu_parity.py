@@ -331,7 +331,7 @@ def test_find_copies_vs_twin(ctx):
     for seed, nf in ((11, 16), (23, 24), (5, 10)):
         g = synth_small.make(seed, n_fam=nf)
         ctx.genome_pack(g["contigs"])
-        ctx._copy_state = None  # new genome -> new index
+        ctx.release_copy_index()  # new genome -> new index
         cands = list(g["cands"]) + ["ACGT" * 3, "A" * 40, g["contigs"][0][5000:5400]]  # too short / low complexity / unique region
         got = ctx.find_copies(cands)
         exp = O.find_copies(g["contigs"], cands)
@@ -342,7 +342,7 @@ def test_find_copies_vs_twin(ctx):
 
     g = synth_small.make(11, n_fam=16)
     ctx.genome_pack(g["contigs"])
-    ctx._copy_state = None
+    ctx.release_copy_index()
     tab = ctx.find_copies(g["cands"])
     copies = [[x[:4] for x in t] for t in tab]
     res, _ = ctx.flank_region_align("tir", g["cands"], copies, plant=1)
@@ -521,7 +521,7 @@ def test_seed_allvsall_vs_twin(ctx):
     for seed, nf, seg in ((31, 10, 100_000), (7, 14, 37_000), (19, 6, 1_000_000)):
         g = synth_small.make(seed, n_fam=nf, n_chr=2, chr_len=260_000)
         ctx.genome_pack(g["contigs"])
-        ctx._copy_state = None
+        ctx.release_copy_index()
         got = ctx.seed_allvsall(seg_len=seg)
         exp = O.seed_allvsall(g["contigs"], seg_len=seg)
         sc, so = ctx.seed_segments(seg)
@@ -671,14 +671,14 @@ def test_seed_allvsall_edge_cases(ctx):
     g4 = [casegen.rand_seq(rng, 3000) + unit * 6 + casegen.rand_seq(rng, 3000), "N" * 2000 + casegen.rand_seq(rng, 4000)]  # tandem array
     for contigs, seg in ((g1, 10_000), (g2, 1000), (g3, 20_000), (g3, 1_000_000), (g4, 2_500)):
         ctx.genome_pack(contigs)
-        ctx._copy_state = None
+        ctx.release_copy_index()
         got = ctx.seed_allvsall(seg_len=seg)
         exp = O.seed_allvsall(contigs, seg_len=seg)
         for k in ("qseg", "sseg", "qs", "qe", "ss", "se"):
             assert np.array_equal(got[k], exp[k]), (len(contigs), seg, k, len(got[k]), len(exp[k]))
     assert len(got["qseg"]) > 0
     ctx.genome_pack(g3)
-    ctx._copy_state = None
+    ctx.release_copy_index()
     h = ctx.seed_allvsall(seg_len=1_000_000)
     assert (h["ss"] > h["se"]).any() and (h["ss"] < h["se"]).any()   # both strands reported
 
