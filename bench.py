@@ -284,7 +284,7 @@ def main():
                 roof["valu_issue"] = {"achieved": round(valu_rate, 1), "peak": PEAK_VALU_GINST, "unit": "G wave64-inst/s",
                                       "frac": round(valu_rate / PEAK_VALU_GINST, 4), "inst_per_dp_step": VALU_PER_DP_STEP}
         out = {
-            "metric": "candidate TE boundaries/sec on 1 Gbp synthetic genome (fine stage: copy finding+gather+align+vote+judge)",
+            "metric": "candidate TE boundaries/sec on %s synthetic genome (fine stage: copy finding+gather+align+vote+judge)" % ("1 Gbp" if args.genome_mbp == 1000 else "%d Mbp" % args.genome_mbp),
             "value": round(value, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
