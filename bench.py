@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--seed", type=int, default=20250927 + 3)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=1, help="worker processes of the cpu_baseline leg (opt-in; default: the scalar port on one core)")
     ap.add_argument("--copies", choices=["found", "truth"], default="found",
                     help="found: copy finding (minimizer index lookup) runs inside the timed step; truth: the generator's copy table is the input")
     ap.add_argument("--verify", type=int, default=0, help="re-judge this many random candidates with the CPU oracle chain and compare")
@@ -306,7 +307,7 @@ def main():
             ctx.lib.hite_debug_judge_clocks(buf, 1)
             out["judge_phase_ticks"] = [int(x) for x in buf[:12]]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, args.cpu_threads)
         if args.verify > 0:
             if args.copies == "found":
                 # the oracle chain re-judges on the SAME copy table the GPU found (copy finding itself is
@@ -449,22 +450,18 @@ def coarse_cpu_baseline(args, mbp):
                       % (mbp, dt, len(h["qseg"]), len(names))}
 
 
-def cpu_baseline(w, budget_s):
-    """the oracle chain (oracle/*.c through tests/oracle_pipeline.py: a single-threaded CPU port of the same
-    step) timed on a bounded sample of the same candidates on this host."""
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
+_CPU = {}
+
+
+def _cpu_worker(job):
+    """one worker of the multi-process CPU baseline: judges its slice of the sample until the budget runs out"""
+    cands, budget_s = job
     import oracle_pipeline as OP
 
-    co = w["contig_off"]
-    g = w["genome"]
-    host = g.cpu().numpy() if hasattr(g, "cpu") else g
-    contigs = {ci: host[co[ci]:co[ci + 1]].tobytes() for ci in range(len(co) - 1)}
-    n_cand = len(w["cand_off"]) - 1
-    rng = np.random.default_rng(1)
-    order = rng.permutation(n_cand)
+    w, contigs = _CPU["w"], _CPU["contigs"]
     t0 = time.perf_counter()
     done = 0
-    for c in order:
+    for c in cands:
         a, b = int(w["copy_first"][c]), int(w["copy_first"][c + 1])
         copies = [(int(w["contig"][i]), int(w["start1"][i]), int(w["end1"][i]), int(w["minus"][i])) for i in range(a, b)]
         cand = w["cands"][w["cand_off"][c]:w["cand_off"][c + 1]].tobytes().decode()
@@ -472,9 +469,38 @@ def cpu_baseline(w, budget_s):
         done += 1
         if time.perf_counter() - t0 > budget_s and done >= 8:
             break
+    return done
+
+
+def cpu_baseline(w, budget_s, threads=1):
+    """the oracle chain (oracle/*.c through tests/oracle_pipeline.py: a CPU port of the same step, gather + alignment +
+    sparse columns + judge on the copy table of the workload) timed on a bounded sample of the same candidates on this host.
+    threads > 1 (--cpu-threads, opt-in): the sample is split over forked worker processes that only run CPU code -- how the
+    reference itself fans candidates out (ProcessPoolExecutor, Util.py:8141)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_pipeline as OP  # noqa: F401  (imported before forking)
+
+    co = w["contig_off"]
+    g = w["genome"]
+    host = g.cpu().numpy() if hasattr(g, "cpu") else g
+    contigs = {ci: host[co[ci]:co[ci + 1]].tobytes() for ci in range(len(co) - 1)}
+    hw = {k: (v.cpu().numpy() if hasattr(v, "cpu") else v) for k, v in w.items() if k in ("copy_first", "contig", "start1", "end1", "minus", "cands", "cand_off")}
+    _CPU["w"], _CPU["contigs"] = hw, contigs
+    n_cand = len(hw["cand_off"]) - 1
+    order = np.random.default_rng(1).permutation(n_cand)
+    threads = max(1, int(threads))
+    t0 = time.perf_counter()
+    if threads == 1:
+        done = _cpu_worker((order, budget_s))
+    else:
+        import multiprocessing as mp
+
+        with mp.get_context("fork").Pool(threads) as pool:
+            done = sum(pool.map(_cpu_worker, [(order[k::threads], budget_s) for k in range(threads)]))
     dt = time.perf_counter() - t0
-    return {"value": round(done / dt, 3), "unit": "candidates/s", "cores": 1, "kind": "port",
-            "sample": "%d random candidates of the same workload (%.1f s), oracle chain single thread" % (done, dt)}
+    return {"value": round(done / dt, 3), "unit": "candidates/s", "cores": threads, "kind": "port",
+            "sample": "%d random candidates of the same workload (%.1f s), oracle chain, %s" %
+                      (done, dt, "single thread" if threads == 1 else "%d worker processes" % threads)}
 
 
 if __name__ == "__main__":
