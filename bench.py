@@ -307,7 +307,11 @@ def main():
             ctx.lib.hite_debug_judge_clocks(buf, 1)
             out["judge_phase_ticks"] = [int(x) for x in buf[:12]]
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, args.cpu_threads)
+            try:
+                out["cpu_baseline"] = cpu_baseline(w, args.cpu_seconds, args.cpu_threads)
+            except Exception as e:   # the GPU line must not depend on the CPU leg
+                out["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": args.cpu_threads, "kind": "port",
+                                       "sample": "failed: %s: %s" % (type(e).__name__, e)}
         if args.verify > 0:
             if args.copies == "found":
                 # the oracle chain re-judges on the SAME copy table the GPU found (copy finding itself is
