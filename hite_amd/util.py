@@ -53,6 +53,73 @@ def store_fasta(contigs, file_path):
             f.write(">" + name + "\n" + seq + "\n")
 
 
+def rename_fasta(input, output, header="N"):
+    """Util.py:7500 -- names become <header>_<i>, a '#class' suffix (text after the last '#') is kept"""
+    names, contigs = read_fasta(input)
+    with open(output, "w") as f_save:
+        for node_index, name in enumerate(names):
+            parts = str(name).split("#")
+            new_name = header + "_" + str(node_index)
+            if len(parts) >= 2:
+                new_name += "#" + parts[-1]
+            f_save.write(">" + new_name + "\n" + contigs[name] + "\n")
+
+
+def rename_reference(input, output, chr_name_map):
+    """Util.py:7517 -- contigs renamed chr_<i>; the map file holds 'new\told' lines"""
+    names, contigs = read_fasta(input)
+    chr_name_dict = {}
+    with open(output, "w") as f_save:
+        for ref_index, name in enumerate(names):
+            new_name = "chr_" + str(ref_index)
+            f_save.write(">" + new_name + "\n" + contigs[name] + "\n")
+            chr_name_dict[new_name] = name
+    with open(chr_name_map, "w") as f_save:
+        for new_name, old in chr_name_dict.items():
+            f_save.write(new_name + "\t" + old + "\n")
+
+
+def lib_add_prefix(HiTE_lib, prefix):
+    """Util.py:11559 -- every name gets '<prefix>-' in front, in place"""
+    lib_names, lib_contigs = read_fasta(HiTE_lib)
+    store_fasta({prefix + "-" + name: lib_contigs[name] for name in lib_names}, HiTE_lib)
+    return HiTE_lib
+
+
+def file_exist(resut_file):
+    """Util.py:2831 -- the reference's 'did this stage succeed' test: a FASTA with at least one record, any other file with
+    a non-comment non-blank line, a non-empty directory"""
+    if os.path.isfile(resut_file):
+        if os.path.getsize(resut_file) > 0:
+            if resut_file.endswith(".fa") or resut_file.endswith(".fasta"):
+                return len(read_fasta(resut_file)[1]) > 0
+            with open(resut_file, "r") as f_r:
+                for line in f_r:
+                    if not line.startswith("#") and line.strip():
+                        return True
+            return False
+        return False
+    if os.path.isdir(resut_file):
+        return len(os.listdir(resut_file)) > 0
+    return False
+
+
+def update_prev_TE(prev_TE, cur_file):
+    """Util.py:6378 -- append cur_file (+ newline) to prev_TE under a lock file (several stage scripts share prev_TE)"""
+    if not os.path.exists(cur_file):
+        print("Warning: %s not found, skipping" % cur_file)
+        return
+    import fcntl
+
+    with open(prev_TE + ".lock", "w") as lock_f:
+        fcntl.flock(lock_f, fcntl.LOCK_EX)
+        try:
+            with open(prev_TE, "a+") as target_f, open(cur_file, "r") as source_f:
+                target_f.write(source_f.read() + "\n")
+        finally:
+            fcntl.flock(lock_f, fcntl.LOCK_UN)
+
+
 def set_reference(reference, device=0):
     """pack the genome into HBM once per process (replaces the per-stage read_fasta(reference))"""
     ctx = get_ctx(device)

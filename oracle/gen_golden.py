@@ -369,7 +369,40 @@ def gen_host(U):
             files = U.split_and_store_sequences(names, {n: "A" * l for n, l in zip(names, lens)}, d, thr)
             groups = [U.read_fasta(f[0])[0] for f in files]
         split_cases.append({"names": names, "lens": lens, "thr": thr, "groups": groups})
+    # on-disk format helpers: rename_fasta (:7500), rename_reference (:7517), lib_add_prefix (:11559),
+    # file_exist (:2831), update_prev_TE (:6378) -- file text in, file text out
+    fmt = {}
+    with tempfile.TemporaryDirectory() as d:
+        src = os.path.join(d, "in.fa")
+        text = ">a#DNA/hAT extra words\nACGTacgtNN\nGGGG\n>b\nTTTT\n>c#x#LTR/Gypsy\nCCCC\n>empty\n>d\tdescr\nAAAA\n"
+        open(src, "w").write(text)
+        out = os.path.join(d, "out.fa")
+        U.rename_fasta(src, out, "TIR_0")
+        fmt["rename_fasta"] = {"in": text, "header": "TIR_0", "out": open(out).read()}
+        ref_out, cmap = os.path.join(d, "ref.fa"), os.path.join(d, "map.txt")
+        U.rename_reference(src, ref_out, cmap)
+        fmt["rename_reference"] = {"in": text, "out": open(ref_out).read(), "map": open(cmap).read()}
+        lib = os.path.join(d, "lib.fa")
+        open(lib, "w").write(text)
+        U.lib_add_prefix(lib, "genomeA")
+        fmt["lib_add_prefix"] = {"in": text, "prefix": "genomeA", "out": open(lib).read()}
+        fe = []
+        for name, body in (("x.fa", ">a\nACGT\n"), ("y.fa", ">a\n"), ("z.fa", ""), ("t.txt", "# only a comment\n\n"), ("u.txt", "#c\nline\n"),
+                           ("v.list", "   \n")):
+            pth = os.path.join(d, name)
+            open(pth, "w").write(body)
+            fe.append([name, body, bool(U.file_exist(pth))])
+        os.makedirs(os.path.join(d, "emptydir")); os.makedirs(os.path.join(d, "fulldir")); open(os.path.join(d, "fulldir", "f"), "w").write("1")
+        fmt["file_exist"] = {"files": fe, "emptydir": bool(U.file_exist(os.path.join(d, "emptydir"))),
+                             "fulldir": bool(U.file_exist(os.path.join(d, "fulldir"))), "missing": bool(U.file_exist(os.path.join(d, "nope")))}
+        prev, cur = os.path.join(d, "prev_TE.fa"), os.path.join(d, "cur.fa")
+        open(prev, "w").write(">p\nAAAA\n")
+        open(cur, "w").write(">q\nCCCC")
+        U.update_prev_TE(prev, cur)
+        U.update_prev_TE(prev, os.path.join(d, "absent.fa"))
+        fmt["update_prev_TE"] = {"prev": ">p\nAAAA\n", "cur": ">q\nCCCC", "out": open(prev).read()}
     rev = [casegen.rand_seq(rng, 30) for _ in range(5)] + ["ACGTNRYacgt-", ""]
+    dump("host_formats", fmt)
     dump("host_glue", {"short_tir": short_cases, "filter_dup": dup_cases, "split": split_cases,
                        "revcomp": [[s, U.getReverseSequence(s)] for s in rev]})
 

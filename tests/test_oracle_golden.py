@@ -269,3 +269,41 @@ def test_fmea_stress_hash():
     names = O.fmea(O.hsp_arrays([tuple(r) for r in rows]), g["skip_gap"], g["max_len"])
     assert len(names) == g["intervals"]
     assert hashlib.sha256("\n".join(names).encode()).hexdigest() == g["sha256"]
+
+
+def test_host_formats_golden(tmp_path):
+    """on-disk format helpers vs the reference's outputs: rename_fasta, rename_reference, lib_add_prefix,
+    file_exist, update_prev_TE"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from hite_amd import util
+
+    g = load_golden("host_formats")
+    src = tmp_path / "in.fa"
+    c = g["rename_fasta"]
+    src.write_text(c["in"])
+    util.rename_fasta(str(src), str(tmp_path / "out.fa"), c["header"])
+    assert (tmp_path / "out.fa").read_text() == c["out"]
+    c = g["rename_reference"]
+    util.rename_reference(str(src), str(tmp_path / "ref.fa"), str(tmp_path / "map.txt"))
+    assert (tmp_path / "ref.fa").read_text() == c["out"] and (tmp_path / "map.txt").read_text() == c["map"]
+    c = g["lib_add_prefix"]
+    lib = tmp_path / "lib.fa"
+    lib.write_text(c["in"])
+    assert util.lib_add_prefix(str(lib), c["prefix"]) == str(lib) and lib.read_text() == c["out"]
+    c = g["file_exist"]
+    for name, body, exp in c["files"]:
+        p = tmp_path / name
+        p.write_text(body)
+        assert util.file_exist(str(p)) == exp, name
+    (tmp_path / "emptydir").mkdir(); (tmp_path / "fulldir").mkdir(); (tmp_path / "fulldir" / "f").write_text("1")
+    assert util.file_exist(str(tmp_path / "emptydir")) == c["emptydir"] and util.file_exist(str(tmp_path / "fulldir")) == c["fulldir"]
+    assert util.file_exist(str(tmp_path / "nope")) == c["missing"]
+    c = g["update_prev_TE"]
+    prev, cur = tmp_path / "prev_TE.fa", tmp_path / "cur.fa"
+    prev.write_text(c["prev"]); cur.write_text(c["cur"])
+    util.update_prev_TE(str(prev), str(cur))
+    util.update_prev_TE(str(prev), str(tmp_path / "absent.fa"))
+    assert prev.read_text() == c["out"]
