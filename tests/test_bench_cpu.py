@@ -1,0 +1,33 @@
+"""CPU-side checks of bench.py: the cpu_baseline leg (the oracle chain is test / measurement infrastructure, the only
+part of bench.py that may touch it) on a tiny workload, scalar and multi-process."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def test_cpu_baseline_leg_runs_on_a_tiny_workload():
+    import torch
+
+    import bench
+    from hite_amd import synth
+
+    w = synth.make_workload(genome_bp=2_000_000, n_tir=6, n_ltr=4, cands_per_family=2, seed=11, device=torch.device("cpu"))
+    for threads in (1, 2):
+        r = bench.cpu_baseline(w, 1.0, threads)
+        assert set(r) == {"value", "unit", "cores", "kind", "sample"}
+        assert r["cores"] == threads and r["kind"] == "port" and r["unit"] == "candidates/s" and r["value"] > 0
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    """no CPU fallback: without a GPU the bench exits with a message instead of timing something else"""
+    import subprocess
+
+    import torch
+
+    if torch.cuda.is_available():
+        return
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "0"],
+                        capture_output=True, text=True)
+    assert rc.returncode != 0 and "needs a GPU" in (rc.stdout + rc.stderr)
