@@ -1,40 +1,35 @@
 /*
  * hite_oracle_msa.c -- TEST INFRASTRUCTURE ONLY (see hite_oracle.c header).
  *
- * CPU twin of the build's OWN star-alignment stage (hite_amd/csrc/hite_msa.hip), which stands
- * where the reference shells out to `mafft --preservecase --quiet --thread 1`
- * (/root/reference/module/Util.py:10416).  mafft is third-party, unpinned
- * (environment.yml:30) and absent from this image: PARITY UNPINNED at that boundary
- * (SURVEY.md 8c).  What is pinned is: HIP output == this twin, byte for byte, and everything
- * downstream of the gapped matrix == the reference (hite_oracle.c).
+ * CPU twin of the product's star-alignment stage (hite_amd/csrc/hite_align.hip + hite_msa.hip), which stands
+ * where the reference shells out to `mafft` (/root/reference/module/Util.py:10416, third-party, unpinned,
+ * absent: PARITY UNPINNED against mafft).  The DEFINITION of the pairwise alignment is band-free and lives in
+ * hite_oracle_nw.c (optimal global alignment under unit costs, canonical traceback diagonal > up > left).
+ * This file restates HOW the product computes it, so that the product can be checked byte for byte also on
+ * the pairs it cannot certify:
  *
- * Definition (shared with the HIP kernels)
- *   centre = row 0 of the candidate; every other row is aligned to it by global
- *   Needleman-Wunsch, match +2 (equal and one of A, C, G, T), mismatch -2, linear gap -4, restricted to an
- *   adaptive band of W=64 cells per anti-diagonal s=i+j (rows i in [t, t+63]):
- *     - t(0) = -32; after anti-diagonal s the band moves right (t same) if H[lane0] > H[lane63],
- *       down (t+1) if H[lane0] < H[lane63], on a tie down when s is even else right;
- *     - then forced: t+1 only if t+1 <= min(m,s+1)-31, and t+1 if t < max(0,s+1-n)-32;
- *   every lane of the band evaluates the same recurrence every step: bases outside the sequences
- *   are sentinels that never match (so cells outside the matrix only ever hold "junk" that
- *   cannot beat a real score), values shifted in from outside the band are 0 and real scores
- *   are biased by 2^28 (H(0,0) = 2^28); 'N' (any byte other than A, C, G, T) never matches.
- *   Stored form (part of the definition, it fixes what the junk cells hold): H is shifted by +4
- *   per anti-diagonal (the recurrence adds +10 / +6 / 0 for match / mismatch / gap), scaled by 4,
- *   and the low two bits carry the winning operand: V = 4 H + tag, candidates
- *   diag = D + 4*score + 2, up = U (stored with tag 1), left = L - 1 (tag 0), V = max of the
- *   three (so ties go diag >= up >= left), direction = V & 3, and (V & ~3) | 1 is stored.  The 0
- *   that enters at a band edge is not transformed (left operand: 0 - 1).  The alignment
- *   fails if H(m,n) <= 2^27 (end cell not reachable inside the band).
- *   The diagonal operand is carried in ONE history register H(s-2)' = H(s-2) re-aligned to the
- *   origin of anti-diagonal s-1, which is simply the previous step's "left" operand; an element
- *   that was shifted out of the band by that re-alignment is gone (0) even if a later move
- *   would shift it back in.
- *   Ties in the recurrence: diag >= up >= left.
- *   Traceback from (m,n) gives per centre position p: gap flag (row has '-') and the number of
- *   row bases inserted before p.  Columns: for p = 0..m an insertion block of
- *   max_r ins[r][p] columns (bases left-justified, '-' padded) followed (p < m) by the centre
- *   column.
+ *   Myers / Hyyro bit-parallel edit distance over an adaptive band of W = 32 NW rows per column.
+ *   Column j (row base b[j-1]) covers the centre rows r = t_j + 1 + k, bit k = 0 .. W-1;  t_0 = -W/2, so the
+ *   band's middle starts on row 0.  Rows r <= 0 are virtual (D(r, j) = j - r: they never help), rows r > m are
+ *   padding that never matches.
+ *   Steering: s_j = t_j - t_{j-1} in {0, 1, 2}.  With d = (sum of the vertical deltas of column j-1 over the
+ *   middle 128 rows of the band), s_j = 0 if d > STEER, 2 if d < -STEER, else 1; then clamped so that
+ *   t_j <= m - W/2 and t_j >= m - W/2 - 2 (n - j)  (t_n = m - W/2: the band's middle ends on row m).  A pair
+ *   for which the lower clamp needs a step > 2 is infeasible (status 2).
+ *   Band edges are pessimistic: a row that enters at the bottom has vertical delta +1 in the previous column,
+ *   the horizontal delta above the band's first row is +1.  Every band value is therefore the cost of a real
+ *   alignment (an upper bound of D), exact whenever an optimal path to the cell stays inside the band.
+ *   Per column the recurrence yields D0 (diagonal delta 0), Ph/Mh, Pv/Mv; the traceback bits are
+ *   DiagOK = Eq | ~D0 and UpOK = Pv (new), left otherwise: the canonical preference of hite_oracle_nw.c.
+ *   The product keeps these bits only for the SLICE = the middle 128 rows of the band (it re-computes the slice
+ *   from check points and, for bands wider than the slice, 2 bytes of boundary information per column); a traceback that needs a cell outside the slice fails
+ *   (status 1) and the pair is re-aligned by the wide fall-back, which keeps the bits of the whole band
+ *   (`full` below) and fails only if the path leaves the band itself.
+ *   Certificate (Ukkonen): let [LO, HI] be the diagonals i - j that the band covered in EVERY column (edges
+ *   that coincide with the matrix border do not constrain).  Every alignment of cost <= k stays within the
+ *   diagonals [min(0, m-n) - e, max(0, m-n) + e], e = floor((k - |m-n|) / 2).  With E = the largest e for which
+ *   that range lies in [LO, HI] and k* = |m-n| + 2 E + 1:  U <= k*  =>  U is the edit distance and every cell
+ *   the canonical traceback consults is exact, i.e. the result IS the alignment of hite_oracle_nw.c.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -42,131 +37,229 @@
 
 #define ORC_EINVAL (-1002)
 #define ORC_ECAP (-1001)
-#define W 64
-#define BIAS (1 << 28)
-/* stored scores: shifted by +4 per anti-diagonal ((+2, -2, -4) + (8, 8, 4) = 10, 6, 0), times 4, + tag 2 */
-#define SC_MATCH 42
-#define SC_MIS 26
+#define NWMAX 64
+#define STEER 48          /* dead zone of the steering */
+#define SLICE_WORDS 4     /* rows kept for the traceback: the middle 128 of the band */
+#define MARGIN 48         /* exact mode: first escalation level is the smallest band with 32 NW >= U + MARGIN */
 
-/* align row b[0..n) to centre a[0..m); ops[p] (p = 0..m): low 15 bits = insertions before p,
- * bit 15 = row has a gap at centre position p.  returns 0 or <0. */
-static int pair_align(const uint8_t *a, int m, const uint8_t *b, int n, uint16_t *ops) {
-    int steps = m + n;
-    /* direction codes per (s, lane) and the band origin t per s */
-    uint8_t *dir = (uint8_t *)malloc((size_t)(steps + 1) * W);
-    int *ts = (int *)malloc(sizeof(int) * (steps + 1));
-    int prev[W], cur[W];
-    if (!dir || !ts) { free(dir); free(ts); return ORC_EINVAL; }
-    int t = -32;
-    int ppal[W]; /* H(s-2) re-aligned to the origin of anti-diagonal s-1 (see header) */
-    for (int k = 0; k < W; k++) { prev[k] = 0; ppal[k] = 0; }
-    prev[32] = (BIAS << 2) | 1; /* H(0,0), stored form */
+static inline int is_acgt(unsigned c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
+static inline int popc(uint32_t x) { return __builtin_popcount(x); }
+
+/*
+ * align row b[0..n) to centre a[0..m) with a band of NW words.  ops: m entries (encoding: hite_oracle_nw.c).
+ * full = 0: the traceback may only use the slice (middle 128 rows);  full = 1: the whole band.
+ * out[0] = U (cost of the alignment found), out[1] = certified (0/1; a property of the forward pass), out[2] = status (0 ok, 1 traceback left the
+ * slice / band, 2 infeasible), out[3] = k* (the certificate's bound, -1 if none).  returns 0 or < 0 (bad arguments).
+ */
+int orc_bp_pair(const uint8_t *a, int m, const uint8_t *b, int n, int NW, int full, uint16_t *ops, int32_t *out) {
+    if (m <= 0 || n <= 0 || m > 32767 || n > 32767 || NW < 2 || NW > NWMAX || (NW & 1)) return ORC_EINVAL;
+    const int W = 32 * NW, H = W / 2;
+    uint32_t Pv[NWMAX], Mv[NWMAX], Eq[NWMAX], D0[NWMAX], Ph[NWMAX], Mh[NWMAX];
+    uint32_t *dg = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1) * NW);
+    uint32_t *up = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1) * NW);
+    int32_t *ts = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
+    if (!dg || !up || !ts) { free(dg); free(up); free(ts); return ORC_EINVAL; }
+    int t = -H;
+    for (int w = 0; w < NW; w++) {
+        Pv[w] = 0; Mv[w] = 0;
+        for (int k = 0; k < 32; k++) { int r = t + 1 + 32 * w + k; if (r >= 1) Pv[w] |= 1u << k; else Mv[w] |= 1u << k; }
+    }
+    long stop = H;                       /* D(t_j, j): the cell above the band's first row */
+    long LO = -(1L << 40), HI = 1L << 40;
+    int status = 0;
     ts[0] = t;
-    for (int s = 1; s <= steps; s++) {
-        /* choose the move from anti-diagonal s-1 (held in prev, origin t) */
-        int h0 = prev[0], h63 = prev[W - 1];
-        int move;
-        if (h0 > h63) move = 0; else if (h0 < h63) move = 1; else move = (s & 1) ? 1 : 0;
-        int lo = s - n > 0 ? s - n : 0, hi = m < s ? m : s;
-        int tn = t + move;
-        if (tn > hi - 31) tn = t;
-        if (tn < lo - 32) tn = t + 1;
-        int down = tn != t;
-        int hlv[W];
-        for (int k = 0; k < W; k++) {
-            int i = tn + k, j = s - i;
-            /* down : (left, up, diag) = (H(s-1)[k+1], H(s-1)[k],   H(s-2)'[k])
-             * right: (left, up, diag) = (H(s-1)[k],   H(s-1)[k-1], H(s-2)'[k-1])   0 from outside the band */
-            int hl = (down ? (k + 1 < W ? prev[k + 1] : 0) : prev[k]) - 1;
-            int hu = down ? prev[k] : (k >= 1 ? prev[k - 1] : 0);
-            int hd = down ? ppal[k] : (k >= 1 ? ppal[k - 1] : 0);
-            int x = (i >= 1 && i <= m) ? a[i - 1] : 0xFF;
-            int y = (j >= 1 && j <= n) ? b[j - 1] : 0xFE;
-            int cd = hd + ((x == y && (x == 'A' || x == 'C' || x == 'G' || x == 'T')) ? SC_MATCH : SC_MIS);
-            int v4 = cd > hu ? cd : hu, v, d;
-            if (hl > v4) v4 = hl;
-            d = (v4 & 2) ? 0 : ((v4 & 1) ? 1 : 2);   /* junk cells may carry any tag; they are never on the path */
-            v = (v4 & ~3) | 1;
-            cur[k] = v;
-            hlv[k] = hl;
-            dir[(size_t)s * W + k] = (uint8_t)d;
+    for (int j = 1; j <= n; j++) {
+        /* steering from column j-1 */
+        int dsum = 0;
+        for (int w = NW / 2 - SLICE_WORDS / 2; w < NW / 2 + SLICE_WORDS / 2; w++) dsum += popc(Pv[w]) - popc(Mv[w]);
+        int s = dsum > STEER ? 0 : (dsum < -STEER ? 2 : 1);
+        const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
+        if (t + s > hi_t) s = hi_t - t;
+        if (t + s < lo_t) s = lo_t - t;
+        if (s < 0 || s > 2) { status = 2; break; }
+        /* shift the band down by s rows: rows that enter have vertical delta +1 in column j-1 */
+        for (int k = 0; k < s; k++) stop += (long)((Pv[0] >> k) & 1) - (long)((Mv[0] >> k) & 1);
+        stop += 1;
+        if (s) {
+            for (int w = 0; w < NW; w++) {
+                uint32_t pn = w + 1 < NW ? Pv[w + 1] : 0xffffffffu, mn = w + 1 < NW ? Mv[w + 1] : 0u;
+                Pv[w] = (Pv[w] >> s) | (pn << (32 - s));
+                Mv[w] = (Mv[w] >> s) | (mn << (32 - s));
+            }
         }
-        memcpy(ppal, hlv, sizeof hlv); /* this step's "left" operand is the next step's re-aligned H(s-2) */
-        memcpy(prev, cur, sizeof cur);
-        t = tn;
-        ts[s] = t;
-    }
-    {
-        int kf = m - t;
-        if (kf < 0 || kf >= W || prev[kf] <= (BIAS / 2) * 4) { free(dir); free(ts); return ORC_EINVAL; }
-    }
-    /* traceback */
-    int i = m, j = n, cur_ins = 0, pend_gap = 0;
-    while (i > 0 || j > 0) {
-        int s = i + j;
-        int k = i - ts[s];
-        int d;
-        if (k < 0 || k >= W) { free(dir); free(ts); return ORC_EINVAL; }
-        d = dir[(size_t)s * W + k];
-        if (i == 0) d = 2; else if (j == 0) d = 1; /* only possible moves on the borders */
-        if (d == 2) { cur_ins++; j--; }
-        else {
-            ops[i] = (uint16_t)((cur_ins > 0x7fff ? 0x7fff : cur_ins) | (pend_gap << 15));
-            pend_gap = d == 1;
-            cur_ins = 0;
-            i--;
-            if (d == 0) j--;
+        t += s;
+        ts[j] = t;
+        if (t >= 1 && (long)t + 1 - j > LO) LO = (long)t + 1 - j;
+        if (t + W < m && (long)t + W - j < HI) HI = (long)t + W - j;
+        /* match bits */
+        const unsigned y = b[j - 1];
+        const int ya = is_acgt(y);
+        for (int w = 0; w < NW; w++) {
+            uint32_t e = 0;
+            if (ya) for (int k = 0; k < 32; k++) { int r = t + 1 + 32 * w + k; if (r >= 1 && r <= m && a[r - 1] == y) e |= 1u << k; }
+            Eq[w] = e;
+        }
+        /* D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv, carries run from low rows to high rows */
+        uint32_t carry = 0;
+        for (int w = 0; w < NW; w++) {
+            uint64_t x = (uint64_t)(Eq[w] & Pv[w]) + Pv[w] + carry;
+            carry = (uint32_t)(x >> 32);
+            D0[w] = (((uint32_t)x) ^ Pv[w]) | Eq[w] | Mv[w];
+            Ph[w] = Mv[w] | ~(D0[w] | Pv[w]);
+            Mh[w] = Pv[w] & D0[w];
+        }
+        uint32_t pc = 1, mc = 0;          /* horizontal delta above the band's first row: +1 */
+        uint32_t *dgj = dg + (size_t)j * NW, *upj = up + (size_t)j * NW;
+        for (int w = 0; w < NW; w++) {
+            uint32_t phs = (Ph[w] << 1) | pc, mhs = (Mh[w] << 1) | mc;
+            pc = Ph[w] >> 31; mc = Mh[w] >> 31;
+            Pv[w] = mhs | ~(D0[w] | phs);
+            Mv[w] = phs & D0[w];
+            dgj[w] = Eq[w] | ~D0[w];
+            upj[w] = Pv[w];
         }
     }
-    ops[0] = (uint16_t)((cur_ins > 0x7fff ? 0x7fff : cur_ins) | (pend_gap << 15));
-    free(dir); free(ts);
+    int U = -1, cert = 0;
+    long kstar = -1;
+    if (status == 0) {
+        long u = stop;                    /* t_n = m - H: row m is bit H - 1 */
+        for (int k = 0; k < H; k++) u += (long)((Pv[k >> 5] >> (k & 31)) & 1) - (long)((Mv[k >> 5] >> (k & 31)) & 1);
+        U = (int)u;
+        const long d = (long)m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
+        long E = dmin - LO;
+        if (HI - dmax < E) E = HI - dmax;
+        if (E > (1L << 30)) E = 1L << 30;
+        if (E >= 0) { kstar = ad + 2 * E + 1; cert = u <= kstar; }
+        /* canonical traceback on the band's bits */
+        int i = m, j = n;
+        const int klo = full ? 0 : H - 16 * SLICE_WORDS, khi = full ? W : H + 16 * SLICE_WORDS;
+        while (i > 0 && j > 0) {
+            const int k = i - ts[j] - 1;
+            if (k < klo || k >= khi) { status = 1; break; }
+            if ((dg[(size_t)j * NW + (k >> 5)] >> (k & 31)) & 1) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
+            else if ((up[(size_t)j * NW + (k >> 5)] >> (k & 31)) & 1) { ops[i - 1] = (uint16_t)(j | 0x8000); i--; }
+            else j--;
+        }
+        if (status == 0) for (; i > 0; i--) ops[i - 1] = (uint16_t)0x8000;
+    }
+    out[0] = U; out[1] = cert; out[2] = status; out[3] = (int32_t)(kstar > 0x7fffffff ? 0x7fffffff : kstar);
+    free(dg); free(up); free(ts);
     return 0;
 }
 
 /*
- * One candidate: R windows (win + win_off[R+1]); writes cols and, if msa != NULL and cap suffices,
- * the R x cols alignment (row-major).  Returns 0 or <0.
+ * The product's schedule for one pair.  exact_cap = 0 (fast: the 4-word band only) or 8 / 16 / 32 (exact mode: largest
+ * band tried for a certificate).
+ *   1. band of 4 words.  Infeasible -> the row is dropped.
+ *   2. exact mode, not certified, U + MARGIN <= 32 exact_cap: re-run with the smallest band of {8, 16, 32} words that has
+ *      32 NW >= U + MARGIN, then with each wider one up to exact_cap until a run is certified (U = the cost of the
+ *      last run).  The alignment kept is that of the last run.
+ *   3. traceback on the slice of the run kept; if it leaves the slice: wide fall-back (32 words, whole-band traceback);
+ *      if that fails as well the row is dropped.
+ * out[0..3] as in orc_bp_pair for the run that produced ops, out[4] = its band words (32 | 0x100 for the fall-back).
+ * returns 0, or 1 if the row is dropped.
  */
-int orc_star_msa(const uint8_t *win, const int64_t *win_off, int R, int *cols_out, uint8_t *msa, int64_t cap) {
+int orc_align_pair(const uint8_t *a, int m, const uint8_t *b, int n, int exact_cap, uint16_t *ops, int32_t *out) {
+    int32_t o[4];
+    int nw = 4;
+    int rc = orc_bp_pair(a, m, b, n, nw, 0, ops, o);
+    if (rc) return rc;
+    if (o[2] == 2) { memcpy(out, o, sizeof o); out[4] = nw; return 1; }
+    if (exact_cap >= 8 && !o[1] && o[0] + MARGIN <= 32 * exact_cap) {
+        int lvl = 8;
+        while (32 * lvl < o[0] + MARGIN) lvl *= 2;
+        for (; lvl <= exact_cap; lvl *= 2) {
+            rc = orc_bp_pair(a, m, b, n, lvl, 0, ops, o);
+            if (rc) return rc;
+            nw = lvl;
+            if (o[1]) break;
+        }
+    }
+    if (o[2] == 1) {
+        nw = 32 | 0x100;
+        rc = orc_bp_pair(a, m, b, n, 32, 1, ops, o);
+        if (rc) return rc;
+    }
+    out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; out[4] = nw;
+    return o[2] != 0;
+}
+
+static int g_exact = 16;   /* the product's default (hite_align.hip: HITE_ALIGN_EXACT) */
+void orc_msa_set_exact(int v) { g_exact = v; }
+int orc_msa_get_exact(void) { return g_exact; }
+
+/*
+ * One candidate: R windows (win + win_off[R+1]); writes cols and, if msa != NULL and cap suffices,
+ * the R x cols alignment (row-major).  Rows whose alignment fails at every level are dropped (rows_out < R).
+ * Columns: for p = 0..m an insertion block of max_r ins[r][p] columns (bases left-justified, '-' padded)
+ * followed (p < m) by the centre column.  Returns 0 or <0.
+ */
+int orc_star_msa2(const uint8_t *win, const int64_t *win_off, int R, int *cols_out, int *rows_out, uint8_t *msa, int64_t cap) {
     if (R <= 0) return ORC_EINVAL;
     const uint8_t *a = win + win_off[0];
     int m = (int)(win_off[1] - win_off[0]);
-    if (m <= 0) return ORC_EINVAL;
+    if (m <= 0 || m > 32767) return ORC_EINVAL;
     uint16_t *ops = (uint16_t *)calloc((size_t)R * (m + 1), sizeof(uint16_t));
-    if (!ops) return ORC_EINVAL;
+    int *rowsrc = (int *)malloc(sizeof(int) * (size_t)R);
+    if (!ops || !rowsrc) { free(ops); free(rowsrc); return ORC_EINVAL; }
+    int K = 0;
+    rowsrc[K++] = 0;
     for (int r = 1; r < R; r++) {
         int n = (int)(win_off[r + 1] - win_off[r]);
-        if (n <= 0) { free(ops); return ORC_EINVAL; }
-        int rc = pair_align(a, m, win + win_off[r], n, ops + (size_t)r * (m + 1));
-        if (rc) { free(ops); return rc; }
+        if (n <= 0 || n > 32767) { free(ops); free(rowsrc); return ORC_EINVAL; }
+        int32_t o[5];
+        int rc = orc_align_pair(a, m, win + win_off[r], n, g_exact, ops + (size_t)K * (m + 1), o);
+        if (rc < 0) { free(ops); free(rowsrc); return rc; }
+        if (rc == 0) rowsrc[K++] = r;
     }
+    /* ins[r][p], gap[r][p] from the ops */
     int *insmax = (int *)calloc(m + 1, sizeof(int));
     int *bstart = (int *)calloc(m + 2, sizeof(int));
-    for (int r = 0; r < R; r++)
+    for (int kr = 1; kr < K; kr++) {
+        const uint16_t *o = ops + (size_t)kr * (m + 1);
+        const int n = (int)(win_off[rowsrc[kr] + 1] - win_off[rowsrc[kr]]);
+        int next = 0;
         for (int p = 0; p <= m; p++) {
-            int v = ops[(size_t)r * (m + 1) + p] & 0x7fff;
-            if (v > insmax[p]) insmax[p] = v;
+            int q = p < m ? (o[p] & 0x7fff) : n;
+            int ins = q - next;
+            if (ins > insmax[p]) insmax[p] = ins;
+            if (p < m) next = (o[p] >> 15) ? q : q + 1;
         }
+    }
     int c = 0;
     for (int p = 0; p <= m; p++) { bstart[p] = c; c += insmax[p] + (p < m ? 1 : 0); }
-    int C = c;
+    const int C = c;
     *cols_out = C;
+    if (rows_out) *rows_out = K;
     if (msa) {
-        if ((int64_t)R * C > cap) { free(ops); free(insmax); free(bstart); return ORC_ECAP; }
-        memset(msa, '-', (size_t)R * C);
-        for (int r = 0; r < R; r++) {
-            const uint8_t *b = win + win_off[r];
-            uint8_t *row = msa + (size_t)r * C;
-            int rp = 0;
+        if ((int64_t)K * C > cap) { free(ops); free(insmax); free(bstart); free(rowsrc); return ORC_ECAP; }
+        memset(msa, '-', (size_t)K * C);
+        for (int kr = 0; kr < K; kr++) {
+            const uint8_t *b = win + win_off[rowsrc[kr]];
+            const int n = (int)(win_off[rowsrc[kr] + 1] - win_off[rowsrc[kr]]);
+            uint8_t *row = msa + (size_t)kr * C;
+            if (kr == 0) { for (int p = 0; p < m; p++) row[bstart[p] + insmax[p]] = b[p]; continue; }
+            const uint16_t *o = ops + (size_t)kr * (m + 1);
+            int next = 0;
             for (int p = 0; p <= m; p++) {
-                uint16_t o = ops[(size_t)r * (m + 1) + p];
-                int ins = o & 0x7fff, gap = o >> 15;
-                for (int q = 0; q < ins; q++) row[bstart[p] + q] = b[rp + q];
-                rp += ins;
-                if (p < m && !gap) { row[bstart[p] + insmax[p]] = b[rp]; rp++; }
+                int q = p < m ? (o[p] & 0x7fff) : n;
+                for (int x = next; x < q; x++) row[bstart[p] + (x - next)] = b[x];
+                if (p < m) {
+                    if (o[p] >> 15) next = q;
+                    else { row[bstart[p] + insmax[p]] = b[q]; next = q + 1; }
+                }
             }
         }
     }
-    free(ops); free(insmax); free(bstart);
+    free(ops); free(insmax); free(bstart); free(rowsrc);
     return 0;
+}
+
+int orc_star_msa(const uint8_t *win, const int64_t *win_off, int R, int *cols_out, uint8_t *msa, int64_t cap) {
+    /* historical entry: fails (instead of dropping rows) when a row cannot be aligned */
+    int rows = 0;
+    int rc = orc_star_msa2(win, win_off, R, cols_out, &rows, NULL, 0);
+    if (rc) return rc;
+    if (rows != R) return ORC_EINVAL;
+    return msa ? orc_star_msa2(win, win_off, R, cols_out, &rows, msa, cap) : 0;
 }

@@ -26,7 +26,7 @@ def build():
 def lib():
     global _lib
     if _lib is None:
-        srcs = [os.path.join(ORACLE_DIR, f) for f in ("hite_oracle.c", "hite_oracle_coarse.c", "hite_oracle_msa.c", "hite_oracle_copies.c")]
+        srcs = [os.path.join(ORACLE_DIR, f) for f in sorted(os.listdir(ORACLE_DIR)) if f.endswith(".c")]
         if not os.path.exists(SO) or any(os.path.getmtime(s) > os.path.getmtime(SO) for s in srcs):
             build()
         _lib = C.CDLL(SO)
@@ -188,20 +188,79 @@ def tir_kmer(seq, raw_start, raw_end, dist, plant):
     return [(int(k[i]), int(ts[i]), int(te[i]), int(d[i])) for i in range(m)]
 
 
-def star_msa(windows):
-    """windows: list of bytes/str (row 0 = centre) -> 2-D uint8 alignment (this build's mafft stand-in)"""
+def star_msa(windows, rows=False):
+    """windows: list of bytes/str (row 0 = centre) -> 2-D uint8 alignment (this build's mafft stand-in: every row aligned
+    to the centre by the optimal unit-cost global alignment, see oracle/hite_oracle_nw.c; rows that cannot be aligned
+    are dropped).  rows=True also returns the number of rows kept."""
     wb = [w.encode() if isinstance(w, str) else bytes(w) for w in windows]
     off = np.zeros(len(wb) + 1, dtype=np.int64)
     np.cumsum([len(w) for w in wb], out=off[1:])
     buf = np.frombuffer(b"".join(wb), dtype=np.uint8)
-    cols = C.c_int(0)
-    rc = lib().orc_star_msa(_ptr(buf, u8p), _ptr(off, i64p), len(wb), C.byref(cols), None, C.c_int64(0))
+    cols, kept = C.c_int(0), C.c_int(0)
+    rc = lib().orc_star_msa2(_ptr(buf, u8p), _ptr(off, i64p), len(wb), C.byref(cols), C.byref(kept), None, C.c_int64(0))
     if rc != 0:
-        return None  # an alignment left the band: the candidate is not judged (GPU: cols = 0)
-    out = np.zeros((len(wb), cols.value), dtype=np.uint8)
-    rc = lib().orc_star_msa(_ptr(buf, u8p), _ptr(off, i64p), len(wb), C.byref(cols), _ptr(out, u8p), C.c_int64(out.size))
+        return (None, 0) if rows else None
+    out = np.zeros((kept.value, cols.value), dtype=np.uint8)
+    rc = lib().orc_star_msa2(_ptr(buf, u8p), _ptr(off, i64p), len(wb), C.byref(cols), C.byref(kept), _ptr(out, u8p),
+                             C.c_int64(out.size))
     assert rc == 0, rc
-    return out
+    return (out, kept.value) if rows else out
+
+
+def set_align_exact(cap):
+    """exact-mode cap of the twin's pair schedule (0 fast, 8 / 16 / 32); returns the previous value"""
+    prev = lib().orc_msa_get_exact()
+    lib().orc_msa_set_exact(int(cap))
+    return prev
+
+
+def _seq(x):
+    return np.frombuffer(x.encode() if isinstance(x, str) else bytes(x), dtype=np.uint8).copy()
+
+
+def nw_pair(a, b):
+    """THE definition (oracle/hite_oracle_nw.c): -> (ops uint16[m], distance)"""
+    a, b = _seq(a), _seq(b)
+    ops = np.zeros(len(a) + 1, dtype=np.uint16)
+    d = lib().orc_nw_pair(_ptr(a, u8p), len(a), _ptr(b, u8p), len(b), _ptr(ops, C.POINTER(C.c_uint16)))
+    assert d >= 0, d
+    return ops[:len(a)], d
+
+
+def nw_distance(a, b):
+    a, b = _seq(a), _seq(b)
+    d = lib().orc_nw_distance(_ptr(a, u8p), len(a), _ptr(b, u8p), len(b))
+    assert d >= 0, d
+    return d
+
+
+def ops_cost(a, b, ops):
+    a, b = _seq(a), _seq(b)
+    ops = np.ascontiguousarray(ops, dtype=np.uint16)
+    return lib().orc_ops_cost(_ptr(a, u8p), len(a), _ptr(b, u8p), len(b), _ptr(ops, C.POINTER(C.c_uint16)))
+
+
+def bp_pair(a, b, nw=4, full=False):
+    """one run of the banded bit-parallel aligner: -> (ops, dict(U, cert, status, kstar))"""
+    a, b = _seq(a), _seq(b)
+    ops = np.zeros(len(a) + 1, dtype=np.uint16)
+    out = np.zeros(4, dtype=np.int32)
+    rc = lib().orc_bp_pair(_ptr(a, u8p), len(a), _ptr(b, u8p), len(b), int(nw), 1 if full else 0,
+                           _ptr(ops, C.POINTER(C.c_uint16)), _ptr(out, i32p))
+    assert rc == 0, rc
+    return ops[:len(a)], dict(U=int(out[0]), cert=int(out[1]), status=int(out[2]), kstar=int(out[3]))
+
+
+def align_pair(a, b, exact_cap=16):
+    """the product's schedule for one pair: -> (ops or None if the row is dropped, dict(U, cert, status, kstar, nw))"""
+    a, b = _seq(a), _seq(b)
+    ops = np.zeros(len(a) + 1, dtype=np.uint16)
+    out = np.zeros(5, dtype=np.int32)
+    rc = lib().orc_align_pair(_ptr(a, u8p), len(a), _ptr(b, u8p), len(b), int(exact_cap), _ptr(ops, C.POINTER(C.c_uint16)),
+                              _ptr(out, i32p))
+    assert rc >= 0, rc
+    info = dict(U=int(out[0]), cert=int(out[1]), status=int(out[2]), kstar=int(out[3]), nw=int(out[4]))
+    return (None if rc else ops[:len(a)]), info
 
 
 def find_copies(contigs, cands):
