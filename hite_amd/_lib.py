@@ -211,11 +211,22 @@ class Context:
         return [(lo[i, :max(ln[i], 0)].tobytes().decode(), ro[i, :max(ln[i], 0)].tobytes().decode(), int(ln[i])) for i in range(n)]
 
     # ---- star alignment (stage where the reference calls mafft) -------------------------------
-    def star_msa(self, groups, sparse=False):
+    def align_config(self, exact_cap):
+        """exact_cap: 0 = fast (band of 128 centre rows only); 8 / 16 / 32 = widest band (x 32 rows) tried for an optimality
+        certificate (default 16 or $HITE_ALIGN_EXACT)"""
+        self._check(self.lib.hite_align_config(self.h, int(exact_cap)), "hite_align_config")
+
+    def align_stats(self, reset=False):
+        """-> dict(pairs, certified, wide, fallback, dropped, cost, columns, exact_cap) accumulated since the last reset"""
+        o = np.zeros(8, dtype=np.int64)
+        self._check(self.lib.hite_align_stats(self.h, _p(o), 1 if reset else 0), "hite_align_stats")
+        return dict(zip(("pairs", "certified", "wide", "fallback", "dropped", "cost", "columns", "exact_cap"), (int(x) for x in o)))
+
+    def star_msa(self, groups, sparse=False, info=False):
         """groups: list of lists of windows (bytes/str), first window of each group = centre.
-        -> list of 2-D uint8 alignments (None where the alignment failed).
-        sparse=True: the fused path, sparse columns (remove_sparse_col_in_align_file) already removed."""
-        fn = self.lib.hite_star_msa_sparse if sparse else self.lib.hite_star_msa
+        -> list of 2-D uint8 alignments (None where the alignment failed); rows that cannot be aligned are dropped.
+        sparse=True: the fused path, sparse columns (remove_sparse_col_in_align_file) already removed.
+        info=True: also, per group, an int32 array (windows x 5): cost U, certified, status, k*, band words (| 0x100 fall-back)."""
         flat = [w.encode() if isinstance(w, str) else bytes(w) for g in groups for w in g]
         n = len(groups)
         row_first = np.zeros(n + 1, dtype=np.int32)
@@ -224,18 +235,29 @@ class Context:
         np.cumsum([len(w) for w in flat], out=off[1:])
         buf = np.frombuffer(b"".join(flat) + b"\0" * 16, dtype=np.uint8)
         cols = np.zeros(n, dtype=np.int32)
-        self._check(fn(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), C.c_int64(0), None, None), "hite_star_msa(sizes)")
-        rows = np.diff(row_first).astype(np.int64)
-        cap = int(((rows * cols + 15) // 16 * 16).sum()) + 16
+        rows = np.zeros(n, dtype=np.int32)
+        inf = np.zeros((len(flat), 5), dtype=np.int32)
+
+        def call(cap, out, moff):
+            if info:
+                return self.lib.hite_star_msa_info(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), _p(rows), _p(inf),
+                                                   C.c_int64(cap), out, moff)
+            fn = self.lib.hite_star_msa_sparse if sparse else self.lib.hite_star_msa
+            return fn(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), _p(rows), C.c_int64(cap), out, moff)
+
+        self._check(call(0, None, None), "hite_star_msa(sizes)")
+        cap = int(((rows.astype(np.int64) * cols + 15) // 16 * 16).sum()) + 16
         out = np.zeros(cap, dtype=np.uint8)
         moff = np.zeros(n, dtype=np.int64)
-        self._check(fn(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), C.c_int64(cap), _p(out), _p(moff)), "hite_star_msa(fill)")
+        self._check(call(cap, _p(out), _p(moff)), "hite_star_msa(fill)")
         res = []
         for i in range(n):
             if cols[i] <= 0:
                 res.append(None)
             else:
-                res.append(out[moff[i]:moff[i] + rows[i] * cols[i]].reshape(int(rows[i]), int(cols[i])).copy())
+                res.append(out[moff[i]:moff[i] + int(rows[i]) * cols[i]].reshape(int(rows[i]), int(cols[i])).copy())
+        if info:
+            return res, [inf[row_first[i]:row_first[i + 1]].copy() for i in range(n)]
         return res
 
     # ---- the fine stage in one call (body of flank_region_align_v5 after copy finding) -----------

@@ -1,0 +1,720 @@
+// hite_align.hip -- pairwise alignment of every copy window to the centre window of its candidate: the compute core of
+// the star alignment that stands where the reference shells out to `mafft` (/root/reference/module/Util.py:10416).
+//
+// Definition (oracle/hite_oracle_nw.c): optimal GLOBAL alignment under unit costs (Levenshtein), canonical traceback
+// diagonal > up > left.  How it is computed here (twin: oracle/hite_oracle_msa.c, byte for byte):
+//
+//   * one THREAD per (row, centre) pair, Myers / Hyyro bit-parallel edit distance over an adaptive band of W = 32 NW
+//     centre rows per column of the row sequence: the band state (vertical deltas Pv / Mv) and the centre's three bit
+//     planes (2-bit code + "never matches") live in registers, pre-shifted to the band's rows; one column costs about
+//     22 NW + 30 integer instructions for 32 NW cells.  The centre planes are built once per candidate
+//     (align_planes_kernel) and shared by all of its rows; the row bases are read 16 at a time.
+//   * steering (the band follows the valley of the distance surface), pessimistic band edges and the Ukkonen
+//     certificate are described in the twin's header.  A certified pair IS the alignment of the definition.
+//   * no per-cell direction is ever written to HBM.  The forward pass keeps, per strip of 16 columns, a check point of
+//     the SLICE (the middle 128 rows of the band: 48 B) and, when the band is wider than the slice, 2 B per column of
+//     boundary information (the step of the band, the bits that enter the slice from the rest of the band).  The
+//     traceback pass (align_tb_kernel) re-computes the slice strip by strip into registers and walks it backwards:
+//     3-5 B of HBM traffic per column instead of 2 bits per DP cell.
+//   * schedule per pair (hite_align_run): band of 4 words; in exact mode a pair that is not certified is re-run with
+//     8 / 16 / 32 words until it is; a traceback that leaves the slice falls back to a 32-word band whose traceback bits
+//     are kept whole (rare: an insertion / deletion longer than about 60 bases); a row that even this cannot align is
+//     dropped from the alignment.
+#include "hite_common.h"
+#include "hite_scan.h"
+#include "hite_arena.h"
+#include "hite_align.h"
+
+#define AL_STEER 48
+#define AL_MARGIN 48
+#define AL_PADR 544          // virtual rows above row 1 in the centre planes (17 words: covers t_0 = -512 of the widest band)
+#define AL_STRIP 16
+#define AL_KBINS 2048        // strips per pair <= 32767 / 16 + 1
+
+struct AlignArgs {
+    const uint8_t *win;
+    const int64_t *win_off;
+    const int32_t *win_len;
+    const int32_t *row_first;   // n_cand + 1
+    int n_cand;
+    const int32_t *row_cand;    // per row: its candidate
+    const uint4 *planes;        // per candidate, per 32 centre rows: (plane0, plane1, planeN, 0)
+    const int64_t *plane_off;   // n_cand
+    const int64_t *rec_off;     // per row: index of its first strip record
+    uint32_t *ckpt;             // 12 words per strip: Pv[4], Mv[4] of the slice, t of the slice, 3 spare
+    uint32_t *bnd;              // 8 words per strip (bands wider than the slice)
+    int32_t *U, *kst, *st, *lvl, *U4;   // per row: cost, certificate bound, status, band words of the run kept, cost of the 4-word run
+    const int64_t *ops_base;
+    uint16_t *ops;
+    const int64_t *full_off;    // per row (fall-back): first column record
+    uint32_t *fullbuf;          // per column: dg[32], up[32]
+    int32_t *fullt;             // per column: t
+};
+
+__device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ bool is_acgt_byte(unsigned c) { return c - 0x41u < 32u && ((0x00080045u >> (c - 0x41u)) & 1u); }
+
+// one row base as the three masks that turn the centre planes into the match vector
+struct BaseMask { uint32_t m0, m1, inv; };
+__device__ __forceinline__ BaseMask base_mask(unsigned ch) {
+    BaseMask b;
+    b.m0 = (uint32_t)(-(int)((ch >> 1) & 1u));
+    b.m1 = (uint32_t)(-(int)((ch >> 2) & 1u));
+    b.inv = is_acgt_byte(ch) ? 0u : 0xffffffffu;
+    return b;
+}
+
+// the Myers / Hyyro column step on NW words, carries running from word 0 (lowest rows) upwards.
+// cin: carry into the addition of word 0; pc / mc: horizontal delta (+1 / -1 flags) of the row below word 0's first row.
+// TAP >= 0: the carries that ENTER word TAP are returned in tap[0..2] (boundary information of the slice).
+template <int NW, bool DIRS, int TAP>
+__device__ __forceinline__ void bp_core(uint32_t (&Pv)[NW], uint32_t (&Mv)[NW], const uint32_t (&A0)[NW], const uint32_t (&A1)[NW],
+                                        const uint32_t (&AN)[NW], const BaseMask bm, uint32_t cin, uint32_t pc, uint32_t mc,
+                                        uint32_t *dg, uint32_t *up, uint32_t *tap) {
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        if (TAP >= 0 && w == TAP) { tap[0] = cin; tap[1] = pc; tap[2] = mc; }
+        const uint32_t eq = ~((A0[w] ^ bm.m0) | (A1[w] ^ bm.m1) | AN[w] | bm.inv);
+        const uint32_t pv = Pv[w], mv = Mv[w];
+        const unsigned long long x = (unsigned long long)(eq & pv) + pv + cin;
+        cin = (uint32_t)(x >> 32);
+        const uint32_t d0 = (((uint32_t)x) ^ pv) | eq | mv;
+        const uint32_t ph = mv | ~(d0 | pv);
+        const uint32_t mh = pv & d0;
+        const uint32_t phs = (ph << 1) | pc, mhs = (mh << 1) | mc;
+        pc = ph >> 31; mc = mh >> 31;
+        Pv[w] = mhs | ~(d0 | phs);
+        Mv[w] = phs & d0;
+        if (DIRS) { dg[w] = eq | ~d0; up[w] = Pv[w]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// preparation
+// ---------------------------------------------------------------------------------------------
+// candidate of every row, strips of every pair (0 for a centre), histogram of the strip counts (for the length order)
+__global__ void __launch_bounds__(256) align_rows_kernel(int n_cand, const int32_t *__restrict__ row_first,
+                                                         const int32_t *__restrict__ win_len, int32_t *__restrict__ row_cand,
+                                                         int32_t *__restrict__ strips, int32_t *__restrict__ hist) {
+    const int c = blockIdx.x;
+    if (c >= n_cand) return;
+    const int g0 = row_first[c], g1 = row_first[c + 1];
+    for (int g = g0 + threadIdx.x; g < g1; g += 256) {
+        row_cand[g] = c;
+        int k = g == g0 ? 0 : (win_len[g] + AL_STRIP - 1) / AL_STRIP;
+        if (k >= AL_KBINS) k = AL_KBINS - 1;
+        strips[g] = g == g0 ? 0 : (win_len[g] + AL_STRIP - 1) / AL_STRIP;
+        atomicAdd(&hist[AL_KBINS - 1 - k], 1);
+    }
+}
+__global__ void __launch_bounds__(1024) align_hist_scan_kernel(int32_t *__restrict__ hist /* AL_KBINS -> exclusive offsets */) {
+    __shared__ int s_w[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    int carry = 0;
+    for (int base = 0; base < AL_KBINS; base += 1024) {
+        const int v = hist[base + threadIdx.x];
+        int x = v;
+        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
+        __syncthreads();
+        if (lane == 63) s_w[w] = x;
+        __syncthreads();
+        int pre = 0, tot = 0;
+        for (int q = 0; q < 16; q++) { const int t = s_w[q]; if (q < w) pre += t; tot += t; }
+        hist[base + threadIdx.x] = carry + pre + x - v;
+        carry += tot;
+        __syncthreads();
+    }
+}
+// rows in the order of decreasing length (lanes of one wavefront run in lockstep: neighbours should be equally long)
+__global__ void align_order_kernel(int64_t total_rows, const int32_t *__restrict__ strips, int32_t *__restrict__ cursor,
+                                   int32_t *__restrict__ order) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_rows) return;
+    int k = strips[g];
+    if (k >= AL_KBINS) k = AL_KBINS - 1;
+    order[atomicAdd(&cursor[AL_KBINS - 1 - k], 1)] = (int32_t)g;
+}
+__global__ void align_plane_words_kernel(int n_cand, const int32_t *__restrict__ row_first, const int32_t *__restrict__ win_len,
+                                         int32_t *__restrict__ words) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    const int g0 = row_first[c];
+    words[c] = row_first[c + 1] > g0 ? (win_len[g0] + 2 * AL_PADR) / 32 + 3 : 0;
+}
+// bit x of a candidate's planes = centre row r = x - AL_PADR + 1 (r <= 0: virtual rows, r > m: padding: never match)
+__global__ void __launch_bounds__(256) align_planes_kernel(int n_cand, const uint8_t *__restrict__ win, const int64_t *__restrict__ win_off,
+                                                           const int32_t *__restrict__ win_len, const int32_t *__restrict__ row_first,
+                                                           const int64_t *__restrict__ plane_off, uint4 *__restrict__ planes) {
+    const int c = blockIdx.x;
+    if (c >= n_cand) return;
+    const int g0 = row_first[c];
+    if (row_first[c + 1] <= g0) return;
+    const int m = win_len[g0];
+    const uint8_t *a = win + win_off[g0];
+    const int nw = (m + 2 * AL_PADR) / 32 + 3;
+    uint4 *out = planes + plane_off[c];
+    for (int wi = threadIdx.x; wi < nw; wi += 256) {
+        uint32_t p0 = 0, p1 = 0, pn = 0;
+        for (int k = 0; k < 32; k++) {
+            const int r = wi * 32 + k - AL_PADR + 1;
+            unsigned ch = (r >= 1 && r <= m) ? a[r - 1] : 0u;
+            if (is_acgt_byte(ch)) { p0 |= ((ch >> 1) & 1u) << k; p1 |= ((ch >> 2) & 1u) << k; }
+            else pn |= 1u << k;
+        }
+        out[wi] = make_uint4(p0, p1, pn, 0u);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward pass
+// ---------------------------------------------------------------------------------------------
+template <int NW, bool FULL>
+__global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    constexpr int W = 32 * NW, H = W / 2, S0 = NW / 2 - 2;
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    const int g = li < nlist ? list[li] : -1;
+    int m = 0, n = 0, g0 = 0, c = 0;
+    if (g >= 0) {
+        c = P.row_cand[g];
+        g0 = P.row_first[c];
+        if (g != g0) { m = P.win_len[g0]; n = P.win_len[g]; }
+    }
+    const int nmax = wave_max_i32(n);
+    if (nmax == 0) return;
+    const uint8_t *b = P.win + (g >= 0 ? P.win_off[g] : 0);
+    const uint4 *pl = P.planes + (g >= 0 ? P.plane_off[c] : 0);
+    const int64_t rec0 = g >= 0 ? P.rec_off[g] : 0;
+    const int64_t full0 = (FULL && g >= 0) ? P.full_off[g] : 0;
+    uint32_t Pv[NW], Mv[NW], A0[NW], A1[NW], AN[NW];
+    int t = -H;
+#pragma unroll
+    for (int w = 0; w < NW; w++) { Pv[w] = w >= NW / 2 ? 0xffffffffu : 0u; Mv[w] = w < NW / 2 ? 0xffffffffu : 0u; }
+    bool act = n > 0;
+    if (act) {   // planes of rows t+1 .. t+W: bit position t + AL_PADR (a multiple of 32 here)
+        const int q0 = (t + AL_PADR) >> 5;
+#pragma unroll
+        for (int w = 0; w < NW; w++) { const uint4 v = pl[q0 + w]; A0[w] = v.x; A1[w] = v.y; AN[w] = v.z; }
+    } else {
+#pragma unroll
+        for (int w = 0; w < NW; w++) { A0[w] = 0; A1[w] = 0; AN[w] = 0xffffffffu; }
+    }
+    int stop = H, LO = -(1 << 28), HI = 1 << 28, status = 0;
+    for (int k = 0; k * AL_STRIP < nmax; k++) {
+        const bool sa = act && k * AL_STRIP < n;
+        uint4 bw = make_uint4(0, 0, 0, 0);
+        uint32_t f0 = 0, f1 = 0, fn = 0;   // the next 32 rows below the band, per plane
+        uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (sa) {
+            uint4 *ck = reinterpret_cast<uint4 *>(P.ckpt + (rec0 + k) * 12);
+            ck[0] = make_uint4(Pv[S0], Pv[S0 + 1], Pv[S0 + 2], Pv[S0 + 3]);
+            ck[1] = make_uint4(Mv[S0], Mv[S0 + 1], Mv[S0 + 2], Mv[S0 + 3]);
+            ck[2] = make_uint4((uint32_t)(t + 32 * S0), 0u, 0u, 0u);
+            bw = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
+            const int fx = t + W + AL_PADR;
+            const uint4 F = pl[fx >> 5], G = pl[(fx >> 5) + 1];
+            const uint32_t sh = (uint32_t)fx & 31u;
+            f0 = alignbit(G.x, F.x, sh); f1 = alignbit(G.y, F.y, sh); fn = alignbit(G.z, F.z, sh);
+        }
+#pragma unroll
+        for (int cc = 0; cc < AL_STRIP; cc++) {
+            const int j = k * AL_STRIP + cc + 1;
+            if (sa && j <= n) {
+                // ---- steering from column j-1 (middle 128 rows), clamps
+                int ds = 0;
+#pragma unroll
+                for (int w = S0; w < S0 + 4; w++) ds += __popc(Pv[w]) - __popc(Mv[w]);
+                int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
+                const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
+                if (t + s > hi_t) s = hi_t - t;
+                if (t + s < lo_t) s = lo_t - t;
+                if ((unsigned)s > 2u) { status = 2; act = false; s = 1; }
+                const uint32_t smask = (1u << s) - 1u;
+                stop += __popc(Pv[0] & smask) - __popc(Mv[0] & smask) + 1;
+                uint32_t pin = 0, min_ = 0;
+                if (NW > 4) { pin = Pv[S0 + 4 < NW ? S0 + 4 : 0] & 3u; min_ = Mv[S0 + 4 < NW ? S0 + 4 : 0] & 3u; }
+                // ---- the band moves down by s rows
+#pragma unroll
+                for (int w = 0; w < NW - 1; w++) {
+                    Pv[w] = alignbit(Pv[w + 1], Pv[w], (uint32_t)s); Mv[w] = alignbit(Mv[w + 1], Mv[w], (uint32_t)s);
+                    A0[w] = alignbit(A0[w + 1], A0[w], (uint32_t)s); A1[w] = alignbit(A1[w + 1], A1[w], (uint32_t)s);
+                    AN[w] = alignbit(AN[w + 1], AN[w], (uint32_t)s);
+                }
+                Pv[NW - 1] = alignbit(0xffffffffu, Pv[NW - 1], (uint32_t)s);
+                Mv[NW - 1] = Mv[NW - 1] >> s;
+                A0[NW - 1] = alignbit(f0, A0[NW - 1], (uint32_t)s); A1[NW - 1] = alignbit(f1, A1[NW - 1], (uint32_t)s);
+                AN[NW - 1] = alignbit(fn, AN[NW - 1], (uint32_t)s);
+                f0 >>= s; f1 >>= s; fn >>= s;
+                t += s;
+                if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
+                if (t + W < m) { const int v = t + W - j; HI = v < HI ? v : HI; }
+                // ---- column
+                const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
+                const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
+                uint32_t dg[NW], up[NW], tap[3] = {0, 1, 0};
+                bp_core<NW, FULL, (NW > 4 ? S0 : -1)>(Pv, Mv, A0, A1, AN, bm, 0u, 1u, 0u, dg, up, tap);
+                if (NW > 4 && !FULL) {
+                    const uint32_t r16 = (uint32_t)s | (pin << 2) | (min_ << 4) | (tap[0] << 6) | (tap[1] << 7) | (tap[2] << 8);
+                    brec[cc >> 1] |= r16 << (16 * (cc & 1));
+                }
+                if (FULL) {
+                    uint4 *fb = reinterpret_cast<uint4 *>(P.fullbuf + (full0 + j) * (2 * NW));
+#pragma unroll
+                    for (int w = 0; w < NW; w += 4) {
+                        fb[w / 4] = make_uint4(dg[w], dg[w + 1], dg[w + 2], dg[w + 3]);
+                        fb[NW / 4 + w / 4] = make_uint4(up[w], up[w + 1], up[w + 2], up[w + 3]);
+                    }
+                    P.fullt[full0 + j] = t;
+                }
+            }
+        }
+        if (NW > 4 && !FULL && sa) {
+            uint4 *bp = reinterpret_cast<uint4 *>(P.bnd + (rec0 + k) * 8);
+            bp[0] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
+            bp[1] = make_uint4(brec[4], brec[5], brec[6], brec[7]);
+        }
+    }
+    if (n > 0) {
+        int U = -1, kstar = -1;
+        if (status == 0) {
+            int u = stop;   // t_n = m - H: row m is bit H - 1
+#pragma unroll
+            for (int w = 0; w < NW / 2; w++) u += __popc(Pv[w]) - __popc(Mv[w]);
+            U = u;
+            const int d = m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
+            int E = dmin - LO;
+            if (HI - dmax < E) E = HI - dmax;
+            if (E > (1 << 27)) kstar = 0x7fffffff;
+            else if (E >= 0) kstar = ad + 2 * E + 1;
+        }
+        P.U[g] = U; P.kst[g] = kstar; P.st[g] = status; P.lvl[g] = NW;
+        if (NW == 4 && !FULL) P.U4[g] = U;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// traceback pass: re-compute the slice strip by strip (registers), walk it backwards
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t sel4(const uint32_t (&v)[4], int w) {
+    const uint32_t a = (w & 1) ? v[1] : v[0], b = (w & 1) ? v[3] : v[2];
+    return (w & 2) ? b : a;
+}
+
+__global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    const int g = li < nlist ? list[li] : -1;
+    int m = 0, n = 0, g0 = 0, c = 0;
+    bool hb = false;
+    if (g >= 0) {
+        c = P.row_cand[g];
+        g0 = P.row_first[c];
+        if (g != g0 && P.st[g] == 0) { m = P.win_len[g0]; n = P.win_len[g]; hb = P.lvl[g] > 4; }
+    }
+    const int nmax = wave_max_i32(n);
+    if (nmax == 0) return;
+    const uint8_t *b = P.win + (g >= 0 ? P.win_off[g] : 0);
+    const uint4 *pl = P.planes + (g >= 0 ? P.plane_off[c] : 0);
+    const int64_t rec0 = g >= 0 ? P.rec_off[g] : 0;
+    uint16_t *ops = P.ops + (g >= 0 ? P.ops_base[c] + (int64_t)(g - g0) * (m + 1) : 0);
+    int i = m, j = n;
+    bool fail = false;
+    const int Kmax = (nmax + AL_STRIP - 1) / AL_STRIP;
+    for (int k = Kmax - 1; k >= 0; k--) {
+        const bool sa = n > 0 && !fail && i > 0 && k * AL_STRIP < n;
+        if (!__any(sa)) continue;
+        uint32_t Pv[4], Mv[4], A0[4], A1[4], AN[4];
+        uint32_t f0 = 0, f1 = 0, fn = 0;
+        uint4 bw = make_uint4(0, 0, 0, 0);
+        uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int t = 0;
+        if (sa) {
+            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k) * 12);
+            const uint4 c0 = ck[0], c1 = ck[1], c2 = ck[2];
+            Pv[0] = c0.x; Pv[1] = c0.y; Pv[2] = c0.z; Pv[3] = c0.w;
+            Mv[0] = c1.x; Mv[1] = c1.y; Mv[2] = c1.z; Mv[3] = c1.w;
+            t = (int)c2.x;
+            bw = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
+            if (hb) {
+                const uint4 *bp = reinterpret_cast<const uint4 *>(P.bnd + (rec0 + k) * 8);
+                const uint4 b0 = bp[0], b1 = bp[1];
+                brec[0] = b0.x; brec[1] = b0.y; brec[2] = b0.z; brec[3] = b0.w;
+                brec[4] = b1.x; brec[5] = b1.y; brec[6] = b1.z; brec[7] = b1.w;
+            }
+            const int x0 = t + AL_PADR;
+            const int q0 = x0 >> 5;
+            const uint32_t sh = (uint32_t)x0 & 31u;
+            uint4 wd[6];
+#pragma unroll
+            for (int w = 0; w < 6; w++) wd[w] = pl[q0 + w];
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                A0[w] = alignbit(wd[w + 1].x, wd[w].x, sh); A1[w] = alignbit(wd[w + 1].y, wd[w].y, sh);
+                AN[w] = alignbit(wd[w + 1].z, wd[w].z, sh);
+            }
+            f0 = alignbit(wd[5].x, wd[4].x, sh); f1 = alignbit(wd[5].y, wd[4].y, sh); fn = alignbit(wd[5].z, wd[4].z, sh);
+        } else {
+#pragma unroll
+            for (int w = 0; w < 4; w++) { Pv[w] = 0; Mv[w] = 0; A0[w] = 0; A1[w] = 0; AN[w] = 0; }
+        }
+        uint32_t dg[AL_STRIP][4], up[AL_STRIP][4];
+        uint32_t sbits = 0;
+#pragma unroll
+        for (int cc = 0; cc < AL_STRIP; cc++) {
+            const int jc = k * AL_STRIP + cc + 1;
+#pragma unroll
+            for (int w = 0; w < 4; w++) { dg[cc][w] = 0; up[cc][w] = 0; }
+            if (sa && jc <= n) {
+                const uint32_t r16 = (brec[cc >> 1] >> (16 * (cc & 1))) & 0xffffu;
+                int s;
+                uint32_t pin, min_, cin, pc, mc;
+                if (hb) {
+                    s = (int)(r16 & 3u); pin = (r16 >> 2) & 3u; min_ = (r16 >> 4) & 3u; cin = (r16 >> 6) & 1u; pc = (r16 >> 7) & 1u; mc = (r16 >> 8) & 1u;
+                } else {   // the 4-word band IS the slice: same steering as the forward pass
+                    int ds = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; w++) ds += __popc(Pv[w]) - __popc(Mv[w]);
+                    s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
+                    const int hi_t = m - 64, lo_t = m - 64 - 2 * (n - jc);
+                    if (t + s > hi_t) s = hi_t - t;
+                    if (t + s < lo_t) s = lo_t - t;
+                    pin = 3u; min_ = 0u; cin = 0u; pc = 1u; mc = 0u;
+                }
+#pragma unroll
+                for (int w = 0; w < 3; w++) {
+                    Pv[w] = alignbit(Pv[w + 1], Pv[w], (uint32_t)s); Mv[w] = alignbit(Mv[w + 1], Mv[w], (uint32_t)s);
+                    A0[w] = alignbit(A0[w + 1], A0[w], (uint32_t)s); A1[w] = alignbit(A1[w + 1], A1[w], (uint32_t)s);
+                    AN[w] = alignbit(AN[w + 1], AN[w], (uint32_t)s);
+                }
+                Pv[3] = alignbit(pin, Pv[3], (uint32_t)s); Mv[3] = alignbit(min_, Mv[3], (uint32_t)s);
+                A0[3] = alignbit(f0, A0[3], (uint32_t)s); A1[3] = alignbit(f1, A1[3], (uint32_t)s); AN[3] = alignbit(fn, AN[3], (uint32_t)s);
+                f0 >>= s; f1 >>= s; fn >>= s;
+                t += s;
+                sbits |= (uint32_t)s << (2 * cc);
+                const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
+                const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
+                uint32_t tap[3];
+                bp_core<4, true, -1>(Pv, Mv, A0, A1, AN, bm, cin, pc, mc, dg[cc], up[cc], tap);
+            }
+        }
+        // walk: every path step leaves column j for column j-1 (diagonal, left) or stays in it (up)
+        int tcur = t;
+#pragma unroll
+        for (int cc = AL_STRIP - 1; cc >= 0; cc--) {
+            const int jc = k * AL_STRIP + cc + 1;
+            bool here = sa && !fail && i > 0 && j == jc;
+            while (__any(here)) {
+                if (here) {
+                    const int kb = i - tcur - 1;
+                    if ((unsigned)kb >= 128u) { fail = true; here = false; }
+                    else {
+                        const uint32_t dw = sel4(dg[cc], kb >> 5), uw = sel4(up[cc], kb >> 5);
+                        const uint32_t bit = 1u << (kb & 31);
+                        if (dw & bit) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; here = false; }
+                        else if (uw & bit) { ops[i - 1] = (uint16_t)(j | 0x8000); i--; here = i > 0; }
+                        else { j--; here = false; }
+                    }
+                }
+            }
+            tcur -= (int)((sbits >> (2 * cc)) & 3u);
+        }
+    }
+    if (n > 0) {
+        if (fail) P.st[g] = 1;
+        else for (int q = i - 1; q >= 0; q--) ops[q] = (uint16_t)0x8000;
+    }
+}
+
+// fall-back traceback on the bits of the whole 32-word band
+__global__ void __launch_bounds__(64) align_tb_full_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    constexpr int NW = 32, W = 32 * NW;
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= nlist) return;
+    const int g = list[li];
+    const int c = P.row_cand[g], g0 = P.row_first[c];
+    if (g == g0 || P.st[g] != 0) return;
+    const int m = P.win_len[g0], n = P.win_len[g];
+    uint16_t *ops = P.ops + P.ops_base[c] + (int64_t)(g - g0) * (m + 1);
+    const int64_t full0 = P.full_off[g];
+    int i = m, j = n;
+    bool fail = false;
+    while (i > 0 && j > 0) {
+        const int kb = i - P.fullt[full0 + j] - 1;
+        if ((unsigned)kb >= (unsigned)W) { fail = true; break; }
+        const uint32_t *fb = P.fullbuf + (full0 + j) * (2 * NW);
+        const uint32_t bit = 1u << (kb & 31);
+        if (fb[kb >> 5] & bit) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
+        else if (fb[NW + (kb >> 5)] & bit) { ops[i - 1] = (uint16_t)(j | 0x8000); i--; }
+        else j--;
+    }
+    if (fail) P.st[g] = 1;
+    else for (int q = i - 1; q >= 0; q--) ops[q] = (uint16_t)0x8000;
+}
+
+// ---------------------------------------------------------------------------------------------
+// schedule
+// ---------------------------------------------------------------------------------------------
+// what: 0 = pairs to re-run with a band of `level` words (exact mode), 1 = pairs whose traceback left the slice
+__global__ void align_flag_kernel(int64_t nrows, const int32_t *__restrict__ order, const int32_t *__restrict__ strips, AlignArgs P,
+                                  int what, int level, int cap, int32_t *__restrict__ flag, int32_t *__restrict__ cols) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nrows) return;
+    const int g = order[x];
+    int f = 0;
+    if (strips[g] > 0) {
+        if (what == 0) {
+            const int u4 = P.U4[g];
+            if (P.st[g] == 0 && u4 >= 0 && u4 + AL_MARGIN <= 32 * cap) {
+                int first = 8;
+                while (32 * first < u4 + AL_MARGIN) first *= 2;
+                const bool cert = P.U[g] <= P.kst[g];
+                f = level >= first && !cert;
+            }
+        } else f = P.st[g] == 1;
+    }
+    flag[x] = f;
+    if (cols) cols[x] = f ? P.win_len[g] + 1 : 0;
+}
+__global__ void align_compact_kernel(int64_t nrows, const int32_t *__restrict__ order, const int32_t *__restrict__ flag,
+                                     const int64_t *__restrict__ pos, int32_t *__restrict__ out, const int64_t *__restrict__ colpos,
+                                     int64_t *__restrict__ full_off, int32_t *__restrict__ st) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x >= nrows) return;
+    if (flag[x]) {
+        const int g = order[x];
+        out[pos[x]] = g;
+        if (full_off) { full_off[g] = colpos[x]; st[g] = 0; }
+    }
+}
+// counters: [0] pairs, [1] certified, [2] kept from a band of > 4 words, [3] fall-back, [4] dropped, [5] sum of U, [6] columns
+__global__ void align_stats_kernel(int64_t total_rows, const int32_t *__restrict__ strips, AlignArgs P, int32_t *__restrict__ row_dead,
+                                   int32_t *__restrict__ cand_status, unsigned long long *__restrict__ acc) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_rows) return;
+    if (strips[g] <= 0) { if (row_dead) row_dead[g] = 0; return; }
+    const int st = P.st[g];
+    atomicAdd(&acc[0], 1ull);
+    if (st == 0 && P.U[g] <= P.kst[g]) atomicAdd(&acc[1], 1ull);
+    if (st == 0 && (P.lvl[g] & 0xff) > 4) atomicAdd(&acc[2], 1ull);
+    if (P.lvl[g] & 0x100) atomicAdd(&acc[3], 1ull);
+    if (st != 0) atomicAdd(&acc[4], 1ull);
+    if (st == 0) atomicAdd(&acc[5], (unsigned long long)P.U[g]);
+    atomicAdd(&acc[6], (unsigned long long)P.win_len[g]);
+    if (row_dead) row_dead[g] = st != 0;
+    if (st != 0 && cand_status) atomicExch(&cand_status[P.row_cand[g]], 2);
+}
+__global__ void align_mark_fallback_kernel(int nlist, const int32_t *__restrict__ list, int32_t *__restrict__ lvl) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < nlist) lvl[list[x]] |= 0x100;
+}
+__global__ void align_info_kernel(int64_t total_rows, AlignArgs P, int32_t *__restrict__ info /* 5 per row */) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_rows) return;
+    const int c = P.row_cand[g];
+    if (g == P.row_first[c]) { for (int q = 0; q < 5; q++) info[g * 5 + q] = 0; return; }
+    info[g * 5 + 0] = P.U[g];
+    info[g * 5 + 1] = P.st[g] != 2 && P.U[g] <= P.kst[g];
+    info[g * 5 + 2] = P.st[g];
+    info[g * 5 + 3] = P.kst[g];
+    info[g * 5 + 4] = P.lvl[g];
+}
+
+struct AlignState {
+    Arena arena;
+    int64_t *h_pin = nullptr;
+    int64_t *d_scal = nullptr;
+    int exact_cap = -1;
+    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+static AlignState *align_state(hite_ctx *ctx) {
+    if (!ctx->align_state) {
+        AlignState *S = new AlignState();
+        if (hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)) != hipSuccess || hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)) != hipSuccess) {
+            delete S;
+            return nullptr;
+        }
+        const char *e = getenv("HITE_ALIGN_EXACT");
+        int cap = e && *e ? atoi(e) : 16;
+        if (cap != 0 && cap != 8 && cap != 16 && cap != 32) cap = 16;
+        S->exact_cap = cap;
+        ctx->align_state = S;
+    }
+    return (AlignState *)ctx->align_state;
+}
+void hite_align_release(hite_ctx *ctx) {
+    AlignState *S = (AlignState *)ctx->align_state;
+    if (!S) return;
+    arena_free(S->arena);
+    if (S->h_pin) (void)hipHostFree(S->h_pin);
+    if (S->d_scal) (void)hipFree(S->d_scal);
+    delete S;
+    ctx->align_state = nullptr;
+}
+
+extern "C" int hite_align_config(hite_ctx *ctx, int32_t exact_cap) {
+    if (!ctx || (exact_cap != 0 && exact_cap != 8 && exact_cap != 16 && exact_cap != 32)) return HITE_EINVAL;
+    AlignState *S = align_state(ctx);
+    if (!S) return HITE_ENOMEM;
+    S->exact_cap = exact_cap;
+    return HITE_OK;
+}
+extern "C" int hite_align_stats(hite_ctx *ctx, int64_t *out8, int32_t reset) {
+    if (!ctx || !out8) return HITE_EINVAL;
+    AlignState *S = align_state(ctx);
+    if (!S) return HITE_ENOMEM;
+    memcpy(out8, S->stats, sizeof S->stats);
+    out8[7] = S->exact_cap;
+    if (reset) memset(S->stats, 0, sizeof S->stats);
+    return HITE_OK;
+}
+
+#define ACHK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
+
+template <typename T>
+static int aalloc(hite_ctx *ctx, Arena &A, size_t count, T **out) {
+    void *p = nullptr;
+    int rc = arena_alloc(ctx, A, count * sizeof(T), &p);
+    *out = (T *)p;
+    return rc;
+}
+
+// order-preserving compaction of the rows flagged for `what`; returns the count (host) and the list (device)
+static int build_list(hite_ctx *ctx, AlignState *S, hipStream_t st, int64_t nrows, const int32_t *order, const int32_t *strips,
+                      AlignArgs &P, int what, int level, int cap, int32_t *flag, int32_t *cols, int64_t *pos, int64_t *colpos,
+                      int64_t *scan_tmp, int32_t *list, int64_t *full_off, int64_t *count, int64_t *total_cols) {
+    const unsigned nb = (unsigned)((nrows + 255) / 256);
+    hipLaunchKernelGGL(align_flag_kernel, dim3(nb), dim3(256), 0, st, nrows, order, strips, P, what, level, cap, flag, cols);
+    ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, flag, nrows, pos, st));
+    if (cols) ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, cols, nrows, colpos, st));
+    hipLaunchKernelGGL(align_compact_kernel, dim3(nb), dim3(256), 0, st, nrows, order, flag, pos, list, cols ? colpos : nullptr,
+                       cols ? full_off : nullptr, P.st);
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, pos + nrows, 8, hipMemcpyDeviceToDevice, st));
+    if (cols) HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, colpos + nrows, 8, hipMemcpyDeviceToDevice, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, 16, hipMemcpyDeviceToHost, st));
+    HITE_CHECK(ctx, hipStreamSynchronize(st));
+    *count = S->h_pin[0];
+    if (total_cols) *total_cols = cols ? S->h_pin[1] : 0;
+    return HITE_OK;
+}
+
+// aligns every row of every candidate to the candidate's first row; ops as described in hite_align.h.
+// d_row_dead (total_rows, may be NULL): 1 for rows that could not be aligned (0 for centres); d_cand_flag (n_cand, may be
+// NULL): set to 2 for candidates that lost a row.  d_info (5 x total_rows int32, may be NULL): per row U, certified, status,
+// k*, band words | 0x100 (fall-back).
+int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const int64_t *d_win_off, const int32_t *d_win_len,
+                   const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base, uint16_t *d_ops,
+                   int32_t *d_row_dead, int32_t *d_cand_flag, int32_t *d_info, const char *tag, hipStream_t st) {
+    if (!ctx || n_cand < 0 || total_rows < 0 || total_rows > 0x7fffffff) return HITE_EINVAL;
+    if (n_cand == 0 || total_rows == 0) return HITE_OK;
+    AlignState *S = align_state(ctx);
+    if (!S) return HITE_ENOMEM;
+    Arena &A = S->arena;
+    ACHK(arena_reset(ctx, A, true));
+    const int cap = S->exact_cap;
+    AlignArgs P;
+    memset(&P, 0, sizeof P);
+    P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first; P.n_cand = n_cand;
+    P.ops_base = d_ops_base; P.ops = d_ops;
+    int32_t *row_cand, *strips, *hist, *cursor, *order, *pwords, *flag, *cols, *list;
+    int64_t *plane_off, *rec_off, *pos, *colpos, *scan_tmp, *full_off;
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &row_cand));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &strips));
+    ACHK(aalloc(ctx, A, (size_t)AL_KBINS * 2, &hist));
+    cursor = hist;
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &order));
+    ACHK(aalloc(ctx, A, (size_t)n_cand, &pwords));
+    ACHK(aalloc(ctx, A, (size_t)n_cand + 1, &plane_off));
+    ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &rec_off));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &flag));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &cols));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &list));
+    ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &pos));
+    ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &colpos));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &full_off));
+    ACHK(aalloc(ctx, A, (size_t)scan_tmp_elems(total_rows > n_cand ? total_rows : n_cand) + 16, &scan_tmp));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &P.U));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &P.kst));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &P.st));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &P.lvl));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &P.U4));
+    P.row_cand = row_cand; P.full_off = full_off;
+    int tk = hite_prof_begin(ctx, "align_prep", st);
+    HITE_CHECK(ctx, hipMemsetAsync(hist, 0, AL_KBINS * 4, st));
+    HITE_CHECK(ctx, hipMemsetAsync(P.st, 0, (size_t)total_rows * 4, st));
+    HITE_CHECK(ctx, hipMemsetAsync(P.lvl, 0, (size_t)total_rows * 4, st));
+    hipLaunchKernelGGL(align_rows_kernel, dim3(n_cand), dim3(256), 0, st, n_cand, d_row_first, d_win_len, row_cand, strips, hist);
+    hipLaunchKernelGGL(align_hist_scan_kernel, dim3(1), dim3(1024), 0, st, hist);
+    hipLaunchKernelGGL(align_order_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, total_rows, strips, cursor, order);
+    hipLaunchKernelGGL(align_plane_words_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, d_row_first, d_win_len, pwords);
+    ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, pwords, n_cand, plane_off, st));
+    ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, strips, total_rows, rec_off, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, plane_off + n_cand, 8, hipMemcpyDeviceToDevice, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, rec_off + total_rows, 8, hipMemcpyDeviceToDevice, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, 16, hipMemcpyDeviceToHost, st));
+    HITE_CHECK(ctx, hipStreamSynchronize(st));
+    const int64_t plane_words = S->h_pin[0], total_strips = S->h_pin[1];
+    uint4 *planes;
+    ACHK(aalloc(ctx, A, (size_t)plane_words + 8, &planes));
+    ACHK(aalloc(ctx, A, (size_t)total_strips * 12 + 16, &P.ckpt));
+    if (cap >= 8) ACHK(aalloc(ctx, A, (size_t)total_strips * 8 + 16, &P.bnd));
+    P.planes = planes; P.plane_off = plane_off; P.rec_off = rec_off;
+    hipLaunchKernelGGL(align_planes_kernel, dim3(n_cand), dim3(256), 0, st, n_cand, d_win, d_win_off, d_win_len, d_row_first, plane_off, planes);
+    hite_prof_end(ctx, tk, st);
+    HITE_CHECK(ctx, hipGetLastError());
+    char name[32];
+    const int nrows = (int)total_rows;
+    // ---- the 4-word band for every pair
+    snprintf(name, sizeof name, "align_fwd4%s", tag ? tag : "");
+    tk = hite_prof_begin(ctx, name, st);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<4, false>), dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
+    hite_prof_end(ctx, tk, st);
+    // ---- exact mode: wider bands for the pairs without a certificate
+    if (cap >= 8) {
+        snprintf(name, sizeof name, "align_fwd_wide%s", tag ? tag : "");
+        tk = hite_prof_begin(ctx, name, st);
+        for (int level = 8; level <= cap; level *= 2) {
+            int64_t cnt = 0;
+            ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 0, level, cap, flag, nullptr, pos, colpos, scan_tmp, list, nullptr, &cnt, nullptr));
+            if (cnt == 0) continue;
+            const dim3 grid((unsigned)((cnt + 63) / 64));
+            if (level == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<8, false>), grid, dim3(64), 0, st, P, list, (int)cnt);
+            else if (level == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<16, false>), grid, dim3(64), 0, st, P, list, (int)cnt);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<32, false>), grid, dim3(64), 0, st, P, list, (int)cnt);
+        }
+        hite_prof_end(ctx, tk, st);
+    }
+    // ---- traceback on the slice of the run kept
+    snprintf(name, sizeof name, "align_tb%s", tag ? tag : "");
+    tk = hite_prof_begin(ctx, name, st);
+    hipLaunchKernelGGL(align_tb_kernel, dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
+    hite_prof_end(ctx, tk, st);
+    HITE_CHECK(ctx, hipGetLastError());
+    // ---- fall-back: the pairs whose path left the slice
+    {
+        int64_t cnt = 0, tcols = 0;
+        ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 1, 0, cap, flag, cols, pos, colpos, scan_tmp, list, full_off, &cnt, &tcols));
+        if (cnt > 0) {
+            tk = hite_prof_begin(ctx, "align_fallback", st);
+            ACHK(aalloc(ctx, A, (size_t)tcols * 64 + 64, &P.fullbuf));
+            ACHK(aalloc(ctx, A, (size_t)tcols + 16, &P.fullt));
+            const dim3 grid((unsigned)((cnt + 63) / 64));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<32, true>), grid, dim3(64), 0, st, P, list, (int)cnt);
+            hipLaunchKernelGGL(align_mark_fallback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (int)cnt, list, P.lvl);
+            hipLaunchKernelGGL(align_tb_full_kernel, grid, dim3(64), 0, st, P, list, (int)cnt);
+            hite_prof_end(ctx, tk, st);
+        }
+    }
+    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    hipLaunchKernelGGL(align_stats_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, total_rows, strips, P, d_row_dead, d_cand_flag,
+                       (unsigned long long *)S->d_scal);
+    if (d_info) hipLaunchKernelGGL(align_info_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, total_rows, P, d_info);
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, 56, hipMemcpyDeviceToHost, st));
+    HITE_CHECK(ctx, hipStreamSynchronize(st));
+    for (int q = 0; q < 7; q++) S->stats[q] += S->h_pin[q];
+    HITE_CHECK(ctx, hipGetLastError());
+    return HITE_OK;
+}

@@ -28,12 +28,16 @@ struct hite_ctx {
     // optional per-stage HIP-event profiling (hite_profile_*)
     int prof_on;
     int prof_n;                 // stages seen
-    char prof_name[32][32];
-    double prof_ms[32];
-    int64_t prof_count[32];
+    char prof_name[64][32];
+    double prof_ms[64];
+    int64_t prof_count[64];
     int prof_pending;           // event pairs recorded and not yet resolved
     void *prof_ev[512][2];
     int prof_stage[512];
+    // star alignment (hite_align.hip / hite_msa.hip): state of the pairwise aligner, row map of the last alignment call
+    void *align_state;
+    const int32_t *d_msa_row_map;   // per compacted row: source row (NULL: identity)
+    const int32_t *d_msa_rows_eff;  // per candidate: rows that were aligned (NULL: all)
 };
 
 // record the time of everything enqueued on `st` between begin and end as stage `name`

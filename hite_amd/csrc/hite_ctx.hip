@@ -7,6 +7,7 @@
 // Algorithmic bytes: pack reads G bytes, writes G/4 + G/8; gather reads W/4 + W/8 per window
 // and writes W (+1000 for the first500+last500 form).  Both are HBM-bound streaming kernels.
 #include "hite_common.h"
+#include "hite_align.h"
 #include "hite_genome.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -43,6 +44,7 @@ extern "C" void hite_ctx_destroy(hite_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_genome(c);
+    hite_align_release(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_scratch2) (void)hipFree(c->d_scratch2);
     free(c);
@@ -363,7 +365,7 @@ int hite_prof_begin(hite_ctx *ctx, const char *name, hipStream_t st) {
     int sidx = -1;
     for (int i = 0; i < ctx->prof_n; i++) if (strcmp(ctx->prof_name[i], name) == 0) { sidx = i; break; }
     if (sidx < 0) {
-        if (ctx->prof_n >= 32) return -1;
+        if (ctx->prof_n >= 64) return -1;
         sidx = ctx->prof_n++;
         strncpy(ctx->prof_name[sidx], name, 31);
         ctx->prof_name[sidx][31] = 0;

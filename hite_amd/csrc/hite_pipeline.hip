@@ -259,14 +259,6 @@ struct PassOut {
 };
 struct StageTimes;  // (events are recorded by bench.py around the whole call; per-kernel via rocprof)
 
-extern "C" int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
-                                 const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows,
-                                 const int64_t *d_ops_base, int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out,
-                                 int32_t *d_status, void *stream);
-extern "C" int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
-                                      const int32_t *d_win_len, const int32_t *d_row_first, const int64_t *d_ops_base,
-                                      const int32_t *d_cols, const int64_t *d_msa_off, uint8_t *d_msa, void *stream);
-
 static int read_scalars(hite_ctx *ctx, PipeState *S, hipStream_t st, int count) {
     HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, sizeof(int64_t) * count, hipMemcpyDeviceToHost, st));
     HITE_CHECK(ctx, hipStreamSynchronize(st));
@@ -339,10 +331,12 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     int32_t *last_extra;
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); last_extra = (int32_t *)p;
     // alignment + layout + sparse-column selection: the full alignment is never written
+    int32_t *rows_al;
+    ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); rows_al = (int32_t *)p;
     ACHK(hite_star_msa_sparse_dev(ctx, n, win, win_off, row_len, row_first32, total_rows, ops_base, ops_elems, max_len > 0 ? max_len : 1,
-                                  cols, status, new_cols, last_extra, st));
+                                  cols, status, new_cols, last_extra, rows_al, st));
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); eff = (int32_t *)p;
-    hipLaunchKernelGGL(eff_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, nrows, cols, eff);
+    hipLaunchKernelGGL(eff_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, rows_al, cols, eff);
     ACHK(arena_alloc(ctx, T, (size_t)n * 8, &p)); msa_bytes = (int64_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); msa_off = (int64_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); col_off2 = (int64_t *)p;

@@ -267,23 +267,42 @@ int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8
                          int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus, int32_t **d_anchors, void *stream);
 
 /* ---- star alignment: this build's GPU-native stage where the reference runs the external
- * `mafft --preservecase --quiet --thread 1` (Util.py:10416; third-party, unpinned -> parity is
- * pinned against the build's own CPU twin, oracle/hite_oracle_msa.c).
+ * `mafft --preservecase --quiet --thread 1` (Util.py:10416; third-party, unpinned, absent -> parity unpinned against
+ * mafft itself).  Definition of the stage: every row is aligned to the centre (first row of the candidate) by the
+ * optimal global alignment under unit costs, canonical traceback diagonal > up > left -- the textbook full-matrix
+ * programme of oracle/hite_oracle_nw.c; insertion blocks are left-justified.  The device computes it with a banded
+ * bit-parallel aligner that CERTIFIES its result (twin: oracle/hite_oracle_msa.c, byte-exact): a certified row is the
+ * alignment of the definition, a row without certificate is a valid alignment whose cost bounds the optimum from above.
+ * hite_align_config: exact_cap = 0 (fast: band of 128 centre rows only), 8 / 16 / 32 = widest band (x 32 rows) that
+ * is tried to obtain a certificate (default 16, or the environment variable HITE_ALIGN_EXACT).
+ * hite_align_stats: out8 = pairs, certified, kept from a band wider than 128 rows, wide fall-backs, rows dropped,
+ * sum of the costs, sum of the row lengths (columns), exact_cap -- accumulated over the calls since the last reset.
  * windows of candidate c = rows row_first[c] .. row_first[c+1]-1 of the CSR (win, win_off);
- * the first row of each candidate is the centre.  Window length <= 32767.
- * hite_star_msa: pass msa_out = NULL to get cols_out only; otherwise the rows x cols matrices are
+ * the first row of each candidate is the centre.  Window length <= 32767.  A row that cannot be aligned (shorter than
+ * half the centre, or an insertion / deletion beyond the widest band) is DROPPED: rows_out[c] (may be NULL) = rows of
+ * the alignment.
+ * hite_star_msa: pass msa_out = NULL to get cols_out / rows_out only; otherwise the rows x cols matrices are
  * written at msa_off_out[c] (16-byte aligned slots) and msa_cap is checked.
- * _dev: window g starts at d_win_off[g] and is d_win_len[g] long; d_ops_base[n+1] = exclusive scan of (R_c + 1) * (m_c + 1) (m_c = centre length),
- * ops_elems its last element; d_status[c] != 0 marks a candidate whose alignment failed
- * (cols_out[c] = 0).  The fill call must follow the align call on the same ctx/stream. */
+ * hite_star_msa_info: same + info_out = 5 int32 per input window (zeros for centres): cost U of the alignment kept,
+ * certified, status (0 aligned, else dropped), the certificate's bound k*, band words of the run kept (| 0x100: wide fall-back).
+ * _dev: window g starts at d_win_off[g] (16-byte aligned, readable up to the next multiple of 16) and is d_win_len[g]
+ * long; d_ops_base[n+1] = exclusive scan of (R_c + 1) * (m_c + 1) (m_c = centre length),
+ * ops_elems its last element; d_status[c] != 0 marks a candidate whose alignment failed (wider than 65535 columns;
+ * cols_out[c] = 0); d_rows_out (may be NULL) = rows per alignment.  The fill call must follow the align call on the
+ * same ctx/stream. */
+int hite_align_config(hite_ctx *ctx, int32_t exact_cap);
+int hite_align_stats(hite_ctx *ctx, int64_t *out8, int32_t reset);
 int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
-                  int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out, int64_t *msa_off_out);
+                  int32_t *cols_out, int32_t *rows_out, int64_t msa_cap, uint8_t *msa_out, int64_t *msa_off_out);
 /* hite_star_msa followed by remove_sparse_col_in_align_file in one step (same two-call protocol; cols_out = surviving columns) */
 int hite_star_msa_sparse(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
-                         int32_t *cols_out, int64_t msa_cap, uint8_t *msa_out, int64_t *msa_off_out);
+                         int32_t *cols_out, int32_t *rows_out, int64_t msa_cap, uint8_t *msa_out, int64_t *msa_off_out);
+int hite_star_msa_info(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
+                       int32_t *cols_out, int32_t *rows_out, int32_t *info_out, int64_t msa_cap, uint8_t *msa_out,
+                       int64_t *msa_off_out);
 int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
                       const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base, int64_t ops_elems,
-                      int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status, void *stream);
+                      int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status, int32_t *d_rows_out, void *stream);
 int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
                            const int32_t *d_win_len, const int32_t *d_row_first, const int64_t *d_ops_base, const int32_t *d_cols,
                            const int64_t *d_msa_off, uint8_t *d_msa, void *stream);
@@ -295,7 +314,7 @@ int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
 int hite_star_msa_sparse_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
                              const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows,
                              const int64_t *d_ops_base, int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out,
-                             int32_t *d_status, int32_t *d_new_cols, int32_t *d_last_extra, void *stream);
+                             int32_t *d_status, int32_t *d_new_cols, int32_t *d_last_extra, int32_t *d_rows_out, void *stream);
 int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
                                   const int32_t *d_win_len, const int32_t *d_row_first, const int64_t *d_ops_base,
                                   const int32_t *d_new_cols, const int32_t *d_last_extra, const int64_t *d_msa_off,
