@@ -179,6 +179,7 @@ def main():
         step()
     for ctx_ in ctxs:
         ctx_.profile(on=True, reset=True)
+        ctx_.align_stats(reset=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -226,6 +227,10 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    align_stats = {}
+    for ctx_ in ctxs:
+        for k_, v_ in ctx_.align_stats().items():
+            align_stats[k_] = v_ if k_ == "exact_cap" else align_stats.get(k_, 0) + v_
     calls = d_calls.cpu().numpy().view(CALL_DTYPE).copy()
     for P in parts:   # consensus offsets are relative to each share's pool
         calls["cons_off"][P["lo"]:P["lo"] + P["n"]] += P["cons_base"]
@@ -295,7 +300,7 @@ def main():
                                          if args.copies == "found" else "copy table = generator truth; copy finding not in the timed path"),
                        "genome_bp": G, "candidates_per_gpu": n_cand, "candidate_bases": cand_bytes, "copies": int(found["n"]), "copy_table": args.copies, "rows_aligned_per_step": rows,
                        "pipeline_stats": [int(x) for x in stats], "copy_stats": [int(x) for x in np.sum([cx.copy_stats() for cx in ctxs], axis=0)] if args.copies == "found" else None,
-                       "streams": K,
+                       "streams": K, "align_stats_per_step": {k_: (v_ // max(1, args.steps) if k_ != "exact_cap" else v_) for k_, v_ in align_stats.items()},
                        "is_te": n_te, "parallelism": "replicated genome, candidates sharded x%d, all-gather of 32-B calls" % world,
                        "setup_s": round(setup_s, 1)},
             "roofline": roof,

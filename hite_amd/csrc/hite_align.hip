@@ -1,33 +1,41 @@
 // hite_align.hip -- pairwise alignment of every copy window to the centre window of its candidate: the compute core of
 // the star alignment that stands where the reference shells out to `mafft` (/root/reference/module/Util.py:10416).
 //
-// Definition (oracle/hite_oracle_nw.c): optimal GLOBAL alignment under unit costs (Levenshtein), canonical traceback
-// diagonal > up > left.  How it is computed here (twin: oracle/hite_oracle_msa.c, byte for byte):
+// Definition (oracle/hite_oracle_nw.c): optimal GLOBAL alignment, mismatch 1, gap AL_GAP = 3 per base, canonical
+// traceback diagonal > up > left.  How it is computed here (twin: oracle/hite_oracle_msa.c, byte for byte):
 //
-//   * one THREAD per (row, centre) pair, Myers / Hyyro bit-parallel edit distance over an adaptive band of W = 32 NW
-//     centre rows per column of the row sequence: the band state (vertical deltas Pv / Mv) and the centre's three bit
-//     planes (2-bit code + "never matches") live in registers, pre-shifted to the band's rows; one column costs about
-//     22 NW + 30 integer instructions for 32 NW cells.  The centre planes are built once per candidate
-//     (align_planes_kernel) and shared by all of its rows; the row bases are read 16 at a time.
-//   * steering (the band follows the valley of the distance surface), pessimistic band edges and the Ukkonen
+//   * one THREAD per (row, centre) pair, bit-parallel dynamic programming over an adaptive band of W = 32 NW centre
+//     rows per column of the row sequence.  The state is the vertical difference of neighbouring cells, -3 .. +3,
+//     kept as three bit planes (difference + 3) per 32 rows.  As in Myers' algorithm for unit costs, the diagonal
+//     difference is 0 or 1, and "0" propagates up a column exactly like a carry: Z = B | (P & (Z << 1)) with
+//     B = match | (vertical difference -3 in the previous column), P = (vertical difference +3) one row below; ONE
+//     multi-word addition resolves the chain.  The horizontal and the new vertical differences are then two
+//     bit-sliced subtractions "6 + (1 - Z) - x".  The band state and the centre's three bit planes (2-bit code +
+//     "never matches") live in registers, pre-shifted to the band's rows; one column costs about 30 NW + 40 integer
+//     instructions for 32 NW cells.  The centre planes are built once per candidate (align_planes_kernel) and shared by
+//     all of its rows; the row bases are read 16 at a time.
+//   * steering (the band follows the valley of the cost surface), pessimistic band edges and the Ukkonen
 //     certificate are described in the twin's header.  A certified pair IS the alignment of the definition.
 //   * no per-cell direction is ever written to HBM.  The forward pass keeps, per strip of 16 columns, a check point of
-//     the SLICE (the middle 128 rows of the band: 48 B) and, when the band is wider than the slice, 2 B per column of
+//     the SLICE (the middle 128 rows of the band: 64 B) and, when the band is wider than the slice, 2 B per column of
 //     boundary information (the step of the band, the bits that enter the slice from the rest of the band).  The
 //     traceback pass (align_tb_kernel) re-computes the slice strip by strip into registers and walks it backwards:
-//     3-5 B of HBM traffic per column instead of 2 bits per DP cell.
+//     4-6 B of HBM traffic per column instead of 2 bits per DP cell.
 //   * schedule per pair (hite_align_run): band of 4 words; in exact mode a pair that is not certified is re-run with
-//     8 / 16 / 32 words until it is; a traceback that leaves the slice falls back to a 32-word band whose traceback bits
-//     are kept whole (rare: an insertion / deletion longer than about 60 bases); a row that even this cannot align is
-//     dropped from the alignment.
+//     8 / 16 / 32 words until it is; a traceback that leaves the slice falls back to a 64-word band computed by one
+//     wavefront per pair, whose traceback bits are kept whole (rare: an insertion / deletion longer than about 60 bases);
+//     a row that even this cannot align is dropped from the alignment.
 #include "hite_common.h"
 #include "hite_scan.h"
 #include "hite_arena.h"
+#include "hite_sort.h"
 #include "hite_align.h"
 
+#define AL_GAP 3
 #define AL_STEER 48
 #define AL_MARGIN 48
-#define AL_PADR 544          // virtual rows above row 1 in the centre planes (17 words: covers t_0 = -512 of the widest band)
+#define AL_PADR 1056         // virtual rows above row 1 in the centre planes (33 words: covers t_0 = -1024 of the fall-back band)
+#define AL_WIDE_NW 64         // words of the fall-back band (one per lane of a wavefront)
 #define AL_STRIP 16
 #define AL_KBINS 2048        // strips per pair <= 32767 / 16 + 1
 
@@ -41,13 +49,13 @@ struct AlignArgs {
     const uint4 *planes;        // per candidate, per 32 centre rows: (plane0, plane1, planeN, 0)
     const int64_t *plane_off;   // n_cand
     const int64_t *rec_off;     // per row: index of its first strip record
-    uint32_t *ckpt;             // 12 words per strip: Pv[4], Mv[4] of the slice, t of the slice, 3 spare
+    uint32_t *ckpt;             // 16 words per strip: the three planes of the slice (4 words each), t of the slice, 3 spare
     uint32_t *bnd;              // 8 words per strip (bands wider than the slice)
     int32_t *U, *kst, *st, *lvl, *U4;   // per row: cost, certificate bound, status, band words of the run kept, cost of the 4-word run
     const int64_t *ops_base;
     uint16_t *ops;
     const int64_t *full_off;    // per row (fall-back): first column record
-    uint32_t *fullbuf;          // per column: dg[32], up[32]
+    uint32_t *fullbuf;          // per column: dg[64], up[64]
     int32_t *fullt;             // per column: t
 };
 
@@ -69,75 +77,63 @@ __device__ __forceinline__ BaseMask base_mask(unsigned ch) {
     return b;
 }
 
-// the Myers / Hyyro column step on NW words, carries running from word 0 (lowest rows) upwards.
-// cin: carry into the addition of word 0; pc / mc: horizontal delta (+1 / -1 flags) of the row below word 0's first row.
-// TAP >= 0: the carries that ENTER word TAP are returned in tap[0..2] (boundary information of the slice).
+// One column of the recurrence on NW words, carries running from word 0 (lowest rows) upwards.  X2/X1/X0: bit planes of
+// (vertical difference + 3) of the previous column, replaced by those of this column.
+// carry[0]: carry into the addition of word 0; carry[1]: "vertical difference +3" of the row below word 0's first row;
+// carry[2..4]: planes of the horizontal difference of that row (+3 above the band: 1, 1, 0).
+// TAP >= 0: the carries that ENTER word TAP are returned in tap[0..4] (boundary information of the slice).
 template <int NW, bool DIRS, int TAP>
-__device__ __forceinline__ void bp_core(uint32_t (&Pv)[NW], uint32_t (&Mv)[NW], const uint32_t (&A0)[NW], const uint32_t (&A1)[NW],
-                                        const uint32_t (&AN)[NW], const BaseMask bm, uint32_t cin, uint32_t pc, uint32_t mc,
-                                        uint32_t *dg, uint32_t *up, uint32_t *tap) {
+__device__ __forceinline__ void bp_core(uint32_t (&X2)[NW], uint32_t (&X1)[NW], uint32_t (&X0)[NW], const uint32_t (&A0)[NW],
+                                        const uint32_t (&A1)[NW], const uint32_t (&AN)[NW], const BaseMask bm, uint32_t cin, uint32_t vpc,
+                                        uint32_t h2c, uint32_t h1c, uint32_t h0c, uint32_t *dg, uint32_t *up, uint32_t *tap) {
 #pragma unroll
     for (int w = 0; w < NW; w++) {
-        if (TAP >= 0 && w == TAP) { tap[0] = cin; tap[1] = pc; tap[2] = mc; }
+        if (TAP >= 0 && w == TAP) { tap[0] = cin; tap[1] = vpc; tap[2] = h2c; tap[3] = h1c; tap[4] = h0c; }
         const uint32_t eq = ~((A0[w] ^ bm.m0) | (A1[w] ^ bm.m1) | AN[w] | bm.inv);
-        const uint32_t pv = Pv[w], mv = Mv[w];
-        const unsigned long long x = (unsigned long long)(eq & pv) + pv + cin;
-        cin = (uint32_t)(x >> 32);
-        const uint32_t d0 = (((uint32_t)x) ^ pv) | eq | mv;
-        const uint32_t ph = mv | ~(d0 | pv);
-        const uint32_t mh = pv & d0;
-        const uint32_t phs = (ph << 1) | pc, mhs = (mh << 1) | mc;
-        pc = ph >> 31; mc = mh >> 31;
-        Pv[w] = mhs | ~(d0 | phs);
-        Mv[w] = phs & d0;
-        if (DIRS) { dg[w] = eq | ~d0; up[w] = Pv[w]; }
+        const uint32_t x2 = X2[w], x1 = X1[w], x0 = X0[w];
+        const uint32_t vneg = ~(x2 | x1 | x0), vpos = x2 & x1;
+        const uint32_t B = eq | vneg, P = (vpos << 1) | vpc;
+        vpc = vpos >> 31;
+        const uint32_t Y = P | B;
+        const unsigned long long sum = (unsigned long long)B + Y + cin;
+        cin = (uint32_t)(sum >> 32);
+        const uint32_t Z = B | (P & ((uint32_t)sum ^ B ^ Y));        // diagonal difference 0
+        // horizontal difference + 3 = 6 + (1 - Z) - x
+        const uint32_t h0 = ~(Z ^ x0), b1 = Z & x0, h1 = ~(x1 ^ b1), b2 = x1 & b1, h2 = ~(x2 ^ b2);
+        const uint32_t s2 = (h2 << 1) | h2c, s1 = (h1 << 1) | h1c, s0 = (h0 << 1) | h0c;
+        h2c = h2 >> 31; h1c = h1 >> 31; h0c = h0 >> 31;
+        // new vertical difference + 3 = 6 + (1 - Z) - (horizontal difference of the row below + 3)
+        const uint32_t n0 = ~(Z ^ s0), c1 = Z & s0, n1 = ~(s1 ^ c1), c2 = s1 & c1, n2 = ~(s2 ^ c2);
+        X2[w] = n2; X1[w] = n1; X0[w] = n0;
+        if (DIRS) { dg[w] = eq | ~Z; up[w] = n2 & n1; }
     }
+}
+// rows whose value exceeds the row below them minus rows whose value is below it (the steering signal), of one word
+__device__ __forceinline__ int slope_count(uint32_t x2, uint32_t x1, uint32_t x0) { return __popc(x2) - __popc(~x2 & ~(x1 & x0)); }
+// sum of (vertical difference + 3) over the rows selected by mask
+__device__ __forceinline__ int plane_sum(uint32_t x2, uint32_t x1, uint32_t x0, uint32_t mask) {
+    return 4 * __popc(x2 & mask) + 2 * __popc(x1 & mask) + __popc(x0 & mask);
 }
 
 // ---------------------------------------------------------------------------------------------
 // preparation
 // ---------------------------------------------------------------------------------------------
-// candidate of every row, strips of every pair (0 for a centre), histogram of the strip counts (for the length order)
+// candidate of every row, strips of every pair (0 for a centre), sort keys for the length order (longest first: lanes of one
+// wavefront run in lockstep, neighbours should be equally long)
 __global__ void __launch_bounds__(256) align_rows_kernel(int n_cand, const int32_t *__restrict__ row_first,
                                                          const int32_t *__restrict__ win_len, int32_t *__restrict__ row_cand,
-                                                         int32_t *__restrict__ strips, int32_t *__restrict__ hist) {
+                                                         int32_t *__restrict__ strips, unsigned long long *__restrict__ keys,
+                                                         unsigned *__restrict__ vals) {
     const int c = blockIdx.x;
     if (c >= n_cand) return;
     const int g0 = row_first[c], g1 = row_first[c + 1];
     for (int g = g0 + threadIdx.x; g < g1; g += 256) {
         row_cand[g] = c;
-        int k = g == g0 ? 0 : (win_len[g] + AL_STRIP - 1) / AL_STRIP;
-        if (k >= AL_KBINS) k = AL_KBINS - 1;
-        strips[g] = g == g0 ? 0 : (win_len[g] + AL_STRIP - 1) / AL_STRIP;
-        atomicAdd(&hist[AL_KBINS - 1 - k], 1);
+        const int k = g == g0 ? 0 : (win_len[g] + AL_STRIP - 1) / AL_STRIP;
+        strips[g] = k;
+        keys[g] = (unsigned long long)(AL_KBINS - 1 - (k >= AL_KBINS ? AL_KBINS - 1 : k));
+        vals[g] = (unsigned)g;
     }
-}
-__global__ void __launch_bounds__(1024) align_hist_scan_kernel(int32_t *__restrict__ hist /* AL_KBINS -> exclusive offsets */) {
-    __shared__ int s_w[16];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    int carry = 0;
-    for (int base = 0; base < AL_KBINS; base += 1024) {
-        const int v = hist[base + threadIdx.x];
-        int x = v;
-        for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d, 64); if (lane >= d) x += y; }
-        __syncthreads();
-        if (lane == 63) s_w[w] = x;
-        __syncthreads();
-        int pre = 0, tot = 0;
-        for (int q = 0; q < 16; q++) { const int t = s_w[q]; if (q < w) pre += t; tot += t; }
-        hist[base + threadIdx.x] = carry + pre + x - v;
-        carry += tot;
-        __syncthreads();
-    }
-}
-// rows in the order of decreasing length (lanes of one wavefront run in lockstep: neighbours should be equally long)
-__global__ void align_order_kernel(int64_t total_rows, const int32_t *__restrict__ strips, int32_t *__restrict__ cursor,
-                                   int32_t *__restrict__ order) {
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total_rows) return;
-    int k = strips[g];
-    if (k >= AL_KBINS) k = AL_KBINS - 1;
-    order[atomicAdd(&cursor[AL_KBINS - 1 - k], 1)] = (int32_t)g;
 }
 __global__ void align_plane_words_kernel(int n_cand, const int32_t *__restrict__ row_first, const int32_t *__restrict__ win_len,
                                          int32_t *__restrict__ words) {
@@ -173,7 +169,7 @@ __global__ void __launch_bounds__(256) align_planes_kernel(int n_cand, const uin
 // ---------------------------------------------------------------------------------------------
 // forward pass
 // ---------------------------------------------------------------------------------------------
-template <int NW, bool FULL>
+template <int NW>
 __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
     constexpr int W = 32 * NW, H = W / 2, S0 = NW / 2 - 2;
     const int li = blockIdx.x * 64 + threadIdx.x;
@@ -189,11 +185,10 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
     const uint8_t *b = P.win + (g >= 0 ? P.win_off[g] : 0);
     const uint4 *pl = P.planes + (g >= 0 ? P.plane_off[c] : 0);
     const int64_t rec0 = g >= 0 ? P.rec_off[g] : 0;
-    const int64_t full0 = (FULL && g >= 0) ? P.full_off[g] : 0;
-    uint32_t Pv[NW], Mv[NW], A0[NW], A1[NW], AN[NW];
+    uint32_t X2[NW], X1[NW], X0[NW], A0[NW], A1[NW], AN[NW];
     int t = -H;
 #pragma unroll
-    for (int w = 0; w < NW; w++) { Pv[w] = w >= NW / 2 ? 0xffffffffu : 0u; Mv[w] = w < NW / 2 ? 0xffffffffu : 0u; }
+    for (int w = 0; w < NW; w++) { X2[w] = w >= NW / 2 ? 0xffffffffu : 0u; X1[w] = X2[w]; X0[w] = 0u; }   // +3 from row 1 on, -3 above
     bool act = n > 0;
     if (act) {   // planes of rows t+1 .. t+W: bit position t + AL_PADR (a multiple of 32 here)
         const int q0 = (t + AL_PADR) >> 5;
@@ -203,17 +198,18 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
 #pragma unroll
         for (int w = 0; w < NW; w++) { A0[w] = 0; A1[w] = 0; AN[w] = 0xffffffffu; }
     }
-    int stop = H, LO = -(1 << 28), HI = 1 << 28, status = 0;
+    int stop = AL_GAP * H, LO = -(1 << 28), HI = 1 << 28, status = 0;
     for (int k = 0; k * AL_STRIP < nmax; k++) {
         const bool sa = act && k * AL_STRIP < n;
         uint4 bw = make_uint4(0, 0, 0, 0);
         uint32_t f0 = 0, f1 = 0, fn = 0;   // the next 32 rows below the band, per plane
         uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (sa) {
-            uint4 *ck = reinterpret_cast<uint4 *>(P.ckpt + (rec0 + k) * 12);
-            ck[0] = make_uint4(Pv[S0], Pv[S0 + 1], Pv[S0 + 2], Pv[S0 + 3]);
-            ck[1] = make_uint4(Mv[S0], Mv[S0 + 1], Mv[S0 + 2], Mv[S0 + 3]);
-            ck[2] = make_uint4((uint32_t)(t + 32 * S0), 0u, 0u, 0u);
+            uint4 *ck = reinterpret_cast<uint4 *>(P.ckpt + (rec0 + k) * 16);
+            ck[0] = make_uint4(X2[S0], X2[S0 + 1], X2[S0 + 2], X2[S0 + 3]);
+            ck[1] = make_uint4(X1[S0], X1[S0 + 1], X1[S0 + 2], X1[S0 + 3]);
+            ck[2] = make_uint4(X0[S0], X0[S0 + 1], X0[S0 + 2], X0[S0 + 3]);
+            ck[3] = make_uint4((uint32_t)(t + 32 * S0), 0u, 0u, 0u);
             bw = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
             const int fx = t + W + AL_PADR;
             const uint4 F = pl[fx >> 5], G = pl[(fx >> 5) + 1];
@@ -227,25 +223,26 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
                 // ---- steering from column j-1 (middle 128 rows), clamps
                 int ds = 0;
 #pragma unroll
-                for (int w = S0; w < S0 + 4; w++) ds += __popc(Pv[w]) - __popc(Mv[w]);
+                for (int w = S0; w < S0 + 4; w++) ds += slope_count(X2[w], X1[w], X0[w]);
                 int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
                 const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
                 if (t + s > hi_t) s = hi_t - t;
                 if (t + s < lo_t) s = lo_t - t;
                 if ((unsigned)s > 2u) { status = 2; act = false; s = 1; }
-                const uint32_t smask = (1u << s) - 1u;
-                stop += __popc(Pv[0] & smask) - __popc(Mv[0] & smask) + 1;
-                uint32_t pin = 0, min_ = 0;
-                if (NW > 4) { pin = Pv[S0 + 4 < NW ? S0 + 4 : 0] & 3u; min_ = Mv[S0 + 4 < NW ? S0 + 4 : 0] & 3u; }
-                // ---- the band moves down by s rows
+                stop += plane_sum(X2[0], X1[0], X0[0], (1u << s) - 1u) - AL_GAP * s + AL_GAP;
+                uint32_t in2 = 0, in1 = 0, in0 = 0;
+                if (NW > 4) { in2 = X2[S0 + 4 < NW ? S0 + 4 : 0] & 3u; in1 = X1[S0 + 4 < NW ? S0 + 4 : 0] & 3u; in0 = X0[S0 + 4 < NW ? S0 + 4 : 0] & 3u; }
+                // ---- the band moves down by s rows (rows that enter: +3)
 #pragma unroll
                 for (int w = 0; w < NW - 1; w++) {
-                    Pv[w] = alignbit(Pv[w + 1], Pv[w], (uint32_t)s); Mv[w] = alignbit(Mv[w + 1], Mv[w], (uint32_t)s);
+                    X2[w] = alignbit(X2[w + 1], X2[w], (uint32_t)s); X1[w] = alignbit(X1[w + 1], X1[w], (uint32_t)s);
+                    X0[w] = alignbit(X0[w + 1], X0[w], (uint32_t)s);
                     A0[w] = alignbit(A0[w + 1], A0[w], (uint32_t)s); A1[w] = alignbit(A1[w + 1], A1[w], (uint32_t)s);
                     AN[w] = alignbit(AN[w + 1], AN[w], (uint32_t)s);
                 }
-                Pv[NW - 1] = alignbit(0xffffffffu, Pv[NW - 1], (uint32_t)s);
-                Mv[NW - 1] = Mv[NW - 1] >> s;
+                X2[NW - 1] = alignbit(0xffffffffu, X2[NW - 1], (uint32_t)s);
+                X1[NW - 1] = alignbit(0xffffffffu, X1[NW - 1], (uint32_t)s);
+                X0[NW - 1] = X0[NW - 1] >> s;
                 A0[NW - 1] = alignbit(f0, A0[NW - 1], (uint32_t)s); A1[NW - 1] = alignbit(f1, A1[NW - 1], (uint32_t)s);
                 AN[NW - 1] = alignbit(fn, AN[NW - 1], (uint32_t)s);
                 f0 >>= s; f1 >>= s; fn >>= s;
@@ -255,24 +252,16 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
                 // ---- column
                 const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
                 const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
-                uint32_t dg[NW], up[NW], tap[3] = {0, 1, 0};
-                bp_core<NW, FULL, (NW > 4 ? S0 : -1)>(Pv, Mv, A0, A1, AN, bm, 0u, 1u, 0u, dg, up, tap);
-                if (NW > 4 && !FULL) {
-                    const uint32_t r16 = (uint32_t)s | (pin << 2) | (min_ << 4) | (tap[0] << 6) | (tap[1] << 7) | (tap[2] << 8);
+                uint32_t tap[5] = {0, 0, 1, 1, 0};
+                bp_core<NW, false, (NW > 4 ? S0 : -1)>(X2, X1, X0, A0, A1, AN, bm, 0u, 0u, 1u, 1u, 0u, nullptr, nullptr, tap);
+                if (NW > 4) {
+                    const uint32_t r16 = (uint32_t)s | (in2 << 2) | (in1 << 4) | (in0 << 6) | (tap[0] << 8) | (tap[1] << 9) | (tap[2] << 10) |
+                                         (tap[3] << 11) | (tap[4] << 12);
                     brec[cc >> 1] |= r16 << (16 * (cc & 1));
-                }
-                if (FULL) {
-                    uint4 *fb = reinterpret_cast<uint4 *>(P.fullbuf + (full0 + j) * (2 * NW));
-#pragma unroll
-                    for (int w = 0; w < NW; w += 4) {
-                        fb[w / 4] = make_uint4(dg[w], dg[w + 1], dg[w + 2], dg[w + 3]);
-                        fb[NW / 4 + w / 4] = make_uint4(up[w], up[w + 1], up[w + 2], up[w + 3]);
-                    }
-                    P.fullt[full0 + j] = t;
                 }
             }
         }
-        if (NW > 4 && !FULL && sa) {
+        if (NW > 4 && sa) {
             uint4 *bp = reinterpret_cast<uint4 *>(P.bnd + (rec0 + k) * 8);
             bp[0] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
             bp[1] = make_uint4(brec[4], brec[5], brec[6], brec[7]);
@@ -281,29 +270,24 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
     if (n > 0) {
         int U = -1, kstar = -1;
         if (status == 0) {
-            int u = stop;   // t_n = m - H: row m is bit H - 1
+            int u = stop - AL_GAP * H;   // t_n = m - H: row m is bit H - 1
 #pragma unroll
-            for (int w = 0; w < NW / 2; w++) u += __popc(Pv[w]) - __popc(Mv[w]);
+            for (int w = 0; w < NW / 2; w++) u += plane_sum(X2[w], X1[w], X0[w], 0xffffffffu);
             U = u;
             const int d = m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
             int E = dmin - LO;
             if (HI - dmax < E) E = HI - dmax;
             if (E > (1 << 27)) kstar = 0x7fffffff;
-            else if (E >= 0) kstar = ad + 2 * E + 1;
+            else if (E >= 0) kstar = AL_GAP * ad + 2 * AL_GAP * E + 2 * AL_GAP - 1;
         }
         P.U[g] = U; P.kst[g] = kstar; P.st[g] = status; P.lvl[g] = NW;
-        if (NW == 4 && !FULL) P.U4[g] = U;
+        if (NW == 4) P.U4[g] = U;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // traceback pass: re-compute the slice strip by strip (registers), walk it backwards
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t sel4(const uint32_t (&v)[4], int w) {
-    const uint32_t a = (w & 1) ? v[1] : v[0], b = (w & 1) ? v[3] : v[2];
-    return (w & 2) ? b : a;
-}
-
 __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
     const int li = blockIdx.x * 64 + threadIdx.x;
     const int g = li < nlist ? list[li] : -1;
@@ -326,17 +310,18 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     for (int k = Kmax - 1; k >= 0; k--) {
         const bool sa = n > 0 && !fail && i > 0 && k * AL_STRIP < n;
         if (!__any(sa)) continue;
-        uint32_t Pv[4], Mv[4], A0[4], A1[4], AN[4];
+        uint32_t X2[4], X1[4], X0[4], A0[4], A1[4], AN[4];
         uint32_t f0 = 0, f1 = 0, fn = 0;
         uint4 bw = make_uint4(0, 0, 0, 0);
         uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int t = 0;
         if (sa) {
-            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k) * 12);
-            const uint4 c0 = ck[0], c1 = ck[1], c2 = ck[2];
-            Pv[0] = c0.x; Pv[1] = c0.y; Pv[2] = c0.z; Pv[3] = c0.w;
-            Mv[0] = c1.x; Mv[1] = c1.y; Mv[2] = c1.z; Mv[3] = c1.w;
-            t = (int)c2.x;
+            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k) * 16);
+            const uint4 c2 = ck[0], c1 = ck[1], c0 = ck[2], c3 = ck[3];
+            X2[0] = c2.x; X2[1] = c2.y; X2[2] = c2.z; X2[3] = c2.w;
+            X1[0] = c1.x; X1[1] = c1.y; X1[2] = c1.z; X1[3] = c1.w;
+            X0[0] = c0.x; X0[1] = c0.y; X0[2] = c0.z; X0[3] = c0.w;
+            t = (int)c3.x;
             bw = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
             if (hb) {
                 const uint4 *bp = reinterpret_cast<const uint4 *>(P.bnd + (rec0 + k) * 8);
@@ -358,7 +343,7 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
             f0 = alignbit(wd[5].x, wd[4].x, sh); f1 = alignbit(wd[5].y, wd[4].y, sh); fn = alignbit(wd[5].z, wd[4].z, sh);
         } else {
 #pragma unroll
-            for (int w = 0; w < 4; w++) { Pv[w] = 0; Mv[w] = 0; A0[w] = 0; A1[w] = 0; AN[w] = 0; }
+            for (int w = 0; w < 4; w++) { X2[w] = 0; X1[w] = 0; X0[w] = 0; A0[w] = 0; A1[w] = 0; AN[w] = 0; }
         }
         uint32_t dg[AL_STRIP][4], up[AL_STRIP][4];
         uint32_t sbits = 0;
@@ -370,52 +355,77 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
             if (sa && jc <= n) {
                 const uint32_t r16 = (brec[cc >> 1] >> (16 * (cc & 1))) & 0xffffu;
                 int s;
-                uint32_t pin, min_, cin, pc, mc;
+                uint32_t in2, in1, in0, cin, vpc, h2c, h1c, h0c;
                 if (hb) {
-                    s = (int)(r16 & 3u); pin = (r16 >> 2) & 3u; min_ = (r16 >> 4) & 3u; cin = (r16 >> 6) & 1u; pc = (r16 >> 7) & 1u; mc = (r16 >> 8) & 1u;
+                    s = (int)(r16 & 3u); in2 = (r16 >> 2) & 3u; in1 = (r16 >> 4) & 3u; in0 = (r16 >> 6) & 3u;
+                    cin = (r16 >> 8) & 1u; vpc = (r16 >> 9) & 1u; h2c = (r16 >> 10) & 1u; h1c = (r16 >> 11) & 1u; h0c = (r16 >> 12) & 1u;
                 } else {   // the 4-word band IS the slice: same steering as the forward pass
                     int ds = 0;
 #pragma unroll
-                    for (int w = 0; w < 4; w++) ds += __popc(Pv[w]) - __popc(Mv[w]);
+                    for (int w = 0; w < 4; w++) ds += slope_count(X2[w], X1[w], X0[w]);
                     s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
                     const int hi_t = m - 64, lo_t = m - 64 - 2 * (n - jc);
                     if (t + s > hi_t) s = hi_t - t;
                     if (t + s < lo_t) s = lo_t - t;
-                    pin = 3u; min_ = 0u; cin = 0u; pc = 1u; mc = 0u;
+                    in2 = 3u; in1 = 3u; in0 = 0u; cin = 0u; vpc = 0u; h2c = 1u; h1c = 1u; h0c = 0u;
                 }
 #pragma unroll
                 for (int w = 0; w < 3; w++) {
-                    Pv[w] = alignbit(Pv[w + 1], Pv[w], (uint32_t)s); Mv[w] = alignbit(Mv[w + 1], Mv[w], (uint32_t)s);
+                    X2[w] = alignbit(X2[w + 1], X2[w], (uint32_t)s); X1[w] = alignbit(X1[w + 1], X1[w], (uint32_t)s);
+                    X0[w] = alignbit(X0[w + 1], X0[w], (uint32_t)s);
                     A0[w] = alignbit(A0[w + 1], A0[w], (uint32_t)s); A1[w] = alignbit(A1[w + 1], A1[w], (uint32_t)s);
                     AN[w] = alignbit(AN[w + 1], AN[w], (uint32_t)s);
                 }
-                Pv[3] = alignbit(pin, Pv[3], (uint32_t)s); Mv[3] = alignbit(min_, Mv[3], (uint32_t)s);
+                X2[3] = alignbit(in2, X2[3], (uint32_t)s); X1[3] = alignbit(in1, X1[3], (uint32_t)s); X0[3] = alignbit(in0, X0[3], (uint32_t)s);
                 A0[3] = alignbit(f0, A0[3], (uint32_t)s); A1[3] = alignbit(f1, A1[3], (uint32_t)s); AN[3] = alignbit(fn, AN[3], (uint32_t)s);
                 f0 >>= s; f1 >>= s; fn >>= s;
                 t += s;
                 sbits |= (uint32_t)s << (2 * cc);
                 const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
                 const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
-                uint32_t tap[3];
-                bp_core<4, true, -1>(Pv, Mv, A0, A1, AN, bm, cin, pc, mc, dg[cc], up[cc], tap);
+                uint32_t tap[5], dgc[4], upc[4];
+                bp_core<4, true, -1>(X2, X1, X0, A0, A1, AN, bm, cin, vpc, h2c, h1c, h0c, dgc, upc, tap);
+#pragma unroll
+                for (int w = 0; w < 4; w++) { dg[cc][w] = dgc[w]; up[cc][w] = upc[w]; }
             }
         }
-        // walk: every path step leaves column j for column j-1 (diagonal, left) or stays in it (up)
+        // walk: every path step leaves column j for column j-1 (diagonal, left) or stays in it (up).  A run of up steps ends at
+        // the highest row at or above the current one where the diagonal is allowed or up is not: found with bit operations on
+        // the column's 128 slice bits, so that the register arrays are only ever indexed by constants.
         int tcur = t;
 #pragma unroll
         for (int cc = AL_STRIP - 1; cc >= 0; cc--) {
             const int jc = k * AL_STRIP + cc + 1;
-            bool here = sa && !fail && i > 0 && j == jc;
-            while (__any(here)) {
-                if (here) {
-                    const int kb = i - tcur - 1;
-                    if ((unsigned)kb >= 128u) { fail = true; here = false; }
+            if (sa && !fail && i > 0 && j == jc) {
+                const int kb = i - tcur - 1;
+                if ((unsigned)kb >= 128u) fail = true;
+                else {
+                    const int wq = kb >> 5;
+                    const uint32_t low = 0xffffffffu >> (31 - (kb & 31));      // bits 0 .. kb & 31
+                    const uint32_t s0 = dg[cc][0] | ~up[cc][0], s1 = dg[cc][1] | ~up[cc][1], s2 = dg[cc][2] | ~up[cc][2],
+                                   s3 = dg[cc][3] | ~up[cc][3];
+                    const uint32_t m3 = wq == 3 ? s3 & low : 0u;
+                    const uint32_t m2 = wq > 2 ? s2 : (wq == 2 ? s2 & low : 0u);
+                    const uint32_t m1 = wq > 1 ? s1 : (wq == 1 ? s1 & low : 0u);
+                    const uint32_t m0 = wq > 0 ? s0 : s0 & low;
+                    int ps;
+                    uint32_t dsel;
+                    if (m3) { ps = 127 - __clz(m3); dsel = dg[cc][3]; }
+                    else if (m2) { ps = 95 - __clz(m2); dsel = dg[cc][2]; }
+                    else if (m1) { ps = 63 - __clz(m1); dsel = dg[cc][1]; }
+                    else if (m0) { ps = 31 - __clz(m0); dsel = dg[cc][0]; }
+                    else { ps = -1; dsel = 0; }
+                    if (ps < 0) fail = true;      // the run of up steps leaves the slice at its first row
                     else {
-                        const uint32_t dw = sel4(dg[cc], kb >> 5), uw = sel4(up[cc], kb >> 5);
-                        const uint32_t bit = 1u << (kb & 31);
-                        if (dw & bit) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; here = false; }
-                        else if (uw & bit) { ops[i - 1] = (uint16_t)(j | 0x8000); i--; here = i > 0; }
-                        else { j--; here = false; }
+                        int ups = kb - ps;
+                        if (ups > i) ups = i;     // (cannot happen: row 0 stops every run)
+                        const uint16_t gapv = (uint16_t)(j | 0x8000);
+                        for (int x = 0; x < ups; x++) ops[i - 1 - x] = gapv;
+                        i -= ups;
+                        if (i > 0) {
+                            if ((dsel >> (ps & 31)) & 1u) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
+                            else j--;
+                        }
                     }
                 }
             }
@@ -428,12 +438,113 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     }
 }
 
-// fall-back traceback on the bits of the whole 32-word band
-__global__ void __launch_bounds__(64) align_tb_full_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
-    constexpr int NW = 32, W = 32 * NW;
-    const int li = blockIdx.x * 64 + threadIdx.x;
-    if (li >= nlist) return;
-    const int g = list[li];
+// ---------------------------------------------------------------------------------------------
+// wide fall-back: one WAVEFRONT per pair, lane w = word w of a band of 64 words (2048 centre rows); the traceback bits of
+// the whole band are kept (512 B per column).  Same recurrence as bp_core; what runs along the words there runs along the
+// lanes here: neighbours by DPP wave_shl / wave_shr, the carry chain of the addition by a carry-lookahead on two ballots.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_above(uint32_t v, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x130, 0xf, 0xf, false); }   // lane i <- lane i+1
+__device__ __forceinline__ uint32_t lane_below(uint32_t v, uint32_t fill) { return (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)v, 0x138, 0xf, 0xf, false); }   // lane i <- lane i-1
+__device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+__global__ void __launch_bounds__(64) align_wide_fwd_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    constexpr int NW = AL_WIDE_NW, W = 32 * NW, H = W / 2, S0 = NW / 2 - 2;
+    const int pi = blockIdx.x;
+    if (pi >= nlist) return;
+    const int lane = threadIdx.x;
+    const int g = list[pi];
+    const int c = P.row_cand[g], g0 = P.row_first[c];
+    if (g == g0) return;
+    const int m = P.win_len[g0], n = P.win_len[g];
+    const uint8_t *b = P.win + P.win_off[g];
+    const uint4 *pl = P.planes + P.plane_off[c];
+    const int64_t full0 = P.full_off[g];
+    int t = -H;
+    uint32_t X2 = lane >= NW / 2 ? 0xffffffffu : 0u, X1 = X2, X0 = 0u;
+    uint32_t A0, A1, AN;
+    { const uint4 v = pl[((t + AL_PADR) >> 5) + lane]; A0 = v.x; A1 = v.y; AN = v.z; }
+    int stop = AL_GAP * H, LO = -(1 << 28), HI = 1 << 28, status = 0;
+    uint32_t f0 = 0, f1 = 0, fn = 0;
+    uint4 bw = make_uint4(0, 0, 0, 0);
+    for (int j = 1; j <= n; j++) {
+        const int cc = (j - 1) & 15;
+        if (cc == 0) {   // 16 row bases; the next 32 rows below the band, per plane (at most 2 rows enter per column)
+            bw = *reinterpret_cast<const uint4 *>(b + (j - 1));
+            const int fx = t + W + AL_PADR;
+            const uint4 F = pl[fx >> 5], G = pl[(fx >> 5) + 1];
+            const uint32_t sh = (uint32_t)fx & 31u;
+            f0 = alignbit(G.x, F.x, sh); f1 = alignbit(G.y, F.y, sh); fn = alignbit(G.z, F.z, sh);
+        }
+        const int dv = slope_count(X2, X1, X0);
+        const int ds = __builtin_amdgcn_readlane(dv, S0) + __builtin_amdgcn_readlane(dv, S0 + 1) + __builtin_amdgcn_readlane(dv, S0 + 2) +
+                       __builtin_amdgcn_readlane(dv, S0 + 3);
+        int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
+        const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
+        if (t + s > hi_t) s = hi_t - t;
+        if (t + s < lo_t) s = lo_t - t;
+        if ((unsigned)s > 2u) { status = 2; break; }
+        const uint32_t smask = (1u << s) - 1u;
+        stop += plane_sum((uint32_t)__builtin_amdgcn_readlane((int)X2, 0), (uint32_t)__builtin_amdgcn_readlane((int)X1, 0),
+                          (uint32_t)__builtin_amdgcn_readlane((int)X0, 0), smask) - AL_GAP * s + AL_GAP;
+        X2 = alignbit(lane_above(X2, 0xffffffffu), X2, (uint32_t)s);
+        X1 = alignbit(lane_above(X1, 0xffffffffu), X1, (uint32_t)s);
+        X0 = alignbit(lane_above(X0, 0u), X0, (uint32_t)s);
+        A0 = alignbit(lane_above(A0, f0), A0, (uint32_t)s);
+        A1 = alignbit(lane_above(A1, f1), A1, (uint32_t)s);
+        AN = alignbit(lane_above(AN, fn), AN, (uint32_t)s);
+        f0 >>= s; f1 >>= s; fn >>= s;
+        t += s;
+        if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
+        if (t + W < m) { const int v = t + W - j; HI = v < HI ? v : HI; }
+        const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
+        const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
+        const uint32_t eq = ~((A0 ^ bm.m0) | (A1 ^ bm.m1) | AN | bm.inv);
+        const uint32_t vneg = ~(X2 | X1 | X0), vpos = X2 & X1;
+        const uint32_t B = eq | vneg, Pp = (vpos << 1) | (lane_below(vpos, 0u) >> 31);
+        const uint32_t Y = Pp | B;
+        uint32_t sum = B + Y;
+        {   // carries along the lanes: lane w generates (its sum wrapped) or propagates (its sum is all ones)
+            const unsigned long long Gm = __ballot(sum < B), Pm = __ballot(sum == 0xffffffffu);
+            const unsigned long long Yy = Pm | Gm, ss = Gm + Yy;
+            const unsigned long long into = ss ^ Gm ^ Yy;                // carry into bit u of Gm + (Pm | Gm) = carry into lane u
+            sum += (uint32_t)((into >> lane) & 1ull);
+        }
+        const uint32_t Z = B | (Pp & (sum ^ B ^ Y));
+        const uint32_t h0 = ~(Z ^ X0), b1 = Z & X0, h1 = ~(X1 ^ b1), b2 = X1 & b1, h2 = ~(X2 ^ b2);
+        const uint32_t s2 = (h2 << 1) | (lane_below(h2, 0x80000000u) >> 31), s1 = (h1 << 1) | (lane_below(h1, 0x80000000u) >> 31),
+                       s0 = (h0 << 1) | (lane_below(h0, 0u) >> 31);
+        const uint32_t n0 = ~(Z ^ s0), c1 = Z & s0, n1 = ~(s1 ^ c1), c2 = s1 & c1, n2 = ~(s2 ^ c2);
+        X2 = n2; X1 = n1; X0 = n0;
+        uint32_t *fb = P.fullbuf + (full0 + j) * (2 * NW);
+        fb[lane] = eq | ~Z;
+        fb[NW + lane] = n2 & n1;
+        if (lane == 0) P.fullt[full0 + j] = t;
+    }
+    int U = -1, kstar = -1;
+    if (status == 0) {
+        U = stop - AL_GAP * H + wave_sum_i32(lane < NW / 2 ? plane_sum(X2, X1, X0, 0xffffffffu) : 0);
+        const int d = m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
+        int E = dmin - LO;
+        if (HI - dmax < E) E = HI - dmax;
+        if (E > (1 << 27)) kstar = 0x7fffffff;
+        else if (E >= 0) kstar = AL_GAP * ad + 2 * AL_GAP * E + 2 * AL_GAP - 1;
+    }
+    if (lane == 0) { P.U[g] = U; P.kst[g] = kstar; P.st[g] = status; P.lvl[g] = NW | 0x100; }
+}
+
+// traceback of the fall-back: one wavefront per pair, lane w holds word w of the column's bits; the run of up steps ends at
+// the highest stop bit (diagonal allowed, or up not allowed) at or below the current row -- two ballots and a count of
+// leading zeros; ops leave in coalesced runs.  The columns are fetched eight at a time (the walk visits them in order).
+__global__ void __launch_bounds__(64) align_wide_tb_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    constexpr int NW = AL_WIDE_NW, W = 32 * NW, PF = 8;
+    const int pi = blockIdx.x;
+    if (pi >= nlist) return;
+    const int lane = threadIdx.x;
+    const int g = list[pi];
     const int c = P.row_cand[g], g0 = P.row_first[c];
     if (g == g0 || P.st[g] != 0) return;
     const int m = P.win_len[g0], n = P.win_len[g];
@@ -441,17 +552,48 @@ __global__ void __launch_bounds__(64) align_tb_full_kernel(AlignArgs P, const in
     const int64_t full0 = P.full_off[g];
     int i = m, j = n;
     bool fail = false;
-    while (i > 0 && j > 0) {
-        const int kb = i - P.fullt[full0 + j] - 1;
-        if ((unsigned)kb >= (unsigned)W) { fail = true; break; }
-        const uint32_t *fb = P.fullbuf + (full0 + j) * (2 * NW);
-        const uint32_t bit = 1u << (kb & 31);
-        if (fb[kb >> 5] & bit) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
-        else if (fb[NW + (kb >> 5)] & bit) { ops[i - 1] = (uint16_t)(j | 0x8000); i--; }
-        else j--;
+    while (i > 0 && j > 0 && !fail) {
+        uint32_t dgs[PF], ups[PF];
+        int tts[PF];
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            const int jq = j - q > 0 ? j - q : 1;
+            const uint32_t *fb = P.fullbuf + (full0 + jq) * (2 * NW);
+            dgs[q] = fb[lane]; ups[q] = fb[NW + lane]; tts[q] = P.fullt[full0 + jq];
+        }
+#pragma unroll
+        for (int q = 0; q < PF; q++) {
+            if (i > 0 && j > 0 && !fail) {
+                const uint32_t dgw = dgs[q], upw = ups[q];
+                const int kb = i - tts[q] - 1;
+                if ((unsigned)kb >= (unsigned)W) fail = true;
+                else {
+                    const int wq = kb >> 5;
+                    const uint32_t low = 0xffffffffu >> (31 - (kb & 31));
+                    const uint32_t sbit = dgw | ~upw;
+                    const uint32_t mk = lane > wq ? 0u : (lane == wq ? sbit & low : sbit);
+                    const unsigned long long nz = __ballot(mk != 0u);
+                    if (nz == 0ull) fail = true;
+                    else {
+                        const int tl = 63 - __clzll(nz);
+                        const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)mk, tl), dt = (uint32_t)__builtin_amdgcn_readlane((int)dgw, tl);
+                        const int ps = 32 * tl + 31 - __clz(mt);
+                        int nup = kb - ps;
+                        if (nup > i) nup = i;
+                        const uint16_t gapv = (uint16_t)(j | 0x8000);
+                        for (int x = lane; x < nup; x += 64) ops[i - 1 - x] = gapv;
+                        i -= nup;
+                        if (i > 0) {
+                            if ((dt >> (ps & 31)) & 1u) { if (lane == 0) ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
+                            else j--;
+                        }
+                    }
+                }
+            }
+        }
     }
-    if (fail) P.st[g] = 1;
-    else for (int q = i - 1; q >= 0; q--) ops[q] = (uint16_t)0x8000;
+    if (fail) { if (lane == 0) P.st[g] = 1; }
+    else for (int q = lane; q < i; q += 64) ops[q] = (uint16_t)0x8000;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -467,9 +609,9 @@ __global__ void align_flag_kernel(int64_t nrows, const int32_t *__restrict__ ord
     if (strips[g] > 0) {
         if (what == 0) {
             const int u4 = P.U4[g];
-            if (P.st[g] == 0 && u4 >= 0 && u4 + AL_MARGIN <= 32 * cap) {
+            if (P.st[g] == 0 && u4 >= 0 && u4 + AL_GAP * AL_MARGIN <= 32 * AL_GAP * cap) {
                 int first = 8;
-                while (32 * first < u4 + AL_MARGIN) first *= 2;
+                while (32 * AL_GAP * first < u4 + AL_GAP * AL_MARGIN) first *= 2;
                 const bool cert = P.U[g] <= P.kst[g];
                 f = level >= first && !cert;
             }
@@ -506,10 +648,6 @@ __global__ void align_stats_kernel(int64_t total_rows, const int32_t *__restrict
     if (row_dead) row_dead[g] = st != 0;
     if (st != 0 && cand_status) atomicExch(&cand_status[P.row_cand[g]], 2);
 }
-__global__ void align_mark_fallback_kernel(int nlist, const int32_t *__restrict__ list, int32_t *__restrict__ lvl) {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x < nlist) lvl[list[x]] |= 0x100;
-}
 __global__ void align_info_kernel(int64_t total_rows, AlignArgs P, int32_t *__restrict__ info /* 5 per row */) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total_rows) return;
@@ -527,6 +665,7 @@ struct AlignState {
     int64_t *h_pin = nullptr;
     int64_t *d_scal = nullptr;
     int exact_cap = -1;
+    bool sort_attr = false;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -619,13 +758,20 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     memset(&P, 0, sizeof P);
     P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first; P.n_cand = n_cand;
     P.ops_base = d_ops_base; P.ops = d_ops;
-    int32_t *row_cand, *strips, *hist, *cursor, *order, *pwords, *flag, *cols, *list;
+    int32_t *row_cand, *strips, *order, *pwords, *flag, *cols, *list;
+    unsigned long long *skeys;
     int64_t *plane_off, *rec_off, *pos, *colpos, *scan_tmp, *full_off;
     ACHK(aalloc(ctx, A, (size_t)total_rows, &row_cand));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &strips));
-    ACHK(aalloc(ctx, A, (size_t)AL_KBINS * 2, &hist));
-    cursor = hist;
-    ACHK(aalloc(ctx, A, (size_t)total_rows, &order));
+    ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &skeys));
+    ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &order));
+    Sorter srt;
+    srt.ctx = ctx; srt.st = st; srt.cap = total_rows; srt.hist_n = sorter_hist_elems(total_rows);
+    ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &srt.k2));
+    ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &srt.v2));
+    ACHK(aalloc(ctx, A, (size_t)srt.hist_n, &srt.hist));
+    ACHK(aalloc(ctx, A, (size_t)srt.hist_n + 1, &srt.offs));
+    ACHK(aalloc(ctx, A, (size_t)scan_tmp_elems(srt.hist_n), &srt.bs));
     ACHK(aalloc(ctx, A, (size_t)n_cand, &pwords));
     ACHK(aalloc(ctx, A, (size_t)n_cand + 1, &plane_off));
     ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &rec_off));
@@ -643,12 +789,14 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     ACHK(aalloc(ctx, A, (size_t)total_rows, &P.U4));
     P.row_cand = row_cand; P.full_off = full_off;
     int tk = hite_prof_begin(ctx, "align_prep", st);
-    HITE_CHECK(ctx, hipMemsetAsync(hist, 0, AL_KBINS * 4, st));
     HITE_CHECK(ctx, hipMemsetAsync(P.st, 0, (size_t)total_rows * 4, st));
     HITE_CHECK(ctx, hipMemsetAsync(P.lvl, 0, (size_t)total_rows * 4, st));
-    hipLaunchKernelGGL(align_rows_kernel, dim3(n_cand), dim3(256), 0, st, n_cand, d_row_first, d_win_len, row_cand, strips, hist);
-    hipLaunchKernelGGL(align_hist_scan_kernel, dim3(1), dim3(1024), 0, st, hist);
-    hipLaunchKernelGGL(align_order_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, total_rows, strips, cursor, order);
+    hipLaunchKernelGGL(align_rows_kernel, dim3(n_cand), dim3(256), 0, st, n_cand, d_row_first, d_win_len, row_cand, strips, skeys, (unsigned *)order);
+    if (!S->sort_attr) {
+        HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RSS_LDS_BYTES));
+        S->sort_attr = true;
+    }
+    ACHK(sorter_sort(srt, skeys, (unsigned *)order, total_rows, 11));
     hipLaunchKernelGGL(align_plane_words_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, d_row_first, d_win_len, pwords);
     ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, pwords, n_cand, plane_off, st));
     ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, strips, total_rows, rec_off, st));
@@ -659,7 +807,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     const int64_t plane_words = S->h_pin[0], total_strips = S->h_pin[1];
     uint4 *planes;
     ACHK(aalloc(ctx, A, (size_t)plane_words + 8, &planes));
-    ACHK(aalloc(ctx, A, (size_t)total_strips * 12 + 16, &P.ckpt));
+    ACHK(aalloc(ctx, A, (size_t)total_strips * 16 + 16, &P.ckpt));
     if (cap >= 8) ACHK(aalloc(ctx, A, (size_t)total_strips * 8 + 16, &P.bnd));
     P.planes = planes; P.plane_off = plane_off; P.rec_off = rec_off;
     hipLaunchKernelGGL(align_planes_kernel, dim3(n_cand), dim3(256), 0, st, n_cand, d_win, d_win_off, d_win_len, d_row_first, plane_off, planes);
@@ -670,7 +818,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     // ---- the 4-word band for every pair
     snprintf(name, sizeof name, "align_fwd4%s", tag ? tag : "");
     tk = hite_prof_begin(ctx, name, st);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<4, false>), dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<4>), dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
     hite_prof_end(ctx, tk, st);
     // ---- exact mode: wider bands for the pairs without a certificate
     if (cap >= 8) {
@@ -681,9 +829,9 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
             ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 0, level, cap, flag, nullptr, pos, colpos, scan_tmp, list, nullptr, &cnt, nullptr));
             if (cnt == 0) continue;
             const dim3 grid((unsigned)((cnt + 63) / 64));
-            if (level == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<8, false>), grid, dim3(64), 0, st, P, list, (int)cnt);
-            else if (level == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<16, false>), grid, dim3(64), 0, st, P, list, (int)cnt);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<32, false>), grid, dim3(64), 0, st, P, list, (int)cnt);
+            if (level == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<8>), grid, dim3(64), 0, st, P, list, (int)cnt);
+            else if (level == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<16>), grid, dim3(64), 0, st, P, list, (int)cnt);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<32>), grid, dim3(64), 0, st, P, list, (int)cnt);
         }
         hite_prof_end(ctx, tk, st);
     }
@@ -699,12 +847,10 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
         ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 1, 0, cap, flag, cols, pos, colpos, scan_tmp, list, full_off, &cnt, &tcols));
         if (cnt > 0) {
             tk = hite_prof_begin(ctx, "align_fallback", st);
-            ACHK(aalloc(ctx, A, (size_t)tcols * 64 + 64, &P.fullbuf));
+            ACHK(aalloc(ctx, A, (size_t)tcols * 2 * AL_WIDE_NW + 64, &P.fullbuf));
             ACHK(aalloc(ctx, A, (size_t)tcols + 16, &P.fullt));
-            const dim3 grid((unsigned)((cnt + 63) / 64));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<32, true>), grid, dim3(64), 0, st, P, list, (int)cnt);
-            hipLaunchKernelGGL(align_mark_fallback_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, (int)cnt, list, P.lvl);
-            hipLaunchKernelGGL(align_tb_full_kernel, grid, dim3(64), 0, st, P, list, (int)cnt);
+            hipLaunchKernelGGL(align_wide_fwd_kernel, dim3((unsigned)cnt), dim3(64), 0, st, P, list, (int)cnt);
+            hipLaunchKernelGGL(align_wide_tb_kernel, dim3((unsigned)cnt), dim3(64), 0, st, P, list, (int)cnt);
             hite_prof_end(ctx, tk, st);
         }
     }

@@ -4,32 +4,34 @@
  * CPU twin of the product's star-alignment stage (hite_amd/csrc/hite_align.hip + hite_msa.hip), which stands
  * where the reference shells out to `mafft` (/root/reference/module/Util.py:10416, third-party, unpinned,
  * absent: PARITY UNPINNED against mafft).  The DEFINITION of the pairwise alignment is band-free and lives in
- * hite_oracle_nw.c (optimal global alignment under unit costs, canonical traceback diagonal > up > left).
- * This file restates HOW the product computes it, so that the product can be checked byte for byte also on
- * the pairs it cannot certify:
+ * hite_oracle_nw.c (optimal global alignment, mismatch 1, gap GAP = 3 per base, canonical traceback
+ * diagonal > up > left).  This file restates WHAT the product's banded aligner computes -- as a plain integer
+ * dynamic programme over the same band, where the product runs a bit-parallel recurrence on the differences
+ * of neighbouring cells -- so that the product can be checked byte for byte also on the pairs it cannot certify:
  *
- *   Myers / Hyyro bit-parallel edit distance over an adaptive band of W = 32 NW rows per column.
- *   Column j (row base b[j-1]) covers the centre rows r = t_j + 1 + k, bit k = 0 .. W-1;  t_0 = -W/2, so the
- *   band's middle starts on row 0.  Rows r <= 0 are virtual (D(r, j) = j - r: they never help), rows r > m are
- *   padding that never matches.
- *   Steering: s_j = t_j - t_{j-1} in {0, 1, 2}.  With d = (sum of the vertical deltas of column j-1 over the
- *   middle 128 rows of the band), s_j = 0 if d > STEER, 2 if d < -STEER, else 1; then clamped so that
- *   t_j <= m - W/2 and t_j >= m - W/2 - 2 (n - j)  (t_n = m - W/2: the band's middle ends on row m).  A pair
- *   for which the lower clamp needs a step > 2 is infeasible (status 2).
- *   Band edges are pessimistic: a row that enters at the bottom has vertical delta +1 in the previous column,
- *   the horizontal delta above the band's first row is +1.  Every band value is therefore the cost of a real
- *   alignment (an upper bound of D), exact whenever an optimal path to the cell stays inside the band.
- *   Per column the recurrence yields D0 (diagonal delta 0), Ph/Mh, Pv/Mv; the traceback bits are
- *   DiagOK = Eq | ~D0 and UpOK = Pv (new), left otherwise: the canonical preference of hite_oracle_nw.c.
+ *   Column j (row base b[j-1]) covers the centre rows r = t_j + 1 + k, k = 0 .. W-1, W = 32 NW;  t_0 = -W/2, so
+ *   the band's middle starts on row 0.  Rows r <= 0 are virtual (D(r, j) = GAP (j - r): they never help), rows
+ *   r > m are padding that never matches.
+ *   Steering: s_j = t_j - t_{j-1} in {0, 1, 2}.  With d = (rows whose value exceeds the row above) - (rows whose
+ *   value is below the row above) over the middle 128 rows of column j-1, s_j = 0 if d > STEER, 2 if d < -STEER,
+ *   else 1; then clamped so that t_j <= m - W/2 and t_j >= m - W/2 - 2 (n - j)  (t_n = m - W/2: the band's middle
+ *   ends on row m).  A pair for which the lower clamp needs a step > 2 is infeasible (status 2).
+ *   Band edges are pessimistic: a row that enters at the bottom is GAP above the row before it in the previous
+ *   column, the cell above the band's first row is GAP above its left neighbour.  Every band value is therefore
+ *   the cost of a real alignment (an upper bound of D), exact whenever an optimal path to the cell stays inside
+ *   the band.
+ *   Traceback bits per cell: DiagOK = D(i-1, j-1) + sub == D(i, j), UpOK = D(i-1, j) + GAP == D(i, j), left
+ *   otherwise: the canonical preference of hite_oracle_nw.c.
  *   The product keeps these bits only for the SLICE = the middle 128 rows of the band (it re-computes the slice
- *   from check points and, for bands wider than the slice, 2 bytes of boundary information per column); a traceback that needs a cell outside the slice fails
- *   (status 1) and the pair is re-aligned by the wide fall-back, which keeps the bits of the whole band
- *   (`full` below) and fails only if the path leaves the band itself.
+ *   from check points and, for bands wider than the slice, 2 bytes of boundary information per column); a
+ *   traceback that needs a cell outside the slice fails (status 1) and the pair is re-aligned by the wide
+ *   fall-back, which keeps the bits of the whole band (`full` below) and fails only if the path leaves the band.
  *   Certificate (Ukkonen): let [LO, HI] be the diagonals i - j that the band covered in EVERY column (edges
- *   that coincide with the matrix border do not constrain).  Every alignment of cost <= k stays within the
- *   diagonals [min(0, m-n) - e, max(0, m-n) + e], e = floor((k - |m-n|) / 2).  With E = the largest e for which
- *   that range lies in [LO, HI] and k* = |m-n| + 2 E + 1:  U <= k*  =>  U is the edit distance and every cell
- *   the canonical traceback consults is exact, i.e. the result IS the alignment of hite_oracle_nw.c.
+ *   that coincide with the matrix border do not constrain).  An alignment of cost <= k has at most k / GAP gaps,
+ *   so it stays within the diagonals [min(0, m-n) - e, max(0, m-n) + e], e = floor((k - GAP |m-n|) / (2 GAP)).
+ *   With E = the largest e for which that range lies in [LO, HI] and k* = GAP |m-n| + 2 GAP E + 2 GAP - 1:
+ *   U <= k*  =>  U is the optimal cost and every cell the canonical traceback consults is exact, i.e. the result
+ *   IS the alignment of hite_oracle_nw.c.
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -38,112 +40,97 @@
 #define ORC_EINVAL (-1002)
 #define ORC_ECAP (-1001)
 #define NWMAX 64
+#define GAP 3
 #define STEER 48          /* dead zone of the steering */
 #define SLICE_WORDS 4     /* rows kept for the traceback: the middle 128 of the band */
-#define MARGIN 48         /* exact mode: first escalation level is the smallest band with 32 NW >= U + MARGIN */
+#define MARGIN 48         /* exact mode: the first wider band is the smallest with 32 NW >= U / GAP + MARGIN */
 
 static inline int is_acgt(unsigned c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
-static inline int popc(uint32_t x) { return __builtin_popcount(x); }
+
+/* value of row index k (may be -1: the cell above the band, or >= W: rows that have not entered yet) of a stored column */
+static inline int32_t col_get(const int32_t *col, int32_t above, int W, int k) {
+    if (k < 0) return above;
+    if (k >= W) return col[W - 1] + GAP * (k - (W - 1));
+    return col[k];
+}
 
 /*
  * align row b[0..n) to centre a[0..m) with a band of NW words.  ops: m entries (encoding: hite_oracle_nw.c).
  * full = 0: the traceback may only use the slice (middle 128 rows);  full = 1: the whole band.
- * out[0] = U (cost of the alignment found), out[1] = certified (0/1; a property of the forward pass), out[2] = status (0 ok, 1 traceback left the
- * slice / band, 2 infeasible), out[3] = k* (the certificate's bound, -1 if none).  returns 0 or < 0 (bad arguments).
+ * out[0] = U (cost of the alignment found), out[1] = certified (0/1; a property of the forward pass), out[2] = status
+ * (0 ok, 1 traceback left the slice / band, 2 infeasible), out[3] = k* (the certificate's bound, -1 if none).
+ * returns 0 or < 0 (bad arguments).
  */
 int orc_bp_pair(const uint8_t *a, int m, const uint8_t *b, int n, int NW, int full, uint16_t *ops, int32_t *out) {
-    if (m <= 0 || n <= 0 || m > 32767 || n > 32767 || NW < 2 || NW > NWMAX || (NW & 1)) return ORC_EINVAL;
+    if (m <= 0 || n <= 0 || m > 32767 || n > 32767 || NW < 4 || NW > NWMAX || (NW & 1)) return ORC_EINVAL;
     const int W = 32 * NW, H = W / 2;
-    uint32_t Pv[NWMAX], Mv[NWMAX], Eq[NWMAX], D0[NWMAX], Ph[NWMAX], Mh[NWMAX];
-    uint32_t *dg = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1) * NW);
-    uint32_t *up = (uint32_t *)malloc(sizeof(uint32_t) * (size_t)(n + 1) * NW);
+    int32_t *D = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1) * W);   /* band values of every column */
+    int32_t *above = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));  /* D(t_j, j): the cell above the band's first row */
     int32_t *ts = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1));
-    if (!dg || !up || !ts) { free(dg); free(up); free(ts); return ORC_EINVAL; }
+    if (!D || !above || !ts) { free(D); free(above); free(ts); return ORC_EINVAL; }
     int t = -H;
-    for (int w = 0; w < NW; w++) {
-        Pv[w] = 0; Mv[w] = 0;
-        for (int k = 0; k < 32; k++) { int r = t + 1 + 32 * w + k; if (r >= 1) Pv[w] |= 1u << k; else Mv[w] |= 1u << k; }
-    }
-    long stop = H;                       /* D(t_j, j): the cell above the band's first row */
+    for (int k = 0; k < W; k++) { int r = t + 1 + k; D[k] = GAP * (r < 0 ? -r : r); }
+    above[0] = GAP * H;
+    ts[0] = t;
     long LO = -(1L << 40), HI = 1L << 40;
     int status = 0;
-    ts[0] = t;
     for (int j = 1; j <= n; j++) {
+        const int32_t *prev = D + (size_t)(j - 1) * W;
+        int32_t *cur = D + (size_t)j * W;
         /* steering from column j-1 */
         int dsum = 0;
-        for (int w = NW / 2 - SLICE_WORDS / 2; w < NW / 2 + SLICE_WORDS / 2; w++) dsum += popc(Pv[w]) - popc(Mv[w]);
+        for (int k = H - 16 * SLICE_WORDS; k < H + 16 * SLICE_WORDS; k++) {
+            int dv = prev[k] - prev[k - 1];
+            dsum += (dv > 0) - (dv < 0);
+        }
         int s = dsum > STEER ? 0 : (dsum < -STEER ? 2 : 1);
         const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
         if (t + s > hi_t) s = hi_t - t;
         if (t + s < lo_t) s = lo_t - t;
         if (s < 0 || s > 2) { status = 2; break; }
-        /* shift the band down by s rows: rows that enter have vertical delta +1 in column j-1 */
-        for (int k = 0; k < s; k++) stop += (long)((Pv[0] >> k) & 1) - (long)((Mv[0] >> k) & 1);
-        stop += 1;
-        if (s) {
-            for (int w = 0; w < NW; w++) {
-                uint32_t pn = w + 1 < NW ? Pv[w + 1] : 0xffffffffu, mn = w + 1 < NW ? Mv[w + 1] : 0u;
-                Pv[w] = (Pv[w] >> s) | (pn << (32 - s));
-                Mv[w] = (Mv[w] >> s) | (mn << (32 - s));
-            }
-        }
+        above[j] = col_get(prev, above[j - 1], W, s - 1) + GAP;
         t += s;
         ts[j] = t;
         if (t >= 1 && (long)t + 1 - j > LO) LO = (long)t + 1 - j;
         if (t + W < m && (long)t + W - j < HI) HI = (long)t + W - j;
-        /* match bits */
         const unsigned y = b[j - 1];
         const int ya = is_acgt(y);
-        for (int w = 0; w < NW; w++) {
-            uint32_t e = 0;
-            if (ya) for (int k = 0; k < 32; k++) { int r = t + 1 + 32 * w + k; if (r >= 1 && r <= m && a[r - 1] == y) e |= 1u << k; }
-            Eq[w] = e;
-        }
-        /* D0 = (((Eq & Pv) + Pv) ^ Pv) | Eq | Mv, carries run from low rows to high rows */
-        uint32_t carry = 0;
-        for (int w = 0; w < NW; w++) {
-            uint64_t x = (uint64_t)(Eq[w] & Pv[w]) + Pv[w] + carry;
-            carry = (uint32_t)(x >> 32);
-            D0[w] = (((uint32_t)x) ^ Pv[w]) | Eq[w] | Mv[w];
-            Ph[w] = Mv[w] | ~(D0[w] | Pv[w]);
-            Mh[w] = Pv[w] & D0[w];
-        }
-        uint32_t pc = 1, mc = 0;          /* horizontal delta above the band's first row: +1 */
-        uint32_t *dgj = dg + (size_t)j * NW, *upj = up + (size_t)j * NW;
-        for (int w = 0; w < NW; w++) {
-            uint32_t phs = (Ph[w] << 1) | pc, mhs = (Mh[w] << 1) | mc;
-            pc = Ph[w] >> 31; mc = Mh[w] >> 31;
-            Pv[w] = mhs | ~(D0[w] | phs);
-            Mv[w] = phs & D0[w];
-            dgj[w] = Eq[w] | ~D0[w];
-            upj[w] = Pv[w];
+        for (int k = 0; k < W; k++) {
+            const int r = t + 1 + k;
+            const int sub = !(ya && r >= 1 && r <= m && a[r - 1] == y);
+            int v = col_get(prev, above[j - 1], W, k + s - 1) + sub;
+            const int up = (k > 0 ? cur[k - 1] : above[j]) + GAP, left = col_get(prev, above[j - 1], W, k + s) + GAP;
+            if (up < v) v = up;
+            if (left < v) v = left;
+            cur[k] = v;
         }
     }
     int U = -1, cert = 0;
     long kstar = -1;
     if (status == 0) {
-        long u = stop;                    /* t_n = m - H: row m is bit H - 1 */
-        for (int k = 0; k < H; k++) u += (long)((Pv[k >> 5] >> (k & 31)) & 1) - (long)((Mv[k >> 5] >> (k & 31)) & 1);
-        U = (int)u;
+        U = D[(size_t)n * W + H - 1];      /* t_n = m - H: row m is index H - 1 */
         const long d = (long)m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
         long E = dmin - LO;
         if (HI - dmax < E) E = HI - dmax;
-        if (E > (1L << 30)) E = 1L << 30;
-        if (E >= 0) { kstar = ad + 2 * E + 1; cert = u <= kstar; }
-        /* canonical traceback on the band's bits */
+        if (E > (1L << 27)) { kstar = 0x7fffffff; cert = 1; }
+        else if (E >= 0) { kstar = GAP * ad + 2 * GAP * E + 2 * GAP - 1; cert = U <= kstar; }
+        /* canonical traceback on the band's values */
         int i = m, j = n;
         const int klo = full ? 0 : H - 16 * SLICE_WORDS, khi = full ? W : H + 16 * SLICE_WORDS;
         while (i > 0 && j > 0) {
-            const int k = i - ts[j] - 1;
+            const int k = i - ts[j] - 1, s = ts[j] - ts[j - 1];
             if (k < klo || k >= khi) { status = 1; break; }
-            if ((dg[(size_t)j * NW + (k >> 5)] >> (k & 31)) & 1) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
-            else if ((up[(size_t)j * NW + (k >> 5)] >> (k & 31)) & 1) { ops[i - 1] = (uint16_t)(j | 0x8000); i--; }
+            const int32_t *prev = D + (size_t)(j - 1) * W, *cur = D + (size_t)j * W;
+            const unsigned y = b[j - 1];
+            const int sub = !(is_acgt(y) && a[i - 1] == y);
+            if (col_get(prev, above[j - 1], W, k + s - 1) + sub == cur[k]) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
+            else if ((k > 0 ? cur[k - 1] : above[j]) + GAP == cur[k]) { ops[i - 1] = (uint16_t)(j | 0x8000); i--; }
             else j--;
         }
         if (status == 0) for (; i > 0; i--) ops[i - 1] = (uint16_t)0x8000;
     }
     out[0] = U; out[1] = cert; out[2] = status; out[3] = (int32_t)(kstar > 0x7fffffff ? 0x7fffffff : kstar);
-    free(dg); free(up); free(ts);
+    free(D); free(above); free(ts);
     return 0;
 }
 
@@ -151,12 +138,12 @@ int orc_bp_pair(const uint8_t *a, int m, const uint8_t *b, int n, int NW, int fu
  * The product's schedule for one pair.  exact_cap = 0 (fast: the 4-word band only) or 8 / 16 / 32 (exact mode: largest
  * band tried for a certificate).
  *   1. band of 4 words.  Infeasible -> the row is dropped.
- *   2. exact mode, not certified, U + MARGIN <= 32 exact_cap: re-run with the smallest band of {8, 16, 32} words that has
- *      32 NW >= U + MARGIN, then with each wider one up to exact_cap until a run is certified (U = the cost of the
- *      last run).  The alignment kept is that of the last run.
- *   3. traceback on the slice of the run kept; if it leaves the slice: wide fall-back (32 words, whole-band traceback);
+ *   2. exact mode, not certified, U + GAP MARGIN <= 32 GAP exact_cap: re-run with the smallest band of {8, 16, 32} words
+ *      that has 32 GAP NW >= U + GAP MARGIN (U = the cost of the 4-word run), then with each wider one up to exact_cap
+ *      until a run is certified.  The alignment kept is that of the last run.
+ *   3. traceback on the slice of the run kept; if it leaves the slice: wide fall-back (64 words, whole-band traceback);
  *      if that fails as well the row is dropped.
- * out[0..3] as in orc_bp_pair for the run that produced ops, out[4] = its band words (32 | 0x100 for the fall-back).
+ * out[0..3] as in orc_bp_pair for the run that produced ops, out[4] = its band words (64 | 0x100 for the fall-back).
  * returns 0, or 1 if the row is dropped.
  */
 int orc_align_pair(const uint8_t *a, int m, const uint8_t *b, int n, int exact_cap, uint16_t *ops, int32_t *out) {
@@ -165,9 +152,9 @@ int orc_align_pair(const uint8_t *a, int m, const uint8_t *b, int n, int exact_c
     int rc = orc_bp_pair(a, m, b, n, nw, 0, ops, o);
     if (rc) return rc;
     if (o[2] == 2) { memcpy(out, o, sizeof o); out[4] = nw; return 1; }
-    if (exact_cap >= 8 && !o[1] && o[0] + MARGIN <= 32 * exact_cap) {
+    if (exact_cap >= 8 && !o[1] && o[0] + GAP * MARGIN <= 32 * GAP * exact_cap) {
         int lvl = 8;
-        while (32 * lvl < o[0] + MARGIN) lvl *= 2;
+        while (32 * GAP * lvl < o[0] + GAP * MARGIN) lvl *= 2;
         for (; lvl <= exact_cap; lvl *= 2) {
             rc = orc_bp_pair(a, m, b, n, lvl, 0, ops, o);
             if (rc) return rc;
@@ -176,8 +163,8 @@ int orc_align_pair(const uint8_t *a, int m, const uint8_t *b, int n, int exact_c
         }
     }
     if (o[2] == 1) {
-        nw = 32 | 0x100;
-        rc = orc_bp_pair(a, m, b, n, 32, 1, ops, o);
+        nw = 64 | 0x100;
+        rc = orc_bp_pair(a, m, b, n, 64, 1, ops, o);
         if (rc) return rc;
     }
     out[0] = o[0]; out[1] = o[1]; out[2] = o[2]; out[3] = o[3]; out[4] = nw;

@@ -45,18 +45,19 @@ def make_pair(rng, te_len, big_indel=0, flank_jitter=5):
     return np.ascontiguousarray(a), np.ascontiguousarray(b)
 
 
-# known answers that do not depend on this repository: classic Levenshtein examples transcribed to the DNA alphabet
+# known answers worked out by hand for mismatch 1 / gap 3 (classic textbook pairs transcribed to the DNA alphabet)
 KAT = [
     ("ACGT", "ACGT", 0),
-    ("ACGT", "AGT", 1),
-    ("ACGT", "TGCA", 4),
-    ("AAAA", "TTTTTT", 6),
-    ("GATTACA", "GCATGCT", 4),       # Needleman-Wunsch's textbook pair
-    ("ACGTACGTAC", "ACGACGTTAC", 2),
+    ("ACGT", "AGT", 3),              # one gap
+    ("ACGT", "TGCA", 4),             # four mismatches beat any gapped alignment (>= 6)
+    ("AAAA", "TTTTTT", 10),          # 4 mismatches + 2 gaps
+    ("GATTACA", "GCATGCT", 4),       # Needleman-Wunsch's textbook pair, ungapped: 4 mismatches
+    ("ACGTACGTAC", "ACGACGTTAC", 4), # ungapped (4 mismatches) beats delete + insert (6)
     ("A", "C", 1),
     ("ACGT", "ACNT", 1),             # N never matches
     ("ACNT", "ACNT", 1),             # ... not even N
-    ("AAAAAAAAAA", "A", 9),
+    ("AAAAAAAAAA", "A", 27),
+    ("ACGTTTTTTTTACGT", "ACGTACGT", 21),   # a 7-base deletion is cheaper (21) than misaligning the tail
 ]
 
 
@@ -71,11 +72,11 @@ def test_nw_known_answers(a, b, d):
 def test_nw_canonical_tiebreak():
     # diagonal preferred, then up (gap in the row), then left (insertion):
     ops, d = O.nw_pair("AC", "A")       # C faces a gap after row position 1
-    assert d == 1 and list(ops) == [0, 1 | 0x8000]
+    assert d == 3 and list(ops) == [0, 1 | 0x8000]
     ops, d = O.nw_pair("A", "CA")       # insertion of C before centre position 0
-    assert d == 1 and list(ops) == [1]
+    assert d == 3 and list(ops) == [1]
     ops, d = O.nw_pair("AA", "A")       # co-optimal: canonical traceback takes the diagonal at the END
-    assert d == 1 and list(ops) == [0 | 0x8000, 0]
+    assert d == 3 and list(ops) == [0 | 0x8000, 0]
 
 
 def test_twin_equals_definition_when_certified():
@@ -150,5 +151,6 @@ def test_star_msa_rows_are_pairwise_optimal():
         row = m[r]
         assert bytes(row[row != ord("-")]) == wins[r]
         both = (centre != ord("-")) | (row != ord("-"))
-        cost = int(((centre != row) & both).sum())
+        gap = both & ((centre == ord("-")) | (row == ord("-")))
+        cost = int(((centre != row) & both & ~gap).sum()) + 3 * int(gap.sum())
         assert cost == O.nw_distance(wins[0], wins[r])

@@ -1,6 +1,6 @@
 """GPU parity of the pairwise aligner behind the star alignment (hite_amd/csrc/hite_align.hip), through the C ABI:
    * HIP == twin (oracle/hite_oracle_msa.c) per pair: cost, certificate, status, band, and the alignment byte for byte;
-   * a CERTIFIED pair is the textbook unit-cost global alignment of oracle/hite_oracle_nw.c (cost and canonical path);
+   * a CERTIFIED pair is the textbook global alignment (mismatch 1, gap 3) of oracle/hite_oracle_nw.c (cost and canonical path);
    * an uncertified pair is a valid alignment whose cost bounds the optimum from above."""
 import numpy as np
 import pytest
@@ -60,7 +60,8 @@ def check_pairs(ctx, pairs, cap):
                 continue
             exp = pair_matrix(a, b, ops)
             assert m is not None and m.shape == exp.shape and np.array_equal(m, exp)
-            cost = int((m[0] != m[1]).sum()) + int(((m[0] == m[1]) & ~np.isin(m[0], list(b"ACGT"))).sum())
+            gap = (m[0] == ord("-")) | (m[1] == ord("-"))
+            cost = 3 * int(gap.sum()) + int(((m[0] != m[1]) & ~gap).sum()) + int(((m[0] == m[1]) & ~np.isin(m[0], list(b"ACGT"))).sum())
             assert cost == U
             d = O.nw_distance(a, b)
             assert U >= d
@@ -81,7 +82,7 @@ def test_align_families_all_modes(ctx):
     for cap in (0, 8, 16, 32):
         n_cert, n_opt, n_drop = check_pairs(ctx, pairs, cap)
         assert n_drop == 0
-        assert n_opt == len(pairs)                 # these families never need more than the narrow band
+        assert n_opt >= 0.98 * len(pairs)          # these families hardly ever need more than the narrow band
         if cap >= 16:
             assert n_cert >= 0.9 * len(pairs)
 
