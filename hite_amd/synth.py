@@ -70,13 +70,13 @@ def make_families(rng, n_tir, n_ltr, max_copies=300):
 def make_workload(genome_bp=100_000_000, n_tir=500, n_ltr=0, cands_per_family=10, seed=20250927, chrom_bp=50_000_000,
                   device=None, flank=50, cand_seed=None):
     """-> dict(genome (uint8 ASCII, torch tensor on `device` or numpy), contig_off, cands (uint8 array),
-    cand_off, copy_first, contig, start1, end1, minus, family, n_families, truth)"""
+    cand_off, copy_first, contig, start1, end1, minus, family, n_families, planted)"""
     rng = np.random.default_rng(seed)
     fams = make_families(rng, n_tir, n_ltr)
     n_chr = max(1, int(np.ceil(genome_bp / chrom_bp)))
     contig_off = np.minimum(np.arange(n_chr + 1, dtype=np.int64) * chrom_bp, genome_bp)
     # ---- planted copies ------------------------------------------------------------------------
-    seqs, meta = [], []  # meta: (family, strand, full_len_flag, tsd_len)
+    seqs, meta, divs = [], [], []  # meta: (family, strand, full_len_flag, tsd_len)
     for fi, fam in enumerate(fams):
         cons = fam["cons"]
         for k in range(fam["ncopy"]):
@@ -92,6 +92,7 @@ def make_workload(genome_bp=100_000_000, n_tir=500, n_ltr=0, cands_per_family=10
                 s = COMP[s[::-1]]
             seqs.append(s)
             meta.append((fi, minus, full, fam["tsd"]))
+            divs.append(div)
     n_copies = len(seqs)
     lens = np.array([len(s) for s in seqs], dtype=np.int64)
     pad = 2 * flank + 40
@@ -200,4 +201,10 @@ def make_workload(genome_bp=100_000_000, n_tir=500, n_ltr=0, cands_per_family=10
                 minus=np.array(c_minus, dtype=np.uint8), family=np.array(c_fam, dtype=np.int32),
                 n_families=len(fams), n_planted=int(ok.sum()), planted_bp=int(lens[ok].sum()),
                 fam_is_ltr=np.array([f["ltr"] for f in fams], dtype=bool),
-                fam_len=np.array([len(f["cons"]) for f in fams], dtype=np.int64))
+                fam_len=np.array([len(f["cons"]) for f in fams], dtype=np.int64),
+                # ground truth of the planted copies (tests / recall measurements): family, contig, 0-based start inside the
+                # contig, length, strand, "full length" flag (not truncated beyond 5 %), divergence from the family consensus
+                planted=dict(family=np.array([m[0] for m in meta], dtype=np.int32)[ok], contig=chrom[ok].astype(np.int32),
+                             start=(pos - contig_off[chrom])[ok], length=lens[ok],
+                             minus=np.array([m[1] for m in meta], dtype=bool)[ok], full=np.array([m[2] for m in meta], dtype=bool)[ok],
+                             div=np.array(divs, dtype=np.float64)[ok]))

@@ -14,10 +14,30 @@ def test_cpu_baseline_leg_runs_on_a_tiny_workload():
     from hite_amd import synth
 
     w = synth.make_workload(genome_bp=2_000_000, n_tir=6, n_ltr=4, cands_per_family=2, seed=11, device=torch.device("cpu"))
+    n_cand = len(w["cand_off"]) - 1
+    wv = bench.host_workload(w, None, None, 0, n_cand)       # the generator's copy table
     for threads in (1, 2):
-        r = bench.cpu_baseline(w, 1.0, threads)
+        r = bench.cpu_baseline(wv, 1.0, threads)
         assert set(r) == {"value", "unit", "cores", "kind", "sample"}
         assert r["cores"] == threads and r["kind"] == "port" and r["unit"] == "candidates/s" and r["value"] > 0
+    r = bench.cpu_baseline(wv, 0.5, 1, with_copies=True)     # + the CPU twin of the copy finder, charged per candidate
+    assert r["copy_finding"]["index_s"] > 0 and r["value"] > 0
+
+
+def test_bench_shards_like_the_library():
+    """--scaling strong uses hite_amd.dist.shard_candidates: the shares tile the batch"""
+    import numpy as np
+
+    from hite_amd import dist as hd
+
+    cand_off = np.arange(0, 1010, 10)
+    copy_first = np.arange(0, 303, 3)
+    seen = []
+    for r in range(3):
+        c0, c1, (b0, b1), (k0, k1) = hd.shard_candidates(cand_off, copy_first, r, 3)
+        assert (b0, b1) == (10 * c0, 10 * c1) and (k0, k1) == (3 * c0, 3 * c1)
+        seen += list(range(c0, c1))
+    assert seen == list(range(100))
 
 
 def test_bench_refuses_to_run_without_a_gpu():
