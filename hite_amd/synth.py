@@ -163,7 +163,7 @@ def make_workload(genome_bp=100_000_000, n_tir=500, n_ltr=0, cands_per_family=10
         if ok[i] and full:
             by_fam.setdefault(fi, []).append(i)
     cand_chunks, cand_len, copy_first = [], [], [0]
-    c_contig, c_s1, c_e1, c_minus, c_fam = [], [], [], [], []
+    c_contig, c_s1, c_e1, c_minus, c_fam, c_div = [], [], [], [], [], []
     rc_lut = np.zeros(256, dtype=np.uint8)
     rc_lut[:] = ord("N")
     for a, b in zip(b"ACGT", b"TGCA"):
@@ -192,6 +192,7 @@ def make_workload(genome_bp=100_000_000, n_tir=500, n_ltr=0, cands_per_family=10
                 c_minus.append(1 if meta[j][1] else 0)
             copy_first.append(len(c_contig))
             c_fam.append(fi)
+            c_div.append(divs[i])
     cand_off = np.zeros(len(cand_len) + 1, dtype=np.int64)
     np.cumsum(cand_len, out=cand_off[1:])
     cands = np.concatenate(cand_chunks) if cand_chunks else np.zeros(0, np.uint8)
@@ -199,6 +200,8 @@ def make_workload(genome_bp=100_000_000, n_tir=500, n_ltr=0, cands_per_family=10
                 copy_first=np.array(copy_first, dtype=np.int32), contig=np.array(c_contig, dtype=np.int32),
                 start1=np.array(c_s1, dtype=np.int64), end1=np.array(c_e1, dtype=np.int64),
                 minus=np.array(c_minus, dtype=np.uint8), family=np.array(c_fam, dtype=np.int32),
+                cand_div=np.array(c_div, dtype=np.float64),   # divergence of the copy each candidate was cut from
+               
                 n_families=len(fams), n_planted=int(ok.sum()), planted_bp=int(lens[ok].sum()),
                 fam_is_ltr=np.array([f["ltr"] for f in fams], dtype=bool),
                 fam_len=np.array([len(f["cons"]) for f in fams], dtype=np.int64),

@@ -1,0 +1,225 @@
+"""Full-size GPU tests on the generator of the bench (hite_amd/synth.py): BASELINE.json config C2 (100 Mbp, 500 TIR families,
+~5k candidates) through coarse + fine, and config C3 (1 Gbp, 2.5k TIR + 2.5k LTR families, 50k candidates) through the fine
+stage.  Parity: random candidates re-judged by the oracle chain (tests/oracle_pipeline.py) on the copy table the GPU found.
+Ground truth (the planted copies): recall / precision of the copy finder, recovery of the families by the coarse stage,
+boundaries of the TE calls -- thresholds set from the measured values of round 2 (noted beside each assert)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+
+def run_fine(mbp, n_tir, n_ltr, seed):
+    import torch
+
+    import hite_amd
+    from hite_amd import synth
+    from hite_amd._lib import CALL_DTYPE
+
+    dev = torch.device("cuda", 0)
+    w = synth.make_workload(genome_bp=mbp * 1_000_000, n_tir=n_tir, n_ltr=n_ltr, cands_per_family=10, seed=seed, device=dev)
+    ctx = hite_amd.Context(0)
+    ctx.genome_pack_dev(w["genome"].data_ptr(), w["contig_off"])
+    ctx.copy_index_build()
+    n = len(w["cand_off"]) - 1
+    nbytes = int(w["cand_off"][-1])
+    d_cand = torch.from_numpy(np.concatenate([w["cands"], np.zeros(64, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(w["cand_off"])).to(dev)
+    d_calls = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+    cap = nbytes + 200 * n + 4096
+    d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
+    ctx.align_stats(reset=True)
+    nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
+    stats = ctx.flank_region_align_dev("tir", 1, n, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
+                                       d_calls.data_ptr(), d_cons.data_ptr(), cap)
+    torch.cuda.synchronize()
+    found = dict(copy_first=ctx.download(p_cf, n + 1, np.int32), contig=ctx.download(p_ct, nc, np.int32),
+                 start1=ctx.download(p_s1, nc, np.int64), end1=ctx.download(p_e1, nc, np.int64), minus=ctx.download(p_mn, nc, np.uint8))
+    return dict(w=w, ctx=ctx, n=n, calls=d_calls.cpu().numpy().view(CALL_DTYPE).copy(), cons=d_cons.cpu().numpy(), found=found,
+                stats=stats, align=ctx.align_stats(), genome=w["genome"].cpu().numpy(), seed=seed, n_tir=n_tir, n_ltr=n_ltr)
+
+
+def oracle_check(R, count, seed):
+    """re-judge `count` random candidates with the oracle chain on the copy table the GPU found"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_pipeline as OP
+
+    w, f = R["w"], R["found"]
+    co = w["contig_off"]
+    contigs = {ci: R["genome"][co[ci]:co[ci + 1]].tobytes() for ci in range(len(co) - 1)}
+    info_names = {0: "", 1: "nb", 2: "fl1", 3: "EXC"}
+    bad = []
+    n_te = 0
+    for c in np.random.default_rng(seed).permutation(R["n"])[:count]:
+        a, b = int(f["copy_first"][c]), int(f["copy_first"][c + 1])
+        copies = [(int(f["contig"][i]), int(f["start1"][i]), int(f["end1"][i]), int(f["minus"][i])) for i in range(a, b)]
+        cand = w["cands"][w["cand_off"][c]:w["cand_off"][c + 1]].tobytes().decode()
+        exp = OP.fine_stage_candidate("tir", cand, copies, contigs, plant=1)
+        r = R["calls"][c]
+        got = [bool(r["is_te"]), info_names[int(r["info"])],
+               R["cons"][r["cons_off"]:r["cons_off"] + r["cons_len"]].tobytes().decode() if r["is_te"] else "", int(r["row_num"])]
+        n_te += got[0]
+        if got != exp:
+            bad.append(int(c))
+    return bad, n_te
+
+
+def _find(hay, needle, maxmm=3):
+    """offset of the best occurrence of needle in hay with <= maxmm mismatches, or None"""
+    k = len(needle)
+    if len(hay) < k:
+        return None
+    win = np.lib.stride_tricks.sliding_window_view(hay, k)
+    mm = (win != needle).sum(axis=1)
+    o = int(np.argmin(mm))
+    return o if mm[o] <= maxmm else None
+
+
+def boundary_stats(R, limit=4000):
+    """TE calls on candidates of TIR families: how far the ends of the consensus are from the ends of the planted element.
+    -> (TIR candidates, judged TE, checked, both ends exact, both ends within 3 bp)"""
+    from hite_amd import synth
+
+    fams = synth.make_families(np.random.default_rng(R["seed"]), R["n_tir"], R["n_ltr"])
+    w = R["w"]
+    tir_cand = ~w["fam_is_ltr"][w["family"]]
+    calls = R["calls"]
+    idx = np.flatnonzero(tir_cand & (calls["is_te"] != 0))
+    called = len(idx)
+    exact = near = checked = 0
+    for c in idx[:limit]:
+        r = calls[c]
+        cons = R["cons"][r["cons_off"]:r["cons_off"] + r["cons_len"]]
+        ref = ASCII[fams[int(w["family"][c])]["cons"]]
+        if len(cons) < 40 or len(ref) < 100:
+            continue
+        checked += 1
+        so = _find(ref[:60], cons[:16])               # consensus starts `so` bases inside the element ...
+        if so is None:
+            o2 = _find(cons[:60], ref[:16])           # ... or -so bases before it
+            so = -o2 if o2 is not None else None
+        eo = _find(ref[-60:][::-1], cons[-16:][::-1])
+        if eo is None:
+            o2 = _find(cons[-60:][::-1], ref[-16:][::-1])
+            eo = -o2 if o2 is not None else None
+        if so is None or eo is None:
+            continue
+        exact += so == 0 and eo == 0
+        near += abs(so) <= 3 and abs(eo) <= 3
+    return int(tir_cand.sum()), called, checked, exact, near
+
+
+def copy_recall_precision(R, sample=1500):
+    w, f, p = R["w"], R["found"], R["w"]["planted"]
+    rng = np.random.default_rng(5)
+    order = np.argsort(p["family"], kind="stable")
+    fam_sorted = p["family"][order]
+    tot_truth = hit_truth = tot_found = ok_found = near_truth = near_hit = 0
+    for c in rng.permutation(R["n"])[:sample]:
+        fam = int(w["family"][c])
+        lo, hi = np.searchsorted(fam_sorted, [fam, fam + 1])
+        idx = order[lo:hi]
+        a, b = int(f["copy_first"][c]), int(f["copy_first"][c + 1])
+        fc, fs, fe, fm = f["contig"][a:b], f["start1"][a:b] - 1, f["end1"][a:b], f["minus"][a:b].astype(bool)
+        matched_found = np.zeros(b - a, dtype=bool)
+        for i in idx:
+            s, e = int(p["start"][i]), int(p["start"][i] + p["length"][i])
+            ov = np.minimum(fe, e) - np.maximum(fs, s)
+            m = (fc == p["contig"][i]) & (fm == p["minus"][i]) & (ov >= 0.8 * (e - s))
+            if p["full"][i]:
+                tot_truth += 1
+                hit_truth += bool(m.any())
+                if w["cand_div"][c] + p["div"][i] <= 0.15:      # pairs within 15 % of each other
+                    near_truth += 1
+                    near_hit += bool(m.any())
+            matched_found |= (fc == p["contig"][i]) & (ov >= 0.5 * np.minimum(fe - fs, e - s))
+        tot_found += b - a
+        ok_found += int(matched_found.sum())
+    return hit_truth / max(1, tot_truth), ok_found / max(1, tot_found), tot_truth, tot_found, near_hit / max(1, near_truth), near_truth
+
+
+@pytest.fixture(scope="module")
+def c2():
+    R = run_fine(100, 500, 0, 20250927 + 2)
+    yield R
+    R["ctx"].close()
+
+
+def test_c2_fine_stage_matches_oracle_chain(c2):
+    bad, n_te = oracle_check(c2, 200, 1)
+    assert bad == [] and n_te >= 60
+    st = c2["align"]
+    assert st["dropped"] == 0 and st["pairs"] > 50_000
+    assert st["certified"] >= 0.85 * st["pairs"]            # measured r02: 0.96 (exact_cap 16)
+
+
+def test_c2_copy_finder_recall_precision(c2):
+    recall, precision, n_truth, n_found, near_recall, n_near = copy_recall_precision(c2)
+    print("copy finder: recall %.4f of %d planted full-length copies (%.4f of the %d within 15 %% of the candidate), precision %.4f of %d copies found"
+          % (recall, n_truth, near_recall, n_near, precision, n_found))
+    assert n_truth > 10_000 and n_found > 10_000 and n_near > 3_000
+    assert near_recall >= 0.78                              # measured r02: 0.833 (profiles/r02_scale_tests.txt)
+    assert recall >= 0.57                                   # measured r02: 0.622 over all pairs, up to 30 % apart: (w=10, k=15) minimizers lose the far ones
+    assert precision >= 0.97
+
+
+def test_c2_te_calls_have_the_planted_boundaries(c2):
+    n_tir_cand, called, checked, exact, near = boundary_stats(c2)
+    print("fine stage: %d TIR candidates (boundaries off by up to 30 bp on input), %d judged TE; of %d checked: both ends exact %d, within 3 bp %d"
+          % (n_tir_cand, called, checked, exact, near))
+    assert called >= 0.50 * n_tir_cand                      # measured r02: 0.585
+    assert exact >= 0.40 * checked and near >= 0.65 * checked   # measured r02: 0.48 / 0.74 (judge_boundary_v5's own TSD / homology choices)
+
+
+def test_c2_coarse_stage_recovers_the_families(c2):
+    """stage 3.1 on the same genome (all-vs-all seeding + FMEA, GPU): planted families with >= 3 full copies come out as intervals"""
+    w, ctx, p = c2["w"], c2["ctx"], c2["w"]["planted"]
+    sc, so = ctx.seed_segments(1_000_000)
+    (oc, os_, oe), st = ctx.coarse_stage_dev(1_000_000, sc, so, 2000, 30000)
+    assert len(oc) > 1000
+    key = oc.astype(np.int64) << 40
+    order = np.argsort(key + os_)
+    oc, os_, oe = oc[order], os_[order], oe[order]
+    skey = key[order] + os_
+    rec = {}
+    for i in np.flatnonzero(p["full"]):
+        fam = int(p["family"][i])
+        s, e = int(p["start"][i]), int(p["start"][i] + p["length"][i])
+        k = (int(p["contig"][i]) << 40)
+        lo = np.searchsorted(skey, k + max(0, s - 30000))
+        hi = np.searchsorted(skey, k + e)
+        hit = False
+        for q in range(lo, hi):
+            ov = min(int(oe[q]), e) - max(int(os_[q]) - 1, s)
+            if ov >= 0.8 * (e - s) and (int(oe[q]) - int(os_[q])) <= 1.5 * (e - s) + 100:
+                hit = True
+                break
+        a, b = rec.get(fam, (0, 0))
+        rec[fam] = (a + 1, b + hit)
+    multi = [f for f, (a, _b) in rec.items() if a >= 3]
+    got = sum(1 for f in multi if rec[f][1] >= 1)
+    print("coarse stage: %d intervals; %d of %d families with >= 3 full copies recovered" % (len(oc), got, len(multi)))
+    assert len(multi) >= 400 and got >= 0.95 * len(multi)   # measured r02: 489 of 489
+
+
+def test_c3_fine_stage_matches_oracle_chain():
+    R = run_fine(1000, 2500, 2500, 20250927 + 3)
+    try:
+        bad, n_te = oracle_check(R, 200, 2)
+        assert bad == [] and n_te >= 60
+        n_tir_cand, called, checked, exact, near = boundary_stats(R)
+        print("C3: %d TIR candidates, %d judged TE; of %d checked: both ends exact %d, within 3 bp %d; %d TE calls in all" %
+              (n_tir_cand, called, checked, exact, near, int((R["calls"]["is_te"] != 0).sum())))
+        assert called >= 0.50 * n_tir_cand and exact >= 0.40 * checked and near >= 0.65 * checked
+        st = R["align"]
+        assert st["dropped"] == 0 and st["certified"] >= 0.8 * st["pairs"]
+    finally:
+        R["ctx"].close()
