@@ -213,7 +213,7 @@ class Context:
     # ---- star alignment (stage where the reference calls mafft) -------------------------------
     def align_config(self, exact_cap):
         """exact_cap: 0 = fast (band of 128 centre rows only); 8 / 16 / 32 = widest band (x 32 rows) tried for an optimality
-        certificate (default 16 or $HITE_ALIGN_EXACT)"""
+        certificate (default 8 or $HITE_ALIGN_EXACT)"""
         self._check(self.lib.hite_align_config(self.h, int(exact_cap)), "hite_align_config")
 
     def align_stats(self, reset=False):

@@ -17,10 +17,10 @@
 //   * steering (the band follows the valley of the cost surface), pessimistic band edges and the Ukkonen
 //     certificate are described in the twin's header.  A certified pair IS the alignment of the definition.
 //   * no per-cell direction is ever written to HBM.  The forward pass keeps, per strip of 16 columns, a check point of
-//     the SLICE (the middle 128 rows of the band: 64 B) and, when the band is wider than the slice, 2 B per column of
+//     the SLICE (the middle 64 rows of the band: 32 B) and 2 B per column of
 //     boundary information (the step of the band, the bits that enter the slice from the rest of the band).  The
 //     traceback pass (align_tb_kernel) re-computes the slice strip by strip into registers and walks it backwards:
-//     4-6 B of HBM traffic per column instead of 2 bits per DP cell.
+//     4 B of HBM traffic per column instead of 2 bits per DP cell.
 //   * schedule per pair (hite_align_run): band of 4 words; in exact mode a pair that is not certified is re-run with
 //     8 / 16 / 32 words until it is; a traceback that leaves the slice falls back to a 64-word band computed by one
 //     wavefront per pair, whose traceback bits are kept whole (rare: an insertion / deletion longer than about 60 bases);
@@ -32,11 +32,12 @@
 #include "hite_align.h"
 
 #define AL_GAP 3
-#define AL_STEER 48
+#define AL_STEER 24
 #define AL_MARGIN 48
 #define AL_PADR 1056         // virtual rows above row 1 in the centre planes (33 words: covers t_0 = -1024 of the fall-back band)
 #define AL_WIDE_NW 64         // words of the fall-back band (one per lane of a wavefront)
 #define AL_STRIP 16
+#define AL_DEFAULT_CAP 8      // exact mode: widest band (words) tried for a certificate unless configured otherwise
 #define AL_KBINS 2048        // strips per pair <= 32767 / 16 + 1
 
 struct AlignArgs {
@@ -49,8 +50,8 @@ struct AlignArgs {
     const uint4 *planes;        // per candidate, per 32 centre rows: (plane0, plane1, planeN, 0)
     const int64_t *plane_off;   // n_cand
     const int64_t *rec_off;     // per row: index of its first strip record
-    uint32_t *ckpt;             // 16 words per strip: the three planes of the slice (4 words each), t of the slice, 3 spare
-    uint32_t *bnd;              // 8 words per strip (bands wider than the slice)
+    uint32_t *ckpt;             // 8 words per strip: the three planes of the slice (2 words each), t of the slice, 1 spare
+    uint32_t *bnd;              // 8 words per strip: 16 bits per column
     int32_t *U, *kst, *st, *lvl, *U4;   // per row: cost, certificate bound, status, band words of the run kept, cost of the 4-word run
     const int64_t *ops_base;
     uint16_t *ops;
@@ -171,7 +172,7 @@ __global__ void __launch_bounds__(256) align_planes_kernel(int n_cand, const uin
 // ---------------------------------------------------------------------------------------------
 template <int NW>
 __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
-    constexpr int W = 32 * NW, H = W / 2, S0 = NW / 2 - 2;
+    constexpr int W = 32 * NW, H = W / 2, S0 = NW / 2 - 1;
     const int li = blockIdx.x * 64 + threadIdx.x;
     const int g = li < nlist ? list[li] : -1;
     int m = 0, n = 0, g0 = 0, c = 0;
@@ -205,11 +206,9 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
         uint32_t f0 = 0, f1 = 0, fn = 0;   // the next 32 rows below the band, per plane
         uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (sa) {
-            uint4 *ck = reinterpret_cast<uint4 *>(P.ckpt + (rec0 + k) * 16);
-            ck[0] = make_uint4(X2[S0], X2[S0 + 1], X2[S0 + 2], X2[S0 + 3]);
-            ck[1] = make_uint4(X1[S0], X1[S0 + 1], X1[S0 + 2], X1[S0 + 3]);
-            ck[2] = make_uint4(X0[S0], X0[S0 + 1], X0[S0 + 2], X0[S0 + 3]);
-            ck[3] = make_uint4((uint32_t)(t + 32 * S0), 0u, 0u, 0u);
+            uint4 *ck = reinterpret_cast<uint4 *>(P.ckpt + (rec0 + k) * 8);
+            ck[0] = make_uint4(X2[S0], X2[S0 + 1], X1[S0], X1[S0 + 1]);
+            ck[1] = make_uint4(X0[S0], X0[S0 + 1], (uint32_t)(t + 32 * S0), 0u);
             bw = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
             const int fx = t + W + AL_PADR;
             const uint4 F = pl[fx >> 5], G = pl[(fx >> 5) + 1];
@@ -220,10 +219,8 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
         for (int cc = 0; cc < AL_STRIP; cc++) {
             const int j = k * AL_STRIP + cc + 1;
             if (sa && j <= n) {
-                // ---- steering from column j-1 (middle 128 rows), clamps
-                int ds = 0;
-#pragma unroll
-                for (int w = S0; w < S0 + 4; w++) ds += slope_count(X2[w], X1[w], X0[w]);
+                // ---- steering from column j-1 (middle 64 rows), clamps
+                const int ds = slope_count(X2[S0], X1[S0], X0[S0]) + slope_count(X2[S0 + 1], X1[S0 + 1], X0[S0 + 1]);
                 int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
                 const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
                 if (t + s > hi_t) s = hi_t - t;
@@ -231,7 +228,7 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
                 if ((unsigned)s > 2u) { status = 2; act = false; s = 1; }
                 stop += plane_sum(X2[0], X1[0], X0[0], (1u << s) - 1u) - AL_GAP * s + AL_GAP;
                 uint32_t in2 = 0, in1 = 0, in0 = 0;
-                if (NW > 4) { in2 = X2[S0 + 4 < NW ? S0 + 4 : 0] & 3u; in1 = X1[S0 + 4 < NW ? S0 + 4 : 0] & 3u; in0 = X0[S0 + 4 < NW ? S0 + 4 : 0] & 3u; }
+                if (NW > 2) { in2 = X2[S0 + 2 < NW ? S0 + 2 : 0] & 3u; in1 = X1[S0 + 2 < NW ? S0 + 2 : 0] & 3u; in0 = X0[S0 + 2 < NW ? S0 + 2 : 0] & 3u; }
                 // ---- the band moves down by s rows (rows that enter: +3)
 #pragma unroll
                 for (int w = 0; w < NW - 1; w++) {
@@ -253,15 +250,15 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
                 const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
                 const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
                 uint32_t tap[5] = {0, 0, 1, 1, 0};
-                bp_core<NW, false, (NW > 4 ? S0 : -1)>(X2, X1, X0, A0, A1, AN, bm, 0u, 0u, 1u, 1u, 0u, nullptr, nullptr, tap);
-                if (NW > 4) {
+                bp_core<NW, false, (NW > 2 ? S0 : -1)>(X2, X1, X0, A0, A1, AN, bm, 0u, 0u, 1u, 1u, 0u, nullptr, nullptr, tap);
+                if (NW > 2) {
                     const uint32_t r16 = (uint32_t)s | (in2 << 2) | (in1 << 4) | (in0 << 6) | (tap[0] << 8) | (tap[1] << 9) | (tap[2] << 10) |
                                          (tap[3] << 11) | (tap[4] << 12);
                     brec[cc >> 1] |= r16 << (16 * (cc & 1));
                 }
             }
         }
-        if (NW > 4 && sa) {
+        if (NW > 2 && sa) {
             uint4 *bp = reinterpret_cast<uint4 *>(P.bnd + (rec0 + k) * 8);
             bp[0] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
             bp[1] = make_uint4(brec[4], brec[5], brec[6], brec[7]);
@@ -288,6 +285,27 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
 // ---------------------------------------------------------------------------------------------
 // traceback pass: re-compute the slice strip by strip (registers), walk it backwards
 // ---------------------------------------------------------------------------------------------
+// ops leave the traceback in descending positions, one at a time and per lane: a lane collects four of them in a 64-bit
+// shift register and stores 8 bytes at a time (2-byte stores from 64 lanes to 64 different lines were the kernel's bound)
+struct OpsOut {
+    uint16_t *ops;
+    unsigned long long acc;
+    int cnt;
+    __device__ __forceinline__ void push(int pos, uint32_t val) {
+        acc = (acc << 16) | (unsigned long long)(val & 0xffffu);
+        cnt++;
+        if ((pos & 3) == 0) {
+            if (cnt == 4) *reinterpret_cast<unsigned long long *>(ops + pos) = acc;     // (unaligned 8-byte store: fine for global memory)
+            else for (int x = 0; x < cnt; x++) ops[pos + x] = (uint16_t)(acc >> (16 * x));
+            cnt = 0;
+        }
+    }
+    __device__ __forceinline__ void flush(int next_pos) {   // next_pos = the position that would have been pushed next (pos - 1)
+        for (int x = 0; x < cnt; x++) ops[next_pos + 1 + x] = (uint16_t)(acc >> (16 * x));
+        cnt = 0;
+    }
+};
+
 __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
     const int li = blockIdx.x * 64 + threadIdx.x;
     const int g = li < nlist ? list[li] : -1;
@@ -296,7 +314,7 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     if (g >= 0) {
         c = P.row_cand[g];
         g0 = P.row_first[c];
-        if (g != g0 && P.st[g] == 0) { m = P.win_len[g0]; n = P.win_len[g]; hb = P.lvl[g] > 4; }
+        if (g != g0 && P.st[g] == 0) { m = P.win_len[g0]; n = P.win_len[g]; hb = P.lvl[g] > 2; }
     }
     const int nmax = wave_max_i32(n);
     if (nmax == 0) return;
@@ -306,22 +324,22 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     uint16_t *ops = P.ops + (g >= 0 ? P.ops_base[c] + (int64_t)(g - g0) * (m + 1) : 0);
     int i = m, j = n;
     bool fail = false;
+    OpsOut out;
+    out.ops = ops; out.acc = 0ull; out.cnt = 0;
     const int Kmax = (nmax + AL_STRIP - 1) / AL_STRIP;
     for (int k = Kmax - 1; k >= 0; k--) {
         const bool sa = n > 0 && !fail && i > 0 && k * AL_STRIP < n;
         if (!__any(sa)) continue;
-        uint32_t X2[4], X1[4], X0[4], A0[4], A1[4], AN[4];
+        uint32_t X2[2], X1[2], X0[2], A0[2], A1[2], AN[2];
         uint32_t f0 = 0, f1 = 0, fn = 0;
         uint4 bw = make_uint4(0, 0, 0, 0);
         uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int t = 0;
         if (sa) {
-            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k) * 16);
-            const uint4 c2 = ck[0], c1 = ck[1], c0 = ck[2], c3 = ck[3];
-            X2[0] = c2.x; X2[1] = c2.y; X2[2] = c2.z; X2[3] = c2.w;
-            X1[0] = c1.x; X1[1] = c1.y; X1[2] = c1.z; X1[3] = c1.w;
-            X0[0] = c0.x; X0[1] = c0.y; X0[2] = c0.z; X0[3] = c0.w;
-            t = (int)c3.x;
+            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k) * 8);
+            const uint4 c0 = ck[0], c1 = ck[1];
+            X2[0] = c0.x; X2[1] = c0.y; X1[0] = c0.z; X1[1] = c0.w; X0[0] = c1.x; X0[1] = c1.y;
+            t = (int)c1.z;
             bw = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
             if (hb) {
                 const uint4 *bp = reinterpret_cast<const uint4 *>(P.bnd + (rec0 + k) * 8);
@@ -332,26 +350,25 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
             const int x0 = t + AL_PADR;
             const int q0 = x0 >> 5;
             const uint32_t sh = (uint32_t)x0 & 31u;
-            uint4 wd[6];
+            uint4 wd[4];
 #pragma unroll
-            for (int w = 0; w < 6; w++) wd[w] = pl[q0 + w];
+            for (int w = 0; w < 4; w++) wd[w] = pl[q0 + w];
 #pragma unroll
-            for (int w = 0; w < 4; w++) {
+            for (int w = 0; w < 2; w++) {
                 A0[w] = alignbit(wd[w + 1].x, wd[w].x, sh); A1[w] = alignbit(wd[w + 1].y, wd[w].y, sh);
                 AN[w] = alignbit(wd[w + 1].z, wd[w].z, sh);
             }
-            f0 = alignbit(wd[5].x, wd[4].x, sh); f1 = alignbit(wd[5].y, wd[4].y, sh); fn = alignbit(wd[5].z, wd[4].z, sh);
+            f0 = alignbit(wd[3].x, wd[2].x, sh); f1 = alignbit(wd[3].y, wd[2].y, sh); fn = alignbit(wd[3].z, wd[2].z, sh);
         } else {
 #pragma unroll
-            for (int w = 0; w < 4; w++) { X2[w] = 0; X1[w] = 0; X0[w] = 0; A0[w] = 0; A1[w] = 0; AN[w] = 0; }
+            for (int w = 0; w < 2; w++) { X2[w] = 0; X1[w] = 0; X0[w] = 0; A0[w] = 0; A1[w] = 0; AN[w] = 0; }
         }
-        uint32_t dg[AL_STRIP][4], up[AL_STRIP][4];
+        unsigned long long dg[AL_STRIP], up[AL_STRIP];
         uint32_t sbits = 0;
 #pragma unroll
         for (int cc = 0; cc < AL_STRIP; cc++) {
             const int jc = k * AL_STRIP + cc + 1;
-#pragma unroll
-            for (int w = 0; w < 4; w++) { dg[cc][w] = 0; up[cc][w] = 0; }
+            dg[cc] = 0ull; up[cc] = 0ull;
             if (sa && jc <= n) {
                 const uint32_t r16 = (brec[cc >> 1] >> (16 * (cc & 1))) & 0xffffu;
                 int s;
@@ -359,71 +376,51 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
                 if (hb) {
                     s = (int)(r16 & 3u); in2 = (r16 >> 2) & 3u; in1 = (r16 >> 4) & 3u; in0 = (r16 >> 6) & 3u;
                     cin = (r16 >> 8) & 1u; vpc = (r16 >> 9) & 1u; h2c = (r16 >> 10) & 1u; h1c = (r16 >> 11) & 1u; h0c = (r16 >> 12) & 1u;
-                } else {   // the 4-word band IS the slice: same steering as the forward pass
-                    int ds = 0;
-#pragma unroll
-                    for (int w = 0; w < 4; w++) ds += slope_count(X2[w], X1[w], X0[w]);
+                } else {   // a 2-word band IS the slice: same steering as the forward pass
+                    const int ds = slope_count(X2[0], X1[0], X0[0]) + slope_count(X2[1], X1[1], X0[1]);
                     s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
-                    const int hi_t = m - 64, lo_t = m - 64 - 2 * (n - jc);
+                    const int hi_t = m - 32, lo_t = m - 32 - 2 * (n - jc);
                     if (t + s > hi_t) s = hi_t - t;
                     if (t + s < lo_t) s = lo_t - t;
                     in2 = 3u; in1 = 3u; in0 = 0u; cin = 0u; vpc = 0u; h2c = 1u; h1c = 1u; h0c = 0u;
                 }
-#pragma unroll
-                for (int w = 0; w < 3; w++) {
-                    X2[w] = alignbit(X2[w + 1], X2[w], (uint32_t)s); X1[w] = alignbit(X1[w + 1], X1[w], (uint32_t)s);
-                    X0[w] = alignbit(X0[w + 1], X0[w], (uint32_t)s);
-                    A0[w] = alignbit(A0[w + 1], A0[w], (uint32_t)s); A1[w] = alignbit(A1[w + 1], A1[w], (uint32_t)s);
-                    AN[w] = alignbit(AN[w + 1], AN[w], (uint32_t)s);
-                }
-                X2[3] = alignbit(in2, X2[3], (uint32_t)s); X1[3] = alignbit(in1, X1[3], (uint32_t)s); X0[3] = alignbit(in0, X0[3], (uint32_t)s);
-                A0[3] = alignbit(f0, A0[3], (uint32_t)s); A1[3] = alignbit(f1, A1[3], (uint32_t)s); AN[3] = alignbit(fn, AN[3], (uint32_t)s);
+                X2[0] = alignbit(X2[1], X2[0], (uint32_t)s); X1[0] = alignbit(X1[1], X1[0], (uint32_t)s); X0[0] = alignbit(X0[1], X0[0], (uint32_t)s);
+                A0[0] = alignbit(A0[1], A0[0], (uint32_t)s); A1[0] = alignbit(A1[1], A1[0], (uint32_t)s); AN[0] = alignbit(AN[1], AN[0], (uint32_t)s);
+                X2[1] = alignbit(in2, X2[1], (uint32_t)s); X1[1] = alignbit(in1, X1[1], (uint32_t)s); X0[1] = alignbit(in0, X0[1], (uint32_t)s);
+                A0[1] = alignbit(f0, A0[1], (uint32_t)s); A1[1] = alignbit(f1, A1[1], (uint32_t)s); AN[1] = alignbit(fn, AN[1], (uint32_t)s);
                 f0 >>= s; f1 >>= s; fn >>= s;
                 t += s;
                 sbits |= (uint32_t)s << (2 * cc);
                 const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
                 const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
-                uint32_t tap[5], dgc[4], upc[4];
-                bp_core<4, true, -1>(X2, X1, X0, A0, A1, AN, bm, cin, vpc, h2c, h1c, h0c, dgc, upc, tap);
-#pragma unroll
-                for (int w = 0; w < 4; w++) { dg[cc][w] = dgc[w]; up[cc][w] = upc[w]; }
+                uint32_t tap[5], dgc[2], upc[2];
+                bp_core<2, true, -1>(X2, X1, X0, A0, A1, AN, bm, cin, vpc, h2c, h1c, h0c, dgc, upc, tap);
+                dg[cc] = ((unsigned long long)dgc[1] << 32) | dgc[0];
+                up[cc] = ((unsigned long long)upc[1] << 32) | upc[0];
             }
         }
         // walk: every path step leaves column j for column j-1 (diagonal, left) or stays in it (up).  A run of up steps ends at
-        // the highest row at or above the current one where the diagonal is allowed or up is not: found with bit operations on
-        // the column's 128 slice bits, so that the register arrays are only ever indexed by constants.
+        // the highest row at or above the current one where the diagonal is allowed or up is not: one count of leading zeros
+        // on the column's 64 slice bits, so that the register arrays are only ever indexed by constants.
         int tcur = t;
 #pragma unroll
         for (int cc = AL_STRIP - 1; cc >= 0; cc--) {
             const int jc = k * AL_STRIP + cc + 1;
             if (sa && !fail && i > 0 && j == jc) {
                 const int kb = i - tcur - 1;
-                if ((unsigned)kb >= 128u) fail = true;
+                if ((unsigned)kb >= 64u) fail = true;
                 else {
-                    const int wq = kb >> 5;
-                    const uint32_t low = 0xffffffffu >> (31 - (kb & 31));      // bits 0 .. kb & 31
-                    const uint32_t s0 = dg[cc][0] | ~up[cc][0], s1 = dg[cc][1] | ~up[cc][1], s2 = dg[cc][2] | ~up[cc][2],
-                                   s3 = dg[cc][3] | ~up[cc][3];
-                    const uint32_t m3 = wq == 3 ? s3 & low : 0u;
-                    const uint32_t m2 = wq > 2 ? s2 : (wq == 2 ? s2 & low : 0u);
-                    const uint32_t m1 = wq > 1 ? s1 : (wq == 1 ? s1 & low : 0u);
-                    const uint32_t m0 = wq > 0 ? s0 : s0 & low;
-                    int ps;
-                    uint32_t dsel;
-                    if (m3) { ps = 127 - __clz(m3); dsel = dg[cc][3]; }
-                    else if (m2) { ps = 95 - __clz(m2); dsel = dg[cc][2]; }
-                    else if (m1) { ps = 63 - __clz(m1); dsel = dg[cc][1]; }
-                    else if (m0) { ps = 31 - __clz(m0); dsel = dg[cc][0]; }
-                    else { ps = -1; dsel = 0; }
-                    if (ps < 0) fail = true;      // the run of up steps leaves the slice at its first row
+                    const unsigned long long stopm = (dg[cc] | ~up[cc]) & (0xffffffffffffffffull >> (63 - kb));   // bits 0 .. kb
+                    if (stopm == 0ull) fail = true;      // the run of up steps leaves the slice at its first row
                     else {
+                        const int ps = 63 - __clzll(stopm);
                         int ups = kb - ps;
-                        if (ups > i) ups = i;     // (cannot happen: row 0 stops every run)
-                        const uint16_t gapv = (uint16_t)(j | 0x8000);
-                        for (int x = 0; x < ups; x++) ops[i - 1 - x] = gapv;
+                        if (ups > i) ups = i;            // (cannot happen: row 0 stops every run)
+                        const uint32_t gapv = (uint32_t)j | 0x8000u;
+                        for (int x = 0; x < ups; x++) out.push(i - 1 - x, gapv);
                         i -= ups;
                         if (i > 0) {
-                            if ((dsel >> (ps & 31)) & 1u) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
+                            if ((dg[cc] >> ps) & 1ull) { out.push(i - 1, (uint32_t)(j - 1)); i--; j--; }
                             else j--;
                         }
                     }
@@ -434,7 +431,10 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     }
     if (n > 0) {
         if (fail) P.st[g] = 1;
-        else for (int q = i - 1; q >= 0; q--) ops[q] = (uint16_t)0x8000;
+        else {
+            for (int q = i - 1; q >= 0; q--) out.push(q, 0x8000u);
+            out.flush(-1);
+        }
     }
 }
 
@@ -452,7 +452,7 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 }
 
 __global__ void __launch_bounds__(64) align_wide_fwd_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
-    constexpr int NW = AL_WIDE_NW, W = 32 * NW, H = W / 2, S0 = NW / 2 - 2;
+    constexpr int NW = AL_WIDE_NW, W = 32 * NW, H = W / 2, S0 = NW / 2 - 1;
     const int pi = blockIdx.x;
     if (pi >= nlist) return;
     const int lane = threadIdx.x;
@@ -480,8 +480,7 @@ __global__ void __launch_bounds__(64) align_wide_fwd_kernel(AlignArgs P, const i
             f0 = alignbit(G.x, F.x, sh); f1 = alignbit(G.y, F.y, sh); fn = alignbit(G.z, F.z, sh);
         }
         const int dv = slope_count(X2, X1, X0);
-        const int ds = __builtin_amdgcn_readlane(dv, S0) + __builtin_amdgcn_readlane(dv, S0 + 1) + __builtin_amdgcn_readlane(dv, S0 + 2) +
-                       __builtin_amdgcn_readlane(dv, S0 + 3);
+        const int ds = __builtin_amdgcn_readlane(dv, S0) + __builtin_amdgcn_readlane(dv, S0 + 1);
         int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
         const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
         if (t + s > hi_t) s = hi_t - t;
@@ -677,8 +676,8 @@ static AlignState *align_state(hite_ctx *ctx) {
             return nullptr;
         }
         const char *e = getenv("HITE_ALIGN_EXACT");
-        int cap = e && *e ? atoi(e) : 16;
-        if (cap != 0 && cap != 8 && cap != 16 && cap != 32) cap = 16;
+        int cap = e && *e ? atoi(e) : AL_DEFAULT_CAP;
+        if (cap != 0 && cap != 8 && cap != 16 && cap != 32) cap = AL_DEFAULT_CAP;
         S->exact_cap = cap;
         ctx->align_state = S;
     }
@@ -807,8 +806,8 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     const int64_t plane_words = S->h_pin[0], total_strips = S->h_pin[1];
     uint4 *planes;
     ACHK(aalloc(ctx, A, (size_t)plane_words + 8, &planes));
-    ACHK(aalloc(ctx, A, (size_t)total_strips * 16 + 16, &P.ckpt));
-    if (cap >= 8) ACHK(aalloc(ctx, A, (size_t)total_strips * 8 + 16, &P.bnd));
+    ACHK(aalloc(ctx, A, (size_t)total_strips * 8 + 16, &P.ckpt));
+    ACHK(aalloc(ctx, A, (size_t)total_strips * 8 + 16, &P.bnd));
     P.planes = planes; P.plane_off = plane_off; P.rec_off = rec_off;
     hipLaunchKernelGGL(align_planes_kernel, dim3(n_cand), dim3(256), 0, st, n_cand, d_win, d_win_off, d_win_len, d_row_first, plane_off, planes);
     hite_prof_end(ctx, tk, st);

@@ -274,7 +274,7 @@ int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8
  * bit-parallel aligner that CERTIFIES its result (twin: oracle/hite_oracle_msa.c, byte-exact): a certified row is the
  * alignment of the definition, a row without certificate is a valid alignment whose cost bounds the optimum from above.
  * hite_align_config: exact_cap = 0 (fast: band of 128 centre rows only), 8 / 16 / 32 = widest band (x 32 rows) that
- * is tried to obtain a certificate (default 16, or the environment variable HITE_ALIGN_EXACT).
+ * is tried to obtain a certificate (default 8, or the environment variable HITE_ALIGN_EXACT).
  * hite_align_stats: out8 = pairs, certified, kept from a band wider than 128 rows, wide fall-backs, rows dropped,
  * sum of the costs, sum of the row lengths (columns), exact_cap -- accumulated over the calls since the last reset.
  * windows of candidate c = rows row_first[c] .. row_first[c+1]-1 of the CSR (win, win_off);

@@ -13,7 +13,7 @@
  *   the band's middle starts on row 0.  Rows r <= 0 are virtual (D(r, j) = GAP (j - r): they never help), rows
  *   r > m are padding that never matches.
  *   Steering: s_j = t_j - t_{j-1} in {0, 1, 2}.  With d = (rows whose value exceeds the row above) - (rows whose
- *   value is below the row above) over the middle 128 rows of column j-1, s_j = 0 if d > STEER, 2 if d < -STEER,
+ *   value is below the row above) over the middle 64 rows of column j-1, s_j = 0 if d > STEER, 2 if d < -STEER,
  *   else 1; then clamped so that t_j <= m - W/2 and t_j >= m - W/2 - 2 (n - j)  (t_n = m - W/2: the band's middle
  *   ends on row m).  A pair for which the lower clamp needs a step > 2 is infeasible (status 2).
  *   Band edges are pessimistic: a row that enters at the bottom is GAP above the row before it in the previous
@@ -22,8 +22,8 @@
  *   the band.
  *   Traceback bits per cell: DiagOK = D(i-1, j-1) + sub == D(i, j), UpOK = D(i-1, j) + GAP == D(i, j), left
  *   otherwise: the canonical preference of hite_oracle_nw.c.
- *   The product keeps these bits only for the SLICE = the middle 128 rows of the band (it re-computes the slice
- *   from check points and, for bands wider than the slice, 2 bytes of boundary information per column); a
+ *   The product keeps these bits only for the SLICE = the middle 64 rows of the band (it re-computes the slice
+ *   from check points and 2 bytes of boundary information per column); a
  *   traceback that needs a cell outside the slice fails (status 1) and the pair is re-aligned by the wide
  *   fall-back, which keeps the bits of the whole band (`full` below) and fails only if the path leaves the band.
  *   Certificate (Ukkonen): let [LO, HI] be the diagonals i - j that the band covered in EVERY column (edges
@@ -41,8 +41,8 @@
 #define ORC_ECAP (-1001)
 #define NWMAX 64
 #define GAP 3
-#define STEER 48          /* dead zone of the steering */
-#define SLICE_WORDS 4     /* rows kept for the traceback: the middle 128 of the band */
+#define STEER 24          /* dead zone of the steering */
+#define SLICE_WORDS 2     /* rows kept for the traceback (and watched by the steering): the middle 64 of the band */
 #define MARGIN 48         /* exact mode: the first wider band is the smallest with 32 NW >= U / GAP + MARGIN */
 
 static inline int is_acgt(unsigned c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
@@ -56,7 +56,7 @@ static inline int32_t col_get(const int32_t *col, int32_t above, int W, int k) {
 
 /*
  * align row b[0..n) to centre a[0..m) with a band of NW words.  ops: m entries (encoding: hite_oracle_nw.c).
- * full = 0: the traceback may only use the slice (middle 128 rows);  full = 1: the whole band.
+ * full = 0: the traceback may only use the slice (middle 64 rows);  full = 1: the whole band.
  * out[0] = U (cost of the alignment found), out[1] = certified (0/1; a property of the forward pass), out[2] = status
  * (0 ok, 1 traceback left the slice / band, 2 infeasible), out[3] = k* (the certificate's bound, -1 if none).
  * returns 0 or < 0 (bad arguments).
@@ -171,7 +171,7 @@ int orc_align_pair(const uint8_t *a, int m, const uint8_t *b, int n, int exact_c
     return o[2] != 0;
 }
 
-static int g_exact = 16;   /* the product's default (hite_align.hip: HITE_ALIGN_EXACT) */
+static int g_exact = 8;    /* the product's default (hite_align.hip: AL_DEFAULT_CAP / HITE_ALIGN_EXACT) */
 void orc_msa_set_exact(int v) { g_exact = v; }
 int orc_msa_get_exact(void) { return g_exact; }
 

@@ -251,7 +251,7 @@ def bp_pair(a, b, nw=4, full=False):
     return ops[:len(a)], dict(U=int(out[0]), cert=int(out[1]), status=int(out[2]), kstar=int(out[3]))
 
 
-def align_pair(a, b, exact_cap=16):
+def align_pair(a, b, exact_cap=8):
     """the product's schedule for one pair: -> (ops or None if the row is dropped, dict(U, cert, status, kstar, nw))"""
     a, b = _seq(a), _seq(b)
     ops = np.zeros(len(a) + 1, dtype=np.uint16)

@@ -73,7 +73,7 @@ def check_pairs(ctx, pairs, cap):
         return n_cert, n_opt, n_drop
     finally:
         O.set_align_exact(prev)
-        ctx.align_config(16)
+        ctx.align_config(8)
 
 
 def test_align_families_all_modes(ctx):
@@ -139,5 +139,6 @@ def test_align_stats_counters(ctx):
     ctx.align_config(16)
     ctx.star_msa([[bytes(a), bytes(b)] for a, b in pairs])
     st = ctx.align_stats()
+    ctx.align_config(8)
     assert st["pairs"] == 40 and st["dropped"] == 0 and st["exact_cap"] == 16      # two calls (sizes + fill)
     assert st["certified"] >= 36 and st["columns"] == 2 * sum(len(b) for _, b in pairs)

@@ -1,0 +1,60 @@
+#!/usr/bin/env python
+"""Per-kernel SQ counters of one rocprofv3 PMC pass -> profiles/r02_sq_counters.json (+ a text table).
+usage: pmc_counters.py <rocprof_out_dir> <bench_json_of_the_same_run> <out_json> <out_txt> [header]
+The bench line of the profiled run gives the steps of the run (timed + untimed) and the pair-columns per step, so that the
+json can state wave-level vector instructions per step and per pair-column for every alignment kernel; bench.py reads it."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from pmc_traffic import per_kernel  # noqa: E402
+
+COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_INSTS_VMEM"]
+STAGE = {"align_fwd_kernel<4>": "align_fwd4", "align_fwd_kernel<8>": "align_fwd_wide8", "align_fwd_kernel<16>": "align_fwd_wide16",
+         "align_fwd_kernel<32>": "align_fwd_wide32", "align_tb_kernel": "align_tb", "align_wide_fwd_kernel": "align_fallback_fwd",
+         "align_wide_tb_kernel": "align_fallback_tb", "align_planes_kernel": "align_prep_planes"}
+
+
+def main():
+    d, bj, oj, ot = sys.argv[1:5]
+    hdr = sys.argv[5] if len(sys.argv) > 5 else ""
+    bench = json.loads([ln for ln in open(bj) if ln.startswith("{")][-1])
+    steps_run = bench["steps"] + bench["warmup"] + 2      # bench.py makes two residency calls before the warm-up
+    cols = bench["config"]["align_stats_per_step"]["columns"]
+    tab = {c: per_kernel(d, c) for c in COUNTERS}
+    kernels = sorted({k for c in tab.values() for k in c})
+    res = {"_columns_per_step": cols, "_steps_in_profiled_run": steps_run, "_command": hdr}
+    lines = []
+    for k in kernels:
+        row = {c: tab[c].get(k, (0.0, 0))[0] for c in COUNTERS}
+        launches = max(tab[c].get(k, (0.0, 0))[1] for c in COUNTERS)
+        name = k
+        for pat, st in STAGE.items():
+            if pat.split("<")[0] in k and (("<" not in pat) or pat.split("<")[1].rstrip(">") + ">" in k.replace(" ", "").replace("(int)", "") or pat in k):
+                name = st
+        if not any(row.values()):
+            continue
+        e = res.setdefault(name, {"launches": 0, "valu_inst_per_step": 0.0, "salu_inst_per_step": 0.0, "wave_quad_cycles_per_step": 0.0,
+                                  "active_valu_quad_cycles_per_step": 0.0})
+        e["launches"] += launches
+        e["valu_inst_per_step"] += row["SQ_INSTS_VALU"] / steps_run
+        e["salu_inst_per_step"] += row["SQ_INSTS_SALU"] / steps_run
+        e["wave_quad_cycles_per_step"] += row["SQ_WAVE_CYCLES"] / steps_run
+        e["active_valu_quad_cycles_per_step"] += row["SQ_ACTIVE_INST_VALU"] / steps_run
+        lines.append((k, launches, row))
+    for name, e in res.items():
+        if isinstance(e, dict) and name.startswith("align_"):
+            e["valu_inst_per_pair_column"] = e["valu_inst_per_step"] / cols if cols else None
+    json.dump(res, open(oj, "w"), indent=1, sort_keys=True)
+    with open(ot, "w") as o:
+        if hdr:
+            o.write("# " + hdr + "\n")
+        o.write("# sums over the launches of the run (%d pipeline steps, %d pair-columns per step); SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* count quad-cycles\n" % (steps_run, cols))
+        o.write("%-44s %8s " % ("kernel", "launches") + " ".join("%18s" % c for c in COUNTERS) + "\n")
+        for k, launches, row in sorted(lines, key=lambda x: -x[2]["SQ_INSTS_VALU"])[:40]:
+            o.write("%-44s %8d " % (k[:44], launches) + " ".join("%18d" % int(row[c]) for c in COUNTERS) + "\n")
+
+
+if __name__ == "__main__":
+    main()

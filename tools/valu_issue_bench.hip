@@ -21,11 +21,12 @@
     __global__ void __launch_bounds__(256) NAME(uint32_t *out, uint32_t seed) {                       \
         uint32_t a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
         uint32_t k = seed | 1u, s = seed & 3u;                                                        \
+        asm volatile("s_mov_b32 s20, 0x55555555\n\ts_mov_b32 s21, 0x55555555\n\ts_mov_b64 vcc, s[20:21]" ::: "s20", "s21", "vcc");                  \
         for (int it = 0; it < ITER; it++) {                                                           \
             asm volatile(BLOCK64(OP)                                                                  \
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
                          : "v"(k), "v"(s)                                                             \
-                         : "vcc");                                                                    \
+                         : "vcc", "s20", "s21");                                                                    \
         }                                                                                             \
         out[blockIdx.x * blockDim.x + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;           \
     }
@@ -45,6 +46,16 @@
 #define OP_MOV_DPP_WSHR(R) "v_mov_b32_dpp " R ", " R " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
 #define OP_CNDMASK(R) "v_cndmask_b32 " R ", " R ", %8, vcc\n\t"
 #define OP_LSHLADD(R) "v_lshl_add_u32 " R ", " R ", 1, %8\n\t"
+#define OP_CNDMASK64(R) "v_cndmask_b32_e64 " R ", " R ", %8, s[20:21]\n\t"
+#define OP_CMP_CND(R) "v_cmp_lt_u32_e32 vcc, " R ", %8\n\tv_cndmask_b32_e32 " R ", " R ", %9, vcc\n\t"
+#define OP_BFE(R) "v_bfe_u32 " R ", " R ", 1, 31\n\t"
+#define OP_AND(R) "v_and_b32 " R ", " R ", %8\n\t"
+#define OP_OR(R) "v_or_b32 " R ", " R ", %8\n\t"
+#define OP_NOT(R) "v_not_b32 " R ", " R "\n\t"
+#define OP_BITOP3(R) "v_bitop3_b32 " R ", " R ", %8, %9 bitop3:0x96\n\t"
+#define OP_LSHR(R) "v_lshrrev_b32 " R ", 1, " R "\n\t"
+#define OP_MIN(R) "v_min_i32 " R ", " R ", %8\n\t"
+#define OP_SUB(R) "v_sub_u32 " R ", " R ", %8\n\t"
 
 KERNEL(k_add, OP_ADD)
 KERNEL(k_xor, OP_XOR)
@@ -61,6 +72,16 @@ KERNEL(k_add_dpp, OP_ADD_DPP)
 KERNEL(k_mov_dpp_wshr, OP_MOV_DPP_WSHR)
 KERNEL(k_cndmask, OP_CNDMASK)
 KERNEL(k_lshladd, OP_LSHLADD)
+KERNEL(k_cndmask64, OP_CNDMASK64)
+KERNEL(k_cmp_cnd, OP_CMP_CND)
+KERNEL(k_bfe, OP_BFE)
+KERNEL(k_and, OP_AND)
+KERNEL(k_or, OP_OR)
+KERNEL(k_not, OP_NOT)
+KERNEL(k_bitop3, OP_BITOP3)
+KERNEL(k_lshr, OP_LSHR)
+KERNEL(k_min, OP_MIN)
+KERNEL(k_sub, OP_SUB)
 
 typedef void (*kfn)(uint32_t *, uint32_t);
 struct Entry { const char *name; kfn fn; };
@@ -75,7 +96,9 @@ int main() {
     Entry tab[] = {{"v_add_u32", k_add}, {"v_xor_b32", k_xor}, {"v_or3_b32", k_or3}, {"v_and_or_b32", k_andor}, {"v_alignbit_b32", k_alignbit},
                    {"v_lshlrev_b32", k_lshl}, {"v_bcnt_u32_b32", k_bcnt}, {"v_perm_b32", k_perm}, {"v_max3_i32", k_max3}, {"v_bfi_b32", k_bfi},
                    {"v_addc_co_u32", k_addc}, {"v_add_u32_dpp row", k_add_dpp}, {"v_mov_dpp wave_shr", k_mov_dpp_wshr}, {"v_cndmask_b32", k_cndmask},
-                   {"v_lshl_add_u32", k_lshladd}};
+                   {"v_lshl_add_u32", k_lshladd}, {"v_cndmask_e64 sgpr", k_cndmask64}, {"v_cmp+v_cndmask (2)", k_cmp_cnd},
+                   {"v_bfe_u32", k_bfe}, {"v_and_b32", k_and}, {"v_or_b32", k_or}, {"v_not_b32", k_not}, {"v_bitop3_b32", k_bitop3},
+                   {"v_lshrrev_b32", k_lshr}, {"v_min_i32", k_min}, {"v_sub_u32", k_sub}};
     uint32_t *out;
     if (hipMalloc(&out, (size_t)cus * 8 * 256 * 4 * 4) != hipSuccess) return 1;
     hipEvent_t e0, e1;
