@@ -279,11 +279,17 @@ class Context:
         mn = _arr([t[3] for t in flat], np.uint8)
         calls = np.zeros(n, dtype=CALL_DTYPE)
         cap = int(coff[-1]) + (2 * flank + 64) * n + 4096
-        cons = np.zeros(cap + 16, dtype=np.uint8)
         stats = np.zeros(12, dtype=np.int64)
-        self._check(self.lib.hite_flank_region_align(self.h, HITE_TE[te_type], int(plant), n, _p(cbuf), _p(coff), _p(cf),
-                                                     C.c_int64(len(flat)), _p(contig), _p(s1), _p(e1), _p(mn), int(flank),
-                                                     _p(calls), _p(cons), C.c_int64(cap), _p(stats)), "hite_flank_region_align")
+        for _attempt in range(2):
+            cons = np.zeros(cap + 16, dtype=np.uint8)
+            rc = self.lib.hite_flank_region_align(self.h, HITE_TE[te_type], int(plant), n, _p(cbuf), _p(coff), _p(cf),
+                                                  C.c_int64(len(flat)), _p(contig), _p(s1), _p(e1), _p(mn), int(flank),
+                                                  _p(calls), _p(cons), C.c_int64(cap), _p(stats))
+            if rc == -4 and stats[10] > cap:     # HITE_ECAP: the consensus pool was too small; stats[10] says how much is needed
+                cap = int(stats[10]) + 4096
+                continue
+            break
+        self._check(rc, "hite_flank_region_align")
         out = []
         for i in range(n):
             c = calls[i]
@@ -353,11 +359,18 @@ class Context:
         return oc[:k].copy(), os_[:k].copy(), oe[:k].copy()
 
     # ---- copy finding (stage where the reference calls minimap2, Util.py:7933) ---------------------------
+    FIND_COPIES_BATCH = 1 << 18
+
     def find_copies(self, cands):
         """-> per candidate list of (contig, start1, end1, minus, anchors); needs genome_pack() first"""
         if getattr(self, "_copy_state", None) is None:
             self._copy_state = C.c_void_p(None)
         cb = [c.encode() if isinstance(c, str) else bytes(c) for c in cands]
+        if len(cb) > self.FIND_COPIES_BATCH:    # one device call handles < 2^19 candidates: larger libraries go in batches
+            out = []
+            for k in range(0, len(cb), self.FIND_COPIES_BATCH):
+                out += self.find_copies(cb[k:k + self.FIND_COPIES_BATCH])
+            return out
         n = len(cb)
         off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum([len(c) for c in cb], out=off[1:])

@@ -501,6 +501,18 @@ static int read_back(hite_ctx *ctx, CopyState *S, hipStream_t st, int count) {
 }
 
 // builds the minimizer index of the packed genome; *state_io receives the index handle
+// device temporaries of a host-side function: freed on every return path
+struct DevTmp {
+    void *p[8];
+    int n = 0;
+    ~DevTmp() { for (int i = 0; i < n; i++) if (p[i]) (void)hipFree(p[i]); }
+    hipError_t alloc(void **out, size_t bytes) {
+        hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+        if (e == hipSuccess && n < 8) p[n++] = *out;
+        return e;
+    }
+};
+
 extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream) {
     if (!ctx || !ctx->d_bases || !state_io) return HITE_EINVAL;
     if (ctx->n_bases >= 0xfffe0000ll) return HITE_EINVAL;  // positions are 32-bit
@@ -523,8 +535,9 @@ extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *strea
     unsigned long long cap = (unsigned long long)(G * 0.32) + 4096;
     unsigned long long *keys = nullptr;
     unsigned *vals = nullptr;
-    HITE_CHECK(ctx, hipMalloc((void **)&keys, cap * 8));
-    HITE_CHECK(ctx, hipMalloc((void **)&vals, cap * 4));
+    DevTmp tmp;
+    HITE_CHECK(ctx, tmp.alloc((void **)&keys, cap * 8));
+    HITE_CHECK(ctx, tmp.alloc((void **)&vals, cap * 4));
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
     int64_t blocks = (G + GM_TILE - 1) / GM_TILE; if (blocks > 256 * 64) blocks = 256 * 64;
     hipLaunchKernelGGL(genome_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
@@ -532,27 +545,26 @@ extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *strea
     HITE_CHECK(ctx, hipGetLastError());
     CCHK(read_back(ctx, S, st, 1));
     const int64_t M = S->h_pin[0];
-    if ((unsigned long long)M > cap) { (void)hipFree(keys); (void)hipFree(vals); return HITE_ECAP; }
+    if ((unsigned long long)M > cap) return HITE_ECAP;
     S->M = M;
     Sorter so;
-    if (sorter_init(so, ctx, st, M > 0 ? M : 1)) { (void)hipFree(keys); (void)hipFree(vals); return HITE_EHIP; }
+    struct SorterGuard { Sorter &s; ~SorterGuard() { sorter_free(s); } } sguard{so};
+    if (sorter_init(so, ctx, st, M > 0 ? M : 1)) return HITE_EHIP;
     int rc = sorter_sort(so, keys, vals, M, 64);
-    if (rc) { sorter_free(so); (void)hipFree(keys); (void)hipFree(vals); return rc; }
+    if (rc) return rc;
     HITE_CHECK(ctx, hipMalloc((void **)&S->idx_hs, (size_t)(M + 16) * 4));
     HITE_CHECK(ctx, hipMalloc((void **)&S->idx_pos, (size_t)(M + 16) * 4));
     HITE_CHECK(ctx, hipMalloc((void **)&S->dir, (size_t)((1 << DIRBITS) + 2) * 4));
     unsigned *dircnt = nullptr;
     int64_t *diroff = nullptr, *bs = nullptr;
-    HITE_CHECK(ctx, hipMalloc((void **)&dircnt, (size_t)((1 << DIRBITS) + 2) * 4));
-    HITE_CHECK(ctx, hipMalloc((void **)&diroff, (size_t)((1 << DIRBITS) + 2) * 8));
-    HITE_CHECK(ctx, hipMalloc((void **)&bs, (size_t)scan_tmp_elems((1 << DIRBITS) + 1) * 8));
+    HITE_CHECK(ctx, tmp.alloc((void **)&dircnt, (size_t)((1 << DIRBITS) + 2) * 4));
+    HITE_CHECK(ctx, tmp.alloc((void **)&diroff, (size_t)((1 << DIRBITS) + 2) * 8));
+    HITE_CHECK(ctx, tmp.alloc((void **)&bs, (size_t)scan_tmp_elems((1 << DIRBITS) + 1) * 8));
     HITE_CHECK(ctx, hipMemsetAsync(dircnt, 0, (size_t)((1 << DIRBITS) + 2) * 4, st));
     hipLaunchKernelGGL(split_index_kernel, CGRID(M), 0, st, M, keys, S->idx_hs, S->idx_pos, dircnt);
     rc = scan_excl_buf<int32_t>(ctx, bs, (int32_t *)dircnt, (int64_t)(1 << DIRBITS), diroff, st);
     hipLaunchKernelGGL(i64_to_u32_kernel, CGRID((int64_t)(1 << DIRBITS) + 1), 0, st, (int64_t)(1 << DIRBITS) + 1, diroff, S->dir);
     HITE_CHECK(ctx, hipStreamSynchronize(st));
-    sorter_free(so);
-    (void)hipFree(keys); (void)hipFree(vals); (void)hipFree(dircnt); (void)hipFree(diroff); (void)hipFree(bs);
     return rc;
 }
 
@@ -725,8 +737,9 @@ extern "C" int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, 
     uint8_t *dc = nullptr;
     int64_t *dco = nullptr;
     int64_t bytes = cand_off[n_cand];
-    HITE_CHECK(ctx, hipMalloc((void **)&dc, (size_t)bytes + 64));
-    HITE_CHECK(ctx, hipMalloc((void **)&dco, (size_t)(n_cand + 1) * 8));
+    DevTmp tmp;
+    HITE_CHECK(ctx, tmp.alloc((void **)&dc, (size_t)bytes + 64));
+    HITE_CHECK(ctx, tmp.alloc((void **)&dco, (size_t)(n_cand + 1) * 8));
     HITE_CHECK(ctx, hipMemcpy(dc, cand, (size_t)bytes, hipMemcpyHostToDevice));
     HITE_CHECK(ctx, hipMemcpy(dco, cand_off, (size_t)(n_cand + 1) * 8, hipMemcpyHostToDevice));
     int32_t *dcf, *dct, *dan;
@@ -750,7 +763,6 @@ extern "C" int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, 
             if (e != hipSuccess) rc = HITE_EHIP;
         }
     }
-    (void)hipFree(dc); (void)hipFree(dco);
     return rc;
 }
 

@@ -11,19 +11,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from hite_amd import util  # noqa: E402
 
 
-def copy_finder():
-    """copy finder with the signature util.flank_region_align_v5 expects (stands where the reference calls minimap2)"""
-    ctx = util.get_ctx()
-
-    def finder(cand_path, reference):
-        names, contigs = util.read_fasta(cand_path)
-        tab = ctx.find_copies([contigs[n] for n in names])
-        rev = {v: k for k, v in util._PACKED["names"].items()}
-        return {n: [(rev[c], s, e, e - s + 1, "-" if m else "+") for (c, s, e, m, _an) in t] for n, t in zip(names, tab) if t}
-
-    return finder
-
-
 def run_cd_hit(inp, outp, threads):
     """cd-hit-est -aS .95 -aL .95 -c .8 -G 0 -g 1 -A 80 (judge_TIR_transposons.py:87); pass-through when not installed"""
     if shutil.which("cd-hit-est") is None:
@@ -36,30 +23,26 @@ def run_cd_hit(inp, outp, threads):
 
 def refine(te_type, first_input, out_dir, stem, ref_index, reference, split_ref_dir, threads, plant, debug, low_copy, iters, flank=50):
     """iters rounds of flank_region_align_v5, each fed with the consensus of the previous one -> path of the last output"""
-    finder = copy_finder()
     cur = first_input
     for it in range(iters):
         nxt = os.path.join(out_dir, "%s_%s.r%d.fa" % (stem, ref_index, it))
         util.flank_region_align_v5(cur, nxt, flank, reference, split_ref_dir, te_type, out_dir, threads, ref_index, None, "", plant, debug,
-                                   it, low_copy, copy_finder=finder)
+                                   it, low_copy)
         cur = nxt
     return cur
 
 
-def finish(result_path, final_path, label, ref_index, reference, min_len, prev_TE, strip_hash=False):
-    """length filter, rename to <genomeprefix>-<label>_<i>_<n>, atomic publish (success == the file exists, Util.py:2831),
-    append to prev_TE"""
+def finish(result_path, final_path, label, ref_index, reference, min_len, prev_TE):
+    """length filter, rename_fasta to <label>_<i>_<n> (a '#class' suffix survives, Util.py:7500), lib_add_prefix with the genome
+    prefix (:11559), atomic publish (success == the file exists, :2831), update_prev_TE under its lock (:6378) -- the tail of
+    judge_TIR / judge_Helitron / judge_Non_LTR_transposons.py"""
     names, contigs = util.read_fasta(result_path)
-    prefix = os.path.basename(reference).split(".")[0]
-    kept = {}
-    for n in names:
-        if len(contigs[n]) >= min_len:
-            kept["%s-%s_%s_%d" % (prefix, label, ref_index, len(kept))] = contigs[n]
     tmp = final_path + ".tmp"
-    util.store_fasta(kept, tmp)
+    util.store_fasta({n: contigs[n] for n in names if len(contigs[n]) >= min_len}, tmp + ".len")
+    util.rename_fasta(tmp + ".len", tmp, "%s_%s" % (label, ref_index))
+    os.remove(tmp + ".len")
+    util.lib_add_prefix(tmp, os.path.basename(reference).split(".")[0])
     os.replace(tmp, final_path)
     if prev_TE:
-        with open(prev_TE, "a") as f:
-            for n, s in kept.items():
-                f.write(">" + n + "\n" + s + "\n")
-    return kept
+        util.update_prev_TE(prev_TE, final_path)
+    return util.read_fasta(final_path)[1]

@@ -8,8 +8,9 @@ GPU: the all-vs-all search of the chunk's 1 Mbp segments against each other (the
 reference runs `blastn`, Util.py:4068 -- hite_seed_allvsall), FMEA chaining + de-duplication
 (get_longest_repeats_v4) and the flank gather.  `--hsp <blast6 file(s)>` (an extension of this build) takes
 the HSP tables from real blastn runs instead (what sequence2sequenceBlastn writes, one file per query FASTA as
-process_blast_alignments concatenates them, Util.py:4750-4769).  Tandem-repeat masking (`trf`, Util.py:2855)
-stays an external pre-step: run it on the chunk first if wanted."""
+process_blast_alignments concatenates them, Util.py:4750-4769).  As in the reference the chunk is first masked: tandem
+repeats by `trf` (Util.py:2855; external tool, used when installed, a warning otherwise), full-length copies of the TEs of
+--prev_TE by mask_genome_intactTE (Util.py:6389), so that a later chunk does not re-discover what an earlier one found."""
 import argparse
 import os
 import sys
@@ -67,7 +68,8 @@ def main():
         return 0
     if not a.hsp:
         tmp = lr + ".tmp"
-        util.determine_repeat_boundary_v5(a.g, tmp, a.fixed_extend_base_threshold, a.max_repeat_len, a.r)
+        util.determine_repeat_boundary_v5(a.g, tmp, a.prev_TE, a.fixed_extend_base_threshold, a.max_repeat_len, out_dir, a.thread, a.ref_index,
+                                          a.r, a.debug)
         os.replace(tmp, lr)
         util.flanking_seq(lr, fl + ".tmp", a.r, a.flanking_len)
         os.replace(fl + ".tmp", fl)

@@ -2,14 +2,17 @@
 (/root/reference/module/Util.py).  Same names, argument meaning and file contracts; the
 arithmetic runs in libhite_gpu.so through `hite_amd._lib` (no CPU fallback).
 
-What is NOT reproduced here (third-party tools the reference shells out to, outside this build):
-`minimap2` copy finding (pass `all_copies=` or a `copy_finder=` callable to flank_region_align_v5),
-and the low-copy rescue by trf / itrsearch / blastx (Util.py:8196-8281): low-copy elements are
-written to `all_low_copy` exactly like the reference does, nothing is rescued.
+Third-party tools the reference shells out to: `minimap2` copy finding is replaced by the build's own minimizer-based
+finder (get_full_length_copies; `all_copies=` / `copy_finder=` of flank_region_align_v5 override it); `trf`, `cd-hit-est`
+and `itrsearch` are called where the reference calls them when they are installed (a warning otherwise); the low-copy
+rescue by itrsearch / blastx domains (Util.py:8196-8281) is not reproduced: low-copy elements are written to
+`all_low_copy` exactly like the reference does, nothing is rescued.
 """
 import os
-import sys
 import re
+import shutil
+import subprocess
+import sys
 
 import numpy as np
 
@@ -126,6 +129,7 @@ def set_reference(reference, device=0):
     if _PACKED["path"] != os.path.abspath(reference):
         names, contigs = read_fasta(reference)
         ctx.genome_pack([contigs[n] for n in names])
+        ctx.release_copy_index()          # the minimizer index belongs to the genome that was packed before
         _PACKED.update(path=os.path.abspath(reference), names={n: i for i, n in enumerate(names)},
                        lens=[len(contigs[n]) for n in names])
     return ctx
@@ -513,23 +517,64 @@ def split_and_store_sequences(names, contigs, base_threshold):
     return groups
 
 
-def determine_repeat_boundary_v5(repeats_path, longest_repeats_path, fixed_extend_base_threshold, max_single_repeat_len, reference,
-                                 device=0):
-    """determine_repeat_boundary_v5 (Util.py:4637) from the all-vs-all search on: process_blast_alignments (:4724) +
-    get_longest_repeats_v4 per query file + generate_final_result (:4783).  repeats_path = the chunk FASTA of
-    'chr$offset' segments; the all-vs-all stage is hite_seed_allvsall (the build's blastn stand-in), FMEA runs per
-    query file as in the reference (each call has its own first-come de-duplication), results are unioned by name in
-    query-file order (the canonical replacement of the reference's as_completed order)."""
+def run_remove_TR(target_file, trf_dir):
+    """Util.py:2855-2874 -- `trf <file> 2 7 7 80 10 50 500 -f -d -m -h` in trf_dir; returns the .mask FASTA (tandem repeats -> N)"""
+    os.makedirs(trf_dir, exist_ok=True)
+    subprocess.run("cd %s && trf %s 2 7 7 80 10 50 500 -f -d -m -h > /dev/null 2>&1" % (trf_dir, target_file), shell=True, check=False)
+    return os.path.join(trf_dir, os.path.basename(target_file) + ".2.7.7.80.10.50.500.mask")
+
+
+def filter_tandem_repeats(repeat_names, repeat_contigs, tmp_output_dir, ref_index, threads):
+    """Util.py:4672-4697 -- the chunk is cut into files of >= 100 kb (split_and_store_sequences), every file goes through TRF,
+    the masked files are concatenated (in file order: the canonical replacement of the reference's as_completed order) into
+    filter_tandem_{ref_index}.fa.  `trf` is an external tool: when it is not installed the chunk passes unmasked
+    and a warning says so."""
+    out = os.path.join(tmp_output_dir, "filter_tandem_%s.fa" % ref_index)
+    if shutil.which("trf") is None:
+        sys.stderr.write("[hite_amd] trf not found: tandem repeats are NOT masked before the all-vs-all search\n")
+        store_fasta({n: repeat_contigs[n] for n in repeat_names}, out)
+        return out
+    tmp_dir = os.path.join(tmp_output_dir, "trf_filter_%s" % ref_index)
+    os.makedirs(tmp_dir, exist_ok=True)
+    jobs = []
+    for i, group in enumerate(split_and_store_sequences(repeat_names, repeat_contigs, 100000)):
+        sub = os.path.join(tmp_dir, str(i))
+        os.makedirs(sub, exist_ok=True)
+        target = os.path.join(sub, "%d_target.fa" % i)
+        store_fasta({n: repeat_contigs[n] for n in group}, target)
+        jobs.append((target, os.path.join(sub, "%d_trf" % i)))
+    from concurrent.futures import ThreadPoolExecutor
+
+    with ThreadPoolExecutor(max_workers=max(1, int(threads))) as ex:     # the workers only wait for `trf` processes
+        masked = list(ex.map(lambda j: run_remove_TR(*j), jobs))
+    with open(out, "w") as f:
+        for (target, _d), m in zip(jobs, masked):
+            with open(m if os.path.exists(m) else target) as g:
+                f.write(g.read())
+    return out
+
+
+def determine_repeat_boundary_v5(repeats_path, longest_repeats_path, prev_TE, fixed_extend_base_threshold, max_single_repeat_len,
+                                 tmp_output_dir, threads, ref_index, reference, debug, device=0):
+    """determine_repeat_boundary_v5 (Util.py:4637-4670), same positional arguments: TRF masking of the chunk
+    (filter_tandem_repeats), N-masking of the full-length copies of the TEs found so far (mask_genome_intactTE with prev_TE),
+    process_blast_alignments (:4724) + get_longest_repeats_v4 per query file + generate_final_result (:4783).
+    repeats_path = the chunk FASTA of 'chr$offset' segments; the all-vs-all stage is hite_seed_allvsall (the build's blastn
+    stand-in), FMEA runs per query file as in the reference (each call has its own first-come de-duplication), results are
+    unioned by name in query-file order (the canonical replacement of the reference's as_completed order)."""
+    os.makedirs(tmp_output_dir, exist_ok=True)
     ctx = get_ctx(device)
-    names, contigs = read_fasta(repeats_path)
-    if not names:
+    repeat_names, repeat_contigs = read_fasta(repeats_path)
+    if not repeat_names:
         store_fasta({}, longest_repeats_path)
         return longest_repeats_path
+    filter_tandem_file = filter_tandem_repeats(repeat_names, repeat_contigs, tmp_output_dir, ref_index, threads)
+    masked_file_path = mask_genome_intactTE(prev_TE, filter_tandem_file, tmp_output_dir, threads, ref_index, debug=debug, device=device)
+    names, contigs = read_fasta(masked_file_path)
     ctx.genome_pack([contigs[n] for n in names])
     ctx.release_copy_index()
     _PACKED["path"] = None   # the reference genome has to be packed again by whoever needs it next
     seg_len = max(len(contigs[n]) for n in names)
-    tab = ctx.seed_allvsall(seg_len=max(seg_len, 1))
     chroms, seg_chrom, seg_off = {}, [], []
     for n in names:
         c, off = n.split("$")
@@ -537,25 +582,34 @@ def determine_repeat_boundary_v5(repeats_path, longest_repeats_path, fixed_exten
         seg_chrom.append(chroms[c])
         seg_off.append(int(off))
     inv = {v: k for k, v in chroms.items()}
+    # query files of >= 1 Mbp as in the reference: FMEA (with its own first-come de-duplication) runs per query file; the HSP
+    # table is sorted by query segment, so a file's records are one slice of it
+    tab = ctx.seed_allvsall(seg_len=max(seg_len, 1))
+    qseg = np.asarray(tab["qseg"])
+    order = np.argsort(qseg, kind="stable")
+    qsorted = qseg[order]
     index_of = {n: i for i, n in enumerate(names)}
-    qseg = tab["qseg"]
-    final = []
-    seen = set()
+    final, seen = [], set()
     for group in split_and_store_sequences(names, contigs, 1_000_000):
-        ids = np.array([index_of[n] for n in group], dtype=np.int64)
-        sel = np.isin(qseg, ids)
-        if not sel.any():
+        ids = sorted(index_of[n] for n in group)
+        sel = np.concatenate([order[np.searchsorted(qsorted, i, "left"):np.searchsorted(qsorted, i, "right")] for i in ids]) if ids else np.zeros(0, np.int64)
+        if len(sel) == 0:
             continue
+        sel = np.sort(sel)      # table order inside the file
         oc, os_, oe = ctx.fmea_chain(tab["qseg"][sel], tab["sseg"][sel], tab["qs"][sel], tab["qe"][sel], tab["ss"][sel], tab["se"][sel],
                                      seg_chrom, seg_off, fixed_extend_base_threshold, max_single_repeat_len)
-        for c, a, b in zip(oc, os_, oe):
-            name = "%s:%d-%d" % (inv[int(c)], a, b)
+        for c, a_, b_ in zip(oc, os_, oe):
+            name = "%s:%d-%d" % (inv[int(c)], a_, b_)
             if name not in seen:
                 seen.add(name)
-                final.append((name, inv[int(c)], int(a), int(b)))
+                final.append((name, inv[int(c)], int(a_), int(b_)))
     _rn, ref = read_fasta(reference)
-    out = {name: ref[c][a:b] for name, c, a, b in final}
-    store_fasta(out, longest_repeats_path)
+    store_fasta({name: ref[c][a_:b_] for name, c, a_, b_ in final}, longest_repeats_path)
+    if not debug:      # cleanup_temp_files (Util.py:4797)
+        shutil.rmtree(os.path.join(tmp_output_dir, "trf_filter_%s" % ref_index), ignore_errors=True)
+        for p_ in (filter_tandem_file, masked_file_path):
+            if os.path.exists(p_):
+                os.remove(p_)
     return longest_repeats_path
 
 
@@ -581,28 +635,43 @@ def flanking_seq(longest_repeats_path, longest_repeats_flanked_path, reference, 
         e1.append(ref_end + flanking_len)
     wins, _ = ctx.flank_gather(contig, s1, e1, [0] * len(contig), flank=0)
     flanked = {}
+    host_ref = None
     for n, w, (c, a, b) in zip(new_names, wins, zip(contig, s1, e1)):
-        flanked[n] = w.decode() if w is not None else ""
+        if w is None:   # the gather applies the 100-bp rule of the copy windows (Util.py:8116); flanking_seq has no minimum
+            if host_ref is None:
+                rn, rc_ = read_fasta(reference)
+                host_ref = [rc_[x] for x in rn]
+            flanked[n] = host_ref[c][max(0, a - 1):max(0, b)]
+        else:
+            flanked[n] = w.decode()
     store_fasta(flanked, longest_repeats_flanked_path)
 
 
 # ---- the fine stage (Util.py:8032-8287) -----------------------------------------------------------------
+def get_full_length_copies(query_path, reference, device=0):
+    """stands where the reference calls get_full_length_copies_minimap2 (Util.py:7933): {query: [(chr, start1, end1, length,
+    '+'/'-'), ...]} from the build's minimizer-based copy finder on the resident genome (packed from `reference`)"""
+    ctx = set_reference(reference, device)
+    names, contigs = read_fasta(query_path)
+    tab = ctx.find_copies([contigs[n] for n in names])
+    rev = {v: k for k, v in _PACKED["names"].items()}
+    return {n: [(rev[c], s_, e_, e_ - s_ + 1, "-" if m_ else "+") for (c, s_, e_, m_, _an) in t] for n, t in zip(names, tab) if t}
+
+
 def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, reference, split_ref_dir, TE_type, tmp_output_dir,
                           threads, ref_index, log, subset_script_path, plant, debug, iter_num, all_low_copy,
                           result_type="cons", all_copies=None, copy_finder=None):
-    """Same contract as the reference: reads the candidate FASTA, writes `real_TEs` and appends the low-copy
-    elements to `all_low_copy`.  `all_copies` = what get_full_length_copies_minimap2 returns
-    ({query: [(chr, start1, end1, aligned_len, '+'/'-'), ...]}) or `copy_finder(candidate_path, reference)`
-    producing it; one batched GPU call replaces the per-candidate process pool."""
+    """Same contract and positional arguments as the reference (Util.py:8032): reads the candidate FASTA, writes `real_TEs` and
+    appends the low-copy elements to `all_low_copy`.  The copies come from the built-in copy finder (get_full_length_copies,
+    where the reference runs minimap2, Util.py:8076); `all_copies` ({query: [(chr, start1, end1, aligned_len, '+'/'-'), ...]},
+    what get_full_length_copies_minimap2 returns) or `copy_finder(candidate_path, reference)` override it; one batched GPU call
+    replaces the per-candidate process pool."""
     if result_type != "cons":
         raise NotImplementedError("only result_type='cons'")
     names, contigs = read_fasta(candidate_sequence_path)
+    ctx = set_reference(reference)          # before the copy finder: it searches whatever genome is resident
     if all_copies is None:
-        if copy_finder is None:
-            raise ValueError("copy finding (minimap2 in the reference, Util.py:7933) is outside this build: "
-                             "pass all_copies= or copy_finder=")
-        all_copies = copy_finder(candidate_sequence_path, reference)
-    ctx = set_reference(reference)
+        all_copies = (copy_finder or get_full_length_copies)(candidate_sequence_path, reference)
     idx = _PACKED["names"]
     qnames = [q for q in all_copies.keys() if q in contigs]  # reference iterates all_copies (Util.py:8095)
     cands = [contigs[q] for q in qnames]

@@ -973,3 +973,110 @@ def test_fmea_stress_hash(ctx):
     got, _h = _fmea_gpu(ctx, rows, g["skip_gap"], g["max_len"])
     assert len(rows) == g["lines"] and len(got) == g["intervals"]
     assert hashlib.sha256("\n".join(got).encode()).hexdigest() == g["sha256"]
+
+
+def test_coarse_boundary_honours_prev_TE(ctx, tmp_path):
+    """argv as main.py builds it (main.py:520-532), --prev_TE with a non-empty library: the chunk is N-masked with the
+    full-length copies of those TEs before seeding (mask_genome_intactTE, Util.py:6389), so the families already in prev_TE
+    do not come out again, the others still do"""
+    import os
+    import subprocess
+    import sys as _sys
+
+    import synth_small
+    from hite_amd import util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = synth_small.make(43, n_fam=10, n_chr=2, chr_len=300_000)
+    ref = tmp_path / "genome.fa"
+    ref.write_text("".join(">chr%d\n%s\n" % (i + 1, s) for i, s in enumerate(g["contigs"])))
+    cut = tmp_path / "genome.cut0.fa"
+    with open(cut, "w") as f:
+        for i, s in enumerate(g["contigs"]):
+            for o in range(0, len(s), 100_000):
+                f.write(">chr%d$%d\n%s\n" % (i + 1, o, s[o:o + 100_000]))
+    multi = [k for k, (fam, div) in enumerate(zip(g["truth"], g["divs"])) if len(fam) >= 3 and div <= 0.08]
+    assert len(multi) >= 4
+    known = multi[:len(multi) // 2]
+    prev = tmp_path / "prev_TE.fa"
+    prev.write_text("".join(">known_%d\n%s\n" % (k, g["cands"][k]) for k in known))
+
+    def run(out, prev_path):
+        argv = [_sys.executable, root + "/hite_amd/scripts/coarse_boundary.py", "-g", str(cut), "--tmp_output_dir", str(out),
+                "--prev_TE", str(prev_path), "--fixed_extend_base_threshold", "1000", "--max_repeat_len", "30000", "--thread", "2",
+                "--flanking_len", "50", "--tandem_region_cutoff", "0.5", "--ref_index", "0", "-r", str(ref), "--recover", "0",
+                "--debug", "0", "-w", str(tmp_path)]
+        rc = subprocess.run(argv, capture_output=True, text=True)
+        assert rc.returncode == 0, rc.stderr[-2000:]
+        names, _ = util.read_fasta(str(out / "longest_repeats_0.fa"))
+        iv = []
+        for n in names:
+            c, pos = n.split(":")
+            a, b = map(int, pos.split("-"))
+            iv.append((int(c[3:]) - 1, a, b))
+        return iv
+
+    def recovered(iv, k):
+        c0, a0, b0, _m = g["truth"][k][0]
+        return any(c == c0 and min(b, b0) - max(a, a0) > 0.7 * (b0 - a0) for c, a, b in iv)
+
+    empty = tmp_path / "none.fa"
+    empty.write_text("")
+    base = run(tmp_path / "out_a", empty)
+    masked = run(tmp_path / "out_b", prev)
+    assert sum(recovered(base, k) for k in multi) >= len(multi) - 1
+    assert sum(recovered(masked, k) for k in known) == 0                       # already in prev_TE: masked, not re-discovered
+    assert sum(recovered(masked, k) for k in multi if k not in known) >= len(multi) - len(known) - 1
+
+
+def test_reference_signatures_and_prev_TE_lock(ctx, tmp_path):
+    """flank_region_align_v5 called with exactly the reference's positional arguments (Util.py:8032) uses the built-in copy
+    finder; determine_repeat_boundary_v5 takes the reference's ten arguments (Util.py:4637); the stage tail renames through
+    rename_fasta / lib_add_prefix and appends to prev_TE through update_prev_TE"""
+    import inspect
+    import os
+    import sys as _sys
+
+    import synth_small
+    from hite_amd import util
+
+    assert list(inspect.signature(util.determine_repeat_boundary_v5).parameters)[:10] == [
+        "repeats_path", "longest_repeats_path", "prev_TE", "fixed_extend_base_threshold", "max_single_repeat_len", "tmp_output_dir",
+        "threads", "ref_index", "reference", "debug"]
+    assert list(inspect.signature(util.flank_region_align_v5).parameters)[:16] == [
+        "candidate_sequence_path", "real_TEs", "flanking_len", "reference", "split_ref_dir", "TE_type", "tmp_output_dir", "threads",
+        "ref_index", "log", "subset_script_path", "plant", "debug", "iter_num", "all_low_copy", "result_type"]
+    g = synth_small.make(5, n_fam=10)
+    gref = tmp_path / "genome.fa"
+    gref.write_text("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(g["contigs"])))
+    cand = tmp_path / "cand.fa"
+    cand.write_text("".join(">q%d\n%s\n" % (i, s) for i, s in enumerate(g["cands"])))
+    real, low = tmp_path / "real.fa", tmp_path / "low.fa"
+    t, l = util.flank_region_align_v5(str(cand), str(real), 50, str(gref), None, "tir", str(tmp_path), 1, 0, None, "", 1, 0, 0, str(low))
+    assert len(t) + len(l) >= 3 and set(util.read_fasta(str(real))[0]) == set(t)
+    # the copy finder follows the genome: a second reference in the same process gives that genome's copies
+    g2 = synth_small.make(6, n_fam=6)
+    gref2 = tmp_path / "genome2.fa"
+    gref2.write_text("".join(">d%d\n%s\n" % (i, s) for i, s in enumerate(g2["contigs"])))
+    cand2 = tmp_path / "cand2.fa"
+    cand2.write_text("".join(">p%d\n%s\n" % (i, s) for i, s in enumerate(g2["cands"])))
+    cp2 = util.get_full_length_copies(str(cand2), str(gref2))
+    exp2 = O.find_copies(g2["contigs"], g2["cands"])
+    for i, e in enumerate(exp2):
+        got = cp2.get("p%d" % i, [])
+        assert [(int(c[0][1:]), c[1], c[2], c[4] == "-") for c in got] == [(x[0], x[1], x[2], bool(x[3])) for x in e]
+    cp1 = util.get_full_length_copies(str(cand), str(gref))
+    exp1 = O.find_copies(g["contigs"], g["cands"])
+    assert sum(len(v) for v in cp1.values()) == sum(len(e) for e in exp1)
+    # stage tail
+    _sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "hite_amd", "scripts"))
+    import _stage
+
+    prev = tmp_path / "prev_TE.fa"
+    prev.write_text(">old_0\nACGTACGTAC\n")
+    res = tmp_path / "res.fa"
+    res.write_text(">a#DNA/hAT\n" + "ACGT" * 30 + "\n>b\n" + "AC" * 20 + "\n>c\n" + "TTGA" * 25 + "\n")
+    kept = _stage.finish(str(res), str(tmp_path / "confident_tir_0.fa"), "TIR", "0", str(gref), 80, str(prev))
+    assert list(kept) == ["genome-TIR_0_0#DNA/hAT", "genome-TIR_0_1"]
+    pn, _pc = util.read_fasta(str(prev))
+    assert pn == ["old_0", "genome-TIR_0_0#DNA/hAT", "genome-TIR_0_1"] and os.path.exists(str(prev) + ".lock")
