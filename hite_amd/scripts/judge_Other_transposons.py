@@ -59,7 +59,7 @@ def main():
         return 2
     reference = os.path.realpath(a.r)
     util.set_reference(reference)
-    all_copies = util.get_full_length_copies(lib, reference)
+    all_copies = util.get_full_length_copies_minimap2(lib, reference)
     _names, ref_contigs = util.read_fasta(reference)
     best = longest_copies(all_copies, ref_contigs)
     kept = {n: s for n, s in best.items() if len(s) >= a.min_TE_len}

@@ -3,7 +3,7 @@
 arithmetic runs in libhite_gpu.so through `hite_amd._lib` (no CPU fallback).
 
 Third-party tools the reference shells out to: `minimap2` copy finding is replaced by the build's own minimizer-based
-finder (get_full_length_copies; `all_copies=` / `copy_finder=` of flank_region_align_v5 override it); `trf`, `cd-hit-est`
+finder (get_full_length_copies_minimap2; `all_copies=` / `copy_finder=` of flank_region_align_v5 override it); `trf`, `cd-hit-est`
 and `itrsearch` are called where the reference calls them when they are installed (a warning otherwise); the low-copy
 rescue by itrsearch / blastx domains (Util.py:8196-8281) is not reproduced: low-copy elements are written to
 `all_low_copy` exactly like the reference does, nothing is rescued.
@@ -87,6 +87,98 @@ def lib_add_prefix(HiTE_lib, prefix):
     lib_names, lib_contigs = read_fasta(HiTE_lib)
     store_fasta({prefix + "-" + name: lib_contigs[name] for name in lib_names}, HiTE_lib)
     return HiTE_lib
+
+
+def convertToUpperCase_v1(reference):
+    """Util.py:1521 -- the genome FASTA is rewritten in place: names cut at the first blank, sequences upper-case on one line"""
+    names, contigs = [], {}
+    with open(reference, "r") as f_r:
+        name, seq = "", []
+        for line in f_r:
+            if line.startswith(">"):
+                if name != "" and seq:
+                    contigs[name] = "".join(seq)
+                    names.append(name)
+                name, seq = line.strip()[1:].split(" ")[0], []
+            else:
+                seq.append(line.strip().upper())
+        contigs[name] = "".join(seq)
+        names.append(name)
+    with open(reference, "w") as f_save:
+        for name in names:
+            f_save.write(">" + name + "\n" + contigs[name] + "\n")
+    return reference
+
+
+def genome_segments(reference, chrom_seg_length):
+    """multi_line (Util.py:1801) + the naming of split_genome_chunks.py:41-52 without the temporary file: yields
+    ('chr$offset', segment, len of the '>chr\\toffset\\tsegment' text line) in genome order"""
+    names, contigs = read_fasta(reference)
+    for name in names:
+        contig = contigs[name]
+        for start in range(0, len(contig), chrom_seg_length):
+            seg = contig[start:start + chrom_seg_length]
+            yield name + "$" + str(start), seg, len(">" + name + "\t" + str(start) + "\t" + seg)
+
+
+def split_chromosomes(chromosomes_dict, max_length=200_000_000):
+    """Util.py:10252 -- sequences longer than max_length become <name>_part<k> pieces"""
+    out = {}
+    for chrom, sequence in chromosomes_dict.items():
+        if len(sequence) > max_length:
+            for i in range((len(sequence) + max_length - 1) // max_length):
+                out["%s_part%d" % (chrom, i + 1)] = sequence[i * max_length:min((i + 1) * max_length, len(sequence))]
+        else:
+            out[chrom] = sequence
+    return out
+
+
+def split_dict_into_blocks(chromosomes_dict, threads, chunk_size):
+    """Util.py:10276 -- consecutive sequences are grouped until a block holds total / threads bases"""
+    chromosomes_dict = split_chromosomes(chromosomes_dict, max_length=chunk_size)
+    target = sum(len(s) for s in chromosomes_dict.values()) // threads
+    blocks, cur, cur_len = [], {}, 0
+    for chrom, seq in chromosomes_dict.items():
+        cur[chrom] = seq
+        cur_len += len(seq)
+        if cur_len >= target:
+            blocks.append(cur)
+            cur, cur_len = {}, 0
+    if cur:
+        blocks.append(cur)
+    return blocks
+
+
+def split_genome_chunks(reference, tmp_output_dir, chrom_seg_length, chunk_size_mb):
+    """module/split_genome_chunks.py:27-88: genome.cut{i}.fa (chr$offset segments, a new chunk whenever the FASTA-text bytes
+    read reach chunk_size) and ref_chr/ref_block_{i}.fa; returns the chunk paths"""
+    chunk_size = int(float(chunk_size_mb) * 1024 * 1024)
+    tmp_output_dir = os.path.abspath(tmp_output_dir)
+    os.makedirs(tmp_output_dir, exist_ok=True)
+    convertToUpperCase_v1(reference)
+    cut_references, cur, cur_base_num, ref_index = [], {}, 0, 0
+    for seg_name, seg, line_len in genome_segments(reference, int(chrom_seg_length)):
+        cur[seg_name] = seg
+        cur_base_num += line_len
+        if cur_base_num >= chunk_size:
+            path = os.path.join(tmp_output_dir, "genome.cut%d.fa" % ref_index)
+            store_fasta(cur, path)
+            cut_references.append(path)
+            cur, cur_base_num, ref_index = {}, 0, ref_index + 1
+    if cur:
+        path = os.path.join(tmp_output_dir, "genome.cut%d.fa" % ref_index)
+        store_fasta(cur, path)
+        cut_references.append(path)
+    _names, ref_contigs = read_fasta(reference)
+    split_ref_dir = os.path.join(tmp_output_dir, "ref_chr")
+    shutil.rmtree(split_ref_dir, ignore_errors=True)
+    os.makedirs(split_ref_dir)
+    for i, block in enumerate(split_dict_into_blocks(ref_contigs, 100, chunk_size)):
+        chr_path = os.path.join(split_ref_dir, "ref_block_%d.fa" % i)
+        store_fasta(block, chr_path)
+        if shutil.which("makeblastdb"):     # only the blastn route of the reference reads these databases
+            subprocess.run("makeblastdb -in %s -dbtype nucl > /dev/null 2>&1" % chr_path, shell=True, check=False)
+    return cut_references
 
 
 def file_exist(resut_file):
@@ -648,9 +740,11 @@ def flanking_seq(longest_repeats_path, longest_repeats_flanked_path, reference, 
 
 
 # ---- the fine stage (Util.py:8032-8287) -----------------------------------------------------------------
-def get_full_length_copies(query_path, reference, device=0):
-    """stands where the reference calls get_full_length_copies_minimap2 (Util.py:7933): {query: [(chr, start1, end1, length,
-    '+'/'-'), ...]} from the build's minimizer-based copy finder on the resident genome (packed from `reference`)"""
+def get_full_length_copies_minimap2(query_path, reference, temp_dir=None, max_copy_num=100, threads=1, device=0):
+    """Same arguments as the reference's function (Util.py:7933, which runs minimap2): {query: [(chr, start1, end1, length,
+    '+'/'-'), ...]} from the build's minimizer-based copy finder on the resident genome (packed from `reference`).  The finder
+    keeps up to 300 copies per query (the reference's own -N of the masking step); the <= 100 rows of an alignment are chosen
+    later by the longest-100 rule (ready_for_MSA.sh 100 100), so max_copy_num / temp_dir / threads have nothing to steer here."""
     ctx = set_reference(reference, device)
     names, contigs = read_fasta(query_path)
     tab = ctx.find_copies([contigs[n] for n in names])
@@ -662,7 +756,7 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
                           threads, ref_index, log, subset_script_path, plant, debug, iter_num, all_low_copy,
                           result_type="cons", all_copies=None, copy_finder=None):
     """Same contract and positional arguments as the reference (Util.py:8032): reads the candidate FASTA, writes `real_TEs` and
-    appends the low-copy elements to `all_low_copy`.  The copies come from the built-in copy finder (get_full_length_copies,
+    appends the low-copy elements to `all_low_copy`.  The copies come from the built-in copy finder (get_full_length_copies_minimap2,
     where the reference runs minimap2, Util.py:8076); `all_copies` ({query: [(chr, start1, end1, aligned_len, '+'/'-'), ...]},
     what get_full_length_copies_minimap2 returns) or `copy_finder(candidate_path, reference)` override it; one batched GPU call
     replaces the per-candidate process pool."""
@@ -671,7 +765,7 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
     names, contigs = read_fasta(candidate_sequence_path)
     ctx = set_reference(reference)          # before the copy finder: it searches whatever genome is resident
     if all_copies is None:
-        all_copies = (copy_finder or get_full_length_copies)(candidate_sequence_path, reference)
+        all_copies = (copy_finder or get_full_length_copies_minimap2)(candidate_sequence_path, reference)
     idx = _PACKED["names"]
     qnames = [q for q in all_copies.keys() if q in contigs]  # reference iterates all_copies (Util.py:8095)
     cands = [contigs[q] for q in qnames]
@@ -686,25 +780,34 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
             lst.append((idx[cp[0]], int(cp[1]), int(cp[2]), 1 if cp[4] == "-" else 0))
         copies.append(lst)
     res, _stats = ctx.flank_region_align(TE_type, cands, copies, plant=int(plant), flank=int(flanking_len)) if qnames else ([], None)
-    # result bucketing  Util.py:8159-8194, 8282-8287
-    true_tes, low_copy = {}, {}
-    thr = 5 if TE_type in ("tir", "non_ltr") else 2
-    for q, (is_te, info, cons, copy_count, _bs, _be) in zip(qnames, res):
-        if not is_te:
-            continue
-        if TE_type in ("tir", "helitron", "non_ltr"):
-            if cons.startswith("TG") and cons.endswith("CA"):
-                continue
-            if copy_count <= thr:
-                low_copy[q] = cons
-            else:
-                true_tes[q] = cons
-        else:
-            true_tes[q] = cons
+    true_tes, low_copy = bucket_results(TE_type, [(q if is_te else None, cons if is_te else None, info, copy_count)
+                                                  for q, (is_te, info, cons, copy_count, _bs, _be) in zip(qnames, res)])
     store_fasta(true_tes, real_TEs)
     with open(all_low_copy, "a") as f:
         for q, s in low_copy.items():
             f.write(">" + q + "\n" + s + "\n")
+    return true_tes, low_copy
+
+
+def bucket_results(TE_type, results):
+    """the collection loop of flank_region_align_v5 (Util.py:8159-8194, 8282-8287) on (cur_name, cur_seq, info, copy_count)
+    tuples (cur_name None = not a TE): TIR / Helitron / non-LTR consensi that start with TG and end with CA are dropped (LTR
+    ends), those with copy_count <= 5 (TIR, non-LTR) or <= 2 (Helitron) go to the low-copy bucket, the rest are real TEs.
+    -> (true_tes, low_copy) in result order.  (The rescue of low-copy elements by itrsearch / blastx is not reproduced.)"""
+    true_tes, low_copy = {}, {}
+    thr = 5 if TE_type in ("tir", "non_ltr") else 2
+    for cur_name, cur_seq, _info, copy_count in results:
+        if cur_name is None:
+            continue
+        if TE_type in ("tir", "helitron", "non_ltr"):
+            if cur_seq.startswith("TG") and cur_seq.endswith("CA"):
+                continue
+            if copy_count <= thr:
+                low_copy[cur_name] = cur_seq
+            else:
+                true_tes[cur_name] = cur_seq
+        else:
+            true_tes[cur_name] = cur_seq
     return true_tes, low_copy
 
 

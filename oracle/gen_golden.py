@@ -690,11 +690,126 @@ def gen_lib_dedup(U, tmp):
     dump("lib_dedup", {"chain": cases, "cons": cons})
 
 
+def gen_split_chunks(U, tmp):
+    """module/split_genome_chunks.py run as a script (runpy) on small genomes: the reference FASTA is rewritten upper-case in
+    place (convertToUpperCase_v1), cut into chr$offset segments (multi_line) and grouped into genome.cut{i}.fa by FASTA-text
+    bytes; ref_chr/ref_block_{i}.fa by split_dict_into_blocks.  makeblastdb is absent here (its call fails silently)."""
+    import runpy
+
+    script = os.path.join(ref_harness.REFERENCE_ROOT, "module", "split_genome_chunks.py")
+    cases = []
+    rng = np.random.default_rng(4711)
+    for ci, (seg_len, chunk_mb, lens) in enumerate([(1000, 0.005, [3500, 1200, 999, 1000, 2001]), (700, 0.002, [5000]),
+                                                    (1000, 400, [1500, 800]), (500, 0.0011, [499, 500, 501, 1, 2600])]):
+        d = os.path.join(tmp, "split_%d" % ci)
+        os.makedirs(d)
+        ref = os.path.join(d, "genome.fa")
+        text = []
+        for k, L in enumerate(lens):
+            seq = casegen.rand_seq(rng, L)
+            if k % 2 == 0:
+                seq = seq.lower() if k % 4 == 0 else seq[:L // 2] + seq[L // 2:].lower()
+            text.append(">Chr%d some description %d\n" % (k + 1, k))
+            w = int(rng.integers(50, 90))
+            text += [seq[p:p + w] + "\n" for p in range(0, L, w)]
+        text = "".join(text)
+        with open(ref, "w") as f:
+            f.write(text)
+        argv = sys.argv
+        sys.argv = [script, "-g", ref, "--tmp_output_dir", d, "--chrom_seg_length", str(seg_len), "--chunk_size", str(chunk_mb)]
+        try:
+            runpy.run_path(script, run_name="__main__")
+        finally:
+            sys.argv = argv
+        files = {}
+        for fn in sorted(os.listdir(d)):
+            if fn.startswith("genome.cut") and fn.endswith(".fa"):
+                files[fn] = open(os.path.join(d, fn)).read()
+        for fn in sorted(os.listdir(os.path.join(d, "ref_chr"))):
+            if fn.endswith(".fa"):
+                files["ref_chr/" + fn] = open(os.path.join(d, "ref_chr", fn)).read()
+        files["genome.fa"] = open(ref).read()
+        cases.append(dict(input=text, chrom_seg_length=seg_len, chunk_size=chunk_mb, files=files))
+    dump("split_chunks", cases)
+
+
+def gen_bucketing(U, tmp):
+    """the collection loop of flank_region_align_v5 (Util.py:8159-8194, 8282-8287) with run_find_members_v8 replaced by a table
+    of result tuples: which consensus goes to real_TEs, which to all_low_copy, which is dropped (TG...CA), per TE type.  The
+    low-copy rescue (itrsearch / blastx domains, external tools) is stubbed to rescue nothing, as when those tools are absent."""
+    rng = np.random.default_rng(8159)
+    cases = []
+    for te_type in ("tir", "helitron", "non_ltr", "other"):
+        for rep in range(3):
+            names, seqs = casegen.make_genome(10 + rep)
+            ref = os.path.join(tmp, "bg_%s_%d.fa" % (te_type, rep))
+            write_fasta(ref, names, seqs)
+            table = {}
+            copies = {}
+            for q in range(40):
+                qn = "q%d-C_%d" % (q, rep)
+                body = casegen.rand_seq(rng, int(rng.integers(90, 400)))
+                kind = int(rng.integers(0, 5))
+                if kind == 0:
+                    body = "TG" + body[2:-2] + "CA"
+                if kind == 1:
+                    body = "TG" + body[2:]
+                cc = int(rng.choice([0, 1, 2, 3, 5, 6, 7, 40, 100]))
+                info = str(rng.choice(["", "", "", "nb", "fl1", "copy_num:3"]))
+                is_te = info in ("", "copy_num:3") and rng.random() < 0.8
+                table[qn] = (qn if is_te else None, body if is_te else None, info, cc)
+                copies[qn] = [(names[0], 100, 400, 301, "+")]
+            cand = os.path.join(tmp, "bc_%s_%d.fa" % (te_type, rep))
+            write_fasta(cand, list(table.keys()), ["ACGT" * 30 for _ in table])
+
+            def fake_copies(query_path, reference, temp_dir, max_copy_num, threads, _c=copies):
+                os.makedirs(temp_dir, exist_ok=True)
+                return _c
+
+            def fake_members(task, temp_dir, subset_script_path, plant, TE_type, debug, result_type, _t=table):
+                (query_name, cur_seq, trunc_member_file, extend_member_file) = task
+                r = _t[query_name]
+                return (r[0], r[1], r[2], r[3], extend_member_file)
+
+            def fake_remove_no_tirs(low_copy_path, plant, TRsearch_dir, low_copy_dir):
+                w, n = os.path.join(low_copy_dir, "with_tir.fa"), os.path.join(low_copy_dir, "no_tir.fa")
+                open(w, "w").close(); open(n, "w").close()
+                return w, n
+
+            def fake_domain(path, db, output_table, threads, temp_dir):
+                with open(output_table, "w") as f:
+                    f.write("#h1\n#h2\n")
+
+            saved = (U.get_full_length_copies_minimap2, U.run_find_members_v8, U.ProcessPoolExecutor, U.as_completed, U.remove_no_tirs,
+                     U.get_domain_info)
+            U.get_full_length_copies_minimap2 = fake_copies
+            U.run_find_members_v8 = fake_members
+            U.ProcessPoolExecutor = ref_harness.SyncExecutor
+            U.as_completed = lambda fs: fs
+            U.remove_no_tirs = fake_remove_no_tirs
+            U.get_domain_info = fake_domain
+            real = os.path.join(tmp, "real_%s_%d.fa" % (te_type, rep))
+            low = os.path.join(tmp, "low_%s_%d.fa" % (te_type, rep))
+            with open(low, "w") as f:
+                f.write(">earlier\nACGT\n")
+            try:
+                log = type("L", (), {"logger": type("LL", (), {"info": staticmethod(lambda *a: None), "debug": staticmethod(lambda *a: None)})})()
+                U.flank_region_align_v5(cand, real, 50, ref, None, te_type, os.path.join(tmp, "bw_%s_%d" % (te_type, rep)), 1, 0, log,
+                                        "", 1, 0, 0, low)
+            finally:
+                (U.get_full_length_copies_minimap2, U.run_find_members_v8, U.ProcessPoolExecutor, U.as_completed, U.remove_no_tirs,
+                 U.get_domain_info) = saved
+            rn, rc = U.read_fasta(real)
+            cases.append(dict(te_type=te_type, table=[[k, v[0], v[1], v[2], v[3]] for k, v in table.items()],
+                              real=[[x, rc[x]] for x in rn], low_text=open(low).read()))
+    dump("bucketing", cases)
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -722,6 +837,10 @@ def main():
             gen_lib_dedup(U, tmp)
         if "bothends" in which:
             gen_ltr_both_ends(tmp)
+        if "split" in which:
+            gen_split_chunks(U, tmp)
+        if "bucketing" in which:
+            gen_bucketing(U, tmp)
 
 
 if __name__ == "__main__":

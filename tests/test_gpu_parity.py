@@ -1060,12 +1060,12 @@ def test_reference_signatures_and_prev_TE_lock(ctx, tmp_path):
     gref2.write_text("".join(">d%d\n%s\n" % (i, s) for i, s in enumerate(g2["contigs"])))
     cand2 = tmp_path / "cand2.fa"
     cand2.write_text("".join(">p%d\n%s\n" % (i, s) for i, s in enumerate(g2["cands"])))
-    cp2 = util.get_full_length_copies(str(cand2), str(gref2))
+    cp2 = util.get_full_length_copies_minimap2(str(cand2), str(gref2))
     exp2 = O.find_copies(g2["contigs"], g2["cands"])
     for i, e in enumerate(exp2):
         got = cp2.get("p%d" % i, [])
         assert [(int(c[0][1:]), c[1], c[2], c[4] == "-") for c in got] == [(x[0], x[1], x[2], bool(x[3])) for x in e]
-    cp1 = util.get_full_length_copies(str(cand), str(gref))
+    cp1 = util.get_full_length_copies_minimap2(str(cand), str(gref))
     exp1 = O.find_copies(g["contigs"], g["cands"])
     assert sum(len(v) for v in cp1.values()) == sum(len(e) for e in exp1)
     # stage tail

@@ -1,5 +1,6 @@
 """The CPU oracle (oracle/*.c) must reproduce every golden vector generated from the
 reference's own Python (oracle/gen_golden.py).  CPU only."""
+import os
 import numpy as np
 import pytest
 
@@ -307,3 +308,46 @@ def test_host_formats_golden(tmp_path):
     util.update_prev_TE(str(prev), str(cur))
     util.update_prev_TE(str(prev), str(tmp_path / "absent.fa"))
     assert prev.read_text() == c["out"]
+
+
+def test_split_genome_chunks_golden(tmp_path):
+    """f-1: the drop-in of module/split_genome_chunks.py writes byte-identical genome.cut{i}.fa / ref_chr/ref_block_{i}.fa and
+    rewrites the genome like the reference (upper case, one line per contig, names cut at the first blank)"""
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for ci, case in enumerate(load_golden("split_chunks")):
+        d = tmp_path / ("c%d" % ci)
+        d.mkdir()
+        ref = d / "genome.fa"
+        ref.write_text(case["input"])
+        rc = subprocess.run([_sys.executable, os.path.join(root, "hite_amd", "scripts", "split_genome_chunks.py"), "-g", str(ref),
+                             "--tmp_output_dir", str(d), "--chrom_seg_length", str(case["chrom_seg_length"]), "--chunk_size",
+                             str(case["chunk_size"])], capture_output=True, text=True)
+        assert rc.returncode == 0, rc.stderr[-1500:]
+        got = {}
+        for fn in sorted(os.listdir(d)):
+            if fn.startswith("genome.cut") and fn.endswith(".fa"):
+                got[fn] = (d / fn).read_text()
+        for fn in sorted(os.listdir(d / "ref_chr")):
+            if fn.endswith(".fa"):
+                got["ref_chr/" + fn] = (d / "ref_chr" / fn).read_text()
+        got["genome.fa"] = ref.read_text()
+        assert got == case["files"]
+
+
+def test_result_bucketing_golden():
+    """a-22: which consensus is a real TE, which goes to the low-copy file, which is dropped -- the reference's collection loop
+    (Util.py:8159-8194, 8282-8287) run on tables of result tuples"""
+    from hite_amd import util
+
+    n_real = n_low = 0
+    for case in load_golden("bucketing"):
+        true_tes, low = util.bucket_results(case["te_type"], [(r[1], r[2], r[3], r[4]) for r in case["table"]])
+        assert [[k, v] for k, v in true_tes.items()] == case["real"]
+        exp_low = case["low_text"].split(">earlier\nACGT\n", 1)[1]
+        assert "".join(">%s\n%s\n" % (k, v) for k, v in low.items()) == exp_low
+        n_real += len(true_tes)
+        n_low += len(low)
+    assert n_real > 50 and n_low > 30
