@@ -598,7 +598,8 @@ __global__ void __launch_bounds__(64) align_wide_tb_kernel(AlignArgs P, const in
 // ---------------------------------------------------------------------------------------------
 // schedule
 // ---------------------------------------------------------------------------------------------
-// what: 0 = pairs to re-run with a band of `level` words (exact mode), 1 = pairs whose traceback left the slice
+// what: 0 = pairs to re-run with a band of `level` words (exact mode), 1 = pairs whose traceback left the slice,
+// 2 / 3 = pairs that will / will not be re-run with a wider band at all (asked after the 4-word run)
 __global__ void align_flag_kernel(int64_t nrows, const int32_t *__restrict__ order, const int32_t *__restrict__ strips, AlignArgs P,
                                   int what, int level, int cap, int32_t *__restrict__ flag, int32_t *__restrict__ cols) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -614,7 +615,12 @@ __global__ void align_flag_kernel(int64_t nrows, const int32_t *__restrict__ ord
                 const bool cert = P.U[g] <= P.kst[g];
                 f = level >= first && !cert;
             }
-        } else f = P.st[g] == 1;
+        } else if (what == 1) f = P.st[g] == 1;
+        else {      // 2: pairs that will be re-run with a wider band (decided by the 4-word run alone); 3: the others
+            const int u4 = P.U4[g];
+            const bool esc = P.st[g] == 0 && u4 >= 0 && u4 + AL_GAP * AL_MARGIN <= 32 * AL_GAP * cap && !(P.U[g] <= P.kst[g]);
+            f = what == 2 ? esc : !esc;
+        }
     }
     flag[x] = f;
     if (cols) cols[x] = f ? P.win_len[g] + 1 : 0;
@@ -665,13 +671,24 @@ struct AlignState {
     int64_t *d_scal = nullptr;
     int exact_cap = -1;
     bool sort_attr = false;
+    hipStream_t st2 = nullptr;     // the wider bands run here, beside the traceback of the pairs that are already final
+    hipEvent_t ev = nullptr;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+
+// the second stream gets the highest priority: its few long-running waves are the critical path and must not queue behind the
+// traceback's many short workgroups
+static hipError_t align_make_stream(hipStream_t *out) {
+    int lo = 0, hi = 0;
+    if (hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess) { lo = 0; hi = 0; }
+    return hipStreamCreateWithPriority(out, hipStreamNonBlocking, hi);
+}
 
 static AlignState *align_state(hite_ctx *ctx) {
     if (!ctx->align_state) {
         AlignState *S = new AlignState();
-        if (hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)) != hipSuccess || hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)) != hipSuccess) {
+        if (hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)) != hipSuccess || hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)) != hipSuccess ||
+            align_make_stream(&S->st2) != hipSuccess || hipEventCreateWithFlags(&S->ev, hipEventDisableTiming) != hipSuccess) {
             delete S;
             return nullptr;
         }
@@ -689,6 +706,8 @@ void hite_align_release(hite_ctx *ctx) {
     arena_free(S->arena);
     if (S->h_pin) (void)hipHostFree(S->h_pin);
     if (S->d_scal) (void)hipFree(S->d_scal);
+    if (S->st2) (void)hipStreamDestroy(S->st2);
+    if (S->ev) (void)hipEventDestroy(S->ev);
     delete S;
     ctx->align_state = nullptr;
 }
@@ -723,19 +742,19 @@ static int aalloc(hite_ctx *ctx, Arena &A, size_t count, T **out) {
 // order-preserving compaction of the rows flagged for `what`; returns the count (host) and the list (device)
 static int build_list(hite_ctx *ctx, AlignState *S, hipStream_t st, int64_t nrows, const int32_t *order, const int32_t *strips,
                       AlignArgs &P, int what, int level, int cap, int32_t *flag, int32_t *cols, int64_t *pos, int64_t *colpos,
-                      int64_t *scan_tmp, int32_t *list, int64_t *full_off, int64_t *count, int64_t *total_cols) {
+                      int64_t *scan_tmp, int32_t *list, int64_t *full_off, int64_t *count, int64_t *total_cols, int slot = 0) {
     const unsigned nb = (unsigned)((nrows + 255) / 256);
     hipLaunchKernelGGL(align_flag_kernel, dim3(nb), dim3(256), 0, st, nrows, order, strips, P, what, level, cap, flag, cols);
     ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, flag, nrows, pos, st));
     if (cols) ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, cols, nrows, colpos, st));
     hipLaunchKernelGGL(align_compact_kernel, dim3(nb), dim3(256), 0, st, nrows, order, flag, pos, list, cols ? colpos : nullptr,
                        cols ? full_off : nullptr, P.st);
-    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, pos + nrows, 8, hipMemcpyDeviceToDevice, st));
-    if (cols) HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, colpos + nrows, 8, hipMemcpyDeviceToDevice, st));
-    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, 16, hipMemcpyDeviceToHost, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + slot, pos + nrows, 8, hipMemcpyDeviceToDevice, st));
+    if (cols) HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + slot + 1, colpos + nrows, 8, hipMemcpyDeviceToDevice, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin + slot, S->d_scal + slot, 16, hipMemcpyDeviceToHost, st));
     HITE_CHECK(ctx, hipStreamSynchronize(st));
-    *count = S->h_pin[0];
-    if (total_cols) *total_cols = cols ? S->h_pin[1] : 0;
+    *count = S->h_pin[slot];
+    if (total_cols) *total_cols = cols ? S->h_pin[slot + 1] : 0;
     return HITE_OK;
 }
 
@@ -757,9 +776,9 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     memset(&P, 0, sizeof P);
     P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first; P.n_cand = n_cand;
     P.ops_base = d_ops_base; P.ops = d_ops;
-    int32_t *row_cand, *strips, *order, *pwords, *flag, *cols, *list;
+    int32_t *row_cand, *strips, *order, *pwords, *flag, *flag2, *cols, *list, *list_esc, *list_fin;
     unsigned long long *skeys;
-    int64_t *plane_off, *rec_off, *pos, *colpos, *scan_tmp, *full_off;
+    int64_t *plane_off, *rec_off, *pos, *pos2, *colpos, *scan_tmp, *scan_tmp2, *full_off;
     ACHK(aalloc(ctx, A, (size_t)total_rows, &row_cand));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &strips));
     ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &skeys));
@@ -777,6 +796,11 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     ACHK(aalloc(ctx, A, (size_t)total_rows, &flag));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &cols));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &list));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &list_esc));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &list_fin));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &flag2));
+    ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &pos2));
+    ACHK(aalloc(ctx, A, (size_t)scan_tmp_elems(total_rows) + 16, &scan_tmp2));
     ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &pos));
     ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &colpos));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &full_off));
@@ -819,26 +843,59 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     tk = hite_prof_begin(ctx, name, st);
     hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<4>), dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
     hite_prof_end(ctx, tk, st);
-    // ---- exact mode: wider bands for the pairs without a certificate
-    if (cap >= 8) {
-        snprintf(name, sizeof name, "align_fwd_wide%s", tag ? tag : "");
-        tk = hite_prof_begin(ctx, name, st);
+    // ---- exact mode: wider bands for the pairs without a certificate, on a second stream, beside the traceback of the pairs
+    //      whose 4-word run is final (the wider bands have few, long-running waves: alone they leave most SIMDs idle)
+    snprintf(name, sizeof name, "align_tb%s", tag ? tag : "");
+    char wname[32];
+    snprintf(wname, sizeof wname, "align_fwd_wide%s", tag ? tag : "");
+    int64_t n_esc = 0, n_fin = 0;
+    // measured on C3: beside the 8-word level alone the traceback gains nothing (both are issue-bound: 148.8 vs 140.6 ms per step),
+    // with the 16-word level (1.5 waves per SIMD, long tail) the overlap saves 10 ms (170 vs 180)
+    const bool overlap = cap >= 16;
+    if (cap >= 8 && !overlap) {
+        tk = hite_prof_begin(ctx, wname, st);
         for (int level = 8; level <= cap; level *= 2) {
             int64_t cnt = 0;
             ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 0, level, cap, flag, nullptr, pos, colpos, scan_tmp, list, nullptr, &cnt, nullptr));
             if (cnt == 0) continue;
-            const dim3 grid((unsigned)((cnt + 63) / 64));
-            if (level == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<8>), grid, dim3(64), 0, st, P, list, (int)cnt);
-            else if (level == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<16>), grid, dim3(64), 0, st, P, list, (int)cnt);
-            else hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<32>), grid, dim3(64), 0, st, P, list, (int)cnt);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<8>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, P, list, (int)cnt);
         }
         hite_prof_end(ctx, tk, st);
     }
-    // ---- traceback on the slice of the run kept
-    snprintf(name, sizeof name, "align_tb%s", tag ? tag : "");
-    tk = hite_prof_begin(ctx, name, st);
-    hipLaunchKernelGGL(align_tb_kernel, dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
-    hite_prof_end(ctx, tk, st);
+    if (overlap) {
+        ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 2, 0, cap, flag, nullptr, pos, colpos, scan_tmp, list_esc, nullptr, &n_esc, nullptr));
+        if (n_esc > 0)
+            ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 3, 0, cap, flag, nullptr, pos, colpos, scan_tmp, list_fin, nullptr, &n_fin, nullptr));
+    }
+    if (n_esc > 0) {
+        if (n_fin > 0) {
+            tk = hite_prof_begin(ctx, name, st);
+            hipLaunchKernelGGL(align_tb_kernel, dim3((unsigned)((n_fin + 63) / 64)), dim3(64), 0, st, P, list_fin, (int)n_fin);
+            hite_prof_end(ctx, tk, st);
+        }
+        hipStream_t s2 = S->st2;
+        tk = hite_prof_begin(ctx, wname, s2);
+        for (int level = 8; level <= cap; level *= 2) {
+            int64_t cnt = 0;
+            ACHK(build_list(ctx, S, s2, total_rows, order, strips, P, 0, level, cap, flag2, nullptr, pos2, colpos, scan_tmp2, list, nullptr, &cnt, nullptr, 8));
+            if (cnt == 0) continue;
+            const dim3 grid((unsigned)((cnt + 63) / 64));
+            if (level == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<8>), grid, dim3(64), 0, s2, P, list, (int)cnt);
+            else if (level == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<16>), grid, dim3(64), 0, s2, P, list, (int)cnt);
+            else hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<32>), grid, dim3(64), 0, s2, P, list, (int)cnt);
+        }
+        hite_prof_end(ctx, tk, s2);
+        HITE_CHECK(ctx, hipEventRecord(S->ev, s2));
+        HITE_CHECK(ctx, hipStreamWaitEvent(st, S->ev, 0));
+        tk = hite_prof_begin(ctx, name, st);
+        hipLaunchKernelGGL(align_tb_kernel, dim3((unsigned)((n_esc + 63) / 64)), dim3(64), 0, st, P, list_esc, (int)n_esc);
+        hite_prof_end(ctx, tk, st);
+    } else {
+        // ---- traceback on the slice of the run kept
+        tk = hite_prof_begin(ctx, name, st);
+        hipLaunchKernelGGL(align_tb_kernel, dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
+        hite_prof_end(ctx, tk, st);
+    }
     HITE_CHECK(ctx, hipGetLastError());
     // ---- fall-back: the pairs whose path left the slice
     {
