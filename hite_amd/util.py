@@ -564,6 +564,83 @@ def cons_from_mafft_v1(align_file, device=0):
     return get_ctx(device).msa_consensus([[align_contigs[name] for name in align_names]])[0]
 
 
+def split_internal_out(merge_te_file, output_dir):
+    """Util.py:14577 -- LTR internal sequences ('-int#' in the name) and the rest of a merged library go to two files"""
+    names, contigs = read_fasta(merge_te_file)
+    other_path, internal_path = os.path.join(output_dir, "merged_other.fa"), os.path.join(output_dir, "merged_internal.fa")
+    store_fasta({n: contigs[n] for n in names if "-int#" not in n}, other_path)
+    store_fasta({n: contigs[n] for n in names if "-int#" in n}, internal_path)
+    return other_path, internal_path
+
+
+def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_threshold, debug, device=0):
+    """deredundant_for_LTR_v5 (Util.py:12202-12337, the library de-duplication of panHiTE, config C5), same arguments.
+    Reference: blastn all-vs-all of the library -> chunked fragment chaining (process_blast_results_in_chunks +
+    FMEA_new1_parallel_large) -> greedy clusters (cluster_sequences_from_chunks) -> per cluster generate_cons_v1 (mafft ->
+    Ninja sub-clusters -> mafft -> cons_from_mafft_v1) -> cd-hit-est.  Here: the library is packed as a genome and searched
+    against itself by hite_seed_allvsall (where the reference runs blastn), chaining / clustering / consensus are the pinned
+    device stages (hite_lib_chain, hite_lib_cluster, hite_msa_consensus), the alignment of a cluster is the star alignment
+    (where the reference runs mafft; centre = first member); the Ninja split (external tool) is not made: one consensus per
+    cluster, named like the reference names it (the cluster's last member); cd-hit-est runs when it is installed.
+    Writes <redundant_ltr>.tmp.cons and <redundant_ltr>.cons, returns the former like the reference."""
+    names, contigs = read_fasta(redundant_ltr)
+    cons_path, final_path = redundant_ltr + ".tmp.cons", redundant_ltr + ".cons"
+    if not names:
+        store_fasta({}, cons_path)
+        store_fasta({}, final_path)
+        return cons_path
+    if len(names) >= 65535:
+        raise ValueError("library of %d sequences: the all-vs-all stage addresses < 65535 segments per call" % len(names))
+    ctx = get_ctx(device)
+    ctx.genome_pack([contigs[n] for n in names])
+    ctx.release_copy_index()
+    _PACKED["path"] = None
+    lens = [len(contigs[n]) for n in names]
+    tab = ctx.seed_allvsall(seg_len=max(lens))
+    # the seeding stage reports a hit from its first to its last anchor; blastn extends an alignment to the ends of the
+    # sequences when they keep matching.  Hits are therefore stretched along their diagonal over a short overhang (<= 30 bases on
+    # both sequences): without it two copies of one family miss the 0.95 coverage rule by the few bases outside the anchors.
+    L = np.asarray(lens, dtype=np.int64)
+    q, s = np.asarray(tab["qseg"]), np.asarray(tab["sseg"])
+    qs, qe = np.asarray(tab["qs"]).copy(), np.asarray(tab["qe"]).copy()
+    ss, se = np.asarray(tab["ss"]).copy(), np.asarray(tab["se"]).copy()
+    fwd = ss <= se
+    left = np.minimum(qs - 1, np.where(fwd, ss - 1, L[s] - ss))
+    right = np.minimum(L[q] - qe, np.where(fwd, L[s] - se, se - 1))
+    left = np.where(left <= 30, left, 0)
+    right = np.where(right <= 30, right, 0)
+    qs -= left; qe += right
+    ss = np.where(fwd, ss - left, ss + left)
+    se = np.where(fwd, se + right, se - right)
+    recs = ctx.lib_chain(q, s, qs, qe, ss, se, lens, coverage_threshold, 5_000_000)
+    clusters = ctx.lib_cluster(recs, lens, coverage_threshold)
+    groups = [[contigs[names[i]] for i in cl] for cl in clusters if len(cl) >= 1]
+    aligned = ctx.star_msa(groups) if groups else []
+    all_cons, clustered = {}, set()
+    rows = [[bytes(r).decode() for r in m] if m is not None else None for m in aligned]
+    cons = ctx.msa_consensus([r for r in rows if r is not None]) if any(r is not None for r in rows) else []
+    k = 0
+    for cl, r in zip([c for c in clusters if len(c) >= 1], rows):
+        clustered.update(cl)
+        if r is None:
+            for i in cl:
+                all_cons[names[i]] = contigs[names[i]]
+            continue
+        all_cons[names[cl[-1]]] = cons[k] if cons[k] else contigs[names[cl[-1]]]
+        k += 1
+    for i, n in enumerate(names):      # sequences outside every cluster pass unchanged
+        if i not in clustered:
+            all_cons[n] = contigs[n]
+    store_fasta(all_cons, cons_path)
+    if shutil.which("cd-hit-est"):
+        subprocess.run("cd-hit-est -aS 0.95 -aL 0.95 -c %s -G 0 -g 1 -A 80 -i %s -o %s -T 0 -M 0 > /dev/null 2>&1" %
+                       (coverage_threshold, cons_path, final_path), shell=True, check=False)
+    else:
+        sys.stderr.write("[hite_amd] cd-hit-est not found: the fragment-merging pass after the consensus step is skipped\n")
+        shutil.copyfile(cons_path, final_path)
+    return cons_path
+
+
 def mask_genome_intactTE(TE_lib, genome_path, work_dir=None, thread=1, ref_index=0, debug=0, device=0):
     """mask_genome_intactTE (Util.py:6389-6431): the full-length copies (coverage >= 0.95 of the library sequence) of the
     TEs found so far are replaced by N in the chunk, written to <genome_path>.masked.  The copies come from the build's

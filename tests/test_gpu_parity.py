@@ -1080,3 +1080,44 @@ def test_reference_signatures_and_prev_TE_lock(ctx, tmp_path):
     assert list(kept) == ["genome-TIR_0_0#DNA/hAT", "genome-TIR_0_1"]
     pn, _pc = util.read_fasta(str(prev))
     assert pn == ["old_0", "genome-TIR_0_0#DNA/hAT", "genome-TIR_0_1"] and os.path.exists(str(prev) + ".lock")
+
+
+def test_pan_remove_redundancy_script(ctx, tmp_path):
+    """config C5 in miniature: the TE libraries of several genomes, concatenated, come out as one non-redundant library:
+    one consensus per family (copies 1-4 % apart collapse), unrelated sequences pass unchanged, LTR internal sequences
+    ('-int#') are handled apart with their own coverage threshold"""
+    import os
+    import subprocess
+    import sys as _sys
+
+    from hite_amd import util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rng = np.random.default_rng(515)
+    recs, fams = [], []
+    for f in range(6):
+        cons = casegen.rand_seq(rng, int(rng.integers(400, 1500)))
+        fams.append(cons)
+        internal = f >= 4
+        for g in range(int(rng.integers(3, 7))):     # one copy per "genome"
+            s = casegen.mutate(rng, cons, float(rng.uniform(0.01, 0.04)))
+            recs.append(("G%d-fam%d%s#%s" % (g, f, "-int" if internal else "", "LTR/Gypsy" if internal else "DNA/hAT"), s))
+    for k in range(5):
+        recs.append(("single%d#Unknown" % k, casegen.rand_seq(rng, int(rng.integers(300, 900)))))
+    order = rng.permutation(len(recs))
+    merged = tmp_path / "merged.fa"
+    merged.write_text("".join(">%s\n%s\n" % recs[i] for i in order))
+    out = tmp_path / "out"
+    rc = subprocess.run([_sys.executable, root + "/hite_amd/scripts/pan_remove_redundancy.py", "--merge_te_file", str(merged), "--threads", "2",
+                         "--output_dir", str(out), "-w", str(tmp_path)], capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stderr[-2000:]
+    names, seqs = util.read_fasta(str(out / "panTE.fa"))
+    assert sum(n.startswith("single") for n in names) == 5
+    for f, cons in enumerate(fams):
+        mine = [n for n in names if "-fam%d" % f in n]
+        assert len(mine) == 1, (f, mine)          # the family collapsed into one record ...
+        got = seqs[mine[0]]
+        assert abs(len(got) - len(cons)) <= 0.02 * len(cons)
+        d = O.nw_distance(got, cons)
+        assert d <= 0.03 * len(cons) * 3, (f, d, len(cons))   # ... whose consensus is closer to the family than its members
+    assert len(names) == 11
