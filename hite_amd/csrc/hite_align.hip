@@ -200,6 +200,12 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
         for (int w = 0; w < NW; w++) { A0[w] = 0; A1[w] = 0; AN[w] = 0xffffffffu; }
     }
     int stop = AL_GAP * H, LO = -(1 << 28), HI = 1 << 28, status = 0;
+    // what a strip needs from memory is fetched one strip ahead (the loads of a strip used to be its exposed latency): the 16
+    // row bases of the next strip, and a window of three plane words Wa, Wb, Wc = words fq, fq + 1, fq + 2 of the rows that
+    // enter below the band (the band moves <= 32 rows per strip, so the next strip starts in word fq or fq + 1)
+    int fq = (t + W + AL_PADR) >> 5;
+    uint4 Wa = make_uint4(0, 0, 0xffffffffu, 0), Wb = Wa, Wc = Wa, bnext = make_uint4(0, 0, 0, 0);
+    if (act) { Wa = pl[fq]; Wb = pl[fq + 1]; Wc = pl[fq + 2]; bnext = *reinterpret_cast<const uint4 *>(b); }
     for (int k = 0; k * AL_STRIP < nmax; k++) {
         const bool sa = act && k * AL_STRIP < n;
         uint4 bw = make_uint4(0, 0, 0, 0);
@@ -209,52 +215,66 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
             uint4 *ck = reinterpret_cast<uint4 *>(P.ckpt + (rec0 + k) * 8);
             ck[0] = make_uint4(X2[S0], X2[S0 + 1], X1[S0], X1[S0 + 1]);
             ck[1] = make_uint4(X0[S0], X0[S0 + 1], (uint32_t)(t + 32 * S0), 0u);
-            bw = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
+            bw = bnext;
+            if ((k + 1) * AL_STRIP < n) bnext = *reinterpret_cast<const uint4 *>(b + (k + 1) * AL_STRIP);
             const int fx = t + W + AL_PADR;
-            const uint4 F = pl[fx >> 5], G = pl[(fx >> 5) + 1];
+            if ((fx >> 5) != fq) { Wa = Wb; Wb = Wc; fq++; Wc = pl[fq + 2]; }      // (at most one word further than a strip ago)
             const uint32_t sh = (uint32_t)fx & 31u;
-            f0 = alignbit(G.x, F.x, sh); f1 = alignbit(G.y, F.y, sh); fn = alignbit(G.z, F.z, sh);
+            f0 = alignbit(Wb.x, Wa.x, sh); f1 = alignbit(Wb.y, Wa.y, sh); fn = alignbit(Wb.z, Wa.z, sh);
         }
 #pragma unroll
         for (int cc = 0; cc < AL_STRIP; cc++) {
             const int j = k * AL_STRIP + cc + 1;
             if (sa && j <= n) {
-                // ---- steering from column j-1 (middle 64 rows), clamps
-                const int ds = slope_count(X2[S0], X1[S0], X0[S0]) + slope_count(X2[S0 + 1], X1[S0 + 1], X0[S0 + 1]);
-                int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
-                const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
-                if (t + s > hi_t) s = hi_t - t;
-                if (t + s < lo_t) s = lo_t - t;
-                if ((unsigned)s > 2u) { status = 2; act = false; s = 1; }
-                stop += plane_sum(X2[0], X1[0], X0[0], (1u << s) - 1u) - AL_GAP * s + AL_GAP;
-                uint32_t in2 = 0, in1 = 0, in0 = 0;
-                if (NW > 2) { in2 = X2[S0 + 2 < NW ? S0 + 2 : 0] & 3u; in1 = X1[S0 + 2 < NW ? S0 + 2 : 0] & 3u; in0 = X0[S0 + 2 < NW ? S0 + 2 : 0] & 3u; }
-                // ---- the band moves down by s rows (rows that enter: +3)
+                if ((cc & 3) == 0) {
+                    // ---- the band moves in every fourth column only, by 0 / 4 / 8 rows: steering from column j-1 (middle 64
+                    //      rows), clamps (never beyond the row m - H; far enough for the moves still to come)
+                    const int ds = slope_count(X2[S0], X1[S0], X0[S0]) + slope_count(X2[S0 + 1], X1[S0 + 1], X0[S0 + 1]);
+                    int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 8 : 4);
+                    const int tr = m - H;
+                    if (t + s > tr) s = (tr - t) & ~3;
+                    const int need = tr - 3 - 8 * ((n - j) >> 2) - t;
+                    if (s < need) s = (need + 3) & ~3;
+                    if (s > 8) { status = 2; act = false; s = 8; }
+                    stop += plane_sum(X2[0], X1[0], X0[0], (1u << s) - 1u) - AL_GAP * s;
+                    unsigned long long rec = (unsigned long long)(s >> 2);
+                    if (NW > 2) {
+                        rec |= (unsigned long long)(X2[S0 + 2 < NW ? S0 + 2 : 0] & 0xffu) << 2;
+                        rec |= (unsigned long long)(X1[S0 + 2 < NW ? S0 + 2 : 0] & 0xffu) << 10;
+                        rec |= (unsigned long long)(X0[S0 + 2 < NW ? S0 + 2 : 0] & 0xffu) << 18;
+                    }
+                    brec[(cc >> 2) * 2] = (uint32_t)rec;
+                    // rows that enter: +3
 #pragma unroll
-                for (int w = 0; w < NW - 1; w++) {
-                    X2[w] = alignbit(X2[w + 1], X2[w], (uint32_t)s); X1[w] = alignbit(X1[w + 1], X1[w], (uint32_t)s);
-                    X0[w] = alignbit(X0[w + 1], X0[w], (uint32_t)s);
-                    A0[w] = alignbit(A0[w + 1], A0[w], (uint32_t)s); A1[w] = alignbit(A1[w + 1], A1[w], (uint32_t)s);
-                    AN[w] = alignbit(AN[w + 1], AN[w], (uint32_t)s);
+                    for (int w = 0; w < NW - 1; w++) {
+                        X2[w] = alignbit(X2[w + 1], X2[w], (uint32_t)s); X1[w] = alignbit(X1[w + 1], X1[w], (uint32_t)s);
+                        X0[w] = alignbit(X0[w + 1], X0[w], (uint32_t)s);
+                        A0[w] = alignbit(A0[w + 1], A0[w], (uint32_t)s); A1[w] = alignbit(A1[w + 1], A1[w], (uint32_t)s);
+                        AN[w] = alignbit(AN[w + 1], AN[w], (uint32_t)s);
+                    }
+                    X2[NW - 1] = alignbit(0xffffffffu, X2[NW - 1], (uint32_t)s);
+                    X1[NW - 1] = alignbit(0xffffffffu, X1[NW - 1], (uint32_t)s);
+                    X0[NW - 1] = X0[NW - 1] >> s;
+                    A0[NW - 1] = alignbit(f0, A0[NW - 1], (uint32_t)s); A1[NW - 1] = alignbit(f1, A1[NW - 1], (uint32_t)s);
+                    AN[NW - 1] = alignbit(fn, AN[NW - 1], (uint32_t)s);
+                    f0 >>= s; f1 >>= s; fn >>= s;
+                    t += s;
+                    if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
+                    if (t + W < m) { const int jl = j + 3 < n ? j + 3 : n; const int v = t + W - jl; HI = v < HI ? v : HI; }
                 }
-                X2[NW - 1] = alignbit(0xffffffffu, X2[NW - 1], (uint32_t)s);
-                X1[NW - 1] = alignbit(0xffffffffu, X1[NW - 1], (uint32_t)s);
-                X0[NW - 1] = X0[NW - 1] >> s;
-                A0[NW - 1] = alignbit(f0, A0[NW - 1], (uint32_t)s); A1[NW - 1] = alignbit(f1, A1[NW - 1], (uint32_t)s);
-                AN[NW - 1] = alignbit(fn, AN[NW - 1], (uint32_t)s);
-                f0 >>= s; f1 >>= s; fn >>= s;
-                t += s;
-                if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
-                if (t + W < m) { const int v = t + W - j; HI = v < HI ? v : HI; }
+                stop += AL_GAP;
                 // ---- column
                 const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
                 const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
                 uint32_t tap[5] = {0, 0, 1, 1, 0};
                 bp_core<NW, false, (NW > 2 ? S0 : -1)>(X2, X1, X0, A0, A1, AN, bm, 0u, 0u, 1u, 1u, 0u, nullptr, nullptr, tap);
                 if (NW > 2) {
-                    const uint32_t r16 = (uint32_t)s | (in2 << 2) | (in1 << 4) | (in0 << 6) | (tap[0] << 8) | (tap[1] << 9) | (tap[2] << 10) |
-                                         (tap[3] << 11) | (tap[4] << 12);
-                    brec[cc >> 1] |= r16 << (16 * (cc & 1));
+                    // 5 carry bits per column: bits 26 + 5 c of the group's 64-bit record
+                    const uint32_t c5 = tap[0] | (tap[1] << 1) | (tap[2] << 2) | (tap[3] << 3) | (tap[4] << 4);
+                    const int sh = 26 + 5 * (cc & 3);
+                    if (sh + 5 <= 32) brec[(cc >> 2) * 2] |= c5 << sh;
+                    else if (sh >= 32) brec[(cc >> 2) * 2 + 1] |= c5 << (sh - 32);
+                    else { brec[(cc >> 2) * 2] |= c5 << sh; brec[(cc >> 2) * 2 + 1] |= c5 >> (32 - sh); }
                 }
             }
         }
@@ -267,9 +287,13 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
     if (n > 0) {
         int U = -1, kstar = -1;
         if (status == 0) {
-            int u = stop - AL_GAP * H;   // t_n = m - H: row m is bit H - 1
+            int u = stop - AL_GAP * H;   // row m is bit H - 1 + (m - H - t_n), 0 .. 3 bits into word NW / 2
 #pragma unroll
             for (int w = 0; w < NW / 2; w++) u += plane_sum(X2[w], X1[w], X0[w], 0xffffffffu);
+            {
+                const int extra = m - H - t;          // 0 .. 3
+                u += plane_sum(X2[NW / 2], X1[NW / 2], X0[NW / 2], (1u << extra) - 1u) - AL_GAP * extra;
+            }
             U = u;
             const int d = m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
             int E = dmin - LO;
@@ -310,11 +334,10 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     const int li = blockIdx.x * 64 + threadIdx.x;
     const int g = li < nlist ? list[li] : -1;
     int m = 0, n = 0, g0 = 0, c = 0;
-    bool hb = false;
     if (g >= 0) {
         c = P.row_cand[g];
         g0 = P.row_first[c];
-        if (g != g0 && P.st[g] == 0) { m = P.win_len[g0]; n = P.win_len[g]; hb = P.lvl[g] > 2; }
+        if (g != g0 && P.st[g] == 0) { m = P.win_len[g0]; n = P.win_len[g]; }   // (every band is wider than the slice: records exist)
     }
     const int nmax = wave_max_i32(n);
     if (nmax == 0) return;
@@ -327,74 +350,97 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     OpsOut out;
     out.ops = ops; out.acc = 0ull; out.cnt = 0;
     const int Kmax = (nmax + AL_STRIP - 1) / AL_STRIP;
+    // software pipeline over the strips (last to first): the check point of strip k-2, the boundary record and the row bases of
+    // strip k-1 and -- with the position the check point of strip k-1 gives -- its centre planes are fetched while strip k is
+    // computed; without it every strip began with two dependent memory round trips
+    const int K = (n + AL_STRIP - 1) / AL_STRIP;      // this lane's strips (0 = nothing to do)
+    uint4 ckA0, ckA1, ckB0, ckB1, bdA0, bdA1, bwA, plA[4];
+    ckA0 = ckA1 = ckB0 = ckB1 = bdA0 = bdA1 = bwA = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int w = 0; w < 4; w++) plA[w] = make_uint4(0, 0, 0, 0);
+    {
+        const int k = Kmax - 1;
+        if (k < K) {
+            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k) * 8);
+            ckA0 = ck[0]; ckA1 = ck[1];
+            const uint4 *bp = reinterpret_cast<const uint4 *>(P.bnd + (rec0 + k) * 8);
+            bdA0 = bp[0]; bdA1 = bp[1];
+            bwA = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
+            const int q0 = ((int)ckA1.z + AL_PADR) >> 5;
+#pragma unroll
+            for (int w = 0; w < 4; w++) plA[w] = pl[q0 + w];
+        }
+        if (k >= 1 && k - 1 < K) {
+            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k - 1) * 8);
+            ckB0 = ck[0]; ckB1 = ck[1];
+        }
+    }
     for (int k = Kmax - 1; k >= 0; k--) {
-        const bool sa = n > 0 && !fail && i > 0 && k * AL_STRIP < n;
-        if (!__any(sa)) continue;
+        const bool sa = n > 0 && !fail && i > 0 && k < K;
+        // ---- fetch for the strips to come (A = strip k, B = check point of strip k-1)
+        uint4 ckC0 = make_uint4(0, 0, 0, 0), ckC1 = ckC0, bdB0 = ckC0, bdB1 = ckC0, bwB = ckC0, plB[4];
+#pragma unroll
+        for (int w = 0; w < 4; w++) plB[w] = ckC0;
+        if (k >= 1 && k - 1 < K && !fail && i > 0) {      // (its check point arrived a strip ago, or in the prologue)
+            const uint4 *bp = reinterpret_cast<const uint4 *>(P.bnd + (rec0 + k - 1) * 8);
+            bdB0 = bp[0]; bdB1 = bp[1];
+            bwB = *reinterpret_cast<const uint4 *>(b + (k - 1) * AL_STRIP);
+            const int q0 = ((int)ckB1.z + AL_PADR) >> 5;
+#pragma unroll
+            for (int w = 0; w < 4; w++) plB[w] = pl[q0 + w];
+        }
+        if (k >= 2 && k - 2 < K && !fail && i > 0) {
+            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k - 2) * 8);
+            ckC0 = ck[0]; ckC1 = ck[1];
+        }
+        if (__any(sa)) {
         uint32_t X2[2], X1[2], X0[2], A0[2], A1[2], AN[2];
         uint32_t f0 = 0, f1 = 0, fn = 0;
         uint4 bw = make_uint4(0, 0, 0, 0);
         uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int t = 0;
         if (sa) {
-            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k) * 8);
-            const uint4 c0 = ck[0], c1 = ck[1];
-            X2[0] = c0.x; X2[1] = c0.y; X1[0] = c0.z; X1[1] = c0.w; X0[0] = c1.x; X0[1] = c1.y;
-            t = (int)c1.z;
-            bw = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
-            if (hb) {
-                const uint4 *bp = reinterpret_cast<const uint4 *>(P.bnd + (rec0 + k) * 8);
-                const uint4 b0 = bp[0], b1 = bp[1];
-                brec[0] = b0.x; brec[1] = b0.y; brec[2] = b0.z; brec[3] = b0.w;
-                brec[4] = b1.x; brec[5] = b1.y; brec[6] = b1.z; brec[7] = b1.w;
-            }
-            const int x0 = t + AL_PADR;
-            const int q0 = x0 >> 5;
-            const uint32_t sh = (uint32_t)x0 & 31u;
-            uint4 wd[4];
-#pragma unroll
-            for (int w = 0; w < 4; w++) wd[w] = pl[q0 + w];
+            X2[0] = ckA0.x; X2[1] = ckA0.y; X1[0] = ckA0.z; X1[1] = ckA0.w; X0[0] = ckA1.x; X0[1] = ckA1.y;
+            t = (int)ckA1.z;
+            bw = bwA;
+            brec[0] = bdA0.x; brec[1] = bdA0.y; brec[2] = bdA0.z; brec[3] = bdA0.w;
+            brec[4] = bdA1.x; brec[5] = bdA1.y; brec[6] = bdA1.z; brec[7] = bdA1.w;
+            const uint32_t sh = (uint32_t)(t + AL_PADR) & 31u;
 #pragma unroll
             for (int w = 0; w < 2; w++) {
-                A0[w] = alignbit(wd[w + 1].x, wd[w].x, sh); A1[w] = alignbit(wd[w + 1].y, wd[w].y, sh);
-                AN[w] = alignbit(wd[w + 1].z, wd[w].z, sh);
+                A0[w] = alignbit(plA[w + 1].x, plA[w].x, sh); A1[w] = alignbit(plA[w + 1].y, plA[w].y, sh);
+                AN[w] = alignbit(plA[w + 1].z, plA[w].z, sh);
             }
-            f0 = alignbit(wd[3].x, wd[2].x, sh); f1 = alignbit(wd[3].y, wd[2].y, sh); fn = alignbit(wd[3].z, wd[2].z, sh);
+            f0 = alignbit(plA[3].x, plA[2].x, sh); f1 = alignbit(plA[3].y, plA[2].y, sh); fn = alignbit(plA[3].z, plA[2].z, sh);
         } else {
 #pragma unroll
             for (int w = 0; w < 2; w++) { X2[w] = 0; X1[w] = 0; X0[w] = 0; A0[w] = 0; A1[w] = 0; AN[w] = 0; }
         }
         unsigned long long dg[AL_STRIP], up[AL_STRIP];
-        uint32_t sbits = 0;
+        uint32_t sbits = 0;     // 2 bits per group of four columns: rows the band moved / 4
 #pragma unroll
         for (int cc = 0; cc < AL_STRIP; cc++) {
             const int jc = k * AL_STRIP + cc + 1;
             dg[cc] = 0ull; up[cc] = 0ull;
             if (sa && jc <= n) {
-                const uint32_t r16 = (brec[cc >> 1] >> (16 * (cc & 1))) & 0xffffu;
-                int s;
-                uint32_t in2, in1, in0, cin, vpc, h2c, h1c, h0c;
-                if (hb) {
-                    s = (int)(r16 & 3u); in2 = (r16 >> 2) & 3u; in1 = (r16 >> 4) & 3u; in0 = (r16 >> 6) & 3u;
-                    cin = (r16 >> 8) & 1u; vpc = (r16 >> 9) & 1u; h2c = (r16 >> 10) & 1u; h1c = (r16 >> 11) & 1u; h0c = (r16 >> 12) & 1u;
-                } else {   // a 2-word band IS the slice: same steering as the forward pass
-                    const int ds = slope_count(X2[0], X1[0], X0[0]) + slope_count(X2[1], X1[1], X0[1]);
-                    s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
-                    const int hi_t = m - 32, lo_t = m - 32 - 2 * (n - jc);
-                    if (t + s > hi_t) s = hi_t - t;
-                    if (t + s < lo_t) s = lo_t - t;
-                    in2 = 3u; in1 = 3u; in0 = 0u; cin = 0u; vpc = 0u; h2c = 1u; h1c = 1u; h0c = 0u;
+                const uint32_t rlo = brec[(cc >> 2) * 2], rhi = brec[(cc >> 2) * 2 + 1];
+                if ((cc & 3) == 0) {
+                    const uint32_t s = (rlo & 3u) << 2;
+                    const uint32_t in2 = (rlo >> 2) & 0xffu, in1 = (rlo >> 10) & 0xffu, in0 = (rlo >> 18) & 0xffu;
+                    X2[0] = alignbit(X2[1], X2[0], s); X1[0] = alignbit(X1[1], X1[0], s); X0[0] = alignbit(X0[1], X0[0], s);
+                    A0[0] = alignbit(A0[1], A0[0], s); A1[0] = alignbit(A1[1], A1[0], s); AN[0] = alignbit(AN[1], AN[0], s);
+                    X2[1] = alignbit(in2, X2[1], s); X1[1] = alignbit(in1, X1[1], s); X0[1] = alignbit(in0, X0[1], s);
+                    A0[1] = alignbit(f0, A0[1], s); A1[1] = alignbit(f1, A1[1], s); AN[1] = alignbit(fn, AN[1], s);
+                    f0 >>= s; f1 >>= s; fn >>= s;
+                    t += (int)s;
+                    sbits |= (rlo & 3u) << (2 * (cc >> 2));
                 }
-                X2[0] = alignbit(X2[1], X2[0], (uint32_t)s); X1[0] = alignbit(X1[1], X1[0], (uint32_t)s); X0[0] = alignbit(X0[1], X0[0], (uint32_t)s);
-                A0[0] = alignbit(A0[1], A0[0], (uint32_t)s); A1[0] = alignbit(A1[1], A1[0], (uint32_t)s); AN[0] = alignbit(AN[1], AN[0], (uint32_t)s);
-                X2[1] = alignbit(in2, X2[1], (uint32_t)s); X1[1] = alignbit(in1, X1[1], (uint32_t)s); X0[1] = alignbit(in0, X0[1], (uint32_t)s);
-                A0[1] = alignbit(f0, A0[1], (uint32_t)s); A1[1] = alignbit(f1, A1[1], (uint32_t)s); AN[1] = alignbit(fn, AN[1], (uint32_t)s);
-                f0 >>= s; f1 >>= s; fn >>= s;
-                t += s;
-                sbits |= (uint32_t)s << (2 * cc);
+                const int sh = 26 + 5 * (cc & 3);
+                const uint32_t c5 = (sh + 5 <= 32 ? rlo >> sh : (sh >= 32 ? rhi >> (sh - 32) : (rlo >> sh) | (rhi << (32 - sh)))) & 31u;
                 const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
                 const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
                 uint32_t tap[5], dgc[2], upc[2];
-                bp_core<2, true, -1>(X2, X1, X0, A0, A1, AN, bm, cin, vpc, h2c, h1c, h0c, dgc, upc, tap);
+                bp_core<2, true, -1>(X2, X1, X0, A0, A1, AN, bm, c5 & 1u, (c5 >> 1) & 1u, (c5 >> 2) & 1u, (c5 >> 3) & 1u, (c5 >> 4) & 1u, dgc, upc, tap);
                 dg[cc] = ((unsigned long long)dgc[1] << 32) | dgc[0];
                 up[cc] = ((unsigned long long)upc[1] << 32) | upc[0];
             }
@@ -426,8 +472,12 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
                     }
                 }
             }
-            tcur -= (int)((sbits >> (2 * cc)) & 3u);
+            if ((cc & 3) == 0) tcur -= (int)(((sbits >> (2 * (cc >> 2))) & 3u) << 2);
         }
+        }
+        ckA0 = ckB0; ckA1 = ckB1; ckB0 = ckC0; ckB1 = ckC1; bdA0 = bdB0; bdA1 = bdB1; bwA = bwB;
+#pragma unroll
+        for (int w = 0; w < 4; w++) plA[w] = plB[w];
     }
     if (n > 0) {
         if (fail) P.st[g] = 1;
@@ -479,26 +529,30 @@ __global__ void __launch_bounds__(64) align_wide_fwd_kernel(AlignArgs P, const i
             const uint32_t sh = (uint32_t)fx & 31u;
             f0 = alignbit(G.x, F.x, sh); f1 = alignbit(G.y, F.y, sh); fn = alignbit(G.z, F.z, sh);
         }
-        const int dv = slope_count(X2, X1, X0);
-        const int ds = __builtin_amdgcn_readlane(dv, S0) + __builtin_amdgcn_readlane(dv, S0 + 1);
-        int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 2 : 1);
-        const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
-        if (t + s > hi_t) s = hi_t - t;
-        if (t + s < lo_t) s = lo_t - t;
-        if ((unsigned)s > 2u) { status = 2; break; }
-        const uint32_t smask = (1u << s) - 1u;
-        stop += plane_sum((uint32_t)__builtin_amdgcn_readlane((int)X2, 0), (uint32_t)__builtin_amdgcn_readlane((int)X1, 0),
-                          (uint32_t)__builtin_amdgcn_readlane((int)X0, 0), smask) - AL_GAP * s + AL_GAP;
-        X2 = alignbit(lane_above(X2, 0xffffffffu), X2, (uint32_t)s);
-        X1 = alignbit(lane_above(X1, 0xffffffffu), X1, (uint32_t)s);
-        X0 = alignbit(lane_above(X0, 0u), X0, (uint32_t)s);
-        A0 = alignbit(lane_above(A0, f0), A0, (uint32_t)s);
-        A1 = alignbit(lane_above(A1, f1), A1, (uint32_t)s);
-        AN = alignbit(lane_above(AN, fn), AN, (uint32_t)s);
-        f0 >>= s; f1 >>= s; fn >>= s;
-        t += s;
-        if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
-        if (t + W < m) { const int v = t + W - j; HI = v < HI ? v : HI; }
+        if ((cc & 3) == 0) {   // the band moves in every fourth column only, by 0 / 4 / 8 rows (same rule as align_fwd_kernel)
+            const int dv = slope_count(X2, X1, X0);
+            const int ds = __builtin_amdgcn_readlane(dv, S0) + __builtin_amdgcn_readlane(dv, S0 + 1);
+            int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 8 : 4);
+            const int tr = m - H;
+            if (t + s > tr) s = (tr - t) & ~3;
+            const int need = tr - 3 - 8 * ((n - j) >> 2) - t;
+            if (s < need) s = (need + 3) & ~3;
+            if (s > 8) { status = 2; break; }
+            const uint32_t smask = (1u << s) - 1u;
+            stop += plane_sum((uint32_t)__builtin_amdgcn_readlane((int)X2, 0), (uint32_t)__builtin_amdgcn_readlane((int)X1, 0),
+                              (uint32_t)__builtin_amdgcn_readlane((int)X0, 0), smask) - AL_GAP * s;
+            X2 = alignbit(lane_above(X2, 0xffffffffu), X2, (uint32_t)s);
+            X1 = alignbit(lane_above(X1, 0xffffffffu), X1, (uint32_t)s);
+            X0 = alignbit(lane_above(X0, 0u), X0, (uint32_t)s);
+            A0 = alignbit(lane_above(A0, f0), A0, (uint32_t)s);
+            A1 = alignbit(lane_above(A1, f1), A1, (uint32_t)s);
+            AN = alignbit(lane_above(AN, fn), AN, (uint32_t)s);
+            f0 >>= s; f1 >>= s; fn >>= s;
+            t += s;
+            if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
+            if (t + W < m) { const int jl = j + 3 < n ? j + 3 : n; const int v = t + W - jl; HI = v < HI ? v : HI; }
+        }
+        stop += AL_GAP;
         const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
         const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
         const uint32_t eq = ~((A0 ^ bm.m0) | (A1 ^ bm.m1) | AN | bm.inv);
@@ -525,7 +579,9 @@ __global__ void __launch_bounds__(64) align_wide_fwd_kernel(AlignArgs P, const i
     }
     int U = -1, kstar = -1;
     if (status == 0) {
-        U = stop - AL_GAP * H + wave_sum_i32(lane < NW / 2 ? plane_sum(X2, X1, X0, 0xffffffffu) : 0);
+        const int extra = m - H - t;   // row m is bit H - 1 + extra, extra = 0 .. 3
+        U = stop - AL_GAP * H - AL_GAP * extra +
+            wave_sum_i32(lane < NW / 2 ? plane_sum(X2, X1, X0, 0xffffffffu) : (lane == NW / 2 ? plane_sum(X2, X1, X0, (1u << extra) - 1u) : 0));
         const int d = m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
         int E = dmin - LO;
         if (HI - dmax < E) E = HI - dmax;

@@ -12,10 +12,12 @@
  *   Column j (row base b[j-1]) covers the centre rows r = t_j + 1 + k, k = 0 .. W-1, W = 32 NW;  t_0 = -W/2, so
  *   the band's middle starts on row 0.  Rows r <= 0 are virtual (D(r, j) = GAP (j - r): they never help), rows
  *   r > m are padding that never matches.
- *   Steering: s_j = t_j - t_{j-1} in {0, 1, 2}.  With d = (rows whose value exceeds the row above) - (rows whose
- *   value is below the row above) over the middle 64 rows of column j-1, s_j = 0 if d > STEER, 2 if d < -STEER,
- *   else 1; then clamped so that t_j <= m - W/2 and t_j >= m - W/2 - 2 (n - j)  (t_n = m - W/2: the band's middle
- *   ends on row m).  A pair for which the lower clamp needs a step > 2 is infeasible (status 2).
+ *   Steering: the band moves only in the columns j = 1, 5, 9, ... and then by s_j = t_j - t_{j-1} in {0, 4, 8} rows (the
+ *   product shifts its registers once per four columns).  With d = (rows whose value exceeds the row above) - (rows
+ *   whose value is below the row above) over the middle 64 rows of column j-1, s_j = 0 if d > STEER, 8 if d < -STEER,
+ *   else 4; then clamped: t_j <= m - W/2 (the step is cut to a multiple of 4), and large enough that the remaining
+ *   moves (8 rows each) can still bring t to within 3 rows below m - W/2: at the end row m sits in the band's
+ *   middle, bit W/2 - 1 + (m - W/2 - t_n).  A pair for which that needs a step > 8 is infeasible (status 2).
  *   Band edges are pessimistic: a row that enters at the bottom is GAP above the row before it in the previous
  *   column, the cell above the band's first row is GAP above its left neighbour.  Every band value is therefore
  *   the cost of a real alignment (an upper bound of D), exact whenever an optimal path to the cell stays inside
@@ -78,16 +80,20 @@ int orc_bp_pair(const uint8_t *a, int m, const uint8_t *b, int n, int NW, int fu
         const int32_t *prev = D + (size_t)(j - 1) * W;
         int32_t *cur = D + (size_t)j * W;
         /* steering from column j-1 */
-        int dsum = 0;
-        for (int k = H - 16 * SLICE_WORDS; k < H + 16 * SLICE_WORDS; k++) {
-            int dv = prev[k] - prev[k - 1];
-            dsum += (dv > 0) - (dv < 0);
+        int s = 0;
+        if ((j & 3) == 1) {
+            int dsum = 0;
+            for (int k = H - 16 * SLICE_WORDS; k < H + 16 * SLICE_WORDS; k++) {
+                int dv = prev[k] - prev[k - 1];
+                dsum += (dv > 0) - (dv < 0);
+            }
+            s = dsum > STEER ? 0 : (dsum < -STEER ? 8 : 4);
+            const int tr = m - H;                               /* t never exceeds tr */
+            if (t + s > tr) s = (tr - t) & ~3;
+            const int need = tr - 3 - 8 * ((n - j) >> 2) - t;   /* the moves still to come cover 8 rows each */
+            if (s < need) s = (need + 3) & ~3;
+            if (s > 8) { status = 2; break; }
         }
-        int s = dsum > STEER ? 0 : (dsum < -STEER ? 2 : 1);
-        const int hi_t = m - H, lo_t = m - H - 2 * (n - j);
-        if (t + s > hi_t) s = hi_t - t;
-        if (t + s < lo_t) s = lo_t - t;
-        if (s < 0 || s > 2) { status = 2; break; }
         above[j] = col_get(prev, above[j - 1], W, s - 1) + GAP;
         t += s;
         ts[j] = t;
@@ -108,7 +114,7 @@ int orc_bp_pair(const uint8_t *a, int m, const uint8_t *b, int n, int NW, int fu
     int U = -1, cert = 0;
     long kstar = -1;
     if (status == 0) {
-        U = D[(size_t)n * W + H - 1];      /* t_n = m - H: row m is index H - 1 */
+        U = D[(size_t)n * W + (m - ts[n] - 1)];     /* row m: index H - 1 .. H + 2 */
         const long d = (long)m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
         long E = dmin - LO;
         if (HI - dmax < E) E = HI - dmax;
