@@ -354,10 +354,12 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     // strip k-1 and -- with the position the check point of strip k-1 gives -- its centre planes are fetched while strip k is
     // computed; without it every strip began with two dependent memory round trips
     const int K = (n + AL_STRIP - 1) / AL_STRIP;      // this lane's strips (0 = nothing to do)
-    uint4 ckA0, ckA1, ckB0, ckB1, bdA0, bdA1, bwA, plA[4];
+    struct Pw { uint32_t x, y, z; };
+    uint4 ckA0, ckA1, ckB0, ckB1, bdA0, bdA1, bwA;
+    Pw plA[4];
     ckA0 = ckA1 = ckB0 = ckB1 = bdA0 = bdA1 = bwA = make_uint4(0, 0, 0, 0);
 #pragma unroll
-    for (int w = 0; w < 4; w++) plA[w] = make_uint4(0, 0, 0, 0);
+    for (int w = 0; w < 4; w++) { plA[w].x = 0; plA[w].y = 0; plA[w].z = 0; }
     {
         const int k = Kmax - 1;
         if (k < K) {
@@ -368,7 +370,7 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
             bwA = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
             const int q0 = ((int)ckA1.z + AL_PADR) >> 5;
 #pragma unroll
-            for (int w = 0; w < 4; w++) plA[w] = pl[q0 + w];
+            for (int w = 0; w < 4; w++) { const uint4 v = pl[q0 + w]; plA[w].x = v.x; plA[w].y = v.y; plA[w].z = v.z; }
         }
         if (k >= 1 && k - 1 < K) {
             const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k - 1) * 8);
@@ -378,16 +380,17 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     for (int k = Kmax - 1; k >= 0; k--) {
         const bool sa = n > 0 && !fail && i > 0 && k < K;
         // ---- fetch for the strips to come (A = strip k, B = check point of strip k-1)
-        uint4 ckC0 = make_uint4(0, 0, 0, 0), ckC1 = ckC0, bdB0 = ckC0, bdB1 = ckC0, bwB = ckC0, plB[4];
+        uint4 ckC0 = make_uint4(0, 0, 0, 0), ckC1 = ckC0, bdB0 = ckC0, bdB1 = ckC0, bwB = ckC0;
+        Pw plB[4];
 #pragma unroll
-        for (int w = 0; w < 4; w++) plB[w] = ckC0;
+        for (int w = 0; w < 4; w++) { plB[w].x = 0; plB[w].y = 0; plB[w].z = 0; }
         if (k >= 1 && k - 1 < K && !fail && i > 0) {      // (its check point arrived a strip ago, or in the prologue)
             const uint4 *bp = reinterpret_cast<const uint4 *>(P.bnd + (rec0 + k - 1) * 8);
             bdB0 = bp[0]; bdB1 = bp[1];
             bwB = *reinterpret_cast<const uint4 *>(b + (k - 1) * AL_STRIP);
             const int q0 = ((int)ckB1.z + AL_PADR) >> 5;
 #pragma unroll
-            for (int w = 0; w < 4; w++) plB[w] = pl[q0 + w];
+            for (int w = 0; w < 4; w++) { const uint4 v = pl[q0 + w]; plB[w].x = v.x; plB[w].y = v.y; plB[w].z = v.z; }
         }
         if (k >= 2 && k - 2 < K && !fail && i > 0) {
             const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k - 2) * 8);
