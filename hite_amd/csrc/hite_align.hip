@@ -14,13 +14,15 @@
 //     "never matches") live in registers, pre-shifted to the band's rows; one column costs about 30 NW + 40 integer
 //     instructions for 32 NW cells.  The centre planes are built once per candidate (align_planes_kernel) and shared by
 //     all of its rows; the row bases are read 16 at a time.
-//   * steering (the band follows the valley of the cost surface), pessimistic band edges and the Ukkonen
-//     certificate are described in the twin's header.  A certified pair IS the alignment of the definition.
+//   * steering (the band follows the valley of the cost surface: it moves in every fourth column, by 0, 4 or 8 rows, so that
+//     the register shifts, the steering and the book-keeping are paid once per four columns), pessimistic band edges and
+//     the Ukkonen certificate are described in the twin's header.  A certified pair IS the alignment of the definition.
 //   * no per-cell direction is ever written to HBM.  The forward pass keeps, per strip of 16 columns, a check point of
 //     the SLICE (the middle 64 rows of the band: 32 B) and 2 B per column of
 //     boundary information (the step of the band, the bits that enter the slice from the rest of the band).  The
 //     traceback pass (align_tb_kernel) re-computes the slice strip by strip into registers and walks it backwards:
-//     4 B of HBM traffic per column instead of 2 bits per DP cell.
+//     4 B of HBM traffic per column instead of 2 bits per DP cell.  Both passes fetch what the next strip needs one strip
+//     ahead (software pipeline); ops leave through a 64-bit shift register per lane (8-byte stores).
 //   * schedule per pair (hite_align_run): band of 4 words; in exact mode a pair that is not certified is re-run with
 //     8 / 16 / 32 words until it is; a traceback that leaves the slice falls back to a 64-word band computed by one
 //     wavefront per pair, whose traceback bits are kept whole (rare: an insertion / deletion longer than about 60 bases);

@@ -9,9 +9,13 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --verify 0"
 timeout 900 python bench.py > $OUT/${TAG}_bench_fine.json 2> $OUT/${TAG}_bench_fine.err
+timeout 600 python bench.py --config C2 > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
+timeout 600 python bench.py --stage coarse > $OUT/${TAG}_bench_coarse.json 2> $OUT/${TAG}_bench_coarse.err
+HITE_ALIGN_EXACT=16 timeout 600 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_fine_cap16.json 2> /dev/null
+HITE_ALIGN_EXACT=0 timeout 600 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_fine_cap0.json 2> /dev/null
 rm -rf $OUT/prof_stats $OUT/prof_sq $OUT/prof_fetch $OUT/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o run -- $BENCH > $OUT/prof_stats.json 2> $OUT/prof_stats.log
-timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM -d $OUT/prof_sq -o run -- $BENCH > $OUT/prof_sq.json 2> $OUT/prof_sq.log
+timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_|judge_kernel|star_" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM -d $OUT/prof_sq -o run -- $BENCH > $OUT/prof_sq.json 2> $OUT/prof_sq.log
 timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_|judge|star_|row_gather|rs_|hit_|occ_|cluster|cand_min" --pmc FETCH_SIZE -d $OUT/prof_fetch -o run -- $BENCH > $OUT/prof_fetch.json 2> $OUT/prof_fetch.log
 timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_|judge|star_|row_gather|rs_|hit_|occ_|cluster|cand_min" --pmc WRITE_SIZE -d $OUT/prof_write -o run -- $BENCH > $OUT/prof_write.json 2> $OUT/prof_write.log
 python tools/pmc_counters.py $OUT/prof_sq $OUT/prof_sq.json $OUT/${TAG}_sq_counters.json $OUT/${TAG}_sq_counters.txt "rocprofv3 --kernel-trace --kernel-include-regex align_ --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM -- $BENCH" 2> $OUT/pmc_counters.err
