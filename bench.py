@@ -258,9 +258,17 @@ def main():
             avg_launch_ms = ms_tot / max(1, cnt)
             bytes_per_launch = alg.get(dom, 0.0) * steps / max(1, cnt)
             achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
+            # HBM traffic of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs:
+            # profiles/r02_pmc_traffic.json); a profiler stage can cover several kernel instantiations
             traffic = None
             try:
-                traffic = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get(dom, {}).get("bytes_per_launch")
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                names = {"align_fwd4": ["align_fwd_kernel<4>"], "align_tb": ["align_tb_kernel"],
+                         "align_fwd_wide": ["align_fwd_kernel<8>", "align_fwd_kernel<16>", "align_fwd_kernel<32>"],
+                         "radix_sort_hits": ["rs_scatter_staged_kernel", "rs_hist_kernel<10, 32>"]}.get(dom, [dom])
+                tot = sum(pmc[k_]["bytes_per_launch"] * pmc[k_]["launches"] for k_ in names if k_ in pmc)
+                runs = pmc.get(names[0], {}).get("launches", 0)
+                traffic = int(tot / runs) if tot and runs else None      # per launch of the stage
             except Exception:
                 traffic = None
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
