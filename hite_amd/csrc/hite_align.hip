@@ -39,6 +39,7 @@
 #define AL_PADR 1056         // virtual rows above row 1 in the centre planes (33 words: covers t_0 = -1024 of the fall-back band)
 #define AL_WIDE_NW 64         // words of the fall-back band (one per lane of a wavefront)
 #define AL_STRIP 16
+#define AL_RECB 4096          // bytes of strip records per strip and block of 64 pairs: 64 check points, then 64 boundary records
 #define AL_DEFAULT_CAP 8      // exact mode: widest band (words) tried for a certificate unless configured otherwise
 #define AL_KBINS 2048        // strips per pair <= 32767 / 16 + 1
 
@@ -51,9 +52,11 @@ struct AlignArgs {
     const int32_t *row_cand;    // per row: its candidate
     const uint4 *planes;        // per candidate, per 32 centre rows: (plane0, plane1, planeN, 0)
     const int64_t *plane_off;   // n_cand
-    const int64_t *rec_off;     // per row: index of its first strip record
-    uint32_t *ckpt;             // 8 words per strip: the three planes of the slice (2 words each), t of the slice, 1 spare
-    uint32_t *bnd;              // 8 words per strip: 16 bits per column
+    // strip records.  The 64 pairs of a wavefront of the forward pass keep their records interleaved: a block of the run's list
+    // owns AL_RECB bytes per strip -- 64 check points of 32 B (the three planes of the slice, 2 words each, t of the slice, 1 spare),
+    // then 64 boundary records of 32 B (four 64-bit groups of four columns) -- so that a wavefront writes and reads 2 KB runs
+    // (per-pair runs of 32 B were re-fetched from HBM: a 128-B line serves four strips only while it stays in the L2)
+    const unsigned long long *rec;   // per row: address of its check point of strip 0 (written by the run that is kept)
     int32_t *U, *kst, *st, *lvl, *U4;   // per row: cost, certificate bound, status, band words of the run kept, cost of the 4-word run
     const int64_t *ops_base;
     uint16_t *ops;
@@ -187,7 +190,7 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
     if (nmax == 0) return;
     const uint8_t *b = P.win + (g >= 0 ? P.win_off[g] : 0);
     const uint4 *pl = P.planes + (g >= 0 ? P.plane_off[c] : 0);
-    const int64_t rec0 = g >= 0 ? P.rec_off[g] : 0;
+    char *rec0 = g >= 0 ? reinterpret_cast<char *>(P.rec[g]) : nullptr;
     uint32_t X2[NW], X1[NW], X0[NW], A0[NW], A1[NW], AN[NW];
     int t = -H;
 #pragma unroll
@@ -214,7 +217,7 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
         uint32_t f0 = 0, f1 = 0, fn = 0;   // the next 32 rows below the band, per plane
         uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (sa) {
-            uint4 *ck = reinterpret_cast<uint4 *>(P.ckpt + (rec0 + k) * 8);
+            uint4 *ck = reinterpret_cast<uint4 *>(rec0 + (size_t)k * AL_RECB);
             ck[0] = make_uint4(X2[S0], X2[S0 + 1], X1[S0], X1[S0 + 1]);
             ck[1] = make_uint4(X0[S0], X0[S0 + 1], (uint32_t)(t + 32 * S0), 0u);
             bw = bnext;
@@ -277,11 +280,13 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
                     if (sh + 5 <= 32) brec[(cc >> 2) * 2] |= c5 << sh;
                     else if (sh >= 32) brec[(cc >> 2) * 2 + 1] |= c5 << (sh - 32);
                     else { brec[(cc >> 2) * 2] |= c5 << sh; brec[(cc >> 2) * 2 + 1] |= c5 >> (32 - sh); }
+                    // the row base as the traceback needs it (3 bits: the two code bits, "never matches"): bits 46 + 3 c
+                    brec[(cc >> 2) * 2 + 1] |= ((bm.m0 & 1u) | (bm.m1 & 2u) | (bm.inv & 4u)) << (14 + 3 * (cc & 3));
                 }
             }
         }
         if (NW > 2 && sa) {
-            uint4 *bp = reinterpret_cast<uint4 *>(P.bnd + (rec0 + k) * 8);
+            uint4 *bp = reinterpret_cast<uint4 *>(rec0 + (size_t)k * AL_RECB + AL_RECB / 2);
             bp[0] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
             bp[1] = make_uint4(brec[4], brec[5], brec[6], brec[7]);
         }
@@ -343,9 +348,8 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     }
     const int nmax = wave_max_i32(n);
     if (nmax == 0) return;
-    const uint8_t *b = P.win + (g >= 0 ? P.win_off[g] : 0);
     const uint4 *pl = P.planes + (g >= 0 ? P.plane_off[c] : 0);
-    const int64_t rec0 = g >= 0 ? P.rec_off[g] : 0;
+    const char *rec0 = g >= 0 ? reinterpret_cast<const char *>(P.rec[g]) : nullptr;
     uint16_t *ops = P.ops + (g >= 0 ? P.ops_base[c] + (int64_t)(g - g0) * (m + 1) : 0);
     int i = m, j = n;
     bool fail = false;
@@ -357,57 +361,53 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     // computed; without it every strip began with two dependent memory round trips
     const int K = (n + AL_STRIP - 1) / AL_STRIP;      // this lane's strips (0 = nothing to do)
     struct Pw { uint32_t x, y, z; };
-    uint4 ckA0, ckA1, ckB0, ckB1, bdA0, bdA1, bwA;
+    uint4 ckA0, ckA1, ckB0, ckB1, bdA0, bdA1;
     Pw plA[4];
-    ckA0 = ckA1 = ckB0 = ckB1 = bdA0 = bdA1 = bwA = make_uint4(0, 0, 0, 0);
+    ckA0 = ckA1 = ckB0 = ckB1 = bdA0 = bdA1 = make_uint4(0, 0, 0, 0);
 #pragma unroll
     for (int w = 0; w < 4; w++) { plA[w].x = 0; plA[w].y = 0; plA[w].z = 0; }
     {
         const int k = Kmax - 1;
         if (k < K) {
-            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k) * 8);
+            const uint4 *ck = reinterpret_cast<const uint4 *>(rec0 + (size_t)k * AL_RECB);
             ckA0 = ck[0]; ckA1 = ck[1];
-            const uint4 *bp = reinterpret_cast<const uint4 *>(P.bnd + (rec0 + k) * 8);
+            const uint4 *bp = reinterpret_cast<const uint4 *>(rec0 + (size_t)k * AL_RECB + AL_RECB / 2);
             bdA0 = bp[0]; bdA1 = bp[1];
-            bwA = *reinterpret_cast<const uint4 *>(b + k * AL_STRIP);
             const int q0 = ((int)ckA1.z + AL_PADR) >> 5;
 #pragma unroll
             for (int w = 0; w < 4; w++) { const uint4 v = pl[q0 + w]; plA[w].x = v.x; plA[w].y = v.y; plA[w].z = v.z; }
         }
         if (k >= 1 && k - 1 < K) {
-            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k - 1) * 8);
+            const uint4 *ck = reinterpret_cast<const uint4 *>(rec0 + (size_t)(k - 1) * AL_RECB);
             ckB0 = ck[0]; ckB1 = ck[1];
         }
     }
     for (int k = Kmax - 1; k >= 0; k--) {
         const bool sa = n > 0 && !fail && i > 0 && k < K;
         // ---- fetch for the strips to come (A = strip k, B = check point of strip k-1)
-        uint4 ckC0 = make_uint4(0, 0, 0, 0), ckC1 = ckC0, bdB0 = ckC0, bdB1 = ckC0, bwB = ckC0;
+        uint4 ckC0 = make_uint4(0, 0, 0, 0), ckC1 = ckC0, bdB0 = ckC0, bdB1 = ckC0;
         Pw plB[4];
 #pragma unroll
         for (int w = 0; w < 4; w++) { plB[w].x = 0; plB[w].y = 0; plB[w].z = 0; }
         if (k >= 1 && k - 1 < K && !fail && i > 0) {      // (its check point arrived a strip ago, or in the prologue)
-            const uint4 *bp = reinterpret_cast<const uint4 *>(P.bnd + (rec0 + k - 1) * 8);
+            const uint4 *bp = reinterpret_cast<const uint4 *>(rec0 + (size_t)(k - 1) * AL_RECB + AL_RECB / 2);
             bdB0 = bp[0]; bdB1 = bp[1];
-            bwB = *reinterpret_cast<const uint4 *>(b + (k - 1) * AL_STRIP);
             const int q0 = ((int)ckB1.z + AL_PADR) >> 5;
 #pragma unroll
             for (int w = 0; w < 4; w++) { const uint4 v = pl[q0 + w]; plB[w].x = v.x; plB[w].y = v.y; plB[w].z = v.z; }
         }
         if (k >= 2 && k - 2 < K && !fail && i > 0) {
-            const uint4 *ck = reinterpret_cast<const uint4 *>(P.ckpt + (rec0 + k - 2) * 8);
+            const uint4 *ck = reinterpret_cast<const uint4 *>(rec0 + (size_t)(k - 2) * AL_RECB);
             ckC0 = ck[0]; ckC1 = ck[1];
         }
         if (__any(sa)) {
         uint32_t X2[2], X1[2], X0[2], A0[2], A1[2], AN[2];
         uint32_t f0 = 0, f1 = 0, fn = 0;
-        uint4 bw = make_uint4(0, 0, 0, 0);
         uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         int t = 0;
         if (sa) {
             X2[0] = ckA0.x; X2[1] = ckA0.y; X1[0] = ckA0.z; X1[1] = ckA0.w; X0[0] = ckA1.x; X0[1] = ckA1.y;
             t = (int)ckA1.z;
-            bw = bwA;
             brec[0] = bdA0.x; brec[1] = bdA0.y; brec[2] = bdA0.z; brec[3] = bdA0.w;
             brec[4] = bdA1.x; brec[5] = bdA1.y; brec[6] = bdA1.z; brec[7] = bdA1.w;
             const uint32_t sh = (uint32_t)(t + AL_PADR) & 31u;
@@ -442,8 +442,9 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
                 }
                 const int sh = 26 + 5 * (cc & 3);
                 const uint32_t c5 = (sh + 5 <= 32 ? rlo >> sh : (sh >= 32 ? rhi >> (sh - 32) : (rlo >> sh) | (rhi << (32 - sh)))) & 31u;
-                const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
-                const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
+                const uint32_t code = rhi >> (14 + 3 * (cc & 3));     // the row base, as the forward pass left it in the record
+                BaseMask bm;
+                bm.m0 = 0u - (code & 1u); bm.m1 = 0u - ((code >> 1) & 1u); bm.inv = 0u - ((code >> 2) & 1u);
                 uint32_t tap[5], dgc[2], upc[2];
                 bp_core<2, true, -1>(X2, X1, X0, A0, A1, AN, bm, c5 & 1u, (c5 >> 1) & 1u, (c5 >> 2) & 1u, (c5 >> 3) & 1u, (c5 >> 4) & 1u, dgc, upc, tap);
                 dg[cc] = ((unsigned long long)dgc[1] << 32) | dgc[0];
@@ -480,7 +481,7 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
             if ((cc & 3) == 0) tcur -= (int)(((sbits >> (2 * (cc >> 2))) & 3u) << 2);
         }
         }
-        ckA0 = ckB0; ckA1 = ckB1; ckB0 = ckC0; ckB1 = ckC1; bdA0 = bdB0; bdA1 = bdB1; bwA = bwB;
+        ckA0 = ckB0; ckA1 = ckB1; ckB0 = ckC0; ckB1 = ckC1; bdA0 = bdB0; bdA1 = bdB1;
 #pragma unroll
         for (int w = 0; w < 4; w++) plA[w] = plB[w];
     }
@@ -697,6 +698,19 @@ __global__ void align_compact_kernel(int64_t nrows, const int32_t *__restrict__ 
         if (full_off) { full_off[g] = colpos[x]; st[g] = 0; }
     }
 }
+// strips of the longest pair of every block of 64 list entries (= the strips the block's wavefront runs), and -- after the
+// exclusive scan of those -- the record address of every pair of the list
+__global__ void __launch_bounds__(256) align_blockmax_kernel(int64_t cnt, const int32_t *__restrict__ list, const int32_t *__restrict__ strips,
+                                                             int32_t *__restrict__ bk) {
+    const int64_t x = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int k = wave_max_i32(x < cnt ? strips[list[x]] : 0);
+    if ((threadIdx.x & 63) == 0 && x < cnt) bk[x >> 6] = k;
+}
+__global__ void align_assign_kernel(int64_t cnt, const int32_t *__restrict__ list, const int64_t *__restrict__ boff, char *region,
+                                    unsigned long long *__restrict__ rec) {
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (x < cnt) rec[list[x]] = (unsigned long long)(uintptr_t)(region + boff[x >> 6] * (int64_t)AL_RECB + (x & 63) * 32);
+}
 // counters: [0] pairs, [1] certified, [2] kept from a band of > 4 words, [3] fall-back, [4] dropped, [5] sum of U, [6] columns
 __global__ void align_stats_kernel(int64_t total_rows, const int32_t *__restrict__ strips, AlignArgs P, int32_t *__restrict__ row_dead,
                                    int32_t *__restrict__ cand_status, unsigned long long *__restrict__ acc) {
@@ -819,6 +833,23 @@ static int build_list(hite_ctx *ctx, AlignState *S, hipStream_t st, int64_t nrow
     return HITE_OK;
 }
 
+// strip records of one forward run over `list`: block sizes, their scan, the region (arena), the addresses
+static int assign_records(hite_ctx *ctx, AlignState *S, hipStream_t st, const int32_t *list, int64_t cnt, const int32_t *strips, int32_t *bk,
+                          int64_t *boff, int64_t *scan_tmp, unsigned long long *rec, int slot) {
+    if (cnt <= 0) return HITE_OK;
+    const int64_t nb = (cnt + 63) / 64;
+    hipLaunchKernelGGL(align_blockmax_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cnt, list, strips, bk);
+    ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, bk, nb, boff, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + slot, boff + nb, 8, hipMemcpyDeviceToDevice, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin + slot, S->d_scal + slot, 8, hipMemcpyDeviceToHost, st));
+    HITE_CHECK(ctx, hipStreamSynchronize(st));
+    const int64_t block_strips = S->h_pin[slot];
+    char *region;
+    ACHK(aalloc(ctx, S->arena, (size_t)block_strips * AL_RECB + 256, &region));
+    hipLaunchKernelGGL(align_assign_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cnt, list, boff, region, rec);
+    return HITE_OK;
+}
+
 // aligns every row of every candidate to the candidate's first row; ops as described in hite_align.h.
 // d_row_dead (total_rows, may be NULL): 1 for rows that could not be aligned (0 for centres); d_cand_flag (n_cand, may be
 // NULL): set to 2 for candidates that lost a row.  d_info (5 x total_rows int32, may be NULL): per row U, certified, status,
@@ -839,7 +870,9 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     P.ops_base = d_ops_base; P.ops = d_ops;
     int32_t *row_cand, *strips, *order, *pwords, *flag, *flag2, *cols, *list, *list_esc, *list_fin;
     unsigned long long *skeys;
-    int64_t *plane_off, *rec_off, *pos, *pos2, *colpos, *scan_tmp, *scan_tmp2, *full_off;
+    int64_t *plane_off, *pos, *pos2, *colpos, *scan_tmp, *scan_tmp2, *full_off, *boff, *boff2;
+    int32_t *bk, *bk2;
+    unsigned long long *rec;
     ACHK(aalloc(ctx, A, (size_t)total_rows, &row_cand));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &strips));
     ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &skeys));
@@ -853,7 +886,11 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     ACHK(aalloc(ctx, A, (size_t)scan_tmp_elems(srt.hist_n), &srt.bs));
     ACHK(aalloc(ctx, A, (size_t)n_cand, &pwords));
     ACHK(aalloc(ctx, A, (size_t)n_cand + 1, &plane_off));
-    ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &rec_off));
+    ACHK(aalloc(ctx, A, (size_t)total_rows, &rec));
+    ACHK(aalloc(ctx, A, (size_t)total_rows / 64 + 2, &bk));
+    ACHK(aalloc(ctx, A, (size_t)total_rows / 64 + 3, &boff));
+    ACHK(aalloc(ctx, A, (size_t)total_rows / 64 + 2, &bk2));
+    ACHK(aalloc(ctx, A, (size_t)total_rows / 64 + 3, &boff2));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &flag));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &cols));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &list));
@@ -883,17 +920,13 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     ACHK(sorter_sort(srt, skeys, (unsigned *)order, total_rows, 11));
     hipLaunchKernelGGL(align_plane_words_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, d_row_first, d_win_len, pwords);
     ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, pwords, n_cand, plane_off, st));
-    ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, strips, total_rows, rec_off, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, plane_off + n_cand, 8, hipMemcpyDeviceToDevice, st));
-    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, rec_off + total_rows, 8, hipMemcpyDeviceToDevice, st));
-    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, 16, hipMemcpyDeviceToHost, st));
-    HITE_CHECK(ctx, hipStreamSynchronize(st));
-    const int64_t plane_words = S->h_pin[0], total_strips = S->h_pin[1];
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, 8, hipMemcpyDeviceToHost, st));
+    ACHK(assign_records(ctx, S, st, order, total_rows, strips, bk, boff, scan_tmp, rec, 1));     // (synchronises)
+    const int64_t plane_words = S->h_pin[0];
     uint4 *planes;
     ACHK(aalloc(ctx, A, (size_t)plane_words + 8, &planes));
-    ACHK(aalloc(ctx, A, (size_t)total_strips * 8 + 16, &P.ckpt));
-    ACHK(aalloc(ctx, A, (size_t)total_strips * 8 + 16, &P.bnd));
-    P.planes = planes; P.plane_off = plane_off; P.rec_off = rec_off;
+    P.planes = planes; P.plane_off = plane_off; P.rec = rec;
     hipLaunchKernelGGL(align_planes_kernel, dim3(n_cand), dim3(256), 0, st, n_cand, d_win, d_win_off, d_win_len, d_row_first, plane_off, planes);
     hite_prof_end(ctx, tk, st);
     HITE_CHECK(ctx, hipGetLastError());
@@ -919,6 +952,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
             int64_t cnt = 0;
             ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 0, level, cap, flag, nullptr, pos, colpos, scan_tmp, list, nullptr, &cnt, nullptr));
             if (cnt == 0) continue;
+            ACHK(assign_records(ctx, S, st, list, cnt, strips, bk, boff, scan_tmp, rec, 1));
             hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<8>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, P, list, (int)cnt);
         }
         hite_prof_end(ctx, tk, st);
@@ -940,6 +974,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
             int64_t cnt = 0;
             ACHK(build_list(ctx, S, s2, total_rows, order, strips, P, 0, level, cap, flag2, nullptr, pos2, colpos, scan_tmp2, list, nullptr, &cnt, nullptr, 8));
             if (cnt == 0) continue;
+            ACHK(assign_records(ctx, S, s2, list, cnt, strips, bk2, boff2, scan_tmp2, rec, 10));
             const dim3 grid((unsigned)((cnt + 63) / 64));
             if (level == 8) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<8>), grid, dim3(64), 0, s2, P, list, (int)cnt);
             else if (level == 16) hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<16>), grid, dim3(64), 0, s2, P, list, (int)cnt);

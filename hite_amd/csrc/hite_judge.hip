@@ -40,7 +40,7 @@ struct JShared {
     int flagged[64];
     int tsd[25];
     int fo[5], eo[5];
-    uint8_t tile[TILE_COLS * MAXSEL];   // symbol classes of the selected rows over the column span of the current scan
+    alignas(16) uint8_t tile[TILE_COLS * 6 * 4 * 4];   // row-set masks of the current scan: per column and symbol class, up to 4 words of 32 rows
 #ifdef JUDGE_CLOCKS
     unsigned long long jt;
 #endif
@@ -341,49 +341,17 @@ __device__ int wave_window_homology(const uint8_t *__restrict__ msa, int C, cons
     return avg >= thr ? first_cand : -1;
 }
 
-// the same window evaluated on the LDS tile (column-major: tile[(c - lo) * MAXSEL + rank]); identical arithmetic
-__device__ int wave_window_homology_tile(const uint8_t *tile, int lo, int rn, int first, int n, int step, double thr) {
-    const int lane = lane_id();
-    const bool h0 = lane < rn, h1 = lane + 64 < rn;
-    const uint8_t *t0 = tile + lane, *t1 = tile + lane + 64;
-    int g0 = 0, g1 = 0;
-    for (int i = 0, c = first - lo; i < n; i++, c += step) {
-        if (h0) g0 += t0[c * MAXSEL] == 5;
-        if (h1) g1 += t1[c * MAXSEL] == 5;
-    }
-    const bool v0 = h0 && 2 * g0 <= n;
-    const bool v1 = h1 && 2 * g1 <= n;
-    const int nv = __popcll(__ballot(v0)) + __popcll(__ballot(v1));
-    if (nv < 2) return -1;
-    double total = 0.0;
-    const double lim = thr - 0.1;
-    int first_cand = -1;
-    for (int i = 0, c = first - lo; i < n; i++, c += step) {
-        const int k0 = v0 ? t0[c * MAXSEL] : 7;
-        const int k1 = v1 ? t1[c * MAXSEL] : 7;
-        int best = 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) {
-            int cnt = __popcll(__ballot(k0 == k)) + __popcll(__ballot(k1 == k));
-            best = cnt > best ? cnt : best;
-        }
-        double ratio = best ? (double)best / (double)nv : 0.0;
-        if (ratio >= lim && first_cand == -1) first_cand = c + lo;
-        total += ratio;
-    }
-    double avg = total / (double)n;
-    return avg >= thr ? first_cand : -1;
-}
-
-// collect up to 100 valid columns into S.cols; mode as in the oracle's scan_valid
+// collect up to 100 valid columns into S.cols; mode as in the oracle's scan_valid.  256 positions per round: every wave
+// ballots its valid ("1") and out-of-range ("2") positions, keeps the valid ones before its first "2", and places them
+// behind the counts of the waves before it (a wave behind a "2" contributes nothing) -- the list is the one a serial walk
+// builds (the walk by thread 0 used to be a fifth of the boundary search).
 __device__ int blk_scan_valid(const uint8_t *__restrict__ cstat, int C, int vthr, int from, int dir, int mode,
                               JShared &S) {
-    __syncthreads();
-    if (threadIdx.x == 0) { S.iv[0] = 0; S.iv[1] = 0; }
-    __syncthreads();
-    int c0 = from;
+    __syncthreads();   // readers of the previous list are done
+    const int lane = lane_id(), w = wave_id();
+    int n = 0, c0 = from;
     for (;;) {
-        int c = c0 + dir * (int)threadIdx.x;
+        const int c = c0 + dir * (int)threadIdx.x;
         bool ok;
         switch (mode) {
             case 0: ok = 2 * c < C; break;        // c < C/2 (float)
@@ -392,21 +360,127 @@ __device__ int blk_scan_valid(const uint8_t *__restrict__ cstat, int C, int vthr
             default: ok = 2 * c >= C; break;      // c >= C/2 (float)
         }
         ok = ok && c >= 0 && c < C;
-        S.flag[threadIdx.x] = ok ? (cstat[(size_t)c * CS + 5] <= vthr ? 1 : 0) : 2;
+        const bool one = ok && cstat[(size_t)c * CS + 5] <= vthr;
+        const unsigned long long b2 = __ballot(!ok);
+        const unsigned long long lim = b2 ? ((1ull << (__ffsll((long long)b2) - 1)) - 1ull) : ~0ull;
+        const unsigned long long v1 = __ballot(one) & lim;
+        if (lane == 0) { S.scan[w] = __popcll(v1); S.scan[4 + w] = b2 != 0ull; }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int n = S.iv[0];
-            for (int t = 0; t < JB; t++) {
-                if (S.flag[t] == 2) { S.iv[1] = 1; break; }
-                if (S.flag[t] == 1) { S.cols[n++] = c0 + dir * t; if (n == 100) { S.iv[1] = 1; break; } }
-            }
-            S.iv[0] = n;
+        int tot = n, pre = n;
+        bool stop = false, dead = false;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            if (q == w) { pre = tot; dead = stop; }
+            if (!stop) tot += S.scan[q];
+            stop = stop || S.scan[4 + q] != 0;
         }
+        if (!dead && ((v1 >> lane) & 1ull)) {
+            const int pos = pre + __popcll(v1 & ((1ull << lane) - 1ull));
+            if (pos < 100) S.cols[pos] = c;
+        }
+        n = tot > 100 ? 100 : tot;
         __syncthreads();
-        if (S.iv[1]) break;
+        if (stop || n >= 100) break;
         c0 += dir * JB;
     }
-    return S.iv[0];
+    return n;
+}
+
+// ---- the window scans with lanes = windows ------------------------------------------------------------------------------
+// Row sets as bit masks: for every column of the staged span and every symbol class one mask over the selected rows
+// (W32 words of 32 rows), kept where the byte tile used to be.  A thread then evaluates a whole window by itself: the rows
+// with <= half gaps through an 8-plane bit-sliced counter over the gap masks, the vote of a column as five and + popcount
+// pairs -- ~60 integer operations per window column instead of a wavefront's ballots, and all (<= 91) windows of a scan at
+// once instead of four per block round.  Arithmetic and order of the binary64 sums are those of wave_window_homology.
+template <int W32>
+__device__ __forceinline__ int lane_window_homology(const uint32_t *mk, const uint32_t (&rowmask)[W32], int lo, int first, int n,
+                                                    int step, double thr) {
+    if (n <= 0) return -1;                       // (0 / 0 in the reference arithmetic: never >= thr)
+    uint32_t P[8][W32];
+#pragma unroll
+    for (int p = 0; p < 8; p++)
+#pragma unroll
+        for (int w = 0; w < W32; w++) P[p][w] = 0u;
+    for (int i = 0, c = first - lo; i < n; i++, c += step) {
+        const uint32_t *g = mk + ((size_t)c * 6 + 5) * W32;
+#pragma unroll
+        for (int w = 0; w < W32; w++) {
+            uint32_t carry = g[w];
+#pragma unroll
+            for (int p = 0; p < 8; p++) { const uint32_t t = P[p][w] & carry; P[p][w] ^= carry; carry = t; }
+        }
+    }
+    // valid rows: gap count <= n / 2  (2 * gaps <= n)
+    const int h = n >> 1;
+    uint32_t V[W32];
+    int nv = 0;
+#pragma unroll
+    for (int w = 0; w < W32; w++) {
+        uint32_t lt = 0u, eq = 0xffffffffu;
+#pragma unroll
+        for (int p = 7; p >= 0; p--) {
+            const uint32_t hb = ((h >> p) & 1) ? 0xffffffffu : 0u;
+            lt |= eq & ~P[p][w] & hb;
+            eq &= ~(P[p][w] ^ hb);
+        }
+        V[w] = (lt | eq) & rowmask[w];
+        nv += __popc(V[w]);
+    }
+    if (nv < 2) return -1;
+    double total = 0.0;
+    const double lim = thr - 0.1;
+    int first_cand = -1;
+    for (int i = 0, c = first - lo; i < n; i++, c += step) {
+        const uint32_t *m = mk + (size_t)c * 6 * W32;
+        int best = 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int cnt = 0;
+#pragma unroll
+            for (int w = 0; w < W32; w++) cnt += __popc(m[k * W32 + w] & V[w]);
+            best = cnt > best ? cnt : best;
+        }
+        const double ratio = best ? (double)best / (double)nv : 0.0;
+        if (ratio >= lim && first_cand == -1) first_cand = c + lo;
+        total += ratio;
+    }
+    const double avg = total / (double)n;
+    return avg >= thr ? first_cand : -1;
+}
+
+template <int W32>
+__device__ int blk_first_window_masks(const uint8_t *__restrict__ msa, int C, const uint16_t *sel, int rn, int n, int ws,
+                                      bool rev_list, bool desc, double thr, int lo, int span, JShared &S) {
+    uint32_t *mk = reinterpret_cast<uint32_t *>(S.tile);
+    __syncthreads();
+    for (int i = threadIdx.x; i < span * 6 * W32; i += JB) mk[i] = 0u;
+    if (threadIdx.x == 0) S.red[6] = 0xffffffffu;
+    __syncthreads();
+    {
+        // rows_per_round rows at a time, consecutive threads on consecutive columns of a row
+        const int r0 = (int)threadIdx.x / span, c = (int)threadIdx.x - r0 * span, rstep = JB / span;
+        if (r0 < rstep)
+            for (int r = r0; r < rn; r += rstep) {
+                const int k = sym_class(msa[(size_t)sel[r] * C + lo + c]);
+                atomicOr(&mk[((size_t)c * 6 + k) * W32 + (r >> 5)], 1u << (r & 31));
+            }
+    }
+    __syncthreads();
+    uint32_t rowmask[W32];
+#pragma unroll
+    for (int w = 0; w < W32; w++) rowmask[w] = rn >= 32 * (w + 1) ? 0xffffffffu : (rn > 32 * w ? (1u << (rn - 32 * w)) - 1u : 0u);
+    const int nwin = n - ws + 1;
+    for (int i = threadIdx.x; i < nwin; i += JB) {
+        const int a = rev_list ? S.cols[n - 1 - i] : S.cols[i];
+        const int b = rev_list ? S.cols[n - 1 - (i + ws - 1)] : S.cols[i + ws - 1];
+        const int r = !desc ? lane_window_homology<W32>(mk, rowmask, lo, a, b - a + 1, +1, thr)
+                            : lane_window_homology<W32>(mk, rowmask, lo, a, a - b - 1, -1, thr);
+        if (r != -1) atomicMin(&S.red[6], ((unsigned)i << 16) | (unsigned)r);
+    }
+    __syncthreads();
+    const unsigned key = S.red[6];
+    __syncthreads();
+    return key == 0xffffffffu ? -1 : (int)(key & 0xffffu);
 }
 
 // first homologous window over S.cols.  rev_list: logical list is S.cols reversed.
@@ -416,28 +490,23 @@ __device__ int blk_first_window(const uint8_t *__restrict__ msa, int C, const ui
     int nwin = n - ws + 1;
     int w = wave_id();
     int found = -1;
-    // every window is a contiguous column range inside [lo, hi]: stage that span once (rows = selected rows)
+    // every window is a contiguous column range inside [lo, hi]
     const int e0 = S.cols[0], e1 = S.cols[n - 1];   // the list is monotonic (either direction)
     const int lo = e0 < e1 ? e0 : e1, hi = e0 < e1 ? e1 : e0;
     const int span = hi - lo + 1;
-    const bool tiled = span <= TILE_COLS && rn <= MAXSEL;
-    if (tiled) {
-        __syncthreads();
-        for (int idx = threadIdx.x; idx < rn * span; idx += JB) {
-            const int r = idx / span, c = idx - r * span;
-            S.tile[c * MAXSEL + r] = (uint8_t)sym_class(msa[(size_t)sel[r] * C + lo + c]);
-        }
-        __syncthreads();
+    if (span <= TILE_COLS && rn <= MAXSEL && nwin < 65536) {
+        if (rn <= 32) return blk_first_window_masks<1>(msa, C, sel, rn, n, ws, rev_list, desc, thr, lo, span, S);
+        if (rn <= 64) return blk_first_window_masks<2>(msa, C, sel, rn, n, ws, rev_list, desc, thr, lo, span, S);
+        return blk_first_window_masks<4>(msa, C, sel, rn, n, ws, rev_list, desc, thr, lo, span, S);
     }
+    // wider spans (more than 60 invalid columns among 100 valid ones): one window per wavefront on the alignment itself
     for (int base = 0; base < nwin; base += 4) {
         int i = base + w;
         int r = -1;
         if (i < nwin) {
             int a = rev_list ? S.cols[n - 1 - i] : S.cols[i];
             int b = rev_list ? S.cols[n - 1 - (i + ws - 1)] : S.cols[i + ws - 1];
-            if (tiled) r = !desc ? wave_window_homology_tile(S.tile, lo, rn, a, b - a + 1, +1, thr)
-                                 : wave_window_homology_tile(S.tile, lo, rn, a, a - b - 1, -1, thr);
-            else if (!desc) r = wave_window_homology(msa, C, sel, rn, a, b - a + 1, +1, thr);
+            if (!desc) r = wave_window_homology(msa, C, sel, rn, a, b - a + 1, +1, thr);
             else r = wave_window_homology(msa, C, sel, rn, a, a - b - 1, -1, thr);
         }
         __syncthreads();
