@@ -38,6 +38,7 @@ struct hite_ctx {
     void *align_state;
     const int32_t *d_msa_row_map;   // per compacted row: source row (NULL: identity)
     const int32_t *d_msa_rows_eff;  // per candidate: rows that were aligned (NULL: all)
+    uint32_t *d_msa_lay;             // layout words of the last sparse star alignment (hite_msa.hip)
 };
 
 // record the time of everything enqueued on `st` between begin and end as stage `name`

@@ -29,6 +29,9 @@ struct MsaParams {
     int32_t *status;           // n : 0 ok, 1 failed (alignment too wide)
     const int32_t *row_map;    // total_rows : source row of each row that was aligned (NULL: identity)
     const int32_t *rows_eff;   // n : rows that were aligned (NULL: all)
+    uint32_t *lay;             // sparse layout, one word per centre position (0..m) of candidate c at lay[ops_base[c] / 2 + p]:
+                               // kept insertion columns | keep-centre << 15 | first output column << 16  (a candidate owns
+                               // (R + 1)(m + 1) >= 2 (m + 1) ops, so the halves of the ops offsets never overlap)
 };
 
 // rows of candidate c after dropped rows; source row (relative to g0) of row r
@@ -138,8 +141,10 @@ __global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
 //   * column j of the insertion block before p: a base in every row with ins_r > j, a gap elsewhere (centre included),
 //     so the kept columns of a block are a PREFIX of length kw = the ceil(R/2)-th largest ins_r;
 //   * the first / last column of the alignment are kept regardless (the last one may be a non-prefix column of block m).
-// Per position p: ops row-0 slot = kw | keep_centre << 15, extra slot = first kept column of the block.
+// Per position p one layout word (MsaParams::lay): kw | keep_centre << 15 | first kept column of the block << 16.
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long lay_ld8(const uint16_t *p) { unsigned long long v; __builtin_memcpy(&v, p, 8); return v; }
+
 __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, int32_t *__restrict__ new_cols,
                                                                  int32_t *__restrict__ last_extra) {
     __shared__ int s_scan[8];
@@ -151,8 +156,7 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
     if (R <= 0 || P.status[c]) { if (threadIdx.x == 0) { P.cols_out[c] = 0; new_cols[c] = 0; last_extra[c] = -1; } return; }
     const int m = P.win_len[g0];
     uint16_t *ops = P.ops + P.ops_base[c];
-    uint16_t *kwslot = ops;                              // centre row slot
-    uint16_t *nstart = ops + (int64_t)R * (m + 1);       // extra slot
+    uint32_t *lay = P.lay + (P.ops_base[c] >> 1);
     const int h = (R + 1) >> 1;                          // fewest rows with a base for a column to survive
     __shared__ int s_wl[MSA_MAXR];
     for (int r = threadIdx.x; r < R && r < MSA_MAXR; r += 256) s_wl[r] = P.win_len[g0 + msa_src(P.row_map, g0, r)];
@@ -167,75 +171,90 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
     __syncthreads();
     const int mxm = s_mxm;
     int run_new = 0, run_full = 0, extra = -1;
-    for (int base = 0; base <= m; base += 256) {
-        const int p = base + threadIdx.x;
-        int mx = 0, npos = 0, gapc = 0;
-        if (p <= m) {
-            // ins_r(p) = q_r(p) - end_r(p-1): two u16 per row, four rows in flight
-            const uint16_t *col = ops + p;
+    // a thread owns FOUR consecutive positions per round: one 8-byte load per row brings their four ops (plus the op before the
+    // first), a fourth of the memory instructions of one position per thread; block scans over the threads' sums
+    for (int base = 0; base <= m; base += 4 * 256) {
+        const int p0 = base + 4 * (int)threadIdx.x;
+        int mx[4] = {0, 0, 0, 0}, npos[4] = {0, 0, 0, 0}, gapc[4] = {0, 0, 0, 0};
+        if (p0 <= m) {
+            const uint16_t *col = ops + p0;
             int r = 1;
-            for (; r + 7 < R; r += 8) {
-                unsigned oc[8], op[8];
+            for (; r + 3 < R; r += 4) {      // four rows in flight
+                unsigned long long o4[4];
+                unsigned om[4];
 #pragma unroll
-                for (int u = 0; u < 8; u++) { oc[u] = p < m ? col[(r + u) * rs] : 0u; op[u] = p > 0 ? col[(r + u) * rs - 1] : 0u; }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int pe = p > 0 ? (int)(op[u] & 0x7fff) + ((op[u] >> 15) ? 0 : 1) : 0;
-                    const int q = p < m ? (int)(oc[u] & 0x7fff) : (r + u < MSA_MAXR ? s_wl[r + u] : P.win_len[g0 + msa_src(P.row_map, g0, r + u)]);
-                    const int v = q - pe;
-                    mx = v > mx ? v : mx; npos += v > 0; gapc += (int)(oc[u] >> 15);
-                }
-            }
-            for (; r + 3 < R; r += 4) {
-                unsigned oc[4], op[4];
-#pragma unroll
-                for (int u = 0; u < 4; u++) { oc[u] = p < m ? col[(r + u) * rs] : 0u; op[u] = p > 0 ? col[(r + u) * rs - 1] : 0u; }
+                for (int u = 0; u < 4; u++) { o4[u] = lay_ld8(col + (int64_t)(r + u) * rs); om[u] = p0 > 0 ? col[(int64_t)(r + u) * rs - 1] : 0u; }
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const int pe = p > 0 ? (int)(op[u] & 0x7fff) + ((op[u] >> 15) ? 0 : 1) : 0;
-                    const int q = p < m ? (int)(oc[u] & 0x7fff) : (r + u < MSA_MAXR ? s_wl[r + u] : P.win_len[g0 + msa_src(P.row_map, g0, r + u)]);
-                    const int v = q - pe;
-                    mx = v > mx ? v : mx; npos += v > 0; gapc += (int)(oc[u] >> 15);
+                    const int wl = r + u < MSA_MAXR ? s_wl[r + u] : P.win_len[g0 + msa_src(P.row_map, g0, r + u)];
+                    unsigned op = om[u];
+#pragma unroll
+                    for (int x = 0; x < 4; x++) {
+                        const int p = p0 + x;
+                        const unsigned oc = p < m ? (unsigned)(o4[u] >> (16 * x)) & 0xffffu : 0u;
+                        const int pe = p > 0 ? (int)(op & 0x7fffu) + ((op >> 15) ? 0 : 1) : 0;
+                        const int q = p < m ? (int)(oc & 0x7fffu) : wl;
+                        const int v = p <= m ? q - pe : 0;
+                        mx[x] = v > mx[x] ? v : mx[x]; npos[x] += v > 0; gapc[x] += (int)(oc >> 15);
+                        op = oc;
+                    }
                 }
             }
             for (; r < R; r++) {
-                const uint16_t *rop = ops + r * rs;
-                const int v = row_ins(rop, p, m, r < MSA_MAXR ? s_wl[r] : P.win_len[g0 + msa_src(P.row_map, g0, r)]);
-                mx = v > mx ? v : mx;
-                npos += v > 0;
-                if (p < m) gapc += rop[p] >> 15;
+                const unsigned long long o4 = lay_ld8(col + (int64_t)r * rs);
+                unsigned op = p0 > 0 ? col[(int64_t)r * rs - 1] : 0u;
+                const int wl = r < MSA_MAXR ? s_wl[r] : P.win_len[g0 + msa_src(P.row_map, g0, r)];
+#pragma unroll
+                for (int x = 0; x < 4; x++) {
+                    const int p = p0 + x;
+                    const unsigned oc = p < m ? (unsigned)(o4 >> (16 * x)) & 0xffffu : 0u;
+                    const int pe = p > 0 ? (int)(op & 0x7fffu) + ((op >> 15) ? 0 : 1) : 0;
+                    const int q = p < m ? (int)(oc & 0x7fffu) : wl;
+                    const int v = p <= m ? q - pe : 0;
+                    mx[x] = v > mx[x] ? v : mx[x]; npos[x] += v > 0; gapc[x] += (int)(oc >> 15);
+                    op = oc;
+                }
             }
         }
-        int kw = 0;
-        if (npos >= h) {
-            kw = 1;
-            for (;;) {
-                int cnt = 0;
-                for (int r = 1; r < R; r++) cnt += row_ins(ops + (int64_t)r * (m + 1), p, m, P.win_len[g0 + msa_src(P.row_map, g0, r)]) > kw;
-                if (cnt >= h) kw++; else break;
+        int wnew[4], wfull[4], kws[4], sum_new = 0, sum_full = 0;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const int p = p0 + x;
+            int kw = 0;
+            if (p <= m && npos[x] >= h) {
+                kw = 1;
+                for (;;) {
+                    int cnt = 0;
+                    for (int r = 1; r < R; r++) cnt += row_ins(ops + (int64_t)r * (m + 1), p, m, P.win_len[g0 + msa_src(P.row_map, g0, r)]) > kw;
+                    if (cnt >= h) kw++; else break;
+                }
             }
+            int keepc = (p < m && 2 * gapc[x] <= R) ? 1 : 0;
+            int ex = 0;
+            if (p == 0) { if (mx[x] > 0) kw = kw > 1 ? kw : 1; else if (m > 0) keepc = 1; }     // first column
+            if (p == m - 1 && mxm == 0) keepc = 1;                                            // last column = centre column m-1
+            if (p == m && mx[x] > 0 && kw < mx[x]) { ex = 1; extra = mx[x] - 1; }                // last column = block m, j = mx-1
+            if (kw > 0x7fff) kw = 0x7fff;
+            wnew[x] = p <= m ? kw + keepc + ex : 0;
+            wfull[x] = p <= m ? mx[x] + (p < m ? 1 : 0) : 0;
+            kws[x] = kw | (keepc << 15);
+            sum_new += wnew[x]; sum_full += wfull[x];
         }
-        int keepc = (p < m && 2 * gapc <= R) ? 1 : 0;
-        int ex = 0;
-        if (p == 0) { if (mx > 0) kw = kw > 1 ? kw : 1; else if (m > 0) keepc = 1; }     // first column
-        if (p == m - 1 && mxm == 0) keepc = 1;                                            // last column = centre column m-1
-        if (p == m && mx > 0 && kw < mx) { ex = 1; extra = mx - 1; }                       // last column = block m, j = mx-1
-        if (kw > 0x7fff) kw = 0x7fff;
-        const int wnew = p <= m ? kw + keepc + ex : 0;
-        const int wfull = p <= m ? mx + (p < m ? 1 : 0) : 0;
         int tot_new, tot_full;
-        const int pre = block_excl_scan(wnew, s_scan, &tot_new);
+        const int pre = block_excl_scan(sum_new, s_scan, &tot_new);
         __syncthreads();
-        (void)block_excl_scan(wfull, s_scan, &tot_full);
-        if (p <= m) {
-            const int bs = run_new + pre;
-            kwslot[p] = (uint16_t)(kw | (keepc << 15));
-            nstart[p] = (uint16_t)(bs > 65535 ? 65535 : bs);
+        (void)block_excl_scan(sum_full, s_scan, &tot_full);
+        int bs = run_new + pre;
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const int p = p0 + x;
+            if (p <= m) lay[p] = (uint32_t)kws[x] | ((uint32_t)(bs > 65535 ? 65535 : bs) << 16);
+            bs += wnew[x];
         }
         run_new += tot_new; run_full += tot_full;
         __syncthreads();
     }
-    if (threadIdx.x == (m & 255)) last_extra[c] = extra;   // the thread that owned p == m
+    if ((int)threadIdx.x == ((m & 1023) >> 2)) last_extra[c] = extra;   // the thread that owned p == m
     if (threadIdx.x == 0) {
         if (run_full > 65535) { P.status[c] = 1; P.cols_out[c] = 0; new_cols[c] = 0; }
         else { P.cols_out[c] = run_full; new_cols[c] = run_new; }
@@ -245,6 +264,7 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
 struct FillSparseParams {
     FillParams F;              // cols = kept columns per candidate, msa = compacted output
     const int32_t *last_extra;
+    const uint32_t *lay;       // as in MsaParams
 };
 
 // fill of the kept columns only: item (r, p) owns the kept prefix of insertion block p, the centre column p if kept
@@ -259,8 +279,7 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
     const int R = msa_rows(P.rows_eff, P.row_first, c);
     const int m = P.win_len[g0];
     const uint16_t *ops = P.ops + P.ops_base[c];
-    const uint16_t *kwslot = ops;
-    const uint16_t *nstart = ops + (int64_t)R * (m + 1);
+    const uint32_t *lay = Q.lay + (P.ops_base[c] >> 1);
     const int le = Q.last_extra[c];
     uint8_t *out = P.msa + P.msa_off[c];
     // rows of the candidate are spread over blockIdx.y, positions over the threads: FILL_U positions per thread and trip, the
@@ -273,31 +292,27 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
         const uint16_t *rop = ops + (int64_t)r * rs;
         uint8_t *row = out + (int64_t)r * C;
         for (int p0 = threadIdx.x; p0 <= m; p0 += FILL_U * 256) {
-            int p[FILL_U], kw[FILL_U], kc[FILL_U], ins[FILL_U], gap[FILL_U], q[FILL_U], bs[FILL_U];
+            int p[FILL_U], kw[FILL_U], kc[FILL_U], gap[FILL_U], q[FILL_U], bs[FILL_U];
             bool live[FILL_U], ex[FILL_U];
-            unsigned ks[FILL_U], oc[FILL_U], op[FILL_U];
+            unsigned ks[FILL_U], oc[FILL_U];
+            // three memory instructions per output byte on the common path (layout word, op, base) + the store: the kernel is
+            // bound by the rate the texture addresser takes wave64 instructions (16 cycles each), not by bytes -- the op before
+            // the position, which only an insertion block needs, is fetched where one is kept
 #pragma unroll
             for (int u = 0; u < FILL_U; u++) {
                 p[u] = p0 + u * 256;
                 live[u] = p[u] <= m;
                 if (!live[u]) p[u] = 0;
-                ks[u] = kwslot[p[u]];
+                ks[u] = lay[p[u]];
                 oc[u] = (r > 0 && p[u] < m) ? rop[p[u]] : 0u;
-                op[u] = (r > 0 && p[u] > 0) ? rop[p[u] - 1] : 0u;
-                bs[u] = nstart[p[u]];
             }
 #pragma unroll
             for (int u = 0; u < FILL_U; u++) {
-                kw[u] = (int)(ks[u] & 0x7fff); kc[u] = (int)(ks[u] >> 15);
+                kw[u] = (int)(ks[u] & 0x7fff); kc[u] = (int)(ks[u] >> 15) & 1; bs[u] = (int)(ks[u] >> 16);
                 ex[u] = p[u] == m && le >= 0;
                 live[u] = live[u] && (kw[u] != 0 || kc[u] || ex[u]);
-                if (r == 0) { ins[u] = 0; q[u] = p[u]; gap[u] = 0; }
-                else {
-                    const int pe = p[u] > 0 ? (int)(op[u] & 0x7fff) + ((op[u] >> 15) ? 0 : 1) : 0;
-                    q[u] = p[u] < m ? (int)(oc[u] & 0x7fff) : nrow;
-                    gap[u] = (int)(oc[u] >> 15);
-                    ins[u] = q[u] - pe;
-                }
+                if (r == 0) { q[u] = p[u]; gap[u] = 0; }
+                else { q[u] = p[u] < m ? (int)(oc[u] & 0x7fff) : nrow; gap[u] = (int)(oc[u] >> 15); }
             }
             uint8_t cb[FILL_U];
 #pragma unroll
@@ -305,10 +320,16 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
 #pragma unroll
             for (int u = 0; u < FILL_U; u++) {
                 if (!live[u]) continue;
-                const int rp = q[u] - ins[u];  // first inserted base
-                for (int k = 0; k < kw[u]; k++) row[bs[u] + k] = k < ins[u] ? b[rp + k] : (uint8_t)'-';
                 if (kc[u]) row[bs[u] + kw[u]] = cb[u];
-                if (ex[u]) row[bs[u] + kw[u]] = le < ins[u] ? b[rp + le] : (uint8_t)'-';
+                if (kw[u] == 0 && !ex[u]) continue;
+                int ins = 0;
+                if (r > 0) {
+                    const unsigned op = p[u] > 0 ? rop[p[u] - 1] : 0u;
+                    ins = q[u] - (p[u] > 0 ? (int)(op & 0x7fff) + ((op >> 15) ? 0 : 1) : 0);
+                }
+                const int rp = q[u] - ins;  // first inserted base
+                for (int k = 0; k < kw[u]; k++) row[bs[u] + k] = k < ins ? b[rp + k] : (uint8_t)'-';
+                if (ex[u]) row[bs[u] + kw[u]] = le < ins ? b[rp + le] : (uint8_t)'-';
             }
         }
     }
@@ -361,7 +382,8 @@ static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
     const size_t ops_bytes = ((size_t)ops_elems * 2 + 255) & ~(size_t)255;
     const size_t rows_bytes = ((size_t)total_rows * 4 + 255) & ~(size_t)255, cand_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
     void *opsb = nullptr;
-    int rc = hite_scratch2_reserve(ctx, ops_bytes + 2 * rows_bytes + 2 * cand_bytes + 256, &opsb);
+    const size_t lay_bytes = d_new_cols ? (((size_t)ops_elems / 2 + 32768 + 16) * 4 + 255) & ~(size_t)255 : 0;
+    int rc = hite_scratch2_reserve(ctx, ops_bytes + 2 * rows_bytes + 2 * cand_bytes + lay_bytes + 256, &opsb);
     if (rc) return rc;
     uint8_t *base = (uint8_t *)opsb;
     int32_t *row_dead = (int32_t *)(base + ops_bytes), *row_map = (int32_t *)(base + ops_bytes + rows_bytes);
@@ -382,6 +404,8 @@ static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
     P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first;
     P.ops_base = d_ops_base; P.ops = (uint16_t *)opsb; P.cols_out = d_cols_out; P.status = d_status;
     P.row_map = nullptr; P.rows_eff = nullptr;
+    P.lay = d_new_cols ? (uint32_t *)(base + ops_bytes + 2 * rows_bytes + 2 * cand_bytes) : nullptr;
+    ctx->d_msa_lay = P.lay;
     if (dropped) {
         hipLaunchKernelGGL(msa_compact_rows_kernel, dim3(n), dim3(256), 0, st, n, d_row_first, d_win_len, d_ops_base, (uint16_t *)opsb, cand_flag,
                            row_dead, row_map, rows_eff);
@@ -435,7 +459,8 @@ extern "C" int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uin
     P.n = n; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first; P.ops_base = d_ops_base;
     P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_new_cols; P.msa_off = d_msa_off; P.msa = d_msa;
     P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff;
-    Q.last_extra = d_last_extra;
+    Q.last_extra = d_last_extra; Q.lay = ctx->d_msa_lay;
+    if (!Q.lay) return HITE_EINVAL;
     hipLaunchKernelGGL(star_fill_sparse_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
     HITE_CHECK(ctx, hipGetLastError());
     return HITE_OK;

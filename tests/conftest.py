@@ -24,3 +24,18 @@ def load_golden(name):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_device_first():
+    """Two HIP runtimes live in a GPU test process: /opt/rocm's (libhite_gpu.so links it) and the one PyTorch bundles
+    (test_gpu_scale builds its synthetic genome with torch on the device).  bench.py always brings torch's up first; a test
+    session does the same, whatever the order of the test files, instead of leaving it to the first test that needs it."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+            torch.zeros(1, device="cuda:0")
+    except ImportError:
+        pass
+    yield
