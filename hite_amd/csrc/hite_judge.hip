@@ -24,6 +24,7 @@
 #define MAXSEL 128      // capacity of the selected-row list (the reference keeps <= 101)
 #define CS 12           // bytes of column statistics per column: cnt[6], first[6]
 #define SCR_PER_COL 32  // scratch bytes per column per block slot
+#define ANCHOR_LDS_COLS 5104   // ungapped row (<= this many bytes) + 2 bytes of match record per text start fit the 15 KB mask area
 #define TILE_COLS 160   // widest column span staged in LDS for the window scans (wider spans read the alignment directly)
 
 struct JShared {
@@ -848,9 +849,13 @@ __global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(5, 8)))
         call.is_te = 0; call.info = HITE_INFO_NONE; call.row_num = 0; call.bstart = -1; call.bend = -1;
         call.cons_len = 0; call.cons_off = cons_base;
         // slot layout (multiples of maxC16): ung 1 | reflex 4 | minfo 2 | cstat 12 | wave bufs 4 | rowres
-        uint8_t *ung = slot;
+        // the ungapped row and the 2-byte match records of the anchor search live in LDS (where the row-set masks of the
+        // window scans go later) when the alignment has <= ANCHOR_LDS_COLS columns: the bit-parallel scan reads the text one
+        // character at a time, a chain of dependent loads that global scratch made ~10x longer
+        const bool anchors_in_lds = C <= ANCHOR_LDS_COLS;
+        uint8_t *ung = anchors_in_lds ? S.tile : slot;
         int *reflex = (int *)(slot + P.maxC16);
-        uint8_t *minfo = slot + 5 * P.maxC16;
+        uint8_t *minfo = anchors_in_lds ? S.tile + ANCHOR_LDS_COLS + 16 : slot + 5 * P.maxC16;
         uint8_t *cstat = slot + 7 * P.maxC16;
         bool done = false;
         if (R <= 0 || C <= 0 || clen <= 0) { call.info = HITE_INFO_EXC; done = true; }
