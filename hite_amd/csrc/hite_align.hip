@@ -914,7 +914,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     HITE_CHECK(ctx, hipMemsetAsync(P.lvl, 0, (size_t)total_rows * 4, st));
     hipLaunchKernelGGL(align_rows_kernel, dim3(n_cand), dim3(256), 0, st, n_cand, d_row_first, d_win_len, row_cand, strips, skeys, (unsigned *)order);
     if (!S->sort_attr) {
-        HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, RSS_LDS_BYTES));
+        HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RSS_LDS_BYTES));
         S->sort_attr = true;
     }
     ACHK(sorter_sort(srt, skeys, (unsigned *)order, total_rows, 11));

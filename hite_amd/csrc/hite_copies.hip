@@ -193,7 +193,7 @@ __global__ void i64_to_u32_kernel(int64_t n, const int64_t *__restrict__ in, uns
 __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const uint8_t *__restrict__ cand,
                                                              const int64_t *__restrict__ cand_off,
                                                              unsigned *__restrict__ r_pos, unsigned *__restrict__ r_hs,
-                                                             int32_t *__restrict__ q_cnt) {
+                                                             int32_t *__restrict__ q_cnt, unsigned long long *__restrict__ max_len) {
     __shared__ uint8_t sb[256 * CM_KPT + CK + 8];     // sb[q] = code of base (tile - 1 + q): 0..3, 4 = not A/C/G/T or outside
     __shared__ unsigned sh[256 * CM_KPT];             // sh[q] = hs of the k-mer starting at base (tile - 1 + q)
     __shared__ int s_cnt[4];
@@ -202,6 +202,7 @@ __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const ui
         const int64_t cb = cand_off[c];
         const int L = (int)(cand_off[c + 1] - cb);
         const int nk = L - CK + 1;
+        if (threadIdx.x == 0 && L > 0) atomicMax(max_len, (unsigned long long)L);
         if (nk <= 0) { if (threadIdx.x == 0) q_cnt[c] = 0; continue; }
         const int nwin = nk >= CW ? nk - CW + 1 : 1;
         const uint8_t *s = cand + cb;
@@ -287,7 +288,22 @@ __global__ void occ_kernel(int64_t nq, const unsigned *__restrict__ q_hs, const 
     occ_n[t] = n > C_MAXOCC ? 0 : n;
 }
 
-// hits: key = candidate << 34 | rel << 33 | (d + DBIAS), value = qo.
+// Hit records.  Wide form: key = candidate << 34 | rel << 33 | (d + DBIAS), value = qo (12 bytes).  Packed form (whenever the
+// fields fit 64 bits: qbits for qo < longest candidate, dbits for d + DBIAS < n_bases + DBIAS, 1, bits of the candidate count):
+// key = candidate | rel | d + DBIAS | qo from the top down, no value array -- the radix passes move 8 instead of 12 bytes per
+// element and skip the qo bits (the order of equal diagonals stays the order of generation, as with the wide form).
+struct HitFmt {
+    int qbits, dbits;           // packed: field widths (qbits = 0: wide form)
+    const unsigned *hval;       // wide form: qo
+};
+__device__ __forceinline__ unsigned hit_cand(const HitFmt &F, unsigned long long k) { return (unsigned)(k >> (F.qbits ? F.qbits + F.dbits + 1 : 34)); }
+__device__ __forceinline__ unsigned long long hit_strand_key(const HitFmt &F, unsigned long long k) { return k >> (F.qbits ? F.qbits + F.dbits : 33); }   // candidate | rel
+__device__ __forceinline__ unsigned hit_rel(const HitFmt &F, unsigned long long k) { return (unsigned)hit_strand_key(F, k) & 1u; }
+__device__ __forceinline__ long long hit_dbias(const HitFmt &F, unsigned long long k) {      // d + DBIAS
+    return F.qbits ? (long long)((k >> F.qbits) & ((1ull << F.dbits) - 1ull)) : (long long)(k & 0x1ffffffffull);
+}
+__device__ __forceinline__ unsigned hit_qo(const HitFmt &F, unsigned long long k, int64_t i) { return F.qbits ? (unsigned)(k & ((1ull << F.qbits) - 1ull)) : F.hval[i]; }
+//
 // One wavefront expands 64 consecutive candidate minimizers: their hits are a contiguous output range (hit_off is the
 // exclusive scan of the counts), lanes walk that range 64 at a time and find the owning minimizer by a 6-step search
 // over the lanes' prefix sums (shuffles): balanced work and coalesced 12-byte stores whatever the occurrence counts are.
@@ -296,7 +312,7 @@ __global__ void __launch_bounds__(256) hit_kernel(int64_t nq, const unsigned *__
                                                   const unsigned *__restrict__ idx_hs, const unsigned *__restrict__ idx_pos,
                                                   const unsigned *__restrict__ occ_lo, const int32_t *__restrict__ occ_n,
                                                   const int64_t *__restrict__ hit_off, unsigned long long *__restrict__ hkey,
-                                                  unsigned *__restrict__ hval) {
+                                                  unsigned *__restrict__ hval, HitFmt F) {
     const int lane = threadIdx.x & 63;
     const int64_t t0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 64;
     if (t0 >= nq) return;
@@ -328,21 +344,24 @@ __global__ void __launch_bounds__(256) hit_kernel(int64_t nq, const unsigned *__
         const unsigned rel = (uqh ^ gh) & 1u;
         const long long qo = rel ? (uL - uqp - CK) : uqp;
         const long long d = gpos - qo + DBIAS;
-        hkey[o0 + j] = ((unsigned long long)uc << 34) | ((unsigned long long)rel << 33) | (unsigned long long)d;
-        hval[o0 + j] = (unsigned)qo;
+        if (F.qbits) hkey[o0 + j] = ((((unsigned long long)uc << 1 | rel) << F.dbits | (unsigned long long)d) << F.qbits) | (unsigned long long)qo;
+        else {
+            hkey[o0 + j] = ((unsigned long long)uc << 34) | ((unsigned long long)rel << 33) | (unsigned long long)d;
+            hval[o0 + j] = (unsigned)qo;
+        }
     }
 }
 
-__global__ void cluster_flag_kernel(int64_t nh, const unsigned long long *__restrict__ hkey, const unsigned *__restrict__ hval,
+__global__ void cluster_flag_kernel(int64_t nh, const unsigned long long *__restrict__ hkey, HitFmt F,
                                     const int64_t *__restrict__ coff, int nc, int32_t *__restrict__ flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nh) return;
     int f = 1;
     if (i > 0) {
         unsigned long long a = hkey[i - 1], b = hkey[i];
-        long long da = (long long)(a & 0x1ffffffffull), db = (long long)(b & 0x1ffffffffull);
-        long long ga = da - DBIAS + hval[i - 1], gb = db - DBIAS + hval[i];
-        f = (a >> 33) != (b >> 33) || db - da > C_TD || contig_of(coff, nc, ga) != contig_of(coff, nc, gb);
+        long long da = hit_dbias(F, a), db = hit_dbias(F, b);
+        long long ga = da - DBIAS + hit_qo(F, a, i - 1), gb = db - DBIAS + hit_qo(F, b, i);
+        f = hit_strand_key(F, a) != hit_strand_key(F, b) || db - da > C_TD || contig_of(coff, nc, ga) != contig_of(coff, nc, gb);
     }
     flag[i] = f;
 }
@@ -361,7 +380,7 @@ __global__ void cluster_first_kernel(int64_t nh, const int32_t *__restrict__ fla
 // scan over the lanes of a wavefront (segments = clusters), the last lane of each segment holds the wave's partial result:
 // stored directly when the whole cluster sits in this wave, merged with 64-bit atomics otherwise (c_lo / c_hi preset).
 __global__ void __launch_bounds__(256) cluster_acc_kernel(int64_t nh, const unsigned long long *__restrict__ hkey,
-                                                          const unsigned *__restrict__ hval, const int32_t *__restrict__ flag,
+                                                          HitFmt F, const int32_t *__restrict__ flag,
                                                           const int64_t *__restrict__ cid_excl, unsigned long long *__restrict__ c_lo,
                                                           unsigned long long *__restrict__ c_hi) {
     const int lane = threadIdx.x & 63;
@@ -373,8 +392,9 @@ __global__ void __launch_bounds__(256) cluster_acc_kernel(int64_t nh, const unsi
     if (have) {
         head = flag[i];
         k = cid_excl[i] + head - 1;
-        const long long d = (long long)(hkey[i] & 0x1ffffffffull) - DBIAS;
-        const unsigned qo = hval[i];
+        const unsigned long long hk = hkey[i];
+        const long long d = hit_dbias(F, hk) - DBIAS;
+        const unsigned qo = hit_qo(F, hk, i);
         lo = hi = ((unsigned long long)qo << 32) | ((unsigned long long)(d + qo) & 0xffffffffull);
     }
     int has_head = head;       // does the run of this cluster inside the wave include the cluster's first hit?
@@ -402,7 +422,7 @@ __global__ void cluster_acc_init_kernel(int64_t ncl, unsigned long long *__restr
 // WRITE = false counts the accepted clusters per candidate, WRITE = true places each record at
 // cstart[candidate] + (a per-candidate atomic counter): no single hot append counter (740 k same-address atomics cost 5 ms).
 template <bool WRITE>
-__global__ void cluster_copy_kernel(int64_t ncl, const unsigned long long *__restrict__ hkey, const unsigned *__restrict__ c_first,
+__global__ void cluster_copy_kernel(int64_t ncl, const unsigned long long *__restrict__ hkey, HitFmt F, const unsigned *__restrict__ c_first,
                                     const unsigned long long *__restrict__ c_lo, const unsigned long long *__restrict__ c_hi,
                                     const int32_t *__restrict__ c_cnt, const int64_t *__restrict__ cand_off,
                                     const int64_t *__restrict__ coff, int nc, unsigned long long *__restrict__ ckey,
@@ -414,8 +434,8 @@ __global__ void cluster_copy_kernel(int64_t ncl, const unsigned long long *__res
     int na = (int)(c_first[k + 1] - c_first[k]);
     if (na < C_MINANCH) return;
     unsigned long long key = hkey[c_first[k]];
-    unsigned c = (unsigned)(key >> 34);
-    unsigned rel = (unsigned)(key >> 33) & 1u;
+    unsigned c = hit_cand(F, key);
+    unsigned rel = hit_rel(F, key);
     long long Lq = cand_off[c + 1] - cand_off[c];
     long long qlo = (long long)(c_lo[k] >> 32), glo = (long long)(c_lo[k] & 0xffffffffull);
     long long qhi = (long long)(c_hi[k] >> 32), ghi = (long long)(c_hi[k] & 0xffffffffull);
@@ -596,7 +616,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_pos = (unsigned *)p;
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_hs = (unsigned *)p;
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
-    int64_t nq;
+    int64_t nq, max_cand_len = 0;
     {
         int32_t *q_cnt; int64_t *q_first, *qbs; unsigned *r_pos, *r_hs;
         CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); q_cnt = (int32_t *)p;
@@ -606,11 +626,13 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
         CCHK(arena_alloc(ctx, A, (size_t)(cand_bytes + 64) * 4, &p)); r_hs = (unsigned *)p;
         int wblocks = n_cand < 65536 ? n_cand : 65536;
         int tk_cm = hite_prof_begin(ctx, "cand_minimizer_kernel", st);
-        hipLaunchKernelGGL(cand_minimizer_kernel, dim3(wblocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, r_pos, r_hs, q_cnt);
+        hipLaunchKernelGGL(cand_minimizer_kernel, dim3(wblocks), dim3(256), 0, st, n_cand, d_cand, d_cand_off, r_pos, r_hs, q_cnt,
+                           (unsigned long long *)(S->d_scal + 1));
         CCHK(scan_excl_buf<int32_t>(ctx, qbs, q_cnt, n_cand, q_first, st));
         HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, q_first + n_cand, 8, hipMemcpyDeviceToDevice, st));
-        CCHK(read_back(ctx, S, st, 1));
+        CCHK(read_back(ctx, S, st, 2));
         nq = S->h_pin[0];
+        max_cand_len = S->h_pin[1];
         if ((unsigned long long)nq > qcap) return HITE_ECAP;
         S->last[0] = nq; S->last[1] = S->last[2] = S->last[3] = 0;
         hipLaunchKernelGGL(cand_minimizer_pack_kernel, dim3((n_cand + 3) / 4 < 8192 ? (n_cand + 3) / 4 : 8192), dim3(256), 0, st, n_cand,
@@ -632,16 +654,37 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     S->last[1] = nh;
     if (nh == 0) return HITE_OK;
     if (nh >= 0xffffffffll) return HITE_ECAP;
+    int cbits = 1; while ((1ll << cbits) < n_cand) cbits++;
+    int dbits = 1; while ((1ll << dbits) < ctx->n_bases + DBIAS + 1) dbits++;
+    if (dbits > 33) dbits = 33;
+    int qbits = 1; while ((1ll << qbits) < max_cand_len) qbits++;
+    HitFmt F;
+    F.qbits = qbits + dbits + 1 + cbits <= 64 ? qbits : 0; F.dbits = dbits; F.hval = nullptr;
+    {   // HITE_HITS_WIDE=1 (tests): the 12-byte form whatever the sizes
+        static const bool wide_only = [] { const char *e = getenv("HITE_HITS_WIDE"); return e && *e && atoi(e) != 0; }();
+        if (wide_only) F.qbits = 0;
+    }
     CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 8, &p)); hkey = (unsigned long long *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 4, &p)); hval = (unsigned *)p;
+    hval = nullptr;
+    if (!F.qbits) { CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 4, &p)); hval = (unsigned *)p; F.hval = hval; }
     int tk_hit_kernel = hite_prof_begin(ctx, "hit_kernel", st);
-    hipLaunchKernelGGL(hit_kernel, CGRID(nq), 0, st, nq, q_c, q_pos, q_hs, d_cand_off, S->idx_hs, S->idx_pos, occ_lo, occ_n, hit_off, hkey, hval);
+    hipLaunchKernelGGL(hit_kernel, CGRID(nq), 0, st, nq, q_c, q_pos, q_hs, d_cand_off, S->idx_hs, S->idx_pos, occ_lo, occ_n, hit_off, hkey, hval, F);
     hite_prof_end(ctx, tk_hit_kernel, st);
     Sorter so;
     CCHK(sorter_from_arena(so, ctx, A, st, nh));
-    int cbits = 1; while ((1ll << cbits) < n_cand) cbits++;
     int tk_sh = hite_prof_begin(ctx, "radix_sort_hits", st);
-    CCHK(sorter_sort(so, hkey, hval, nh, 34 + cbits));
+    {   // the key has a hole: the diagonal (gpos - qo + DBIAS < n_bases + DBIAS) rarely needs its 33 bits.  Two runs of stable
+        // passes -- the diagonal's bits, then strand + candidate -- take 3 + 2 passes at 1 Gbp / 2^17 candidates where the
+        // 51-bit key as a whole takes 6; the sorted pair of buffers is taken over instead of copied back
+        if (F.qbits) {
+            CCHK(sorter_sort_bits_swap(so, &hkey, &hval, nh, F.qbits, F.qbits + dbits));
+            CCHK(sorter_sort_bits_swap(so, &hkey, &hval, nh, F.qbits + dbits, F.qbits + dbits + 1 + cbits));
+        } else {
+            CCHK(sorter_sort_bits_swap(so, &hkey, &hval, nh, 0, dbits));
+            CCHK(sorter_sort_bits_swap(so, &hkey, &hval, nh, 33, 34 + cbits));
+            F.hval = hval;
+        }
+    }
     hite_prof_end(ctx, tk_sh, st);
     // clusters
     CCHK(arena_alloc(ctx, A, (size_t)(nh + 1) * 4, &p)); flag = (int32_t *)p;
@@ -649,7 +692,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     int64_t *bs2;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(nh) * 8, &p)); bs2 = (int64_t *)p;
     int tk_cluster_flag_kernel = hite_prof_begin(ctx, "cluster_flag_kernel", st);
-    hipLaunchKernelGGL(cluster_flag_kernel, CGRID(nh), 0, st, nh, hkey, hval, ctx->d_contig_off, ctx->n_contigs, flag);
+    hipLaunchKernelGGL(cluster_flag_kernel, CGRID(nh), 0, st, nh, hkey, F, ctx->d_contig_off, ctx->n_contigs, flag);
     hite_prof_end(ctx, tk_cluster_flag_kernel, st);
     CCHK(scan_excl_buf<int32_t>(ctx, bs2, flag, nh, cid, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cid + nh, 8, hipMemcpyDeviceToDevice, st));
@@ -663,7 +706,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     hipLaunchKernelGGL(cluster_first_kernel, CGRID(nh), 0, st, nh, flag, cid, c_first, ncl);
     int tk_cluster_acc_kernel = hite_prof_begin(ctx, "cluster_acc_kernel", st);
     hipLaunchKernelGGL(cluster_acc_init_kernel, CGRID(ncl), 0, st, ncl, c_lo, c_hi);
-    hipLaunchKernelGGL(cluster_acc_kernel, CGRID(nh), 0, st, nh, hkey, hval, flag, cid, c_lo, c_hi);
+    hipLaunchKernelGGL(cluster_acc_kernel, CGRID(nh), 0, st, nh, hkey, F, flag, cid, c_lo, c_hi);
     hite_prof_end(ctx, tk_cluster_acc_kernel, st);
     // clusters -> copies
     int32_t *r_contig, *r_anch;
@@ -688,10 +731,10 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     int64_t *bs3;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(n_cand) * 8, &p)); bs3 = (int64_t *)p;
     int tk_cluster_copy_kernel = hite_prof_begin(ctx, "cluster_copy_kernel", st);
-    hipLaunchKernelGGL(cluster_copy_kernel<false>, CGRID(ncl), 0, st, ncl, hkey, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
+    hipLaunchKernelGGL(cluster_copy_kernel<false>, CGRID(ncl), 0, st, ncl, hkey, F, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
                        ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, per_cand, (const int64_t *)nullptr);
     CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand, n_cand, cstart, st));
-    hipLaunchKernelGGL(cluster_copy_kernel<true>, CGRID(ncl), 0, st, ncl, hkey, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
+    hipLaunchKernelGGL(cluster_copy_kernel<true>, CGRID(ncl), 0, st, ncl, hkey, F, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
                        ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, fill, (const int64_t *)cstart);
     hite_prof_end(ctx, tk_cluster_copy_kernel, st);
     hipLaunchKernelGGL(cap300_kernel, CGRID((int64_t)n_cand), 0, st, n_cand, per_cand, per_cand300);

@@ -50,7 +50,7 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
         int64_t i = tile + it * 256 + threadIdx.x;
         bool act = i < n;
         unsigned long long k = act ? kin[i] : 0;
-        unsigned v = act ? vin[i] : 0;
+        unsigned v = (act && vin) ? vin[i] : 0;       // vin == NULL: keys only
         int d = (int)((k >> shift) & (unsigned long long)(BINS - 1));
         // lanes of this wave with the same digit (inactive lanes match nothing)
         unsigned long long peers = __ballot(act);
@@ -66,7 +66,8 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
         if (act) {
             unsigned pos = base[d] + (unsigned)rank;
             for (int q = 0; q < w; q++) pos += (unsigned)cnt[q][d];
-            kout[pos] = k; vout[pos] = v;
+            kout[pos] = k;
+            if (vin) vout[pos] = v;
         }
         __syncthreads();
         if (act && rank == 0) { atomicAdd(&base[d], (unsigned)mine); cnt[w][d] = 0; }
@@ -83,6 +84,7 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
 // LDS: keys 64 KB | values 32 KB | per-wave digit offsets u16 [8][1024] 16 KB | run shift u32 [1024] 4 KB | scan 64 B.
 #define RSS_TILE 8192
 #define RSS_LDS_BYTES (RSS_TILE * 12 + 8 * 1024 * 2 + 1024 * 4 + 64)
+template <bool VALS>
 static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const unsigned long long *__restrict__ kin, const unsigned *__restrict__ vin,
                                                                        unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
                                                                        int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
@@ -102,7 +104,7 @@ static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const uns
         const int64_t i = tile + w * 1024 + r * 64 + lane;
         const bool act = i < n;
         k[r] = act ? kin[i] : 0ull;
-        v[r] = act ? vin[i] : 0u;
+        v[r] = (VALS && act) ? vin[i] : 0u;
     }
     for (int b = threadIdx.x; b < 8 * 1024; b += 512) woff[b] = 0;
     __syncthreads();
@@ -157,7 +159,7 @@ static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const uns
         int pos = 0;
         if (act) pos = myoff[d] + rank;
         __builtin_amdgcn_wave_barrier();
-        if (act) { skey[pos] = k[r]; sval[pos] = v[r]; if (rank == 0) myoff[d] = (unsigned short)(myoff[d] + mine); }
+        if (act) { skey[pos] = k[r]; if (VALS) sval[pos] = v[r]; if (rank == 0) myoff[d] = (unsigned short)(myoff[d] + mine); }
         __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
@@ -166,7 +168,7 @@ static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const uns
         const unsigned long long key = skey[j];
         const unsigned pos = (unsigned)j + delta[(int)((key >> shift) & 1023ull)];
         kout[pos] = key;
-        vout[pos] = sval[j];
+        if (VALS) vout[pos] = sval[j];
     }
 }
 
@@ -190,7 +192,9 @@ static inline int64_t sorter_hist_elems(int64_t n) {
 
 static int sorter_init(Sorter &S, hite_ctx *ctx, hipStream_t st, int64_t n) {
     S.ctx = ctx; S.st = st; S.cap = n;
-    HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+    HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        RSS_LDS_BYTES));
+    HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         RSS_LDS_BYTES));
     S.hist_n = sorter_hist_elems(n);
     HITE_CHECK(ctx, hipMalloc((void **)&S.k2, (size_t)(n + 1) * 8));
@@ -208,7 +212,9 @@ static void sorter_free(Sorter &S) {
     if (S.bs) (void)hipFree(S.bs);
 }
 // sorts (keys, vals) in place (ping-pong through the sorter's buffers) on the key bits [lo_bit, hi_bit), stable
-static int sorter_sort_bits(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int lo_bit, int hi_bit) {
+static int sorter_sort_bits_impl(Sorter &S, unsigned long long **keys_io, unsigned **vals_io, int64_t n, int lo_bit, int hi_bit, bool swap) {
+    unsigned long long *keys = *keys_io;
+    unsigned *vals = *vals_io;
     if (n <= 1) return HITE_OK;
     if (n >= 0xffffffffll) return HITE_EINVAL;   // 32-bit positions inside the scatter kernel
     // HITE_SORT_WIDE_MIN (tests): element count from which the 10-bit staged form is used, default RS_WIDE_MIN
@@ -218,7 +224,7 @@ static int sorter_sort_bits(Sorter &S, unsigned long long *keys, unsigned *vals,
     const int tile = wide ? 8192 : RS_TILE;
     int nblocks = (int)((n + tile - 1) / tile);
     unsigned long long *ka = keys, *kb = S.k2;
-    unsigned *va = vals, *vb = S.v2;
+    unsigned *va = vals, *vb = vals ? S.v2 : nullptr;      // vals == NULL: keys only (8 instead of 12 bytes moved per element and pass)
     int passes = (hi_bit - lo_bit + bits - 1) / bits;
     for (int p = 0; p < passes; p++) {
         const int sh = lo_bit + p * bits;
@@ -226,17 +232,29 @@ static int sorter_sort_bits(Sorter &S, unsigned long long *keys, unsigned *vals,
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
         int rc = scan_excl_buf<int32_t>(S.ctx, S.bs, S.hist, (int64_t)(1 << bits) * nblocks, S.offs, S.st);
         if (rc) return rc;
-        if (wide) hipLaunchKernelGGL(rs_scatter_staged_kernel, dim3(nblocks), dim3(512), RSS_LDS_BYTES, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
+        if (wide && vals) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_staged_kernel<true>), dim3(nblocks), dim3(512), RSS_LDS_BYTES, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
+        else if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_staged_kernel<false>), dim3(nblocks), dim3(512), RSS_LDS_BYTES, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         unsigned long long *tk = ka; ka = kb; kb = tk;
         unsigned *tv = va; va = vb; vb = tv;
     }
     if (ka != keys) {
-        HITE_CHECK(S.ctx, hipMemcpyAsync(keys, ka, (size_t)n * 8, hipMemcpyDeviceToDevice, S.st));
-        HITE_CHECK(S.ctx, hipMemcpyAsync(vals, va, (size_t)n * 4, hipMemcpyDeviceToDevice, S.st));
+        if (swap) { *keys_io = ka; S.k2 = keys; if (vals) { *vals_io = va; S.v2 = vals; } }   // the caller goes on with the other buffers
+        else {
+            HITE_CHECK(S.ctx, hipMemcpyAsync(keys, ka, (size_t)n * 8, hipMemcpyDeviceToDevice, S.st));
+            if (vals) HITE_CHECK(S.ctx, hipMemcpyAsync(vals, va, (size_t)n * 4, hipMemcpyDeviceToDevice, S.st));
+        }
     }
     HITE_CHECK(S.ctx, hipGetLastError());
     return HITE_OK;
+}
+static int sorter_sort_bits(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int lo_bit, int hi_bit) {
+    return sorter_sort_bits_impl(S, &keys, &vals, n, lo_bit, hi_bit, false);
+}
+// the same without the copy back after an odd number of passes: *keys / *vals name the sorted buffers on return (either the
+// caller's or the sorter's second pair: both stay valid)
+static int sorter_sort_bits_swap(Sorter &S, unsigned long long **keys, unsigned **vals, int64_t n, int lo_bit, int hi_bit) {
+    return sorter_sort_bits_impl(S, keys, vals, n, lo_bit, hi_bit, true);
 }
 // bits [0, nbits)
 static int sorter_sort(Sorter &S, unsigned long long *keys, unsigned *vals, int64_t n, int nbits) {

@@ -962,6 +962,13 @@ def test_wide_radix_sort_on_small_inputs(tmp_path):
                          "fmea or query_copies or lib_dedup or find_copies or seed_allvsall"], env=env, capture_output=True, text=True, cwd=root)
     assert rc.returncode == 0, rc.stdout[-3000:] + rc.stderr[-2000:]
     assert " passed" in rc.stdout
+    # the copy finder's hits travel as packed 8-byte records when their fields fit 64 bits (always, at test sizes): the
+    # 12-byte key + value form, with both radix-sort forms, must give the same tables
+    for extra in ({"HITE_HITS_WIDE": "1"}, {"HITE_HITS_WIDE": "1", "HITE_SORT_WIDE_MIN": "2"}):
+        rc = subprocess.run([_sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                             "find_copies or hot_path or flank_region_align"], env=dict(os.environ, **extra), capture_output=True, text=True, cwd=root)
+        assert rc.returncode == 0, rc.stdout[-3000:] + rc.stderr[-2000:]
+        assert " passed" in rc.stdout
 
 
 def test_fmea_stress_hash(ctx):
