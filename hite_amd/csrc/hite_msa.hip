@@ -291,45 +291,46 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
         const int nrow = P.win_len[g0 + msa_src(P.row_map, g0, r)];
         const uint16_t *rop = ops + (int64_t)r * rs;
         uint8_t *row = out + (int64_t)r * C;
+        const bool centre = r == 0;       // the centre row: position p faces its own base p
         for (int p0 = threadIdx.x; p0 <= m; p0 += FILL_U * 256) {
-            int p[FILL_U], kw[FILL_U], kc[FILL_U], gap[FILL_U], q[FILL_U], bs[FILL_U];
-            bool live[FILL_U], ex[FILL_U];
-            unsigned ks[FILL_U], oc[FILL_U];
-            // three memory instructions per output byte on the common path (layout word, op, base) + the store: the kernel is
-            // bound by the rate the texture addresser takes wave64 instructions (16 cycles each), not by bytes -- the op before
-            // the position, which only an insertion block needs, is fetched where one is kept
+            // the common position keeps its centre column and nothing else: layout word, op, base, one store -- straight-line
+            // code for FILL_U positions, their loads issued level by level.  Kept insertion columns and the extra last column
+            // are rare and leave through one branch at the end (the kernel is bound by instruction issue: every branch that a
+            // wave takes for one of its lanes costs all 64)
+            unsigned w[FILL_U], oc[FILL_U];
 #pragma unroll
             for (int u = 0; u < FILL_U; u++) {
-                p[u] = p0 + u * 256;
-                live[u] = p[u] <= m;
-                if (!live[u]) p[u] = 0;
-                ks[u] = lay[p[u]];
-                oc[u] = (r > 0 && p[u] < m) ? rop[p[u]] : 0u;
+                const int p = p0 + u * 256;
+                w[u] = p <= m ? lay[p] : 0u;
+                oc[u] = centre ? (unsigned)p : (p < m ? (unsigned)rop[p] : 0x8000u);
             }
+            uint8_t ch[FILL_U];
+#pragma unroll
+            for (int u = 0; u < FILL_U; u++) ch[u] = ((w[u] >> 15) & 1u) && !(oc[u] >> 15) ? b[oc[u] & 0x7fffu] : (uint8_t)'-';
+            bool rare = false;
 #pragma unroll
             for (int u = 0; u < FILL_U; u++) {
-                kw[u] = (int)(ks[u] & 0x7fff); kc[u] = (int)(ks[u] >> 15) & 1; bs[u] = (int)(ks[u] >> 16);
-                ex[u] = p[u] == m && le >= 0;
-                live[u] = live[u] && (kw[u] != 0 || kc[u] || ex[u]);
-                if (r == 0) { q[u] = p[u]; gap[u] = 0; }
-                else { q[u] = p[u] < m ? (int)(oc[u] & 0x7fff) : nrow; gap[u] = (int)(oc[u] >> 15); }
+                const unsigned kw = w[u] & 0x7fffu;
+                if ((w[u] >> 15) & 1u) row[(w[u] >> 16) + kw] = ch[u];
+                rare = rare || kw != 0u || (p0 + u * 256 == m && le >= 0);
             }
-            uint8_t cb[FILL_U];
-#pragma unroll
-            for (int u = 0; u < FILL_U; u++) cb[u] = (live[u] && kc[u] && !gap[u]) ? b[q[u]] : (uint8_t)'-';
-#pragma unroll
-            for (int u = 0; u < FILL_U; u++) {
-                if (!live[u]) continue;
-                if (kc[u]) row[bs[u] + kw[u]] = cb[u];
-                if (kw[u] == 0 && !ex[u]) continue;
-                int ins = 0;
-                if (r > 0) {
-                    const unsigned op = p[u] > 0 ? rop[p[u] - 1] : 0u;
-                    ins = q[u] - (p[u] > 0 ? (int)(op & 0x7fff) + ((op >> 15) ? 0 : 1) : 0);
+            if (rare) {
+#pragma unroll 1
+                for (int u = 0; u < FILL_U; u++) {
+                    const int p = p0 + u * 256;
+                    const int kw = (int)(w[u] & 0x7fffu), bs = (int)(w[u] >> 16);
+                    const bool ex = p == m && le >= 0;
+                    if (p > m || (kw == 0 && !ex)) continue;
+                    int ins = 0, q = p;
+                    if (!centre) {
+                        q = p < m ? (int)(oc[u] & 0x7fffu) : nrow;
+                        const unsigned op = p > 0 ? rop[p - 1] : 0u;
+                        ins = q - (p > 0 ? (int)(op & 0x7fff) + ((op >> 15) ? 0 : 1) : 0);
+                    }
+                    const int rp = q - ins;  // first inserted base
+                    for (int k = 0; k < kw; k++) row[bs + k] = k < ins ? b[rp + k] : (uint8_t)'-';
+                    if (ex) row[bs + kw] = le < ins ? b[rp + le] : (uint8_t)'-';
                 }
-                const int rp = q[u] - ins;  // first inserted base
-                for (int k = 0; k < kw[u]; k++) row[bs[u] + k] = k < ins ? b[rp + k] : (uint8_t)'-';
-                if (ex[u]) row[bs[u] + kw[u]] = le < ins ? b[rp + le] : (uint8_t)'-';
             }
         }
     }
