@@ -883,7 +883,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     ACHK(aalloc(ctx, A, (size_t)total_rows + 1, &srt.v2));
     ACHK(aalloc(ctx, A, (size_t)srt.hist_n, &srt.hist));
     ACHK(aalloc(ctx, A, (size_t)srt.hist_n + 1, &srt.offs));
-    ACHK(aalloc(ctx, A, (size_t)scan_tmp_elems(srt.hist_n), &srt.bs));
+    ACHK(aalloc(ctx, A, (size_t)sorter_tmp_elems(srt.hist_n), &srt.bs));
     ACHK(aalloc(ctx, A, (size_t)n_cand, &pwords));
     ACHK(aalloc(ctx, A, (size_t)n_cand + 1, &plane_off));
     ACHK(aalloc(ctx, A, (size_t)total_rows, &rec));

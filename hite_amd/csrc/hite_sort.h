@@ -28,7 +28,63 @@ static __global__ void __launch_bounds__(256) rs_hist_kernel(const unsigned long
         if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & (unsigned long long)(BINS - 1))], 1);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < BINS; b += 256) hist[(int64_t)b * nblocks + blockIdx.x] = h[b];
+    for (int b = threadIdx.x; b < BINS; b += 256) hist[(int64_t)blockIdx.x * BINS + b] = h[b];      // tile-major: one coalesced run per tile
+}
+
+// ---------------------------------------------------------------------------------------------
+// offsets of every (tile, digit): offs[t][d] = elements with a smaller digit + elements of digit d in the tiles before t.
+// The histogram is tile-major (a tile's histogram is written and its offsets are read as one contiguous run; the digit-major
+// form cost a 64-byte sector per 4-byte counter on both sides: PMC showed 1 GB written per pass for a 100 MB histogram), so
+// the scan runs down the columns of the [tile][digit] matrix: column sums of groups of RS_GROUP tiles, a scan of the group
+// sums along each column (one wavefront per digit), a scan of the digit totals, and the running sums inside each group.
+// ---------------------------------------------------------------------------------------------
+#define RS_GROUP 64
+template <int BINS>
+static __global__ void __launch_bounds__(256) rs_colsum_kernel(const int32_t *__restrict__ hist, int nblocks, long long *__restrict__ gsum /* [groups][BINS] */) {
+    const int d = blockIdx.y * 256 + threadIdx.x, g = blockIdx.x;
+    const int t0 = g * RS_GROUP, t1 = t0 + RS_GROUP < nblocks ? t0 + RS_GROUP : nblocks;
+    long long acc = 0;
+    for (int t = t0; t < t1; t++) acc += hist[(int64_t)t * BINS + d];
+    gsum[(int64_t)g * BINS + d] = acc;
+}
+// one wavefront per digit: exclusive scan of its group sums (in place), digit total out
+template <int BINS>
+static __global__ void __launch_bounds__(256) rs_colscan_kernel(long long *__restrict__ gsum, int ngroups, long long *__restrict__ dtot) {
+    const int lane = threadIdx.x & 63, d = blockIdx.x * 4 + (threadIdx.x >> 6);
+    long long carry = 0;
+    for (int base = 0; base < ngroups; base += 64) {
+        const int g = base + lane;
+        const long long v = g < ngroups ? gsum[(int64_t)g * BINS + d] : 0;
+        long long x = v;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) { const long long y = __shfl_up(x, dd, 64); if (lane >= dd) x += y; }
+        if (g < ngroups) gsum[(int64_t)g * BINS + d] = carry + x - v;
+        carry += __shfl(x, 63, 64);
+    }
+    if (lane == 0) dtot[d] = carry;
+}
+// exclusive scan of the digit totals (one block)
+template <int BINS>
+static __global__ void __launch_bounds__(BINS > 1024 ? 1024 : BINS) rs_digitscan_kernel(long long *__restrict__ dtot) {
+    __shared__ long long s_w[16];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const long long v = dtot[threadIdx.x];
+    long long x = v;
+#pragma unroll
+    for (int dd = 1; dd < 64; dd <<= 1) { const long long y = __shfl_up(x, dd, 64); if (lane >= dd) x += y; }
+    if (lane == 63) s_w[w] = x;
+    __syncthreads();
+    long long pre = 0;
+    for (int q = 0; q < w; q++) pre += s_w[q];
+    dtot[threadIdx.x] = pre + x - v;
+}
+template <int BINS>
+static __global__ void __launch_bounds__(256) rs_coloffs_kernel(const int32_t *__restrict__ hist, int nblocks, const long long *__restrict__ gsum,
+                                                                const long long *__restrict__ dbase, int64_t *__restrict__ offs) {
+    const int d = blockIdx.y * 256 + threadIdx.x, g = blockIdx.x;
+    const int t0 = g * RS_GROUP, t1 = t0 + RS_GROUP < nblocks ? t0 + RS_GROUP : nblocks;
+    long long run = gsum[(int64_t)g * BINS + d] + dbase[d];
+    for (int t = t0; t < t1; t++) { offs[(int64_t)t * BINS + d] = run; run += hist[(int64_t)t * BINS + d]; }
 }
 
 template <int BITS, int ITEMS>
@@ -40,7 +96,7 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
     __shared__ int cnt[4][BINS];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int b = threadIdx.x; b < BINS; b += 256) {
-        base[b] = (unsigned)offs[(int64_t)b * nblocks + blockIdx.x];
+        base[b] = (unsigned)offs[(int64_t)blockIdx.x * BINS + b];
         cnt[0][b] = 0; cnt[1][b] = 0; cnt[2][b] = 0; cnt[3][b] = 0;
     }
     __syncthreads();
@@ -140,8 +196,8 @@ static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const uns
         for (int q = 0; q < w; q++) pre += wsum[q];
         // pre = local start of digit d0, pre + c0 = local start of digit d0 + 1
         int s0 = pre, s1 = pre + c0;
-        delta[d0] = (unsigned)offs[(int64_t)d0 * nblocks + blockIdx.x] - (unsigned)s0;
-        delta[d0 + 1] = (unsigned)offs[(int64_t)(d0 + 1) * nblocks + blockIdx.x] - (unsigned)s1;
+        delta[d0] = (unsigned)offs[(int64_t)blockIdx.x * 1024 + d0] - (unsigned)s0;
+        delta[d0 + 1] = (unsigned)offs[(int64_t)blockIdx.x * 1024 + d0 + 1] - (unsigned)s1;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int a0 = woff[q * 1024 + d0], a1 = woff[q * 1024 + d0 + 1];
@@ -183,6 +239,8 @@ struct Sorter {
     int64_t hist_n = 0;
 };
 // histogram entries a sort of n elements needs (the larger of the two forms)
+// int64 elements of scan scratch (Sorter::bs) for a histogram of hist_n counters: the group sums + the digit totals
+static inline int64_t sorter_tmp_elems(int64_t hist_n) { return hist_n / RS_GROUP + 3 * 1024 + 64; }
 static inline int64_t sorter_hist_elems(int64_t n) {
     int64_t nb8 = (n + RS_TILE - 1) / RS_TILE; if (nb8 < 1) nb8 = 1;
     int64_t nb10 = (n + 8191) / 8192; if (nb10 < 1) nb10 = 1;
@@ -201,7 +259,7 @@ static int sorter_init(Sorter &S, hite_ctx *ctx, hipStream_t st, int64_t n) {
     HITE_CHECK(ctx, hipMalloc((void **)&S.v2, (size_t)(n + 1) * 4));
     HITE_CHECK(ctx, hipMalloc((void **)&S.hist, (size_t)S.hist_n * 4));
     HITE_CHECK(ctx, hipMalloc((void **)&S.offs, (size_t)(S.hist_n + 1) * 8));
-    HITE_CHECK(ctx, hipMalloc((void **)&S.bs, (size_t)scan_tmp_elems(S.hist_n) * 8));
+    HITE_CHECK(ctx, hipMalloc((void **)&S.bs, (size_t)sorter_tmp_elems(S.hist_n) * 8));
     return HITE_OK;
 }
 static void sorter_free(Sorter &S) {
@@ -230,8 +288,21 @@ static int sorter_sort_bits_impl(Sorter &S, unsigned long long **keys_io, unsign
         const int sh = lo_bit + p * bits;
         if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<10, 32>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
-        int rc = scan_excl_buf<int32_t>(S.ctx, S.bs, S.hist, (int64_t)(1 << bits) * nblocks, S.offs, S.st);
-        if (rc) return rc;
+        {
+            const int ngroups = (nblocks + RS_GROUP - 1) / RS_GROUP;
+            long long *gsum = reinterpret_cast<long long *>(S.bs), *dtot = gsum + (int64_t)ngroups * (1 << bits);
+            if (wide) {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_colsum_kernel<1024>), dim3(ngroups, 4), dim3(256), 0, S.st, S.hist, nblocks, gsum);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_colscan_kernel<1024>), dim3(256), dim3(256), 0, S.st, gsum, ngroups, dtot);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_digitscan_kernel<1024>), dim3(1), dim3(1024), 0, S.st, dtot);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_coloffs_kernel<1024>), dim3(ngroups, 4), dim3(256), 0, S.st, S.hist, nblocks, gsum, dtot, S.offs);
+            } else {
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_colsum_kernel<256>), dim3(ngroups, 1), dim3(256), 0, S.st, S.hist, nblocks, gsum);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_colscan_kernel<256>), dim3(64), dim3(256), 0, S.st, gsum, ngroups, dtot);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_digitscan_kernel<256>), dim3(1), dim3(256), 0, S.st, dtot);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_coloffs_kernel<256>), dim3(ngroups, 1), dim3(256), 0, S.st, S.hist, nblocks, gsum, dtot, S.offs);
+            }
+        }
         if (wide && vals) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_staged_kernel<true>), dim3(nblocks), dim3(512), RSS_LDS_BYTES, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         else if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_staged_kernel<false>), dim3(nblocks), dim3(512), RSS_LDS_BYTES, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
