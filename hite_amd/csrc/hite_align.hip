@@ -712,21 +712,33 @@ __global__ void align_assign_kernel(int64_t cnt, const int32_t *__restrict__ lis
     if (x < cnt) rec[list[x]] = (unsigned long long)(uintptr_t)(region + boff[x >> 6] * (int64_t)AL_RECB + (x & 63) * 32);
 }
 // counters: [0] pairs, [1] certified, [2] kept from a band of > 4 words, [3] fall-back, [4] dropped, [5] sum of U, [6] columns
-__global__ void align_stats_kernel(int64_t total_rows, const int32_t *__restrict__ strips, AlignArgs P, int32_t *__restrict__ row_dead,
-                                   int32_t *__restrict__ cand_status, unsigned long long *__restrict__ acc) {
+__global__ void __launch_bounds__(256) align_stats_kernel(int64_t total_rows, const int32_t *__restrict__ strips, AlignArgs P, int32_t *__restrict__ row_dead,
+                                                          int32_t *__restrict__ cand_status, unsigned long long *__restrict__ acc) {
+    // (sums over the wavefront first: seven same-address atomics per row were 0.6 ms per launch)
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total_rows) return;
-    if (strips[g] <= 0) { if (row_dead) row_dead[g] = 0; return; }
-    const int st = P.st[g];
-    atomicAdd(&acc[0], 1ull);
-    if (st == 0 && P.U[g] <= P.kst[g]) atomicAdd(&acc[1], 1ull);
-    if (st == 0 && (P.lvl[g] & 0xff) > 4) atomicAdd(&acc[2], 1ull);
-    if (P.lvl[g] & 0x100) atomicAdd(&acc[3], 1ull);
-    if (st != 0) atomicAdd(&acc[4], 1ull);
-    if (st == 0) atomicAdd(&acc[5], (unsigned long long)P.U[g]);
-    atomicAdd(&acc[6], (unsigned long long)P.win_len[g]);
-    if (row_dead) row_dead[g] = st != 0;
-    if (st != 0 && cand_status) atomicExch(&cand_status[P.row_cand[g]], 2);
+    unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
+    if (g < total_rows) {
+        if (strips[g] <= 0) { if (row_dead) row_dead[g] = 0; }
+        else {
+            const int st = P.st[g];
+            v[0] = 1ull;
+            v[1] = st == 0 && P.U[g] <= P.kst[g];
+            v[2] = st == 0 && (P.lvl[g] & 0xff) > 4;
+            v[3] = (P.lvl[g] & 0x100) != 0;
+            v[4] = st != 0;
+            v[5] = st == 0 ? (unsigned long long)P.U[g] : 0ull;
+            v[6] = (unsigned long long)P.win_len[g];
+            if (row_dead) row_dead[g] = st != 0;
+            if (st != 0 && cand_status) atomicExch(&cand_status[P.row_cand[g]], 2);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 7; q++) {
+        unsigned long long x = v[q];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&acc[q], x);
+    }
 }
 __global__ void align_info_kernel(int64_t total_rows, AlignArgs P, int32_t *__restrict__ info /* 5 per row */) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
