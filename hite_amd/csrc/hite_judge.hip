@@ -28,6 +28,7 @@
 #define CS 12           // bytes of column statistics per column: cnt[6], first[6]
 #define SCR_PER_COL 32  // scratch bytes per column per block slot
 #define ANCHOR_LDS_COLS 5104   // ungapped row (<= this many bytes) + 2 bytes of match record per text start fit the 15 KB mask area
+#define FNM_LIST 320    // 64 flagged ends x (2 k + 1 = 5) starts
 #define TILE_COLS 160   // widest column span staged in LDS for the window scans (wider spans read the alignment directly)
 
 struct JShared {
@@ -42,6 +43,8 @@ struct JShared {
     unsigned peq[8];       // Myers match masks per symbol class
     int nflag;             // flagged match ends of the current anchor search
     int flagged[64];
+    uint16_t mst[FNM_LIST]; // match list of the anchor search: start, longest match length, best distance << 5 | its length, group start
+    uint8_t mml[FNM_LIST], mb[FNM_LIST], mgs[FNM_LIST];
     int tsd[25];
     int fo[5], eo[5];
     alignas(16) uint8_t tile[TILE_COLS * 6 * 4 * 4];   // row-set masks of the current scan: per column and symbol class, up to 4 words of 32 rows
@@ -141,49 +144,10 @@ __device__ int blk_ungap_row(const uint8_t *__restrict__ row, int C, uint8_t *__
 // of the FIRST overlap group; side 1: end (exclusive) of the best match of the LAST group.
 // Returns -1 when there is no match.  minfo: 2 bytes per text start.
 // ---------------------------------------------------------------------------------------------
-__device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ ung, int n, int k,
-                       uint8_t *__restrict__ minfo, int side, JShared &S) {
-    // Phase 1 (filter): Myers' bit-parallel approximate search.  Each thread scans a chunk of end positions
-    // (plus m+k characters of warm-up, which makes every distance <= k exact) and flags the ends where
-    // the pattern matches within k edits; 17 word operations per character instead of one banded DP per start.
-    // Phase 2: the exact per-start banded DP runs only for the <= 2k+1 starts that can end at a flagged position.
+// the form with a match record per text start (2 bytes, minfo): used when the filter flags more than 64 ends (repetitive text)
+__device__ int blk_fnm_full(const uint8_t *pat, int m, const uint8_t *__restrict__ ung, int n, int k,
+                            uint8_t *__restrict__ minfo, int side, JShared &S) {
     for (int i = threadIdx.x; i < 2 * n; i += JB) minfo[i] = 0;
-    if (threadIdx.x < 8) {
-        unsigned mk = 0;
-        for (int i = 0; i < m; i++) if (sym_class(pat[i]) == (int)threadIdx.x) mk |= 1u << i;
-        S.peq[threadIdx.x] = mk;
-        if (threadIdx.x == 0) S.nflag = 0;
-    }
-    __syncthreads();
-    {
-        int L = (n + JB - 1) / JB;
-        if (L < 6) L = 6;
-        const int cs = threadIdx.x * L;            // ends [cs, cs + L) belong to this thread (end = index of last char)
-        if (cs < n) {
-            const int ce = cs + L < n ? cs + L : n;
-            int j0 = cs - (m + k); if (j0 < 0) j0 = 0;
-            unsigned Pv = 0xffffffffu, Mv = 0;
-            int score = m;
-            const unsigned top = 1u << (m - 1);
-            for (int j = j0; j < ce; j++) {
-                const unsigned Eq = S.peq[sym_class(ung[j])];
-                const unsigned Xv = Eq | Mv;
-                const unsigned Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
-                unsigned Ph = Mv | ~(Xh | Pv);
-                unsigned Mh = Pv & Xh;
-                score += (Ph & top) ? 1 : 0;
-                score -= (Mh & top) ? 1 : 0;
-                Ph <<= 1; Mh <<= 1;
-                Pv = Mh | ~(Xv | Ph);
-                Mv = Ph & Xv;
-                if (j >= cs && score <= k) {
-                    // a match ends at character j: remember the exclusive end e = j + 1
-                    const int q = atomicAdd(&S.nflag, 1);
-                    if (q < 64) S.flagged[q] = j + 1;
-                }
-            }
-        }
-    }
     __syncthreads();
     {
         // Phase 2: exact banded DP for the starts e-(m+k) .. e-(m-k) of every flagged end, one (end, start)
@@ -260,6 +224,126 @@ __device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ un
         }
         __syncthreads();
         unsigned key = S.red[3];
+        result = (int)(key & 0xffffu) + (int)(63u - ((key >> 16) & 0xffu));
+    }
+    __syncthreads();
+    return result;
+}
+
+__device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ ung, int n, int k,
+                       uint8_t *__restrict__ minfo, int side, JShared &S) {
+    // Phase 1 (filter): Myers' bit-parallel approximate search.  Each thread scans a chunk of end positions
+    // (plus m+k characters of warm-up, which makes every distance <= k exact) and flags the ends where
+    // the pattern matches within k edits; 17 word operations per character instead of one banded DP per start.
+    // Chunks are at least as long as the warm-up: the kernel is bound by instruction issue, and with 12-character chunks
+    // (2 700 characters over 256 threads) two thirds of the filter's instructions were warm-up (chunks of twice the warm-up
+    // measured better on long rows, worse on short ones: the chain of one thread gets too long).
+    // Phase 2: the exact per-start banded DP runs only for the <= 2k+1 starts that can end at a flagged position; their
+    // match records form a LIST (<= 64 ends x 5 starts) on which the overlap-group rule is evaluated pair by pair -- no
+    // per-start array to clear and to scan three times.
+    if (threadIdx.x < 8) {
+        unsigned mk = 0;
+        for (int i = 0; i < m; i++) if (sym_class(pat[i]) == (int)threadIdx.x) mk |= 1u << i;
+        S.peq[threadIdx.x] = mk;
+        if (threadIdx.x == 0) S.nflag = 0;
+    }
+    __syncthreads();
+    {
+        int L = (n + JB - 1) / JB;
+        if (L < m + k) L = m + k;
+        const int cs = threadIdx.x * L;            // ends [cs, cs + L) belong to this thread (end = index of last char)
+        if (cs < n) {
+            const int ce = cs + L < n ? cs + L : n;
+            int j0 = cs - (m + k); if (j0 < 0) j0 = 0;
+            unsigned Pv = 0xffffffffu, Mv = 0;
+            int score = m;
+            const unsigned top = 1u << (m - 1);
+            for (int j = j0; j < ce; j++) {
+                const unsigned Eq = S.peq[sym_class(ung[j])];
+                const unsigned Xv = Eq | Mv;
+                const unsigned Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
+                unsigned Ph = Mv | ~(Xh | Pv);
+                unsigned Mh = Pv & Xh;
+                score += (Ph & top) ? 1 : 0;
+                score -= (Mh & top) ? 1 : 0;
+                Ph <<= 1; Mh <<= 1;
+                Pv = Mh | ~(Xv | Ph);
+                Mv = Ph & Xv;
+                if (j >= cs && score <= k) {
+                    // a match ends at character j: remember the exclusive end e = j + 1
+                    const int q = atomicAdd(&S.nflag, 1);
+                    if (q < 64) S.flagged[q] = j + 1;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const int nf = S.nflag;
+    if (nf == 0) return -1;
+    if (nf > 64) return blk_fnm_full(pat, m, ung, n, k, minfo, side, S);
+    const int span = 2 * k + 1, N = nf * span;                 // N <= FNM_LIST
+    for (int t = threadIdx.x; t < N; t += JB) {
+        const int st = S.flagged[t / span] - (m + k) + (t % span);
+        int maxL = 0, bd = 3, bL = 0;
+        if (st >= 0 && st < n) {
+            const int w = (m + k) < (n - st) ? (m + k) : (n - st);
+            if (w >= m - k && w > 0) {
+                int d[5];
+                banded_dist(pat, m, ung + st, w, k, d);
+                const int L0 = m - k > 1 ? m - k : 1;
+                for (int LL = L0; LL <= w && LL <= m + k; LL++) {
+                    const int dd = d[LL - (m - 2)];
+                    if (dd <= k) { maxL = LL; if (dd < bd || (dd == bd && LL > bL)) { bd = dd; bL = LL; } }
+                }
+            }
+        }
+        S.mst[t] = (uint16_t)(maxL ? st : 0);
+        S.mml[t] = (uint8_t)maxL;
+        S.mb[t] = (uint8_t)((bd << 5) | bL);
+    }
+    if (threadIdx.x == 0) { S.red[0] = 0xffffffffu; S.red[1] = 0u; S.red[2] = 0xffffffffu; S.red[3] = 0xffffffffu; }
+    __syncthreads();
+    // group starts: a start with a match that no earlier match overlaps (the same start may sit in the list more than once,
+    // with the same record: it does not overlap itself)
+    for (int t = threadIdx.x; t < N; t += JB) {
+        bool gs = S.mml[t] != 0;
+        if (gs) {
+            const int s0 = S.mst[t];
+            for (int q = 0; q < N; q++) {
+                const int mL = S.mml[q], sq = S.mst[q];
+                if (mL && sq < s0 && sq + mL > s0) { gs = false; break; }
+            }
+            if (gs) { atomicMin(&S.red[0], (unsigned)s0); atomicMax(&S.red[1], (unsigned)s0 + 1u); }
+        }
+        S.mgs[t] = gs;
+    }
+    __syncthreads();
+    const unsigned first_gs = S.red[0];
+    if (first_gs == 0xffffffffu) { __syncthreads(); return -1; }
+    const unsigned last_gs = S.red[1] - 1u;
+    int result;
+    if (side == 0) {
+        for (int t = threadIdx.x; t < N; t += JB)
+            if (S.mgs[t] && (unsigned)S.mst[t] > first_gs) atomicMin(&S.red[2], (unsigned)S.mst[t]);
+        __syncthreads();
+        const unsigned second = S.red[2] == 0xffffffffu ? (unsigned)n : S.red[2];
+        for (int t = threadIdx.x; t < N; t += JB) {
+            const unsigned s0 = S.mst[t];
+            if (!S.mml[t] || s0 < first_gs || s0 >= second) continue;
+            const unsigned b = S.mb[t];
+            atomicMin(&S.red[3], ((b >> 5) << 24) | ((63u - (b & 31u)) << 16) | s0);
+        }
+        __syncthreads();
+        result = (int)(S.red[3] & 0xffffu);
+    } else {
+        for (int t = threadIdx.x; t < N; t += JB) {
+            const unsigned s0 = S.mst[t];
+            if (!S.mml[t] || s0 < last_gs) continue;
+            const unsigned b = S.mb[t];
+            atomicMin(&S.red[3], ((b >> 5) << 24) | ((63u - (b & 31u)) << 16) | s0);
+        }
+        __syncthreads();
+        const unsigned key = S.red[3];
         result = (int)(key & 0xffffu) + (int)(63u - ((key >> 16) & 0xffu));
     }
     __syncthreads();
