@@ -139,6 +139,40 @@ __device__ int blk_ungap_row(const uint8_t *__restrict__ row, int C, uint8_t *__
     return running;
 }
 
+// the same for the judge's anchor search: a thread owns a contiguous segment of the row (count, ONE block scan, write), and
+// the position map is not stored at all -- the two columns the caller needs are looked up in the owning thread's segment
+// (the round-by-round form above costs two barriers per 256 columns and a 4-byte store per base)
+struct UngapSeg { int c0, L, off, cnt; };
+__device__ int blk_ungap_row_seg(const uint8_t *__restrict__ row, int C, uint8_t *__restrict__ ung, UngapSeg &G, JShared &S) {
+    const int L = (C + JB - 1) / JB, c0 = (int)threadIdx.x * L;
+    int cnt = 0;
+    for (int x = 0; x < L; x++) { const int c = c0 + x; if (c < C && row[c] != '-') cnt++; }
+    int tot;
+    const int off = block_excl_scan(cnt, S.scan, &tot);
+    int o = off;
+    for (int x = 0; x < L; x++) {
+        const int c = c0 + x;
+        if (c < C) { const uint8_t ch = row[c]; if (ch != '-') ung[o++] = ch; }
+    }
+    __syncthreads();
+    G.c0 = c0; G.L = L; G.off = off; G.cnt = cnt;
+    return tot;
+}
+// alignment column of base idx (0-based, < n) of the row last passed to blk_ungap_row_seg
+__device__ int blk_col_of(const uint8_t *__restrict__ row, int C, const UngapSeg &G, int idx, JShared &S) {
+    if (idx >= G.off && idx < G.off + G.cnt) {
+        int k = idx - G.off;
+        for (int x = 0; x < G.L; x++) {
+            const int c = G.c0 + x;
+            if (c < C && row[c] != '-') { if (k == 0) { S.iv[14] = c; break; } k--; }
+        }
+    }
+    __syncthreads();
+    const int r = S.iv[14];
+    __syncthreads();
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // find_near_matches restatement (oracle/stubs.py definition).  side 0: start of the best match
 // of the FIRST overlap group; side 1: end (exclusive) of the best match of the LAST group.
@@ -937,7 +971,6 @@ __global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(5, 8)))
         // character at a time, a chain of dependent loads that global scratch made ~10x longer
         const bool anchors_in_lds = C <= ANCHOR_LDS_COLS;
         uint8_t *ung = anchors_in_lds ? S.tile : slot;
-        int *reflex = (int *)(slot + P.maxC16);
         uint8_t *minfo = anchors_in_lds ? S.tile + ANCHOR_LDS_COLS + 16 : slot + 5 * P.maxC16;
         uint8_t *cstat = slot + 7 * P.maxC16;
         bool done = false;
@@ -953,13 +986,14 @@ __global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(5, 8)))
             if (P.te_type != HITE_TE_HELITRON) {
                 // first row that has both anchors (Util.py:9158-9181)
                 for (int r = 0; r < R; r++) {
-                    int n = blk_ungap_row(msa + (size_t)r * C, C, ung, reflex, S);
+                    UngapSeg G;
+                    int n = blk_ungap_row_seg(msa + (size_t)r * C, C, ung, G, S);
                     int fs = blk_fnm(S.pat[0], m1, ung, n, 2, minfo, 0, S);
                     if (fs < 0) continue;
                     int le = blk_fnm(S.pat[1], m1, ung, n, 2, minfo, 1, S);
                     if (le < 0) continue;
-                    astart = reflex[fs];
-                    aend = reflex[le - 1];
+                    astart = blk_col_of(msa + (size_t)r * C, C, G, fs, S);
+                    aend = blk_col_of(msa + (size_t)r * C, C, G, le - 1, S);
                     break;
                 }
             } else {
@@ -968,12 +1002,14 @@ __global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(5, 8)))
                 int *ae = as + R;
                 int na = 0;
                 for (int r = 0; r < R; r++) {
-                    int n = blk_ungap_row(msa + (size_t)r * C, C, ung, reflex, S);
+                    UngapSeg G;
+                    int n = blk_ungap_row_seg(msa + (size_t)r * C, C, ung, G, S);
                     int fs = blk_fnm(S.pat[0], m1, ung, n, 2, minfo, 0, S);
                     if (fs < 0) continue;
                     int le = blk_fnm(S.pat[1], m1, ung, n, 2, minfo, 1, S);
                     if (le < 0) continue;
-                    if (threadIdx.x == 0) { as[na] = reflex[fs]; ae[na] = reflex[le - 1]; }
+                    const int cs_ = blk_col_of(msa + (size_t)r * C, C, G, fs, S), ce_ = blk_col_of(msa + (size_t)r * C, C, G, le - 1, S);
+                    if (threadIdx.x == 0) { as[na] = cs_; ae[na] = ce_; }
                     na++;
                 }
                 __syncthreads();
