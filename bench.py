@@ -245,12 +245,21 @@ def main():
         alg = {
             "align_fwd4": 5.0 * cols_step,                 # row base read + 64-B check point per 16 columns
             "align_fwd_wide": 7.0 * cols_step * (per_step["wide"] / pairs_step),   # + 2 B of boundary information per column
-            "align_tb": 5.0 * cols_step + ops_bytes,                              # the same back + 2 B of ops per centre position
+            "align_tb": 4.0 * cols_step + ops_bytes,                              # the records back (they carry the row bases) + 2 B of ops per centre position
             "row_gather_kernel": float((stats[1] + stats[5]) * (1 + 0.375)),
             "star_layout_sparse_kernel": ops_bytes,
             "star_fill_sparse_kernel": float((stats[1] + stats[5]) + (stats[2] + stats[6])),
             "judge_kernel": float((stats[2] + stats[6]) * (1 + 13.0 / 32.0)),
         }
+        if args.copies == "found":
+            cs = [int(x) for x in ctx.copy_stats()]          # candidate minimizers, hits, clusters, accepted copies of the last step
+            dbits = max(1, int(G + 65536).bit_length())
+            cbits = max(1, int(max(1, n_cand) - 1).bit_length())
+            passes = -(-dbits // 10) + -(-(1 + cbits) // 10)
+            alg["radix_sort_hits"] = float(cs[1]) * (8 + 16) * passes     # 8-byte keys: histogram read + scatter read/write per pass
+            alg["hit_kernel"] = float(cs[1]) * (8 + 8)                       # index entry gathered + packed hit written
+            alg["cluster_flag_kernel"] = float(cs[1]) * (8 + 4)
+            alg["cluster_acc_kernel"] = float(cs[1]) * (8 + 4 + 8)
         dom = max(merged_prof.items(), key=lambda kv: kv[1][0])[0] if merged_prof else None
         roof = None
         if dom:
@@ -293,6 +302,10 @@ def main():
                     blk["valu_issue"] = {"achieved": round(rate, 1), "peak": round(slow, 1), "unit": "G wave64-inst/s", "frac": round(rate / slow, 4),
                                          "wave_inst_per_pair_column": round(per_col, 4), "source": "profiles/r02_sq_counters.json"}
                 roof["align"] = blk
+            # every stage with an algorithmic byte count, against the same HBM peak (what each is really bound by: DESIGN.md section 4)
+            roof["stages"] = {k: {"ms_per_step": round(ms / steps, 3), "achieved": round(alg[k] / (ms / steps * 1e-3) / 1e9, 1),
+                                  "frac": round(alg[k] / (ms / steps * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
+                              for k, (ms, _c) in sorted(merged_prof.items()) if k in alg and ms > 0}
         out = {
             "metric": "candidate TE boundaries/sec on %s synthetic genome (fine stage: copy finding+gather+align+vote+judge)" % ("1 Gbp" if mbp == 1000 else "%d Mbp" % mbp),
             "value": round(value, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
