@@ -5,8 +5,8 @@ arithmetic runs in libhite_gpu.so through `hite_amd._lib` (no CPU fallback).
 Third-party tools the reference shells out to: `minimap2` copy finding is replaced by the build's own minimizer-based
 finder (get_full_length_copies_minimap2; `all_copies=` / `copy_finder=` of flank_region_align_v5 override it); `trf`, `cd-hit-est`
 and `itrsearch` are called where the reference calls them when they are installed (a warning otherwise); the low-copy
-rescue by itrsearch / blastx domains (Util.py:8196-8281) is not reproduced: low-copy elements are written to
-`all_low_copy` exactly like the reference does, nothing is rescued.
+recall of TIR candidates by structure (Util.py:8196-8213: short-TIR signatures, itrsearch when installed) is reproduced,
+the recall by blastx protein domains (:8215-8276) is not: those low-copy elements are written to `all_low_copy`.
 """
 import os
 import re
@@ -859,6 +859,8 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
     res, _stats = ctx.flank_region_align(TE_type, cands, copies, plant=int(plant), flank=int(flanking_len)) if qnames else ([], None)
     true_tes, low_copy = bucket_results(TE_type, [(q if is_te else None, cons if is_te else None, info, copy_count)
                                                   for q, (is_te, info, cons, copy_count, _bs, _be) in zip(qnames, res)])
+    rescued, low_copy = rescue_low_copy(TE_type, low_copy, plant, os.path.join(tmp_output_dir, "low_copy_%s_%s" % (TE_type, ref_index)))
+    true_tes.update(rescued)
     store_fasta(true_tes, real_TEs)
     with open(all_low_copy, "a") as f:
         for q, s in low_copy.items():
@@ -866,11 +868,53 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
     return true_tes, low_copy
 
 
+def rescue_low_copy(TE_type, low_copy, plant, work_dir):
+    """The recall of low-copy elements by structure (Util.py:8196-8213 + remove_no_tirs, :13897-13920), TIR stage: the
+    low-copy sequences go through TRF (tandem repeats -> N) when `trf` is installed, those with a short-TIR signature
+    (get_short_tir_contigs: hAT / Mutator / CACTA / CCC..GGG ends matching the TSD length in the name) are real TEs, the
+    rest is handed to `itrsearch -i 0.7 -l 7` when it is installed and kept if it reports a terminal inverted repeat
+    (with the sequence itrsearch writes).  -> (rescued, still low copy).  The recall by intact protein domains
+    (get_domain_info = blastx against TIRPeps / HelitronPeps / non_LTR libraries, :8215-8276) is an external search and is
+    not reproduced: Helitron and non-LTR low-copy elements all stay in `all_low_copy`."""
+    import shutil
+    import subprocess
+
+    if TE_type != "tir" or not low_copy:
+        return {}, dict(low_copy)
+    os.makedirs(work_dir, exist_ok=True)
+    masked = dict(low_copy)
+    if shutil.which("trf") is not None:
+        path = os.path.join(work_dir, "low_copy.fa")
+        store_fasta(low_copy, path)
+        m = run_remove_TR(path, work_dir)
+        if os.path.exists(m):
+            _n, mc = read_fasta(m)
+            masked = {n: mc[n] for n in low_copy if n in mc}
+    else:
+        sys.stderr.write("[hite_amd] trf not found: low-copy candidates are not TRF-masked before the TIR-structure recall\n")
+    short = get_short_tir_contigs(masked, plant)
+    rest = {n: s_ for n, s_ in masked.items() if n not in short}
+    found = {}
+    exe = shutil.which("itrsearch")
+    if exe is None:
+        sys.stderr.write("[hite_amd] itrsearch not found: only short-TIR signatures recall low-copy TIR candidates\n")
+    elif rest:
+        path = os.path.join(work_dir, "low_copy.no_short_tir.fa")
+        store_fasta(rest, path)
+        subprocess.run("cd %s && %s -i 0.7 -l 7 %s > %s.log 2>&1" % (work_dir, exe, path, path), shell=True, check=False)
+        if os.path.exists(path + ".itr"):
+            _n, found = read_fasta(path + ".itr")
+            found = {n: s_ for n, s_ in found.items() if n in rest}
+    rescued = dict(found)
+    rescued.update(short)
+    return rescued, {n: s_ for n, s_ in low_copy.items() if n not in rescued}
+
+
 def bucket_results(TE_type, results):
     """the collection loop of flank_region_align_v5 (Util.py:8159-8194, 8282-8287) on (cur_name, cur_seq, info, copy_count)
     tuples (cur_name None = not a TE): TIR / Helitron / non-LTR consensi that start with TG and end with CA are dropped (LTR
     ends), those with copy_count <= 5 (TIR, non-LTR) or <= 2 (Helitron) go to the low-copy bucket, the rest are real TEs.
-    -> (true_tes, low_copy) in result order.  (The rescue of low-copy elements by itrsearch / blastx is not reproduced.)"""
+    -> (true_tes, low_copy) in result order (the recall of low-copy elements follows in rescue_low_copy)."""
     true_tes, low_copy = {}, {}
     thr = 5 if TE_type in ("tir", "non_ltr") else 2
     for cur_name, cur_seq, _info, copy_count in results:

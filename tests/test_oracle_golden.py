@@ -351,3 +351,29 @@ def test_result_bucketing_golden():
         n_real += len(true_tes)
         n_low += len(low)
     assert n_real > 50 and n_low > 30
+
+
+def test_low_copy_tir_recall_by_structure(tmp_path):
+    """rescue_low_copy (Util.py:8196-8213 + remove_no_tirs :13897): low-copy TIR candidates with a short-TIR signature are real
+    TEs; without trf / itrsearch installed nothing else is recalled; Helitron / non-LTR candidates stay low copy (the blastx
+    domain recall is external)"""
+    from hite_amd import util
+
+    comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
+    core = "ACGTTGCATGCAAGCTTGCA" * 20
+    head = "GGGTC"
+    tail = "".join(comp[c] for c in reversed(head))
+    low = {"N_1-C_0-tsd_ACGTACGT-distance_0": head + core + tail,        # 8-bp TSD (hAT), first 5 = revcomp(last 5), < 4 kb
+           "N_2-C_0-tsd_ACGTACGT-distance_0": "TTTTT" + core + "CCCCC",  # no terminal inverted repeat
+           "N_3-C_0-tsd_AC-distance_0": head + core + tail}              # 2-bp TSD: no short-TIR family
+    assert util.get_short_tir_contigs(low, 1).keys() == {"N_1-C_0-tsd_ACGTACGT-distance_0"}
+    import shutil
+    rescued, still = util.rescue_low_copy("tir", low, 1, str(tmp_path / "lc"))
+    if shutil.which("itrsearch") is None and shutil.which("trf") is None:
+        assert rescued == {"N_1-C_0-tsd_ACGTACGT-distance_0": low["N_1-C_0-tsd_ACGTACGT-distance_0"]}
+        assert list(still) == ["N_2-C_0-tsd_ACGTACGT-distance_0", "N_3-C_0-tsd_AC-distance_0"]
+    else:
+        assert "N_1-C_0-tsd_ACGTACGT-distance_0" in rescued and set(rescued) | set(still) == set(low)
+    for te in ("helitron", "non_ltr"):
+        r2, s2 = util.rescue_low_copy(te, low, 1, str(tmp_path / te))
+        assert r2 == {} and s2 == low
