@@ -134,6 +134,36 @@ def test_judge_random_vs_oracle(ctx, te_type):
     assert ntrue >= 1
 
 
+@pytest.mark.parametrize("te_type", ["tir", "helitron"])
+def test_judge_anchors_in_repetitive_rows(ctx, te_type):
+    """tandem arrays of the candidate's own ends on both sides of every row: the anchor filter flags far more than 64 match ends,
+    so the search takes the form with a match record per text start (blk_fnm_full) instead of the match list; same calls as
+    the oracle"""
+    cases = []
+    for i in range(6):
+        c = casegen.make_msa_case(seed=7100 + i, te_type=te_type, rows=8 + 3 * i, te_len=240, tsd_len=8, tsd_frac=1.0,
+                                  shift_l=(i % 3) * 3, shift_r=-(i % 2) * 2)
+        head, tail = c["cand"][:20], c["cand"][-20:]
+        reps = 70 + 5 * i
+        c = dict(c, seqs=[(head * reps)[: 20 * reps - (3 * r) % 7] + "-" * ((3 * r) % 7) + s + "-" * ((5 * r) % 6) + (tail * reps)[(5 * r) % 6:]
+                          for r, s in enumerate(c["seqs"])])
+        cases.append(c)
+    msas = _msas(cases)
+    clean = ctx.sparse_cols(msas)
+    got = ctx.judge(te_type, clean, [c["cand"] for c in cases], plant=1)
+    for c, m, cl, g in zip(cases, msas, clean, got):
+        keep = O.sparse_cols(m).astype(bool)
+        mc = np.ascontiguousarray(m[:, keep])
+        assert np.array_equal(mc, cl)
+        exp, (bs, be) = O.judge(te_type, mc, c["cand"], 1)
+        if exp[0] == "EXC":
+            assert g[1] == "EXC"
+            continue
+        assert [g[0], g[1], g[2], g[3]] == exp
+        if exp[0]:
+            assert (g[4], g[5]) == (bs, be)
+
+
 def test_tsd_search_golden(ctx):
     cases = load_golden("tsd_search")
     for plant in (0, 1):
