@@ -314,6 +314,200 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
 }
 
 // ---------------------------------------------------------------------------------------------
+// the 8-word level with TWO LANES PER PAIR (lane 2i: words 0-3, lane 2i+1: words 4-7 of pair i).  The pairs that reach this
+// level are few (13 % on C3: 1.2 wavefronts per SIMD) and long, so the kernel's time is the instruction chain of its
+// longest wavefront (300 instructions per column at the 4.4 cycles a lone wavefront issues at), not its work: half the
+// words per lane halve that chain.  Same recurrence, same records, bit for bit, as align_fwd_kernel<8>; what crosses
+// the lane boundary: the carry of the addition (the upper lane adds with carry-in 0, then ripples the lower lane's
+// carry-out through its sums), bit 31 of vpos / h2 / h1 / h0 of word 3, the words that move across when the band moves,
+// the steering count of word 4, and word 4's planes for the check point -- quad-permute DPP moves.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t pair_partner(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false); }   // lane ^ 1
+
+__global__ void __launch_bounds__(64) align_fwd8_pair_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    constexpr int NW = 8, HW = 4, W = 32 * NW, H = W / 2, S0 = NW / 2 - 1;
+    const int half = threadIdx.x & 1;                    // 0: words 0..3 (writes the records and the results), 1: words 4..7
+    const int li = blockIdx.x * 32 + (threadIdx.x >> 1);
+    const int g = li < nlist ? list[li] : -1;
+    int m = 0, n = 0, g0 = 0, c = 0;
+    if (g >= 0) {
+        c = P.row_cand[g];
+        g0 = P.row_first[c];
+        if (g != g0) { m = P.win_len[g0]; n = P.win_len[g]; }
+    }
+    const int nmax = wave_max_i32(n);
+    if (nmax == 0) return;
+    const uint8_t *b = P.win + (g >= 0 ? P.win_off[g] : 0);
+    const uint4 *pl = P.planes + (g >= 0 ? P.plane_off[c] : 0);
+    char *rec0 = g >= 0 ? reinterpret_cast<char *>(P.rec[g]) : nullptr;
+    uint32_t X2[HW], X1[HW], X0[HW], A0[HW], A1[HW], AN[HW];
+    int t = -H;
+#pragma unroll
+    for (int w = 0; w < HW; w++) { X2[w] = half ? 0xffffffffu : 0u; X1[w] = X2[w]; X0[w] = 0u; }   // +3 from row 1 on, -3 above
+    bool act = n > 0;
+    if (act) {
+        const int q0 = ((t + AL_PADR) >> 5) + half * HW;
+#pragma unroll
+        for (int w = 0; w < HW; w++) { const uint4 v = pl[q0 + w]; A0[w] = v.x; A1[w] = v.y; AN[w] = v.z; }
+    } else {
+#pragma unroll
+        for (int w = 0; w < HW; w++) { A0[w] = 0; A1[w] = 0; AN[w] = 0xffffffffu; }
+    }
+    int stop = AL_GAP * H, LO = -(1 << 28), HI = 1 << 28, status = 0;
+    int fq = (t + W + AL_PADR) >> 5;
+    uint4 Wa = make_uint4(0, 0, 0xffffffffu, 0), Wb = Wa, Wc = Wa, bnext = make_uint4(0, 0, 0, 0);
+    if (act) { Wa = pl[fq]; Wb = pl[fq + 1]; Wc = pl[fq + 2]; bnext = *reinterpret_cast<const uint4 *>(b); }
+    for (int k = 0; k * AL_STRIP < nmax; k++) {
+        const bool sa = act && k * AL_STRIP < n;
+        uint4 bw = make_uint4(0, 0, 0, 0);
+        uint32_t f0 = 0, f1 = 0, fn = 0;
+        uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        {   // check point: words 3 and 4 of the pair = word 3 of the lower lane, word 0 of the upper lane
+            const uint32_t p2 = pair_partner(X2[0]), p1 = pair_partner(X1[0]), p0 = pair_partner(X0[0]);
+            if (sa && !half) {
+                uint4 *ck = reinterpret_cast<uint4 *>(rec0 + (size_t)k * AL_RECB);
+                ck[0] = make_uint4(X2[HW - 1], p2, X1[HW - 1], p1);
+                ck[1] = make_uint4(X0[HW - 1], p0, (uint32_t)(t + 32 * S0), 0u);
+            }
+        }
+        if (sa) {
+            bw = bnext;
+            if ((k + 1) * AL_STRIP < n) bnext = *reinterpret_cast<const uint4 *>(b + (k + 1) * AL_STRIP);
+            const int fx = t + W + AL_PADR;
+            if ((fx >> 5) != fq) { Wa = Wb; Wb = Wc; fq++; Wc = pl[fq + 2]; }
+            const uint32_t sh = (uint32_t)fx & 31u;
+            f0 = alignbit(Wb.x, Wa.x, sh); f1 = alignbit(Wb.y, Wa.y, sh); fn = alignbit(Wb.z, Wa.z, sh);
+        }
+#pragma unroll
+        for (int cc = 0; cc < AL_STRIP; cc++) {
+            const int j = k * AL_STRIP + cc + 1;
+            const bool on = sa && j <= n;                // (the same in both lanes of a pair; DPP moves run for every lane)
+            if ((cc & 3) == 0) {
+                // ---- band move: steering count of words 3 + 4, the words that cross the lane boundary
+                const int own = half ? slope_count(X2[0], X1[0], X0[0]) : slope_count(X2[HW - 1], X1[HW - 1], X0[HW - 1]);
+                const int ds = own + (int)pair_partner((uint32_t)own);
+                const uint32_t i2 = pair_partner(X2[1] & 0xffu), i1 = pair_partner(X1[1] & 0xffu), i0 = pair_partner(X0[1] & 0xffu);   // word 5's low rows (upper lane's word 1)
+                const uint32_t u2 = pair_partner(X2[0]), u1 = pair_partner(X1[0]), u0 = pair_partner(X0[0]);
+                const uint32_t ua0 = pair_partner(A0[0]), ua1 = pair_partner(A1[0]), uan = pair_partner(AN[0]);
+                if (on) {
+                    int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 8 : 4);
+                    const int tr = m - H;
+                    if (t + s > tr) s = (tr - t) & ~3;
+                    const int need = tr - 3 - 8 * ((n - j) >> 2) - t;
+                    if (s < need) s = (need + 3) & ~3;
+                    if (s > 8) { status = 2; act = false; s = 8; }
+                    if (!half) {
+                        stop += plane_sum(X2[0], X1[0], X0[0], (1u << s) - 1u) - AL_GAP * s;
+                        brec[(cc >> 2) * 2] = (uint32_t)(s >> 2) | (i2 << 2) | (i1 << 10) | (i0 << 18);
+                    }
+#pragma unroll
+                    for (int w = 0; w < HW - 1; w++) {
+                        X2[w] = alignbit(X2[w + 1], X2[w], (uint32_t)s); X1[w] = alignbit(X1[w + 1], X1[w], (uint32_t)s);
+                        X0[w] = alignbit(X0[w + 1], X0[w], (uint32_t)s);
+                        A0[w] = alignbit(A0[w + 1], A0[w], (uint32_t)s); A1[w] = alignbit(A1[w + 1], A1[w], (uint32_t)s);
+                        AN[w] = alignbit(AN[w + 1], AN[w], (uint32_t)s);
+                    }
+                    // the top word of a lane: the lower lane takes the upper lane's word 0 (before its move), the upper lane the rows that enter
+                    X2[HW - 1] = alignbit(half ? 0xffffffffu : u2, X2[HW - 1], (uint32_t)s);
+                    X1[HW - 1] = alignbit(half ? 0xffffffffu : u1, X1[HW - 1], (uint32_t)s);
+                    X0[HW - 1] = alignbit(half ? 0u : u0, X0[HW - 1], (uint32_t)s);
+                    A0[HW - 1] = alignbit(half ? f0 : ua0, A0[HW - 1], (uint32_t)s);
+                    A1[HW - 1] = alignbit(half ? f1 : ua1, A1[HW - 1], (uint32_t)s);
+                    AN[HW - 1] = alignbit(half ? fn : uan, AN[HW - 1], (uint32_t)s);
+                    f0 >>= s; f1 >>= s; fn >>= s;
+                    t += s;
+                    if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
+                    if (t + W < m) { const int jl = j + 3 < n ? j + 3 : n; const int v = t + W - jl; HI = v < HI ? v : HI; }
+                }
+            }
+            // ---- column.  Phase 1: match vector, B, P, Y and the sums with carry-in 0, word by word inside the lane
+            const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
+            const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
+            uint32_t Bv[HW], Pv[HW], Yv[HW], Sv[HW], eqv[HW], vposv[HW];
+#pragma unroll
+            for (int w = 0; w < HW; w++) {
+                eqv[w] = ~((A0[w] ^ bm.m0) | (A1[w] ^ bm.m1) | AN[w] | bm.inv);
+                vposv[w] = X2[w] & X1[w];
+                Bv[w] = eqv[w] | ~(X2[w] | X1[w] | X0[w]);
+            }
+            const uint32_t pvpos = pair_partner(vposv[HW - 1]);          // (every lane takes part in a DPP move: no lane-dependent branch around it)
+            const uint32_t vin = half ? pvpos >> 31 : 0u;
+            uint32_t cin = 0u, tap0 = 0u;
+#pragma unroll
+            for (int w = 0; w < HW; w++) {
+                if (w == HW - 1) tap0 = cin;               // lower lane: the carry that enters word 3 (exact: its carry-in is 0)
+                Pv[w] = (vposv[w] << 1) | (w ? vposv[w - 1] >> 31 : vin);
+                Yv[w] = Pv[w] | Bv[w];
+                const unsigned long long sum = (unsigned long long)Bv[w] + Yv[w] + cin;
+                Sv[w] = (uint32_t)sum;
+                cin = (uint32_t)(sum >> 32);
+            }
+            {   // the upper lane's carry-in = the lower lane's carry-out: ripple it through sums that are all ones
+                const uint32_t pc = pair_partner(cin);
+                uint32_t e = half ? pc : 0u;
+#pragma unroll
+                for (int w = 0; w < HW; w++) { const uint32_t o = Sv[w]; Sv[w] = o + e; e &= (o == 0xffffffffu) ? 1u : 0u; }
+            }
+            // Phase 2a: diagonal zeros, horizontal differences
+            uint32_t Zv[HW], h2v[HW], h1v[HW], h0v[HW];
+#pragma unroll
+            for (int w = 0; w < HW; w++) {
+                Zv[w] = Bv[w] | (Pv[w] & (Sv[w] ^ Bv[w] ^ Yv[w]));
+                const uint32_t b1 = Zv[w] & X0[w], b2 = X1[w] & b1;
+                h0v[w] = ~(Zv[w] ^ X0[w]); h1v[w] = ~(X1[w] ^ b1); h2v[w] = ~(X2[w] ^ b2);
+            }
+            const uint32_t q2 = pair_partner(h2v[HW - 1]) >> 31, q1 = pair_partner(h1v[HW - 1]) >> 31, q0 = pair_partner(h0v[HW - 1]) >> 31;
+            const uint32_t hin2 = half ? q2 : 1u, hin1 = half ? q1 : 1u, hin0 = half ? q0 : 0u;
+            if (on) {
+                // Phase 2b: the row below, new vertical differences
+#pragma unroll
+                for (int w = 0; w < HW; w++) {
+                    const uint32_t s2 = (h2v[w] << 1) | (w ? h2v[w - 1] >> 31 : hin2), s1 = (h1v[w] << 1) | (w ? h1v[w - 1] >> 31 : hin1),
+                                   s0 = (h0v[w] << 1) | (w ? h0v[w - 1] >> 31 : hin0);
+                    const uint32_t c1 = Zv[w] & s0, c2 = s1 & c1;
+                    X0[w] = ~(Zv[w] ^ s0); X1[w] = ~(s1 ^ c1); X2[w] = ~(s2 ^ c2);
+                }
+                if (!half) {
+                    stop += AL_GAP;
+                    const uint32_t c5 = tap0 | ((vposv[HW - 2] >> 31) << 1) | ((h2v[HW - 2] >> 31) << 2) | ((h1v[HW - 2] >> 31) << 3) | ((h0v[HW - 2] >> 31) << 4);
+                    const int sh = 26 + 5 * (cc & 3);
+                    if (sh + 5 <= 32) brec[(cc >> 2) * 2] |= c5 << sh;
+                    else if (sh >= 32) brec[(cc >> 2) * 2 + 1] |= c5 << (sh - 32);
+                    else { brec[(cc >> 2) * 2] |= c5 << sh; brec[(cc >> 2) * 2 + 1] |= c5 >> (32 - sh); }
+                    brec[(cc >> 2) * 2 + 1] |= ((bm.m0 & 1u) | (bm.m1 & 2u) | (bm.inv & 4u)) << (14 + 3 * (cc & 3));
+                }
+            }
+        }
+        if (sa && !half) {
+            uint4 *bp = reinterpret_cast<uint4 *>(rec0 + (size_t)k * AL_RECB + AL_RECB / 2);
+            bp[0] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
+            bp[1] = make_uint4(brec[4], brec[5], brec[6], brec[7]);
+        }
+    }
+    {
+        // row m is bit H - 1 + (m - H - t_n), 0 .. 3 bits into word NW / 2 = the upper lane's word 0
+        const int extra = m - H - t;
+        const uint32_t part = pair_partner((uint32_t)plane_sum(X2[0], X1[0], X0[0], (1u << (extra & 31)) - 1u));
+        if (n > 0 && !half) {
+            int U = -1, kstar = -1;
+            if (status == 0) {
+                int u = stop - AL_GAP * H;
+#pragma unroll
+                for (int w = 0; w < HW; w++) u += plane_sum(X2[w], X1[w], X0[w], 0xffffffffu);
+                u += (int)part - AL_GAP * extra;
+                U = u;
+                const int d = m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
+                int E = dmin - LO;
+                if (HI - dmax < E) E = HI - dmax;
+                if (E > (1 << 27)) kstar = 0x7fffffff;
+                else if (E >= 0) kstar = AL_GAP * ad + 2 * AL_GAP * E + 2 * AL_GAP - 1;
+            }
+            P.U[g] = U; P.kst[g] = kstar; P.st[g] = status; P.lvl[g] = NW;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // traceback pass: re-compute the slice strip by strip (registers), walk it backwards
 // ---------------------------------------------------------------------------------------------
 // ops leave the traceback in descending positions, one at a time and per lane: a lane collects four of them in a 64-bit
@@ -965,7 +1159,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
             ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 0, level, cap, flag, nullptr, pos, colpos, scan_tmp, list, nullptr, &cnt, nullptr));
             if (cnt == 0) continue;
             ACHK(assign_records(ctx, S, st, list, cnt, strips, bk, boff, scan_tmp, rec, 1));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<8>), dim3((unsigned)((cnt + 63) / 64)), dim3(64), 0, st, P, list, (int)cnt);
+            hipLaunchKernelGGL(align_fwd8_pair_kernel, dim3((unsigned)((cnt + 31) / 32)), dim3(64), 0, st, P, list, (int)cnt);
         }
         hite_prof_end(ctx, tk, st);
     }
