@@ -807,14 +807,26 @@ __global__ void __launch_bounds__(64) align_wide_tb_kernel(AlignArgs P, const in
     const int64_t full0 = P.full_off[g];
     int i = m, j = n;
     bool fail = false;
+    // the columns are visited one per step in descending order, so the next eight are fetched while these eight are walked
+    // (a lone wavefront per pair has nothing else to hide the load behind: the fetch used to be half of the kernel's time)
+    uint32_t dgn[PF], upn[PF];
+    int ttn[PF];
+#pragma unroll
+    for (int q = 0; q < PF; q++) {
+        const int jq = j - q > 0 ? j - q : 1;
+        const uint32_t *fb = P.fullbuf + (full0 + jq) * (2 * NW);
+        dgn[q] = fb[lane]; upn[q] = fb[NW + lane]; ttn[q] = P.fullt[full0 + jq];
+    }
     while (i > 0 && j > 0 && !fail) {
         uint32_t dgs[PF], ups[PF];
         int tts[PF];
 #pragma unroll
+        for (int q = 0; q < PF; q++) { dgs[q] = dgn[q]; ups[q] = upn[q]; tts[q] = ttn[q]; }
+#pragma unroll
         for (int q = 0; q < PF; q++) {
-            const int jq = j - q > 0 ? j - q : 1;
+            const int jq = j - PF - q > 0 ? j - PF - q : 1;
             const uint32_t *fb = P.fullbuf + (full0 + jq) * (2 * NW);
-            dgs[q] = fb[lane]; ups[q] = fb[NW + lane]; tts[q] = P.fullt[full0 + jq];
+            dgn[q] = fb[lane]; upn[q] = fb[NW + lane]; ttn[q] = P.fullt[full0 + jq];
         }
 #pragma unroll
         for (int q = 0; q < PF; q++) {

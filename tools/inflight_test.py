@@ -17,11 +17,29 @@ w = synth.make_workload(genome_bp=G, n_tir=2500, n_ltr=2500, cands_per_family=10
 def up(a):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
+lens_all = np.diff(w["cand_off"])
+order_len = np.argsort(-lens_all, kind="stable")
+frac = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0     # > 0: part 0 = the longest `frac` of the candidates, part 1 = the rest
+
 class Half:
     def __init__(self, rank, world):
+        if frac > 0 and world == 2:
+            k = int(len(order_len) * frac)
+            sel = np.sort(order_len[:k] if rank == 0 else order_len[k:])
+            offs = w["cand_off"]
+            pieces = [w["cands"][offs[c]:offs[c + 1]] for c in sel]
+            self.n = len(sel)
+            cand_bytes = np.concatenate(pieces)
+            cand_off = np.zeros(self.n + 1, np.int64); np.cumsum([len(x) for x in pieces], out=cand_off[1:])
+            self.bytes = int(cand_off[-1])
+            self._init_rest(cand_bytes, cand_off)
+            return
         c0, c1, (b0, b1), (k0, k1) = hd.shard_candidates(w["cand_off"], w["copy_first"], rank, world)
         self.n = c1 - c0
         self.bytes = b1 - b0
+        self._init_rest(w["cands"][b0:b1], w["cand_off"][c0:c1 + 1] - b0)
+
+    def _init_rest(self, cand_bytes, cand_off):
         self.ctx = hite_amd.Context(0)
         self.stream = torch.cuda.Stream(device=dev)
         self.sp = self.stream.cuda_stream
@@ -32,8 +50,8 @@ class Half:
         self.d_calls = torch.zeros(max(1, self.n) * 32, dtype=torch.uint8, device=dev)
         self.cons_cap = self.bytes + 200 * self.n + 4096
         self.d_cons = torch.zeros(self.cons_cap + 64, dtype=torch.uint8, device=dev)
-        self.d_cand = up(np.concatenate([w["cands"][b0:b1], np.zeros(64, np.uint8)]))
-        self.d_cand_off = up(w["cand_off"][c0:c1 + 1] - b0)
+        self.d_cand = up(np.concatenate([cand_bytes, np.zeros(64, np.uint8)]))
+        self.d_cand_off = up(cand_off)
     def step(self):
         nc, p_cf, p_ct, p_s1, p_e1, p_mn, _ = self.ctx.find_copies_dev(self.n, self.d_cand.data_ptr(), self.d_cand_off.data_ptr(), self.bytes, self.sp)
         self.ctx.flank_region_align_dev("tir", 1, self.n, self.d_cand.data_ptr(), self.d_cand_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn,
