@@ -440,6 +440,7 @@ __global__ void cluster_copy_kernel(int64_t ncl, const unsigned long long *__res
     long long qlo = (long long)(c_lo[k] >> 32), glo = (long long)(c_lo[k] & 0xffffffffull);
     long long qhi = (long long)(c_hi[k] >> 32), ghi = (long long)(c_hi[k] & 0xffffffffull);
     if ((qhi + CK - qlo) * 100 < 80 * Lq) return;
+    if ((qhi + CK - qlo) * 100 < 95 * (ghi + CK - glo)) return;      // target coverage (Util.py:8008-8020): aligned query / genome span >= 0.95
     int ctg = contig_of(coff, nc, glo);
     long long s0 = glo - qlo, e0 = ghi + CK + (Lq - (qhi + CK));
     long long cb = coff[ctg], ce = coff[ctg + 1];

@@ -199,7 +199,10 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
             if (hits[t].qo > qhi || (hits[t].qo == qhi && hits[t].gpos > ghi)) { qhi = hits[t].qo; ghi = hits[t].gpos; }
         }
         int64_t na = j - i;
-        if (na >= MINANCH && (qhi + CK - qlo) * 100 >= 80 * Lq) {
+        /* acceptance (the reference keeps a minimap2 alignment with query coverage >= 0.95 and aligned query / (M + D) >= 0.95,
+         * Util.py:7977-8030): the anchors span >= 80 % of the candidate (anchors do not reach the ends the way a base-level
+         * extension does), and the candidate span they cover is >= 95 % of the genome span they cover */
+        if (na >= MINANCH && (qhi + CK - qlo) * 100 >= 80 * Lq && (qhi + CK - qlo) * 100 >= 95 * (ghi + CK - glo)) {
             int64_t s0 = glo - qlo, e0 = ghi + CK + (Lq - (qhi + CK));
             int64_t cb = contig_off[ctg], ce = contig_off[ctg + 1];
             if (s0 < cb) s0 = cb;
