@@ -233,7 +233,8 @@ int hite_tsd_kmer_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_seqs, const int
  * `minimap2 -ax map-ont -N 300 -p 0.2` + SAM filtering (get_full_length_copies_minimap2, Util.py:7933-8030;
  * third-party, unpinned -> parity is pinned against the build's own CPU twin, oracle/hite_oracle_copies.c,
  * whose header holds the definition: (w=10,k=15) minimizers, diagonal clustering, >= 3 anchors spanning
- * >= 80 % of the candidate, boundaries extrapolated from the extreme anchors, <= 300 copies per candidate
+ * >= 80 % of the candidate and covering a candidate span >= 95 % of the genome span they cover (the target-coverage
+ * filter of get_copies_minimap2), boundaries extrapolated from the extreme anchors, <= 300 copies per candidate
  * ordered by anchors).  Needs a packed genome (< 4 Gbp).  The index handle (*state_io, initially NULL)
  * is built once per genome; free it with hite_copy_index_release.
  * Output = the copy table get_full_length_copies_minimap2 returns, as the CSR that
