@@ -19,7 +19,8 @@
  *   an occurrence gives a hit: rel = strand_q ^ strand_g, qo = rel ? Lq - qpos - K : qpos,
  *   d = gpos - qo.  Hits are sorted by (candidate, rel, d); a new cluster starts when candidate, rel
  *   or the contig of gpos changes or d jumps by more than TD = 64.  A cluster with >= 3 anchors whose
- *   anchor span (max qo + K - min qo) covers >= 80 % of the candidate becomes a copy:
+ *   anchor span (max qo + K - min qo) covers >= 80 % of the candidate AND >= 95 % of the genome span of the same anchors
+ *   (get_copies_minimap2's target coverage, Util.py:8008-8020) becomes a copy:
  *   start0 = gpos(min qo) - min qo, end0 = gpos(max qo) + K + (Lq - (max qo + K)), clamped to the
  *   contig (ties: min qo -> smallest gpos, max qo -> largest gpos).  Per candidate the copies are
  *   ordered by (anchors descending (capped at 4095), start ascending) and the first 300 are kept.
