@@ -314,8 +314,8 @@ __device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ un
     __syncthreads();
     const int nf = S.nflag;
     if (nf == 0) return -1;
-    if (nf > 64) return blk_fnm_full(pat, m, ung, n, k, minfo, side, S);
-    const int span = 2 * k + 1, N = nf * span;                 // N <= FNM_LIST
+    const int span = 2 * k + 1, N = nf * span;
+    if (nf > 64 || N > FNM_LIST) return blk_fnm_full(pat, m, ung, n, k, minfo, side, S);
     for (int t = threadIdx.x; t < N; t += JB) {
         const int st = S.flagged[t / span] - (m + k) + (t % span);
         int maxL = 0, bd = 3, bL = 0;
