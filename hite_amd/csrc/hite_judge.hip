@@ -41,6 +41,8 @@ struct JShared {
     uint8_t flag[JB];
     uint8_t pat[2][24];    // anchor patterns
     unsigned peq[8];       // Myers match masks per symbol class
+    uint8_t cls[256];      // sym_class of every byte value: one LDS read (64 dwords, 64 banks: conflict-free) where the
+                           // compare chain of sym_class costs ~8 instructions -- the kernel is bound by instruction issue
     int nflag;             // flagged match ends of the current anchor search
     int flagged[64];
     uint16_t mst[FNM_LIST]; // match list of the anchor search: start, longest match length, best distance << 5 | its length, group start
@@ -52,6 +54,11 @@ struct JShared {
     unsigned long long jt;
 #endif
 };
+
+__device__ __forceinline__ void jshared_init(JShared &S) {
+    for (int i = threadIdx.x; i < 256; i += JB) S.cls[i] = (uint8_t)sym_class((uint8_t)i);
+    __syncthreads();
+}
 
 #ifdef JUDGE_CLOCKS
 // development aid (-DJUDGE_CLOCKS): wall-clock ticks per phase, summed over blocks by thread 0
@@ -293,7 +300,7 @@ __device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ un
             int score = m;
             const unsigned top = 1u << (m - 1);
             for (int j = j0; j < ce; j++) {
-                const unsigned Eq = S.peq[sym_class(ung[j])];
+                const unsigned Eq = S.peq[S.cls[ung[j]]];
                 const unsigned Xv = Eq | Mv;
                 const unsigned Xh = (((Eq & Pv) + Pv) ^ Pv) | Eq;
                 unsigned Ph = Mv | ~(Xh | Pv);
@@ -388,7 +395,7 @@ __device__ int blk_fnm(const uint8_t *pat, int m, const uint8_t *__restrict__ un
 // column statistics over the selected rows: cnt[6] (ACGTN-) and first-appearance row rank[6]
 // ---------------------------------------------------------------------------------------------
 __device__ void blk_colstats(const uint8_t *__restrict__ msa, int C, const uint16_t *sel, int rn,
-                             uint8_t *__restrict__ cstat) {
+                             uint8_t *__restrict__ cstat, const uint8_t *cls /* JShared::cls */) {
     // the six counters and the six first-appearance ranks live in two 64-bit registers (one byte per symbol class): a
     // dynamically indexed register array costs a compare-select chain per access.  rn <= MAXSEL (128) fits a byte.
     for (int c = threadIdx.x; c < C; c += JB) {
@@ -401,7 +408,7 @@ __device__ void blk_colstats(const uint8_t *__restrict__ msa, int C, const uint1
             for (int u = 0; u < 8; u++) sy[u] = msa[(size_t)sel[r + u] * C + c];
 #pragma unroll
             for (int u = 0; u < 8; u++) {
-                const int k8 = sym_class(sy[u]) * 8;
+                const int k8 = cls[sy[u]] * 8;
                 const unsigned fresh = ((seen >> k8 / 8) & 1u) ^ 1u;
                 cnt += 1ull << k8;
                 fst |= (unsigned long long)((unsigned)(r + u) & (0u - fresh)) << k8;
@@ -409,7 +416,7 @@ __device__ void blk_colstats(const uint8_t *__restrict__ msa, int C, const uint1
             }
         }
         for (; r < rn; r++) {
-            const int k8 = sym_class(msa[(size_t)sel[r] * C + c]) * 8;
+            const int k8 = cls[msa[(size_t)sel[r] * C + c]] * 8;
             const unsigned fresh = ((seen >> k8 / 8) & 1u) ^ 1u;
             cnt += 1ull << k8;
             fst |= (unsigned long long)((unsigned)r & (0u - fresh)) << k8;
@@ -580,7 +587,7 @@ __device__ int blk_first_window_masks(const uint8_t *__restrict__ msa, int C, co
     __syncthreads();
     for (int idx = threadIdx.x; idx < rn * span; idx += JB) {      // consecutive threads on consecutive columns of a row
         const int r = idx / span, c = idx - r * span;
-        const int k = sym_class(msa[(size_t)sel[r] * C + lo + c]);
+        const int k = S.cls[msa[(size_t)sel[r] * C + lo + c]];
         atomicOr(&mk[((size_t)c * 6 + k) * W32 + (r >> 5)], 1u << (r & 31));
     }
     __syncthreads();
@@ -946,6 +953,7 @@ __device__ void judge_v6_body(const JudgeParams &P, const uint8_t *msa, int R, i
 
 __global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(5, 8))) judge_kernel(JudgeParams P) {
     __shared__ JShared S;
+    jshared_init(S);
 #ifdef JUDGE_CLOCKS
     if (threadIdx.x == 0) S.jt = wall_clock64();
 #endif
@@ -1033,7 +1041,7 @@ __global__ void __launch_bounds__(JB) __attribute__((amdgpu_waves_per_eu(5, 8)))
             else if (rn <= 1) { call.info = HITE_INFO_FL1; call.row_num = (P.te_type == HITE_TE_TIR) ? 1 : rn; done = true; }
             if (!done) {
                 call.row_num = rn;
-                blk_colstats(msa, C, S.sel, rn, cstat);
+                blk_colstats(msa, C, S.sel, rn, cstat, S.cls);
                 JCLK(2);   // column statistics
                 double thr = homo_thr(rn, P.te_type == HITE_TE_TIR ? 0.7 : 0.8);
                 int hs = blk_search_v3(msa, cstat, C, S.sel, rn, astart, 0, thr, 20, 10, S);
@@ -1308,19 +1316,19 @@ __device__ void judge_v6_body(const JudgeParams &P, const uint8_t *msa, int R, i
     }
     int ns = S.iv[4], ne = S.iv[5];
     if (ne <= 0) return;
-    blk_colstats(msa, C, s_end, ne, cstat);
+    blk_colstats(msa, C, s_end, ne, cstat, S.cls);
     double thr = homo_thr(ne, 0.7);
     int valid = 0;
     int he = blk_search_v4(msa, cstat, C, s_end, ne, aend, 1, thr, int_thr_tab(ne), thr, 20, 10, S, &valid);
     if (!valid) return;
     if (ns <= 0) { out.info = HITE_INFO_EXC; return; }
-    blk_colstats(msa, C, s_start, ns, cstat);
+    blk_colstats(msa, C, s_start, ns, cstat, S.cls);
     thr = homo_thr(ns, 0.7);
     int hs = blk_search_v4(msa, cstat, C, s_start, ns, astart, 0, thr, int_thr_tab(ns), thr, 20, 10, S, &valid);
     int nf = blk_select_rows(msa, R, C, hs, he, 1, true, true, S.sel, S);
     if (nf <= 0) return;
     out.row_num = nf;
-    blk_colstats(msa, C, S.sel, nf, cstat);
+    blk_colstats(msa, C, S.sel, nf, cstat, S.cls);
     uint8_t *mbody = model + 1;  // one slot in front for the 1-bp left extension
     int ml = blk_consensus(cstat, nf, hs, he, 1, mbody, S);
     __syncthreads();
@@ -1461,6 +1469,7 @@ struct SearchParams {
 };
 __global__ void __launch_bounds__(JB) search_kernel(SearchParams P) {
     __shared__ JShared S;
+    jshared_init(S);
     int ci = blockIdx.x;
     if (ci >= P.n) return;
     const int R = P.rows[ci], C = P.cols[ci];
@@ -1468,7 +1477,7 @@ __global__ void __launch_bounds__(JB) search_kernel(SearchParams P) {
     uint8_t *cstat = P.cstat + P.col_off[ci] * CS;
     for (int r = threadIdx.x; r < R && r < MAXSEL; r += JB) S.sel[r] = (uint16_t)r;
     __syncthreads();
-    blk_colstats(msa, C, S.sel, R, cstat);
+    blk_colstats(msa, C, S.sel, R, cstat, S.cls);
     int b, valid = 1;
     if (P.variant == 3) b = blk_search_v3(msa, cstat, C, S.sel, R, P.pos[ci], P.side[ci], P.thr[ci], P.win_in, P.win_out, S);
     else b = blk_search_v4(msa, cstat, C, S.sel, R, P.pos[ci], P.side[ci], P.thr[ci], P.int_thr[ci], P.out_thr[ci], P.win_in, P.win_out, S, &valid);
@@ -1832,6 +1841,7 @@ struct BothEndsParams {
 
 __global__ void __launch_bounds__(JB) ltr_both_ends_kernel(BothEndsParams P) {
     __shared__ JShared S;
+    jshared_init(S);
     const int a = blockIdx.x;
     uint8_t *slot = P.scratch + (size_t)a * P.slot_bytes;
     const int R = P.rows[a], C = P.cols[a], F = P.flank;
