@@ -756,22 +756,29 @@ __device__ int blk_search_v4(const uint8_t *__restrict__ msa, const uint8_t *__r
 // returns 0 when the column contributes nothing.
 __device__ __forceinline__ uint8_t cons_col(const uint8_t *cs, int rn, int mode, int *best_all_cnt,
                                             int *best_all_sym) {
+    // the 12 bytes of a column's statistics as three aligned words (cstat is 16-byte aligned, CS = 12), the symbol of a class
+    // from a packed constant: twelve byte loads and a string look-up per column were a visible part of the consensus phase
+    const uint32_t *cw = reinterpret_cast<const uint32_t *>(cs);
+    const uint32_t w0 = cw[0], w1 = cw[1], w2 = cw[2];
+    const unsigned long long cnt = ((unsigned long long)(w1 & 0xffffu) << 32) | w0;                   // counts of classes 0..5
+    const unsigned long long fst = ((unsigned long long)w2 << 16) | (w1 >> 16);                        // first-appearance ranks 0..5
+    const unsigned long long syms = 0x2d4e54474341ull;                                                 // "ACGTN-"
     int best = 0, bk = -1, bf = 256;
 #pragma unroll
     for (int k = 0; k < 6; k++) {
-        int c = cs[k], f = cs[6 + k];
+        const int c = (int)(cnt >> (8 * k)) & 0xff, f = (int)(fst >> (8 * k)) & 0xff;
         if (c > best || (c == best && c > 0 && f < bf)) { best = c; bk = k; bf = f; }
     }
     if (best_all_cnt) { *best_all_cnt = best; *best_all_sym = bk; }
-    if (best >= rn / 2) return bk != 5 ? class_sym(bk) : 0;
+    if (best >= rn / 2) return bk != 5 ? (uint8_t)(syms >> (8 * bk)) : 0;
     if (mode == 1) return 'N';
     best = 0; bk = -1; bf = 256;
 #pragma unroll
     for (int k = 0; k < 5; k++) {
-        int c = cs[k], f = cs[6 + k];
+        const int c = (int)(cnt >> (8 * k)) & 0xff, f = (int)(fst >> (8 * k)) & 0xff;
         if (c > best || (c == best && c > 0 && f < bf)) { best = c; bk = k; bf = f; }
     }
-    return bk >= 0 ? class_sym(bk) : 0;
+    return bk >= 0 ? (uint8_t)(syms >> (8 * bk)) : 0;
 }
 
 // ordered compaction of the consensus of columns [hs, he] into out; returns length
