@@ -119,6 +119,10 @@ def gen_judge(U, tmp):
         big = casegen.make_msa_case(seed=seed0 * 7, te_type=te_type, rows=110, te_len=900, div=0.1, ins_cols=10,
                                     trunc_rows=4, shift_l=6, shift_r=-4, tsd_len=8, tsd_frac=0.9)
         cases.append(run_msa_case(U, tmp, big))
+        # round 3: cases aimed at the rare exits -- positives with plant 0 and 1, 'nb', 'fl1', inputs the reference raises on,
+        # the 100-row cap (appended: the cases above keep their indices)
+        for c in casegen.msa_outcome_cases(te_type, seed0 + 10):
+            cases.append(run_msa_case(U, tmp, c))
         stats = {}
         for c in cases:
             k = str(c["expected"][:2])
@@ -157,6 +161,33 @@ def gen_boundary_search(U):
         res2 = U.calculate_window_homology(mat, list(range(W - 1, 1, -1)), thr)
         ties.append(dict(seqs=rows, thr=thr, fwd=int(res), rev=int(res2)))
     dump("thr_ties", ties)
+
+    # round 3: the same binary64 ties reached THROUGH the searches (so that the GPU path, which has no entry for a single
+    # window, is pinned on them as well): 30 unrelated columns, then columns whose majority is exactly k/R, (k-1)/R or
+    # (k+1)/R of the rows; window means of 20 / 10 such ratios against thr, single ratios against thr - 0.1
+    rng = np.random.default_rng(78)
+    ts = []
+    for R, k, thr in ((10, 6, 0.7), (10, 7, 0.7), (10, 7, 0.8), (10, 8, 0.8), (20, 19, 0.95), (20, 14, 0.8), (20, 14, 0.7),
+                      (10, 9, 0.9), (10, 8, 0.9), (5, 4, 0.9), (4, 3, 0.9), (20, 16, 0.8), (20, 12, 0.7), (30, 21, 0.7),
+                      (30, 24, 0.8), (50, 35, 0.7), (100, 70, 0.7), (100, 80, 0.8), (101, 71, 0.7), (7, 5, 0.7)):
+        for mix in (0, 1, 2):
+            C = 120
+            cols = []
+            for c in range(C):
+                if c < 30 or c >= C - 30:
+                    cols.append([casegen.BASES[int(x)] for x in rng.integers(0, 4, size=R)])
+                else:
+                    kk = k if mix == 0 else int(k + rng.choice([-1, 0, 0, 1] if mix == 1 else [-1, 0, 1]))
+                    kk = max(1, min(R, kk))
+                    cols.append(["A" if r < kk else "CGT"[(r + c) % 3] for r in range(R)])
+            rows = ["".join(cols[c][r] for c in range(C)) for r in range(R)]
+            mat = [list(x) for x in rows]
+            for side, pos in (("start", 20), ("end", C - 21), ("start", 35), ("end", C - 36)):
+                v3 = U.search_boundary_homo_v3(int(R / 2), pos, mat, R, C, side, thr, 0, 20, 10)
+                v4 = U.search_boundary_homo_v4(int(R / 2), pos, mat, R, C, side, thr, thr - 0.05, thr, 0, 20, 10)
+                ts.append(dict(seqs=rows, pos=pos, side=side, thr=thr, v3=int(v3), v4=[bool(v4[0]), int(v4[1])]))
+    print("thr_ties_search: v3 found", sum(c["v3"] != -1 for c in ts), "of", len(ts), "; v4 valid", sum(c["v4"][0] for c in ts))
+    dump("thr_ties_search", ts)
 
 
 def gen_tsd(U):

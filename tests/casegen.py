@@ -313,3 +313,91 @@ def make_copies(seed, names, seqs, n_cand=6, per_cand=(1, 12), length=(60, 2500)
             lst.append((names[ci], st, en, en - st + 1, "+-"[int(rng.integers(0, 2))]))
         out["cand_%d" % q] = lst
     return out
+
+
+# ----------------------------------------------------------------------------------
+# alignment cases aimed at the rare outcomes of judge_boundary_v5/v6/v9: positives, 'nb' (no anchor),
+# 'fl1' (one full-length row), and inputs on which the reference raises
+# ----------------------------------------------------------------------------------
+def msa_outcome_cases(te_type, seed0):
+    """Deterministic list of cases (dicts as make_msa_case returns, `plant` set) whose outcomes cover
+    every exit of the three judges: >= 12 positives (plant 0 and 1), >= 6 'nb', >= 6 'fl1'-shaped inputs
+    (for Helitron, which has no such exit, they pin whatever v6 does with one start/end row) and
+    degenerate inputs (empty candidate, one-column rows, truncated rows in front of the 100-row cap)."""
+    rng = np.random.default_rng(seed0)
+    out = []
+
+    def base(i, **kw):
+        p = dict(seed=seed0 * 100 + i, te_type=te_type, rows=int(rng.choice([3, 5, 8, 12, 20, 30, 64, 70])),
+                 te_len=int(rng.choice([120, 200, 350, 700])), div=float(rng.choice([0.0, 0.03, 0.08])),
+                 row_gap_rate=float(rng.choice([0.0, 0.005])), ins_cols=int(rng.choice([0, 2])), trunc_rows=0,
+                 shift_l=0, shift_r=0, tsd_len=int(rng.choice([2, 3, 4, 5, 8, 9, 11])), tsd_frac=1.0)
+        p.update(kw)
+        return make_msa_case(**p)
+
+    # positives, both values of `plant`
+    for i in range(14):
+        c = base(i)
+        c["plant"] = i % 2
+        c["aim"] = "positive"
+        out.append(c)
+    # 'nb': the candidate is not in any row (unrelated, or both ends rewritten)
+    for i in range(6):
+        c = base(20 + i)
+        r2 = np.random.default_rng(seed0 * 7 + i)
+        if i % 2 == 0:
+            c["cand"] = rand_seq(r2, len(c["cand"]))
+        else:
+            c["cand"] = rand_seq(r2, 20) + c["cand"][20:-20] + rand_seq(r2, 20)
+        c["plant"] = i % 2
+        c["aim"] = "nb"
+        out.append(c)
+    # 'fl1': only the first row has bases at both anchors (a single row; or the other rows lost one end each -- half of
+    # them the left one, half the right one, so that no column becomes sparse)
+    for i in range(6):
+        rows = 1 if i < 2 else int(rng.choice([3, 7, 13]))
+        c = base(30 + i, rows=rows, trunc_rows=0, ins_cols=0)
+        if rows > 1:
+            W = len(c["seqs"][0])
+            cut = 50 + 15 + 3 * i
+            seqs = [c["seqs"][0]]
+            for r, s in enumerate(c["seqs"][1:]):
+                seqs.append("-" * cut + s[cut:] if r % 2 == 0 else s[:W - cut] + "-" * cut)
+            c["seqs"] = seqs
+        c["plant"] = i % 2
+        c["aim"] = "fl1"
+        out.append(c)
+    # degenerate inputs
+    c = base(40)
+    c["cand"] = ""
+    c["aim"] = "empty candidate"
+    out.append(c)
+    c = base(41, rows=4, te_len=90)
+    c["cand"] = c["cand"][:12]           # shorter than the 20-bp anchors: both anchors are the whole candidate
+    c["aim"] = "short candidate"
+    out.append(c)
+    c = base(42, rows=3, te_len=90)
+    c["seqs"] = [s[:1] for s in c["seqs"]]   # one-column alignment
+    c["aim"] = "one column"
+    out.append(c)
+    # the 100-row cap of the row sets: 101 rows without a left end in front of 110 full-length rows (columns stay dense)
+    def renamed(c):
+        c["names"] = ["chr%d:%d-%d(%s)" % (i % 5, 1000 + 37 * i, 1000 + 37 * i + 199, "+-"[i % 2]) for i in range(len(c["seqs"]))]
+        return c
+    c = base(43, rows=110, te_len=200, ins_cols=0, div=0.03)
+    c["seqs"] = ["-" * 90 + s[90:] for s in c["seqs"][1:102]] + c["seqs"]
+    c["aim"] = "101 rows without a left end, then the full-length rows"
+    out.append(renamed(c))
+    c = base(44, rows=110, te_len=200, ins_cols=0, div=0.03)
+    c["seqs"] = c["seqs"][:1] + ["-" * 90 + s[90:] for s in c["seqs"][1:102]] + c["seqs"][1:]
+    c["aim"] = "anchor row first, then 101 rows without a left end"
+    out.append(renamed(c))
+    W = len(c["seqs"][0])
+    c = base(45, rows=110, te_len=200, ins_cols=0, div=0.03)
+    W = len(c["seqs"][0])
+    c["seqs"] = [s[:W - 90] + "-" * 90 for s in c["seqs"][1:102]] + c["seqs"]
+    c["aim"] = "101 rows without a right end, then the full-length rows"
+    out.append(renamed(c))
+    for c in out:
+        c.setdefault("plant", 1)
+    return out

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
-def run_fine(mbp, n_tir, n_ltr, seed):
+def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",)):
     import torch
 
     import hite_amd
@@ -38,16 +38,27 @@ def run_fine(mbp, n_tir, n_ltr, seed):
     d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
     ctx.align_stats(reset=True)
     nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
+    # the same candidates and copy table judged as Helitron / non-LTR as well (judge_Helitron_transposons.py:86-97,
+    # judge_Non_LTR_transposons.py:48-51 run the same flank_region_align_v5 with another TE_type)
+    other = {}
+    for te in te_types:
+        if te == "tir":
+            continue
+        stats = ctx.flank_region_align_dev(te, 1, n, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
+                                           d_calls.data_ptr(), d_cons.data_ptr(), cap)
+        torch.cuda.synchronize()
+        other[te] = (d_calls.cpu().numpy().view(CALL_DTYPE).copy(), d_cons.cpu().numpy().copy())
+    ctx.align_stats(reset=True)
     stats = ctx.flank_region_align_dev("tir", 1, n, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
                                        d_calls.data_ptr(), d_cons.data_ptr(), cap)
     torch.cuda.synchronize()
     found = dict(copy_first=ctx.download(p_cf, n + 1, np.int32), contig=ctx.download(p_ct, nc, np.int32),
                  start1=ctx.download(p_s1, nc, np.int64), end1=ctx.download(p_e1, nc, np.int64), minus=ctx.download(p_mn, nc, np.uint8))
     return dict(w=w, ctx=ctx, n=n, calls=d_calls.cpu().numpy().view(CALL_DTYPE).copy(), cons=d_cons.cpu().numpy(), found=found,
-                stats=stats, align=ctx.align_stats(), genome=w["genome"].cpu().numpy(), seed=seed, n_tir=n_tir, n_ltr=n_ltr)
+                other=other, stats=stats, align=ctx.align_stats(), genome=w["genome"].cpu().numpy(), seed=seed, n_tir=n_tir, n_ltr=n_ltr)
 
 
-def oracle_check(R, count, seed):
+def oracle_check(R, count, seed, te_type="tir"):
     """re-judge `count` random candidates with the oracle chain on the copy table the GPU found"""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import oracle_pipeline as OP
@@ -58,14 +69,15 @@ def oracle_check(R, count, seed):
     info_names = {0: "", 1: "nb", 2: "fl1", 3: "EXC"}
     bad = []
     n_te = 0
+    calls_all, cons_all = (R["calls"], R["cons"]) if te_type == "tir" else R["other"][te_type]
     for c in np.random.default_rng(seed).permutation(R["n"])[:count]:
         a, b = int(f["copy_first"][c]), int(f["copy_first"][c + 1])
         copies = [(int(f["contig"][i]), int(f["start1"][i]), int(f["end1"][i]), int(f["minus"][i])) for i in range(a, b)]
         cand = w["cands"][w["cand_off"][c]:w["cand_off"][c + 1]].tobytes().decode()
-        exp = OP.fine_stage_candidate("tir", cand, copies, contigs, plant=1)
-        r = R["calls"][c]
+        exp = OP.fine_stage_candidate(te_type, cand, copies, contigs, plant=1)
+        r = calls_all[c]
         got = [bool(r["is_te"]), info_names[int(r["info"])],
-               R["cons"][r["cons_off"]:r["cons_off"] + r["cons_len"]].tobytes().decode() if r["is_te"] else "", int(r["row_num"])]
+               cons_all[r["cons_off"]:r["cons_off"] + r["cons_len"]].tobytes().decode() if r["is_te"] else "", int(r["row_num"])]
         n_te += got[0]
         if got != exp:
             bad.append(int(c))
@@ -148,7 +160,7 @@ def copy_recall_precision(R, sample=1500):
 
 @pytest.fixture(scope="module")
 def c2():
-    R = run_fine(100, 500, 0, 20250927 + 2)
+    R = run_fine(100, 500, 0, 20250927 + 2, te_types=("tir", "helitron", "non_ltr"))
     yield R
     R["ctx"].close()
 
@@ -159,6 +171,14 @@ def test_c2_fine_stage_matches_oracle_chain(c2):
     st = c2["align"]
     assert st["dropped"] == 0 and st["pairs"] > 50_000
     assert st["certified"] >= 0.80 * st["pairs"]            # measured r02: 0.89 (exact_cap 8)
+
+
+@pytest.mark.parametrize("te_type", ["helitron", "non_ltr"])
+def test_c2_fine_stage_other_types_match_oracle_chain(c2, te_type):
+    """the fused pipeline with TE_type Helitron / non-LTR (what judge_Helitron/Non_LTR_transposons.py run) on the C2 batch: the
+    same 120 random candidates through the oracle chain (the families are TIR elements: mostly rejections, each one compared)"""
+    bad, n_te = oracle_check(c2, 120, 3, te_type)
+    assert bad == []
 
 
 def test_c2_copy_finder_recall_precision(c2):

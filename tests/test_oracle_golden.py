@@ -60,6 +60,18 @@ def test_threshold_ties_golden():
         assert O.window_homology(msa, W - 1, W - 2, -1, case["thr"]) == case["rev"]
 
 
+def test_threshold_ties_through_search_golden():
+    """the binary64 ties of thr / thr - 0.1 reached through search_boundary_homo_v3 / _v4 (240 reference runs)"""
+    cases = load_golden("thr_ties_search")
+    assert sum(c["v3"] != -1 for c in cases) > 50 and sum(c["v3"] == -1 for c in cases) > 50
+    for i, case in enumerate(cases):
+        msa = O.msa_array(case["seqs"])
+        thr = case["thr"]
+        assert O.search_v3(msa, case["pos"], case["side"], thr) == case["v3"], i
+        v, b = O.search_v4(msa, case["pos"], case["side"], thr, thr - 0.05, thr)
+        assert [v, b] == case["v4"], i
+
+
 def test_tsd_search_golden():
     for case in load_golden("tsd_search"):
         got = O.tsd_search_v5(case["seq"], case["start"], case["end"], case["plant"])
