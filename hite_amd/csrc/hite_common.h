@@ -39,7 +39,11 @@ struct hite_ctx {
     const int32_t *d_msa_row_map;   // per compacted row: source row (NULL: identity)
     const int32_t *d_msa_rows_eff;  // per candidate: rows that were aligned (NULL: all)
     uint32_t *d_msa_lay;             // layout words of the last sparse star alignment (hite_msa.hip)
+    // second stream + fork / join events for kernels that run beside each other inside one call (the two judge kernels)
+    void *aux_stream;
+    void *aux_ev[2];
 };
+int hite_aux_stream(hite_ctx *ctx, hipStream_t *st, hipEvent_t *fork_ev, hipEvent_t *join_ev);
 
 // record the time of everything enqueued on `st` between begin and end as stage `name`
 int hite_prof_begin(hite_ctx *ctx, const char *name, hipStream_t st);

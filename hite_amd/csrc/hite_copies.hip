@@ -418,41 +418,237 @@ __global__ void cluster_acc_init_kernel(int64_t ncl, unsigned long long *__restr
     if (k < ncl) { c_lo[k] = 0xffffffffffffffffull; c_hi[k] = 0; }
 }
 
-// accepted clusters -> copy records + sort key (candidate:19 | 4095-anchors:12 | start:32 | minus:1).  Two passes:
-// WRITE = false counts the accepted clusters per candidate, WRITE = true places each record at
+// ---- chains -> copies: base-level end extension + the reference's two coverage filters (definition: header of the twin) --
+// chains = clusters with >= 3 anchors whose query span is >= 95 % of their genome span; their ids go to a dense list
+// (a thread per cluster of the 10^8 diagonal clusters would leave one or two live lanes per wavefront in the extension).
+// Chains with a long end to extend (>= EXT_LONG bases) are listed from the front, the others from the back of the same array:
+// the extension takes its tasks front to back, so the long chains -- the tail of the kernel otherwise -- start first.
+#define EXT_LONG 384
+__global__ void __launch_bounds__(256) chain_list_kernel(int64_t ncl, const unsigned long long *__restrict__ hkey, HitFmt F,
+                                                         const unsigned *__restrict__ c_first, const unsigned long long *__restrict__ c_lo,
+                                                         const unsigned long long *__restrict__ c_hi, const int64_t *__restrict__ cand_off,
+                                                         unsigned *__restrict__ list, unsigned long long cap,
+                                                         unsigned long long *__restrict__ counters /* [0] long, [1] short */) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool want = false, lng = false;
+    if (k < ncl && (int)(c_first[k + 1] - c_first[k]) >= C_MINANCH) {
+        const long long qlo = (long long)(c_lo[k] >> 32), glo = (long long)(c_lo[k] & 0xffffffffull);
+        const long long qhi = (long long)(c_hi[k] >> 32), ghi = (long long)(c_hi[k] & 0xffffffffull);
+        want = (qhi + CK - qlo) * 100 >= 95 * (ghi + CK - glo);
+        if (want) {
+            const unsigned c = hit_cand(F, hkey[c_first[k]]);
+            const long long Lq = cand_off[c + 1] - cand_off[c];
+            lng = qlo >= EXT_LONG || Lq - (qhi + CK) >= EXT_LONG;
+        }
+    }
+    const unsigned long long sa = wave_append(want && lng, &counters[0]);
+    const unsigned long long sb = wave_append(want && !lng, &counters[1]);
+    if (want && lng && sa < cap) list[sa] = (unsigned)k;
+    if (want && !lng && sb < cap) list[cap - 1 - sb] = (unsigned)k;
+}
+// chain number e (long ones first) -> cluster id
+__device__ __forceinline__ unsigned chain_at(const unsigned *__restrict__ list, unsigned long long cap, unsigned long long n_long, unsigned long long e) {
+    return e < n_long ? list[e] : list[cap - 1 - (e - n_long)];
+}
+
+// >>> ext_align_dev (tests/test_host_compiled.py compiles this block for the host and compares it with the twin)
+#define EXT_B 8
+#define EXT_W (2 * EXT_B + 1)
+#define EXT_PEN 3
+#define EXT_XDROP 40
+#define EXT_INF (1 << 20)
+// code of genome base g: 0..3, 4 = not A/C/G/T
+__device__ __forceinline__ unsigned ext_genome_code(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g) {
+    const unsigned c = (bases[g >> 4] >> (2 * (int)(g & 15))) & 3u;
+    return ((nmask[g >> 5] >> (int)(g & 31)) & 1u) ? 4u : c;
+}
+__device__ __forceinline__ unsigned ext_cand_code(unsigned ch, bool comp) {
+    const unsigned c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
+    return (comp && c < 4u) ? 3u - c : c;
+}
+// ext_align of the twin as a state machine: query bases q[p0], q[p0 + step], ... (n of them; complemented when comp), genome
+// bases g0, g0 + 1, ... (dir = +1) or g0 - 1, g0 - 2, ... (dir = -1), at most jmax of them.  The 17 band cells live in
+// registers (the loops over the band are unrolled), the genome bases under the band as three 17-bit planes that shift by one
+// cell per column: a column costs one new genome base, one query base and ~8 integer operations per cell.
+struct ExtState {
+    int D[EXT_W];
+    uint32_t W0, W1, WN;
+    int i, n, best_i, best_t, best_s;
+    unsigned gnext, qnext;
+    const uint8_t *q;
+    int64_t p0, g0, jmax;
+    int step, dir;
+    bool comp;
+};
+__device__ __forceinline__ void ext_init(ExtState &E, const uint8_t *__restrict__ q, int64_t p0, int step, bool comp, int n,
+                                         const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g0, int dir, int64_t jmax) {
+    E.q = q; E.p0 = p0; E.step = step; E.comp = comp; E.n = n; E.g0 = g0; E.dir = dir; E.jmax = jmax;
+#pragma unroll
+    for (int b = 0; b < EXT_W; b++) { const int j = b - EXT_B; E.D[b] = (j >= 0 && j <= jmax) ? j : EXT_INF; }
+    // planes of "column 0": bit b = genome base number j = b - EXT_B (1-based in walking order); bit set in WN = never matches
+    E.W0 = 0u; E.W1 = 0u; E.WN = (1u << EXT_W) - 1u;
+#pragma unroll
+    for (int j = 1; j <= EXT_B; j++) {
+        if (j <= jmax) {
+            const unsigned cd = ext_genome_code(bases, nmask, dir > 0 ? g0 + j - 1 : g0 - j);
+            E.W0 |= (cd & 1u) << (j + EXT_B); E.W1 |= ((cd >> 1) & 1u) << (j + EXT_B); E.WN &= ~((~(cd >> 2) & 1u) << (j + EXT_B));
+        }
+    }
+    E.best_i = 0; E.best_t = 0; E.best_s = 0; E.i = 1;
+    E.gnext = 4u; E.qnext = 4u;
+    if (n >= 1) {
+        if (1 + EXT_B <= jmax) E.gnext = ext_genome_code(bases, nmask, dir > 0 ? g0 + EXT_B : g0 - 1 - EXT_B);
+        E.qnext = ext_cand_code(q[p0], comp);
+    }
+}
+// one column (E.i <= E.n on entry); returns true when the extension is finished (result in best_i / best_t)
+__device__ __forceinline__ bool ext_step(ExtState &E, const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask) {
+    const int i = E.i;
+    const unsigned gc = E.gnext, qc = E.qnext;
+    if (i < E.n) {    // what column i + 1 needs, fetched a column ahead
+        const int64_t j = (int64_t)i + 1 + EXT_B;
+        E.gnext = j <= E.jmax ? ext_genome_code(bases, nmask, E.dir > 0 ? E.g0 + j - 1 : E.g0 - j) : 4u;
+        E.qnext = ext_cand_code(E.q[E.p0 + (int64_t)E.step * i], E.comp);
+    }
+    E.W0 = (E.W0 >> 1) | ((gc & 1u) << (EXT_W - 1)); E.W1 = (E.W1 >> 1) | (((gc >> 1) & 1u) << (EXT_W - 1)); E.WN = (E.WN >> 1) | ((gc >> 2) << (EXT_W - 1));
+    const uint32_t eq = qc < 4u ? (~(E.W0 ^ (0u - (qc & 1u))) & ~(E.W1 ^ (0u - ((qc >> 1) & 1u))) & ~E.WN) : 0u;
+    const int lo = EXT_B - i;                                   // cells with j >= 0
+    const int64_t hi64 = E.jmax - i + EXT_B;                    // cells with j <= jmax
+    const int hi = hi64 > EXT_W ? EXT_W : (int)hi64;
+    int left = EXT_INF, kmin = 0x7fffffff;
+#pragma unroll
+    for (int b = 0; b < EXT_W; b++) {
+        const int diag = E.D[b] + (int)(((eq >> b) & 1u) ^ 1u);
+        const int up = b + 1 < EXT_W ? E.D[b + 1] + 1 : EXT_INF;
+        int v = min(min(diag, up), left + 1);
+        v = (b >= lo && b <= hi) ? v : EXT_INF;
+        E.D[b] = v;
+        left = v;
+        const int tc = 2 * (b > EXT_B ? b - EXT_B : EXT_B - b) + (b > EXT_B ? 1 : 0);   // ties: |j - i| smallest, then the smaller j
+        const int key = (v << 5) | tc;
+        kmin = key < kmin ? key : kmin;
+    }
+    const int cmin = kmin >> 5;
+    if (cmin >= EXT_INF) return true;
+    const int tcv = kmin & 31;
+    const int tmin = i + ((tcv & 1) ? (tcv >> 1) : -(tcv >> 1));
+    const int sc = i - EXT_PEN * cmin;
+    if (sc >= E.best_s) { E.best_s = sc; E.best_i = i; E.best_t = tmin; }
+    else if (sc < E.best_s - EXT_XDROP) return true;
+    E.i = i + 1;
+    return E.i > E.n;
+}
+__device__ __forceinline__ void ext_align_dev(const uint8_t *__restrict__ q, int64_t p0, int step, bool comp, int n,
+                                              const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g0, int dir,
+                                              int64_t jmax, int *i_out, int *t_out) {
+    ExtState E;
+    ext_init(E, q, p0, step, comp, n, bases, nmask, g0, dir, jmax);
+    if (n >= 1) while (!ext_step(E, bases, nmask)) { }
+    *i_out = E.best_i; *t_out = E.best_t;
+}
+// <<< ext_align_dev
+
+// one LANE per (chain, end) task -- even tasks extend to the left of the first anchor, odd ones to the right of the last --
+// and a lane that has finished takes the next task from the queue while its neighbours go on (the lengths run from 0 to
+// thousands of columns: with a fixed task per thread every wavefront waited for its longest).  Refill when a quarter of
+// the lanes is idle, so that the set-up code is paid for 16 tasks at a time.
+__global__ void __launch_bounds__(256) chain_extend_kernel(const unsigned long long *__restrict__ counters, const unsigned *__restrict__ list,
+                                                           const unsigned long long *__restrict__ hkey, HitFmt F, const unsigned *__restrict__ c_first,
+                                                           const unsigned long long *__restrict__ c_lo, const unsigned long long *__restrict__ c_hi,
+                                                           const uint8_t *__restrict__ cand, const int64_t *__restrict__ cand_off,
+                                                           const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                                           const int64_t *__restrict__ coff, int nc, unsigned long long cap,
+                                                           unsigned long long *__restrict__ queue, int32_t *__restrict__ x_i, int32_t *__restrict__ x_t) {
+    unsigned long long n_long = counters[0], n_short = counters[1];
+    if (n_long > cap) n_long = cap;
+    if (n_long + n_short > cap) n_short = cap - n_long;
+    const unsigned long long ntask = 2ull * (n_long + n_short);
+    const int lane = threadIdx.x & 63;
+    ExtState E;
+    E.n = 0; E.i = 1;
+    bool active = false, exhausted = false;
+    unsigned long long my = 0;
+    for (;;) {
+        const unsigned long long idle = __ballot(!active);
+        if (!exhausted && (idle == ~0ull || __popcll(idle) >= 16)) {
+            const int leader = __ffsll((long long)idle) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(queue, (unsigned long long)__popcll(idle));
+            base = ((unsigned long long)(unsigned)__shfl((int)(base >> 32), leader) << 32) | (unsigned)__shfl((int)base, leader);
+            if (base + (unsigned long long)__popcll(idle) >= ntask) exhausted = true;
+            if (!active) {
+                const unsigned long long t = base + (unsigned long long)__popcll(idle & ((1ull << lane) - 1ull));
+                if (t < ntask) {
+                    const unsigned k = chain_at(list, cap, n_long, t >> 1);
+                    const int side = (int)(t & 1ull);
+                    const unsigned long long key = hkey[c_first[k]];
+                    const unsigned c = hit_cand(F, key), rel = hit_rel(F, key);
+                    const int64_t qb = cand_off[c];
+                    const int Lq = (int)(cand_off[c + 1] - qb);
+                    const long long qlo = (long long)(c_lo[k] >> 32), glo = (long long)(c_lo[k] & 0xffffffffull);
+                    const long long qhi = (long long)(c_hi[k] >> 32), ghi = (long long)(c_hi[k] & 0xffffffffull);
+                    const int ctg = contig_of(coff, nc, glo);
+                    // the query in the orientation of the genome: rel = 1 reads the reverse complement of the candidate, x -> Lq - 1 - x
+                    if (side == 0)        // x = qlo - 1, qlo - 2, ..., 0
+                        ext_init(E, cand, rel ? qb + Lq - qlo : qb + qlo - 1, rel ? +1 : -1, rel != 0, (int)qlo, bases, nmask, glo, -1, glo - coff[ctg]);
+                    else                  // x = qhi + K, qhi + K + 1, ...
+                        ext_init(E, cand, rel ? qb + Lq - 1 - (qhi + CK) : qb + qhi + CK, rel ? -1 : +1, rel != 0, (int)(Lq - (qhi + CK)), bases, nmask,
+                                 ghi + CK, +1, coff[ctg + 1] - (ghi + CK));
+                    my = t;
+                    if (E.n >= 1) active = true;
+                    else { x_i[t] = 0; x_t[t] = 0; }
+                }
+            }
+        }
+        if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
+        if (active && ext_step(E, bases, nmask)) { x_i[my] = E.best_i; x_t[my] = E.best_t; active = false; }
+    }
+}
+
+// accepted chains -> copy records + sort key (candidate:19 | 4095-anchors:12 | start:32 | minus:1).  Two passes:
+// WRITE = false counts the accepted chains per candidate, WRITE = true places each record at
 // cstart[candidate] + (a per-candidate atomic counter): no single hot append counter (740 k same-address atomics cost 5 ms).
+// aligned = the candidate minus what the two extensions clipped; the two filters of get_copies_minimap2 (Util.py:8008-8022)
+// are evaluated on the aligned part, the interval handed on covers the whole candidate (clipped ends on the diagonal of the
+// last aligned base, <= 5 % of the candidate: see the twin's header).
 template <bool WRITE>
-__global__ void cluster_copy_kernel(int64_t ncl, const unsigned long long *__restrict__ hkey, HitFmt F, const unsigned *__restrict__ c_first,
-                                    const unsigned long long *__restrict__ c_lo, const unsigned long long *__restrict__ c_hi,
-                                    const int32_t *__restrict__ c_cnt, const int64_t *__restrict__ cand_off,
-                                    const int64_t *__restrict__ coff, int nc, unsigned long long *__restrict__ ckey,
-                                    unsigned *__restrict__ cval, int32_t *__restrict__ r_contig, int64_t *__restrict__ r_s1,
-                                    int64_t *__restrict__ r_e1, uint8_t *__restrict__ r_minus, int32_t *__restrict__ r_anch,
-                                    int32_t *__restrict__ per_cand, const int64_t *__restrict__ cstart) {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ncl) return;
-    int na = (int)(c_first[k + 1] - c_first[k]);
-    if (na < C_MINANCH) return;
-    unsigned long long key = hkey[c_first[k]];
-    unsigned c = hit_cand(F, key);
-    unsigned rel = hit_rel(F, key);
-    long long Lq = cand_off[c + 1] - cand_off[c];
-    long long qlo = (long long)(c_lo[k] >> 32), glo = (long long)(c_lo[k] & 0xffffffffull);
-    long long qhi = (long long)(c_hi[k] >> 32), ghi = (long long)(c_hi[k] & 0xffffffffull);
-    if ((qhi + CK - qlo) * 100 < 80 * Lq) return;
-    if ((qhi + CK - qlo) * 100 < 95 * (ghi + CK - glo)) return;      // target coverage (Util.py:8008-8020): aligned query / genome span >= 0.95
-    int ctg = contig_of(coff, nc, glo);
-    long long s0 = glo - qlo, e0 = ghi + CK + (Lq - (qhi + CK));
-    long long cb = coff[ctg], ce = coff[ctg + 1];
-    if (s0 < cb) s0 = cb;
-    if (e0 > ce) e0 = ce;
-    if (e0 <= s0) return;
-    if (!WRITE) { atomicAdd(&per_cand[c], 1); return; }
-    const int64_t slot = cstart[c] + atomicAdd(&per_cand[c], 1);
-    r_contig[slot] = ctg; r_s1[slot] = s0 - cb + 1; r_e1[slot] = e0 - cb; r_minus[slot] = (uint8_t)rel; r_anch[slot] = na;
-    int ac = na > 4095 ? 4095 : na;
-    ckey[slot] = ((unsigned long long)c << 45) | ((unsigned long long)(4095 - ac) << 33) | ((unsigned long long)(unsigned)s0 << 1) | rel;
-    cval[slot] = (unsigned)slot;
+__global__ void __launch_bounds__(256) chain_copy_kernel(const unsigned long long *__restrict__ counters, unsigned long long cap,
+                                                         const unsigned *__restrict__ list, const int32_t *__restrict__ x_i,
+                                                         const int32_t *__restrict__ x_t, const unsigned long long *__restrict__ hkey, HitFmt F,
+                                                         const unsigned *__restrict__ c_first, const unsigned long long *__restrict__ c_lo,
+                                                         const unsigned long long *__restrict__ c_hi, const int64_t *__restrict__ cand_off,
+                                                         const int64_t *__restrict__ coff, int nc, unsigned long long *__restrict__ ckey,
+                                                         unsigned *__restrict__ cval, int32_t *__restrict__ r_contig, int64_t *__restrict__ r_s1,
+                                                         int64_t *__restrict__ r_e1, uint8_t *__restrict__ r_minus, int32_t *__restrict__ r_anch,
+                                                         int32_t *__restrict__ per_cand, const int64_t *__restrict__ cstart) {
+    unsigned long long n_long = counters[0], n_short = counters[1];
+    if (n_long > cap) n_long = cap;
+    if (n_long + n_short > cap) n_short = cap - n_long;
+    const unsigned long long nch = n_long + n_short;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < nch; e += (unsigned long long)gridDim.x * blockDim.x) {
+        const unsigned k = chain_at(list, cap, n_long, e);
+        const int na = (int)(c_first[k + 1] - c_first[k]);
+        const unsigned long long key = hkey[c_first[k]];
+        const unsigned c = hit_cand(F, key), rel = hit_rel(F, key);
+        const long long Lq = cand_off[c + 1] - cand_off[c];
+        const long long qlo = (long long)(c_lo[k] >> 32), glo = (long long)(c_lo[k] & 0xffffffffull);
+        const long long qhi = (long long)(c_hi[k] >> 32), ghi = (long long)(c_hi[k] & 0xffffffffull);
+        const long long clip_l = qlo - x_i[2 * e], clip_r = Lq - (qhi + CK) - x_i[2 * e + 1];
+        const long long aligned = Lq - clip_l - clip_r;
+        const long long a0 = glo - x_t[2 * e], a1 = ghi + CK + x_t[2 * e + 1];          // genome interval of the aligned part
+        if (!(a1 > a0 && aligned * 100 >= 95 * Lq && aligned * 100 >= 95 * (a1 - a0))) continue;   // Util.py:8008-8022
+        if (!WRITE) { atomicAdd(&per_cand[c], 1); continue; }
+        const int ctg = contig_of(coff, nc, glo);
+        const long long cb = coff[ctg], ce = coff[ctg + 1];
+        long long s0 = a0 - clip_l, e0 = a1 + clip_r;
+        if (s0 < cb) s0 = cb;
+        if (e0 > ce) e0 = ce;
+        const int64_t slot = cstart[c] + atomicAdd(&per_cand[c], 1);
+        r_contig[slot] = ctg; r_s1[slot] = s0 - cb + 1; r_e1[slot] = e0 - cb; r_minus[slot] = (uint8_t)rel; r_anch[slot] = na;
+        const int ac = na > 4095 ? 4095 : na;
+        ckey[slot] = ((unsigned long long)c << 45) | ((unsigned long long)(4095 - ac) << 33) | ((unsigned long long)(unsigned)s0 << 1) | rel;
+        cval[slot] = (unsigned)slot;
+    }
 }
 
 __global__ void cap300_kernel(int n, const int32_t *__restrict__ in, int32_t *__restrict__ out) {
@@ -610,7 +806,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     // candidate minimizers
     unsigned long long qcap = (unsigned long long)(cand_bytes * 0.32) + 4096 + (unsigned long long)n_cand;
     unsigned *q_c, *q_pos, *q_hs, *occ_lo, *hval, *c_first, *cval;
-    int32_t *occ_n, *flag, *c_cnt, *per_cand, *per_cand300;
+    int32_t *occ_n, *flag, *per_cand, *per_cand300;
     int64_t *hit_off, *cid, *bs, *cstart, *ofirst;
     unsigned long long *hkey, *c_lo, *c_hi, *ckey;
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_c = (unsigned *)p;
@@ -702,24 +898,42 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     S->last[2] = ncl;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); c_lo = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); c_hi = (unsigned long long *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); c_cnt = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 4, &p)); c_first = (unsigned *)p;
     hipLaunchKernelGGL(cluster_first_kernel, CGRID(nh), 0, st, nh, flag, cid, c_first, ncl);
     int tk_cluster_acc_kernel = hite_prof_begin(ctx, "cluster_acc_kernel", st);
     hipLaunchKernelGGL(cluster_acc_init_kernel, CGRID(ncl), 0, st, ncl, c_lo, c_hi);
     hipLaunchKernelGGL(cluster_acc_kernel, CGRID(nh), 0, st, nh, hkey, F, flag, cid, c_lo, c_hi);
     hite_prof_end(ctx, tk_cluster_acc_kernel, st);
-    // clusters -> copies
+    // chains -> end extension -> copies.  The chain list is sized for the worst case (every chain needs >= 3 hits); its length
+    // stays on the device (the kernels behind it run grid-stride loops up to the count they read there)
+    const unsigned long long chcap = (unsigned long long)(nh / C_MINANCH) + 1;
+    unsigned *chain_list; int32_t *x_i, *x_t;
+    CCHK(arena_alloc(ctx, A, (size_t)chcap * 4, &p)); chain_list = (unsigned *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)chcap * 8, &p)); x_i = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)chcap * 8, &p)); x_t = (int32_t *)p;
+    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+    unsigned long long *d_nchain = (unsigned long long *)(S->d_scal + 4);     // [0] long chains, [1] short chains, [2] task queue
+    int tk_ext = hite_prof_begin(ctx, "chain_extend_kernel", st);
+    hipLaunchKernelGGL(chain_list_kernel, CGRID(ncl), 0, st, ncl, hkey, F, c_first, c_lo, c_hi, d_cand_off, chain_list, chcap, d_nchain);
+    {
+        // persistent lanes: every lane takes (chain, end) tasks from the queue until it is empty
+        unsigned long long want_blocks = (2ull * chcap + 255ull) / 256ull;
+        const unsigned eblocks = (unsigned)(want_blocks < 2048ull ? (want_blocks ? want_blocks : 1ull) : 2048ull);
+        hipLaunchKernelGGL(chain_extend_kernel, dim3(eblocks), dim3(256), 0, st, d_nchain, chain_list, hkey, F, c_first, c_lo, c_hi, d_cand,
+                           d_cand_off, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off, ctx->n_contigs, chcap, d_nchain + 2, x_i, x_t);
+    }
+    hite_prof_end(ctx, tk_ext, st);
     int32_t *r_contig, *r_anch;
     int64_t *r_s1, *r_e1;
     uint8_t *r_minus;
-    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); ckey = (unsigned long long *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); cval = (unsigned *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); r_contig = (int32_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); r_s1 = (int64_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 8, &p)); r_e1 = (int64_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 16), &p)); r_minus = (uint8_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); r_anch = (int32_t *)p;
+    // (records: at most one per chain)
+    CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 8, &p)); ckey = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 4, &p)); cval = (unsigned *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 4, &p)); r_contig = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 8, &p)); r_s1 = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 8, &p)); r_e1 = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(chcap + 16), &p)); r_minus = (uint8_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 4, &p)); r_anch = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); per_cand = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); per_cand300 = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); cstart = (int64_t *)p;
@@ -728,15 +942,20 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); fill = (int32_t *)p;
     HITE_CHECK(ctx, hipMemsetAsync(per_cand, 0, (size_t)(n_cand + 1) * 4, st));
     HITE_CHECK(ctx, hipMemsetAsync(fill, 0, (size_t)(n_cand + 1) * 4, st));
-    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
     int64_t *bs3;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(n_cand) * 8, &p)); bs3 = (int64_t *)p;
-    int tk_cluster_copy_kernel = hite_prof_begin(ctx, "cluster_copy_kernel", st);
-    hipLaunchKernelGGL(cluster_copy_kernel<false>, CGRID(ncl), 0, st, ncl, hkey, F, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
-                       ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, per_cand, (const int64_t *)nullptr);
-    CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand, n_cand, cstart, st));
-    hipLaunchKernelGGL(cluster_copy_kernel<true>, CGRID(ncl), 0, st, ncl, hkey, F, c_first, c_lo, c_hi, c_cnt, d_cand_off, ctx->d_contig_off,
-                       ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, fill, (const int64_t *)cstart);
+    int tk_cluster_copy_kernel = hite_prof_begin(ctx, "chain_copy_kernel", st);
+    {
+        unsigned long long want_blocks = (chcap + 255ull) / 256ull;
+        const unsigned cblocks = (unsigned)(want_blocks < 8192ull ? (want_blocks ? want_blocks : 1ull) : 8192ull);
+        hipLaunchKernelGGL(chain_copy_kernel<false>, dim3(cblocks), dim3(256), 0, st, d_nchain, chcap, chain_list, x_i, x_t, hkey, F, c_first, c_lo,
+                           c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, per_cand,
+                           (const int64_t *)nullptr);
+        CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand, n_cand, cstart, st));
+        hipLaunchKernelGGL(chain_copy_kernel<true>, dim3(cblocks), dim3(256), 0, st, d_nchain, chcap, chain_list, x_i, x_t, hkey, F, c_first, c_lo,
+                           c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, fill,
+                           (const int64_t *)cstart);
+    }
     hite_prof_end(ctx, tk_cluster_copy_kernel, st);
     hipLaunchKernelGGL(cap300_kernel, CGRID((int64_t)n_cand), 0, st, n_cand, per_cand, per_cand300);
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cstart + n_cand, 8, hipMemcpyDeviceToDevice, st));

@@ -47,10 +47,29 @@ extern "C" void hite_ctx_destroy(hite_ctx *c) {
     hite_align_release(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_scratch2) (void)hipFree(c->d_scratch2);
+    if (c->aux_ev[0]) (void)hipEventDestroy((hipEvent_t)c->aux_ev[0]);
+    if (c->aux_ev[1]) (void)hipEventDestroy((hipEvent_t)c->aux_ev[1]);
+    if (c->aux_stream) (void)hipStreamDestroy((hipStream_t)c->aux_stream);
     free(c);
 }
 
 extern "C" const char *hite_last_error(hite_ctx *c) { return c ? c->err : "null ctx"; }
+
+// the context's second stream (created on first use) with one event to fork it off the caller's stream and one to join it
+int hite_aux_stream(hite_ctx *ctx, hipStream_t *st, hipEvent_t *fork_ev, hipEvent_t *join_ev) {
+    if (!ctx->aux_stream) {
+        hipStream_t s;
+        HITE_CHECK(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        ctx->aux_stream = s;
+        hipEvent_t e0, e1;
+        HITE_CHECK(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
+        ctx->aux_ev[0] = e0;
+        HITE_CHECK(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
+        ctx->aux_ev[1] = e1;
+    }
+    *st = (hipStream_t)ctx->aux_stream; *fork_ev = (hipEvent_t)ctx->aux_ev[0]; *join_ev = (hipEvent_t)ctx->aux_ev[1];
+    return HITE_OK;
+}
 
 int hite_scratch_reserve(hite_ctx *ctx, size_t bytes, void **out) {
     if (bytes > ctx->scratch_bytes) {

@@ -18,12 +18,25 @@
  *   entries with the same hs >> 1 are its occurrences (skipped when more than MAXOCC = 2000);
  *   an occurrence gives a hit: rel = strand_q ^ strand_g, qo = rel ? Lq - qpos - K : qpos,
  *   d = gpos - qo.  Hits are sorted by (candidate, rel, d); a new cluster starts when candidate, rel
- *   or the contig of gpos changes or d jumps by more than TD = 64.  A cluster with >= 3 anchors whose
- *   anchor span (max qo + K - min qo) covers >= 80 % of the candidate AND >= 95 % of the genome span of the same anchors
- *   (get_copies_minimap2's target coverage, Util.py:8008-8020) becomes a copy:
- *   start0 = gpos(min qo) - min qo, end0 = gpos(max qo) + K + (Lq - (max qo + K)), clamped to the
- *   contig (ties: min qo -> smallest gpos, max qo -> largest gpos).  Per candidate the copies are
- *   ordered by (anchors descending (capped at 4095), start ascending) and the first 300 are kept.
+ *   or the contig of gpos changes or d jumps by more than TD = 64.  Extreme anchors of a cluster: (qlo, glo) = the
+ *   smallest qo (ties: smallest gpos), (qhi, ghi) = the largest qo (ties: largest gpos).  A cluster with >= 3 anchors whose
+ *   query span qhi + K - qlo is >= 95 % of its genome span ghi + K - glo is a CHAIN.  A chain is extended base by base from
+ *   its extreme anchors to both ends of the candidate (ext_align below: unit-cost edit distance in a band of +-8 diagonals,
+ *   cut where the score i - 3 cost is largest, abandoned 40 below the best score) -- the stand-in for minimap2's end
+ *   extension and soft clipping.  aligned = Lq - (clipped bases of both ends); the aligned part covers the genome interval
+ *   a0 = glo - (genome bases of the left extension) .. a1 = ghi + K + (genome bases of the right one).  The chain is kept
+ *   when aligned >= 95 % of Lq and aligned >= 95 % of a1 - a0: get_copies_minimap2's two filters,
+ *   query_alignment_length / len(query) >= 0.95 and query_alignment_length / (M + D) >= 0.95 (Util.py:8008-8022).
+ *   DEVIATION, deliberate: the reference reports the aligned interval (reference_start + 1, reference_end); this build hands
+ *   on start0 = a0 - clipped_left, end0 = a1 + clipped_right (clamped to the contig), the interval of the WHOLE candidate.
+ *   With the aligned interval a candidate whose ends overhang the element by more than two bases loses its 20-bp anchors in
+ *   every row but its own (the overhang columns are sparse and removed, judge_boundary_v5 answers 'nb'); with the whole-
+ *   candidate interval the rows keep equal extents and the boundary search walks inwards to the homology boundary: on 300
+ *   candidates with ends perturbed by +-30 bp the oracle chain calls 152 TE (51 with both ends exact) on aligned intervals,
+ *   209 (127) on whole-candidate intervals (round 2's finder, which extrapolated without looking at the bases: 190 (92)).
+ *   (Round 2 accepted "anchor span >= 80 % of the candidate" with extrapolated ends: recall of the planted full-length copies
+ *   0.62 -> 0.84, of those within 15 % of the candidate 0.81 -> 0.94, precision 1.000, on a 20 Mbp / 100 family sample.)
+ *   Per candidate the copies are ordered by (anchors descending (capped at 4095), start ascending) and the first 300 are kept.
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdint.h>
@@ -132,6 +145,67 @@ static int contig_of(const int64_t *coff, int nc, int64_t g) {
  * Output: CSR copy_first[ncand+1] into (contig, start1, end1 (1-based inclusive), minus, anchors).
  * Returns total copies or <0.
  */
+/* ---- end extension ---------------------------------------------------------------------------------------------
+ * Base-level extension of a chain from its outermost anchor to the end of the candidate, where minimap2 extends its chain
+ * by dynamic programming and clips what does not align.  Unit-cost edit distance in a diagonal band of half-width EXT_B:
+ * D[i][j] = cheapest alignment of the first i bases of the query segment (in walking order, away from the anchor) with the
+ * first j genome bases in the same direction, |j - i| <= EXT_B (dir = +1: genome g0, g0 + 1, ...; dir = -1: g0 - 1, g0 - 2, ...);
+ * cells that need genome bases outside [gmin, gmax) are unreachable; two bases match iff equal and one of ACGT.
+ * C(i) = min_j D[i][j].  The extension is CUT where the score S(i) = i - EXT_PEN * C(i) is largest (a matched base +1, an
+ * edit -(EXT_PEN - 1) or -EXT_PEN: with EXT_PEN = 3 the drift changes sign at 33 % divergence, as it does for minimap2's
+ * map-ont scores 2 / -4 / -4-2k); ties: the largest i.  Returns i* = aligned query bases (0 .. n), *t_out = genome bases
+ * used: the j with the smallest D[i*][j], ties |j - i*| smallest, then the smaller j. */
+#define EXT_B 8
+#define EXT_PEN 3
+#define EXT_XDROP 40
+#define EXT_INF 1000000
+static uint8_t comp_of(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
+static int64_t ext_align(const uint8_t *qseg, int64_t n, int dir, const uint8_t *genome, int64_t g0, int64_t gmin, int64_t gmax, int64_t *t_out) {
+    int prev[2 * EXT_B + 1], cur[2 * EXT_B + 1];
+    /* cell (i, j) with j = i + b - EXT_B */
+    for (int b = 0; b <= 2 * EXT_B; b++) {
+        int64_t j = b - EXT_B;
+        int ok = j >= 0 && (dir > 0 ? g0 + j <= gmax : g0 - j >= gmin);
+        prev[b] = ok ? (int)j : EXT_INF;
+    }
+    int64_t best_i = 0, best_t = 0, best_s = 0;     /* i = 0: C = 0 (j = 0), S = 0 */
+    for (int64_t i = 1; i <= n; i++) {
+        uint8_t qc = qseg[i - 1];
+        int cmin = EXT_INF; int64_t tmin = i;
+        for (int b = 0; b <= 2 * EXT_B; b++) {
+            int64_t j = i + b - EXT_B;
+            int v = EXT_INF;
+            if (j >= 0 && (dir > 0 ? g0 + j <= gmax : g0 - j >= gmin)) {
+                if (j >= 1) {
+                    uint8_t gc = dir > 0 ? genome[g0 + j - 1] : genome[g0 - j];
+                    int d = prev[b] + ((qc == gc && code_of(qc) >= 0) ? 0 : 1);
+                    if (d < v) v = d;
+                }
+                if (b + 1 <= 2 * EXT_B && prev[b + 1] + 1 < v) v = prev[b + 1] + 1;     /* query base against a gap */
+                if (b >= 1 && j >= 1 && cur[b - 1] + 1 < v) v = cur[b - 1] + 1;         /* genome base against a gap */
+                if (v > EXT_INF) v = EXT_INF;
+            }
+            cur[b] = v;
+            if (v < EXT_INF) {
+                int64_t dv = j > i ? j - i : i - j, db = tmin > i ? tmin - i : i - tmin;
+                if (v < cmin || (v == cmin && (dv < db || (dv == db && j < tmin)))) { cmin = v; tmin = j; }
+            }
+        }
+        memcpy(prev, cur, sizeof prev);
+        if (cmin >= EXT_INF) break;                 /* the band left the contig: nothing further is reachable */
+        int64_t sc = i - (int64_t)EXT_PEN * cmin;
+        if (sc >= best_s) { best_s = sc; best_i = i; best_t = tmin; }
+        else if (sc < best_s - EXT_XDROP) break;
+    }
+    *t_out = best_t;
+    return best_i;
+}
+
+/* ext_align for the tests (tests/test_host_compiled.py: the HIP device function compiled for the host against this one) */
+int64_t orc_ext_align(const uint8_t *qseg, int64_t n, int dir, const uint8_t *genome, int64_t g0, int64_t gmin, int64_t gmax, int64_t *t_out) {
+    return ext_align(qseg, n, dir, genome, g0, gmin, gmax, t_out);
+}
+
 /* seconds the last orc_find_copies call spent building its index (bench.py separates residency set-up from the lookups) */
 static double g_index_seconds = 0.0;
 double orc_find_copies_index_seconds(void) { return g_index_seconds; }
@@ -200,15 +274,34 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
             if (hits[t].qo > qhi || (hits[t].qo == qhi && hits[t].gpos > ghi)) { qhi = hits[t].qo; ghi = hits[t].gpos; }
         }
         int64_t na = j - i;
-        /* acceptance (the reference keeps a minimap2 alignment with query coverage >= 0.95 and aligned query / (M + D) >= 0.95,
-         * Util.py:7977-8030): the anchors span >= 80 % of the candidate (anchors do not reach the ends the way a base-level
-         * extension does), and the candidate span they cover is >= 95 % of the genome span they cover */
-        if (na >= MINANCH && (qhi + CK - qlo) * 100 >= 80 * Lq && (qhi + CK - qlo) * 100 >= 95 * (ghi + CK - glo)) {
-            int64_t s0 = glo - qlo, e0 = ghi + CK + (Lq - (qhi + CK));
+        /* acceptance.  The reference keeps a minimap2 alignment when query_alignment_length / len(query) >= 0.95 and
+         * query_alignment_length / (M + D) >= 0.95 (get_copies_minimap2, Util.py:8008-8022).  Here a chain of >= 3 anchors whose
+         * query span is >= 95 % of its genome span is extended base by base from its outermost anchors to both ends of the
+         * candidate (ext_align); what the extension cuts off is clipped, as minimap2 soft-clips it.  aligned = Lq - clipped;
+         * the copy is the genome interval of the aligned part, kept when aligned >= 95 % of Lq and aligned >= 95 % of that interval. */
+        if (na >= MINANCH && (qhi + CK - qlo) * 100 >= 95 * (ghi + CK - glo)) {
             int64_t cb = contig_off[ctg], ce = contig_off[ctg + 1];
-            if (s0 < cb) s0 = cb;
-            if (e0 > ce) e0 = ce;
-            if (e0 > s0) {
+            const uint8_t *q = cand + cand_off[hits[i].c];
+            int rel = hits[i].rel;
+            int64_t nl = qlo, nr = Lq - (qhi + CK);
+            uint8_t *seg = (uint8_t *)malloc((size_t)(nl > nr ? nl : nr) + 1);
+            /* query in the orientation of the genome: rel = 1 reads the reverse complement of the candidate */
+#define QAT(x) (rel ? comp_of(q[Lq - 1 - (x)]) : q[(x)])
+            for (int64_t x = 0; x < nl; x++) seg[x] = QAT(qlo - 1 - x);
+            int64_t tl = 0, tr = 0;
+            int64_t il = ext_align(seg, nl, -1, genome, glo, cb, ce, &tl);
+            for (int64_t x = 0; x < nr; x++) seg[x] = QAT(qhi + CK + x);
+            int64_t ir = ext_align(seg, nr, +1, genome, ghi + CK, cb, ce, &tr);
+            free(seg);
+            int64_t clip_l = nl - il, clip_r = nr - ir;
+            int64_t aligned = Lq - clip_l - clip_r;
+            int64_t a0 = glo - tl, a1 = ghi + CK + tr;                 /* genome interval of the aligned part */
+            if (a1 > a0 && aligned * 100 >= 95 * Lq && aligned * 100 >= 95 * (a1 - a0)) {
+                /* the interval handed on covers the whole candidate: the clipped ends (<= 5 % of it) lie on the diagonal of the last
+                 * aligned base, clamped to the contig */
+                int64_t s0 = a0 - clip_l, e0 = a1 + clip_r;
+                if (s0 < cb) s0 = cb;
+                if (e0 > ce) e0 = ce;
                 if (ncp == ccap) { ccap *= 2; cps = (copy_t *)realloc(cps, sizeof(copy_t) * ccap); }
                 cps[ncp].c = hits[i].c; cps[ncp].contig = ctg; cps[ncp].minus = hits[i].rel; cps[ncp].anch = (int32_t)na;
                 cps[ncp].start1 = s0 - cb + 1; cps[ncp].end1 = e0 - cb; cps[ncp].gstart = s0;

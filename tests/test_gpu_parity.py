@@ -130,6 +130,38 @@ def test_judge_golden(ctx, name, te_type):
                 assert [g[0], g[1], g[2], g[3]] == exp, (i, g, exp)
 
 
+@pytest.mark.parametrize("mode", ["block_only", "wave_rows_32", "wave_wide"])
+@pytest.mark.parametrize("name,te_type", [("judge_tir", "tir"), ("judge_non_ltr", "non_ltr"), ("judge_helitron", "helitron")])
+def test_judge_golden_kernel_forms(ctx, name, te_type, mode, monkeypatch):
+    """the two judge kernels (one wavefront per alignment / one workgroup per alignment) give the same calls: every golden
+    through the workgroup kernel only, through the wave kernel with the row limit at 32 (the 64-row mask path stays in the
+    workgroup kernel), and with the column limit lifted (anchor text of wide alignments in global scratch)"""
+    env = {"block_only": {"HITE_JUDGE_WAVE_COLS": "0"}, "wave_rows_32": {"HITE_JUDGE_WAVE_ROWS": "32"},
+           "wave_wide": {"HITE_JUDGE_WAVE_COLS": "60000", "HITE_JUDGE_OVERLAP": "0"}}[mode]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cases = load_golden(name)
+    if mode == "wave_wide":   # a wide alignment with few rows: above the LDS anchor limit of the wave kernel (2544 columns)
+        c = casegen.make_msa_case(seed=4242, te_type=te_type, rows=9, te_len=3300, div=0.04, ins_cols=4, trunc_rows=1, tsd_len=8, tsd_frac=1.0)
+        m = O.msa_array(c["seqs"])
+        keep = O.sparse_cols(m).astype(bool)
+        mc = np.ascontiguousarray(m[:, keep])
+        exp, _ = O.judge(te_type, mc, c["cand"], 1)
+        g = ctx.judge(te_type, [mc], [c["cand"]], plant=1)[0]
+        assert [g[0], g[1], g[2], g[3]] == exp and mc.shape[1] > 2544
+    for plant in (0, 1):
+        sub = [c for c in cases if c["plant"] == plant]
+        if not sub:
+            continue
+        got = ctx.judge(te_type, _msas(sub, "clean"), [c["cand"] for c in sub], plant=plant)
+        for i, (c, g) in enumerate(zip(sub, got)):
+            exp = c["expected"]
+            if exp[0] == "EXC":
+                assert g[1] == "EXC", (i, g, exp)
+            else:
+                assert [g[0], g[1], g[2], g[3]] == exp, (i, g, exp)
+
+
 @pytest.mark.parametrize("te_type", ["tir", "non_ltr", "helitron"])
 def test_judge_random_vs_oracle(ctx, te_type):
     """fresh seeds, sparse-col removal + judge chained on the GPU, compared with the oracle chain"""

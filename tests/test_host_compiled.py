@@ -1,0 +1,127 @@
+"""Device functions of the HIP sources that are plain integer code are compiled for the HOST (g++) straight from the .hip file
+and compared with the CPU twins on random inputs -- a CPU-side check of the kernel logic itself (no GPU needed; the GPU
+parity tests then cover launch geometry and memory layout).  Blocks are cut out between `// >>> name` and `// <<< name`."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import oracle_lib as O  # noqa: E402
+
+PRELUDE = r"""
+#include <stdint.h>
+#include <algorithm>
+#define __device__
+#define __forceinline__ inline
+#define __restrict__
+using std::min;
+using std::max;
+"""
+
+
+def _block(path, name):
+    src = open(path).read()
+    m = re.search(r"// >>> %s.*?\n(.*?)// <<< %s" % (name, name), src, re.S)
+    assert m, name
+    return m.group(1)
+
+
+def _build(tmp_path, name, body, wrapper):
+    cpp = tmp_path / (name + ".cpp")
+    so = tmp_path / (name + ".so")
+    cpp.write_text(PRELUDE + body + wrapper)
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", str(so), str(cpp)], check=True)
+    return C.CDLL(str(so))
+
+
+def test_ext_align_device_function_vs_twin(tmp_path):
+    """chain end extension (hite_copies.hip:ext_align_dev) == oracle/hite_oracle_copies.c:ext_align: aligned bases and genome
+    bases used, both directions, both strands, contig borders inside the band, N bases, unrelated sequence (x-drop)"""
+    body = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_copies.hip"), "ext_align_dev")
+    lib = _build(tmp_path, "ext", body, r"""
+extern "C" void host_ext(const uint8_t *q, int64_t p0, int step, int comp, int n, const uint32_t *bases, const uint32_t *nmask,
+                         int64_t g0, int dir, int64_t jmax, int *i_out, int *t_out) {
+    ext_align_dev(q, p0, step, comp != 0, n, bases, nmask, g0, dir, jmax, i_out, t_out);
+}
+""")
+    L = O.lib()
+    L.orc_ext_align.restype = C.c_int64
+    rng = np.random.default_rng(7)
+    comp = {65: 84, 67: 71, 71: 67, 84: 65}
+    n_cases = n_cut = n_full = 0
+    for case in range(400):
+        G = int(rng.integers(80, 900))
+        genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=G)
+        if case % 7 == 0:
+            genome[rng.integers(0, G, size=3)] = ord("N")
+        # packed form the kernels read (16 bases per word + 1-bit mask), with slack words
+        codes = np.zeros(G + 64, np.uint32)
+        lut = np.full(256, 0, np.uint32)
+        lut[[65, 67, 71, 84]] = [0, 1, 2, 3]
+        codes[:G] = lut[genome]
+        bases = np.zeros((G + 64) // 16 + 2, np.uint32)
+        for k in range(16):
+            part = codes[k::16]
+            bases[:len(part)] |= part << np.uint32(2 * k)
+        nm = np.zeros((G + 64) // 32 + 2, np.uint32)
+        isn = np.zeros(G + 64, np.uint32)
+        isn[:G] = (genome == ord("N"))
+        for k in range(32):
+            part = isn[k::32]
+            nm[:len(part)] |= part << np.uint32(k)
+        d = +1 if case % 2 == 0 else -1
+        n = int(rng.integers(0, min(G - 20, 400)))
+        g0 = int(rng.integers(10, G - 10))
+        gmin, gmax = (0, G) if case % 5 else (int(rng.integers(0, g0 + 1)), int(rng.integers(g0, G + 1)))
+        # query segment in walking order: a diverged copy of the genome it walks over for `hom` bases, then unrelated bases
+        hom = int(rng.integers(0, n + 1)) if case % 3 else n
+        walk = genome[g0:g0 + n + 40] if d > 0 else genome[max(0, g0 - n - 40):g0][::-1]
+        seg = []
+        wi = 0
+        div = float(rng.choice([0.0, 0.05, 0.15, 0.3]))
+        while len(seg) < hom and wi < len(walk):
+            x = rng.random()
+            if x < div * 0.1:
+                wi += 1
+                continue
+            if x < div * 0.2:
+                seg.append(int(rng.choice([65, 67, 71, 84])))
+                continue
+            b = int(walk[wi])
+            wi += 1
+            if rng.random() < div:
+                b = int(rng.choice([65, 67, 71, 84]))
+            seg.append(b)
+        while len(seg) < n:
+            seg.append(int(rng.choice([65, 67, 71, 84, 78] if case % 11 == 0 else [65, 67, 71, 84])))
+        seg = np.array(seg[:n], np.uint8)
+        t_ref = C.c_int64(0)
+        gbuf = np.ascontiguousarray(genome)
+        i_ref = L.orc_ext_align(seg.ctypes.data_as(O.u8p), C.c_int64(n), d, gbuf.ctypes.data_as(O.u8p), C.c_int64(g0), C.c_int64(gmin),
+                                C.c_int64(gmax), C.byref(t_ref))
+        # the kernel reads the candidate itself: forward (step +1 / -1) or as reverse complement (comp): lay the segment out so
+        strand = case % 4 >= 2
+        step = +1 if (case // 2) % 2 == 0 else -1
+        stored = np.array([comp.get(int(b), 78) for b in seg], np.uint8) if strand else seg.copy()
+        q = np.zeros(n + 8, np.uint8)
+        if step > 0:
+            q[4:4 + n] = stored
+            p0 = 4
+        else:
+            q[4:4 + n] = stored[::-1]
+            p0 = 4 + n - 1
+        jmax = (gmax - g0) if d > 0 else (g0 - gmin)
+        io, to = C.c_int(0), C.c_int(0)
+        lib.host_ext(q.ctypes.data_as(O.u8p), C.c_int64(p0), step, int(strand), n, bases.ctypes.data_as(C.POINTER(C.c_uint32)),
+                     nm.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(g0), d, C.c_int64(jmax), C.byref(io), C.byref(to))
+        assert (io.value, to.value) == (int(i_ref), int(t_ref.value)), (case, n, hom, d, g0, gmin, gmax, io.value, to.value, i_ref, t_ref.value)
+        n_cases += 1
+        n_cut += 0 < i_ref < n
+        n_full += i_ref == n and n > 0
+    assert n_cases == 400 and n_cut > 40 and n_full > 40
