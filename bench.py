@@ -318,7 +318,7 @@ def main():
                                     if args.copies == "found" else "copy table = generator truth; copy finding not in the timed path"),
                        "genome_bp": G, "candidates_per_gpu": n_cand, "candidate_bases": b1 - b0, "copies": int(state["n_copies"]),
                        "copy_table": args.copies, "rows_aligned_per_step": rows,
-                       "pipeline_stats": [int(x) for x in stats], "copy_stats": [int(x) for x in ctx.copy_stats()] if args.copies == "found" else None,
+                       "pipeline_stats": [int(x) for x in stats], "copy_stats": [int(x) for x in ctx.copy_stats_ext()] if args.copies == "found" else None,
                        "align_stats_per_step": {k_: int(v_) for k_, v_ in per_step.items()},
                        "is_te": n_te_all, "parallelism": "replicated genome, candidates %s x%d, all-gather of 32-B calls" %
                                                         ("sharded" if strong else "per rank", world),

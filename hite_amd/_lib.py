@@ -618,6 +618,12 @@ class Context:
         self._check(self.lib.hite_copy_stats(self._copy_state, out), "hite_copy_stats")
         return tuple(int(x) for x in out)
 
+    def copy_stats_ext(self):
+        """copy_stats() + (chains with a long end to extend, the other chains, DP columns of the end extension, 0)"""
+        out = (C.c_int64 * 8)()
+        self._check(self.lib.hite_copy_stats_ext(self._copy_state, out), "hite_copy_stats_ext")
+        return tuple(int(x) for x in out)
+
     def download(self, d_ptr, count, dtype):
         """numpy copy of `count` elements of `dtype` at raw device pointer d_ptr"""
         out = np.zeros(int(count), dtype=dtype)

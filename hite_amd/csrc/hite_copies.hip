@@ -37,7 +37,7 @@ struct CopyState {
     Arena out;        // copy table handed to the caller (valid until the next call)
     int64_t *h_pin = nullptr;
     int64_t *d_scal = nullptr;
-    int64_t last[4] = {0, 0, 0, 0};   // last call: candidate minimizers, hits, clusters, copies (before the 300 cap)
+    int64_t last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last call: candidate minimizers, hits, clusters, copies (before the 300 cap); chains with a long / short end to extend, extension columns
 };
 
 __device__ __forceinline__ unsigned lowbias32(unsigned x) {
@@ -424,27 +424,49 @@ __global__ void cluster_acc_init_kernel(int64_t ncl, unsigned long long *__restr
 // Chains with a long end to extend (>= EXT_LONG bases) are listed from the front, the others from the back of the same array:
 // the extension takes its tasks front to back, so the long chains -- the tail of the kernel otherwise -- start first.
 #define EXT_LONG 384
+#define EXT_MAXLEN 2048     // an end of more than this many bases beyond the outermost anchor is not extended: no chain
+#define CL_ITEMS 16         // clusters per thread: ONE pair of atomics on the two list counters per 4096 clusters (one per wavefront
+                            // was a million same-address atomics: 10 ms)
 __global__ void __launch_bounds__(256) chain_list_kernel(int64_t ncl, const unsigned long long *__restrict__ hkey, HitFmt F,
                                                          const unsigned *__restrict__ c_first, const unsigned long long *__restrict__ c_lo,
                                                          const unsigned long long *__restrict__ c_hi, const int64_t *__restrict__ cand_off,
                                                          unsigned *__restrict__ list, unsigned long long cap,
                                                          unsigned long long *__restrict__ counters /* [0] long, [1] short */) {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool want = false, lng = false;
-    if (k < ncl && (int)(c_first[k + 1] - c_first[k]) >= C_MINANCH) {
-        const long long qlo = (long long)(c_lo[k] >> 32), glo = (long long)(c_lo[k] & 0xffffffffull);
-        const long long qhi = (long long)(c_hi[k] >> 32), ghi = (long long)(c_hi[k] & 0xffffffffull);
-        want = (qhi + CK - qlo) * 100 >= 95 * (ghi + CK - glo);
-        if (want) {
-            const unsigned c = hit_cand(F, hkey[c_first[k]]);
-            const long long Lq = cand_off[c + 1] - cand_off[c];
-            lng = qlo >= EXT_LONG || Lq - (qhi + CK) >= EXT_LONG;
+    __shared__ int s_scan[8];
+    __shared__ unsigned long long s_base[2];
+    for (int64_t tile = (int64_t)blockIdx.x * 256 * CL_ITEMS; tile < ncl; tile += (int64_t)gridDim.x * 256 * CL_ITEMS) {
+        unsigned wantL = 0u, wantS = 0u;
+#pragma unroll 4
+        for (int it = 0; it < CL_ITEMS; it++) {
+            const int64_t k = tile + it * 256 + threadIdx.x;
+            if (k < ncl && (int)(c_first[k + 1] - c_first[k]) >= C_MINANCH) {
+                const long long qlo = (long long)(c_lo[k] >> 32), glo = (long long)(c_lo[k] & 0xffffffffull);
+                const long long qhi = (long long)(c_hi[k] >> 32), ghi = (long long)(c_hi[k] & 0xffffffffull);
+                if ((qhi + CK - qlo) * 100 >= 95 * (ghi + CK - glo)) {
+                    const unsigned c = hit_cand(F, hkey[c_first[k]]);
+                    const long long Lq = cand_off[c + 1] - cand_off[c];
+                    const long long nl = qlo, nr = Lq - (qhi + CK);
+                    if (nl <= EXT_MAXLEN && nr <= EXT_MAXLEN) {
+                        if (nl >= EXT_LONG || nr >= EXT_LONG) wantL |= 1u << it; else wantS |= 1u << it;
+                    }
+                }
+            }
         }
+        int tot;
+        const int pre = block_excl_scan(__popc(wantL) | (__popc(wantS) << 16), s_scan, &tot);
+        if (threadIdx.x == 0) {
+            s_base[0] = (tot & 0xffff) ? atomicAdd(&counters[0], (unsigned long long)(tot & 0xffff)) : 0ull;
+            s_base[1] = (tot >> 16) ? atomicAdd(&counters[1], (unsigned long long)(tot >> 16)) : 0ull;
+        }
+        __syncthreads();
+        unsigned long long oL = s_base[0] + (unsigned long long)(pre & 0xffff), oS = s_base[1] + (unsigned long long)(pre >> 16);
+        for (int it = 0; it < CL_ITEMS; it++) {
+            const unsigned k = (unsigned)(tile + it * 256 + threadIdx.x);
+            if ((wantL >> it) & 1u) { if (oL < cap) list[oL] = k; oL++; }
+            if ((wantS >> it) & 1u) { if (oS < cap) list[cap - 1 - oS] = k; oS++; }
+        }
+        __syncthreads();
     }
-    const unsigned long long sa = wave_append(want && lng, &counters[0]);
-    const unsigned long long sb = wave_append(want && !lng, &counters[1]);
-    if (want && lng && sa < cap) list[sa] = (unsigned)k;
-    if (want && !lng && sb < cap) list[cap - 1 - sb] = (unsigned)k;
 }
 // chain number e (long ones first) -> cluster id
 __device__ __forceinline__ unsigned chain_at(const unsigned *__restrict__ list, unsigned long long cap, unsigned long long n_long, unsigned long long e) {
@@ -457,11 +479,6 @@ __device__ __forceinline__ unsigned chain_at(const unsigned *__restrict__ list, 
 #define EXT_PEN 3
 #define EXT_XDROP 40
 #define EXT_INF (1 << 20)
-// code of genome base g: 0..3, 4 = not A/C/G/T
-__device__ __forceinline__ unsigned ext_genome_code(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g) {
-    const unsigned c = (bases[g >> 4] >> (2 * (int)(g & 15))) & 3u;
-    return ((nmask[g >> 5] >> (int)(g & 31)) & 1u) ? 4u : c;
-}
 __device__ __forceinline__ unsigned ext_cand_code(unsigned ch, bool comp) {
     const unsigned c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
     return (comp && c < 4u) ? 3u - c : c;
@@ -469,64 +486,106 @@ __device__ __forceinline__ unsigned ext_cand_code(unsigned ch, bool comp) {
 // ext_align of the twin as a state machine: query bases q[p0], q[p0 + step], ... (n of them; complemented when comp), genome
 // bases g0, g0 + 1, ... (dir = +1) or g0 - 1, g0 - 2, ... (dir = -1), at most jmax of them.  The 17 band cells live in
 // registers (the loops over the band are unrolled), the genome bases under the band as three 17-bit planes that shift by one
-// cell per column: a column costs one new genome base, one query base and ~8 integer operations per cell.
+// cell per column: a column costs one new genome base, one query base and ~8 integer operations per cell.  Both sequences
+// are walked one base per column, so the words they come from are kept in registers -- 16 genome bases, 32 mask bits, 4 query
+// bytes per load, each fetched one word ahead of its use (a load per base and column made the kernel a gather benchmark).
 struct ExtState {
     int D[EXT_W];
     uint32_t W0, W1, WN;
     int i, n, best_i, best_t, best_s;
-    unsigned gnext, qnext;
-    const uint8_t *q;
+    unsigned gnext_, qnext_;                // codes of the next column
+    uint32_t gw, gwn, mw, mwn, qw, qwn;     // current / next word of genome bases, mask bits, query bytes
+    int64_t gwi, mwi, qwi;                   // their word indices
+    const uint32_t *q4;                      // the candidate bytes as aligned words (base address rounded down)
     int64_t p0, g0, jmax;
     int step, dir;
     bool comp;
 };
+// code of genome base g (0..3, 4 = not A/C/G/T); g moves by one base per call in direction E.dir
+__device__ __forceinline__ unsigned ext_genome_next(ExtState &E, const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g) {
+    const int64_t wi = g >> 4, mi = g >> 5;
+    if (wi != E.gwi) { E.gw = E.gwn; E.gwi = wi; const int64_t nx = wi + E.dir; E.gwn = bases[nx > 0 ? nx : 0]; }
+    if (mi != E.mwi) { E.mw = E.mwn; E.mwi = mi; const int64_t nx = mi + E.dir; E.mwn = nmask[nx > 0 ? nx : 0]; }
+    const unsigned c = (E.gw >> (2 * (int)(g & 15))) & 3u;
+    return ((E.mw >> (int)(g & 31)) & 1u) ? 4u : c;
+}
+// code of query byte at byte address a (relative to q4); a moves by E.step per call
+__device__ __forceinline__ unsigned ext_query_next(ExtState &E, int64_t a) {
+    const int64_t wi = a >> 2;
+    if (wi != E.qwi) { E.qw = E.qwn; E.qwi = wi; const int64_t nx = wi + E.step; E.qwn = E.q4[nx > 0 ? nx : 0]; }
+    return ext_cand_code((E.qw >> (8 * (int)(a & 3))) & 0xffu, E.comp);
+}
 __device__ __forceinline__ void ext_init(ExtState &E, const uint8_t *__restrict__ q, int64_t p0, int step, bool comp, int n,
                                          const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g0, int dir, int64_t jmax) {
-    E.q = q; E.p0 = p0; E.step = step; E.comp = comp; E.n = n; E.g0 = g0; E.dir = dir; E.jmax = jmax;
+    const uintptr_t qa = (uintptr_t)q;
+    E.q4 = (const uint32_t *)(qa & ~(uintptr_t)3);
+    E.p0 = p0 + (int64_t)(qa & 3);           // byte offset of the first query base from q4
+    E.step = step; E.comp = comp; E.n = n; E.g0 = g0; E.dir = dir; E.jmax = jmax;
 #pragma unroll
     for (int b = 0; b < EXT_W; b++) { const int j = b - EXT_B; E.D[b] = (j >= 0 && j <= jmax) ? j : EXT_INF; }
-    // planes of "column 0": bit b = genome base number j = b - EXT_B (1-based in walking order); bit set in WN = never matches
+    E.best_i = 0; E.best_t = 0; E.best_s = 0; E.i = 1;
     E.W0 = 0u; E.W1 = 0u; E.WN = (1u << EXT_W) - 1u;
+    E.gnext_ = 4u; E.qnext_ = 4u;
+    if (n < 1) return;
+    // word caches: the first genome base read is number 1 (g0 or g0 - 1), the first query byte p0
+    {
+        const int64_t g = dir > 0 ? g0 : g0 - 1;
+        const int64_t gs = g > 0 ? g : 0;
+        E.gwi = gs >> 4; E.gw = bases[E.gwi]; { const int64_t nx = E.gwi + dir; E.gwn = bases[nx > 0 ? nx : 0]; }
+        E.mwi = gs >> 5; E.mw = nmask[E.mwi]; { const int64_t nx = E.mwi + dir; E.mwn = nmask[nx > 0 ? nx : 0]; }
+        E.qwi = E.p0 >> 2; E.qw = E.q4[E.qwi]; { const int64_t nx = E.qwi + step; E.qwn = E.q4[nx > 0 ? nx : 0]; }
+    }
+    // planes of "column 0": bit b = genome base number j = b - EXT_B (1-based in walking order); bit set in WN = never matches
 #pragma unroll
     for (int j = 1; j <= EXT_B; j++) {
         if (j <= jmax) {
-            const unsigned cd = ext_genome_code(bases, nmask, dir > 0 ? g0 + j - 1 : g0 - j);
+            const unsigned cd = ext_genome_next(E, bases, nmask, dir > 0 ? g0 + j - 1 : g0 - j);
             E.W0 |= (cd & 1u) << (j + EXT_B); E.W1 |= ((cd >> 1) & 1u) << (j + EXT_B); E.WN &= ~((~(cd >> 2) & 1u) << (j + EXT_B));
         }
     }
-    E.best_i = 0; E.best_t = 0; E.best_s = 0; E.i = 1;
-    E.gnext = 4u; E.qnext = 4u;
-    if (n >= 1) {
-        if (1 + EXT_B <= jmax) E.gnext = ext_genome_code(bases, nmask, dir > 0 ? g0 + EXT_B : g0 - 1 - EXT_B);
-        E.qnext = ext_cand_code(q[p0], comp);
-    }
+    if (1 + EXT_B <= jmax) E.gnext_ = ext_genome_next(E, bases, nmask, dir > 0 ? g0 + EXT_B : g0 - 1 - EXT_B);
+    E.qnext_ = ext_query_next(E, E.p0);
 }
 // one column (E.i <= E.n on entry); returns true when the extension is finished (result in best_i / best_t)
 __device__ __forceinline__ bool ext_step(ExtState &E, const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask) {
     const int i = E.i;
-    const unsigned gc = E.gnext, qc = E.qnext;
-    if (i < E.n) {    // what column i + 1 needs, fetched a column ahead
+    const unsigned gc = E.gnext_, qc = E.qnext_;
+    if (i < E.n) {    // the bases of column i + 1
         const int64_t j = (int64_t)i + 1 + EXT_B;
-        E.gnext = j <= E.jmax ? ext_genome_code(bases, nmask, E.dir > 0 ? E.g0 + j - 1 : E.g0 - j) : 4u;
-        E.qnext = ext_cand_code(E.q[E.p0 + (int64_t)E.step * i], E.comp);
+        E.gnext_ = j <= E.jmax ? ext_genome_next(E, bases, nmask, E.dir > 0 ? E.g0 + j - 1 : E.g0 - j) : 4u;
+        E.qnext_ = ext_query_next(E, E.p0 + (int64_t)E.step * i);
     }
     E.W0 = (E.W0 >> 1) | ((gc & 1u) << (EXT_W - 1)); E.W1 = (E.W1 >> 1) | (((gc >> 1) & 1u) << (EXT_W - 1)); E.WN = (E.WN >> 1) | ((gc >> 2) << (EXT_W - 1));
     const uint32_t eq = qc < 4u ? (~(E.W0 ^ (0u - (qc & 1u))) & ~(E.W1 ^ (0u - ((qc >> 1) & 1u))) & ~E.WN) : 0u;
-    const int lo = EXT_B - i;                                   // cells with j >= 0
+    // cells with j < 0 need no guard: they start at EXT_INF and every move into them comes from such a cell.  Cells with
+    // j > jmax (beyond the contig) are forced to EXT_INF -- only the rare extension that can reach the contig end pays for it
     const int64_t hi64 = E.jmax - i + EXT_B;                    // cells with j <= jmax
-    const int hi = hi64 > EXT_W ? EXT_W : (int)hi64;
     int left = EXT_INF, kmin = 0x7fffffff;
+    if (hi64 >= EXT_W - 1) {
 #pragma unroll
-    for (int b = 0; b < EXT_W; b++) {
-        const int diag = E.D[b] + (int)(((eq >> b) & 1u) ^ 1u);
-        const int up = b + 1 < EXT_W ? E.D[b + 1] + 1 : EXT_INF;
-        int v = min(min(diag, up), left + 1);
-        v = (b >= lo && b <= hi) ? v : EXT_INF;
-        E.D[b] = v;
-        left = v;
-        const int tc = 2 * (b > EXT_B ? b - EXT_B : EXT_B - b) + (b > EXT_B ? 1 : 0);   // ties: |j - i| smallest, then the smaller j
-        const int key = (v << 5) | tc;
-        kmin = key < kmin ? key : kmin;
+        for (int b = 0; b < EXT_W; b++) {
+            // min(diag, up, left + 1) = 1 + min(D[b] - match, D[b + 1], left)
+            const int dm = E.D[b] - (int)((eq >> b) & 1u);
+            const int v = 1 + min(min(dm, b + 1 < EXT_W ? E.D[b + 1] : EXT_INF), left);
+            E.D[b] = v;
+            left = v;
+            const int tc = 2 * (b > EXT_B ? b - EXT_B : EXT_B - b) + (b > EXT_B ? 1 : 0);   // ties: |j - i| smallest, then the smaller j
+            const int key = (v << 5) | tc;
+            kmin = key < kmin ? key : kmin;
+        }
+    } else {
+        const int hi = (int)hi64;
+#pragma unroll
+        for (int b = 0; b < EXT_W; b++) {
+            const int dm = E.D[b] - (int)((eq >> b) & 1u);
+            int v = 1 + min(min(dm, b + 1 < EXT_W ? E.D[b + 1] : EXT_INF), left);
+            v = b <= hi ? v : EXT_INF;
+            E.D[b] = v;
+            left = v;
+            const int tc = 2 * (b > EXT_B ? b - EXT_B : EXT_B - b) + (b > EXT_B ? 1 : 0);
+            const int key = (v << 5) | tc;
+            kmin = key < kmin ? key : kmin;
+        }
     }
     const int cmin = kmin >> 5;
     if (cmin >= EXT_INF) return true;
@@ -567,7 +626,7 @@ __global__ void __launch_bounds__(256) chain_extend_kernel(const unsigned long l
     ExtState E;
     E.n = 0; E.i = 1;
     bool active = false, exhausted = false;
-    unsigned long long my = 0;
+    unsigned long long my = 0, cols_done = 0;
     for (;;) {
         const unsigned long long idle = __ballot(!active);
         if (!exhausted && (idle == ~0ull || __popcll(idle) >= 16)) {
@@ -601,8 +660,15 @@ __global__ void __launch_bounds__(256) chain_extend_kernel(const unsigned long l
             }
         }
         if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
-        if (active && ext_step(E, bases, nmask)) { x_i[my] = E.best_i; x_t[my] = E.best_t; active = false; }
+        if (active) {
+            cols_done++;
+            if (ext_step(E, bases, nmask)) { x_i[my] = E.best_i; x_t[my] = E.best_t; active = false; }
+        }
     }
+    // statistics: DP columns computed (one atomic per wavefront)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) cols_done += ((unsigned long long)(unsigned)__shfl_xor((int)(cols_done >> 32), d) << 32) | (unsigned)__shfl_xor((int)cols_done, d);
+    if (lane == 0 && cols_done) atomicAdd(queue + 1, cols_done);
 }
 
 // accepted chains -> copy records + sort key (candidate:19 | 4095-anchors:12 | start:32 | minus:1).  Two passes:
@@ -831,7 +897,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
         nq = S->h_pin[0];
         max_cand_len = S->h_pin[1];
         if ((unsigned long long)nq > qcap) return HITE_ECAP;
-        S->last[0] = nq; S->last[1] = S->last[2] = S->last[3] = 0;
+        S->last[0] = nq; S->last[1] = S->last[2] = S->last[3] = S->last[4] = S->last[5] = S->last[6] = 0;
         hipLaunchKernelGGL(cand_minimizer_pack_kernel, dim3((n_cand + 3) / 4 < 8192 ? (n_cand + 3) / 4 : 8192), dim3(256), 0, st, n_cand,
                            d_cand_off, r_pos, r_hs, q_first, q_c, q_pos, q_hs);
         hite_prof_end(ctx, tk_cm, st);
@@ -914,7 +980,12 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
     unsigned long long *d_nchain = (unsigned long long *)(S->d_scal + 4);     // [0] long chains, [1] short chains, [2] task queue
     int tk_ext = hite_prof_begin(ctx, "chain_extend_kernel", st);
-    hipLaunchKernelGGL(chain_list_kernel, CGRID(ncl), 0, st, ncl, hkey, F, c_first, c_lo, c_hi, d_cand_off, chain_list, chcap, d_nchain);
+    {
+        int64_t lblocks = (ncl + 256 * CL_ITEMS - 1) / (256 * CL_ITEMS);
+        if (lblocks > 16384) lblocks = 16384;
+        if (lblocks < 1) lblocks = 1;
+        hipLaunchKernelGGL(chain_list_kernel, dim3((unsigned)lblocks), dim3(256), 0, st, ncl, hkey, F, c_first, c_lo, c_hi, d_cand_off, chain_list, chcap, d_nchain);
+    }
     {
         // persistent lanes: every lane takes (chain, end) tasks from the queue until it is empty
         unsigned long long want_blocks = (2ull * chcap + 255ull) / 256ull;
@@ -961,8 +1032,9 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cstart + n_cand, 8, hipMemcpyDeviceToDevice, st));
     CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand300, n_cand, ofirst, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + 1, ofirst + n_cand, 8, hipMemcpyDeviceToDevice, st));
-    CCHK(read_back(ctx, S, st, 2));
+    CCHK(read_back(ctx, S, st, 8));
     const int64_t ncp = S->h_pin[0], nout = S->h_pin[1];
+    S->last[4] = S->h_pin[4]; S->last[5] = S->h_pin[5]; S->last[6] = S->h_pin[7];
     *n_copies = nout;
     S->last[3] = ncp;
     hipLaunchKernelGGL(i64_to_i32_kernel, CGRID((int64_t)n_cand + 1), 0, st, (int64_t)n_cand + 1, ofirst, ofirst32);
@@ -1034,6 +1106,13 @@ extern "C" int hite_copy_stats(void *state, int64_t out[4]) {
     CopyState *S = (CopyState *)state;
     if (!S || !out) return HITE_EINVAL;
     for (int i = 0; i < 4; i++) out[i] = S->last[i];
+    return HITE_OK;
+}
+// + {chains with an end of >= 384 bases to extend, the other chains, dynamic-programming columns of the end extension, 0}
+extern "C" int hite_copy_stats_ext(void *state, int64_t out[8]) {
+    CopyState *S = (CopyState *)state;
+    if (!S || !out) return HITE_EINVAL;
+    for (int i = 0; i < 8; i++) out[i] = S->last[i];
     return HITE_OK;
 }
 

