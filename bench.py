@@ -30,26 +30,38 @@ sys.path.insert(0, ROOT)
 
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 CONFIGS = {
-    # name: (genome Mbp, TIR families per Mbp, LTR families per Mbp)  -- BASELINE.json configs[1] / configs[2]
+    # name: (genome Mbp, TIR families per Mbp, LTR families per Mbp)  -- BASELINE.json configs[1] / configs[2] / configs[4]
     "C2": (100, 5.0, 0.0),
     "C3": (1000, 2.5, 2.5),
+    "C5": (300, 2.5, 2.5),     # panHiTE: one 300 Mbp genome per GPU, 70 % of the families shared, libraries merged (c5_mode)
 }
 
 
 def valu_peak():
-    """wave64 issue rate of the instruction classes the alignment kernels are made of, MEASURED on MI355X by
-    tools/valu_issue_bench.hip (profiles/r02_valu_issue.txt): bit-field / 3-operand / carry / DPP instructions issue
-    every ~4.1 cycles per SIMD, plain 2-operand add / xor every ~2.1 -> G wave-instructions/s at 8 waves per SIMD"""
-    slow, fast = [], []
+    """wave64 issue rates MEASURED on MI355X by tools/valu_issue_bench.hip (profiles/r02_valu_issue.txt), at 8 waves per SIMD, as two
+    classes and no blend: instructions that issue every ~4.1 cycles per SIMD (3-operand, bit-field, carry, DPP, shifts: what the
+    alignment recurrence is mostly made of) and those that issue every ~2.1 cycles (2-operand add / xor).  -> (G wave-inst/s of
+    the 4-cycle class, of the 2-cycle class): medians of the measured lines of each class."""
+    c4, c2 = [], []
     try:
         for line in open(os.path.join(ROOT, "profiles", "r02_valu_issue.txt")):
             f = line.split()
-            if len(f) >= 4 and f[-3] == "8":
-                (fast if f[0] in ("v_add_u32", "v_xor_b32") and len(f) == 4 else slow).append(float(f[-2]))
+            if len(f) < 4 or line.startswith("#"):
+                continue
+            try:
+                waves, rate, cyc = int(f[-3]), float(f[-2]), float(f[-1])
+            except ValueError:
+                continue
+            if waves != 8:
+                continue
+            if cyc < 3.0:
+                c2.append(rate)
+            elif cyc < 6.0:
+                c4.append(rate)       # (v_cndmask at 23 cycles is VCC-serialised in that micro-benchmark: neither class)
     except OSError:
         pass
-    slow = [x for x in slow if x > 300.0]   # drop the VCC-serialised v_cndmask line
-    return (sum(slow) / len(slow) if slow else 600.0), (sum(fast) / len(fast) if fast else 1165.0)
+    med = lambda v, d: sorted(v)[len(v) // 2] if v else d  # noqa: E731
+    return med(c4, 600.0), med(c2, 1180.0)
 
 
 def kept_counters():
@@ -88,6 +100,7 @@ def main():
     ap.add_argument("--copies", choices=["found", "truth"], default="found",
                     help="found: copy finding (minimizer index lookup) runs inside the timed step; truth: the generator's copy table is the input")
     ap.add_argument("--verify", type=int, default=24, help="candidates re-judged with the CPU oracle chain after the timed region (0 = none)")
+    ap.add_argument("--no-coarse", action="store_true", help="skip the coarse-stage block of the default line")
     ap.add_argument("--stage", choices=["fine", "coarse"], default="fine",
                     help="fine (default): BASELINE.json's metric; coarse: the companion line of stage 3.1 (all-vs-all seeding + FMEA)")
     args = ap.parse_args()
@@ -101,6 +114,8 @@ def main():
         raise SystemExit(subprocess.call(cmd, env=env))
     if args.stage == "coarse":
         return coarse_stage(args)
+    if args.config == "C5":
+        return c5_mode(args)
 
     import torch
     import torch.distributed as dist
@@ -134,11 +149,21 @@ def main():
                             device=dev, cand_seed=args.seed + 7919 + (0 if strong else 104729 * rank))
     setup_s = time.time() - t0
     n_all = len(w["cand_off"]) - 1
+    shares = None
     if strong:
-        c0, c1, (b0, b1), (k0, k1) = hd.shard_candidates(w["cand_off"], w["copy_first"], rank, world)
+        # ONE batch over the ranks: length-balanced block-cyclic shares (hite_amd.dist: the step time of a rank is set by its longest
+        # alignments), the share as its own CSR; the all-gathered records go back to candidate order by the inverse permutation
+        ids, shares = hd.shard_candidates_balanced(w["cand_off"], w["copy_first"], rank, world)
+        L = {}
+        L["cands"], L["cand_off"] = hd.gather_csr(w["cands"], w["cand_off"], ids)
+        cf64 = np.asarray(w["copy_first"], dtype=np.int64)
+        for k_ in ("contig", "start1", "end1", "minus"):
+            L[k_], new_cf = hd.gather_csr(w[k_], cf64, ids)
+        L["copy_first"] = new_cf.astype(np.int32)
     else:
-        c0, c1, b0, b1, k0, k1 = 0, n_all, 0, int(w["cand_off"][-1]), 0, len(w["contig"])
-    n_cand = c1 - c0
+        L = {k_: w[k_] for k_ in ("cands", "cand_off", "copy_first", "contig", "start1", "end1", "minus")}
+    n_cand = len(L["cand_off"]) - 1
+    c0, c1, b0, b1, k0, k1 = 0, n_cand, 0, int(L["cand_off"][-1]), 0, len(L["contig"])
 
     ctx = hite_amd.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
@@ -158,11 +183,11 @@ def main():
     d_calls = torch.zeros(max(1, n_cand) * 32, dtype=torch.uint8, device=dev)
     cons_cap = (b1 - b0) + 200 * n_cand + 4096
     d_cons = torch.zeros(cons_cap + 64, dtype=torch.uint8, device=dev)
-    d_cand = up(np.concatenate([w["cands"][b0:b1], np.zeros(64, np.uint8)]))
-    d_cand_off = up(w["cand_off"][c0:c1 + 1] - b0)
-    d_cf = up(w["copy_first"][c0:c1 + 1] - k0)
-    d_ct, d_s1, d_e1 = up(w["contig"][k0:k1]), up(w["start1"][k0:k1]), up(w["end1"][k0:k1])
-    d_mn = up(np.concatenate([w["minus"][k0:k1], np.zeros(16, np.uint8)]))
+    d_cand = up(np.concatenate([L["cands"], np.zeros(64, np.uint8)]))
+    d_cand_off = up(np.asarray(L["cand_off"], dtype=np.int64))
+    d_cf = up(np.asarray(L["copy_first"], dtype=np.int32))
+    d_ct, d_s1, d_e1 = up(L["contig"]), up(L["start1"]), up(L["end1"])
+    d_mn = up(np.concatenate([L["minus"], np.zeros(16, np.uint8)]))
     state = {"found": None, "n_copies": k1 - k0}
     n_merge = n_all if strong else world * n_cand
 
@@ -183,7 +208,8 @@ def main():
         stream.synchronize()
         merged = None
         if world > 1:   # merge the boundary calls (RCCL over xGMI): ONE all-gather of the 32-byte records
-            merged = hd.allgather_calls(d_calls[: n_cand * 32], n_merge)
+            merged = (hd.allgather_calls_balanced(d_calls[: n_cand * 32], shares) if shares is not None
+                      else hd.allgather_calls(d_calls[: n_cand * 32], n_merge))
         return st, merged
 
     # residency set-up, like the index build above: the library's grow-only arenas reach their final size in the first call
@@ -256,7 +282,8 @@ def main():
             dbits = max(1, int(G + 65536).bit_length())
             cbits = max(1, int(max(1, n_cand) - 1).bit_length())
             passes = -(-dbits // 10) + -(-(1 + cbits) // 10)
-            alg["radix_sort_hits"] = float(cs[1]) * (8 + 16) * passes     # 8-byte keys: histogram read + scatter read/write per pass
+            alg["radix_sort_hits"] = float(cs[1]) * 16.0                    # 16 B per hit, whatever the number of passes (passes = the sort's own business)
+            _ = passes
             alg["hit_kernel"] = float(cs[1]) * (8 + 8)                       # index entry gathered + packed hit written
             alg["cluster_flag_kernel"] = float(cs[1]) * (8 + 4)
             alg["cluster_acc_kernel"] = float(cs[1]) * (8 + 4 + 8)
@@ -295,13 +322,30 @@ def main():
                        "band_gcells_per_s": round(128.0 * cols_step / (align_ms * 1e-3) / 1e9, 1),
                        "certified_frac": round(per_step["certified"] / pairs_step, 4), "wide_frac": round(per_step["wide"] / pairs_step, 4),
                        "fallback_per_step": per_step["fallback"], "dropped_per_step": per_step["dropped"], "exact_cap": per_step["exact_cap"],
-                       "peak_ginst_3op": round(slow, 1), "peak_ginst_2op": round(fast, 1)}
+                       "peak_ginst_4cycle_class": round(slow, 1), "peak_ginst_2cycle_class": round(fast, 1)}
                 if inst > 0 and cols_file > 0:
                     per_col = inst / cols_file            # wave-level instructions per pair-column
                     rate = per_col * cols_step / (align_ms * 1e-3) / 1e9
-                    blk["valu_issue"] = {"achieved": round(rate, 1), "peak": round(slow, 1), "unit": "G wave64-inst/s", "frac": round(rate / slow, 4),
+                    # no blended peak: the fraction against the 4-cycle class (an upper bound of the true fraction: some of the mix
+                    # issues in 2 cycles) and against the 2-cycle class (a lower bound)
+                    blk["valu_issue"] = {"achieved": round(rate, 1), "unit": "G wave64-inst/s", "peak_4cycle_class": round(slow, 1),
+                                         "peak_2cycle_class": round(fast, 1), "frac_of_4cycle_peak": round(rate / slow, 4),
+                                         "frac_of_2cycle_peak": round(rate / fast, 4),
                                          "wave_inst_per_pair_column": round(per_col, 4), "source": "profiles/r02_sq_counters.json"}
                 roof["align"] = blk
+            # the whole step by SURVEY.md 8(d)'s formulas, verbatim: B_copy = Q/4 + 12 M_q + 16 hits; B_gather = sum R_c (W_c/4 + W_c);
+            # B_vote = sum (R_c W_c + 20 W_c)  -- the path as built is instruction / latency bound, not bandwidth bound
+            if args.copies == "found":
+                cs_ = [int(x) for x in ctx.copy_stats()]
+                b_copy = (b1 - b0) / 4.0 + 12.0 * cs_[0] + 16.0 * cs_[1]
+            else:
+                b_copy = 0.0
+            b_gather = 1.25 * float(stats[1] + stats[5])
+            b_vote = float(stats[2] + stats[6]) + 20.0 * float(stats[11])
+            sb = b_copy + b_gather + b_vote
+            roof["step"] = {"survey_alg_bytes": int(sb), "copy": int(b_copy), "gather": int(b_gather), "vote": int(b_vote),
+                            "GB/s": round(sb / (ms_per_step * 1e-3) / 1e9, 1), "frac": round(sb / (ms_per_step * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                            "note": "SURVEY 8(d) formulas over the whole step time; the step is instruction / latency bound (see align.valu_issue, kernels)"}
             # every stage with an algorithmic byte count, against the same HBM peak (what each is really bound by: DESIGN.md section 4)
             roof["stages"] = {k: {"ms_per_step": round(ms / steps, 3), "achieved": round(alg[k] / (ms / steps * 1e-3) / 1e9, 1),
                                   "frac": round(alg[k] / (ms / steps * 1e-3) / 1e9 / PEAK_HBM_GBS, 4)}
@@ -321,7 +365,7 @@ def main():
                        "pipeline_stats": [int(x) for x in stats], "copy_stats": [int(x) for x in ctx.copy_stats_ext()] if args.copies == "found" else None,
                        "align_stats_per_step": {k_: int(v_) for k_, v_ in per_step.items()},
                        "is_te": n_te_all, "parallelism": "replicated genome, candidates %s x%d, all-gather of 32-B calls" %
-                                                        ("sharded" if strong else "per rank", world),
+                                                        ("sharded (length-balanced block-cyclic)" if strong else "per rank", world),
                        "setup_s": round(setup_s, 1)},
             "roofline": roof,
             "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kern.items())},
@@ -331,9 +375,16 @@ def main():
             buf = (ctypes.c_ulonglong * 16)()
             ctx.lib.hite_debug_judge_clocks(buf, 1)
             out["judge_phase_ticks"] = [int(x) for x in buf[:12]]
+        if world == 1 and not args.no_coarse:
+            # north_star's >= 20x target is phrased on the coarse_boundary step: measured here, after the headline's timed region, on
+            # the same resident genome (stage 3.1: index + all-vs-all seeding + FMEA over the whole genome as one chunk)
+            try:
+                out["coarse"] = coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, not args.no_cpu_baseline)
+            except Exception as e:
+                out["coarse"] = {"error": "%s: %s" % (type(e).__name__, e)}
         wv = None
         if (world == 1 and not args.no_cpu_baseline) or args.verify > 0:
-            wv = host_workload(w, ctx, state if args.copies == "found" else None, c0, c1)
+            wv = host_workload(dict(w, **L), ctx, state if args.copies == "found" else None, c0, c1)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wv, args.cpu_seconds, args.cpu_threads, args.cpu_copies or mbp <= 1000)
@@ -341,9 +392,12 @@ def main():
                 out["cpu_baseline"] = {"value": None, "unit": "candidates/s", "cores": args.cpu_threads, "kind": "port",
                                        "sample": "failed: %s: %s" % (type(e).__name__, e)}
         if args.verify > 0:
-            # the oracle chain re-judges on the SAME copy table the GPU used (copy finding itself is checked against its twin
-            # in tests/test_gpu_parity.py::test_find_copies_vs_twin); outside the timed region
+            # the oracle chain re-judges on the SAME copy table the GPU used; the copy table itself is compared with the CPU twin's
+            # on the sample of the cpu_baseline leg (copy_tables); outside the timed region
             out["verify"] = verify(wv, calls, d_cons.cpu().numpy(), args.verify)
+            ct = (out.get("cpu_baseline") or {}).pop("copy_tables", None)
+            if ct is not None:
+                out["verify"]["copy_tables"] = ct
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -466,6 +520,15 @@ def cpu_baseline(wv, budget_s, threads=0, with_copies=False):
     note = "%d random candidates of the same workload (%.1f s judging, %.1f s wall incl. worker start-up), oracle chain, %d worker process%s" % (
         done, busy, wall, threads, "" if threads == 1 else "es")
     outd = {"value": round(rate, 3), "unit": "candidates/s", "cores": threads, "kind": "port", "sample": note}
+    try:   # how the C port relates to the reference's own Python on the functions HiTE owns (measured in the build container)
+        rt = json.load(open(os.path.join(ROOT, "profiles", "r01_reference_python_timing.json")))
+        outd["reference_python_vs_c_port"] = {
+            "judge_candidates_per_s_per_core": {"reference_python": rt["judge"]["python_1proc_cand_per_s"], "c_port": rt["judge"]["c_port_1thread_cand_per_s"]},
+            "fmea_hsp_per_s_per_core": {"reference_python": rt["fmea"]["python_1proc_hsp_per_s"], "c_port": rt["fmea"]["c_port_1thread_hsp_per_s"]},
+            "note": "the reference's Python is ~60x (judges) / ~27x (FMEA) slower per core than this C port; its blastn / minimap2 / mafft share cannot be timed here",
+            "source": "profiles/r01_reference_python_timing.json"}
+    except (OSError, KeyError, ValueError):
+        pass
     if with_copies:
         import oracle_lib as O
 
@@ -475,8 +538,19 @@ def cpu_baseline(wv, budget_s, threads=0, with_copies=False):
         cands = [wv["cands"][wv["cand_off"][c]:wv["cand_off"][c + 1]].tobytes() for c in sample]
         import ctypes
         t0 = time.perf_counter()
-        O.find_copies(contigs, cands)
+        twin_tab = O.find_copies(contigs, cands)
         t_all = time.perf_counter() - t0
+        # the twin's copy rows for the sample against the rows the GPU step produced for the same candidates (same order)
+        mism = []
+        if "copy_first" in wv:
+            for c, rows in zip(sample, twin_tab):
+                a, b = int(wv["copy_first"][c]), int(wv["copy_first"][c + 1])
+                gpu_rows = [(int(wv["contig"][i]), int(wv["start1"][i]), int(wv["end1"][i]), int(wv["minus"][i])) for i in range(a, b)]
+                if gpu_rows != [r[:4] for r in rows]:
+                    mism.append(int(c))
+            outd["copy_tables"] = {"checked": int(len(sample)), "mismatches": len(mism), "bad_candidates": mism[:10],
+                                   "copies_in_sample": int(sum(len(r) for r in twin_tab)),
+                                   "against": "CPU twin of the copy finder (oracle/hite_oracle_copies.c) on the whole genome"}
         O.lib().orc_find_copies_index_seconds.restype = ctypes.c_double
         t_index = float(O.lib().orc_find_copies_index_seconds())      # one index build, timed inside the twin
         per_cand = max(0.0, t_all - t_index) / len(cands)
@@ -488,6 +562,188 @@ def cpu_baseline(wv, budget_s, threads=0, with_copies=False):
     else:
         outd["sample"] = note + "; copy finding not charged to the CPU leg (genomes above 1 Gbp: the CPU index alone takes minutes; --cpu-copies)"
     return outd
+
+
+def _coarse_cpu_worker(job):
+    seed, mbp = job
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib as O
+    from hite_amd import synth
+
+    w = synth.make_workload(genome_bp=mbp * 1_000_000, n_tir=max(1, int(2.5 * mbp)), n_ltr=int(2.5 * mbp), cands_per_family=1, seed=seed)
+    co = w["contig_off"]
+    contigs = [w["genome"][co[i]:co[i + 1]].tobytes() for i in range(len(co) - 1)]
+    t0 = time.perf_counter()
+    h = O.seed_allvsall(contigs, seg_len=1_000_000)
+    h["chrom_names"] = ["c%d" % i for i in range(len(contigs))]
+    names = O.fmea(h, 4000, 30000)
+    return time.perf_counter() - t0, len(h["qseg"]), len(names)
+
+
+def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu):
+    """stage 3.1 on the resident genome of the headline workload: a step = minimizer index + hite_seed_allvsall + hite_fmea_chain
+    over the whole genome as one chunk.  CPU leg: the twins of the same stages on min(40, cores) workers, one 20 Mbp sub-genome
+    of the same family density each (the all-vs-all stage is super-linear in the genome, so the CPU's Mbp/s on 20 Mbp pieces
+    flatters it against the 1 Gbp step)."""
+    sc, so = ctx.seed_segments(1_000_000)
+
+    def cstep():
+        ctx.copy_index_build()
+        (oc, _os, _oe), st = ctx.coarse_stage_dev(1_000_000, sc, so, 4000, 30000)
+        return st, len(oc)
+
+    for _ in range(2):
+        cstep()
+    torch.cuda.synchronize()
+    steps = max(1, min(3, args.steps))
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        st, n_iv = cstep()
+    torch.cuda.synchronize()
+    ms = 1000.0 * (time.perf_counter() - t1) / steps
+    alg = 12.0 * st[0] * 9 + 24.0 * st[1] * 5 + 48.0 * st[3] * 5
+    blk = {"metric": "coarse_boundary step (stage 3.1: index + all-vs-all seeding + FMEA), whole genome as one chunk", "ms_per_step": round(ms, 3),
+           "value": round(mbp / (ms * 1e-3), 1), "unit": "Mbp/s", "steps": steps,
+           "seeds": st[0], "anchors": st[1], "clusters": st[2], "hsp_records": st[3], "repeat_intervals": n_iv,
+           "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                        "note": "algorithmic bytes = radix passes x 2 x record size over seeds / anchors / HSP records (whole step, not one kernel)"}}
+    if with_cpu:
+        import multiprocessing as mp
+        threads = int(args.cpu_threads) if args.cpu_threads and args.cpu_threads > 0 else min(40, os.cpu_count() or 1)
+        sub = min(mbp, 20)
+        t0 = time.perf_counter()
+        if threads == 1:
+            res = [_coarse_cpu_worker((args.seed, sub))]
+        else:
+            with mp.get_context("spawn").Pool(threads) as pool:
+                res = pool.map(_coarse_cpu_worker, [(args.seed + 31 * k, sub) for k in range(threads)])
+        wall = time.perf_counter() - t0
+        busy = max(r[0] for r in res)
+        cpu = {"value": round(threads * sub / busy, 2), "unit": "Mbp/s", "cores": threads, "kind": "port",
+               "sample": "%d workers x one %d Mbp sub-genome each, same family density (slowest worker %.1f s, %.1f s wall incl. start-up and generation): "
+                         "%d HSP records -> %d intervals in all; CPU twins of the same stages (orc_seed_allvsall + orc_fmea)"
+                         % (threads, sub, busy, wall, sum(r[1] for r in res), sum(r[2] for r in res))}
+        blk["cpu_baseline"] = cpu
+        blk["speedup_vs_cpu_baseline"] = round(blk["value"] / cpu["value"], 1) if cpu["value"] else None
+    return blk
+
+
+def c5_mode(args):
+    """BASELINE.json configs[4]: panHiTE-style population genomes, ONE genome per GPU (replicas of the whole fine stage, no
+    data-path collective), then the per-genome TE libraries are all-gathered (padded consensus pools + lengths, RCCL) and
+    merged into one non-redundant library by deredundant_for_LTR_v5 (pan_remove_redundancy.py:16-46) on rank 0.
+    A step = copy finding + fine stage on the rank's genome + the all-gather; the merge is timed separately (once)."""
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    import tempfile
+
+    import hite_amd
+    from hite_amd import dist as hd
+    from hite_amd import synth, util
+    from hite_amd._lib import CALL_DTYPE
+
+    mbp, tir_d, ltr_d = CONFIGS["C5"]
+    if args.genome_mbp is not None:
+        mbp = args.genome_mbp
+    n_tir = args.tir_families if args.tir_families is not None else int(tir_d * mbp)
+    n_ltr = args.ltr_families if args.ltr_families is not None else int(ltr_d * mbp)
+    w = synth.make_workload(genome_bp=mbp * 1_000_000, n_tir=n_tir, n_ltr=n_ltr, cands_per_family=args.cands_per_family,
+                            seed=args.seed + 1009 * (rank + 1), device=dev, family_seed=args.seed, family_keep=0.7)
+    n_cand = len(w["cand_off"]) - 1
+    nbytes = int(w["cand_off"][-1])
+    ctx = hite_amd.Context(local_rank)
+    stream = torch.cuda.Stream(device=dev)
+    sp = stream.cuda_stream
+    ctx.genome_pack_dev(w["genome"].data_ptr(), w["contig_off"], sp)
+    ctx.copy_index_build(sp)
+    torch.cuda.synchronize()
+    d_cand = torch.from_numpy(np.concatenate([w["cands"], np.zeros(64, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(w["cand_off"])).to(dev)
+    d_calls = torch.zeros(max(1, n_cand) * 32, dtype=torch.uint8, device=dev)
+    cap = nbytes + 200 * n_cand + 4096
+    d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
+
+    def library():
+        calls = d_calls.cpu().numpy().view(CALL_DTYPE)[:n_cand]
+        pool = d_cons.cpu().numpy()
+        return [pool[c["cons_off"]:c["cons_off"] + c["cons_len"]].tobytes() for c in calls if c["is_te"]]
+
+    def step(gather):
+        nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n_cand, d_cand.data_ptr(), d_off.data_ptr(), nbytes, sp)
+        ctx.flank_region_align_dev("tir", 1, n_cand, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
+                                   d_calls.data_ptr(), d_cons.data_ptr(), cap, sp)
+        stream.synchronize()
+        if not gather:
+            return None
+        mine = library()
+        if world > 1:
+            return hd.allgather_library(mine, device=dev)
+        return mine, np.zeros(len(mine), dtype=np.int64)
+
+    for _ in range(2 + args.warmup):
+        step(False)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t1 = time.perf_counter()
+    lib = None
+    for _ in range(args.steps):
+        lib = step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t1
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        tn = torch.tensor([n_cand], dtype=torch.int64, device=dev)
+        dist.all_reduce(tn)
+        total_cands = int(tn.item())
+    else:
+        total_cands = n_cand
+    if rank == 0:
+        seqs, ranks = lib
+        tmp = tempfile.mkdtemp(prefix="hite_c5_")
+        merged = os.path.join(tmp, "merged.fa")
+        with open(merged, "w") as f:
+            for i, (sq, r) in enumerate(zip(seqs, ranks)):
+                f.write(">G%d-TE_%d#Unknown\n%s\n" % (int(r), i, sq.decode()))
+        t2 = time.perf_counter()
+        util._CTX = ctx
+        out_path = util.deredundant_for_LTR_v5(merged, tmp, 1, "terminal", 0.95, 0)
+        merge_s = time.perf_counter() - t2
+        n_out = len(util.read_fasta(out_path)[0])
+        import shutil as _sh
+        _sh.rmtree(tmp, ignore_errors=True)
+        ms = 1000.0 * elapsed / max(1, args.steps)
+        print(json.dumps({
+            "metric": "candidate TE boundaries/sec, %d Mbp population genomes, one genome per GPU (config C5), + merged non-redundant TE library" % mbp,
+            "value": round(total_cands * args.steps / elapsed, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C5: %d x %d Mbp genomes (one per GPU), %d TIR + %d LTR families drawn from a shared pool (70 %% per genome), "
+                                   "%d candidates/GPU judged as TIR; step = copy finding + fine stage + all-gather of the per-genome libraries"
+                                   % (world, mbp, n_tir, n_ltr, n_cand),
+                       "library_sequences_in": len(seqs), "library_sequences_out": n_out, "merge_seconds": round(merge_s, 2),
+                       "merge": "deredundant_for_LTR_v5 on rank 0 (library-vs-library seeding, chaining, clustering, star alignments, consensus)",
+                       "parallelism": "replicas (one genome per GPU), all-gather of padded consensus pools"},
+            "roofline": None, "cpu_baseline": None}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def coarse_stage(args):

@@ -271,7 +271,7 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
                     const int64_t *d_cand_off, const int32_t *d_copy_first, const int32_t *d_contig,
                     const int64_t *d_s1, const int64_t *d_e1, const uint8_t *d_minus, int flank, const int64_t *d_len,
                     const int32_t *d_mode, PassOut *out, int64_t *stats /* rows, win_bytes, msa_bytes, align_bytes */,
-                    int64_t *extra /* steps */, bool pass_b, hipStream_t st) {
+                    int64_t *extra /* steps */, int64_t *cols_acc /* cleaned columns, both passes */, bool pass_b, hipStream_t st) {
     Arena &T = S->tmp, &K = S->keep;
     int32_t *nrows, *sel, *row_first32, *row_copy, *row_len, *row_pad, *cols, *status, *eff, *new_cols;
     int64_t *row_first, *win_off, *ops_cnt, *ops_base, *msa_bytes, *msa_off, *col_off2;
@@ -354,6 +354,7 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     ACHK(hite_star_msa_fill_sparse_dev(ctx, n, win, win_off, row_len, row_first32, ops_base, new_cols, last_extra, msa_off, clean, st));
     hite_prof_end(ctx, tk, st);
     const int64_t total_cols2 = S->h_pin[0];
+    if (cols_acc) *cols_acc += total_cols2;
     const int max_cols2 = (int)(((int32_t *)(S->h_pin + 2))[0]);
     ACHK(arena_alloc(ctx, K, (size_t)total_cols2 + 8 * (size_t)n + 64, &p)); out->cons = (uint8_t *)p;
     tk = hite_prof_begin(ctx, extra == nullptr ? "judge_kernel" : (pass_b ? "judge_kernel_passB" : "judge_kernel_passA"), st);
@@ -404,11 +405,11 @@ extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32
     HITE_CHECK(ctx, hipGetLastError());
     PassOut A, B;
     ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, flank,
-                  len, mode_a, &A, stats, stats + 8, false, st));
+                  len, mode_a, &A, stats, stats + 8, stats + 11, false, st));
     ACHK(arena_reset(ctx, S->tmp, false));
     hipLaunchKernelGGL(mode_b_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, mode_a, A.calls, mode_b);
     ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, flank,
-                  len, mode_b, &B, stats + 4, stats + 9, true, st));
+                  len, mode_b, &B, stats + 4, stats + 9, stats + 11, true, st));
     hipLaunchKernelGGL(merge_calls_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, mode_a, A.calls, B.calls, d_calls,
                        src_pass, keep_len);
     ACHK(scan_excl<int64_t>(ctx, S->tmp, keep_len, n_cand, out_off, st));

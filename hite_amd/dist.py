@@ -25,6 +25,89 @@ def shard_candidates(cand_off, copy_first, rank, world):
     return c0, c1, (int(cand_off[c0]), int(cand_off[c1])), (int(copy_first[c0]), int(copy_first[c1]))
 
 
+# ---- length-balanced block-cyclic sharding -----------------------------------------------------------------
+# The step time of a rank is set by its longest alignments (the kernels are chains of the longest wavefront), so a contiguous
+# block split lets one rank hold the long candidates.  Candidates are ordered by cost (bases x copies, descending; ties by
+# index) and dealt to the ranks in a boustrophedon: position p of that order goes to rank p % world on even rounds and to
+# world - 1 - p % world on odd ones.  Every rank computes the same assignment from the replicated CSR arrays, so the merge
+# needs no exchange of indices: the all-gathered records are put back in candidate order by the inverse permutation.
+def balanced_assignment(cost, world):
+    """-> list of int64 arrays: the candidate ids of each rank, ascending"""
+    cost = np.asarray(cost, dtype=np.int64)
+    n = len(cost)
+    order = np.lexsort((np.arange(n), -cost))          # cost descending, index ascending
+    pos = np.arange(n)
+    rnd, k = pos // world, pos % world
+    rank_of_pos = np.where(rnd % 2 == 0, k, world - 1 - k)
+    return [np.sort(order[rank_of_pos == r]).astype(np.int64) for r in range(world)]
+
+
+def candidate_cost(cand_off, copy_first):
+    """bases x (copies + 1) of every candidate: what its alignments cost, to first order"""
+    cand_off = np.asarray(cand_off, dtype=np.int64)
+    copy_first = np.asarray(copy_first, dtype=np.int64)
+    return np.diff(cand_off) * (np.diff(copy_first) + 1)
+
+
+def gather_csr(buf, off, ids):
+    """rows `ids` of a CSR (buf, off) -> (buf', off') in that order"""
+    off = np.asarray(off, dtype=np.int64)
+    ids = np.asarray(ids, dtype=np.int64)
+    lens = off[ids + 1] - off[ids]
+    new_off = np.zeros(len(ids) + 1, dtype=np.int64)
+    np.cumsum(lens, out=new_off[1:])
+    if len(ids) == 0 or new_off[-1] == 0:
+        return np.asarray(buf)[:0].copy(), new_off
+    src = np.repeat(off[ids] - new_off[:-1], lens) + np.arange(new_off[-1], dtype=np.int64)
+    return np.asarray(buf)[src], new_off
+
+
+def shard_candidates_balanced(cand_off, copy_first, rank, world):
+    """-> (ids of this rank, ids of every rank): the length-balanced block-cyclic share of the candidate batch"""
+    shares = balanced_assignment(candidate_cost(cand_off, copy_first), world)
+    return shares[rank], shares
+
+
+def allgather_calls_balanced(local_calls, shares, group=None):
+    """local_calls: uint8 tensor (len(shares[rank]) * 32) in the order of shares[rank].  ONE padded all_gather_into_tensor, then
+    the inverse permutation: returns the records of all candidates in candidate order."""
+    world = dist.get_world_size(group)
+    max_n = max(1, max(len(s) for s in shares))
+    pad = torch.zeros(max_n * 32, dtype=torch.uint8, device=local_calls.device)
+    pad[: local_calls.numel()] = local_calls
+    out = torch.empty(world * max_n * 32, dtype=torch.uint8, device=local_calls.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    n_total = sum(len(s) for s in shares)
+    # row of candidate c in the gathered buffer
+    src = np.empty(n_total, dtype=np.int64)
+    for r, ids in enumerate(shares):
+        src[ids] = r * max_n + np.arange(len(ids))
+    idx = torch.from_numpy(src).to(out.device)
+    return out.view(world * max_n, 32)[idx].reshape(-1)
+
+
+def allgather_consensus_balanced(local_calls_np, local_cons, shares, group=None):
+    """as allgather_consensus for balanced shares: -> (calls in candidate order with cons_off rebased into the merged pool, pool)"""
+    world = dist.get_world_size(group)
+    dev = local_cons.device
+    used = int(local_calls_np["cons_len"][local_calls_np["is_te"] != 0].sum())
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([used], dtype=torch.int64, device=dev), group=group)
+    sizes = sizes.cpu().numpy()
+    mx = max(int(sizes.max()), 1)
+    pad = torch.zeros(mx, dtype=torch.uint8, device=dev)
+    pad[:used] = local_cons[:used]
+    out = torch.empty(world * mx, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    calls_t = torch.from_numpy(local_calls_np.view(np.uint8).copy()).to(dev)
+    allc = allgather_calls_balanced(calls_t, shares, group).cpu().numpy().view(CALL_DTYPE).copy()
+    base = np.concatenate([[0], np.cumsum(sizes)])
+    for r, ids in enumerate(shares):
+        allc["cons_off"][ids] += base[r]
+    cons = torch.cat([out[r * mx: r * mx + int(sizes[r])] for r in range(world)])
+    return allc, cons
+
+
 def allgather_calls(local_calls, n_total, group=None):
     """local_calls: uint8 tensor (n_local * 32) on the backend's device.  Returns the n_total records of all
     ranks in candidate order (block partition => rank order).  One padded all_gather_into_tensor."""
@@ -61,3 +144,36 @@ def allgather_consensus(local_calls_np, local_cons, n_total, group=None):
     for r in range(world):
         allc["cons_off"][b[r]:b[r + 1]] += base[r]
     return allc, cons
+
+
+# ---- config C5 (panHiTE: one genome per GPU): the per-rank TE libraries become one library on every rank ----------------------
+def allgather_varlen(local, group=None):
+    """local: 1-D tensor (any length, same dtype on every rank) -> (concatenation in rank order, per-rank lengths).  Two
+    collectives: the lengths, then ONE padded all_gather_into_tensor."""
+    world = dist.get_world_size(group)
+    dev = local.device
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, torch.tensor([local.numel()], dtype=torch.int64, device=dev), group=group)
+    sizes = sizes.cpu().numpy()
+    mx = max(int(sizes.max()), 1)
+    pad = torch.zeros(mx, dtype=local.dtype, device=dev)
+    pad[: local.numel()] = local
+    out = torch.empty(world * mx, dtype=local.dtype, device=dev)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * mx: r * mx + int(sizes[r])] for r in range(world)]), sizes
+
+
+def allgather_library(seqs, device="cpu", group=None):
+    """seqs: this rank's library (list of bytes / str) -> the libraries of all ranks as (list of bytes, rank of each), in rank
+    order: the all-gather of padded consensus pools + their lengths that SURVEY 8e describes for config C5"""
+    sb = [x.encode() if isinstance(x, str) else bytes(x) for x in seqs]
+    pool = torch.from_numpy(np.frombuffer(b"".join(sb) + b"", dtype=np.uint8).copy()).to(device)
+    lens = torch.tensor([len(x) for x in sb], dtype=torch.int64, device=device)
+    all_pool, _ = allgather_varlen(pool, group)
+    all_lens, counts = allgather_varlen(lens, group)
+    all_pool = all_pool.cpu().numpy()
+    all_lens = all_lens.cpu().numpy()
+    off = np.concatenate([[0], np.cumsum(all_lens)])
+    out = [all_pool[off[i]:off[i + 1]].tobytes() for i in range(len(all_lens))]
+    ranks = np.repeat(np.arange(len(counts)), counts)
+    return out, ranks

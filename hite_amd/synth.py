@@ -68,11 +68,19 @@ def make_families(rng, n_tir, n_ltr, max_copies=300):
 
 
 def make_workload(genome_bp=100_000_000, n_tir=500, n_ltr=0, cands_per_family=10, seed=20250927, chrom_bp=50_000_000,
-                  device=None, flank=50, cand_seed=None):
+                  device=None, flank=50, cand_seed=None, family_seed=None, family_keep=1.0):
     """-> dict(genome (uint8 ASCII, torch tensor on `device` or numpy), contig_off, cands (uint8 array),
     cand_off, copy_first, contig, start1, end1, minus, family, n_families, planted)"""
     rng = np.random.default_rng(seed)
-    fams = make_families(rng, n_tir, n_ltr)
+    if family_seed is None:
+        fams = make_families(rng, n_tir, n_ltr)
+    else:
+        # population genomes (config C5): the families come from a seed all genomes share, each genome carries a random
+        # family_keep fraction of them (its own copies, positions and divergences)
+        fams = make_families(np.random.default_rng(family_seed), n_tir, n_ltr)
+        for f_, keep_ in zip(fams, rng.random(len(fams)) < family_keep):
+            if not keep_:
+                f_["ncopy"] = 0
     n_chr = max(1, int(np.ceil(genome_bp / chrom_bp)))
     contig_off = np.minimum(np.arange(n_chr + 1, dtype=np.int64) * chrom_bp, genome_bp)
     # ---- planted copies ------------------------------------------------------------------------

@@ -573,15 +573,175 @@ def split_internal_out(merge_te_file, output_dir):
     return other_path, internal_path
 
 
+def read_Ninja_clusters(cluster_file):
+    """Util.py:12500 -- '<cluster id>\t<sequence name>' per line -> {cluster id: [names in file order]}"""
+    clusters = {}
+    with open(cluster_file) as f_r:
+        for line in f_r:
+            parts = line.rstrip("\n").split("\t")
+            if len(parts) < 2:
+                continue
+            clusters.setdefault(int(parts[0]), []).append(parts[1])
+    return clusters
+
+
+NINJA_CUTOFF = 0.2        # generate_cons_v1 runs `Ninja --cluster_cutoff 0.2` (Util.py:12470)
+STAR_MAX_LEN = 32767      # longest window the star aligner takes (include/hite_gpu.h)
+SEED_MAX_SEGMENTS = 65000  # sequences per all-vs-all call (the seeding stage addresses < 65535 segments)
+
+
+def ninja_stand_in(rows):
+    """The build's stand-in for Ninja's re-clustering of an aligned cluster (Util.py:12468-12474; Ninja is an external tool,
+    absent: PARITY UNPINNED).  Leader clustering on the aligned rows: a row joins the first earlier leader it differs from
+    in <= 20 % of the columns where both have a base (Ninja cuts its neighbour-joining tree at distance 0.2), else it becomes
+    a leader.  rows: 2-D uint8 alignment -> list of lists of row indices (sub-clusters in order of their leaders)."""
+    rows = np.asarray(rows)
+    leaders, members = [], []
+    for r in range(rows.shape[0]):
+        placed = False
+        for k, l in enumerate(leaders):
+            both = (rows[r] != 45) & (rows[l] != 45)
+            n = int(both.sum())
+            if n > 0 and int(((rows[r] != rows[l]) & both).sum()) <= NINJA_CUTOFF * n:
+                members[k].append(r)
+                placed = True
+                break
+        if not placed:
+            leaders.append(r)
+            members.append([r])
+    return members
+
+
+def _star_align_clusters(ctx, clusters):
+    """clusters: list of lists of (name, sequence).  Every cluster is aligned as a star around its LONGEST member (ties: the
+    first), rows returned in the cluster's own order -- the stand-in for `mafft --preservecase` (Util.py:12464, 12490; mafft
+    compares case-insensitively: sequences are upper-cased first).  -> per cluster (rows: {name: aligned row}, dropped: [names
+    the aligner could not place (shorter than half the centre, or an insertion / deletion beyond its widest band)])."""
+    groups, orders = [], []
+    for cl in clusters:
+        seqs = [sq.upper() for _n, sq in cl]
+        centre = max(range(len(seqs)), key=lambda i: (len(seqs[i]), -i))
+        order = [centre] + [i for i in range(len(seqs)) if i != centre]
+        orders.append(order)
+        groups.append([seqs[i] for i in order])
+    aligned, info = ctx.star_msa(groups, info=True) if groups else ([], [])
+    out = []
+    for cl, order, m, inf in zip(clusters, orders, aligned, info):
+        rows, dropped = {}, []
+        if m is None:
+            out.append(({}, [n for n, _s in cl]))
+            continue
+        k = 0
+        by_member = {}
+        for pos, i in enumerate(order):
+            if pos == 0 or int(inf[pos][2]) == 0:
+                by_member[i] = bytes(m[k]).decode()
+                k += 1
+            else:
+                dropped.append(cl[i][0])
+        for i in range(len(cl)):               # back to the cluster's own order
+            if i in by_member:
+                rows[cl[i][0]] = by_member[i]
+        out.append((rows, dropped))
+    return out
+
+
+def _generate_cons_batch(ctx, clusters, ninja=None):
+    """generate_cons_v1 (Util.py:12457-12498) for a batch of clusters, each a list of (name, sequence) in file order:
+    alignment -> sub-clusters (Ninja in the reference, ninja_stand_in here; `ninja` = per cluster {id: [names]} overrides it,
+    which is how the goldens pin everything around the external tool) -> alignment of every sub-cluster -> strict-majority
+    consensus (cons_from_mafft_v1) named after the sub-cluster's LAST member.  A cluster that yields no consensus returns
+    its sequences unchanged; members the aligner dropped pass unchanged as well.  -> per cluster {name: sequence}."""
+    need_first = [ci for ci in range(len(clusters)) if ninja is None or ninja[ci] is None]
+    first = dict(zip(need_first, _star_align_clusters(ctx, [clusters[ci] for ci in need_first])))
+    subs, owner = [], []
+    passed = [dict() for _ in clusters]
+    for ci, cl in enumerate(clusters):
+        seq_of = dict(cl)
+        if ci in first:
+            rows, dropped = first[ci]
+            for n in dropped:                # not placed in the cluster's alignment: passes unchanged
+                passed[ci][n] = seq_of[n]
+            names = [n for n, _s in cl if n in rows]
+            if not names:
+                continue
+            mat = np.frombuffer("".join(rows[n] for n in names).encode(), dtype=np.uint8).reshape(len(names), -1)
+            parts = [[names[r] for r in grp] for grp in ninja_stand_in(mat)]
+        else:
+            parts = [list(ninja[ci][k]) for k in ninja[ci]]
+        for part in parts:
+            if part:
+                subs.append([(n, seq_of[n]) for n in part])
+                owner.append(ci)
+    second = _star_align_clusters(ctx, subs)
+    als, who = [], []
+    for si, (sub, (rows, dropped)) in enumerate(zip(subs, second)):
+        for n in dropped:
+            passed[owner[si]][n] = dict(sub)[n]
+        kept = [n for n, _s in sub if n in rows]
+        if kept:
+            als.append([rows[n] for n in kept])
+            who.append((owner[si], kept[-1]))
+    cons = ctx.msa_consensus(als) if als else []
+    out = [dict() for _ in clusters]
+    for (ci, last), c in zip(who, cons):
+        out[ci][last] = c
+    for ci, cl in enumerate(clusters):
+        if not out[ci]:                      # no reliable consensus: the original sequences (Util.py:12495-12498)
+            out[ci] = dict(cl)
+        else:
+            out[ci].update(passed[ci])
+    return out
+
+
+def generate_cons_v1(cluster_id, cur_cluster_path, cluster_dir, threads, device=0, ninja_clusters=None):
+    """generate_cons_v1 (Util.py:12457), same arguments: the FASTA of one cluster -> {name: consensus}.  ninja_clusters: the
+    parsed output of Ninja ({id: [names]}, read_Ninja_clusters) when the caller has one; else the build's stand-in."""
+    names, contigs = read_fasta(cur_cluster_path)
+    if not names:
+        return {}
+    return _generate_cons_batch(get_ctx(device), [[(n, contigs[n]) for n in names]], [ninja_clusters])[0]
+
+
+def _library_hits(ctx, names, contigs):
+    """all-vs-all of a library with itself where the reference runs blastn (multi_process_align, Util.py:12209): the library is
+    packed as a genome (one contig per sequence) and searched by hite_seed_allvsall, in blocks when it has more sequences
+    than one call addresses (every pair of blocks once: the blocks of a pair are packed together).
+    -> (q, s, qs, qe, ss, se) arrays over the indices of `names`."""
+    n = len(names)
+    half = SEED_MAX_SEGMENTS // 2
+    blocks = [list(range(a, min(n, a + half))) for a in range(0, n, half)] if n > SEED_MAX_SEGMENTS else [list(range(n))]
+    parts = []
+    pairs = [(i, j) for i in range(len(blocks)) for j in range(i, len(blocks))] if len(blocks) > 1 else [(0, 0)]
+    for (i, j) in pairs:
+        ids = blocks[i] + (blocks[j] if j != i else [])
+        ctx.genome_pack([contigs[names[t]].upper() for t in ids])
+        ctx.release_copy_index()
+        _PACKED["path"] = None
+        lens = [len(contigs[names[t]]) for t in ids]
+        tab = ctx.seed_allvsall(seg_len=max(lens))
+        gi = np.asarray(ids, dtype=np.int64)
+        q, s2 = gi[np.asarray(tab["qseg"], dtype=np.int64)], gi[np.asarray(tab["sseg"], dtype=np.int64)]
+        keep = np.ones(len(q), dtype=bool)
+        if j != i:          # a mixed pair contributes the hits BETWEEN its two blocks only
+            inb = np.zeros(n, dtype=bool)
+            inb[blocks[i]] = True
+            keep = inb[q] != inb[s2]
+        parts.append(tuple(np.asarray(x)[keep] for x in (q, s2, tab["qs"], tab["qe"], tab["ss"], tab["se"])))
+    return tuple(np.concatenate([p[k] for p in parts]) for k in range(6))
+
+
 def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_threshold, debug, device=0):
     """deredundant_for_LTR_v5 (Util.py:12202-12337, the library de-duplication of panHiTE, config C5), same arguments.
     Reference: blastn all-vs-all of the library -> chunked fragment chaining (process_blast_results_in_chunks +
     FMEA_new1_parallel_large) -> greedy clusters (cluster_sequences_from_chunks) -> per cluster generate_cons_v1 (mafft ->
     Ninja sub-clusters -> mafft -> cons_from_mafft_v1) -> cd-hit-est.  Here: the library is packed as a genome and searched
-    against itself by hite_seed_allvsall (where the reference runs blastn), chaining / clustering / consensus are the pinned
-    device stages (hite_lib_chain, hite_lib_cluster, hite_msa_consensus), the alignment of a cluster is the star alignment
-    (where the reference runs mafft; centre = first member); the Ninja split (external tool) is not made: one consensus per
-    cluster, named like the reference names it (the cluster's last member); cd-hit-est runs when it is installed.
+    against itself by hite_seed_allvsall (where the reference runs blastn; libraries of >= 65 000 sequences in blocks),
+    chaining / clustering / consensus are the pinned device stages (hite_lib_chain, hite_lib_cluster, hite_msa_consensus),
+    the alignments are star alignments (where the reference runs mafft), the sub-clusters come from ninja_stand_in (where it
+    runs Ninja); the cd-hit-est pre-reduction of clusters above 10 000 members (:12256-12299) is not made (the star aligner
+    takes clusters of any size); cd-hit-est after the consensus step runs when it is installed.  Sequences longer than the
+    aligner's 32 767-base windows pass unclustered.
     Writes <redundant_ltr>.tmp.cons and <redundant_ltr>.cons, returns the former like the reference."""
     names, contigs = read_fasta(redundant_ltr)
     cons_path, final_path = redundant_ltr + ".tmp.cons", redundant_ltr + ".cons"
@@ -589,54 +749,41 @@ def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_thre
         store_fasta({}, cons_path)
         store_fasta({}, final_path)
         return cons_path
-    if len(names) >= 65535:
-        raise ValueError("library of %d sequences: the all-vs-all stage addresses < 65535 segments per call" % len(names))
     ctx = get_ctx(device)
-    ctx.genome_pack([contigs[n] for n in names])
-    ctx.release_copy_index()
-    _PACKED["path"] = None
-    lens = [len(contigs[n]) for n in names]
-    tab = ctx.seed_allvsall(seg_len=max(lens))
-    # the seeding stage reports a hit from its first to its last anchor; blastn extends an alignment to the ends of the
-    # sequences when they keep matching.  Hits are therefore stretched along their diagonal over a short overhang (<= 30 bases on
-    # both sequences): without it two copies of one family miss the 0.95 coverage rule by the few bases outside the anchors.
-    L = np.asarray(lens, dtype=np.int64)
-    q, s = np.asarray(tab["qseg"]), np.asarray(tab["sseg"])
-    qs, qe = np.asarray(tab["qs"]).copy(), np.asarray(tab["qe"]).copy()
-    ss, se = np.asarray(tab["ss"]).copy(), np.asarray(tab["se"]).copy()
-    fwd = ss <= se
-    left = np.minimum(qs - 1, np.where(fwd, ss - 1, L[s] - ss))
-    right = np.minimum(L[q] - qe, np.where(fwd, L[s] - se, se - 1))
-    left = np.where(left <= 30, left, 0)
-    right = np.where(right <= 30, right, 0)
-    qs -= left; qe += right
-    ss = np.where(fwd, ss - left, ss + left)
-    se = np.where(fwd, se + right, se - right)
-    recs = ctx.lib_chain(q, s, qs, qe, ss, se, lens, coverage_threshold, 5_000_000)
-    clusters = ctx.lib_cluster(recs, lens, coverage_threshold)
-    groups = [[contigs[names[i]] for i in cl] for cl in clusters if len(cl) >= 1]
-    aligned = ctx.star_msa(groups) if groups else []
+    work = [n for n in names if 0 < len(contigs[n]) <= STAR_MAX_LEN]       # the rest passes unchanged
     all_cons, clustered = {}, set()
-    rows = [[bytes(r).decode() for r in m] if m is not None else None for m in aligned]
-    cons = ctx.msa_consensus([r for r in rows if r is not None]) if any(r is not None for r in rows) else []
-    k = 0
-    for cl, r in zip([c for c in clusters if len(c) >= 1], rows):
-        clustered.update(cl)
-        if r is None:
-            for i in cl:
-                all_cons[names[i]] = contigs[names[i]]
-            continue
-        all_cons[names[cl[-1]]] = cons[k] if cons[k] else contigs[names[cl[-1]]]
-        k += 1
-    for i, n in enumerate(names):      # sequences outside every cluster pass unchanged
-        if i not in clustered:
+    if work:
+        q, s, qs, qe, ss, se = _library_hits(ctx, work, contigs)
+        lens = [len(contigs[n]) for n in work]
+        # the seeding stage reports a hit from its first to its last anchor; blastn extends an alignment to the ends of the
+        # sequences when they keep matching.  Hits are therefore stretched along their diagonal over a short overhang (<= 30 bases on
+        # both sequences): without it two copies of one family miss the 0.95 coverage rule by the few bases outside the anchors.
+        L = np.asarray(lens, dtype=np.int64)
+        qs, qe, ss, se = (np.asarray(x).copy() for x in (qs, qe, ss, se))
+        fwd = ss <= se
+        left = np.minimum(qs - 1, np.where(fwd, ss - 1, L[s] - ss))
+        right = np.minimum(L[q] - qe, np.where(fwd, L[s] - se, se - 1))
+        left = np.where(left <= 30, left, 0)
+        right = np.where(right <= 30, right, 0)
+        qs -= left; qe += right
+        ss = np.where(fwd, ss - left, ss + left)
+        se = np.where(fwd, se + right, se - right)
+        recs = ctx.lib_chain(q, s, qs, qe, ss, se, lens, coverage_threshold, 5_000_000)
+        clusters = [cl for cl in ctx.lib_cluster(recs, lens, coverage_threshold) if len(cl) >= 1]
+        batch = [[(work[i], contigs[work[i]]) for i in cl] for cl in clusters]
+        for cl, cons in zip(clusters, _generate_cons_batch(ctx, batch) if batch else []):
+            clustered.update(work[i] for i in cl)
+            all_cons.update(cons)
+    for n in names:      # sequences outside every cluster (and the over-long ones) pass unchanged
+        if n not in clustered:
             all_cons[n] = contigs[n]
     store_fasta(all_cons, cons_path)
     if shutil.which("cd-hit-est"):
         subprocess.run("cd-hit-est -aS 0.95 -aL 0.95 -c %s -G 0 -g 1 -A 80 -i %s -o %s -T 0 -M 0 > /dev/null 2>&1" %
                        (coverage_threshold, cons_path, final_path), shell=True, check=False)
     else:
-        sys.stderr.write("[hite_amd] cd-hit-est not found: the fragment-merging pass after the consensus step is skipped\n")
+        sys.stderr.write("[hite_amd] cd-hit-est not found: the fragment-merging pass after the consensus step is skipped "
+                         "(<library>.cons is a copy of <library>.tmp.cons)\n")
         shutil.copyfile(cons_path, final_path)
     return cons_path
 

@@ -332,7 +332,7 @@ int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win
  * into cons (cons_off/cons_len in the record); HITE_ECAP if cons_cap is too small.
  * stats_out (12 x int64, host, optional): [0..3] pass A rows, window bytes, matrix bytes, alignment
  * algorithmic bytes; [4..7] the same for pass B; [8],[9] anti-diagonal steps of pass A / B (x64 = DP
- * cells); [10] consensus bytes kept; [11] 0.
+ * cells); [10] consensus bytes kept; [11] cleaned alignment columns judged (both passes).
  * _dev: all pointers are device pointers; *state_io (initially NULL) keeps the arenas between
  * calls so the steady state performs no allocation; free it with hite_pipeline_release. */
 int hite_flank_region_align(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,

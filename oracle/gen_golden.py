@@ -721,6 +721,90 @@ def gen_lib_dedup(U, tmp):
     dump("lib_dedup", {"chain": cases, "cons": cons})
 
 
+def gen_cons_v1(U, tmp):
+    """generate_cons_v1 (Util.py:12457-12498) with its two external tools replaced inside the harness: `mafft` by the oracle's
+    star alignment (centre = the longest sequence, rows in input order), `Ninja` by a cluster file FABRICATED per case.
+    What the fixture pins is everything HiTE owns around them: read_Ninja_clusters, the sub-cluster files, the
+    second alignment, cons_from_mafft_v1, the naming by the last member, the fall-back to the original sequences."""
+    import oracle_lib as O
+
+    rng = np.random.default_rng(1212)
+    cases = []
+    state = {"ninja": None, "first_call": True}
+
+    def fake_system(cmd):
+        if "mafft " in cmd:
+            left, out = cmd.rsplit(">", 1)
+            src = left.split()[-1]
+            names, contigs = U.read_fasta(src)
+            seqs = [contigs[n] for n in names]
+            centre = max(range(len(seqs)), key=lambda i: (len(seqs[i]), -i))
+            order = [centre] + [i for i in range(len(seqs)) if i != centre]
+            m, kept = O.star_msa([seqs[i] for i in order], rows=True)
+            back = {i: k for k, i in enumerate(order)}
+            with open(out.strip(), "w") as f:
+                if m is None or kept != len(seqs):
+                    # unrelated sequences in one file (the whole-cluster alignment, which only Ninja reads): any valid alignment
+                    # will do for a fabricated Ninja -- left-justified rows
+                    assert state["first_call"], "a sub-cluster of the harness cases must align completely"
+                    W = max(len(x) for x in seqs)
+                    for n, x in zip(names, seqs):
+                        f.write(">" + n + "\n" + x + "-" * (W - len(x)) + "\n")
+                else:
+                    for i, n in enumerate(names):
+                        f.write(">" + n + "\n" + bytes(m[back[i]]).decode() + "\n")
+            state["first_call"] = False
+            return 0
+        if cmd.startswith("Ninja "):
+            toks = cmd.split()
+            out = toks[toks.index("--out") + 1]
+            with open(out, "w") as f:
+                for cid, members in state["ninja"].items():
+                    for n in members:
+                        f.write("%d\t%s\n" % (cid, n))
+            return 0
+        return 0
+
+    real_system = U.os.system
+    U.os.system = fake_system
+    try:
+        for ci in range(14):
+            nfam = int(rng.integers(1, 4))
+            recs, assign = [], {}
+            for f in range(nfam):
+                cons = casegen.rand_seq(rng, int(rng.integers(150, 700)))
+                for k in range(int(rng.integers(1, 6))):
+                    sq = casegen.mutate(rng, cons, float(rng.uniform(0.0, 0.06)))
+                    if rng.random() < 0.3:      # a few bases missing at one end
+                        cut = int(rng.integers(1, 12))
+                        sq = sq[cut:] if rng.random() < 0.5 else sq[:-cut]
+                    name = "G%d-fam%d_%d#LTR/Gypsy" % (k, f, ci)
+                    recs.append((name, sq))
+                    assign.setdefault(f, []).append(name)
+            order = rng.permutation(len(recs))
+            recs = [recs[i] for i in order]
+            pos = {n: i for i, (n, _s) in enumerate(recs)}
+            ninja = {cid: sorted(members, key=lambda n: pos[n]) for cid, members in assign.items()}
+            cdir = os.path.join(tmp, "cons_v1_%d" % ci)
+            os.makedirs(cdir, exist_ok=True)
+            path = os.path.join(cdir, "0.fa")
+            write_fasta(path, [n for n, _s in recs], [sq for _n, sq in recs])
+            state["ninja"] = ninja
+            if ci % 4 == 3 and nfam == 1 and len(recs) >= 4:
+                # Ninja may also split one family: two sub-clusters of the same family
+                half = len(recs) // 2
+                ninja = {0: [n for n, _s in recs[:half]], 1: [n for n, _s in recs[half:]]}
+                state["ninja"] = ninja
+            state["first_call"] = True
+            got = U.generate_cons_v1(0, path, cdir, 1)
+            cases.append(dict(names=[n for n, _s in recs], seqs=[sq for _n, sq in recs], ninja={str(k): v for k, v in ninja.items()},
+                              expected={k: v for k, v in got.items()}))
+    finally:
+        U.os.system = real_system
+    print("cons_v1: %d cases, %d consensus sequences" % (len(cases), sum(len(c["expected"]) for c in cases)))
+    dump("cons_v1", cases)
+
+
 def gen_split_chunks(U, tmp):
     """module/split_genome_chunks.py run as a script (runpy) on small genomes: the reference FASTA is rewritten upper-case in
     place (convertToUpperCase_v1), cut into chr$offset segments (multi_line) and grouped into genome.cut{i}.fa by FASTA-text
@@ -840,7 +924,7 @@ def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -872,6 +956,8 @@ def main():
             gen_split_chunks(U, tmp)
         if "bucketing" in which:
             gen_bucketing(U, tmp)
+        if "consv1" in which:
+            gen_cons_v1(U, tmp)
 
 
 if __name__ == "__main__":

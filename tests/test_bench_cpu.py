@@ -18,10 +18,21 @@ def test_cpu_baseline_leg_runs_on_a_tiny_workload():
     wv = bench.host_workload(w, None, None, 0, n_cand)       # the generator's copy table
     for threads in (1, 2):
         r = bench.cpu_baseline(wv, 1.0, threads)
-        assert set(r) == {"value", "unit", "cores", "kind", "sample"}
+        assert set(r) == {"value", "unit", "cores", "kind", "sample", "reference_python_vs_c_port"}
         assert r["cores"] == threads and r["kind"] == "port" and r["unit"] == "candidates/s" and r["value"] > 0
     r = bench.cpu_baseline(wv, 0.5, 1, with_copies=True)     # + the CPU twin of the copy finder, charged per candidate
     assert r["copy_finding"]["index_s"] > 0 and r["value"] > 0
+    # the twin's copy table is kept and compared with the table of the step (here: the generator's, which differs -- the
+    # comparison itself is what is exercised; on the GPU box the step's table comes from the HIP finder and must agree)
+    assert r["copy_tables"]["checked"] > 0 and r["copy_tables"]["copies_in_sample"] > 0
+
+
+def test_coarse_cpu_worker_runs():
+    """the CPU leg of the coarse block of the default bench line: the twins of stage 3.1 on one small sub-genome"""
+    import bench
+
+    dt, n_hsp, n_iv = bench._coarse_cpu_worker((5, 2))
+    assert dt > 0 and n_hsp > 0 and n_iv > 0
 
 
 def test_bench_shards_like_the_library():

@@ -164,3 +164,123 @@ def test_strong_scaling_merge_world2():
     for f in ("is_te", "info", "row_num", "cons_len"):
         assert np.array_equal(raw[f], exp_calls[f])
     assert exp_calls["is_te"].sum() >= 1
+
+
+# ---- length-balanced block-cyclic sharding ----------------------------------------------------------------------
+def test_balanced_assignment_is_a_balanced_partition():
+    from hite_amd import dist as hd
+
+    rng = np.random.default_rng(3)
+    cost = np.concatenate([rng.integers(100, 3000, size=900), rng.integers(5000, 12000, size=100)]) * rng.integers(1, 100, size=1000)
+    for world in (1, 2, 3, 8):
+        shares = hd.balanced_assignment(cost, world)
+        allids = np.sort(np.concatenate(shares))
+        assert np.array_equal(allids, np.arange(1000))
+        loads = np.array([cost[s].sum() for s in shares], dtype=np.float64)
+        assert loads.max() <= 1.03 * loads.mean()                       # (the contiguous block split of the same costs: up to 1.4x)
+        assert max(len(s) for s in shares) - min(len(s) for s in shares) <= 1
+        # the heaviest candidates are spread: no rank holds two of the `world` heaviest
+        top = set(np.argsort(-cost, kind="stable")[:world].tolist())
+        assert all(len(top & set(s.tolist())) == 1 for s in shares)
+    buf = np.arange(50, dtype=np.uint8)
+    off = np.array([0, 5, 5, 20, 50])
+    b2, o2 = hd.gather_csr(buf, off, [3, 0, 1])
+    assert o2.tolist() == [0, 30, 35, 35] and b2.tolist() == list(range(20, 50)) + list(range(0, 5))
+
+
+def _balanced_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hite_amd import dist as hd
+
+    w = _tiny_workload()
+    ids, shares = hd.shard_candidates_balanced(w["cand_off"], w["copy_first"], rank, world)
+    # the rank's share as its own CSR (what bench.py --scaling strong uploads), judged by the oracle chain
+    sub = dict(w)
+    sub["cands"], sub["cand_off"] = hd.gather_csr(w["cands"], w["cand_off"], ids)
+    cf = np.asarray(w["copy_first"], dtype=np.int64)
+    for k in ("contig", "start1", "end1", "minus"):
+        sub[k], new_cf = hd.gather_csr(w[k], cf, ids)
+    sub["copy_first"] = new_cf
+    calls, cons = _oracle_calls(sub, 0, len(ids))
+    merged = hd.allgather_calls_balanced(torch.from_numpy(calls.view(np.uint8).copy()), shares)
+    allc, allcons = hd.allgather_consensus_balanced(calls, torch.from_numpy(cons.copy()), shares)
+    if rank == 0:
+        q.put((merged.numpy().tobytes(), allc.tobytes(), allcons.numpy().tobytes(), [s.tolist() for s in shares]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_balanced_sharding_merge_world2():
+    """ONE batch dealt to two ranks by cost (not a contiguous block), each share judged, records all-gathered and put back in
+    candidate order: equal to the single-process result"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_balanced_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    merged, allc, allcons, shares = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    from hite_amd._lib import CALL_DTYPE
+
+    w = _tiny_workload()
+    n_all = len(w["cand_off"]) - 1
+    assert sorted(shares[0] + shares[1]) == list(range(n_all)) and shares[0] != list(range(len(shares[0])))   # really interleaved
+    exp_calls, exp_cons = _oracle_calls(w, 0, n_all)
+    raw = np.frombuffer(merged, dtype=CALL_DTYPE)
+    got = np.frombuffer(allc, dtype=CALL_DTYPE)
+    for f in ("is_te", "info", "row_num", "cons_len"):
+        assert np.array_equal(raw[f], exp_calls[f]) and np.array_equal(got[f], exp_calls[f])
+    # the merged pool holds every consensus at its rebased offset
+    pool = np.frombuffer(allcons, dtype=np.uint8)
+    for c in range(n_all):
+        if exp_calls["is_te"][c]:
+            a = int(got["cons_off"][c])
+            e = int(exp_calls["cons_off"][c])
+            L = int(exp_calls["cons_len"][c])
+            assert pool[a:a + L].tobytes() == exp_cons[e:e + L].tobytes()
+    assert exp_calls["is_te"].sum() >= 1
+
+
+# ---- config C5: per-rank libraries -> one library on every rank ---------------------------------------------------------------
+def _library_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hite_amd import dist as hd
+
+    rng = np.random.default_rng(100 + rank)
+    mine = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), size=int(rng.integers(0, 900))).tobytes()) for _ in range(5 + 7 * rank)]
+    lib, ranks = hd.allgather_library(mine)
+    q.put((rank, mine, lib, ranks.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allgather_library_world2():
+    """config C5's collective: every rank ends with the concatenation of all per-rank libraries (ragged counts and lengths,
+    an empty sequence included), in rank order"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_library_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    expect = res[0][1] + res[1][1]
+    for rank, _mine, lib, ranks in res:
+        assert lib == expect
+        assert ranks == [0] * len(res[0][1]) + [1] * len(res[1][1])

@@ -1217,3 +1217,62 @@ def test_pan_remove_redundancy_script(ctx, tmp_path):
         d = O.nw_distance(got, cons)
         assert d <= 0.03 * len(cons) * 3, (f, d, len(cons))   # ... whose consensus is closer to the family than its members
     assert len(names) == 11
+
+
+def test_generate_cons_v1_golden_on_gpu(ctx, tmp_path):
+    """util.generate_cons_v1 (alignments and consensus on the GPU) against the reference's own generate_cons_v1 run with a
+    fabricated Ninja file (tests/golden/cons_v1.json.gz), and the build's Ninja stand-in on the same clusters"""
+    from hite_amd import util
+
+    util._CTX = ctx
+    cases = load_golden("cons_v1")
+    for ci, c in enumerate(cases):
+        fa = tmp_path / ("cl%d.fa" % ci)
+        fa.write_text("".join(">%s\n%s\n" % (n, s) for n, s in zip(c["names"], c["seqs"])))
+        ninja = {int(k): v for k, v in c["ninja"].items()}
+        got = util.generate_cons_v1(0, str(fa), str(tmp_path), 1, ninja_clusters=ninja)
+        assert got == c["expected"], ci
+        # the stand-in (leader clustering at 20 % on the cluster's alignment) finds the planted families: the names tell them
+        own = util.generate_cons_v1(0, str(fa), str(tmp_path), 1)
+        fams = {n.split("_")[0].split("-")[1] for n in c["names"]}
+        assert {n.split("_")[0].split("-")[1] for n in own} == fams and len(own) <= len(c["names"])
+    assert util.read_Ninja_clusters.__doc__
+
+
+def test_deredundant_limits(ctx, tmp_path, monkeypatch):
+    """libraries beyond one all-vs-all call are searched in blocks (same clusters as in one call), members longer
+    than the aligner's windows pass unclustered instead of failing the whole library, lower-case input is compared
+    case-insensitively, members the aligner drops pass unchanged"""
+    from hite_amd import util
+
+    util._CTX = ctx
+    rng = np.random.default_rng(99)
+    recs = []
+    fams = []
+    for f in range(5):
+        cons = casegen.rand_seq(rng, int(rng.integers(500, 1200)))
+        fams.append(cons)
+        for g in range(4):
+            sq = casegen.mutate(rng, cons, 0.02)
+            recs.append(("G%d-fam%d#DNA/hAT" % (g, f), sq.lower() if (f + g) % 3 == 0 else sq))
+    big = casegen.rand_seq(rng, 40_000)                              # an LTR internal sequence beyond 32 767 bases, twice
+    recs.append(("G0-long-int#LTR/Gypsy", big))
+    recs.append(("G1-long-int#LTR/Gypsy", casegen.mutate(rng, big, 0.01)))
+    recs.append(("single#Unknown", casegen.rand_seq(rng, 700)))
+    lib = tmp_path / "lib.fa"
+    lib.write_text("".join(">%s\n%s\n" % r for r in recs))
+    out1 = util.deredundant_for_LTR_v5(str(lib), str(tmp_path), 1, "x", 0.95, 0)
+    n1, s1 = util.read_fasta(out1)
+    assert sum("-long-int" in n for n in n1) == 2 and "single#Unknown" in n1            # passed unchanged
+    assert s1["G0-long-int#LTR/Gypsy"] == big
+    for f in range(5):
+        mine = [n for n in n1 if "-fam%d#" % f in n]
+        assert len(mine) == 1, (f, mine)
+        assert O.nw_distance(s1[mine[0]].upper(), fams[f]) <= 0.03 * len(fams[f]) * 3
+    # the same library in blocks of 6 sequences (pairs of blocks packed together)
+    monkeypatch.setattr(util, "SEED_MAX_SEGMENTS", 12)
+    lib2 = tmp_path / "lib2.fa"
+    lib2.write_text(lib.read_text())
+    out2 = util.deredundant_for_LTR_v5(str(lib2), str(tmp_path), 1, "y", 0.95, 0)
+    n2, s2 = util.read_fasta(out2)
+    assert sorted(n2) == sorted(n1) and all(s2[n] == s1[n] for n in n1)

@@ -389,3 +389,25 @@ def test_low_copy_tir_recall_by_structure(tmp_path):
     for te in ("helitron", "non_ltr"):
         r2, s2 = util.rescue_low_copy(te, low, 1, str(tmp_path / te))
         assert r2 == {} and s2 == low
+
+
+def test_generate_cons_v1_golden():
+    """generate_cons_v1 (Util.py:12457) run by the reference with `mafft` = the oracle's star alignment and a fabricated Ninja
+    file: the oracle pieces (star alignment around the longest member, strict-majority consensus) chained the same way give
+    the reference's dict -- naming by the last member of each sub-cluster included"""
+    cases = load_golden("cons_v1")
+    assert len(cases) >= 10 and sum(len(c["expected"]) for c in cases) >= 20
+    for ci, c in enumerate(cases):
+        seq_of = dict(zip(c["names"], c["seqs"]))
+        got = {}
+        for k in c["ninja"]:
+            members = c["ninja"][k]
+            seqs = [seq_of[n] for n in members]
+            centre = max(range(len(seqs)), key=lambda i: (len(seqs[i]), -i))
+            order = [centre] + [i for i in range(len(seqs)) if i != centre]
+            m, kept = O.star_msa([seqs[i] for i in order], rows=True)
+            assert kept == len(seqs)
+            back = {i: q for q, i in enumerate(order)}
+            rows = [bytes(m[back[i]]).decode() for i in range(len(seqs))]
+            got[members[-1]] = O.cons_majority(rows)
+        assert got == c["expected"], ci
