@@ -618,6 +618,17 @@ class Context:
         self._check(self.lib.hite_copy_stats(self._copy_state, out), "hite_copy_stats")
         return tuple(int(x) for x in out)
 
+    def tr_mask(self, max_period=500):
+        """tandem repeats of the resident genome -> N (in place, for every later stage); returns a bool array over the
+        concatenated contigs (True = masked) -- the build's stage where the reference runs TRF (Util.py:2855)"""
+        G = int(self.lib.hite_genome_bases(self.h))
+        bits = np.zeros((G + 31) // 32 + 1, dtype=np.uint32)
+        n = C.c_int64(0)
+        self._check(self.lib.hite_tr_mask(self.h, int(max_period), _p(bits), C.byref(n)), "hite_tr_mask")
+        m = np.unpackbits(bits.view(np.uint8), bitorder="little")[:G].astype(bool)
+        assert int(m.sum()) == n.value
+        return m
+
     def copy_stats_ext(self):
         """copy_stats() + (chains with a long end to extend, the other chains, DP columns of the end extension, 0)"""
         out = (C.c_int64 * 8)()

@@ -473,139 +473,8 @@ __device__ __forceinline__ unsigned chain_at(const unsigned *__restrict__ list, 
     return e < n_long ? list[e] : list[cap - 1 - (e - n_long)];
 }
 
-// >>> ext_align_dev (tests/test_host_compiled.py compiles this block for the host and compares it with the twin)
-#define EXT_B 8
-#define EXT_W (2 * EXT_B + 1)
-#define EXT_PEN 3
-#define EXT_XDROP 40
-#define EXT_INF (1 << 20)
-__device__ __forceinline__ unsigned ext_cand_code(unsigned ch, bool comp) {
-    const unsigned c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
-    return (comp && c < 4u) ? 3u - c : c;
-}
-// ext_align of the twin as a state machine: query bases q[p0], q[p0 + step], ... (n of them; complemented when comp), genome
-// bases g0, g0 + 1, ... (dir = +1) or g0 - 1, g0 - 2, ... (dir = -1), at most jmax of them.  The 17 band cells live in
-// registers (the loops over the band are unrolled), the genome bases under the band as three 17-bit planes that shift by one
-// cell per column: a column costs one new genome base, one query base and ~8 integer operations per cell.  Both sequences
-// are walked one base per column, so the words they come from are kept in registers -- 16 genome bases, 32 mask bits, 4 query
-// bytes per load, each fetched one word ahead of its use (a load per base and column made the kernel a gather benchmark).
-struct ExtState {
-    int D[EXT_W];
-    uint32_t W0, W1, WN;
-    int i, n, best_i, best_t, best_s;
-    unsigned gnext_, qnext_;                // codes of the next column
-    uint32_t gw, gwn, mw, mwn, qw, qwn;     // current / next word of genome bases, mask bits, query bytes
-    int64_t gwi, mwi, qwi;                   // their word indices
-    const uint32_t *q4;                      // the candidate bytes as aligned words (base address rounded down)
-    int64_t p0, g0, jmax;
-    int step, dir;
-    bool comp;
-};
-// code of genome base g (0..3, 4 = not A/C/G/T); g moves by one base per call in direction E.dir
-__device__ __forceinline__ unsigned ext_genome_next(ExtState &E, const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g) {
-    const int64_t wi = g >> 4, mi = g >> 5;
-    if (wi != E.gwi) { E.gw = E.gwn; E.gwi = wi; const int64_t nx = wi + E.dir; E.gwn = bases[nx > 0 ? nx : 0]; }
-    if (mi != E.mwi) { E.mw = E.mwn; E.mwi = mi; const int64_t nx = mi + E.dir; E.mwn = nmask[nx > 0 ? nx : 0]; }
-    const unsigned c = (E.gw >> (2 * (int)(g & 15))) & 3u;
-    return ((E.mw >> (int)(g & 31)) & 1u) ? 4u : c;
-}
-// code of query byte at byte address a (relative to q4); a moves by E.step per call
-__device__ __forceinline__ unsigned ext_query_next(ExtState &E, int64_t a) {
-    const int64_t wi = a >> 2;
-    if (wi != E.qwi) { E.qw = E.qwn; E.qwi = wi; const int64_t nx = wi + E.step; E.qwn = E.q4[nx > 0 ? nx : 0]; }
-    return ext_cand_code((E.qw >> (8 * (int)(a & 3))) & 0xffu, E.comp);
-}
-__device__ __forceinline__ void ext_init(ExtState &E, const uint8_t *__restrict__ q, int64_t p0, int step, bool comp, int n,
-                                         const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g0, int dir, int64_t jmax) {
-    const uintptr_t qa = (uintptr_t)q;
-    E.q4 = (const uint32_t *)(qa & ~(uintptr_t)3);
-    E.p0 = p0 + (int64_t)(qa & 3);           // byte offset of the first query base from q4
-    E.step = step; E.comp = comp; E.n = n; E.g0 = g0; E.dir = dir; E.jmax = jmax;
-#pragma unroll
-    for (int b = 0; b < EXT_W; b++) { const int j = b - EXT_B; E.D[b] = (j >= 0 && j <= jmax) ? j : EXT_INF; }
-    E.best_i = 0; E.best_t = 0; E.best_s = 0; E.i = 1;
-    E.W0 = 0u; E.W1 = 0u; E.WN = (1u << EXT_W) - 1u;
-    E.gnext_ = 4u; E.qnext_ = 4u;
-    if (n < 1) return;
-    // word caches: the first genome base read is number 1 (g0 or g0 - 1), the first query byte p0
-    {
-        const int64_t g = dir > 0 ? g0 : g0 - 1;
-        const int64_t gs = g > 0 ? g : 0;
-        E.gwi = gs >> 4; E.gw = bases[E.gwi]; { const int64_t nx = E.gwi + dir; E.gwn = bases[nx > 0 ? nx : 0]; }
-        E.mwi = gs >> 5; E.mw = nmask[E.mwi]; { const int64_t nx = E.mwi + dir; E.mwn = nmask[nx > 0 ? nx : 0]; }
-        E.qwi = E.p0 >> 2; E.qw = E.q4[E.qwi]; { const int64_t nx = E.qwi + step; E.qwn = E.q4[nx > 0 ? nx : 0]; }
-    }
-    // planes of "column 0": bit b = genome base number j = b - EXT_B (1-based in walking order); bit set in WN = never matches
-#pragma unroll
-    for (int j = 1; j <= EXT_B; j++) {
-        if (j <= jmax) {
-            const unsigned cd = ext_genome_next(E, bases, nmask, dir > 0 ? g0 + j - 1 : g0 - j);
-            E.W0 |= (cd & 1u) << (j + EXT_B); E.W1 |= ((cd >> 1) & 1u) << (j + EXT_B); E.WN &= ~((~(cd >> 2) & 1u) << (j + EXT_B));
-        }
-    }
-    if (1 + EXT_B <= jmax) E.gnext_ = ext_genome_next(E, bases, nmask, dir > 0 ? g0 + EXT_B : g0 - 1 - EXT_B);
-    E.qnext_ = ext_query_next(E, E.p0);
-}
-// one column (E.i <= E.n on entry); returns true when the extension is finished (result in best_i / best_t)
-__device__ __forceinline__ bool ext_step(ExtState &E, const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask) {
-    const int i = E.i;
-    const unsigned gc = E.gnext_, qc = E.qnext_;
-    if (i < E.n) {    // the bases of column i + 1
-        const int64_t j = (int64_t)i + 1 + EXT_B;
-        E.gnext_ = j <= E.jmax ? ext_genome_next(E, bases, nmask, E.dir > 0 ? E.g0 + j - 1 : E.g0 - j) : 4u;
-        E.qnext_ = ext_query_next(E, E.p0 + (int64_t)E.step * i);
-    }
-    E.W0 = (E.W0 >> 1) | ((gc & 1u) << (EXT_W - 1)); E.W1 = (E.W1 >> 1) | (((gc >> 1) & 1u) << (EXT_W - 1)); E.WN = (E.WN >> 1) | ((gc >> 2) << (EXT_W - 1));
-    const uint32_t eq = qc < 4u ? (~(E.W0 ^ (0u - (qc & 1u))) & ~(E.W1 ^ (0u - ((qc >> 1) & 1u))) & ~E.WN) : 0u;
-    // cells with j < 0 need no guard: they start at EXT_INF and every move into them comes from such a cell.  Cells with
-    // j > jmax (beyond the contig) are forced to EXT_INF -- only the rare extension that can reach the contig end pays for it
-    const int64_t hi64 = E.jmax - i + EXT_B;                    // cells with j <= jmax
-    int left = EXT_INF, kmin = 0x7fffffff;
-    if (hi64 >= EXT_W - 1) {
-#pragma unroll
-        for (int b = 0; b < EXT_W; b++) {
-            // min(diag, up, left + 1) = 1 + min(D[b] - match, D[b + 1], left)
-            const int dm = E.D[b] - (int)((eq >> b) & 1u);
-            const int v = 1 + min(min(dm, b + 1 < EXT_W ? E.D[b + 1] : EXT_INF), left);
-            E.D[b] = v;
-            left = v;
-            const int tc = 2 * (b > EXT_B ? b - EXT_B : EXT_B - b) + (b > EXT_B ? 1 : 0);   // ties: |j - i| smallest, then the smaller j
-            const int key = (v << 5) | tc;
-            kmin = key < kmin ? key : kmin;
-        }
-    } else {
-        const int hi = (int)hi64;
-#pragma unroll
-        for (int b = 0; b < EXT_W; b++) {
-            const int dm = E.D[b] - (int)((eq >> b) & 1u);
-            int v = 1 + min(min(dm, b + 1 < EXT_W ? E.D[b + 1] : EXT_INF), left);
-            v = b <= hi ? v : EXT_INF;
-            E.D[b] = v;
-            left = v;
-            const int tc = 2 * (b > EXT_B ? b - EXT_B : EXT_B - b) + (b > EXT_B ? 1 : 0);
-            const int key = (v << 5) | tc;
-            kmin = key < kmin ? key : kmin;
-        }
-    }
-    const int cmin = kmin >> 5;
-    if (cmin >= EXT_INF) return true;
-    const int tcv = kmin & 31;
-    const int tmin = i + ((tcv & 1) ? (tcv >> 1) : -(tcv >> 1));
-    const int sc = i - EXT_PEN * cmin;
-    if (sc >= E.best_s) { E.best_s = sc; E.best_i = i; E.best_t = tmin; }
-    else if (sc < E.best_s - EXT_XDROP) return true;
-    E.i = i + 1;
-    return E.i > E.n;
-}
-__device__ __forceinline__ void ext_align_dev(const uint8_t *__restrict__ q, int64_t p0, int step, bool comp, int n,
-                                              const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g0, int dir,
-                                              int64_t jmax, int *i_out, int *t_out) {
-    ExtState E;
-    ext_init(E, q, p0, step, comp, n, bases, nmask, g0, dir, jmax);
-    if (n >= 1) while (!ext_step(E, bases, nmask)) { }
-    *i_out = E.best_i; *t_out = E.best_t;
-}
-// <<< ext_align_dev
+#include "hite_ext.h"
+using ExtState = ExtStateT<ExtCopyMode>;
 
 // one LANE per (chain, end) task -- even tasks extend to the left of the first anchor, odd ones to the right of the last --
 // and a lane that has finished takes the next task from the queue while its neighbours go on (the lengths run from 0 to

@@ -1,0 +1,183 @@
+// hite_trmask.hip -- tandem-repeat masking of the resident genome: this build's GPU stage where the reference shells out to
+// `trf <file> 2 7 7 80 10 50 500 -f -d -m -h` and continues with the .mask FASTA (run_remove_TR,
+// /root/reference/module/Util.py:2855-2874; filter_tandem_repeats :4672-4697).  TRF is third-party: PARITY UNPINNED; the
+// definition is the header of the twin, oracle/hite_oracle_trf.c (HIP == twin bit for bit; both measured against TRF 4.09's
+// own masks, tests/test_trmask.py).
+//
+//   seed filter: a workgroup owns 4096 bases (256 words of 16 two-bit bases, staged in LDS with the "not A/C/G/T" bits spread
+//     to the same layout); for every period p = 1 .. 500 a thread XORs its word with the word p bases further on (two LDS
+//     reads + a funnel shift) and tests its aligned blocks of 8 positions for "all equal"; periods >= 64 look at every other
+//     word only, which two periods share per trip.  ~20 integer operations per (word, period): 500 periods x G/16 words --
+//     about 9 s per Gbp, once per chunk (TRF: minutes per Gbp and core); not part of any timed step.
+//   extension: the leftmost seed of a run aligns the stretch with itself one period on by the banded end extension of the copy
+//     finder (hite_ext.h, TRF's 2 / 7 / 7 as S = 2 i - 9 cost), in the thread that found the seed (seeds are rare outside arrays);
+//   accepted stretches are OR-ed into a bit map, which is then OR-ed into the genome's "not A/C/G/T" mask: every later stage
+//     sees N where the reference's later stages read the masked FASTA.
+#include "hite_common.h"
+#include "hite_ext.h"
+
+#define TR_MAXEXT 4096
+#define TR_MINSCORE 50
+#define TR_RESEED 2048
+#define TR_TILE 256          // words per workgroup
+#define TR_HALO 34           // words behind the tile a period of <= 500 bases reaches (32) + the funnel's second word + 1
+
+__device__ __forceinline__ int tr_contig_of(const int64_t *__restrict__ coff, int nc, int64_t g) {
+    int lo = 0, hi = nc;
+    while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (coff[mid] <= g) lo = mid; else hi = mid; }
+    return lo;
+}
+// bit k of a 16-bit mask -> bit 2k
+__device__ __forceinline__ uint32_t spread16(uint32_t x) {
+    x &= 0xffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+struct TrTile { uint32_t b[TR_TILE + TR_HALO + 2], nx[TR_TILE + TR_HALO + 2]; };   // index 0 = word w0 - 1
+
+// "mismatch or invalid" flags (even bits) of the 16 positions of word index wi (tile-relative, 1-based on w0 - 1) at period p
+__device__ __forceinline__ uint32_t tr_bad(const TrTile &T, int wi, int p) {
+    const int q = wi + (p >> 4), sh = 2 * (p & 15);
+    const uint32_t sb = __builtin_amdgcn_alignbit(T.b[q + 1], T.b[q], sh), sn = __builtin_amdgcn_alignbit(T.nx[q + 1], T.nx[q], sh);
+    const uint32_t x = T.b[wi] ^ sb;
+    return ((x | (x >> 1)) & 0x55555555u) | T.nx[wi] | sn;
+}
+
+// the stretch around seed block s at period p: extension both ways, acceptance, mask bits
+__device__ void tr_extend(int64_t s, int p, const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                          const int64_t *__restrict__ coff, int nc, uint32_t *__restrict__ trmask) {
+    const int c = tr_contig_of(coff, nc, s);
+    const int64_t cb = coff[c], ce = coff[c + 1];
+    if (s + p > ce) return;
+    int64_t nr = ce - (s + p); if (nr > TR_MAXEXT) nr = TR_MAXEXT; if (nr < 0) nr = 0;
+    int64_t nl = s - cb; if (nl > TR_MAXEXT) nl = TR_MAXEXT;
+    const int lim = p - 1 < EXT_B ? p - 1 : EXT_B;
+    int ir, tr, sr, il, tl, sl;
+    ext_align_dev<ExtTandemMode>(nullptr, s, +1, false, (int)nr, bases, nmask, s + p, +1, ce - (s + p), -lim, EXT_B, &ir, &tr, &sr);
+    ext_align_dev<ExtTandemMode>(nullptr, s - 1, -1, false, (int)nl, bases, nmask, s + p, -1, s + p - cb, -EXT_B, lim, &il, &tl, &sl);
+    if (il + ir <= 0) return;
+    if (sl + sr + 2 * p < TR_MINSCORE) return;
+    if (il + ir < (85 * p + 99) / 100) return;
+    int64_t a = s - il, hi = s + tr - 1 + p;
+    if (hi >= ce) hi = ce - 1;
+    for (int64_t w = a >> 5; w <= (hi >> 5); w++) {
+        const int64_t lo_b = w << 5;
+        uint32_t m = 0xffffffffu;
+        if (a > lo_b) m &= 0xffffffffu << (int)(a - lo_b);
+        if (hi < lo_b + 31) m &= 0xffffffffu >> (int)(lo_b + 31 - hi);
+        atomicOr(&trmask[w], m);
+    }
+}
+
+__global__ void __launch_bounds__(256) tr_seed_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                                      const int64_t *__restrict__ coff, int nc, int64_t G, int max_period,
+                                                      uint32_t *__restrict__ trmask) {
+    __shared__ TrTile T;
+    const int64_t nwords = (G + 15) >> 4;
+    for (int64_t w0 = (int64_t)blockIdx.x * TR_TILE; w0 < nwords; w0 += (int64_t)gridDim.x * TR_TILE) {
+        __syncthreads();
+        for (int k = threadIdx.x; k < TR_TILE + TR_HALO + 2; k += 256) {
+            const int64_t w = w0 - 1 + k;
+            uint32_t b = 0u, nx = 0x55555555u;
+            if (w >= 0 && w < nwords) {
+                b = bases[w];
+                nx = spread16(nmask[w >> 1] >> (16 * (int)(w & 1)));
+                const int64_t rest = G - (w << 4);                 // positions beyond the genome never match
+                if (rest < 16) nx |= 0x55555555u << (2 * (int)rest);
+            }
+            T.b[k] = b; T.nx[k] = nx;
+        }
+        __syncthreads();
+        // item = (period, word): every word for p < 64, every other word for p >= 64 (two periods per trip)
+        const int trips = (max_period < 64 ? max_period : 63) + (max_period >= 64 ? (max_period - 63 + 1) / 2 : 0);
+        for (int it = 0; it < trips; it++) {
+            int p, wl;
+            if (it < 63 && it < max_period) { p = it + 1; wl = threadIdx.x; }
+            else { p = 64 + 2 * (it - 63) + (threadIdx.x >> 7); wl = 2 * (threadIdx.x & 127); if ((w0 + wl) & 1) wl++; }
+            if (p > max_period || wl >= TR_TILE) continue;
+            const int64_t w = w0 + wl;
+            if (w >= nwords) continue;
+            const uint32_t bad = tr_bad(T, wl + 1, p);
+            const int st = p < 32 ? 8 : (p < 64 ? 16 : 32);
+            const int64_t s_base = w << 4;
+#pragma unroll
+            for (int blk = 0; blk < 2; blk++) {
+                if (blk == 1 && st != 8) break;
+                const int64_t s = s_base + 8 * blk;
+                if (s + 8 > G) continue;
+                if (st == 32 && (s & 31)) continue;
+                if ((bad >> (16 * blk)) & 0x5555u) continue;        // not a seed
+                // previous block of the stride: a seed as well -> this one is not the leftmost of its run
+                bool prev;
+                if (st == 8 && blk == 1) prev = (bad & 0x5555u) == 0u;
+                else if (s - st < 0) prev = false;
+                else {
+                    const int pw = (int)(((s - st) >> 4) - (w0 - 1));     // tile index of the previous block's word (>= 0: halo of one word, st <= 32 -> up to 2 words back)
+                    uint32_t pb;
+                    if (pw >= 0) pb = tr_bad(T, pw, p);
+                    else {   // two words back of the tile's first word: from global memory (rare: once per tile and period)
+                        const int64_t pwi = (s - st) >> 4;
+                        const int64_t q = pwi + (p >> 4);
+                        const int sh = 2 * (p & 15);
+                        const uint32_t sb = __builtin_amdgcn_alignbit(bases[q + 1], bases[q], sh);
+                        const uint32_t n0 = spread16(nmask[pwi >> 1] >> (16 * (int)(pwi & 1)));
+                        const uint32_t n1 = spread16(nmask[q >> 1] >> (16 * (int)(q & 1))), n2 = spread16(nmask[(q + 1) >> 1] >> (16 * (int)((q + 1) & 1)));
+                        const uint32_t x = bases[pwi] ^ sb;
+                        pb = ((x | (x >> 1)) & 0x55555555u) | n0 | __builtin_amdgcn_alignbit(n2, n1, sh);
+                    }
+                    prev = ((pb >> (((s - st) & 8) ? 16 : 0)) & 0x5555u) == 0u;
+                }
+                if (prev && (s % TR_RESEED) != 0) continue;
+                tr_extend(s, p, bases, nmask, coff, nc, trmask);
+            }
+        }
+    }
+}
+
+// masked bases -> the genome's "not A/C/G/T" mask; count of newly masked-or-not bases of the tandem mask
+__global__ void tr_apply_kernel(int64_t nw32, const uint32_t *__restrict__ trmask, uint32_t *__restrict__ nmask, unsigned long long *__restrict__ count) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int c = 0;
+    if (i < nw32) { const uint32_t m = trmask[i]; if (m) { nmask[i] |= m; c = __popc(m); } }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(count, (unsigned long long)c);
+}
+
+// Tandem repeats of the resident genome (periods 1 .. max_period, TRF's 2 7 7 scheme, score >= 50) become N for every later
+// stage.  mask_bits_host (optional): (n_bases + 31) / 32 words, bit i & 31 of word i >> 5 = base i of the concatenated contigs
+// is masked -- what the host side needs to write the reference's .mask FASTA.
+extern "C" int hite_tr_mask(hite_ctx *ctx, int32_t max_period, uint32_t *mask_bits_host, int64_t *masked_bases_out) {
+    if (!ctx || !ctx->d_bases || max_period < 1 || max_period > 500) return HITE_EINVAL;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    const int64_t G = ctx->n_bases;
+    const int64_t nw32 = (G + 31) >> 5;
+    uint32_t *trmask = nullptr;
+    unsigned long long *cnt = nullptr;
+    HITE_CHECK(ctx, hipMalloc((void **)&trmask, (size_t)(nw32 + 2) * 4 + 16));
+    hipError_t e = hipMemset(trmask, 0, (size_t)(nw32 + 2) * 4 + 16);
+    cnt = (unsigned long long *)(trmask + nw32 + 2);
+    int rc = HITE_OK;
+    if (e == hipSuccess) {
+        const int64_t nwords = (G + 15) >> 4;
+        int64_t blocks = (nwords + TR_TILE - 1) / TR_TILE;
+        if (blocks > 65536) blocks = 65536;
+        if (blocks < 1) blocks = 1;
+        hipLaunchKernelGGL(tr_seed_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off, ctx->n_contigs, G,
+                           (int)max_period, trmask);
+        hipLaunchKernelGGL(tr_apply_kernel, dim3((unsigned)((nw32 + 255) / 256)), dim3(256), 0, nullptr, nw32, trmask, ctx->d_nmask, cnt);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        unsigned long long n = 0;
+        if (e == hipSuccess) e = hipMemcpy(&n, cnt, 8, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && mask_bits_host) e = hipMemcpy(mask_bits_host, trmask, (size_t)nw32 * 4, hipMemcpyDeviceToHost);
+        if (masked_bases_out) *masked_bases_out = (int64_t)n;
+    }
+    (void)hipFree(trmask);
+    if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hite_tr_mask: %s", hipGetErrorString(e)); rc = HITE_EHIP; }
+    return rc;
+}

@@ -840,15 +840,32 @@ def run_remove_TR(target_file, trf_dir):
     return os.path.join(trf_dir, os.path.basename(target_file) + ".2.7.7.80.10.50.500.mask")
 
 
-def filter_tandem_repeats(repeat_names, repeat_contigs, tmp_output_dir, ref_index, threads):
+def mask_tandem_repeats(names, contigs, device=0, max_period=500):
+    """The build's own tandem-repeat masker (hite_tr_mask; definition oracle/hite_oracle_trf.c) where the reference runs TRF:
+    {name: sequence} -> {name: sequence with tandem repeats as N}.  The resident genome becomes these sequences."""
+    ctx = get_ctx(device)
+    ctx.genome_pack([contigs[n] for n in names])
+    ctx.release_copy_index()
+    _PACKED["path"] = None
+    m = ctx.tr_mask(max_period)
+    out, pos = {}, 0
+    for n in names:
+        a = np.frombuffer(contigs[n].encode(), dtype=np.uint8).copy()
+        a[m[pos:pos + len(a)]] = ord("N")
+        out[n] = a.tobytes().decode()
+        pos += len(a)
+    return out
+
+
+def filter_tandem_repeats(repeat_names, repeat_contigs, tmp_output_dir, ref_index, threads, device=0):
     """Util.py:4672-4697 -- the chunk is cut into files of >= 100 kb (split_and_store_sequences), every file goes through TRF,
     the masked files are concatenated (in file order: the canonical replacement of the reference's as_completed order) into
-    filter_tandem_{ref_index}.fa.  `trf` is an external tool: when it is not installed the chunk passes unmasked
-    and a warning says so."""
+    filter_tandem_{ref_index}.fa.  `trf` is an external tool: when it is installed (and HITE_TR_MASKER is not
+    "gpu") it is called exactly as the reference calls it; otherwise the chunk is masked by the build's own GPU masker
+    (mask_tandem_repeats: same 2 / 7 / 7 scores, periods <= 500, score >= 50) -- the chunk never passes unmasked."""
     out = os.path.join(tmp_output_dir, "filter_tandem_%s.fa" % ref_index)
-    if shutil.which("trf") is None:
-        sys.stderr.write("[hite_amd] trf not found: tandem repeats are NOT masked before the all-vs-all search\n")
-        store_fasta({n: repeat_contigs[n] for n in repeat_names}, out)
+    if shutil.which("trf") is None or os.environ.get("HITE_TR_MASKER", "") == "gpu":
+        store_fasta(mask_tandem_repeats(repeat_names, repeat_contigs, device=device), out)
         return out
     tmp_dir = os.path.join(tmp_output_dir, "trf_filter_%s" % ref_index)
     os.makedirs(tmp_dir, exist_ok=True)

@@ -102,6 +102,14 @@ int hite_sparse_cols_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_msa, const i
                          const int32_t *d_rows, const int32_t *d_cols, const int64_t *d_col_off, int64_t total_cols,
                          uint8_t *d_out, int32_t *d_new_cols, void *stream);
 
+/* ---- tandem-repeat masking --- run_remove_TR / filter_tandem_repeats  Util.py:2855-2874, 4672-4697 (a-2) ---
+ * The reference runs `trf <file> 2 7 7 80 10 50 500 -f -d -m -h` and continues with the .mask FASTA.  This build's own stage
+ * (definition: oracle/hite_oracle_trf.c; TRF is third-party, parity unpinned): stretches of the resident genome that align
+ * with themselves max_period (<= 500) or fewer bases further on with score >= 50 under match 2 / mismatch 7 / indel 7 and
+ * at least 1.85 copies become N for every later stage.  mask_bits_host (optional, (n_bases + 31) / 32 words): bit (i & 31) of
+ * word (i >> 5) = base i of the concatenated contigs is masked.  masked_bases_out (optional): their number. */
+int hite_tr_mask(hite_ctx *ctx, int32_t max_period, uint32_t *mask_bits_host, int64_t *masked_bases_out);
+
 /* ---- column vote --- col_base_map  Util.py:9251-9266 (a-15) --------------------------------
  * counts_out[col_off[i] + c][6] = per-column counts of A,C,G,T,N,'-' over ALL rows of
  * alignment i, with col_off[i] = caller's exclusive scan of cols. */

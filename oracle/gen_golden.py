@@ -805,6 +805,34 @@ def gen_cons_v1(U, tmp):
     dump("cons_v1", cases)
 
 
+def gen_trf_mask(tmp):
+    """TRF 4.09 itself -- the binary the reference bundles (tools/trf409.linux64) run with the reference's command line
+    (Util.py:2859) -- on seeded sequences with planted tandem arrays: the fixture holds the sequences, the planted intervals
+    and TRF's .mask output as intervals.  The build's masker is MEASURED against it (it is not a restatement of TRF)."""
+    import re
+    import shutil
+    import subprocess
+
+    exe = os.path.join(tmp, "trf")
+    shutil.copyfile(os.path.join(ref_harness.REFERENCE_ROOT, "tools", "trf409.linux64"), exe)
+    os.chmod(exe, 0o755)
+    cases = []
+    for seed in (101, 102, 103):
+        seq, planted = casegen.make_tandem_case(seed)
+        d = os.path.join(tmp, "trf_%d" % seed)
+        os.makedirs(d)
+        with open(os.path.join(d, "x.fa"), "w") as f:
+            f.write(">s\n" + seq + "\n")
+        subprocess.run("cd %s && %s x.fa 2 7 7 80 10 50 500 -f -d -m -h > /dev/null 2>&1" % (d, exe), shell=True, check=False)
+        masked = open(os.path.join(d, "x.fa.2.7.7.80.10.50.500.mask")).read().split("\n", 1)[1].replace("\n", "")
+        assert len(masked) == len(seq)
+        iv = [[m.start(), m.end()] for m in re.finditer("N+", masked)]
+        cases.append(dict(seed=seed, seq=seq, planted=planted, trf_masked=iv))
+        print("trf_mask seed %d: %d bases, %d planted arrays, TRF masks %d intervals / %d bases" %
+              (seed, len(seq), len(planted), len(iv), sum(b - a for a, b in iv)))
+    dump("trf_mask", cases)
+
+
 def gen_split_chunks(U, tmp):
     """module/split_genome_chunks.py run as a script (runpy) on small genomes: the reference FASTA is rewritten upper-case in
     place (convertToUpperCase_v1), cut into chr$offset segments (multi_line) and grouped into genome.cut{i}.fa by FASTA-text
@@ -924,7 +952,7 @@ def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -958,6 +986,8 @@ def main():
             gen_bucketing(U, tmp)
         if "consv1" in which:
             gen_cons_v1(U, tmp)
+        if "trf" in which:
+            gen_trf_mask(tmp)
 
 
 if __name__ == "__main__":

@@ -164,12 +164,16 @@ static int contig_of(const int64_t *coff, int nc, int64_t g) {
 #define EXT_MAXLEN 2048   /* an end of more than this many bases beyond the outermost anchor is not extended: the chain is dropped */
 #define EXT_INF 1000000
 static uint8_t comp_of(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
-static int64_t ext_align(const uint8_t *qseg, int64_t n, int dir, const uint8_t *genome, int64_t g0, int64_t gmin, int64_t gmax, int64_t *t_out) {
+/* S(i) = sa * i - sb * C(i), abandoned xdrop below the best: (1, 3, 40) for the copy finder; the tandem-repeat masker
+ * (hite_oracle_trf.c) runs the same programme with TRF's 2 / 7 / 7 as (2, 9, 30).  Only the diagonals dlo <= j - i <= dhi of
+ * the band are used (the copy finder: all 17; the masker keeps the sequence from being aligned with ITSELF). */
+int64_t orc_ext_align_scored(const uint8_t *qseg, int64_t n, int dir, const uint8_t *genome, int64_t g0, int64_t gmin, int64_t gmax,
+                             int sa, int sb, int xdrop, int dlo, int dhi, int64_t *t_out, int64_t *score_out) {
     int prev[2 * EXT_B + 1], cur[2 * EXT_B + 1];
     /* cell (i, j) with j = i + b - EXT_B */
     for (int b = 0; b <= 2 * EXT_B; b++) {
         int64_t j = b - EXT_B;
-        int ok = j >= 0 && (dir > 0 ? g0 + j <= gmax : g0 - j >= gmin);
+        int ok = j >= 0 && j <= dhi && (dir > 0 ? g0 + j <= gmax : g0 - j >= gmin);
         prev[b] = ok ? (int)j : EXT_INF;
     }
     int64_t best_i = 0, best_t = 0, best_s = 0;     /* i = 0: C = 0 (j = 0), S = 0 */
@@ -179,7 +183,7 @@ static int64_t ext_align(const uint8_t *qseg, int64_t n, int dir, const uint8_t 
         for (int b = 0; b <= 2 * EXT_B; b++) {
             int64_t j = i + b - EXT_B;
             int v = EXT_INF;
-            if (j >= 0 && (dir > 0 ? g0 + j <= gmax : g0 - j >= gmin)) {
+            if (j >= 0 && b - EXT_B >= dlo && b - EXT_B <= dhi && (dir > 0 ? g0 + j <= gmax : g0 - j >= gmin)) {
                 if (j >= 1) {
                     uint8_t gc = dir > 0 ? genome[g0 + j - 1] : genome[g0 - j];
                     int d = prev[b] + ((qc == gc && code_of(qc) >= 0) ? 0 : 1);
@@ -197,12 +201,16 @@ static int64_t ext_align(const uint8_t *qseg, int64_t n, int dir, const uint8_t 
         }
         memcpy(prev, cur, sizeof prev);
         if (cmin >= EXT_INF) break;                 /* the band left the contig: nothing further is reachable */
-        int64_t sc = i - (int64_t)EXT_PEN * cmin;
+        int64_t sc = (int64_t)sa * i - (int64_t)sb * cmin;
         if (sc >= best_s) { best_s = sc; best_i = i; best_t = tmin; }
-        else if (sc < best_s - EXT_XDROP) break;
+        else if (sc < best_s - xdrop) break;
     }
     *t_out = best_t;
+    if (score_out) *score_out = best_s;
     return best_i;
+}
+static int64_t ext_align(const uint8_t *qseg, int64_t n, int dir, const uint8_t *genome, int64_t g0, int64_t gmin, int64_t gmax, int64_t *t_out) {
+    return orc_ext_align_scored(qseg, n, dir, genome, g0, gmin, gmax, 1, EXT_PEN, EXT_XDROP, -EXT_B, EXT_B, t_out, NULL);
 }
 
 /* ext_align for the tests (tests/test_host_compiled.py: the HIP device function compiled for the host against this one) */

@@ -401,3 +401,35 @@ def msa_outcome_cases(te_type, seed0):
     for c in out:
         c.setdefault("plant", 1)
     return out
+
+
+# ----------------------------------------------------------------------------------
+# sequences with planted tandem arrays (input of the tandem-repeat masker / of TRF)
+# ----------------------------------------------------------------------------------
+def make_tandem_case(seed, G=120_000, n_arr=70):
+    """-> (sequence, [[start, end, period, copies, substitution rate per copy, indel rate]]): random background with tandem
+    arrays of period 1 .. 500, 1.6 .. 25 copies, 0-15 % substitutions and 0-2 % indels per copy, 300-1500 bases apart"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seq = rng.choice(acgt, size=G)
+    pos, planted = 3000, []
+    while pos < G - 14000 and len(planted) < n_arr:
+        p = int(rng.choice([1, 2, 3, 4, 5, 6, 7, 9, 12, 15, 21, 33, 48, 77, 120, 180, 260, 390, 500]))
+        copies = float(rng.choice([1.6, 2.0, 2.5, 3, 4, 6, 10, 25]))
+        div = float(rng.choice([0, 0, 0.03, 0.08, 0.15]))
+        ind = float(rng.choice([0, 0, 0.005, 0.02]))
+        L = max(int(p * copies), int(rng.integers(20, 70)) if p < 8 else 0)
+        unit = rng.choice(acgt, size=p)
+        arr = []
+        while len(arr) < L:
+            for ch in unit:
+                x = rng.random()
+                if x < ind / 2:
+                    continue
+                if x < ind:
+                    arr.append(int(rng.choice(acgt)))
+                arr.append(int(ch) if rng.random() >= div else int(rng.choice(acgt)))
+        seq[pos:pos + L] = arr[:L]
+        planted.append([pos, pos + L, p, copies, div, ind])
+        pos += L + int(rng.integers(300, 1500))
+    return seq.tobytes().decode(), planted

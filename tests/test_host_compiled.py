@@ -40,16 +40,102 @@ def _build(tmp_path, name, body, wrapper):
     return C.CDLL(str(so))
 
 
+def _ext_lib(tmp_path):
+    body = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_ext.h"), "ext_align_dev")
+    return _build(tmp_path, "ext", body, r"""
+extern "C" void host_ext(const uint8_t *q, int64_t p0, int step, int comp, int n, const uint32_t *bases, const uint32_t *nmask,
+                         int64_t g0, int dir, int64_t jmax, int *i_out, int *t_out) {
+    int s;
+    ext_align_dev<ExtCopyMode>(q, p0, step, comp != 0, n, bases, nmask, g0, dir, jmax, -EXT_B, EXT_B, i_out, t_out, &s);
+}
+extern "C" void host_ext_tandem(int64_t p0, int step, int n, const uint32_t *bases, const uint32_t *nmask,
+                                int64_t g0, int dir, int64_t jmax, int dlo, int dhi, int *i_out, int *t_out, int *s_out) {
+    ext_align_dev<ExtTandemMode>(nullptr, p0, step, false, n, bases, nmask, g0, dir, jmax, dlo, dhi, i_out, t_out, s_out);
+}
+""")
+
+
+def _pack(genome):
+    G = len(genome)
+    codes = np.zeros(G + 64, np.uint32)
+    lut = np.full(256, 0, np.uint32)
+    lut[[65, 67, 71, 84]] = [0, 1, 2, 3]
+    codes[:G] = lut[genome]
+    bases = np.zeros((G + 64) // 16 + 2, np.uint32)
+    for k in range(16):
+        part = codes[k::16]
+        bases[:len(part)] |= part << np.uint32(2 * k)
+    nm = np.zeros((G + 64) // 32 + 2, np.uint32)
+    isn = np.zeros(G + 64, np.uint32)
+    isn[:G] = ~np.isin(genome, [65, 67, 71, 84])
+    for k in range(32):
+        part = isn[k::32]
+        nm[:len(part)] |= part << np.uint32(k)
+    return bases, nm
+
+
+def test_ext_align_tandem_mode_vs_twin(tmp_path):
+    """the same device function in the tandem-repeat masker's mode (query = the packed genome itself, TRF's 2 / 7 / 7 as
+    S = 2 i - 9 cost, diagonals that pair a base with itself excluded) == orc_ext_align_scored"""
+    lib = _ext_lib(tmp_path)
+    L = O.lib()
+    L.orc_ext_align_scored.restype = C.c_int64
+    rng = np.random.default_rng(8)
+    n_pos = 0
+    for case in range(300):
+        G = int(rng.integers(200, 3000))
+        genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=G)
+        p = int(rng.choice([1, 2, 3, 5, 7, 8, 9, 12, 20, 33, 77, 150]))
+        a0 = int(rng.integers(20, G // 2))
+        copies = float(rng.choice([1.5, 2, 3, 6, 12]))
+        Lr = min(int(p * copies) + int(rng.integers(0, 30)), G - a0 - 10)
+        unit = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=p)
+        arr = []
+        div, ind = float(rng.choice([0, 0.03, 0.1])), float(rng.choice([0, 0.01, 0.03]))
+        while len(arr) < Lr:
+            for ch in unit:
+                x = rng.random()
+                if x < ind / 2:
+                    continue
+                if x < ind:
+                    arr.append(int(rng.choice([65, 67, 71, 84])))
+                arr.append(int(ch) if rng.random() >= div else int(rng.choice([65, 67, 71, 84])))
+        genome[a0:a0 + Lr] = arr[:Lr]
+        if case % 9 == 0:
+            genome[rng.integers(0, G, size=2)] = ord("N")
+        bases, nm = _pack(genome)
+        s = a0 + int(rng.integers(0, max(1, Lr // 2)))
+        cb, ce = (0, G) if case % 4 else (max(0, s - int(rng.integers(0, 60))), min(G, s + p + int(rng.integers(0, 200))))
+        lim = min(p - 1, 8)
+        for d in (+1, -1):
+            if d > 0:
+                n = max(0, min(ce - (s + p), 4096))
+                seg = genome[s:s + n].copy()
+                dlo, dhi = -lim, 8
+            else:
+                n = max(0, min(s - cb, 4096))
+                seg = genome[s - n:s][::-1].copy()
+                dlo, dhi = -8, lim
+            if s + p > ce:
+                continue
+            t_ref, s_ref = C.c_int64(0), C.c_int64(0)
+            gbuf = np.ascontiguousarray(genome)
+            segb = np.ascontiguousarray(np.concatenate([seg, np.zeros(1, np.uint8)]))
+            i_ref = L.orc_ext_align_scored(segb.ctypes.data_as(O.u8p), C.c_int64(n), d, gbuf.ctypes.data_as(O.u8p), C.c_int64(s + p), C.c_int64(cb),
+                                           C.c_int64(ce), 2, 9, 30, dlo, dhi, C.byref(t_ref), C.byref(s_ref))
+            jmax = (ce - (s + p)) if d > 0 else (s + p - cb)
+            io, to, so = C.c_int(0), C.c_int(0), C.c_int(0)
+            lib.host_ext_tandem(C.c_int64(s if d > 0 else s - 1), d, n, bases.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                nm.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(s + p), d, C.c_int64(jmax), dlo, dhi, C.byref(io), C.byref(to), C.byref(so))
+            assert (io.value, to.value, so.value) == (int(i_ref), int(t_ref.value), int(s_ref.value)), (case, p, d, s, n, io.value, to.value, so.value, i_ref, t_ref.value, s_ref.value)
+            n_pos += i_ref > 20
+    assert n_pos > 100
+
+
 def test_ext_align_device_function_vs_twin(tmp_path):
     """chain end extension (hite_copies.hip:ext_align_dev) == oracle/hite_oracle_copies.c:ext_align: aligned bases and genome
     bases used, both directions, both strands, contig borders inside the band, N bases, unrelated sequence (x-drop)"""
-    body = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_copies.hip"), "ext_align_dev")
-    lib = _build(tmp_path, "ext", body, r"""
-extern "C" void host_ext(const uint8_t *q, int64_t p0, int step, int comp, int n, const uint32_t *bases, const uint32_t *nmask,
-                         int64_t g0, int dir, int64_t jmax, int *i_out, int *t_out) {
-    ext_align_dev(q, p0, step, comp != 0, n, bases, nmask, g0, dir, jmax, i_out, t_out);
-}
-""")
+    lib = _ext_lib(tmp_path)
     L = O.lib()
     L.orc_ext_align.restype = C.c_int64
     rng = np.random.default_rng(7)
