@@ -131,7 +131,7 @@ __global__ void __launch_bounds__(256) tr_seed_kernel(const uint32_t *__restrict
                     }
                     prev = ((pb >> (((s - st) & 8) ? 16 : 0)) & 0x5555u) == 0u;
                 }
-                if (prev && (s % TR_RESEED) != 0) continue;
+                if (prev && (s % TR_RESEED) != 0 && s - st >= coff[tr_contig_of(coff, nc, s)]) continue;   // (a run may cross a contig border)
                 tr_extend(s, p, bases, nmask, coff, nc, trmask);
             }
         }

@@ -11,7 +11,8 @@
  * (500, TRF's MaxPeriod) position i MATCHES when i + p < G and bases i and i + p are the same one of A C G T.
  *   Seeds: aligned blocks of 8 positions [s, s + 8), s a multiple of stride(p) (8 for p < 32, 16 for p < 64, else 32), whose
  *   8 positions all match.  A seed is extended only when the block at s - stride(p) is not a seed as well (the leftmost of a run).
- *   A seed is extended when the block at s - stride(p) is not a seed as well (the leftmost of a run) or s is a multiple of
+ *   A seed is extended when the block at s - stride(p) is not a seed as well or lies before the seed's contig (the leftmost of
+ *   a run) or s is a multiple of
  *   TR_RESEED = 2048 (runs longer than one extension are covered piece by piece).
  *   Extension inside the seed's contig [cb, ce): the sequence from s is aligned with ITSELF p bases further on by the banded
  *   end extension of the copy finder (orc_ext_align_scored, hite_oracle_copies.c: unit-cost edit distance in a band of +-8
@@ -67,9 +68,11 @@ int64_t orc_tr_mask(const uint8_t *genome, const int64_t *contig_off, int nconti
     for (int p = 1; p <= max_period; p++) {
         const int st = tr_stride(p);
         for (int64_t s = 0; s + 8 <= G; s += st) {
-            if (!seed_at(code, G, s, p) || (seed_at(code, G, s - st, p) && (s % TR_RESEED) != 0)) continue;
+            if (!seed_at(code, G, s, p)) continue;
             const int c = contig_of64(contig_off, ncontig, s);
             const int64_t cb = contig_off[c], ce = contig_off[c + 1];
+            /* the leftmost seed of a run INSIDE its contig (a run may cross a contig border in the filter's eyes) */
+            if (s - st >= cb && seed_at(code, G, s - st, p) && (s % TR_RESEED) != 0) continue;
             if (s + p > ce) continue;                      /* the partner of the seed lies in the next contig */
             int64_t nr = ce - (s + p);                     /* query bases available: the partner s + p + i must stay inside the contig */
             if (nr > TR_MAXEXT) nr = TR_MAXEXT;
