@@ -186,8 +186,10 @@ def test_c2_copy_finder_recall_precision(c2):
     print("copy finder: recall %.4f of %d planted full-length copies (%.4f of the %d within 15 %% of the candidate), precision %.4f of %d copies found"
           % (recall, n_truth, near_recall, n_near, precision, n_found))
     assert n_truth > 10_000 and n_found > 10_000 and n_near > 3_000
-    assert near_recall >= 0.78                              # measured r02: 0.833 (profiles/r02_scale_tests.txt)
-    assert recall >= 0.57                                   # measured r02: 0.622 over all pairs, up to 30 % apart: (w=10, k=15) minimizers lose the far ones
+    # round 3 (chains extended base by base to the candidate ends + the reference's two 95 % filters, Util.py:8008-8022):
+    # measured 0.923 / 0.838 / 1.000 (profiles/r03_scale_tests.txt); round 2 ("anchor span >= 80 %"): 0.833 / 0.622 / 1.000
+    assert near_recall >= 0.90
+    assert recall >= 0.75                                   # over all pairs, up to 30 % apart: (w=10, k=15) minimizers lose the far ones
     assert precision >= 0.97
 
 
@@ -195,8 +197,8 @@ def test_c2_te_calls_have_the_planted_boundaries(c2):
     n_tir_cand, called, checked, exact, near = boundary_stats(c2)
     print("fine stage: %d TIR candidates (boundaries off by up to 30 bp on input), %d judged TE; of %d checked: both ends exact %d, within 3 bp %d"
           % (n_tir_cand, called, checked, exact, near))
-    assert called >= 0.50 * n_tir_cand                      # measured r02: 0.585
-    assert exact >= 0.40 * checked and near >= 0.65 * checked   # measured r02: 0.48 / 0.74 (judge_boundary_v5's own TSD / homology choices)
+    assert called >= 0.58 * n_tir_cand                      # measured r03: 0.661 (r02: 0.585 -- more copies per candidate found)
+    assert exact >= 0.45 * checked and near >= 0.72 * checked   # measured r03: 0.535 / 0.816 (r02: 0.48 / 0.74; judge_boundary_v5's own TSD / homology choices)
 
 
 def test_c2_coarse_stage_recovers_the_families(c2):
@@ -238,7 +240,7 @@ def test_c3_fine_stage_matches_oracle_chain():
         n_tir_cand, called, checked, exact, near = boundary_stats(R)
         print("C3: %d TIR candidates, %d judged TE; of %d checked: both ends exact %d, within 3 bp %d; %d TE calls in all" %
               (n_tir_cand, called, checked, exact, near, int((R["calls"]["is_te"] != 0).sum())))
-        assert called >= 0.50 * n_tir_cand and exact >= 0.40 * checked and near >= 0.65 * checked
+        assert called >= 0.58 * n_tir_cand and exact >= 0.45 * checked and near >= 0.72 * checked    # measured r03: 0.673 / 0.556 / 0.826
         st = R["align"]
         assert st["dropped"] == 0 and st["certified"] >= 0.65 * st["pairs"]   # measured r02: 0.74 (exact_cap 8; 0.90 with 16)
     finally:
