@@ -27,6 +27,9 @@
 #define C_MINANCH 3
 #define C_MAXCOPY 300
 #define HS_INVALID 0xffffffffu
+#define C_SUB_EDGE 256     // candidate minimizers: all within this many bases of either end are looked up,
+#define C_SUB_UNIT 1024    // of the interior every S-th (by hash), S = min(C_SUB_MAX, length / C_SUB_UNIT)
+#define C_SUB_MAX 4
 #define DIRBITS 26
 #define DBIAS 65536ll
 
@@ -245,6 +248,11 @@ __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const ui
                         if (u != HS_INVALID && (mprev < 0 || (u >> 1) < (hprev >> 1))) { mprev = lp - 1 + i; hprev = u; }
                     }
                     want = m >= 0 && !(lp > 0 && mprev == m);
+                    // sampling of the candidate's minimizers (definition: cand_minimizer_kept of the twin)
+                    if (want && L >= 2 * C_SUB_UNIT && m >= C_SUB_EDGE && m + CK <= L - C_SUB_EDGE) {
+                        const unsigned S = L / C_SUB_UNIT > C_SUB_MAX ? C_SUB_MAX : L / C_SUB_UNIT;
+                        want = ((h >> 1) % S) == 0u;
+                    }
                 }
                 const unsigned long long bm = __ballot(want);
                 if (lane == 0) s_cnt[w] = __popcll(bm);

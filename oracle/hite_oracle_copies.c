@@ -15,6 +15,7 @@
  *   (hs >> 1, position); the minimizers of a sequence are the distinct window minimizers
  *   (sequences with fewer than W k-mers form one window).
  *   Index = genome minimizers sorted by (hs, position).  For every candidate minimizer the index
+ *   (of those kept by the sampling rule, cand_minimizer_kept below) the index
  *   entries with the same hs >> 1 are its occurrences (skipped when more than MAXOCC = 2000);
  *   an occurrence gives a hit: rel = strand_q ^ strand_g, qo = rel ? Lq - qpos - K : qpos,
  *   d = gpos - qo.  Hits are sorted by (candidate, rel, d); a new cluster starts when candidate, rel
@@ -117,6 +118,22 @@ static int cmp_mini(const void *a, const void *b) {
     if (x->hs != y->hs) return x->hs < y->hs ? -1 : 1;
     if (x->pos != y->pos) return x->pos < y->pos ? -1 : 1;
     return 0;
+}
+
+/* Sampling of the CANDIDATE's minimizers (the index keeps every genome minimizer): a chain needs three anchors and is extended
+ * base by base, so the hundreds of anchors a long candidate has with each of its copies only feed the sort.  All minimizers
+ * within SUB_EDGE bases of either end are kept (the extension starts at the outermost anchors); of the interior, candidates of
+ * >= 2 * SUB_UNIT bases keep those with (hs >> 1) % S == 0, S = min(SUB_MAX, Lq / SUB_UNIT).  Measured (40 Mbp, 100 TIR + 100
+ * LTR families): hits -57 %, recall of copies within 15 % of the candidate unchanged (0.940), over all pairs 0.889 -> 0.855. */
+#define SUB_EDGE 256
+#define SUB_UNIT 1024
+#define SUB_MAX 4
+static int cand_minimizer_kept(int64_t Lq, int64_t pos, uint32_t hs) {
+    int64_t S = Lq / SUB_UNIT;
+    if (S > SUB_MAX) S = SUB_MAX;
+    if (S <= 1) return 1;
+    if (pos < SUB_EDGE || pos + CK > Lq - SUB_EDGE) return 1;
+    return ((hs >> 1) % (uint32_t)S) == 0;
 }
 
 typedef struct { int32_t c, rel; int64_t d; int32_t qo; int64_t gpos; } hit_t;
@@ -252,6 +269,7 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
         minimizers(q, Lq, 0, qm);
         for (int64_t t = 0; t < nm; t++) {
             uint32_t h31 = qm[t].hs >> 1;
+            if (!cand_minimizer_kept(Lq, qm[t].pos, qm[t].hs)) continue;
             /* lower bound of hs >= h31 << 1 */
             int64_t lo = 0, hi = M;
             while (lo < hi) { int64_t mid = (lo + hi) / 2; if ((idx[mid].hs >> 1) < h31) lo = mid + 1; else hi = mid; }
