@@ -924,7 +924,14 @@ __global__ void __launch_bounds__(256) align_stats_kernel(int64_t total_rows, co
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
     if (g < total_rows) {
-        if (strips[g] <= 0) { if (row_dead) row_dead[g] = 0; }
+        if (strips[g] <= 0) {
+            // a centre -- or an EMPTY non-centre row (the _dev entry points do not validate lengths): that one is dropped like a
+            // row the aligner could not place, instead of reaching the layout with an ops row nobody wrote
+            const bool empty_row = g != P.row_first[P.row_cand[g]];
+            if (empty_row) { P.st[g] = 2; P.U[g] = -1; P.kst[g] = -1; P.lvl[g] = 0; v[0] = 1ull; v[4] = 1ull; }
+            if (row_dead) row_dead[g] = empty_row;
+            if (empty_row && cand_status) atomicExch(&cand_status[P.row_cand[g]], 2);
+        }
         else {
             const int st = P.st[g];
             v[0] = 1ull;

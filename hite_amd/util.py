@@ -593,19 +593,18 @@ SEED_MAX_SEGMENTS = 65000  # sequences per all-vs-all call (the seeding stage ad
 def ninja_stand_in(rows):
     """The build's stand-in for Ninja's re-clustering of an aligned cluster (Util.py:12468-12474; Ninja is an external tool,
     absent: PARITY UNPINNED).  Leader clustering on the aligned rows: a row joins the first earlier leader it differs from
-    in <= 20 % of the columns where both have a base -- at least half of the shorter row's bases -- (Ninja cuts its
+    in <= 20 % of the columns where either has a base (a base against a gap is a difference; Ninja cuts its
     neighbour-joining tree at distance 0.2), else it becomes a leader.  rows: 2-D uint8 alignment -> list of lists of row indices (sub-clusters in order of their leaders)."""
     rows = np.asarray(rows)
     leaders, members = [], []
-    bases = (rows != 45).sum(axis=1)
     for r in range(rows.shape[0]):
         placed = False
         for k, l in enumerate(leaders):
-            both = (rows[r] != 45) & (rows[l] != 45)
-            n = int(both.sum())
-            # (two rows that share fewer columns than half the shorter one are not compared: unrelated members of a cluster
-            # end up side by side in the star alignment, not on top of each other)
-            if 2 * n >= min(int(bases[r]), int(bases[l])) and n > 0 and int(((rows[r] != rows[l]) & both).sum()) <= NINJA_CUTOFF * n:
+            either = (rows[r] != 45) | (rows[l] != 45)
+            n = int(either.sum())
+            # a base against a gap counts like a base against another base (the star alignment threads a short unrelated
+            # member through the centre with gaps wherever that makes bases agree: its aligned bases alone look similar)
+            if n > 0 and int(((rows[r] != rows[l]) & either).sum()) <= NINJA_CUTOFF * n:
                 members[k].append(r)
                 placed = True
                 break

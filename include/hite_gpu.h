@@ -280,7 +280,9 @@ int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8
 /* ---- star alignment: this build's GPU-native stage where the reference runs the external
  * `mafft --preservecase --quiet --thread 1` (Util.py:10416; third-party, unpinned, absent -> parity unpinned against
  * mafft itself).  Definition of the stage: every row is aligned to the centre (first row of the candidate) by the
- * optimal global alignment under unit costs, canonical traceback diagonal > up > left -- the textbook full-matrix
+ * optimal global alignment under the costs mismatch 1, gap 3 per base (two bases match only when they are the same
+ * upper-case A, C, G or T: callers that may hold lower-case sequence upper-case it first, as hite_amd/util.py does --
+ * mafft --preservecase compares case-insensitively), canonical traceback diagonal > up > left -- the textbook full-matrix
  * programme of oracle/hite_oracle_nw.c; insertion blocks are left-justified.  The device computes it with a banded
  * bit-parallel aligner that CERTIFIES its result (twin: oracle/hite_oracle_msa.c, byte-exact): a certified row is the
  * alignment of the definition, a row without certificate is a valid alignment whose cost bounds the optimum from above.
