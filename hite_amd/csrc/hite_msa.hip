@@ -462,6 +462,9 @@ extern "C" int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uin
     P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff;
     Q.last_extra = d_last_extra; Q.lay = ctx->d_msa_lay;
     if (!Q.lay) return HITE_EINVAL;
+    // (round 3 measured a positions-outer form -- a thread owns four centre positions, keeps their layout words in registers
+    // and walks the rows four at a time, 8-byte ops loads, 4-byte base loads and stores: half the traffic and a third of
+    // the instructions of this kernel, and twice its time (3.9 + 13.1 ms against 1.9 + 6.4 ms per C3 step); not kept)
     hipLaunchKernelGGL(star_fill_sparse_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
     HITE_CHECK(ctx, hipGetLastError());
     return HITE_OK;

@@ -22,6 +22,7 @@
 #define TR_TILE 256          // words per workgroup
 #define TR_HALO 34           // words behind the tile a period of <= 500 bases reaches (32) + the funnel's second word + 1
 
+// >>> tr_seed (tests/test_host_compiled.py compiles this block for the host and runs it thread by thread against the twin)
 __device__ __forceinline__ int tr_contig_of(const int64_t *__restrict__ coff, int nc, int64_t g) {
     int lo = 0, hi = nc;
     while (hi - lo > 1) { int mid = (lo + hi) >> 1; if (coff[mid] <= g) lo = mid; else hi = mid; }
@@ -36,13 +37,28 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
     x = (x | (x << 1)) & 0x55555555u;
     return x;
 }
+__device__ __forceinline__ uint32_t tr_funnel(uint32_t hi, uint32_t lo, int sh) { return sh ? (lo >> sh) | (hi << (32 - sh)) : lo; }
 
 struct TrTile { uint32_t b[TR_TILE + TR_HALO + 2], nx[TR_TILE + TR_HALO + 2]; };   // index 0 = word w0 - 1
+
+// entry k of the tile of the workgroup that owns words w0 .. w0 + TR_TILE - 1
+__device__ __forceinline__ void tr_tile_load(TrTile &T, int k, int64_t w0, int64_t nwords, int64_t G, const uint32_t *__restrict__ bases,
+                                             const uint32_t *__restrict__ nmask) {
+    const int64_t w = w0 - 1 + k;
+    uint32_t b = 0u, nx = 0x55555555u;
+    if (w >= 0 && w < nwords) {
+        b = bases[w];
+        nx = spread16(nmask[w >> 1] >> (16 * (int)(w & 1)));
+        const int64_t rest = G - (w << 4);                 // positions beyond the genome never match
+        if (rest < 16) nx |= 0x55555555u << (2 * (int)rest);
+    }
+    T.b[k] = b; T.nx[k] = nx;
+}
 
 // "mismatch or invalid" flags (even bits) of the 16 positions of word index wi (tile-relative, 1-based on w0 - 1) at period p
 __device__ __forceinline__ uint32_t tr_bad(const TrTile &T, int wi, int p) {
     const int q = wi + (p >> 4), sh = 2 * (p & 15);
-    const uint32_t sb = __builtin_amdgcn_alignbit(T.b[q + 1], T.b[q], sh), sn = __builtin_amdgcn_alignbit(T.nx[q + 1], T.nx[q], sh);
+    const uint32_t sb = tr_funnel(T.b[q + 1], T.b[q], sh), sn = tr_funnel(T.nx[q + 1], T.nx[q], sh);
     const uint32_t x = T.b[wi] ^ sb;
     return ((x | (x >> 1)) & 0x55555555u) | T.nx[wi] | sn;
 }
@@ -73,68 +89,63 @@ __device__ void tr_extend(int64_t s, int p, const uint32_t *__restrict__ bases, 
     }
 }
 
+// trip `it` of thread `tid` of the workgroup that owns words w0 ..: one (period, word) item -- every word for p < 64, every
+// other word for p >= 64 (two periods per trip)
+__device__ __forceinline__ void tr_item(const TrTile &T, int tid, int it, int64_t w0, int64_t nwords, int64_t G, int max_period,
+                                        const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                        const int64_t *__restrict__ coff, int nc, uint32_t *__restrict__ trmask) {
+    int p, wl;
+    if (it < 63 && it < max_period) { p = it + 1; wl = tid; }
+    else { p = 64 + 2 * (it - 63) + (tid >> 7); wl = 2 * (tid & 127); }     // (w0 is even: the tile starts on a 32-base boundary)
+    if (p > max_period || wl >= TR_TILE) return;
+    const int64_t w = w0 + wl;
+    if (w >= nwords) return;
+    const uint32_t bad = tr_bad(T, wl + 1, p);
+    const int st = p < 32 ? 8 : (p < 64 ? 16 : 32);
+    const int64_t s_base = w << 4;
+    for (int blk = 0; blk < 2; blk++) {
+        if (blk == 1 && st != 8) break;
+        const int64_t s = s_base + 8 * blk;
+        if (s + 8 > G) continue;
+        if ((bad >> (16 * blk)) & 0x5555u) continue;        // not a seed
+        // previous block of the stride: a seed as well -> this one is not the leftmost of its run
+        bool prev;
+        if (st == 8 && blk == 1) prev = (bad & 0x5555u) == 0u;
+        else if (s - st < 0) prev = false;
+        else {
+            const int64_t pwi = (s - st) >> 4;                      // the previous block's word: at most two words back
+            const int pw = (int)(pwi - (w0 - 1));                    // its tile index (the tile starts one word early)
+            uint32_t pb;
+            if (pw >= 0) pb = tr_bad(T, pw, p);
+            else {   // two words back of the tile's first word: from global memory (once per tile and period)
+                const int64_t q = pwi + (p >> 4);
+                const int sh = 2 * (p & 15);
+                const uint32_t sb = tr_funnel(bases[q + 1], bases[q], sh);
+                const uint32_t n0 = spread16(nmask[pwi >> 1] >> (16 * (int)(pwi & 1)));
+                const uint32_t n1 = spread16(nmask[q >> 1] >> (16 * (int)(q & 1))), n2 = spread16(nmask[(q + 1) >> 1] >> (16 * (int)((q + 1) & 1)));
+                const uint32_t x = bases[pwi] ^ sb;
+                pb = ((x | (x >> 1)) & 0x55555555u) | n0 | tr_funnel(n2, n1, sh);
+            }
+            prev = ((pb >> (((s - st) & 8) ? 16 : 0)) & 0x5555u) == 0u;
+        }
+        if (prev && (s % TR_RESEED) != 0 && s - st >= coff[tr_contig_of(coff, nc, s)]) continue;   // (a run may cross a contig border)
+        tr_extend(s, p, bases, nmask, coff, nc, trmask);
+    }
+}
+__device__ __forceinline__ int tr_trips(int max_period) { return (max_period < 64 ? max_period : 63) + (max_period >= 64 ? (max_period - 63 + 1) / 2 : 0); }
+// <<< tr_seed
+
 __global__ void __launch_bounds__(256) tr_seed_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
                                                       const int64_t *__restrict__ coff, int nc, int64_t G, int max_period,
                                                       uint32_t *__restrict__ trmask) {
     __shared__ TrTile T;
     const int64_t nwords = (G + 15) >> 4;
+    const int trips = tr_trips(max_period);
     for (int64_t w0 = (int64_t)blockIdx.x * TR_TILE; w0 < nwords; w0 += (int64_t)gridDim.x * TR_TILE) {
         __syncthreads();
-        for (int k = threadIdx.x; k < TR_TILE + TR_HALO + 2; k += 256) {
-            const int64_t w = w0 - 1 + k;
-            uint32_t b = 0u, nx = 0x55555555u;
-            if (w >= 0 && w < nwords) {
-                b = bases[w];
-                nx = spread16(nmask[w >> 1] >> (16 * (int)(w & 1)));
-                const int64_t rest = G - (w << 4);                 // positions beyond the genome never match
-                if (rest < 16) nx |= 0x55555555u << (2 * (int)rest);
-            }
-            T.b[k] = b; T.nx[k] = nx;
-        }
+        for (int k = threadIdx.x; k < TR_TILE + TR_HALO + 2; k += 256) tr_tile_load(T, k, w0, nwords, G, bases, nmask);
         __syncthreads();
-        // item = (period, word): every word for p < 64, every other word for p >= 64 (two periods per trip)
-        const int trips = (max_period < 64 ? max_period : 63) + (max_period >= 64 ? (max_period - 63 + 1) / 2 : 0);
-        for (int it = 0; it < trips; it++) {
-            int p, wl;
-            if (it < 63 && it < max_period) { p = it + 1; wl = threadIdx.x; }
-            else { p = 64 + 2 * (it - 63) + (threadIdx.x >> 7); wl = 2 * (threadIdx.x & 127); if ((w0 + wl) & 1) wl++; }
-            if (p > max_period || wl >= TR_TILE) continue;
-            const int64_t w = w0 + wl;
-            if (w >= nwords) continue;
-            const uint32_t bad = tr_bad(T, wl + 1, p);
-            const int st = p < 32 ? 8 : (p < 64 ? 16 : 32);
-            const int64_t s_base = w << 4;
-#pragma unroll
-            for (int blk = 0; blk < 2; blk++) {
-                if (blk == 1 && st != 8) break;
-                const int64_t s = s_base + 8 * blk;
-                if (s + 8 > G) continue;
-                if (st == 32 && (s & 31)) continue;
-                if ((bad >> (16 * blk)) & 0x5555u) continue;        // not a seed
-                // previous block of the stride: a seed as well -> this one is not the leftmost of its run
-                bool prev;
-                if (st == 8 && blk == 1) prev = (bad & 0x5555u) == 0u;
-                else if (s - st < 0) prev = false;
-                else {
-                    const int pw = (int)(((s - st) >> 4) - (w0 - 1));     // tile index of the previous block's word (>= 0: halo of one word, st <= 32 -> up to 2 words back)
-                    uint32_t pb;
-                    if (pw >= 0) pb = tr_bad(T, pw, p);
-                    else {   // two words back of the tile's first word: from global memory (rare: once per tile and period)
-                        const int64_t pwi = (s - st) >> 4;
-                        const int64_t q = pwi + (p >> 4);
-                        const int sh = 2 * (p & 15);
-                        const uint32_t sb = __builtin_amdgcn_alignbit(bases[q + 1], bases[q], sh);
-                        const uint32_t n0 = spread16(nmask[pwi >> 1] >> (16 * (int)(pwi & 1)));
-                        const uint32_t n1 = spread16(nmask[q >> 1] >> (16 * (int)(q & 1))), n2 = spread16(nmask[(q + 1) >> 1] >> (16 * (int)((q + 1) & 1)));
-                        const uint32_t x = bases[pwi] ^ sb;
-                        pb = ((x | (x >> 1)) & 0x55555555u) | n0 | __builtin_amdgcn_alignbit(n2, n1, sh);
-                    }
-                    prev = ((pb >> (((s - st) & 8) ? 16 : 0)) & 0x5555u) == 0u;
-                }
-                if (prev && (s % TR_RESEED) != 0 && s - st >= coff[tr_contig_of(coff, nc, s)]) continue;   // (a run may cross a contig border)
-                tr_extend(s, p, bases, nmask, coff, nc, trmask);
-            }
-        }
+        for (int it = 0; it < trips; it++) tr_item(T, (int)threadIdx.x, it, w0, nwords, G, max_period, bases, nmask, coff, nc, trmask);
     }
 }
 
@@ -158,9 +169,10 @@ extern "C" int hite_tr_mask(hite_ctx *ctx, int32_t max_period, uint32_t *mask_bi
     const int64_t nw32 = (G + 31) >> 5;
     uint32_t *trmask = nullptr;
     unsigned long long *cnt = nullptr;
-    HITE_CHECK(ctx, hipMalloc((void **)&trmask, (size_t)(nw32 + 2) * 4 + 16));
-    hipError_t e = hipMemset(trmask, 0, (size_t)(nw32 + 2) * 4 + 16);
-    cnt = (unsigned long long *)(trmask + nw32 + 2);
+    const int64_t cnt_at = (nw32 + 3) & ~(int64_t)1;          // 8-byte aligned word index behind the bit map
+    HITE_CHECK(ctx, hipMalloc((void **)&trmask, (size_t)(cnt_at + 4) * 4));
+    hipError_t e = hipMemset(trmask, 0, (size_t)(cnt_at + 4) * 4);
+    cnt = (unsigned long long *)(trmask + cnt_at);
     int rc = HITE_OK;
     if (e == hipSuccess) {
         const int64_t nwords = (G + 15) >> 4;

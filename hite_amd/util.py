@@ -758,15 +758,17 @@ def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_thre
         q, s, qs, qe, ss, se = _library_hits(ctx, work, contigs)
         lens = [len(contigs[n]) for n in work]
         # the seeding stage reports a hit from its first to its last anchor; blastn extends an alignment to the ends of the
-        # sequences when they keep matching.  Hits are therefore stretched along their diagonal over a short overhang (<= 30 bases on
-        # both sequences): without it two copies of one family miss the 0.95 coverage rule by the few bases outside the anchors.
+        # sequences when they keep matching.  Hits are therefore stretched along their diagonal over a short overhang (on both
+        # sequences; <= 30 bases or a tenth of the shorter sequence): without it two copies of one family miss the 0.95 coverage
+        # rule by the bases outside the anchors (a copy with a few substitutions near one end has no shared minimizer there).
         L = np.asarray(lens, dtype=np.int64)
         qs, qe, ss, se = (np.asarray(x).copy() for x in (qs, qe, ss, se))
         fwd = ss <= se
         left = np.minimum(qs - 1, np.where(fwd, ss - 1, L[s] - ss))
         right = np.minimum(L[q] - qe, np.where(fwd, L[s] - se, se - 1))
-        left = np.where(left <= 30, left, 0)
-        right = np.where(right <= 30, right, 0)
+        reach = np.maximum(30, np.minimum(L[q], L[s]) // 10)
+        left = np.where(left <= reach, left, 0)
+        right = np.where(right <= reach, right, 0)
         qs -= left; qe += right
         ss = np.where(fwd, ss - left, ss + left)
         se = np.where(fwd, se + right, se - right)

@@ -211,3 +211,49 @@ def test_ext_align_device_function_vs_twin(tmp_path):
         n_cut += 0 < i_ref < n
         n_full += i_ref == n and n > 0
     assert n_cases == 400 and n_cut > 40 and n_full > 40
+
+
+def test_tr_seed_kernel_logic_vs_twin(tmp_path):
+    """the tandem-repeat masker's kernel body (tile load, seed filter per (period, word) item, leftmost-of-run rule, extension,
+    mask bits) run thread by thread on the host == oracle/hite_oracle_trf.c, on a multi-contig genome with N runs"""
+    import casegen
+    from test_trmask import twin_mask
+
+    ext = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_ext.h"), "ext_align_dev")
+    body = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_trmask.hip"), "tr_seed")
+    lib = _build(tmp_path, "trseed", ext + r"""
+#define TR_MAXEXT 4096
+#define TR_MINSCORE 50
+#define TR_RESEED 2048
+#define TR_TILE 256
+#define TR_HALO 34
+static inline void atomicOr(uint32_t *p, uint32_t v) { *p |= v; }
+""" + body, r"""
+extern "C" void host_tr_mask(const uint32_t *bases, const uint32_t *nmask, const int64_t *coff, int nc, int64_t G, int max_period, uint32_t *trmask) {
+    static TrTile T;
+    const int64_t nwords = (G + 15) >> 4;
+    const int trips = tr_trips(max_period);
+    for (int64_t w0 = 0; w0 < nwords; w0 += TR_TILE) {
+        for (int k = 0; k < TR_TILE + TR_HALO + 2; k++) tr_tile_load(T, k, w0, nwords, G, bases, nmask);
+        for (int tid = 0; tid < 256; tid++)
+            for (int it = 0; it < trips; it++) tr_item(T, tid, it, w0, nwords, G, max_period, bases, nmask, coff, nc, trmask);
+    }
+}
+""")
+    seq, _planted = casegen.make_tandem_case(777, G=40_000, n_arr=40)
+    contigs = [seq[:9_000], seq[9_000:9_777] + "N" * 40 + seq[9_777:30_003], seq[30_003:], "ACGT" * 10, "ACGTTGCA" * 5]
+    genome = np.frombuffer("".join(contigs).encode(), dtype=np.uint8)
+    G = len(genome)
+    coff = np.zeros(len(contigs) + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in contigs], out=coff[1:])
+    bases, nm = _pack(genome)
+    # the product's buffers carry 8 words of padding; the kernel may read one word beyond the last one it needs
+    bases = np.concatenate([bases, np.zeros(40, np.uint32)])
+    nm = np.concatenate([nm, np.zeros(40, np.uint32)])
+    tr = np.zeros((G + 31) // 32 + 4, dtype=np.uint32)
+    lib.host_tr_mask(bases.ctypes.data_as(C.POINTER(C.c_uint32)), nm.ctypes.data_as(C.POINTER(C.c_uint32)), coff.ctypes.data_as(O.i64p),
+                     len(contigs), C.c_int64(G), 500, tr.ctypes.data_as(C.POINTER(C.c_uint32)))
+    got = np.unpackbits(tr.view(np.uint8), bitorder="little")[:G].astype(bool)
+    exp = twin_mask(contigs)
+    assert exp.sum() > 3000
+    assert np.array_equal(got, exp), (int(got.sum()), int(exp.sum()), np.flatnonzero(got != exp)[:10])
