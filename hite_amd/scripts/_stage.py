@@ -12,10 +12,10 @@ from hite_amd import util  # noqa: E402
 
 
 def run_cd_hit(inp, outp, threads):
-    """cd-hit-est -aS .95 -aL .95 -c .8 -G 0 -g 1 -A 80 (judge_TIR_transposons.py:87); pass-through when not installed"""
+    """cd-hit-est -aS .95 -aL .95 -c .8 -G 0 -g 1 -A 80 (judge_TIR_transposons.py:87); when it is not installed the build's own
+    stand-in removes the redundant sequences (util.remove_redundant_sequences) -- the step is never skipped"""
     if shutil.which("cd-hit-est") is None:
-        sys.stderr.write("[hite_amd] cd-hit-est not found: redundancy removal skipped\n")
-        shutil.copyfile(inp, outp)
+        util.remove_redundant_sequences(inp, outp, 0.95, 0.95)
         return
     subprocess.run("cd-hit-est -aS 0.95 -aL 0.95 -c 0.8 -G 0 -g 1 -A 80 -i %s -o %s -T %d -M 0 > /dev/null 2>&1" % (inp, outp, threads),
                    shell=True, check=False)

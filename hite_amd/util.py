@@ -733,6 +733,25 @@ def _library_hits(ctx, names, contigs):
     return tuple(np.concatenate([p[k] for p in parts]) for k in range(6))
 
 
+def _stretch_hits(q, s, qs, qe, ss, se, lens):
+    """The seeding stage reports a hit from its first to its last anchor; blastn extends an alignment to the ends of the
+    sequences when they keep matching.  Hits are therefore stretched along their diagonal over a short overhang (on both
+    sequences; <= 30 bases or a tenth of the shorter sequence): without it two copies of one family miss a 0.95 coverage
+    rule by the bases outside the anchors (a copy with a few substitutions near one end has no shared minimizer there)."""
+    L = np.asarray(lens, dtype=np.int64)
+    qs, qe, ss, se = (np.asarray(x).copy() for x in (qs, qe, ss, se))
+    fwd = ss <= se
+    left = np.minimum(qs - 1, np.where(fwd, ss - 1, L[s] - ss))
+    right = np.minimum(L[q] - qe, np.where(fwd, L[s] - se, se - 1))
+    reach = np.maximum(30, np.minimum(L[q], L[s]) // 10)
+    left = np.where(left <= reach, left, 0)
+    right = np.where(right <= reach, right, 0)
+    qs -= left; qe += right
+    ss = np.where(fwd, ss - left, ss + left)
+    se = np.where(fwd, se + right, se - right)
+    return qs, qe, ss, se
+
+
 def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_threshold, debug, device=0):
     """deredundant_for_LTR_v5 (Util.py:12202-12337, the library de-duplication of panHiTE, config C5), same arguments.
     Reference: blastn all-vs-all of the library -> chunked fragment chaining (process_blast_results_in_chunks +
@@ -757,21 +776,7 @@ def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_thre
     if work:
         q, s, qs, qe, ss, se = _library_hits(ctx, work, contigs)
         lens = [len(contigs[n]) for n in work]
-        # the seeding stage reports a hit from its first to its last anchor; blastn extends an alignment to the ends of the
-        # sequences when they keep matching.  Hits are therefore stretched along their diagonal over a short overhang (on both
-        # sequences; <= 30 bases or a tenth of the shorter sequence): without it two copies of one family miss the 0.95 coverage
-        # rule by the bases outside the anchors (a copy with a few substitutions near one end has no shared minimizer there).
-        L = np.asarray(lens, dtype=np.int64)
-        qs, qe, ss, se = (np.asarray(x).copy() for x in (qs, qe, ss, se))
-        fwd = ss <= se
-        left = np.minimum(qs - 1, np.where(fwd, ss - 1, L[s] - ss))
-        right = np.minimum(L[q] - qe, np.where(fwd, L[s] - se, se - 1))
-        reach = np.maximum(30, np.minimum(L[q], L[s]) // 10)
-        left = np.where(left <= reach, left, 0)
-        right = np.where(right <= reach, right, 0)
-        qs -= left; qe += right
-        ss = np.where(fwd, ss - left, ss + left)
-        se = np.where(fwd, se + right, se - right)
+        qs, qe, ss, se = _stretch_hits(q, s, qs, qe, ss, se, lens)
         recs = ctx.lib_chain(q, s, qs, qe, ss, se, lens, coverage_threshold, 5_000_000)
         clusters = [cl for cl in ctx.lib_cluster(recs, lens, coverage_threshold) if len(cl) >= 1]
         batch = [[(work[i], contigs[work[i]]) for i in cl] for cl in clusters]
@@ -786,10 +791,47 @@ def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_thre
         subprocess.run("cd-hit-est -aS 0.95 -aL 0.95 -c %s -G 0 -g 1 -A 80 -i %s -o %s -T 0 -M 0 > /dev/null 2>&1" %
                        (coverage_threshold, cons_path, final_path), shell=True, check=False)
     else:
-        sys.stderr.write("[hite_amd] cd-hit-est not found: the fragment-merging pass after the consensus step is skipped "
-                         "(<library>.cons is a copy of <library>.tmp.cons)\n")
-        shutil.copyfile(cons_path, final_path)
+        remove_redundant_sequences(cons_path, final_path, 0.95, 0.95, device=device)     # the build's stand-in, never a plain copy
     return cons_path
+
+
+def remove_redundant_sequences(inp, outp, aS=0.95, aL=0.95, device=0):
+    """The build's stand-in for `cd-hit-est -aS 0.95 -aL 0.95 -c <c> -G 0 -g 1 -A 80 -i inp -o outp` (judge_TIR_transposons.py:87,
+    Util.py:12330; cd-hit-est is an external tool: PARITY UNPINNED), used when it is not installed -- the step is never skipped.
+    Greedy incremental clustering in cd-hit's order (longest first, ties in input order): a sequence joins the first longer
+    representative that a chain of library-vs-library hits (hite_seed_allvsall + hite_lib_chain, the stages of the library
+    merge) covers to >= aS of the shorter and >= aL of the longer sequence; otherwise it becomes a representative.  The
+    representatives are written longest first, as cd-hit-est writes them.  Identity is not computed: hits are runs of shared
+    15-base minimizers, which sequences below ~85 % identity hardly have (cd-hit's -c 0.8 / 0.95 asks for less / more)."""
+    names, contigs = read_fasta(inp)
+    work = [n for n in names if 0 < len(contigs[n]) <= STAR_MAX_LEN]
+    drop = set()
+    if len(work) > 1:
+        ctx = get_ctx(device)
+        q, s_, qs, qe, ss, se = _library_hits(ctx, work, contigs)
+        lens = [len(contigs[n]) for n in work]
+        qs, qe, ss, se = _stretch_hits(q, s_, qs, qe, ss, se, lens)
+        recs = ctx.lib_chain(q, s_, qs, qe, ss, se, lens, min(aS, aL), 5_000_000)
+        covered = {}
+        for (_ch, qi, a, b, si, c, d) in recs:
+            if qi == si:
+                continue
+            cq, cs = (b - a) / lens[qi], abs(d - c) / lens[si]
+            short_cov, long_cov = (cq, cs) if lens[qi] <= lens[si] else (cs, cq)
+            if short_cov >= aS and long_cov >= aL:
+                covered.setdefault(qi, set()).add(si)
+                covered.setdefault(si, set()).add(qi)
+        order = sorted(range(len(work)), key=lambda i: (-lens[i], i))
+        reps = set()
+        for i in order:
+            if covered.get(i, set()) & reps:
+                drop.add(work[i])
+            else:
+                reps.add(i)
+    keep = [n for n in names if n not in drop]
+    keep.sort(key=lambda n: -len(contigs[n]))          # (stable: ties stay in input order)
+    store_fasta({n: contigs[n] for n in keep}, outp)
+    return outp
 
 
 def mask_genome_intactTE(TE_lib, genome_path, work_dir=None, thread=1, ref_index=0, debug=0, device=0):

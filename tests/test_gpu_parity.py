@@ -1276,3 +1276,80 @@ def test_deredundant_limits(ctx, tmp_path, monkeypatch):
     out2 = util.deredundant_for_LTR_v5(str(lib2), str(tmp_path), 1, "y", 0.95, 0)
     n2, s2 = util.read_fasta(out2)
     assert sorted(n2) == sorted(n1) and all(s2[n] == s1[n] for n in n1)
+
+
+@pytest.mark.parametrize("te_type,script,outname,label", [
+    ("helitron", "judge_Helitron_transposons.py", "confident_helitron_0.fa", "Helitron_0_"),
+    ("non_ltr", "judge_Non_LTR_transposons.py", "confident_non_ltr_0.fa", "Non_LTR_0_")])
+def test_typed_stage_scripts_find_the_planted_families(ctx, tmp_path, te_type, script, outname, label):
+    """the Helitron / non-LTR drop-in scripts on families shaped for them (judge_Helitron_transposons.py:86-125,
+    judge_Non_LTR_transposons.py:48-92): every sequence of the output FASTA is one planted element (within 3 % of one genomic
+    copy, strand free), at least four families come out, none twice, names follow rename_fasta + lib_add_prefix"""
+    import os
+    import subprocess
+    import sys as _sys
+
+    import synth_small
+    from hite_amd import util
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = synth_small.make(12, n_fam=16, te_type=te_type)
+    ref = tmp_path / "genome.fa"
+    ref.write_text("".join(">chr%d\n%s\n" % (i + 1, s) for i, s in enumerate(g["contigs"])))
+    flanked = tmp_path / "cand.flanked.fa"
+    recs = []
+    for cand, cps in zip(g["cands"], g["copies"]):
+        c, a, b, _m = cps[0]
+        recs.append(">chr%d:%d-%d\n%s\n" % (c + 1, a - 50, b + 50, g["contigs"][c][a - 1 - 50:b + 50]))
+    flanked.write_text("".join(recs))
+    candf = tmp_path / "cand.fa"
+    candf.write_text("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(g["cands"])))
+    out = tmp_path / "out"
+    rc = subprocess.run([_sys.executable, root + "/hite_amd/scripts/" + script, "--seqs", str(flanked), "-t", "1", "--tmp_output_dir", str(out),
+                         "--ref_index", "0", "--flanking_len", "50", "--recover", "0", "-r", str(ref), "--min_TE_len", "80",
+                         "--candidates", str(candf)], capture_output=True, text=True)
+    assert rc.returncode == 0, rc.stderr[-2000:]
+    names, seqs = util.read_fasta(str(out / outname))
+    assert len(names) >= 4 and all(n.startswith("genome-" + label) for n in names), names
+    hit_fams = []
+    for n in names:
+        sq = seqs[n]
+        best = None
+        for f, fam in enumerate(g["truth"]):
+            c, a, b, mn = fam[0]
+            el = g["contigs"][c][a - 1:b]
+            if abs(len(el) - len(sq)) > 0.1 * len(el):
+                continue
+            d = min(O.nw_distance(sq, el), O.nw_distance(util.getReverseSequence(sq), el))
+            if best is None or d < best[0]:
+                best = (d, f, len(el))
+        assert best is not None and best[0] <= 0.03 * 3 * best[2], (n, len(sq), best)
+        hit_fams.append(best[1])
+    assert len(set(hit_fams)) == len(hit_fams) and len(hit_fams) >= 4
+
+
+def test_remove_redundant_sequences(ctx, tmp_path):
+    """the stand-in for `cd-hit-est -aS 0.95 -aL 0.95` (used when cd-hit-est is not installed): near-identical sequences of about
+    the same length collapse to the longest, a fragment of 70 % stays (-aL), unrelated sequences stay, the output is ordered
+    longest first"""
+    from hite_amd import util
+
+    util._CTX = ctx
+    rng = np.random.default_rng(808)
+    recs = []
+    fams = [casegen.rand_seq(rng, L) for L in (900, 1400, 600)]
+    for f, cons in enumerate(fams):
+        for k in range(3):
+            sq = casegen.mutate(rng, cons, 0.02)
+            recs.append(("f%d_%d" % (f, k), sq[: len(sq) - 3 * k]))       # lengths differ a little: the first is the longest
+    recs.append(("frag_of_f1", fams[1][:980]))
+    recs.append(("other_a", casegen.rand_seq(rng, 800)))
+    recs.append(("other_b", casegen.rand_seq(rng, 300)))
+    order = rng.permutation(len(recs))
+    inp, outp = tmp_path / "in.fa", tmp_path / "out.fa"
+    inp.write_text("".join(">%s\n%s\n" % recs[i] for i in order))
+    util.remove_redundant_sequences(str(inp), str(outp))
+    names, seqs = util.read_fasta(str(outp))
+    assert sorted(names) == sorted(["f0_0", "f1_0", "f2_0", "frag_of_f1", "other_a", "other_b"])
+    lens = [len(seqs[n]) for n in names]
+    assert lens == sorted(lens, reverse=True)
