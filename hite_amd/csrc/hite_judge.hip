@@ -207,7 +207,7 @@ __global__ void tsd_search_kernel(int n, const uint8_t *__restrict__ bytes, cons
     if (i >= n) return;
     int C = (int)(off[i + 1] - off[i]);
     uint8_t l[12], r[12];
-    int k = tsd_search_v5(bytes + off[i], C, bs[i], be[i], plant, l, r);
+    int k = tsd_search_v5(RowPlain{bytes + off[i]}, C, bs[i], be[i], plant, l, r);
     len_out[i] = k;
     for (int j = 0; j < 16; j++) { left[(size_t)i * 16 + j] = (k > 0 && j < k) ? l[j] : 0; right[(size_t)i * 16 + j] = (k > 0 && j < k) ? r[j] : 0; }
 }
@@ -351,24 +351,44 @@ extern "C" int hite_boundary_search(hite_ctx *ctx, int32_t n, const uint8_t *msa
 }
 
 // which kernel judges which alignment: one wavefront per alignment when it has <= wrows rows and <= wcols columns, a
-// four-wavefront workgroup otherwise.  Two dense lists (order free: both kernels take their entries from a work queue).
-__global__ void __launch_bounds__(256) judge_split_kernel(int n, const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
-                                                          int wrows, int wcols, int32_t *__restrict__ list_b, int32_t *__restrict__ list_w,
-                                                          unsigned int *__restrict__ counters /* [2] n_b, [3] n_w */) {
+// four-wavefront workgroup otherwise.  Two dense lists, each ordered by cost class (log2 of rows x cols) DESCENDING: both
+// kernels take their entries from a work queue, and the largest alignments -- one workgroup can spend milliseconds on a
+// 30 000-column alignment -- must not be the ones that start last.  Three small launches: class histogram, offsets, scatter.
+#define JSPLIT_CLASSES 24
+__device__ __forceinline__ int judge_cost_class(int rows, int cols) {
+    const unsigned long long cost = (unsigned long long)(rows > 0 ? rows : 1) * (unsigned long long)(cols > 0 ? cols : 1);
+    const int lg = 63 - __clzll(cost);                       // 0 .. ~22
+    return lg >= JSPLIT_CLASSES ? JSPLIT_CLASSES - 1 : lg;
+}
+__global__ void __launch_bounds__(256) judge_split_count_kernel(int n, const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
+                                                                int wrows, int wcols, unsigned int *__restrict__ hist /* [2][JSPLIT_CLASSES] */) {
+    __shared__ unsigned int s_h[2 * JSPLIT_CLASSES];
+    if (threadIdx.x < 2 * JSPLIT_CLASSES) s_h[threadIdx.x] = 0u;
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int lane = threadIdx.x & 63;
-    const bool have = i < n;
-    const bool small = have && rows[i] <= wrows && cols[i] <= wcols;
-    const unsigned long long mw = __ballot(small), mb = __ballot(have && !small);
-    unsigned bw = 0, bb = 0;
-    if (lane == 0) {
-        if (mw) bw = atomicAdd(&counters[3], (unsigned)__popcll(mw));
-        if (mb) bb = atomicAdd(&counters[2], (unsigned)__popcll(mb));
+    if (i < n) {
+        const bool small = rows[i] <= wrows && cols[i] <= wcols;
+        atomicAdd(&s_h[(small ? JSPLIT_CLASSES : 0) + judge_cost_class(rows[i], cols[i])], 1u);
     }
-    bw = (unsigned)__shfl((int)bw, 0); bb = (unsigned)__shfl((int)bb, 0);
-    const unsigned long long below = (1ull << lane) - 1ull;
-    if (small) list_w[bw + __popcll(mw & below)] = i;
-    else if (have) list_b[bb + __popcll(mb & below)] = i;
+    __syncthreads();
+    if (threadIdx.x < 2 * JSPLIT_CLASSES && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+}
+// offsets of the classes inside each list, largest class first; list lengths into counters[2], counters[3]; hist becomes cursors
+__global__ void judge_split_offsets_kernel(unsigned int *__restrict__ hist, unsigned int *__restrict__ counters) {
+    if (threadIdx.x >= 2) return;
+    unsigned int *h = hist + threadIdx.x * JSPLIT_CLASSES;
+    unsigned int run = 0;
+    for (int c = JSPLIT_CLASSES - 1; c >= 0; c--) { const unsigned int k = h[c]; h[c] = run; run += k; }
+    counters[2 + threadIdx.x] = run;
+}
+__global__ void __launch_bounds__(256) judge_split_scatter_kernel(int n, const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
+                                                                  int wrows, int wcols, unsigned int *__restrict__ cursors,
+                                                                  int32_t *__restrict__ list_b, int32_t *__restrict__ list_w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool small = rows[i] <= wrows && cols[i] <= wcols;
+    const unsigned int at = atomicAdd(&cursors[(small ? JSPLIT_CLASSES : 0) + judge_cost_class(rows[i], cols[i])], 1u);
+    (small ? list_w : list_b)[at] = i;
 }
 
 static int env_int(const char *name, int dflt) {
@@ -402,12 +422,15 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
     int grid_w = wcols > 0 ? (n < 4096 ? n : 4096) : 0;
     const size_t off_w = (size_t)grid * slot, off_l = off_w + (size_t)grid_w * slot_w;
     void *scr = nullptr;
-    int rc = hite_scratch_reserve(ctx, off_l + 2 * (size_t)n * 4 + 256, &scr);
+    int rc = hite_scratch_reserve(ctx, off_l + 2 * (size_t)n * 4 + 512, &scr);
     if (rc) return rc;
     int32_t *list_b = (int32_t *)((uint8_t *)scr + off_l), *list_w = list_b + n;
-    unsigned int *counters = (unsigned int *)(list_w + n);          // queue heads [0] [1], list lengths [2] [3]
-    HITE_CHECK(ctx, hipMemsetAsync(counters, 0, 16, st));
-    hipLaunchKernelGGL(judge_split_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows, d_cols, wrows, wcols, list_b, list_w, counters);
+    unsigned int *counters = (unsigned int *)(list_w + n);          // queue heads [0] [1], list lengths [2] [3], then the class histogram
+    unsigned int *hist = counters + 4;
+    HITE_CHECK(ctx, hipMemsetAsync(counters, 0, (4 + 2 * JSPLIT_CLASSES) * 4, st));
+    hipLaunchKernelGGL(judge_split_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows, d_cols, wrows, wcols, hist);
+    hipLaunchKernelGGL(judge_split_offsets_kernel, dim3(1), dim3(64), 0, st, hist, counters);
+    hipLaunchKernelGGL(judge_split_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows, d_cols, wrows, wcols, hist, list_b, list_w);
     JudgeParams P;
     P.te_type = te_type; P.plant = plant; P.n = n; P.msa = d_msa; P.msa_off = d_msa_off; P.rows = d_rows; P.cols = d_cols;
     P.cand = d_cand; P.cand_off = d_cand_off; P.col_off = d_col_off; P.calls = d_calls; P.cons = d_cons;

@@ -3,15 +3,14 @@ set -u
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout 1200 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_scale.py > $OUT/s7_tests.log 2>&1
-echo "tests rc=$?" > $OUT/s7_summary.txt
-tail -12 $OUT/s7_tests.log >> $OUT/s7_summary.txt
+timeout 1200 python -m pytest tests -m gpu -x -q --deselect tests/test_gpu_scale.py > $OUT/s10_tests.log 2>&1
+echo "tests rc=$?" > $OUT/s10_summary.txt
+tail -12 $OUT/s10_tests.log >> $OUT/s10_summary.txt
 B="python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-coarse --verify 48"
-timeout 300 $B > $OUT/s7_bench_default.json 2> $OUT/s7_bench_default.err
-HITE_FILL_OLD=1 timeout 300 $B > $OUT/s7_bench_fillold.json 2> /dev/null
-python - <<'PY' >> $OUT/s7_summary.txt
+timeout 300 $B > $OUT/s10_bench_default.json 2> $OUT/s10_bench_default.err
+python - <<'PY' >> $OUT/s10_summary.txt
 import json,glob
-for f in sorted(glob.glob('gpurun_out/s7_bench_*.json')):
+for f in sorted(glob.glob('gpurun_out/s10_bench_*.json')):
     try:
         d=json.loads(open(f).read().strip().splitlines()[-1])
         k=d['kernels']
@@ -20,4 +19,4 @@ for f in sorted(glob.glob('gpurun_out/s7_bench_*.json')):
     except Exception as e:
         print(f, 'ERR', e)
 PY
-cat $OUT/s7_summary.txt
+cat $OUT/s10_summary.txt
