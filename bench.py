@@ -64,12 +64,20 @@ def valu_peak():
     return med(c4, 600.0), med(c2, 1180.0)
 
 
+def _kept_profile(stem):
+    """the newest committed profile file profiles/rNN_<stem> (rounds keep their own files) -> (parsed JSON, its name)"""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_" + stem)), reverse=True):
+        try:
+            return json.load(open(path)), "profiles/" + os.path.basename(path)
+        except (OSError, ValueError):
+            continue
+    return {}, None
+
+
 def kept_counters():
-    """per-kernel SQ counters of the committed profile (profiles/r02_sq_counters.json: rocprofv3 --pmc SQ_INSTS_VALU ...)"""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "r02_sq_counters.json")))
-    except (OSError, ValueError):
-        return {}
+    """per-kernel SQ counters of the committed profile (profiles/rNN_sq_counters.json: rocprofv3 --pmc SQ_INSTS_VALU ...)"""
+    return _kept_profile("sq_counters.json")
 
 
 def free_port():
@@ -295,13 +303,14 @@ def main():
             bytes_per_launch = alg.get(dom, 0.0) * steps / max(1, cnt)
             achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if avg_launch_ms > 0 else 0.0
             # HBM traffic of that kernel from the committed PMC passes (FETCH_SIZE / WRITE_SIZE, separate rocprofv3 runs:
-            # profiles/r02_pmc_traffic.json); a profiler stage can cover several kernel instantiations
+            # profiles/rNN_pmc_traffic.json, the newest round's); a profiler stage can cover several kernel instantiations
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+                pmc, pmc_src = _kept_profile("pmc_traffic.json")
                 names = {"align_fwd4": ["align_fwd_kernel<4>"], "align_tb": ["align_tb_kernel"],
                          "align_fwd_wide": ["align_fwd_kernel<8>", "align_fwd_kernel<16>", "align_fwd_kernel<32>"],
-                         "radix_sort_hits": ["rs_scatter_staged_kernel", "rs_hist_kernel<10, 32>"]}.get(dom, [dom])
+                         "radix_sort_hits": ["rs_scatter_staged_kernel", "rs_hist_kernel<10, 32>"],
+                         "judge_kernel": ["jblk::judge_kernel", "jwav::judge_wave_kernel"]}.get(dom, [dom])
                 tot = sum(pmc[k_]["bytes_per_launch"] * pmc[k_]["launches"] for k_ in names if k_ in pmc)
                 runs = pmc.get(names[0], {}).get("launches", 0)
                 traffic = int(tot / runs) if tot and runs else None      # per launch of the stage
@@ -315,7 +324,7 @@ def main():
             align_ms = sum(ms for k, (ms, _c) in merged_prof.items() if k.startswith("align_")) / steps
             if align_ms > 0 and cols_step > 0:
                 slow, fast = valu_peak()
-                cnt_file = kept_counters()
+                cnt_file, cnt_src = kept_counters()
                 inst = sum(v.get("valu_inst_per_step", 0.0) for k, v in cnt_file.items() if k.startswith("align_"))
                 cols_file = cnt_file.get("_columns_per_step", 0.0)
                 blk = {"ms_per_step": round(align_ms, 3), "pairs_per_step": int(per_step["pairs"]), "columns_per_step": int(cols_step),
@@ -331,7 +340,7 @@ def main():
                     blk["valu_issue"] = {"achieved": round(rate, 1), "unit": "G wave64-inst/s", "peak_4cycle_class": round(slow, 1),
                                          "peak_2cycle_class": round(fast, 1), "frac_of_4cycle_peak": round(rate / slow, 4),
                                          "frac_of_2cycle_peak": round(rate / fast, 4),
-                                         "wave_inst_per_pair_column": round(per_col, 4), "source": "profiles/r02_sq_counters.json"}
+                                         "wave_inst_per_pair_column": round(per_col, 4), "source": cnt_src}
                 roof["align"] = blk
             # the whole step by SURVEY.md 8(d)'s formulas, verbatim: B_copy = Q/4 + 12 M_q + 16 hits; B_gather = sum R_c (W_c/4 + W_c);
             # B_vote = sum (R_c W_c + 20 W_c)  -- the path as built is instruction / latency bound, not bandwidth bound

@@ -99,6 +99,17 @@ class Context:
         self._check(self.lib.hite_genome_pack(self.h, _p(buf), _p(off), len(bs)), "hite_genome_pack")
         self.contig_len = np.diff(off)
 
+    def set_contig_order(self, names):
+        """contig names (in packing order) -> the byte order of "<name>:" that breaks length ties between alignment rows
+        (tools/ready_for_MSA.sh); None clears it (contigs then compare by index)"""
+        if names is None:
+            self._check(self.lib.hite_set_contig_order(self.h, None, 0), "hite_set_contig_order")
+            return
+        keyed = sorted(range(len(names)), key=lambda i: (names[i] + ":").encode())
+        rank = np.zeros(len(names), dtype=np.int32)
+        rank[keyed] = np.arange(len(names), dtype=np.int32)
+        self._check(self.lib.hite_set_contig_order(self.h, _p(rank), len(names)), "hite_set_contig_order")
+
     def genome_pack_dev(self, d_ptr, contig_off, stream=0):
         off = _arr(contig_off, np.int64)
         self._check(self.lib.hite_genome_pack_dev(self.h, C.c_void_p(d_ptr), _p(off), len(off) - 1, C.c_void_p(stream)),

@@ -39,6 +39,7 @@ struct hite_ctx {
     const int32_t *d_msa_row_map;   // per compacted row: source row (NULL: identity)
     const int32_t *d_msa_rows_eff;  // per candidate: rows that were aligned (NULL: all)
     uint32_t *d_msa_lay;             // layout words of the last sparse star alignment (hite_msa.hip)
+    int32_t *d_contig_rank;         // byte order of "<contig name>:" among the contigs (hite_set_contig_order; NULL: the index)
     // second stream + fork / join events for kernels that run beside each other inside one call (the two judge kernels)
     void *aux_stream;
     void *aux_ev[2];

@@ -29,6 +29,7 @@ extern "C" int hite_ctx_create(int device_id, hite_ctx **out) {
 }
 
 static void free_genome(hite_ctx *c) {
+    if (c->d_contig_rank) { (void)hipFree(c->d_contig_rank); c->d_contig_rank = nullptr; }
     if (c->d_bases) (void)hipFree(c->d_bases);
     if (c->d_nmask) (void)hipFree(c->d_nmask);
     if (c->d_contig_off) (void)hipFree(c->d_contig_off);
@@ -47,6 +48,7 @@ extern "C" void hite_ctx_destroy(hite_ctx *c) {
     hite_align_release(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_scratch2) (void)hipFree(c->d_scratch2);
+    if (c->d_contig_rank) (void)hipFree(c->d_contig_rank);
     if (c->aux_ev[0]) (void)hipEventDestroy((hipEvent_t)c->aux_ev[0]);
     if (c->aux_ev[1]) (void)hipEventDestroy((hipEvent_t)c->aux_ev[1]);
     if (c->aux_stream) (void)hipStreamDestroy((hipStream_t)c->aux_stream);
@@ -54,6 +56,19 @@ extern "C" void hite_ctx_destroy(hite_ctx *c) {
 }
 
 extern "C" const char *hite_last_error(hite_ctx *c) { return c ? c->err : "null ctx"; }
+
+// Byte order of the contig NAMES (each followed by ':'): the rows of an alignment are named "<contig>:<start>-<end>(<strand>)" and
+// tools/ready_for_MSA.sh breaks length ties by name (hite_pipeline.hip, select_rows_kernel).  rank[i] = position of contig i in
+// that order; NULL or n != the number of packed contigs clears it (then contigs compare by their index).  Packing a genome clears it.
+extern "C" int hite_set_contig_order(hite_ctx *ctx, const int32_t *rank, int32_t n) {
+    if (!ctx) return HITE_EINVAL;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_contig_rank) { (void)hipFree(ctx->d_contig_rank); ctx->d_contig_rank = nullptr; }
+    if (!rank || n <= 0 || n != ctx->n_contigs) return rank && n > 0 ? HITE_EINVAL : HITE_OK;
+    HITE_CHECK(ctx, hipMalloc((void **)&ctx->d_contig_rank, (size_t)n * 4));
+    HITE_CHECK(ctx, hipMemcpy(ctx->d_contig_rank, rank, (size_t)n * 4, hipMemcpyHostToDevice));
+    return HITE_OK;
+}
 
 // the context's second stream (created on first use) with one event to fork it off the caller's stream and one to join it
 int hite_aux_stream(hite_ctx *ctx, hipStream_t *st, hipEvent_t *fork_ev, hipEvent_t *join_ev) {

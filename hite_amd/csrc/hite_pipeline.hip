@@ -68,11 +68,45 @@ __global__ void mode_b_kernel(int n, const int32_t *__restrict__ mode_a, const h
     mode[c] = (mode_a[c] == 2 && calls_a[c].is_te) ? 1 : 0;
 }
 
-// rows of each candidate: eligible copies, at most the 100 longest (ties: input order), input order kept
+// >>> copy_name_cmp (tests/test_host_compiled.py compiles this block for the host and compares it with Python's string order)
+// The windows of a candidate are named "<contig>:<start>-<end>(<strand>)" (Util.py:8110) and tools/ready_for_MSA.sh keeps the 100
+// longest by `sort -nk 2 -r` on the .fai: equal lengths fall to the reverse byte order of the line, i.e. of the NAME (POSIX
+// locale, the reference's container).  Byte order of two such names without building them: the contigs by a rank the host
+// computed on "<contig>:" (hite_set_contig_order; identity when none was given), then start and end as DECIMAL STRINGS (a
+// string that is a prefix of the other is the smaller: its next byte, '-' or '(', sorts before every digit), then '+' < '-'.
+__device__ __forceinline__ int dec_digits(long long v) {
+    int d = 1;
+    while (v >= 10) { v /= 10; d++; }
+    return d;
+}
+__device__ __forceinline__ long long pow10ll(int k) { long long r = 1; while (k-- > 0) r *= 10; return r; }
+__device__ __forceinline__ int dec_str_cmp(long long a, long long b) {
+    if (a == b) return 0;
+    const int da = dec_digits(a), db = dec_digits(b);
+    const int k = da < db ? da : db;
+    const long long ta = a / pow10ll(da - k), tb = b / pow10ll(db - k);     // the first k digits of each
+    if (ta != tb) return ta < tb ? -1 : 1;
+    return da < db ? -1 : 1;
+}
+// is the name of copy (c1, s1, e1, m1) greater than that of (c2, s2, e2, m2)?  r1 / r2 = ranks of the contigs
+__device__ __forceinline__ bool copy_name_gt(int r1, long long s1, long long e1, int m1, int r2, long long s2, long long e2, int m2) {
+    if (r1 != r2) return r1 > r2;
+    int c = dec_str_cmp(s1, s2);
+    if (c) return c > 0;
+    c = dec_str_cmp(e1, e2);
+    if (c) return c > 0;
+    return m1 > m2;
+}
+// <<< copy_name_cmp
+
+// rows of each candidate: eligible copies, at most the 100 longest (ties: the greater name first, as ready_for_MSA.sh's sort
+// leaves them), input order kept
 __global__ void __launch_bounds__(256) select_rows_kernel(int n, const int32_t *__restrict__ copy_first,
                                                           const int64_t *__restrict__ len,
-                                                          const int32_t *__restrict__ mode, int32_t *__restrict__ nrows,
-                                                          int32_t *__restrict__ sel /* n x 100 */) {
+                                                          const int32_t *__restrict__ mode, const int32_t *__restrict__ contig,
+                                                          const int64_t *__restrict__ s1, const int64_t *__restrict__ e1,
+                                                          const uint8_t *__restrict__ minus, const int32_t *__restrict__ contig_rank,
+                                                          int32_t *__restrict__ nrows, int32_t *__restrict__ sel /* n x 100 */) {
     __shared__ int s_scan[8];
     __shared__ int s_cnt;
     int c = blockIdx.x;
@@ -99,13 +133,24 @@ __global__ void __launch_bounds__(256) select_rows_kernel(int n, const int32_t *
                 if (E <= MAXROWS) keep = 1;
                 else {
                     int64_t Li = md == 2 ? 1000 : L;
+                    const int ri = contig_rank ? contig_rank[contig[f + i]] : contig[f + i];
+                    const long long si = s1[f + i], ei = e1[f + i];
+                    const int mi = minus[f + i] != 0;
                     int rank = 0;
                     for (int j = 0; j < k; j++) {
                         int64_t Lj = len[f + j];
                         bool ej = md == 2 ? (Lj > 1000) : (Lj > 0);
                         if (!ej) continue;
                         if (md == 2) Lj = 1000;
-                        rank += (Lj > Li) || (Lj == Li && j < i);
+                        if (Lj > Li) rank++;
+                        else if (Lj == Li && j != i) {
+                            const int rj = contig_rank ? contig_rank[contig[f + j]] : contig[f + j];
+                            const int mj = minus[f + j] != 0;
+                            const bool gt = copy_name_gt(rj, s1[f + j], e1[f + j], mj, ri, si, ei, mi);
+                            // two copies with the same name (the same interval twice): the earlier one first
+                            const bool same = rj == ri && s1[f + j] == si && e1[f + j] == ei && mj == mi;
+                            rank += gt || (same && j < i);
+                        }
                     }
                     keep = rank < MAXROWS;
                 }
@@ -280,7 +325,8 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     ACHK(arena_alloc(ctx, T, (size_t)n * 4, &p)); nrows = (int32_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)n * MAXROWS * 4, &p)); sel = (int32_t *)p;
     int tk = hite_prof_begin(ctx, "select_rows_kernel", st);
-    hipLaunchKernelGGL(select_rows_kernel, dim3(n), dim3(256), 0, st, n, d_copy_first, d_len, d_mode, nrows, sel);
+    hipLaunchKernelGGL(select_rows_kernel, dim3(n), dim3(256), 0, st, n, d_copy_first, d_len, d_mode, d_contig, d_s1, d_e1, d_minus,
+                       (const int32_t *)ctx->d_contig_rank, nrows, sel);
     hite_prof_end(ctx, tk, st);
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); row_first = (int64_t *)p;
     ACHK(scan_excl<int32_t>(ctx, T, nrows, n, row_first, st));

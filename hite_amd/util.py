@@ -221,6 +221,7 @@ def set_reference(reference, device=0):
     if _PACKED["path"] != os.path.abspath(reference):
         names, contigs = read_fasta(reference)
         ctx.genome_pack([contigs[n] for n in names])
+        ctx.set_contig_order(names)       # length ties between alignment rows fall to the row NAME (tools/ready_for_MSA.sh)
         ctx.release_copy_index()          # the minimizer index belongs to the genome that was packed before
         _PACKED.update(path=os.path.abspath(reference), names={n: i for i, n in enumerate(names)},
                        lens=[len(contigs[n]) for n in names])

@@ -69,6 +69,10 @@ int hite_genome_pack(hite_ctx *ctx, const uint8_t *seq, const int64_t *contig_of
 int hite_genome_pack_dev(hite_ctx *ctx, const uint8_t *d_seq, const int64_t *contig_off_host, int32_t n_contigs,
                          void *stream);
 int64_t hite_genome_bases(hite_ctx *ctx);
+/* Byte order of the contig names, each followed by ':' (rank[i] = position of contig i): tools/ready_for_MSA.sh keeps the 100
+ * longest windows and breaks length ties by window NAME "<contig>:<start>-<end>(<strand>)" (`sort -nk 2 -r` on the .fai,
+ * POSIX locale; Util.py:8110, 10410).  Optional: without it contigs compare by their index.  Cleared by hite_genome_pack. */
+int hite_set_contig_order(hite_ctx *ctx, const int32_t *rank, int32_t n);
 /* N-mask intervals (contig id, 1-based inclusive, clamped into the contig) of the resident genome: the masking step of
  * mask_genome_intactTE (Util.py:6389-6431).  A minimizer index built before the call does not see the mask. */
 int hite_genome_mask(hite_ctx *ctx, int64_t n, const int32_t *contig, const int64_t *start1, const int64_t *end1);

@@ -833,6 +833,56 @@ def gen_trf_mask(tmp):
     dump("trf_mask", cases)
 
 
+def gen_ready_for_msa(tmp):
+    """tools/ready_for_MSA.sh <file> 100 100 (is_TE_from_align_file, Util.py:10410) run as the reference runs it, under the POSIX
+    locale of the reference's container.  Its one external call, `samtools faidx <file>`, only writes the .fai index (name,
+    length, offset, line bases, line width -- the documented format); samtools is absent from this image, so a ten-line writer
+    of that file stands on the PATH under its name.  Everything the fixture pins is the script's own: `sort -nk 2 -r` (equal
+    lengths fall to the reverse byte order of the line), head, `grep -a -A 1 -f` (input order kept)."""
+    import subprocess
+
+    bindir = os.path.join(tmp, "fakebin")
+    os.makedirs(bindir, exist_ok=True)
+    shim = os.path.join(bindir, "samtools")
+    with open(shim, "w") as f:
+        f.write("#!/usr/bin/env python3\nimport sys\nassert sys.argv[1] == 'faidx'\npath = sys.argv[2]\nout = open(path + '.fai', 'w')\n"
+                "data = open(path, 'rb').read()\npos = 0\nlines = data.split(b'\\n')\ni = 0\n"
+                "while i + 1 < len(lines):\n    h, s = lines[i], lines[i + 1]\n    if h.startswith(b'>'):\n"
+                "        name = h[1:].split()[0].decode()\n        off = pos + len(h) + 1\n"
+                "        out.write('%s\\t%d\\t%d\\t%d\\t%d\\n' % (name, len(s), off, len(s), len(s) + 1))\n"
+                "    pos += len(h) + 1 + len(s) + 1\n    i += 2\nout.close()\n")
+    os.chmod(shim, 0o755)
+    rng = np.random.default_rng(4410)
+    contig_sets = (["chr1", "chr2", "chr10"], ["scaffold_3", "Chr1", "chr1_random", "chr1"], ["1", "10", "2", "X"])
+    cases = []
+    for ci in range(10):
+        cn = contig_sets[ci % 3]
+        n = int(rng.choice([90, 101, 130, 260, 300]))
+        names, lens, seen = [], [], set()
+        while len(names) < n:
+            s = int(rng.choice([7, 95, 99, 100, 1000, 9999, 10000, 123456, int(rng.integers(1, 2_000_000))]))
+            ln = 1000 if ci % 2 == 0 else int(rng.choice([150, 150, 151, 400, 1000, 1000, int(rng.integers(100, 3000))]))
+            nm = "%s:%d-%d(%s)" % (cn[int(rng.integers(0, len(cn)))], s, s + ln - 101, "+-"[int(rng.integers(0, 2))])
+            if nm in seen:
+                continue
+            seen.add(nm)
+            names.append(nm)
+            lens.append(ln)
+        d = os.path.join(tmp, "rfm_%d" % ci)
+        os.makedirs(d)
+        fa = os.path.join(d, "members.fa")
+        with open(fa, "w") as f:
+            for nm, ln in zip(names, lens):
+                f.write(">" + nm + "\n" + "ACGT" * (ln // 4) + "A" * (ln % 4) + "\n")
+        env = dict(os.environ, PATH=bindir + ":" + os.environ["PATH"], LC_ALL="C")
+        subprocess.run(["sh", os.path.join(ref_harness.REFERENCE_ROOT, "tools", "ready_for_MSA.sh"), fa, "100", "100"], cwd=d, env=env, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        picked = [ln_[1:].strip() for ln_ in open(fa + ".rdmSubset.fa") if ln_.startswith(">")]
+        cases.append(dict(names=names, lens=lens, selected=picked))
+        print("ready_for_MSA case %d: %d members -> %d kept" % (ci, n, len(picked)))
+    dump("ready_for_msa", cases)
+
+
 def gen_split_chunks(U, tmp):
     """module/split_genome_chunks.py run as a script (runpy) on small genomes: the reference FASTA is rewritten upper-case in
     place (convertToUpperCase_v1), cut into chr$offset segments (multi_line) and grouped into genome.cut{i}.fa by FASTA-text
@@ -952,7 +1002,7 @@ def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf", "rfm"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -988,6 +1038,8 @@ def main():
             gen_cons_v1(U, tmp)
         if "trf" in which:
             gen_trf_mask(tmp)
+        if "rfm" in which:
+            gen_ready_for_msa(tmp)
 
 
 if __name__ == "__main__":

@@ -257,3 +257,31 @@ extern "C" void host_tr_mask(const uint32_t *bases, const uint32_t *nmask, const
     exp = twin_mask(contigs)
     assert exp.sum() > 3000
     assert np.array_equal(got, exp), (int(got.sum()), int(exp.sum()), np.flatnonzero(got != exp)[:10])
+
+
+def test_copy_name_order_vs_python_strings(tmp_path):
+    """select_rows_kernel's tie-break: copy_name_gt on (contig rank, start, end, strand) == byte order of the window names
+    "<contig>:<start>-<end>(<strand>)" (ranks as hite_amd._lib.Context.set_contig_order computes them)"""
+    body = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_pipeline.hip"), "copy_name_cmp")
+    lib = _build(tmp_path, "cmp", body, r"""
+extern "C" int host_name_gt(int r1, long long s1, long long e1, int m1, int r2, long long s2, long long e2, int m2) {
+    return copy_name_gt(r1, s1, e1, m1, r2, s2, e2, m2) ? 1 : 0;
+}
+""")
+    rng = np.random.default_rng(3)
+    contigs = ["chr1", "chr10", "chr2", "Chr1", "chr1_random", "1", "10", "X", "scaffold_3"]
+    keyed = sorted(range(len(contigs)), key=lambda i: (contigs[i] + ":").encode())
+    rank = {contigs[i]: r for r, i in enumerate(keyed)}
+    vals = [1, 7, 9, 10, 11, 99, 100, 101, 999, 1000, 1001, 9999, 10000, 99999, 100000, 123456, 1234567, 2_000_000_000, 12345678901]
+    def rnd():
+        c = contigs[int(rng.integers(0, len(contigs)))]
+        s = int(rng.choice(vals)) if rng.random() < 0.7 else int(rng.integers(1, 3_000_000))
+        e = int(rng.choice(vals)) if rng.random() < 0.5 else s + int(rng.integers(0, 40000))
+        return c, s, e, int(rng.integers(0, 2))
+    for _ in range(20000):
+        a, b = rnd(), rnd()
+        if rng.random() < 0.3:
+            b = (a[0], a[1], b[2], b[3])          # same contig and start: decided by the end
+        na, nb = ("%s:%d-%d(%s)" % (a[0], a[1], a[2], "+-"[a[3]])).encode(), ("%s:%d-%d(%s)" % (b[0], b[1], b[2], "+-"[b[3]])).encode()
+        got = lib.host_name_gt(rank[a[0]], C.c_longlong(a[1]), C.c_longlong(a[2]), a[3], rank[b[0]], C.c_longlong(b[1]), C.c_longlong(b[2]), b[3])
+        assert bool(got) == (na > nb), (na, nb, got)

@@ -411,3 +411,21 @@ def test_generate_cons_v1_golden():
             rows = [bytes(m[back[i]]).decode() for i in range(len(seqs))]
             got[members[-1]] = O.cons_majority(rows)
         assert got == c["expected"], ci
+
+
+def test_ready_for_msa_golden():
+    """tools/ready_for_MSA.sh <members.fa> 100 100 as the reference runs it (is_TE_from_align_file, Util.py:10410): the rows the
+    script keeps == oracle_pipeline.select_rows with the window names -- the 100 longest, equal lengths in descending byte
+    order of the name, output in input order"""
+    import oracle_pipeline as OP
+
+    cases = load_golden("ready_for_msa")
+    assert len(cases) == 10
+    ties_decided = 0
+    for ci, c in enumerate(cases):
+        keep = OP.select_rows(c["lens"], c["names"])
+        assert [c["names"][i] for i in keep] == c["selected"], ci
+        if len(c["names"]) > 100:
+            cut = sorted(c["lens"], reverse=True)[99]
+            ties_decided += sum(1 for x in c["lens"] if x == cut) > sum(1 for i in keep if c["lens"][i] == cut)
+    assert ties_decided >= 6          # the cut falls inside a run of equal lengths in most cases: the tie rule is what is pinned

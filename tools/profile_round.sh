@@ -3,21 +3,20 @@
 # --kernel-trace only), summaries written under gpurun_out/ for copying into profiles/.
 # usage: tools/profile_round.sh <tag>     (e.g. r02)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --verify 0"
+BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-coarse --verify 0"
 timeout 900 python bench.py > $OUT/${TAG}_bench_fine.json 2> $OUT/${TAG}_bench_fine.err
 timeout 600 python bench.py --config C2 > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
-timeout 600 python bench.py --stage coarse > $OUT/${TAG}_bench_coarse.json 2> $OUT/${TAG}_bench_coarse.err
-HITE_ALIGN_EXACT=16 timeout 600 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_fine_cap16.json 2> /dev/null
-HITE_ALIGN_EXACT=0 timeout 600 python bench.py --no-cpu-baseline > $OUT/${TAG}_bench_fine_cap0.json 2> /dev/null
+HITE_ALIGN_EXACT=16 timeout 600 python bench.py --no-cpu-baseline --no-coarse > $OUT/${TAG}_bench_fine_cap16.json 2> /dev/null
+HITE_ALIGN_EXACT=0 timeout 600 python bench.py --no-cpu-baseline --no-coarse > $OUT/${TAG}_bench_fine_cap0.json 2> /dev/null
 rm -rf $OUT/prof_stats $OUT/prof_sq $OUT/prof_fetch $OUT/prof_write
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_stats -o run -- $BENCH > $OUT/prof_stats.json 2> $OUT/prof_stats.log
-timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_|judge_kernel|star_" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM -d $OUT/prof_sq -o run -- $BENCH > $OUT/prof_sq.json 2> $OUT/prof_sq.log
-timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_|judge|star_|row_gather|rs_|hit_|occ_|cluster|cand_min" --pmc FETCH_SIZE -d $OUT/prof_fetch -o run -- $BENCH > $OUT/prof_fetch.json 2> $OUT/prof_fetch.log
-timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_|judge|star_|row_gather|rs_|hit_|occ_|cluster|cand_min" --pmc WRITE_SIZE -d $OUT/prof_write -o run -- $BENCH > $OUT/prof_write.json 2> $OUT/prof_write.log
+timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_|judge|star_|chain_" --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM -d $OUT/prof_sq -o run -- $BENCH > $OUT/prof_sq.json 2> $OUT/prof_sq.log
+timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_|judge|star_|row_gather|rs_|hit_|occ_|cluster|cand_min|chain_" --pmc FETCH_SIZE -d $OUT/prof_fetch -o run -- $BENCH > $OUT/prof_fetch.json 2> $OUT/prof_fetch.log
+timeout 900 rocprofv3 --kernel-trace --kernel-include-regex "align_|judge|star_|row_gather|rs_|hit_|occ_|cluster|cand_min|chain_" --pmc WRITE_SIZE -d $OUT/prof_write -o run -- $BENCH > $OUT/prof_write.json 2> $OUT/prof_write.log
 python tools/pmc_counters.py $OUT/prof_sq $OUT/prof_sq.json $OUT/${TAG}_sq_counters.json $OUT/${TAG}_sq_counters.txt "rocprofv3 --kernel-trace --kernel-include-regex align_ --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_INSTS_VMEM -- $BENCH" 2> $OUT/pmc_counters.err
 python tools/pmc_traffic.py $OUT/prof_fetch $OUT/prof_write $OUT/${TAG}_pmc_traffic.json $OUT/${TAG}_pmc_hbm.txt "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace) -- $BENCH" 2> $OUT/pmc_traffic.err
 python - <<PY > $OUT/${TAG}_kernel_stats.txt 2> $OUT/kernel_stats.err
