@@ -22,15 +22,17 @@ __device__ __forceinline__ unsigned ext_cand_code(unsigned ch, bool comp) {
 // them.  The 17 band cells live in registers (the loops over the band are unrolled), the genome bases under the band as
 // three 17-bit planes that shift by one cell per column: a column costs one new genome base, one query base and ~8 integer
 // operations per cell.  Both sequences are walked one base per column, so the words they come from are kept in registers -- 16
-// genome bases, 32 mask bits, 4 query bytes per load, each fetched one word ahead of its use (a load per base and column made
-// the kernel a gather benchmark).
+// genome bases, 32 mask bits, 4 query bytes per load, each fetched a few words ahead of its use (a load per base and column
+// made the kernel a gather benchmark; one word ahead left the last long extensions of a batch -- a lane alone in its
+// wavefront -- waiting for HBM every fourth column).
 template <class M>
 struct ExtStateT {
     int D[EXT_W];
     uint32_t W0, W1, WN;
     int i, n, best_i, best_t, best_s;
     unsigned gnext_, qnext_;                // codes of the next column
-    uint32_t gw, gwn, mw, mwn, qw, qwn;     // current / next word of genome bases, mask bits, query bytes
+    uint32_t gw, gwn, gwn2, mw, mwn, qw, qwn, qwn2, qwn3;   // current word and the ones fetched ahead: genome bases (2 ahead = 32 columns),
+                                                            // mask bits (1 ahead = 32 columns), query bytes (3 ahead = 12 columns)
     int64_t gwi, mwi, qwi;                   // their word indices
     const uint32_t *q4;                      // the candidate bytes as aligned words (base address rounded down)
     int64_t p0, g0, jmax;
@@ -47,7 +49,7 @@ __device__ __forceinline__ unsigned ext_genome_code(const uint32_t *__restrict__
 template <class M>
 __device__ __forceinline__ unsigned ext_genome_next(ExtStateT<M> &E, const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g) {
     const int64_t wi = g >> 4, mi = g >> 5;
-    if (wi != E.gwi) { E.gw = E.gwn; E.gwi = wi; const int64_t nx = wi + E.dir; E.gwn = bases[nx > 0 ? nx : 0]; }
+    if (wi != E.gwi) { E.gw = E.gwn; E.gwn = E.gwn2; E.gwi = wi; const int64_t nx = wi + 2 * E.dir; E.gwn2 = bases[nx > 0 ? nx : 0]; }
     if (mi != E.mwi) { E.mw = E.mwn; E.mwi = mi; const int64_t nx = mi + E.dir; E.mwn = nmask[nx > 0 ? nx : 0]; }
     const unsigned c = (E.gw >> (2 * (int)(g & 15))) & 3u;
     return ((E.mw >> (int)(g & 31)) & 1u) ? 4u : c;
@@ -57,7 +59,7 @@ template <class M>
 __device__ __forceinline__ unsigned ext_query_next(ExtStateT<M> &E, const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t a) {
     if (M::PACKEDQ) return a >= 0 ? ext_genome_code(bases, nmask, a) : 4u;
     const int64_t wi = a >> 2;
-    if (wi != E.qwi) { E.qw = E.qwn; E.qwi = wi; const int64_t nx = wi + E.step; E.qwn = E.q4[nx > 0 ? nx : 0]; }
+    if (wi != E.qwi) { E.qw = E.qwn; E.qwn = E.qwn2; E.qwn2 = E.qwn3; E.qwi = wi; const int64_t nx = wi + 3 * E.step; E.qwn3 = E.q4[nx > 0 ? nx : 0]; }
     return ext_cand_code((E.qw >> (8 * (int)(a & 3))) & 0xffu, E.comp);
 }
 // dlo .. dhi: the diagonals j - i in use (DIAGLIM only; else all of the band)
@@ -83,9 +85,14 @@ __device__ __forceinline__ void ext_init(ExtStateT<M> &E, const uint8_t *__restr
     {
         const int64_t g = dir > 0 ? g0 : g0 - 1;
         const int64_t gs = g > 0 ? g : 0;
-        E.gwi = gs >> 4; E.gw = bases[E.gwi]; { const int64_t nx = E.gwi + dir; E.gwn = bases[nx > 0 ? nx : 0]; }
+        E.gwi = gs >> 4; E.gw = bases[E.gwi];
+        { const int64_t n1 = E.gwi + dir, n2 = E.gwi + 2 * dir; E.gwn = bases[n1 > 0 ? n1 : 0]; E.gwn2 = bases[n2 > 0 ? n2 : 0]; }
         E.mwi = gs >> 5; E.mw = nmask[E.mwi]; { const int64_t nx = E.mwi + dir; E.mwn = nmask[nx > 0 ? nx : 0]; }
-        if (!M::PACKEDQ) { E.qwi = E.p0 >> 2; E.qw = E.q4[E.qwi]; { const int64_t nx = E.qwi + step; E.qwn = E.q4[nx > 0 ? nx : 0]; } }
+        if (!M::PACKEDQ) {
+            E.qwi = E.p0 >> 2; E.qw = E.q4[E.qwi];
+            const int64_t n1 = E.qwi + step, n2 = E.qwi + 2 * step, n3 = E.qwi + 3 * step;
+            E.qwn = E.q4[n1 > 0 ? n1 : 0]; E.qwn2 = E.q4[n2 > 0 ? n2 : 0]; E.qwn3 = E.q4[n3 > 0 ? n3 : 0];
+        }
     }
     // planes of "column 0": bit b = genome base number j = b - EXT_B (1-based in walking order); bit set in WN = never matches
 #pragma unroll

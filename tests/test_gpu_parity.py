@@ -130,14 +130,16 @@ def test_judge_golden(ctx, name, te_type):
                 assert [g[0], g[1], g[2], g[3]] == exp, (i, g, exp)
 
 
-@pytest.mark.parametrize("mode", ["block_only", "wave_rows_32", "wave_wide"])
+@pytest.mark.parametrize("mode", ["block_only", "wave_default", "wave_rows_32", "wave_wide"])
 @pytest.mark.parametrize("name,te_type", [("judge_tir", "tir"), ("judge_non_ltr", "non_ltr"), ("judge_helitron", "helitron")])
 def test_judge_golden_kernel_forms(ctx, name, te_type, mode, monkeypatch):
     """the two judge kernels (one wavefront per alignment / one workgroup per alignment) give the same calls: every golden
-    through the workgroup kernel only, through the wave kernel with the row limit at 32 (the 64-row mask path stays in the
+    through the workgroup kernel only (what a batch below HITE_JUDGE_WAVE_MIN_BATCH alignments gets by default), through the
+    wave kernel as a large batch gets it, through the wave kernel with the row limit at 32 (the 64-row mask path stays in the
     workgroup kernel), and with the column limit lifted (anchor text of wide alignments in global scratch)"""
-    env = {"block_only": {"HITE_JUDGE_WAVE_COLS": "0"}, "wave_rows_32": {"HITE_JUDGE_WAVE_ROWS": "32"},
-           "wave_wide": {"HITE_JUDGE_WAVE_COLS": "60000", "HITE_JUDGE_OVERLAP": "0"}}[mode]
+    env = {"block_only": {"HITE_JUDGE_WAVE_COLS": "0"}, "wave_rows_32": {"HITE_JUDGE_WAVE_ROWS": "32", "HITE_JUDGE_WAVE_MIN_BATCH": "0"},
+           "wave_default": {"HITE_JUDGE_WAVE_MIN_BATCH": "0"},
+           "wave_wide": {"HITE_JUDGE_WAVE_COLS": "60000", "HITE_JUDGE_OVERLAP": "0", "HITE_JUDGE_WAVE_MIN_BATCH": "0"}}[mode]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cases = load_golden(name)
@@ -302,11 +304,15 @@ def _synthetic_fine_inputs(seed, n_fam=14, te_types=("tir",)):
 
 
 @pytest.mark.parametrize("te_type", ["tir", "helitron", "non_ltr"])
-def test_fine_stage_vs_oracle_chain(ctx, te_type):
+def test_fine_stage_vs_oracle_chain(ctx, te_type, monkeypatch):
     """the fused pipeline per TE type (judge_TIR / judge_Helitron:86-97 / judge_Non_LTR:48-51 all run flank_region_align_v5)
-    on families shaped for that type, against the oracle chain"""
+    on families shaped for that type, against the oracle chain.  TIR and non-LTR with the one-wavefront-per-alignment judge
+    kernel switched on for this small batch (large batches get it by default), Helitron with the workgroup kernel alone."""
     import oracle_pipeline as OP
     import synth_small
+
+    if te_type != "helitron":
+        monkeypatch.setenv("HITE_JUDGE_WAVE_MIN_BATCH", "0")
 
     n_te = 0
     ran_a = ran_b = 0

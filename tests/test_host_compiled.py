@@ -195,13 +195,13 @@ def test_ext_align_device_function_vs_twin(tmp_path):
         strand = case % 4 >= 2
         step = +1 if (case // 2) % 2 == 0 else -1
         stored = np.array([comp.get(int(b), 78) for b in seg], np.uint8) if strand else seg.copy()
-        q = np.zeros(n + 8, np.uint8)
+        q = np.zeros(n + 40, np.uint8)       # (the kernel reads up to three words ahead of the byte it needs)
         if step > 0:
-            q[4:4 + n] = stored
-            p0 = 4
+            q[20:20 + n] = stored
+            p0 = 20
         else:
-            q[4:4 + n] = stored[::-1]
-            p0 = 4 + n - 1
+            q[20:20 + n] = stored[::-1]
+            p0 = 20 + n - 1
         jmax = (gmax - g0) if d > 0 else (g0 - gmin)
         io, to = C.c_int(0), C.c_int(0)
         lib.host_ext(q.ctypes.data_as(O.u8p), C.c_int64(p0), step, int(strand), n, bases.ctypes.data_as(C.POINTER(C.c_uint32)),
