@@ -1090,6 +1090,13 @@ def rescue_low_copy(TE_type, low_copy, plant, work_dir):
     import shutil
     import subprocess
 
+    if low_copy:
+        # (said once per stage call, in the stage's stderr log: a user must know what this build cannot rescue)
+        sys.stderr.write("[hite_amd] %d low-copy %s candidate%s: the recall by intact protein domains (blastx against the TIR / Helitron / "
+                         "non-LTR peptide libraries, Util.py:8215-8276) is an external search this build does not run%s\n" %
+                         (len(low_copy), TE_type, "" if len(low_copy) == 1 else "s",
+                          "; only TIR-structure signatures are recalled" if TE_type == "tir" else
+                          ": low-copy %s elements stay in the low-copy file" % TE_type))
     if TE_type != "tir" or not low_copy:
         return {}, dict(low_copy)
     os.makedirs(work_dir, exist_ok=True)
@@ -1102,7 +1109,9 @@ def rescue_low_copy(TE_type, low_copy, plant, work_dir):
             _n, mc = read_fasta(m)
             masked = {n: mc[n] for n in low_copy if n in mc}
     else:
-        sys.stderr.write("[hite_amd] trf not found: low-copy candidates are not TRF-masked before the TIR-structure recall\n")
+        # the build's own masker (the resident genome becomes these sequences; whoever needs the reference next packs it again)
+        names_lc = list(low_copy.keys())
+        masked = mask_tandem_repeats(names_lc, low_copy)
     short = get_short_tir_contigs(masked, plant)
     rest = {n: s_ for n, s_ in masked.items() if n not in short}
     found = {}
