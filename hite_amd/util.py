@@ -1079,9 +1079,10 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
     return true_tes, low_copy
 
 
-def rescue_low_copy(TE_type, low_copy, plant, work_dir):
+def rescue_low_copy(TE_type, low_copy, plant, work_dir, tandem_masker=None):
     """The recall of low-copy elements by structure (Util.py:8196-8213 + remove_no_tirs, :13897-13920), TIR stage: the
-    low-copy sequences go through TRF (tandem repeats -> N) when `trf` is installed, those with a short-TIR signature
+    low-copy sequences go through TRF (tandem repeats -> N) when `trf` is installed and through the build's own masker
+    otherwise (`tandem_masker(names, contigs) -> contigs` overrides it), those with a short-TIR signature
     (get_short_tir_contigs: hAT / Mutator / CACTA / CCC..GGG ends matching the TSD length in the name) are real TEs, the
     rest is handed to `itrsearch -i 0.7 -l 7` when it is installed and kept if it reports a terminal inverted repeat
     (with the sequence itrsearch writes).  -> (rescued, still low copy).  The recall by intact protein domains
@@ -1110,8 +1111,7 @@ def rescue_low_copy(TE_type, low_copy, plant, work_dir):
             masked = {n: mc[n] for n in low_copy if n in mc}
     else:
         # the build's own masker (the resident genome becomes these sequences; whoever needs the reference next packs it again)
-        names_lc = list(low_copy.keys())
-        masked = mask_tandem_repeats(names_lc, low_copy)
+        masked = (tandem_masker or mask_tandem_repeats)(list(low_copy.keys()), low_copy)
     short = get_short_tir_contigs(masked, plant)
     rest = {n: s_ for n, s_ in masked.items() if n not in short}
     found = {}
