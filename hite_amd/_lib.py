@@ -39,6 +39,8 @@ def load():
         lib = C.CDLL(SO_PATH)
         lib.hite_last_error.restype = C.c_char_p
         lib.hite_genome_bases.restype = C.c_int64
+        lib.hite_host_free.restype = None
+        lib.hite_host_free.argtypes = [C.c_void_p]
         _lib = lib
     return _lib
 
@@ -248,19 +250,18 @@ class Context:
         cols = np.zeros(n, dtype=np.int32)
         rows = np.zeros(n, dtype=np.int32)
         inf = np.zeros((len(flat), 5), dtype=np.int32)
-
-        def call(cap, out, moff):
-            if info:
-                return self.lib.hite_star_msa_info(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), _p(rows), _p(inf),
-                                                   C.c_int64(cap), out, moff)
-            fn = self.lib.hite_star_msa_sparse if sparse else self.lib.hite_star_msa
-            return fn(self.h, n, _p(buf), _p(off), _p(row_first), _p(cols), _p(rows), C.c_int64(cap), out, moff)
-
-        self._check(call(0, None, None), "hite_star_msa(sizes)")
-        cap = int(((rows.astype(np.int64) * cols + 15) // 16 * 16).sum()) + 16
-        out = np.zeros(cap, dtype=np.uint8)
-        moff = np.zeros(n, dtype=np.int64)
-        self._check(call(cap, _p(out), _p(moff)), "hite_star_msa(fill)")
+        moff = np.zeros(max(n, 1), dtype=np.int64)
+        if n == 0:
+            return ([], []) if info else []
+        # ONE call: the library allocates the result (the sizes-then-fill protocol of hite_star_msa ran the alignment twice)
+        ptr = C.POINTER(C.c_uint8)()
+        nbytes = C.c_int64(0)
+        self._check(self.lib.hite_star_msa_once(self.h, n, _p(buf), _p(off), _p(row_first), 1 if sparse else 0, _p(cols), _p(rows),
+                                                _p(inf) if info else None, C.byref(ptr), _p(moff), C.byref(nbytes)), "hite_star_msa_once")
+        try:
+            out = np.ctypeslib.as_array(ptr, shape=(max(int(nbytes.value), 1),)).copy() if nbytes.value > 0 else np.zeros(1, dtype=np.uint8)
+        finally:
+            self.lib.hite_host_free(C.cast(ptr, C.c_void_p))
         res = []
         for i in range(n):
             if cols[i] <= 0:

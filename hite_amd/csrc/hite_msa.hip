@@ -500,7 +500,7 @@ struct MBuf {
 // input row (U, certified, status, k*, band words | 0x100), zeros for the centres.
 static int star_msa_host(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off,
                          const int32_t *row_first, int32_t *cols_out, int32_t *rows_out, int64_t msa_cap, uint8_t *msa_out,
-                         int64_t *msa_off_out, int32_t *info_out, bool sparse) {
+                         int64_t *msa_off_out, int32_t *info_out, bool sparse, uint8_t **msa_alloc = nullptr, int64_t *msa_bytes = nullptr) {
     if (!ctx || n < 0 || !win || !win_off || !row_first || !cols_out) return HITE_EINVAL;
     if (n == 0) return HITE_OK;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
@@ -555,7 +555,7 @@ static int star_msa_host(hite_ctx *ctx, int32_t n, const uint8_t *win, const int
     if (hipMemcpy(rows_h, drows.p, n * 4, hipMemcpyDeviceToHost) != hipSuccess) { free(rows_h); return HITE_EHIP; }
     if (rows_out) memcpy(rows_out, rows_h, sizeof(int32_t) * n);
     if (info_out && hipMemcpy(info_out, dinfo.p, (size_t)total_rows * 20, hipMemcpyDeviceToHost) != hipSuccess) { free(rows_h); return HITE_EHIP; }
-    if (!msa_out) { free(rows_h); return HITE_OK; }
+    if (!msa_out && !msa_alloc) { free(rows_h); return HITE_OK; }
     if (!msa_off_out) { free(rows_h); return HITE_EINVAL; }
     int64_t off = 0;
     for (int c = 0; c < n; c++) {
@@ -563,7 +563,12 @@ static int star_msa_host(hite_ctx *ctx, int32_t n, const uint8_t *win, const int
         off += ((int64_t)rows_h[c] * cols_out[c] + 15) / 16 * 16;
     }
     free(rows_h);
-    if (off > msa_cap) return HITE_ECAP;
+    if (msa_alloc) {       // one-call form: the alignments come back in a buffer of exactly the size they need (hite_host_free)
+        msa_out = (uint8_t *)malloc((size_t)off + 16);
+        if (!msa_out) return HITE_ENOMEM;
+        *msa_alloc = msa_out;
+        if (msa_bytes) *msa_bytes = off;
+    } else if (off > msa_cap) return HITE_ECAP;
     e = dmo.up(msa_off_out, n * 8); if (e == hipSuccess) e = dmsa.alloc(off + 16);
     HITE_CHECK(ctx, e);
     if (sparse)
@@ -589,6 +594,19 @@ extern "C" int hite_star_msa_sparse(hite_ctx *ctx, int32_t n, const uint8_t *win
                                     int64_t *msa_off_out) {
     return star_msa_host(ctx, n, win, win_off, row_first, cols_out, rows_out, msa_cap, msa_out, msa_off_out, nullptr, true);
 }
+// One call instead of the sizes call + the fill call (each of which runs the whole pairwise alignment): the alignments are
+// returned in a host buffer this function allocates (*msa_out, *msa_bytes_out bytes; release it with hite_host_free);
+// sparse != 0: sparse columns already removed; info_out (may be NULL) as hite_star_msa_info.
+extern "C" int hite_star_msa_once(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
+                                  int32_t sparse, int32_t *cols_out, int32_t *rows_out, int32_t *info_out, uint8_t **msa_out,
+                                  int64_t *msa_off_out, int64_t *msa_bytes_out) {
+    if (!msa_out || !msa_off_out) return HITE_EINVAL;
+    *msa_out = nullptr;
+    int rc = star_msa_host(ctx, n, win, win_off, row_first, cols_out, rows_out, 0, nullptr, msa_off_out, info_out, sparse != 0, msa_out, msa_bytes_out);
+    if (rc && *msa_out) { free(*msa_out); *msa_out = nullptr; }
+    return rc;
+}
+extern "C" void hite_host_free(void *p) { free(p); }
 // pairwise view of the same stage (tests, diagnostics): group c = (centre, row_1, ..., row_k); info_out = 5 int32 per input
 // window (zeros for the centres): cost U of the alignment kept, certified (0/1), status (0 aligned, 1 / 2 dropped), the
 // certificate's bound k*, band words of the run kept | 0x100 for the wide fall-back.  With msa_out the alignments too.

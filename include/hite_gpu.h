@@ -317,6 +317,13 @@ int hite_star_msa_sparse(hite_ctx *ctx, int32_t n, const uint8_t *win, const int
 int hite_star_msa_info(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
                        int32_t *cols_out, int32_t *rows_out, int32_t *info_out, int64_t msa_cap, uint8_t *msa_out,
                        int64_t *msa_off_out);
+/* One call for the host form (the sizes call + the fill call each run the whole pairwise alignment): the alignments come back in
+ * a host buffer the library allocates (*msa_out, *msa_bytes_out bytes, alignment i at msa_off_out[i]; release with
+ * hite_host_free); sparse != 0: sparse columns removed; info_out (optional): 5 int32 per input row as hite_star_msa_info. */
+int hite_star_msa_once(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
+                       int32_t sparse, int32_t *cols_out, int32_t *rows_out, int32_t *info_out, uint8_t **msa_out,
+                       int64_t *msa_off_out, int64_t *msa_bytes_out);
+void hite_host_free(void *p);
 int hite_star_msa_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
                       const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base, int64_t ops_elems,
                       int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status, int32_t *d_rows_out, void *stream);
