@@ -38,13 +38,14 @@ CONFIGS = {
 
 
 def valu_peak():
-    """wave64 issue rates MEASURED on MI355X by tools/valu_issue_bench.hip (profiles/r02_valu_issue.txt), at 8 waves per SIMD, as two
+    """wave64 issue rates MEASURED on MI355X by tools/valu_issue_bench.hip (profiles/rNN_valu_issue.txt, newest), at 8 waves per SIMD, as two
     classes and no blend: instructions that issue every ~4.1 cycles per SIMD (3-operand, bit-field, carry, DPP, shifts: what the
     alignment recurrence is mostly made of) and those that issue every ~2.1 cycles (2-operand add / xor).  -> (G wave-inst/s of
     the 4-cycle class, of the 2-cycle class): medians of the measured lines of each class."""
     c4, c2 = [], []
     try:
-        for line in open(os.path.join(ROOT, "profiles", "r02_valu_issue.txt")):
+        import glob
+        for line in open(sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_valu_issue.txt")))[-1]):
             f = line.split()
             if len(f) < 4 or line.startswith("#"):
                 continue

@@ -101,9 +101,10 @@ __device__ __forceinline__ void bp_core(uint32_t (&X2)[NW], uint32_t (&X1)[NW], 
         const uint32_t B = eq | vneg, P = (vpos << 1) | vpc;
         vpc = vpos >> 31;
         const uint32_t Y = P | B;
-        const unsigned long long sum = (unsigned long long)B + Y + cin;
-        cin = (uint32_t)(sum >> 32);
-        const uint32_t Z = B | (P & ((uint32_t)sum ^ B ^ Y));        // diagonal difference 0
+        unsigned cout;                                              // (add-with-carry: one v_addc_co_u32 per word)
+        const uint32_t sum = __builtin_addc(B, Y, cin, &cout);
+        cin = cout;
+        const uint32_t Z = B | (P & (sum ^ B ^ Y));                  // diagonal difference 0
         // horizontal difference + 3 = 6 + (1 - Z) - x
         const uint32_t h0 = ~(Z ^ x0), b1 = Z & x0, h1 = ~(x1 ^ b1), b2 = x1 & b1, h2 = ~(x2 ^ b2);
         const uint32_t s2 = (h2 << 1) | h2c, s1 = (h1 << 1) | h1c, s0 = (h0 << 1) | h0c;
@@ -438,9 +439,9 @@ __global__ void __launch_bounds__(64) align_fwd8_pair_kernel(AlignArgs P, const 
                 if (w == HW - 1) tap0 = cin;               // lower lane: the carry that enters word 3 (exact: its carry-in is 0)
                 Pv[w] = (vposv[w] << 1) | (w ? vposv[w - 1] >> 31 : vin);
                 Yv[w] = Pv[w] | Bv[w];
-                const unsigned long long sum = (unsigned long long)Bv[w] + Yv[w] + cin;
-                Sv[w] = (uint32_t)sum;
-                cin = (uint32_t)(sum >> 32);
+                unsigned cout;
+                Sv[w] = __builtin_addc(Bv[w], Yv[w], cin, &cout);
+                cin = cout;
             }
             {   // the upper lane's carry-in = the lower lane's carry-out: ripple it through sums that are all ones
                 const uint32_t pc = pair_partner(cin);

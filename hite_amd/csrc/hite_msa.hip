@@ -462,9 +462,14 @@ extern "C" int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uin
     P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff;
     Q.last_extra = d_last_extra; Q.lay = ctx->d_msa_lay;
     if (!Q.lay) return HITE_EINVAL;
-    // (round 3 measured a positions-outer form -- a thread owns four centre positions, keeps their layout words in registers
-    // and walks the rows four at a time, 8-byte ops loads, 4-byte base loads and stores: half the traffic and a third of
-    // the instructions of this kernel, and twice its time (3.9 + 13.1 ms against 1.9 + 6.4 ms per C3 step); not kept)
+    // Round 3 measured three other forms of this kernel on C3 (this one: 1.9 + 6.0 ms per step for the two passes):
+    //   * positions-outer (a thread owns four centre positions, keeps their layout words and walks the rows): 3.9 + 13.1 ms;
+    //   * four consecutive positions per thread, 16 / 8 / 8-byte loads and one 4-byte store, one, two or four rows per
+    //     trip, no conditional load on the main path: 2.2 + 6.6, 2.4 + 7.3, 2.1 + 6.2 ms -- a quarter of the memory
+    //     instructions, no gain;
+    //   * this kernel with two rows per trip (twice the bytes in flight per wavefront): 3.5 + 11.7 ms.
+    // Neither instructions nor latency bound it: the two launches move 19 GB (FETCH_SIZE + WRITE_SIZE as counted; 34 GB
+    // with the guide's gfx950 fetch correction) in 8 ms, 2.3 - 4 TB/s; 2 B of ops per cell are most of it.
     hipLaunchKernelGGL(star_fill_sparse_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
     HITE_CHECK(ctx, hipGetLastError());
     return HITE_OK;

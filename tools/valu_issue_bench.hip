@@ -56,6 +56,35 @@
 #define OP_LSHR(R) "v_lshrrev_b32 " R ", 1, " R "\n\t"
 #define OP_MIN(R) "v_min_i32 " R ", " R ", %8\n\t"
 #define OP_SUB(R) "v_sub_u32 " R ", " R ", %8\n\t"
+#define OP_FFBH(R) "v_ffbh_u32 " R ", " R "\n\t"
+#define OP_MOV(R) "v_mov_b32 " R ", %8\n\t"
+#define OP_XAD(R) "v_xad_u32 " R ", " R ", %8, %9\n\t"
+#define OP_ADD3(R) "v_add3_u32 " R ", " R ", %8, %9\n\t"
+#define OP_LSHLOR(R) "v_lshl_or_b32 " R ", " R ", 1, %8\n\t"
+#define OP_BFEI(R) "v_bfe_i32 " R ", " R ", 1, 1\n\t"
+#define OP_ASHR(R) "v_ashrrev_i32 " R ", 1, " R "\n\t"
+#define OP_CMPEQ(R) "v_cmp_eq_u32 vcc, " R ", %8\n\t"
+#define OP_LSHRV(R) "v_lshrrev_b32 " R ", %9, " R "\n\t"
+#define OP_LSHLV(R) "v_lshlrev_b32 " R ", %9, " R "\n\t"
+#define OP_ADDCO(R) "v_add_co_u32 " R ", vcc, " R ", %8\n\t"
+// 64-bit operands (register pairs)
+#define OP_LSHR64(R) "v_lshrrev_b64 " R ", 1, " R "\n\t"
+#define OP_LSHL64(R) "v_lshlrev_b64 " R ", 1, " R "\n\t"
+#define OP_LSHLADD64(R) "v_lshl_add_u64 " R ", " R ", 0, %8\n\t"
+#define OP_LSHR64V(R) "v_lshrrev_b64 " R ", %9, " R "\n\t"
+
+#define KERNEL64(NAME, OP)                                                                            \
+    __global__ void __launch_bounds__(256) NAME(uint32_t *out, uint32_t seed) {                       \
+        unsigned long long a0 = threadIdx.x + seed, a1 = a0 * 3, a2 = a0 * 5, a3 = a0 * 7, a4 = a0 * 11, a5 = a0 * 13, a6 = a0 * 17, a7 = a0 * 19; \
+        unsigned long long k = seed | 1u; uint32_t s = seed & 3u;                                     \
+        for (int it = 0; it < ITER; it++) {                                                           \
+            asm volatile(BLOCK64(OP)                                                                  \
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
+                         : "v"(k), "v"(s)                                                             \
+                         : "vcc");                                                                    \
+        }                                                                                             \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (uint32_t)(a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7);           \
+    }
 
 KERNEL(k_add, OP_ADD)
 KERNEL(k_xor, OP_XOR)
@@ -82,6 +111,21 @@ KERNEL(k_bitop3, OP_BITOP3)
 KERNEL(k_lshr, OP_LSHR)
 KERNEL(k_min, OP_MIN)
 KERNEL(k_sub, OP_SUB)
+KERNEL(k_ffbh, OP_FFBH)
+KERNEL(k_mov, OP_MOV)
+KERNEL(k_xad, OP_XAD)
+KERNEL(k_add3, OP_ADD3)
+KERNEL(k_lshlor, OP_LSHLOR)
+KERNEL(k_bfei, OP_BFEI)
+KERNEL(k_ashr, OP_ASHR)
+KERNEL(k_cmpeq, OP_CMPEQ)
+KERNEL(k_lshrv, OP_LSHRV)
+KERNEL(k_lshlv, OP_LSHLV)
+KERNEL(k_addco, OP_ADDCO)
+KERNEL64(k_lshr64, OP_LSHR64)
+KERNEL64(k_lshl64, OP_LSHL64)
+KERNEL64(k_lshladd64, OP_LSHLADD64)
+KERNEL64(k_lshr64v, OP_LSHR64V)
 
 typedef void (*kfn)(uint32_t *, uint32_t);
 struct Entry { const char *name; kfn fn; };
@@ -98,7 +142,11 @@ int main() {
                    {"v_addc_co_u32", k_addc}, {"v_add_u32_dpp row", k_add_dpp}, {"v_mov_dpp wave_shr", k_mov_dpp_wshr}, {"v_cndmask_b32", k_cndmask},
                    {"v_lshl_add_u32", k_lshladd}, {"v_cndmask_e64 sgpr", k_cndmask64}, {"v_cmp+v_cndmask (2)", k_cmp_cnd},
                    {"v_bfe_u32", k_bfe}, {"v_and_b32", k_and}, {"v_or_b32", k_or}, {"v_not_b32", k_not}, {"v_bitop3_b32", k_bitop3},
-                   {"v_lshrrev_b32", k_lshr}, {"v_min_i32", k_min}, {"v_sub_u32", k_sub}};
+                   {"v_lshrrev_b32", k_lshr}, {"v_min_i32", k_min}, {"v_sub_u32", k_sub},
+                   {"v_ffbh_u32", k_ffbh}, {"v_mov_b32", k_mov}, {"v_xad_u32", k_xad}, {"v_add3_u32", k_add3}, {"v_lshl_or_b32", k_lshlor},
+                   {"v_bfe_i32", k_bfei}, {"v_ashrrev_i32", k_ashr}, {"v_cmp_eq_u32 vcc", k_cmpeq}, {"v_lshrrev_b32 var", k_lshrv},
+                   {"v_lshlrev_b32 var", k_lshlv}, {"v_add_co_u32", k_addco}, {"v_lshrrev_b64", k_lshr64}, {"v_lshlrev_b64", k_lshl64},
+                   {"v_lshl_add_u64", k_lshladd64}, {"v_lshrrev_b64 var", k_lshr64v}};
     uint32_t *out;
     if (hipMalloc(&out, (size_t)cus * 8 * 256 * 4 * 4) != hipSuccess) return 1;
     hipEvent_t e0, e1;
