@@ -921,27 +921,28 @@ __global__ void align_assign_kernel(int64_t cnt, const int32_t *__restrict__ lis
 // counters: [0] pairs, [1] certified, [2] kept from a band of > 4 words, [3] fall-back, [4] dropped, [5] sum of U, [6] columns
 __global__ void __launch_bounds__(256) align_stats_kernel(int64_t total_rows, const int32_t *__restrict__ strips, AlignArgs P, int32_t *__restrict__ row_dead,
                                                           int32_t *__restrict__ cand_status, unsigned long long *__restrict__ acc) {
-    // (sums over the wavefront first: seven same-address atomics per row were 0.6 ms per launch)
-    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // grid-stride over the rows, sums kept in registers, one reduction per workgroup at the end: 7 atomics per workgroup of a
+    // 1024-workgroup launch (seven same-address atomics per row were 0.6 ms per launch, per wavefront still 0.55 ms)
+    __shared__ unsigned long long s_acc[4][7];
     unsigned long long v[7] = {0, 0, 0, 0, 0, 0, 0};
-    if (g < total_rows) {
+    for (int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; g < total_rows; g += (int64_t)gridDim.x * blockDim.x) {
         if (strips[g] <= 0) {
             // a centre -- or an EMPTY non-centre row (the _dev entry points do not validate lengths): that one is dropped like a
             // row the aligner could not place, instead of reaching the layout with an ops row nobody wrote
             const bool empty_row = g != P.row_first[P.row_cand[g]];
-            if (empty_row) { P.st[g] = 2; P.U[g] = -1; P.kst[g] = -1; P.lvl[g] = 0; v[0] = 1ull; v[4] = 1ull; }
+            if (empty_row) { P.st[g] = 2; P.U[g] = -1; P.kst[g] = -1; P.lvl[g] = 0; v[0] += 1ull; v[4] += 1ull; }
             if (row_dead) row_dead[g] = empty_row;
             if (empty_row && cand_status) atomicExch(&cand_status[P.row_cand[g]], 2);
         }
         else {
             const int st = P.st[g];
-            v[0] = 1ull;
-            v[1] = st == 0 && P.U[g] <= P.kst[g];
-            v[2] = st == 0 && (P.lvl[g] & 0xff) > 4;
-            v[3] = (P.lvl[g] & 0x100) != 0;
-            v[4] = st != 0;
-            v[5] = st == 0 ? (unsigned long long)P.U[g] : 0ull;
-            v[6] = (unsigned long long)P.win_len[g];
+            v[0] += 1ull;
+            v[1] += st == 0 && P.U[g] <= P.kst[g];
+            v[2] += st == 0 && (P.lvl[g] & 0xff) > 4;
+            v[3] += (P.lvl[g] & 0x100) != 0;
+            v[4] += st != 0;
+            v[5] += st == 0 ? (unsigned long long)P.U[g] : 0ull;
+            v[6] += (unsigned long long)P.win_len[g];
             if (row_dead) row_dead[g] = st != 0;
             if (st != 0 && cand_status) atomicExch(&cand_status[P.row_cand[g]], 2);
         }
@@ -951,7 +952,12 @@ __global__ void __launch_bounds__(256) align_stats_kernel(int64_t total_rows, co
         unsigned long long x = v[q];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&acc[q], x);
+        if ((threadIdx.x & 63) == 0) s_acc[threadIdx.x >> 6][q] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < 7) {
+        const unsigned long long x = s_acc[0][threadIdx.x] + s_acc[1][threadIdx.x] + s_acc[2][threadIdx.x] + s_acc[3][threadIdx.x];
+        if (x) atomicAdd(&acc[threadIdx.x], x);
     }
 }
 __global__ void align_info_kernel(int64_t total_rows, AlignArgs P, int32_t *__restrict__ info /* 5 per row */) {
@@ -1233,7 +1239,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
         }
     }
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
-    hipLaunchKernelGGL(align_stats_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, total_rows, strips, P, d_row_dead, d_cand_flag,
+    hipLaunchKernelGGL(align_stats_kernel, dim3((unsigned)(total_rows + 255 < 1024 * 256 ? (total_rows + 255) / 256 : 1024)), dim3(256), 0, st, total_rows, strips, P, d_row_dead, d_cand_flag,
                        (unsigned long long *)S->d_scal);
     if (d_info) hipLaunchKernelGGL(align_info_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, total_rows, P, d_info);
     HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, 56, hipMemcpyDeviceToHost, st));

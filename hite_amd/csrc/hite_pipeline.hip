@@ -176,6 +176,7 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
     if (threadIdx.x == 0) { row_first32[c] = (int32_t)row_first[c]; if (c == n - 1) row_first32[n] = (int32_t)row_first[n]; }
     int R = nrows[c];
     int md = mode[c];
+    int mx = 0;
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
         int64_t g = row_first[c] + r;
         int cp = sel[(int64_t)c * MAXROWS + r];
@@ -184,8 +185,12 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
         row_len[g] = L;
         row_pad[g] = (L + 15) & ~15;
         row_trunc[g] = md == 2;
-        atomicMax(maxlen, L);
+        mx = L > mx ? L : mx;
     }
+    // one atomic per wavefront (one per row on a single address was half a millisecond per launch)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
+    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(maxlen, mx);
 }
 
 // one wavefront per row: window (or its first500+last500 form) from the packed genome
