@@ -702,8 +702,101 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
     return v;
 }
 
-__global__ void __launch_bounds__(64) align_wide_fwd_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+// A lone wavefront issues one instruction every ~4.6 cycles whatever its kind (profiles/r03_valu_issue.txt, 1 wave per SIMD), and
+// the 51 pairs of a C3 step that come here are its longest: the kernel's time is instructions per column x columns of the
+// longest pair.  So the columns are unrolled in strips of 16 (every index a constant, no loop arithmetic), the 16 row bases
+// of a strip are decoded by 16 lanes at once into three wave masks (one scalar bit-field extract per column and mask
+// instead of the scalar compare chain), the carry of the addition comes straight from the add's carry-out mask and goes back
+// in through an add-with-carry, and the band position is stored once per move (four columns).
+__device__ __forceinline__ uint32_t add_co_mask(uint32_t a, uint32_t b, unsigned long long &carry_mask) {
+    uint32_t r;
+    asm volatile("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(carry_mask) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t add_mask_bit(uint32_t a, unsigned long long mask) {     // a + (this lane's bit of mask)
+    uint32_t r;
+    unsigned long long dummy;
+    asm volatile("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(dummy) : "v"(a), "s"(mask));
+    return r;
+}
+// lane i <- lane i-1 of v; lane 0 keeps what `keep` held before (its own fill value, written once before the loop: the
+// builtin form re-materialises the fill in front of every move).  The s_nop covers the VALU-write -> DPP-read hazard of v,
+// which the compiler does not track through an asm statement.
+__device__ __forceinline__ uint32_t lane_below_keep(uint32_t v, uint32_t &keep) {
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(keep) : "v"(v));
+    return keep;
+}
+__device__ __forceinline__ void lane_below_keep3(uint32_t v2, uint32_t v1, uint32_t v0, uint32_t &k2, uint32_t &k1, uint32_t &k0) {
+    asm volatile("s_nop 1\n\tv_mov_b32_dpp %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf\n\tv_mov_b32_dpp %1, %4 wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_mov_b32_dpp %2, %5 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(k2), "+v"(k1), "+v"(k0) : "v"(v2), "v"(v1), "v"(v0));
+}
+struct WideFwd {
+    uint32_t X2, X1, X0, A0, A1, AN, f0, f1, fn;
+    uint32_t kz0, kz1, ko0, ko1;       // registers of lane_below_keep: lane 0 holds 0 / 0 / bit 31 / bit 31
+    int t, stop, LO, HI, status;
+};
+// one strip of <= 16 columns j0 .. j0 + 15 (FULL: all 16 exist, no per-column test)
+template <bool FULL>
+__device__ __forceinline__ void wide_fwd_strip(WideFwd &S, const AlignArgs &P, int lane, int m, int n, int j0, int64_t full0, unsigned long long M0,
+                                               unsigned long long M1, unsigned long long MI) {
     constexpr int NW = AL_WIDE_NW, W = 32 * NW, H = W / 2, S0 = NW / 2 - 1;
+    uint32_t *fb = P.fullbuf + (full0 + j0) * (2 * NW) + lane;
+#pragma unroll
+    for (int cc = 0; cc < AL_STRIP; cc++) {
+        const int j = j0 + cc;
+        if (FULL || (j <= n && S.status == 0)) {
+            if ((cc & 3) == 0) {   // the band moves in every fourth column only, by 0 / 4 / 8 rows (same rule as align_fwd_kernel)
+                const int dv = slope_count(S.X2, S.X1, S.X0);
+                const int ds = __builtin_amdgcn_readlane(dv, S0) + __builtin_amdgcn_readlane(dv, S0 + 1);
+                int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 8 : 4);
+                const int tr = m - H;
+                if (S.t + s > tr) s = (tr - S.t) & ~3;
+                const int need = tr - 3 - 8 * ((n - j) >> 2) - S.t;
+                if (s < need) s = (need + 3) & ~3;
+                if (s > 8) { S.status = 2; s = 8; }      // (the columns that follow compute on, nothing of them is used)
+                const uint32_t smask = (1u << s) - 1u;
+                S.stop += plane_sum((uint32_t)__builtin_amdgcn_readlane((int)S.X2, 0), (uint32_t)__builtin_amdgcn_readlane((int)S.X1, 0),
+                                    (uint32_t)__builtin_amdgcn_readlane((int)S.X0, 0), smask) - AL_GAP * s;
+                S.X2 = alignbit(lane_above(S.X2, 0xffffffffu), S.X2, (uint32_t)s);
+                S.X1 = alignbit(lane_above(S.X1, 0xffffffffu), S.X1, (uint32_t)s);
+                S.X0 = alignbit(lane_above(S.X0, 0u), S.X0, (uint32_t)s);
+                S.A0 = alignbit(lane_above(S.A0, S.f0), S.A0, (uint32_t)s);
+                S.A1 = alignbit(lane_above(S.A1, S.f1), S.A1, (uint32_t)s);
+                S.AN = alignbit(lane_above(S.AN, S.fn), S.AN, (uint32_t)s);
+                S.f0 >>= s; S.f1 >>= s; S.fn >>= s;
+                S.t += s;
+                if (S.t >= 1) { const int v = S.t + 1 - j; S.LO = v > S.LO ? v : S.LO; }
+                if (S.t + W < m) { const int jl = j + 3 < n ? j + 3 : n; const int v = S.t + W - jl; S.HI = v < S.HI ? v : S.HI; }
+                if (lane < 4 && j + lane <= n) P.fullt[full0 + j + lane] = S.t;      // t of the four columns of this move
+            }
+            S.stop += AL_GAP;
+            BaseMask bm;
+            bm.m0 = 0u - (uint32_t)((M0 >> cc) & 1ull); bm.m1 = 0u - (uint32_t)((M1 >> cc) & 1ull); bm.inv = 0u - (uint32_t)((MI >> cc) & 1ull);
+            const uint32_t eq = ~((S.A0 ^ bm.m0) | (S.A1 ^ bm.m1) | S.AN | bm.inv);
+            const uint32_t vneg = ~(S.X2 | S.X1 | S.X0), vpos = S.X2 & S.X1;
+            const uint32_t B = eq | vneg, Pp = alignbit(vpos, lane_below_keep(vpos, S.kz0), 31);
+            const uint32_t Y = Pp | B;
+            unsigned long long Gm;
+            uint32_t sum = add_co_mask(B, Y, Gm);
+            {   // carries along the lanes: lane w generates (its sum wrapped) or propagates (its sum is all ones)
+                const unsigned long long Pm = __ballot(sum == 0xffffffffu);
+                const unsigned long long Yy = Pm | Gm, ss = Gm + Yy;
+                const unsigned long long into = ss ^ Gm ^ Yy;                // carry into bit u of Gm + (Pm | Gm) = carry into lane u
+                sum = add_mask_bit(sum, into);
+            }
+            const uint32_t Z = B | (Pp & (sum ^ B ^ Y));
+            const uint32_t h0 = ~(Z ^ S.X0), b1 = Z & S.X0, h1 = ~(S.X1 ^ b1), b2 = S.X1 & b1, h2 = ~(S.X2 ^ b2);
+            lane_below_keep3(h2, h1, h0, S.ko0, S.ko1, S.kz1);
+            const uint32_t s2 = alignbit(h2, S.ko0, 31), s1 = alignbit(h1, S.ko1, 31), s0 = alignbit(h0, S.kz1, 31);
+            const uint32_t n0 = ~(Z ^ s0), c1 = Z & s0, n1 = ~(s1 ^ c1), c2 = s1 & c1, n2 = ~(s2 ^ c2);
+            S.X2 = n2; S.X1 = n1; S.X0 = n0;
+            fb[cc * (2 * NW)] = eq | ~Z;
+            fb[cc * (2 * NW) + NW] = n2 & n1;
+        }
+    }
+}
+__global__ void __launch_bounds__(64) align_wide_fwd_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    constexpr int NW = AL_WIDE_NW, W = 32 * NW, H = W / 2;
     const int pi = blockIdx.x;
     if (pi >= nlist) return;
     const int lane = threadIdx.x;
@@ -714,87 +807,66 @@ __global__ void __launch_bounds__(64) align_wide_fwd_kernel(AlignArgs P, const i
     const uint8_t *b = P.win + P.win_off[g];
     const uint4 *pl = P.planes + P.plane_off[c];
     const int64_t full0 = P.full_off[g];
-    int t = -H;
-    uint32_t X2 = lane >= NW / 2 ? 0xffffffffu : 0u, X1 = X2, X0 = 0u;
-    uint32_t A0, A1, AN;
-    { const uint4 v = pl[((t + AL_PADR) >> 5) + lane]; A0 = v.x; A1 = v.y; AN = v.z; }
-    int stop = AL_GAP * H, LO = -(1 << 28), HI = 1 << 28, status = 0;
-    uint32_t f0 = 0, f1 = 0, fn = 0;
-    uint4 bw = make_uint4(0, 0, 0, 0);
-    for (int j = 1; j <= n; j++) {
-        const int cc = (j - 1) & 15;
-        if (cc == 0) {   // 16 row bases; the next 32 rows below the band, per plane (at most 2 rows enter per column)
-            bw = *reinterpret_cast<const uint4 *>(b + (j - 1));
-            const int fx = t + W + AL_PADR;
+    WideFwd S;
+    S.t = -H;
+    S.X2 = lane >= NW / 2 ? 0xffffffffu : 0u; S.X1 = S.X2; S.X0 = 0u;
+    { const uint4 v = pl[((S.t + AL_PADR) >> 5) + lane]; S.A0 = v.x; S.A1 = v.y; S.AN = v.z; }
+    S.stop = AL_GAP * H; S.LO = -(1 << 28); S.HI = 1 << 28; S.status = 0;
+    S.kz0 = 0u; S.kz1 = 0u; S.ko0 = 0x80000000u; S.ko1 = 0x80000000u;
+    unsigned chn = b[lane & 15];                     // the row bases of the next strip, one per lane (windows sit in padded slots)
+    for (int j0 = 1; j0 <= n && S.status == 0; j0 += AL_STRIP) {
+        // the strip's bases as three masks: bit cc = code bit 0 / code bit 1 / "never matches" of column j0 + cc
+        const unsigned ch = chn;
+        chn = b[j0 - 1 + AL_STRIP + (lane & 15)];
+        const unsigned long long M0 = __ballot((ch >> 1) & 1u), M1 = __ballot((ch >> 2) & 1u), MI = __ballot(!is_acgt_byte(ch));
+        {   // the next 32 rows below the band, per plane (at most 2 rows enter per column)
+            const int fx = S.t + W + AL_PADR;
             const uint4 F = pl[fx >> 5], G = pl[(fx >> 5) + 1];
             const uint32_t sh = (uint32_t)fx & 31u;
-            f0 = alignbit(G.x, F.x, sh); f1 = alignbit(G.y, F.y, sh); fn = alignbit(G.z, F.z, sh);
+            S.f0 = alignbit(G.x, F.x, sh); S.f1 = alignbit(G.y, F.y, sh); S.fn = alignbit(G.z, F.z, sh);
         }
-        if ((cc & 3) == 0) {   // the band moves in every fourth column only, by 0 / 4 / 8 rows (same rule as align_fwd_kernel)
-            const int dv = slope_count(X2, X1, X0);
-            const int ds = __builtin_amdgcn_readlane(dv, S0) + __builtin_amdgcn_readlane(dv, S0 + 1);
-            int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 8 : 4);
-            const int tr = m - H;
-            if (t + s > tr) s = (tr - t) & ~3;
-            const int need = tr - 3 - 8 * ((n - j) >> 2) - t;
-            if (s < need) s = (need + 3) & ~3;
-            if (s > 8) { status = 2; break; }
-            const uint32_t smask = (1u << s) - 1u;
-            stop += plane_sum((uint32_t)__builtin_amdgcn_readlane((int)X2, 0), (uint32_t)__builtin_amdgcn_readlane((int)X1, 0),
-                              (uint32_t)__builtin_amdgcn_readlane((int)X0, 0), smask) - AL_GAP * s;
-            X2 = alignbit(lane_above(X2, 0xffffffffu), X2, (uint32_t)s);
-            X1 = alignbit(lane_above(X1, 0xffffffffu), X1, (uint32_t)s);
-            X0 = alignbit(lane_above(X0, 0u), X0, (uint32_t)s);
-            A0 = alignbit(lane_above(A0, f0), A0, (uint32_t)s);
-            A1 = alignbit(lane_above(A1, f1), A1, (uint32_t)s);
-            AN = alignbit(lane_above(AN, fn), AN, (uint32_t)s);
-            f0 >>= s; f1 >>= s; fn >>= s;
-            t += s;
-            if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
-            if (t + W < m) { const int jl = j + 3 < n ? j + 3 : n; const int v = t + W - jl; HI = v < HI ? v : HI; }
-        }
-        stop += AL_GAP;
-        const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
-        const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
-        const uint32_t eq = ~((A0 ^ bm.m0) | (A1 ^ bm.m1) | AN | bm.inv);
-        const uint32_t vneg = ~(X2 | X1 | X0), vpos = X2 & X1;
-        const uint32_t B = eq | vneg, Pp = (vpos << 1) | (lane_below(vpos, 0u) >> 31);
-        const uint32_t Y = Pp | B;
-        uint32_t sum = B + Y;
-        {   // carries along the lanes: lane w generates (its sum wrapped) or propagates (its sum is all ones)
-            const unsigned long long Gm = __ballot(sum < B), Pm = __ballot(sum == 0xffffffffu);
-            const unsigned long long Yy = Pm | Gm, ss = Gm + Yy;
-            const unsigned long long into = ss ^ Gm ^ Yy;                // carry into bit u of Gm + (Pm | Gm) = carry into lane u
-            sum += (uint32_t)((into >> lane) & 1ull);
-        }
-        const uint32_t Z = B | (Pp & (sum ^ B ^ Y));
-        const uint32_t h0 = ~(Z ^ X0), b1 = Z & X0, h1 = ~(X1 ^ b1), b2 = X1 & b1, h2 = ~(X2 ^ b2);
-        const uint32_t s2 = (h2 << 1) | (lane_below(h2, 0x80000000u) >> 31), s1 = (h1 << 1) | (lane_below(h1, 0x80000000u) >> 31),
-                       s0 = (h0 << 1) | (lane_below(h0, 0u) >> 31);
-        const uint32_t n0 = ~(Z ^ s0), c1 = Z & s0, n1 = ~(s1 ^ c1), c2 = s1 & c1, n2 = ~(s2 ^ c2);
-        X2 = n2; X1 = n1; X0 = n0;
-        uint32_t *fb = P.fullbuf + (full0 + j) * (2 * NW);
-        fb[lane] = eq | ~Z;
-        fb[NW + lane] = n2 & n1;
-        if (lane == 0) P.fullt[full0 + j] = t;
+        if (j0 + AL_STRIP - 1 <= n) wide_fwd_strip<true>(S, P, lane, m, n, j0, full0, M0, M1, MI);
+        else wide_fwd_strip<false>(S, P, lane, m, n, j0, full0, M0, M1, MI);
     }
     int U = -1, kstar = -1;
-    if (status == 0) {
-        const int extra = m - H - t;   // row m is bit H - 1 + extra, extra = 0 .. 3
-        U = stop - AL_GAP * H - AL_GAP * extra +
-            wave_sum_i32(lane < NW / 2 ? plane_sum(X2, X1, X0, 0xffffffffu) : (lane == NW / 2 ? plane_sum(X2, X1, X0, (1u << extra) - 1u) : 0));
+    if (S.status == 0) {
+        const int extra = m - H - S.t;   // row m is bit H - 1 + extra, extra = 0 .. 3
+        U = S.stop - AL_GAP * H - AL_GAP * extra +
+            wave_sum_i32(lane < NW / 2 ? plane_sum(S.X2, S.X1, S.X0, 0xffffffffu) : (lane == NW / 2 ? plane_sum(S.X2, S.X1, S.X0, (1u << extra) - 1u) : 0));
         const int d = m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
-        int E = dmin - LO;
-        if (HI - dmax < E) E = HI - dmax;
+        int E = dmin - S.LO;
+        if (S.HI - dmax < E) E = S.HI - dmax;
         if (E > (1 << 27)) kstar = 0x7fffffff;
         else if (E >= 0) kstar = AL_GAP * ad + 2 * AL_GAP * E + 2 * AL_GAP - 1;
     }
-    if (lane == 0) { P.U[g] = U; P.kst[g] = kstar; P.st[g] = status; P.lvl[g] = NW | 0x100; }
+    if (lane == 0) { P.U[g] = U; P.kst[g] = kstar; P.st[g] = S.status; P.lvl[g] = NW | 0x100; }
 }
 
 // traceback of the fall-back: one wavefront per pair, lane w holds word w of the column's bits; the run of up steps ends at
 // the highest stop bit (diagonal allowed, or up not allowed) at or below the current row -- two ballots and a count of
 // leading zeros; ops leave in coalesced runs.  The columns are fetched eight at a time (the walk visits them in order).
+// ops leave through the lanes: lane l holds the op of position base + l of the current block of 64 positions; a block goes out
+// as one coalesced store when the walk leaves it downwards
+struct WideOps {
+    uint16_t *ops;
+    int m, lane;
+    uint32_t acc;
+    __device__ __forceinline__ void flush(int base) { if (base + lane < m) ops[base + lane] = (uint16_t)acc; }
+    __device__ __forceinline__ void put(int pos, uint32_t val) {          // one op at position pos (wave-uniform)
+        if (lane == (pos & 63)) acc = val;
+        if ((pos & 63) == 0) flush(pos);
+    }
+    __device__ __forceinline__ void run(int hi, int count, uint32_t val) {   // positions hi, hi - 1, ..., hi - count + 1
+        while (count > 0) {
+            const int base = hi & ~63;
+            const int lo = hi - count + 1 > base ? hi - count + 1 : base;
+            if (base + lane >= lo && base + lane <= hi) acc = val;
+            const int k = hi - lo + 1;
+            count -= k; hi -= k;
+            if (lo == base) flush(base);
+        }
+    }
+};
 __global__ void __launch_bounds__(64) align_wide_tb_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
     constexpr int NW = AL_WIDE_NW, W = 32 * NW, PF = 8;
     const int pi = blockIdx.x;
@@ -804,56 +876,61 @@ __global__ void __launch_bounds__(64) align_wide_tb_kernel(AlignArgs P, const in
     const int c = P.row_cand[g], g0 = P.row_first[c];
     if (g == g0 || P.st[g] != 0) return;
     const int m = P.win_len[g0], n = P.win_len[g];
-    uint16_t *ops = P.ops + P.ops_base[c] + (int64_t)(g - g0) * (m + 1);
+    WideOps out;
+    out.ops = P.ops + P.ops_base[c] + (int64_t)(g - g0) * (m + 1); out.m = m; out.lane = lane; out.acc = 0u;
     const int64_t full0 = P.full_off[g];
     int i = m, j = n;
     bool fail = false;
     // the columns are visited one per step in descending order, so the next eight are fetched while these eight are walked
-    // (a lone wavefront per pair has nothing else to hide the load behind: the fetch used to be half of the kernel's time)
-    uint32_t dgn[PF], upn[PF];
+    // (a lone wavefront per pair has nothing else to hide the load behind: the fetch used to be half of the kernel's time).
+    // The common step is the diagonal one -- the diagonal bit of the current cell is set: canonical first choice -- and needs
+    // that one bit only (a readlane and scalar code); the "up" words are fetched when a column needs the general rule.
+    uint32_t dgn[PF];
     int ttn[PF];
 #pragma unroll
     for (int q = 0; q < PF; q++) {
         const int jq = j - q > 0 ? j - q : 1;
-        const uint32_t *fb = P.fullbuf + (full0 + jq) * (2 * NW);
-        dgn[q] = fb[lane]; upn[q] = fb[NW + lane]; ttn[q] = P.fullt[full0 + jq];
+        dgn[q] = P.fullbuf[(full0 + jq) * (2 * NW) + lane]; ttn[q] = P.fullt[full0 + jq];
     }
     while (i > 0 && j > 0 && !fail) {
-        uint32_t dgs[PF], ups[PF];
+        uint32_t dgs[PF];
         int tts[PF];
 #pragma unroll
-        for (int q = 0; q < PF; q++) { dgs[q] = dgn[q]; ups[q] = upn[q]; tts[q] = ttn[q]; }
+        for (int q = 0; q < PF; q++) { dgs[q] = dgn[q]; tts[q] = ttn[q]; }
 #pragma unroll
         for (int q = 0; q < PF; q++) {
             const int jq = j - PF - q > 0 ? j - PF - q : 1;
-            const uint32_t *fb = P.fullbuf + (full0 + jq) * (2 * NW);
-            dgn[q] = fb[lane]; upn[q] = fb[NW + lane]; ttn[q] = P.fullt[full0 + jq];
+            dgn[q] = P.fullbuf[(full0 + jq) * (2 * NW) + lane]; ttn[q] = P.fullt[full0 + jq];
         }
 #pragma unroll
         for (int q = 0; q < PF; q++) {
             if (i > 0 && j > 0 && !fail) {
-                const uint32_t dgw = dgs[q], upw = ups[q];
+                const uint32_t dgw = dgs[q];
                 const int kb = i - tts[q] - 1;
                 if ((unsigned)kb >= (unsigned)W) fail = true;
                 else {
                     const int wq = kb >> 5;
-                    const uint32_t low = 0xffffffffu >> (31 - (kb & 31));
-                    const uint32_t sbit = dgw | ~upw;
-                    const uint32_t mk = lane > wq ? 0u : (lane == wq ? sbit & low : sbit);
-                    const unsigned long long nz = __ballot(mk != 0u);
-                    if (nz == 0ull) fail = true;
+                    const uint32_t dcur = (uint32_t)__builtin_amdgcn_readlane((int)dgw, wq);
+                    if ((dcur >> (kb & 31)) & 1u) { out.put(i - 1, (uint32_t)(j - 1)); i--; j--; }
                     else {
-                        const int tl = 63 - __clzll(nz);
-                        const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)mk, tl), dt = (uint32_t)__builtin_amdgcn_readlane((int)dgw, tl);
-                        const int ps = 32 * tl + 31 - __clz(mt);
-                        int nup = kb - ps;
-                        if (nup > i) nup = i;
-                        const uint16_t gapv = (uint16_t)(j | 0x8000);
-                        for (int x = lane; x < nup; x += 64) ops[i - 1 - x] = gapv;
-                        i -= nup;
-                        if (i > 0) {
-                            if ((dt >> (ps & 31)) & 1u) { if (lane == 0) ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
-                            else j--;
+                        const uint32_t upw = P.fullbuf[(full0 + j) * (2 * NW) + NW + lane];
+                        const uint32_t low = 0xffffffffu >> (31 - (kb & 31));
+                        const uint32_t sbit = dgw | ~upw;
+                        const uint32_t mk = lane > wq ? 0u : (lane == wq ? sbit & low : sbit);
+                        const unsigned long long nz = __ballot(mk != 0u);
+                        if (nz == 0ull) fail = true;
+                        else {
+                            const int tl = 63 - __clzll(nz);
+                            const uint32_t mt = (uint32_t)__builtin_amdgcn_readlane((int)mk, tl), dt = (uint32_t)__builtin_amdgcn_readlane((int)dgw, tl);
+                            const int ps = 32 * tl + 31 - __clz(mt);
+                            int nup = kb - ps;
+                            if (nup > i) nup = i;
+                            out.run(i - 1, nup, (uint32_t)j | 0x8000u);
+                            i -= nup;
+                            if (i > 0) {
+                                if ((dt >> (ps & 31)) & 1u) { out.put(i - 1, (uint32_t)(j - 1)); i--; j--; }
+                                else j--;
+                            }
                         }
                     }
                 }
@@ -861,7 +938,7 @@ __global__ void __launch_bounds__(64) align_wide_tb_kernel(AlignArgs P, const in
         }
     }
     if (fail) { if (lane == 0) P.st[g] = 1; }
-    else for (int q = lane; q < i; q += 64) ops[q] = (uint16_t)0x8000;
+    else out.run(i - 1, i, 0x8000u);
 }
 
 // ---------------------------------------------------------------------------------------------
