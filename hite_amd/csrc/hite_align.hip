@@ -512,23 +512,23 @@ __global__ void __launch_bounds__(64) align_fwd8_pair_kernel(AlignArgs P, const 
 // traceback pass: re-compute the slice strip by strip (registers), walk it backwards
 // ---------------------------------------------------------------------------------------------
 // ops leave the traceback in descending positions, one at a time and per lane: a lane collects four of them in a 64-bit
-// shift register and stores 8 bytes at a time (2-byte stores from 64 lanes to 64 different lines were the kernel's bound)
+// shift register and stores 8 bytes at a time (2-byte stores from 64 lanes to 64 different lines were the kernel's bound).
+// Every group of four positions 4 k .. 4 k + 3 is complete when position 4 k arrives, except the topmost one when m is not a
+// multiple of 4: that one is kept aside and written entry by entry at the end, so that the walk carries no partial-store code.
 struct OpsOut {
     uint16_t *ops;
-    unsigned long long acc;
-    int cnt;
+    unsigned long long acc, top;
+    int m;
     __device__ __forceinline__ void push(int pos, uint32_t val) {
         acc = (acc << 16) | (unsigned long long)(val & 0xffffu);
-        cnt++;
         if ((pos & 3) == 0) {
-            if (cnt == 4) *reinterpret_cast<unsigned long long *>(ops + pos) = acc;     // (unaligned 8-byte store: fine for global memory)
-            else for (int x = 0; x < cnt; x++) ops[pos + x] = (uint16_t)(acc >> (16 * x));
-            cnt = 0;
+            if (pos + 4 <= m) *reinterpret_cast<unsigned long long *>(ops + pos) = acc;     // (unaligned 8-byte store: fine for global memory)
+            else top = acc;
         }
     }
-    __device__ __forceinline__ void flush(int next_pos) {   // next_pos = the position that would have been pushed next (pos - 1)
-        for (int x = 0; x < cnt; x++) ops[next_pos + 1 + x] = (uint16_t)(acc >> (16 * x));
-        cnt = 0;
+    __device__ __forceinline__ void finish() {   // after position 0 has been pushed
+        const int k = m & 3, p0 = m & ~3;
+        for (int x = 0; x < k; x++) ops[p0 + x] = (uint16_t)(top >> (16 * x));
     }
 };
 
@@ -549,7 +549,7 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     int i = m, j = n;
     bool fail = false;
     OpsOut out;
-    out.ops = ops; out.acc = 0ull; out.cnt = 0;
+    out.ops = ops; out.acc = 0ull; out.top = 0ull; out.m = m;
     const int Kmax = (nmax + AL_STRIP - 1) / AL_STRIP;
     // software pipeline over the strips (last to first): the check point of strip k-2, the boundary record and the row bases of
     // strip k-1 and -- with the position the check point of strip k-1 gives -- its centre planes are fetched while strip k is
@@ -684,7 +684,7 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
         if (fail) P.st[g] = 1;
         else {
             for (int q = i - 1; q >= 0; q--) out.push(q, 0x8000u);
-            out.flush(-1);
+            out.finish();
         }
     }
 }
