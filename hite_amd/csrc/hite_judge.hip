@@ -65,7 +65,12 @@ struct JudgeParams {
 #define JT_W32 4
 #define ANCHOR_LDS_COLS 5104   // ungapped row (<= this many bytes) + 2 bytes of match record per text start fit the 15 KB mask area
 #define JT_KERNEL judge_kernel
-#define JT_WAVES_MIN 5
+// minimum waves per SIMD asked of the compiler (it spills to get there).  Measured on C3, workgroup / wave kernel: 5/4 11.3 ms,
+// 6/4 11.5, 4/4 12.2, 5/3 12.4, 4/3 12.7, 3/3 (no spills) 13.6: waves in flight beat spills, the judges wait on dependent loads
+#ifndef JBLK_WAVES
+#define JBLK_WAVES 5
+#endif
+#define JT_WAVES_MIN JBLK_WAVES
 namespace jblk {
 #include "hite_judge_team.inc"
 }
@@ -80,7 +85,10 @@ namespace jblk {
 #define JT_W32 2
 #define ANCHOR_LDS_COLS 2544   // 3 x 2544 + 16 <= 7680 bytes of mask tile
 #define JT_KERNEL judge_wave_kernel
-#define JT_WAVES_MIN 4
+#ifndef JWAV_WAVES
+#define JWAV_WAVES 4
+#endif
+#define JT_WAVES_MIN JWAV_WAVES
 namespace jwav {
 #include "hite_judge_team.inc"
 }
