@@ -360,6 +360,17 @@ __global__ void __launch_bounds__(256) hit_kernel(int64_t nq, const unsigned *__
     }
 }
 
+// (diagnostic, HITE_HIT_HIST=1) hits per candidate: candidates and hits in the classes <= 1024, <= 2048, <= 4096, <= 8192, above
+__global__ void hit_hist_kernel(int n_cand, const int64_t *__restrict__ q_first, const int64_t *__restrict__ hit_off,
+                                unsigned long long *__restrict__ out /* [2][5] + max */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    const long long k = hit_off[q_first[c + 1]] - hit_off[q_first[c]];
+    const int cls = k <= 1024 ? 0 : k <= 2048 ? 1 : k <= 4096 ? 2 : k <= 8192 ? 3 : 4;
+    atomicAdd(&out[cls], 1ull);
+    atomicAdd(&out[5 + cls], (unsigned long long)k);
+    atomicMax(&out[10], (unsigned long long)k);
+}
 __global__ void cluster_flag_kernel(int64_t nh, const unsigned long long *__restrict__ hkey, HitFmt F,
                                     const int64_t *__restrict__ coff, int nc, int32_t *__restrict__ flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -757,8 +768,9 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     CCHK(arena_alloc(ctx, A, qcap * 4, &p)); q_hs = (unsigned *)p;
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
     int64_t nq, max_cand_len = 0;
+    int64_t *q_first = nullptr;          // first minimizer of every candidate (n_cand + 1): the hits of a candidate are one contiguous range
     {
-        int32_t *q_cnt; int64_t *q_first, *qbs; unsigned *r_pos, *r_hs;
+        int32_t *q_cnt; int64_t *qbs; unsigned *r_pos, *r_hs;
         CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); q_cnt = (int32_t *)p;
         CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); q_first = (int64_t *)p;
         CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(n_cand) * 8, &p)); qbs = (int64_t *)p;
@@ -810,6 +822,21 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     int tk_hit_kernel = hite_prof_begin(ctx, "hit_kernel", st);
     hipLaunchKernelGGL(hit_kernel, CGRID(nq), 0, st, nq, q_c, q_pos, q_hs, d_cand_off, S->idx_hs, S->idx_pos, occ_lo, occ_n, hit_off, hkey, hval, F);
     hite_prof_end(ctx, tk_hit_kernel, st);
+    {
+        static const bool hist = [] { const char *e = getenv("HITE_HIT_HIST"); return e && *e && atoi(e) != 0; }();
+        static bool printed = false;
+        if (hist && !printed) {
+            printed = true;
+            unsigned long long *d_h, h_h[11];
+            CCHK(arena_alloc(ctx, A, 11 * 8, &p)); d_h = (unsigned long long *)p;
+            HITE_CHECK(ctx, hipMemsetAsync(d_h, 0, 11 * 8, st));
+            hipLaunchKernelGGL(hit_hist_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, q_first, hit_off, d_h);
+            HITE_CHECK(ctx, hipMemcpyAsync(h_h, d_h, 11 * 8, hipMemcpyDeviceToHost, st));
+            HITE_CHECK(ctx, hipStreamSynchronize(st));
+            fprintf(stderr, "hit_hist: candidates %d hits %lld max %llu | classes <=1024 <=2048 <=4096 <=8192 above: candidates %llu %llu %llu %llu %llu hits %llu %llu %llu %llu %llu\n",
+                    n_cand, (long long)nh, h_h[10], h_h[0], h_h[1], h_h[2], h_h[3], h_h[4], h_h[5], h_h[6], h_h[7], h_h[8], h_h[9]);
+        }
+    }
     Sorter so;
     CCHK(sorter_from_arena(so, ctx, A, st, nh));
     int tk_sh = hite_prof_begin(ctx, "radix_sort_hits", st);
