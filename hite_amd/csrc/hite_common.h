@@ -10,6 +10,29 @@
 #define HITE_WAVE 64
 #define HITE_BLOCK 256
 
+// which judge kernel takes an alignment (hite_judge.hip).  The LDS classes are one launch per tile size: the LDS a workgroup
+// holds is fixed per launch, and the tile decides how many alignments a CU has in flight
+#define JUDGE_CLS_BLOCK 0       // workgroup per alignment, alignment in HBM
+#define JUDGE_CLS_WAVE 1        // wavefront per alignment, alignment in HBM
+#define JUDGE_CLS_LDS 2         // first class whose kernel builds the alignment in LDS
+#define JUDGE_LDS_WAVE_SIZES 3  // classes 2..4: wavefront per alignment, tile sizes ascending
+#define JUDGE_LDS_BLOCK_SIZES 2 // classes 5..6: workgroup per alignment
+#define JUDGE_NCLS (JUDGE_CLS_LDS + JUDGE_LDS_WAVE_SIZES + JUDGE_LDS_BLOCK_SIZES)
+#define HITE_AUX_STREAMS (JUDGE_NCLS - 1)
+// sources of the sparse star alignment (hite_msa.hip): what star_fill_sparse_kernel reads
+struct JudgeFuse {
+    const uint8_t *win;
+    const int64_t *win_off;
+    const int32_t *win_len;
+    const int32_t *row_first;
+    const int64_t *ops_base;
+    const uint16_t *ops;
+    const uint32_t *lay;
+    const int32_t *last_extra;
+    const int32_t *row_map;
+    const int32_t *rows_eff;
+};
+
 struct hite_ctx {
     int device;
     char err[512];
@@ -40,11 +63,17 @@ struct hite_ctx {
     const int32_t *d_msa_rows_eff;  // per candidate: rows that were aligned (NULL: all)
     uint32_t *d_msa_lay;             // layout words of the last sparse star alignment (hite_msa.hip)
     int32_t *d_contig_rank;         // byte order of "<contig name>:" among the contigs (hite_set_contig_order; NULL: the index)
-    // second stream + fork / join events for kernels that run beside each other inside one call (the two judge kernels)
-    void *aux_stream;
-    void *aux_ev[2];
+    // side streams + one fork event and a join event per stream for kernels that run beside each other inside one call (the
+    // judge kernels)
+    void *aux_stream[HITE_AUX_STREAMS];
+    void *aux_fork;
+    void *aux_join[HITE_AUX_STREAMS];
+    // fused fill + judge (hite_pipeline.hip -> hite_judge.hip): the pipeline classifies the alignments (hite_judge_classify_dev),
+    // leaves the LDS classes out of the fill and hands the judge what it needs to build them in LDS
+    const uint8_t *d_judge_cls;     // per alignment: JUDGE_CLS_* (NULL: hite_judge_dev classifies by itself)
+    JudgeFuse judge_fuse;           // win == NULL: the LDS classes copy their alignment from d_msa
 };
-int hite_aux_stream(hite_ctx *ctx, hipStream_t *st, hipEvent_t *fork_ev, hipEvent_t *join_ev);
+int hite_aux_streams(hite_ctx *ctx, int k, hipStream_t *st, hipEvent_t *fork_ev, hipEvent_t *join_ev);
 
 // record the time of everything enqueued on `st` between begin and end as stage `name`
 int hite_prof_begin(hite_ctx *ctx, const char *name, hipStream_t st);

@@ -49,9 +49,11 @@ extern "C" void hite_ctx_destroy(hite_ctx *c) {
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_scratch2) (void)hipFree(c->d_scratch2);
     if (c->d_contig_rank) (void)hipFree(c->d_contig_rank);
-    if (c->aux_ev[0]) (void)hipEventDestroy((hipEvent_t)c->aux_ev[0]);
-    if (c->aux_ev[1]) (void)hipEventDestroy((hipEvent_t)c->aux_ev[1]);
-    if (c->aux_stream) (void)hipStreamDestroy((hipStream_t)c->aux_stream);
+    if (c->aux_fork) (void)hipEventDestroy((hipEvent_t)c->aux_fork);
+    for (int i = 0; i < HITE_AUX_STREAMS; i++) {
+        if (c->aux_join[i]) (void)hipEventDestroy((hipEvent_t)c->aux_join[i]);
+        if (c->aux_stream[i]) (void)hipStreamDestroy((hipStream_t)c->aux_stream[i]);
+    }
     free(c);
 }
 
@@ -70,19 +72,28 @@ extern "C" int hite_set_contig_order(hite_ctx *ctx, const int32_t *rank, int32_t
     return HITE_OK;
 }
 
-// the context's second stream (created on first use) with one event to fork it off the caller's stream and one to join it
-int hite_aux_stream(hite_ctx *ctx, hipStream_t *st, hipEvent_t *fork_ev, hipEvent_t *join_ev) {
-    if (!ctx->aux_stream) {
-        hipStream_t s;
-        HITE_CHECK(ctx, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        ctx->aux_stream = s;
-        hipEvent_t e0, e1;
-        HITE_CHECK(ctx, hipEventCreateWithFlags(&e0, hipEventDisableTiming));
-        ctx->aux_ev[0] = e0;
-        HITE_CHECK(ctx, hipEventCreateWithFlags(&e1, hipEventDisableTiming));
-        ctx->aux_ev[1] = e1;
+// the context's side streams (created on first use, all or none) with one event to fork them off the caller's stream and one
+// event per stream to join it; st / join_ev receive k <= HITE_AUX_STREAMS entries
+int hite_aux_streams(hite_ctx *ctx, int k, hipStream_t *st, hipEvent_t *fork_ev, hipEvent_t *join_ev) {
+    if (k < 0 || k > HITE_AUX_STREAMS) return HITE_EINVAL;
+    if (!ctx->aux_fork) {
+        hipStream_t s[HITE_AUX_STREAMS] = {};
+        hipEvent_t j[HITE_AUX_STREAMS] = {}, f = nullptr;
+        hipError_t e = hipEventCreateWithFlags(&f, hipEventDisableTiming);
+        for (int i = 0; i < HITE_AUX_STREAMS && e == hipSuccess; i++) {
+            e = hipStreamCreateWithFlags(&s[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&j[i], hipEventDisableTiming);
+        }
+        if (e != hipSuccess) {      // nothing half-made is published
+            if (f) (void)hipEventDestroy(f);
+            for (int i = 0; i < HITE_AUX_STREAMS; i++) { if (j[i]) (void)hipEventDestroy(j[i]); if (s[i]) (void)hipStreamDestroy(s[i]); }
+            HITE_CHECK(ctx, e);
+        }
+        for (int i = 0; i < HITE_AUX_STREAMS; i++) { ctx->aux_stream[i] = s[i]; ctx->aux_join[i] = j[i]; }
+        ctx->aux_fork = f;
     }
-    *st = (hipStream_t)ctx->aux_stream; *fork_ev = (hipEvent_t)ctx->aux_ev[0]; *join_ev = (hipEvent_t)ctx->aux_ev[1];
+    for (int i = 0; i < k; i++) { st[i] = (hipStream_t)ctx->aux_stream[i]; join_ev[i] = (hipEvent_t)ctx->aux_join[i]; }
+    *fork_ev = (hipEvent_t)ctx->aux_fork;
     return HITE_OK;
 }
 

@@ -1,0 +1,54 @@
+// hite_fill.h -- one row of the sparse star alignment (the kept columns only) from windows + ops + layout words: the body
+// star_fill_sparse_kernel (hite_msa.hip) runs per (candidate, row), shared with the judge kernels that build their alignment in
+// LDS instead of reading it back from HBM (hite_judge_team.inc, JT_LDS_MSA).  Item (r, p) owns the kept prefix of insertion
+// block p, the centre column p if kept and (p == m) the extra last column: every output byte is written exactly once.
+#pragma once
+#include "hite_common.h"
+
+#define FILL_U 4        // positions in flight per thread
+
+// Out: pointer to the output row (global or LDS bytes); t = index of the thread among the TS threads that share the row
+template <class Out, int TS>
+__device__ __forceinline__ void fill_sparse_row(Out row, const uint8_t *__restrict__ b, int nrow, const uint16_t *__restrict__ rop,
+                                                const uint32_t *__restrict__ lay, int m, int le, bool centre, int t) {
+    for (int p0 = t; p0 <= m; p0 += FILL_U * TS) {
+        // the common position keeps its centre column and nothing else: layout word, op, base, one store -- straight-line
+        // code for FILL_U positions, their loads issued level by level.  Kept insertion columns and the extra last column
+        // are rare and leave through one branch at the end (every branch that a wave takes for one of its lanes costs all 64)
+        unsigned w[FILL_U], oc[FILL_U];
+#pragma unroll
+        for (int u = 0; u < FILL_U; u++) {
+            const int p = p0 + u * TS;
+            w[u] = p <= m ? lay[p] : 0u;
+            oc[u] = centre ? (unsigned)p : (p < m ? (unsigned)rop[p] : 0x8000u);
+        }
+        uint8_t ch[FILL_U];
+#pragma unroll
+        for (int u = 0; u < FILL_U; u++) ch[u] = ((w[u] >> 15) & 1u) && !(oc[u] >> 15) ? b[oc[u] & 0x7fffu] : (uint8_t)'-';
+        bool rare = false;
+#pragma unroll
+        for (int u = 0; u < FILL_U; u++) {
+            const unsigned kw = w[u] & 0x7fffu;
+            if ((w[u] >> 15) & 1u) row[(w[u] >> 16) + kw] = ch[u];
+            rare = rare || kw != 0u || (p0 + u * TS == m && le >= 0);
+        }
+        if (rare) {
+#pragma unroll 1
+            for (int u = 0; u < FILL_U; u++) {
+                const int p = p0 + u * TS;
+                const int kw = (int)(w[u] & 0x7fffu), bs = (int)(w[u] >> 16);
+                const bool ex = p == m && le >= 0;
+                if (p > m || (kw == 0 && !ex)) continue;
+                int ins = 0, q = p;
+                if (!centre) {
+                    q = p < m ? (int)(oc[u] & 0x7fffu) : nrow;
+                    const unsigned op = p > 0 ? rop[p - 1] : 0u;
+                    ins = q - (p > 0 ? (int)(op & 0x7fff) + ((op >> 15) ? 0 : 1) : 0);
+                }
+                const int rp = q - ins;  // first inserted base
+                for (int k = 0; k < kw; k++) row[bs + k] = k < ins ? b[rp + k] : (uint8_t)'-';
+                if (ex) row[bs + kw] = le < ins ? b[rp + le] : (uint8_t)'-';
+            }
+        }
+    }
+}

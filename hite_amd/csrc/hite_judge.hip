@@ -19,6 +19,7 @@
 // Algorithmic bytes per candidate: rows*cols read (1 B/cell) + 12 B/col of column statistics
 // + cols bytes of consensus written.
 #include "hite_common.h"
+#include "hite_fill.h"
 
 #ifndef JB
 #define JB 256          // threads per block (every kernel of this file; 128 measured: short alignments 20 % faster, long ones 23 % slower)
@@ -58,13 +59,20 @@ struct JudgeParams {
     unsigned int *counter;   // work queue: next entry of list
     const int32_t *list;     // alignments this kernel judges
     const unsigned int *n_list;
+    JudgeFuse fuse;          // LDS kernels: win != NULL -> the alignment is built from these, not copied from msa
 };
+typedef const uint8_t *jt_gptr;
+typedef const __attribute__((address_space(3))) uint8_t *jt_lptr_c;
+typedef __attribute__((address_space(3))) uint8_t *jt_lptr;
+typedef unsigned int jt_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) jt_u32x4 *jt_lptr16;
 
-// ---- the team code, twice ---------------------------------------------------------------------------------------------
+// ---- the team code, four times: {workgroup, wavefront} x {alignment in HBM, alignment built in LDS} --------------------------
 #define JW (JB / 64)
 #define JT_W32 4
 #define ANCHOR_LDS_COLS 5104   // ungapped row (<= this many bytes) + 2 bytes of match record per text start fit the 15 KB mask area
 #define JT_KERNEL judge_kernel
+#define JT_MSA_PTR jt_gptr
 // minimum waves per SIMD asked of the compiler (it spills to get there).  Measured on C3, workgroup / wave kernel: 5/4 11.3 ms,
 // 6/4 11.5, 4/4 12.2, 5/3 12.4, 4/3 12.7, 3/3 (no spills) 13.6: waves in flight beat spills, the judges wait on dependent loads
 #ifndef JBLK_WAVES
@@ -74,22 +82,19 @@ struct JudgeParams {
 namespace jblk {
 #include "hite_judge_team.inc"
 }
-#undef JB
-#undef JW
-#undef JT_W32
-#undef ANCHOR_LDS_COLS
 #undef JT_KERNEL
+#undef JT_MSA_PTR
 #undef JT_WAVES_MIN
-#define JB 64
-#define JW 1
-#define JT_W32 2
-#define ANCHOR_LDS_COLS 2544   // 3 x 2544 + 16 <= 7680 bytes of mask tile
-#define JT_KERNEL judge_wave_kernel
-#ifndef JWAV_WAVES
-#define JWAV_WAVES 4
+#define JT_KERNEL judge_lds_kernel
+#define JT_MSA_PTR jt_lptr_c
+#define JT_LDS_PTR jt_lptr
+#define JT_LDS_PTR16 jt_lptr16
+#define JT_LDS_MSA 1
+#ifndef JBLK_LDS_WAVES
+#define JBLK_LDS_WAVES 2
 #endif
-#define JT_WAVES_MIN JWAV_WAVES
-namespace jwav {
+#define JT_WAVES_MIN JBLK_LDS_WAVES
+namespace jblds {
 #include "hite_judge_team.inc"
 }
 #undef JB
@@ -98,6 +103,42 @@ namespace jwav {
 #undef ANCHOR_LDS_COLS
 #undef JT_KERNEL
 #undef JT_WAVES_MIN
+#undef JT_MSA_PTR
+#undef JT_LDS_MSA
+#define JB 64
+#define JW 1
+#define JT_W32 2
+#define ANCHOR_LDS_COLS 2544   // 3 x 2544 + 16 <= 7680 bytes of mask tile
+#define JT_KERNEL judge_wave_kernel
+#define JT_MSA_PTR jt_gptr
+#ifndef JWAV_WAVES
+#define JWAV_WAVES 4
+#endif
+#define JT_WAVES_MIN JWAV_WAVES
+namespace jwav {
+#include "hite_judge_team.inc"
+}
+#undef JT_KERNEL
+#undef JT_MSA_PTR
+#undef JT_WAVES_MIN
+#define JT_KERNEL judge_wave_lds_kernel
+#define JT_MSA_PTR jt_lptr_c
+#define JT_LDS_MSA 1
+#ifndef JWAV_LDS_WAVES
+#define JWAV_LDS_WAVES 2
+#endif
+#define JT_WAVES_MIN JWAV_LDS_WAVES
+namespace jwlds {
+#include "hite_judge_team.inc"
+}
+#undef JB
+#undef JW
+#undef JT_W32
+#undef ANCHOR_LDS_COLS
+#undef JT_KERNEL
+#undef JT_WAVES_MIN
+#undef JT_MSA_PTR
+#undef JT_LDS_MSA
 // the other kernels of this file are four-wavefront workgroups on the block form of the helpers
 #define JB 256
 #define JW (JB / 64)
@@ -358,63 +399,128 @@ extern "C" int hite_boundary_search(hite_ctx *ctx, int32_t n, const uint8_t *msa
     return HITE_OK;
 }
 
-// which kernel judges which alignment: one wavefront per alignment when it has <= wrows rows and <= wcols columns, a
-// four-wavefront workgroup otherwise.  Two dense lists, each ordered by cost class (log2 of rows x cols) DESCENDING: both
-// kernels take their entries from a work queue, and the largest alignments -- one workgroup can spend milliseconds on a
-// 30 000-column alignment -- must not be the ones that start last.  Three small launches: class histogram, offsets, scatter.
+// which kernel judges which alignment (JUDGE_CLS_*):
+//   * one wavefront per alignment when it has <= wrows rows and <= wcols columns, a four-wavefront workgroup otherwise;
+//   * of either, the form that holds the alignment in LDS when its rows x cols bytes fit the class's tile (lds_wave / lds_blk).
+// One dense list per class, each ordered by cost class (log2 of rows x cols) DESCENDING: the kernels take their entries from
+// work queues, and the largest alignments -- one workgroup can spend milliseconds on a 30 000-column alignment -- must not be
+// the ones that start last.  Small launches: classify (unless the pipeline did), class histogram, offsets, scatter.
 #define JSPLIT_CLASSES 24
+struct JudgeLimits { int wrows, wcols, lds_wave[JUDGE_LDS_WAVE_SIZES], lds_blk[JUDGE_LDS_BLOCK_SIZES]; };   // tile bytes, 0 = class unused
+__device__ __forceinline__ int judge_class_of(int rows, int cols, const JudgeLimits &L) {
+    if (rows <= 0 || cols <= 0) return JUDGE_CLS_BLOCK;
+    const long long tile = (long long)rows * cols;
+    const bool small = rows <= L.wrows && cols <= L.wcols;
+    if (small)
+        for (int k = 0; k < JUDGE_LDS_WAVE_SIZES; k++) if (tile <= L.lds_wave[k]) return JUDGE_CLS_LDS + k;
+    for (int k = 0; k < JUDGE_LDS_BLOCK_SIZES; k++) if (tile <= L.lds_blk[k]) return JUDGE_CLS_LDS + JUDGE_LDS_WAVE_SIZES + k;
+    return small ? JUDGE_CLS_WAVE : JUDGE_CLS_BLOCK;
+}
+__global__ void judge_classify_kernel(int n, const int32_t *__restrict__ rows, const int32_t *__restrict__ cols, JudgeLimits L,
+                                      uint8_t *__restrict__ cls) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) cls[i] = (uint8_t)judge_class_of(rows[i], cols[i], L);
+}
 __device__ __forceinline__ int judge_cost_class(int rows, int cols) {
     const unsigned long long cost = (unsigned long long)(rows > 0 ? rows : 1) * (unsigned long long)(cols > 0 ? cols : 1);
     const int lg = 63 - __clzll(cost);                       // 0 .. ~22
     return lg >= JSPLIT_CLASSES ? JSPLIT_CLASSES - 1 : lg;
 }
+#define JSPLIT_SLOTS (JUDGE_NCLS * JSPLIT_CLASSES)
 __global__ void __launch_bounds__(256) judge_split_count_kernel(int n, const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
-                                                                int wrows, int wcols, unsigned int *__restrict__ hist /* [2][JSPLIT_CLASSES] */) {
-    __shared__ unsigned int s_h[2 * JSPLIT_CLASSES];
-    if (threadIdx.x < 2 * JSPLIT_CLASSES) s_h[threadIdx.x] = 0u;
+                                                                const uint8_t *__restrict__ cls, unsigned int *__restrict__ hist /* [JUDGE_NCLS][JSPLIT_CLASSES] */) {
+    __shared__ unsigned int s_h[JSPLIT_SLOTS];
+    if (threadIdx.x < JSPLIT_SLOTS) s_h[threadIdx.x] = 0u;
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) {
-        const bool small = rows[i] <= wrows && cols[i] <= wcols;
-        atomicAdd(&s_h[(small ? JSPLIT_CLASSES : 0) + judge_cost_class(rows[i], cols[i])], 1u);
-    }
+    if (i < n) atomicAdd(&s_h[(int)cls[i] * JSPLIT_CLASSES + judge_cost_class(rows[i], cols[i])], 1u);
     __syncthreads();
-    if (threadIdx.x < 2 * JSPLIT_CLASSES && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
+    if (threadIdx.x < JSPLIT_SLOTS && s_h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], s_h[threadIdx.x]);
 }
-// offsets of the classes inside each list, largest class first; list lengths into counters[2], counters[3]; hist becomes cursors
+// offsets of the cost classes inside each list, largest class first; list lengths into counters[JUDGE_NCLS + k]; hist becomes cursors
 __global__ void judge_split_offsets_kernel(unsigned int *__restrict__ hist, unsigned int *__restrict__ counters) {
-    if (threadIdx.x >= 2) return;
+    if (threadIdx.x >= JUDGE_NCLS) return;
     unsigned int *h = hist + threadIdx.x * JSPLIT_CLASSES;
     unsigned int run = 0;
     for (int c = JSPLIT_CLASSES - 1; c >= 0; c--) { const unsigned int k = h[c]; h[c] = run; run += k; }
-    counters[2 + threadIdx.x] = run;
+    counters[JUDGE_NCLS + threadIdx.x] = run;
 }
 __global__ void __launch_bounds__(256) judge_split_scatter_kernel(int n, const int32_t *__restrict__ rows, const int32_t *__restrict__ cols,
-                                                                  int wrows, int wcols, unsigned int *__restrict__ cursors,
-                                                                  int32_t *__restrict__ list_b, int32_t *__restrict__ list_w) {
-    // ranks inside the workgroup by LDS atomics, one global atomic per (workgroup, class): 50 k atomics on 48 addresses were
-    // 0.35 ms per launch.  (The order inside a class only schedules the judges; it does not reach any result.)
-    __shared__ unsigned int s_cnt[2 * JSPLIT_CLASSES], s_base[2 * JSPLIT_CLASSES];
-    if (threadIdx.x < 2 * JSPLIT_CLASSES) s_cnt[threadIdx.x] = 0u;
+                                                                  const uint8_t *__restrict__ cls, unsigned int *__restrict__ cursors,
+                                                                  int32_t *__restrict__ lists /* [JUDGE_NCLS][n] */) {
+    // ranks inside the workgroup by LDS atomics, one global atomic per (workgroup, slot): 50 k atomics on 48 addresses were
+    // 0.35 ms per launch.  (The order inside a cost class only schedules the judges; it does not reach any result.)
+    __shared__ unsigned int s_cnt[JSPLIT_SLOTS], s_base[JSPLIT_SLOTS];
+    if (threadIdx.x < JSPLIT_SLOTS) s_cnt[threadIdx.x] = 0u;
     __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool small = false;
-    int cls = 0;
+    int k = 0, slot = 0;
     unsigned int local = 0u;
     if (i < n) {
-        small = rows[i] <= wrows && cols[i] <= wcols;
-        cls = (small ? JSPLIT_CLASSES : 0) + judge_cost_class(rows[i], cols[i]);
-        local = atomicAdd(&s_cnt[cls], 1u);
+        k = cls[i];
+        slot = k * JSPLIT_CLASSES + judge_cost_class(rows[i], cols[i]);
+        local = atomicAdd(&s_cnt[slot], 1u);
     }
     __syncthreads();
-    if (threadIdx.x < 2 * JSPLIT_CLASSES && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], s_cnt[threadIdx.x]);
+    if (threadIdx.x < JSPLIT_SLOTS && s_cnt[threadIdx.x]) s_base[threadIdx.x] = atomicAdd(&cursors[threadIdx.x], s_cnt[threadIdx.x]);
     __syncthreads();
-    if (i < n) (small ? list_w : list_b)[s_base[cls] + local] = i;
+    if (i < n) lists[(size_t)k * n + s_base[slot] + local] = i;
 }
 
 static int env_int(const char *name, int dflt) {
     const char *e = getenv(name);
     return (e && *e) ? atoi(e) : dflt;
+}
+
+// the limits of the four classes for a batch of n alignments (environment overrides are for measurements and tests)
+static JudgeLimits judge_limits(int n) {
+    JudgeLimits L;
+    // HITE_JUDGE_WAVE_COLS = 0 sends every alignment to the workgroup kernels; the wave kernels' LDS holds the anchor text of
+    // <= 2544 columns, wider alignments would search their anchors in global scratch
+    L.wcols = env_int("HITE_JUDGE_WAVE_COLS", 2544); L.wrows = env_int("HITE_JUDGE_WAVE_ROWS", 64);
+    if (L.wrows > 64) L.wrows = 64;
+    if (L.wcols < 0 || L.wrows <= 0) L.wcols = 0;
+    // one wavefront per alignment pays off when the batch keeps the machine busy for many rounds (throughput: four times the
+    // alignments in flight); a small batch is over in one round, where the workgroup form's shorter chain per alignment wins
+    // (C2, 5 000 candidates: 1.8 ms with the wave kernel, 1.3 ms without)
+    if (n < env_int("HITE_JUDGE_WAVE_MIN_BATCH", 16384)) L.wcols = 0;
+    // LDS tiles (bytes of rows x cols), ascending; a launch holds its tile + 11.4 KB (wavefront) / 19.3 KB (workgroup) of LDS per
+    // resident workgroup out of 160 KB per CU.  HITE_JUDGE_LDS = 0 switches all of them off, a size of 0 one class.
+    static const int dflt_w[JUDGE_LDS_WAVE_SIZES] = {8192, 16384, 32768}, dflt_b[JUDGE_LDS_BLOCK_SIZES] = {61440, 0};
+    static const char *name_w[JUDGE_LDS_WAVE_SIZES] = {"HITE_JUDGE_LDS_WAVE0", "HITE_JUDGE_LDS_WAVE1", "HITE_JUDGE_LDS_WAVE2"};
+    static const char *name_b[JUDGE_LDS_BLOCK_SIZES] = {"HITE_JUDGE_LDS_BLOCK0", "HITE_JUDGE_LDS_BLOCK1"};
+    // OFF by default: measured on C3 (MI355X, round 4, gpurun_out/s1): calls identical, but judge 11.9 -> 27.3 ms per step with
+    // every class on (fill 10.0 -> 7.1 ms), 15.9 ms with the 8 KB / 16 KB wavefront tiles alone, 19.6 ms when the tiles are
+    // copied from HBM instead of built.  A tile costs residency (8 / 5 / 3 wavefronts per CU at 8 / 16 / 32 KB against 14 for
+    // the kernels on HBM) and the judges turn out to be bound by instruction issue at ~3.5 wavefronts per SIMD, not by the
+    // latency of their alignment reads: fewer wavefronts per CU lose more than LDS reads win.
+    const bool on = env_int("HITE_JUDGE_LDS", 0) != 0;
+    for (int k = 0; k < JUDGE_LDS_WAVE_SIZES; k++) {
+        int v = on && L.wcols > 0 ? env_int(name_w[k], dflt_w[k]) : 0;
+        L.lds_wave[k] = v < 0 ? 0 : (v > 98304 ? 98304 : v);
+    }
+    for (int k = 0; k < JUDGE_LDS_BLOCK_SIZES; k++) {
+        int v = on ? env_int(name_b[k], dflt_b[k]) : 0;
+        L.lds_blk[k] = v < 0 ? 0 : (v > 131072 ? 131072 : v);
+    }
+    return L;
+}
+
+// do the LDS classes exist at all for a batch of n alignments?  (the pipeline leaves alignments out of the fill only then)
+extern "C" int hite_judge_lds_enabled(int32_t n) {
+    const JudgeLimits L = judge_limits(n);
+    int any = 0;
+    for (int k = 0; k < JUDGE_LDS_WAVE_SIZES; k++) any |= L.lds_wave[k] > 0;
+    for (int k = 0; k < JUDGE_LDS_BLOCK_SIZES; k++) any |= L.lds_blk[k] > 0;
+    return any;
+}
+// JUDGE_CLS_* per alignment, exactly as hite_judge_dev will split a batch of n with these rows / columns
+extern "C" int hite_judge_classify_dev(hite_ctx *ctx, int32_t n, const int32_t *d_rows, const int32_t *d_cols, uint8_t *d_cls, void *stream) {
+    if (!ctx || n < 0) return HITE_EINVAL;
+    if (n == 0) return HITE_OK;
+    hipLaunchKernelGGL(judge_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, n, d_rows, d_cols, judge_limits(n), d_cls);
+    HITE_CHECK(ctx, hipGetLastError());
+    return HITE_OK;
 }
 
 extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n, const uint8_t *d_msa,
@@ -425,59 +531,90 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
     if (n == 0) return HITE_OK;
     if (max_cols <= 0 || max_cols > 65535 || max_rows <= 0) return HITE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
-    // HITE_JUDGE_WAVE_COLS = 0 sends every alignment to the workgroup kernel (the round-2 form); the wave kernel's LDS holds
-    // the anchor text of <= 2544 columns, wider alignments would search their anchors in global scratch
-    int wcols = env_int("HITE_JUDGE_WAVE_COLS", 2544), wrows = env_int("HITE_JUDGE_WAVE_ROWS", 64);
-    if (wrows > 64) wrows = 64;
-    if (wcols < 0 || wrows <= 0) wcols = 0;
-    // one wavefront per alignment pays off when the batch keeps the machine busy for many rounds (throughput: four times the
-    // alignments in flight); a small batch is over in one round, where the workgroup form's shorter chain per alignment wins
-    // (C2, 5 000 candidates: 1.8 ms with the wave kernel, 1.3 ms without)
-    if (n < env_int("HITE_JUDGE_WAVE_MIN_BATCH", 16384)) wcols = 0;
+    const JudgeLimits L = judge_limits(n);
     const bool overlap = env_int("HITE_JUDGE_OVERLAP", 1) != 0;
-    size_t maxC16 = ((size_t)max_cols + 15) & ~(size_t)15;
-    size_t slot = 23 * maxC16 + 16 * (size_t)max_rows + 64;
-    slot = (slot + 63) & ~(size_t)63;
-    int grid = n < 2048 ? n : 2048;
-    // keep the scratch bounded (<= 4 GiB): fewer resident slots for very wide alignments
-    while (grid > 64 && (size_t)grid * slot > ((size_t)4 << 30)) grid /= 2;
-    size_t maxC16w = (size_t)(wcols < max_cols ? wcols : max_cols);
+    // scratch slots per resident workgroup: 23 * maxC16 + 16 * maxR + 64 (the wave kernels never see more than wcols columns / 64 rows)
+    const size_t maxC16 = ((size_t)max_cols + 15) & ~(size_t)15;
+    size_t slot[JUDGE_NCLS], mc16[JUDGE_NCLS];
+    int grid[JUDGE_NCLS], lds[JUDGE_NCLS];
+    bool wave[JUDGE_NCLS];
+    size_t maxC16w = (size_t)(L.wcols < max_cols ? L.wcols : max_cols);
     maxC16w = (maxC16w + 15) & ~(size_t)15;
-    size_t slot_w = (23 * maxC16w + 16 * (size_t)64 + 64 + 63) & ~(size_t)63;
-    int grid_w = wcols > 0 ? (n < 4096 ? n : 4096) : 0;
-    const size_t off_w = (size_t)grid * slot, off_l = off_w + (size_t)grid_w * slot_w;
+    for (int k = 0; k < JUDGE_NCLS; k++) {
+        const int kl = k - JUDGE_CLS_LDS;
+        wave[k] = k == JUDGE_CLS_WAVE || (kl >= 0 && kl < JUDGE_LDS_WAVE_SIZES);
+        lds[k] = kl < 0 ? 0 : (kl < JUDGE_LDS_WAVE_SIZES ? L.lds_wave[kl] : L.lds_blk[kl - JUDGE_LDS_WAVE_SIZES]);
+        mc16[k] = wave[k] ? maxC16w : maxC16;
+        slot[k] = ((wave[k] ? 23 * maxC16w + 16 * (size_t)64 : 23 * maxC16 + 16 * (size_t)max_rows) + 64 + 63) & ~(size_t)63;
+        const int cap = wave[k] ? 4096 : (kl >= 0 ? 1024 : 2048);
+        grid[k] = n < cap ? n : cap;
+        if ((k == JUDGE_CLS_WAVE && L.wcols <= 0) || (kl >= 0 && lds[k] <= 0)) grid[k] = 0;
+        // keep the scratch bounded (<= 4 GiB per class): fewer resident slots for very wide alignments
+        while (grid[k] > 64 && (size_t)grid[k] * slot[k] > ((size_t)4 << 30)) grid[k] /= 2;
+    }
+    size_t off[JUDGE_NCLS + 1];
+    off[0] = 0;
+    for (int k = 0; k < JUDGE_NCLS; k++) off[k + 1] = off[k] + (size_t)grid[k] * slot[k];
+    const size_t off_l = off[JUDGE_NCLS], cls_bytes = ((size_t)n + 255) & ~(size_t)255;
     void *scr = nullptr;
-    int rc = hite_scratch_reserve(ctx, off_l + 2 * (size_t)n * 4 + 512, &scr);
+    int rc = hite_scratch_reserve(ctx, off_l + (size_t)JUDGE_NCLS * n * 4 + cls_bytes + 4096, &scr);
     if (rc) return rc;
-    int32_t *list_b = (int32_t *)((uint8_t *)scr + off_l), *list_w = list_b + n;
-    unsigned int *counters = (unsigned int *)(list_w + n);          // queue heads [0] [1], list lengths [2] [3], then the class histogram
-    unsigned int *hist = counters + 4;
-    HITE_CHECK(ctx, hipMemsetAsync(counters, 0, (4 + 2 * JSPLIT_CLASSES) * 4, st));
-    hipLaunchKernelGGL(judge_split_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows, d_cols, wrows, wcols, hist);
+    int32_t *lists = (int32_t *)((uint8_t *)scr + off_l);
+    uint8_t *cls_own = (uint8_t *)(lists + (size_t)JUDGE_NCLS * n);
+    unsigned int *counters = (unsigned int *)(cls_own + cls_bytes);   // queue heads [0..3], list lengths [4..7], then the class histogram
+    unsigned int *hist = counters + 2 * JUDGE_NCLS;
+    HITE_CHECK(ctx, hipMemsetAsync(counters, 0, (2 * JUDGE_NCLS + JSPLIT_SLOTS) * 4, st));
+    const uint8_t *cls = ctx->d_judge_cls;
+    if (!cls) {
+        hipLaunchKernelGGL(judge_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows, d_cols, L, cls_own);
+        cls = cls_own;
+    }
+    hipLaunchKernelGGL(judge_split_count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows, d_cols, cls, hist);
     hipLaunchKernelGGL(judge_split_offsets_kernel, dim3(1), dim3(64), 0, st, hist, counters);
-    hipLaunchKernelGGL(judge_split_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows, d_cols, wrows, wcols, hist, list_b, list_w);
-    JudgeParams P;
-    P.te_type = te_type; P.plant = plant; P.n = n; P.msa = d_msa; P.msa_off = d_msa_off; P.rows = d_rows; P.cols = d_cols;
-    P.cand = d_cand; P.cand_off = d_cand_off; P.col_off = d_col_off; P.calls = d_calls; P.cons = d_cons;
-    P.scratch = (uint8_t *)scr; P.slot_bytes = slot; P.maxC16 = maxC16; P.counter = counters; P.list = list_b; P.n_list = counters + 2;
-    JudgeParams Q = P;
-    Q.scratch = (uint8_t *)scr + off_w; Q.slot_bytes = slot_w; Q.maxC16 = maxC16w; Q.counter = counters + 1; Q.list = list_w; Q.n_list = counters + 3;
-    hipStream_t aux = st;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    if (grid_w > 0 && overlap) {
-        rc = hite_aux_stream(ctx, &aux, &ev_fork, &ev_join);
+    hipLaunchKernelGGL(judge_split_scatter_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows, d_cols, cls, hist, lists);
+    JudgeParams P[JUDGE_NCLS];
+    for (int k = 0; k < JUDGE_NCLS; k++) {
+        JudgeParams &p = P[k];
+        p.te_type = te_type; p.plant = plant; p.n = n; p.msa = d_msa; p.msa_off = d_msa_off; p.rows = d_rows; p.cols = d_cols;
+        p.cand = d_cand; p.cand_off = d_cand_off; p.col_off = d_col_off; p.calls = d_calls; p.cons = d_cons;
+        p.scratch = (uint8_t *)scr + off[k]; p.slot_bytes = slot[k]; p.maxC16 = mc16[k];
+        p.counter = counters + k; p.list = lists + (size_t)k * n; p.n_list = counters + JUDGE_NCLS + k;
+        p.fuse = ctx->judge_fuse;
+    }
+    static bool attr_done = false;       // more than 64 KB of LDS per workgroup needs the attribute (once per process)
+    if (!attr_done) {
+        HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jblds::judge_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jwlds::judge_wave_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
+        attr_done = true;
+    }
+    // the workgroup kernel on HBM holds the long chains (wide / deep alignments): it starts first, the others fill the machine
+    // beside it, each on its own stream, the largest tiles first
+    hipStream_t aux[HITE_AUX_STREAMS];
+    for (int i = 0; i < HITE_AUX_STREAMS; i++) aux[i] = st;
+    hipEvent_t ev_fork = nullptr, ev_join[HITE_AUX_STREAMS] = {};
+    bool side = false;
+    for (int k = 1; k < JUDGE_NCLS; k++) side = side || grid[k] > 0;
+    side = side && overlap;
+    if (side) {
+        rc = hite_aux_streams(ctx, HITE_AUX_STREAMS, aux, &ev_fork, ev_join);
         if (rc) return rc;
         HITE_CHECK(ctx, hipEventRecord(ev_fork, st));
-        HITE_CHECK(ctx, hipStreamWaitEvent(aux, ev_fork, 0));
+        for (int i = 0; i < HITE_AUX_STREAMS; i++) if (grid[i + 1] > 0) HITE_CHECK(ctx, hipStreamWaitEvent(aux[i], ev_fork, 0));
     }
-    // the workgroup kernel holds the long chains (wide / deep alignments): it starts first, the wave kernel fills the machine beside it
-    hipLaunchKernelGGL(jblk::judge_kernel, dim3(grid), dim3(256), 0, st, P);
-    if (grid_w > 0) hipLaunchKernelGGL(jwav::judge_wave_kernel, dim3(grid_w), dim3(64), 0, aux, Q);
+    hipLaunchKernelGGL(jblk::judge_kernel, dim3(grid[JUDGE_CLS_BLOCK]), dim3(256), 0, st, P[JUDGE_CLS_BLOCK]);
+    for (int k = JUDGE_NCLS - 1; k >= 1; k--) {
+        if (grid[k] <= 0) continue;
+        if (k == JUDGE_CLS_WAVE) hipLaunchKernelGGL(jwav::judge_wave_kernel, dim3(grid[k]), dim3(64), 0, aux[k - 1], P[k]);
+        else if (wave[k]) hipLaunchKernelGGL(jwlds::judge_wave_lds_kernel, dim3(grid[k]), dim3(64), (size_t)lds[k], aux[k - 1], P[k]);
+        else hipLaunchKernelGGL(jblds::judge_lds_kernel, dim3(grid[k]), dim3(256), (size_t)lds[k], aux[k - 1], P[k]);
+    }
     HITE_CHECK(ctx, hipGetLastError());
-    if (grid_w > 0 && overlap) {
-        HITE_CHECK(ctx, hipEventRecord(ev_join, aux));
-        HITE_CHECK(ctx, hipStreamWaitEvent(st, ev_join, 0));
-    }
+    if (side)
+        for (int i = 0; i < HITE_AUX_STREAMS; i++) {
+            if (grid[i + 1] <= 0) continue;
+            HITE_CHECK(ctx, hipEventRecord(ev_join[i], aux[i]));
+            HITE_CHECK(ctx, hipStreamWaitEvent(st, ev_join[i], 0));
+        }
     return HITE_OK;
 }
 

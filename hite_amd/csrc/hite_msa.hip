@@ -12,8 +12,8 @@
 #include "hite_common.h"
 #include "hite_align.h"
 #include "hite_scan.h"
+#include "hite_fill.h"
 
-#define FILL_U 4        // items in flight per thread in the fill kernel
 #define MSA_MAXR 128   // rows whose lengths are cached in LDS by the layout / fill kernels
 
 struct MsaParams {
@@ -265,6 +265,7 @@ struct FillSparseParams {
     FillParams F;              // cols = kept columns per candidate, msa = compacted output
     const int32_t *last_extra;
     const uint32_t *lay;       // as in MsaParams
+    const uint8_t *cls;        // per candidate JUDGE_CLS_* (may be NULL): the LDS classes are built by the judge itself
 };
 
 // fill of the kept columns only: item (r, p) owns the kept prefix of insertion block p, the centre column p if kept
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
     const int c = blockIdx.x;
     if (c >= P.n) return;
     const int C = P.cols[c];
-    if (C <= 0) return;
+    if (C <= 0 || (Q.cls && Q.cls[c] >= JUDGE_CLS_LDS)) return;
     const int64_t g0 = P.row_first[c];
     const int R = msa_rows(P.rows_eff, P.row_first, c);
     const int m = P.win_len[g0];
@@ -291,48 +292,7 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
         const int nrow = P.win_len[g0 + msa_src(P.row_map, g0, r)];
         const uint16_t *rop = ops + (int64_t)r * rs;
         uint8_t *row = out + (int64_t)r * C;
-        const bool centre = r == 0;       // the centre row: position p faces its own base p
-        for (int p0 = threadIdx.x; p0 <= m; p0 += FILL_U * 256) {
-            // the common position keeps its centre column and nothing else: layout word, op, base, one store -- straight-line
-            // code for FILL_U positions, their loads issued level by level.  Kept insertion columns and the extra last column
-            // are rare and leave through one branch at the end (the kernel is bound by instruction issue: every branch that a
-            // wave takes for one of its lanes costs all 64)
-            unsigned w[FILL_U], oc[FILL_U];
-#pragma unroll
-            for (int u = 0; u < FILL_U; u++) {
-                const int p = p0 + u * 256;
-                w[u] = p <= m ? lay[p] : 0u;
-                oc[u] = centre ? (unsigned)p : (p < m ? (unsigned)rop[p] : 0x8000u);
-            }
-            uint8_t ch[FILL_U];
-#pragma unroll
-            for (int u = 0; u < FILL_U; u++) ch[u] = ((w[u] >> 15) & 1u) && !(oc[u] >> 15) ? b[oc[u] & 0x7fffu] : (uint8_t)'-';
-            bool rare = false;
-#pragma unroll
-            for (int u = 0; u < FILL_U; u++) {
-                const unsigned kw = w[u] & 0x7fffu;
-                if ((w[u] >> 15) & 1u) row[(w[u] >> 16) + kw] = ch[u];
-                rare = rare || kw != 0u || (p0 + u * 256 == m && le >= 0);
-            }
-            if (rare) {
-#pragma unroll 1
-                for (int u = 0; u < FILL_U; u++) {
-                    const int p = p0 + u * 256;
-                    const int kw = (int)(w[u] & 0x7fffu), bs = (int)(w[u] >> 16);
-                    const bool ex = p == m && le >= 0;
-                    if (p > m || (kw == 0 && !ex)) continue;
-                    int ins = 0, q = p;
-                    if (!centre) {
-                        q = p < m ? (int)(oc[u] & 0x7fffu) : nrow;
-                        const unsigned op = p > 0 ? rop[p - 1] : 0u;
-                        ins = q - (p > 0 ? (int)(op & 0x7fff) + ((op >> 15) ? 0 : 1) : 0);
-                    }
-                    const int rp = q - ins;  // first inserted base
-                    for (int k = 0; k < kw; k++) row[bs + k] = k < ins ? b[rp + k] : (uint8_t)'-';
-                    if (ex) row[bs + kw] = le < ins ? b[rp + le] : (uint8_t)'-';
-                }
-            }
-        }
+        fill_sparse_row<uint8_t *, 256>(row, b, nrow, rop, lay, m, le, r == 0 /* the centre row: position p faces its own base p */, (int)threadIdx.x);
     }
 }
 
@@ -461,6 +421,7 @@ extern "C" int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uin
     P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_new_cols; P.msa_off = d_msa_off; P.msa = d_msa;
     P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff;
     Q.last_extra = d_last_extra; Q.lay = ctx->d_msa_lay;
+    Q.cls = ctx->judge_fuse.win ? ctx->d_judge_cls : nullptr;   // set by the pipeline around this call only
     if (!Q.lay) return HITE_EINVAL;
     // Round 3 measured three other forms of this kernel on C3 (this one: 1.9 + 6.0 ms per step for the two passes):
     //   * positions-outer (a thread owns four centre positions, keeps their layout words and walks the rows): 3.9 + 13.1 ms;

@@ -22,6 +22,9 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
                               const uint8_t *d_cand, const int64_t *d_cand_off, const int64_t *d_col_off,
                               int32_t max_cols, int32_t max_rows, hite_call *d_calls, uint8_t *d_cons, void *stream);
 
+extern "C" int hite_judge_lds_enabled(int32_t n);
+extern "C" int hite_judge_classify_dev(hite_ctx *ctx, int32_t n, const int32_t *d_rows, const int32_t *d_cols, uint8_t *d_cls, void *stream);
+
 #define MAXROWS 100
 
 struct PipeState {
@@ -241,11 +244,12 @@ __global__ void ops_count_kernel(int n, const int64_t *__restrict__ row_first, c
     if (bytes) { atomicAdd(&acc[0], bytes); atomicAdd(&acc[1], steps); }
 }
 
+// bytes of each alignment in HBM: none for the classes whose judge kernel builds the alignment in LDS (cls may be NULL)
 __global__ void msa_size_kernel(int n, const int32_t *__restrict__ nrows, const int32_t *__restrict__ cols,
-                                int64_t *__restrict__ bytes, int32_t *__restrict__ maxcols) {
+                                const uint8_t *__restrict__ cls, int64_t *__restrict__ bytes, int32_t *__restrict__ maxcols) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n) return;
-    int64_t b = (int64_t)nrows[c] * cols[c];
+    int64_t b = (cls && cls[c] >= JUDGE_CLS_LDS) ? 0 : (int64_t)nrows[c] * cols[c];
     bytes[c] = (b + 15) & ~(int64_t)15;
     atomicMax(maxcols, cols[c]);
 }
@@ -392,7 +396,18 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); msa_off = (int64_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)(n + 1) * 8, &p)); col_off2 = (int64_t *)p;
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
-    hipLaunchKernelGGL(msa_size_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, eff, new_cols, msa_bytes, (int32_t *)(S->d_scal + 2));
+    // fill fused into the judge, when the judge's LDS kernels are switched on (HITE_JUDGE_LDS=1; HITE_JUDGE_FUSE=0 then makes
+    // them copy their alignment from HBM instead): the LDS classes are left out of the fill, their kernels build the alignment
+    // from windows + ops + layout words
+    uint8_t *jcls = nullptr;
+    {
+        const char *e = getenv("HITE_JUDGE_FUSE");
+        if (!(e && *e && atoi(e) == 0) && hite_judge_lds_enabled(n)) {
+            ACHK(arena_alloc(ctx, T, (size_t)n + 16, &p)); jcls = (uint8_t *)p;
+            ACHK(hite_judge_classify_dev(ctx, n, eff, new_cols, jcls, st));
+        }
+    }
+    hipLaunchKernelGGL(msa_size_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, eff, new_cols, jcls, msa_bytes, (int32_t *)(S->d_scal + 2));
     ACHK(scan_excl<int64_t>(ctx, T, msa_bytes, n, msa_off, st));
     ACHK(scan_excl<int32_t>(ctx, T, new_cols, n, col_off2, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, col_off2 + n, 8, hipMemcpyDeviceToDevice, st));
@@ -402,6 +417,18 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     stats[2] += msa_total;
     ACHK(arena_alloc(ctx, T, (size_t)msa_total + 64, &p)); clean = (uint8_t *)p;
     tk = hite_prof_begin(ctx, extra == nullptr ? "star_fill_sparse_kernel" : (pass_b ? "star_fill_sparse_kernel_passB" : "star_fill_sparse_kernel_passA"), st);
+    // (what the judge's LDS kernels read is what the fill reads: the state of the last hite_star_msa_sparse_dev call)
+    struct FuseGuard {      // cleared on every way out: a later stand-alone hite_judge_dev call must not see this pass's buffers
+        hite_ctx *c;
+        ~FuseGuard() { c->d_judge_cls = nullptr; c->judge_fuse = JudgeFuse{}; }
+    } fuse_guard{ctx};
+    if (jcls) {
+        JudgeFuse F;
+        F.win = win; F.win_off = win_off; F.win_len = row_len; F.row_first = row_first32; F.ops_base = ops_base;
+        F.ops = (const uint16_t *)ctx->d_scratch2; F.lay = ctx->d_msa_lay; F.last_extra = last_extra;
+        F.row_map = ctx->d_msa_row_map; F.rows_eff = ctx->d_msa_rows_eff;
+        ctx->judge_fuse = F; ctx->d_judge_cls = jcls;
+    }
     ACHK(hite_star_msa_fill_sparse_dev(ctx, n, win, win_off, row_len, row_first32, ops_base, new_cols, last_extra, msa_off, clean, st));
     hite_prof_end(ctx, tk, st);
     const int64_t total_cols2 = S->h_pin[0];

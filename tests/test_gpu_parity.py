@@ -130,16 +130,23 @@ def test_judge_golden(ctx, name, te_type):
                 assert [g[0], g[1], g[2], g[3]] == exp, (i, g, exp)
 
 
-@pytest.mark.parametrize("mode", ["block_only", "wave_default", "wave_rows_32", "wave_wide"])
+@pytest.mark.parametrize("mode", ["block_only", "wave_default", "wave_rows_32", "wave_wide", "lds_block", "lds_wave", "lds_wave_small_tiles"])
 @pytest.mark.parametrize("name,te_type", [("judge_tir", "tir"), ("judge_non_ltr", "non_ltr"), ("judge_helitron", "helitron")])
 def test_judge_golden_kernel_forms(ctx, name, te_type, mode, monkeypatch):
-    """the two judge kernels (one wavefront per alignment / one workgroup per alignment) give the same calls: every golden
-    through the workgroup kernel only (what a batch below HITE_JUDGE_WAVE_MIN_BATCH alignments gets by default), through the
-    wave kernel as a large batch gets it, through the wave kernel with the row limit at 32 (the 64-row mask path stays in the
-    workgroup kernel), and with the column limit lifted (anchor text of wide alignments in global scratch)"""
-    env = {"block_only": {"HITE_JUDGE_WAVE_COLS": "0"}, "wave_rows_32": {"HITE_JUDGE_WAVE_ROWS": "32", "HITE_JUDGE_WAVE_MIN_BATCH": "0"},
-           "wave_default": {"HITE_JUDGE_WAVE_MIN_BATCH": "0"},
-           "wave_wide": {"HITE_JUDGE_WAVE_COLS": "60000", "HITE_JUDGE_OVERLAP": "0", "HITE_JUDGE_WAVE_MIN_BATCH": "0"}}[mode]
+    """the four judge kernels ({one wavefront, one workgroup} per alignment x {alignment read from HBM, alignment held in LDS}) give
+    the same calls: every golden through the workgroup kernel on HBM only, through the wave kernel on HBM as a large batch got it
+    before the LDS forms, with the row limit at 32 (the 64-row mask path stays in the workgroup kernel), with the column limit
+    lifted (anchor text of wide alignments in global scratch); then through the LDS forms (HITE_JUDGE_LDS=1; off by default, they
+    measured slower): workgroup, wavefront with the default tiles, wavefront with tiles so small that the classes split the
+    goldens between all kernels"""
+    env = {"block_only": {"HITE_JUDGE_WAVE_COLS": "0", "HITE_JUDGE_LDS": "0"},
+           "wave_rows_32": {"HITE_JUDGE_WAVE_ROWS": "32", "HITE_JUDGE_WAVE_MIN_BATCH": "0", "HITE_JUDGE_LDS": "0"},
+           "wave_default": {"HITE_JUDGE_WAVE_MIN_BATCH": "0", "HITE_JUDGE_LDS": "0"},
+           "wave_wide": {"HITE_JUDGE_WAVE_COLS": "60000", "HITE_JUDGE_OVERLAP": "0", "HITE_JUDGE_WAVE_MIN_BATCH": "0", "HITE_JUDGE_LDS": "0"},
+           "lds_block": {"HITE_JUDGE_LDS": "1", "HITE_JUDGE_LDS_BLOCK0": "61440", "HITE_JUDGE_LDS_BLOCK1": "126976"},
+           "lds_wave": {"HITE_JUDGE_LDS": "1", "HITE_JUDGE_WAVE_MIN_BATCH": "0"},
+           "lds_wave_small_tiles": {"HITE_JUDGE_LDS": "1", "HITE_JUDGE_WAVE_MIN_BATCH": "0", "HITE_JUDGE_LDS_WAVE0": "2048", "HITE_JUDGE_LDS_WAVE1": "6000",
+                                    "HITE_JUDGE_LDS_WAVE2": "12000", "HITE_JUDGE_LDS_BLOCK0": "20000", "HITE_JUDGE_LDS_BLOCK1": "40000"}}[mode]
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     cases = load_golden(name)
@@ -320,6 +327,13 @@ def test_fine_stage_vs_oracle_chain(ctx, te_type, monkeypatch):
         g = synth_small.make(seed, n_fam=16, te_type=te_type)
         ctx.genome_pack(g["contigs"])
         got, stats = ctx.flank_region_align(te_type, g["cands"], g["copies"], plant=1)
+        # the same batch with the fill fused into the judge's LDS kernels (off by default): alignments of the LDS classes never
+        # reach HBM, the calls are the same
+        with monkeypatch.context() as mp:
+            mp.setenv("HITE_JUDGE_LDS", "1")
+            fused, stats_fused = ctx.flank_region_align(te_type, g["cands"], g["copies"], plant=1)
+        assert fused == got
+        assert stats_fused[2] + stats_fused[6] < stats[2] + stats[6]      # alignment bytes in HBM
         for cand, copies, res in zip(g["cands"], g["copies"], got):
             exp = OP.fine_stage_candidate(te_type, cand, copies, g["contigs"], plant=1)
             assert [res[0], res[1], res[2], res[3]] == exp, (te_type, seed, res, exp)
