@@ -405,7 +405,9 @@ class Context:
         self._check(self.lib.hite_copy_index_build(self.h, C.byref(self._copy_state), C.c_void_p(stream)), "hite_copy_index_build")
 
     def find_copies_dev(self, n_cand, d_cand, d_cand_off, cand_bytes, stream=0):
-        """device-resident: -> (n_copies, d_copy_first, d_contig, d_start1, d_end1, d_minus, d_anchors) raw device pointers"""
+        """device-resident: -> (n_copies, d_copy_first, d_contig, d_start1, d_end1, d_minus, d_anchors) raw device pointers.
+        PRECONDITION (include/hite_gpu.h): the buffer at d_cand is readable for 16 bytes beyond cand_bytes -- allocate
+        cand_bytes + 16 (the end extension fetches candidate words ahead of use)."""
         v = C.c_void_p
         outs = [v() for _ in range(6)]
         n = C.c_int64(0)

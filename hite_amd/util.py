@@ -586,6 +586,7 @@ def read_Ninja_clusters(cluster_file):
     return clusters
 
 
+CLUSTER_CLEAN_THRESHOLD = 10000   # "mafft cannot take too many rows": clusters are kept within this size (Util.py:12254)
 NINJA_CUTOFF = 0.2        # generate_cons_v1 runs `Ninja --cluster_cutoff 0.2` (Util.py:12470)
 STAR_MAX_LEN = 32767      # longest window the star aligner takes (include/hite_gpu.h)
 SEED_MAX_SEGMENTS = 65000  # sequences per all-vs-all call (the seeding stage addresses < 65535 segments)
@@ -597,21 +598,32 @@ def ninja_stand_in(rows):
     in <= 20 % of the columns where either has a base (a base against a gap is a difference; Ninja cuts its
     neighbour-joining tree at distance 0.2), else it becomes a leader.  rows: 2-D uint8 alignment -> list of lists of row indices (sub-clusters in order of their leaders)."""
     rows = np.asarray(rows)
-    leaders, members = [], []
-    for r in range(rows.shape[0]):
-        placed = False
-        for k, l in enumerate(leaders):
-            either = (rows[r] != 45) | (rows[l] != 45)
-            n = int(either.sum())
+    R, C = rows.shape if rows.ndim == 2 else (0, 0)
+    base = rows != 45
+    lead_rows = np.empty((0, C), dtype=rows.dtype)     # the leaders' rows, grown in blocks: one vectorised compare per row
+    lead_base = np.empty((0, C), dtype=bool)
+    n_lead, members = 0, []
+    for r in range(R):
+        k = -1
+        if n_lead:
             # a base against a gap counts like a base against another base (the star alignment threads a short unrelated
             # member through the centre with gaps wherever that makes bases agree: its aligned bases alone look similar)
-            if n > 0 and int(((rows[r] != rows[l]) & either).sum()) <= NINJA_CUTOFF * n:
-                members[k].append(r)
-                placed = True
-                break
-        if not placed:
-            leaders.append(r)
-            members.append([r])
+            either = lead_base[:n_lead] | base[r]
+            n = either.sum(axis=1)
+            diff = ((lead_rows[:n_lead] != rows[r]) & either).sum(axis=1)
+            ok = np.nonzero((n > 0) & (diff <= NINJA_CUTOFF * n))[0]
+            if len(ok):
+                k = int(ok[0])
+        if k >= 0:
+            members[k].append(r)
+            continue
+        if n_lead == len(lead_rows):
+            grow = max(16, n_lead)
+            lead_rows = np.concatenate([lead_rows, np.empty((grow, C), dtype=rows.dtype)])
+            lead_base = np.concatenate([lead_base, np.zeros((grow, C), dtype=bool)])
+        lead_rows[n_lead], lead_base[n_lead] = rows[r], base[r]
+        n_lead += 1
+        members.append([r])
     return members
 
 
@@ -734,19 +746,60 @@ def _library_hits(ctx, names, contigs):
     return tuple(np.concatenate([p[k] for p in parts]) for k in range(6))
 
 
-def _stretch_hits(q, s, qs, qe, ss, se, lens):
+_COMP = np.full(256, ord("N"), dtype=np.uint8)
+for _a, _b in zip(b"ACGT", b"TGCA"):
+    _COMP[_a] = _b
+
+
+def _stretch_hits(q, s, qs, qe, ss, se, lens, seqs):
     """The seeding stage reports a hit from its first to its last anchor; blastn extends an alignment to the ends of the
-    sequences when they keep matching.  Hits are therefore stretched along their diagonal over a short overhang (on both
-    sequences; <= 30 bases or a tenth of the shorter sequence): without it two copies of one family miss a 0.95 coverage
-    rule by the bases outside the anchors (a copy with a few substitutions near one end has no shared minimizer there)."""
+    sequences when they keep matching.  A hit whose ends lie within a short overhang of the sequence ends (on both sequences;
+    <= 30 bases or a tenth of the shorter sequence) is therefore stretched along its diagonal -- BY THE BASES THAT ALIGN: the
+    overhang is compared base by base (match +1, mismatch -2 as megablast scores, no gaps) and the hit grows to the best-scoring prefix of it,
+    as an ungapped X-drop extension would leave it.  Copies of one family (<= 15 % apart) gain nearly the whole overhang and
+    pass a 0.95 coverage rule they would miss by the bases outside their anchors; unrelated termini (a quarter of the bases
+    agree by chance) gain a handful of bases at most and stay below it, as they do under blastn / cd-hit-est.
+    seqs: the upper-case sequences behind the ids (bytes / str)."""
     L = np.asarray(lens, dtype=np.int64)
-    qs, qe, ss, se = (np.asarray(x).copy() for x in (qs, qe, ss, se))
+    q, s = np.asarray(q, dtype=np.int64), np.asarray(s, dtype=np.int64)
+    qs, qe, ss, se = (np.asarray(x, dtype=np.int64).copy() for x in (qs, qe, ss, se))
+    if len(q) == 0:
+        return qs, qe, ss, se
+    off = np.zeros(len(L) + 1, dtype=np.int64)
+    np.cumsum(L, out=off[1:])
+    buf = np.frombuffer(b"".join(x.encode() if isinstance(x, str) else bytes(x) for x in seqs), dtype=np.uint8)
     fwd = ss <= se
     left = np.minimum(qs - 1, np.where(fwd, ss - 1, L[s] - ss))
     right = np.minimum(L[q] - qe, np.where(fwd, L[s] - se, se - 1))
     reach = np.maximum(30, np.minimum(L[q], L[s]) // 10)
     left = np.where(left <= reach, left, 0)
     right = np.where(right <= reach, right, 0)
+
+    def aligned(room, q0, qstep, s0, sstep):
+        """room[h] candidate bases; base j of hit h: query q0 + qstep * j, subject s0 + sstep * j (0-based, inside the
+        sequence); -> the length of the best-scoring prefix"""
+        out = np.zeros(len(room), dtype=np.int64)
+        idx = np.nonzero(room > 0)[0]
+        CH = 4096
+        for a in range(0, len(idx), CH):
+            h = idx[a:a + CH]
+            w = int(room[h].max())
+            j = np.arange(w, dtype=np.int64)[None, :]
+            ok = j < room[h][:, None]
+            qi = off[q[h]][:, None] + np.where(ok, q0[h][:, None] + qstep * j, 0)
+            si = off[s[h]][:, None] + np.where(ok, s0[h][:, None] + sstep[h][:, None] * j, 0)
+            qb, sb = buf[qi], buf[si]
+            sb = np.where(fwd[h][:, None], sb, _COMP[sb])
+            sc = np.where(ok, np.where((qb == sb) & (qb != ord("N")), 1, -2), -(1 << 20)).cumsum(axis=1)
+            best = sc.argmax(axis=1)
+            out[h] = np.where(sc[np.arange(len(h)), best] > 0, best + 1, 0)
+        return out
+
+    one = np.where(fwd, 1, -1).astype(np.int64)
+    # to the left of the hit: query bases qs-2, qs-3, ... (0-based); subject ss-2, ss-3, ... (forward) / ss, ss+1, ... (reverse)
+    left = aligned(left, qs - 2, -1, np.where(fwd, ss - 2, ss), -one)
+    # to the right: query qe, qe+1, ...; subject se, se+1, ... (forward) / se-2, se-3, ... (reverse)
+    right = aligned(right, qe, 1, np.where(fwd, se, se - 2), one)
     qs -= left; qe += right
     ss = np.where(fwd, ss - left, ss + left)
     se = np.where(fwd, se + right, se - right)
@@ -761,9 +814,10 @@ def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_thre
     against itself by hite_seed_allvsall (where the reference runs blastn; libraries of >= 65 000 sequences in blocks),
     chaining / clustering / consensus are the pinned device stages (hite_lib_chain, hite_lib_cluster, hite_msa_consensus),
     the alignments are star alignments (where the reference runs mafft), the sub-clusters come from ninja_stand_in (where it
-    runs Ninja); the cd-hit-est pre-reduction of clusters above 10 000 members (:12256-12299) is not made (the star aligner
-    takes clusters of any size); cd-hit-est after the consensus step runs when it is installed.  Sequences longer than the
-    aligner's 32 767-base windows pass unclustered.
+    runs Ninja); a cluster above 10 000 members is cut in file order into pieces of <= 10 000, the fall-back the reference
+    itself takes when its cd-hit-est pre-reduction does not get a cluster below that size (:12252-12299; the pre-reduction
+    itself needs the external tool); cd-hit-est after the consensus step runs when it is installed.  Sequences longer than
+    the aligner's 32 767-base windows pass unclustered.
     Writes <redundant_ltr>.tmp.cons and <redundant_ltr>.cons, returns the former like the reference."""
     names, contigs = read_fasta(redundant_ltr)
     cons_path, final_path = redundant_ltr + ".tmp.cons", redundant_ltr + ".cons"
@@ -777,9 +831,10 @@ def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_thre
     if work:
         q, s, qs, qe, ss, se = _library_hits(ctx, work, contigs)
         lens = [len(contigs[n]) for n in work]
-        qs, qe, ss, se = _stretch_hits(q, s, qs, qe, ss, se, lens)
+        qs, qe, ss, se = _stretch_hits(q, s, qs, qe, ss, se, lens, [contigs[n].upper() for n in work])
         recs = ctx.lib_chain(q, s, qs, qe, ss, se, lens, coverage_threshold, 5_000_000)
         clusters = [cl for cl in ctx.lib_cluster(recs, lens, coverage_threshold) if len(cl) >= 1]
+        clusters = [cl[a:a + CLUSTER_CLEAN_THRESHOLD] for cl in clusters for a in range(0, len(cl), CLUSTER_CLEAN_THRESHOLD)]
         batch = [[(work[i], contigs[work[i]]) for i in cl] for cl in clusters]
         for cl, cons in zip(clusters, _generate_cons_batch(ctx, batch) if batch else []):
             clustered.update(work[i] for i in cl)
@@ -805,13 +860,13 @@ def remove_redundant_sequences(inp, outp, aS=0.95, aL=0.95, device=0):
     representatives are written longest first, as cd-hit-est writes them.  Identity is not computed: hits are runs of shared
     15-base minimizers, which sequences below ~85 % identity hardly have (cd-hit's -c 0.8 / 0.95 asks for less / more)."""
     names, contigs = read_fasta(inp)
-    work = [n for n in names if 0 < len(contigs[n]) <= STAR_MAX_LEN]
+    work = [n for n in names if len(contigs[n]) > 0]         # (nothing is aligned here: no length limit)
     drop = set()
     if len(work) > 1:
         ctx = get_ctx(device)
         q, s_, qs, qe, ss, se = _library_hits(ctx, work, contigs)
         lens = [len(contigs[n]) for n in work]
-        qs, qe, ss, se = _stretch_hits(q, s_, qs, qe, ss, se, lens)
+        qs, qe, ss, se = _stretch_hits(q, s_, qs, qe, ss, se, lens, [contigs[n].upper() for n in work])
         recs = ctx.lib_chain(q, s_, qs, qe, ss, se, lens, min(aS, aL), 5_000_000)
         covered = {}
         for (_ch, qi, a, b, si, c, d) in recs:
@@ -890,6 +945,8 @@ def run_remove_TR(target_file, trf_dir):
 def mask_tandem_repeats(names, contigs, device=0, max_period=500):
     """The build's own tandem-repeat masker (hite_tr_mask; definition oracle/hite_oracle_trf.c) where the reference runs TRF:
     {name: sequence} -> {name: sequence with tandem repeats as N}.  The resident genome becomes these sequences."""
+    if not names or not any(len(contigs[n]) for n in names):     # an empty chunk stays an empty file, as in the reference
+        return {n: contigs[n] for n in names}
     ctx = get_ctx(device)
     ctx.genome_pack([contigs[n] for n in names])
     ctx.release_copy_index()

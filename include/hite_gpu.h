@@ -268,7 +268,7 @@ int hite_copy_stats_ext(void *state, int64_t out[8]);
  * (hite_seed_segments gives the table, split_genome_chunks.py:41-52), 1-based inclusive coordinates inside the segment,
  * ss > se for reverse-strand hits; ordered by (query segment, subject segment).  *n_out is set even on HITE_ECAP.
  * max_anchors bounds the device memory of the anchor sort (24 B per anchor).  stats_out (may be NULL) =
- * {seeds, anchors, clusters, records}. * _dev: d_cand must be readable for 16 bytes beyond cand_bytes (the end extension fetches candidate words ahead of use). */
+ * {seeds, anchors, clusters, records}. */
 int hite_seed_allvsall_dev(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int32_t **d_qseg, int32_t **d_sseg,
                            int64_t **d_qs, int64_t **d_qe, int64_t **d_ss, int64_t **d_se, int64_t *n_out, int64_t *stats_out);
 int hite_seed_segments(hite_ctx *ctx, int64_t seg_len, int32_t cap, int32_t *seg_chrom, int64_t *seg_off, int32_t *nseg_out);
@@ -277,6 +277,8 @@ int hite_seed_allvsall(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t 
 int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
                      int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
                      int32_t *anchors, int64_t *n_out);
+/* _dev PRECONDITION: d_cand must be readable for 16 bytes beyond cand_bytes (the end extension fetches candidate words ahead
+ * of use); hite_find_copies pads its upload, a caller that owns the device buffer allocates cand_bytes + 16. */
 int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8_t *d_cand, const int64_t *d_cand_off,
                          int64_t cand_bytes, int32_t **d_copy_first, int64_t *n_copies, int32_t **d_contig,
                          int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus, int32_t **d_anchors, void *stream);

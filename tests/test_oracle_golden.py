@@ -430,3 +430,38 @@ def test_ready_for_msa_golden():
             cut = sorted(c["lens"], reverse=True)[99]
             ties_decided += sum(1 for x in c["lens"] if x == cut) > sum(1 for i in keep if c["lens"][i] == cut)
     assert ties_decided >= 6          # the cut falls inside a run of equal lengths in most cases: the tie rule is what is pinned
+
+
+def test_stretch_hits_looks_at_the_bases():
+    """util._stretch_hits (host arithmetic of the library merge): a hit grows over the overhang only by the bases that align
+    -- the same core with unrelated 8 % termini must stay below a 0.95 coverage rule, copies of one family reach the ends, on
+    either strand"""
+    import numpy as np
+    from hite_amd import util as U
+
+    rng = np.random.default_rng(7)
+    rnd = lambda n: "".join("ACGT"[i] for i in rng.integers(0, 4, n))  # noqa: E731
+    rc = lambda x: x[::-1].translate(str.maketrans("ACGT", "TGCA"))  # noqa: E731
+
+    def mutate(x, frac):
+        a = list(x)
+        for i in rng.choice(len(a), int(len(a) * frac), replace=False):
+            a[i] = "ACGT"[("ACGT".index(a[i]) + 1 + int(rng.integers(0, 3))) % 4]
+        return "".join(a)
+
+    for trial in range(20):
+        core = rnd(800)
+        a = rnd(80) + core + rnd(80)
+        b = rnd(80) + core + rnd(80)          # same core, different termini
+        c = mutate(a, 0.10)                   # a copy of a, 10 % substitutions
+        seqs = [a, b, c, rc(c)]
+        lens = [len(x) for x in seqs]
+        # hits over the core only (what the anchors of the seeding stage span), 1-based inclusive; the last one on the minus strand
+        qs, qe, ss, se = U._stretch_hits([0, 0, 0], [1, 2, 3], [81, 81, 81], [880, 880, 880], [81, 81, 880], [880, 880, 81], lens, seqs)
+        assert (qe[0] - qs[0] + 1) / 960 < 0.95 and abs(se[0] - ss[0]) + 1 == qe[0] - qs[0] + 1, (trial, qs, qe)
+        assert (qe[1] - qs[1] + 1) / 960 >= 0.97 and ss[1] == qs[1] and se[1] == qe[1], (trial, qs, qe, ss, se)
+        assert (qe[2] - qs[2] + 1) / 960 >= 0.97 and ss[2] == 961 - qs[2] and se[2] == 961 - qe[2], (trial, qs, qe, ss, se)
+    # an overhang beyond the reach (a tenth of the shorter sequence, at least 30) is left alone
+    a = rnd(1000)
+    qs, qe, ss, se = U._stretch_hits([0], [1], [201], [800], [201], [800], [1000, 1000], [a, a])
+    assert (int(qs[0]), int(qe[0])) == (201, 800)
