@@ -65,6 +65,11 @@ class Context:
         self.h = h
         self.device = device
 
+    def copy_config(self, aligned_interval):
+        """which interval copy records carry (process-wide, include/hite_gpu.h hite_copy_config): False = whole candidate
+        (default), True = the aligned interval as get_copies_minimap2 reports it (Util.py:8026), None = from HITE_COPY_INTERVAL"""
+        self._check(self.lib.hite_copy_config(-1 if aligned_interval is None else int(bool(aligned_interval))), "hite_copy_config")
+
     def release_copy_index(self):
         """drops the minimizer index of the packed genome (device memory is freed); the next copy / seeding call rebuilds it"""
         if getattr(self, "_copy_state", None) is not None and getattr(self, "h", None):

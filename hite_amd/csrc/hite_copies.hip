@@ -574,7 +574,7 @@ __global__ void __launch_bounds__(256) chain_copy_kernel(const unsigned long lon
                                                          const int64_t *__restrict__ coff, int nc, unsigned long long *__restrict__ ckey,
                                                          unsigned *__restrict__ cval, int32_t *__restrict__ r_contig, int64_t *__restrict__ r_s1,
                                                          int64_t *__restrict__ r_e1, uint8_t *__restrict__ r_minus, int32_t *__restrict__ r_anch,
-                                                         int32_t *__restrict__ per_cand, const int64_t *__restrict__ cstart) {
+                                                         int32_t *__restrict__ per_cand, const int64_t *__restrict__ cstart, int aligned_iv) {
     unsigned long long n_long = counters[0], n_short = counters[1];
     if (n_long > cap) n_long = cap;
     if (n_long + n_short > cap) n_short = cap - n_long;
@@ -594,7 +594,8 @@ __global__ void __launch_bounds__(256) chain_copy_kernel(const unsigned long lon
         if (!WRITE) { atomicAdd(&per_cand[c], 1); continue; }
         const int ctg = contig_of(coff, nc, glo);
         const long long cb = coff[ctg], ce = coff[ctg + 1];
-        long long s0 = a0 - clip_l, e0 = a1 + clip_r;
+        // whole-candidate interval (default) or the aligned interval as get_copies_minimap2 reports it (Util.py:8026; hite_copy_config)
+        long long s0 = aligned_iv ? a0 : a0 - clip_l, e0 = aligned_iv ? a1 : a1 + clip_r;
         if (s0 < cb) s0 = cb;
         if (e0 > ce) e0 = ce;
         const int64_t slot = cstart[c] + atomicAdd(&per_cand[c], 1);
@@ -649,6 +650,23 @@ static int sorter_from_arena(Sorter &S, hite_ctx *ctx, Arena &A, hipStream_t st,
     CCHK(arena_alloc(ctx, A, (size_t)S.hist_n * 4, &p)); S.hist = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(S.hist_n + 1) * 8, &p)); S.offs = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)sorter_tmp_elems(S.hist_n) * 8, &p)); S.bs = (int64_t *)p;
+    return HITE_OK;
+}
+
+// which interval a copy record carries: 0 (default) = the interval of the WHOLE candidate (clipped ends extrapolated on the
+// diagonal; DESIGN.md deviation v), 1 = the ALIGNED interval, reference_start + 1 .. reference_end as get_copies_minimap2
+// reports it (Util.py:8026).  Process-wide; initialised from the environment (HITE_COPY_INTERVAL=aligned), -1 = ask the environment again.
+static int g_copy_interval = -1;
+static int copy_interval_mode() {
+    if (g_copy_interval < 0) {
+        const char *e = getenv("HITE_COPY_INTERVAL");
+        g_copy_interval = (e && (!strcmp(e, "aligned") || !strcmp(e, "1"))) ? 1 : 0;
+    }
+    return g_copy_interval;
+}
+extern "C" int hite_copy_config(int32_t aligned_interval) {
+    if (aligned_interval < -1 || aligned_interval > 1) return HITE_EINVAL;
+    g_copy_interval = aligned_interval;
     return HITE_OK;
 }
 
@@ -925,11 +943,11 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
         const unsigned cblocks = (unsigned)(want_blocks < 8192ull ? (want_blocks ? want_blocks : 1ull) : 8192ull);
         hipLaunchKernelGGL(chain_copy_kernel<false>, dim3(cblocks), dim3(256), 0, st, d_nchain, chcap, chain_list, x_i, x_t, hkey, F, c_first, c_lo,
                            c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, per_cand,
-                           (const int64_t *)nullptr);
+                           (const int64_t *)nullptr, copy_interval_mode());
         CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand, n_cand, cstart, st));
         hipLaunchKernelGGL(chain_copy_kernel<true>, dim3(cblocks), dim3(256), 0, st, d_nchain, chcap, chain_list, x_i, x_t, hkey, F, c_first, c_lo,
                            c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, fill,
-                           (const int64_t *)cstart);
+                           (const int64_t *)cstart, copy_interval_mode());
     }
     hite_prof_end(ctx, tk_cluster_copy_kernel, st);
     hipLaunchKernelGGL(cap300_kernel, CGRID((int64_t)n_cand), 0, st, n_cand, per_cand, per_cand300);

@@ -746,9 +746,9 @@ def _library_hits(ctx, names, contigs):
     return tuple(np.concatenate([p[k] for p in parts]) for k in range(6))
 
 
-_COMP = np.full(256, ord("N"), dtype=np.uint8)
+_COMP_U8 = np.full(256, ord("N"), dtype=np.uint8)
 for _a, _b in zip(b"ACGT", b"TGCA"):
-    _COMP[_a] = _b
+    _COMP_U8[_a] = _b
 
 
 def _stretch_hits(q, s, qs, qe, ss, se, lens, seqs):
@@ -789,7 +789,7 @@ def _stretch_hits(q, s, qs, qe, ss, se, lens, seqs):
             qi = off[q[h]][:, None] + np.where(ok, q0[h][:, None] + qstep * j, 0)
             si = off[s[h]][:, None] + np.where(ok, s0[h][:, None] + sstep[h][:, None] * j, 0)
             qb, sb = buf[qi], buf[si]
-            sb = np.where(fwd[h][:, None], sb, _COMP[sb])
+            sb = np.where(fwd[h][:, None], sb, _COMP_U8[sb])
             sc = np.where(ok, np.where((qb == sb) & (qb != ord("N")), 1, -2), -(1 << 20)).cumsum(axis=1)
             best = sc.argmax(axis=1)
             out[h] = np.where(sc[np.arange(len(h)), best] > 0, best + 1, 0)

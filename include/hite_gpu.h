@@ -253,6 +253,11 @@ int hite_tsd_kmer_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_seqs, const int
  * hite_flank_region_align consumes (1-based inclusive coordinates).  n_cand < 2^19 per call.
  * _dev: the returned device arrays live in the index state's arena until the next call. */
 int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream);
+/* which interval the copy records of hite_find_copies[_dev] carry (process-wide): 0 = the interval of the WHOLE candidate, the
+ * ends that the extension clipped extrapolated on the diagonal (default; DESIGN.md section 2, deviation v); 1 = the ALIGNED
+ * interval, reference_start + 1 .. reference_end exactly as get_copies_minimap2 reports it (Util.py:8026); -1 = take the
+ * setting from the environment again (HITE_COPY_INTERVAL=aligned).  Both are twin-pinned (orc_find_copies_config). */
+int hite_copy_config(int32_t aligned_interval);
 void hite_copy_index_release(void *state);
 /* sizes of the last hite_find_copies[_dev] call on this index (diagnostics / roofline accounting):
  * out = {candidate minimizers, index hits, diagonal clusters, copies before the 300-per-candidate cap} */

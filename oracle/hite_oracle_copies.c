@@ -235,6 +235,10 @@ int64_t orc_ext_align(const uint8_t *qseg, int64_t n, int dir, const uint8_t *ge
     return ext_align(qseg, n, dir, genome, g0, gmin, gmax, t_out);
 }
 
+/* interval mode of the records (hite_copy_config): 0 = whole candidate (default), 1 = aligned interval (Util.py:8026) */
+static int g_aligned_interval = 0;
+void orc_find_copies_config(int aligned_interval) { g_aligned_interval = aligned_interval ? 1 : 0; }
+
 /* seconds the last orc_find_copies call spent building its index (bench.py separates residency set-up from the lookups) */
 static double g_index_seconds = 0.0;
 double orc_find_copies_index_seconds(void) { return g_index_seconds; }
@@ -329,7 +333,7 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
             if (a1 > a0 && aligned * 100 >= 95 * Lq && aligned * 100 >= 95 * (a1 - a0)) {
                 /* the interval handed on covers the whole candidate: the clipped ends (<= 5 % of it) lie on the diagonal of the last
                  * aligned base, clamped to the contig */
-                int64_t s0 = a0 - clip_l, e0 = a1 + clip_r;
+                int64_t s0 = g_aligned_interval ? a0 : a0 - clip_l, e0 = g_aligned_interval ? a1 : a1 + clip_r;
                 if (s0 < cb) s0 = cb;
                 if (e0 > ce) e0 = ce;
                 if (ncp == ccap) { ccap *= 2; cps = (copy_t *)realloc(cps, sizeof(copy_t) * ccap); }

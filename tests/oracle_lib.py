@@ -286,6 +286,11 @@ def find_copies(contigs, cands):
     return [[(int(ct[i]), int(s1[i]), int(e1[i]), int(mn[i]), int(an[i])) for i in range(cf[c], cf[c + 1])] for c in range(len(cb))]
 
 
+def find_copies_config(aligned_interval):
+    """interval mode of the twin's records (mirror of hite_copy_config)"""
+    lib().orc_find_copies_config(int(bool(aligned_interval)))
+
+
 def seed_allvsall(contigs, seg_len=1_000_000):
     """this build's blastn stand-in (twin): -> dict(qseg, sseg, qs, qe, ss, se) + the segment table"""
     gb = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]

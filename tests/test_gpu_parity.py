@@ -459,6 +459,36 @@ def test_find_copies_vs_twin(ctx):
         assert [r[0], r[1], r[2], r[3]] == OP.fine_stage_candidate("tir", cand, cp, g["contigs"], plant=1)
 
 
+def test_find_copies_aligned_interval_mode(ctx):
+    """hite_copy_config(1): the records carry the ALIGNED interval, reference_start + 1 .. reference_end as
+    get_copies_minimap2 reports it (Util.py:8026), instead of the interval of the whole candidate (the default; DESIGN.md
+    deviation v).  Both modes are twin-pinned; the aligned intervals lie inside the whole-candidate ones, copy for copy."""
+    import synth_small
+
+    g = synth_small.make(23, n_fam=24)
+    ctx.genome_pack(g["contigs"])
+    ctx.release_copy_index()
+    whole = ctx.find_copies(g["cands"])
+    try:
+        ctx.copy_config(True)
+        O.find_copies_config(True)
+        aligned = ctx.find_copies(g["cands"])
+        assert aligned == O.find_copies(g["contigs"], g["cands"])
+    finally:
+        ctx.copy_config(False)
+        O.find_copies_config(False)
+    assert ctx.find_copies(g["cands"]) == whole == O.find_copies(g["contigs"], g["cands"])
+    n_shorter = 0
+    for w, a in zip(whole, aligned):
+        assert len(w) == len(a)                    # the same chains are accepted: the two filters do not see the mode
+        key = lambda t: (t[0], t[3], t[4])         # noqa: E731  (contig, strand, anchors)
+        for x in a:
+            inside = [y for y in w if key(y) == key(x) and y[1] <= x[1] and x[2] <= y[2]]
+            assert inside, (x, w)
+            n_shorter += min(y[2] - y[1] for y in inside) > x[2] - x[1]
+    assert n_shorter > 0                           # some copies were clipped: their aligned interval is shorter
+
+
 def test_edge_cases(ctx):
     """empty / ragged / degenerate inputs the reference also meets: empty batches, single-row and
     two-row alignments, candidates without copies, candidates shorter than the 20-bp anchor, copies at contig ends"""
