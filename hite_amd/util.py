@@ -806,7 +806,7 @@ def _stretch_hits(q, s, qs, qe, ss, se, lens, seqs):
     return qs, qe, ss, se
 
 
-def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_threshold, debug, device=0):
+def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_threshold, debug, device=0, ctx=None, stages=None):
     """deredundant_for_LTR_v5 (Util.py:12202-12337, the library de-duplication of panHiTE, config C5), same arguments.
     Reference: blastn all-vs-all of the library -> chunked fragment chaining (process_blast_results_in_chunks +
     FMEA_new1_parallel_large) -> greedy clusters (cluster_sequences_from_chunks) -> per cluster generate_cons_v1 (mafft ->
@@ -818,14 +818,17 @@ def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_thre
     itself takes when its cd-hit-est pre-reduction does not get a cluster below that size (:12252-12299; the pre-reduction
     itself needs the external tool); cd-hit-est after the consensus step runs when it is installed.  Sequences longer than
     the aligner's 32 767-base windows pass unclustered.
-    Writes <redundant_ltr>.tmp.cons and <redundant_ltr>.cons, returns the former like the reference."""
+    Writes <redundant_ltr>.tmp.cons and <redundant_ltr>.cons, returns the former like the reference.
+    ctx: the context to run on (default: the process-wide one of `device`); stages: a dict that receives the intermediate
+    results ('hits', 'clusters': lists of names) -- what the parity tests compare between two runs."""
     names, contigs = read_fasta(redundant_ltr)
     cons_path, final_path = redundant_ltr + ".tmp.cons", redundant_ltr + ".cons"
     if not names:
         store_fasta({}, cons_path)
         store_fasta({}, final_path)
         return cons_path
-    ctx = get_ctx(device)
+    if ctx is None:
+        ctx = get_ctx(device)
     work = [n for n in names if 0 < len(contigs[n]) <= STAR_MAX_LEN]       # the rest passes unchanged
     all_cons, clustered = {}, set()
     if work:
@@ -835,6 +838,9 @@ def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_thre
         recs = ctx.lib_chain(q, s, qs, qe, ss, se, lens, coverage_threshold, 5_000_000)
         clusters = [cl for cl in ctx.lib_cluster(recs, lens, coverage_threshold) if len(cl) >= 1]
         clusters = [cl[a:a + CLUSTER_CLEAN_THRESHOLD] for cl in clusters for a in range(0, len(cl), CLUSTER_CLEAN_THRESHOLD)]
+        if stages is not None:
+            stages["hits"] = len(q)
+            stages["clusters"] = [[work[i] for i in cl] for cl in clusters]
         batch = [[(work[i], contigs[work[i]]) for i in cl] for cl in clusters]
         for cl, cons in zip(clusters, _generate_cons_batch(ctx, batch) if batch else []):
             clustered.update(work[i] for i in cl)
@@ -847,11 +853,11 @@ def deredundant_for_LTR_v5(redundant_ltr, work_dir, threads, type, coverage_thre
         subprocess.run("cd-hit-est -aS 0.95 -aL 0.95 -c %s -G 0 -g 1 -A 80 -i %s -o %s -T 0 -M 0 > /dev/null 2>&1" %
                        (coverage_threshold, cons_path, final_path), shell=True, check=False)
     else:
-        remove_redundant_sequences(cons_path, final_path, 0.95, 0.95, device=device)     # the build's stand-in, never a plain copy
+        remove_redundant_sequences(cons_path, final_path, 0.95, 0.95, device=device, ctx=ctx)     # the build's stand-in, never a plain copy
     return cons_path
 
 
-def remove_redundant_sequences(inp, outp, aS=0.95, aL=0.95, device=0):
+def remove_redundant_sequences(inp, outp, aS=0.95, aL=0.95, device=0, ctx=None):
     """The build's stand-in for `cd-hit-est -aS 0.95 -aL 0.95 -c <c> -G 0 -g 1 -A 80 -i inp -o outp` (judge_TIR_transposons.py:87,
     Util.py:12330; cd-hit-est is an external tool: PARITY UNPINNED), used when it is not installed -- the step is never skipped.
     Greedy incremental clustering in cd-hit's order (longest first, ties in input order): a sequence joins the first longer
@@ -863,7 +869,8 @@ def remove_redundant_sequences(inp, outp, aS=0.95, aL=0.95, device=0):
     work = [n for n in names if len(contigs[n]) > 0]         # (nothing is aligned here: no length limit)
     drop = set()
     if len(work) > 1:
-        ctx = get_ctx(device)
+        if ctx is None:
+            ctx = get_ctx(device)
         q, s_, qs, qe, ss, se = _library_hits(ctx, work, contigs)
         lens = [len(contigs[n]) for n in work]
         qs, qe, ss, se = _stretch_hits(q, s_, qs, qe, ss, se, lens, [contigs[n].upper() for n in work])

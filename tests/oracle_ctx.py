@@ -1,0 +1,59 @@
+"""TEST INFRASTRUCTURE: an object with the method names of hite_amd.Context that answers from the CPU twins / oracle
+(tests/oracle_lib.py over oracle/*.c).  It lets a test drive the product's HOST glue (hite_amd/util.py: library merge, ...)
+a second time with every device stage replaced by its twin, so that whole multi-stage results can be compared -- the
+product itself never sees this file (tests/test_abi.py: nothing under hite_amd/ imports the oracle)."""
+import numpy as np
+
+import oracle_lib as O
+
+
+class OracleCtx:
+    def __init__(self):
+        self.contigs = []
+
+    # ---- residency ------------------------------------------------------------------------------
+    def genome_pack(self, contigs):
+        self.contigs = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]
+
+    def release_copy_index(self):
+        pass
+
+    # ---- stages ---------------------------------------------------------------------------------
+    def seed_allvsall(self, seg_len=1_000_000, max_anchors=None, cap=None):
+        t = O.seed_allvsall(self.contigs, seg_len)
+        return {k: t[k] for k in ("qseg", "sseg", "qs", "qe", "ss", "se")}
+
+    def lib_chain(self, qid, sid, qs, qe, ss, se, seq_len, threshold, chunk_size=0):
+        rows = list(zip((int(x) for x in qid), (int(x) for x in sid), (int(x) for x in qs), (int(x) for x in qe), (int(x) for x in ss),
+                        (int(x) for x in se)))
+        return O.lib_chain(rows, list(seq_len), threshold, chunk_size)
+
+    def lib_cluster(self, recs, seq_len, threshold):
+        return O.lib_cluster(recs, list(seq_len), threshold)
+
+    def star_msa(self, groups, sparse=False, info=False):
+        """as Context.star_msa (not sparse); the per-window status of `info` (column 2: 0 = aligned) is recovered from the rows
+        of the twin's alignment: they come in input order, a dropped window has no row (equal windows share their fate)"""
+        assert not sparse
+        res, infos = [], []
+        for g in groups:
+            wb = [w.encode() if isinstance(w, str) else bytes(w) for w in g]
+            m, kept = O.star_msa(wb, rows=True)
+            inf = np.zeros((len(wb), 5), dtype=np.int32)
+            if m is None:
+                res.append(None)
+                inf[1:, 2] = 1
+            else:
+                k = 1
+                for i in range(1, len(wb)):
+                    if k < kept and m[k][m[k] != 45].tobytes() == wb[i]:
+                        k += 1
+                    else:
+                        inf[i, 2] = 1
+                assert k == kept, (k, kept)
+                res.append(m)
+            infos.append(inf)
+        return (res, infos) if info else res
+
+    def msa_consensus(self, alignments):
+        return [O.cons_majority([r if isinstance(r, str) else bytes(r).decode() for r in al]) for al in alignments]

@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 ASCII = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
-def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",)):
+def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",), **workload_kw):
     import torch
 
     import hite_amd
@@ -25,7 +25,7 @@ def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",)):
     from hite_amd._lib import CALL_DTYPE
 
     dev = torch.device("cuda", 0)
-    w = synth.make_workload(genome_bp=mbp * 1_000_000, n_tir=n_tir, n_ltr=n_ltr, cands_per_family=10, seed=seed, device=dev)
+    w = synth.make_workload(genome_bp=mbp * 1_000_000, n_tir=n_tir, n_ltr=n_ltr, cands_per_family=10, seed=seed, device=dev, **workload_kw)
     ctx = hite_amd.Context(0)
     ctx.genome_pack_dev(w["genome"].data_ptr(), w["contig_off"])
     ctx.copy_index_build()
@@ -166,8 +166,8 @@ def c2():
 
 
 def test_c2_fine_stage_matches_oracle_chain(c2):
-    bad, n_te = oracle_check(c2, 200, 1)
-    assert bad == [] and n_te >= 60
+    bad, n_te = oracle_check(c2, 500, 1)
+    assert bad == [] and n_te >= 150
     st = c2["align"]
     assert st["dropped"] == 0 and st["pairs"] > 50_000
     assert st["certified"] >= 0.80 * st["pairs"]            # measured r02: 0.89 (exact_cap 8)
@@ -235,8 +235,8 @@ def test_c2_coarse_stage_recovers_the_families(c2):
 def test_c3_fine_stage_matches_oracle_chain():
     R = run_fine(1000, 2500, 2500, 20250927 + 3)
     try:
-        bad, n_te = oracle_check(R, 200, 2)
-        assert bad == [] and n_te >= 60
+        bad, n_te = oracle_check(R, 1000, 2)
+        assert bad == [] and n_te >= 300
         n_tir_cand, called, checked, exact, near = boundary_stats(R)
         print("C3: %d TIR candidates, %d judged TE; of %d checked: both ends exact %d, within 3 bp %d; %d TE calls in all" %
               (n_tir_cand, called, checked, exact, near, int((R["calls"]["is_te"] != 0).sum())))
@@ -245,3 +245,93 @@ def test_c3_fine_stage_matches_oracle_chain():
         assert st["dropped"] == 0 and st["certified"] >= 0.65 * st["pairs"]   # measured r02: 0.74 (exact_cap 8; 0.90 with 16)
     finally:
         R["ctx"].close()
+
+
+def test_c5_two_population_genomes_merge_into_one_library(tmp_path):
+    """BASELINE.json configs[4] (panHiTE) at its configured genome size on the one GPU there is: two 300 Mbp genomes drawn from
+    a shared family pool (70 % of the families each, as bench.py --config C5 draws them) go through copy finding + the fine
+    stage one after the other; their TE libraries are concatenated and merged by deredundant_for_LTR_v5
+    (pan_remove_redundancy.py:16-46, Util.py:12202-12337).
+      (i)  parity of the merge: the clusters of the WHOLE library are those the same host code finds when every device stage
+           is replaced by its CPU twin (tests/oracle_ctx.py), and on a sub-library (the members of 150 random clusters + 100
+           unclustered sequences) the two runs write byte-identical .tmp.cons and .cons files;
+      (ii) the result is non-redundant: a planted family that reached the merged library comes out as ONE record."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from hite_amd import util
+    from oracle_ctx import OracleCtx
+
+    seed = 20250927 + 5
+    names, seqs, fam_of = [], {}, {}
+    ctx = None
+    for g in range(2):
+        R = run_fine(300, 750, 750, seed + 1009 * (g + 1), family_seed=seed, family_keep=0.7)
+        try:
+            calls, cons, w = R["calls"], R["cons"], R["w"]
+            assert 5_000 < R["n"] < 20_000
+            for c in np.flatnonzero(calls["is_te"] != 0):
+                r = calls[c]
+                nm = "G%d-TE_%d#Unknown" % (g, int(c))
+                names.append(nm)
+                seqs[nm] = cons[r["cons_off"]:r["cons_off"] + r["cons_len"]].tobytes().decode()
+                fam_of[nm] = int(w["family"][c])
+        finally:
+            if g == 0:
+                R["ctx"].close()
+            else:
+                ctx = R["ctx"]
+    try:
+        assert len(names) > 8_000
+        merged = str(tmp_path / "merged.fa")
+        util.store_fasta({n: seqs[n] for n in names}, merged)
+        st_gpu, st_cpu = {}, {}
+        out = util.deredundant_for_LTR_v5(merged, str(tmp_path), 1, "terminal", 0.95, 0, ctx=ctx, stages=st_gpu)
+        final_names, _final = util.read_fasta(merged + ".cons")
+        # (i) whole library: hits and clusters through the twins
+        twin_in = str(tmp_path / "twin_merged.fa")
+        util.store_fasta({n: seqs[n] for n in names}, twin_in)
+        # (the twin run of the whole library stops after the clusters: its alignments are compared on the sub-library below)
+        class StopAfterClusters(Exception):
+            pass
+
+        class ClustersOnly(OracleCtx):
+            def star_msa(self, *a, **k):
+                raise StopAfterClusters()
+
+        try:
+            util.deredundant_for_LTR_v5(twin_in, str(tmp_path), 1, "terminal", 0.95, 0, ctx=ClustersOnly(), stages=st_cpu)
+        except StopAfterClusters:
+            pass
+        assert st_cpu["hits"] == st_gpu["hits"] and st_cpu["clusters"] == st_gpu["clusters"]
+        clusters = st_gpu["clusters"]
+        rng = np.random.default_rng(11)
+        pick = [clusters[i] for i in rng.permutation(len(clusters))[:150]]
+        in_cluster = set(n for cl in clusters for n in cl)
+        loose = [n for n in names if n not in in_cluster]
+        sub = [n for cl in pick for n in cl] + [loose[i] for i in rng.permutation(len(loose))[:100]]
+        sub_set = set(sub)
+        sub = [n for n in names if n in sub_set]          # library order
+        outs = []
+        for tag, cx in (("gpu", ctx), ("cpu", OracleCtx())):
+            path = str(tmp_path / ("sub_%s.fa" % tag))
+            util.store_fasta({n: seqs[n] for n in sub}, path)
+            util.deredundant_for_LTR_v5(path, str(tmp_path), 1, "terminal", 0.95, 0, ctx=cx)
+            outs.append((open(path + ".tmp.cons").read(), open(path + ".cons").read()))
+        assert outs[0] == outs[1]
+        assert len(util.read_fasta(str(tmp_path / "sub_gpu.fa.cons"))[0]) < len(sub)
+        # (ii) non-redundant: records per planted family in the merged library
+        per_fam = {}
+        for n in final_names:
+            per_fam[fam_of[n]] = per_fam.get(fam_of[n], 0) + 1
+        fams_in = set(fam_of[n] for n in names)
+        once = sum(1 for f in fams_in if per_fam.get(f, 0) == 1)
+        lost = sum(1 for f in fams_in if per_fam.get(f, 0) == 0)
+        more = sorted((per_fam[f] for f in fams_in if per_fam.get(f, 0) > 1), reverse=True)
+        print("C5 merge: %d sequences of 2 genomes (%d families) -> %d clusters -> %d records; families with exactly one record %d, "
+              "with none %d, with more %d (largest %s); %d hits" % (len(names), len(fams_in), len(clusters), len(final_names), once, lost,
+                                                                     len(more), more[:5], st_gpu["hits"]))
+        assert os.path.exists(out) and len(final_names) < 0.3 * len(names)
+        assert lost == 0
+        assert once >= 0.80 * len(fams_in)
+    finally:
+        if ctx is not None:
+            ctx.close()

@@ -465,3 +465,32 @@ def test_stretch_hits_looks_at_the_bases():
     a = rnd(1000)
     qs, qe, ss, se = U._stretch_hits([0], [1], [201], [800], [201], [800], [1000, 1000], [a, a])
     assert (int(qs[0]), int(qe[0])) == (201, 800)
+
+
+def test_library_merge_host_code_through_the_twins(tmp_path):
+    """deredundant_for_LTR_v5's HOST code (hits -> stretch -> chains -> clusters -> sub-clusters -> consensus -> cd-hit stand-in)
+    driven with every device stage answered by its CPU twin (tests/oracle_ctx.py) -- the second leg of the C5 parity test
+    (tests/test_gpu_scale.py), checked here where there is no GPU: planted families collapse, singletons pass"""
+    from hite_amd import util
+    from oracle_ctx import OracleCtx
+
+    rng = np.random.default_rng(515)
+    recs, fams = [], []
+    for f in range(6):
+        cons = casegen.rand_seq(rng, int(rng.integers(400, 1500)))
+        fams.append(cons)
+        for g in range(int(rng.integers(3, 7))):
+            recs.append(("G%d-fam%d#DNA/hAT" % (g, f), casegen.mutate(rng, cons, float(rng.uniform(0.01, 0.04)))))
+    for k in range(5):
+        recs.append(("single%d#Unknown" % k, casegen.rand_seq(rng, int(rng.integers(300, 900)))))
+    merged = str(tmp_path / "m.fa")
+    util.store_fasta(dict(recs), merged)
+    st = {}
+    out = util.deredundant_for_LTR_v5(merged, str(tmp_path), 1, "terminal", 0.95, 0, ctx=OracleCtx(), stages=st)
+    assert out == merged + ".tmp.cons" and st["hits"] > 50
+    assert sum(len(c) > 1 for c in st["clusters"]) == 6           # (a member the greedy clustering leaves out falls to the cd-hit stand-in)
+    names, seqs = util.read_fasta(merged + ".cons")
+    assert sum(n.startswith("single") for n in names) == 5 and len(names) == 11
+    for f, cons in enumerate(fams):
+        mine = [n for n in names if "-fam%d#" % f in n]
+        assert len(mine) == 1 and abs(len(seqs[mine[0]]) - len(cons)) <= 0.02 * len(cons)
