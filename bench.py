@@ -108,7 +108,7 @@ def main():
                     help="cpu_baseline: also time the CPU twin of the copy finder on the whole genome (default up to 1 Gbp, where its index takes about a minute and a half)")
     ap.add_argument("--copies", choices=["found", "truth"], default="found",
                     help="found: copy finding (minimizer index lookup) runs inside the timed step; truth: the generator's copy table is the input")
-    ap.add_argument("--verify", type=int, default=24, help="candidates re-judged with the CPU oracle chain after the timed region (0 = none)")
+    ap.add_argument("--verify", type=int, default=512, help="candidates re-judged with the CPU oracle chain after the timed region (0 = none)")
     ap.add_argument("--no-coarse", action="store_true", help="skip the coarse-stage block of the default line")
     ap.add_argument("--stage", choices=["fine", "coarse"], default="fine",
                     help="fine (default): BASELINE.json's metric; coarse: the companion line of stage 3.1 (all-vs-all seeding + FMEA)")
@@ -389,7 +389,7 @@ def main():
             # north_star's >= 20x target is phrased on the coarse_boundary step: measured here, after the headline's timed region, on
             # the same resident genome (stage 3.1: index + all-vs-all seeding + FMEA over the whole genome as one chunk)
             try:
-                out["coarse"] = coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, not args.no_cpu_baseline)
+                out["coarse"] = coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, not args.no_cpu_baseline, w=dict(w, **L))
             except Exception as e:
                 out["coarse"] = {"error": "%s: %s" % (type(e).__name__, e)}
         wv = None
@@ -574,50 +574,173 @@ def cpu_baseline(wv, budget_s, threads=0, with_copies=False):
     return outd
 
 
+def _prev_te_library(w, seed, n_prev):
+    """a TE library "found in the chunks before" (what --prev_TE holds from chunk 2 on, main.py:496-505): the first copy of
+    n_prev random families, as planted in this genome"""
+    p = w["planted"]
+    g = w["genome"]
+    host = g.cpu().numpy() if hasattr(g, "cpu") else np.asarray(g)
+    co = np.asarray(w["contig_off"])
+    rng = np.random.default_rng(seed)
+    fams = np.unique(p["family"][p["full"]])
+    pick = set(int(f) for f in rng.permutation(fams)[:n_prev])
+    out, seen = [], set()
+    for i in np.flatnonzero(p["full"]):
+        f = int(p["family"][i])
+        if f in pick and f not in seen and 80 <= int(p["length"][i]) <= 30000:
+            seen.add(f)
+            a_ = int(co[int(p["contig"][i])] + p["start"][i])
+            s_ = host[a_:a_ + int(p["length"][i])].tobytes()
+            out.append(s_)
+    return out
+
+
 def _coarse_cpu_worker(job):
+    """CPU leg of stage 3.1 end to end on one sub-genome: the twins of every stage of the GPU step, in its order"""
     seed, mbp = job
     sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes as C
+
     import oracle_lib as O
     from hite_amd import synth
 
     w = synth.make_workload(genome_bp=mbp * 1_000_000, n_tir=max(1, int(2.5 * mbp)), n_ltr=int(2.5 * mbp), cands_per_family=1, seed=seed)
-    co = w["contig_off"]
-    contigs = [w["genome"][co[i]:co[i + 1]].tobytes() for i in range(len(co) - 1)]
+    co = np.asarray(w["contig_off"])
+    genome = np.asarray(w["genome"]).copy()
+    prev = _prev_te_library(w, seed, max(1, int(0.5 * mbp)))
+    t = {}
     t0 = time.perf_counter()
+    # filter_tandem_repeats (Util.py:4672): the twin of the tandem masker
+    L = O.lib()
+    L.orc_tr_mask.restype = C.c_int64
+    mask = np.zeros(len(genome), dtype=np.uint8)
+    L.orc_tr_mask(genome.ctypes.data_as(O.u8p), co.ctypes.data_as(O.i64p), len(co) - 1, 500, mask.ctypes.data_as(O.u8p))
+    genome[mask != 0] = ord("N")
+    t["tandem"] = time.perf_counter() - t0
+    # mask_genome_intactTE (Util.py:6389): copies of the TEs found so far -> N
+    t1 = time.perf_counter()
+    contigs = [genome[co[i]:co[i + 1]].tobytes() for i in range(len(co) - 1)]
+    tab = O.find_copies(contigs, prev)
+    for q, copies in zip(prev, tab):
+        for (c, s1, e1, _m, _a) in copies:
+            if e1 - s1 + 1 >= 0.95 * len(q):
+                genome[co[c] + max(0, s1 - 1):co[c] + e1] = ord("N")
+    t["prev_te"] = time.perf_counter() - t1
+    # process_blast_alignments + get_longest_repeats_v4 (Util.py:4724, 4122)
+    t2 = time.perf_counter()
+    contigs = [genome[co[i]:co[i + 1]].tobytes() for i in range(len(co) - 1)]
     h = O.seed_allvsall(contigs, seg_len=1_000_000)
     h["chrom_names"] = ["c%d" % i for i in range(len(contigs))]
     names = O.fmea(h, 4000, 30000)
-    return time.perf_counter() - t0, len(h["qseg"]), len(names)
+    t["search_fmea"] = time.perf_counter() - t2
+    # generate_final_result + flanking_seq (Util.py:4783, 4614): the sequences of the intervals with 50 flanking bases
+    t3 = time.perf_counter()
+    raw = np.asarray(w["genome"])
+    nbytes = 0
+    for nm in names:
+        c, pos = nm.split(":")
+        a_, b_ = (int(x) for x in pos.split("-"))
+        ci = int(c[1:])
+        clen = int(co[ci + 1] - co[ci])
+        s1, e1 = a_ + 1, b_
+        if s1 - 1 - 50 < 0:
+            s1 = 51
+        if e1 + 50 > clen:
+            e1 = clen - 50
+        nbytes += len(raw[co[ci] + s1 - 1 - 50:co[ci] + e1 + 50].tobytes())
+    t["flank"] = time.perf_counter() - t3
+    return time.perf_counter() - t0, len(h["qseg"]), len(names), t, int(mask.sum())
 
 
-def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu):
-    """stage 3.1 on the resident genome of the headline workload: a step = minimizer index + hite_seed_allvsall + hite_fmea_chain
-    over the whole genome as one chunk.  CPU leg: the twins of the same stages on min(40, cores) workers, one 20 Mbp sub-genome
-    of the same family density each (the all-vs-all stage is super-linear in the genome, so the CPU's Mbp/s on 20 Mbp pieces
-    flatters it against the 1 Gbp step)."""
+def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
+    """stage 3.1 END TO END on the genome of the headline workload (coarse_boundary.py:14-32 -> determine_repeat_boundary_v5,
+    Util.py:4637-4670, + flanking_seq :4614), the whole genome as one chunk, everything device-resident.  A step =
+      pack the chunk (read_fasta's place)  ->  tandem repeats to N (filter_tandem_repeats :4672; hite_tr_mask)
+      ->  full-length copies of the TEs found so far to N (mask_genome_intactTE :6389; minimizer index + hite_find_copies + hite_genome_mask)
+      ->  minimizer index of the masked chunk + all-vs-all seeding + FMEA (process_blast_alignments :4724, get_longest_repeats_v4 :4122)
+      ->  the intervals with 50 flanking bases gathered from the packed genome (generate_final_result :4783, flanking_seq :4614).
+    `inner` keeps the number of the earlier rounds (index + seeding + FMEA alone).  CPU leg: the twins of the same stages in the
+    same order on min(40, cores) workers, one 20 Mbp sub-genome of the same family density each (the all-vs-all stage is
+    super-linear in the genome, so the CPU's Mbp/s on 20 Mbp pieces flatters it against the 1 Gbp step)."""
     sc, so = ctx.seed_segments(1_000_000)
+    prev = _prev_te_library(w, args.seed, max(1, int(0.5 * mbp))) if w is not None else []
+    genome_ptr, contig_off = (w["genome"].data_ptr(), w["contig_off"]) if w is not None else (None, None)
+    stage_ms = {}
 
-    def cstep():
+    def lap(name, t0):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        stage_ms[name] = stage_ms.get(name, 0.0) + 1000.0 * (t1 - t0)
+        return t1
+
+    def inner_step():
         ctx.copy_index_build()
-        (oc, _os, _oe), st = ctx.coarse_stage_dev(1_000_000, sc, so, 4000, 30000)
-        return st, len(oc)
+        (oc, os_, oe), st = ctx.coarse_stage_dev(1_000_000, sc, so, 4000, 30000)
+        return st, (oc, os_, oe)
 
+    def full_step():
+        t0 = time.perf_counter()
+        ctx.genome_pack_dev(genome_ptr, contig_off)
+        t0 = lap("pack", t0)
+        masked = ctx.tr_mask_dev(500)
+        t0 = lap("tandem_mask", t0)
+        n_masked_copies = 0
+        if prev:
+            ctx.release_copy_index()
+            tab = ctx.find_copies(prev)
+            cc, ss, ee = [], [], []
+            for q, copies in zip(prev, tab):
+                for (c, s1, e1, _m, _a) in copies:
+                    if e1 - s1 + 1 >= 0.95 * len(q):
+                        cc.append(c); ss.append(s1); ee.append(e1)
+            ctx.genome_mask(cc, ss, ee)
+            n_masked_copies = len(cc)
+        t0 = lap("prev_te_mask", t0)
+        ctx.release_copy_index()
+        st, (oc, os_, oe) = inner_step()
+        t0 = lap("index_search_fmea", t0)
+        nb = ctx.flanking_seq_dev(oc, os_, oe, 50)
+        t0 = lap("flank_gather", t0)
+        return st, len(oc), masked, n_masked_copies, nb
+
+    # ---- inner number (as in rounds 2 and 3) --------------------------------------------------------------------------------
     for _ in range(2):
-        cstep()
+        inner_step()
     torch.cuda.synchronize()
     steps = max(1, min(3, args.steps))
     t1 = time.perf_counter()
     for _ in range(steps):
-        st, n_iv = cstep()
+        st, iv = inner_step()
+    torch.cuda.synchronize()
+    ms_inner = 1000.0 * (time.perf_counter() - t1) / steps
+    alg = 12.0 * st[0] * 9 + 24.0 * st[1] * 5 + 48.0 * st[3] * 5
+    inner = {"metric": "index + all-vs-all seeding + FMEA alone (the coarse number of rounds 2 and 3)", "ms_per_step": round(ms_inner, 3),
+             "value": round(mbp / (ms_inner * 1e-3), 1), "unit": "Mbp/s", "seeds": st[0], "anchors": st[1], "clusters": st[2], "hsp_records": st[3],
+             "repeat_intervals": len(iv[0]),
+             "roofline": {"bound": "hbm", "achieved": round(alg / (ms_inner * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                          "frac": round(alg / (ms_inner * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                          "note": "algorithmic bytes = radix passes x 2 x record size over seeds / anchors / HSP records (whole step, not one kernel)"}}
+    if w is None:
+        return dict(inner, inner=None)
+    # ---- end to end -----------------------------------------------------------------------------------------------------
+    full_step()
+    stage_ms.clear()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        st, n_iv, masked, n_mc, nb = full_step()
     torch.cuda.synchronize()
     ms = 1000.0 * (time.perf_counter() - t1) / steps
-    alg = 12.0 * st[0] * 9 + 24.0 * st[1] * 5 + 48.0 * st[3] * 5
-    blk = {"metric": "coarse_boundary step (stage 3.1: index + all-vs-all seeding + FMEA), whole genome as one chunk", "ms_per_step": round(ms, 3),
-           "value": round(mbp / (ms * 1e-3), 1), "unit": "Mbp/s", "steps": steps,
-           "seeds": st[0], "anchors": st[1], "clusters": st[2], "hsp_records": st[3], "repeat_intervals": n_iv,
-           "roofline": {"bound": "hbm", "achieved": round(alg / (ms * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(alg / (ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
-                        "note": "algorithmic bytes = radix passes x 2 x record size over seeds / anchors / HSP records (whole step, not one kernel)"}}
+    blk = {"metric": "coarse_boundary step END TO END (stage 3.1: pack + tandem masking + prev_TE masking + index + all-vs-all seeding + FMEA + "
+                     "flanked sequences), whole genome as one chunk",
+           "ms_per_step": round(ms, 3), "value": round(mbp / (ms * 1e-3), 1), "unit": "Mbp/s", "steps": steps,
+           "stages_ms": {k: round(v / steps, 3) for k, v in stage_ms.items()},
+           "tandem_masked_bases": int(masked), "prev_te_sequences": len(prev), "prev_te_copies_masked": int(n_mc),
+           "hsp_records": st[3], "repeat_intervals": n_iv, "flanked_bytes": int(nb), "inner": inner}
+    # leave the context as the headline left it: the unmasked genome and its index
+    ctx.genome_pack_dev(genome_ptr, contig_off)
+    ctx.release_copy_index()
+    ctx.copy_index_build()
     if with_cpu:
         import multiprocessing as mp
         threads = int(args.cpu_threads) if args.cpu_threads and args.cpu_threads > 0 else min(40, os.cpu_count() or 1)
@@ -630,9 +753,12 @@ def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu):
                 res = pool.map(_coarse_cpu_worker, [(args.seed + 31 * k, sub) for k in range(threads)])
         wall = time.perf_counter() - t0
         busy = max(r[0] for r in res)
+        slow = max(res, key=lambda r: r[0])
         cpu = {"value": round(threads * sub / busy, 2), "unit": "Mbp/s", "cores": threads, "kind": "port",
+               "stages_s_slowest_worker": {k: round(v, 2) for k, v in slow[3].items()},
                "sample": "%d workers x one %d Mbp sub-genome each, same family density (slowest worker %.1f s, %.1f s wall incl. start-up and generation): "
-                         "%d HSP records -> %d intervals in all; CPU twins of the same stages (orc_seed_allvsall + orc_fmea)"
+                         "%d HSP records -> %d intervals in all; CPU twins of the same stages in the same order (orc_tr_mask, orc_find_copies + "
+                         "masking, orc_seed_allvsall + orc_fmea, flank slices)"
                          % (threads, sub, busy, wall, sum(r[1] for r in res), sum(r[2] for r in res))}
         blk["cpu_baseline"] = cpu
         blk["speedup_vs_cpu_baseline"] = round(blk["value"] / cpu["value"], 1) if cpu["value"] else None
@@ -690,8 +816,11 @@ def c5_mode(args):
         pool = d_cons.cpu().numpy()
         return [pool[c["cons_off"]:c["cons_off"] + c["cons_len"]].tobytes() for c in calls if c["is_te"]]
 
+    state = {"found": None, "n_copies": 0}
+
     def step(gather):
         nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n_cand, d_cand.data_ptr(), d_off.data_ptr(), nbytes, sp)
+        state["found"], state["n_copies"] = (nc, p_cf, p_ct, p_s1, p_e1, p_mn), nc
         ctx.flank_region_align_dev("tir", 1, n_cand, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
                                    d_calls.data_ptr(), d_cons.data_ptr(), cap, sp)
         stream.synchronize()
@@ -731,11 +860,40 @@ def c5_mode(args):
         with open(merged, "w") as f:
             for i, (sq, r) in enumerate(zip(seqs, ranks)):
                 f.write(">G%d-TE_%d#Unknown\n%s\n" % (int(r), i, sq.decode()))
+        # host view of the step's candidates, copy table and calls for the CPU leg / the spot checks: taken NOW, the merge below
+        # re-packs the context with the library and drops the copy index the table lives in
+        calls = d_calls.cpu().numpy().view(CALL_DTYPE)[:n_cand].copy()
+        cons_host = d_cons.cpu().numpy()
+        wv = None
+        if (world == 1 and not args.no_cpu_baseline) or args.verify > 0:
+            wv = host_workload(w, ctx, state, 0, n_cand)
         t2 = time.perf_counter()
         util._CTX = ctx
-        out_path = util.deredundant_for_LTR_v5(merged, tmp, 1, "terminal", 0.95, 0)
+        stages = {}
+        out_path = util.deredundant_for_LTR_v5(merged, tmp, 1, "terminal", 0.95, 0, ctx=ctx, stages=stages)
         merge_s = time.perf_counter() - t2
         n_out = len(util.read_fasta(out_path)[0])
+        n_final = len(util.read_fasta(merged + ".cons")[0])
+        # ---- outside the timed region: the same-host CPU leg and the parity spot checks of THIS run --------------------------
+        cpu, ver = None, None
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cpu = cpu_baseline(wv, args.cpu_seconds, args.cpu_threads, True)
+                cpu["merge"] = c5_merge_cpu(merged, tmp, util)
+            except Exception as e:   # the GPU line must not depend on the CPU leg
+                cpu = {"value": None, "unit": "candidates/s", "cores": args.cpu_threads, "kind": "port", "sample": "failed: %s: %s" % (type(e).__name__, e)}
+        if args.verify > 0:
+            ver = verify(wv, calls, cons_host, args.verify)
+            ct = (cpu or {}).pop("copy_tables", None)
+            if ct is not None:
+                ver["copy_tables"] = ct
+            try:
+                ver["merge"] = c5_merge_verify(merged, tmp, util, ctx, stages, (cpu or {}).get("merge"))
+            except Exception as e:
+                ver["merge"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if cpu and "merge" in cpu:
+            cpu["merge"].pop("_clusters", None)
+            cpu["merge"].pop("_files", None)
         import shutil as _sh
         _sh.rmtree(tmp, ignore_errors=True)
         ms = 1000.0 * elapsed / max(1, args.steps)
@@ -747,13 +905,58 @@ def c5_mode(args):
             "config": {"workload": "C5: %d x %d Mbp genomes (one per GPU), %d TIR + %d LTR families drawn from a shared pool (70 %% per genome), "
                                    "%d candidates/GPU judged as TIR; step = copy finding + fine stage + all-gather of the per-genome libraries"
                                    % (world, mbp, n_tir, n_ltr, n_cand),
-                       "library_sequences_in": len(seqs), "library_sequences_out": n_out, "merge_seconds": round(merge_s, 2),
+                       "library_sequences_in": len(seqs), "library_sequences_out": n_out, "library_sequences_final": n_final,
+                       "library_clusters": len(stages.get("clusters", [])), "library_hits": stages.get("hits"), "merge_seconds": round(merge_s, 2),
                        "merge": "deredundant_for_LTR_v5 on rank 0 (library-vs-library seeding, chaining, clustering, star alignments, consensus)",
                        "parallelism": "replicas (one genome per GPU), all-gather of padded consensus pools"},
-            "roofline": None, "cpu_baseline": None}))
+            "roofline": None, "cpu_baseline": cpu, "verify": ver}))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def c5_merge_cpu(merged, tmp, util):
+    """CPU leg of the library merge: the same host code (hite_amd/util.py deredundant_for_LTR_v5) with every device stage
+    answered by its CPU twin (tests/oracle_ctx.py), on the WHOLE merged library, single thread, timed"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_ctx import OracleCtx
+
+    twin = os.path.join(tmp, "twin_merged.fa")
+    import shutil as _sh
+    _sh.copyfile(merged, twin)
+    st = {}
+    t0 = time.perf_counter()
+    util.deredundant_for_LTR_v5(twin, tmp, 1, "terminal", 0.95, 0, ctx=OracleCtx(), stages=st)
+    dt = time.perf_counter() - t0
+    return {"seconds": round(dt, 2), "cores": 1, "kind": "port", "clusters": len(st.get("clusters", [])),
+            "sample": "the whole merged library through deredundant_for_LTR_v5 with the CPU twins of every device stage", "_clusters": st.get("clusters"),
+            "_files": (open(twin + ".tmp.cons").read(), open(twin + ".cons").read())}
+
+
+def c5_merge_verify(merged, tmp, util, ctx, stages, cpu_merge):
+    """parity of the merge of THIS run: clusters and output files of the GPU run against the twin run (the CPU leg when it ran,
+    else a twin run on a sub-library of 150 clusters)"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle_ctx import OracleCtx
+
+    gpu_files = (open(merged + ".tmp.cons").read(), open(merged + ".cons").read())
+    if cpu_merge and cpu_merge.get("_clusters") is not None:
+        files = cpu_merge.get("_files")
+        return {"scope": "whole library", "clusters_equal": cpu_merge["_clusters"] == stages.get("clusters"),
+                "files_equal": files == gpu_files, "against": "the same host code with the CPU twins of every device stage (tests/oracle_ctx.py)"}
+    names, seqs = util.read_fasta(merged)
+    clusters = stages.get("clusters", [])
+    rng = np.random.default_rng(11)
+    keep = set(n for i in rng.permutation(len(clusters))[:150] for n in clusters[i])
+    sub = {n: seqs[n] for n in names if n in keep}
+    outs = []
+    for tag, cx in (("gpu", ctx), ("cpu", OracleCtx())):
+        path = os.path.join(tmp, "sub_%s.fa" % tag)
+        util.store_fasta(sub, path)
+        util.deredundant_for_LTR_v5(path, tmp, 1, "terminal", 0.95, 0, ctx=cx)
+        outs.append((open(path + ".tmp.cons").read(), open(path + ".cons").read()))
+    return {"scope": "sub-library: the %d members of 150 random clusters" % len(sub), "files_equal": outs[0] == outs[1],
+            "against": "the same host code with the CPU twins of every device stage (tests/oracle_ctx.py)"}
 
 
 def coarse_stage(args):

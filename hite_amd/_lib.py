@@ -648,6 +648,40 @@ class Context:
         assert int(m.sum()) == n.value
         return m
 
+    def tr_mask_dev(self, max_period=500):
+        """tr_mask without the bit map on the host: the resident genome is masked in place -> number of masked bases"""
+        n = C.c_int64(0)
+        self._check(self.lib.hite_tr_mask(self.h, int(max_period), None, C.byref(n)), "hite_tr_mask")
+        return int(n.value)
+
+    def flanking_seq_dev(self, chrom, start0, end0, flank, contig_len=None):
+        """generate_final_result + flanking_seq (Util.py:4783, 4614) for intervals (contig id, 0-based start, end) of the resident
+        genome: the window of each interval with `flank` bases either side, clamped into the contig as the reference clamps it
+        -> total bytes gathered (hite_flank_gather: coordinates up, sequences down)"""
+        c = _arr(chrom, np.int32)
+        if len(c) == 0:
+            return 0
+        if contig_len is None:
+            contig_len = self.contig_len
+        clen = np.asarray(contig_len, dtype=np.int64)[c]
+        s1 = _arr(start0, np.int64) + 1
+        e1 = _arr(end0, np.int64).copy()
+        s1 = np.where(s1 - 1 - flank < 0, flank + 1, s1)
+        e1 = np.where(e1 + flank > clen, clen - flank, e1)
+        n = len(c)
+        ws, we, mn = np.ascontiguousarray(s1 - flank), np.ascontiguousarray(e1 + flank), np.zeros(n, dtype=np.uint8)
+        ln, tl = np.zeros(n, dtype=np.int64), np.zeros(n, dtype=np.int64)
+        self._check(self.lib.hite_flank_sizes(self.h, C.c_int64(n), _p(c), _p(ws), _p(we), 0, _p(ln), _p(tl)), "hite_flank_sizes")
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum((ln + 15) // 16 * 16, out=off[1:])
+        toff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum((tl + 15) // 16 * 16, out=toff[1:])
+        out = np.empty(int(off[-1]) + 16, dtype=np.uint8)
+        tout = np.empty(int(toff[-1]) + 16, dtype=np.uint8)
+        self._check(self.lib.hite_flank_gather(self.h, C.c_int64(n), _p(c), _p(ws), _p(we), _p(mn), 0, _p(off), _p(out), _p(toff), _p(tout)),
+                    "hite_flank_gather")
+        return int(ln.sum())
+
     def copy_stats_ext(self):
         """copy_stats() + (chains with a long end to extend, the other chains, DP columns of the end extension, 0)"""
         out = (C.c_int64 * 8)()
