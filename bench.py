@@ -458,9 +458,13 @@ def verify(wv, calls, cons, count):
     info_names = {0: "", 1: "nb", 2: "fl1", 3: "EXC"}
     picks = rng.permutation(n_cand)[:count]
     n_te = 0
+    anchors = {"none": 0, "exact": 0, "interior": 0, "end": 0}     # per judged pass of the sample (tests/oracle_pipeline.py anchor_class)
     for c in picks:
         cand, copies = _candidate(wv, c)
-        exp = OP.fine_stage_candidate("tir", cand, copies, contigs, plant=1)
+        msas = []
+        exp = OP.fine_stage_candidate("tir", cand, copies, contigs, plant=1, keep_msa=msas)
+        for m_ in msas:
+            anchors[OP.anchor_class(cand, m_)] += 1
         r = calls[c]
         got = [bool(r["is_te"]), info_names[int(r["info"])],
                cons[r["cons_off"]:r["cons_off"] + r["cons_len"]].tobytes().decode() if r["is_te"] else "", int(r["row_num"])]
@@ -468,7 +472,10 @@ def verify(wv, calls, cons, count):
         if got != exp:
             bad.append(int(c))
     return {"checked": int(len(picks)), "mismatches": len(bad), "bad_candidates": bad[:10], "te_calls_in_sample": n_te,
-            "against": "oracle chain (tests/oracle_pipeline.py over oracle/*.c) on the copy table of the step"}
+            "against": "oracle chain (tests/oracle_pipeline.py over oracle/*.c) on the copy table of the step",
+            "anchor_matches": dict(anchors, note="judged alignments of the sample by how the two 20-base anchors match their first common row: "
+                                                 "'end' = an edit on the first / last base of a match, the only class where the real fuzzysearch "
+                                                 "package could choose another start / end than the definition the goldens use (oracle/stubs.py)")}
 
 
 # ---------------------------------------------------------------------------------------------

@@ -31,19 +31,54 @@ def select_rows(lens, names=None):
     return sorted(order)
 
 
-def judge_windows(te_type, cand, windows, plant, names=None):
+def judge_windows(te_type, cand, windows, plant, names=None, keep_msa=None):
     keep = select_rows([len(w) for w in windows], names)
     wins = [windows[i] for i in keep]
     m = O.star_msa(wins)
     if m is None:
         return ["EXC", 0], (-1, -1)
     kc = O.sparse_cols(m).astype(bool)
-    res, b = O.judge(te_type, np.ascontiguousarray(m[:, kc]), cand, plant)
+    clean = np.ascontiguousarray(m[:, kc])
+    if keep_msa is not None:
+        keep_msa.append(clean)
+    res, b = O.judge(te_type, clean, cand, plant)
     return res, b
 
 
-def fine_stage_candidate(te_type, cand, copies, contigs, plant=1, flank=50, contig_names=None):
-    """copies: (contig_index, start1, end1, minus) -> [is_TE, info, cons, row_num]"""
+def anchor_class(cand, msa):
+    """How the two 20-base anchors of judge_boundary_v5 / v9 (Util.py:9158-9181) sit in the first row that carries both:
+    'none' (no row has both), 'exact' (both found without an edit), 'interior' (edits, but the first and the last base of each
+    match agree with the pattern), 'end' (an edit on the first or last base of a match: the class where the real
+    fuzzysearch package may report another start / end than the definition in oracle/stubs.py -- SURVEY.md 8c)."""
+    import ctypes as C
+
+    cb = cand.encode() if isinstance(cand, str) else bytes(cand)
+    p1, p2 = cb[:20], cb[-20:]
+    L = O.lib()
+    out = (C.c_int * 4)()
+    for r in range(msa.shape[0]):
+        ung = msa[r][msa[r] != 45].tobytes()
+        t = np.frombuffer(ung, dtype=np.uint8)
+        g1 = L.orc_find_near_matches(O._ptr(O._u8(p1), O.u8p), len(p1), O._ptr(t, O.u8p), len(ung), 2, out)
+        a = (out[0], out[1])
+        if g1 <= 0:
+            continue
+        g2 = L.orc_find_near_matches(O._ptr(O._u8(p2), O.u8p), len(p2), O._ptr(t, O.u8p), len(ung), 2, out)
+        b = (out[2], out[3])
+        if g2 <= 0:
+            continue
+        ma, mb = ung[a[0]:a[1]], ung[b[0]:b[1]]
+        if ma == p1 and mb == p2:
+            return "exact"
+        if ma[:1] != p1[:1] or ma[-1:] != p1[-1:] or mb[:1] != p2[:1] or mb[-1:] != p2[-1:]:
+            return "end"
+        return "interior"
+    return "none"
+
+
+def fine_stage_candidate(te_type, cand, copies, contigs, plant=1, flank=50, contig_names=None, keep_msa=None):
+    """copies: (contig_index, start1, end1, minus) -> [is_TE, info, cons, row_num]; keep_msa: a list that receives the cleaned
+    alignment of every pass that was judged"""
     full, trunc, fn, tn = [], [], [], []
     for cp in copies:
         (ci, s, e, mn) = cp[:4]
@@ -58,10 +93,10 @@ def fine_stage_candidate(te_type, cand, copies, contigs, plant=1, flank=50, cont
     if not full:
         return [False, "", "", 0]
     if trunc:
-        res, _ = judge_windows(te_type, cand, trunc, plant, tn)
+        res, _ = judge_windows(te_type, cand, trunc, plant, tn, keep_msa)
         if res[0] == "EXC" or not res[0]:
             return res if res[0] != "EXC" else [False, "EXC", "", 0]
-    res, _ = judge_windows(te_type, cand, full, plant, fn)
+    res, _ = judge_windows(te_type, cand, full, plant, fn, keep_msa)
     if res[0] == "EXC":
         return [False, "EXC", "", 0]
     return res
