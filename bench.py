@@ -385,6 +385,11 @@ def main():
             buf = (ctypes.c_ulonglong * 16)()
             ctx.lib.hite_debug_judge_clocks(buf, 1)
             out["judge_phase_ticks"] = [int(x) for x in buf[:12]]
+        # the host view of the step (candidates, the copy table the GPU used, its calls) is taken BEFORE the coarse block: that one
+        # re-packs the genome and rebuilds the index the copy table lives in
+        wv = None
+        if (world == 1 and not args.no_cpu_baseline) or args.verify > 0:
+            wv = host_workload(dict(w, **L), ctx, state if args.copies == "found" else None, c0, c1)
         if world == 1 and not args.no_coarse:
             # north_star's >= 20x target is phrased on the coarse_boundary step: measured here, after the headline's timed region, on
             # the same resident genome (stage 3.1: index + all-vs-all seeding + FMEA over the whole genome as one chunk)
@@ -392,9 +397,6 @@ def main():
                 out["coarse"] = coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, not args.no_cpu_baseline, w=dict(w, **L))
             except Exception as e:
                 out["coarse"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        wv = None
-        if (world == 1 and not args.no_cpu_baseline) or args.verify > 0:
-            wv = host_workload(dict(w, **L), ctx, state if args.copies == "found" else None, c0, c1)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(wv, args.cpu_seconds, args.cpu_threads, args.cpu_copies or mbp <= 1000)
@@ -693,7 +695,7 @@ def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
         t0 = lap("tandem_mask", t0)
         n_masked_copies = 0
         if prev:
-            ctx.release_copy_index()
+            ctx.copy_index_build()          # the index of the tandem-masked chunk (rebuilt on the same handle: its arenas stay)
             tab = ctx.find_copies(prev)
             cc, ss, ee = [], [], []
             for q, copies in zip(prev, tab):
@@ -703,8 +705,7 @@ def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
             ctx.genome_mask(cc, ss, ee)
             n_masked_copies = len(cc)
         t0 = lap("prev_te_mask", t0)
-        ctx.release_copy_index()
-        st, (oc, os_, oe) = inner_step()
+        st, (oc, os_, oe) = inner_step()    # (builds the index of the masked chunk first)
         t0 = lap("index_search_fmea", t0)
         nb = ctx.flanking_seq_dev(oc, os_, oe, 50)
         t0 = lap("flank_gather", t0)
@@ -746,7 +747,6 @@ def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
            "hsp_records": st[3], "repeat_intervals": n_iv, "flanked_bytes": int(nb), "inner": inner}
     # leave the context as the headline left it: the unmasked genome and its index
     ctx.genome_pack_dev(genome_ptr, contig_off)
-    ctx.release_copy_index()
     ctx.copy_index_build()
     if with_cpu:
         import multiprocessing as mp

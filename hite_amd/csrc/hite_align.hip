@@ -511,24 +511,44 @@ __global__ void __launch_bounds__(64) align_fwd8_pair_kernel(AlignArgs P, const 
 // ---------------------------------------------------------------------------------------------
 // traceback pass: re-compute the slice strip by strip (registers), walk it backwards
 // ---------------------------------------------------------------------------------------------
-// ops leave the traceback in descending positions, one at a time and per lane: a lane collects four of them in a 64-bit
-// shift register and stores 8 bytes at a time (2-byte stores from 64 lanes to 64 different lines were the kernel's bound).
-// Every group of four positions 4 k .. 4 k + 3 is complete when position 4 k arrives, except the topmost one when m is not a
-// multiple of 4: that one is kept aside and written entry by entry at the end, so that the walk carries no partial-store code.
+// ops leave the traceback in descending positions, one at a time and per lane, every lane into its own row: 64 different
+// cache lines per wavefront.  Round 3 stored 8 bytes per four positions straight to the row: a line then sees 16 partial
+// stores spread over 64 traceback steps, and with ~130 000 such lines open across the machine they leave L2 before they are
+// complete -- WRITE_SIZE 12.6 GB per launch for 3.3 GB of ops (profiles/r03_pmc_hbm.txt).  Now a lane stages the ops of one
+// 128-byte line of its row (64 positions) in LDS and writes the line in one burst of eight 16-byte stores when the walk
+// crosses the line's lower edge; the partial lines at the two ends of a row are written entry by entry.
+#define TB_LINE 64           // positions (u16) per 128-byte line
+#define TB_STRIDE 72         // u16 per lane in LDS (144 B: 16-byte aligned, lanes spread over the banks)
+typedef unsigned int tb_u32x4 __attribute__((ext_vector_type(4)));
 struct OpsOut {
-    uint16_t *ops;
-    unsigned long long acc, top;
-    int m;
+    uint16_t *ops;           // the lane's row
+    uint16_t *lds;           // the lane's TB_STRIDE entries
+    int m, off;              // off: (address of ops[0] / 2) mod 64 -- slot of position p = (p + off) & 63; slot 0 starts a line
+    int low;                 // lowest position written to the row so far
+    __device__ __forceinline__ void init(uint16_t *row, uint16_t *stage, int m_) {
+        ops = row; lds = stage; m = m_; low = m_;
+        off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & (TB_LINE - 1));
+    }
     __device__ __forceinline__ void push(int pos, uint32_t val) {
-        acc = (acc << 16) | (unsigned long long)(val & 0xffffu);
-        if ((pos & 3) == 0) {
-            if (pos + 4 <= m) *reinterpret_cast<unsigned long long *>(ops + pos) = acc;     // (unaligned 8-byte store: fine for global memory)
-            else top = acc;
+        const int slot = (pos + off) & (TB_LINE - 1);
+        lds[slot] = (uint16_t)val;
+        if (slot == 0) {
+            if (pos + TB_LINE <= m) {        // a whole line [pos, pos + 64) lies in the row and has been pushed
+                const tb_u32x4 *src = reinterpret_cast<const tb_u32x4 *>(lds);
+                tb_u32x4 *dst = reinterpret_cast<tb_u32x4 *>(ops + pos);     // 128-byte aligned by the choice of off
+                tb_u32x4 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; q++) v[q] = src[q];
+#pragma unroll
+                for (int q = 0; q < 8; q++) dst[q] = v[q];
+            } else {
+                for (int x = pos; x < m; x++) ops[x] = lds[(x + off) & (TB_LINE - 1)];   // the topmost, partial line
+            }
+            low = pos;
         }
     }
-    __device__ __forceinline__ void finish() {   // after position 0 has been pushed
-        const int k = m & 3, p0 = m & ~3;
-        for (int x = 0; x < k; x++) ops[p0 + x] = (uint16_t)(top >> (16 * x));
+    __device__ __forceinline__ void finish() {   // after position 0 has been pushed: the partial line at the start of the row
+        for (int x = 0; x < low; x++) ops[x] = lds[(x + off) & (TB_LINE - 1)];
     }
 };
 
@@ -548,8 +568,9 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     uint16_t *ops = P.ops + (g >= 0 ? P.ops_base[c] + (int64_t)(g - g0) * (m + 1) : 0);
     int i = m, j = n;
     bool fail = false;
+    __shared__ __attribute__((aligned(16))) uint16_t s_stage[64 * TB_STRIDE];
     OpsOut out;
-    out.ops = ops; out.acc = 0ull; out.top = 0ull; out.m = m;
+    out.init(ops, s_stage + threadIdx.x * TB_STRIDE, m);
     const int Kmax = (nmax + AL_STRIP - 1) / AL_STRIP;
     // software pipeline over the strips (last to first): the check point of strip k-2, the boundary record and the row bases of
     // strip k-1 and -- with the position the check point of strip k-1 gives -- its centre planes are fetched while strip k is

@@ -31,8 +31,10 @@ def test_coarse_cpu_worker_runs():
     """the CPU leg of the coarse block of the default bench line: the twins of stage 3.1 on one small sub-genome"""
     import bench
 
-    dt, n_hsp, n_iv = bench._coarse_cpu_worker((5, 2))
+    dt, n_hsp, n_iv, stages, n_masked = bench._coarse_cpu_worker((5, 2))
     assert dt > 0 and n_hsp > 0 and n_iv > 0
+    # stage 3.1 end to end: tandem masking, prev_TE masking, search + FMEA, flanked sequences -- every leg ran
+    assert set(stages) == {"tandem", "prev_te", "search_fmea", "flank"} and all(v > 0 for v in stages.values()) and n_masked >= 0
 
 
 def test_bench_shards_like_the_library():
