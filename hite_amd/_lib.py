@@ -448,6 +448,24 @@ class Context:
         return [[(int(osid[i]), int(os_[i]), int(oe[i]), int(ol[i]), "-" if om[i] else "+") for i in range(cf[q], cf[q + 1])]
                 for q in range(nq)]
 
+    def chain_all(self, qid, sid, qs, qe, ss, se, nq, ns, qgap):
+        """every chain of every cluster (hite_chain_all: the core of FMEA / get_full_length_copies_from_blastn_v1) ->
+        per query list of (subject id, q_start, q_end, s_start, s_end, extend_num) in the reference's order"""
+        n = len(qid)
+        qid, sid = _arr(qid, np.int32), _arr(sid, np.int32)
+        qs, qe, ss, se = _arr(qs, np.int64), _arr(qe, np.int64), _arr(ss, np.int64), _arr(se, np.int64)
+        gap = _arr(qgap, np.int64)
+        cap = n + 16
+        cf = np.zeros(nq + 1, dtype=np.int64)
+        osid, onext = np.zeros(cap, dtype=np.int32), np.zeros(cap, dtype=np.int32)
+        oqs, oqe, oss, ose = (np.zeros(cap, dtype=np.int64) for _ in range(4))
+        tot = C.c_int64(0)
+        self._check(self.lib.hite_chain_all(self.h, C.c_int64(n), _p(qid), _p(sid), _p(qs), _p(qe), _p(ss), _p(se), int(nq), int(ns), _p(gap),
+                                            C.c_int64(cap), _p(cf), _p(osid), _p(oqs), _p(oqe), _p(oss), _p(ose), _p(onext), C.byref(tot)),
+                    "hite_chain_all")
+        return [[(int(osid[i]), int(oqs[i]), int(oqe[i]), int(oss[i]), int(ose[i]), int(onext[i])) for i in range(cf[q], cf[q + 1])]
+                for q in range(nq)]
+
     def lib_chain(self, qid, sid, qs, qe, ss, se, seq_len, threshold, chunk_size=0):
         """library-vs-itself HSP table -> chain records [chunk, q, qs-1, qe, s, ss-1, se] in the reference's chunk-file order"""
         n = len(qid)

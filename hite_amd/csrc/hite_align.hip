@@ -512,43 +512,64 @@ __global__ void __launch_bounds__(64) align_fwd8_pair_kernel(AlignArgs P, const 
 // traceback pass: re-compute the slice strip by strip (registers), walk it backwards
 // ---------------------------------------------------------------------------------------------
 // ops leave the traceback in descending positions, one at a time and per lane, every lane into its own row: 64 different
-// cache lines per wavefront.  Round 3 stored 8 bytes per four positions straight to the row: a line then sees 16 partial
-// stores spread over 64 traceback steps, and with ~130 000 such lines open across the machine they leave L2 before they are
-// complete -- WRITE_SIZE 12.6 GB per launch for 3.3 GB of ops (profiles/r03_pmc_hbm.txt).  Now a lane stages the ops of one
-// 128-byte line of its row (64 positions) in LDS and writes the line in one burst of eight 16-byte stores when the walk
-// crosses the line's lower edge; the partial lines at the two ends of a row are written entry by entry.
-#define TB_LINE 64           // positions (u16) per 128-byte line
-#define TB_STRIDE 72         // u16 per lane in LDS (144 B: 16-byte aligned, lanes spread over the banks)
+// cache lines per wavefront.  Round 3 stored 8 bytes per four positions straight to the row: HBM is written in 32-byte
+// sectors, and with ~130 000 rows open across the machine the partly written sectors leave L2 one store at a time --
+// WRITE_SIZE 12.6 GB per launch for 3.3 GB of ops (profiles/r03_pmc_hbm.txt).  Now a lane parks its ops in a ring of 128
+// positions in LDS (a write the walk never waits for) and the wavefront drains the rings once per strip of 16 columns, all
+// lanes together: whole 32-byte sectors (16 positions, aligned in memory), two 16-byte stores each.  Measured (round 4):
+// WRITE_SIZE 3.3 GB per launch.  (A first form -- a ring of one 128-byte line per lane, written by the lane that crossed the
+// line's edge, inside the walk -- had the same traffic but ran the flush for one lane on most steps: 13.8 -> 17.4 ms.)
+#define TB_RING 128          // positions per lane (power of two, multiple of TB_SECT)
+#define TB_SECT 16           // positions per 32-byte sector
+#define TB_STRIDE (TB_RING + 16)    // u16 per lane in LDS (288 B: 32-byte aligned, lanes spread over the banks)
 typedef unsigned int tb_u32x4 __attribute__((ext_vector_type(4)));
 struct OpsOut {
     uint16_t *ops;           // the lane's row
-    uint16_t *lds;           // the lane's TB_STRIDE entries
-    int m, off;              // off: (address of ops[0] / 2) mod 64 -- slot of position p = (p + off) & 63; slot 0 starts a line
-    int low;                 // lowest position written to the row so far
-    __device__ __forceinline__ void init(uint16_t *row, uint16_t *stage, int m_) {
-        ops = row; lds = stage; m = m_; low = m_;
-        off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & (TB_LINE - 1));
+    uint16_t *lds;           // the lane's ring
+    int m, off;              // off: (address of ops[0] / 2) mod 16 -- ring slot of position p = (p + off) & 127; slot % 16 == 0 starts a sector
+    int low;                 // positions >= low are in the row already
+    int cur;                 // lowest position pushed so far: [cur, low) waits in the ring
+    __device__ __forceinline__ void init(uint16_t *row, uint16_t *ring, int m_) {
+        ops = row; lds = ring; m = m_; low = m_; cur = m_;
+        off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & (TB_SECT - 1));
     }
-    __device__ __forceinline__ void push(int pos, uint32_t val) {
-        const int slot = (pos + off) & (TB_LINE - 1);
-        lds[slot] = (uint16_t)val;
-        if (slot == 0) {
-            if (pos + TB_LINE <= m) {        // a whole line [pos, pos + 64) lies in the row and has been pushed
-                const tb_u32x4 *src = reinterpret_cast<const tb_u32x4 *>(lds);
-                tb_u32x4 *dst = reinterpret_cast<tb_u32x4 *>(ops + pos);     // 128-byte aligned by the choice of off
-                tb_u32x4 v[8];
-#pragma unroll
-                for (int q = 0; q < 8; q++) v[q] = src[q];
-#pragma unroll
-                for (int q = 0; q < 8; q++) dst[q] = v[q];
-            } else {
-                for (int x = pos; x < m; x++) ops[x] = lds[(x + off) & (TB_LINE - 1)];   // the topmost, partial line
+    // whole sectors of [cur, low) -> the row.  Wave-uniform loop: every lane calls it at the same place.
+    __device__ __forceinline__ void drain() {
+        if (low == m && cur < m) {           // the topmost, partial sector: entry by entry, once
+            const int g = m - ((m + off) & (TB_SECT - 1));      // the sector edge at or below m
+            if (g >= cur && g < m) { for (int x = g; x < m; x++) ops[x] = lds[(x + off) & (TB_RING - 1)]; low = g; }
+            else if (g == m) low = m;
+        }
+        while (__any(low - TB_SECT >= cur && ((low + off) & (TB_SECT - 1)) == 0)) {
+            if (low - TB_SECT >= cur && ((low + off) & (TB_SECT - 1)) == 0) {
+                const int g = low - TB_SECT;
+                const tb_u32x4 *src = reinterpret_cast<const tb_u32x4 *>(lds + ((g + off) & (TB_RING - 1)));
+                tb_u32x4 *dst = reinterpret_cast<tb_u32x4 *>(ops + g);          // 32-byte aligned by the choice of off
+                const tb_u32x4 v0 = src[0], v1 = src[1];
+                dst[0] = v0; dst[1] = v1;
+                low = g;
             }
-            low = pos;
         }
     }
-    __device__ __forceinline__ void finish() {   // after position 0 has been pushed: the partial line at the start of the row
-        for (int x = 0; x < low; x++) ops[x] = lds[(x + off) & (TB_LINE - 1)];
+    __device__ __forceinline__ void push(int pos, uint32_t val) {
+        lds[(pos + off) & (TB_RING - 1)] = (uint16_t)val;
+        cur = pos;
+        if (low - pos >= TB_RING - TB_SECT) {       // the ring is nearly full (a long run of gaps inside one strip): this lane alone
+            if (low == m) {
+                const int g = m - ((m + off) & (TB_SECT - 1));
+                if (g >= cur && g < m) { for (int x = g; x < m; x++) ops[x] = lds[(x + off) & (TB_RING - 1)]; low = g; }
+            }
+            while (low - TB_SECT >= cur && ((low + off) & (TB_SECT - 1)) == 0) {
+                const int g = low - TB_SECT;
+                for (int x = g; x < low; x++) ops[x] = lds[(x + off) & (TB_RING - 1)];
+                low = g;
+            }
+        }
+    }
+    __device__ __forceinline__ void finish() {   // after position 0 has been pushed: what is left below the last sector edge
+        drain();
+        for (int x = 0; x < low; x++) ops[x] = lds[(x + off) & (TB_RING - 1)];
+        low = 0;
     }
 };
 
@@ -568,7 +589,7 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     uint16_t *ops = P.ops + (g >= 0 ? P.ops_base[c] + (int64_t)(g - g0) * (m + 1) : 0);
     int i = m, j = n;
     bool fail = false;
-    __shared__ __attribute__((aligned(16))) uint16_t s_stage[64 * TB_STRIDE];
+    __shared__ __attribute__((aligned(32))) uint16_t s_stage[64 * TB_STRIDE];
     OpsOut out;
     out.init(ops, s_stage + threadIdx.x * TB_STRIDE, m);
     const int Kmax = (nmax + AL_STRIP - 1) / AL_STRIP;
@@ -696,17 +717,21 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
             }
             if ((cc & 3) == 0) tcur -= (int)(((sbits >> (2 * (cc >> 2))) & 3u) << 2);
         }
+        out.drain();
         }
         ckA0 = ckB0; ckA1 = ckB1; ckB0 = ckC0; ckB1 = ckC1; bdA0 = bdB0; bdA1 = bdB1;
 #pragma unroll
         for (int w = 0; w < 4; w++) plA[w] = plB[w];
     }
-    if (n > 0) {
-        if (fail) P.st[g] = 1;
-        else {
-            for (int q = i - 1; q >= 0; q--) out.push(q, 0x8000u);
-            out.finish();
-        }
+    const bool good = n > 0 && !fail;
+    if (n > 0 && fail) P.st[g] = 1;
+    // the rest of the row: gaps down to position 0, drained every 64 positions (a lane cannot hold more than its ring)
+    while (__any(good && i > 0)) {
+        if (good) for (int x = 0; x < 64 && i > 0; x++) { out.push(i - 1, 0x8000u); i--; }
+        out.drain();
+    }
+    if (good) {
+        for (int x = 0; x < out.low; x++) out.ops[x] = out.lds[(x + out.off) & (TB_RING - 1)];
     }
 }
 

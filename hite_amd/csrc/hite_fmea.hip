@@ -137,12 +137,15 @@ __global__ void fm_gather_key_kernel(int64_t m, const unsigned *__restrict__ val
 __global__ void __launch_bounds__(256) fm_cluster_kernel(int64_t nslots, const int64_t *__restrict__ slot_start,
                                                          const unsigned *__restrict__ order /* HSP idx, sorted */,
                                                          const int64_t *__restrict__ qe, const int64_t *__restrict__ ss,
-                                                         const int64_t *__restrict__ se, int64_t gap, int parity_rev,
-                                                         int32_t *__restrict__ clid, int32_t *__restrict__ ncl) {
+                                                         const int64_t *__restrict__ se, int64_t gap_all, int parity_rev,
+                                                         int32_t *__restrict__ clid, int32_t *__restrict__ ncl,
+                                                         const int64_t *__restrict__ qgap = nullptr /* per query (hite_chain_all) */,
+                                                         const int32_t *__restrict__ qid = nullptr) {
     const int lane = threadIdx.x & 63;
     for (int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); g < nslots; g += (int64_t)gridDim.x * 4) {
         const int64_t b = slot_start[g], e = slot_start[g + 1];
         if (e <= b) { if (lane == 0) ncl[g] = 0; continue; }
+        const int64_t gap = qgap ? qgap[qid[order[b]]] : gap_all;
         const bool rev = parity_rev ? (bool)(g & 1) : (ss[order[b]] > se[order[b]]);
         int cl = 0;
         int64_t cstart = b;
@@ -720,6 +723,73 @@ __global__ void qc_chain_kernel(int64_t ncl, const int64_t *__restrict__ cl_star
     atomicAdd(&qcount[r.qid], 1);
 }
 
+// hite_chain_all: one thread per cluster, EVERY chain (the core of FMEA Util.py:10527-10645 and of
+// get_full_length_copies_from_blastn_v1 :5990-6103; visited fragments are keyed by the 4-tuple there)
+struct ChainA { long long qs, qe, ss, se; int sid, qid, next, pad; };
+__global__ void ca_chain_kernel(int64_t ncl, const int64_t *__restrict__ cl_start, const unsigned *__restrict__ order,
+                                const int32_t *__restrict__ qid, const int32_t *__restrict__ sid, const int64_t *__restrict__ qs,
+                                const int64_t *__restrict__ qe, const int64_t *__restrict__ ss, const int64_t *__restrict__ se,
+                                const int64_t *__restrict__ qgap, uint8_t *__restrict__ vis, int32_t *__restrict__ canon,
+                                ChainA *__restrict__ chains, int32_t *__restrict__ is_chain, int32_t *__restrict__ qcount) {
+    int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncl) return;
+    const int64_t b = cl_start[c], e = cl_start[c + 1];
+    for (int64_t i = b; i < e; i++) {
+        vis[i] = 0; is_chain[i] = 0;
+        int32_t cn = (int32_t)(i - b);
+        unsigned hi = order[i];
+        for (int64_t j = i - 1; j >= b; j--) {
+            unsigned hj = order[j];
+            if (qs[hj] != qs[hi] || qe[hj] != qe[hi]) break;
+            if (ss[hj] == ss[hi] && se[hj] == se[hi]) cn = canon[j];
+        }
+        canon[i] = cn;
+    }
+    const unsigned h0 = order[b];
+    const int q0 = qid[h0];
+    const long long gap = qgap[q0];
+    int made = 0;
+    for (int64_t i = b; i < e; i++) {
+        if (vis[b + canon[i]]) continue;
+        unsigned hi = order[i];
+        long long pqs = qs[hi], pqe = qe[hi], pss = ss[hi], pse = se[hi];
+        int next = 0;
+        vis[b + canon[i]] = 1;
+        for (int64_t j = i + 1; j < e; j++) {
+            if (vis[b + canon[j]]) continue;
+            unsigned hj = order[j];
+            long long cqs = qs[hj], cqe = qe[hj], css = ss[hj], cse = se[hj];
+            if (cqe > pqe) {
+                if (pss < pse && css < cse) {
+                    if (cse > pse) {
+                        if (cqs - pqe < gap && css - pse < gap) { pqe = cqe; pss = pss < css ? pss : css; pse = cse; next++; vis[b + canon[j]] = 1; }
+                        else if (cqs - pqe >= gap) break;
+                    }
+                } else if (pss > pse && css > cse) {
+                    if (cse < pse) {
+                        if (cqs - pqe < gap && pse - css < gap) { pqe = cqe; pss = pss > css ? pss : css; pse = cse; next++; vis[b + canon[j]] = 1; }
+                        else if (cqs - pqe >= gap) break;
+                    }
+                }
+            }
+        }
+        ChainA ch; ch.qs = pqs; ch.qe = pqe; ch.ss = pss; ch.se = pse; ch.sid = sid[h0]; ch.qid = q0; ch.next = next; ch.pad = 0;
+        chains[i] = ch;
+        is_chain[i] = 1;
+        made++;
+    }
+    atomicAdd(&qcount[q0], made);
+}
+__global__ void ca_emit_kernel(int64_t m, const int32_t *__restrict__ flag, const int64_t *__restrict__ pos, const ChainA *__restrict__ in,
+                               int32_t *__restrict__ o_sid, int64_t *__restrict__ o_qs, int64_t *__restrict__ o_qe,
+                               int64_t *__restrict__ o_ss, int64_t *__restrict__ o_se, int32_t *__restrict__ o_next) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m || !flag[i]) return;
+    const int64_t o = pos[i];
+    const ChainA c = in[i];
+    o_sid[o] = c.sid; o_qs[o] = c.qs; o_qe[o] = c.qe; o_ss[o] = c.ss; o_se[o] = c.se; o_next[o] = c.next;
+}
+
 // step 7: one wavefront per query
 template <bool WRITE>
 __global__ void __launch_bounds__(256) qc_select_kernel(int nq, const int64_t *__restrict__ qstart, const unsigned *__restrict__ cidx,
@@ -771,11 +841,14 @@ __global__ void __launch_bounds__(256) qc_select_kernel(int nq, const int64_t *_
 #define QSORT(k, v, cnt, bits) do { if (sorter_sort(S, (unsigned long long *)(k), (unsigned *)(v), (cnt), (bits))) { sorter_free(S); return HITE_EHIP; } } while (0)
 #define QSCAN(in, cnt, out) do { if (scan_excl_buf<int32_t>(ctx, (int64_t *)dbs.p, (int32_t *)(in), (cnt), (int64_t *)(out), st)) { sorter_free(S); return HITE_EHIP; } } while (0)
 
-extern "C" int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe,
-                                 const int64_t *ss, const int64_t *se, const double *ident, int32_t nq, const int64_t *qlen, int32_t ns,
-                                 const int64_t *slen, double qcov, double scov, int64_t qthr, int64_t sthr, int32_t max_copy, int64_t cap,
-                                 int64_t *copy_first, int32_t *o_sid, int64_t *o_s, int64_t *o_e, int64_t *o_len, uint8_t *o_minus,
-                                 int64_t *n_out) {
+// all_chains != NULL: hite_chain_all -- steps 1-4 as below with the query's own gap (qlen then holds the gaps), then every
+// chain of every cluster instead of steps 5-7
+struct ChainAllOut { int32_t *o_sid; int64_t *o_qs, *o_qe, *o_ss, *o_se; int32_t *o_next; };
+static int query_copies_impl(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe,
+                             const int64_t *ss, const int64_t *se, const double *ident, int32_t nq, const int64_t *qlen, int32_t ns,
+                             const int64_t *slen, double qcov, double scov, int64_t qthr, int64_t sthr, int32_t max_copy, int64_t cap,
+                             int64_t *copy_first, int32_t *o_sid, int64_t *o_s, int64_t *o_e, int64_t *o_len, uint8_t *o_minus,
+                             int64_t *n_out, const ChainAllOut *all_chains) {
     if (!ctx || n < 0 || n >= 0x7fffffff || nq <= 0 || ns <= 0 || !qlen || !copy_first || !n_out || max_copy < 0 || max_copy > QC_MAXKEEP - 2 ||
         (scov > 0 && !slen) || (double)nq * (double)ns >= 1e12)
         return HITE_EINVAL;
@@ -830,7 +903,8 @@ extern "C" int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, c
     {
         int64_t blocks = (nslots + 3) / 4; if (blocks > 4096) blocks = 4096; if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(fm_cluster_kernel, dim3((unsigned)blocks), dim3(256), 0, st, nslots, (int64_t *)dslotstart.p, (unsigned *)dval.p,
-                           (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, sthr, 0, (int32_t *)dclid.p, (int32_t *)dncl.p);
+                           (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, sthr, 0, (int32_t *)dclid.p, (int32_t *)dncl.p,
+                           all_chains ? (const int64_t *)dql.p : (const int64_t *)nullptr, (const int32_t *)dq.p);
     }
     {   // the scan scratch must cover nslots too (nslots <= n)
         QSCAN(dncl.p, nslots, dclbase.p);
@@ -853,6 +927,35 @@ extern "C" int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, c
     QSORT(dtmpk.p, dp2.p, n, cl_bits);
     hipLaunchKernelGGL(fm_compose_kernel, GRID(n), 0, st, n, (unsigned *)dp2.p, (unsigned *)dval.p, (unsigned *)dorder2.p);
     QSCAN(dclcnt.p, ncl, dclstart.p);
+    if (all_chains) {
+        // 5': every chain of every cluster, in cluster order = (query, subject by first appearance, forward before reverse,
+        // cluster, chain start); per-query counts -> CSR
+        FBuf dch, disch, dchpos;
+        FCHK(dvis.alloc(n + 16)); FCHK(dcanon.alloc((n + 1) * 4)); FCHK(dch.alloc((n + 1) * sizeof(ChainA))); FCHK(disch.alloc((n + 1) * 4));
+        FCHK(dchpos.alloc((n + 2) * 8)); FCHK(dqcount.alloc(((size_t)nq + 1) * 4)); FCHK(dfirst.alloc(((size_t)nq + 2) * 8));
+        FCHK(hipMemset(dqcount.p, 0, ((size_t)nq + 1) * 4));
+        hipLaunchKernelGGL(ca_chain_kernel, GRID(ncl), 0, st, ncl, (int64_t *)dclstart.p, (unsigned *)dorder2.p, (int32_t *)dq.p, (int32_t *)dsg.p,
+                           (int64_t *)dqs.p, (int64_t *)dqe.p, (int64_t *)dss.p, (int64_t *)dse.p, (const int64_t *)dql.p, (uint8_t *)dvis.p,
+                           (int32_t *)dcanon.p, (ChainA *)dch.p, (int32_t *)disch.p, (int32_t *)dqcount.p);
+        QSCAN(disch.p, n, dchpos.p);
+        QSCAN(dqcount.p, (int64_t)nq, dfirst.p);
+        FCHK(hipMemcpy(copy_first, dfirst.p, ((size_t)nq + 1) * 8, hipMemcpyDeviceToHost));
+        const int64_t nch = copy_first[nq];
+        *n_out = nch;
+        if (nch > cap) { sorter_free(S); return HITE_ECAP; }
+        if (nch > 0) {
+            FBuf a1, a2, a3, a4, a5, a6;
+            FCHK(a1.alloc(nch * 4)); FCHK(a2.alloc(nch * 8)); FCHK(a3.alloc(nch * 8)); FCHK(a4.alloc(nch * 8)); FCHK(a5.alloc(nch * 8)); FCHK(a6.alloc(nch * 4));
+            hipLaunchKernelGGL(ca_emit_kernel, GRID(n), 0, st, n, (int32_t *)disch.p, (int64_t *)dchpos.p, (ChainA *)dch.p, (int32_t *)a1.p,
+                               (int64_t *)a2.p, (int64_t *)a3.p, (int64_t *)a4.p, (int64_t *)a5.p, (int32_t *)a6.p);
+            FCHK(hipGetLastError());
+            FCHK(hipMemcpy(all_chains->o_sid, a1.p, nch * 4, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(all_chains->o_qs, a2.p, nch * 8, hipMemcpyDeviceToHost));
+            FCHK(hipMemcpy(all_chains->o_qe, a3.p, nch * 8, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(all_chains->o_ss, a4.p, nch * 8, hipMemcpyDeviceToHost));
+            FCHK(hipMemcpy(all_chains->o_se, a5.p, nch * 8, hipMemcpyDeviceToHost)); FCHK(hipMemcpy(all_chains->o_next, a6.p, nch * 4, hipMemcpyDeviceToHost));
+        }
+        sorter_free(S);
+        return HITE_OK;
+    }
     // 5: best chain per cluster
     FCHK(dvis.alloc(n + 16)); FCHK(dcanon.alloc((n + 1) * 4)); FCHK(dbest.alloc((ncl + 1) * sizeof(QBest))); FCHK(dlkey.alloc((ncl + 1) * 8));
     FCHK(dlval.alloc((ncl + 1) * 4)); FCHK(dqcount.alloc(((size_t)nq + 1) * 4)); FCHK(dqstart.alloc(((size_t)nq + 2) * 8));
@@ -888,6 +991,27 @@ extern "C" int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, c
     }
     sorter_free(S);
     return HITE_OK;
+}
+
+extern "C" int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe,
+                                 const int64_t *ss, const int64_t *se, const double *ident, int32_t nq, const int64_t *qlen, int32_t ns,
+                                 const int64_t *slen, double qcov, double scov, int64_t qthr, int64_t sthr, int32_t max_copy, int64_t cap,
+                                 int64_t *copy_first, int32_t *o_sid, int64_t *o_s, int64_t *o_e, int64_t *o_len, uint8_t *o_minus,
+                                 int64_t *n_out) {
+    return query_copies_impl(ctx, n, qid, sid, qs, qe, ss, se, ident, nq, qlen, ns, slen, qcov, scov, qthr, sthr, max_copy, cap, copy_first, o_sid,
+                             o_s, o_e, o_len, o_minus, n_out, nullptr);
+}
+
+// every chain of every cluster (FMEA Util.py:10452, get_full_length_copies_from_blastn_v1 :5907): include/hite_gpu.h
+extern "C" int hite_chain_all(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe,
+                              const int64_t *ss, const int64_t *se, int32_t nq, int32_t ns, const int64_t *qgap, int64_t cap,
+                              int64_t *chain_first, int32_t *o_sid, int64_t *o_qs, int64_t *o_qe, int64_t *o_ss, int64_t *o_se,
+                              int32_t *o_next, int64_t *n_out) {
+    if (!qgap || !chain_first || !n_out || (cap > 0 && (!o_sid || !o_qs || !o_qe || !o_ss || !o_se || !o_next))) return HITE_EINVAL;
+    for (int32_t q = 0; q < nq; q++) if (qgap[q] < 0) return HITE_EINVAL;
+    ChainAllOut O{o_sid, o_qs, o_qe, o_ss, o_se, o_next};
+    return query_copies_impl(ctx, n, qid, sid, qs, qe, ss, se, nullptr, nq, qgap, ns, nullptr, 0.0, 0.0, 0, 0, 0, cap, chain_first, nullptr, nullptr,
+                             nullptr, nullptr, nullptr, n_out, &O);
 }
 
 // =============================================================================================

@@ -480,7 +480,7 @@ def get_candidate_non_LTR(longest_repeats_flanked_path, flanking_len=50, device=
 
 
 def get_query_copies(cur_segments, query_contigs, subject_path, query_coverage, subject_coverage, query_fixed_extend_base_threshold=200,
-                     subject_fixed_extend_base_threshold=200, max_copy_num=100, device=0):
+                     subject_fixed_extend_base_threshold=200, max_copy_num=100, device=0, ctx=None):
     """Util.py:6828 -- cur_segments = [(query_name, {subject_name: [(q_start, q_end, s_start, s_end, identity)]})] ->
     {query_name: [(subject_name, start, end, chain_len, '+'/'-')]}.  One device call for all queries."""
     subject_contigs = read_fasta(subject_path)[1] if subject_coverage > 0 else {}
@@ -500,7 +500,7 @@ def get_query_copies(cur_segments, query_contigs, subject_path, query_coverage, 
         return all_copies
     qlen = [len(query_contigs[name]) for name in qnames]
     slen = [len(subject_contigs[name]) for name in snames] if subject_coverage > 0 else None
-    res = get_ctx(device).query_copies(qid, sid, qs, qe, ss, se, ident, qlen, slen, ns=max(1, len(snames)), qcov=query_coverage,
+    res = (ctx or get_ctx(device)).query_copies(qid, sid, qs, qe, ss, se, ident, qlen, slen, ns=max(1, len(snames)), qcov=query_coverage,
                                        scov=subject_coverage, qthr=query_fixed_extend_base_threshold,
                                        sthr=subject_fixed_extend_base_threshold, max_copy=max_copy_num)
     for q, name in enumerate(qnames):
@@ -508,7 +508,7 @@ def get_query_copies(cur_segments, query_contigs, subject_path, query_coverage, 
     return all_copies
 
 
-def get_copies_v1(blastnResults_path, query_path, subject_path, query_coverage=0.95, subject_coverage=0, device=0):
+def get_copies_v1(blastnResults_path, query_path, subject_path, query_coverage=0.95, subject_coverage=0, device=0, ctx=None):
     """Util.py:7032 -- blast6 table -> {query: copies}; lines with query == subject name are skipped"""
     query_records = {}
     with open(blastnResults_path) as f_r:
@@ -519,7 +519,202 @@ def get_copies_v1(blastnResults_path, query_path, subject_path, query_coverage=0
             query_records.setdefault(parts[0], {}).setdefault(parts[1], []).append(
                 (int(parts[6]), int(parts[7]), int(parts[8]), int(parts[9]), float(parts[2])))
     _names, query_contigs = read_fasta(query_path)
-    return get_query_copies(list(query_records.items()), query_contigs, subject_path, query_coverage, subject_coverage, device=device)
+    return get_query_copies(list(query_records.items()), query_contigs, subject_path, query_coverage, subject_coverage, device=device, ctx=ctx)
+
+
+def _chain_all_by_name(query_records, gap_of, ctx):
+    """query_records: {query: {subject: [(q_start, q_end, s_start, s_end), ...]}} in the reference's insertion order;
+    gap_of(query) -> its skip_gap (real).  -> {query: [(q_start, q_end, length, s_start, s_end, |s span|, subject, extend_num)]}:
+    the reference's longest_queries tuples, per query, in its order (hite_chain_all)"""
+    import math
+
+    qnames = list(query_records.keys())
+    snames, sidx = [], {}
+    qid, sid, qs, qe, ss, se = [], [], [], [], [], []
+    for qi, q in enumerate(qnames):
+        for sname, frags in query_records[q].items():
+            si = sidx.setdefault(sname, len(sidx))
+            if si == len(snames):
+                snames.append(sname)
+            for f in frags:
+                qid.append(qi); sid.append(si); qs.append(f[0]); qe.append(f[1]); ss.append(f[2]); se.append(f[3])
+    out = {q: [] for q in qnames}
+    if not qid:
+        return out
+    # an integer distance is below the real skip_gap exactly when it is below its ceiling
+    gaps = [int(math.ceil(gap_of(q))) for q in qnames]
+    chains = ctx.chain_all(qid, sid, qs, qe, ss, se, len(qnames), len(snames), gaps)
+    for q, lst in zip(qnames, chains):
+        for (si, a, b, c, d, nx) in lst:
+            out[q].append((a, b, (b - a) if nx else abs(b - a), c, d, abs(d - c), snames[si], nx))
+    return out
+
+
+def FMEA(blastn2Results_path, fixed_extend_base_threshold, device=0, ctx=None):
+    """FMEA (Util.py:10452-10645), same arguments: blast6 table -> {query_name: [(query_name, q_start - 1, q_end, subject_name,
+    s_start - 1, s_end), ...]} -- every chain of get_longest_repeats_v4's chaining core with a fixed skip_gap, no
+    de-duplication (deredundant_for_LTR, Util.py:10750).  A zero-length HSP raises ZeroDivisionError (the reference divides
+    by the fragment lengths, :10550-10554, wherever such a fragment meets another one; here: always)."""
+    query_records = {}
+    with open(blastn2Results_path) as f_r:
+        for line in f_r:
+            parts = line.split("\t")
+            query_name, subject_name = parts[0], parts[1]
+            float(parts[2]); int(parts[3])                     # (identity, alignment length: parsed, unused -- a malformed line raises as in the reference)
+            q_start, q_end, s_start, s_end = int(parts[6]), int(parts[7]), int(parts[8]), int(parts[9])
+            if query_name == subject_name and q_start == s_start and q_end == s_end:
+                continue
+            if q_start == q_end or s_start == s_end:
+                raise ZeroDivisionError("zero-length HSP")
+            query_records.setdefault(query_name, {}).setdefault(subject_name, []).append((q_start, q_end, s_start, s_end))
+    if ctx is None:
+        ctx = get_ctx(device)
+    chains = _chain_all_by_name(query_records, lambda _q: fixed_extend_base_threshold, ctx)
+    return {q: [(q, r[0] - 1, r[1], r[6], r[3] - 1, r[4]) for r in lst] for q, lst in chains.items()}
+
+
+def get_full_length_copies_from_blastn_v1(TE_lib, reference, blastn_out, tmp_output_dir, threads, divergence_threshold,
+                                          full_length_threshold, search_struct, tools_dir, device=0, ctx=None):
+    """get_full_length_copies_from_blastn_v1 (Util.py:5907-6135), same arguments: blast6 table of a TE library against a genome
+    -> ({query: {'chr:start-end': sequence | '1'}}, the same with flanks): the chains (skip_gap = len(query) * threshold) that
+    cover >= threshold of their query; names lose their '#class' suffix; with search_struct the sequences (flank 5 for
+    'Helitron' names, else 50) come from `reference`, else '1' as in the reference."""
+    ref_names, ref_contigs = read_fasta(reference) if search_struct else ([], {})
+    query_names, query_contigs = read_fasta(TE_lib)
+    query_contigs = {name.split("#")[0]: query_contigs[name] for name in query_names}
+    query_records = {}
+    with open(blastn_out) as f_r:
+        for line in f_r:
+            if line.startswith("#"):
+                continue
+            info_parts = line.split("\t")
+            query_name = info_parts[0].split("#")[0]
+            query_records.setdefault(query_name, {}).setdefault(info_parts[1], []).append(
+                (int(info_parts[6]), int(info_parts[7]), int(info_parts[8]), int(info_parts[9])))
+    known = {q: v for q, v in query_records.items() if q in query_contigs}       # (`continue` at :5943: no entry in the results)
+    if ctx is None:
+        ctx = get_ctx(device)
+    chains = _chain_all_by_name(known, lambda q: len(query_contigs[q]) * full_length_threshold, ctx)
+    full_length_copies, flank_full_length_copies = {}, {}
+    for query_name in query_records.keys():
+        if query_name not in query_contigs:
+            continue
+        query_len = len(query_contigs[query_name])
+        flanking_len = 5 if "Helitron" in str(query_name) else 50
+        query_copies, flank_query_copies = {}, {}
+        for repeat in chains[query_name]:
+            if repeat[2] < full_length_threshold * query_len:
+                continue
+            subject_name = repeat[6]
+            if repeat[3] > repeat[4]:
+                start, end = repeat[4] - 1, repeat[3]
+            else:
+                start, end = repeat[3] - 1, repeat[4]
+            subject_pos = subject_name + ":" + str(start) + "-" + str(end)
+            if search_struct:
+                subject_seq = ref_contigs[subject_name][start:end]
+                flank_subject_seq = ref_contigs[subject_name][start - flanking_len:end + flanking_len]
+            else:
+                subject_seq = flank_subject_seq = "1"
+            if float(repeat[2]) / query_len >= full_length_threshold:
+                query_copies[subject_pos] = subject_seq
+                flank_query_copies[subject_pos] = flank_subject_seq
+        full_length_copies[query_name] = query_copies
+        flank_full_length_copies[query_name] = flank_query_copies
+    return full_length_copies, flank_full_length_copies
+
+
+def generate_full_length_out_v1(BlastnOut, TE_lib, reference, tmp_output_dir, tools_dir, full_length_threshold, category, debug=0,
+                                device=0, ctx=None):
+    """generate_full_length_out_v1 (Util.py:6288-6316), same arguments: the full-length copies of every library sequence as
+    pickled sets of (query_name, chr_name, chr_start, chr_end) (1-based, inclusive), one file per batch of 500 queries --
+    what mask_genome_intactTE (:6406-6417) reads.  category 'Total' keeps every line of the table, another value those
+    whose query class (after '#') contains it (filter_out_by_category :5014).  The structure search of the reference's
+    get_structure_info_v1 is switched off in this call there as well (search_struct = False)."""
+    import pickle
+
+    os.makedirs(tmp_output_dir, exist_ok=True)
+    filter_tmp_out = os.path.join(tmp_output_dir, "tmp.out")
+    shutil.copy(BlastnOut, filter_tmp_out)
+    if category != "Total":
+        kept = [line for line in open(filter_tmp_out) if category in line.split("\t")[0].split("#")[1]]
+        filter_tmp_out = os.path.join(tmp_output_dir, "tmp.filter.out")
+        with open(filter_tmp_out, "w") as f_save:
+            f_save.writelines(kept)
+    if os.path.exists(BlastnOut) and debug != 1:
+        os.remove(BlastnOut)
+    full_length_copies, _flank = get_full_length_copies_from_blastn_v1(TE_lib, reference, filter_tmp_out, tmp_output_dir, 1, 20,
+                                                                       full_length_threshold, False, tools_dir, device=device, ctx=ctx)
+    if os.path.exists(filter_tmp_out) and debug != 1:
+        os.remove(filter_tmp_out)
+    cluster_dir = os.path.join(tmp_output_dir, "cluster")
+    shutil.rmtree(cluster_dir, ignore_errors=True)
+    os.makedirs(cluster_dir)
+    all_query_names = list(full_length_copies.keys())
+    output_files = []
+    for batch_start in range(0, len(all_query_names), 500):
+        lines = set()
+        for query_name in all_query_names[batch_start:batch_start + 500]:
+            for chr_pos in full_length_copies[query_name].keys():
+                chr_name, span = chr_pos.split(":")[0], chr_pos.split(":")[1].split("-")
+                lines.add((str(query_name), chr_name, int(span[0]) + 1, int(span[1])))
+        output_file = os.path.join(cluster_dir, "result_%d.pkl" % batch_start)
+        with open(output_file, "wb") as f:
+            pickle.dump(lines, f)
+        output_files.append(output_file)
+    return output_files
+
+
+def multiple_alignment_blast_and_get_copies_v1(repeats_path, align_fn=None, device=0, ctx=None):
+    """multiple_alignment_blast_and_get_copies_v1 (Util.py:7179-7210), same argument (query FASTA, directory of per-chromosome
+    '.fa' databases, scratch blast6 path): the chromosomes are searched one after the other (os.listdir order), the copies of
+    every query accumulate (get_copies_v1), a query that has reached 100 copies leaves the query file.  align_fn(chr_path,
+    query_path, out_path) writes the blast6 table of one chromosome: by default `blastn -evalue 1e-20 -outfmt 6` as in the
+    reference when it is installed (it is external), else the build's copy finder, one line per copy."""
+    split_repeats_path, split_ref_dir, blastn2Results_path = repeats_path[0], repeats_path[1], repeats_path[2]
+    if os.path.exists(blastn2Results_path):
+        os.remove(blastn2Results_path)
+    if align_fn is None:
+        align_fn = _blastn_one_chromosome if shutil.which("blastn") else (lambda c, q, o: _copies_as_blast6(c, q, o, device))
+    all_copies = {}
+    repeat_names, repeat_contigs = read_fasta(split_repeats_path)
+    remain_contigs = repeat_contigs
+    for chr_name in os.listdir(split_ref_dir):
+        if len(remain_contigs) > 0:
+            if not str(chr_name).endswith(".fa"):
+                continue
+            align_fn(split_ref_dir + "/" + chr_name, split_repeats_path, blastn2Results_path)
+            cur_all_copies = get_copies_v1(blastn2Results_path, split_repeats_path, "", device=device, ctx=ctx)
+            for query_name in cur_all_copies.keys():
+                update_copy_list = all_copies.get(query_name, []) + cur_all_copies[query_name]
+                all_copies[query_name] = update_copy_list
+                if len(update_copy_list) >= 100:
+                    del repeat_contigs[query_name]
+            remain_contigs = repeat_contigs
+            store_fasta(remain_contigs, split_repeats_path)
+    return all_copies
+
+
+def _blastn_one_chromosome(chr_path, query_path, out_path):
+    subprocess.run("blastn -db %s -num_threads 1 -query %s -evalue 1e-20 -outfmt 6 > %s" % (chr_path, query_path, out_path), shell=True, check=False)
+
+
+def _copies_as_blast6(chr_path, query_path, out_path, device=0):
+    """the build's stand-in for one blastn run: the copies hite_find_copies reports for the queries in the sequences of
+    chr_path, one blast6 line per copy (the whole query against the copy's interval)"""
+    names, contigs = read_fasta(chr_path)
+    qnames, queries = read_fasta(query_path)
+    ctx = get_ctx(device)
+    ctx.genome_pack([contigs[n].upper() for n in names])
+    ctx.release_copy_index()
+    _PACKED["path"] = None
+    tab = ctx.find_copies([queries[q].upper() for q in qnames]) if qnames and names else []
+    with open(out_path, "w") as f:
+        for q, copies in zip(qnames, tab):
+            L = len(queries[q])
+            for (c, s1, e1, minus, _anch) in copies:
+                a, b = (e1, s1) if minus else (s1, e1)
+                f.write("%s\t%s\t%.3f\t%d\t0\t0\t1\t%d\t%d\t%d\t1e-50\t%.1f\n" % (q, names[c], 95.0, L, L, a, b, 2.0 * L))
 
 
 def lib_longest_repeats(blastnResults_path, redundant_ltr, coverage_threshold, chunk_size=5_000_000, device=0):
@@ -898,31 +1093,42 @@ def remove_redundant_sequences(inp, outp, aS=0.95, aL=0.95, device=0, ctx=None):
 
 
 def mask_genome_intactTE(TE_lib, genome_path, work_dir=None, thread=1, ref_index=0, debug=0, device=0):
-    """mask_genome_intactTE (Util.py:6389-6431): the full-length copies (coverage >= 0.95 of the library sequence) of the
-    TEs found so far are replaced by N in the chunk, written to <genome_path>.masked.  The copies come from the build's
-    copy finder (where the reference runs minimap2, :6318) and the resident genome is masked as well."""
+    """mask_genome_intactTE (Util.py:6389-6431), step for step: the library is searched in the chunk (the reference runs
+    minimap2 and converts its PAF to blast6, :6396-6398; here the build's copy finder, one blast6 line per copy:
+    _copies_as_blast6), generate_full_length_out_v1 (:6406) turns the table into the full-length copies (coverage >= 0.95 of
+    the library sequence), and those intervals become N -- in <genome_path>.masked and in the resident genome."""
     masked = genome_path + ".masked"
     names, contigs = read_fasta(genome_path)
     te_names, tes = read_fasta(TE_lib) if TE_lib is not None and os.path.exists(TE_lib) else ([], {})
     if not te_names:
         store_fasta(contigs, masked)
         return masked
+    import pickle
+    import tempfile
+
     ctx = get_ctx(device)
-    ctx.genome_pack([contigs[n] for n in names])
-    ctx.release_copy_index()
-    _PACKED["path"] = None
-    tab = ctx.find_copies([tes[n] for n in te_names])
+    own_dir = work_dir is None
+    work = tempfile.mkdtemp(prefix="hite_mask_") if own_dir else work_dir
+    os.makedirs(work, exist_ok=True)
+    tmp_blast_dir = work + "/mask_tmp_" + str(ref_index)
+    lib_out = work + "/prev_TE_" + str(ref_index) + ".out"
+    _copies_as_blast6(genome_path, TE_lib, lib_out, device)         # (packs the chunk: it is the resident genome from here on)
+    output_files = generate_full_length_out_v1(lib_out, TE_lib, genome_path, tmp_blast_dir, "", 0.95, "Total", debug=debug, device=device)
+    idx = {n: i for i, n in enumerate(names)}
     cc, ss, ee = [], [], []
-    for n, copies in zip(te_names, tab):
-        L = len(tes[n])
-        for (c, s1, e1, _minus, _anch) in copies:
-            if (e1 - s1 + 1) >= 0.95 * L:
-                cc.append(c); ss.append(s1); ee.append(e1)
+    for output_file in output_files:
+        with open(output_file, "rb") as f:
+            for _query_name, chr_name, chr_start, chr_end in sorted(pickle.load(f)):
+                cc.append(idx[chr_name]); ss.append(chr_start); ee.append(chr_end)
     ctx.genome_mask(cc, ss, ee)
     arrs = [np.frombuffer(contigs[n].encode(), dtype=np.uint8).copy() for n in names]
     for c, s1, e1 in zip(cc, ss, ee):
         arrs[c][max(0, s1 - 1):e1] = ord("N")
     store_fasta({n: a.tobytes().decode() for n, a in zip(names, arrs)}, masked)
+    if debug != 1:
+        shutil.rmtree(tmp_blast_dir, ignore_errors=True)
+        if own_dir:
+            shutil.rmtree(work, ignore_errors=True)
     return masked
 
 

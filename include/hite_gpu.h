@@ -194,6 +194,22 @@ int hite_query_copies(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_
                       int64_t *copy_first, int32_t *o_sid, int64_t *o_s, int64_t *o_e, int64_t *o_len, uint8_t *o_minus,
                       int64_t *n_out);
 
+/* ---- every chain of every cluster --- the chaining core of FMEA (Util.py:10452-10645) and of
+ * get_full_length_copies_from_blastn_v1 (:5907-6105; with generate_full_length_out_v1 :6288 what mask_genome_intactTE :6389
+ * consumes), i.e. get_longest_repeats_v4's core without its de-duplication.  n HSPs in file order (host arrays; the caller
+ * drops the lines its function skips), query id in [0, nq), subject id in [0, ns), 1-based inclusive coordinates (s_start >
+ * s_end = minus strand).  qgap[q] = the query's skip_gap: an HSP joins a cluster / extends a chain while the distance is
+ * < qgap[q] (FMEA: fixed_extend_base_threshold for every query; full-length copies: ceil(len(query) * threshold) -- an
+ * integer distance is below a real gap exactly when it is below its ceiling).  Output CSR chain_first[nq + 1] over the chains
+ * of each query in the reference's order (subjects by first appearance, forward clusters before reverse ones, clusters in
+ * sweep order, chains by their first fragment): subject id, (prev_query_start, prev_query_end, prev_subject_start,
+ * prev_subject_end) as the reference holds them (1-based, s_start > s_end on the minus strand), cur_extend_num.
+ * *n_out = total; HITE_ECAP if total > cap; HITE_EINVAL on ids / coordinates out of range. */
+int hite_chain_all(hite_ctx *ctx, int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe,
+                   const int64_t *ss, const int64_t *se, int32_t nq, int32_t ns, const int64_t *qgap, int64_t cap,
+                   int64_t *chain_first, int32_t *o_sid, int64_t *o_qs, int64_t *o_qe, int64_t *o_ss, int64_t *o_se,
+                   int32_t *o_next, int64_t *n_out);
+
 /* ---- library de-duplication (panHiTE merge) --- the arithmetic between the external tools of deredundant_for_LTR_v5 -----
  * hite_lib_chain: process_blast_results_in_chunks + process_chunk + extend_fragments (Util.py:12146-12200, 11958-12003,
  * 11869-11944).  n blast6 lines of a library-vs-itself search in file order (host arrays), ids into seq_len[nseq],

@@ -636,6 +636,165 @@ def gen_query_copies(U, tmp):
     dump("query_copies", cases)
 
 
+def _te_vs_genome_rows(rng, nq, ns, qlen, slen, many_first=False):
+    """blast6-like HSPs of TE queries against chromosomes: copies cut into fragments with gaps / shifts around the thresholds"""
+    rows = []
+    for q in range(nq):
+        for _copy in range(int(rng.integers(105, 125)) if (many_first and q == 0) else int(rng.integers(1, 12))):
+            s = int(rng.integers(0, ns))
+            rev = rng.random() < 0.5
+            pos = int(rng.integers(100, slen[s] - 2 * qlen[q] - 100))
+            cov = float(rng.choice([1.0, 1.0, 0.97, 0.94, 0.6]))
+            span = int(qlen[q] * cov)
+            q0 = int(rng.integers(1, qlen[q] - span + 2))
+            nfr = int(rng.integers(1, 5))
+            cuts = sorted(set([0, span] + [int(x) for x in rng.integers(20, max(21, span - 20), size=nfr - 1)]))
+            shift = 0
+            for i in range(len(cuts) - 1):
+                a, b = cuts[i], cuts[i + 1]
+                gapq = int(rng.choice([0, 0, 5, 150, 300])) if i else 0
+                shift += int(rng.choice([0, 0, 3, -3, 120, 400, 1200])) if i else 0
+                fs, fe = q0 + a + (5 if gapq else 0), q0 + b - 1
+                if fe <= fs:
+                    continue
+                if not rev:
+                    ss_, se_ = pos + a + shift, pos + b - 1 + shift
+                else:
+                    ss_, se_ = pos + span - a + shift, pos + span - b + 1 + shift
+                rows.append((q, s, fs, fe, ss_, se_))
+                if rng.random() < 0.08:
+                    rows.append((q, s, fs, fe, ss_, se_))                      # exact duplicate line
+                if rng.random() < 0.08:
+                    rows.append((q, s, fs + 3, fe, ss_ + (3 if not rev else -3), se_))   # overlapping HSP
+    order = rng.permutation(len(rows))
+    return [rows[i] for i in order]
+
+
+def gen_chain_variants(U, tmp):
+    """The chaining variants next to get_longest_repeats_v4 / get_query_copies:
+    FMEA (Util.py:10452), get_full_length_copies_from_blastn_v1 (:5907), generate_full_length_out_v1 (:6288; what
+    mask_genome_intactTE reads) and multiple_alignment_blast_and_get_copies_v1 (:7179, its blastn call answered from
+    prepared tables), each run by the reference on synthetic blast6 tables."""
+    import shutil as _sh
+
+    rng = np.random.default_rng(10452)
+    out = {"fmea": [], "full_length": [], "multi_blast": []}
+    # ---- FMEA: a library against itself (names coincide: exact self hits are skipped), fixed gaps
+    for ci in range(16):
+        n = int(rng.integers(2, 7))
+        L = [int(rng.integers(300, 4000)) for _ in range(n)]
+        rows = []
+        for _ in range(int(rng.integers(4, 40))):
+            q, s_ = int(rng.integers(0, n)), int(rng.integers(0, n))
+            span = int(rng.integers(60, min(L[q], L[s_]) - 20))
+            qa, sa = int(rng.integers(1, L[q] - span + 1)), int(rng.integers(1, L[s_] - span + 1))
+            cuts = sorted(set([0, span] + [int(x) for x in rng.integers(10, max(11, span - 10), size=int(rng.integers(0, 3)))]))
+            rev = rng.random() < 0.4
+            for i in range(len(cuts) - 1):
+                a, b = cuts[i], cuts[i + 1] - 1
+                if b <= a:
+                    continue
+                g = int(rng.choice([0, 0, 7, 40]))
+                if not rev:
+                    rows.append((q, s_, qa + a + g, qa + b, sa + a + g, sa + b))
+                else:
+                    rows.append((q, s_, qa + a + g, qa + b, sa + span - a - g, sa + span - b))
+        for q in range(n):
+            if rng.random() < 0.7:
+                rows.append((q, q, 1, L[q], 1, L[q]))            # the self hit of a library-vs-itself search
+        rows = [rows[i] for i in rng.permutation(len(rows))]
+        names = ["LTR_%d" % i for i in range(n)]
+        p = os.path.join(tmp, "cv_fmea_%d.out" % ci)
+        with open(p, "w") as f:
+            f.writelines(casegen.hsp_to_blast6_lines([(names[q], names[s_], a, b, c, d) for (q, s_, a, b, c, d) in rows]))
+        gap = int(rng.choice([1000, 50, 8]))
+        res = U.FMEA(p, gap)
+        out["fmea"].append({"rows": [list(r) for r in rows], "names": names, "gap": gap,
+                            # (lists of [key, value]: dump() sorts dict keys, the insertion order of the reference's dicts is part of the contract)
+                            "out": [[k, [[t[0], int(t[1]), int(t[2]), t[3], int(t[4]), int(t[5])] for t in v]] for k, v in res.items()]})
+    # ---- full-length copies of a TE library in a genome, and the sets mask_genome_intactTE reads
+    for ci in range(24):
+        nq, ns = int(rng.integers(1, 6)), int(rng.integers(1, 4))
+        qlen = [int(rng.integers(200, 3000)) for _ in range(nq)]
+        slen = [int(rng.integers(20_000, 200_000)) for _ in range(ns)]
+        rows = _te_vs_genome_rows(rng, nq, ns, qlen, slen)
+        qnames = ["TE_%d#%s" % (q, ["DNA/hAT", "LTR/Gypsy", "Unknown"][q % 3]) if q % 2 else "Helitron_%d" % q for q in range(nq)]
+        snames = ["chr%d" % s_ for s_ in range(ns)]
+        thr = float(rng.choice([0.95, 0.95, 0.8]))
+        lib = os.path.join(tmp, "cv_lib_%d.fa" % ci)
+        ref = os.path.join(tmp, "cv_ref_%d.fa" % ci)
+        # one query of the table is missing from the library every few cases (the reference skips it)
+        drop = int(rng.integers(0, nq)) if (ci % 5 == 4 and nq > 1) else -1
+        write_fasta(lib, [qnames[q] for q in range(nq) if q != drop], ["ACGT" * (qlen[q] // 4) + "A" * (qlen[q] % 4) for q in range(nq) if q != drop])
+        gen = np.random.default_rng(1000 + ci)
+        refseqs = ["".join("ACGT"[i] for i in gen.integers(0, 4, slen[s_])) for s_ in range(ns)]
+        write_fasta(ref, snames, refseqs)
+        p = os.path.join(tmp, "cv_fl_%d.out" % ci)
+        lines = casegen.hsp_to_blast6_lines([(qnames[q], snames[s_], a, b, c, d) for (q, s_, a, b, c, d) in rows])
+        if ci % 6 == 1:
+            lines.insert(0, "# a comment line\n")
+        with open(p, "w") as f:
+            f.writelines(lines)
+        search_struct = ci % 4 == 3
+        fl, ffl = U.get_full_length_copies_from_blastn_v1(lib, ref, p, tmp, 1, 20, thr, search_struct, "")
+        p2 = p + ".copy"
+        _sh.copy(p, p2)
+        cat = "Total" if ci % 3 else "DNA"
+        if cat != "Total" and any("#" not in qn for qn in qnames):
+            cat = "Total"                     # (the reference indexes the class after '#': names without one would raise)
+        files = U.generate_full_length_out_v1(p2, lib, ref, os.path.join(tmp, "cv_w_%d" % ci), "", thr, cat, debug=0)
+        sets = [sorted([list(t) for t in U.load_from_file(fp)]) for fp in files]
+        out["full_length"].append({"rows": [list(r) for r in rows], "qnames": qnames, "snames": snames, "qlen": qlen, "slen": slen, "thr": thr,
+                                   "drop": drop, "comment": ci % 6 == 1, "search_struct": search_struct, "ref_seed": 1000 + ci,
+                                   "copies": [[k, [[kk, vv] for kk, vv in v.items()]] for k, v in fl.items()],
+                                   "flank_copies": [[k, [[kk, vv] for kk, vv in v.items()]] for k, v in ffl.items()],
+                                   "category": cat, "out_files": [os.path.basename(fp) for fp in files], "out_sets": sets})
+    # ---- multiple_alignment_blast_and_get_copies_v1: the blastn of each chromosome file answered from a prepared table
+    real_system, real_listdir = os.system, os.listdir
+    for ci in range(6):
+        nq, ns = int(rng.integers(2, 6)), int(rng.integers(2, 5))
+        qlen = [int(rng.integers(200, 2000)) for _ in range(nq)]
+        slen = [int(rng.integers(60_000, 200_000)) for _ in range(ns)]
+        rows = _te_vs_genome_rows(rng, nq, ns, qlen, slen, many_first=ci % 2 == 0)
+        qnames = ["TE_%d" % q for q in range(nq)]
+        files = ["chr%d.fa" % s_ for s_ in range(ns)] + ["chr0.fa.nhr", "notes.txt"]
+        files = [files[i] for i in rng.permutation(len(files))]
+        d = os.path.join(tmp, "cv_mb_%d" % ci)
+        os.makedirs(d, exist_ok=True)
+        qpath = os.path.join(d, "q.fa")
+        write_fasta(qpath, qnames, ["A" * L for L in qlen])
+        refdir = os.path.join(d, "ref")
+        os.makedirs(refdir, exist_ok=True)
+        tables = {}
+        for s_ in range(ns):
+            tables["chr%d.fa" % s_] = [(qnames[q], "chr%d" % s2, a, b, c, e) for (q, s2, a, b, c, e) in rows if s2 == s_]
+        calls = []
+
+        def fake_system(cmd, _tables=tables, _calls=calls):
+            if cmd.startswith("blastn "):
+                db = cmd.split(" -db ")[1].split(" ")[0]
+                outp = cmd.split(" > ")[1].strip()
+                qp = cmd.split(" -query ")[1].split(" ")[0]
+                live = set(U.read_fasta(qp)[0])
+                _calls.append(os.path.basename(db))
+                with open(outp, "w") as f:
+                    f.writelines(casegen.hsp_to_blast6_lines([r for r in _tables[os.path.basename(db)] if r[0] in live]))
+                return 0
+            return real_system(cmd)
+
+        os.system = fake_system
+        os.listdir = lambda pth, _files=files, _refdir=refdir: list(_files) if pth == _refdir else real_listdir(pth)
+        try:
+            res = U.multiple_alignment_blast_and_get_copies_v1((qpath, refdir, os.path.join(d, "b.out")))
+        finally:
+            os.system, os.listdir = real_system, real_listdir
+        out["multi_blast"].append({"qnames": qnames, "qlen": qlen, "files": files,
+                                   "tables": {k: [list(r) for r in v] for k, v in tables.items()}, "blast_calls": calls,
+                                   "left_in_query_file": U.read_fasta(qpath)[0],
+                                   "out": [[k, [[c[0], int(c[1]), int(c[2]), int(c[3]), c[4]] for c in v]] for k, v in res.items()]})
+    dump("chain_variants", out)
+
+
 def gen_lib_dedup(U, tmp):
     """panHiTE library de-duplication: process_blast_results_in_chunks -> process_chunk (extend_fragments) ->
     cluster_sequences_from_chunks, and cons_from_mafft_v1, run through the reference on synthetic all-vs-all tables"""
@@ -1002,7 +1161,7 @@ def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf", "rfm"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf", "rfm", "chainvar"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -1040,6 +1199,8 @@ def main():
             gen_trf_mask(tmp)
         if "rfm" in which:
             gen_ready_for_msa(tmp)
+        if "chainvar" in which:
+            gen_chain_variants(U, tmp)
 
 
 if __name__ == "__main__":

@@ -48,7 +48,7 @@ static int cmp_q(const hsp_t *a, const hsp_t *b) { /* key (qs, qe)   :4231 */
     return 0;
 }
 
-typedef struct { int64_t qs, qe, ss, se; int32_t sseg; } chain_t;
+typedef struct { int64_t qs, qe, ss, se; int32_t sseg; int32_t next; /* HSPs the chain took in beyond its first (cur_extend_num) */ } chain_t;
 
 typedef struct { chain_t *v; int n, cap; } chainvec;
 static void cv_push(chainvec *c, chain_t x) {
@@ -70,6 +70,7 @@ static void chain_cluster(hsp_t *cl, hsp_t *tmp, int n, int64_t gap, int32_t sse
     for (int i = 0; i < n; i++) {
         if (vis[canon[i]]) continue;
         int64_t pqs = cl[i].qs, pqe = cl[i].qe, pss = cl[i].ss, pse = cl[i].se;
+        int32_t next = 0;
         vis[canon[i]] = 1;
         for (int j = i + 1; j < n; j++) {
             if (vis[canon[j]]) continue;
@@ -78,21 +79,21 @@ static void chain_cluster(hsp_t *cl, hsp_t *tmp, int n, int64_t gap, int32_t sse
                 if (pss < pse && css < cse) {
                     if (cse > pse) {
                         if (cqs - pqe < gap && cqe > pqe && css - pse < gap) {
-                            pqe = cqe; pss = pss < css ? pss : css; pse = cse;
+                            pqe = cqe; pss = pss < css ? pss : css; pse = cse; next++;
                             vis[canon[j]] = 1;
                         } else if (cqs - pqe >= gap) break;
                     }
                 } else if (pss > pse && css > cse) {
                     if (cse < pse) {
                         if (cqs - pqe < gap && cqe > pqe && pse - css < gap) {
-                            pqe = cqe; pss = pss > css ? pss : css; pse = cse;
+                            pqe = cqe; pss = pss > css ? pss : css; pse = cse; next++;
                             vis[canon[j]] = 1;
                         } else if (cqs - pqe >= gap) break;
                     }
                 }
             }
         }
-        chain_t c = {pqs, pqe, pss, pse, sseg};
+        chain_t c = {pqs, pqe, pss, pse, sseg, next};
         cv_push(out, c);
     }
     free(canon); free(vis);
@@ -288,6 +289,70 @@ int orc_fmea(int n, const int32_t *qseg, const int32_t *sseg, const int64_t *qs,
 /* Returns window length written to out (0 = copy skipped), trunc_out gets the      */
 /* first500+last500 form when the window is > 1000 (else *trunc_len = 0).           */
 /* ------------------------------------------------------------------------------- */
+/* ---------------------------------------------------------------------------------------------
+ * Every chain of every cluster: the chaining core that FMEA (Util.py:10452-10645) and get_full_length_copies_from_blastn_v1
+ * (:5907-6105) share with get_longest_repeats_v4, without that function's de-duplication.
+ * n HSPs in file order (the caller has already dropped the lines its function skips), query id in [0, nq), subject id in
+ * [0, ns), 1-based inclusive coordinates.  qgap[q] = the query's skip_gap (FMEA: the same for all; full-length copies:
+ * ceil(len(query) * threshold) -- an integer d is < a real g exactly when d < ceil(g)).  Queries in order of first appearance,
+ * subjects of a query in order of first appearance, forward clusters before reverse ones, chains in creation order: the
+ * order of the reference's longest_queries lists.  Output per chain: query, (prev_query_start, prev_query_end,
+ * prev_subject_start, prev_subject_end) as the reference holds them, subject, cur_extend_num.  Returns the number of chains
+ * (ORC_ECAP if more than cap). */
+int64_t orc_chain_all(int64_t n, const int32_t *qid, const int32_t *sid, const int64_t *qs, const int64_t *qe, const int64_t *ss,
+                      const int64_t *se, int32_t nq, int32_t ns, const int64_t *qgap, int64_t cap, int32_t *o_q, int64_t *o_qs,
+                      int64_t *o_qe, int32_t *o_s, int64_t *o_ss, int64_t *o_se, int32_t *o_next) {
+    if (n < 0 || nq <= 0 || ns <= 0) return ORC_EINVAL;
+    for (int64_t i = 0; i < n; i++) if (qid[i] < 0 || qid[i] >= nq || sid[i] < 0 || sid[i] >= ns) return ORC_EINVAL;
+    int *qorder = (int *)malloc(sizeof(int) * nq), nqs = 0;
+    char *seenq = (char *)calloc(nq, 1);
+    int *qcount = (int *)calloc((size_t)nq + 1, sizeof(int));
+    for (int64_t i = 0; i < n; i++) { if (!seenq[qid[i]]) { seenq[qid[i]] = 1; qorder[nqs++] = qid[i]; } qcount[qid[i] + 1]++; }
+    for (int q = 0; q < nq; q++) qcount[q + 1] += qcount[q];
+    int *qfill = (int *)malloc(sizeof(int) * nq);
+    memcpy(qfill, qcount, sizeof(int) * nq);
+    int *byq = (int *)malloc(sizeof(int) * ((size_t)n + 1));
+    for (int64_t i = 0; i < n; i++) byq[qfill[qid[i]]++] = (int)i;
+    int *sfirst = (int *)malloc(sizeof(int) * ns), *sorder = (int *)malloc(sizeof(int) * ns);
+    for (int s = 0; s < ns; s++) sfirst[s] = -1;
+    hsp_t *fwd = (hsp_t *)malloc(sizeof(hsp_t) * ((size_t)n + 1)), *rev = (hsp_t *)malloc(sizeof(hsp_t) * ((size_t)n + 1));
+    hsp_t *tmp = (hsp_t *)malloc(sizeof(hsp_t) * ((size_t)n + 1));
+    chainvec chains = {0, 0, 0};
+    int64_t nout = 0;
+    int over = 0;
+    for (int qi = 0; qi < nqs; qi++) {
+        const int q = qorder[qi];
+        const int b0 = qcount[q], b1 = qcount[q + 1];
+        int nsub = 0;
+        for (int t = b0; t < b1; t++) { const int s = sid[byq[t]]; if (sfirst[s] < 0) { sfirst[s] = t; sorder[nsub++] = s; } }
+        chains.n = 0;
+        for (int k = 0; k < nsub; k++) {
+            const int s = sorder[k];
+            int nf = 0, nr = 0;
+            for (int t = b0; t < b1; t++) {
+                const int h = byq[t];
+                if (sid[h] != s) continue;
+                hsp_t x = {qs[h], qe[h], ss[h], se[h], h};
+                if (x.ss > x.se) rev[nr++] = x; else fwd[nf++] = x;
+            }
+            msort(fwd, tmp, nf, cmp_fwd);
+            msort(rev, tmp, nr, cmp_rev);
+            cluster_and_chain(fwd, nf, 0, qgap[q], s, tmp, &chains);
+            cluster_and_chain(rev, nr, 1, qgap[q], s, tmp, &chains);
+        }
+        for (int k = 0; k < nsub; k++) sfirst[sorder[k]] = -1;
+        for (int c = 0; c < chains.n; c++) {
+            if (nout < cap) {
+                o_q[nout] = q; o_qs[nout] = chains.v[c].qs; o_qe[nout] = chains.v[c].qe; o_s[nout] = chains.v[c].sseg;
+                o_ss[nout] = chains.v[c].ss; o_se[nout] = chains.v[c].se; o_next[nout] = chains.v[c].next;
+            } else over = 1;
+            nout++;
+        }
+    }
+    free(qorder); free(seenq); free(qcount); free(qfill); free(byq); free(sfirst); free(sorder); free(fwd); free(rev); free(tmp); free(chains.v);
+    return over ? ORC_ECAP : nout;
+}
+
 int64_t orc_flank_window(const uint8_t *contig, int64_t clen, int64_t start1, int64_t end1, int minus, int64_t flank,
                          uint8_t *out, uint8_t *trunc_out, int64_t *trunc_len) {
     *trunc_len = 0;

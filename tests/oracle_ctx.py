@@ -23,6 +23,16 @@ class OracleCtx:
         t = O.seed_allvsall(self.contigs, seg_len)
         return {k: t[k] for k in ("qseg", "sseg", "qs", "qe", "ss", "se")}
 
+    def query_copies(self, qid, sid, qs, qe, ss, se, ident, qlen, slen=None, ns=None, qcov=0.95, scov=0.0, qthr=200, sthr=200, max_copy=100):
+        n = len(qid)
+        if ns is None:
+            ns = len(slen) if slen is not None else (max(sid) + 1 if n else 1)
+        rows = [(int(qid[i]), int(sid[i]), int(qs[i]), int(qe[i]), int(ss[i]), int(se[i]), float(ident[i]) if ident is not None else 0.0) for i in range(n)]
+        return O.query_copies(rows, list(qlen), list(slen) if slen is not None else [1] * int(ns), qcov, scov, qthr, sthr, max_copy)
+
+    def chain_all(self, qid, sid, qs, qe, ss, se, nq, ns, qgap):
+        return O.chain_all(qid, sid, qs, qe, ss, se, nq, ns, qgap)
+
     def lib_chain(self, qid, sid, qs, qe, ss, se, seq_len, threshold, chunk_size=0):
         rows = list(zip((int(x) for x in qid), (int(x) for x in sid), (int(x) for x in qs), (int(x) for x in qe), (int(x) for x in ss),
                         (int(x) for x in se)))

@@ -371,6 +371,27 @@ def query_copies(rows, qlen, slen, qcov, scov=0.0, qthr=200, sthr=200, max_copy=
     return [[(int(osid[i]), int(os_[i]), int(oe[i]), int(ol[i]), "-" if om[i] else "+") for i in range(cf[q], cf[q + 1])] for q in range(nq)]
 
 
+def chain_all(qid, sid, qs, qe, ss, se, nq, ns, qgap):
+    """orc_chain_all -> per query list of (subject id, q_start, q_end, s_start, s_end, extend_num), as Context.chain_all"""
+    n = len(qid)
+    a32 = lambda x: np.ascontiguousarray(x, dtype=np.int32)  # noqa: E731
+    a64 = lambda x: np.ascontiguousarray(x, dtype=np.int64)  # noqa: E731
+    qid, sid, qs, qe, ss, se, gap = a32(qid), a32(sid), a64(qs), a64(qe), a64(ss), a64(se), a64(qgap)
+    cap = n + 16
+    oq, os_, onx = (np.zeros(cap, dtype=np.int32) for _ in range(3))
+    oqs, oqe, oss, ose = (np.zeros(cap, dtype=np.int64) for _ in range(4))
+    L = lib()
+    L.orc_chain_all.restype = C.c_int64
+    k = L.orc_chain_all(C.c_int64(n), _ptr(qid, i32p), _ptr(sid, i32p), _ptr(qs, i64p), _ptr(qe, i64p), _ptr(ss, i64p), _ptr(se, i64p),
+                        int(nq), int(ns), _ptr(gap, i64p), C.c_int64(cap), _ptr(oq, i32p), _ptr(oqs, i64p), _ptr(oqe, i64p), _ptr(os_, i32p),
+                        _ptr(oss, i64p), _ptr(ose, i64p), _ptr(onx, i32p))
+    assert k >= 0, k
+    out = [[] for _ in range(nq)]
+    for i in range(k):
+        out[int(oq[i])].append((int(os_[i]), int(oqs[i]), int(oqe[i]), int(oss[i]), int(ose[i]), int(onx[i])))
+    return out
+
+
 def lib_chain(rows, lens, thr, chunk_size=0):
     """process_blast_results_in_chunks + process_chunk: rows (q, s, qs, qe, ss, se) -> records [chunk, q, qs-1, qe, s, ss-1, se]"""
     n = len(rows)

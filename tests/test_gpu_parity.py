@@ -737,15 +737,15 @@ def test_mask_genome_intactTE(ctx, tmp_path):
     out = util.mask_genome_intactTE(str(lib), str(gp))
     names, masked = util.read_fasta(out)
     assert names == ["chr%d$0" % (i + 1) for i in range(len(g["contigs"]))]
-    # expectation from the twin's copy table
+    # expectation from the twin's copy table: every copy the finder reports has >= 95 % of the library sequence aligned (its own
+    # acceptance rule), which is the coverage rule of get_full_length_copies_from_blastn_v1 on the blast6 line written for it
     tab = O.find_copies(g["contigs"], g["cands"][:6])
     exp = [np.frombuffer(s.encode(), dtype=np.uint8).copy() for s in g["contigs"]]
     nmask = 0
     for cand, copies in zip(g["cands"][:6], tab):
         for (c, s1, e1, _m, _a) in copies:
-            if e1 - s1 + 1 >= 0.95 * len(cand):
-                exp[c][s1 - 1:e1] = ord("N")
-                nmask += 1
+            exp[c][s1 - 1:e1] = ord("N")
+            nmask += 1
     assert nmask >= 6
     for n, e in zip(names, exp):
         assert masked[n] == e.tobytes().decode()
@@ -1426,3 +1426,38 @@ def test_row_selection_ties_follow_the_window_names(ctx):
             n_big += len(copies) > 100
     ctx.set_contig_order(None)
     assert n_checked >= 15 and n_big >= 3
+
+
+def test_chain_variants_golden_on_gpu(ctx, tmp_path):
+    """FMEA (Util.py:10452), get_full_length_copies_from_blastn_v1 (:5907), generate_full_length_out_v1 (:6288) and
+    multiple_alignment_blast_and_get_copies_v1 (:7179) with the chaining on the GPU (hite_chain_all / hite_query_copies)
+    against what the reference computed (tests/golden/chain_variants.json.gz), then hite_chain_all against its twin on random
+    tables large enough for every kernel path (many queries and subjects, both strands, duplicates, per-query gaps)"""
+    import chain_variant_cases
+    from hite_amd import util
+
+    n_chains, n_copies = chain_variant_cases.check_all(util, ctx, str(tmp_path))
+    assert n_chains > 100 and n_copies > 50
+    rng = np.random.default_rng(6288)
+    for trial in range(6):
+        nq, ns = int(rng.integers(1, 40)), int(rng.integers(1, 12))
+        n = int(rng.integers(50, 6000))
+        qid = rng.integers(0, nq, n).astype(np.int32)
+        sid = rng.integers(0, ns, n).astype(np.int32)
+        qs = rng.integers(1, 3000, n).astype(np.int64)
+        qe = qs + rng.integers(1, 400, n)
+        ss = rng.integers(1, 40000 if trial % 2 else 4000, n).astype(np.int64)
+        ln = rng.integers(1, 400, n)
+        rev = rng.random(n) < 0.45
+        se = np.where(rev, ss - ln, ss + ln)
+        keep = se >= 1
+        qid, sid, qs, qe, ss, se = (x[keep] for x in (qid, sid, qs, qe, ss, se))
+        # duplicates
+        dup = rng.integers(0, len(qid), len(qid) // 10)
+        qid, sid, qs, qe, ss, se = (np.concatenate([x, x[dup]]) for x in (qid, sid, qs, qe, ss, se))
+        gaps = rng.integers(0, 3000, nq).astype(np.int64) if trial % 3 else np.full(nq, 200, dtype=np.int64)
+        got = ctx.chain_all(qid, sid, qs, qe, ss, se, nq, ns, gaps)
+        exp = O.chain_all(qid, sid, qs, qe, ss, se, nq, ns, gaps)
+        assert got == exp, trial
+        assert sum(len(x) for x in got) > 10
+    assert ctx.chain_all([], [], [], [], [], [], 3, 2, [5, 5, 5]) == [[], [], []]

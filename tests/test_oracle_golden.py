@@ -494,3 +494,15 @@ def test_library_merge_host_code_through_the_twins(tmp_path):
     for f, cons in enumerate(fams):
         mine = [n for n in names if "-fam%d#" % f in n]
         assert len(mine) == 1 and abs(len(seqs[mine[0]]) - len(cons)) <= 0.02 * len(cons)
+
+
+def test_chain_variants_golden_through_the_twins(tmp_path):
+    """FMEA (Util.py:10452), get_full_length_copies_from_blastn_v1 (:5907), generate_full_length_out_v1 (:6288) and
+    multiple_alignment_blast_and_get_copies_v1 (:7179): the product's host mirrors with the chaining answered by the CPU twin
+    (orc_chain_all / orc_query_copies) reproduce what the reference computed (tests/golden/chain_variants.json.gz)"""
+    import chain_variant_cases
+    from hite_amd import util
+    from oracle_ctx import OracleCtx
+
+    n_chains, n_copies = chain_variant_cases.check_all(util, OracleCtx(), str(tmp_path))
+    assert n_chains > 100 and n_copies > 50
