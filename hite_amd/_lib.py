@@ -607,6 +607,10 @@ class Context:
         self._check(self.lib.hite_seed_segments(self.h, C.c_int64(seg_len), n.value, _p(sc), _p(so), C.byref(n)), "hite_seed_segments")
         return sc[:n.value], so[:n.value]
 
+    def seed_shard(self, rank, world):
+        """the seeding calls of this context compute rank's share of `world` (hite_seed_shard); world <= 1: everything"""
+        self._check(self.lib.hite_seed_shard(self.h, int(rank), int(world)), "hite_seed_shard")
+
     def seed_allvsall(self, seg_len=1_000_000, max_anchors=2_000_000_000, cap=None):
         """all-vs-all seeding of the packed genome -> dict(qseg, sseg, qs, qe, ss, se, stats): the HSP table fmea_chain takes"""
         if getattr(self, "_copy_state", None) is None:

@@ -514,66 +514,63 @@ __global__ void __launch_bounds__(64) align_fwd8_pair_kernel(AlignArgs P, const 
 // ops leave the traceback in descending positions, one at a time and per lane, every lane into its own row: 64 different
 // cache lines per wavefront.  Round 3 stored 8 bytes per four positions straight to the row: HBM is written in 32-byte
 // sectors, and with ~130 000 rows open across the machine the partly written sectors leave L2 one store at a time --
-// WRITE_SIZE 12.6 GB per launch for 3.3 GB of ops (profiles/r03_pmc_hbm.txt).  Now a lane parks its ops in a ring of 128
-// positions in LDS (a write the walk never waits for) and the wavefront drains the rings once per strip of 16 columns, all
-// lanes together: whole 32-byte sectors (16 positions, aligned in memory), two 16-byte stores each.  Measured (round 4):
-// WRITE_SIZE 3.3 GB per launch.  (A first form -- a ring of one 128-byte line per lane, written by the lane that crossed the
-// line's edge, inside the walk -- had the same traffic but ran the flush for one lane on most steps: 13.8 -> 17.4 ms.)
-#define TB_RING 128          // positions per lane (power of two, multiple of TB_SECT)
-#define TB_SECT 16           // positions per 32-byte sector
-#define TB_STRIDE (TB_RING + 16)    // u16 per lane in LDS (288 B: 32-byte aligned, lanes spread over the banks)
+// WRITE_SIZE 12.6 GB per launch for 3.3 GB of ops (profiles/r03_pmc_hbm.txt).  Now a lane collects a whole sector -- 16
+// positions, aligned in MEMORY (q = position + the row's phase) -- in four 64-bit registers and writes it with two 16-byte
+// stores; the partial sectors at the two ends of a row go out entry by entry.  Round 4 measured three forms on C3 (13.8 ms,
+// 12.6 GB written per launch before): a 128-byte line per lane staged in LDS, flushed inside the walk by the lane that
+// crossed its edge: 3.3 GB, 17.4 ms (the flush ran for one lane on most steps); a ring of 128 positions per lane in LDS
+// drained once per strip by all lanes: 3.1 GB, 16.0 ms; this one: registers only.
 typedef unsigned int tb_u32x4 __attribute__((ext_vector_type(4)));
 struct OpsOut {
     uint16_t *ops;           // the lane's row
-    uint16_t *lds;           // the lane's ring
-    int m, off;              // off: (address of ops[0] / 2) mod 16 -- ring slot of position p = (p + off) & 127; slot % 16 == 0 starts a sector
-    int low;                 // positions >= low are in the row already
-    int cur;                 // lowest position pushed so far: [cur, low) waits in the ring
-    __device__ __forceinline__ void init(uint16_t *row, uint16_t *ring, int m_) {
-        ops = row; lds = ring; m = m_; low = m_; cur = m_;
-        off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & (TB_SECT - 1));
+    unsigned long long acc;  // the group of four being collected (newest = lowest position in the low 16 bits)
+    unsigned long long g0, g1, g2, g3;   // the complete groups of the sector being collected (g0 = lowest positions)
+    int m, off;              // off = (address of ops[0] / 2) mod 16: q = position + off; q % 16 == 0 starts a sector
+    int q_low;               // q of the lowest position whose SECTOR has been written (m + off: none yet)
+    __device__ __forceinline__ void init(uint16_t *row, int m_) {
+        ops = row; m = m_; acc = 0ull; g0 = g1 = g2 = g3 = 0ull;
+        off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & 15);
+        q_low = m_ + off;
     }
-    // whole sectors of [cur, low) -> the row.  Wave-uniform loop: every lane calls it at the same place.
-    __device__ __forceinline__ void drain() {
-        if (low == m && cur < m) {           // the topmost, partial sector: entry by entry, once
-            const int g = m - ((m + off) & (TB_SECT - 1));      // the sector edge at or below m
-            if (g >= cur && g < m) { for (int x = g; x < m; x++) ops[x] = lds[(x + off) & (TB_RING - 1)]; low = g; }
-            else if (g == m) low = m;
-        }
-        while (__any(low - TB_SECT >= cur && ((low + off) & (TB_SECT - 1)) == 0)) {
-            if (low - TB_SECT >= cur && ((low + off) & (TB_SECT - 1)) == 0) {
-                const int g = low - TB_SECT;
-                const tb_u32x4 *src = reinterpret_cast<const tb_u32x4 *>(lds + ((g + off) & (TB_RING - 1)));
-                tb_u32x4 *dst = reinterpret_cast<tb_u32x4 *>(ops + g);          // 32-byte aligned by the choice of off
-                const tb_u32x4 v0 = src[0], v1 = src[1];
-                dst[0] = v0; dst[1] = v1;
-                low = g;
-            }
-        }
+    // entry q of the sector / group being collected (rare paths only: the ends of a row)
+    __device__ __forceinline__ uint16_t held(int q, int q_acc_low) const {
+        if ((q >> 2) == (q_acc_low >> 2) && (q_acc_low & 3)) return (uint16_t)(acc >> (16 * (q - q_acc_low)));   // still in acc
+        const int g = (q >> 2) & 3;
+        const unsigned long long s = g == 0 ? g0 : (g == 1 ? g1 : (g == 2 ? g2 : g3));
+        return (uint16_t)(s >> (16 * (q & 3)));
     }
     __device__ __forceinline__ void push(int pos, uint32_t val) {
-        lds[(pos + off) & (TB_RING - 1)] = (uint16_t)val;
-        cur = pos;
-        if (low - pos >= TB_RING - TB_SECT) {       // the ring is nearly full (a long run of gaps inside one strip): this lane alone
-            if (low == m) {
-                const int g = m - ((m + off) & (TB_SECT - 1));
-                if (g >= cur && g < m) { for (int x = g; x < m; x++) ops[x] = lds[(x + off) & (TB_RING - 1)]; low = g; }
-            }
-            while (low - TB_SECT >= cur && ((low + off) & (TB_SECT - 1)) == 0) {
-                const int g = low - TB_SECT;
-                for (int x = g; x < low; x++) ops[x] = lds[(x + off) & (TB_RING - 1)];
-                low = g;
+        acc = (acc << 16) | (unsigned long long)(val & 0xffffu);
+        const int q = pos + off;
+        if ((q & 3) == 0) {
+            const int g = (q >> 2) & 3;
+            g0 = g == 0 ? acc : g0; g1 = g == 1 ? acc : g1; g2 = g == 2 ? acc : g2; g3 = g == 3 ? acc : g3;
+            if (g == 0) {                    // the sector [pos, pos + 16) is complete as far as the row goes
+                if (pos + 16 <= m) {
+                    tb_u32x4 *dst = reinterpret_cast<tb_u32x4 *>(ops + pos);      // 32-byte aligned
+                    tb_u32x4 v0, v1;
+                    v0.x = (unsigned)g0; v0.y = (unsigned)(g0 >> 32); v0.z = (unsigned)g1; v0.w = (unsigned)(g1 >> 32);
+                    v1.x = (unsigned)g2; v1.y = (unsigned)(g2 >> 32); v1.z = (unsigned)g3; v1.w = (unsigned)(g3 >> 32);
+                    dst[0] = v0; dst[1] = v1;
+                } else {
+                    for (int x = pos; x < m; x++) ops[x] = held(x + off, q);      // the topmost sector of the row (partial)
+                }
+                q_low = q;
             }
         }
     }
-    __device__ __forceinline__ void finish() {   // after position 0 has been pushed: what is left below the last sector edge
-        drain();
-        for (int x = 0; x < low; x++) ops[x] = lds[(x + off) & (TB_RING - 1)];
-        low = 0;
+    __device__ __forceinline__ void finish() {   // after position 0 has been pushed: the partial sector at the start of the row
+        const int top = q_low - off < m ? q_low - off : m;       // positions [0, top) are still held
+        for (int x = 0; x < top; x++) ops[x] = held(x + off, off);
     }
 };
 
-__global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+#ifdef ALIGN_TB_OCC      // experiment: ask for this many waves per SIMD (the kernel sits just above the register count of the next step)
+#define ALIGN_TB_ATTR __attribute__((amdgpu_waves_per_eu(ALIGN_TB_OCC, ALIGN_TB_OCC)))
+#else
+#define ALIGN_TB_ATTR
+#endif
+__global__ void __launch_bounds__(64) ALIGN_TB_ATTR align_tb_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
     const int li = blockIdx.x * 64 + threadIdx.x;
     const int g = li < nlist ? list[li] : -1;
     int m = 0, n = 0, g0 = 0, c = 0;
@@ -589,9 +586,8 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
     uint16_t *ops = P.ops + (g >= 0 ? P.ops_base[c] + (int64_t)(g - g0) * (m + 1) : 0);
     int i = m, j = n;
     bool fail = false;
-    __shared__ __attribute__((aligned(32))) uint16_t s_stage[64 * TB_STRIDE];
     OpsOut out;
-    out.init(ops, s_stage + threadIdx.x * TB_STRIDE, m);
+    out.init(ops, m);
     const int Kmax = (nmax + AL_STRIP - 1) / AL_STRIP;
     // software pipeline over the strips (last to first): the check point of strip k-2, the boundary record and the row bases of
     // strip k-1 and -- with the position the check point of strip k-1 gives -- its centre planes are fetched while strip k is
@@ -717,21 +713,17 @@ __global__ void __launch_bounds__(64) align_tb_kernel(AlignArgs P, const int32_t
             }
             if ((cc & 3) == 0) tcur -= (int)(((sbits >> (2 * (cc >> 2))) & 3u) << 2);
         }
-        out.drain();
         }
         ckA0 = ckB0; ckA1 = ckB1; ckB0 = ckC0; ckB1 = ckC1; bdA0 = bdB0; bdA1 = bdB1;
 #pragma unroll
         for (int w = 0; w < 4; w++) plA[w] = plB[w];
     }
-    const bool good = n > 0 && !fail;
-    if (n > 0 && fail) P.st[g] = 1;
-    // the rest of the row: gaps down to position 0, drained every 64 positions (a lane cannot hold more than its ring)
-    while (__any(good && i > 0)) {
-        if (good) for (int x = 0; x < 64 && i > 0; x++) { out.push(i - 1, 0x8000u); i--; }
-        out.drain();
-    }
-    if (good) {
-        for (int x = 0; x < out.low; x++) out.ops[x] = out.lds[(x + out.off) & (TB_RING - 1)];
+    if (n > 0) {
+        if (fail) P.st[g] = 1;
+        else {
+            for (int q = i - 1; q >= 0; q--) out.push(q, 0x8000u);
+            out.finish();
+        }
     }
 }
 

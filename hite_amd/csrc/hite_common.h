@@ -70,6 +70,7 @@ struct hite_ctx {
     void *aux_join[HITE_AUX_STREAMS];
     // fused fill + judge (hite_pipeline.hip -> hite_judge.hip): the pipeline classifies the alignments (hite_judge_classify_dev),
     // leaves the LDS classes out of the fill and hands the judge what it needs to build them in LDS
+    int32_t seed_rank, seed_world;  // hite_seed_shard: the share of the all-vs-all stage this context computes (world 0: all of it)
     const uint8_t *d_judge_cls;     // per alignment: JUDGE_CLS_* (NULL: hite_judge_dev classifies by itself)
     JudgeFuse judge_fuse;           // win == NULL: the LDS classes copy their alignment from d_msa
 };

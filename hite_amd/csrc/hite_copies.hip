@@ -1068,20 +1068,44 @@ __global__ void seed_rid_fix_kernel(int64_t M, const int32_t *__restrict__ flag,
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) rid[i] = rid[i] + flag[i] - 1;
 }
-// per seed (position order): partners = run size - 1 (0 when the run is too large)
-__global__ void seed_count_kernel(int64_t M, const unsigned *__restrict__ rank, const int64_t *__restrict__ rid,
-                                  const unsigned *__restrict__ run_first, int32_t *__restrict__ cnt) {
+// Sharding of the all-vs-all stage over ranks (hite_seed_shard; hite_amd/dist.py): a rank keeps the anchors whose sort key
+// (strand | diagonal) lies in its range.  Clusters never straddle two ranges (a cluster lives inside one 64-diagonal bucket and
+// the range edges are multiples of 64), so the clusters -- and the HSPs -- of the ranks together are exactly those of one
+// unsharded run, in the same order when the ranks are concatenated.  lin = strand * 2 G + diagonal in [0, 4 G).
+struct SeedShard { unsigned long long lo, hi; long long twoG; };      // lin in [lo, hi); hi == 0: unsharded
+__device__ __forceinline__ bool seed_owned(const SeedShard &sh, unsigned long long rel, unsigned long long d) {
+    if (sh.hi == 0ull) return true;
+    const unsigned long long lin = (rel ? (unsigned long long)sh.twoG : 0ull) + d;
+    return lin >= sh.lo && lin < sh.hi;
+}
+// per seed (position order): partners = run size - 1 (0 when the run is too large); sharded: the partners whose anchor this rank owns
+__global__ void seed_count_kernel(int64_t M, int64_t G, const unsigned *__restrict__ rank, const int64_t *__restrict__ rid,
+                                  const unsigned *__restrict__ run_first, const unsigned *__restrict__ idx_hs,
+                                  const unsigned *__restrict__ idx_pos, SeedShard sh, int32_t *__restrict__ cnt) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M) return;
     const unsigned i = rank[t];
     const int64_t r = rid[i];
-    const unsigned occ = run_first[r + 1] - run_first[r];
-    cnt[t] = occ > SEED_MAXOCC ? 0 : (int32_t)(occ - 1);
+    const unsigned lo = run_first[r], hi = run_first[r + 1];
+    const unsigned occ = hi - lo;
+    if (occ > SEED_MAXOCC) { cnt[t] = 0; return; }
+    if (sh.hi == 0ull) { cnt[t] = (int32_t)(occ - 1); return; }
+    const unsigned hq = idx_hs[i];
+    const long long pi = idx_pos[i];
+    int c = 0;
+    for (unsigned j = lo; j < hi; j++) {
+        if (j == i) continue;
+        const unsigned long long rel = (hq ^ idx_hs[j]) & 1u;
+        const long long pj = idx_pos[j];
+        c += seed_owned(sh, rel, rel ? (unsigned long long)(pi + pj) : (unsigned long long)(pj - pi + G));
+    }
+    cnt[t] = c;
 }
 __global__ void seed_anchor_kernel(int64_t M, int64_t G, const unsigned *__restrict__ rank, const int64_t *__restrict__ rid,
                                    const unsigned *__restrict__ run_first, const unsigned *__restrict__ idx_hs,
                                    const unsigned *__restrict__ idx_pos, const int32_t *__restrict__ cnt,
-                                   const int64_t *__restrict__ aoff, unsigned long long *__restrict__ akey, unsigned *__restrict__ aval) {
+                                   const int64_t *__restrict__ aoff, SeedShard sh, unsigned long long *__restrict__ akey,
+                                   unsigned *__restrict__ aval) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M || cnt[t] <= 0) return;
     const unsigned i = rank[t];
@@ -1095,6 +1119,7 @@ __global__ void seed_anchor_kernel(int64_t M, int64_t G, const unsigned *__restr
         const unsigned long long rel = (hq ^ idx_hs[j]) & 1u;
         const long long pj = idx_pos[j];
         const unsigned long long d = rel ? (unsigned long long)(pi + pj) : (unsigned long long)(pj - pi + G);
+        if (!seed_owned(sh, rel, d)) continue;
         akey[o] = (rel << 34) | d;
         aval[o] = (unsigned)pi;
         o++;
@@ -1182,6 +1207,41 @@ __global__ void seed_gather_kernel(int64_t n, const unsigned *__restrict__ perm,
     if (i >= n) return;
     const unsigned s = perm[i];
     o_qseg[i] = i_qseg[s]; o_sseg[i] = i_sseg[s]; o_qs[i] = i_qs[s]; o_qe[i] = i_qe[s]; o_ss[i] = i_ss[s]; o_se[i] = i_se[s];
+}
+
+// >>> seed_shard (the twin, oracle/hite_oracle_copies.c, carries the same arithmetic)
+// Range of rank r of `world` in lin = strand * 2 G + diagonal.  Diagonals of two uniform positions have a triangular density
+// (difference for the forward strand, sum for the reverse one, both peaking at G), so the edges sit at equal steps of its
+// distribution function, not of the diagonal: mass t in [0, 1) of one strand lies below G sqrt(2 t) (t <= 1/2) or
+// 2 G - G sqrt(2 (1 - t)).  Edges are rounded down to multiples of 64 (a cluster never leaves its 64-diagonal bucket).
+static unsigned long long seed_shard_edge(long long G, int k, int world) {     // lower edge of rank k (k == world: the end)
+    if (k <= 0) return 0ull;
+    if (k >= world) return 4ull * (unsigned long long)G + 64ull;
+    const double mass = 2.0 * (double)k / (double)world;                        // over both strands
+    const int strand = mass >= 1.0 ? 1 : 0;
+    const double t = mass - (double)strand;
+    const double d = t <= 0.5 ? (double)G * sqrt(2.0 * t) : 2.0 * (double)G - (double)G * sqrt(2.0 * (1.0 - t));
+    unsigned long long e = (unsigned long long)(d < 0 ? 0 : d);
+    e &= ~63ull;
+    return (strand ? 2ull * (unsigned long long)G : 0ull) + e;
+}
+// <<< seed_shard
+static SeedShard seed_shard_of(hite_ctx *ctx, long long G) {
+    SeedShard s; s.lo = 0ull; s.hi = 0ull; s.twoG = 2 * G;
+    if (ctx->seed_world > 1) {
+        // (2 G must be a multiple of 64 for the strand border to be a bucket border: the forward keys end below 2 G anyway)
+        s.lo = seed_shard_edge(G, ctx->seed_rank, ctx->seed_world);
+        s.hi = seed_shard_edge(G, ctx->seed_rank + 1, ctx->seed_world);
+        if (s.hi <= s.lo) s.hi = s.lo + 1;      // (an empty range still has to read as "sharded")
+    }
+    return s;
+}
+// hite_seed_allvsall[_dev] of this context keeps the share of rank `rank` of `world` (world <= 1: everything; the default)
+extern "C" int hite_seed_shard(hite_ctx *ctx, int32_t rank, int32_t world) {
+    if (!ctx || world < 0 || (world > 1 && (rank < 0 || rank >= world))) return HITE_EINVAL;
+    ctx->seed_rank = world > 1 ? rank : 0;
+    ctx->seed_world = world > 1 ? world : 0;
+    return HITE_OK;
 }
 
 // segment table of the packed genome (host side): per contig ceil(len / seg_len) segments, ids in contig order
@@ -1274,7 +1334,8 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     hipLaunchKernelGGL(seed_rid_fix_kernel, CGRID(M), 0, st, M, rflag, rid);
     CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); cnt = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 8, &p)); aoff = (int64_t *)p;
-    hipLaunchKernelGGL(seed_count_kernel, CGRID(M), 0, st, M, rank, rid, run_first, cnt);
+    const SeedShard shard = seed_shard_of(ctx, G);
+    hipLaunchKernelGGL(seed_count_kernel, CGRID(M), 0, st, M, G, rank, rid, run_first, S->idx_hs, S->idx_pos, shard, cnt);
     CCHK(scan_excl_buf<int32_t>(ctx, bs, cnt, M, aoff, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, aoff + M, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
@@ -1285,7 +1346,7 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     unsigned long long *akey; unsigned *aval;
     CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 8, &p)); akey = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 4, &p)); aval = (unsigned *)p;
-    hipLaunchKernelGGL(seed_anchor_kernel, CGRID(M), 0, st, M, G, rank, rid, run_first, S->idx_hs, S->idx_pos, cnt, aoff, akey, aval);
+    hipLaunchKernelGGL(seed_anchor_kernel, CGRID(M), 0, st, M, G, rank, rid, run_first, S->idx_hs, S->idx_pos, cnt, aoff, shard, akey, aval);
     {
         Sorter so;
         CCHK(sorter_from_arena(so, ctx, A, st, na));

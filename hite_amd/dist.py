@@ -177,3 +177,107 @@ def allgather_library(seqs, device="cpu", group=None):
     out = [all_pool[off[i]:off[i + 1]].tobytes() for i in range(len(all_lens))]
     ranks = np.repeat(np.arange(len(counts)), counts)
     return out, ranks
+
+
+# ---- stage 3.1 (coarse_boundary) sharded over the ranks of a node ------------------------------------------
+# The reference's units are the query FILES of the all-vs-all search: every get_longest_repeats_v4 call has its own first-come
+# de-duplication and the results are unioned by name in file order (Util.py:4155, 4787-4794).  With the packed genome and its
+# minimizer index replicated on every GPU:
+#   1. seeding: rank r computes the HSPs of ITS share of the anchors -- a range of (strand, diagonal) whose edges never cut a
+#      cluster (hite_seed_shard) -- so the union over the ranks is the unsharded table, record for record;
+#   2. ONE all-to-all of 48-byte HSP records routes every record to the owner of its query file (files dealt round-robin);
+#      the owner puts the pieces in rank order and sorts them stably by (query segment, subject segment): its slice of the
+#      unsharded table, in the unsharded order (FMEA is order dependent);
+#   3. FMEA per owned query file (hite_fmea_chain);
+#   4. ONE all-gather of the interval lists (file id, contig, start, end), merged in file order, first name wins -- the
+#      reference's dict union.
+# The result equals the single-rank result by construction; tests/test_dist_gloo.py checks it on two gloo ranks with the CPU twins.
+def query_files_of_segments(seg_len_each, base_threshold=1_000_000):
+    """split_and_store_sequences (Util.py:4987) on the segment lengths: consecutive segments are collected until their total
+    reaches base_threshold -> file id of every segment"""
+    out = np.zeros(len(seg_len_each), dtype=np.int64)
+    f, count = 0, 0
+    for i, L in enumerate(seg_len_each):
+        out[i] = f
+        count += int(L)
+        if count >= base_threshold:
+            f += 1
+            count = 0
+    return out
+
+
+def _exchange_rows(rows, dest, group=None, device="cpu"):
+    """rows: int64 [n, k]; dest: rank of every row -> the rows sent to this rank by all ranks, in source-rank order (the order
+    inside a source is kept).  all_to_all_single where the backend has it (RCCL), else a padded all-gather (gloo)."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    k = rows.shape[1] if rows.ndim == 2 else 1
+    order = np.argsort(dest, kind="stable")
+    send = np.ascontiguousarray(rows[order])
+    counts = np.bincount(dest, minlength=world).astype(np.int64)
+    t_counts = torch.from_numpy(counts).to(device)
+    all_counts = torch.empty(world * world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(all_counts, t_counts, group=group)
+    all_counts = all_counts.cpu().numpy().reshape(world, world)          # [source, destination]
+    recv_counts = all_counts[:, rank]
+    t_send = torch.from_numpy(send.reshape(-1)).to(device)
+    if dist.get_backend(group) == "nccl":
+        t_recv = torch.empty(int(recv_counts.sum()) * k, dtype=torch.int64, device=device)
+        dist.all_to_all_single(t_recv, t_send, output_split_sizes=[int(c) * k for c in recv_counts],
+                               input_split_sizes=[int(c) * k for c in counts], group=group)
+        return t_recv.cpu().numpy().reshape(-1, k)
+    gathered, sizes = allgather_varlen(t_send, group)
+    gathered = gathered.cpu().numpy().reshape(-1, k)
+    src_first = np.concatenate([[0], np.cumsum(all_counts.sum(axis=1))])
+    parts = []
+    for src in range(world):
+        a = src_first[src] + int(all_counts[src, :rank].sum())
+        parts.append(gathered[a:a + int(all_counts[src, rank])])
+    return np.concatenate(parts) if parts else gathered[:0]
+
+
+def coarse_stage_sharded(ctx, seg_len, skip_gap, max_len, group=None, device="cpu", base_threshold=1_000_000):
+    """stage 3.1 on the genome resident in `ctx` (the same on every rank), sharded as described above.
+    -> (contig ids, starts, ends) of the repeat intervals in the single-rank order, identical on every rank.
+    Without an initialised process group: the single-rank computation (the same code path, no collectives)."""
+    multi = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if multi else 1
+    rank = dist.get_rank(group) if multi else 0
+    seg_chrom, seg_off = ctx.seed_segments(seg_len)
+    clen = np.asarray(ctx.contig_len, dtype=np.int64)
+    seg_lens = np.minimum(seg_len, clen[seg_chrom] - seg_off)
+    file_of = query_files_of_segments(seg_lens, base_threshold)
+    n_files = int(file_of[-1]) + 1 if len(file_of) else 0
+    ctx.seed_shard(rank, world)
+    try:
+        tab = ctx.seed_allvsall(seg_len=seg_len)
+    finally:
+        ctx.seed_shard(0, 0)
+    rows = np.stack([np.asarray(tab[k], dtype=np.int64) for k in ("qseg", "sseg", "qs", "qe", "ss", "se")], axis=1) if len(tab["qseg"]) \
+        else np.zeros((0, 6), dtype=np.int64)
+    if multi and world > 1:
+        rows = _exchange_rows(rows, (file_of[rows[:, 0]] % world).astype(np.int64), group, device)
+    order = np.argsort(rows[:, 0] * (len(seg_chrom) + 1) + rows[:, 1], kind="stable")
+    rows = rows[order]
+    fkey = file_of[rows[:, 0]] if len(rows) else np.zeros(0, dtype=np.int64)
+    out_f, out_c, out_s, out_e = [], [], [], []
+    for f in range(rank, n_files, world):
+        a, b = np.searchsorted(fkey, f, "left"), np.searchsorted(fkey, f, "right")
+        if b <= a:
+            continue
+        r = rows[a:b]
+        oc, os_, oe = ctx.fmea_chain(r[:, 0], r[:, 1], r[:, 2], r[:, 3], r[:, 4], r[:, 5], seg_chrom, seg_off, skip_gap, max_len)
+        out_f.append(np.full(len(oc), f, dtype=np.int64)); out_c.append(np.asarray(oc, dtype=np.int64))
+        out_s.append(np.asarray(os_, dtype=np.int64)); out_e.append(np.asarray(oe, dtype=np.int64))
+    mine = np.stack([np.concatenate(x) if x else np.zeros(0, dtype=np.int64) for x in (out_f, out_c, out_s, out_e)], axis=1)
+    if multi and world > 1:
+        allv, _ = allgather_varlen(torch.from_numpy(np.ascontiguousarray(mine).reshape(-1)).to(device), group)
+        mine = allv.cpu().numpy().reshape(-1, 4)
+    mine = mine[np.argsort(mine[:, 0], kind="stable")]          # file order; inside a file the owner's order
+    seen, keep = set(), []
+    for i, (_f, c, s_, e_) in enumerate(mine.tolist()):
+        if (c, s_, e_) not in seen:
+            seen.add((c, s_, e_))
+            keep.append(i)
+    mine = mine[keep]
+    return mine[:, 1].astype(np.int32), mine[:, 2].copy(), mine[:, 3].copy()

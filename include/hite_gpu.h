@@ -293,6 +293,13 @@ int hite_copy_stats_ext(void *state, int64_t out[8]);
 int hite_seed_allvsall_dev(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int32_t **d_qseg, int32_t **d_sseg,
                            int64_t **d_qs, int64_t **d_qe, int64_t **d_ss, int64_t **d_se, int64_t *n_out, int64_t *stats_out);
 int hite_seed_segments(hite_ctx *ctx, int64_t seg_len, int32_t cap, int32_t *seg_chrom, int64_t *seg_off, int32_t *nseg_out);
+/* Sharding of the all-vs-all stage over the ranks of a node (one process per GPU, the packed genome replicated):
+ * after hite_seed_shard(ctx, rank, world) the seeding calls of this context emit the HSPs of rank's share only -- the
+ * anchors whose (strand, diagonal) falls into the rank's range; clusters never straddle two ranges, so the tables of the
+ * ranks, concatenated in rank order and stably sorted by (query segment, subject segment), are the unsharded table record
+ * for record.  world <= 1 restores the whole.  hite_amd/dist.py routes the records to the owners of the query files
+ * (all-to-all), runs hite_fmea_chain per file there and all-gathers the interval lists. */
+int hite_seed_shard(hite_ctx *ctx, int32_t rank, int32_t world);
 int hite_seed_allvsall(hite_ctx *ctx, void **state_io, int64_t seg_len, int64_t max_anchors, int64_t cap, int32_t *qseg,
                        int32_t *sseg, int64_t *qs, int64_t *qe, int64_t *ss, int64_t *se, int64_t *n_out, int64_t *stats_out);
 int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,

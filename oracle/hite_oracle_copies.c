@@ -44,6 +44,7 @@
  */
 #define _POSIX_C_SOURCE 199309L
 #include <stdint.h>
+#include <math.h>
 #include <time.h>
 #include <stdlib.h>
 #include <string.h>
@@ -430,10 +431,34 @@ int orc_seed_segments(const int64_t *contig_off, int ncontig, int64_t seg_len, i
     return n;
 }
 
+/* Sharding over ranks (mirror of hite_seed_shard, hite_amd/csrc/hite_copies.hip): a rank keeps the anchors whose
+ * lin = strand * 2 G + diagonal lies in its range; the edges sit at equal steps of the triangular distribution of the
+ * diagonals of two uniform positions and are multiples of 64, so that no cluster straddles two ranks: the HSPs of the ranks,
+ * concatenated in rank order, are those of one unsharded run in its order. */
+static int g_seed_rank = 0, g_seed_world = 0;
+void orc_seed_shard(int rank, int world) { g_seed_rank = world > 1 ? rank : 0; g_seed_world = world > 1 ? world : 0; }
+static uint64_t seed_shard_edge(int64_t G, int k, int world) {
+    if (k <= 0) return 0;
+    if (k >= world) return 4ull * (uint64_t)G + 64ull;
+    const double mass = 2.0 * (double)k / (double)world;
+    const int strand = mass >= 1.0 ? 1 : 0;
+    const double t = mass - (double)strand;
+    const double d = t <= 0.5 ? (double)G * sqrt(2.0 * t) : 2.0 * (double)G - (double)G * sqrt(2.0 * (1.0 - t));
+    uint64_t e = (uint64_t)(d < 0 ? 0 : d);
+    e &= ~63ull;
+    return (strand ? 2ull * (uint64_t)G : 0ull) + e;
+}
+
 int64_t orc_seed_allvsall(const uint8_t *genome, const int64_t *contig_off, int ncontig, int64_t seg_len, int64_t cap,
                           int32_t *qseg, int32_t *sseg, int64_t *qs, int64_t *qe, int64_t *ss, int64_t *se) {
     if (ncontig <= 0 || seg_len <= 0) return ORC_EINVAL;
     const int64_t G = contig_off[ncontig];
+    uint64_t sh_lo = 0, sh_hi = 0;
+    if (g_seed_world > 1) {
+        sh_lo = seed_shard_edge(G, g_seed_rank, g_seed_world);
+        sh_hi = seed_shard_edge(G, g_seed_rank + 1, g_seed_world);
+        if (sh_hi <= sh_lo) sh_hi = sh_lo + 1;
+    }
     int64_t M = 0;
     for (int c = 0; c < ncontig; c++) M += minimizers(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], NULL);
     mini_t *idx = (mini_t *)malloc(sizeof(mini_t) * (M + 1)), *byp = (mini_t *)malloc(sizeof(mini_t) * (M + 1));
@@ -463,6 +488,7 @@ int64_t orc_seed_allvsall(const uint8_t *genome, const int64_t *contig_off, int 
             if (na == acap) { acap *= 2; an = (anchor_t *)realloc(an, sizeof(anchor_t) * acap); }
             uint64_t rel = (byp[t].hs ^ idx[i].hs) & 1u;
             uint64_t d = rel ? (uint64_t)(byp[t].pos + idx[i].pos) : (uint64_t)(idx[i].pos - byp[t].pos + G);
+            if (sh_hi) { const uint64_t lin = (rel ? 2ull * (uint64_t)G : 0ull) + d; if (lin < sh_lo || lin >= sh_hi) continue; }
             an[na].key = (rel << 34) | d; an[na].pi = (uint32_t)byp[t].pos; an[na].ord = na;
             na++;
         }

@@ -14,14 +14,47 @@ class OracleCtx:
     # ---- residency ------------------------------------------------------------------------------
     def genome_pack(self, contigs):
         self.contigs = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]
+        self.contig_len = np.asarray([len(c) for c in self.contigs], dtype=np.int64)
 
     def release_copy_index(self):
         pass
 
     # ---- stages ---------------------------------------------------------------------------------
+    def seed_shard(self, rank, world):
+        self._shard = (int(rank), int(world))
+
     def seed_allvsall(self, seg_len=1_000_000, max_anchors=None, cap=None):
-        t = O.seed_allvsall(self.contigs, seg_len)
+        r, w = getattr(self, "_shard", (0, 0))
+        O.lib().orc_seed_shard(r, w)
+        try:
+            t = O.seed_allvsall(self.contigs, seg_len)
+        finally:
+            O.lib().orc_seed_shard(0, 0)
         return {k: t[k] for k in ("qseg", "sseg", "qs", "qe", "ss", "se")}
+
+    def seed_segments(self, seg_len=1_000_000):
+        import numpy as _np
+        sc, so = [], []
+        for ci, c in enumerate(self.contigs):
+            nseg = max(1, (len(c) + seg_len - 1) // seg_len)
+            for k in range(nseg):
+                sc.append(ci); so.append(k * seg_len)
+        return _np.asarray(sc, dtype=_np.int32), _np.asarray(so, dtype=_np.int64)
+
+    def fmea_chain(self, qseg, sseg, qs, qe, ss, se, seg_chrom, seg_off, skip_gap, max_len):
+        import numpy as _np
+        nchrom = int(max(seg_chrom)) + 1 if len(seg_chrom) else 1
+        i32 = lambda x: _np.ascontiguousarray(x, dtype=_np.int32)  # noqa: E731
+        i64 = lambda x: _np.ascontiguousarray(x, dtype=_np.int64)  # noqa: E731
+        h = {"qseg": i32(qseg), "sseg": i32(sseg), "qs": i64(qs), "qe": i64(qe), "ss": i64(ss), "se": i64(se), "seg_chrom": _np.asarray(seg_chrom, dtype=_np.int32), "seg_off": _np.asarray(seg_off, dtype=_np.int64),
+             "chrom_names": ["c%d" % i for i in range(nchrom)]}
+        names = O.fmea(h, skip_gap, max_len)
+        oc, os_, oe = [], [], []
+        for nm in names:
+            c, pos = nm.split(":")
+            a, b = pos.split("-")
+            oc.append(int(c[1:])); os_.append(int(a)); oe.append(int(b))
+        return _np.asarray(oc, dtype=_np.int32), _np.asarray(os_, dtype=_np.int64), _np.asarray(oe, dtype=_np.int64)
 
     def query_copies(self, qid, sid, qs, qe, ss, se, ident, qlen, slen=None, ns=None, qcov=0.95, scov=0.0, qthr=200, sthr=200, max_copy=100):
         n = len(qid)

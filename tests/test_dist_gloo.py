@@ -284,3 +284,65 @@ def test_allgather_library_world2():
     for rank, _mine, lib, ranks in res:
         assert lib == expect
         assert ranks == [0] * len(res[0][1]) + [1] * len(res[1][1])
+
+
+# ---- stage 3.1 sharded over ranks: anchors by diagonal range, HSPs to the owners of the query files, intervals gathered ---------
+def _coarse_genome():
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import synth_small
+
+    return synth_small.make(31, n_fam=14, n_chr=3, chr_len=150_000)["contigs"]
+
+
+def _coarse_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hite_amd import dist as hd
+    from oracle_ctx import OracleCtx
+
+    ctx = OracleCtx()
+    ctx.genome_pack(_coarse_genome())
+    ctx.seed_shard(rank, world)
+    share = len(ctx.seed_allvsall(seg_len=50_000)["qseg"])          # this rank's share of the HSP table
+    ctx.seed_shard(0, 0)
+    oc, os_, oe = hd.coarse_stage_sharded(ctx, 50_000, 2000, 30000, base_threshold=100_000)
+    q.put((rank, share, oc.tolist(), os_.tolist(), oe.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_coarse_stage_sharded_world2():
+    """stage 3.1 over two ranks: each rank seeds its range of (strand, diagonal), the HSP records go to the owners
+    of the query files, FMEA runs per file, the interval lists are gathered -- the result on every rank is the single-rank
+    result, interval for interval and in its order.  Device stages = the CPU twins (tests/oracle_ctx.py)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hite_amd import dist as hd
+    from oracle_ctx import OracleCtx
+
+    ctx1 = OracleCtx()
+    ctx1.genome_pack(_coarse_genome())
+    whole = len(ctx1.seed_allvsall(seg_len=50_000)["qseg"])
+    oc, os_, oe = hd.coarse_stage_sharded(ctx1, 50_000, 2000, 30000, base_threshold=100_000)      # no process group: one rank
+    expect = (oc.tolist(), os_.tolist(), oe.tolist())
+    assert len(expect[0]) >= 20
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_coarse_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res[0][1] + res[1][1] == whole and min(res[0][1], res[1][1]) > 0.15 * whole     # a partition of the table, both parts real
+    for _rank, _share, c, a, b in res:
+        assert (c, a, b) == expect

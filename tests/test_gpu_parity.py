@@ -1461,3 +1461,41 @@ def test_chain_variants_golden_on_gpu(ctx, tmp_path):
         assert got == exp, trial
         assert sum(len(x) for x in got) > 10
     assert ctx.chain_all([], [], [], [], [], [], 3, 2, [5, 5, 5]) == [[], [], []]
+
+
+def test_seed_shard_partitions_the_hsp_table(ctx):
+    """hite_seed_shard (hite_amd/dist.py coarse_stage_sharded): the shares of three ranks, computed one after the
+    other on the one GPU, are each the twin's share, and together -- concatenated in rank order, stably sorted by (query
+    segment, subject segment) -- the unsharded HSP table record for record; the sharded stage as one rank runs it gives the
+    intervals of the stage computed directly"""
+    import synth_small
+    from hite_amd import dist as hd
+    from oracle_ctx import OracleCtx
+
+    g = synth_small.make(31, n_fam=14, n_chr=3, chr_len=150_000)
+    ctx.genome_pack(g["contigs"])
+    ctx.release_copy_index()
+    keys = ("qseg", "sseg", "qs", "qe", "ss", "se")
+    whole = ctx.seed_allvsall(seg_len=50_000)
+    tw = OracleCtx()
+    tw.genome_pack(g["contigs"])
+    parts = []
+    try:
+        for r in range(3):
+            ctx.seed_shard(r, 3)
+            tw.seed_shard(r, 3)
+            part = ctx.seed_allvsall(seg_len=50_000)
+            twin = tw.seed_allvsall(seg_len=50_000)
+            for k in keys:
+                assert np.array_equal(part[k], twin[k]), (r, k)
+            assert len(part["qseg"]) > 0
+            parts.append(np.stack([np.asarray(part[k], dtype=np.int64) for k in keys], axis=1))
+    finally:
+        ctx.seed_shard(0, 0)
+    rows = np.concatenate(parts)
+    rows = rows[np.argsort(rows[:, 0] * 100000 + rows[:, 1], kind="stable")]
+    for i, k in enumerate(keys):
+        assert np.array_equal(rows[:, i], np.asarray(whole[k], dtype=np.int64)), k
+    oc, os_, oe = hd.coarse_stage_sharded(ctx, 50_000, 2000, 30000, base_threshold=100_000)
+    tc, ts, te = hd.coarse_stage_sharded(tw, 50_000, 2000, 30000, base_threshold=100_000)
+    assert (oc.tolist(), os_.tolist(), oe.tolist()) == (tc.tolist(), ts.tolist(), te.tolist()) and len(oc) >= 20
