@@ -521,6 +521,26 @@ __global__ void __launch_bounds__(64) align_fwd8_pair_kernel(AlignArgs P, const 
 // crossed its edge: 3.3 GB, 17.4 ms (the flush ran for one lane on most steps); a ring of 128 positions per lane in LDS
 // drained once per strip by all lanes: 3.1 GB, 16.0 ms; this one: registers only.
 typedef unsigned int tb_u32x4 __attribute__((ext_vector_type(4)));
+#if defined(ALIGN_TB_STORE8)
+// round 3's form: 8 bytes per four positions, groups aligned to the POSITION (kept for measurements)
+struct OpsOut {
+    uint16_t *ops;
+    unsigned long long acc, top;
+    int m;
+    __device__ __forceinline__ void init(uint16_t *row, int m_) { ops = row; m = m_; acc = 0ull; top = 0ull; }
+    __device__ __forceinline__ void push(int pos, uint32_t val) {
+        acc = (acc << 16) | (unsigned long long)(val & 0xffffu);
+        if ((pos & 3) == 0) {
+            if (pos + 4 <= m) *reinterpret_cast<unsigned long long *>(ops + pos) = acc;
+            else top = acc;
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        const int k = m & 3, p0 = m & ~3;
+        for (int x = 0; x < k; x++) ops[p0 + x] = (uint16_t)(top >> (16 * x));
+    }
+};
+#elif defined(ALIGN_TB_STORE32)
 struct OpsOut {
     uint16_t *ops;           // the lane's row
     unsigned long long acc;  // the group of four being collected (newest = lowest position in the low 16 bits)
@@ -564,6 +584,47 @@ struct OpsOut {
         for (int x = 0; x < top; x++) ops[x] = held(x + off, off);
     }
 };
+
+#else
+// 16 bytes per eight positions, chunks aligned in MEMORY (q = position + the row's phase, q % 8 == 0 starts a chunk): half a
+// sector per store, never straddling two -- the traffic of the 8-byte form halves at its instruction count.  The walk itself
+// only ever stores whole chunks; the partial chunks at the two ends of a row are kept in registers and written at the end.
+struct OpsOut {
+    uint16_t *ops;
+    unsigned long long acc, hi;   // the group of four being collected; the complete upper group of the chunk being collected
+    unsigned long long tacc, thi; // the topmost chunk of the row when it is partial
+    int m, off;                   // off = (address of ops[0] / 2) mod 8
+    __device__ __forceinline__ void init(uint16_t *row, int m_) {
+        ops = row; m = m_; acc = 0ull; hi = 0ull; tacc = 0ull; thi = 0ull;
+        off = (int)((reinterpret_cast<uintptr_t>(row) >> 1) & 7);
+    }
+    __device__ __forceinline__ void push(int pos, uint32_t val) {
+        acc = (acc << 16) | (unsigned long long)(val & 0xffffu);
+        const int q = pos + off;
+        if ((q & 3) == 0) {
+            if (q & 4) hi = acc;
+            else if (pos + 8 <= m) {
+                tb_u32x4 v;
+                v.x = (unsigned)acc; v.y = (unsigned)(acc >> 32); v.z = (unsigned)hi; v.w = (unsigned)(hi >> 32);
+                *reinterpret_cast<tb_u32x4 *>(ops + pos) = v;                 // 16-byte aligned
+            } else { tacc = acc; thi = hi; }
+        }
+    }
+    __device__ __forceinline__ void finish() {   // after position 0 has been pushed
+        // the topmost chunk [t0, m), t0 = the chunk edge at or below m (nothing when m sits on an edge)
+        const int t0 = m - ((m + off) & 7);
+        if (t0 >= 0) for (int x = t0; x < m; x++) { const int qq = x + off; ops[x] = (uint16_t)(((qq & 4) ? thi : tacc) >> (16 * (qq & 3))); }
+        // what lies below the lowest chunk edge b0 (when the row does not even reach it, the chunk [.., m) is the one above: t0 < 0)
+        const int b0 = (8 - off) & 7;
+        const int lowm = b0 < m ? b0 : m;
+        for (int x = 0; x < lowm; x++) {
+            const int qq = x + off;
+            const bool in_acc = (off & 3) != 0 && (qq >> 2) == (off >> 2);        // the group position 0 sits in was never completed
+            ops[x] = in_acc ? (uint16_t)(acc >> (16 * x)) : (uint16_t)(hi >> (16 * (qq & 3)));
+        }
+    }
+};
+#endif
 
 #ifdef ALIGN_TB_OCC      // experiment: ask for this many waves per SIMD (the kernel sits just above the register count of the next step)
 #define ALIGN_TB_ATTR __attribute__((amdgpu_waves_per_eu(ALIGN_TB_OCC, ALIGN_TB_OCC)))
