@@ -308,12 +308,12 @@ def main():
             traffic = None
             try:
                 pmc, pmc_src = _kept_profile("pmc_traffic.json")
-                names = {"align_fwd4": ["align_fwd_kernel<4>"], "align_tb": ["align_tb_kernel"],
+                names = {"align_fwd4": ["align_fwd4_kernel", "align_fwd_kernel<4>"], "align_tb": ["align_tb_kernel"],
                          "align_fwd_wide": ["align_fwd_kernel<8>", "align_fwd_kernel<16>", "align_fwd_kernel<32>"],
                          "radix_sort_hits": ["rs_scatter_staged_kernel", "rs_hist_kernel<10, 32>"],
                          "judge_kernel": ["jblk::judge_kernel", "jwav::judge_wave_kernel"]}.get(dom, [dom])
                 tot = sum(pmc[k_]["bytes_per_launch"] * pmc[k_]["launches"] for k_ in names if k_ in pmc)
-                runs = pmc.get(names[0], {}).get("launches", 0)
+                runs = max([pmc.get(k_, {}).get("launches", 0) for k_ in names] + [0])
                 traffic = int(tot / runs) if tot and runs else None      # per launch of the stage
             except Exception:
                 traffic = None

@@ -176,9 +176,39 @@ __global__ void __launch_bounds__(256) align_planes_kernel(int n_cand, const uin
 // ---------------------------------------------------------------------------------------------
 // forward pass
 // ---------------------------------------------------------------------------------------------
+#ifdef ALIGN_CLOCKS
+// development aid (-DALIGN_CLOCKS, tools/align_wave_hist.py): start / end of every wavefront of the last align_fwd_kernel<4> and
+// align_tb_kernel launches on the constant 100 MHz clock, + the SIMD it ran on -- separates the tail of the longest wavefronts
+// from stalls inside them
+#define ALIGN_CLK_MAX (1 << 17)
+__device__ unsigned long long g_aclk[2][4][ALIGN_CLK_MAX];     // start, end, xcc << 16 | hw_id, columns of the longest lane
+extern "C" int hite_debug_align_clocks(int which, unsigned long long *out, int n) {
+    if (which < 0 || which > 1 || n > ALIGN_CLK_MAX) return -1;
+    for (int k = 0; k < 4; k++)
+        if (hipMemcpyFromSymbol(out + (size_t)k * n, HIP_SYMBOL(g_aclk), sizeof(unsigned long long) * n,
+                                ((size_t)which * 4 + k) * ALIGN_CLK_MAX * sizeof(unsigned long long)) != hipSuccess) return -1;
+    unsigned long long *z = (unsigned long long *)calloc((size_t)4 * ALIGN_CLK_MAX, sizeof(unsigned long long));      // next launch starts clean
+    if (z) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_aclk), z, sizeof(unsigned long long) * 4 * ALIGN_CLK_MAX, (size_t)which * 4 * ALIGN_CLK_MAX * sizeof(unsigned long long)); free(z); }
+    return 0;
+}
+__device__ __forceinline__ unsigned aclk_hw_id() {
+    unsigned v, x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(v));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    return ((x & 0xfu) << 16) | (v & 0xffffu);
+}
+#define ACLK_BEGIN(which) const unsigned long long aclk_t0 = wall_clock64(); const int aclk_w = (which)
+#define ACLK_END() do { if (threadIdx.x == 0 && blockIdx.x < ALIGN_CLK_MAX) { g_aclk[aclk_w][0][blockIdx.x] = aclk_t0; \
+    g_aclk[aclk_w][1][blockIdx.x] = wall_clock64(); g_aclk[aclk_w][2][blockIdx.x] = aclk_hw_id(); g_aclk[aclk_w][3][blockIdx.x] = (unsigned long long)nmax; } } while (0)
+#else
+#define ACLK_BEGIN(which) do { } while (0)
+#define ACLK_END() do { } while (0)
+#endif
+
 template <int NW>
-__global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+__device__ __forceinline__ void align_fwd_body(const AlignArgs &P, const int32_t *__restrict__ list, int nlist) {
     constexpr int W = 32 * NW, H = W / 2, S0 = NW / 2 - 1;
+    ACLK_BEGIN(0);
     const int li = blockIdx.x * 64 + threadIdx.x;
     const int g = li < nlist ? list[li] : -1;
     int m = 0, n = 0, g0 = 0, c = 0;
@@ -312,7 +342,21 @@ __global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_
         P.U[g] = U; P.kst[g] = kstar; P.st[g] = status; P.lvl[g] = NW;
         if (NW == 4) P.U4[g] = U;
     }
+    if (NW == 4) ACLK_END();
 }
+template <int NW>
+__global__ void __launch_bounds__(64) align_fwd_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) { align_fwd_body<NW>(P, list, nlist); }
+// the 4-word level (every pair runs it): its own kernel, so that its occupancy can be set apart from the wider levels'.
+// tools/align_wave_hist.py (profiles/r04_align_wave_hist.txt): a wavefront needs ~1100 ns per column with one neighbour on its
+// SIMD and ~1260 ns with three or four -- most of its time is its own dependency chain.  More wavefronts per SIMD do not pay for
+// their spills, though (C3, ms per step of this kernel): 5 per SIMD (96 registers, no spill) 13.8; 6 (80, 24 spilled) 14.6;
+// 7 (72, 44 spilled) 15.8.
+#ifdef ALIGN_FWD4_OCC
+#define ALIGN_FWD4_ATTR __attribute__((amdgpu_waves_per_eu(ALIGN_FWD4_OCC, ALIGN_FWD4_OCC)))
+#else
+#define ALIGN_FWD4_ATTR
+#endif
+__global__ void __launch_bounds__(64) ALIGN_FWD4_ATTR align_fwd4_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) { align_fwd_body<4>(P, list, nlist); }
 
 // ---------------------------------------------------------------------------------------------
 // the 8-word level with TWO LANES PER PAIR (lane 2i: words 0-3, lane 2i+1: words 4-7 of pair i).  The pairs that reach this
@@ -632,6 +676,7 @@ struct OpsOut {
 #define ALIGN_TB_ATTR
 #endif
 __global__ void __launch_bounds__(64) ALIGN_TB_ATTR align_tb_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    ACLK_BEGIN(1);
     const int li = blockIdx.x * 64 + threadIdx.x;
     const int g = li < nlist ? list[li] : -1;
     int m = 0, n = 0, g0 = 0, c = 0;
@@ -786,6 +831,7 @@ __global__ void __launch_bounds__(64) ALIGN_TB_ATTR align_tb_kernel(AlignArgs P,
             out.finish();
         }
     }
+    ACLK_END();
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1343,7 +1389,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     // ---- the 4-word band for every pair
     snprintf(name, sizeof name, "align_fwd4%s", tag ? tag : "");
     tk = hite_prof_begin(ctx, name, st);
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_kernel<4>), dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
+    hipLaunchKernelGGL(align_fwd4_kernel, dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
     hite_prof_end(ctx, tk, st);
     // ---- exact mode: wider bands for the pairs without a certificate, on a second stream, beside the traceback of the pairs
     //      whose 4-word run is final (the wider bands have few, long-running waves: alone they leave most SIMDs idle)

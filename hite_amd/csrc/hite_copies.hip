@@ -371,6 +371,90 @@ __global__ void hit_hist_kernel(int n_cand, const int64_t *__restrict__ q_first,
     atomicAdd(&out[5 + cls], (unsigned long long)k);
     atomicMax(&out[10], (unsigned long long)k);
 }
+// ---------------------------------------------------------------------------------------------
+// per-candidate sort of the hits.  The hits of a candidate are generated contiguously (hit_off[q_first[c]] ..), so the order
+// (candidate, strand, diagonal) only has to be established INSIDE every candidate's range: a workgroup loads the range into
+// LDS, sorts it there on the (strand | diagonal) field by a stable LSD radix sort (4-bit digits, two LDS buffers) and writes
+// it back in place -- one global read and one write of 8 bytes per hit where the global radix sort of round 3 made five
+// passes (5 x 16 B + histograms).  Three classes by hits per candidate (C3: <= 2048: 75 % of the candidates, 51 % of the hits;
+// <= 8192: 24 % / 45 %; above: 0.6 % / 3.6 %, profiles of round 3): 2 x 16 KB, 2 x 64 KB of LDS, and global ping-pong buffers
+// (the range against the sorter's spare array) for the rest.  Stable, like the global passes it replaces: the table is
+// the same, hit for hit.  (Packed 8-byte hits only; the 12-byte form keeps the global sort.)
+// ---------------------------------------------------------------------------------------------
+#define HS_SMALL 2048
+#define HS_MEDIUM 8192
+typedef __attribute__((address_space(3))) unsigned long long *hs_lptr;
+__global__ void hit_sort_classify_kernel(int n_cand, const int64_t *__restrict__ q_first, const int64_t *__restrict__ hit_off,
+                                         unsigned *__restrict__ counts /* 3 */, int32_t *__restrict__ lists /* 3 x n_cand */) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_cand) return;
+    const long long k = hit_off[q_first[c + 1]] - hit_off[q_first[c]];
+    if (k <= 1) return;
+    const int cls = k <= HS_SMALL ? 0 : (k <= HS_MEDIUM ? 1 : 2);
+    lists[(size_t)cls * n_cand + atomicAdd(&counts[cls], 1u)] = c;
+}
+// one stable pass on digit (key >> shift) & 15 from src to dst (n elements, all 256 threads of the block)
+template <class PS, class PD>
+__device__ __forceinline__ void hs_pass(PS src, PD dst, int n, int shift, unsigned *s_cnt /* 16 x 256 */, int *s_scan) {
+    const int t = threadIdx.x;
+    // a thread's chunk: contiguous (stability), of ODD length (consecutive lanes then start 2 E dwords apart: all banks, where an
+    // even length would put the 64 lanes of an 8-byte read on a handful of them)
+    const int E = ((n + 255) >> 8) | 1, b = t * E < n ? t * E : n, e = b + E < n ? b + E : n;
+    for (int k = 0; k < 16; k++) s_cnt[k * 256 + t] = 0u;
+    for (int i = b; i < e; i++) s_cnt[(int)((src[i] >> shift) & 15ull) * 256 + t]++;
+    __syncthreads();
+    // exclusive scan of the 4096 counters in (digit, thread) order: a thread takes 16 consecutive ones
+    unsigned v[16], sum = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; k++) { v[k] = s_cnt[t * 16 + k]; sum += v[k]; }
+    int tot;
+    unsigned run = (unsigned)block_excl_scan((int)sum, s_scan, &tot);
+#pragma unroll
+    for (int k = 0; k < 16; k++) { const unsigned x = v[k]; s_cnt[t * 16 + k] = run; run += x; }
+    __syncthreads();
+    for (int i = b; i < e; i++) {
+        const unsigned long long x = src[i];
+        dst[s_cnt[(int)((x >> shift) & 15ull) * 256 + t]++] = x;
+    }
+    __syncthreads();
+}
+template <int CAP /* elements per LDS buffer; 0: global ping-pong */>
+__global__ void __launch_bounds__(256) hit_segsort_kernel(const unsigned *__restrict__ count, const int32_t *__restrict__ list,
+                                                          const int64_t *__restrict__ q_first, const int64_t *__restrict__ hit_off,
+                                                          unsigned long long *__restrict__ hkey, unsigned long long *__restrict__ spare,
+                                                          int shift0, int bits) {
+    __shared__ unsigned s_cnt[16 * 256];
+    __shared__ int s_scan[8];
+    extern __shared__ __attribute__((aligned(16))) unsigned long long s_dyn[];
+    const unsigned cnt = *count;
+    const int passes = (bits + 3) / 4;
+    for (unsigned it = blockIdx.x; it < cnt; it += gridDim.x) {
+        const int c = list[it];
+        const int64_t o = hit_off[q_first[c]];
+        const int n = (int)(hit_off[q_first[c + 1]] - o);
+        unsigned long long *g = hkey + o;
+        if (CAP > 0) {
+            hs_lptr a = (hs_lptr)s_dyn, bq = (hs_lptr)s_dyn + CAP;
+            for (int i = threadIdx.x; i < n; i += 256) a[i] = g[i];
+            __syncthreads();
+            for (int ps = 0; ps < passes; ps++) {
+                if (ps & 1) hs_pass(bq, a, n, shift0 + 4 * ps, s_cnt, s_scan); else hs_pass(a, bq, n, shift0 + 4 * ps, s_cnt, s_scan);
+            }
+            hs_lptr r = (passes & 1) ? bq : a;
+            for (int i = threadIdx.x; i < n; i += 256) g[i] = r[i];
+            __syncthreads();
+        } else {
+            unsigned long long *h = spare + o;
+            for (int ps = 0; ps < passes; ps++) {
+                if (ps & 1) hs_pass(h, g, n, shift0 + 4 * ps, s_cnt, s_scan); else hs_pass(g, h, n, shift0 + 4 * ps, s_cnt, s_scan);
+                __threadfence_block();
+            }
+            if (passes & 1) { for (int i = threadIdx.x; i < n; i += 256) g[i] = h[i]; }
+            __syncthreads();
+        }
+    }
+}
+
 __global__ void cluster_flag_kernel(int64_t nh, const unsigned long long *__restrict__ hkey, HitFmt F,
                                     const int64_t *__restrict__ coff, int nc, int32_t *__restrict__ flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -861,7 +945,27 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
     {   // the key has a hole: the diagonal (gpos - qo + DBIAS < n_bases + DBIAS) rarely needs its 33 bits.  Two runs of stable
         // passes -- the diagonal's bits, then strand + candidate -- take 3 + 2 passes at 1 Gbp / 2^17 candidates where the
         // 51-bit key as a whole takes 6; the sorted pair of buffers is taken over instead of copied back
-        if (F.qbits) {
+        static const bool seg_sort = [] { const char *e = getenv("HITE_HIT_SEGSORT"); return !(e && *e && atoi(e) == 0); }();
+        if (F.qbits && seg_sort) {
+            // per-candidate sort in LDS (above): classify, then one launch per class
+            unsigned *hs_counts; int32_t *hs_lists;
+            CCHK(arena_alloc(ctx, A, 16, &p)); hs_counts = (unsigned *)p;
+            CCHK(arena_alloc(ctx, A, (size_t)3 * n_cand * 4 + 16, &p)); hs_lists = (int32_t *)p;
+            HITE_CHECK(ctx, hipMemsetAsync(hs_counts, 0, 16, st));
+            hipLaunchKernelGGL(hit_sort_classify_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, q_first, hit_off, hs_counts, hs_lists);
+            static bool attr_done = false;
+            if (!attr_done) {
+                HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&hit_segsort_kernel<HS_MEDIUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HS_MEDIUM * 8));
+                attr_done = true;
+            }
+            const int sbits = dbits + 1;
+            const int gsm = n_cand < 8192 ? n_cand : 8192, gmd = n_cand < 2048 ? n_cand : 2048, glg = n_cand < 1024 ? n_cand : 1024;
+            // the few large ranges first (they run longest), then the medium ones, the small ones fill the machine around them
+            hipLaunchKernelGGL(hit_segsort_kernel<0>, dim3(glg), dim3(256), 0, st, hs_counts + 2, hs_lists + (size_t)2 * n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            hipLaunchKernelGGL(hit_segsort_kernel<HS_MEDIUM>, dim3(gmd), dim3(256), 2 * HS_MEDIUM * 8, st, hs_counts + 1, hs_lists + (size_t)n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            hipLaunchKernelGGL(hit_segsort_kernel<HS_SMALL>, dim3(gsm), dim3(256), 2 * HS_SMALL * 8, st, hs_counts, hs_lists, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            HITE_CHECK(ctx, hipGetLastError());
+        } else if (F.qbits) {
             CCHK(sorter_sort_bits_swap(so, &hkey, &hval, nh, F.qbits, F.qbits + dbits));
             CCHK(sorter_sort_bits_swap(so, &hkey, &hval, nh, F.qbits + dbits, F.qbits + dbits + 1 + cbits));
         } else {

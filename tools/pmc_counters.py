@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from pmc_traffic import per_kernel  # noqa: E402
 
 COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_INSTS_VMEM"]
-STAGE = {"align_fwd_kernel<4>": "align_fwd4", "align_fwd_kernel<8>": "align_fwd_wide8", "align_fwd_kernel<16>": "align_fwd_wide16",
+STAGE = {"align_fwd4_kernel": "align_fwd4", "align_fwd_kernel<4>": "align_fwd4", "align_fwd_kernel<8>": "align_fwd_wide8", "align_fwd_kernel<16>": "align_fwd_wide16",
          "align_fwd_kernel<32>": "align_fwd_wide32", "align_tb_kernel": "align_tb", "align_wide_fwd_kernel": "align_fallback_fwd",
          "align_wide_tb_kernel": "align_fallback_tb", "align_planes_kernel": "align_prep_planes"}
 
