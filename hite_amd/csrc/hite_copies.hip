@@ -387,44 +387,55 @@ typedef __attribute__((address_space(3))) unsigned long long *hs_lptr;
 __global__ void hit_sort_classify_kernel(int n_cand, const int64_t *__restrict__ q_first, const int64_t *__restrict__ hit_off,
                                          unsigned *__restrict__ counts /* 3 */, int32_t *__restrict__ lists /* 3 x n_cand */) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cand) return;
-    const long long k = hit_off[q_first[c + 1]] - hit_off[q_first[c]];
-    if (k <= 1) return;
-    const int cls = k <= HS_SMALL ? 0 : (k <= HS_MEDIUM ? 1 : 2);
-    lists[(size_t)cls * n_cand + atomicAdd(&counts[cls], 1u)] = c;
+    long long k = 0;
+    if (c < n_cand) k = hit_off[q_first[c + 1]] - hit_off[q_first[c]];
+    const int cls = k <= 1 ? -1 : (k <= HS_SMALL ? 0 : (k <= HS_MEDIUM ? 1 : 2));
+    // one atomic per wavefront and class (50 000 atomics on three addresses cost 0.5 ms)
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+        const unsigned long long m = __ballot(cls == q);
+        if (m == 0ull) continue;
+        unsigned base = 0u;
+        if (lane == __ffsll((long long)m) - 1) base = atomicAdd(&counts[q], (unsigned)__popcll(m));
+        base = __shfl(base, __ffsll((long long)m) - 1, 64);
+        if (cls == q) lists[(size_t)q * n_cand + base + __popcll(m & ((1ull << lane) - 1ull))] = c;
+    }
 }
-// one stable pass on digit (key >> shift) & 15 from src to dst (n elements, all 256 threads of the block)
-template <class PS, class PD>
-__device__ __forceinline__ void hs_pass(PS src, PD dst, int n, int shift, unsigned *s_cnt /* 16 x 256 */, int *s_scan) {
+// one stable pass on digit (key >> shift) & 15 from src to dst (n elements, all NT threads of the block); CT = counter type
+// (uint16_t while n < 65536: half the LDS)
+template <int NT, class CT, class PS, class PD>
+__device__ __forceinline__ void hs_pass(PS src, PD dst, int n, int shift, CT *s_cnt /* 16 x NT */, int *s_scan) {
     const int t = threadIdx.x;
     // a thread's chunk: contiguous (stability), of ODD length (consecutive lanes then start 2 E dwords apart: all banks, where an
     // even length would put the 64 lanes of an 8-byte read on a handful of them)
-    const int E = ((n + 255) >> 8) | 1, b = t * E < n ? t * E : n, e = b + E < n ? b + E : n;
-    for (int k = 0; k < 16; k++) s_cnt[k * 256 + t] = 0u;
-    for (int i = b; i < e; i++) s_cnt[(int)((src[i] >> shift) & 15ull) * 256 + t]++;
+    const int E = ((n + NT - 1) / NT) | 1, b = t * E < n ? t * E : n, e = b + E < n ? b + E : n;
+    for (int k = 0; k < 16; k++) s_cnt[k * NT + t] = (CT)0;
+    for (int i = b; i < e; i++) s_cnt[(int)((src[i] >> shift) & 15ull) * NT + t]++;
     __syncthreads();
-    // exclusive scan of the 4096 counters in (digit, thread) order: a thread takes 16 consecutive ones
+    // exclusive scan of the 16 NT counters in (digit, thread) order: a thread takes 16 consecutive ones
     unsigned v[16], sum = 0u;
 #pragma unroll
     for (int k = 0; k < 16; k++) { v[k] = s_cnt[t * 16 + k]; sum += v[k]; }
     int tot;
     unsigned run = (unsigned)block_excl_scan((int)sum, s_scan, &tot);
 #pragma unroll
-    for (int k = 0; k < 16; k++) { const unsigned x = v[k]; s_cnt[t * 16 + k] = run; run += x; }
+    for (int k = 0; k < 16; k++) { const unsigned x = v[k]; s_cnt[t * 16 + k] = (CT)run; run += x; }
     __syncthreads();
     for (int i = b; i < e; i++) {
         const unsigned long long x = src[i];
-        dst[s_cnt[(int)((x >> shift) & 15ull) * 256 + t]++] = x;
+        dst[s_cnt[(int)((x >> shift) & 15ull) * NT + t]++] = x;
     }
     __syncthreads();
 }
-template <int CAP /* elements per LDS buffer; 0: global ping-pong */>
-__global__ void __launch_bounds__(256) hit_segsort_kernel(const unsigned *__restrict__ count, const int32_t *__restrict__ list,
-                                                          const int64_t *__restrict__ q_first, const int64_t *__restrict__ hit_off,
-                                                          unsigned long long *__restrict__ hkey, unsigned long long *__restrict__ spare,
-                                                          int shift0, int bits) {
-    __shared__ unsigned s_cnt[16 * 256];
-    __shared__ int s_scan[8];
+template <int CAP /* elements per LDS buffer; 0: global ping-pong */, int NT /* threads */>
+__global__ void __launch_bounds__(NT) hit_segsort_kernel(const unsigned *__restrict__ count, const int32_t *__restrict__ list,
+                                                         const int64_t *__restrict__ q_first, const int64_t *__restrict__ hit_off,
+                                                         unsigned long long *__restrict__ hkey, unsigned long long *__restrict__ spare,
+                                                         int shift0, int bits) {
+    typedef typename std::conditional<(CAP > 0), uint16_t, unsigned>::type CT;
+    __shared__ CT s_cnt[16 * NT];
+    __shared__ int s_scan[16];
     extern __shared__ __attribute__((aligned(16))) unsigned long long s_dyn[];
     const unsigned cnt = *count;
     const int passes = (bits + 3) / 4;
@@ -435,21 +446,20 @@ __global__ void __launch_bounds__(256) hit_segsort_kernel(const unsigned *__rest
         unsigned long long *g = hkey + o;
         if (CAP > 0) {
             hs_lptr a = (hs_lptr)s_dyn, bq = (hs_lptr)s_dyn + CAP;
-            for (int i = threadIdx.x; i < n; i += 256) a[i] = g[i];
+            for (int i = threadIdx.x; i < n; i += NT) a[i] = g[i];
             __syncthreads();
             for (int ps = 0; ps < passes; ps++) {
-                if (ps & 1) hs_pass(bq, a, n, shift0 + 4 * ps, s_cnt, s_scan); else hs_pass(a, bq, n, shift0 + 4 * ps, s_cnt, s_scan);
+                if (ps & 1) hs_pass<NT, CT>(bq, a, n, shift0 + 4 * ps, s_cnt, s_scan); else hs_pass<NT, CT>(a, bq, n, shift0 + 4 * ps, s_cnt, s_scan);
             }
             hs_lptr r = (passes & 1) ? bq : a;
-            for (int i = threadIdx.x; i < n; i += 256) g[i] = r[i];
+            for (int i = threadIdx.x; i < n; i += NT) g[i] = r[i];
             __syncthreads();
         } else {
             unsigned long long *h = spare + o;
             for (int ps = 0; ps < passes; ps++) {
-                if (ps & 1) hs_pass(h, g, n, shift0 + 4 * ps, s_cnt, s_scan); else hs_pass(g, h, n, shift0 + 4 * ps, s_cnt, s_scan);
-                __threadfence_block();
+                if (ps & 1) hs_pass<NT, CT>(h, g, n, shift0 + 4 * ps, s_cnt, s_scan); else hs_pass<NT, CT>(g, h, n, shift0 + 4 * ps, s_cnt, s_scan);
             }
-            if (passes & 1) { for (int i = threadIdx.x; i < n; i += 256) g[i] = h[i]; }
+            if (passes & 1) { for (int i = threadIdx.x; i < n; i += NT) g[i] = h[i]; }
             __syncthreads();
         }
     }
@@ -955,15 +965,23 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
             hipLaunchKernelGGL(hit_sort_classify_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, q_first, hit_off, hs_counts, hs_lists);
             static bool attr_done = false;
             if (!attr_done) {
-                HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&hit_segsort_kernel<HS_MEDIUM>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HS_MEDIUM * 8));
+                HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&hit_segsort_kernel<HS_MEDIUM, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HS_MEDIUM * 8));
                 attr_done = true;
             }
             const int sbits = dbits + 1;
             const int gsm = n_cand < 8192 ? n_cand : 8192, gmd = n_cand < 2048 ? n_cand : 2048, glg = n_cand < 1024 ? n_cand : 1024;
-            // the few large ranges first (they run longest), then the medium ones, the small ones fill the machine around them
-            hipLaunchKernelGGL(hit_segsort_kernel<0>, dim3(glg), dim3(256), 0, st, hs_counts + 2, hs_lists + (size_t)2 * n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
-            hipLaunchKernelGGL(hit_segsort_kernel<HS_MEDIUM>, dim3(gmd), dim3(256), 2 * HS_MEDIUM * 8, st, hs_counts + 1, hs_lists + (size_t)n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
-            hipLaunchKernelGGL(hit_segsort_kernel<HS_SMALL>, dim3(gsm), dim3(256), 2 * HS_SMALL * 8, st, hs_counts, hs_lists, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            // the few large ranges (long chains, 32 KB of LDS each) run on a side stream beside the small ones; the medium class
+            // takes a CU's whole LDS and follows on the main stream
+            hipStream_t sside[HITE_AUX_STREAMS];
+            hipEvent_t ev_fork, ev_join[HITE_AUX_STREAMS];
+            CCHK(hite_aux_streams(ctx, 1, sside, &ev_fork, ev_join));
+            HITE_CHECK(ctx, hipEventRecord(ev_fork, st));
+            HITE_CHECK(ctx, hipStreamWaitEvent(sside[0], ev_fork, 0));
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hit_segsort_kernel<0, 512>), dim3(glg), dim3(512), 0, sside[0], hs_counts + 2, hs_lists + (size_t)2 * n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hit_segsort_kernel<HS_SMALL, 256>), dim3(gsm), dim3(256), 2 * HS_SMALL * 8, st, hs_counts, hs_lists, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hit_segsort_kernel<HS_MEDIUM, 512>), dim3(gmd), dim3(512), 2 * HS_MEDIUM * 8, st, hs_counts + 1, hs_lists + (size_t)n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            HITE_CHECK(ctx, hipEventRecord(ev_join[0], sside[0]));
+            HITE_CHECK(ctx, hipStreamWaitEvent(st, ev_join[0], 0));
             HITE_CHECK(ctx, hipGetLastError());
         } else if (F.qbits) {
             CCHK(sorter_sort_bits_swap(so, &hkey, &hval, nh, F.qbits, F.qbits + dbits));
