@@ -556,14 +556,13 @@ __global__ void __launch_bounds__(64) align_fwd8_pair_kernel(AlignArgs P, const 
 // traceback pass: re-compute the slice strip by strip (registers), walk it backwards
 // ---------------------------------------------------------------------------------------------
 // ops leave the traceback in descending positions, one at a time and per lane, every lane into its own row: 64 different
-// cache lines per wavefront.  Round 3 stored 8 bytes per four positions straight to the row: HBM is written in 32-byte
-// sectors, and with ~130 000 rows open across the machine the partly written sectors leave L2 one store at a time --
-// WRITE_SIZE 12.6 GB per launch for 3.3 GB of ops (profiles/r03_pmc_hbm.txt).  Now a lane collects a whole sector -- 16
-// positions, aligned in MEMORY (q = position + the row's phase) -- in four 64-bit registers and writes it with two 16-byte
-// stores; the partial sectors at the two ends of a row go out entry by entry.  Round 4 measured three forms on C3 (13.8 ms,
-// 12.6 GB written per launch before): a 128-byte line per lane staged in LDS, flushed inside the walk by the lane that
-// crossed its edge: 3.3 GB, 17.4 ms (the flush ran for one lane on most steps); a ring of 128 positions per lane in LDS
-// drained once per strip by all lanes: 3.1 GB, 16.0 ms; this one: registers only.
+// cache lines per wavefront.  Round 3 stored 8 bytes per four positions straight to the row: with ~130 000 rows open across the
+// machine the partly written lines leave L2 one store at a time -- WRITE_SIZE 12.6 GB per launch for 3.3 GB of ops
+// (profiles/r03_pmc_hbm.txt).  Round 4 measured five forms on C3 (profiles/r04_align_tb_store_forms.txt): whole 128-byte lines
+// staged per lane in LDS reach 3.3 GB but cost a wavefront per SIMD (192 registers; 17.4 ms against 13.8); 32-byte pieces (an
+// LDS ring drained per strip, or four 64-bit registers) write 6.3 GB -- the unit HBM charges is 64 bytes -- and cost the
+// wavefront as well; the kernel is bound by its registers (three wavefronts per SIMD up to 168), not by its writes.  Kept:
+// 16-byte chunks aligned in memory, 8.5 GB per launch at round 3's time.
 typedef unsigned int tb_u32x4 __attribute__((ext_vector_type(4)));
 #if defined(ALIGN_TB_STORE8)
 // round 3's form: 8 bytes per four positions, groups aligned to the POSITION (kept for measurements)
@@ -630,9 +629,10 @@ struct OpsOut {
 };
 
 #else
-// 16 bytes per eight positions, chunks aligned in MEMORY (q = position + the row's phase, q % 8 == 0 starts a chunk): half a
-// sector per store, never straddling two -- the traffic of the 8-byte form halves at its instruction count.  The walk itself
-// only ever stores whole chunks; the partial chunks at the two ends of a row are kept in registers and written at the end.
+// 16 bytes per eight positions, chunks aligned in MEMORY (q = position + the row's phase, q % 8 == 0 starts a chunk), never
+// straddling a 32-byte sector: a third less write traffic than the 8-byte form at its instruction count and register budget.
+// The walk itself only ever stores whole chunks; the partial chunks at the two ends of a row are kept in registers and written
+// at the end.
 struct OpsOut {
     uint16_t *ops;
     unsigned long long acc, hi;   // the group of four being collected; the complete upper group of the chunk being collected
