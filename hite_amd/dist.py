@@ -236,16 +236,22 @@ def _exchange_rows(rows, dest, group=None, device="cpu"):
     return np.concatenate(parts) if parts else gathered[:0]
 
 
-def coarse_stage_sharded(ctx, seg_len, skip_gap, max_len, group=None, device="cpu", base_threshold=1_000_000):
+def coarse_stage_sharded(ctx, seg_len, skip_gap, max_len, group=None, device="cpu", base_threshold=1_000_000, seg_table=None):
     """stage 3.1 on the genome resident in `ctx` (the same on every rank), sharded as described above.
     -> (contig ids, starts, ends) of the repeat intervals in the single-rank order, identical on every rank.
-    Without an initialised process group: the single-rank computation (the same code path, no collectives)."""
+    Without an initialised process group: the single-rank computation (the same code path, no collectives).
+    seg_table = (chromosome id, offset) of every packed sequence when those are 'chr$offset' segments of a chunk file
+    (determine_repeat_boundary_v5: the intervals then come out in chromosome coordinates); default: the packed contigs cut every seg_len."""
     multi = dist.is_available() and dist.is_initialized()
     world = dist.get_world_size(group) if multi else 1
     rank = dist.get_rank(group) if multi else 0
-    seg_chrom, seg_off = ctx.seed_segments(seg_len)
     clen = np.asarray(ctx.contig_len, dtype=np.int64)
-    seg_lens = np.minimum(seg_len, clen[seg_chrom] - seg_off)
+    if seg_table is None:
+        seg_chrom, seg_off = ctx.seed_segments(seg_len)
+        seg_lens = np.minimum(seg_len, clen[seg_chrom] - seg_off)
+    else:
+        seg_chrom, seg_off = np.asarray(seg_table[0], dtype=np.int32), np.asarray(seg_table[1], dtype=np.int64)
+        seg_lens = clen                 # one segment per packed sequence
     file_of = query_files_of_segments(seg_lens, base_threshold)
     n_files = int(file_of[-1]) + 1 if len(file_of) else 0
     ctx.seed_shard(rank, world)

@@ -1232,27 +1232,13 @@ def determine_repeat_boundary_v5(repeats_path, longest_repeats_path, prev_TE, fi
         seg_chrom.append(chroms[c])
         seg_off.append(int(off))
     inv = {v: k for k, v in chroms.items()}
-    # query files of >= 1 Mbp as in the reference: FMEA (with its own first-come de-duplication) runs per query file; the HSP
-    # table is sorted by query segment, so a file's records are one slice of it
-    tab = ctx.seed_allvsall(seg_len=max(seg_len, 1))
-    qseg = np.asarray(tab["qseg"])
-    order = np.argsort(qseg, kind="stable")
-    qsorted = qseg[order]
-    index_of = {n: i for i, n in enumerate(names)}
-    final, seen = [], set()
-    for group in split_and_store_sequences(names, contigs, 1_000_000):
-        ids = sorted(index_of[n] for n in group)
-        sel = np.concatenate([order[np.searchsorted(qsorted, i, "left"):np.searchsorted(qsorted, i, "right")] for i in ids]) if ids else np.zeros(0, np.int64)
-        if len(sel) == 0:
-            continue
-        sel = np.sort(sel)      # table order inside the file
-        oc, os_, oe = ctx.fmea_chain(tab["qseg"][sel], tab["sseg"][sel], tab["qs"][sel], tab["qe"][sel], tab["ss"][sel], tab["se"][sel],
-                                     seg_chrom, seg_off, fixed_extend_base_threshold, max_single_repeat_len)
-        for c, a_, b_ in zip(oc, os_, oe):
-            name = "%s:%d-%d" % (inv[int(c)], a_, b_)
-            if name not in seen:
-                seen.add(name)
-                final.append((name, inv[int(c)], int(a_), int(b_)))
+    # query files of >= 1 Mbp as in the reference: FMEA (with its own first-come de-duplication) runs per query file, the results
+    # are unioned by name in file order.  One code path for one GPU and for the ranks of a node (hite_amd/dist.py: under
+    # torchrun every rank seeds its share, the HSP records go to the owners of the query files, the interval lists are gathered)
+    from . import dist as hd
+
+    oc, os_, oe = hd.coarse_stage_sharded(ctx, max(seg_len, 1), fixed_extend_base_threshold, max_single_repeat_len, seg_table=(seg_chrom, seg_off))
+    final = [("%s:%d-%d" % (inv[int(c)], a_, b_), inv[int(c)], int(a_), int(b_)) for c, a_, b_ in zip(oc, os_, oe)]
     _rn, ref = read_fasta(reference)
     store_fasta({name: ref[c][a_:b_] for name, c, a_, b_ in final}, longest_repeats_path)
     if not debug:      # cleanup_temp_files (Util.py:4797)

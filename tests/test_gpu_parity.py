@@ -1,5 +1,7 @@
 """GPU parity: the HIP path (through the C ABI) vs the golden vectors generated from the reference's
 Python and vs the C oracle on fresh seeded inputs.  Bit-exact on every integer / byte output."""
+import os
+
 import numpy as np
 import pytest
 
@@ -1499,3 +1501,37 @@ def test_seed_shard_partitions_the_hsp_table(ctx):
     oc, os_, oe = hd.coarse_stage_sharded(ctx, 50_000, 2000, 30000, base_threshold=100_000)
     tc, ts, te = hd.coarse_stage_sharded(tw, 50_000, 2000, 30000, base_threshold=100_000)
     assert (oc.tolist(), os_.tolist(), oe.tolist()) == (tc.tolist(), ts.tolist(), te.tolist()) and len(oc) >= 20
+
+
+def test_coarse_stage_sharded_over_rccl_world1(ctx):
+    """the collectives of the sharded coarse stage on their RCCL code path (all_gather_into_tensor, all_to_all_single with split
+    sizes, the padded variable-length all-gather): one rank, backend "nccl" -- the result must be the stage without a process
+    group.  (Two ranks are checked with gloo and the CPU twins in tests/test_dist_gloo.py; a multi-GPU node was never available.)"""
+    import socket
+
+    import synth_small
+    import torch
+    import torch.distributed as dist
+    from hite_amd import dist as hd
+
+    g = synth_small.make(31, n_fam=14, n_chr=3, chr_len=150_000)
+    ctx.genome_pack(g["contigs"])
+    ctx.release_copy_index()
+    plain = hd.coarse_stage_sharded(ctx, 50_000, 2000, 30000, base_threshold=100_000)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        # world 1 takes the single-rank shortcut inside coarse_stage_sharded: call the exchange helpers directly as well
+        rows = np.arange(60, dtype=np.int64).reshape(10, 6)
+        got = hd._exchange_rows(rows, np.zeros(10, dtype=np.int64), None, torch.device("cuda", 0))
+        assert np.array_equal(got, rows)
+        allv, sizes = hd.allgather_varlen(torch.arange(7, dtype=torch.int64, device="cuda"), None)
+        assert allv.cpu().tolist() == list(range(7)) and sizes.tolist() == [7]
+        shard = hd.coarse_stage_sharded(ctx, 50_000, 2000, 30000, device=torch.device("cuda", 0), base_threshold=100_000)
+    finally:
+        dist.destroy_process_group()
+    assert [x.tolist() for x in shard] == [x.tolist() for x in plain] and len(plain[0]) >= 20
