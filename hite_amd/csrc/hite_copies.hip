@@ -376,24 +376,26 @@ __global__ void hit_hist_kernel(int n_cand, const int64_t *__restrict__ q_first,
 // (candidate, strand, diagonal) only has to be established INSIDE every candidate's range: a workgroup loads the range into
 // LDS, sorts it there on the (strand | diagonal) field by a stable LSD radix sort (4-bit digits, two LDS buffers) and writes
 // it back in place -- one global read and one write of 8 bytes per hit where the global radix sort of round 3 made five
-// passes (5 x 16 B + histograms).  Three classes by hits per candidate (C3: <= 2048: 75 % of the candidates, 51 % of the hits;
-// <= 8192: 24 % / 45 %; above: 0.6 % / 3.6 %, profiles of round 3): 2 x 16 KB, 2 x 64 KB of LDS, and global ping-pong buffers
-// (the range against the sorter's spare array) for the rest.  Stable, like the global passes it replaces: the table is
+// passes (5 x 16 B + histograms).  Four classes by hits per candidate (C3: <= 2048: 75 % of the candidates, 51 % of the hits;
+// <= 4096: 19 % / 31 %; <= 8192: 5 % / 14 %; above: 0.6 % / 3.6 %, profiles of round 3): 2 x 16, 2 x 32, 2 x 64 KB of LDS (the
+// last one holds a CU by itself), and global ping-pong buffers (the range against the sorter's spare array) for the rest.  Stable, like the global passes it replaces: the table is
 // the same, hit for hit.  (Packed 8-byte hits only; the 12-byte form keeps the global sort.)
 // ---------------------------------------------------------------------------------------------
 #define HS_SMALL 2048
+#define HS_MID 4096
 #define HS_MEDIUM 8192
+#define HS_NCLS 4
 typedef __attribute__((address_space(3))) unsigned long long *hs_lptr;
 __global__ void hit_sort_classify_kernel(int n_cand, const int64_t *__restrict__ q_first, const int64_t *__restrict__ hit_off,
-                                         unsigned *__restrict__ counts /* 3 */, int32_t *__restrict__ lists /* 3 x n_cand */) {
+                                         unsigned *__restrict__ counts /* HS_NCLS */, int32_t *__restrict__ lists /* HS_NCLS x n_cand */) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     long long k = 0;
     if (c < n_cand) k = hit_off[q_first[c + 1]] - hit_off[q_first[c]];
-    const int cls = k <= 1 ? -1 : (k <= HS_SMALL ? 0 : (k <= HS_MEDIUM ? 1 : 2));
+    const int cls = k <= 1 ? -1 : (k <= HS_SMALL ? 0 : (k <= HS_MID ? 1 : (k <= HS_MEDIUM ? 2 : 3)));
     // one atomic per wavefront and class (50 000 atomics on three addresses cost 0.5 ms)
     const int lane = threadIdx.x & 63;
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
+    for (int q = 0; q < HS_NCLS; q++) {
         const unsigned long long m = __ballot(cls == q);
         if (m == 0ull) continue;
         unsigned base = 0u;
@@ -960,7 +962,7 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
             // per-candidate sort in LDS (above): classify, then one launch per class
             unsigned *hs_counts; int32_t *hs_lists;
             CCHK(arena_alloc(ctx, A, 16, &p)); hs_counts = (unsigned *)p;
-            CCHK(arena_alloc(ctx, A, (size_t)3 * n_cand * 4 + 16, &p)); hs_lists = (int32_t *)p;
+            CCHK(arena_alloc(ctx, A, (size_t)HS_NCLS * n_cand * 4 + 16, &p)); hs_lists = (int32_t *)p;
             HITE_CHECK(ctx, hipMemsetAsync(hs_counts, 0, 16, st));
             hipLaunchKernelGGL(hit_sort_classify_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, q_first, hit_off, hs_counts, hs_lists);
             static bool attr_done = false;
@@ -977,9 +979,10 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
             CCHK(hite_aux_streams(ctx, 1, sside, &ev_fork, ev_join));
             HITE_CHECK(ctx, hipEventRecord(ev_fork, st));
             HITE_CHECK(ctx, hipStreamWaitEvent(sside[0], ev_fork, 0));
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hit_segsort_kernel<0, 512>), dim3(glg), dim3(512), 0, sside[0], hs_counts + 2, hs_lists + (size_t)2 * n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hit_segsort_kernel<0, 512>), dim3(glg), dim3(512), 0, sside[0], hs_counts + 3, hs_lists + (size_t)3 * n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
             hipLaunchKernelGGL(HIP_KERNEL_NAME(hit_segsort_kernel<HS_SMALL, 256>), dim3(gsm), dim3(256), 2 * HS_SMALL * 8, st, hs_counts, hs_lists, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
-            hipLaunchKernelGGL(HIP_KERNEL_NAME(hit_segsort_kernel<HS_MEDIUM, 512>), dim3(gmd), dim3(512), 2 * HS_MEDIUM * 8, st, hs_counts + 1, hs_lists + (size_t)n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hit_segsort_kernel<HS_MID, 256>), dim3(gmd), dim3(256), 2 * HS_MID * 8, st, hs_counts + 1, hs_lists + (size_t)n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
+            hipLaunchKernelGGL(HIP_KERNEL_NAME(hit_segsort_kernel<HS_MEDIUM, 512>), dim3(gmd), dim3(512), 2 * HS_MEDIUM * 8, st, hs_counts + 2, hs_lists + (size_t)2 * n_cand, q_first, hit_off, hkey, so.k2, F.qbits, sbits);
             HITE_CHECK(ctx, hipEventRecord(ev_join[0], sside[0]));
             HITE_CHECK(ctx, hipStreamWaitEvent(st, ev_join[0], 0));
             HITE_CHECK(ctx, hipGetLastError());
