@@ -11,7 +11,7 @@
 // what a user of the extension fixes at compile time: score S(i) = SA i - SB cost, abandoned XDROP below the best; where the
 // query bases come from (ASCII bytes of a candidate / the packed genome itself); whether only some diagonals are allowed
 struct ExtCopyMode { static constexpr int SA = 1, SB = 3, XDROP = 40; static constexpr bool PACKEDQ = false, DIAGLIM = false; };
-struct ExtTandemMode { static constexpr int SA = 2, SB = 9, XDROP = 30; static constexpr bool PACKEDQ = true, DIAGLIM = true; };
+struct ExtTandemMode { static constexpr int SA = 2, SB = 7, XDROP = 30; static constexpr bool PACKEDQ = true, DIAGLIM = true; };   // match 2, edit 5: oracle/hite_oracle_trf.c, "calibration"
 
 __device__ __forceinline__ unsigned ext_cand_code(unsigned ch, bool comp) {
     const unsigned c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;

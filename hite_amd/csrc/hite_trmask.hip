@@ -10,7 +10,8 @@
 //     word only, which two periods share per trip.  ~20 integer operations per (word, period): 500 periods x G/16 words --
 //     about 9 s per Gbp, once per chunk (TRF: minutes per Gbp and core); not part of any timed step.
 //   extension: the leftmost seed of a run aligns the stretch with itself one period on by the banded end extension of the copy
-//     finder (hite_ext.h, TRF's 2 / 7 / 7 as S = 2 i - 9 cost), in the thread that found the seed (seeds are rare outside arrays);
+//     finder (hite_ext.h; S = 2 i - 7 cost: match 2, edit 5 -- TRF's 7 is a penalty against a consensus, a copy against its
+//     neighbour carries twice the divergence; calibrated on TRF's own masks, see the twin), in the thread that found the seed;
 //   accepted stretches are OR-ed into a bit map, which is then OR-ed into the genome's "not A/C/G/T" mask: every later stage
 //     sees N where the reference's later stages read the masked FASTA.
 #include "hite_common.h"

@@ -17,16 +17,21 @@
  *   Extension inside the seed's contig [cb, ce): the sequence from s is aligned with ITSELF p bases further on by the banded
  *   end extension of the copy finder (orc_ext_align_scored, hite_oracle_copies.c: unit-cost edit distance in a band of +-8
  *   diagonals, so a copy may be a few bases longer or shorter than its neighbour; the diagonals that would pair a base
- *   with itself, j - i = -p to the right and +p to the left, and those beyond, are excluded), scored S = 2 i - 9 cost -- TRF's match 2 /
- *   mismatch 7 / indel 7 -- abandoned 30 below the best, at most TR_MAXEXT = 4096 bases: to the right the query s, s + 1, ...
+ *   with itself, j - i = -p to the right and +p to the left, and those beyond, are excluded), scored S = 2 i - 7 cost (match 2,
+ *   mismatch / indel 5; see "calibration" below) -- abandoned 30 below the best, at most TR_MAXEXT = 4096 bases: to the right the query s, s + 1, ...
  *   against the genome from s + p; to the left the query s - 1, s - 2, ... against the genome leftwards from s + p.
  *   il / ir = query bases aligned, tr = genome bases the right extension used, score = S_left + S_right.
  *   The stretch is a tandem array when score + 2 p >= 50 (TRF's Minscore: the first copy counts as matched) and
  *   il + ir >= (85 p + 99) / 100 (at least 1.85 copies: TRF reports nothing below about 1.9).  Positions s - il .. s + p + tr - 1
  *   are masked (clamped to the contig).
- *   What this does NOT do: TRF scores every copy against a consensus pattern; comparing a copy with its neighbour doubles the
- *   divergence, so arrays whose copies are more than ~10 % from their consensus are found only in part.  Measured against
- *   TRF's own masks in tests/test_trmask.py.
+ *   Calibration (round 4).  TRF scores every copy against a CONSENSUS pattern with match 2 / mismatch 7 / indel 7; this masker
+ *   compares a copy with its NEIGHBOUR, which doubles the divergence: an array whose copies are 15 % from their consensus scores
+ *   +0.65 per base in TRF and -0.5 per base neighbour against neighbour under 2 / 7 / 7 -- round 3 lost those arrays (0.80 of the
+ *   planted bases, TRF itself 0.94; 0.85 of TRF's own mask).  With the edit penalty at 5 the neighbour score of that array is
+ *   +0.6 per base, random sequence stays at -3.25: measured on the three fixtures (TRF 4.09's own masks,
+ *   tests/golden/trf_mask.json.gz; sweep of 3 / 4 / 5 / 7 x X-drop 15 / 20 / 30): planted bases 0.944 (TRF 0.936), arrays with
+ *   <= 8 % substitutions 0.9985, TRF's own mask covered to 0.988, 72 bases masked outside any planted array per 120 kb (TRF: 30-37;
+ *   penalty 4: 150, penalty 3: 349).
  */
 #include <stdint.h>
 #include <stdlib.h>
@@ -35,7 +40,7 @@
 #define TR_XDROP 30
 #define TR_MAXEXT 4096
 #define TR_MATCH 2
-#define TR_MISMATCH 7
+#define TR_MISMATCH 5
 #define TR_MINSCORE 50
 #define TR_RESEED 2048
 #define TR_BAND 8          /* EXT_B of hite_oracle_copies.c */

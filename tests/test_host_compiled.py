@@ -122,7 +122,7 @@ def test_ext_align_tandem_mode_vs_twin(tmp_path):
             gbuf = np.ascontiguousarray(genome)
             segb = np.ascontiguousarray(np.concatenate([seg, np.zeros(1, np.uint8)]))
             i_ref = L.orc_ext_align_scored(segb.ctypes.data_as(O.u8p), C.c_int64(n), d, gbuf.ctypes.data_as(O.u8p), C.c_int64(s + p), C.c_int64(cb),
-                                           C.c_int64(ce), 2, 9, 30, dlo, dhi, C.byref(t_ref), C.byref(s_ref))
+                                           C.c_int64(ce), 2, 7, 30, dlo, dhi, C.byref(t_ref), C.byref(s_ref))
             jmax = (ce - (s + p)) if d > 0 else (s + p - cb)
             io, to, so = C.c_int(0), C.c_int(0), C.c_int(0)
             lib.host_ext_tandem(C.c_int64(s if d > 0 else s - 1), d, n, bases.ctypes.data_as(C.POINTER(C.c_uint32)),

@@ -56,13 +56,14 @@ def test_twin_against_planted_arrays_and_trf():
         tot.append(m)
         print("seed %d: %s" % (case["seed"], {k: round(float(v), 3) for k, v in m.items()}))
     avg = {k: float(np.mean([t[k] for t in tot])) for k in tot[0]}
-    # measured (3 x 120 kb, ~200 arrays of period 1-500, up to 15 % substitutions and 2 % indels per copy): planted bases masked
-    # 0.80 (TRF itself: 0.94), arrays with <= 8 % substitutions 0.96 (TRF 0.985), 40-45 bases masked outside any planted array per
-    # sequence (precision 0.998), 0.85 of TRF's own mask covered.  What is lost are arrays whose copies are ~15 % from their
-    # consensus: the masker compares a copy with its neighbour (twice the divergence), TRF with a consensus pattern.
-    assert avg["planted_recall"] >= 0.75 and avg["clean_recall"] >= 0.93
-    assert avg["precision_vs_planted"] >= 0.995 and max(t["outside"] for t in tot) < 200
-    assert avg["recall_vs_trf"] >= 0.80
+    # measured (3 x 120 kb, ~200 arrays of period 1-500, up to 15 % substitutions and 2 % indels per copy), edit penalty 5 (round 4;
+    # penalty 7 in brackets): planted bases masked 0.944 [0.80] (TRF itself: 0.936), arrays with <= 8 % substitutions 0.9985 [0.96]
+    # (TRF 0.985), 59-93 [40-45] bases masked outside any planted array per sequence (TRF 30-37; precision 0.998), 0.988 [0.85] of
+    # TRF's own mask covered.  The masker compares a copy with its neighbour (twice the divergence TRF's consensus sees), hence the
+    # lower penalty; oracle/hite_oracle_trf.c, "calibration".
+    assert avg["planted_recall"] >= 0.92 and avg["clean_recall"] >= 0.99
+    assert avg["precision_vs_planted"] >= 0.995 and max(t["outside"] for t in tot) < 120
+    assert avg["recall_vs_trf"] >= 0.97
 
 
 def test_twin_leaves_dispersed_repeats_alone():
