@@ -24,7 +24,7 @@ _PACKED = {"path": None, "names": None, "lens": None}
 
 def get_ctx(device=0):
     global _CTX
-    if _CTX is None:
+    if _CTX is None or not getattr(_CTX, "h", None):      # none yet, or closed by its previous owner
         _CTX = Context(device)
     return _CTX
 

@@ -110,4 +110,5 @@ def test_gpu_masker_equals_twin(tmp_path):
         got = np.concatenate([np.frombuffer(c2[n].encode(), dtype=np.uint8) == ord("N") for n in names])
         assert np.array_equal(got, exp)
     finally:
+        util._CTX = None
         ctx.close()
