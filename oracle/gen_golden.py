@@ -131,6 +131,55 @@ def gen_judge(U, tmp):
         dump("judge_" + te_type, cases)
 
 
+def gen_judge_edge(U, tmp):
+    """round 4: the lines of the judges and of the boundary searches that tools/ref_line_coverage.py showed unreached"""
+    cases = [run_msa_case(U, tmp, c) for c in casegen.msa_edge_cases(61)]
+    stats = {}
+    for c in cases:
+        k = c["te_type"] + " " + str(c["expected"][:2])
+        stats[k] = stats.get(k, 0) + 1
+    print("judge_edge outcomes:", stats)
+    dump("judge_edge", cases)
+    # the searches called directly next to the alignment's edges and on alignments too narrow for a window
+    rng = np.random.default_rng(62)
+    out = []
+    for ci, c in enumerate(cases):
+        homolog = c["aim"].startswith("homologous flanks")
+        if ci % 3 and not homolog:
+            continue
+        mat = [list(s) for s in c["clean"]]
+        R, C = len(mat), len(mat[0])
+        if C < 2:
+            continue
+        thr = 0.95 if R <= 2 else (0.9 if R <= 5 else float(rng.choice([0.7, 0.8])))
+        for side in ("start", "end"):
+            near = [0, 3, 9, 10, 11, C - 12, C - 11, C - 10, C - 4, C - 1, int(rng.integers(0, C))]
+            if homolog:      # homology that runs to the alignment's edge: a new boundary within 10 columns of it cannot be judged
+                near += list(range(12, 24, 2)) + list(range(C - 24, C - 12, 2))
+            for pos in sorted(set(near)):
+                if pos < 0 or pos >= C:
+                    continue
+                v3 = U.search_boundary_homo_v3(int(R / 2), pos, mat, R, C, side, thr, 0, 20, 10)
+                v4 = U.search_boundary_homo_v4(int(R / 2), pos, mat, R, C, side, thr, thr - 0.05, thr, 0, 20, 10)
+                out.append(dict(seqs=c["clean"], pos=pos, side=side, thr=thr, v3=int(v3), v4=[bool(v4[0]), int(v4[1])]))
+    # alignments of 5 .. 30 columns
+    for W in (5, 9, 10, 12, 19, 20, 25, 30):
+        for R in (2, 4, 9):
+            rows = []
+            base = casegen.rand_seq(rng, W)
+            for r in range(R):
+                rows.append(casegen.mutate(rng, base, 0.1 if r else 0.0))
+            mat = [list(s) for s in rows]
+            thr = 0.95 if R <= 2 else (0.9 if R <= 5 else 0.7)
+            for side in ("start", "end"):
+                for pos in sorted(set([0, W // 2, W - 1])):
+                    v3 = U.search_boundary_homo_v3(int(R / 2), pos, mat, R, W, side, thr, 0, 20, 10)
+                    v4 = U.search_boundary_homo_v4(int(R / 2), pos, mat, R, W, side, thr, thr - 0.05, thr, 0, 20, 10)
+                    out.append(dict(seqs=rows, pos=pos, side=side, thr=thr, v3=int(v3), v4=[bool(v4[0]), int(v4[1])]))
+    print("boundary_search_edge:", len(out), "cases; v3 found", sum(c["v3"] != -1 for c in out), "; v4 valid", sum(c["v4"][0] for c in out))
+    dump("boundary_search_edge", out)
+
+
 def gen_boundary_search(U):
     """search_boundary_homo_v3 / v4 and calculate_window_homology called directly."""
     rng = np.random.default_rng(77)
@@ -1161,7 +1210,7 @@ def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf", "rfm", "chainvar"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf", "rfm", "chainvar", "edge"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -1201,6 +1250,8 @@ def main():
             gen_ready_for_msa(tmp)
         if "chainvar" in which:
             gen_chain_variants(U, tmp)
+        if "edge" in which:
+            gen_judge_edge(U, tmp)
 
 
 if __name__ == "__main__":

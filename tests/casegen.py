@@ -32,7 +32,7 @@ def mutate(rng, s, sub_rate):
 def make_msa_case(seed, te_type="tir", rows=12, te_len=200, flank=50, div=0.08,
                   row_gap_rate=0.01, ins_cols=3, trunc_rows=1, shift_l=0, shift_r=0,
                   tsd_len=8, tsd_frac=0.8, noise_rows=0, homolog_flank_l=0,
-                  homolog_flank_r=0, long_gap_rows=0):
+                  homolog_flank_r=0, long_gap_rows=0, start_motif=None, end_motif=None):
     """Build a gapped rows x cols alignment of `rows` copies of one synthetic TE family
     with +-`flank` bp of (mostly) non-homologous flanks, plus the candidate sequence
     (row 0's element, boundaries shifted by shift_l/shift_r: positive = candidate longer).
@@ -51,6 +51,10 @@ def make_msa_case(seed, te_type="tir", rows=12, te_len=200, flank=50, div=0.08,
         cons = "TC" + cons[2:-4] + str(rng.choice(["CTAG", "CTAA", "CTGG", "CTGA"]))
     elif te_type == "non_ltr":
         cons = cons[:-14] + "A" * 14
+    if start_motif:
+        cons = start_motif + cons[len(start_motif):]
+    if end_motif:
+        cons = cons[:-len(end_motif)] + end_motif
     L = len(cons)
     hom_l = rand_seq(rng, homolog_flank_l)
     hom_r = rand_seq(rng, homolog_flank_r)
@@ -400,6 +404,67 @@ def msa_outcome_cases(te_type, seed0):
     out.append(renamed(c))
     for c in out:
         c.setdefault("plant", 1)
+    return out
+
+
+def msa_edge_cases(seed0):
+    """Round 4: cases aimed at the lines of judge_boundary_v5 / v6 / v9 and search_boundary_homo_v3 / v4 that the fixtures of rounds
+    1-3 never reached (tools/ref_line_coverage.py): anchors within 10 columns of the alignment's edges, homology that runs to the
+    edge, fewer than 10 homologous columns left for a window, a column of the element whose majority is '-' among the full-length
+    rows, the TA / TAA / TTAA trims at both ends, a homology boundary outside the columns that are dense among the full-length
+    rows.  Every case carries te_type, plant and `aim`."""
+    out = []
+
+    def add(aim, te_type, plant=1, **kw):
+        c = make_msa_case(te_type=te_type, **kw)
+        c["plant"] = plant
+        c["aim"] = aim
+        out.append(c)
+        return c
+
+    i = 0
+    for te_type in ("tir", "non_ltr", "helitron"):
+        tf = 1.0
+        for flank in (3, 6, 9, 10, 11, 12, 20):
+            for rows in (4, 12):
+                i += 1
+                # (the non-LTR target-site duplication, 8-20 bases, does not fit the shorter flanks)
+                add("flank of %d columns" % flank, te_type, plant=i % 2, seed=seed0 * 100 + i, rows=rows, te_len=160, flank=flank, div=0.05,
+                    row_gap_rate=0.0, ins_cols=0, trunc_rows=0, tsd_len=2, tsd_frac=0.0 if te_type == "non_ltr" and flank < 20 else 1.0)
+        # no flank at all: the candidate's ends are the alignment's first and last column
+        for rows in (3, 9):
+            i += 1
+            c = add("no flank", te_type, plant=i % 2, seed=seed0 * 100 + i, rows=rows, te_len=150, flank=4, div=0.04, row_gap_rate=0.0, ins_cols=0,
+                    trunc_rows=0, tsd_len=2, tsd_frac=0.0)
+            c["seqs"] = [x[4:-4] for x in c["seqs"]]
+        for hl, hr in ((50, 0), (0, 50), (50, 50), (44, 0), (0, 44), (41, 47)):
+            i += 1
+            add("homologous flanks %d / %d of 50" % (hl, hr), te_type, plant=i % 2, seed=seed0 * 100 + i, rows=10, te_len=200, div=0.04,
+                row_gap_rate=0.0, ins_cols=0, trunc_rows=0, tsd_len=4, tsd_frac=tf, homolog_flank_l=hl, homolog_flank_r=hr)
+        for rows, tr, lg in ((12, 6, 4), (16, 6, 7), (9, 4, 3)):
+            i += 1
+            add("middle third of the element: '-' in most full-length rows", te_type, plant=1, seed=seed0 * 100 + i, rows=rows, te_len=240, div=0.04,
+                row_gap_rate=0.0, ins_cols=0, trunc_rows=tr, tsd_len=8, tsd_frac=tf, long_gap_rows=lg)
+        # leading / trailing flank columns that are dense in the alignment but '-' in most full-length rows, homology reaching into them
+        for hl, cut, side in ((38, 16, "l"), (36, 20, "l"), (38, 16, "r"), (30, 26, "l")):
+            i += 1
+            c = add("homology starts inside flank columns that most full-length rows lack (%s)" % side, te_type, plant=1, seed=seed0 * 100 + i, rows=12,
+                    te_len=200, div=0.04, row_gap_rate=0.0, ins_cols=0, trunc_rows=0, tsd_len=0, tsd_frac=0.0,
+                    homolog_flank_l=hl if side == "l" else 0, homolog_flank_r=hl if side == "r" else 0)
+            W = len(c["seqs"][0])
+            seqs = list(c["seqs"])
+            for r in range(1, 8):
+                seqs[r] = "-" * cut + seqs[r][cut:] if side == "l" else seqs[r][:W - cut] + "-" * cut
+            # six rows that lack the OTHER end (not full length) keep those columns dense in the alignment
+            extra = [(s[:W - 90] + "-" * 90) if side == "l" else ("-" * 90 + s[90:]) for s in c["seqs"][1:7]]
+            c["seqs"] = seqs + extra
+            c["names"] = ["chr%d:%d-%d(%s)" % (k % 5, 1000 + 37 * k, 1000 + 37 * k + 199, "+-"[k % 2]) for k in range(len(c["seqs"]))]
+    # the terminal trims of judge_boundary_v5: A / TA / AA / TAA / TTA / TTAA at the start, T / TT / TA / TAA / TTA / TTAA at the end
+    for sm, em in (("TTAA", "TTAA"), ("TAA", "TTA"), ("TA", "TA"), ("AA", "TT"), ("A", "T"), ("TTA", "TAA"), (None, "TTAA"), ("TTAA", None)):
+        for tl in (2, 3, 4, 8):
+            i += 1
+            add("ends %s ... %s" % (sm, em), "tir", plant=i % 2, seed=seed0 * 100 + i, rows=10, te_len=180, div=0.03, row_gap_rate=0.0, ins_cols=0,
+                trunc_rows=0, tsd_len=tl, tsd_frac=1.0, start_motif=sm, end_motif=em)
     return out
 
 

@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 ORACLE_DIR = os.path.join(ROOT, "oracle")
-SO = os.path.join(ORACLE_DIR, "libhite_oracle.so")
+SO = os.environ.get("HITE_ORACLE_SO") or os.path.join(ORACLE_DIR, "libhite_oracle.so")     # (override: a gcov build, tools/oracle_line_coverage.sh)
 
 ORC_EXC = -1000
 _lib = None

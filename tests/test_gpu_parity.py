@@ -96,6 +96,50 @@ def test_boundary_search_golden(ctx):
     assert [[bool(v), int(b)] for v, b in zip(v4, b4)] == [c["v4"] for c in cases]
 
 
+def test_boundary_search_edge_golden(ctx):
+    """round 4: positions within 10 columns of the alignment's edges, homology that runs to the edge, alignments of 5-30 columns"""
+    cases = load_golden("boundary_search_edge")
+    msas = _msas(cases)
+    pos = [c["pos"] for c in cases]
+    side = [c["side"] for c in cases]
+    thr = [c["thr"] for c in cases]
+    b3, _ = ctx.boundary_search(msas, pos, side, thr, variant=3)
+    assert list(b3) == [c["v3"] for c in cases]
+    b4, v4 = ctx.boundary_search(msas, pos, side, thr, variant=4, int_thr=[t - 0.05 for t in thr], out_thr=thr)
+    assert [[bool(v), int(b)] for v, b in zip(v4, b4)] == [c["v4"] for c in cases]
+
+
+@pytest.mark.parametrize("mode", ["default", "block_only", "wave", "lds"])
+def test_judge_edge_golden(ctx, mode, monkeypatch):
+    """round 4: the reference's answers on the edge cases (tests/casegen.py: msa_edge_cases), through sparse-column removal and
+    every judge kernel form"""
+    env = {"default": {}, "block_only": {"HITE_JUDGE_WAVE_COLS": "0", "HITE_JUDGE_LDS": "0"},
+           "wave": {"HITE_JUDGE_WAVE_MIN_BATCH": "0", "HITE_JUDGE_LDS": "0"},
+           "lds": {"HITE_JUDGE_LDS": "1", "HITE_JUDGE_WAVE_MIN_BATCH": "0", "HITE_JUDGE_LDS_WAVE0": "2048", "HITE_JUDGE_LDS_WAVE1": "6000"}}[mode]
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cases = load_golden("judge_edge")
+    if mode == "default":
+        got = ctx.sparse_cols(_msas(cases))
+        for c, g in zip(cases, got):
+            assert ["".join(map(chr, r)) for r in g] == c["clean"]
+    n = 0
+    for te_type in ("tir", "non_ltr", "helitron"):
+        for plant in (0, 1):
+            sub = [c for c in cases if c["plant"] == plant and c["te_type"] == te_type]
+            if not sub:
+                continue
+            got = ctx.judge(te_type, _msas(sub, "clean"), [c["cand"] for c in sub], plant=plant)
+            for i, (c, g) in enumerate(zip(sub, got)):
+                exp = c["expected"]
+                if exp[0] == "EXC":
+                    assert g[1] == "EXC", (i, g, exp)
+                else:
+                    assert [g[0], g[1], g[2], g[3]] == exp, (te_type, plant, i, c["aim"], g, exp)
+                n += 1
+    assert n == len(cases)
+
+
 def test_threshold_ties_golden_on_gpu(ctx):
     """thr / thr - 0.1 ties in binary64: columns at exactly k/R of the rows, through the HIP searches"""
     cases = load_golden("thr_ties_search")

@@ -43,6 +43,39 @@ def test_judge_golden(name, te_type):
     assert ntrue >= 2
 
 
+def test_judge_edge_golden():
+    """round 4: the cases aimed at the reference lines the earlier fixtures never reached (tools/ref_line_coverage.py): anchors
+    and homology next to the alignment's edges, no flank at all, '-' majorities inside the element, the TA / TAA / TTAA trims"""
+    cases = load_golden("judge_edge")
+    regen = casegen.msa_edge_cases(61)
+    assert len(cases) == len(regen)
+    seen = {}
+    for i, (case, r) in enumerate(zip(cases, regen)):
+        assert case["seqs"] == r["seqs"] and case["cand"] == r["cand"] and case["aim"] == r["aim"]      # the fixture's inputs are the generator's
+        msa = O.msa_array(case["seqs"])
+        keep = O.sparse_cols(msa).astype(bool)
+        assert ["".join(chr(c) for c in row[keep]) for row in msa] == case["clean"], i
+        got, _ = O.judge(case["te_type"], O.msa_array(case["clean"]), case["cand"], case["plant"])
+        exp = case["expected"]
+        if exp[0] == "EXC":
+            assert got[0] == "EXC", (i, got, exp)
+        else:
+            assert got == exp, (i, case["aim"], got, exp)
+        seen[(case["te_type"], bool(exp[0] is True))] = seen.get((case["te_type"], bool(exp[0] is True)), 0) + 1
+    assert all(seen.get((t, v), 0) >= 5 for t in ("tir", "non_ltr", "helitron") for v in (True, False)), seen
+
+
+def test_boundary_search_edge_golden():
+    cases = load_golden("boundary_search_edge")
+    assert len(cases) > 1500 and sum(c["v3"] != -1 for c in cases) > 300 and sum(c["v3"] == -1 for c in cases) > 300
+    for i, case in enumerate(cases):
+        msa = O.msa_array(case["seqs"])
+        thr = case["thr"]
+        assert O.search_v3(msa, case["pos"], case["side"], thr) == case["v3"], i
+        v, b = O.search_v4(msa, case["pos"], case["side"], thr, thr - 0.05, thr)
+        assert [v, b] == case["v4"], i
+
+
 def test_boundary_search_golden():
     for i, case in enumerate(load_golden("boundary_search")):
         msa = O.msa_array(case["seqs"])
