@@ -318,6 +318,47 @@ def gen_tir_kmer(U):
                     cases.append(dict(seq=seq, flank=flank, plant=plant, name="q%d" % i, n=len(res), items=items))
     dump("tir_kmer", cases)
 
+    # round 4 (tools/ref_line_coverage.py): candidates shorter than two flanks (the right window starts before the sequence, TSD
+    # positions beyond its end), N N as a "TSD" on both sides, elements that start with TATATATA / ATATATAT
+    rng = np.random.default_rng(4100)
+    edge = []
+
+    def run(seq, tag):
+        for plant in (0, 1):
+            res = U.search_confident_tir_v4(seq, 51, len(seq) - 50, 50, tag, plant)
+            items = []
+            for name, s in res.items():
+                parts = name.split("-")
+                tsd = [p for p in parts if p.startswith("tsd_")][0][4:]
+                dist = int([p for p in parts if p.startswith("distance_")][0][9:])
+                items.append([dist, tsd, s])
+            items.sort()
+            edge.append(dict(seq=seq, flank=50, plant=plant, name=tag, n=len(res), items=items))
+
+    for L in (51, 52, 60, 75, 99, 100, 101, 102, 103, 110, 125, 150):      # (a flanked candidate is never shorter than one flank + 1)
+        for rep in range(2):
+            tsd = casegen.rand_seq(rng, int(rng.choice([2, 3, 4, 5, 8])))
+            core = casegen.rand_seq(rng, max(1, L // 3))
+            s = casegen.rand_seq(rng, L)
+            a = max(0, L // 3 - len(tsd))
+            s = (s[:a] + tsd + core + tsd + s)[:L]
+            run(s, "short%d_%d" % (L, rep))
+    for i in range(12):
+        seq, _f = casegen.make_tir_candidate(4200 + i, te_len=200, tsd_len=[2, 3, 4, 8][i % 4], off_l=0, off_r=0)
+        a = 50 - 2 - (i % 5)
+        b = len(seq) - 50 + (i % 4)
+        seq = seq[:a] + "NN" + seq[a + 2:b] + "NN" + seq[b + 2:]
+        if i % 3 == 0:      # a longer run on both sides: NNN, NNNN as k-mers too
+            seq = seq[:a - 2] + "NNNN" + seq[a + 2:b] + "NNNN" + seq[b + 4:]
+        run(seq, "nn%d" % i)
+    for i in range(12):
+        seq, _f = casegen.make_tir_candidate(4300 + i, te_len=180, tsd_len=[2, 3, 4, 5, 8, 9][i % 6], off_l=0, off_r=0)
+        head = "TATATATA" if i % 2 == 0 else "ATATATAT"
+        seq = seq[:50] + head + seq[58:]        # (make_tir_candidate cuts the sequence so that the element starts at column 50)
+        run(seq, "tata%d" % i)
+    print("tir_kmer_edge:", len(edge), "cases,", sum(c["n"] > 0 for c in edge), "with TSDs")
+    dump("tir_kmer_edge", edge)
+
 
 def gen_gather(U, tmp):
     cases = []
@@ -427,6 +468,10 @@ def gen_host(U):
                 seq = seq[:2] + "N" + seq[3:]
             tsd = casegen.rand_seq(rng, int(rng.choice([2, 3, 4, 8, 9, 10, 11, 12])))
             contigs["chr1:%d-%d-C_%d-tsd_%s-distance_%d" % (q * 100, q * 100 + len(seq), q % 7, tsd, int(rng.integers(0, 40)))] = seq
+        # round 4 (Util.py:7329): CACTA / CACTG ends with a 3-base TSD (kept for plants only), and the same ends with a 2-base one
+        for q, (head, tsd) in enumerate((("CACTA", "TAA"), ("CACTG", "GCA"), ("CACTA", "TA"), ("CACTG", "TTAA"))):
+            seq = head + "ACGGTCATTG" * 9 + "".join(comp[c] for c in reversed(head))
+            contigs["chr2:%d-%d-C_0-tsd_%s-distance_3" % (q * 100, q * 100 + len(seq), tsd)] = seq
         got = U.get_short_tir_contigs(dict(contigs), plant)
         short_cases.append({"plant": plant, "names": list(contigs.keys()), "seqs": list(contigs.values()), "kept": list(got.keys())})
     dup_cases = []
@@ -445,6 +490,13 @@ def gen_host(U):
     for thr in (100, 1000, 5000):
         names = ["s%d" % i for i in range(int(rng.integers(1, 30)))]
         lens = [int(rng.integers(1, 1500)) for _ in names]
+        with tempfile.TemporaryDirectory() as d:
+            files = U.split_and_store_sequences(names, {n: "A" * l for n, l in zip(names, lens)}, d, thr)
+            groups = [U.read_fasta(f[0])[0] for f in files]
+        split_cases.append({"names": names, "lens": lens, "thr": thr, "groups": groups})
+    # round 4 (Util.py:5008-5011): sequences left over after the last full file, an exact fit, one sequence below the threshold
+    for names, lens, thr in ((["a", "b", "c"], [400, 700, 50], 1000), (["a", "b", "c", "d"], [500, 500, 999, 1], 1000), (["only"], [12], 1000),
+                             (["a", "b", "c", "d", "e"], [10, 20, 30, 40, 50], 10_000)):
         with tempfile.TemporaryDirectory() as d:
             files = U.split_and_store_sequences(names, {n: "A" * l for n, l in zip(names, lens)}, d, thr)
             groups = [U.read_fasta(f[0])[0] for f in files]
@@ -767,6 +819,11 @@ def gen_chain_variants(U, tmp):
         qlen = [int(rng.integers(200, 3000)) for _ in range(nq)]
         slen = [int(rng.integers(20_000, 200_000)) for _ in range(ns)]
         rows = _te_vs_genome_rows(rng, nq, ns, qlen, slen)
+        if ci % 4 == 2 and qlen[0] >= 320:
+            # round 4 (tools/ref_line_coverage.py, Util.py:6079 / 6096): two short fragments of the two ENDS of a query next to each other
+            # in the subject, both strands -- the query gap reaches skip_gap = 0.95 x the query, the extension loop breaks
+            Lq = qlen[0]
+            rows += [(0, 0, 1, 9, 5001, 5009), (0, 0, Lq - 8, Lq, 5030, 5038), (0, 0, 1, 9, 9038, 9030), (0, 0, Lq - 8, Lq, 9009, 9001)]
         qnames = ["TE_%d#%s" % (q, ["DNA/hAT", "LTR/Gypsy", "Unknown"][q % 3]) if q % 2 else "Helitron_%d" % q for q in range(nq)]
         snames = ["chr%d" % s_ for s_ in range(ns)]
         thr = float(rng.choice([0.95, 0.95, 0.8]))
@@ -805,6 +862,11 @@ def gen_chain_variants(U, tmp):
         qlen = [int(rng.integers(200, 2000)) for _ in range(nq)]
         slen = [int(rng.integers(60_000, 200_000)) for _ in range(ns)]
         rows = _te_vs_genome_rows(rng, nq, ns, qlen, slen, many_first=ci % 2 == 0)
+        if ci == 0:
+            # round 4 (Util.py:7206): 60 full-length single-HSP copies of query 0 per chromosome file -- it reaches 100 copies after
+            # the second file and leaves the query file before the third is searched
+            for s_ in range(ns):
+                rows += [(0, s_, 1, qlen[0], 1000 + 700 * k_, 1000 + 700 * k_ + qlen[0] - 1) for k_ in range(60) if 1000 + 700 * k_ + qlen[0] < slen[s_]]
         qnames = ["TE_%d" % q for q in range(nq)]
         files = ["chr%d.fa" % s_ for s_ in range(ns)] + ["chr0.fa.nhr", "notes.txt"]
         files = [files[i] for i in rng.permutation(len(files))]

@@ -435,7 +435,7 @@ def test_util_mirror_file_contracts(ctx, tmp_path):
 def test_tsd_kmer_golden_and_oracle(ctx):
     from test_oracle_golden import check_tir_items
 
-    cases = load_golden("tir_kmer")
+    cases = load_golden("tir_kmer") + load_golden("tir_kmer_edge")
     for plant in (0, 1):
         sub = [c for c in cases if c["plant"] == plant]
         got = ctx.tsd_kmer([c["seq"] for c in sub], flank=50, plant=plant)

@@ -139,6 +139,18 @@ def test_tir_kmer_golden():
         check_tir_items(items, case)
 
 
+def test_tir_kmer_edge_golden():
+    """round 4: candidates barely longer than their flanks (windows that run past the sequence), 'NN' as a k-mer on both sides, elements
+    that start with TATATATA / ATATATAT (tools/ref_line_coverage.py: the lines of search_confident_tir_v4 the first fixture missed)"""
+    cases = load_golden("tir_kmer_edge")
+    assert len(cases) >= 90 and sum(c["n"] > 0 for c in cases) >= 40 and sum(c["n"] == 0 for c in cases) >= 20
+    for case in cases:
+        seq, flank = case["seq"], case["flank"]
+        recs = O.tir_kmer(seq, flank + 1, len(seq) - flank, flank, case["plant"])
+        items = sorted([d, seq[ts - k:ts], seq[ts:te + 1]] for (k, ts, te, d) in recs)
+        check_tir_items(items, case)
+
+
 def test_gather_golden():
     for case in load_golden("gather"):
         contigs = dict(zip(case["names"], case["seqs"]))
