@@ -5,7 +5,9 @@
 #pragma once
 #include "hite_common.h"
 
+#ifndef FILL_U
 #define FILL_U 4        // positions in flight per thread
+#endif
 
 // Out: pointer to the output row (global or LDS bytes); t = index of the thread among the TS threads that share the row
 template <class Out, int TS>
@@ -15,16 +17,24 @@ __device__ __forceinline__ void fill_sparse_row(Out row, const uint8_t *__restri
         // the common position keeps its centre column and nothing else: layout word, op, base, one store -- straight-line
         // code for FILL_U positions, their loads issued level by level.  Kept insertion columns and the extra last column
         // are rare and leave through one branch at the end (every branch that a wave takes for one of its lanes costs all 64)
+        // (every load is unconditional, from a clamped index, and the value is masked afterwards: a load under a condition
+        // compiles to a branch around it, and the loads of one level then wait for each other instead of flying together)
         unsigned w[FILL_U], oc[FILL_U];
 #pragma unroll
         for (int u = 0; u < FILL_U; u++) {
             const int p = p0 + u * TS;
-            w[u] = p <= m ? lay[p] : 0u;
-            oc[u] = centre ? (unsigned)p : (p < m ? (unsigned)rop[p] : 0x8000u);
+            const unsigned wl = lay[p <= m ? p : m];
+            const unsigned ol = rop[p < m ? p : m - 1];
+            w[u] = p <= m ? wl : 0u;
+            oc[u] = centre ? (unsigned)p : (p < m ? ol : 0x8000u);
         }
         uint8_t ch[FILL_U];
 #pragma unroll
-        for (int u = 0; u < FILL_U; u++) ch[u] = ((w[u] >> 15) & 1u) && !(oc[u] >> 15) ? b[oc[u] & 0x7fffu] : (uint8_t)'-';
+        for (int u = 0; u < FILL_U; u++) {
+            const bool base = ((w[u] >> 15) & 1u) && !(oc[u] >> 15);
+            const uint8_t cb = b[base ? (oc[u] & 0x7fffu) : 0u];
+            ch[u] = base ? cb : (uint8_t)'-';
+        }
         bool rare = false;
 #pragma unroll
         for (int u = 0; u < FILL_U; u++) {

@@ -183,7 +183,7 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
                 unsigned long long o4[4];
                 unsigned om[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { o4[u] = lay_ld8(col + (int64_t)(r + u) * rs); om[u] = p0 > 0 ? col[(int64_t)(r + u) * rs - 1] : 0u; }
+                for (int u = 0; u < 4; u++) { o4[u] = lay_ld8(col + (int64_t)(r + u) * rs); om[u] = col[(int64_t)(r + u) * rs - (p0 > 0 ? 1 : 0)]; }   // (p0 == 0: not used; unconditional loads fly together)
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int wl = r + u < MSA_MAXR ? s_wl[r + u] : P.win_len[g0 + msa_src(P.row_map, g0, r + u)];
@@ -202,7 +202,7 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
             }
             for (; r < R; r++) {
                 const unsigned long long o4 = lay_ld8(col + (int64_t)r * rs);
-                unsigned op = p0 > 0 ? col[(int64_t)r * rs - 1] : 0u;
+                unsigned op = col[(int64_t)r * rs - (p0 > 0 ? 1 : 0)];
                 const int wl = r < MSA_MAXR ? s_wl[r] : P.win_len[g0 + msa_src(P.row_map, g0, r)];
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
@@ -287,12 +287,22 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
     // loads of each dependency level issued together (the chain kwslot -> ops -> base is three loads deep and the kernel is
     // latency bound otherwise); per-row values (window, length, output row) are wave-uniform: no division, little address math
     const int rs = m + 1;
-    for (int r = blockIdx.y; r < R; r += gridDim.y) {
-        const uint8_t *b = P.win + P.win_off[g0 + msa_src(P.row_map, g0, r)];
-        const int nrow = P.win_len[g0 + msa_src(P.row_map, g0, r)];
+    int r = blockIdx.y;
+    if (r >= R) return;
+    // the window of the NEXT row of this block is looked up while the current one is filled: row_map -> win_off / win_len are
+    // two dependent scalar round trips, as long as the two or three trips over the positions that a row of 2.5 kb takes
+    int src = msa_src(P.row_map, g0, r);
+    int64_t woff = P.win_off[g0 + src];
+    int nrow = P.win_len[g0 + src];
+    while (r < R) {
+        const int rn = r + (int)gridDim.y;
+        int64_t woff_n = 0; int nrow_n = 0;
+        if (rn < R) { const int sn = msa_src(P.row_map, g0, rn); woff_n = P.win_off[g0 + sn]; nrow_n = P.win_len[g0 + sn]; }
+        const uint8_t *b = P.win + woff;
         const uint16_t *rop = ops + (int64_t)r * rs;
         uint8_t *row = out + (int64_t)r * C;
         fill_sparse_row<uint8_t *, 256>(row, b, nrow, rop, lay, m, le, r == 0 /* the centre row: position p faces its own base p */, (int)threadIdx.x);
+        r = rn; woff = woff_n; nrow = nrow_n;
     }
 }
 
