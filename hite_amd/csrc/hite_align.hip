@@ -163,9 +163,16 @@ __global__ void __launch_bounds__(256) align_planes_kernel(int n_cand, const uin
     uint4 *out = planes + plane_off[c];
     for (int wi = threadIdx.x; wi < nw; wi += 256) {
         uint32_t p0 = 0, p1 = 0, pn = 0;
+        unsigned chs[32];      // (unconditional loads from a clamped index: all 32 in flight together)
+#pragma unroll
         for (int k = 0; k < 32; k++) {
             const int r = wi * 32 + k - AL_PADR + 1;
-            unsigned ch = (r >= 1 && r <= m) ? a[r - 1] : 0u;
+            chs[k] = a[r < 1 ? 0 : (r > m ? m - 1 : r - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+            const int r = wi * 32 + k - AL_PADR + 1;
+            const unsigned ch = (r >= 1 && r <= m) ? chs[k] : 0u;
             if (is_acgt_byte(ch)) { p0 |= ((ch >> 1) & 1u) << k; p1 |= ((ch >> 2) & 1u) << k; }
             else pn |= 1u << k;
         }

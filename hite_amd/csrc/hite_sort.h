@@ -23,9 +23,18 @@ static __global__ void __launch_bounds__(256) rs_hist_kernel(const unsigned long
     for (int b = threadIdx.x; b < BINS; b += 256) h[b] = 0;
     __syncthreads();
     int64_t base = (int64_t)blockIdx.x * (256 * ITEMS);
+    // all ITEMS keys of a thread are requested before the first is counted (a load under `i < n` compiles to a branch around it and a
+    // wait behind it: ITEMS dependent trips to HBM per thread); the last tile re-reads its last key and does not count it
+    unsigned long long kk[ITEMS];
+#pragma unroll
     for (int it = 0; it < ITEMS; it++) {
-        int64_t i = base + it * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[(int)((keys[i] >> shift) & (unsigned long long)(BINS - 1))], 1);
+        const int64_t i = base + it * 256 + threadIdx.x;
+        kk[it] = keys[i < n ? i : n - 1];
+    }
+#pragma unroll
+    for (int it = 0; it < ITEMS; it++) {
+        const int64_t i = base + it * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(int)((kk[it] >> shift) & (unsigned long long)(BINS - 1))], 1);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < BINS; b += 256) hist[(int64_t)blockIdx.x * BINS + b] = h[b];      // tile-major: one coalesced run per tile
