@@ -96,6 +96,10 @@ def main():
             print("%-52s %4d / %4d  %5.1f %%   %s" % ("%s (%s:%d)" % (name, tag, f.__code__.co_firstlineno), len(ex), len(lines),
                                                      100.0 * len(ex) / max(1, len(lines)), " ".join(map(str, miss)) if miss else "-"))
     print("# total %d / %d = %.1f %%" % (tot_e, tot_x, 100.0 * tot_e / max(1, tot_x)))
+    never = [n for n in WATCH if not any(hasattr(getattr(mod, n, None), "__code__") and (code_lines(getattr(mod, n).__code__) & hs)
+                                         for mod, hs in ((U, allhit), (F, fhit)) if mod is not None)]
+    print("# watched but never entered by a generator (wrappers around the above, or run in worker processes the tracer does not follow): "
+          + ", ".join(never))
 
 
 if __name__ == "__main__":
