@@ -23,7 +23,12 @@ WATCH = ["get_longest_repeats_v4", "FMEA", "get_full_length_copies_from_blastn_v
          "get_boundary_ungap_str", "TSDsearch_v5", "is_TE_from_align_file", "generate_cons_v1", "split_and_store_sequences",
          "get_short_tir_contigs", "filter_dup_itr_v3", "FMEA_new1_parallel_large", "process_blast_results_in_chunks",
          "multiple_alignment_blast_and_get_copies_v1", "get_domain_info", "judge_both_ends_frame_v1", "judge_left_frame_LTR",
-         "judge_right_frame_LTR", "filter_ltr_by_flank_seq_v2", "get_non_empty_seq", "map_fragment"]
+         "judge_right_frame_LTR", "filter_ltr_by_flank_seq_v2", "get_non_empty_seq", "map_fragment",
+         # the pieces the generators call directly (f-1 ... f-4, a-22 and the library merge)
+         "flank_region_align_v5", "calculate_window_homology", "search_polyA_TSD", "find_tail_polyA", "find_longest_tandem_repeat_tail",
+         "process_chunk", "extend_fragments", "cluster_sequences_from_chunks", "cons_from_mafft_v1", "save_data_in_chunks", "rename_fasta",
+         "rename_reference", "lib_add_prefix", "file_exist", "update_prev_TE", "getReverseSequence", "get_both_ends_frame",
+         "most_common_element", "read_Ninja_clusters", "generate_both_ends_frame_for_intactLTR", "get_LTR_seq_from_scn"]
 
 
 def code_lines(code):
