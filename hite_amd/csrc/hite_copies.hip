@@ -607,6 +607,10 @@ __global__ void __launch_bounds__(256) chain_extend_kernel(const unsigned long l
     if (n_long + n_short > cap) n_short = cap - n_long;
     const unsigned long long ntask = 2ull * (n_long + n_short);
     const int lane = threadIdx.x & 63;
+    __shared__ uint32_t s_lut[EXT_LUT_WORDS];          // the column-minimum tables of the bit-parallel band (hite_ext.h)
+    for (int t = threadIdx.x; t < EXT_LUT_WORDS; t += 256) s_lut[t] = ext_lut_entry(t >> 8, t & 255);
+    __syncthreads();
+    EXT_LUT_PTR lut = (EXT_LUT_PTR)s_lut;
     ExtState E;
     E.n = 0; E.i = 1;
     bool active = false, exhausted = false;
@@ -646,7 +650,7 @@ __global__ void __launch_bounds__(256) chain_extend_kernel(const unsigned long l
         if (__ballot(active) == 0ull) { if (exhausted) break; else continue; }
         if (active) {
             cols_done++;
-            if (ext_step(E, bases, nmask)) { x_i[my] = E.best_i; x_t[my] = E.best_t; active = false; }
+            if (ext_step(E, bases, nmask, lut)) { x_i[my] = E.best_i; x_t[my] = E.best_t; active = false; }
         }
     }
     // statistics: DP columns computed (one atomic per wavefront)

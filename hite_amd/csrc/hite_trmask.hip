@@ -74,8 +74,8 @@ __device__ void tr_extend(int64_t s, int p, const uint32_t *__restrict__ bases, 
     int64_t nl = s - cb; if (nl > TR_MAXEXT) nl = TR_MAXEXT;
     const int lim = p - 1 < EXT_B ? p - 1 : EXT_B;
     int ir, tr, sr, il, tl, sl;
-    ext_align_dev<ExtTandemMode>(nullptr, s, +1, false, (int)nr, bases, nmask, s + p, +1, ce - (s + p), -lim, EXT_B, &ir, &tr, &sr);
-    ext_align_dev<ExtTandemMode>(nullptr, s - 1, -1, false, (int)nl, bases, nmask, s + p, -1, s + p - cb, -EXT_B, lim, &il, &tl, &sl);
+    ext_align_dev<ExtTandemMode>(nullptr, s, +1, false, (int)nr, bases, nmask, s + p, +1, ce - (s + p), -lim, EXT_B, &ir, &tr, &sr, nullptr);
+    ext_align_dev<ExtTandemMode>(nullptr, s - 1, -1, false, (int)nl, bases, nmask, s + p, -1, s + p - cb, -EXT_B, lim, &il, &tl, &sl, nullptr);
     if (il + ir <= 0) return;
     if (sl + sr + 2 * p < TR_MINSCORE) return;
     if (il + ir < (85 * p + 99) / 100) return;

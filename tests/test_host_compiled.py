@@ -42,15 +42,47 @@ def _build(tmp_path, name, body, wrapper):
 
 def _ext_lib(tmp_path):
     body = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_ext.h"), "ext_align_dev")
-    return _build(tmp_path, "ext", body, r"""
+    # (on the device the column-minimum tables of the bit-parallel band live in LDS; here they are a plain array)
+    return _build(tmp_path, "ext", "#define EXT_LUT_PTR const uint32_t *\n" + body, r"""
+static uint32_t g_lut[EXT_LUT_WORDS];
+static bool g_lut_ready = false;
+static const uint32_t *host_lut() {
+    if (!g_lut_ready) { for (int t = 0; t < EXT_LUT_WORDS; t++) g_lut[t] = ext_lut_entry(t >> 8, t & 255); g_lut_ready = true; }
+    return g_lut;
+}
 extern "C" void host_ext(const uint8_t *q, int64_t p0, int step, int comp, int n, const uint32_t *bases, const uint32_t *nmask,
                          int64_t g0, int dir, int64_t jmax, int *i_out, int *t_out) {
     int s;
-    ext_align_dev<ExtCopyMode>(q, p0, step, comp != 0, n, bases, nmask, g0, dir, jmax, -EXT_B, EXT_B, i_out, t_out, &s);
+    ext_align_dev<ExtCopyMode>(q, p0, step, comp != 0, n, bases, nmask, g0, dir, jmax, -EXT_B, EXT_B, i_out, t_out, &s, host_lut());
+}
+// the bit-parallel band against the cell-by-cell band, column by column: both states walk the same extension; after every column
+// the 17 cell values (ext_expand of a copy of the fast state), the best score so far and its position must agree.
+// returns -1, or the first column at which they differ
+extern "C" int host_ext_lockstep(const uint8_t *q, int64_t p0, int step, int comp, int n, const uint32_t *bases, const uint32_t *nmask,
+                                 int64_t g0, int dir, int64_t jmax, int *n_fast) {
+    ExtStateT<ExtCopyMode> A, B;
+    ext_init(A, q, p0, step, comp != 0, n, bases, nmask, g0, dir, jmax);
+    ext_init(B, q, p0, step, comp != 0, n, bases, nmask, g0, dir, jmax);
+    B.fast = false;
+    *n_fast = 0;
+    if (n < 1) return -1;
+    for (;;) {
+        const bool was_fast = A.fast;
+        const bool da = ext_step(A, bases, nmask, host_lut()), db = ext_step(B, bases, nmask, host_lut());
+        *n_fast += was_fast && A.fast;
+        if (da != db || A.best_i != B.best_i || A.best_t != B.best_t || A.best_s != B.best_s || A.i != B.i) return B.i;
+        if (da) return -1;
+        ExtStateT<ExtCopyMode> X = A;
+        if (X.fast) ext_expand(X);
+        for (int b = 0; b < EXT_W; b++) {
+            const int va = X.D[b] >= EXT_INF ? EXT_INF : X.D[b], vb = B.D[b] >= EXT_INF ? EXT_INF : B.D[b];
+            if (va != vb) return B.i;
+        }
+    }
 }
 extern "C" void host_ext_tandem(int64_t p0, int step, int n, const uint32_t *bases, const uint32_t *nmask,
                                 int64_t g0, int dir, int64_t jmax, int dlo, int dhi, int *i_out, int *t_out, int *s_out) {
-    ext_align_dev<ExtTandemMode>(nullptr, p0, step, false, n, bases, nmask, g0, dir, jmax, dlo, dhi, i_out, t_out, s_out);
+    ext_align_dev<ExtTandemMode>(nullptr, p0, step, false, n, bases, nmask, g0, dir, jmax, dlo, dhi, i_out, t_out, s_out, nullptr);
 }
 """)
 
@@ -140,9 +172,9 @@ def test_ext_align_device_function_vs_twin(tmp_path):
     L.orc_ext_align.restype = C.c_int64
     rng = np.random.default_rng(7)
     comp = {65: 84, 67: 71, 71: 67, 84: 65}
-    n_cases = n_cut = n_full = 0
-    for case in range(400):
-        G = int(rng.integers(80, 900))
+    n_cases = n_cut = n_full = n_fast_cols = 0
+    for case in range(1600):
+        G = int(rng.integers(80, 900)) if case % 8 else int(rng.integers(2500, 5000))
         genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=G)
         if case % 7 == 0:
             genome[rng.integers(0, G, size=3)] = ord("N")
@@ -162,7 +194,7 @@ def test_ext_align_device_function_vs_twin(tmp_path):
             part = isn[k::32]
             nm[:len(part)] |= part << np.uint32(k)
         d = +1 if case % 2 == 0 else -1
-        n = int(rng.integers(0, min(G - 20, 400)))
+        n = int(rng.integers(0, min(G - 20, 400 if case % 8 else 2048)))
         g0 = int(rng.integers(10, G - 10))
         gmin, gmax = (0, G) if case % 5 else (int(rng.integers(0, g0 + 1)), int(rng.integers(g0, G + 1)))
         # query segment in walking order: a diverged copy of the genome it walks over for `hom` bases, then unrelated bases
@@ -207,10 +239,15 @@ def test_ext_align_device_function_vs_twin(tmp_path):
         lib.host_ext(q.ctypes.data_as(O.u8p), C.c_int64(p0), step, int(strand), n, bases.ctypes.data_as(C.POINTER(C.c_uint32)),
                      nm.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(g0), d, C.c_int64(jmax), C.byref(io), C.byref(to))
         assert (io.value, to.value) == (int(i_ref), int(t_ref.value)), (case, n, hom, d, g0, gmin, gmax, io.value, to.value, i_ref, t_ref.value)
+        nf = C.c_int(0)
+        bad = lib.host_ext_lockstep(q.ctypes.data_as(O.u8p), C.c_int64(p0), step, int(strand), n, bases.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                    nm.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(g0), d, C.c_int64(jmax), C.byref(nf))
+        assert bad == -1, (case, "bit-parallel and cell-by-cell bands differ at column", bad)
+        n_fast_cols += nf.value
         n_cases += 1
         n_cut += 0 < i_ref < n
         n_full += i_ref == n and n > 0
-    assert n_cases == 400 and n_cut > 40 and n_full > 40
+    assert n_cases == 1600 and n_cut > 160 and n_full > 160 and n_fast_cols > 50_000
 
 
 def test_tr_seed_kernel_logic_vs_twin(tmp_path):
@@ -221,7 +258,7 @@ def test_tr_seed_kernel_logic_vs_twin(tmp_path):
 
     ext = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_ext.h"), "ext_align_dev")
     body = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_trmask.hip"), "tr_seed")
-    lib = _build(tmp_path, "trseed", ext + r"""
+    lib = _build(tmp_path, "trseed", "#define EXT_LUT_PTR const uint32_t *\n" + ext + r"""
 #define TR_MAXEXT 4096
 #define TR_MINSCORE 50
 #define TR_RESEED 2048
