@@ -36,7 +36,8 @@ def _build(tmp_path, name, body, wrapper):
     cpp = tmp_path / (name + ".cpp")
     so = tmp_path / (name + ".so")
     cpp.write_text(PRELUDE + body + wrapper)
-    subprocess.run(["g++", "-O2", "-shared", "-fPIC", "-o", str(so), str(cpp)], check=True)
+    extra = os.environ.get("HITE_HOST_CXXFLAGS", "").split()       # e.g. -fsanitize=address,undefined (with libasan preloaded)
+    subprocess.run(["g++", "-O2", "-shared", "-fPIC"] + extra + ["-o", str(so), str(cpp)], check=True)
     return C.CDLL(str(so))
 
 
