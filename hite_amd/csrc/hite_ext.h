@@ -4,7 +4,7 @@
 #pragma once
 #include "hite_common.h"
 
-// the table of ext_lut_fill lives in LDS on the device (the host build of the block below defines its own pointer type)
+// the tables of ext_lut_entry live in LDS on the device (the host build of the block below defines its own pointer type)
 #define EXT_LUT_PTR const __attribute__((address_space(3))) uint32_t *
 
 // >>> ext_align_dev (tests/test_host_compiled.py compiles this block for the host and compares it with the twin)
