@@ -1179,7 +1179,7 @@ def filter_tandem_repeats(repeat_names, repeat_contigs, tmp_output_dir, ref_inde
     the masked files are concatenated (in file order: the canonical replacement of the reference's as_completed order) into
     filter_tandem_{ref_index}.fa.  `trf` is an external tool: when it is installed (and HITE_TR_MASKER is not
     "gpu") it is called exactly as the reference calls it; otherwise the chunk is masked by the build's own GPU masker
-    (mask_tandem_repeats: same 2 / 7 / 7 scores, periods <= 500, score >= 50) -- the chunk never passes unmasked."""
+    (mask_tandem_repeats: match 2 / edit 5 -- TRF's 2 / 7 / 7 calibrated for neighbour-against-neighbour scoring --, periods <= 500, score >= 50) -- the chunk never passes unmasked."""
     out = os.path.join(tmp_output_dir, "filter_tandem_%s.fa" % ref_index)
     if shutil.which("trf") is None or os.environ.get("HITE_TR_MASKER", "") == "gpu":
         store_fasta(mask_tandem_repeats(repeat_names, repeat_contigs, device=device), out)

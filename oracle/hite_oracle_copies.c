@@ -183,7 +183,7 @@ static int contig_of(const int64_t *coff, int nc, int64_t g) {
 #define EXT_INF 1000000
 static uint8_t comp_of(uint8_t c) { return c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N'; }
 /* S(i) = sa * i - sb * C(i), abandoned xdrop below the best: (1, 3, 40) for the copy finder; the tandem-repeat masker
- * (hite_oracle_trf.c) runs the same programme with TRF's 2 / 7 / 7 as (2, 9, 30).  Only the diagonals dlo <= j - i <= dhi of
+ * (hite_oracle_trf.c) runs the same programme with match 2 / edit 5 as (2, 7, 30).  Only the diagonals dlo <= j - i <= dhi of
  * the band are used (the copy finder: all 17; the masker keeps the sequence from being aligned with ITSELF). */
 int64_t orc_ext_align_scored(const uint8_t *qseg, int64_t n, int dir, const uint8_t *genome, int64_t g0, int64_t gmin, int64_t gmax,
                              int sa, int sb, int xdrop, int dlo, int dhi, int64_t *t_out, int64_t *score_out) {

@@ -108,8 +108,8 @@ def _pack(genome):
 
 
 def test_ext_align_tandem_mode_vs_twin(tmp_path):
-    """the same device function in the tandem-repeat masker's mode (query = the packed genome itself, TRF's 2 / 7 / 7 as
-    S = 2 i - 9 cost, diagonals that pair a base with itself excluded) == orc_ext_align_scored"""
+    """the same device function in the tandem-repeat masker's mode (query = the packed genome itself, match 2 / edit 5 as
+    S = 2 i - 7 cost, diagonals that pair a base with itself excluded) == orc_ext_align_scored"""
     lib = _ext_lib(tmp_path)
     L = O.lib()
     L.orc_ext_align_scored.restype = C.c_int64
