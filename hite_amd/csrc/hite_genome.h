@@ -19,6 +19,7 @@ __device__ __forceinline__ void window_rule(const int64_t *__restrict__ coff, in
     g_lo = coff[c] + lo;
 }
 
+// >>> genome_decode (tests/test_host_compiled.py compiles this block for the host and compares it with plain slicing)
 // 4 consecutive bases starting at packed index g -> 4 ASCII bytes (little endian in a u32)
 __device__ __forceinline__ uint32_t fetch4(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
                                            int64_t g) {
@@ -134,6 +135,8 @@ __device__ __forceinline__ void emit_span(const uint32_t *__restrict__ bases, co
     if (done < cnt) emit_span4(bases, nmask, g_lo, wlen, minus, ws + done, cnt - done, dst + done, lane);
 }
 
+
+// <<< genome_decode
 
 static __global__ void flank_sizes_kernel(const int64_t *__restrict__ coff, int32_t ncontig, int64_t n,
                                    const int32_t *__restrict__ contig, const int64_t *__restrict__ s1,

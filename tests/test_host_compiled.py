@@ -323,3 +323,57 @@ extern "C" int host_name_gt(int r1, long long s1, long long e1, int m1, int r2, 
         na, nb = ("%s:%d-%d(%s)" % (a[0], a[1], a[2], "+-"[a[3]])).encode(), ("%s:%d-%d(%s)" % (b[0], b[1], b[2], "+-"[b[3]])).encode()
         got = lib.host_name_gt(rank[a[0]], C.c_longlong(a[1]), C.c_longlong(a[2]), a[3], rank[b[0]], C.c_longlong(b[1]), C.c_longlong(b[2]), b[3])
         assert bool(got) == (na > nb), (na, nb, got)
+
+
+def test_window_decode_vs_slicing(tmp_path):
+    """the window gather's per-lane code (hite_genome.h: emit_span with its 16-bases-per-lane body, byte-permute decode, reverse
+    complement by bit reversal, head / tail four at a time) == plain slicing of the sequence: every alignment of the destination,
+    both strands, spans that start and end anywhere, N bases.  The 64 lanes of the wavefront are run one after the other."""
+    body = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_genome.h"), "genome_decode")
+    lib = _build(tmp_path, "decode", r"""
+struct uint4 { uint32_t x, y, z, w; };
+// v_perm_b32 for selectors 0..3 (bytes of the second operand), which is all the decode uses
+static inline uint32_t __builtin_amdgcn_perm(uint32_t a, uint32_t b, uint32_t sel) {
+    uint32_t out = 0;
+    for (int i = 0; i < 4; i++) { const uint32_t s = (sel >> (8 * i)) & 0xffu; out |= ((s < 4 ? b >> (8 * s) : a >> (8 * (s - 4))) & 0xffu) << (8 * i); }
+    return out;
+}
+static inline uint32_t __builtin_bitreverse32(uint32_t x) { uint32_t r = 0; for (int i = 0; i < 32; i++) r |= ((x >> i) & 1u) << (31 - i); return r; }
+""" + body, r"""
+extern "C" void host_emit_span(const uint32_t *bases, const uint32_t *nmask, int64_t g_lo, int64_t wlen, int minus, int64_t ws, int64_t cnt,
+                               uint8_t *dst) {
+    for (int lane = 0; lane < 64; lane++) emit_span(bases, nmask, g_lo, wlen, minus != 0, ws, cnt, dst, lane);
+}
+""")
+    rng = np.random.default_rng(16)
+    comp = np.full(256, ord("N"), np.uint8)
+    comp[[65, 67, 71, 84]] = [84, 71, 67, 65]
+    n16 = 0
+    for case in range(600):
+        G = int(rng.integers(300, 6000))
+        genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=G)
+        if case % 3 == 0:
+            genome[rng.integers(0, G, size=int(rng.integers(1, 40)))] = ord("N")
+        if case % 10 == 0:
+            a = int(rng.integers(0, G - 40)); genome[a:a + 37] = ord("N")
+        bases, nm = _pack(genome)
+        wlen = int(rng.integers(1, min(G, 3000)))
+        g_lo = int(rng.integers(0, G - wlen + 1)) if case % 7 else 0
+        minus = case % 2
+        ws = int(rng.integers(0, wlen)) if case % 4 else 0
+        cnt = int(rng.integers(0, wlen - ws + 1)) if case % 4 else wlen
+        window = genome[g_lo:g_lo + wlen]
+        if minus:
+            window = comp[window[::-1]]
+        exp = window[ws:ws + cnt]
+        for off in (0, 4, 8, 12, int(rng.integers(0, 16))):          # alignment of the destination within 16 bytes
+            buf = np.full(cnt + 64, 0x5a, np.uint8)
+            base_addr = buf.ctypes.data
+            start = (-base_addr) % 16 + 16 + off
+            dst = C.c_void_p(base_addr + start)
+            lib.host_emit_span(bases.ctypes.data_as(C.POINTER(C.c_uint32)), nm.ctypes.data_as(C.POINTER(C.c_uint32)), C.c_int64(g_lo),
+                               C.c_int64(wlen), minus, C.c_int64(ws), C.c_int64(cnt), dst)
+            assert np.array_equal(buf[start:start + cnt], exp), (case, off, g_lo, wlen, minus, ws, cnt)
+            assert (buf[:start] == 0x5a).all() and (buf[start + cnt:] == 0x5a).all(), (case, off, "wrote outside the span")
+            n16 += cnt >= 32
+    assert n16 > 1500
