@@ -5,6 +5,8 @@
 #pragma once
 #include "hite_common.h"
 
+// >>> fill_sparse_row (tests/test_host_compiled.py compiles this block for the host: rows rebuilt from the twin's ops and a layout derived
+// from the twin's alignment must equal the twin's sparse alignment)
 #ifndef FILL_U
 #define FILL_U 4        // positions in flight per thread
 #endif
@@ -62,3 +64,4 @@ __device__ __forceinline__ void fill_sparse_row(Out row, const uint8_t *__restri
         }
     }
 }
+// <<< fill_sparse_row

@@ -377,3 +377,82 @@ extern "C" void host_emit_span(const uint32_t *bases, const uint32_t *nmask, int
             assert (buf[:start] == 0x5a).all() and (buf[start + cnt:] == 0x5a).all(), (case, off, "wrote outside the span")
             n16 += cnt >= 32
     assert n16 > 1500
+
+
+def test_fill_sparse_row_vs_twin(tmp_path):
+    """hite_fill.h: fill_sparse_row (the body of star_fill_sparse_kernel and of the judge kernels that build their alignment in LDS):
+    every row rebuilt from the twin's ops and layout words derived from the twin's FULL alignment + its sparse-column mask must be
+    the twin's sparse alignment -- insertion blocks with kept prefixes, dropped centre columns, the extra last column"""
+    import casegen
+    body = _block(os.path.join(ROOT, "hite_amd", "csrc", "hite_fill.h"), "fill_sparse_row")
+    lib = _build(tmp_path, "fill", body, r"""
+extern "C" void host_fill(uint8_t *row, const uint8_t *b, int nrow, const uint16_t *rop, const uint32_t *lay, int m, int le, int centre, int ts) {
+    if (ts == 1) fill_sparse_row<uint8_t *, 1>(row, b, nrow, rop, lay, m, le, centre != 0, 0);
+    else for (int t = 0; t < 64; t++) fill_sparse_row<uint8_t *, 64>(row, b, nrow, rop, lay, m, le, centre != 0, t);
+}
+""")
+    rng = np.random.default_rng(23)
+    n_cases = n_ins_kept = n_extra = n_dropped_centre = 0
+    for case in range(120):
+        m = int(rng.integers(100, 700))
+        centre = casegen.rand_seq(rng, m)
+        R = int(rng.integers(2, 14))
+        rows = [centre]
+        shared_ins = casegen.rand_seq(rng, int(rng.integers(1, 6)))
+        ins_at = int(rng.integers(5, m - 5))
+        for r in range(1, R):
+            s = list(casegen.mutate(rng, centre, float(rng.choice([0.0, 0.03, 0.1]))))
+            if rng.random() < 0.7:                    # an insertion most rows share: its columns survive sparse-column removal
+                s[ins_at:ins_at] = list(shared_ins)
+            if rng.random() < 0.75:                   # a deletion most rows share: that centre column is dropped
+                del s[40:40 + int(rng.integers(1, 4))]
+            if rng.random() < 0.3:                    # a private insertion (sparse: removed) and a tail beyond the centre's end
+                k = int(rng.integers(1, len(s) - 1)); s[k:k] = list(casegen.rand_seq(rng, int(rng.integers(1, 4))))
+            if case % 3 == 0 and rng.random() < 0.8:
+                s += list(casegen.rand_seq(rng, int(rng.integers(1, 5))))
+            rows.append("".join(s))
+        full, kept = O.star_msa(rows, rows=True)
+        if full is None or kept != R:
+            continue
+        keep = O.sparse_cols(full).astype(bool)
+        exp = full[:, keep]
+        ops = [None] + [O.align_pair(centre, rows[r])[0] for r in range(1, R)]
+        if any(o is None for o in ops[1:]):
+            continue
+
+        def ins_of(r, p):
+            o = ops[r]
+            prev_end = 0 if p == 0 else int(o[p - 1] & 0x7fff) + (0 if (o[p - 1] >> 15) else 1)
+            q = int(o[p] & 0x7fff) if p < m else len(rows[r])
+            return q - prev_end
+        mx = [max(ins_of(r, p) for r in range(1, R)) for p in range(m + 1)]
+        fs = np.concatenate([[0], np.cumsum([mx[p] + (1 if p < m else 0) for p in range(m + 1)])])
+        assert fs[-1] == full.shape[1]
+        before = np.concatenate([[0], np.cumsum(keep)])
+        lay = np.zeros(m + 1, np.uint32)
+        le = -1
+        for p in range(m + 1):
+            blk = keep[fs[p]:fs[p] + mx[p]]
+            kw = int(blk.sum())
+            if p == m and mx[p] > 0 and not blk[:kw].all():
+                kw -= 1                               # the forced last column is not part of the prefix
+            if p == m and mx[p] > 0 and kw < mx[p] and keep[fs[p] + mx[p] - 1]:
+                le = mx[p] - 1
+                n_extra += 1
+            assert blk[:kw].all() and not blk[kw:mx[p] - (1 if (p == m and le >= 0) else 0)].any(), (case, p)
+            keepc = int(keep[fs[p] + mx[p]]) if p < m else 0
+            lay[p] = kw | (keepc << 15) | (int(before[fs[p]]) << 16)
+            n_ins_kept += kw > 0
+            n_dropped_centre += (p < m and not keepc)
+        C_out = int(keep.sum())
+        for ts in (1, 64):
+            for r in range(R):
+                out = np.full(C_out + 8, 0x2a, np.uint8)
+                b = np.frombuffer(rows[r].encode() + b"\0" * 8, np.uint8)
+                rop = np.concatenate([ops[r], [0]]).astype(np.uint16) if r else np.zeros(m + 1, np.uint16)
+                lib.host_fill(out.ctypes.data_as(O.u8p), b.ctypes.data_as(O.u8p), len(rows[r]), rop.ctypes.data_as(C.POINTER(C.c_uint16)),
+                              lay.ctypes.data_as(C.POINTER(C.c_uint32)), m, le, int(r == 0), ts)
+                assert np.array_equal(out[:C_out], exp[r]), (case, r, ts)
+                assert (out[C_out:] == 0x2a).all()
+        n_cases += 1
+    assert n_cases > 80 and n_ins_kept > 50 and n_dropped_centre > 20 and n_extra > 3, (n_cases, n_ins_kept, n_dropped_centre, n_extra)
