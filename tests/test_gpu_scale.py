@@ -173,6 +173,43 @@ def test_c2_fine_stage_matches_oracle_chain(c2):
     assert st["certified"] >= 0.80 * st["pairs"]            # measured r02: 0.89 (exact_cap 8)
 
 
+def test_c2_wider_bands_never_lower_a_cost(c2):
+    """A re-run in a wider band can only lower a pair's cost, and a certified cost is the optimum.  Equal cost sums over all pairs at
+    exact_cap 0 / 8 / 16 therefore mean that the 4-word band already had the optimal cost for every pair the 16-word schedule
+    certifies (DESIGN.md section 2, profiles/r04_uncertified_rows_vs_optimum.txt: the certificate is conservative, not the band);
+    the calls are the same."""
+    import torch
+    from hite_amd._lib import CALL_DTYPE
+    ctx, w, n = c2["ctx"], c2["w"], c2["n"]
+    dev = torch.device("cuda", 0)
+    nbytes = int(w["cand_off"][-1])
+    d_cand = torch.from_numpy(np.concatenate([w["cands"], np.zeros(64, np.uint8)])).to(dev)
+    d_off = torch.from_numpy(np.ascontiguousarray(w["cand_off"])).to(dev)
+    d_calls = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+    cap = nbytes + 200 * n + 4096
+    d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
+    seen = {8: (c2["align"], c2["calls"])}
+    try:
+        for exact in (0, 16):
+            ctx.align_config(exact)
+            nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
+            ctx.align_stats(reset=True)
+            ctx.flank_region_align_dev("tir", 1, n, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
+                                       d_calls.data_ptr(), d_cons.data_ptr(), cap)
+            torch.cuda.synchronize()
+            seen[exact] = (ctx.align_stats(), d_calls.cpu().numpy().view(CALL_DTYPE).copy())
+    finally:
+        ctx.align_config(8)
+    st = {k: v[0] for k, v in seen.items()}
+    print("cost sums at exact_cap 0 / 8 / 16: %d / %d / %d; certified %d / %d / %d of %d pairs"
+          % (st[0]["cost"], st[8]["cost"], st[16]["cost"], st[0]["certified"], st[8]["certified"], st[16]["certified"], st[8]["pairs"]))
+    assert st[0]["pairs"] == st[8]["pairs"] == st[16]["pairs"] and st[0]["dropped"] == st[16]["dropped"] == 0
+    assert st[0]["certified"] < st[8]["certified"] < st[16]["certified"]
+    assert st[0]["cost"] == st[8]["cost"] == st[16]["cost"]
+    for exact in (0, 16):
+        assert np.array_equal(seen[exact][1]["is_te"], seen[8][1]["is_te"]) and np.array_equal(seen[exact][1]["cons_len"], seen[8][1]["cons_len"])
+
+
 @pytest.mark.parametrize("te_type", ["helitron", "non_ltr"])
 def test_c2_fine_stage_other_types_match_oracle_chain(c2, te_type):
     """the fused pipeline with TE_type Helitron / non-LTR (what judge_Helitron/Non_LTR_transposons.py run) on the C2 batch: the
