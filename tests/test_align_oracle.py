@@ -156,3 +156,40 @@ def test_star_msa_rows_are_pairwise_optimal():
         gap = both & ((centre == ord("-")) | (row == ord("-")))
         cost = int(((centre != row) & both & ~gap).sum()) + 3 * int(gap.sum())
         assert cost == O.nw_distance(wins[0], wins[r])
+
+
+def test_uncertified_rows_of_pipeline_windows_equal_the_definition():
+    """Measured, not proved (tools/uncertified_rows_vs_optimum.py: 3 246 of 3 246): on windows as the pipeline cuts them -- copies of a
+    family with 50 flanking bases, up to 30 % apart -- the rows that NO band certifies still carry the optimal cost and the canonical
+    optimal ops of the band-free definition.  Kept as a small regression sample: a change to the band's steering or to the schedule
+    that makes uncertified rows worse shows up here."""
+    import torch
+    from hite_amd import synth
+
+    w = synth.make_workload(genome_bp=4_000_000, n_tir=10, n_ltr=10, cands_per_family=10, seed=77, device=torch.device("cpu"), chrom_bp=2_000_000)
+    genome = w["genome"].numpy()
+    coff = np.asarray(w["contig_off"], dtype=np.int64)
+    contigs = [genome[coff[i]:coff[i + 1]].tobytes() for i in range(len(coff) - 1)]
+    n = len(w["cand_off"]) - 1
+    pick = np.random.default_rng(3).permutation(n)[:8]
+    tab = O.find_copies(contigs, [bytes(w["cands"][w["cand_off"][c]:w["cand_off"][c + 1]]) for c in pick])
+    comp = bytes.maketrans(b"ACGTN", b"TGCAN")
+    pairs = unc = 0
+    for copies in tab:
+        wins = []
+        for (ci, s1, e1, minus, _a) in copies[:9]:
+            lo, hi = s1 - 1 - 50, e1 + 50
+            if lo < 0 or hi > len(contigs[ci]) or hi - lo < 100:
+                continue
+            s = contigs[ci][lo:hi]
+            wins.append(s.translate(comp)[::-1] if minus else s)
+        for row in wins[1:]:
+            ops, info = O.align_pair(wins[0], row, 8)
+            if ops is None:
+                continue
+            pairs += 1
+            if not info["cert"]:
+                unc += 1
+                exp, d = O.nw_pair(wins[0], row)
+                assert info["U"] == d and np.array_equal(ops, exp), (len(wins[0]), len(row), info, d)
+    assert pairs >= 20 and unc >= 5, (pairs, unc)
