@@ -63,6 +63,17 @@ static inline int32_t col_get(const int32_t *col, int32_t above, int W, int k) {
  * (0 ok, 1 traceback left the slice / band, 2 infeasible), out[3] = k* (the certificate's bound, -1 if none).
  * returns 0 or < 0 (bad arguments).
  */
+/* Measurement aid (tools/first_exit_certificate.py; not part of the product's definition, not thread-safe): when switched on,
+ * orc_bp_pair also computes the FIRST-EXIT bound of the run -- the least cost of any alignment that leaves the band: such a path has a
+ * last in-band cell e before its first cell outside; its prefix is an in-band path (cost >= the band's value at e), the step out
+ * costs GAP (vertical / horizontal) or >= 0 (diagonal), and from the first cell outside, (r', j'), it still has to make up the
+ * diagonal offset, GAP |(m - r') - (n - j')|.  If that bound exceeds U, every optimal alignment stays inside the band, so U is the
+ * optimum and the canonical traceback only consults exact cells -- a certificate that needs no second run. */
+static int g_want_exit_bound = 0;
+static long g_exit_bound = -1;
+void orc_bp_exit_bound_enable(int on) { g_want_exit_bound = on; }
+long orc_bp_last_exit_bound(void) { return g_exit_bound; }
+
 int orc_bp_pair(const uint8_t *a, int m, const uint8_t *b, int n, int NW, int full, uint16_t *ops, int32_t *out) {
     if (m <= 0 || n <= 0 || m > 32767 || n > 32767 || NW < 4 || NW > NWMAX || (NW & 1)) return ORC_EINVAL;
     const int W = 32 * NW, H = W / 2;
@@ -113,6 +124,35 @@ int orc_bp_pair(const uint8_t *a, int m, const uint8_t *b, int n, int NW, int fu
     }
     int U = -1, cert = 0;
     long kstar = -1;
+    g_exit_bound = -1;
+    if (status == 0 && g_want_exit_bound) {
+        long lb = 1L << 60;
+        for (int j = 0; j <= n; j++) {
+            const int32_t *cur = D + (size_t)j * W;
+            const int tj = ts[j], tn = j < n ? ts[j + 1] : 0;
+            for (int k = 0; k < W; k++) {
+                const long r = (long)tj + 1 + k;
+                if (r < 0 || r > m) continue;                        /* not a cell of the matrix */
+                const long F = cur[k];
+                long c;
+                if (k == W - 1 && r + 1 <= m) {                      /* down, out of the band's last row */
+                    c = F + GAP + GAP * labs(((long)m - (r + 1)) - ((long)n - j));
+                    if (c < lb) lb = c;
+                }
+                if (j < n) {
+                    if (r <= tn) {                                   /* right, into a row the band has left */
+                        c = F + GAP + GAP * labs(((long)m - r) - ((long)n - j - 1));
+                        if (c < lb) lb = c;
+                    }
+                    if (r < m && (r + 1 <= tn || r + 1 > (long)tn + W)) {   /* diagonal, out at the top or at the bottom */
+                        c = F + GAP * labs(((long)m - r - 1) - ((long)n - j - 1));
+                        if (c < lb) lb = c;
+                    }
+                }
+            }
+        }
+        g_exit_bound = lb;
+    }
     if (status == 0) {
         U = D[(size_t)n * W + (m - ts[n] - 1)];     /* row m: index H - 1 .. H + 2 */
         const long d = (long)m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
