@@ -356,6 +356,22 @@ class Context:
         self._check(self.lib.hite_tsd_kmer(self.h, n, _p(buf), _p(off), int(flank), int(plant), _p(rec), _p(cnt)), "hite_tsd_kmer")
         return [[tuple(int(x) for x in rec[i, j]) for j in range(max(cnt[i], 0))] for i in range(n)]
 
+    # ---- terminal inverted repeats (run_itrsearch, Util.py:216: tools/itrsearch -i 0.7 -l 7) --------------------
+    def itr_search(self, seqs, end_len=40, min_identity=0.7, min_len=7, match=10, mismatch=16, gap_open=32, gap_extend=32):
+        """-> int32 [n, 8]: score, end1, end2, equal bases, aligned columns, found, "Length itr=", flags.  end_len > 0: the record
+        is s[:end_len] + s[-end_len:] (search_confident_tir_batch_v1, Util.py:6564); end_len = 0: the whole sequence (remove_no_tirs)"""
+        sb = [s.encode() if isinstance(s, str) else bytes(s) for s in seqs]
+        n = len(sb)
+        out = np.zeros((n, 8), dtype=np.int32)
+        if n == 0:
+            return out
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(s) for s in sb], out=off[1:])
+        buf = np.frombuffer(b"".join(sb) + b"\0" * 16, dtype=np.uint8)
+        self._check(self.lib.hite_itr_search(self.h, C.c_int64(n), _p(buf), _p(off), int(end_len), C.c_double(min_identity), int(min_len),
+                                             int(match), int(mismatch), int(gap_open), int(gap_extend), _p(out)), "hite_itr_search")
+        return out
+
     # ---- FMEA (get_longest_repeats_v4 + process_all_seqs, Util.py:4122) --------------------------------
     def fmea_chain(self, qseg, sseg, qs, qe, ss, se, seg_chrom, seg_off, skip_gap, max_len):
         """-> (chrom ids, starts, ends) of the longest_repeats keys, in the reference's insertion order"""

@@ -6,9 +6,9 @@
 
 What runs on the GPU: the k-mer TSD seed search (search_confident_tir_v4), copy finding, flank-window
 gather, star alignment, sparse-column removal and judge_boundary_v5, three refinement iterations.
-External tools are used exactly where the reference uses them and only if they are installed:
-`itrsearch` (TIR length / structure filter, Util.py:216) and `cd-hit-est` (judge_TIR_transposons.py:87);
-when one is missing the step is skipped with a warning (the candidates are passed through)."""
+The terminal-inverted-repeat filter the reference runs as `tools/itrsearch -i 0.7 -l 7` (Util.py:216) is an in-tree GPU stage
+(hite_itr_search, pinned to the tool's own output): it is never skipped.  `cd-hit-est` (judge_TIR_transposons.py:87) is called
+when it is installed; otherwise the in-tree clustering stand-in runs (_stage.run_cd_hit) -- no step passes candidates through."""
 import argparse
 import os
 import sys

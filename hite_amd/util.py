@@ -3,10 +3,11 @@
 arithmetic runs in libhite_gpu.so through `hite_amd._lib` (no CPU fallback).
 
 Third-party tools the reference shells out to: `minimap2` copy finding is replaced by the build's own minimizer-based
-finder (get_full_length_copies_minimap2; `all_copies=` / `copy_finder=` of flank_region_align_v5 override it); `trf`, `cd-hit-est`
-and `itrsearch` are called where the reference calls them when they are installed (a warning otherwise); the low-copy
-recall of TIR candidates by structure (Util.py:8196-8213: short-TIR signatures, itrsearch when installed) is reproduced,
-the recall by blastx protein domains (:8215-8276) is not: those low-copy elements are written to `all_low_copy`.
+finder (get_full_length_copies_minimap2; `all_copies=` / `copy_finder=` of flank_region_align_v5 override it); `itrsearch`
+(run_itrsearch, Util.py:216) is an in-tree GPU stage pinned to the tool's own output; `trf` and `cd-hit-est` are called where the
+reference calls them when they are installed (the build's own masker / clustering otherwise); the low-copy recall of TIR
+candidates by structure (Util.py:8196-8213: short-TIR signatures + terminal inverted repeats) is reproduced, and so is the
+decision of the recall by protein domains (:8215-8276) on a blastx domain table; blastx itself stays external.
 """
 import os
 import re
@@ -387,37 +388,23 @@ def filter_dup_itr_v3(cur_copies_out_contigs, TIR_len_dict):
     return {"%s-tir_%d-tsd_%s" % (query, TIR_len_dict.get(best, 0), tsd): seq} if len(seq) < 30000 else {}
 
 
-def run_itrsearch(contigs, work_dir, tag):
-    """itrsearch -i 0.7 -l 7 on first40+last40 (Util.py:216-224, 6556-6572) if the binary is installed:
-    -> (names with a TIR, {name: TIR length}); None when the tool is absent."""
-    import shutil
-    import subprocess
-
-    exe = shutil.which("itrsearch")
-    if exe is None:
-        return None
-    path = os.path.join(work_dir, tag + ".fa")
-    store_fasta({n: s[:40] + s[-40:] for n, s in contigs.items()}, path)
-    subprocess.run("cd %s && %s -i 0.7 -l 7 %s > /dev/null 2>&1" % (work_dir, exe, path), shell=True, check=False)
-    out = path + ".itr"
-    names, lens = [], {}
-    if os.path.exists(out):
-        with open(out) as f:
-            for line in f:
-                if line.startswith(">"):
-                    q = line[1:].split(" ")[0].strip()
-                    names.append(q)
-                    if "Length itr=" in line:
-                        lens[q] = int(line.split("Length itr=")[1].split()[0])
-    return names, lens
+def run_itrsearch(contigs, end_len=40, device=0, ctx=None):
+    """run_itrsearch (Util.py:216-224: `tools/itrsearch -i 0.7 -l 7 <fasta>`) on {name: sequence}: the in-tree stage
+    (hite_itr_search; defined by oracle/hite_oracle_itr.c, pinned to the tool's own output).  end_len = 40: the records are the
+    first 40 + last 40 bases (Util.py:6564, 6577); end_len = 0: whole sequences (remove_no_tirs, Util.py:13907).
+    -> (names the tool writes to <input>.itr, in input order; {name: the "Length itr=" of its header})."""
+    names = list(contigs.keys())
+    res = (ctx or get_ctx(device)).itr_search([contigs[n] for n in names], end_len=end_len, min_identity=0.7, min_len=7)
+    found = [n for n, r in zip(names, res) if r[5]]
+    return found, {n: int(r[6]) for n, r in zip(names, res) if r[5]}
 
 
-def search_confident_tir_batch_v1(names, contigs, flanking_len, plant, work_dir, device=0):
-    """search_confident_tir_batch_v1 (Util.py:6533-6628) for one batch: k-mer TSD variants on the GPU
-    (search_confident_tir_v4, names '<q>-C_<i>-tsd_<kmer>-distance_<d>' in the canonical order (distance, start, end, k)),
-    terminal-structure shortcuts, itrsearch for the rest when it is installed (otherwise every variant stays a
-    candidate), then one variant per query (filter_dup_itr_v3)."""
-    ctx = get_ctx(device)
+def tir_variants_with_structure(names, contigs, flanking_len, plant, device=0, ctx=None):
+    """the first two thirds of search_confident_tir_batch_v1 (Util.py:6533-6604): k-mer TSD variants on the GPU
+    (search_confident_tir_v4, names '<q>-C_<i>-tsd_<kmer>-distance_<d>' in the canonical order (distance, start, end, k)), the
+    terminal-structure shortcuts (get_short_tir_contigs), the terminal-inverted-repeat filter for the rest (a variant itrsearch
+    does not report is dropped, Util.py:6598-6600)  -> ({variant: sequence} that stay, {variant: TIR length})."""
+    ctx = ctx or get_ctx(device)
     names = [n for n in names if "NNNNNNNNNN" not in contigs[n]]
     recs = ctx.tsd_kmer([contigs[n] for n in names], flank=flanking_len, plant=plant)
     variants = {}
@@ -428,17 +415,19 @@ def search_confident_tir_batch_v1(names, contigs, flanking_len, plant, work_dir,
     short = get_short_tir_contigs(variants, plant)
     rest = {n: s for n, s in variants.items() if n not in short}
     tir_len = {}
-    itr_short = run_itrsearch(short, work_dir, "short_tir") if short else ([], {})
-    itr_rest = run_itrsearch(rest, work_dir, "all_tir") if rest else ([], {})
-    if itr_rest is None:
-        sys.stderr.write("[hite_amd] itrsearch not found: every TSD variant stays a TIR candidate\n")
-        kept = dict(rest)
-    else:
-        kept = {n: rest[n] for n in itr_rest[0] if n in rest}
-        tir_len.update(itr_rest[1])
-    if itr_short is not None:
-        tir_len.update(itr_short[1])
+    _f, lens = run_itrsearch(short, 40, ctx=ctx) if short else ([], {})
+    found, lens_rest = run_itrsearch(rest, 40, ctx=ctx) if rest else ([], {})
+    kept = {n: rest[n] for n in found}
+    tir_len.update(lens_rest)
+    tir_len.update(lens)        # (the reference reads the short set's lengths last, Util.py:6593-6596)
     kept.update(short)
+    return kept, tir_len
+
+
+def search_confident_tir_batch_v1(names, contigs, flanking_len, plant, work_dir=None, device=0, ctx=None):
+    """search_confident_tir_batch_v1 (Util.py:6533-6628) for one batch: the variants that keep a terminal structure
+    (tir_variants_with_structure), then one variant per query (filter_dup_itr_v3: the smallest '-distance_')."""
+    kept, tir_len = tir_variants_with_structure(names, contigs, flanking_len, plant, device, ctx)
     groups = {}
     for n, s in kept.items():
         groups.setdefault(n.split("-C_")[0], {})[n] = s
@@ -446,6 +435,18 @@ def search_confident_tir_batch_v1(names, contigs, flanking_len, plant, work_dir,
     for q in groups:
         out.update(filter_dup_itr_v3(groups[q], tir_len))
     return out
+
+
+def remove_no_tirs(tir_contigs, plant, device=0, ctx=None):
+    """remove_no_tirs (Util.py:13897-13920) on {name: sequence}: sequences with a short-TIR signature stay, the rest is
+    searched whole for a terminal inverted repeat (itrsearch -i 0.7 -l 7)  -> ({with a TIR}, {without}); the first in the
+    reference's order (the tool's output order, then the short-TIR set)."""
+    short = get_short_tir_contigs(tir_contigs, plant)
+    rest = {n: s for n, s in tir_contigs.items() if n not in short}
+    found, _lens = run_itrsearch(rest, 0, device, ctx) if rest else ([], {})
+    with_tir = {n: rest[n] for n in found}
+    with_tir.update(short)
+    return with_tir, {n: s for n, s in tir_contigs.items() if n not in with_tir}
 
 
 def search_polyA_TSD_batch(seqs, flanking_len=50, end_5_window_size=25, device=0):
@@ -1335,13 +1336,13 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
     return true_tes, low_copy
 
 
-def rescue_low_copy(TE_type, low_copy, plant, work_dir, tandem_masker=None):
+def rescue_low_copy(TE_type, low_copy, plant, work_dir, tandem_masker=None, ctx=None):
     """The recall of low-copy elements by structure (Util.py:8196-8213 + remove_no_tirs, :13897-13920), TIR stage: the
     low-copy sequences go through TRF (tandem repeats -> N) when `trf` is installed and through the build's own masker
     otherwise (`tandem_masker(names, contigs) -> contigs` overrides it), those with a short-TIR signature
     (get_short_tir_contigs: hAT / Mutator / CACTA / CCC..GGG ends matching the TSD length in the name) are real TEs, the
-    rest is handed to `itrsearch -i 0.7 -l 7` when it is installed and kept if it reports a terminal inverted repeat
-    (with the sequence itrsearch writes).  -> (rescued, still low copy).  The recall by intact protein domains
+    rest is searched for a terminal inverted repeat as `itrsearch -i 0.7 -l 7` does (remove_no_tirs: the in-tree stage
+    hite_itr_search) and kept if it has one (with the masked sequence, as the tool writes it).  -> (rescued, still low copy).  The recall by intact protein domains
     (get_domain_info = blastx against TIRPeps / HelitronPeps / non_LTR libraries, :8215-8276) is an external search and is
     not reproduced: Helitron and non-LTR low-copy elements all stay in `all_low_copy`."""
     import shutil
@@ -1368,21 +1369,7 @@ def rescue_low_copy(TE_type, low_copy, plant, work_dir, tandem_masker=None):
     else:
         # the build's own masker (the resident genome becomes these sequences; whoever needs the reference next packs it again)
         masked = (tandem_masker or mask_tandem_repeats)(list(low_copy.keys()), low_copy)
-    short = get_short_tir_contigs(masked, plant)
-    rest = {n: s_ for n, s_ in masked.items() if n not in short}
-    found = {}
-    exe = shutil.which("itrsearch")
-    if exe is None:
-        sys.stderr.write("[hite_amd] itrsearch not found: only short-TIR signatures recall low-copy TIR candidates\n")
-    elif rest:
-        path = os.path.join(work_dir, "low_copy.no_short_tir.fa")
-        store_fasta(rest, path)
-        subprocess.run("cd %s && %s -i 0.7 -l 7 %s > %s.log 2>&1" % (work_dir, exe, path, path), shell=True, check=False)
-        if os.path.exists(path + ".itr"):
-            _n, found = read_fasta(path + ".itr")
-            found = {n: s_ for n, s_ in found.items() if n in rest}
-    rescued = dict(found)
-    rescued.update(short)
+    rescued, _no_tir = remove_no_tirs(masked, plant, ctx=ctx)
     return rescued, {n: s_ for n, s_ in low_copy.items() if n not in rescued}
 
 

@@ -257,6 +257,26 @@ int hite_tsd_kmer(hite_ctx *ctx, int32_t n, const uint8_t *seqs, const int64_t *
 int hite_tsd_kmer_dev(hite_ctx *ctx, int32_t n, const uint8_t *d_seqs, const int64_t *d_seq_off, int32_t flank,
                       int32_t plant, int32_t *d_rec_out, int32_t *d_cnt_out, void *stream);
 
+/* ---- terminal inverted repeats --- run_itrsearch  Util.py:216-224 (third-party ELF tools/itrsearch, `-i 0.7 -l 7`) ----------
+ * The filter of search_confident_tir_batch_v1 (Util.py:6556-6587: first 40 + last 40 bases of every k-mer TSD variant; a variant
+ * without a terminal inverted repeat is dropped, "Length itr=" feeds filter_dup_itr_v3) and of remove_no_tirs (Util.py:13897-13920:
+ * whole low-copy sequences).  In-tree stage; definition oracle/hite_oracle_itr.c, read from the tool's disassembly and pinned to
+ * the tool's own output (tests/golden/itr_search.json.gz).  Per sequence (CSR batch; bytes outside ACGT are N, and N scores as a
+ * match against anything, as in the tool): seq1 = first h bases, seq2 = reverse complement of the last h, h = min(500, len / 2), or
+ * min(len, end_len) when end_len > 0 (the record `s[:end_len] + s[-end_len:]` composed on the device); affine-gap extension
+ * alignment from (0,0) with a free end (match / mismatch / gap_open / gap_extend: the tool's defaults are 10 / 16 / 32 / 32 and the
+ * reference passes none of them).
+ * out[8k ..] = { score, end in seq1, end in seq2, equal bases, aligned columns, found, "Length itr=" (end1 - 1; -1 without an
+ * alignment), flags }; found = min_len <= end1 && equal / aligned >= min_identity (binary64), what makes the tool write the record
+ * to <input>.itr.  flags bit 3: the sequence needs more than max_h (the _dev caller's promise) and was skipped. */
+int hite_itr_search(hite_ctx *ctx, int64_t n, const uint8_t *seqs, const int64_t *seq_off, int32_t end_len, double min_identity,
+                    int32_t min_len, int32_t match, int32_t mismatch, int32_t gap_open, int32_t gap_extend, int32_t *out);
+/* device-resident, asynchronous on `stream`; max_h = upper bound of h over the batch (sizes LDS / the scratch slots; <= 64 keeps
+ * everything in LDS).  d_seqs must be readable up to d_seq_off[n]. */
+int hite_itr_search_dev(hite_ctx *ctx, int64_t n, const uint8_t *d_seqs, const int64_t *d_seq_off, int32_t end_len, int32_t max_h,
+                        double min_identity, int32_t min_len, int32_t match, int32_t mismatch, int32_t gap_open, int32_t gap_extend,
+                        int32_t *d_out, void *stream);
+
 /* ---- copy finding: this build's GPU-native stage where the reference runs the external
  * `minimap2 -ax map-ont -N 300 -p 0.2` + SAM filtering (get_full_length_copies_minimap2, Util.py:7933-8030;
  * third-party, unpinned -> parity is pinned against the build's own CPU twin, oracle/hite_oracle_copies.c,

@@ -1268,11 +1268,88 @@ def gen_bucketing(U, tmp):
     dump("bucketing", cases)
 
 
+
+def _itrsearch_dir(tmp):
+    """the ELF the reference bundles (tools/itrsearch), copied and made executable: /root/reference is read-only"""
+    import shutil
+
+    d = os.path.join(tmp, "trsearch")
+    if not os.path.exists(os.path.join(d, "itrsearch")):
+        os.makedirs(d, exist_ok=True)
+        shutil.copyfile(os.path.join(ref_harness.REFERENCE_ROOT, "tools", "itrsearch"), os.path.join(d, "itrsearch"))
+        os.chmod(os.path.join(d, "itrsearch"), 0o755)
+    return d
+
+
+def gen_itr_search(U, tmp):
+    """`itrsearch -i 0.7 -l 7` ITSELF -- the ELF the reference bundles, through the reference's own wrapper run_itrsearch
+    (Util.py:216-224) -- on seeded records: which of them it writes to <input>.itr and the "Length itr=" of their headers (what
+    search_confident_tir_batch_v1 reads, Util.py:6587-6596).  `pairs`: first 40 + last 40 records; `whole`: long sequences as
+    remove_no_tirs submits them.  Then the reference functions around the tool, run with the tool: search_confident_tir_batch_v1
+    (Util.py:6533-6628; its pick among variants of equal distance depends on PYTHONHASHSEED, the test allows any of them) and
+    remove_no_tirs (Util.py:13897-13920)."""
+    trs = _itrsearch_dir(tmp)
+
+    def run(seqs, tag):
+        d = os.path.join(tmp, "itr_" + tag)
+        os.makedirs(d, exist_ok=True)
+        fa = os.path.join(d, tag + ".fa")
+        write_fasta(fa, ["s%d" % k for k in range(len(seqs))], seqs)
+        out, _log = U.run_itrsearch(trs, fa, d)
+        found = {}
+        for line in open(out):
+            if line.startswith(">"):
+                found[int(line[2:].split(" ")[0])] = int(line.split("Length itr=")[1])
+        return [[1, found[k]] if k in found else [0, -1] for k in range(len(seqs))]
+
+    pairs = casegen.make_itr_cases(5101, 3000)
+    whole = casegen.make_itr_cases(5102, 300, long_=True)
+    obj = dict(pairs=dict(seqs=pairs, res=run(pairs, "pairs")), whole=dict(seqs=whole, res=run(whole, "whole")))
+    print("itr_search: pairs %d found of %d, whole %d of %d" % (sum(r[0] for r in obj["pairs"]["res"]), len(pairs),
+                                                                 sum(r[0] for r in obj["whole"]["res"]), len(whole)))
+    batches = []
+    for bi, (seed, plant) in enumerate(((5201, 1), (5202, 0), (5203, 1))):
+        names, seqs = casegen.make_tir_batch(seed, n=70)
+        d = os.path.join(tmp, "itr_batch_%d" % bi)
+        os.makedirs(d, exist_ok=True)
+        fa = os.path.join(d, "split.fa")
+        write_fasta(fa, names, seqs)
+        res = U.search_confident_tir_batch_v1(fa, 50, d, trs, 0, plant)
+        batches.append(dict(names=names, seqs=seqs, plant=plant, flank=50, out=[[k, v] for k, v in res.items()]))
+        print("itr_search batch %d: %d candidates -> %d with a TIR variant" % (bi, len(names), len(res)))
+    obj["batches"] = batches
+    rescue = []
+    for bi, (seed, plant) in enumerate(((5301, 1), (5302, 0))):
+        rng = np.random.default_rng(seed)
+        seqs = casegen.make_itr_cases(seed, 80, long_=True) + casegen.make_itr_cases(seed + 10, 40)
+        names = []
+        for k, s_ in enumerate(seqs):
+            tl = int(rng.choice([2, 3, 8, 9, 10]))
+            names.append("N_%d-tir_%d-tsd_%s" % (k, int(rng.integers(0, 30)), casegen.rand_seq(rng, tl)))
+            r = rng.random()
+            if r < 0.15:      # short-TIR signatures (get_short_tir_contigs, Util.py:7297): kept without the tool
+                head = "CACTA" if (tl == 3 and r < 0.08) else s_[:5].replace("N", "A")
+                seqs[k] = head + s_[5:-5] + casegen.revcomp(head)
+            elif r < 0.2:
+                seqs[k] = "CCC" + s_[3:-3] + "GGG"
+        d = os.path.join(tmp, "itr_rescue_%d" % bi)
+        os.makedirs(d, exist_ok=True)
+        fa = os.path.join(d, "low_copy.fa")
+        write_fasta(fa, names, seqs)
+        with_tir, no_tir = U.remove_no_tirs(fa, plant, trs, d)
+        wn, wc = U.read_fasta(with_tir)
+        nn, nc = U.read_fasta(no_tir)
+        rescue.append(dict(names=names, seqs=seqs, plant=plant, with_tir=[[k, wc[k]] for k in wn], no_tir=[[k, nc[k]] for k in nn]))
+        print("itr_search rescue %d: %d low-copy sequences -> %d with a TIR, %d without" % (bi, len(names), len(wn), len(nn)))
+    obj["rescue"] = rescue
+    dump("itr_search", obj)
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf", "rfm", "chainvar", "edge"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf", "rfm", "chainvar", "edge", "itr"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -1314,6 +1391,8 @@ def main():
             gen_chain_variants(U, tmp)
         if "edge" in which:
             gen_judge_edge(U, tmp)
+        if "itr" in which:
+            gen_itr_search(U, tmp)
 
 
 if __name__ == "__main__":

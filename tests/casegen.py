@@ -498,3 +498,92 @@ def make_tandem_case(seed, G=120_000, n_arr=70):
         planted.append([pos, pos + L, p, copies, div, ind])
         pos += L + int(rng.integers(300, 1500))
     return seq.tobytes().decode(), planted
+
+
+def _mut_indel(rng, s, psub, pindel):
+    out = []
+    for ch in s:
+        r = rng.random()
+        if r < psub:
+            out.append("ACGT"[int(rng.integers(0, 4))])
+        elif r < psub + pindel / 2:
+            continue
+        elif r < psub + pindel:
+            out.append(ch)
+            out.append("ACGT"[int(rng.integers(0, 4))])
+        else:
+            out.append(ch)
+    return "".join(out)
+
+
+def make_itr_cases(seed, n, long_=False):
+    """inputs of the terminal-inverted-repeat filter (itrsearch, Util.py:216): records as search_confident_tir_batch_v1 hands them
+    over (80 bases and shorter: first 40 + last 40) or, long_=True, whole low-copy sequences as remove_no_tirs does (up to ~2 kb,
+    tandem-masked stretches of N).  Terminal inverted repeats of 5-40 (long: 10-700) bases with 0-30 % substitutions, indels,
+    a few bases of overhang on either end; a fifth of the records carries none."""
+    rng = np.random.default_rng(seed)
+    seqs = []
+    for _ in range(n):
+        if long_:
+            t = rand_seq(rng, int(rng.integers(10, 700)))
+            a = _mut_indel(rng, t, float(rng.choice([0, .05, .1, .2, .35])), float(rng.choice([0, .01, .03])))
+            if rng.random() < 0.25:
+                a = rand_seq(rng, len(a))                   # no inverted repeat at all
+            s = (rand_seq(rng, int(rng.choice([0, 0, 1, 3]))) + t + rand_seq(rng, int(rng.integers(0, 900))) + revcomp(a) +
+                 rand_seq(rng, int(rng.choice([0, 0, 2]))))
+            if rng.random() < 0.3:
+                p = int(rng.integers(0, len(s)))
+                q = min(len(s), p + int(rng.integers(1, 60)))
+                s = s[:p] + "N" * (q - p) + s[q:]
+        elif rng.random() < 0.2:
+            s = rand_seq(rng, int(rng.integers(10, 90)))
+        else:
+            t = rand_seq(rng, int(rng.integers(5, 41)))
+            a = _mut_indel(rng, t, float(rng.choice([0, .05, .1, .2, .3])), float(rng.choice([0, 0, .03, .08])))
+            s = (rand_seq(rng, int(rng.choice([0, 0, 0, 1, 2, 3]))) + t + rand_seq(rng, int(rng.integers(0, 60))) + revcomp(a) +
+                 rand_seq(rng, int(rng.choice([0, 0, 0, 1, 2, 3]))))
+            if rng.random() < 0.8:
+                s = s[:40] + s[-40:]
+            if rng.random() < 0.1:
+                b = list(s)
+                for _k in range(int(rng.integers(1, 5))):
+                    b[int(rng.integers(0, len(b)))] = "N"
+                s = "".join(b)
+        seqs.append(s)
+    return seqs
+
+
+def make_tir_batch(seed, n=60, flank=50):
+    """flanked candidates for search_confident_tir_batch_v1 (Util.py:6533): elements with / without terminal inverted repeats of
+    varying quality, TSDs of every length the k-mer search knows, boundaries off by a few bases, some with runs of N"""
+    rng = np.random.default_rng(seed)
+    names, seqs = [], []
+    for q in range(n):
+        te_len = int(rng.choice([90, 160, 400, 1200, 4500]))
+        tsd_len = int(rng.choice([2, 3, 4, 5, 6, 8, 9, 10, 11]))
+        tsd = {2: "TA", 4: "TTAA"}.get(tsd_len, rand_seq(rng, tsd_len))
+        kind = rng.random()
+        if kind < 0.25:
+            te = rand_seq(rng, te_len)                      # no terminal structure
+        else:
+            tl = int(rng.choice([5, 8, 12, 20, 35]))
+            tir = rand_seq(rng, tl)
+            if kind < 0.35:
+                tir = "CACTA" + tir[5:] if tl >= 5 else tir
+            other = _mut_indel(rng, tir, float(rng.choice([0, 0, .1, .25])), float(rng.choice([0, 0, .05])))
+            te = tir + rand_seq(rng, max(10, te_len - len(tir) - len(other))) + revcomp(other)
+        if kind > 0.93:
+            te = "CCC" + te[3:-3] + "GGG"
+        left, right = rand_seq(rng, flank + 30), rand_seq(rng, flank + 30)
+        full = left + tsd + te + tsd + right
+        s0 = len(left) + len(tsd)
+        off_l, off_r = int(rng.integers(-6, 7)), int(rng.integers(-6, 7))
+        cs, ce = max(0, s0 + off_l - flank), min(len(full), s0 + len(te) + off_r + flank)
+        cand = full[cs:ce]
+        if q % 17 == 5:
+            cand = cand[:70] + "N" * 10 + cand[80:]        # the batch function skips these (Util.py:6542)
+        elif q % 11 == 3:
+            cand = cand[:flank + 12] + "NN" + cand[flank + 14:]
+        names.append("N_%d" % q)
+        seqs.append(cand)
+    return names, seqs

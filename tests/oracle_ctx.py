@@ -20,6 +20,12 @@ class OracleCtx:
         pass
 
     # ---- stages ---------------------------------------------------------------------------------
+    def itr_search(self, seqs, end_len=40, min_identity=0.7, min_len=7, match=10, mismatch=16, gap_open=32, gap_extend=32):
+        return O.itr_search(seqs, end_len, min_identity, min_len, match, mismatch, gap_open, gap_extend)
+
+    def tsd_kmer(self, seqs, flank=50, plant=1):
+        return [O.tir_kmer(s, flank + 1, len(s) - flank, flank, plant) for s in seqs]
+
     def seed_shard(self, rank, world):
         self._shard = (int(rank), int(world))
 

@@ -458,3 +458,17 @@ def ltr_both_ends(rows, cur, flank):
               for r in range(R)]
     full = [fu[r * stride:r * stride + fc.value].tobytes().decode() for r in range(R)]
     return frames, full, ns.value, ne.value
+
+
+def itr_search(seqs, end_len=40, min_id=0.7, min_len=7, match=10, mismatch=16, gap_open=32, gap_extend=32, max_len=500):
+    """itrsearch (third-party ELF the reference bundles, Util.py:216-224) as restated in oracle/hite_oracle_itr.c ->
+    int32 [n, 8]: score, end1, end2, matches, aligned, found, header "Length itr=", flags"""
+    bufs = [_u8(s) for s in seqs]
+    off = np.zeros(len(seqs) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(b) for b in bufs])
+    cat = np.ascontiguousarray(np.concatenate(bufs + [np.zeros(16, np.uint8)]))
+    out = np.zeros((len(seqs), 8), dtype=np.int32)
+    rc = lib().orc_itr_search(len(seqs), _ptr(cat, u8p), _ptr(off, i64p), int(end_len), C.c_double(min_id), int(min_len), int(match),
+                              int(mismatch), int(gap_open), int(gap_extend), int(max_len), _ptr(out, i32p))
+    assert rc == 0
+    return out

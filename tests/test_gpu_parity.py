@@ -643,8 +643,25 @@ def test_dropin_scripts(ctx, tmp_path):
                          "--tmp_output_dir", str(out), "--ref_index", "0", "--plant", "1", "--flanking_len", "50", "--recover", "0",
                          "-r", str(ref), "--min_TE_len", "80"], capture_output=True, text=True)
     assert rc.returncode == 0, rc.stderr
+    assert "itrsearch" not in rc.stderr      # the terminal-inverted-repeat filter is an in-tree stage: never skipped, never announced missing
     tn, tc = util.read_fasta(str(out / "confident_tir_0.fa"))
     assert len(tn) >= 2 and all(n.startswith("genome-TIR_0_") for n in tn)
+    # the filter at work (search_confident_tir_batch_v1, Util.py:6598-6600): windows without a terminal inverted repeat leave the
+    # candidate set, the planted TIR families stay
+    fnames, fcontigs = util.read_fasta(str(flanked))
+    rng_d = np.random.default_rng(6598)
+    decoys = {}
+    for k in range(40):
+        c = int(rng_d.integers(0, len(g["contigs"])))
+        p0 = int(rng_d.integers(200, len(g["contigs"][c]) - 1200))
+        decoys["chr%d:%d-%d" % (c + 1, p0 + 1, p0 + 700)] = g["contigs"][c][p0:p0 + 700]
+    allc = dict(fcontigs)
+    allc.update(decoys)
+    util._CTX = ctx
+    kept = util.search_confident_tir_batch_v1(list(allc), allc, 50, 1)
+    kept_q = {k.split("-tir_")[0] for k in kept}
+    assert len(kept_q & set(fnames)) >= 0.8 * len(fnames)
+    assert len(kept_q & set(decoys)) <= 0.3 * len(decoys), sorted(kept_q & set(decoys))
     # Helitron / non-LTR wrappers: same file contract (the synthetic TIR families are not expected to pass their rules)
     candf = tmp_path / "cand.fa"
     candf.write_text("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(g["cands"])))
@@ -1579,3 +1596,36 @@ def test_coarse_stage_sharded_over_rccl_world1(ctx):
     finally:
         dist.destroy_process_group()
     assert [x.tolist() for x in shard] == [x.tolist() for x in plain] and len(plain[0]) >= 20
+
+
+def test_itr_search_tool_golden_and_twin(ctx):
+    """hite_itr_search (the in-tree stage where the reference runs tools/itrsearch -i 0.7 -l 7, Util.py:216-224) against the tool's
+    own output (3 300 records), then field for field against the twin on fresh records: 20 000 first-40 + last-40 records (LDS path),
+    600 whole sequences up to 2 kb (scratch path, 8 strips), other thresholds and scores, empty and one-base records"""
+    import itr_cases
+
+    itr_cases.check_tool_records(lambda seqs, e: ctx.itr_search(seqs, end_len=e))
+    fresh = casegen.make_itr_cases(6101, 20000)
+    assert np.array_equal(ctx.itr_search(fresh, end_len=40), O.itr_search(fresh, 40))
+    assert np.array_equal(ctx.itr_search(fresh[:3000], end_len=0), O.itr_search(fresh[:3000], 0))
+    whole = casegen.make_itr_cases(6102, 600, long_=True)
+    a, b = ctx.itr_search(whole, end_len=0), O.itr_search(whole, 0)
+    assert np.array_equal(a, b) and int(a[:, 5].sum()) > 300 and int(a[:, 1].max()) > 450
+    mixed = whole[:50] + fresh[:50] + ["", "A", "AT", "ACGT", "N" * 90, "ACGTN" * 30]
+    for kw in (dict(min_identity=0.8, min_len=10), dict(min_identity=0.75, min_len=5, match=5, mismatch=4, gap_open=8, gap_extend=2),
+               dict(min_identity=0.0, min_len=0, match=1, mismatch=3, gap_open=5, gap_extend=2)):
+        for e in (0, 40, 7, 200):
+            assert np.array_equal(ctx.itr_search(mixed, end_len=e, **kw),
+                                  O.itr_search(mixed, e, kw["min_identity"], kw["min_len"], kw.get("match", 10), kw.get("mismatch", 16),
+                                               kw.get("gap_open", 32), kw.get("gap_extend", 32)))
+
+
+def test_itr_filter_host_mirrors_golden_on_gpu(ctx):
+    """search_confident_tir_batch_v1 (Util.py:6533-6628) and remove_no_tirs (Util.py:13897-13920) through the HIP library against the
+    reference's own runs with the tool: variants without a terminal inverted repeat are dropped, never passed through"""
+    import itr_cases
+    from hite_amd import util
+
+    n_q, n_drop = itr_cases.check_batches(util, ctx)
+    assert n_drop > n_q
+    itr_cases.check_rescue(util, ctx)

@@ -412,26 +412,27 @@ def test_result_bucketing_golden():
 
 def test_low_copy_tir_recall_by_structure(tmp_path):
     """rescue_low_copy (Util.py:8196-8213 + remove_no_tirs :13897): low-copy TIR candidates with a short-TIR signature are real
-    TEs; without trf / itrsearch installed nothing else is recalled; Helitron / non-LTR candidates stay low copy (the blastx
-    domain recall is external)"""
+    TEs, the others are when the terminal-inverted-repeat search (the in-tree stage where the reference runs itrsearch) finds
+    one; Helitron / non-LTR candidates stay low copy (the blastx domain recall is external)"""
     from hite_amd import util
 
     comp = {"A": "T", "C": "G", "G": "C", "T": "A"}
-    core = "ACGTTGCATGCAAGCTTGCA" * 20
+    core = casegen.rand_seq(np.random.default_rng(8196), 400)
     head = "GGGTC"
     tail = "".join(comp[c] for c in reversed(head))
     low = {"N_1-C_0-tsd_ACGTACGT-distance_0": head + core + tail,        # 8-bp TSD (hAT), first 5 = revcomp(last 5), < 4 kb
            "N_2-C_0-tsd_ACGTACGT-distance_0": "TTTTT" + core + "CCCCC",  # no terminal inverted repeat
            "N_3-C_0-tsd_AC-distance_0": head + core + tail}              # 2-bp TSD: no short-TIR family
     assert util.get_short_tir_contigs(low, 1).keys() == {"N_1-C_0-tsd_ACGTACGT-distance_0"}
-    import shutil
-    # (the tandem-repeat step in front of the recall needs the GPU masker or trf: switched off here, this test is about the glue)
-    rescued, still = util.rescue_low_copy("tir", low, 1, str(tmp_path / "lc"), tandem_masker=lambda names, contigs: dict(contigs))
-    if shutil.which("itrsearch") is None and shutil.which("trf") is None:
-        assert rescued == {"N_1-C_0-tsd_ACGTACGT-distance_0": low["N_1-C_0-tsd_ACGTACGT-distance_0"]}
-        assert list(still) == ["N_2-C_0-tsd_ACGTACGT-distance_0", "N_3-C_0-tsd_AC-distance_0"]
-    else:
-        assert "N_1-C_0-tsd_ACGTACGT-distance_0" in rescued and set(rescued) | set(still) == set(low)
+    from oracle_ctx import OracleCtx
+    # (the tandem-repeat step in front of the recall needs the GPU masker or trf: switched off here, this test is about the glue;
+    # the terminal-inverted-repeat search answers from its twin)
+    rescued, still = util.rescue_low_copy("tir", low, 1, str(tmp_path / "lc"), tandem_masker=lambda names, contigs: dict(contigs), ctx=OracleCtx())
+    with_itr = {n for n, r in zip(low, O.itr_search(list(low.values()), 0)) if r[5]}
+    assert "N_1-C_0-tsd_ACGTACGT-distance_0" in rescued
+    assert set(rescued) == {"N_1-C_0-tsd_ACGTACGT-distance_0"} | (with_itr - {"N_1-C_0-tsd_ACGTACGT-distance_0"})
+    assert set(rescued) | set(still) == set(low) and not set(rescued) & set(still)
+    assert "N_2-C_0-tsd_ACGTACGT-distance_0" in still     # random core, TTTTT ... CCCCC: nothing inverted at its ends
     for te in ("helitron", "non_ltr"):
         r2, s2 = util.rescue_low_copy(te, low, 1, str(tmp_path / te))
         assert r2 == {} and s2 == low
@@ -551,3 +552,24 @@ def test_chain_variants_golden_through_the_twins(tmp_path):
 
     n_chains, n_copies = chain_variant_cases.check_all(util, OracleCtx(), str(tmp_path))
     assert n_chains > 100 and n_copies > 50
+
+
+def test_itr_search_twin_equals_the_tool():
+    """oracle/hite_oracle_itr.c (read from the disassembly of tools/itrsearch) against the tool's own output on 3 300 seeded records:
+    which records it writes to <input>.itr and the "Length itr=" of their headers (run_itrsearch, Util.py:216-224)"""
+    import itr_cases
+
+    assert itr_cases.check_tool_records(lambda seqs, e: O.itr_search(seqs, e)) > 1500
+
+
+def test_itr_filter_host_mirrors_golden():
+    """the product's host mirrors around the filter -- search_confident_tir_batch_v1 (Util.py:6533-6628) and remove_no_tirs
+    (Util.py:13897-13920) -- with the twins behind them, against the reference's own runs WITH the tool"""
+    import itr_cases
+    from hite_amd import util
+    from oracle_ctx import OracleCtx
+
+    ctx = OracleCtx()
+    n_q, n_drop = itr_cases.check_batches(util, ctx)
+    assert n_drop > n_q
+    itr_cases.check_rescue(util, ctx)
