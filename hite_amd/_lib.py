@@ -712,12 +712,15 @@ class Context:
         self._check(self.lib.hite_flank_sizes(self.h, C.c_int64(n), _p(c), _p(ws), _p(we), 0, _p(ln), _p(tl)), "hite_flank_sizes")
         off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum((ln + 15) // 16 * 16, out=off[1:])
-        toff = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum((tl + 15) // 16 * 16, out=toff[1:])
-        out = np.empty(int(off[-1]) + 16, dtype=np.uint8)
-        tout = np.empty(int(toff[-1]) + 16, dtype=np.uint8)
-        self._check(self.lib.hite_flank_gather(self.h, C.c_int64(n), _p(c), _p(ws), _p(we), _p(mn), 0, _p(off), _p(out), _p(toff), _p(tout)),
+        # flanking_seq wants the whole window only (the first500 + last500 form belongs to the copy windows of the fine stage); the
+        # host buffer is kept between calls: fresh pages would be faulted in under the copy
+        need = int(off[-1]) + 16
+        if getattr(self, "_flank_out", None) is None or len(self._flank_out) < need:
+            self._flank_out = np.empty(need + need // 8, dtype=np.uint8)
+        out = self._flank_out
+        self._check(self.lib.hite_flank_gather(self.h, C.c_int64(n), _p(c), _p(ws), _p(we), _p(mn), 0, _p(off), _p(out), None, None),
                     "hite_flank_gather")
+        self.flank_windows = (out, off, ln)      # (bytes, 16-byte aligned offsets, lengths) of the last call
         return int(ln.sum())
 
     def copy_stats_ext(self):

@@ -73,7 +73,9 @@ struct hite_ctx {
     int32_t seed_rank, seed_world;  // hite_seed_shard: the share of the all-vs-all stage this context computes (world 0: all of it)
     const uint8_t *d_judge_cls;     // per alignment: JUDGE_CLS_* (NULL: hite_judge_dev classifies by itself)
     JudgeFuse judge_fuse;           // win == NULL: the LDS classes copy their alignment from d_msa
+    void *fmea_arena;               // grow-only arena of the sort / sweep / chain routines of hite_fmea.hip (Arena *; hite_fmea_release)
 };
+void hite_fmea_release(hite_ctx *ctx);
 int hite_aux_streams(hite_ctx *ctx, int k, hipStream_t *st, hipEvent_t *fork_ev, hipEvent_t *join_ev);
 
 // record the time of everything enqueued on `st` between begin and end as stage `name`

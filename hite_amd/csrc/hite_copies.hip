@@ -35,7 +35,11 @@
 
 struct CopyState {
     unsigned *idx_hs = nullptr, *idx_pos = nullptr, *dir = nullptr;
+    unsigned *idx_t = nullptr;   // rank of every index entry among the minimizers in position order (stage 3.1 walks the seeds in that order)
+    const unsigned long long *idx_key = nullptr;   // the sorted (hash | strand) << 32 | position words themselves (in the build arena: valid until the next build)
     int64_t M = 0;
+    int64_t idx_cap = 0;         // entries the index arrays hold (grow-only: rebuilding on the same handle allocates nothing)
+    Arena build;      // temporaries of the index build
     Arena arena;      // temporaries of one call
     Arena out;        // copy table handed to the caller (valid until the next call)
     int64_t *h_pin = nullptr;
@@ -102,22 +106,28 @@ __device__ __forceinline__ unsigned long long wave_append(bool want, unsigned lo
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
-// genome minimizers.  key = hs << 32 | pos (the index is sorted afterwards: the emission order is free).
+// genome minimizers IN POSITION ORDER.  key = hs << 32 | pos, value = rank of the minimizer along the genome (its slot).
 // One block per tile of GM_TILE window starts: the k-mer hashes the tile needs are computed once into LDS (each from its
 // own contig: a k-mer that crosses the contig end or touches an N is invalid), every thread then scans the windows of
-// GM_TILE / 256 starts (interleaved: conflict-free LDS reads) and their predecessors, and the tile's minimizers leave
-// with ONE atomic on the global counter (one per wavefront -- 15 M same-address atomics at ~12 ns -- was the whole cost).
+// GM_TILE / 256 starts (round j = 256 consecutive starts) and their predecessors.  A window emits its minimizer when it differs
+// from the window before, so along the window starts the emitted positions increase strictly: a tile writes its records --
+// rounds in order, lanes in order inside a round -- to ITS OWN region of a staging array (GM_TILE slots: a window start emits
+// at most one record) and its count; after a scan of the counts genome_minimizer_pack_kernel moves the regions to their place.
+// The array is then sorted by position -- the index is ONE stable sort on the hash (4 passes instead of the 7 of (hash,
+// position)), and the rank of every seed in position order, which stage 3.1 needs, comes with it as the sort's value (it
+// used to be a second 4-pass sort).  No append counter (the single atomic per tile on one was the arbitrary order; a chained
+// scan over the tiles inside the kernel measured 2x the kernel's time: its waiting tiles hold the CUs).
 #define GM_TILE 2048
 __global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
-                                                               const int64_t *__restrict__ coff, int nc, int64_t G,
-                                                               unsigned long long *__restrict__ out, unsigned long long cap,
-                                                               unsigned long long *__restrict__ counter) {
+                                                               const int64_t *__restrict__ coff, int nc, int64_t G, int64_t ntiles,
+                                                               unsigned long long *__restrict__ stage /* [ntiles][GM_TILE] */,
+                                                               int32_t *__restrict__ tile_cnt) {
     __shared__ unsigned sh[GM_TILE + CW + 8];   // sh[q] = hs of the k-mer starting at p0 - 1 + q
-    __shared__ int s_wcnt[4];
-    __shared__ unsigned long long s_base;
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     constexpr int PER = GM_TILE / 256;
-    for (int64_t p0 = (int64_t)blockIdx.x * GM_TILE; p0 < G; p0 += (int64_t)gridDim.x * GM_TILE) {
+    __shared__ int s_cnt[PER][4];               // emitted per round and wavefront
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int64_t p0 = tile * GM_TILE;
         __syncthreads();
         for (int q = threadIdx.x; q < GM_TILE + CW + 1; q += 256) {
             const int64_t g = p0 - 1 + q;
@@ -127,7 +137,7 @@ __global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *_
         }
         __syncthreads();
         unsigned hh[PER]; unsigned mm[PER];
-        int cnt = 0;
+        unsigned wantbits = 0;
 #pragma unroll
         for (int j = 0; j < PER; j++) {
             const int o = j * 256 + threadIdx.x;          // window start p = p0 + o, its k-mers sit at sh[o + 1 ...]
@@ -152,32 +162,75 @@ __global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *_
                     want = m >= 0 && !(p > cb && fprev && mprev == m);
                 }
             }
-            if (want) { hh[cnt] = h; mm[cnt] = (unsigned)(p + m); cnt++; }
+            hh[j] = h; mm[j] = (unsigned)(p + m);
+            const unsigned long long bal = __ballot(want);
+            if (want) wantbits |= 1u << j;
+            if (lane == 0) s_cnt[j][w] = __popcll(bal);
         }
-        // block compaction: wave prefix by shuffles, wave totals through LDS, one atomic per tile
-        int incl = cnt;
+        __syncthreads();
+        unsigned long long *reg = stage + tile * GM_TILE;
+        int slot0 = 0;
 #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(incl, d); if (lane >= d) incl += v; }
-        if (lane == 63) s_wcnt[w] = incl;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
-            s_base = tot ? atomicAdd(counter, (unsigned long long)tot) : 0ull;
+        for (int j = 0; j < PER; j++) {
+            const bool want = (wantbits >> j) & 1u;
+            const unsigned long long bal = __ballot(want);
+            int slot = slot0 + __popcll(bal & ((1ull << lane) - 1ull));
+            for (int q = 0; q < w; q++) slot += s_cnt[j][q];
+            if (want) reg[slot] = ((unsigned long long)hh[j] << 32) | (unsigned long long)mm[j];
+            slot0 += s_cnt[j][0] + s_cnt[j][1] + s_cnt[j][2] + s_cnt[j][3];
         }
-        __syncthreads();
-        unsigned long long slot = s_base + (unsigned long long)(incl - cnt);
-        for (int i = 0; i < w; i++) slot += (unsigned long long)s_wcnt[i];
-        for (int i = 0; i < cnt; i++, slot++) if (slot < cap) out[slot] = ((unsigned long long)hh[i] << 32) | (unsigned long long)mm[i];
+        if (threadIdx.x == 0) tile_cnt[tile] = slot0;
+    }
+}
+// the tiles' regions to their place: record r of tile t -> slot first[t] + r (wavefront per tile; a tile holds ~370 records)
+__global__ void __launch_bounds__(256) genome_minimizer_pack_kernel(int64_t ntiles, const unsigned long long *__restrict__ stage,
+                                                                    const int64_t *__restrict__ first, unsigned long long *__restrict__ out,
+                                                                    unsigned *__restrict__ out_rank, unsigned long long cap) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int64_t a = first[tile];
+    const int n = (int)(first[tile + 1] - a);
+    const unsigned long long *reg = stage + tile * GM_TILE;
+    for (int r = lane; r < n; r += 64) {
+        const unsigned long long slot = (unsigned long long)a + (unsigned long long)r;
+        if (slot < cap) { out[slot] = reg[r]; out_rank[slot] = (unsigned)slot; }
     }
 }
 
+// the sorted keys apart: hash | strand and position of every index entry
 __global__ void split_index_kernel(int64_t M, const unsigned long long *__restrict__ keys, unsigned *__restrict__ hs,
-                                   unsigned *__restrict__ pos, unsigned *__restrict__ dircnt) {
+                                   unsigned *__restrict__ pos) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
-    unsigned h = (unsigned)(keys[i] >> 32);
-    hs[i] = h; pos[i] = (unsigned)keys[i];
-    atomicAdd(&dircnt[h >> (32 - DIRBITS)], 1u);
+    const unsigned long long k = keys[i];
+    hs[i] = (unsigned)(k >> 32); pos[i] = (unsigned)k;
+}
+// directory over the top DIRBITS of the hash: dir[b] = first index entry of bucket b or a later one (dir[2^DIRBITS] = M).  The entries
+// are sorted, so entry i starts every bucket after its predecessor's up to its own (the buckets behind the last entry keep the
+// M the directory is pre-filled with); most buckets hold a few entries: one short run of stores per entry, no counters, no scan.
+__global__ void __launch_bounds__(256) index_directory_kernel(int64_t M, const unsigned *__restrict__ hs, unsigned *__restrict__ dir) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    int a = 0, b = 0;       // this entry starts the buckets (a, b]
+    if (i < M) {
+        b = (int)(hs[i] >> (32 - DIRBITS));
+        a = i > 0 ? (int)(hs[i - 1] >> (32 - DIRBITS)) : -1;
+    }
+    if (b - a <= 8) for (int x = a + 1; x <= b; x++) dir[x] = (unsigned)i;
+    // a long stretch of empty buckets (small genomes) is filled by the whole wavefront
+    unsigned long long big = __ballot(b - a > 8);
+    while (big) {
+        const int l = __ffsll((long long)big) - 1;
+        big &= big - 1ull;
+        const int aa = __shfl(a, l, 64), bb = __shfl(b, l, 64);
+        const unsigned ii = (unsigned)(i - lane + l);
+        for (int x = aa + 1 + lane; x <= bb; x += 64) dir[x] = ii;
+    }
+}
+__global__ void fill_u32_kernel(int64_t n, unsigned *__restrict__ p, unsigned v) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
 }
 __global__ void i64_to_u32_kernel(int64_t n, const int64_t *__restrict__ in, unsigned *__restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -741,12 +794,13 @@ __global__ void fill_u64_kernel(int64_t n, unsigned long long *__restrict__ p, u
 #define CGRID(n) dim3((unsigned)((((n) > 0 ? (n) : 1) + 255) / 256)), dim3(256)
 #define CCHK(x) do { int rc__ = (x); if (rc__) return rc__; } while (0)
 
-static int sorter_from_arena(Sorter &S, hite_ctx *ctx, Arena &A, hipStream_t st, int64_t n) {
+static int sorter_from_arena(Sorter &S, hite_ctx *ctx, Arena &A, hipStream_t st, int64_t n, bool with_vals = true) {
     S.ctx = ctx; S.st = st; S.cap = n;
     S.hist_n = sorter_hist_elems(n);
     void *p;
     CCHK(arena_alloc(ctx, A, (size_t)(n + 1) * 8, &p)); S.k2 = (unsigned long long *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(n + 1) * 4, &p)); S.v2 = (unsigned *)p;
+    S.v2 = nullptr;
+    if (with_vals) { CCHK(arena_alloc(ctx, A, (size_t)(n + 1) * 4, &p)); S.v2 = (unsigned *)p; }
     CCHK(arena_alloc(ctx, A, (size_t)S.hist_n * 4, &p)); S.hist = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(S.hist_n + 1) * 8, &p)); S.offs = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)sorter_tmp_elems(S.hist_n) * 8, &p)); S.bs = (int64_t *)p;
@@ -775,7 +829,9 @@ extern "C" void hite_copy_index_release(void *state) {
     if (!S) return;
     if (S->idx_hs) (void)hipFree(S->idx_hs);
     if (S->idx_pos) (void)hipFree(S->idx_pos);
+    if (S->idx_t) (void)hipFree(S->idx_t);
     if (S->dir) (void)hipFree(S->dir);
+    arena_free(S->build);
     arena_free(S->arena);
     arena_free(S->out);
     if (S->h_pin) (void)hipHostFree(S->h_pin);
@@ -809,52 +865,76 @@ extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *strea
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
     // rebuilding on an existing handle (next genome / chunk) keeps its arenas: their growth is the expensive part of a cold call
     CopyState *S = (CopyState *)*state_io;
-    if (S) {
-        if (S->idx_hs) (void)hipFree(S->idx_hs);
-        if (S->idx_pos) (void)hipFree(S->idx_pos);
-        if (S->dir) (void)hipFree(S->dir);
-        S->idx_hs = nullptr; S->idx_pos = nullptr; S->dir = nullptr; S->M = 0;
-    } else {
+    if (!S) {
         S = new CopyState();
         *state_io = S;
         HITE_CHECK(ctx, hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)));
         HITE_CHECK(ctx, hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)));
     }
+    S->M = 0;
     const int64_t G = ctx->n_bases;
-    unsigned long long cap = (unsigned long long)(G * 0.32) + 4096;
-    unsigned long long *keys = nullptr;
-    unsigned *vals = nullptr;
-    DevTmp tmp;
-    HITE_CHECK(ctx, tmp.alloc((void **)&keys, cap * 8));
-    HITE_CHECK(ctx, tmp.alloc((void **)&vals, cap * 4));
-    HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
-    int64_t blocks = (G + GM_TILE - 1) / GM_TILE; if (blocks > 256 * 64) blocks = 256 * 64;
+    const unsigned long long cap = (unsigned long long)(G * 0.32) + 4096;
+    if ((int64_t)cap > S->idx_cap) {      // the index arrays: grow-only, shared by every genome packed behind this handle
+        if (S->idx_hs) (void)hipFree(S->idx_hs);
+        if (S->idx_pos) (void)hipFree(S->idx_pos);
+        if (S->idx_t) (void)hipFree(S->idx_t);
+        S->idx_hs = S->idx_pos = S->idx_t = nullptr; S->idx_cap = 0;
+        HITE_CHECK(ctx, hipMalloc((void **)&S->idx_hs, (size_t)(cap + 16) * 4));
+        HITE_CHECK(ctx, hipMalloc((void **)&S->idx_pos, (size_t)(cap + 16) * 4));
+        HITE_CHECK(ctx, hipMalloc((void **)&S->idx_t, (size_t)(cap + 16) * 4));
+        S->idx_cap = (int64_t)cap;
+    }
+    if (!S->dir) HITE_CHECK(ctx, hipMalloc((void **)&S->dir, (size_t)((1 << DIRBITS) + 2) * 4));
+    CCHK(arena_reset(ctx, S->build, true));
+    Arena &B = S->build;
+    void *p;
+    const int64_t ntiles = (G + GM_TILE - 1) / GM_TILE;
+    unsigned long long *keys, *stage;
+    unsigned *vals;
+    int32_t *tile_cnt; int64_t *tile_first, *tbs;
+    CCHK(arena_alloc(ctx, B, (size_t)cap * 8, &p)); keys = (unsigned long long *)p;
+    CCHK(arena_alloc(ctx, B, (size_t)cap * 4, &p)); vals = (unsigned *)p;
+    CCHK(arena_alloc(ctx, B, (size_t)(ntiles + 1) * 4, &p)); tile_cnt = (int32_t *)p;
+    CCHK(arena_alloc(ctx, B, (size_t)(ntiles + 2) * 8, &p)); tile_first = (int64_t *)p;
+    CCHK(arena_alloc(ctx, B, (size_t)scan_tmp_elems(ntiles + 1) * 8, &p)); tbs = (int64_t *)p;
+    CCHK(arena_alloc(ctx, B, (size_t)(ntiles > 0 ? ntiles : 1) * GM_TILE * 8, &p)); stage = (unsigned long long *)p;
+    int64_t blocks = ntiles < 256 * 64 ? ntiles : 256 * 64;
+    if (blocks < 1) blocks = 1;
+    int tk_gm = hite_prof_begin(ctx, "index_minimizers", st);
     hipLaunchKernelGGL(genome_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
-                       ctx->n_contigs, G, keys, cap, (unsigned long long *)S->d_scal);
-    HITE_CHECK(ctx, hipGetLastError());
-    CCHK(read_back(ctx, S, st, 1));
-    const int64_t M = S->h_pin[0];
+                       ctx->n_contigs, G, ntiles, stage, tile_cnt);
+    int64_t M = 0;
+    if (ntiles > 0) {
+        CCHK(scan_excl_buf<int32_t>(ctx, tbs, tile_cnt, ntiles, tile_first, st));
+        HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, tile_first + ntiles, 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(genome_minimizer_pack_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, ntiles, stage, tile_first, keys, vals, cap);
+        hite_prof_end(ctx, tk_gm, st);
+        HITE_CHECK(ctx, hipGetLastError());
+        CCHK(read_back(ctx, S, st, 1));
+        M = S->h_pin[0];
+    } else hite_prof_end(ctx, tk_gm, st);
     if ((unsigned long long)M > cap) return HITE_ECAP;
     S->M = M;
-    Sorter so;
-    struct SorterGuard { Sorter &s; ~SorterGuard() { sorter_free(s); } } sguard{so};
-    if (sorter_init(so, ctx, st, M > 0 ? M : 1)) return HITE_EHIP;
-    int rc = sorter_sort(so, keys, vals, M, 64);
-    if (rc) return rc;
-    HITE_CHECK(ctx, hipMalloc((void **)&S->idx_hs, (size_t)(M + 16) * 4));
-    HITE_CHECK(ctx, hipMalloc((void **)&S->idx_pos, (size_t)(M + 16) * 4));
-    HITE_CHECK(ctx, hipMalloc((void **)&S->dir, (size_t)((1 << DIRBITS) + 2) * 4));
-    unsigned *dircnt = nullptr;
-    int64_t *diroff = nullptr, *bs = nullptr;
-    HITE_CHECK(ctx, tmp.alloc((void **)&dircnt, (size_t)((1 << DIRBITS) + 2) * 4));
-    HITE_CHECK(ctx, tmp.alloc((void **)&diroff, (size_t)((1 << DIRBITS) + 2) * 8));
-    HITE_CHECK(ctx, tmp.alloc((void **)&bs, (size_t)scan_tmp_elems((1 << DIRBITS) + 1) * 8));
-    HITE_CHECK(ctx, hipMemsetAsync(dircnt, 0, (size_t)((1 << DIRBITS) + 2) * 4, st));
-    hipLaunchKernelGGL(split_index_kernel, CGRID(M), 0, st, M, keys, S->idx_hs, S->idx_pos, dircnt);
-    rc = scan_excl_buf<int32_t>(ctx, bs, (int32_t *)dircnt, (int64_t)(1 << DIRBITS), diroff, st);
-    hipLaunchKernelGGL(i64_to_u32_kernel, CGRID((int64_t)(1 << DIRBITS) + 1), 0, st, (int64_t)(1 << DIRBITS) + 1, diroff, S->dir);
+    // stable sort on the hash (the key's upper word): equal hashes stay in position order
+    int tk_is = hite_prof_begin(ctx, "index_sort", st);
+    if (M > 1) {
+        Sorter so;
+        CCHK(sorter_from_arena(so, ctx, B, st, M));
+        CCHK(sorter_sort_bits_swap(so, &keys, &vals, M, 32, 64));
+    }
+    hite_prof_end(ctx, tk_is, st);
+    int tk_dir = hite_prof_begin(ctx, "index_directory", st);
+    S->idx_key = keys;
+    hipLaunchKernelGGL(fill_u32_kernel, CGRID((int64_t)(1 << DIRBITS) + 2), 0, st, (int64_t)(1 << DIRBITS) + 2, S->dir, (unsigned)M);
+    if (M > 0) {
+        hipLaunchKernelGGL(split_index_kernel, CGRID(M), 0, st, M, keys, S->idx_hs, S->idx_pos);
+        HITE_CHECK(ctx, hipMemcpyAsync(S->idx_t, vals, (size_t)M * 4, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(index_directory_kernel, CGRID(M), 0, st, M, S->idx_hs, S->dir);
+    }
+    hite_prof_end(ctx, tk_dir, st);
+    HITE_CHECK(ctx, hipGetLastError());
     HITE_CHECK(ctx, hipStreamSynchronize(st));
-    return rc;
+    return HITE_OK;
 }
 
 // candidates (device) -> copy table (device arrays owned by the index state's arena; valid until the next call)
@@ -1172,7 +1252,7 @@ extern "C" int hite_copy_stats_ext(void *state, int64_t out[8]) {
 // 1 Mbp segment file against every file (process_blast_alignments / sequence2sequenceBlastn,
 // /root/reference/module/Util.py:4724-4780, 4068-4091).  Definition: header of the twin in
 // oracle/hite_oracle_copies.c (orc_seed_allvsall), HIP == twin record for record.
-//   minimizers in position order (one radix sort of the index positions) -> run of equal hs >> 1 per seed ->
+//   minimizers in position order (the index build carries every entry's rank along the genome) -> run of equal hs >> 1 per seed ->
 //   anchor counts -> scan -> anchors (key = strand | diagonal, value = query position) -> stable radix sort on
 //   (strand, diagonal >> 6) -> cluster flags -> HSPs from the first / last anchor of each cluster -> cut at the
 //   1 Mbp segment borders -> stable sort by (query segment, subject segment).
@@ -1184,18 +1264,14 @@ extern "C" int hite_copy_stats_ext(void *state, int64_t out[8]) {
 #define SEED_MINSPAN 60
 #define SEED_MINPIECE 20
 
-__global__ void seed_posrank_kernel(int64_t M, const unsigned *__restrict__ idx_pos, unsigned long long *__restrict__ keys,
-                                    unsigned *__restrict__ vals) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) { keys[i] = idx_pos[i]; vals[i] = (unsigned)i; }
-}
 __global__ void seed_runflag_kernel(int64_t M, const unsigned *__restrict__ idx_hs, int32_t *__restrict__ flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < M) flag[i] = (i == 0 || (idx_hs[i] >> 1) != (idx_hs[i - 1] >> 1)) ? 1 : 0;
 }
-__global__ void seed_rid_fix_kernel(int64_t M, const int32_t *__restrict__ flag, int64_t *__restrict__ rid) {
+// first entry of every run (rid = EXCLUSIVE scan of the flags: a flagged entry opens run rid[i])
+__global__ void seed_runfirst_kernel(int64_t M, const int32_t *__restrict__ flag, const int64_t *__restrict__ rid, unsigned *__restrict__ run_first) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) rid[i] = rid[i] + flag[i] - 1;
+    if (i < M && flag[i]) run_first[rid[i]] = (unsigned)i;
 }
 // Sharding of the all-vs-all stage over ranks (hite_seed_shard; hite_amd/dist.py): a rank keeps the anchors whose sort key
 // (strand | diagonal) lies in its range.  Clusters never straddle two ranges (a cluster lives inside one 64-diagonal bucket and
@@ -1207,72 +1283,159 @@ __device__ __forceinline__ bool seed_owned(const SeedShard &sh, unsigned long lo
     const unsigned long long lin = (rel ? (unsigned long long)sh.twoG : 0ull) + d;
     return lin >= sh.lo && lin < sh.hi;
 }
-// per seed (position order): partners = run size - 1 (0 when the run is too large); sharded: the partners whose anchor this rank owns
-__global__ void seed_count_kernel(int64_t M, int64_t G, const unsigned *__restrict__ rank, const int64_t *__restrict__ rid,
-                                  const unsigned *__restrict__ run_first, const unsigned *__restrict__ idx_hs,
-                                  const unsigned *__restrict__ idx_pos, SeedShard sh, int32_t *__restrict__ cnt) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= M) return;
-    const unsigned i = rank[t];
-    const int64_t r = rid[i];
-    const unsigned lo = run_first[r], hi = run_first[r + 1];
+// One thread per INDEX ENTRY (hash order: its run's bounds are a coalesced read): partners = run size - 1 (0 when the run is too
+// large); sharded: the partners whose anchor this rank owns.  The count and the seed's record -- index entry | offset inside
+// its run | run size << 16 -- go to the seed's place in POSITION order (idx_t, left behind by the index build): the only
+// scattered access; the stages behind read both streams in order.
+__global__ void seed_count_kernel(int64_t M, int64_t G, const int32_t *__restrict__ rflag, const int64_t *__restrict__ rid,
+                                  const unsigned *__restrict__ run_first, const unsigned long long *__restrict__ idx_key,
+                                  const unsigned *__restrict__ idx_t, SeedShard sh, int32_t *__restrict__ cnt, uint2 *__restrict__ srec) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const int64_t nrun = rid[M];
+    const int64_t r = rid[i] + rflag[i] - 1;
+    const unsigned lo = run_first[r], hi = r + 1 < nrun ? run_first[r + 1] : (unsigned)M;
     const unsigned occ = hi - lo;
-    if (occ > SEED_MAXOCC) { cnt[t] = 0; return; }
-    if (sh.hi == 0ull) { cnt[t] = (int32_t)(occ - 1); return; }
-    const unsigned hq = idx_hs[i];
-    const long long pi = idx_pos[i];
+    const unsigned t = idx_t[i];
     int c = 0;
-    for (unsigned j = lo; j < hi; j++) {
-        if (j == i) continue;
-        const unsigned long long rel = (hq ^ idx_hs[j]) & 1u;
-        const long long pj = idx_pos[j];
-        c += seed_owned(sh, rel, rel ? (unsigned long long)(pi + pj) : (unsigned long long)(pj - pi + G));
+    if (occ <= SEED_MAXOCC) {
+        if (sh.hi == 0ull) c = (int)(occ - 1);
+        else {
+            const unsigned long long ki = idx_key[i];
+            const unsigned hq = (unsigned)(ki >> 32);
+            const long long pi = (long long)(unsigned)ki;
+            for (unsigned j = lo; j < hi; j++) {
+                if (j == (unsigned)i) continue;
+                const unsigned long long kj = idx_key[j];
+                const unsigned long long rel = (hq ^ (unsigned)(kj >> 32)) & 1u;
+                const long long pj = (long long)(unsigned)kj;
+                c += seed_owned(sh, rel, rel ? (unsigned long long)(pi + pj) : (unsigned long long)(pj - pi + G));
+            }
+        }
     }
     cnt[t] = c;
+    srec[t] = make_uint2((unsigned)i, (((unsigned)i - lo) & 0xffffu) | ((occ <= SEED_MAXOCC ? occ : 0u) << 16));
 }
-__global__ void seed_anchor_kernel(int64_t M, int64_t G, const unsigned *__restrict__ rank, const int64_t *__restrict__ rid,
-                                   const unsigned *__restrict__ run_first, const unsigned *__restrict__ idx_hs,
-                                   const unsigned *__restrict__ idx_pos, const int32_t *__restrict__ cnt,
-                                   const int64_t *__restrict__ aoff, SeedShard sh, unsigned long long *__restrict__ akey,
-                                   unsigned *__restrict__ aval) {
+// Anchor records.  Unpacked (any genome a context holds): key = strand << 34 | diagonal, value = query position.  Packed
+// (PK; genomes of at most 2^30 bases, i.e. every chunk of the reference's own flow -- chunk_size 400 MB, main.py:23 -- and the
+// 1 Gbp of the bench): key = strand << 61 | diagonal << 30 | query position and no value array: 8 instead of 12 bytes through
+// the three sort passes and every kernel behind them.  Both sort (stably) on (strand, diagonal >> 6): the same order.
+#define SEED_PACK_MAXG (1ll << 30)
+template <bool PK> __device__ __forceinline__ unsigned long long anc_make(unsigned long long rel, unsigned long long d, unsigned pi) {
+    return PK ? (rel << 61) | (d << 30) | (unsigned long long)pi : (rel << 34) | d;
+}
+template <bool PK> __device__ __forceinline__ unsigned long long anc_sd(unsigned long long key) {   // strand << 34 | diagonal
+    return PK ? ((key >> 61) << 34) | ((key >> 30) & 0x7fffffffull) : key;
+}
+template <bool PK> __device__ __forceinline__ unsigned anc_pi(unsigned long long key, const unsigned *__restrict__ aval, int64_t i) {
+    return PK ? (unsigned)(key & 0x3fffffffull) : aval[i];
+}
+// a rank's share (hite_seed_shard): one thread per seed walks its run and keeps the partners whose anchor the rank owns
+template <bool PK>
+__global__ void seed_anchor_kernel(int64_t M, int64_t G, const uint2 *__restrict__ srec, const unsigned long long *__restrict__ idx_key,
+                                   const int32_t *__restrict__ cnt, const int64_t *__restrict__ aoff, SeedShard sh,
+                                   unsigned long long *__restrict__ akey, unsigned *__restrict__ aval) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M || cnt[t] <= 0) return;
-    const unsigned i = rank[t];
-    const int64_t r = rid[i];
-    const unsigned lo = run_first[r], hi = run_first[r + 1];
-    const unsigned hq = idx_hs[i];
-    const long long pi = idx_pos[i];
+    const uint2 sr = srec[t];
+    const unsigned i = sr.x, lo = i - (sr.y & 0xffffu), hi = lo + (sr.y >> 16);
+    const unsigned long long ki = idx_key[i];
+    const unsigned hq = (unsigned)(ki >> 32);
+    const long long pi = (long long)(unsigned)ki;
     int64_t o = aoff[t];
     for (unsigned j = lo; j < hi; j++) {
         if (j == i) continue;
-        const unsigned long long rel = (hq ^ idx_hs[j]) & 1u;
-        const long long pj = idx_pos[j];
+        const unsigned long long kj = idx_key[j];
+        const unsigned long long rel = (hq ^ (unsigned)(kj >> 32)) & 1u;
+        const long long pj = (long long)(unsigned)kj;
         const unsigned long long d = rel ? (unsigned long long)(pi + pj) : (unsigned long long)(pj - pi + G);
         if (!seed_owned(sh, rel, d)) continue;
-        akey[o] = (rel << 34) | d;
-        aval[o] = (unsigned)pi;
+        akey[o] = anc_make<PK>(rel, d, (unsigned)pi);
+        if (!PK) aval[o] = (unsigned)pi;
         o++;
+    }
+}
+// the unsharded stage: the anchors of 64 consecutive seeds (position order) are ONE contiguous output range, which the
+// wavefront that owns the seeds fills 64 slots at a time -- slot o belongs to the seed whose range holds it (a search over the
+// 64 range starts, kept in LDS) and is its (o - start)-th partner, the seed itself skipped.  Reads of a run and the writes are
+// coalesced (the thread-per-seed form above writes 64 separate streams: PMC showed 5x the anchor bytes on both sides).
+// Same anchors in the same order.
+template <bool PK>
+__global__ void __launch_bounds__(256) seed_anchor_coop_kernel(int64_t M, int64_t G, const uint2 *__restrict__ srec,
+                                                               const unsigned long long *__restrict__ idx_key,
+                                                               const int64_t *__restrict__ aoff, unsigned long long *__restrict__ akey,
+                                                               unsigned *__restrict__ aval) {
+    __shared__ unsigned s_start[4][65], s_i[4][64], s_lo[4][64], s_hq[4][64], s_pi[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t0 = ((int64_t)blockIdx.x * 4 + w) * 64;
+    if (t0 >= M) return;
+    const int64_t t = t0 + lane;
+    const int64_t base = aoff[t0];
+    const int64_t tend = t0 + 64 < M ? t0 + 64 : M;
+    const unsigned total = (unsigned)(aoff[tend] - base);
+    if (total == 0) return;
+    {
+        unsigned i = 0, lo = 0, hq = 0, pi = 0, start = total;
+        if (t < M) {
+            start = (unsigned)(aoff[t] - base);
+            if (aoff[t + 1] - aoff[t] > 0) {       // (a seed without partners -- run of one, or too large -- owns no slot)
+                const uint2 sr = srec[t];
+                i = sr.x;
+                lo = i - (sr.y & 0xffffu);
+                const unsigned long long ki = idx_key[i];
+                hq = (unsigned)(ki >> 32);
+                pi = (unsigned)ki;
+            }
+        }
+        s_start[w][lane] = start; s_i[w][lane] = i; s_lo[w][lane] = lo; s_hq[w][lane] = hq; s_pi[w][lane] = pi;
+        if (lane == 0) s_start[w][64] = total;
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (unsigned o = lane; o < total; o += 64) {
+        // the last seed whose range starts at or before o (empty ranges share their start with the next seed: the LAST one wins,
+        // and it is the one that is not empty because o < total)
+        int a = 0, b = 64;
+        while (b - a > 1) { const int m = (a + b) >> 1; if (s_start[w][m] <= o) a = m; else b = m; }
+        const unsigned i = s_i[w][a], hq = s_hq[w][a];
+        const long long pi = s_pi[w][a];
+        unsigned j = s_lo[w][a] + (o - s_start[w][a]);
+        if (j >= i) j++;
+        const unsigned long long kj = idx_key[j];
+        const unsigned long long rel = (hq ^ (unsigned)(kj >> 32)) & 1u;
+        const long long pj = (long long)(unsigned)kj;
+        const unsigned long long d = rel ? (unsigned long long)(pi + pj) : (unsigned long long)(pj - pi + G);
+        akey[base + o] = anc_make<PK>(rel, d, (unsigned)pi);
+        if (!PK) aval[base + o] = (unsigned)pi;
     }
 }
 __device__ __forceinline__ long long seed_pj(unsigned long long key, unsigned pi, long long G) {
     const long long d = (long long)(key & 0x3ffffffffull);
     return (key >> 34) ? d - (long long)pi : d - G + (long long)pi;
 }
+template <bool PK>
 __global__ void seed_flag_kernel(int64_t na, int64_t G, const unsigned long long *__restrict__ akey, const unsigned *__restrict__ aval,
                                  const int64_t *__restrict__ coff, int nc, int32_t *__restrict__ flag) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= na) return;
     int f = 1;
     if (i > 0) {
-        const unsigned long long a = akey[i - 1], b = akey[i];
-        const unsigned pa = aval[i - 1], pb = aval[i];
-        f = (a >> 6) != (b >> 6) || (long long)pb - (long long)pa > SEED_GAP || contig_of(coff, nc, pa) != contig_of(coff, nc, pb) ||
-            contig_of(coff, nc, seed_pj(a, pa, G)) != contig_of(coff, nc, seed_pj(b, pb, G));
+        const unsigned long long ka = akey[i - 1], kb = akey[i];
+        const unsigned long long a = anc_sd<PK>(ka), b = anc_sd<PK>(kb);
+        const unsigned pa = anc_pi<PK>(ka, aval, i - 1), pb = anc_pi<PK>(kb, aval, i);
+        f = (a >> 6) != (b >> 6) || (long long)pb - (long long)pa > SEED_GAP;
+        if (!f) {
+            // same bucket, pa <= pb (position order inside a bucket): the two query positions lie in one contig iff pb is below the
+            // end of pa's; likewise the two subject positions
+            const int ca = contig_of(coff, nc, pa);
+            const long long sa = seed_pj(a, pa, G), sb = seed_pj(b, pb, G);
+            const long long s0 = sa < sb ? sa : sb, s1 = sa < sb ? sb : sa;
+            f = (long long)pb >= coff[ca + 1] || s1 >= coff[contig_of(coff, nc, s0) + 1];
+        }
     }
     flag[i] = f;
 }
 // one thread per cluster; EMIT = false counts the pieces, EMIT = true writes them at pfirst[cluster]
-template <bool EMIT>
+template <bool EMIT, bool PK>
 __global__ void seed_piece_kernel(int64_t ncl, int64_t G, int64_t seg_len, const unsigned long long *__restrict__ akey,
                                   const unsigned *__restrict__ aval, const unsigned *__restrict__ c_first,
                                   const int64_t *__restrict__ coff, int nc, const int32_t *__restrict__ seg_base,
@@ -1284,10 +1447,12 @@ __global__ void seed_piece_kernel(int64_t ncl, int64_t G, int64_t seg_len, const
     if (k >= ncl) return;
     const unsigned b = c_first[k], e = c_first[k + 1];
     int n = 0;
-    const long long q0 = aval[b], q1 = (long long)aval[e - 1] + CK;
+    const unsigned long long kf = akey[b], kl = akey[e - 1];
+    const unsigned qf = anc_pi<PK>(kf, aval, b), ql = anc_pi<PK>(kl, aval, e - 1);
+    const long long q0 = qf, q1 = (long long)ql + CK;
     if (e - b >= SEED_MINANCH && q1 - q0 >= SEED_MINSPAN) {
-        const int rel = (int)(akey[b] >> 34);
-        const long long pf = seed_pj(akey[b], aval[b], G), pl = seed_pj(akey[e - 1], aval[e - 1], G);
+        const int rel = (int)(anc_sd<PK>(kf) >> 34);
+        const long long pf = seed_pj(anc_sd<PK>(kf), qf, G), pl = seed_pj(anc_sd<PK>(kl), ql, G);
         const long long s0 = pf < pl ? pf : pl, s1 = (pf < pl ? pl : pf) + CK;
         const int cq = contig_of(coff, nc, q0), cs = contig_of(coff, nc, pf);
         const long long qb = coff[cq], sb = coff[cs];
@@ -1437,57 +1602,66 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     int32_t *seg_base;
     CCHK(arena_alloc(ctx, A, (size_t)(ctx->n_contigs + 1) * 4, &p)); seg_base = (int32_t *)p;
     HITE_CHECK(ctx, hipMemcpyAsync(seg_base, hbase.data(), (size_t)(ctx->n_contigs + 1) * 4, hipMemcpyHostToDevice, st));
-    // seeds in position order
-    unsigned long long *pk; unsigned *rank;
-    CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 8, &p)); pk = (unsigned long long *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); rank = (unsigned *)p;
-    hipLaunchKernelGGL(seed_posrank_kernel, CGRID(M), 0, st, M, S->idx_pos, pk, rank);
-    {
-        Sorter so;
-        CCHK(sorter_from_arena(so, ctx, A, st, M));
-        CCHK(sorter_sort(so, pk, rank, M, 32));
-    }
-    // runs of equal hs >> 1 in the index
-    int32_t *rflag, *cnt; int64_t *rid, *bs, *aoff; unsigned *run_first;
+    int tk_rc = hite_prof_begin(ctx, "seed_runs_count", st);
+    // runs of equal hs >> 1 in the index; per seed -- in position order, the rank the index build left in idx_t -- its partner count
+    // and its record (index entry, place in its run)
+    int32_t *rflag, *cnt; int64_t *rid, *bs, *aoff; unsigned *run_first; uint2 *srec;
     CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); rflag = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 8, &p)); rid = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(M) * 8, &p)); bs = (int64_t *)p;
-    hipLaunchKernelGGL(seed_runflag_kernel, CGRID(M), 0, st, M, S->idx_hs, rflag);
-    CCHK(scan_excl_buf<int32_t>(ctx, bs, rflag, M, rid, st));
-    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, rid + M, 8, hipMemcpyDeviceToDevice, st));
-    CCHK(read_back(ctx, S, st, 1));
-    const int64_t nrun = S->h_pin[0];
-    CCHK(arena_alloc(ctx, A, (size_t)(nrun + 2) * 4, &p)); run_first = (unsigned *)p;
-    hipLaunchKernelGGL(cluster_first_kernel, CGRID(M), 0, st, M, rflag, rid, run_first, nrun);
-    // rid is an EXCLUSIVE scan of the flags: the run of entry i is rid[i] + flag[i] - 1
-    hipLaunchKernelGGL(seed_rid_fix_kernel, CGRID(M), 0, st, M, rflag, rid);
+    CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 4, &p)); run_first = (unsigned *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); cnt = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 8, &p)); aoff = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 8, &p)); srec = (uint2 *)p;
+    hipLaunchKernelGGL(seed_runflag_kernel, CGRID(M), 0, st, M, S->idx_hs, rflag);
+    CCHK(scan_excl_buf<int32_t>(ctx, bs, rflag, M, rid, st));
+    hipLaunchKernelGGL(seed_runfirst_kernel, CGRID(M), 0, st, M, rflag, rid, run_first);
     const SeedShard shard = seed_shard_of(ctx, G);
-    hipLaunchKernelGGL(seed_count_kernel, CGRID(M), 0, st, M, G, rank, rid, run_first, S->idx_hs, S->idx_pos, shard, cnt);
+    hipLaunchKernelGGL(seed_count_kernel, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, cnt, srec);
     CCHK(scan_excl_buf<int32_t>(ctx, bs, cnt, M, aoff, st));
+    hite_prof_end(ctx, tk_rc, st);
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, aoff + M, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
     const int64_t na = S->h_pin[0];
     if (stats_out) stats_out[1] = na;
     if (na == 0) return HITE_OK;
     if (na > max_anchors || na >= 0xffffffffll) return HITE_ECAP;
-    unsigned long long *akey; unsigned *aval;
+    // HITE_SEED_PACK=0 (tests): the unpacked records also where the packed ones fit
+    static const bool pack_ok = [] { const char *e = getenv("HITE_SEED_PACK"); return !(e && *e == '0'); }();
+    const bool packed = pack_ok && G <= SEED_PACK_MAXG;
+    unsigned long long *akey; unsigned *aval = nullptr;
     CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 8, &p)); akey = (unsigned long long *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 4, &p)); aval = (unsigned *)p;
-    hipLaunchKernelGGL(seed_anchor_kernel, CGRID(M), 0, st, M, G, rank, rid, run_first, S->idx_hs, S->idx_pos, cnt, aoff, shard, akey, aval);
+    if (!packed) { CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 4, &p)); aval = (unsigned *)p; }
     {
+        int tk = hite_prof_begin(ctx, "seed_anchor", st);
+        const dim3 cgrid((unsigned)((M + 255) / 256));
+        if (shard.hi != 0ull) {
+            if (packed) hipLaunchKernelGGL(seed_anchor_kernel<true>, CGRID(M), 0, st, M, G, srec, S->idx_key, cnt, aoff, shard, akey, aval);
+            else hipLaunchKernelGGL(seed_anchor_kernel<false>, CGRID(M), 0, st, M, G, srec, S->idx_key, cnt, aoff, shard, akey, aval);
+        } else if (packed) hipLaunchKernelGGL(seed_anchor_coop_kernel<true>, cgrid, dim3(256), 0, st, M, G, srec, S->idx_key, aoff, akey, aval);
+        else hipLaunchKernelGGL(seed_anchor_coop_kernel<false>, cgrid, dim3(256), 0, st, M, G, srec, S->idx_key, aoff, akey, aval);
+        hite_prof_end(ctx, tk, st);
+    }
+    {
+        // stable sort on (strand, diagonal >> 6); after an odd number of passes the sorted records sit in the sorter's buffers
+        // (no copy back: akey / aval are re-pointed)
+        int tk = hite_prof_begin(ctx, "seed_anchor_sort", st);
         Sorter so;
-        CCHK(sorter_from_arena(so, ctx, A, st, na));
-        CCHK(sorter_sort_bits(so, akey, aval, na, 6, 35));
+        CCHK(sorter_from_arena(so, ctx, A, st, na, !packed));
+        if (packed) { unsigned *nov = nullptr; CCHK(sorter_sort_bits_swap(so, &akey, &nov, na, 36, 62)); }
+        else CCHK(sorter_sort_bits_swap(so, &akey, &aval, na, 6, 35));
+        hite_prof_end(ctx, tk, st);
     }
     // clusters
+    int tk_cl = hite_prof_begin(ctx, "seed_clusters", st);
     int32_t *cflag; int64_t *cid, *bs2; unsigned *c_first;
     CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 4, &p)); cflag = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(na + 2) * 8, &p)); cid = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(na) * 8, &p)); bs2 = (int64_t *)p;
-    hipLaunchKernelGGL(seed_flag_kernel, CGRID(na), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, cflag);
+    if (packed) hipLaunchKernelGGL(seed_flag_kernel<true>, CGRID(na), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, cflag);
+    else hipLaunchKernelGGL(seed_flag_kernel<false>, CGRID(na), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, cflag);
     CCHK(scan_excl_buf<int32_t>(ctx, bs2, cflag, na, cid, st));
+    hite_prof_end(ctx, tk_cl, st);
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cid + na, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
     const int64_t ncl = S->h_pin[0];
@@ -1495,14 +1669,18 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 4, &p)); c_first = (unsigned *)p;
     hipLaunchKernelGGL(cluster_first_kernel, CGRID(na), 0, st, na, cflag, cid, c_first, ncl);
     // pieces: count, scan, emit
+    int tk_pc = hite_prof_begin(ctx, "seed_pieces", st);
     int32_t *pcnt; int64_t *pfirst, *bs3;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); pcnt = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 8, &p)); pfirst = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(ncl) * 8, &p)); bs3 = (int64_t *)p;
-    hipLaunchKernelGGL(seed_piece_kernel<false>, CGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs,
-                       seg_base, pcnt, (const int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr, (int32_t *)nullptr,
-                       (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr);
+#define SEED_PIECE_COUNT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<false, PKV>), CGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
+                       seg_base, pcnt, (const int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr, (int32_t *)nullptr, \
+                       (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr)
+    if (packed) SEED_PIECE_COUNT(true); else SEED_PIECE_COUNT(false);
+#undef SEED_PIECE_COUNT
     CCHK(scan_excl_buf<int32_t>(ctx, bs3, pcnt, ncl, pfirst, st));
+    hite_prof_end(ctx, tk_pc, st);
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, pfirst + ncl, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
     const int64_t np = S->h_pin[0];
@@ -1522,8 +1700,11 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
         CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); t_q[i] = (int64_t *)p;
         CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); f_q[i] = (int64_t *)p;
     }
-    hipLaunchKernelGGL(seed_piece_kernel<true>, CGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs,
-                       seg_base, pcnt, (const int64_t *)pfirst, okey, oval, t_qseg, t_sseg, t_q[0], t_q[1], t_q[2], t_q[3]);
+#define SEED_PIECE_EMIT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<true, PKV>), CGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
+                       seg_base, pcnt, (const int64_t *)pfirst, okey, oval, t_qseg, t_sseg, t_q[0], t_q[1], t_q[2], t_q[3])
+    int tk_hs = hite_prof_begin(ctx, "seed_hsp_emit_sort", st);
+    if (packed) SEED_PIECE_EMIT(true); else SEED_PIECE_EMIT(false);
+#undef SEED_PIECE_EMIT
     {
         Sorter so;
         CCHK(sorter_from_arena(so, ctx, A, st, np));
@@ -1531,6 +1712,7 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     }
     hipLaunchKernelGGL(seed_gather_kernel, CGRID(np), 0, st, np, oval, t_qseg, t_sseg, t_q[0], t_q[1], t_q[2], t_q[3], f_qseg, f_sseg, f_q[0],
                        f_q[1], f_q[2], f_q[3]);
+    hite_prof_end(ctx, tk_hs, st);
     HITE_CHECK(ctx, hipGetLastError());
     HITE_CHECK(ctx, hipStreamSynchronize(st));
     if (dev_out) {

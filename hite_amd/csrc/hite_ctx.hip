@@ -46,6 +46,7 @@ extern "C" void hite_ctx_destroy(hite_ctx *c) {
     (void)hipSetDevice(c->device);
     free_genome(c);
     hite_align_release(c);
+    hite_fmea_release(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
     if (c->d_scratch2) (void)hipFree(c->d_scratch2);
     if (c->d_contig_rank) (void)hipFree(c->d_contig_rank);

@@ -405,6 +405,27 @@ __global__ void fm_fill_i32_kernel(int64_t n, int *__restrict__ p, int v) {
 // ---------------------------------------------------------------------------------------------
 // host orchestration
 // ---------------------------------------------------------------------------------------------
+// Every temporary of one call comes from the context's grow-only arena (no hipMalloc / hipFree on the steady-state path: sixty of
+// each per FMEA call used to cost milliseconds and, now and then, a second when the runtime trimmed its pool).
+static thread_local hite_ctx *tl_fbuf_ctx = nullptr;
+struct FArenaScope {
+    bool ok = false;
+    explicit FArenaScope(hite_ctx *ctx) {
+        if (!ctx || hipSetDevice(ctx->device) != hipSuccess) return;
+        if (!ctx->fmea_arena) ctx->fmea_arena = new Arena();
+        if (arena_reset(ctx, *(Arena *)ctx->fmea_arena, true)) return;
+        tl_sort_arena = (Arena *)ctx->fmea_arena;
+        tl_fbuf_ctx = ctx;
+        ok = true;
+    }
+    ~FArenaScope() { tl_sort_arena = nullptr; tl_fbuf_ctx = nullptr; }
+};
+void hite_fmea_release(hite_ctx *ctx) {
+    if (!ctx || !ctx->fmea_arena) return;
+    arena_free(*(Arena *)ctx->fmea_arena);
+    delete (Arena *)ctx->fmea_arena;
+    ctx->fmea_arena = nullptr;
+}
 struct FBuf {
     void *p = nullptr;
     bool owned = true;
@@ -413,7 +434,13 @@ struct FBuf {
         if (on_device) { p = const_cast<void *>(src); owned = false; return hipSuccess; }
         return up(src, n);
     }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    hipError_t alloc(size_t n) {
+        if (tl_sort_arena && tl_fbuf_ctx) {
+            owned = false;
+            return arena_alloc(tl_fbuf_ctx, *tl_sort_arena, n ? n : 16, &p) == HITE_OK ? hipSuccess : hipErrorOutOfMemory;
+        }
+        return hipMalloc(&p, n ? n : 16);
+    }
     hipError_t up(const void *h, size_t n) {
         hipError_t e = alloc(n + 16);
         if (e != hipSuccess) return e;
@@ -427,6 +454,7 @@ static int fmea_impl(hite_ctx *ctx, int64_t n, const int32_t *qseg, const int32_
                      const int64_t *qe, const int64_t *ss, const int64_t *se, bool hsp_on_device, int32_t nseg, const int32_t *seg_chrom,
                      const int64_t *seg_off, int64_t skip_gap, int64_t max_len, int64_t cap, int32_t *out_chrom,
                      int64_t *out_start, int64_t *out_end, int64_t *n_out) {
+    FArenaScope arena_scope(ctx);
     if (!ctx || n < 0 || nseg <= 0 || nseg > FM_MAXSEG || !n_out || n >= 0x7fffffff) return HITE_EINVAL;
     *n_out = 0;
     if (n == 0) return HITE_OK;
@@ -849,6 +877,7 @@ static int query_copies_impl(hite_ctx *ctx, int64_t n, const int32_t *qid, const
                              const int64_t *slen, double qcov, double scov, int64_t qthr, int64_t sthr, int32_t max_copy, int64_t cap,
                              int64_t *copy_first, int32_t *o_sid, int64_t *o_s, int64_t *o_e, int64_t *o_len, uint8_t *o_minus,
                              int64_t *n_out, const ChainAllOut *all_chains) {
+    FArenaScope arena_scope(ctx);
     if (!ctx || n < 0 || n >= 0x7fffffff || nq <= 0 || ns <= 0 || !qlen || !copy_first || !n_out || max_copy < 0 || max_copy > QC_MAXKEEP - 2 ||
         (scov > 0 && !slen) || (double)nq * (double)ns >= 1e12)
         return HITE_EINVAL;
@@ -1126,6 +1155,7 @@ extern "C" int hite_lib_chain(hite_ctx *ctx, int64_t n, const int32_t *qid, cons
                               const int64_t *ss, const int64_t *se, int32_t nseq, const int64_t *seq_len, double threshold,
                               int64_t chunk_size, int64_t cap, int32_t *o_chunk, int32_t *o_q, int64_t *o_qs, int64_t *o_qe, int32_t *o_s,
                               int64_t *o_ss, int64_t *o_se, int64_t *n_out) {
+    FArenaScope arena_scope(ctx);
     if (!ctx || n < 0 || n >= 0x7fffffff || nseq <= 0 || !seq_len || !n_out) return HITE_EINVAL;
     *n_out = 0;
     if (n == 0) return HITE_OK;
@@ -1321,6 +1351,7 @@ __global__ void __launch_bounds__(256) msa_consensus_kernel(int nmat, const int3
 
 extern "C" int hite_msa_consensus(hite_ctx *ctx, int32_t nmat, const int32_t *rows, const int64_t *cols, const int64_t *mat_off,
                                   const uint8_t *mats, const int64_t *out_off, uint8_t *cons, int64_t *cons_len) {
+    FArenaScope arena_scope(ctx);
     if (!ctx || nmat < 0 || (nmat > 0 && (!rows || !cols || !mat_off || !mats || !out_off || !cons || !cons_len))) return HITE_EINVAL;
     if (nmat == 0) return HITE_OK;
     int64_t total_out = 0;

@@ -6,6 +6,7 @@
 #pragma once
 #include "hite_common.h"
 #include "hite_scan.h"
+#include "hite_arena.h"
 
 // ---------------------------------------------------------------------------------------------
 // stable LSD radix sort of (u64 key, u32 value).  Two digit widths: 8 bits (tile = 256 threads x 8 items) for small
@@ -246,7 +247,11 @@ struct Sorter {
     int32_t *hist = nullptr;
     int64_t *offs = nullptr, *bs = nullptr;
     int64_t hist_n = 0;
+    bool owned = true;      // false: the buffers belong to an arena (sorter_free leaves them alone)
 };
+// a routine that wants every temporary of its sorts and buffers from ONE grow-only arena sets this for its duration (hite_fmea.hip):
+// sorter_init then allocates there instead of calling hipMalloc
+static thread_local Arena *tl_sort_arena = nullptr;
 // histogram entries a sort of n elements needs (the larger of the two forms)
 // int64 elements of scan scratch (Sorter::bs) for a histogram of hist_n counters: the group sums + the digit totals
 static inline int64_t sorter_tmp_elems(int64_t hist_n) { return hist_n / RS_GROUP + 3 * 1024 + 64; }
@@ -264,6 +269,17 @@ static int sorter_init(Sorter &S, hite_ctx *ctx, hipStream_t st, int64_t n) {
     HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         RSS_LDS_BYTES));
     S.hist_n = sorter_hist_elems(n);
+    if (tl_sort_arena) {
+        void *p;
+        S.owned = false;
+        int rc;
+        if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)(n + 1) * 8, &p))) return rc; S.k2 = (unsigned long long *)p;
+        if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)(n + 1) * 4, &p))) return rc; S.v2 = (unsigned *)p;
+        if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)S.hist_n * 4, &p))) return rc; S.hist = (int32_t *)p;
+        if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)(S.hist_n + 1) * 8, &p))) return rc; S.offs = (int64_t *)p;
+        if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)sorter_tmp_elems(S.hist_n) * 8, &p))) return rc; S.bs = (int64_t *)p;
+        return HITE_OK;
+    }
     HITE_CHECK(ctx, hipMalloc((void **)&S.k2, (size_t)(n + 1) * 8));
     HITE_CHECK(ctx, hipMalloc((void **)&S.v2, (size_t)(n + 1) * 4));
     HITE_CHECK(ctx, hipMalloc((void **)&S.hist, (size_t)S.hist_n * 4));
@@ -272,6 +288,7 @@ static int sorter_init(Sorter &S, hite_ctx *ctx, hipStream_t st, int64_t n) {
     return HITE_OK;
 }
 static void sorter_free(Sorter &S) {
+    if (!S.owned) return;
     if (S.k2) (void)hipFree(S.k2);
     if (S.v2) (void)hipFree(S.v2);
     if (S.hist) (void)hipFree(S.hist);

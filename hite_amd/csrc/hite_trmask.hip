@@ -7,8 +7,8 @@
 //   seed filter: a workgroup owns 4096 bases (256 words of 16 two-bit bases, staged in LDS with the "not A/C/G/T" bits spread
 //     to the same layout); for every period p = 1 .. 500 a thread XORs its word with the word p bases further on (two LDS
 //     reads + a funnel shift) and tests its aligned blocks of 8 positions for "all equal"; periods >= 64 look at every other
-//     word only, which two periods share per trip.  ~20 integer operations per (word, period): 500 periods x G/16 words --
-//     about 9 s per Gbp, once per chunk (TRF: minutes per Gbp and core); not part of any timed step.
+//     word only.  Round 5: the compared word slides along a 64-bit register window with compile-time shifts (~10 integer
+//     operations per (word, period), one LDS read per array every 16 periods); the rare seed goes through a call.
 //   extension: the leftmost seed of a run aligns the stretch with itself one period on by the banded end extension of the copy
 //     finder (hite_ext.h; S = 2 i - 7 cost: match 2, edit 5 -- TRF's 7 is a penalty against a consensus, a copy against its
 //     neighbour carries twice the divergence; calibrated on TRF's own masks, see the twin), in the thread that found the seed;
@@ -90,50 +90,72 @@ __device__ void tr_extend(int64_t s, int p, const uint32_t *__restrict__ bases, 
     }
 }
 
-// trip `it` of thread `tid` of the workgroup that owns words w0 ..: one (period, word) item -- every word for p < 64, every
-// other word for p >= 64 (two periods per trip)
-__device__ __forceinline__ void tr_item(const TrTile &T, int tid, int it, int64_t w0, int64_t nwords, int64_t G, int max_period,
-                                        const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
-                                        const int64_t *__restrict__ coff, int nc, uint32_t *__restrict__ trmask) {
-    int p, wl;
-    if (it < 63 && it < max_period) { p = it + 1; wl = tid; }
-    else { p = 64 + 2 * (it - 63) + (tid >> 7); wl = 2 * (tid & 127); }     // (w0 is even: the tile starts on a 32-base boundary)
-    if (p > max_period || wl >= TR_TILE) return;
-    const int64_t w = w0 + wl;
-    if (w >= nwords) return;
-    const uint32_t bad = tr_bad(T, wl + 1, p);
+// block blk (0 / 1: positions 0-7 / 8-15) of word wl of the tile at w0 is a seed at period p (`bad` = its word's flags): the rare
+// path.  The leftmost seed of a run extends; a run restarts every TR_RESEED bases and at a contig start.
+__device__ __noinline__ void tr_seed_hit(const TrTile &T, int wl, int blk, uint32_t bad, int p, int64_t w0, int64_t G,
+                                         const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                         const int64_t *__restrict__ coff, int nc, uint32_t *__restrict__ trmask) {
     const int st = p < 32 ? 8 : (p < 64 ? 16 : 32);
-    const int64_t s_base = w << 4;
-    for (int blk = 0; blk < 2; blk++) {
-        if (blk == 1 && st != 8) break;
-        const int64_t s = s_base + 8 * blk;
-        if (s + 8 > G) continue;
-        if ((bad >> (16 * blk)) & 0x5555u) continue;        // not a seed
-        // previous block of the stride: a seed as well -> this one is not the leftmost of its run
-        bool prev;
-        if (st == 8 && blk == 1) prev = (bad & 0x5555u) == 0u;
-        else if (s - st < 0) prev = false;
-        else {
-            const int64_t pwi = (s - st) >> 4;                      // the previous block's word: at most two words back
-            const int pw = (int)(pwi - (w0 - 1));                    // its tile index (the tile starts one word early)
-            uint32_t pb;
-            if (pw >= 0) pb = tr_bad(T, pw, p);
-            else {   // two words back of the tile's first word: from global memory (once per tile and period)
-                const int64_t q = pwi + (p >> 4);
-                const int sh = 2 * (p & 15);
-                const uint32_t sb = tr_funnel(bases[q + 1], bases[q], sh);
-                const uint32_t n0 = spread16(nmask[pwi >> 1] >> (16 * (int)(pwi & 1)));
-                const uint32_t n1 = spread16(nmask[q >> 1] >> (16 * (int)(q & 1))), n2 = spread16(nmask[(q + 1) >> 1] >> (16 * (int)((q + 1) & 1)));
-                const uint32_t x = bases[pwi] ^ sb;
-                pb = ((x | (x >> 1)) & 0x55555555u) | n0 | tr_funnel(n2, n1, sh);
-            }
-            prev = ((pb >> (((s - st) & 8) ? 16 : 0)) & 0x5555u) == 0u;
+    const int64_t w = w0 + wl;
+    const int64_t s = (w << 4) + 8 * blk;
+    if (s + 8 > G) return;
+    // previous block of the stride: a seed as well -> this one is not the leftmost of its run
+    bool prev;
+    if (st == 8 && blk == 1) prev = (bad & 0x5555u) == 0u;
+    else if (s - st < 0) prev = false;
+    else {
+        const int64_t pwi = (s - st) >> 4;                      // the previous block's word: at most two words back
+        const int pw = (int)(pwi - (w0 - 1));                    // its tile index (the tile starts one word early)
+        uint32_t pb;
+        if (pw >= 0) pb = tr_bad(T, pw, p);
+        else {   // two words back of the tile's first word: from global memory (once per tile and period)
+            const int64_t q = pwi + (p >> 4);
+            const int sh = 2 * (p & 15);
+            const uint32_t sb = tr_funnel(bases[q + 1], bases[q], sh);
+            const uint32_t n0 = spread16(nmask[pwi >> 1] >> (16 * (int)(pwi & 1)));
+            const uint32_t n1 = spread16(nmask[q >> 1] >> (16 * (int)(q & 1))), n2 = spread16(nmask[(q + 1) >> 1] >> (16 * (int)((q + 1) & 1)));
+            const uint32_t x = bases[pwi] ^ sb;
+            pb = ((x | (x >> 1)) & 0x55555555u) | n0 | tr_funnel(n2, n1, sh);
         }
-        if (prev && (s % TR_RESEED) != 0 && s - st >= coff[tr_contig_of(coff, nc, s)]) continue;   // (a run may cross a contig border)
-        tr_extend(s, p, bases, nmask, coff, nc, trmask);
+        prev = ((pb >> (((s - st) & 8) ? 16 : 0)) & 0x5555u) == 0u;
+    }
+    if (prev && (s % TR_RESEED) != 0 && s - st >= coff[tr_contig_of(coff, nc, s)]) return;   // (a run may cross a contig border)
+    tr_extend(s, p, bases, nmask, coff, nc, trmask);
+}
+
+// the periods p_lo, p_lo + step, ... <= p_hi (step 1 or 2) of word wl of the tile: the word it is compared with slides along a
+// 64-bit window held in registers (one LDS read per array every 16 periods instead of four per period), the shifts inside a
+// group of 16 periods are compile-time constants
+__device__ __forceinline__ void tr_scan_word(const TrTile &T, int wl, int p_lo, int p_hi, int step, int64_t w0, int64_t G,
+                                             const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                             const int64_t *__restrict__ coff, int nc, uint32_t *__restrict__ trmask) {
+    const int wi = wl + 1;
+    const uint32_t bw = T.b[wi], nw = T.nx[wi];
+    const int par = p_lo & 1;
+    for (int g = p_lo >> 4; g <= (p_hi >> 4); g++) {
+        const uint32_t blo = T.b[wi + g], bhi = T.b[wi + g + 1], nlo = T.nx[wi + g], nhi = T.nx[wi + g + 1];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int p = 16 * g + j;
+            if (p < p_lo || p > p_hi || (step == 2 && (j & 1) != par)) continue;
+            const uint32_t sb = j ? (blo >> (2 * j)) | (bhi << (32 - 2 * j)) : blo;
+            const uint32_t sn = j ? (nlo >> (2 * j)) | (nhi << (32 - 2 * j)) : nlo;
+            const uint32_t x = bw ^ sb;
+            const uint32_t bad = ((x | (x >> 1)) & 0x55555555u) | nw | sn;
+            if ((bad & 0x5555u) == 0u) tr_seed_hit(T, wl, 0, bad, p, w0, G, bases, nmask, coff, nc, trmask);
+            if (p < 32 && (bad & 0x55550000u) == 0u) tr_seed_hit(T, wl, 1, bad, p, w0, G, bases, nmask, coff, nc, trmask);
+        }
     }
 }
-__device__ __forceinline__ int tr_trips(int max_period) { return (max_period < 64 ? max_period : 63) + (max_period >= 64 ? (max_period - 63 + 1) / 2 : 0); }
+// everything thread `tid` of the workgroup that owns words w0 .. does: every period below 64 on its own word (both 8-blocks
+// below 32, the first one from 32 on), the periods from 64 on of one parity on every other word (first 8-block)
+__device__ __forceinline__ void tr_thread(const TrTile &T, int tid, int64_t w0, int64_t nwords, int64_t G, int max_period,
+                                          const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                          const int64_t *__restrict__ coff, int nc, uint32_t *__restrict__ trmask) {
+    if (w0 + tid < nwords) tr_scan_word(T, tid, 1, max_period < 63 ? max_period : 63, 1, w0, G, bases, nmask, coff, nc, trmask);
+    const int wl = 2 * (tid & 127), p0 = 64 + (tid >> 7);        // (w0 is even: the tile starts on a 32-base boundary)
+    if (p0 <= max_period && w0 + wl < nwords) tr_scan_word(T, wl, p0, max_period, 2, w0, G, bases, nmask, coff, nc, trmask);
+}
 // <<< tr_seed
 
 __global__ void __launch_bounds__(256) tr_seed_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
@@ -141,12 +163,11 @@ __global__ void __launch_bounds__(256) tr_seed_kernel(const uint32_t *__restrict
                                                       uint32_t *__restrict__ trmask) {
     __shared__ TrTile T;
     const int64_t nwords = (G + 15) >> 4;
-    const int trips = tr_trips(max_period);
     for (int64_t w0 = (int64_t)blockIdx.x * TR_TILE; w0 < nwords; w0 += (int64_t)gridDim.x * TR_TILE) {
         __syncthreads();
         for (int k = threadIdx.x; k < TR_TILE + TR_HALO + 2; k += 256) tr_tile_load(T, k, w0, nwords, G, bases, nmask);
         __syncthreads();
-        for (int it = 0; it < trips; it++) tr_item(T, (int)threadIdx.x, it, w0, nwords, G, max_period, bases, nmask, coff, nc, trmask);
+        tr_thread(T, (int)threadIdx.x, w0, nwords, G, max_period, bases, nmask, coff, nc, trmask);
     }
 }
 

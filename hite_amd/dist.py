@@ -5,10 +5,31 @@ One process per GPU, torch.distributed ("nccl" = RCCL over xGMI on the GPU box, 
 The reference has no counterpart: it fans candidates out over a fork()ed process pool
 (/root/reference/module/Util.py:8141-8147)."""
 import numpy as np
-import torch
-import torch.distributed as dist
+
+try:        # the single-GPU stages (coarse_boundary.py without torchrun) need numpy and the library only
+    import torch
+    import torch.distributed as dist
+except ImportError:        # pragma: no cover
+    torch = None
+    dist = None
 
 from ._lib import CALL_DTYPE
+
+
+def process_group_state(group=None):
+    """(a process group is up, rank, world); (False, 0, 1) without torch or without an initialised group"""
+    if dist is None or not dist.is_available() or not dist.is_initialized():
+        return False, 0, 1
+    return True, dist.get_rank(group), dist.get_world_size(group)
+
+
+def collective_device(group=None, ctx=None):
+    """where a collective's tensors have to live: RCCL ("nccl") moves device memory only -- the GPU of this rank's context --
+    gloo moves host memory"""
+    if dist is not None and dist.is_initialized() and dist.get_backend(group) == "nccl":
+        dev = getattr(ctx, "device", None)
+        return torch.device("cuda", int(dev) if dev is not None else torch.cuda.current_device())
+    return "cpu"
 
 
 def shard_bounds(n_items, world):
@@ -236,15 +257,16 @@ def _exchange_rows(rows, dest, group=None, device="cpu"):
     return np.concatenate(parts) if parts else gathered[:0]
 
 
-def coarse_stage_sharded(ctx, seg_len, skip_gap, max_len, group=None, device="cpu", base_threshold=1_000_000, seg_table=None):
+def coarse_stage_sharded(ctx, seg_len, skip_gap, max_len, group=None, device=None, base_threshold=1_000_000, seg_table=None):
     """stage 3.1 on the genome resident in `ctx` (the same on every rank), sharded as described above.
     -> (contig ids, starts, ends) of the repeat intervals in the single-rank order, identical on every rank.
     Without an initialised process group: the single-rank computation (the same code path, no collectives).
     seg_table = (chromosome id, offset) of every packed sequence when those are 'chr$offset' segments of a chunk file
-    (determine_repeat_boundary_v5: the intervals then come out in chromosome coordinates); default: the packed contigs cut every seg_len."""
-    multi = dist.is_available() and dist.is_initialized()
-    world = dist.get_world_size(group) if multi else 1
-    rank = dist.get_rank(group) if multi else 0
+    (determine_repeat_boundary_v5: the intervals then come out in chromosome coordinates); default: the packed contigs cut every seg_len.
+    device = where the collectives' tensors live; None: the GPU of `ctx` under RCCL, the host under gloo."""
+    multi, rank, world = process_group_state(group)
+    if device is None:          # the backend decides: device tensors for RCCL, host tensors for gloo
+        device = collective_device(group, ctx)
     clen = np.asarray(ctx.contig_len, dtype=np.int64)
     if seg_table is None:
         seg_chrom, seg_off = ctx.seed_segments(seg_len)

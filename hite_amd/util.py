@@ -1206,21 +1206,39 @@ def filter_tandem_repeats(repeat_names, repeat_contigs, tmp_output_dir, ref_inde
 
 
 def determine_repeat_boundary_v5(repeats_path, longest_repeats_path, prev_TE, fixed_extend_base_threshold, max_single_repeat_len,
-                                 tmp_output_dir, threads, ref_index, reference, debug, device=0):
+                                 tmp_output_dir, threads, ref_index, reference, debug, device=0, ctx=None):
     """determine_repeat_boundary_v5 (Util.py:4637-4670), same positional arguments: TRF masking of the chunk
     (filter_tandem_repeats), N-masking of the full-length copies of the TEs found so far (mask_genome_intactTE with prev_TE),
     process_blast_alignments (:4724) + get_longest_repeats_v4 per query file + generate_final_result (:4783).
     repeats_path = the chunk FASTA of 'chr$offset' segments; the all-vs-all stage is hite_seed_allvsall (the build's blastn
     stand-in), FMEA runs per query file as in the reference (each call has its own first-come de-duplication), results are
     unioned by name in query-file order (the canonical replacement of the reference's as_completed order)."""
+    from . import dist as hd
+
+    # One code path for one GPU and for the ranks of a node (hite_amd/dist.py).  Under torchrun every rank is called with the same
+    # arguments and shares tmp_output_dir: the steps that WRITE files (tandem masking, prev_TE masking, the result, the clean-up)
+    # run on rank 0 only, the others wait at a barrier and read what it wrote; every rank seeds its share of the all-vs-all
+    # stage, the HSP records go to the owners of the query files, the interval lists are gathered.
+    multi, rank, world = hd.process_group_state()
+
+    def barrier():
+        if multi and world > 1:
+            hd.dist.barrier()
+
     os.makedirs(tmp_output_dir, exist_ok=True)
-    ctx = get_ctx(device)
+    ctx = ctx or get_ctx(device)
     repeat_names, repeat_contigs = read_fasta(repeats_path)
     if not repeat_names:
-        store_fasta({}, longest_repeats_path)
+        if rank == 0:
+            store_fasta({}, longest_repeats_path)
+        barrier()
         return longest_repeats_path
-    filter_tandem_file = filter_tandem_repeats(repeat_names, repeat_contigs, tmp_output_dir, ref_index, threads)
-    masked_file_path = mask_genome_intactTE(prev_TE, filter_tandem_file, tmp_output_dir, threads, ref_index, debug=debug, device=device)
+    filter_tandem_file = os.path.join(tmp_output_dir, "filter_tandem_%s.fa" % ref_index)
+    masked_file_path = filter_tandem_file + ".masked"
+    if rank == 0:
+        filter_tandem_file = filter_tandem_repeats(repeat_names, repeat_contigs, tmp_output_dir, ref_index, threads, device=device)
+        masked_file_path = mask_genome_intactTE(prev_TE, filter_tandem_file, tmp_output_dir, threads, ref_index, debug=debug, device=device)
+    barrier()
     names, contigs = read_fasta(masked_file_path)
     ctx.genome_pack([contigs[n] for n in names])
     ctx.release_copy_index()
@@ -1234,15 +1252,14 @@ def determine_repeat_boundary_v5(repeats_path, longest_repeats_path, prev_TE, fi
         seg_off.append(int(off))
     inv = {v: k for k, v in chroms.items()}
     # query files of >= 1 Mbp as in the reference: FMEA (with its own first-come de-duplication) runs per query file, the results
-    # are unioned by name in file order.  One code path for one GPU and for the ranks of a node (hite_amd/dist.py: under
-    # torchrun every rank seeds its share, the HSP records go to the owners of the query files, the interval lists are gathered)
-    from . import dist as hd
-
+    # are unioned by name in file order
     oc, os_, oe = hd.coarse_stage_sharded(ctx, max(seg_len, 1), fixed_extend_base_threshold, max_single_repeat_len, seg_table=(seg_chrom, seg_off))
-    final = [("%s:%d-%d" % (inv[int(c)], a_, b_), inv[int(c)], int(a_), int(b_)) for c, a_, b_ in zip(oc, os_, oe)]
-    _rn, ref = read_fasta(reference)
-    store_fasta({name: ref[c][a_:b_] for name, c, a_, b_ in final}, longest_repeats_path)
-    if not debug:      # cleanup_temp_files (Util.py:4797)
+    if rank == 0:
+        final = [("%s:%d-%d" % (inv[int(c)], a_, b_), inv[int(c)], int(a_), int(b_)) for c, a_, b_ in zip(oc, os_, oe)]
+        _rn, ref = read_fasta(reference)
+        store_fasta({name: ref[c][a_:b_] for name, c, a_, b_ in final}, longest_repeats_path)
+    barrier()                 # nobody is still reading the masked chunk, and the result is there for every rank
+    if rank == 0 and not debug:      # cleanup_temp_files (Util.py:4797)
         shutil.rmtree(os.path.join(tmp_output_dir, "trf_filter_%s" % ref_index), ignore_errors=True)
         for p_ in (filter_tandem_file, masked_file_path):
             if os.path.exists(p_):

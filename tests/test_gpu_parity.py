@@ -1173,6 +1173,22 @@ def test_wide_radix_sort_on_small_inputs(tmp_path):
         assert " passed" in rc.stdout
 
 
+def test_seed_anchor_record_forms(tmp_path):
+    """stage 3.1's anchors travel as packed 8-byte records (strand | diagonal | query position) when the genome has at most 2^30
+    bases -- always, at test sizes; the 12-byte key + value form of larger genomes (HITE_SEED_PACK=0), with both radix-sort forms,
+    must give the same HSP tables, shares and intervals"""
+    import os
+    import subprocess
+    import sys as _sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for extra in ({"HITE_SEED_PACK": "0"}, {"HITE_SEED_PACK": "0", "HITE_SORT_WIDE_MIN": "2"}):
+        rc = subprocess.run([_sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                             "seed_allvsall or seed_shard or coarse_boundary"], env=dict(os.environ, **extra), capture_output=True, text=True, cwd=root)
+        assert rc.returncode == 0, rc.stdout[-3000:] + rc.stderr[-2000:]
+        assert " passed" in rc.stdout
+
+
 def test_fmea_stress_hash(ctx):
     """30 k-line HSP table: the GPU's ordered interval names hash to the reference's sha256 (fixture holds parameters + hash)"""
     import hashlib
@@ -1629,3 +1645,31 @@ def test_itr_filter_host_mirrors_golden_on_gpu(ctx):
     n_q, n_drop = itr_cases.check_batches(util, ctx)
     assert n_drop > n_q
     itr_cases.check_rescue(util, ctx)
+
+
+def test_flanking_seq_dev_windows_vs_oracle(ctx):
+    """generate_final_result + flanking_seq on the device (Context.flanking_seq_dev: what the end-to-end coarse step of bench.py
+    runs): every window == the oracle's clamping rule (Util.py:4614-4634) applied to the contig, for intervals at contig starts and
+    ends, shorter than two flanks, and in the middle"""
+    names, seqs = casegen.make_genome(911, n_chr=3, chr_len=(4000, 30000), other_frac=0.0)
+    ctx.genome_pack(seqs)
+    rng = np.random.default_rng(912)
+    c, a, b = [], [], []
+    for k in range(400):
+        ci = int(rng.integers(0, 3)); L = len(seqs[ci])
+        ln = int(rng.choice([80, 150, 1200, 3000]))
+        s0 = int(rng.choice([0, 3, 49, 50, 51, max(0, L - ln - 30), max(0, L - ln), int(rng.integers(0, max(1, L - ln)))]))
+        c.append(ci); a.append(s0); b.append(min(L, s0 + ln))
+    total = ctx.flanking_seq_dev(c, a, b, 50)
+    out, off, ln = ctx.flank_windows
+    fold = lambda s: "".join(ch if ch in "ACGT" else "N" for ch in s)  # noqa: E731
+    got_total = 0
+    for k in range(len(c)):
+        lo, hi, _ns, _ne = O.flanking_seq(a[k], b[k], len(seqs[c[k]]), 50)        # the slice [lo, hi) of the contig
+        exp = fold(seqs[c[k]][lo:hi])
+        if int(ln[k]) == 0:            # (the gather's 100-base rule; flanking_seq itself has no minimum)
+            assert len(exp) < 100
+            continue
+        assert out[int(off[k]):int(off[k]) + int(ln[k])].tobytes().decode() == exp, k
+        got_total += int(ln[k])
+    assert got_total == total and total > 100_000

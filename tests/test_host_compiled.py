@@ -19,6 +19,7 @@ PRELUDE = r"""
 #include <algorithm>
 #define __device__
 #define __forceinline__ inline
+#define __noinline__
 #define __restrict__
 using std::min;
 using std::max;
@@ -252,7 +253,7 @@ def test_ext_align_device_function_vs_twin(tmp_path):
 
 
 def test_tr_seed_kernel_logic_vs_twin(tmp_path):
-    """the tandem-repeat masker's kernel body (tile load, seed filter per (period, word) item, leftmost-of-run rule, extension,
+    """the tandem-repeat masker's kernel body (tile load, every thread's scan of its words over the periods, leftmost-of-run rule, extension,
     mask bits) run thread by thread on the host == oracle/hite_oracle_trf.c, on a multi-contig genome with N runs"""
     import casegen
     from test_trmask import twin_mask
@@ -270,11 +271,9 @@ static inline void atomicOr(uint32_t *p, uint32_t v) { *p |= v; }
 extern "C" void host_tr_mask(const uint32_t *bases, const uint32_t *nmask, const int64_t *coff, int nc, int64_t G, int max_period, uint32_t *trmask) {
     static TrTile T;
     const int64_t nwords = (G + 15) >> 4;
-    const int trips = tr_trips(max_period);
     for (int64_t w0 = 0; w0 < nwords; w0 += TR_TILE) {
         for (int k = 0; k < TR_TILE + TR_HALO + 2; k++) tr_tile_load(T, k, w0, nwords, G, bases, nmask);
-        for (int tid = 0; tid < 256; tid++)
-            for (int it = 0; it < trips; it++) tr_item(T, tid, it, w0, nwords, G, max_period, bases, nmask, coff, nc, trmask);
+        for (int tid = 0; tid < 256; tid++) tr_thread(T, tid, w0, nwords, G, max_period, bases, nmask, coff, nc, trmask);
     }
 }
 """)
