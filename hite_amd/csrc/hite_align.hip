@@ -167,7 +167,7 @@ __global__ void __launch_bounds__(256) align_planes_kernel(int n_cand, const uin
 #pragma unroll
         for (int k = 0; k < 32; k++) {
             const int r = wi * 32 + k - AL_PADR + 1;
-            chs[k] = a[r < 1 ? 0 : (r > m ? m - 1 : r - 1)];
+            chs[k] = a[r < 1 || m < 1 ? 0 : (r > m ? m - 1 : r - 1)];
         }
 #pragma unroll
         for (int k = 0; k < 32; k++) {

@@ -1049,10 +1049,11 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
             CCHK(arena_alloc(ctx, A, (size_t)HS_NCLS * n_cand * 4 + 16, &p)); hs_lists = (int32_t *)p;
             HITE_CHECK(ctx, hipMemsetAsync(hs_counts, 0, 16, st));
             hipLaunchKernelGGL(hit_sort_classify_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, q_first, hit_off, hs_counts, hs_lists);
-            static bool attr_done = false;
-            if (!attr_done) {
+            static unsigned long long attr_done = 0ull;      // bit = device id: the attribute belongs to the device the kernel runs on
+            const unsigned long long dev_bit = 1ull << (ctx->device & 63);
+            if (!(attr_done & dev_bit)) {
                 HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&hit_segsort_kernel<HS_MEDIUM, 512>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * HS_MEDIUM * 8));
-                attr_done = true;
+                attr_done |= dev_bit;
             }
             const int sbits = dbits + 1;
             const int gsm = n_cand < 8192 ? n_cand : 8192, gmd = n_cand < 2048 ? n_cand : 2048, glg = n_cand < 1024 ? n_cand : 1024;
@@ -1277,19 +1278,19 @@ __global__ void seed_runfirst_kernel(int64_t M, const int32_t *__restrict__ flag
 // (strand | diagonal) lies in its range.  Clusters never straddle two ranges (a cluster lives inside one 64-diagonal bucket and
 // the range edges are multiples of 64), so the clusters -- and the HSPs -- of the ranks together are exactly those of one
 // unsharded run, in the same order when the ranks are concatenated.  lin = strand * 2 G + diagonal in [0, 4 G).
-struct SeedShard { unsigned long long lo, hi; long long twoG; };      // lin in [lo, hi); hi == 0: unsharded
+struct SeedShard { unsigned long long lo, hi; long long twoG; int sharded; };      // lin in [lo, hi) -- possibly empty -- when sharded
 __device__ __forceinline__ bool seed_owned(const SeedShard &sh, unsigned long long rel, unsigned long long d) {
-    if (sh.hi == 0ull) return true;
+    if (!sh.sharded) return true;
     const unsigned long long lin = (rel ? (unsigned long long)sh.twoG : 0ull) + d;
     return lin >= sh.lo && lin < sh.hi;
 }
 // One thread per INDEX ENTRY (hash order: its run's bounds are a coalesced read): partners = run size - 1 (0 when the run is too
-// large); sharded: the partners whose anchor this rank owns.  The count and the seed's record -- index entry | offset inside
-// its run | run size << 16 -- go to the seed's place in POSITION order (idx_t, left behind by the index build): the only
-// scattered access; the stages behind read both streams in order.
+// large); sharded: the partners whose anchor this rank owns.  The seed's record -- index entry, place in its run, run size, partner
+// count -- goes to the seed's place in POSITION order (idx_t, left behind by the index build): the only scattered access; the
+// stages behind read it in order.
 __global__ void seed_count_kernel(int64_t M, int64_t G, const int32_t *__restrict__ rflag, const int64_t *__restrict__ rid,
                                   const unsigned *__restrict__ run_first, const unsigned long long *__restrict__ idx_key,
-                                  const unsigned *__restrict__ idx_t, SeedShard sh, int32_t *__restrict__ cnt, uint2 *__restrict__ srec) {
+                                  const unsigned *__restrict__ idx_t, SeedShard sh, uint2 *__restrict__ srec) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const int64_t nrun = rid[M];
@@ -1299,7 +1300,7 @@ __global__ void seed_count_kernel(int64_t M, int64_t G, const int32_t *__restric
     const unsigned t = idx_t[i];
     int c = 0;
     if (occ <= SEED_MAXOCC) {
-        if (sh.hi == 0ull) c = (int)(occ - 1);
+        if (!sh.sharded) c = (int)(occ - 1);
         else {
             const unsigned long long ki = idx_key[i];
             const unsigned hq = (unsigned)(ki >> 32);
@@ -1313,8 +1314,12 @@ __global__ void seed_count_kernel(int64_t M, int64_t G, const int32_t *__restric
             }
         }
     }
-    cnt[t] = c;
-    srec[t] = make_uint2((unsigned)i, (((unsigned)i - lo) & 0xffffu) | ((occ <= SEED_MAXOCC ? occ : 0u) << 16));
+    // ONE 8-byte scatter per seed: index entry | place in its run (10 bits) | run size (10) | partners (10)
+    srec[t] = make_uint2((unsigned)i, occ <= SEED_MAXOCC ? (((unsigned)i - lo) | (occ << 10) | ((unsigned)c << 20)) : 0u);
+}
+__global__ void seed_cnt_kernel(int64_t M, const uint2 *__restrict__ srec, int32_t *__restrict__ cnt) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < M) cnt[t] = (int32_t)(srec[t].y >> 20);
 }
 // Anchor records.  Unpacked (any genome a context holds): key = strand << 34 | diagonal, value = query position.  Packed
 // (PK; genomes of at most 2^30 bases, i.e. every chunk of the reference's own flow -- chunk_size 400 MB, main.py:23 -- and the
@@ -1338,7 +1343,7 @@ __global__ void seed_anchor_kernel(int64_t M, int64_t G, const uint2 *__restrict
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= M || cnt[t] <= 0) return;
     const uint2 sr = srec[t];
-    const unsigned i = sr.x, lo = i - (sr.y & 0xffffu), hi = lo + (sr.y >> 16);
+    const unsigned i = sr.x, lo = i - (sr.y & 1023u), hi = lo + ((sr.y >> 10) & 1023u);
     const unsigned long long ki = idx_key[i];
     const unsigned hq = (unsigned)(ki >> 32);
     const long long pi = (long long)(unsigned)ki;
@@ -1381,7 +1386,7 @@ __global__ void __launch_bounds__(256) seed_anchor_coop_kernel(int64_t M, int64_
             if (aoff[t + 1] - aoff[t] > 0) {       // (a seed without partners -- run of one, or too large -- owns no slot)
                 const uint2 sr = srec[t];
                 i = sr.x;
-                lo = i - (sr.y & 0xffffu);
+                lo = i - (sr.y & 1023u);
                 const unsigned long long ki = idx_key[i];
                 hq = (unsigned)(ki >> 32);
                 pi = (unsigned)ki;
@@ -1412,27 +1417,53 @@ __device__ __forceinline__ long long seed_pj(unsigned long long key, unsigned pi
     const long long d = (long long)(key & 0x3ffffffffull);
     return (key >> 34) ? d - (long long)pi : d - G + (long long)pi;
 }
+// does anchor i open a cluster?  (different (strand, diagonal >> 6) bucket than the anchor before it, more than SEED_GAP further
+// on, or either position in another contig)
 template <bool PK>
-__global__ void seed_flag_kernel(int64_t na, int64_t G, const unsigned long long *__restrict__ akey, const unsigned *__restrict__ aval,
-                                 const int64_t *__restrict__ coff, int nc, int32_t *__restrict__ flag) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= na) return;
-    int f = 1;
-    if (i > 0) {
-        const unsigned long long ka = akey[i - 1], kb = akey[i];
-        const unsigned long long a = anc_sd<PK>(ka), b = anc_sd<PK>(kb);
-        const unsigned pa = anc_pi<PK>(ka, aval, i - 1), pb = anc_pi<PK>(kb, aval, i);
-        f = (a >> 6) != (b >> 6) || (long long)pb - (long long)pa > SEED_GAP;
-        if (!f) {
-            // same bucket, pa <= pb (position order inside a bucket): the two query positions lie in one contig iff pb is below the
-            // end of pa's; likewise the two subject positions
-            const int ca = contig_of(coff, nc, pa);
-            const long long sa = seed_pj(a, pa, G), sb = seed_pj(b, pb, G);
-            const long long s0 = sa < sb ? sa : sb, s1 = sa < sb ? sb : sa;
-            f = (long long)pb >= coff[ca + 1] || s1 >= coff[contig_of(coff, nc, s0) + 1];
-        }
+__device__ __forceinline__ int seed_opens(int64_t i, unsigned long long ka, unsigned long long kb, const unsigned *__restrict__ aval,
+                                          int64_t G, const int64_t *__restrict__ coff, int nc) {
+    if (i == 0) return 1;
+    const unsigned long long a = anc_sd<PK>(ka), b = anc_sd<PK>(kb);
+    const unsigned pa = anc_pi<PK>(ka, aval, i - 1), pb = anc_pi<PK>(kb, aval, i);
+    if ((a >> 6) != (b >> 6) || (long long)pb - (long long)pa > SEED_GAP) return 1;
+    // same bucket, pa <= pb (position order inside a bucket): the two query positions lie in one contig iff pb is below the
+    // end of pa's; likewise the two subject positions
+    const int ca = contig_of(coff, nc, pa);
+    const long long sa = seed_pj(a, pa, G), sb = seed_pj(b, pb, G);
+    const long long s0 = sa < sb ? sa : sb, s1 = sa < sb ? sb : sa;
+    return ((long long)pb >= coff[ca + 1] || s1 >= coff[contig_of(coff, nc, s0) + 1]) ? 1 : 0;
+}
+// Clusters without a flag array or a scan over the anchors: a workgroup owns SF_TILE consecutive anchors (8 per thread); pass
+// COUNT leaves the number of cluster starts of every tile, after a scan of those (one entry per 2048 anchors) pass EMIT finds the
+// starts again and writes the index of the k-th one of the tile to c_first[first[tile] + k].  The keys are read twice (16 B per
+// anchor) where flags + scan + scatter moved 42.
+#define SF_ITEMS 8
+#define SF_TILE (256 * SF_ITEMS)
+template <bool PK, bool EMIT>
+__global__ void __launch_bounds__(256) seed_clusters_kernel(int64_t na, int64_t G, const unsigned long long *__restrict__ akey,
+                                                            const unsigned *__restrict__ aval, const int64_t *__restrict__ coff, int nc,
+                                                            int32_t *__restrict__ tile_cnt, const int64_t *__restrict__ tile_first,
+                                                            unsigned *__restrict__ c_first) {
+    __shared__ int s_tmp[8];
+    const int64_t base = (int64_t)blockIdx.x * SF_TILE + (int64_t)threadIdx.x * SF_ITEMS;
+    unsigned long long k[SF_ITEMS + 1];
+    k[0] = base > 0 && base <= na ? akey[base - 1] : 0ull;
+#pragma unroll
+    for (int q = 0; q < SF_ITEMS; q++) { const int64_t i = base + q; k[q + 1] = akey[i < na ? i : na - 1]; }
+    unsigned bits = 0;
+    int c = 0;
+#pragma unroll
+    for (int q = 0; q < SF_ITEMS; q++) {
+        const int64_t i = base + q;
+        if (i < na && seed_opens<PK>(i, k[q], k[q + 1], aval, G, coff, nc)) { bits |= 1u << q; c++; }
     }
-    flag[i] = f;
+    int total;
+    const int excl = block_excl_scan(c, s_tmp, &total);
+    if (!EMIT) { if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total; return; }
+    int64_t o = tile_first[blockIdx.x] + excl;
+#pragma unroll
+    for (int q = 0; q < SF_ITEMS; q++) if ((bits >> q) & 1u) c_first[o++] = (unsigned)(base + q);
+    if (base <= na - 1 && na - 1 < base + SF_ITEMS) c_first[tile_first[gridDim.x]] = (unsigned)na;   // (the thread of the last anchor closes the list)
 }
 // one thread per cluster; EMIT = false counts the pieces, EMIT = true writes them at pfirst[cluster]
 template <bool EMIT, bool PK>
@@ -1521,12 +1552,12 @@ static unsigned long long seed_shard_edge(long long G, int k, int world) {     /
 }
 // <<< seed_shard
 static SeedShard seed_shard_of(hite_ctx *ctx, long long G) {
-    SeedShard s; s.lo = 0ull; s.hi = 0ull; s.twoG = 2 * G;
+    SeedShard s; s.lo = 0ull; s.hi = 0ull; s.twoG = 2 * G; s.sharded = 0;
     if (ctx->seed_world > 1) {
         // (2 G must be a multiple of 64 for the strand border to be a bucket border: the forward keys end below 2 G anyway)
         s.lo = seed_shard_edge(G, ctx->seed_rank, ctx->seed_world);
         s.hi = seed_shard_edge(G, ctx->seed_rank + 1, ctx->seed_world);
-        if (s.hi <= s.lo) s.hi = s.lo + 1;      // (an empty range still has to read as "sharded")
+        s.sharded = 1;      // (tiny genome / many ranks: neighbouring edges can round to the same multiple of 64 -- an EMPTY share, which owns nothing)
     }
     return s;
 }
@@ -1617,7 +1648,8 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     CCHK(scan_excl_buf<int32_t>(ctx, bs, rflag, M, rid, st));
     hipLaunchKernelGGL(seed_runfirst_kernel, CGRID(M), 0, st, M, rflag, rid, run_first);
     const SeedShard shard = seed_shard_of(ctx, G);
-    hipLaunchKernelGGL(seed_count_kernel, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, cnt, srec);
+    hipLaunchKernelGGL(seed_count_kernel, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, srec);
+    hipLaunchKernelGGL(seed_cnt_kernel, CGRID(M), 0, st, M, srec, cnt);
     CCHK(scan_excl_buf<int32_t>(ctx, bs, cnt, M, aoff, st));
     hite_prof_end(ctx, tk_rc, st);
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, aoff + M, 8, hipMemcpyDeviceToDevice, st));
@@ -1635,7 +1667,7 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     {
         int tk = hite_prof_begin(ctx, "seed_anchor", st);
         const dim3 cgrid((unsigned)((M + 255) / 256));
-        if (shard.hi != 0ull) {
+        if (shard.sharded) {
             if (packed) hipLaunchKernelGGL(seed_anchor_kernel<true>, CGRID(M), 0, st, M, G, srec, S->idx_key, cnt, aoff, shard, akey, aval);
             else hipLaunchKernelGGL(seed_anchor_kernel<false>, CGRID(M), 0, st, M, G, srec, S->idx_key, cnt, aoff, shard, akey, aval);
         } else if (packed) hipLaunchKernelGGL(seed_anchor_coop_kernel<true>, cgrid, dim3(256), 0, st, M, G, srec, S->idx_key, aoff, akey, aval);
@@ -1652,22 +1684,24 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
         else CCHK(sorter_sort_bits_swap(so, &akey, &aval, na, 6, 35));
         hite_prof_end(ctx, tk, st);
     }
-    // clusters
+    // clusters: starts per tile of 2048 anchors -> scan -> the index of every cluster's first anchor (+ sentinel)
     int tk_cl = hite_prof_begin(ctx, "seed_clusters", st);
-    int32_t *cflag; int64_t *cid, *bs2; unsigned *c_first;
-    CCHK(arena_alloc(ctx, A, (size_t)(na + 1) * 4, &p)); cflag = (int32_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(na + 2) * 8, &p)); cid = (int64_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(na) * 8, &p)); bs2 = (int64_t *)p;
-    if (packed) hipLaunchKernelGGL(seed_flag_kernel<true>, CGRID(na), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, cflag);
-    else hipLaunchKernelGGL(seed_flag_kernel<false>, CGRID(na), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, cflag);
-    CCHK(scan_excl_buf<int32_t>(ctx, bs2, cflag, na, cid, st));
-    hite_prof_end(ctx, tk_cl, st);
-    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, cid + na, 8, hipMemcpyDeviceToDevice, st));
+    const int64_t ntile = (na + SF_TILE - 1) / SF_TILE;
+    int32_t *tcnt; int64_t *tfirst, *bs2; unsigned *c_first;
+    CCHK(arena_alloc(ctx, A, (size_t)(ntile + 1) * 4, &p)); tcnt = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(ntile + 2) * 8, &p)); tfirst = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(ntile) * 8, &p)); bs2 = (int64_t *)p;
+    if (packed) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<true, false>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)nullptr, (unsigned *)nullptr);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<false, false>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)nullptr, (unsigned *)nullptr);
+    CCHK(scan_excl_buf<int32_t>(ctx, bs2, tcnt, ntile, tfirst, st));
+    HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, tfirst + ntile, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
     const int64_t ncl = S->h_pin[0];
     if (stats_out) stats_out[2] = ncl;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 4, &p)); c_first = (unsigned *)p;
-    hipLaunchKernelGGL(cluster_first_kernel, CGRID(na), 0, st, na, cflag, cid, c_first, ncl);
+    if (packed) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<true, true>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)tfirst, c_first);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<false, true>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)tfirst, c_first);
+    hite_prof_end(ctx, tk_cl, st);
     // pieces: count, scan, emit
     int tk_pc = hite_prof_begin(ctx, "seed_pieces", st);
     int32_t *pcnt; int64_t *pfirst, *bs3;

@@ -26,7 +26,7 @@ __device__ __forceinline__ void fill_sparse_row(Out row, const uint8_t *__restri
         for (int u = 0; u < FILL_U; u++) {
             const int p = p0 + u * TS;
             const unsigned wl = lay[p <= m ? p : m];
-            const unsigned ol = rop[p < m ? p : m - 1];
+            const unsigned ol = rop[p < m ? p : (m > 0 ? m - 1 : 0)];      // (m == 0: entry 0 of the padded slot, masked below)
             w[u] = p <= m ? wl : 0u;
             oc[u] = centre ? (unsigned)p : (p < m ? ol : 0x8000u);
         }

@@ -561,7 +561,7 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
     if (rc) return rc;
     int32_t *lists = (int32_t *)((uint8_t *)scr + off_l);
     uint8_t *cls_own = (uint8_t *)(lists + (size_t)JUDGE_NCLS * n);
-    unsigned int *counters = (unsigned int *)(cls_own + cls_bytes);   // queue heads [0..3], list lengths [4..7], then the class histogram
+    unsigned int *counters = (unsigned int *)(cls_own + cls_bytes);   // queue heads [0 .. JUDGE_NCLS), list lengths [JUDGE_NCLS .. 2 JUDGE_NCLS), then the class histogram
     unsigned int *hist = counters + 2 * JUDGE_NCLS;
     HITE_CHECK(ctx, hipMemsetAsync(counters, 0, (2 * JUDGE_NCLS + JSPLIT_SLOTS) * 4, st));
     const uint8_t *cls = ctx->d_judge_cls;
@@ -581,11 +581,22 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
         p.counter = counters + k; p.list = lists + (size_t)k * n; p.n_list = counters + JUDGE_NCLS + k;
         p.fuse = ctx->judge_fuse;
     }
-    static bool attr_done = false;       // more than 64 KB of LDS per workgroup needs the attribute (once per process)
-    if (!attr_done) {
+    // more than 64 KB of LDS per workgroup needs the attribute: once per DEVICE (a second context on another GPU of the process
+    // launches the same functions there), and only for a class that has work -- the default path (LDS classes off) asks for nothing
+    static unsigned long long attr_done[2] = {0ull, 0ull};      // bit = device id (< 64)
+    const unsigned long long dev_bit = 1ull << (ctx->device & 63);
+    bool need_blk = false, need_wav = false;
+    for (int k = JUDGE_CLS_LDS; k < JUDGE_NCLS; k++) {
+        if (grid[k] <= 0) continue;
+        if (k >= JUDGE_CLS_LDS + JUDGE_LDS_WAVE_SIZES) need_blk = true; else need_wav = true;
+    }
+    if (need_blk && !(attr_done[0] & dev_bit)) {
         HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jblds::judge_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+        attr_done[0] |= dev_bit;
+    }
+    if (need_wav && !(attr_done[1] & dev_bit)) {
         HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(&jwlds::judge_wave_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 98304));
-        attr_done = true;
+        attr_done[1] |= dev_bit;
     }
     // the workgroup kernel on HBM holds the long chains (wide / deep alignments): it starts first, the others fill the machine
     // beside it, each on its own stream, the largest tiles first

@@ -454,10 +454,10 @@ int64_t orc_seed_allvsall(const uint8_t *genome, const int64_t *contig_off, int 
     if (ncontig <= 0 || seg_len <= 0) return ORC_EINVAL;
     const int64_t G = contig_off[ncontig];
     uint64_t sh_lo = 0, sh_hi = 0;
-    if (g_seed_world > 1) {
+    const int sharded = g_seed_world > 1;      /* (an empty share -- both edges on the same multiple of 64 -- owns nothing) */
+    if (sharded) {
         sh_lo = seed_shard_edge(G, g_seed_rank, g_seed_world);
         sh_hi = seed_shard_edge(G, g_seed_rank + 1, g_seed_world);
-        if (sh_hi <= sh_lo) sh_hi = sh_lo + 1;
     }
     int64_t M = 0;
     for (int c = 0; c < ncontig; c++) M += minimizers(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], NULL);
@@ -488,7 +488,7 @@ int64_t orc_seed_allvsall(const uint8_t *genome, const int64_t *contig_off, int 
             if (na == acap) { acap *= 2; an = (anchor_t *)realloc(an, sizeof(anchor_t) * acap); }
             uint64_t rel = (byp[t].hs ^ idx[i].hs) & 1u;
             uint64_t d = rel ? (uint64_t)(byp[t].pos + idx[i].pos) : (uint64_t)(idx[i].pos - byp[t].pos + G);
-            if (sh_hi) { const uint64_t lin = (rel ? 2ull * (uint64_t)G : 0ull) + d; if (lin < sh_lo || lin >= sh_hi) continue; }
+            if (sharded) { const uint64_t lin = (rel ? 2ull * (uint64_t)G : 0ull) + d; if (lin < sh_lo || lin >= sh_hi) continue; }
             an[na].key = (rel << 34) | d; an[na].pi = (uint32_t)byp[t].pos; an[na].ord = na;
             na++;
         }

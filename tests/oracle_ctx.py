@@ -10,6 +10,8 @@ import oracle_lib as O
 class OracleCtx:
     def __init__(self):
         self.contigs = []
+        self.h = 1           # (hite_amd.util.get_ctx keeps a context whose handle is alive)
+        self.device = 0
 
     # ---- residency ------------------------------------------------------------------------------
     def genome_pack(self, contigs):
@@ -18,6 +20,20 @@ class OracleCtx:
 
     def release_copy_index(self):
         pass
+
+    def tr_mask(self, max_period=500):
+        """as Context.tr_mask: the twin's tandem mask over the concatenated contigs; the resident genome carries it from here on"""
+        import test_trmask
+
+        m = test_trmask.twin_mask(self.contigs, max_period)
+        pos, out = 0, []
+        for c in self.contigs:
+            a = np.frombuffer(c, dtype=np.uint8).copy()
+            a[m[pos:pos + len(a)]] = ord("N")
+            out.append(a.tobytes())
+            pos += len(a)
+        self.contigs = out
+        return m
 
     # ---- stages ---------------------------------------------------------------------------------
     def itr_search(self, seqs, end_len=40, min_identity=0.7, min_len=7, match=10, mismatch=16, gap_open=32, gap_extend=32):

@@ -346,3 +346,82 @@ def test_coarse_stage_sharded_world2():
     assert res[0][1] + res[1][1] == whole and min(res[0][1], res[1][1]) > 0.15 * whole     # a partition of the table, both parts real
     for _rank, _share, c, a, b in res:
         assert (c, a, b) == expect
+
+
+# ---- determine_repeat_boundary_v5 itself under two ranks that share tmp_output_dir ---------------------------------
+def _drb_files(tmp):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import synth_small
+
+    g = synth_small.make(47, n_fam=10, n_chr=2, chr_len=160_000)
+    ref = os.path.join(tmp, "genome.fa")
+    chunk = os.path.join(tmp, "genome.cut0.fa")
+    with open(ref, "w") as f:
+        for i, s in enumerate(g["contigs"]):
+            f.write(">chr%d\n%s\n" % (i + 1, s))
+    seg = 40_000
+    with open(chunk, "w") as f:
+        for i, s in enumerate(g["contigs"]):
+            for o in range(0, len(s), seg):
+                f.write(">chr%d$%d\n%s\n" % (i + 1, o, s[o:o + seg]))
+    return ref, chunk
+
+
+def _drb_worker(rank, world, port, tmp, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HITE_TR_MASKER"] = "gpu"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from hite_amd import util
+    from oracle_ctx import OracleCtx
+
+    util._CTX = OracleCtx()                      # every device stage answers from its twin
+    ref, chunk = os.path.join(tmp, "genome.fa"), os.path.join(tmp, "genome.cut0.fa")
+    out = os.path.join(tmp, "w2", "longest_repeats_0.fa")
+    util.determine_repeat_boundary_v5(chunk, out, None, 2000, 30000, os.path.join(tmp, "w2"), 1, 0, ref, 0)
+    q.put((rank, open(out).read(), sorted(os.listdir(os.path.join(tmp, "w2")))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_determine_repeat_boundary_v5_world2(tmp_path):
+    """the reference-named entry of stage 3.1 (Util.py:4637) called by two ranks with the SAME arguments and the same
+    tmp_output_dir, as torchrun would: rank 0 alone writes the tandem-masked / prev_TE-masked chunk, the result and cleans up, the
+    collectives' tensors live where the backend wants them (gloo: host), and both ranks return the single-rank file"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hite_amd import util
+    from oracle_ctx import OracleCtx
+
+    tmp = str(tmp_path)
+    ref, chunk = _drb_files(tmp)
+    os.environ["HITE_TR_MASKER"] = "gpu"
+    saved = util._CTX
+    try:
+        util._CTX = OracleCtx()
+        one = os.path.join(tmp, "w1", "longest_repeats_0.fa")
+        util.determine_repeat_boundary_v5(chunk, one, None, 2000, 30000, os.path.join(tmp, "w1"), 1, 0, ref, 0)
+    finally:
+        util._CTX = saved
+        os.environ.pop("HITE_TR_MASKER", None)
+    expect = open(one).read()
+    assert expect.count(">") >= 10
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_drb_worker, args=(r, 2, port, tmp, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda x: x[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    for _rank, text, files in res:
+        assert text == expect
+    assert res[0][2] == ["longest_repeats_0.fa"]          # the temporaries are gone, nothing half-written is left

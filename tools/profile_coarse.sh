@@ -19,7 +19,7 @@ fi
 python - <<PY > $OUT/${TAG}_kernel_stats_coarse.txt 2> $OUT/kernel_stats_coarse.err
 import glob, sqlite3
 dbs = sorted(glob.glob("$OUT/cprof_stats/**/*.db", recursive=True))
-print("# rocprofv3 --kernel-trace --stats -- $BENCH  (MI355X, 1 Gbp; in the run: 6 inner steps (index + seeding + FMEA) + 3 end-to-end steps + set-up); durations in microseconds")
+print("# rocprofv3 --kernel-trace --stats -- $BENCH  (MI355X, 1 Gbp; in the run: 8 inner steps (index + seeding + FMEA) and 4 end-to-end steps (pack + tandem masking + prev_TE masking incl. a second index build + inner + flanks), warm-up included, + the generation of the genome by torch); durations in microseconds")
 for db in dbs:
     con = sqlite3.connect(db)
     views = [r[0] for r in con.execute("select name from sqlite_master where type in ('view','table')")]
