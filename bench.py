@@ -34,6 +34,9 @@ CONFIGS = {
     "C2": (100, 5.0, 0.0),
     "C3": (1000, 2.5, 2.5),
     "C5": (300, 2.5, 2.5),     # panHiTE: one 300 Mbp genome per GPU, 70 % of the families shared, libraries merged (c5_mode)
+    # configs[3] as ONE GPU sees it: the C3 genome and candidate batch, of which this process judges rank 0's strong-scaling share
+    # of 8 (6 250 candidates, length-balanced as hite_amd.dist deals them) -- small-batch efficiency measurable without a node
+    "C4share": (1000, 2.5, 2.5),
 }
 
 
@@ -101,6 +104,8 @@ def main():
     ap.add_argument("--cands-per-family", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20250927 + 3)
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--share-of", type=int, default=0,
+                    help="one process: judge only rank 0's strong-scaling share of this many ranks (config C4share: 8)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="worker processes of the cpu_baseline leg (0 = min(40, cores of this host))")
@@ -152,6 +157,9 @@ def main():
     n_tir = args.tir_families if args.tir_families is not None else max(1, int(tir_d * mbp))
     n_ltr = args.ltr_families if args.ltr_families is not None else max(0, int(ltr_d * mbp))
     strong = args.scaling == "strong" and world > 1
+    share_of = args.share_of if args.share_of > 1 else (8 if args.config == "C4share" else 0)
+    if world > 1:
+        share_of = 0
     t0 = time.time()
     # same genome on every rank (replicated); weak scaling: rank-specific candidate draw, strong scaling: one draw, sharded
     w = synth.make_workload(genome_bp=G, n_tir=n_tir, n_ltr=n_ltr, cands_per_family=args.cands_per_family, seed=args.seed,
@@ -159,10 +167,12 @@ def main():
     setup_s = time.time() - t0
     n_all = len(w["cand_off"]) - 1
     shares = None
-    if strong:
+    if strong or share_of:
         # ONE batch over the ranks: length-balanced block-cyclic shares (hite_amd.dist: the step time of a rank is set by its longest
         # alignments), the share as its own CSR; the all-gathered records go back to candidate order by the inverse permutation
-        ids, shares = hd.shard_candidates_balanced(w["cand_off"], w["copy_first"], rank, world)
+        ids, shares = hd.shard_candidates_balanced(w["cand_off"], w["copy_first"], rank if strong else 0, world if strong else share_of)
+        if not strong:
+            shares = None
         L = {}
         L["cands"], L["cand_off"] = hd.gather_csr(w["cands"], w["cand_off"], ids)
         cf64 = np.asarray(w["copy_first"], dtype=np.int64)
@@ -367,10 +377,12 @@ def main():
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": "%s: %d Mbp synthetic genome, %d TIR + %d LTR families, %d candidates%s judged as TIR (%s)" %
                                    (args.config if args.genome_mbp is None else "custom", mbp, n_tir, n_ltr, total_cands if strong else n_cand,
-                                    " sharded over %d GPUs" % world if strong else "/GPU",
+                                    " sharded over %d GPUs" % world if strong else
+                                    (" = rank 0's length-balanced share of %d ranks of the %d-candidate batch" % (share_of, n_all) if share_of else "/GPU"),
                                     "copy finding by minimizer-index lookup inside the timed step; index build %.1f s untimed" % index_s
                                     if args.copies == "found" else "copy table = generator truth; copy finding not in the timed path"),
-                       "genome_bp": G, "candidates_per_gpu": n_cand, "candidate_bases": b1 - b0, "copies": int(state["n_copies"]),
+                       "genome_bp": G, "candidates_per_gpu": n_cand, "us_per_candidate": round(1000.0 * ms_per_step / max(1, n_cand), 4),
+                       "candidate_bases": b1 - b0, "copies": int(state["n_copies"]),
                        "copy_table": args.copies, "rows_aligned_per_step": rows,
                        "pipeline_stats": [int(x) for x in stats], "copy_stats": [int(x) for x in ctx.copy_stats_ext()] if args.copies == "found" else None,
                        "align_stats_per_step": {k_: int(v_) for k_, v_ in per_step.items()},

@@ -1353,30 +1353,31 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
     return true_tes, low_copy
 
 
-def rescue_low_copy(TE_type, low_copy, plant, work_dir, tandem_masker=None, ctx=None):
-    """The recall of low-copy elements by structure (Util.py:8196-8213 + remove_no_tirs, :13897-13920), TIR stage: the
-    low-copy sequences go through TRF (tandem repeats -> N) when `trf` is installed and through the build's own masker
-    otherwise (`tandem_masker(names, contigs) -> contigs` overrides it), those with a short-TIR signature
-    (get_short_tir_contigs: hAT / Mutator / CACTA / CCC..GGG ends matching the TSD length in the name) are real TEs, the
-    rest is searched for a terminal inverted repeat as `itrsearch -i 0.7 -l 7` does (remove_no_tirs: the in-tree stage
-    hite_itr_search) and kept if it has one (with the masked sequence, as the tool writes it).  -> (rescued, still low copy).  The recall by intact protein domains
-    (get_domain_info = blastx against TIRPeps / HelitronPeps / non_LTR libraries, :8215-8276) is an external search and is
-    not reproduced: Helitron and non-LTR low-copy elements all stay in `all_low_copy`."""
-    import shutil
-    import subprocess
-
-    if low_copy:
-        # (said once per stage call, in the stage's stderr log: a user must know what this build cannot rescue)
-        sys.stderr.write("[hite_amd] %d low-copy %s candidate%s: the recall by intact protein domains (blastx against the TIR / Helitron / "
-                         "non-LTR peptide libraries, Util.py:8215-8276) is an external search this build does not run%s\n" %
-                         (len(low_copy), TE_type, "" if len(low_copy) == 1 else "s",
-                          "; only TIR-structure signatures are recalled" if TE_type == "tir" else
-                          ": low-copy %s elements stay in the low-copy file" % TE_type))
-    if TE_type != "tir" or not low_copy:
+def rescue_low_copy(TE_type, low_copy, plant, work_dir, tandem_masker=None, ctx=None, library_dir=None, threads=1):
+    """The recall of low-copy elements (Util.py:8196-8276): the low-copy sequences go through TRF (tandem repeats -> N) when `trf`
+    is installed and through the build's own masker otherwise (`tandem_masker(names, contigs) -> contigs` overrides it).  TIR
+    stage: those with a short-TIR signature (get_short_tir_contigs) or a terminal inverted repeat (remove_no_tirs: the in-tree
+    stage where the reference runs `itrsearch -i 0.7 -l 7`) are real TEs, with their masked sequence as the tool writes it; the
+    others, and the low-copy Helitron / non-LTR candidates, are searched for intact protein domains (get_domain_info: blastx
+    against <library_dir>/TIRPeps.lib | HelitronPeps.lib | non_LTR.lib, a hit over >= 95 % of a protein recalls the element with
+    its unmasked sequence).  library_dir defaults to $HITE_LIBRARY_DIR; blastx is an external tool: when it or the library is
+    missing that recall finds nothing and the stage log says so.  -> (rescued, still low copy), both in the reference's order."""
+    if not low_copy or TE_type not in _PROTEIN_LIB:
         return {}, dict(low_copy)
+    library_dir = library_dir or os.environ.get("HITE_LIBRARY_DIR")
+    lib = os.path.join(library_dir, _PROTEIN_LIB[TE_type]) if library_dir else None
+    can_search = shutil.which("blastx") is not None and lib is not None and os.path.exists(lib)
+    if not can_search:
+        # (said once per stage call, in the stage's stderr log: a user must know what this run cannot recall)
+        sys.stderr.write("[hite_amd] %d low-copy %s candidate%s: blastx or the protein library (%s) is not there, nothing is recalled by its "
+                         "protein domains (Util.py:8215-8276)%s\n" % (len(low_copy), TE_type, "" if len(low_copy) == 1 else "s",
+                                                                      lib or "set HITE_LIBRARY_DIR", "" if TE_type == "tir" else
+                                                                      ": low-copy %s elements stay in the low-copy file" % TE_type))
+        if TE_type != "tir":
+            return {}, dict(low_copy)
     os.makedirs(work_dir, exist_ok=True)
     masked = dict(low_copy)
-    if shutil.which("trf") is not None:
+    if shutil.which("trf") is not None and tandem_masker is None:
         path = os.path.join(work_dir, "low_copy.fa")
         store_fasta(low_copy, path)
         m = run_remove_TR(path, work_dir)
@@ -1386,8 +1387,185 @@ def rescue_low_copy(TE_type, low_copy, plant, work_dir, tandem_masker=None, ctx=
     else:
         # the build's own masker (the resident genome becomes these sequences; whoever needs the reference next packs it again)
         masked = (tandem_masker or mask_tandem_repeats)(list(low_copy.keys()), low_copy)
-    rescued, _no_tir = remove_no_tirs(masked, plant, ctx=ctx)
+    rescued = {}
+    to_search = masked
+    if TE_type == "tir":
+        rescued, to_search = remove_no_tirs(masked, plant, ctx=ctx)
+    if to_search and can_search:
+        cons = os.path.join(work_dir, "low_copy.%s.fa" % ("no_tir" if TE_type == "tir" else "masked"))
+        table = cons + "." + TE_type + "_domain"
+        store_fasta(to_search, cons)
+        if get_domain_info(cons, lib, table, threads, os.path.join(work_dir, TE_type + "_domain")):
+            for n in intact_domain_names(table, lib):
+                if n in low_copy:
+                    rescued[n] = low_copy[n]
     return rescued, {n: s_ for n, s_ in low_copy.items() if n not in rescued}
+
+
+# ---- low-copy rescue by intact protein domains (Util.py:8215-8276; get_domain_info :4571-4612, multiple_alignment_blastx_v1 :1006-1262)
+def _chain_domain_fragments(frags, thr):
+    """one (query, protein) pair of multiple_alignment_blastx_v1 (Util.py:1055-1207): blastx fragments (q_start, q_end, s_start,
+    s_end) -> [(q_start, q_end, length, s_start, s_end, s_length, extensions)] , one per cluster, in cluster order.  Forward
+    fragments (q_start <= q_end) ordered by the protein interval, reverse ones by descending query position; a fragment joins the
+    running cluster when it starts less than `thr` behind the end of any member (newest first); inside a cluster (ordered by the
+    protein interval again) every unvisited fragment grows a chain over the later ones that advance on the protein, keep the
+    strand, start < thr beyond the chain's query end and < thr / 3 beyond its protein end; the longest chain of a cluster stays
+    (the first among equals).  Fragments are keyed by value: equal tuples share their visited mark, as in the reference's dict."""
+    fwd = sorted((f for f in frags if not f[0] > f[1]), key=lambda x: (x[2], x[3]))
+    rev = sorted((f for f in frags if f[0] > f[1]), key=lambda x: (-x[0], -x[1]))
+    clusters = []
+    for group, sign in ((fwd, 1), (rev, -1)):
+        cur = None
+        for k, f in enumerate(group):
+            if k == 0:
+                cur = [f]
+                clusters.append(cur)
+                continue
+            near = any((f[0] - m[1] if sign > 0 else m[1] - f[0]) < thr for m in reversed(cur))
+            if near:
+                cur.append(f)
+            else:
+                cur = [f]
+                clusters.append(cur)
+    out = []
+    for cl in clusters:
+        cl = sorted(cl, key=lambda x: (x[2], x[3]))
+        best, visited = None, set()
+        for i, origin in enumerate(cl):
+            if origin in visited:
+                continue
+            qs, qe, ss, se = origin
+            length, n_ext = abs(qe - qs), 0
+            visited.add(origin)
+            for ext in cl[i + 1:]:
+                if ext in visited or not ext[3] > se:
+                    continue
+                if qs < qe and ext[0] < ext[1]:
+                    if ext[1] > qe:
+                        if ext[0] - qe < thr and ext[2] - se < thr / 3:
+                            qe, ss, se = ext[1], min(ss, ext[2]), ext[3]
+                            length, n_ext = qe - qs, n_ext + 1
+                            visited.add(ext)
+                        elif ext[0] - qe >= thr:
+                            break
+                elif qs > qe and ext[0] > ext[1]:
+                    if ext[1] < qe:
+                        if qe - ext[0] < thr and ext[2] - se < thr / 3:
+                            qe, ss, se = ext[1], min(ss, ext[2]), ext[3]
+                            length, n_ext = qs - qe, n_ext + 1
+                            visited.add(ext)
+                        elif qe - ext[0] >= thr:
+                            break
+            if best is None or length > best[2]:
+                best = (qs, qe, length, ss, se, se - ss, n_ext)
+        if best is not None:
+            out.append(best)
+    return out
+
+
+def _domain_overlap(pre, cur):
+    """the overlap arithmetic of the table writer (Util.py:1226-1246), both intervals put in ascending order first"""
+    ps, pe = (pre[0], pre[1]) if pre[0] <= pre[1] else (pre[1], pre[0])
+    cs, ce = (cur[0], cur[1]) if cur[0] <= cur[1] else (cur[1], cur[0])
+    if ps <= ce <= pe:
+        return ce - ps if cs <= ps else ce - cs
+    if ce > pe and ps <= cs <= pe:
+        return pe - cs
+    return 0
+
+
+def blastx_domain_table(blastx_out, merge_distance=100):
+    """the part of multiple_alignment_blastx_v1 (Util.py:1017-1262) behind the blastx call: `-outfmt 6` lines -> the rows of the
+    domain table [(TE, protein, TE_start, TE_end, protein_start, protein_end)]: per (TE, protein) the chained fragments, per TE
+    the chains by length (longest first), one dropped when more than half of it lies inside a longer one that stayed"""
+    records = {}
+    with open(blastx_out) as f:
+        for line in f:
+            parts = line.split("\t")
+            if len(parts) < 10:
+                continue
+            records.setdefault(parts[0], {}).setdefault(parts[1], []).append((int(parts[6]), int(parts[7]), int(parts[8]), int(parts[9])))
+    rows = []
+    for te, subjects in records.items():
+        chains = []
+        for protein, frags in subjects.items():
+            chains.extend(c + (protein,) for c in _chain_domain_fragments(frags, merge_distance))
+        chains.sort(key=lambda x: -x[2])
+        kept = []
+        for c in chains:
+            if all(not float(_domain_overlap(k_, c) / c[2]) > 0.5 for k_ in kept):
+                kept.append(c)
+        rows.extend((te, c[7], c[0], c[1], c[3], c[4]) for c in kept)
+    return rows
+
+
+def pet_partitions(items, partitions):
+    """PET / divided_array (Util.py:1771-1798) on (name, sequence) pairs: longest first (stable), dealt to the partitions in rounds
+    that take alternately from the front and from the back of that order"""
+    order = sorted(items, key=lambda x: len(x[1]), reverse=True)
+    parts = [[] for _ in range(partitions)]
+    i, j, k, front = 0, len(order) - 1, 0, True
+    while i <= j:
+        if front:
+            parts[k % partitions].append(order[i])
+            i += 1
+        else:
+            parts[k % partitions].append(order[j])
+            j -= 1
+        k += 1
+        if k % partitions == 0:
+            front = not front
+    return parts
+
+
+def get_domain_info(cons, lib, output_table, threads, temp_dir):
+    """get_domain_info (Util.py:4571-4612), same arguments: `blastx -evalue 1e-20 -outfmt 6` of the sequences of `cons`
+    (in `threads` partitions dealt as the reference's PET deals them) against the protein library `lib`, the fragments chained per
+    protein (blastx_domain_table), written as the reference's table: a header line, an empty line, then
+    TE \t protein \t TE_start \t TE_end \t protein_start \t protein_end.  blastx (NCBI BLAST+) is an external search and
+    stays one: without it the table holds the header only and a warning says so.  -> True when the search ran."""
+    os.makedirs(temp_dir, exist_ok=True)
+    names, contigs = read_fasta(cons)
+    ran = False
+    rows = []
+    if names and shutil.which("blastx") is not None and lib is not None and os.path.exists(lib):
+        if not all(os.path.exists(lib + ext) for ext in (".phr", ".pin", ".psq")) and shutil.which("makeblastdb"):
+            subprocess.run("cd %s && makeblastdb -dbtype prot -in %s > /dev/null 2>&1" % (os.path.dirname(lib) or ".", lib), shell=True, check=False)
+        for pi, part in enumerate(pet_partitions([(n, contigs[n]) for n in names], max(1, int(threads)))):
+            if not part:
+                continue
+            query, out = os.path.join(temp_dir, "%d.fa" % pi), os.path.join(temp_dir, "%d.out" % pi)
+            store_fasta(dict(part), query)
+            subprocess.run("blastx -db %s -num_threads 1 -evalue 1e-20 -query %s -outfmt 6 > %s" % (lib, query, out), shell=True, check=False)
+            if os.path.exists(out):        # (the reference concatenates the partitions' tables as they complete; here: in partition order)
+                rows.extend(blastx_domain_table(out, 100))
+        ran = True
+    elif names:
+        sys.stderr.write("[hite_amd] blastx or the protein library %s not found: no low-copy element is recalled by its protein domains\n" % lib)
+    with open(output_table, "w") as f:
+        f.write("TE_name\tdomain_name\tTE_start\tTE_end\tdomain_start\tdomain_end\n\n")
+        for r in rows:
+            f.write("\t".join(str(x) for x in r) + "\n")
+    return ran
+
+
+def intact_domain_names(output_table, protein_lib):
+    """the decision of the domain recall (Util.py:8221-8234): TEs with a protein hit spanning >= 95 % of the protein"""
+    _pn, proteins = read_fasta(protein_lib)
+    keep = []
+    with open(output_table) as f:
+        for i, line in enumerate(f):
+            if i < 2:
+                continue
+            parts = line.split("\t")
+            if len(parts) < 6:
+                continue
+            if float(abs(int(parts[5]) - int(parts[4]))) / len(proteins[parts[1]]) >= 0.95 and parts[0] not in keep:
+                keep.append(parts[0])
+    return keep
+
+
+_PROTEIN_LIB = {"tir": "TIRPeps.lib", "helitron": "HelitronPeps.lib", "non_ltr": "non_LTR.lib"}
 
 
 def bucket_results(TE_type, results):

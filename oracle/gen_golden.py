@@ -1345,11 +1345,147 @@ def gen_itr_search(U, tmp):
     dump("itr_search", obj)
 
 
+
+def gen_low_copy_rescue(U, tmp):
+    """The low-copy recall at the end of flank_region_align_v5 (Util.py:8196-8287) run by the REFERENCE with its tools: `trf` =
+    the TRF 4.09 it bundles, `itrsearch` = the ELF it bundles (through remove_no_tirs), get_domain_info / multiple_alignment_blastx_v1
+    (Util.py:4571-4612, 1006-1262) as they are, with `blastx` (NCBI BLAST+, absent from the image) answered by a shim that prints a
+    FABRICATED `-outfmt 6` table for the sequences of its query file, and `makeblastdb` a no-op.  run_find_members_v8 is a table of
+    result tuples (as in `bucketing`).  The fixture holds the tuples, the protein libraries, the fabricated blastx lines and what
+    the reference wrote: real_TEs, all_low_copy and the domain table."""
+    import json as _json
+    import shutil
+
+    root = os.path.join(tmp, "lcr_root")
+    os.makedirs(os.path.join(root, "tools"), exist_ok=True)
+    os.makedirs(os.path.join(root, "library"), exist_ok=True)
+    shutil.copyfile(os.path.join(_itrsearch_dir(tmp), "itrsearch"), os.path.join(root, "tools", "itrsearch"))
+    os.chmod(os.path.join(root, "tools", "itrsearch"), 0o755)
+    bindir = os.path.join(tmp, "lcr_bin")
+    os.makedirs(bindir, exist_ok=True)
+    shutil.copyfile(os.path.join(ref_harness.REFERENCE_ROOT, "tools", "trf409.linux64"), os.path.join(bindir, "trf"))
+    os.chmod(os.path.join(bindir, "trf"), 0o755)
+    with open(os.path.join(bindir, "makeblastdb"), "w") as f:
+        f.write("#!/bin/sh\nexit 0\n")
+    with open(os.path.join(bindir, "blastx"), "w") as f:
+        f.write("#!/usr/bin/env python3\nimport json, os, sys\nq = sys.argv[sys.argv.index('-query') + 1]\n"
+                "tab = json.load(open(os.environ['HITE_FAKE_BLASTX']))\n"
+                "for line in open(q):\n    if line.startswith('>'):\n        for r in tab.get(line[1:].strip(), []):\n            sys.stdout.write(r)\n")
+    for x in ("makeblastdb", "blastx"):
+        os.chmod(os.path.join(bindir, x), 0o755)
+    rng = np.random.default_rng(8215)
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    libs = {}
+    for fn in ("TIRPeps.lib", "HelitronPeps.lib", "non_LTR.lib"):
+        prot = {"%s_p%d#DNA" % (fn.split(".")[0], k): "".join(aa[int(x)] for x in rng.integers(0, 20, size=int(rng.integers(120, 600)))) for k in range(6)}
+        write_fasta(os.path.join(root, "library", fn), list(prot.keys()), list(prot.values()))
+        libs[fn] = [[k, v] for k, v in prot.items()]
+    cases = []
+    for te_type, fn in (("tir", "TIRPeps.lib"), ("helitron", "HelitronPeps.lib"), ("non_ltr", "non_LTR.lib")):
+        for rep in range(2):
+            prot = dict(libs[fn])
+            pnames = list(prot.keys())
+            names, seqs = casegen.make_genome(40 + rep)
+            ref = os.path.join(tmp, "lg_%s_%d.fa" % (te_type, rep))
+            write_fasta(ref, names, seqs)
+            table, copies, blast = {}, {}, {}
+            for q in range(48):
+                body = casegen.rand_seq(rng, int(rng.integers(600, 2600)))
+                kind = int(rng.integers(0, 6))
+                tsd = casegen.rand_seq(rng, int(rng.choice([2, 3, 8, 9, 10])))
+                if te_type == "tir" and kind in (0, 1):          # a terminal inverted repeat itrsearch finds
+                    t = casegen.rand_seq(rng, int(rng.integers(12, 40)))
+                    body = t + body[len(t):-len(t)] + casegen.revcomp(casegen.mutate(rng, t, 0.05))
+                if te_type == "tir" and kind == 2 and len(tsd) in (8, 9, 10):   # short-TIR signature (get_short_tir_contigs)
+                    body = body[:-5] + casegen.revcomp(body[:5])
+                qn = ("N_%d-tir_%d-tsd_%s" % (q, int(rng.integers(0, 30)), tsd)) if te_type == "tir" else "N_%d" % q
+                cc = int(rng.choice([1, 2, 3, 4, 5, 6, 9, 40]))
+                table[qn] = (qn, body, "", cc)
+                copies[qn] = [(names[0], 100, 400, 301, "+")]
+                if kind >= 3 or rng.random() < 0.3:              # fabricated blastx fragments against one or two proteins
+                    lines = []
+                    for pn in [pnames[int(rng.integers(0, len(pnames)))] for _ in range(int(rng.integers(1, 3)))]:
+                        plen = len(prot[pn])
+                        cover = float(rng.choice([0.4, 0.8, 0.94, 0.96, 1.0]))
+                        nfrag = int(rng.integers(1, 5))
+                        span = max(nfrag, int(plen * cover))
+                        cuts = sorted(set([0, span] + [int(x) for x in rng.integers(1, max(2, span), size=nfrag - 1)]))
+                        p0 = 1 + int(rng.integers(0, max(1, plen - span)))
+                        q0 = int(rng.integers(1, max(2, len(body) - 3 * span - 400)))
+                        minus = rng.random() < 0.4
+                        frs = []
+                        for a, b in zip(cuts[:-1], cuts[1:]):
+                            if b - a < 2:
+                                continue
+                            gapq = int(rng.choice([0, 0, 20, 60, 150]))
+                            gaps = int(rng.choice([0, 0, 5, 20, 40]))
+                            qs_, qe_ = q0 + 3 * a + gapq, q0 + 3 * b + gapq - 1
+                            ss_, se_ = p0 + a + gaps, min(plen, p0 + b - 1 + gaps)
+                            if minus:
+                                qs_, qe_ = len(body) - qs_, len(body) - qe_
+                            frs.append((qs_, qe_, ss_, se_))
+                        if rng.random() < 0.3:
+                            frs.reverse()
+                        for (qs_, qe_, ss_, se_) in frs:
+                            lines.append("%s\t%s\t%.2f\t%d\t0\t0\t%d\t%d\t%d\t%d\t1e-30\t200\n" % (qn, pn, 60 + 30 * rng.random(), se_ - ss_ + 1, qs_, qe_, ss_, se_))
+                    blast[qn] = lines
+            cand = os.path.join(tmp, "lc_%s_%d.fa" % (te_type, rep))
+            write_fasta(cand, list(table.keys()), ["ACGT" * 30 for _ in table])
+            fake = os.path.join(tmp, "lcr_blastx_%s_%d.json" % (te_type, rep))
+            with open(fake, "w") as f:
+                _json.dump(blast, f)
+
+            def fake_copies(query_path, reference, temp_dir, max_copy_num, threads, _c=copies):
+                os.makedirs(temp_dir, exist_ok=True)
+                return _c
+
+            def fake_members(task, temp_dir, subset_script_path, plant, TE_type, debug, result_type, _t=table):
+                (query_name, cur_seq, trunc_member_file, extend_member_file) = task
+                r = _t[query_name]
+                return (r[0], r[1], r[2], r[3], extend_member_file)
+
+            saved = (U.get_full_length_copies_minimap2, U.run_find_members_v8, U.ProcessPoolExecutor, U.as_completed, U.cur_dir)
+            saved_env = (os.environ.get("PATH"), os.environ.get("HITE_FAKE_BLASTX"))
+            U.get_full_length_copies_minimap2 = fake_copies
+            U.run_find_members_v8 = fake_members
+            U.ProcessPoolExecutor = ref_harness.SyncExecutor
+            U.as_completed = lambda fs: fs
+            U.cur_dir = root
+            os.environ["PATH"] = bindir + os.pathsep + saved_env[0]
+            os.environ["HITE_FAKE_BLASTX"] = fake
+            real = os.path.join(tmp, "lreal_%s_%d.fa" % (te_type, rep))
+            low = os.path.join(tmp, "llow_%s_%d.fa" % (te_type, rep))
+            work = os.path.join(tmp, "lw_%s_%d" % (te_type, rep))
+            open(low, "w").close()
+            try:
+                log = type("L", (), {"logger": type("LL", (), {"info": staticmethod(lambda *a: None), "debug": staticmethod(lambda *a: None)})})()
+                U.flank_region_align_v5(cand, real, 50, ref, None, te_type, work, 1, 0, log, "", rep, 1, 0, low)     # (debug = 1: the working directory stays)
+            finally:
+                (U.get_full_length_copies_minimap2, U.run_find_members_v8, U.ProcessPoolExecutor, U.as_completed, U.cur_dir) = saved
+                os.environ["PATH"] = saved_env[0]
+                if saved_env[1] is None:
+                    os.environ.pop("HITE_FAKE_BLASTX", None)
+            lcd = os.path.join(work, "%s_copies_0_0" % te_type, "low_copy_itr")
+            tables = [x for x in sorted(os.listdir(lcd)) if x.endswith("_domain")]
+            assert len(tables) == 1, tables
+            masked = [x for x in os.listdir(lcd) if x.endswith(".mask")]
+            assert masked, "TRF did not run"
+            mn, mc = U.read_fasta(os.path.join(lcd, masked[0]))
+            rn, rc = U.read_fasta(real)
+            cases.append(dict(te_type=te_type, plant=rep, table=[[k, v[0], v[1], v[2], v[3]] for k, v in table.items()], library=libs[fn],
+                              blastx=blast, real=[[x, rc[x]] for x in rn], low_text=open(low).read(), domain_table=open(os.path.join(lcd, tables[0])).read(),
+                              trf_changed=[k for k in mn if mc[k] != table[k][1]]))
+            print("low_copy_rescue %s %d: %d candidates -> %d real TEs, %d low copy; %d domain rows; TRF changed %d" %
+                  (te_type, rep, len(table), len(rn), open(low).read().count(">"), open(os.path.join(lcd, tables[0])).read().count("\n") - 2,
+                   len(cases[-1]["trf_changed"])))
+    dump("low_copy_rescue", cases)
+
+
 def main():
     assert os.environ.get("PYTHONHASHSEED") == "0", "run with PYTHONHASHSEED=0"
     U = ref_harness.load_reference_util()
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf", "rfm", "chainvar", "edge", "itr"]
+    which = sys.argv[1:] or ["fmea", "judge", "search", "tsd", "kmer", "gather", "tails", "host", "ltr", "nonltr", "qcopies", "libdedup", "bothends", "split", "bucketing", "consv1", "trf", "rfm", "chainvar", "edge", "itr", "lcr"]
     with tempfile.TemporaryDirectory() as tmp:
         if "fmea" in which:
             gen_fmea(U, tmp)
@@ -1393,6 +1529,8 @@ def main():
             gen_judge_edge(U, tmp)
         if "itr" in which:
             gen_itr_search(U, tmp)
+        if "lcr" in which:
+            gen_low_copy_rescue(U, tmp)
 
 
 if __name__ == "__main__":

@@ -77,3 +77,44 @@ def check_rescue(util, ctx):
         n += len(with_tir)
     assert n > 100
     return n
+
+
+def check_low_copy_rescue(util, ctx, tmp_path, monkeypatch):
+    """bucket_results + rescue_low_copy against tests/golden/low_copy_rescue.json.gz (the reference's run of Util.py:8196-8287 with TRF,
+    itrsearch and get_domain_info over a fabricated blastx table); `blastx` is a shim on PATH printing the same fabricated table"""
+    import json
+    import os
+    import stat
+
+    bindir = tmp_path / "bin"
+    bindir.mkdir()
+    (bindir / "makeblastdb").write_text("#!/bin/sh\nexit 0\n")
+    (bindir / "blastx").write_text("#!/usr/bin/env python3\nimport json, os, sys\nq = sys.argv[sys.argv.index('-query') + 1]\n"
+                                   "tab = json.load(open(os.environ['HITE_FAKE_BLASTX']))\n"
+                                   "for line in open(q):\n    if line.startswith('>'):\n        for r in tab.get(line[1:].strip(), []):\n            sys.stdout.write(r)\n")
+    for x in ("makeblastdb", "blastx"):
+        os.chmod(str(bindir / x), os.stat(str(bindir / x)).st_mode | stat.S_IEXEC)
+    monkeypatch.setenv("PATH", str(bindir) + os.pathsep + os.environ["PATH"])
+    n_dom = n_itr = 0
+    for ci, case in enumerate(load_golden("low_copy_rescue")):
+        assert case["trf_changed"] == []
+        te = case["te_type"]
+        lib_dir = tmp_path / ("lib%d" % ci)
+        lib_dir.mkdir()
+        fn = {"tir": "TIRPeps.lib", "helitron": "HelitronPeps.lib", "non_ltr": "non_LTR.lib"}[te]
+        (lib_dir / fn).write_text("".join(">%s\n%s\n" % (k, v) for k, v in case["library"]))
+        fake = tmp_path / ("blastx%d.json" % ci)
+        fake.write_text(json.dumps(case["blastx"]))
+        monkeypatch.setenv("HITE_FAKE_BLASTX", str(fake))
+        true_tes, low = util.bucket_results(te, [(r[1], r[2], r[3], r[4]) for r in case["table"]])
+        work = str(tmp_path / ("w%d" % ci))
+        rescued, still = util.rescue_low_copy(te, low, case["plant"], work, tandem_masker=lambda names, contigs: dict(contigs), ctx=ctx,
+                                              library_dir=str(lib_dir), threads=1)
+        true_tes.update(rescued)
+        assert [[k, v] for k, v in true_tes.items()] == case["real"], (ci, te)
+        assert "".join(">%s\n%s\n" % (k, v) for k, v in still.items()) == case["low_text"]
+        tab = [x for x in os.listdir(work) if x.endswith("_domain") and os.path.isfile(os.path.join(work, x))]
+        assert len(tab) == 1 and open(os.path.join(work, tab[0])).read() == case["domain_table"]
+        n_dom += case["domain_table"].count("\n") - 2
+        n_itr += sum(1 for k in rescued if te == "tir")
+    assert n_dom > 80 and n_itr > 10

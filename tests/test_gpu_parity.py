@@ -1673,3 +1673,12 @@ def test_flanking_seq_dev_windows_vs_oracle(ctx):
         assert out[int(off[k]):int(off[k]) + int(ln[k])].tobytes().decode() == exp, k
         got_total += int(ln[k])
     assert got_total == total and total > 100_000
+
+
+def test_low_copy_rescue_golden_on_gpu(ctx, tmp_path, monkeypatch):
+    """the low-copy recall (Util.py:8196-8287) with the HIP terminal-inverted-repeat stage: real_TEs, all_low_copy and the domain
+    table of the reference's own run (TRF + itrsearch + get_domain_info over a fabricated blastx table)"""
+    import itr_cases
+    from hite_amd import util
+
+    itr_cases.check_low_copy_rescue(util, ctx, tmp_path, monkeypatch)

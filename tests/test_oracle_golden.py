@@ -573,3 +573,15 @@ def test_itr_filter_host_mirrors_golden():
     n_q, n_drop = itr_cases.check_batches(util, ctx)
     assert n_drop > n_q
     itr_cases.check_rescue(util, ctx)
+
+
+def test_low_copy_rescue_golden(tmp_path, monkeypatch):
+    """the low-copy recall (Util.py:8196-8287) against the reference's own run with its tools (TRF 4.09, itrsearch, get_domain_info over
+    a fabricated blastx table): real_TEs, all_low_copy and the domain table.  Here: bucket_results + rescue_low_copy with the
+    terminal-inverted-repeat search answering from its twin and `blastx` = the same fabricated table (a shim on PATH: blastx itself is
+    an external search in both builds); TRF changed none of the fixture's sequences, so the tandem step is the identity"""
+    import itr_cases
+    from hite_amd import util
+    from oracle_ctx import OracleCtx
+
+    itr_cases.check_low_copy_rescue(util, OracleCtx(), tmp_path, monkeypatch)
