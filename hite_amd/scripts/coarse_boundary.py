@@ -50,7 +50,7 @@ def fmea_file(ctx, path, skip_gap, max_len):
     return ["%s:%d-%d" % (inv[c], s, e) for c, s, e in zip(oc, os_, oe)]
 
 
-def main():
+def build_parser():
     p = argparse.ArgumentParser(description="run HiTE De novo TE searching on the MI355X path")
     p.add_argument("-g"); p.add_argument("--prev_TE", default=None)
     p.add_argument("--fixed_extend_base_threshold", type=int, default=4000); p.add_argument("--max_repeat_len", type=int, default=30000)
@@ -59,7 +59,11 @@ def main():
     p.add_argument("-r"); p.add_argument("--tmp_output_dir"); p.add_argument("--recover", type=int, default=0)
     p.add_argument("--debug", type=int, default=0); p.add_argument("-w", "--work_dir", default="/tmp")
     p.add_argument("--hsp", nargs="+", default=None, help="blast6 HSP tables (one per query file) -- extension of this build")
-    a = p.parse_args()
+    return p
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
     out_dir = os.path.abspath(a.tmp_output_dir or os.getcwd())
     os.makedirs(out_dir, exist_ok=True)
     lr = os.path.join(out_dir, "longest_repeats_%s.fa" % a.ref_index)

@@ -18,7 +18,7 @@ import _stage  # noqa: E402
 from _stage import util  # noqa: E402
 
 
-def main():
+def build_parser():
     p = argparse.ArgumentParser(description="run HiTE non-LTR module on the MI355X path")
     p.add_argument("--seqs"); p.add_argument("-t", type=int, default=1); p.add_argument("--subset_script_path", default=None)
     p.add_argument("--tmp_output_dir"); p.add_argument("--library_dir", default=None); p.add_argument("--recover", type=int, default=0)
@@ -28,7 +28,11 @@ def main():
     p.add_argument("--prev_TE", default=None); p.add_argument("--all_low_copy_non_ltr", default=None)
     p.add_argument("--min_TE_len", type=int, default=80); p.add_argument("-w", "--work_dir", default="/tmp")
     p.add_argument("--candidates", default=None, help="candidate non-LTR FASTA -- extension of this build")
-    a = p.parse_args()
+    return p
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
     out_dir = os.path.abspath(a.tmp_output_dir or os.getcwd())
     os.makedirs(out_dir, exist_ok=True)
     final = os.path.join(out_dir, "confident_non_ltr_%s.fa" % a.ref_index)

@@ -25,7 +25,7 @@ def tsd_variants(flanked_path, flanking_len, plant, work_dir):
     return util.search_confident_tir_batch_v1(names, contigs, flanking_len, plant, work_dir)
 
 
-def main():
+def build_parser():
     p = argparse.ArgumentParser(description="run HiTE TIR module on the MI355X path")
     p.add_argument("--seqs"); p.add_argument("-t", type=int, default=1); p.add_argument("--tmp_output_dir")
     p.add_argument("--tandem_region_cutoff", default="0.5"); p.add_argument("--ref_index", default="0")
@@ -34,7 +34,11 @@ def main():
     p.add_argument("-r"); p.add_argument("--split_ref_dir", default=None); p.add_argument("--prev_TE", default=None)
     p.add_argument("--all_low_copy_tir", default=None); p.add_argument("--min_TE_len", type=int, default=80)
     p.add_argument("-w", "--work_dir", default="/tmp")
-    a = p.parse_args()
+    return p
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
     out_dir = os.path.abspath(a.tmp_output_dir or os.getcwd())
     os.makedirs(out_dir, exist_ok=True)
     ref_index, flank = a.ref_index, 50  # the reference pins flanking_len to 50 here (judge_TIR_transposons.py:21)

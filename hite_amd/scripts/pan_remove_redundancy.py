@@ -19,11 +19,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from hite_amd import util  # noqa: E402
 
 
-def main():
+def build_parser():
     p = argparse.ArgumentParser(description="panHiTE remove redundancy.")
     p.add_argument("--merge_te_file"); p.add_argument("--threads", type=int, default=1)
     p.add_argument("--output_dir", nargs="?", default=os.getcwd()); p.add_argument("-w", "--work_dir", nargs="?", default="/tmp")
-    a = p.parse_args()
+    return p
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
     out_dir = os.path.abspath(a.output_dir)
     os.makedirs(out_dir, exist_ok=True)
     tmp = os.path.join(os.path.abspath(a.work_dir), "pan_remove_redundancy_" + str(uuid.uuid4()))

@@ -15,11 +15,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from hite_amd import util  # noqa: E402
 
 
-def main():
+def build_parser():
     p = argparse.ArgumentParser(description="run HiTE split genome chunks...")
     p.add_argument("-g"); p.add_argument("--tmp_output_dir", default=None)
     p.add_argument("--chrom_seg_length"); p.add_argument("--chunk_size")
-    a = p.parse_args()
+    return p
+
+
+def main(argv=None):
+    a = build_parser().parse_args(argv)
     util.split_genome_chunks(a.g, a.tmp_output_dir or os.getcwd(), int(a.chrom_seg_length), float(a.chunk_size))
     return 0
 

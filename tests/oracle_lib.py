@@ -36,6 +36,8 @@ def lib():
 
 
 def _u8(b):
+    if isinstance(b, np.ndarray):        # (a slice of a memory-mapped genome: no copy)
+        return np.ascontiguousarray(b, dtype=np.uint8)
     a = np.frombuffer(b if isinstance(b, (bytes, bytearray)) else b.encode(), dtype=np.uint8)
     return np.ascontiguousarray(a)
 
