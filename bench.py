@@ -674,6 +674,16 @@ def _coarse_cpu_worker(job):
     return time.perf_counter() - t0, len(h["qseg"]), len(names), t, int(mask.sum())
 
 
+COARSE_ALG_NOTE = ("algorithmic bytes = what the step's sorts have to move: index entries 12 B x 2 x 4 passes (hash sort carrying the position rank), "
+                   "anchors 8 B x 2 x 3 passes (packed records, genomes <= 2^30 bases), HSP records 48 B x 2 x 5 (emit, 4-pass sort, gather); "
+                   "whole step, not one kernel (rounds 2-4 counted 9 / 5 passes of 12- / 24-byte records)")
+
+
+def coarse_alg_bytes(st):
+    """st = (seeds, anchors, clusters, HSP records) of one step"""
+    return 12.0 * 2 * 4 * st[0] + 8.0 * 2 * 3 * st[1] + 48.0 * 2 * 5 * st[3]
+
+
 def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
     """stage 3.1 END TO END on the genome of the headline workload (coarse_boundary.py:14-32 -> determine_repeat_boundary_v5,
     Util.py:4637-4670, + flanking_seq :4614), the whole genome as one chunk, everything device-resident.  A step =
@@ -736,13 +746,13 @@ def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
     torch.cuda.synchronize()
     ms_inner = 1000.0 * (time.perf_counter() - t1) / steps
     prof_inner = {k: round(v[0] / steps, 3) for k, v in sorted(ctx.profile(on=False).items())}
-    alg = 12.0 * st[0] * 9 + 24.0 * st[1] * 5 + 48.0 * st[3] * 5
+    alg = coarse_alg_bytes(st)
     inner = {"metric": "index + all-vs-all seeding + FMEA alone (the coarse number of rounds 2 and 3)", "ms_per_step": round(ms_inner, 3),
              "value": round(mbp / (ms_inner * 1e-3), 1), "unit": "Mbp/s", "seeds": st[0], "anchors": st[1], "clusters": st[2], "hsp_records": st[3],
              "repeat_intervals": len(iv[0]), "stages_ms": prof_inner,
              "roofline": {"bound": "hbm", "achieved": round(alg / (ms_inner * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                           "frac": round(alg / (ms_inner * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
-                          "note": "algorithmic bytes = radix passes x 2 x record size over seeds / anchors / HSP records (whole step, not one kernel)"}}
+                          "note": COARSE_ALG_NOTE}}
     if w is None:
         return dict(inner, inner=None)
     # ---- end to end -----------------------------------------------------------------------------------------------------
@@ -1054,9 +1064,9 @@ def coarse_stage(args):
                "config": {"workload": "%s genome: %d Mbp, %d TIR + %d LTR families, 1 Mbp segments, one chunk%s" %
                                       (args.config, mbp, n_tir, n_ltr, "; one genome per GPU (replicas)" if world > 1 else ""),
                           "seeds": stats[0], "anchors": stats[1], "clusters": stats[2], "hsp_records": stats[3], "repeat_intervals": n_iv},
-               "roofline": {"bound": "hbm", "achieved": round((12.0 * stats[0] * 9 + 24.0 * stats[1] * 5 + 48.0 * stats[3] * 5) / (elapsed / args.steps) / 1e9, 2),
+               "roofline": {"bound": "hbm", "achieved": round(coarse_alg_bytes(stats) / (elapsed / args.steps) / 1e9, 2),
                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                            "note": "algorithmic bytes = radix passes x 2 x record size over seeds / anchors / HSP records (whole step, not one kernel)"}}
+                            "note": COARSE_ALG_NOTE}}
         out["roofline"]["frac"] = round(out["roofline"]["achieved"] / PEAK_HBM_GBS, 5)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = coarse_cpu_baseline(args, min(mbp, 20))

@@ -89,22 +89,44 @@ def shard_candidates_balanced(cand_off, copy_first, rank, world):
     return shares[rank], shares
 
 
+# Buffers of the per-step merge, kept between steps (the send pad, the gathered records, the merged records, the inverse
+# permutation): a step that allocates and concatenates them anew pays the allocator and a device synchronisation inside the timed
+# region.  Keyed by (purpose, device); grow-only.  The tensors returned by the merges below alias them: valid until the next merge.
+_MERGE_BUF = {}
+
+
+def _merge_buf(key, n, dtype, device):
+    k = (key, str(device), dtype)
+    t = _MERGE_BUF.get(k)
+    if t is None or t.numel() < n:
+        t = torch.empty(max(n, 1), dtype=dtype, device=device)
+        _MERGE_BUF[k] = t
+    return t[:n]
+
+
 def allgather_calls_balanced(local_calls, shares, group=None):
     """local_calls: uint8 tensor (len(shares[rank]) * 32) in the order of shares[rank].  ONE padded all_gather_into_tensor, then
-    the inverse permutation: returns the records of all candidates in candidate order."""
+    the inverse permutation: returns the records of all candidates in candidate order (a view of a buffer kept between steps)."""
     world = dist.get_world_size(group)
+    dev = local_calls.device
     max_n = max(1, max(len(s) for s in shares))
-    pad = torch.zeros(max_n * 32, dtype=torch.uint8, device=local_calls.device)
-    pad[: local_calls.numel()] = local_calls
-    out = torch.empty(world * max_n * 32, dtype=torch.uint8, device=local_calls.device)
+    pad = _merge_buf("pad", max_n * 32, torch.uint8, dev)
+    pad[: local_calls.numel()] = local_calls            # (the tail of the pad is never read: every rank's count is known)
+    out = _merge_buf("gathered", world * max_n * 32, torch.uint8, dev)
     dist.all_gather_into_tensor(out, pad, group=group)
     n_total = sum(len(s) for s in shares)
-    # row of candidate c in the gathered buffer
-    src = np.empty(n_total, dtype=np.int64)
-    for r, ids in enumerate(shares):
-        src[ids] = r * max_n + np.arange(len(ids))
-    idx = torch.from_numpy(src).to(out.device)
-    return out.view(world * max_n, 32)[idx].reshape(-1)
+    key = ("perm", id(shares))
+    cached = _MERGE_BUF.get(key)
+    if cached is None or cached[0] is not shares:
+        # row of candidate c in the gathered buffer (the shares of a run do not change between its steps)
+        src = np.empty(n_total, dtype=np.int64)
+        for r, ids in enumerate(shares):
+            src[ids] = r * max_n + np.arange(len(ids))
+        cached = (shares, torch.from_numpy(src).to(dev))
+        _MERGE_BUF[key] = cached
+    merged = _merge_buf("merged", n_total * 32, torch.uint8, dev).view(n_total, 32)
+    torch.index_select(out.view(world * max_n, 32), 0, cached[1], out=merged)
+    return merged.reshape(-1)
 
 
 def allgather_consensus_balanced(local_calls_np, local_cons, shares, group=None):
@@ -131,16 +153,20 @@ def allgather_consensus_balanced(local_calls_np, local_cons, shares, group=None)
 
 def allgather_calls(local_calls, n_total, group=None):
     """local_calls: uint8 tensor (n_local * 32) on the backend's device.  Returns the n_total records of all
-    ranks in candidate order (block partition => rank order).  One padded all_gather_into_tensor."""
+    ranks in candidate order (block partition => rank order; a view of a buffer kept between steps).  One padded all_gather_into_tensor."""
     world = dist.get_world_size(group)
+    dev = local_calls.device
     b = shard_bounds(n_total, world)
-    max_n = int(np.max(np.diff(b)))
-    pad = torch.zeros(max_n * 32, dtype=torch.uint8, device=local_calls.device)
+    max_n = max(1, int(np.max(np.diff(b))))
+    pad = _merge_buf("pad", max_n * 32, torch.uint8, dev)
     pad[: local_calls.numel()] = local_calls
-    out = torch.empty(world * max_n * 32, dtype=torch.uint8, device=local_calls.device)
+    out = _merge_buf("gathered", world * max_n * 32, torch.uint8, dev)
     dist.all_gather_into_tensor(out, pad, group=group)
-    parts = [out[r * max_n * 32: r * max_n * 32 + int(b[r + 1] - b[r]) * 32] for r in range(world)]
-    return torch.cat(parts)
+    merged = _merge_buf("merged", n_total * 32, torch.uint8, dev)
+    for r in range(world):                  # block partition: rank order is candidate order; no allocation, no concatenation
+        n_r = int(b[r + 1] - b[r]) * 32
+        merged[int(b[r]) * 32: int(b[r]) * 32 + n_r] = out[r * max_n * 32: r * max_n * 32 + n_r]
+    return merged
 
 
 def allgather_consensus(local_calls_np, local_cons, n_total, group=None):

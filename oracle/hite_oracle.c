@@ -152,6 +152,27 @@ static int build_colmap(const uint8_t **rows, int R, int C, colmap_t *cm) {
     return 0;
 }
 
+/* the column histogram as the GPU entry hite_column_vote reports it: counts of A, C, G, T, N, '-' per column, read off the
+ * oracle's col_base_map (build_colmap above, Util.py:9251-9266); any other symbol is an error (the product folds it to N on entry) */
+int orc_column_vote(const uint8_t *msa, int R, int C, int32_t *out /* C x 6 */) {
+    if (R <= 0 || C <= 0) return ORC_EINVAL;
+    const uint8_t **rows = (const uint8_t **)malloc(sizeof(uint8_t *) * (size_t)R);
+    colmap_t *cm = (colmap_t *)malloc(sizeof(colmap_t) * (size_t)C);
+    if (!rows || !cm) { free(rows); free(cm); return ORC_ECAP; }
+    for (int r = 0; r < R; r++) rows[r] = msa + (size_t)r * C;
+    int rc = build_colmap(rows, R, C, cm);
+    for (int c = 0; c < C && rc == 0; c++) {
+        for (int k = 0; k < 6; k++) out[(size_t)c * 6 + k] = 0;
+        for (int k = 0; k < cm[c].nsym; k++) {
+            const char *pos = strchr("ACGTN-", cm[c].sym[k]);
+            if (!pos || !cm[c].sym[k]) { rc = ORC_EINVAL; break; }
+            out[(size_t)c * 6 + (pos - "ACGTN-")] = cm[c].cnt[k];
+        }
+    }
+    free(rows); free(cm);
+    return rc;
+}
+
 /* ------------------------------------------------------------------------------- */
 /* remove_sparse_col_in_align_file  Util.py:10344-10405                            */
 /* keep[c] = 1 if the column survives                                              */

@@ -61,6 +61,15 @@ def sparse_cols(msa):
     return keep
 
 
+def column_vote(msa):
+    """per-column counts of A, C, G, T, N, '-' from the oracle's col_base_map (Util.py:9251-9266)"""
+    R, Cn = msa.shape
+    out = np.zeros((Cn, 6), dtype=np.int32)
+    rc = lib().orc_column_vote(_ptr(np.ascontiguousarray(msa), u8p), R, Cn, _ptr(out, i32p))
+    assert rc == 0, rc
+    return out
+
+
 def search_v3(msa, pos, side, thr, win_in=20, win_out=10):
     R, Cn = msa.shape
     return lib().orc_search_v3(_ptr(msa, u8p), R, Cn, int(pos), 0 if side == "start" else 1, C.c_double(thr), win_in, win_out)
