@@ -123,46 +123,64 @@ __global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *_
                                                                unsigned long long *__restrict__ stage /* [ntiles][GM_TILE] */,
                                                                int32_t *__restrict__ tile_cnt) {
     __shared__ unsigned sh[GM_TILE + CW + 8];   // sh[q] = hs of the k-mer starting at p0 - 1 + q
+    __shared__ short wm[GM_TILE + 8];           // wm[q] = index into sh of the minimizer of the window starting at p0 - 1 + q (-1: none)
     constexpr int PER = GM_TILE / 256;
     __shared__ int s_cnt[PER][4];               // emitted per round and wavefront
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t p0 = tile * GM_TILE;
+        // a tile and its halo nearly always lie inside ONE contig: its bounds are looked up once (every thread, the same
+        // cached words) instead of once per k-mer and once per window
+        const int64_t g_lo = p0 > 0 ? p0 - 1 : 0;
+        const int c0 = contig_of(coff, nc, g_lo);
+        const int64_t cb0 = coff[c0], ce0 = coff[c0 + 1];
+        const bool one = p0 + GM_TILE + CW + CK <= ce0;
         __syncthreads();
         for (int q = threadIdx.x; q < GM_TILE + CW + 1; q += 256) {
             const int64_t g = p0 - 1 + q;
             unsigned h = HS_INVALID;
-            if (g >= 0 && g < G) { const int c = contig_of(coff, nc, g); h = genome_hs(bases, nmask, g, coff[c + 1]); }
+            if (g >= 0 && g < G) h = genome_hs(bases, nmask, g, one ? ce0 : coff[contig_of(coff, nc, g) + 1]);
             sh[q] = h;
+        }
+        __syncthreads();
+        // the minimizer of every window that starts in the tile or one base before it (a window's predecessor decides whether it emits)
+        for (int q = threadIdx.x; q <= GM_TILE; q += 256) {
+            const int64_t g = p0 - 1 + q;
+            int m = -1;
+            if (g >= 0 && g < G) {
+                int64_t cb = cb0, ce = ce0;
+                if (!one) { const int c = contig_of(coff, nc, g); cb = coff[c]; ce = coff[c + 1]; }
+                const int64_t nk = ce - cb - CK + 1;
+                const int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
+                if (nk > 0 && g - cb < nwin) {
+                    const int lim = (int)((cb + nk - g) < CW ? (cb + nk - g) : CW);          // k-mers [g, min(g + W, cb + nk))
+                    unsigned h = 0;
+#pragma unroll
+                    for (int i = 0; i < CW; i++) {
+                        const unsigned v = sh[q + i];
+                        if (i < lim && v != HS_INVALID && (m < 0 || (v >> 1) < (h >> 1))) { m = q + i; h = v; }
+                    }
+                }
+            }
+            wm[q] = (short)m;
         }
         __syncthreads();
         unsigned hh[PER]; unsigned mm[PER];
         unsigned wantbits = 0;
 #pragma unroll
         for (int j = 0; j < PER; j++) {
-            const int o = j * 256 + threadIdx.x;          // window start p = p0 + o, its k-mers sit at sh[o + 1 ...]
+            const int o = j * 256 + threadIdx.x;          // window start p = p0 + o: wm[o + 1]; its predecessor: wm[o]
             const int64_t p = p0 + o;
             bool want = false; unsigned h = 0; int m = -1;
             if (p < G) {
-                const int c = contig_of(coff, nc, p);
-                const int64_t cb = coff[c], ce = coff[c + 1];
-                const int64_t nk = ce - cb - CK + 1;
-                const int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
-                if (nk > 0 && p - cb < nwin) {
-                    const int lim = (int)((cb + nk - p) < CW ? (cb + nk - p) : CW);          // k-mers [p, min(p + W, cb + nk))
-                    const int limp = (int)((cb + nk - (p - 1)) < CW ? (cb + nk - (p - 1)) : CW);
-                    int mprev = 0; unsigned hprev = 0; bool fprev = false;
-#pragma unroll
-                    for (int i = 0; i < CW; i++) {
-                        const unsigned v = sh[o + 1 + i];
-                        if (i < lim && v != HS_INVALID && (m < 0 || (v >> 1) < (h >> 1))) { m = i; h = v; }
-                        const unsigned u = sh[o + i];
-                        if (i < limp && u != HS_INVALID && (!fprev || (u >> 1) < (hprev >> 1))) { mprev = i - 1; hprev = u; fprev = true; }
-                    }
-                    want = m >= 0 && !(p > cb && fprev && mprev == m);
+                m = wm[o + 1];
+                if (m >= 0) {
+                    h = sh[m];
+                    const int64_t cb = one ? cb0 : coff[contig_of(coff, nc, p)];
+                    want = !(p > cb && wm[o] == m);       // (p > cb: the window before lies in the same contig; -1 never equals m)
                 }
             }
-            hh[j] = h; mm[j] = (unsigned)(p + m);
+            hh[j] = h; mm[j] = (unsigned)(p0 - 1 + m);
             const unsigned long long bal = __ballot(want);
             if (want) wantbits |= 1u << j;
             if (lane == 0) s_cnt[j][w] = __popcll(bal);
