@@ -356,6 +356,12 @@ class Context:
         self._check(self.lib.hite_tsd_kmer(self.h, n, _p(buf), _p(off), int(flank), int(plant), _p(rec), _p(cnt)), "hite_tsd_kmer")
         return [[tuple(int(x) for x in rec[i, j]) for j in range(max(cnt[i], 0))] for i in range(n)]
 
+    # ---- merge of the call records on a caller-owned RCCL communicator (no reference counterpart) ------------
+    def allgather_records(self, nccl_comm, d_send, d_recv, bytes_per_rank, stream=None):
+        """one ncclAllGather of bytes_per_rank bytes per rank (device pointers; nccl_comm = the caller's ncclComm_t as an int / c_void_p)"""
+        self._check(self.lib.hite_allgather_records(self.h, C.c_void_p(nccl_comm), C.c_void_p(d_send), C.c_void_p(d_recv), C.c_int64(bytes_per_rank),
+                                                    C.c_void_p(stream or 0)), "hite_allgather_records")
+
     # ---- terminal inverted repeats (run_itrsearch, Util.py:216: tools/itrsearch -i 0.7 -l 7) --------------------
     def itr_search(self, seqs, end_len=40, min_identity=0.7, min_len=7, match=10, mismatch=16, gap_open=32, gap_extend=32):
         """-> int32 [n, 8]: score, end1, end2, equal bases, aligned columns, found, "Length itr=", flags.  end_len > 0: the record

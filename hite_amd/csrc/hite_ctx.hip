@@ -479,3 +479,22 @@ extern "C" int hite_memcpy_d2h(void *dst, const void *d_src, int64_t bytes) {
     if (hipDeviceSynchronize() != hipSuccess) return HITE_EHIP;
     return hipMemcpy(dst, d_src, (size_t)bytes, hipMemcpyDeviceToHost) == hipSuccess ? HITE_OK : HITE_EHIP;
 }
+
+// ---------------------------------------------------------------------------------------------
+// merge of the call records between ranks: ONE all-gather on the caller's RCCL communicator (include/hite_gpu.h)
+// ---------------------------------------------------------------------------------------------
+#include <dlfcn.h>
+typedef int (*hite_nccl_allgather_fn)(const void *, void *, size_t, int /* ncclDataType_t */, void * /* ncclComm_t */, hipStream_t);
+extern "C" int hite_allgather_records(hite_ctx *ctx, void *nccl_comm, const void *d_send, void *d_recv, int64_t bytes_per_rank, void *stream) {
+    if (!ctx || !nccl_comm || !d_send || !d_recv || bytes_per_rank < 0) return HITE_EINVAL;
+    if (bytes_per_rank == 0) return HITE_OK;
+    static hite_nccl_allgather_fn fn = nullptr;
+    if (!fn) {
+        // the RCCL the process already carries -- the communicator came out of it; this library loads nothing by itself
+        fn = (hite_nccl_allgather_fn)dlsym(RTLD_DEFAULT, "ncclAllGather");
+        if (!fn) { snprintf(ctx->err, sizeof(ctx->err), "hite_allgather_records: no RCCL (ncclAllGather) in this process"); return HITE_ENODEV; }
+    }
+    const int rc = fn(d_send, d_recv, (size_t)bytes_per_rank, 0 /* ncclInt8 */, nccl_comm, (hipStream_t)stream);
+    if (rc != 0) { snprintf(ctx->err, sizeof(ctx->err), "hite_allgather_records: ncclAllGather returned %d", rc); return HITE_EHIP; }
+    return HITE_OK;
+}

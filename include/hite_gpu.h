@@ -433,6 +433,15 @@ int hite_event_record(void *ev, void *stream);
 int hite_event_elapsed_ms(void *ev_start, void *ev_stop, float *ms);
 int hite_event_destroy(void *ev);
 
+/* ---- merge of the boundary calls between the GPUs of a node -----------------------------------------------
+ * The reference has no counterpart (it collects results from a fork()ed process pool, Util.py:8141-8194).  One ncclAllGather
+ * (RCCL over xGMI) of `bytes_per_rank` bytes per rank -- the fixed 32-byte hite_call records of a rank's share, padded to the
+ * largest share -- on the communicator the CALLER owns (`nccl_comm` = its ncclComm_t), asynchronous on `stream`; d_recv holds
+ * world x bytes_per_rank bytes in rank order.  The library neither links nor loads RCCL: the symbol is taken from the RCCL already in
+ * the process (torch's, or the application's -- the communicator came out of it); HITE_ENODEV when there is none.  The Python driver's
+ * merge (hite_amd/dist.py) goes through torch.distributed, which keeps its communicator to itself; this entry is for a C / C++ host. */
+int hite_allgather_records(hite_ctx *ctx, void *nccl_comm, const void *d_send, void *d_recv, int64_t bytes_per_rank, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

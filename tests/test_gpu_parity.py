@@ -1687,3 +1687,38 @@ def test_low_copy_rescue_golden_on_gpu(ctx, tmp_path, monkeypatch):
     from hite_amd import util
 
     itr_cases.check_low_copy_rescue(util, ctx, tmp_path, monkeypatch)
+
+
+def test_allgather_records_on_a_callers_rccl_communicator(ctx):
+    """hite_allgather_records: ONE ncclAllGather on the communicator the caller owns.  Here the caller is this test: a
+    world-1 communicator made with RCCL's own C API (the RCCL torch carries, reached through ctypes), 50 000 call records"""
+    import ctypes as C
+
+    import torch
+
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    path = os.path.join(libdir, "librccl.so")
+    if not os.path.exists(path):
+        pytest.skip("no librccl.so beside torch")
+    rccl = C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        n = 50_000 * 32
+        send = torch.randint(0, 255, (n,), dtype=torch.uint8, device="cuda:0")
+        recv = torch.zeros(n, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.allgather_records(comm.value, send.data_ptr(), recv.data_ptr(), n)
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
