@@ -31,5 +31,7 @@ for db in dbs:
     for row in con.execute("select * from %s limit 60" % v[0]):
         print("  ".join(str(x)[:70] for x in row))
 PY
+# the raw rocprofv3 databases stay on the box: gpurun copies back at most 64 MiB
+rm -rf $OUT/prof_stats $OUT/prof_sq $OUT/prof_fetch $OUT/prof_write $OUT/cprof_stats $OUT/cprof_fetch $OUT/cprof_write
 cat $OUT/${TAG}_kernel_stats_coarse.txt | head -70
 tail -c 1500 $OUT/${TAG}_bench_coarse.json

@@ -12,7 +12,7 @@ timeout 900 python bench.py > $OUT/${TAG}_bench_fine.json 2> $OUT/${TAG}_bench_f
 timeout 600 python bench.py --config C2 > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
 timeout 900 python bench.py --config C5 --steps 3 --warmup 1 > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err
 timeout 600 python -m pytest tests/test_gpu_scale.py -q -m gpu -s -k "c2 or c3 or c5" > $OUT/${TAG}_scale_tests_raw.txt 2>&1
-grep -E "^(copy finder|fine stage|coarse stage|C3:|C5 merge)" $OUT/${TAG}_scale_tests_raw.txt > $OUT/${TAG}_scale_tests.txt
+grep -E "(copy finder|fine stage|coarse stage|C3:|C5 merge|cost sums)" $OUT/${TAG}_scale_tests_raw.txt | sed "s/^\.*//" > $OUT/${TAG}_scale_tests.txt
 timeout 600 python tools/copy_interval_modes.py >> $OUT/${TAG}_scale_tests.txt 2> $OUT/copy_interval_modes.err
 HITE_ALIGN_EXACT=16 timeout 600 python bench.py --no-cpu-baseline --no-coarse > $OUT/${TAG}_bench_fine_cap16.json 2> /dev/null
 HITE_ALIGN_EXACT=0 timeout 600 python bench.py --no-cpu-baseline --no-coarse > $OUT/${TAG}_bench_fine_cap0.json 2> /dev/null
@@ -38,5 +38,7 @@ for db in dbs:
     for row in con.execute("select * from %s limit 45" % v[0]):
         print("  ".join(str(x)[:70] for x in row))
 PY
+# the raw rocprofv3 databases stay on the box: gpurun copies back at most 64 MiB
+rm -rf $OUT/prof_stats $OUT/prof_sq $OUT/prof_fetch $OUT/prof_write $OUT/cprof_stats $OUT/cprof_fetch $OUT/cprof_write
 ls -la $OUT | tail -20
 tail -c 600 $OUT/${TAG}_bench_fine.json
