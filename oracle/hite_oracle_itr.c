@@ -36,7 +36,10 @@
  *
  * out[8 * k ..] = { score, end1, end2, matches, aligned, found, header_len (end1 - 1, -1 if no alignment), flags }
  * end_len > 0: the record is first end_len + last end_len bases of the sequence (Python `s[:e] + s[-e:]`, Util.py:6564, 6577),
- * composed here; end_len <= 0: the whole sequence (remove_no_tirs).  Bytes outside ACGT are N (getReverseSequence, Util.py:1635).
+ * composed here; end_len <= 0: the whole sequence (remove_no_tirs).  Bytes outside ACGT are N: the build folds IUPAC codes to N where the
+ * genome is packed (deviation i), so no other letter reaches this stage.  The tool itself compares the IUPAC
+ * letters K Y S B W R D M H V literally (complement table "TGCAKYSBWRDMHVNX" in its .rodata; only N is a wildcard, X never matches
+ * X) and aborts on any other letter: a record with such codes, which the reference would hand over unfolded, is outside the pin.
  */
 #include <stdint.h>
 #include <stdlib.h>
