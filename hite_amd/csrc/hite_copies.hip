@@ -5,8 +5,10 @@
 // (oracle/hite_oracle_copies.c, whose header holds the definition), record for record.
 //
 // Pipeline (sort / scan / segment, everything resident in HBM):
-//   index (once per genome): (w=10, k=15) minimizers straight from the 2-bit genome, one thread per
-//     window start, wave-aggregated append, radix sort by (hash|strand, position), 2^26-bucket directory;
+//   index (once per genome): (w=10, k=15) minimizers straight from the 2-bit genome, a workgroup per tile of 2048
+//     window starts, emitted IN POSITION ORDER (staging region per tile, scan of the tile counts, pack), ONE stable
+//     4-pass radix sort on hash|strand carrying every entry's rank along the genome, 2^26-bucket directory written
+//     from the sorted hashes (round 5; it was an append in arbitrary order + a 7-pass sort on (hash, position));
 //   query: candidate minimizers (wave per candidate, LDS tile of 64 windows, private regions + pack) -> directory
 //     lookup -> occurrence counts -> scan -> wave-cooperative hit expansion (key = candidate | relative strand |
 //     diagonal) -> radix sort (10-bit digits) -> cluster flags where the diagonal jumps -> extreme anchors per
