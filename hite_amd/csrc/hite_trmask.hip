@@ -123,9 +123,39 @@ __device__ __noinline__ void tr_seed_hit(const TrTile &T, int wl, int blk, uint3
     tr_extend(s, p, bases, nmask, coff, nc, trmask);
 }
 
+// one group of 16 periods (16 g .. 16 g + 15) of word wl: the periods JPAR, JPAR + JSTEP, ... of the group, all of them inside
+// the range (no bound tests: the shifts and the trip count are compile-time constants); TWO: both 8-blocks (periods below 32).
+// The seeds of the group are collected as bits and handled behind ONE branch: a test-and-branch per period cost as much as
+// the period's arithmetic.
+template <int JSTEP, int JPAR, bool TWO>
+__device__ __forceinline__ void tr_group_full(const TrTile &T, int wl, int g, uint32_t bw, uint32_t nw, int64_t w0, int64_t G,
+                                              const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                              const int64_t *__restrict__ coff, int nc, uint32_t *__restrict__ trmask) {
+    const int wi = wl + 1;
+    const uint32_t blo = T.b[wi + g], bhi = T.b[wi + g + 1], nlo = T.nx[wi + g], nhi = T.nx[wi + g + 1];
+    uint32_t hit0 = 0u, hit1 = 0u;
+#pragma unroll
+    for (int j = JPAR; j < 16; j += JSTEP) {
+        const uint32_t sb = j ? (blo >> (2 * j)) | (bhi << (32 - 2 * j)) : blo;
+        const uint32_t sn = j ? (nlo >> (2 * j)) | (nhi << (32 - 2 * j)) : nlo;
+        const uint32_t x = bw ^ sb;
+        const uint32_t bad = ((x | (x >> 1)) & 0x55555555u) | nw | sn;
+        hit0 |= (bad & 0x5555u) == 0u ? 1u << j : 0u;
+        if (TWO) hit1 |= (bad & 0x55550000u) == 0u ? 1u << j : 0u;
+    }
+    if ((hit0 | hit1) != 0u) {
+        for (int j = JPAR; j < 16; j += JSTEP) {
+            if (!(((hit0 | hit1) >> j) & 1u)) continue;
+            const int p = 16 * g + j;
+            const uint32_t bad = tr_bad(T, wi, p);
+            if ((hit0 >> j) & 1u) tr_seed_hit(T, wl, 0, bad, p, w0, G, bases, nmask, coff, nc, trmask);
+            if ((hit1 >> j) & 1u) tr_seed_hit(T, wl, 1, bad, p, w0, G, bases, nmask, coff, nc, trmask);
+        }
+    }
+}
 // the periods p_lo, p_lo + step, ... <= p_hi (step 1 or 2) of word wl of the tile: the word it is compared with slides along a
 // 64-bit window held in registers (one LDS read per array every 16 periods instead of four per period), the shifts inside a
-// group of 16 periods are compile-time constants
+// group of 16 periods are compile-time constants; whole groups run without a test per period, the ragged first / last group with
 __device__ __forceinline__ void tr_scan_word(const TrTile &T, int wl, int p_lo, int p_hi, int step, int64_t w0, int64_t G,
                                              const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
                                              const int64_t *__restrict__ coff, int nc, uint32_t *__restrict__ trmask) {
@@ -133,6 +163,16 @@ __device__ __forceinline__ void tr_scan_word(const TrTile &T, int wl, int p_lo, 
     const uint32_t bw = T.b[wi], nw = T.nx[wi];
     const int par = p_lo & 1;
     for (int g = p_lo >> 4; g <= (p_hi >> 4); g++) {
+        if (16 * g >= p_lo && 16 * g + 15 <= p_hi && (step == 1 || g >= 2)) {
+            if (step == 1) {
+                if (g < 2) tr_group_full<1, 0, true>(T, wl, g, bw, nw, w0, G, bases, nmask, coff, nc, trmask);
+                else tr_group_full<1, 0, false>(T, wl, g, bw, nw, w0, G, bases, nmask, coff, nc, trmask);
+            } else {        // (step 2 starts at period 64: one 8-block per period)
+                if (par) tr_group_full<2, 1, false>(T, wl, g, bw, nw, w0, G, bases, nmask, coff, nc, trmask);
+                else tr_group_full<2, 0, false>(T, wl, g, bw, nw, w0, G, bases, nmask, coff, nc, trmask);
+            }
+            continue;
+        }
         const uint32_t blo = T.b[wi + g], bhi = T.b[wi + g + 1], nlo = T.nx[wi + g], nhi = T.nx[wi + g + 1];
 #pragma unroll
         for (int j = 0; j < 16; j++) {
