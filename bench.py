@@ -696,6 +696,7 @@ def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
     super-linear in the genome, so the CPU's Mbp/s on 20 Mbp pieces flatters it against the 1 Gbp step)."""
     sc, so = ctx.seed_segments(1_000_000)
     prev = _prev_te_library(w, args.seed, max(1, int(0.5 * mbp))) if w is not None else []
+    prev_len = np.array([len(q) for q in prev], dtype=np.float64)
     genome_ptr, contig_off = (w["genome"].data_ptr(), w["contig_off"]) if w is not None else (None, None)
     stage_ms = {}
 
@@ -718,13 +719,11 @@ def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
         t0 = lap("tandem_mask", t0)
         n_masked_copies = 0
         if prev:
-            ctx.copy_index_build()          # the index of the tandem-masked chunk (rebuilt on the same handle: its arenas stay)
-            tab = ctx.find_copies(prev)
-            cc, ss, ee = [], [], []
-            for q, copies in zip(prev, tab):
-                for (c, s1, e1, _m, _a) in copies:
-                    if e1 - s1 + 1 >= 0.95 * len(q):
-                        cc.append(c); ss.append(s1); ee.append(e1)
+            # index of the tandem-masked chunk, for the library's look-ups only (as util._copies_as_blast6)
+            cf, ct, s1, e1, _mn, _an = ctx.find_copies_table(prev, restricted=True)
+            need = np.repeat(0.95 * prev_len, np.diff(cf))            # full-length copies: >= 95 % of the library sequence
+            keep = (e1 - s1 + 1) >= need
+            cc, ss, ee = ct[keep], s1[keep], e1[keep]
             ctx.genome_mask(cc, ss, ee)
             n_masked_copies = len(cc)
         t0 = lap("prev_te_mask", t0)

@@ -400,17 +400,18 @@ class Context:
     # ---- copy finding (stage where the reference calls minimap2, Util.py:7933) ---------------------------
     FIND_COPIES_BATCH = 1 << 18
 
-    def find_copies(self, cands):
-        """-> per candidate list of (contig, start1, end1, minus, anchors); needs genome_pack() first"""
+    def find_copies_table(self, cands, restricted=False):
+        """the copy table as arrays: (copy_first int32[n + 1], contig, start1, end1, minus, anchors) -- the copies of candidate c are
+        rows copy_first[c] .. copy_first[c + 1]; needs genome_pack() first; at most FIND_COPIES_BATCH candidates.
+        restricted=True: the caller uses the index of this genome for THIS candidate set only (the masking step of stage 3.1):
+        hite_find_copies_restricted builds the index from just the genome minimizers the candidates look up -- same table,
+        a fraction of the build; any later use of the handle rebuilds the full index by itself."""
         if getattr(self, "_copy_state", None) is None:
             self._copy_state = C.c_void_p(None)
         cb = [c.encode() if isinstance(c, str) else bytes(c) for c in cands]
-        if len(cb) > self.FIND_COPIES_BATCH:    # one device call handles < 2^19 candidates: larger libraries go in batches
-            out = []
-            for k in range(0, len(cb), self.FIND_COPIES_BATCH):
-                out += self.find_copies(cb[k:k + self.FIND_COPIES_BATCH])
-            return out
         n = len(cb)
+        if n > self.FIND_COPIES_BATCH:
+            raise ValueError("find_copies_table: %d candidates in one call (limit %d)" % (n, self.FIND_COPIES_BATCH))
         off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum([len(c) for c in cb], out=off[1:])
         buf = np.frombuffer(b"".join(cb) + b"\0" * 16, dtype=np.uint8)
@@ -422,9 +423,24 @@ class Context:
         mn = np.zeros(cap, dtype=np.uint8)
         an = np.zeros(cap, dtype=np.int32)
         nout = C.c_int64(0)
-        self._check(self.lib.hite_find_copies(self.h, C.byref(self._copy_state), n, _p(buf), _p(off), C.c_int64(cap), _p(cf), _p(ct),
-                                              _p(s1), _p(e1), _p(mn), _p(an), C.byref(nout)), "hite_find_copies")
-        return [[(int(ct[i]), int(s1[i]), int(e1[i]), int(mn[i]), int(an[i])) for i in range(cf[c], cf[c + 1])] for c in range(n)]
+        fn = self.lib.hite_find_copies_restricted if restricted else self.lib.hite_find_copies
+        self._check(fn(self.h, C.byref(self._copy_state), n, _p(buf), _p(off), C.c_int64(cap), _p(cf), _p(ct), _p(s1), _p(e1), _p(mn),
+                       _p(an), C.byref(nout)), "hite_find_copies_restricted" if restricted else "hite_find_copies")
+        k = int(cf[n])
+        return cf, ct[:k], s1[:k], e1[:k], mn[:k], an[:k]
+
+    def find_copies(self, cands, restricted=False):
+        """-> per candidate list of (contig, start1, end1, minus, anchors); needs genome_pack() first (restricted: see
+        find_copies_table)"""
+        if len(cands) > self.FIND_COPIES_BATCH:    # one device call handles < 2^19 candidates: larger libraries go in batches
+            out = []
+            for k in range(0, len(cands), self.FIND_COPIES_BATCH):     # (batches share one full index)
+                out += self.find_copies(cands[k:k + self.FIND_COPIES_BATCH])
+            return out
+        cf, ct, s1, e1, mn, an = self.find_copies_table(cands, restricted)
+        rows = list(zip(ct.tolist(), s1.tolist(), e1.tolist(), mn.tolist(), an.tolist()))
+        cf = cf.tolist()
+        return [rows[cf[c]:cf[c + 1]] for c in range(len(cands))]
 
     def copy_index_build(self, stream=0):
         if getattr(self, "_copy_state", None) is None:

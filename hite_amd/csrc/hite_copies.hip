@@ -40,6 +40,7 @@ struct CopyState {
     unsigned *idx_t = nullptr;   // rank of every index entry among the minimizers in position order (stage 3.1 walks the seeds in that order)
     const unsigned long long *idx_key = nullptr;   // the sorted (hash | strand) << 32 | position words themselves (in the build arena: valid until the next build)
     int64_t M = 0;
+    bool restricted = false;     // the index holds only the entries one candidate set looks up (hite_find_copies_restricted_dev): any other use rebuilds it
     int64_t idx_cap = 0;         // entries the index arrays hold (grow-only: rebuilding on the same handle allocates nothing)
     Arena build;      // temporaries of the index build
     Arena arena;      // temporaries of one call
@@ -108,6 +109,46 @@ __device__ __forceinline__ unsigned long long wave_append(bool want, unsigned lo
     return base + __popcll(m & ((1ull << lane) - 1ull));
 }
 
+// set of 31-bit hashes (hs >> 1) in an open-addressing table of 2^k words (empty = 0xffffffff, never a hash): the candidate side of a
+// RESTRICTED index build -- the genome pass keeps only the minimizers whose hash some candidate minimizer looks up
+struct HSet {
+    const unsigned *tab;     // open addressing, 2^k words
+    const unsigned *bits;    // one-hash Bloom filter in front of it, 2^b bits (~16 per member: small enough to stay in L2, it answers ~15/16 of the misses)
+    unsigned mask, bmask;
+};
+__device__ __forceinline__ unsigned hset_mix(unsigned h31) { return lowbias32(h31 ^ 0x9e3779b9u); }
+__device__ __forceinline__ unsigned hset_bit(const HSet &H, unsigned h31) { return (hset_mix(h31) >> 7) & H.bmask; }
+__device__ __forceinline__ bool hset_probe(const HSet &H, unsigned h31) {
+    unsigned slot = hset_mix(h31) & H.mask;
+    for (;;) {
+        const unsigned v = H.tab[slot];
+        if (v == h31) return true;
+        if (v == 0xffffffffu) return false;
+        slot = (slot + 1) & H.mask;
+    }
+}
+__global__ void hset_insert_kernel(int ncand, const int64_t *__restrict__ cand_off, const unsigned *__restrict__ r_hs,
+                                   const int32_t *__restrict__ q_cnt, unsigned *__restrict__ tab, unsigned mask,
+                                   unsigned *__restrict__ bits, unsigned bmask) {
+    const int lane = threadIdx.x & 63;
+    for (int c = blockIdx.x * 4 + (threadIdx.x >> 6); c < ncand; c += gridDim.x * 4) {
+        const int64_t src = cand_off[c];
+        const int cnt = q_cnt[c];
+        for (int i = lane; i < cnt; i += 64) {
+            const unsigned h31 = r_hs[src + i] >> 1;
+            const unsigned x = hset_mix(h31);
+            const unsigned b = (x >> 7) & bmask;
+            atomicOr(bits + (b >> 5), 1u << (b & 31));
+            unsigned slot = x & mask;
+            for (;;) {
+                const unsigned old = atomicCAS(tab + slot, 0xffffffffu, h31);
+                if (old == 0xffffffffu || old == h31) break;
+                slot = (slot + 1) & mask;
+            }
+        }
+    }
+}
+
 // genome minimizers IN POSITION ORDER.  key = hs << 32 | pos, value = rank of the minimizer along the genome (its slot).
 // One block per tile of GM_TILE window starts: the k-mer hashes the tile needs are computed once into LDS (each from its
 // own contig: a k-mer that crosses the contig end or touches an N is invalid), every thread then scans the windows of
@@ -120,10 +161,12 @@ __device__ __forceinline__ unsigned long long wave_append(bool want, unsigned lo
 // used to be a second 4-pass sort).  No append counter (the single atomic per tile on one was the arbitrary order; a chained
 // scan over the tiles inside the kernel measured 2x the kernel's time: its waiting tiles hold the CUs).
 #define GM_TILE 2048
+template <bool RS /* restricted to the hashes in hset */>
 __global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
                                                                const int64_t *__restrict__ coff, int nc, int64_t G, int64_t ntiles,
                                                                unsigned long long *__restrict__ stage /* [ntiles][GM_TILE] */,
-                                                               int32_t *__restrict__ tile_cnt) {
+                                                               int32_t *__restrict__ tile_cnt,
+                                                               HSet hset /* tab null: every minimizer */) {
     __shared__ unsigned sh[GM_TILE + CW + 8];   // sh[q] = hs of the k-mer starting at p0 - 1 + q
     __shared__ short wm[GM_TILE + 8];           // wm[q] = index into sh of the minimizer of the window starting at p0 - 1 + q (-1: none)
     constexpr int PER = GM_TILE / 256;
@@ -183,9 +226,24 @@ __global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *_
                 }
             }
             hh[j] = h; mm[j] = (unsigned)(p0 - 1 + m);
-            const unsigned long long bal = __ballot(want);
             if (want) wantbits |= 1u << j;
-            if (lane == 0) s_cnt[j][w] = __popcll(bal);
+            if constexpr (!RS) {
+                const unsigned long long bal = __ballot(want);
+                if (lane == 0) s_cnt[j][w] = __popcll(bal);
+            }
+        }
+        if constexpr (RS) {      // restricted index: only the hashes in the set.  The filter words of all rounds are fetched before any is tested
+            unsigned fw[PER];
+#pragma unroll
+            for (int j = 0; j < PER; j++) fw[j] = ((wantbits >> j) & 1u) ? hset.bits[hset_bit(hset, hh[j] >> 1) >> 5] : 0u;
+#pragma unroll
+            for (int j = 0; j < PER; j++)
+                if (((wantbits >> j) & 1u) && !(((fw[j] >> (hset_bit(hset, hh[j] >> 1) & 31)) & 1u) && hset_probe(hset, hh[j] >> 1))) wantbits &= ~(1u << j);
+#pragma unroll
+            for (int j = 0; j < PER; j++) {
+                const unsigned long long bal = __ballot((wantbits >> j) & 1u);
+                if (lane == 0) s_cnt[j][w] = __popcll(bal);
+            }
         }
         __syncthreads();
         unsigned long long *reg = stage + tile * GM_TILE;
@@ -878,12 +936,7 @@ struct DevTmp {
     }
 };
 
-extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream) {
-    if (!ctx || !ctx->d_bases || !state_io) return HITE_EINVAL;
-    if (ctx->n_bases >= 0xfffe0000ll) return HITE_EINVAL;  // positions are 32-bit
-    hipStream_t st = (hipStream_t)stream;
-    HITE_CHECK(ctx, hipSetDevice(ctx->device));
-    // rebuilding on an existing handle (next genome / chunk) keeps its arenas: their growth is the expensive part of a cold call
+static int copy_state_get(hite_ctx *ctx, void **state_io, CopyState **out) {
     CopyState *S = (CopyState *)*state_io;
     if (!S) {
         S = new CopyState();
@@ -891,7 +944,20 @@ extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *strea
         HITE_CHECK(ctx, hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)));
         HITE_CHECK(ctx, hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)));
     }
+    *out = S;
+    return HITE_OK;
+}
+
+// the index of the packed genome; hset != null: only the minimizers whose hash is in the set (a restricted index)
+static int index_build_impl(hite_ctx *ctx, void **state_io, hipStream_t st, HSet hset) {
+    if (!ctx || !ctx->d_bases || !state_io) return HITE_EINVAL;
+    if (ctx->n_bases >= 0xfffe0000ll) return HITE_EINVAL;  // positions are 32-bit
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    // rebuilding on an existing handle (next genome / chunk) keeps its arenas: their growth is the expensive part of a cold call
+    CopyState *S;
+    CCHK(copy_state_get(ctx, state_io, &S));
     S->M = 0;
+    S->restricted = hset.tab != nullptr;
     const int64_t G = ctx->n_bases;
     const unsigned long long cap = (unsigned long long)(G * 0.32) + 4096;
     if ((int64_t)cap > S->idx_cap) {      // the index arrays: grow-only, shared by every genome packed behind this handle
@@ -921,8 +987,12 @@ extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *strea
     int64_t blocks = ntiles < 256 * 64 ? ntiles : 256 * 64;
     if (blocks < 1) blocks = 1;
     int tk_gm = hite_prof_begin(ctx, "index_minimizers", st);
-    hipLaunchKernelGGL(genome_minimizer_kernel, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
-                       ctx->n_contigs, G, ntiles, stage, tile_cnt);
+    if (hset.tab)
+        hipLaunchKernelGGL(genome_minimizer_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
+                           ctx->n_contigs, G, ntiles, stage, tile_cnt, hset);
+    else
+        hipLaunchKernelGGL(genome_minimizer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
+                           ctx->n_contigs, G, ntiles, stage, tile_cnt, hset);
     int64_t M = 0;
     if (ntiles > 0) {
         CCHK(scan_excl_buf<int32_t>(ctx, tbs, tile_cnt, ntiles, tile_first, st));
@@ -957,14 +1027,23 @@ extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *strea
     return HITE_OK;
 }
 
+extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream) {
+    return index_build_impl(ctx, state_io, (hipStream_t)stream, HSet{nullptr, nullptr, 0, 0});
+}
+
 // candidates (device) -> copy table (device arrays owned by the index state's arena; valid until the next call)
-extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8_t *d_cand, const int64_t *d_cand_off,
-                                    int64_t cand_bytes, int32_t **d_copy_first, int64_t *n_copies, int32_t **d_contig,
-                                    int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus, int32_t **d_anchors, void *stream) {
+static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const uint8_t *d_cand, const int64_t *d_cand_off,
+                            int64_t cand_bytes, int32_t **d_copy_first, int64_t *n_copies, int32_t **d_contig,
+                            int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus, int32_t **d_anchors, void *stream,
+                            bool restricted_ok /* the index was restricted to THESE candidates by the caller */) {
     CopyState *S = (CopyState *)state;
     if (!ctx || !S || !ctx->d_bases || n_cand < 0 || n_cand >= (1 << 19) || !n_copies) return HITE_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    if (S->restricted && !restricted_ok) {     // an index restricted to another candidate set answers nothing else: the full one
+        void *sp = S;
+        CCHK(index_build_impl(ctx, &sp, st, HSet{nullptr, nullptr, 0, 0}));
+    }
     CCHK(arena_reset(ctx, S->arena, true));
     CCHK(arena_reset(ctx, S->out, true));
     Arena &A = S->arena;
@@ -1215,12 +1294,76 @@ extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, 
 }
 
 // host-buffer wrapper: builds the index if *state_io is NULL, uploads the candidates, downloads the table
-extern "C" int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
-                                int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
-                                int32_t *anchors, int64_t *n_out) {
+extern "C" int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8_t *d_cand, const int64_t *d_cand_off,
+                                    int64_t cand_bytes, int32_t **d_copy_first, int64_t *n_copies, int32_t **d_contig,
+                                    int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus, int32_t **d_anchors, void *stream) {
+    return find_copies_impl(ctx, state, n_cand, d_cand, d_cand_off, cand_bytes, d_copy_first, n_copies, d_contig, d_start1, d_end1, d_minus,
+                            d_anchors, stream, false);
+}
+
+// hite_find_copies_dev for a caller that needs the index for THESE candidates only (masking the genome with a TE library before
+// the index proper is built on the masked genome: stage 3.1).  The genome pass keeps just the minimizers whose hash one of the
+// candidates' minimizers looks up -- every entry occ_kernel / hit_kernel would read, with the same run lengths (so the C_MAXOCC
+// rule sees the same counts) and in the same order -- and the hash sort and the directory run on those few entries instead of
+// ~0.18 G of them.  The copy table is identical to the full index's; the handle is left flagged `restricted`, and every other
+// use of it (hite_find_copies[_dev], hite_seed_allvsall[_dev]) rebuilds the full index first.
+extern "C" int hite_find_copies_restricted_dev(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *d_cand,
+                                               const int64_t *d_cand_off, int64_t cand_bytes, int32_t **d_copy_first, int64_t *n_copies,
+                                               int32_t **d_contig, int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus,
+                                               int32_t **d_anchors, void *stream) {
+    if (!ctx || !ctx->d_bases || !state_io || n_cand < 0 || n_cand >= (1 << 19) || !n_copies) return HITE_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    CopyState *S;
+    CCHK(copy_state_get(ctx, state_io, &S));
+    CCHK(arena_reset(ctx, S->arena, true));
+    Arena &A = S->arena;
+    void *p;
+    unsigned *tab = nullptr, *bits = nullptr; unsigned mask = 1023, bmask = 65535;
+    const int64_t cb = cand_bytes > 0 ? cand_bytes : 0;
+    int tk = hite_prof_begin(ctx, "restricted_set", st);
+    if (n_cand > 0 && cb > 0) {
+        int32_t *q_cnt; unsigned *r_pos, *r_hs; int64_t *q_first, *qbs;
+        CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); q_cnt = (int32_t *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); q_first = (int64_t *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(n_cand) * 8, &p)); qbs = (int64_t *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(cb + 64) * 4, &p)); r_pos = (unsigned *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(cb + 64) * 4, &p)); r_hs = (unsigned *)p;
+        HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
+        hipLaunchKernelGGL(cand_minimizer_kernel, dim3(n_cand < 65536 ? n_cand : 65536), dim3(256), 0, st, n_cand, d_cand, d_cand_off, r_pos,
+                           r_hs, q_cnt, (unsigned long long *)(S->d_scal + 1));
+        CCHK(scan_excl_buf<int32_t>(ctx, qbs, q_cnt, n_cand, q_first, st));
+        HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, q_first + n_cand, 8, hipMemcpyDeviceToDevice, st));
+        CCHK(read_back(ctx, S, st, 1));
+        const int64_t nq = S->h_pin[0];
+        while ((int64_t)mask + 1 < 4 * nq && mask < 0x7fffffffu) mask = mask * 2 + 1;     // load <= 1/4
+        if ((int64_t)mask + 1 < 2 * nq) return HITE_ECAP;
+        while ((int64_t)bmask + 1 < 16 * nq && bmask < 0x00ffffffu) bmask = bmask * 2 + 1;     // <= 2 MiB
+        CCHK(arena_alloc(ctx, A, ((size_t)mask + 1) * 4, &p)); tab = (unsigned *)p;
+        CCHK(arena_alloc(ctx, A, ((size_t)bmask + 1) / 8, &p)); bits = (unsigned *)p;
+        HITE_CHECK(ctx, hipMemsetAsync(tab, 0xff, ((size_t)mask + 1) * 4, st));
+        HITE_CHECK(ctx, hipMemsetAsync(bits, 0, ((size_t)bmask + 1) / 8, st));
+        hipLaunchKernelGGL(hset_insert_kernel, dim3((n_cand + 3) / 4 < 8192 ? (n_cand + 3) / 4 : 8192), dim3(256), 0, st, n_cand, d_cand_off,
+                           r_hs, q_cnt, tab, mask, bits, bmask);
+        HITE_CHECK(ctx, hipGetLastError());
+    } else {
+        CCHK(arena_alloc(ctx, A, ((size_t)mask + 1) * 4, &p)); tab = (unsigned *)p;
+        CCHK(arena_alloc(ctx, A, ((size_t)bmask + 1) / 8, &p)); bits = (unsigned *)p;
+        HITE_CHECK(ctx, hipMemsetAsync(tab, 0xff, ((size_t)mask + 1) * 4, st));
+        HITE_CHECK(ctx, hipMemsetAsync(bits, 0, ((size_t)bmask + 1) / 8, st));
+    }
+    hite_prof_end(ctx, tk, st);
+    CCHK(index_build_impl(ctx, state_io, st, HSet{tab, bits, mask, bmask}));     // (its own arena; ends with a stream synchronise: `tab` is free to go)
+    return find_copies_impl(ctx, *state_io, n_cand, d_cand, d_cand_off, cand_bytes, d_copy_first, n_copies, d_contig, d_start1, d_end1,
+                            d_minus, d_anchors, stream, true);
+}
+
+static int find_copies_host(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
+                            int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
+                            int32_t *anchors, int64_t *n_out, bool restricted) {
     if (!ctx || !state_io || !cand || !cand_off || !copy_first || !n_out) return HITE_EINVAL;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
-    if (!*state_io) CCHK(hite_copy_index_build(ctx, state_io, nullptr));
+    if (!*state_io && !restricted) CCHK(hite_copy_index_build(ctx, state_io, nullptr));
     uint8_t *dc = nullptr;
     int64_t *dco = nullptr;
     int64_t bytes = cand_off[n_cand];
@@ -1233,7 +1376,8 @@ extern "C" int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, 
     int64_t *ds1, *de1;
     uint8_t *dmn;
     int64_t n = 0;
-    int rc = hite_find_copies_dev(ctx, *state_io, n_cand, dc, dco, bytes, &dcf, &n, &dct, &ds1, &de1, &dmn, &dan, nullptr);
+    int rc = restricted ? hite_find_copies_restricted_dev(ctx, state_io, n_cand, dc, dco, bytes, &dcf, &n, &dct, &ds1, &de1, &dmn, &dan, nullptr)
+                        : hite_find_copies_dev(ctx, *state_io, n_cand, dc, dco, bytes, &dcf, &n, &dct, &ds1, &de1, &dmn, &dan, nullptr);
     if (rc == HITE_OK) {
         *n_out = n;
         if (hipDeviceSynchronize() != hipSuccess) rc = HITE_EHIP;
@@ -1254,6 +1398,16 @@ extern "C" int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, 
 }
 
 // sizes of the last hite_find_copies[_dev] call on this index: {candidate minimizers, index hits, diagonal clusters, copies before the cap}
+extern "C" int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
+                                int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
+                                int32_t *anchors, int64_t *n_out) {
+    return find_copies_host(ctx, state_io, n_cand, cand, cand_off, cap, copy_first, contig, start1, end1, minus, anchors, n_out, false);
+}
+extern "C" int hite_find_copies_restricted(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
+                                           int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1,
+                                           uint8_t *minus, int32_t *anchors, int64_t *n_out) {
+    return find_copies_host(ctx, state_io, n_cand, cand, cand_off, cap, copy_first, contig, start1, end1, minus, anchors, n_out, true);
+}
 extern "C" int hite_copy_stats(void *state, int64_t out[4]) {
     CopyState *S = (CopyState *)state;
     if (!S || !out) return HITE_EINVAL;
@@ -1633,7 +1787,7 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     if (!ctx || !ctx->d_bases || !state_io || seg_len <= 0 || !n_out) return HITE_EINVAL;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
     hipStream_t st = nullptr;
-    if (!*state_io) CCHK(hite_copy_index_build(ctx, state_io, nullptr));
+    if (!*state_io || ((CopyState *)*state_io)->restricted) CCHK(hite_copy_index_build(ctx, state_io, nullptr));   // seeding walks EVERY minimizer
     CopyState *S = (CopyState *)*state_io;
     *n_out = 0;
     const int64_t M = S->M, G = ctx->n_bases;

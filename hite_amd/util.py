@@ -709,7 +709,8 @@ def _copies_as_blast6(chr_path, query_path, out_path, device=0):
     ctx.genome_pack([contigs[n].upper() for n in names])
     ctx.release_copy_index()
     _PACKED["path"] = None
-    tab = ctx.find_copies([queries[q].upper() for q in qnames]) if qnames and names else []
+    # (the index of this chunk serves this one query set -- the caller masks the chunk next: built for these queries only)
+    tab = ctx.find_copies([queries[q].upper() for q in qnames], restricted=True) if qnames and names else []
     with open(out_path, "w") as f:
         for q, copies in zip(qnames, tab):
             L = len(queries[q])

@@ -330,6 +330,20 @@ int hite_find_copies(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8
 int hite_find_copies_dev(hite_ctx *ctx, void *state, int32_t n_cand, const uint8_t *d_cand, const int64_t *d_cand_off,
                          int64_t cand_bytes, int32_t **d_copy_first, int64_t *n_copies, int32_t **d_contig,
                          int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus, int32_t **d_anchors, void *stream);
+/* hite_find_copies_dev for ONE candidate set on a genome whose index nothing else will use (stage 3.1 masks the genome with the
+ * previous TE library -- Util.py:6021-6081 `mask_genome_intactTE`, the reference's blastn of the library against the chunk -- and only then
+ * indexes the MASKED genome): the index is built for these candidates only -- the genome pass keeps the minimizers whose hash one of
+ * their minimizers looks up, so the hash sort and the directory run on those few entries.  Every entry the look-up would read is
+ * there, with the same run lengths and order: the copy table equals hite_find_copies_dev's on the full index (tests assert it).
+ * *state_io as for hite_find_copies (created when null); the handle is left flagged restricted, and hite_find_copies[_dev] /
+ * hite_seed_allvsall[_dev] rebuild the full index before they use it.  Same _dev PRECONDITION. */
+int hite_find_copies_restricted_dev(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *d_cand, const int64_t *d_cand_off,
+                                    int64_t cand_bytes, int32_t **d_copy_first, int64_t *n_copies, int32_t **d_contig,
+                                    int64_t **d_start1, int64_t **d_end1, uint8_t **d_minus, int32_t **d_anchors, void *stream);
+/* host-buffer form (arguments as hite_find_copies) */
+int hite_find_copies_restricted(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
+                                int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
+                                int32_t *anchors, int64_t *n_out);
 
 /* ---- star alignment: this build's GPU-native stage where the reference runs the external
  * `mafft --preservecase --quiet --thread 1` (Util.py:10416; third-party, unpinned, absent -> parity unpinned against

@@ -510,6 +510,37 @@ def test_find_copies_vs_twin(ctx):
         assert [r[0], r[1], r[2], r[3]] == OP.fine_stage_candidate("tir", cand, cp, g["contigs"], plant=1)
 
 
+def test_find_copies_restricted_index(ctx):
+    """hite_find_copies_restricted (index built from the genome minimizers the candidates look up, stage 3.1's masking step):
+    the same copy table as the full index and the twin, on a fresh handle and on a reused one; every other use of the handle
+    afterwards (another candidate set, all-vs-all seeding) sees the full index again."""
+    import synth_small
+
+    for seed, nf in ((11, 16), (23, 24)):
+        g = synth_small.make(seed, n_fam=nf)
+        ctx.genome_pack(g["contigs"])
+        ctx.release_copy_index()
+        cands = list(g["cands"]) + ["ACGT" * 3, "A" * 40, g["contigs"][0][5000:5400]]
+        exp = O.find_copies(g["contigs"], cands)
+        got = ctx.find_copies(cands, restricted=True)           # fresh handle: no full index was ever built
+        st = ctx.copy_stats()
+        assert got == exp
+        assert st[0] > 0
+        half = cands[: len(cands) // 2]
+        assert ctx.find_copies(half, restricted=True) == exp[: len(half)]      # same handle, other set: rebuilt for it
+        other = [g["contigs"][-1][3000:3600]] + cands[::-1]
+        assert ctx.find_copies(other) == O.find_copies(g["contigs"], other)     # plain call after a restricted one: full index
+        full = ctx.seed_allvsall(seg_len=1_000_000)
+        ctx.find_copies(cands[:3], restricted=True)
+        again = ctx.seed_allvsall(seg_len=1_000_000)                            # seeding after a restricted build: full index
+        for k in ("qseg", "sseg", "qs", "qe", "ss", "se"):
+            assert np.array_equal(full[k], again[k])
+        assert list(full["stats"]) == list(again["stats"]) and full["stats"][0] > 0
+    # nothing to look up: empty set, candidates without a valid k-mer
+    assert ctx.find_copies([], restricted=True) == []
+    assert ctx.find_copies(["ACGT", "N" * 100], restricted=True) == [[], []]
+
+
 def test_find_copies_aligned_interval_mode(ctx):
     """hite_copy_config(1): the records carry the ALIGNED interval, reference_start + 1 .. reference_end as
     get_copies_minimap2 reports it (Util.py:8026), instead of the interval of the whole candidate (the default; DESIGN.md
