@@ -63,23 +63,23 @@ static uint32_t lowbias32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-static uint32_t rev2_30(uint32_t x) { /* reverse the order of the 15 2-bit groups of a 30-bit value */
+static uint32_t rev2_k(uint32_t x, int K) { /* reverse the order of the K 2-bit groups of a 2K-bit value */
     uint32_t y = 0;
-    for (int i = 0; i < 15; i++) y |= ((x >> (2 * i)) & 3u) << (2 * (14 - i));
+    for (int i = 0; i < K; i++) y |= ((x >> (2 * i)) & 3u) << (2 * (K - 1 - i));
     return y;
 }
 static int code_of(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : -1; }
 
-/* hs of the k-mer starting at p of seq[0..L) */
-static uint32_t kmer_hs(const uint8_t *seq, int64_t L, int64_t p) {
-    if (p < 0 || p + CK > L) return HS_INVALID;
+/* hs of the K-mer starting at p of seq[0..L) */
+static uint32_t kmer_hs(const uint8_t *seq, int64_t L, int64_t p, int K) {
+    if (p < 0 || p + K > L) return HS_INVALID;
     uint32_t x = 0;
-    for (int i = 0; i < CK; i++) {
+    for (int i = 0; i < K; i++) {
         int c = code_of(seq[p + i]);
         if (c < 0) return HS_INVALID;
         x |= (uint32_t)c << (2 * i);
     }
-    uint32_t rc = rev2_30(x ^ 0x3fffffffu);
+    uint32_t rc = rev2_k(x ^ ((1u << (2 * K)) - 1u), K);
     uint32_t can = x < rc ? x : rc;
     uint32_t strand = rc < x ? 1u : 0u;
     uint32_t hs = (lowbias32(can) & ~1u) | strand;
@@ -89,16 +89,16 @@ static uint32_t kmer_hs(const uint8_t *seq, int64_t L, int64_t p) {
 
 typedef struct { uint32_t hs; int64_t pos; } mini_t;
 
-/* minimizers of seq[0..L); pos offset added; returns count (out may be NULL to count) */
-static int64_t minimizers(const uint8_t *seq, int64_t L, int64_t pos_off, mini_t *out) {
-    int64_t nk = L - CK + 1;
+/* (W, K) minimizers of seq[0..L); pos offset added; returns count (out may be NULL to count) */
+static int64_t minimizers_kw(const uint8_t *seq, int64_t L, int64_t pos_off, mini_t *out, int K, int W) {
+    int64_t nk = L - K + 1;
     if (nk <= 0) return 0;
     uint32_t *hs = (uint32_t *)malloc(sizeof(uint32_t) * nk);
-    for (int64_t p = 0; p < nk; p++) hs[p] = kmer_hs(seq, L, p);
-    int64_t nwin = nk >= CW ? nk - CW + 1 : 1;
+    for (int64_t p = 0; p < nk; p++) hs[p] = kmer_hs(seq, L, p, K);
+    int64_t nwin = nk >= W ? nk - W + 1 : 1;
     int64_t n = 0, last = -1;
     for (int64_t p = 0; p < nwin; p++) {
-        int64_t hi = p + CW < nk ? p + CW : nk;
+        int64_t hi = p + W < nk ? p + W : nk;
         int64_t best = -1;
         for (int64_t i = p; i < hi; i++) {
             if (hs[i] == HS_INVALID) continue;
@@ -113,6 +113,7 @@ static int64_t minimizers(const uint8_t *seq, int64_t L, int64_t pos_off, mini_t
     free(hs);
     return n;
 }
+static int64_t minimizers(const uint8_t *seq, int64_t L, int64_t pos_off, mini_t *out) { return minimizers_kw(seq, L, pos_off, out, CK, CW); }
 
 static int cmp_mini(const void *a, const void *b) {
     const mini_t *x = (const mini_t *)a, *y = (const mini_t *)b;
@@ -129,11 +130,11 @@ static int cmp_mini(const void *a, const void *b) {
 #define SUB_EDGE 256
 #define SUB_UNIT 1024
 #define SUB_MAX 4
-static int cand_minimizer_kept(int64_t Lq, int64_t pos, uint32_t hs) {
+static int cand_minimizer_kept(int64_t Lq, int64_t pos, uint32_t hs, int K) {
     int64_t S = Lq / SUB_UNIT;
     if (S > SUB_MAX) S = SUB_MAX;
     if (S <= 1) return 1;
-    if (pos < SUB_EDGE || pos + CK > Lq - SUB_EDGE) return 1;
+    if (pos < SUB_EDGE || pos + K > Lq - SUB_EDGE) return 1;
     return ((hs >> 1) % (uint32_t)S) == 0;
 }
 
@@ -244,37 +245,39 @@ void orc_find_copies_config(int aligned_interval) { g_aligned_interval = aligned
 static double g_index_seconds = 0.0;
 double orc_find_copies_index_seconds(void) { return g_index_seconds; }
 
-int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int ncontig, const uint8_t *cand,
-                        const int64_t *cand_off, int ncand, int64_t cap, int32_t *copy_first, int32_t *contig,
-                        int64_t *start1, int64_t *end1, uint8_t *minus, int32_t *anchors) {
-    if (ncontig <= 0 || ncand < 0) return ORC_EINVAL;
+/* one search of the candidates `sel[0..nsel)` (NULL: all) in the (W, K) minimizer index of the genome -> the chains kept, sorted by
+ * (candidate, anchors descending, start, strand); *index_s += seconds spent building the index */
+static copy_t *find_pass(const uint8_t *genome, const int64_t *contig_off, int ncontig, const uint8_t *cand, const int64_t *cand_off,
+                         int ncand, const int32_t *sel, int nsel, int K, int W, int64_t *ncp_out, double *index_s) {
     /* index */
     struct timespec t0;
     clock_gettime(CLOCK_MONOTONIC, &t0);
     int64_t M = 0;
-    for (int c = 0; c < ncontig; c++) M += minimizers(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], NULL);
+    for (int c = 0; c < ncontig; c++) M += minimizers_kw(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], NULL, K, W);
     mini_t *idx = (mini_t *)malloc(sizeof(mini_t) * (M + 1));
     int64_t k = 0;
-    for (int c = 0; c < ncontig; c++) k += minimizers(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], idx + k);
+    for (int c = 0; c < ncontig; c++) k += minimizers_kw(genome + contig_off[c], contig_off[c + 1] - contig_off[c], contig_off[c], idx + k, K, W);
     qsort(idx, M, sizeof(mini_t), cmp_mini);
     {
         struct timespec t1;
         clock_gettime(CLOCK_MONOTONIC, &t1);
-        g_index_seconds = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+        *index_s += (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
     }
     /* hits */
     int64_t hcap = 1 << 16, nh = 0;
     hit_t *hits = (hit_t *)malloc(sizeof(hit_t) * hcap);
-    for (int c = 0; c < ncand; c++) {
+    const int ntodo = sel ? nsel : ncand;
+    for (int ci = 0; ci < ntodo; ci++) {
+        const int c = sel ? sel[ci] : ci;
         const uint8_t *q = cand + cand_off[c];
         int64_t Lq = cand_off[c + 1] - cand_off[c];
-        int64_t nm = minimizers(q, Lq, 0, NULL);
+        int64_t nm = minimizers_kw(q, Lq, 0, NULL, K, W);
         if (nm <= 0) continue;
         mini_t *qm = (mini_t *)malloc(sizeof(mini_t) * nm);
-        minimizers(q, Lq, 0, qm);
+        minimizers_kw(q, Lq, 0, qm, K, W);
         for (int64_t t = 0; t < nm; t++) {
             uint32_t h31 = qm[t].hs >> 1;
-            if (!cand_minimizer_kept(Lq, qm[t].pos, qm[t].hs)) continue;
+            if (!cand_minimizer_kept(Lq, qm[t].pos, qm[t].hs, K)) continue;
             /* lower bound of hs >= h31 << 1 */
             int64_t lo = 0, hi = M;
             while (lo < hi) { int64_t mid = (lo + hi) / 2; if ((idx[mid].hs >> 1) < h31) lo = mid + 1; else hi = mid; }
@@ -284,7 +287,7 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
             for (int64_t i = lo; i < e; i++) {
                 if (nh == hcap) { hcap *= 2; hits = (hit_t *)realloc(hits, sizeof(hit_t) * hcap); }
                 int rel = (int)((qm[t].hs ^ idx[i].hs) & 1u);
-                int64_t qo = rel ? (Lq - qm[t].pos - CK) : qm[t].pos;
+                int64_t qo = rel ? (Lq - qm[t].pos - K) : qm[t].pos;
                 hits[nh].c = c; hits[nh].rel = rel; hits[nh].qo = (int32_t)qo; hits[nh].gpos = idx[i].pos;
                 hits[nh].d = idx[i].pos - qo;
                 nh++;
@@ -314,23 +317,23 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
          * query span is >= 95 % of its genome span is extended base by base from its outermost anchors to both ends of the
          * candidate (ext_align); what the extension cuts off is clipped, as minimap2 soft-clips it.  aligned = Lq - clipped;
          * the copy is the genome interval of the aligned part, kept when aligned >= 95 % of Lq and aligned >= 95 % of that interval. */
-        if (na >= MINANCH && (qhi + CK - qlo) * 100 >= 95 * (ghi + CK - glo) && qlo <= EXT_MAXLEN && Lq - (qhi + CK) <= EXT_MAXLEN) {
+        if (na >= MINANCH && (qhi + K - qlo) * 100 >= 95 * (ghi + K - glo) && qlo <= EXT_MAXLEN && Lq - (qhi + K) <= EXT_MAXLEN) {
             int64_t cb = contig_off[ctg], ce = contig_off[ctg + 1];
             const uint8_t *q = cand + cand_off[hits[i].c];
             int rel = hits[i].rel;
-            int64_t nl = qlo, nr = Lq - (qhi + CK);
+            int64_t nl = qlo, nr = Lq - (qhi + K);
             uint8_t *seg = (uint8_t *)malloc((size_t)(nl > nr ? nl : nr) + 1);
             /* query in the orientation of the genome: rel = 1 reads the reverse complement of the candidate */
 #define QAT(x) (rel ? comp_of(q[Lq - 1 - (x)]) : q[(x)])
             for (int64_t x = 0; x < nl; x++) seg[x] = QAT(qlo - 1 - x);
             int64_t tl = 0, tr = 0;
             int64_t il = ext_align(seg, nl, -1, genome, glo, cb, ce, &tl);
-            for (int64_t x = 0; x < nr; x++) seg[x] = QAT(qhi + CK + x);
-            int64_t ir = ext_align(seg, nr, +1, genome, ghi + CK, cb, ce, &tr);
+            for (int64_t x = 0; x < nr; x++) seg[x] = QAT(qhi + K + x);
+            int64_t ir = ext_align(seg, nr, +1, genome, ghi + K, cb, ce, &tr);
             free(seg);
             int64_t clip_l = nl - il, clip_r = nr - ir;
             int64_t aligned = Lq - clip_l - clip_r;
-            int64_t a0 = glo - tl, a1 = ghi + CK + tr;                 /* genome interval of the aligned part */
+            int64_t a0 = glo - tl, a1 = ghi + K + tr;                 /* genome interval of the aligned part */
             if (a1 > a0 && aligned * 100 >= 95 * Lq && aligned * 100 >= 95 * (a1 - a0)) {
                 /* the interval handed on covers the whole candidate: the clipped ends (<= 5 % of it) lie on the diagonal of the last
                  * aligned base, clamped to the contig */
@@ -346,15 +349,67 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
         i = j;
     }
     qsort(cps, ncp, sizeof(copy_t), cmp_copy);
+    free(idx); free(hits);
+    *ncp_out = ncp;
+    return cps;
+}
+
+/* The far pass (where minimap2 keeps secondary chains of any divergence its -N 300 -p 0.2 admits, Util.py:7952-7961): a (10, 15)
+ * minimizer survives a pair divergence d with (1 - d)^15 -- 2 % at d = 0.225 --, so copies 20-30 % from the candidate are found at
+ * 0.66 / 0.37 (tools/copy_recall_by_divergence.py).  Candidates that come out of the first search with FEWER THAN far_min copies are
+ * searched a second time in a (FAR_W, FAR_K) = (8, 13) index of the same genome, same rules; the second table REPLACES the
+ * candidate's first when it holds more copies (else the first stands).  far_min = 0: no far pass. */
+#define FAR_K 13
+#define FAR_W 8
+static int g_far_min = 0;
+void orc_find_copies_far(int min_copies) { g_far_min = min_copies > 0 ? min_copies : 0; }
+
+int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int ncontig, const uint8_t *cand,
+                        const int64_t *cand_off, int ncand, int64_t cap, int32_t *copy_first, int32_t *contig,
+                        int64_t *start1, int64_t *end1, uint8_t *minus, int32_t *anchors) {
+    if (ncontig <= 0 || ncand < 0) return ORC_EINVAL;
+    g_index_seconds = 0.0;
+    int64_t ncp = 0, ncp2 = 0;
+    copy_t *cps = find_pass(genome, contig_off, ncontig, cand, cand_off, ncand, NULL, 0, CK, CW, &ncp, &g_index_seconds);
+    copy_t *cps2 = NULL;
+    int64_t *first2 = NULL;      /* rows of candidate c in the far table: first2[c] .. first2[c + 1] */
+    uint8_t *use2 = NULL;        /* the far table replaces the first for candidate c */
+    if (g_far_min > 0 && ncand > 0) {
+        int32_t *cnt = (int32_t *)calloc((size_t)ncand, sizeof(int32_t)), *sel = (int32_t *)malloc(sizeof(int32_t) * (size_t)ncand);
+        for (int64_t t = 0; t < ncp; t++) cnt[cps[t].c]++;
+        int nsel = 0;
+        for (int c = 0; c < ncand; c++) if (cnt[c] < g_far_min) sel[nsel++] = c;
+        if (nsel > 0) {
+            cps2 = find_pass(genome, contig_off, ncontig, cand, cand_off, ncand, sel, nsel, FAR_K, FAR_W, &ncp2, &g_index_seconds);
+            first2 = (int64_t *)calloc((size_t)ncand + 1, sizeof(int64_t));
+            int32_t *cnt2 = (int32_t *)calloc((size_t)ncand, sizeof(int32_t));
+            for (int64_t t = 0; t < ncp2; t++) cnt2[cps2[t].c]++;
+            int64_t acc = 0;
+            for (int c = 0; c < ncand; c++) { first2[c] = acc; acc += cnt2[c]; }
+            first2[ncand] = acc;
+            use2 = (uint8_t *)calloc((size_t)ncand, 1);
+            for (int c = 0; c < ncand; c++) use2[c] = cnt2[c] > cnt[c];
+            free(cnt2);
+        }
+        free(cnt); free(sel);
+    }
     int64_t nout = 0;
-    int cur = 0;
     copy_first[0] = 0;
     int64_t p = 0;
     for (int c = 0; c < ncand; c++) {
         int kept = 0;
+        const int far = use2 && use2[c];
+        if (far) {
+            for (int64_t t = first2[c]; t < first2[c + 1] && kept < MAXCOPY; t++, kept++) {
+                if (nout >= cap) { free(cps); free(cps2); free(first2); free(use2); return ORC_ECAP; }
+                contig[nout] = cps2[t].contig; start1[nout] = cps2[t].start1; end1[nout] = cps2[t].end1;
+                minus[nout] = (uint8_t)cps2[t].minus; anchors[nout] = cps2[t].anch;
+                nout++;
+            }
+        }
         while (p < ncp && cps[p].c == c) {
-            if (kept < MAXCOPY) {
-                if (nout >= cap) { free(idx); free(hits); free(cps); return ORC_ECAP; }
+            if (!far && kept < MAXCOPY) {
+                if (nout >= cap) { free(cps); free(cps2); free(first2); free(use2); return ORC_ECAP; }
                 contig[nout] = cps[p].contig; start1[nout] = cps[p].start1; end1[nout] = cps[p].end1;
                 minus[nout] = (uint8_t)cps[p].minus; anchors[nout] = cps[p].anch;
                 nout++; kept++;
@@ -363,8 +418,7 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
         }
         copy_first[c + 1] = (int32_t)nout;
     }
-    (void)cur;
-    free(idx); free(hits); free(cps);
+    free(cps); free(cps2); free(first2); free(use2);
     return nout;
 }
 

@@ -302,6 +302,11 @@ def find_copies_config(aligned_interval):
     lib().orc_find_copies_config(int(bool(aligned_interval)))
 
 
+def find_copies_far(min_copies):
+    """far pass of the twin (mirror of hite_copy_far_pass): candidates with fewer copies are searched again in the (8, 13) index; 0 = off"""
+    lib().orc_find_copies_far(int(min_copies))
+
+
 def seed_allvsall(contigs, seg_len=1_000_000):
     """this build's blastn stand-in (twin): -> dict(qseg, sseg, qs, qe, ss, se) + the segment table"""
     gb = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]

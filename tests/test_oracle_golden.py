@@ -595,3 +595,20 @@ def test_column_vote_oracle_is_the_plain_count():
         m = O.msa_array(case["clean"])
         exp = np.stack([(m == ord(ch)).sum(axis=0) for ch in "ACGTN-"], axis=1)
         assert np.array_equal(O.column_vote(m), exp)
+
+
+def test_twin_far_pass_is_off_by_default_and_only_adds():
+    """orc_find_copies_far is a MEASUREMENT AID of the twin (tools/far_copy_pass.py, profiles/r05_far_copy_pass.txt): the product has no
+    far pass, so the twin's default must be the plain (10, 15) search; switched on, a candidate's table is replaced only by a larger one."""
+    import synth_small
+
+    g = synth_small.make(23, n_fam=12)
+    base = O.find_copies(g["contigs"], g["cands"])
+    try:
+        O.find_copies_far(1 << 20)
+        far = O.find_copies(g["contigs"], g["cands"])
+    finally:
+        O.find_copies_far(0)
+    assert O.find_copies(g["contigs"], g["cands"]) == base
+    assert all(len(b) >= len(a) for a, b in zip(base, far))
+    assert all(a == b for a, b in zip(base, far) if len(a) == len(b))
