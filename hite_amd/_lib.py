@@ -281,6 +281,8 @@ class Context:
     def flank_region_align(self, te_type, cands, copies, plant=1, flank=50):
         """cands: list of candidate sequences; copies: list (per candidate) of
         (contig_index, start1, end1, minus) tuples.  Needs genome_pack() first.
+        Tuples as find_copies(..., clips=True) returns them -- (contig, start1, end1, minus, anchors, clip) -- hand their clip
+        words on (hite_flank_region_align_clip: rows padded by the clipped candidate bases); shorter tuples: no pads.
         -> (list of (is_TE, info, cons, row_num, bstart, bend), stats)"""
         n = len(cands)
         cb = [c.encode() if isinstance(c, str) else bytes(c) for c in cands]
@@ -294,14 +296,16 @@ class Context:
         s1 = _arr([t[1] for t in flat], np.int64)
         e1 = _arr([t[2] for t in flat], np.int64)
         mn = _arr([t[3] for t in flat], np.uint8)
+        clip = _arr([t[5] if len(t) > 5 else 0 for t in flat], np.uint32) if any(len(t) > 5 and t[5] for t in flat) else None
         calls = np.zeros(n, dtype=CALL_DTYPE)
         cap = int(coff[-1]) + (2 * flank + 64) * n + 4096
         stats = np.zeros(12, dtype=np.int64)
         for _attempt in range(2):
             cons = np.zeros(cap + 16, dtype=np.uint8)
-            rc = self.lib.hite_flank_region_align(self.h, HITE_TE[te_type], int(plant), n, _p(cbuf), _p(coff), _p(cf),
-                                                  C.c_int64(len(flat)), _p(contig), _p(s1), _p(e1), _p(mn), int(flank),
-                                                  _p(calls), _p(cons), C.c_int64(cap), _p(stats))
+            rc = self.lib.hite_flank_region_align_clip(self.h, HITE_TE[te_type], int(plant), n, _p(cbuf), _p(coff), _p(cf),
+                                                       C.c_int64(len(flat)), _p(contig), _p(s1), _p(e1), _p(mn),
+                                                       _p(clip) if clip is not None else None, int(flank),
+                                                       _p(calls), _p(cons), C.c_int64(cap), _p(stats))
             if rc == -4 and stats[10] > cap:     # HITE_ECAP: the consensus pool was too small; stats[10] says how much is needed
                 cap = int(stats[10]) + 4096
                 continue
@@ -316,16 +320,17 @@ class Context:
 
     # device-resident variant: every argument is a raw device pointer (e.g. torch tensor .data_ptr())
     def flank_region_align_dev(self, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, n_copies, d_contig, d_start1,
-                               d_end1, d_minus, flank, d_calls, d_cons, cons_cap, stream=0):
+                               d_end1, d_minus, flank, d_calls, d_cons, cons_cap, stream=0, d_clip=0):
+        """d_clip: device pointer of the records' clip words (copy_clips_dev()), 0: no pads"""
         if not hasattr(self, "_pipe_state"):
             self._pipe_state = C.c_void_p(None)
         stats = np.zeros(12, dtype=np.int64)
         v = C.c_void_p
-        rc = self.lib.hite_flank_region_align_dev(self.h, C.byref(self._pipe_state), HITE_TE[te_type], int(plant), int(n_cand),
-                                                  v(d_cand), v(d_cand_off), v(d_copy_first), C.c_int64(n_copies), v(d_contig),
-                                                  v(d_start1), v(d_end1), v(d_minus), int(flank), v(d_calls), v(d_cons),
-                                                  C.c_int64(cons_cap), _p(stats), v(stream))
-        self._check(rc, "hite_flank_region_align_dev")
+        rc = self.lib.hite_flank_region_align_clip_dev(self.h, C.byref(self._pipe_state), HITE_TE[te_type], int(plant), int(n_cand),
+                                                       v(d_cand), v(d_cand_off), v(d_copy_first), C.c_int64(n_copies), v(d_contig),
+                                                       v(d_start1), v(d_end1), v(d_minus), v(d_clip or None), int(flank), v(d_calls),
+                                                       v(d_cons), C.c_int64(cons_cap), _p(stats), v(stream))
+        self._check(rc, "hite_flank_region_align_clip_dev")
         return stats
 
     def profile(self, on=None, reset=False):
@@ -400,9 +405,12 @@ class Context:
     # ---- copy finding (stage where the reference calls minimap2, Util.py:7933) ---------------------------
     FIND_COPIES_BATCH = 1 << 18
 
-    def find_copies_table(self, cands, restricted=False):
+    def find_copies_table(self, cands, restricted=False, clips=False):
         """the copy table as arrays: (copy_first int32[n + 1], contig, start1, end1, minus, anchors) -- the copies of candidate c are
         rows copy_first[c] .. copy_first[c + 1]; needs genome_pack() first; at most FIND_COPIES_BATCH candidates.
+        clips=True: a 7th array, uint32 per record: the candidate bases the end extensions clipped, left | right << 16 in the
+        orientation of the genome (hite_copy_clips) -- zero unless the records carry the reference's aligned interval
+        (hite_copy_config(1)); flank_region_align pads the rows of the star alignment with them.
         restricted=True: the caller uses the index of this genome for THIS candidate set only (the masking step of stage 3.1):
         hite_find_copies_restricted builds the index from just the genome minimizers the candidates look up -- same table,
         a fraction of the build; any later use of the handle rebuilds the full index by itself."""
@@ -427,18 +435,23 @@ class Context:
         self._check(fn(self.h, C.byref(self._copy_state), n, _p(buf), _p(off), C.c_int64(cap), _p(cf), _p(ct), _p(s1), _p(e1), _p(mn),
                        _p(an), C.byref(nout)), "hite_find_copies_restricted" if restricted else "hite_find_copies")
         k = int(cf[n])
+        if clips:
+            cl = np.zeros(k + 1, dtype=np.uint32)
+            self._check(self.lib.hite_copy_clips(self._copy_state, C.c_int64(k + 1), _p(cl)), "hite_copy_clips")
+            return cf, ct[:k], s1[:k], e1[:k], mn[:k], an[:k], cl[:k]
         return cf, ct[:k], s1[:k], e1[:k], mn[:k], an[:k]
 
-    def find_copies(self, cands, restricted=False):
-        """-> per candidate list of (contig, start1, end1, minus, anchors); needs genome_pack() first (restricted: see
-        find_copies_table)"""
+    def find_copies(self, cands, restricted=False, clips=False):
+        """-> per candidate list of (contig, start1, end1, minus, anchors); needs genome_pack() first (restricted, clips: see
+        find_copies_table; clips=True appends the packed clip word to every tuple: flank_region_align reads it from there)"""
         if len(cands) > self.FIND_COPIES_BATCH:    # one device call handles < 2^19 candidates: larger libraries go in batches
             out = []
             for k in range(0, len(cands), self.FIND_COPIES_BATCH):     # (batches share one full index)
-                out += self.find_copies(cands[k:k + self.FIND_COPIES_BATCH])
+                out += self.find_copies(cands[k:k + self.FIND_COPIES_BATCH], clips=clips)
             return out
-        cf, ct, s1, e1, mn, an = self.find_copies_table(cands, restricted)
-        rows = list(zip(ct.tolist(), s1.tolist(), e1.tolist(), mn.tolist(), an.tolist()))
+        tab = self.find_copies_table(cands, restricted, clips)
+        cf, ct, s1, e1, mn, an = tab[:6]
+        rows = list(zip(ct.tolist(), s1.tolist(), e1.tolist(), mn.tolist(), an.tolist(), *([tab[6].tolist()] if clips else [])))
         cf = cf.tolist()
         return [rows[cf[c]:cf[c + 1]] for c in range(len(cands))]
 
@@ -459,6 +472,13 @@ class Context:
                                            C.byref(outs[4]), C.byref(outs[5]), v(stream))
         self._check(rc, "hite_find_copies_dev")
         return (n.value,) + tuple(o.value or 0 for o in outs)
+
+    def copy_clips_dev(self):
+        """raw device pointer of the clip words of the last find_copies_dev call's records (0: none) -- the d_clip of flank_region_align_dev"""
+        d = C.c_void_p()
+        n = C.c_int64(0)
+        self._check(self.lib.hite_copy_clips_dev(self._copy_state, C.byref(d), C.byref(n)), "hite_copy_clips_dev")
+        return d.value or 0
 
     def query_copies(self, qid, sid, qs, qe, ss, se, ident, qlen, slen=None, ns=None, qcov=0.95, scov=0.0, qthr=200, sthr=200, max_copy=100):
         """get_query_copies on an HSP table in file order -> per query list of (subject id, start, end, chain length, '+'/'-')"""

@@ -47,6 +47,8 @@ struct CopyState {
     Arena out;        // copy table handed to the caller (valid until the next call)
     int64_t *h_pin = nullptr;
     int64_t *d_scal = nullptr;
+    const uint32_t *out_clip = nullptr;   // per copy record of the last call (in `out`): candidate bases clipped left | right << 16 (hite_copy_clips_dev)
+    int64_t out_n = 0;
     int64_t last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last call: candidate minimizers, hits, clusters, copies (before the 300 cap); chains with a long / short end to extend, extension columns
 };
 
@@ -805,7 +807,8 @@ __global__ void __launch_bounds__(256) chain_copy_kernel(const unsigned long lon
                                                          const int64_t *__restrict__ coff, int nc, unsigned long long *__restrict__ ckey,
                                                          unsigned *__restrict__ cval, int32_t *__restrict__ r_contig, int64_t *__restrict__ r_s1,
                                                          int64_t *__restrict__ r_e1, uint8_t *__restrict__ r_minus, int32_t *__restrict__ r_anch,
-                                                         int32_t *__restrict__ per_cand, const int64_t *__restrict__ cstart, int aligned_iv) {
+                                                         uint32_t *__restrict__ r_clip, int32_t *__restrict__ per_cand,
+                                                         const int64_t *__restrict__ cstart, int aligned_iv) {
     unsigned long long n_long = counters[0], n_short = counters[1];
     if (n_long > cap) n_long = cap;
     if (n_long + n_short > cap) n_short = cap - n_long;
@@ -831,6 +834,9 @@ __global__ void __launch_bounds__(256) chain_copy_kernel(const unsigned long lon
         if (e0 > ce) e0 = ce;
         const int64_t slot = cstart[c] + atomicAdd(&per_cand[c], 1);
         r_contig[slot] = ctg; r_s1[slot] = s0 - cb + 1; r_e1[slot] = e0 - cb; r_minus[slot] = (uint8_t)rel; r_anch[slot] = na;
+        // aligned interval: the candidate bases the extensions clipped (<= 5 % of it each) travel beside the record -- the rows of the
+        // star alignment are padded by them (hite_flank_region_align_clip_dev); whole-candidate interval: they are inside it, no pads
+        r_clip[slot] = aligned_iv ? ((uint32_t)(clip_l > 0xffff ? 0xffff : clip_l) | ((uint32_t)(clip_r > 0xffff ? 0xffff : clip_r) << 16)) : 0u;
         const int ac = na > 4095 ? 4095 : na;
         ckey[slot] = ((unsigned long long)c << 45) | ((unsigned long long)(4095 - ac) << 33) | ((unsigned long long)(unsigned)s0 << 1) | rel;
         cval[slot] = (unsigned)slot;
@@ -846,8 +852,9 @@ __global__ void emit_copies_kernel(int64_t ncp, const unsigned long long *__rest
                                    const int64_t *__restrict__ cstart /* per candidate, all accepted */,
                                    const int64_t *__restrict__ ofirst /* per candidate, kept */, const int32_t *__restrict__ r_contig,
                                    const int64_t *__restrict__ r_s1, const int64_t *__restrict__ r_e1, const uint8_t *__restrict__ r_minus,
-                                   const int32_t *__restrict__ r_anch, int32_t *__restrict__ o_contig, int64_t *__restrict__ o_s1,
-                                   int64_t *__restrict__ o_e1, uint8_t *__restrict__ o_minus, int32_t *__restrict__ o_anch) {
+                                   const int32_t *__restrict__ r_anch, const uint32_t *__restrict__ r_clip, int32_t *__restrict__ o_contig,
+                                   int64_t *__restrict__ o_s1, int64_t *__restrict__ o_e1, uint8_t *__restrict__ o_minus,
+                                   int32_t *__restrict__ o_anch, uint32_t *__restrict__ o_clip) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ncp) return;
     unsigned c = (unsigned)(ckey[i] >> 45);
@@ -855,7 +862,7 @@ __global__ void emit_copies_kernel(int64_t ncp, const unsigned long long *__rest
     if (rank >= C_MAXCOPY) return;
     int64_t o = ofirst[c] + rank;
     unsigned s = cval[i];
-    o_contig[o] = r_contig[s]; o_s1[o] = r_s1[s]; o_e1[o] = r_e1[s]; o_minus[o] = r_minus[s]; o_anch[o] = r_anch[s];
+    o_contig[o] = r_contig[s]; o_s1[o] = r_s1[s]; o_e1[o] = r_e1[s]; o_minus[o] = r_minus[s]; o_anch[o] = r_anch[s]; o_clip[o] = r_clip[s];
 }
 __global__ void i64_to_i32_kernel(int64_t n, const int64_t *__restrict__ in, int32_t *__restrict__ out) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1051,6 +1058,7 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
     int32_t *ofirst32;
     CCHK(arena_alloc(ctx, S->out, (size_t)(n_cand + 2) * 4, &p)); ofirst32 = (int32_t *)p;
     *d_copy_first = ofirst32; *n_copies = 0;
+    S->out_clip = nullptr; S->out_n = 0;
     HITE_CHECK(ctx, hipMemsetAsync(ofirst32, 0, (size_t)(n_cand + 2) * 4, st));
     *d_contig = nullptr; *d_start1 = nullptr; *d_end1 = nullptr; *d_minus = nullptr; *d_anchors = nullptr;
     if (n_cand == 0 || cand_bytes <= 0 || S->M == 0) return HITE_OK;
@@ -1228,6 +1236,7 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
     int32_t *r_contig, *r_anch;
     int64_t *r_s1, *r_e1;
     uint8_t *r_minus;
+    uint32_t *r_clip;
     // (records: at most one per chain)
     CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 8, &p)); ckey = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 4, &p)); cval = (unsigned *)p;
@@ -1236,6 +1245,7 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
     CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 8, &p)); r_e1 = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(chcap + 16), &p)); r_minus = (uint8_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 4, &p)); r_anch = (int32_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(chcap + 1) * 4, &p)); r_clip = (uint32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); per_cand = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 1) * 4, &p)); per_cand300 = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(n_cand + 2) * 8, &p)); cstart = (int64_t *)p;
@@ -1251,11 +1261,11 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
         unsigned long long want_blocks = (chcap + 255ull) / 256ull;
         const unsigned cblocks = (unsigned)(want_blocks < 8192ull ? (want_blocks ? want_blocks : 1ull) : 8192ull);
         hipLaunchKernelGGL(chain_copy_kernel<false>, dim3(cblocks), dim3(256), 0, st, d_nchain, chcap, chain_list, x_i, x_t, hkey, F, c_first, c_lo,
-                           c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, per_cand,
+                           c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, r_clip, per_cand,
                            (const int64_t *)nullptr, copy_interval_mode());
         CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand, n_cand, cstart, st));
         hipLaunchKernelGGL(chain_copy_kernel<true>, dim3(cblocks), dim3(256), 0, st, d_nchain, chcap, chain_list, x_i, x_t, hkey, F, c_first, c_lo,
-                           c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, fill,
+                           c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, r_clip, fill,
                            (const int64_t *)cstart, copy_interval_mode());
     }
     hite_prof_end(ctx, tk_cluster_copy_kernel, st);
@@ -1283,8 +1293,11 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
     CCHK(arena_alloc(ctx, S->out, (size_t)(nout + 1) * 8, &p)); o_e1 = (int64_t *)p;
     CCHK(arena_alloc(ctx, S->out, (size_t)(nout + 16), &p)); o_minus = (uint8_t *)p;
     CCHK(arena_alloc(ctx, S->out, (size_t)(nout + 1) * 4, &p)); o_anch = (int32_t *)p;
-    hipLaunchKernelGGL(emit_copies_kernel, CGRID(ncp), 0, st, ncp, ckey, cval, cstart, ofirst, r_contig, r_s1, r_e1, r_minus, r_anch,
-                       o_contig, o_s1, o_e1, o_minus, o_anch);
+    uint32_t *o_clip;
+    CCHK(arena_alloc(ctx, S->out, (size_t)(nout + 1) * 4, &p)); o_clip = (uint32_t *)p;
+    hipLaunchKernelGGL(emit_copies_kernel, CGRID(ncp), 0, st, ncp, ckey, cval, cstart, ofirst, r_contig, r_s1, r_e1, r_minus, r_anch, r_clip,
+                       o_contig, o_s1, o_e1, o_minus, o_anch, o_clip);
+    S->out_clip = o_clip; S->out_n = nout;
     HITE_CHECK(ctx, hipGetLastError());
     *d_contig = o_contig; *d_start1 = o_s1; *d_end1 = o_e1; *d_minus = o_minus; *d_anchors = o_anch;
     // if the temporaries grew into several chunks during this call, merge them NOW (they are dead; the copy table lives in
@@ -1407,6 +1420,21 @@ extern "C" int hite_find_copies_restricted(hite_ctx *ctx, void **state_io, int32
                                            int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1,
                                            uint8_t *minus, int32_t *anchors, int64_t *n_out) {
     return find_copies_host(ctx, state_io, n_cand, cand, cand_off, cap, copy_first, contig, start1, end1, minus, anchors, n_out, true);
+}
+/* the clipped candidate bases of the last hite_find_copies[_dev] / _restricted call's records (see hite_gpu.h) */
+extern "C" int hite_copy_clips_dev(void *state, const uint32_t **d_clip, int64_t *n) {
+    CopyState *S = (CopyState *)state;
+    if (!S || !d_clip) return HITE_EINVAL;
+    *d_clip = S->out_clip;
+    if (n) *n = S->out_n;
+    return HITE_OK;
+}
+extern "C" int hite_copy_clips(void *state, int64_t cap, uint32_t *clip) {
+    CopyState *S = (CopyState *)state;
+    if (!S || (!clip && cap > 0)) return HITE_EINVAL;
+    if (S->out_n > cap) return HITE_ECAP;
+    if (S->out_n > 0 && S->out_clip && hipMemcpy(clip, S->out_clip, (size_t)S->out_n * 4, hipMemcpyDeviceToHost) != hipSuccess) return HITE_EHIP;
+    return HITE_OK;
 }
 extern "C" int hite_copy_stats(void *state, int64_t out[4]) {
     CopyState *S = (CopyState *)state;

@@ -343,6 +343,52 @@ __global__ void msa_rows_out_kernel(int n, const int32_t *__restrict__ row_first
     if (c < n) rows_out[c] = rows_eff ? rows_eff[c] : row_first[c + 1] - row_first[c];
 }
 
+// ---- rows that begin / end with HITE_ROW_PAD (include/hite_gpu.h) ---------------------------------------------------------
+// per row: the pads it begins and ends with, and the window without them
+__global__ void row_pad_scan_kernel(int64_t total_rows, const uint8_t *__restrict__ win, const int64_t *__restrict__ win_off,
+                                    const int32_t *__restrict__ win_len, int64_t *__restrict__ off2, int32_t *__restrict__ len2,
+                                    uint32_t *__restrict__ pads) {
+    const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total_rows) return;
+    const uint8_t *b = win + win_off[g];
+    const int n = win_len[g];
+    int pf = 0, pb = 0;
+    if (n > 0 && b[0] == HITE_ROW_PAD) { pf = 1; while (pf < n && b[pf] == HITE_ROW_PAD) pf++; }
+    if (pf < n && b[n - 1] == HITE_ROW_PAD) { pb = 1; while (pf + pb < n && b[n - 1 - pb] == HITE_ROW_PAD) pb++; }
+    off2[g] = win_off[g] + pf; len2[g] = n - pf - pb;
+    pads[g] = (uint32_t)pf | ((uint32_t)pb << 16);
+}
+// the ops of a padded row, rewritten for the row without its pads: a centre position aligned to a pad (or facing a gap among them)
+// becomes a gap of the row before its first / after its last base
+__global__ void __launch_bounds__(256) ops_unpad_kernel(int n, const int32_t *__restrict__ row_first, const int32_t *__restrict__ win_len,
+                                                        const int64_t *__restrict__ ops_base, uint16_t *__restrict__ ops_all,
+                                                        const uint32_t *__restrict__ pads, const int64_t *__restrict__ win_off,
+                                                        int64_t *__restrict__ off2, int32_t *__restrict__ len2) {
+    const int c = blockIdx.x;
+    if (c >= n) return;
+    const int g0 = row_first[c], R = row_first[c + 1] - g0;
+    if (R >= 1 && threadIdx.x == 0) { off2[g0] = win_off[g0]; len2[g0] = win_len[g0]; }     // the centre is taken as it is
+    if (R <= 1) return;
+    const int m = win_len[g0];
+    uint16_t *ops = ops_all + ops_base[c];
+    for (int r = 1; r < R; r++) {
+        const uint32_t pd = pads[g0 + r];        // uniform over the block
+        if (!pd) continue;
+        const int pf = (int)(pd & 0xffffu), pb = (int)(pd >> 16), nn = win_len[g0 + r];
+        const int hi = nn - pb, n2 = nn - pf - pb;
+        uint16_t *o = ops + (int64_t)r * (m + 1);
+        for (int p = threadIdx.x; p < m; p += 256) {
+            const unsigned v = o[p];
+            const int q = (int)(v & 0x7fffu);
+            unsigned w;
+            if (q < pf) w = 0x8000u;
+            else if (q >= hi) w = 0x8000u | (unsigned)n2;
+            else w = (v & 0x8000u) | (unsigned)(q - pf);
+            o[p] = (uint16_t)w;
+        }
+    }
+}
+
 static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const int64_t *d_win_off,
                            const int32_t *d_win_len, const int32_t *d_row_first, int64_t total_rows, const int64_t *d_ops_base,
                            int64_t ops_elems, int32_t max_win_len, int32_t *d_cols_out, int32_t *d_status,
@@ -354,7 +400,7 @@ static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
     const size_t rows_bytes = ((size_t)total_rows * 4 + 255) & ~(size_t)255, cand_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
     void *opsb = nullptr;
     const size_t lay_bytes = d_new_cols ? (((size_t)ops_elems / 2 + 32768 + 16) * 4 + 255) & ~(size_t)255 : 0;
-    int rc = hite_scratch2_reserve(ctx, ops_bytes + 2 * rows_bytes + 2 * cand_bytes + lay_bytes + 256, &opsb);
+    int rc = hite_scratch2_reserve(ctx, ops_bytes + 2 * rows_bytes + 2 * cand_bytes + lay_bytes + 4 * rows_bytes + 256, &opsb);
     if (rc) return rc;
     uint8_t *base = (uint8_t *)opsb;
     int32_t *row_dead = (int32_t *)(base + ops_bytes), *row_map = (int32_t *)(base + ops_bytes + rows_bytes);
@@ -371,14 +417,25 @@ static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
     rc = hite_align_stats(ctx, after, 0);
     if (rc) return rc;
     const bool dropped = after[4] > before[4];
+    // rows padded with HITE_ROW_PAD leave their pads here: from now on (compaction, layout, fill, judge) a row is its window without them
+    int64_t *off2 = (int64_t *)(base + ops_bytes + 2 * rows_bytes + 2 * cand_bytes + lay_bytes);
+    int32_t *len2 = (int32_t *)((uint8_t *)off2 + 2 * rows_bytes);
+    uint32_t *pads = (uint32_t *)((uint8_t *)off2 + 3 * rows_bytes);
+    if (total_rows > 0) {
+        hipLaunchKernelGGL(row_pad_scan_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, total_rows, d_win, d_win_off, d_win_len,
+                           off2, len2, pads);
+        hipLaunchKernelGGL(ops_unpad_kernel, dim3(n), dim3(256), 0, st, n, d_row_first, d_win_len, d_ops_base, (uint16_t *)opsb, pads, d_win_off,
+                           off2, len2);
+    }
+    ctx->d_msa_win_off = off2; ctx->d_msa_win_len = len2;
     MsaParams P;
-    P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first;
+    P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = off2; P.win_len = len2; P.row_first = d_row_first;
     P.ops_base = d_ops_base; P.ops = (uint16_t *)opsb; P.cols_out = d_cols_out; P.status = d_status;
     P.row_map = nullptr; P.rows_eff = nullptr;
     P.lay = d_new_cols ? (uint32_t *)(base + ops_bytes + 2 * rows_bytes + 2 * cand_bytes) : nullptr;
     ctx->d_msa_lay = P.lay;
     if (dropped) {
-        hipLaunchKernelGGL(msa_compact_rows_kernel, dim3(n), dim3(256), 0, st, n, d_row_first, d_win_len, d_ops_base, (uint16_t *)opsb, cand_flag,
+        hipLaunchKernelGGL(msa_compact_rows_kernel, dim3(n), dim3(256), 0, st, n, d_row_first, len2, d_ops_base, (uint16_t *)opsb, cand_flag,
                            row_dead, row_map, rows_eff);
         P.row_map = row_map; P.rows_eff = rows_eff;
     }
@@ -427,7 +484,9 @@ extern "C" int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uin
     if (n == 0) return HITE_OK;
     FillSparseParams Q;
     FillParams &P = Q.F;
-    P.n = n; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first; P.ops_base = d_ops_base;
+    // (rows through the star stage's view of them: without the HITE_ROW_PAD runs they were aligned with)
+    P.n = n; P.win = d_win; P.win_off = ctx->d_msa_win_off ? ctx->d_msa_win_off : d_win_off; P.win_len = ctx->d_msa_win_len ? ctx->d_msa_win_len : d_win_len;
+    P.row_first = d_row_first; P.ops_base = d_ops_base;
     P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_new_cols; P.msa_off = d_msa_off; P.msa = d_msa;
     P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff;
     Q.last_extra = d_last_extra; Q.lay = ctx->d_msa_lay;
@@ -452,7 +511,8 @@ extern "C" int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d
     if (!ctx || n < 0 || !ctx->d_scratch2) return HITE_EINVAL;
     if (n == 0) return HITE_OK;
     FillParams P;
-    P.n = n; P.win = d_win; P.win_off = d_win_off; P.win_len = d_win_len; P.row_first = d_row_first; P.ops_base = d_ops_base;
+    P.n = n; P.win = d_win; P.win_off = ctx->d_msa_win_off ? ctx->d_msa_win_off : d_win_off; P.win_len = ctx->d_msa_win_len ? ctx->d_msa_win_len : d_win_len;
+    P.row_first = d_row_first; P.ops_base = d_ops_base;
     P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_cols; P.msa_off = d_msa_off; P.msa = d_msa;
     P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff;
     hipLaunchKernelGGL(star_fill_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, P);

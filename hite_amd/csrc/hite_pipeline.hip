@@ -173,7 +173,7 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
                                 const int64_t *__restrict__ len, int32_t *__restrict__ row_first32,
                                 int32_t *__restrict__ row_copy, int32_t *__restrict__ row_len,
                                 int32_t *__restrict__ row_pad, uint8_t *__restrict__ row_trunc,
-                                int32_t *__restrict__ maxlen) {
+                                int32_t *__restrict__ maxlen, const uint32_t *__restrict__ clip /* per copy, or NULL */) {
     int c = blockIdx.x;
     if (c >= n) return;
     if (threadIdx.x == 0) { row_first32[c] = (int32_t)row_first[c]; if (c == n - 1) row_first32[n] = (int32_t)row_first[n]; }
@@ -183,7 +183,8 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
         int64_t g = row_first[c] + r;
         int cp = sel[(int64_t)c * MAXROWS + r];
-        int L = md == 2 ? 1000 : (int)len[cp];
+        // (the rows of the first500 + last500 form are cut from the PADDED window: still 1000 bytes)
+        int L = md == 2 ? 1000 : (int)len[cp] + (clip ? (int)(clip[cp] & 0xffffu) + (int)(clip[cp] >> 16) : 0);
         row_copy[g] = cp;
         row_len[g] = L;
         row_pad[g] = (L + 15) & ~15;
@@ -196,7 +197,23 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
     if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(maxlen, mx);
 }
 
-// one wavefront per row: window (or its first500+last500 form) from the packed genome
+// positions [ws, ws + cnt) of a window padded by `a` bytes in front and `b` behind: HITE_ROW_PAD where the genome window is not
+__device__ __forceinline__ void emit_padded(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g_lo, int64_t len,
+                                            bool mn, int64_t a, int64_t b, int64_t ws, int64_t cnt, uint8_t *__restrict__ dst, int lane) {
+    (void)b;
+    int64_t n1 = a - ws; n1 = n1 < 0 ? 0 : (n1 > cnt ? cnt : n1);                 // pad bytes in front
+    const int64_t off = ws + n1 - a;                                              // first window position wanted
+    int64_t n2 = len - off; n2 = n2 < 0 ? 0 : (n2 > cnt - n1 ? cnt - n1 : n2);    // genome bytes
+    for (int64_t i = lane; i < n1; i += 64) dst[i] = HITE_ROW_PAD;
+    if (n2 > 0) emit_span(bases, nmask, g_lo, len, mn, off, n2, dst + n1, lane);
+    for (int64_t i = n1 + n2 + lane; i < cnt; i += 64) dst[i] = HITE_ROW_PAD;
+}
+
+// one wavefront per row: window (or its first500+last500 form) from the packed genome.  clip != NULL (copy records in the reference's
+// coordinates, the aligned interval of Util.py:8026): the window is padded by the candidate bases the copy finder's end extensions
+// clipped -- in front by the left clip (the right one for a minus copy: the window is reverse-complemented), behind by the other --
+// with HITE_ROW_PAD, a byte that matches nothing and leaves the alignment as '-': the row then faces the part of the centre it was
+// found with, and its path stays on the diagonal instead of opening a gap of the clipped length at 3 per base
 __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restrict__ bases,
                                                          const uint32_t *__restrict__ nmask,
                                                          const int64_t *__restrict__ coff, int32_t ncontig,
@@ -205,7 +222,8 @@ __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restr
                                                          const int32_t *__restrict__ contig,
                                                          const int64_t *__restrict__ s1, const int64_t *__restrict__ e1,
                                                          const uint8_t *__restrict__ minus, int32_t flank,
-                                                         const int64_t *__restrict__ win_off, uint8_t *__restrict__ win) {
+                                                         const int64_t *__restrict__ win_off, uint8_t *__restrict__ win,
+                                                         const uint32_t *__restrict__ clip) {
     int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= nrows_total) return;
     int lane = threadIdx.x & 63;
@@ -215,6 +233,18 @@ __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restr
     if (len == 0) return;
     bool mn = minus[cp] != 0;
     uint8_t *dst = win + win_off[g];
+    const uint32_t cl = clip ? clip[cp] : 0u;
+    if (cl) {
+        const int64_t a = mn ? (int64_t)(cl >> 16) : (int64_t)(cl & 0xffffu), b = mn ? (int64_t)(cl & 0xffffu) : (int64_t)(cl >> 16);
+        const int64_t plen = a + len + b;
+        if (row_trunc[g]) {
+            emit_padded(bases, nmask, g_lo, len, mn, a, b, 0, 500, dst, lane);
+            emit_padded(bases, nmask, g_lo, len, mn, a, b, plen - 500, 500, dst + 500, lane);
+        } else {
+            emit_padded(bases, nmask, g_lo, len, mn, a, b, 0, plen, dst, lane);
+        }
+        return;
+    }
     if (row_trunc[g]) {
         emit_span(bases, nmask, g_lo, len, mn, 0, 500, dst, lane);
         emit_span(bases, nmask, g_lo, len, mn, len - 500, 500, dst + 500, lane);
@@ -323,7 +353,7 @@ static int read_scalars(hite_ctx *ctx, PipeState *S, hipStream_t st, int count) 
 
 static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, const uint8_t *d_cand,
                     const int64_t *d_cand_off, const int32_t *d_copy_first, const int32_t *d_contig,
-                    const int64_t *d_s1, const int64_t *d_e1, const uint8_t *d_minus, int flank, const int64_t *d_len,
+                    const int64_t *d_s1, const int64_t *d_e1, const uint8_t *d_minus, const uint32_t *d_clip, int flank, const int64_t *d_len,
                     const int32_t *d_mode, PassOut *out, int64_t *stats /* rows, win_bytes, msa_bytes, align_bytes */,
                     int64_t *extra /* steps */, int64_t *cols_acc /* cleaned columns, both passes */, bool pass_b, hipStream_t st) {
     Arena &T = S->tmp, &K = S->keep;
@@ -355,7 +385,7 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     ACHK(arena_alloc(ctx, T, (size_t)total_rows, &p)); row_trunc = (uint8_t *)p;
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
     hipLaunchKernelGGL(row_meta_kernel, dim3(n), dim3(128), 0, st, n, row_first, nrows, sel, d_mode, d_len, row_first32,
-                       row_copy, row_len, row_pad, row_trunc, (int32_t *)(S->d_scal + 2));
+                       row_copy, row_len, row_pad, row_trunc, (int32_t *)(S->d_scal + 2), d_clip);
     ACHK(arena_alloc(ctx, T, (size_t)(total_rows + 1) * 8, &p)); win_off = (int64_t *)p;
     ACHK(scan_excl<int32_t>(ctx, T, row_pad, total_rows, win_off, st));
     ACHK(arena_alloc(ctx, T, (size_t)n * 8, &p)); ops_cnt = (int64_t *)p;
@@ -376,7 +406,7 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     tk = hite_prof_begin(ctx, "row_gather_kernel", st);
     hipLaunchKernelGGL(row_gather_kernel, dim3((unsigned)((total_rows + 3) / 4)), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask,
                        ctx->d_contig_off, ctx->n_contigs, total_rows, row_copy, row_trunc, d_contig, d_s1, d_e1, d_minus,
-                       flank, win_off, win);
+                       flank, win_off, win, d_clip);
     hite_prof_end(ctx, tk, st);
     HITE_CHECK(ctx, hipGetLastError());
 
@@ -424,7 +454,8 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     } fuse_guard{ctx};
     if (jcls) {
         JudgeFuse F;
-        F.win = win; F.win_off = win_off; F.win_len = row_len; F.row_first = row_first32; F.ops_base = ops_base;
+        F.win = win; F.win_off = ctx->d_msa_win_off ? ctx->d_msa_win_off : win_off; F.win_len = ctx->d_msa_win_len ? ctx->d_msa_win_len : row_len;
+        F.row_first = row_first32; F.ops_base = ops_base;
         F.ops = (const uint16_t *)ctx->d_scratch2; F.lay = ctx->d_msa_lay; F.last_extra = last_extra;
         F.row_map = ctx->d_msa_row_map; F.rows_eff = ctx->d_msa_rows_eff;
         ctx->judge_fuse = F; ctx->d_judge_cls = jcls;
@@ -446,12 +477,12 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
 // ---------------------------------------------------------------------------------------------
 // public entry: the fine stage for one batch of candidates
 // ---------------------------------------------------------------------------------------------
-extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32_t te_type, int32_t plant, int32_t n_cand,
-                                           const uint8_t *d_cand, const int64_t *d_cand_off, const int32_t *d_copy_first,
-                                           int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1,
-                                           const int64_t *d_end1, const uint8_t *d_minus, int32_t flank, hite_call *d_calls,
-                                           uint8_t *d_cons, int64_t cons_cap, int64_t *stats_out /* 12 x int64, host, may be NULL */,
-                                           void *stream) {
+extern "C" int hite_flank_region_align_clip_dev(hite_ctx *ctx, void **state_io, int32_t te_type, int32_t plant, int32_t n_cand,
+                                                const uint8_t *d_cand, const int64_t *d_cand_off, const int32_t *d_copy_first,
+                                                int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1,
+                                                const int64_t *d_end1, const uint8_t *d_minus, const uint32_t *d_clip /* per copy, or NULL */,
+                                                int32_t flank, hite_call *d_calls, uint8_t *d_cons, int64_t cons_cap,
+                                                int64_t *stats_out /* 12 x int64, host, may be NULL */, void *stream) {
     if (!ctx || !ctx->d_bases || !state_io || n_cand < 0 || n_copies < 0 || te_type < 0 || te_type > 2) return HITE_EINVAL;
     if (n_cand == 0) return HITE_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -482,11 +513,11 @@ extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32
     hipLaunchKernelGGL(mode_a_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, d_copy_first, len, mode_a);
     HITE_CHECK(ctx, hipGetLastError());
     PassOut A, B;
-    ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, flank,
+    ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, d_clip, flank,
                   len, mode_a, &A, stats, stats + 8, stats + 11, false, st));
     ACHK(arena_reset(ctx, S->tmp, false));
     hipLaunchKernelGGL(mode_b_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, mode_a, A.calls, mode_b);
-    ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, flank,
+    ACHK(run_pass(ctx, S, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, d_contig, d_start1, d_end1, d_minus, d_clip, flank,
                   len, mode_b, &B, stats + 4, stats + 9, stats + 11, true, st));
     hipLaunchKernelGGL(merge_calls_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, mode_a, A.calls, B.calls, d_calls,
                        src_pass, keep_len);
@@ -506,6 +537,15 @@ extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32
     return HITE_OK;
 }
 
+extern "C" int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32_t te_type, int32_t plant, int32_t n_cand,
+                                           const uint8_t *d_cand, const int64_t *d_cand_off, const int32_t *d_copy_first,
+                                           int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1,
+                                           const int64_t *d_end1, const uint8_t *d_minus, int32_t flank, hite_call *d_calls,
+                                           uint8_t *d_cons, int64_t cons_cap, int64_t *stats_out, void *stream) {
+    return hite_flank_region_align_clip_dev(ctx, state_io, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, n_copies, d_contig,
+                                            d_start1, d_end1, d_minus, nullptr, flank, d_calls, d_cons, cons_cap, stats_out, stream);
+}
+
 // host-buffer wrapper (numpy callers / the drop-in scripts): uploads, runs, downloads
 struct PBuf {
     void *p = nullptr;
@@ -521,27 +561,29 @@ __global__ void fold_bytes_kernel(uint8_t *__restrict__ p, int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = fold_sym(p[i]);
 }
 
-extern "C" int hite_flank_region_align(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
-                                       const int64_t *cand_off, const int32_t *copy_first, int64_t n_copies,
-                                       const int32_t *contig, const int64_t *start1, const int64_t *end1,
-                                       const uint8_t *minus, int32_t flank, hite_call *calls, uint8_t *cons, int64_t cons_cap,
-                                       int64_t *stats_out) {
+extern "C" int hite_flank_region_align_clip(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
+                                            const int64_t *cand_off, const int32_t *copy_first, int64_t n_copies,
+                                            const int32_t *contig, const int64_t *start1, const int64_t *end1,
+                                            const uint8_t *minus, const uint32_t *clip /* per copy, or NULL */, int32_t flank,
+                                            hite_call *calls, uint8_t *cons, int64_t cons_cap, int64_t *stats_out) {
     if (!ctx || n_cand < 0 || !cand || !cand_off || !copy_first || !calls || !cons) return HITE_EINVAL;
     if (n_cand == 0) return HITE_OK;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
-    PBuf dc, dco, dcf, dct, ds, de, dm, dcalls, dcons;
+    PBuf dc, dco, dcf, dct, ds, de, dm, dcl, dcalls, dcons;
     hipError_t e;
     e = dc.up(cand, cand_off[n_cand]); if (e == hipSuccess) e = dco.up(cand_off, (n_cand + 1) * 8);
     if (e == hipSuccess) e = dcf.up(copy_first, (n_cand + 1) * 4); if (e == hipSuccess) e = dct.up(contig, n_copies * 4);
     if (e == hipSuccess) e = ds.up(start1, n_copies * 8); if (e == hipSuccess) e = de.up(end1, n_copies * 8);
     if (e == hipSuccess) e = dm.up(minus, n_copies); if (e == hipSuccess) e = dcalls.alloc(sizeof(hite_call) * n_cand);
     if (e == hipSuccess) e = dcons.alloc(cons_cap + 16);
+    if (e == hipSuccess && clip) e = dcl.up(clip, n_copies * 4);
     HITE_CHECK(ctx, e);
     hipLaunchKernelGGL(fold_bytes_kernel, dim3(256), dim3(256), 0, nullptr, (uint8_t *)dc.p, cand_off[n_cand]);
     void *state = nullptr;
-    int rc = hite_flank_region_align_dev(ctx, &state, te_type, plant, n_cand, (uint8_t *)dc.p, (int64_t *)dco.p, (int32_t *)dcf.p,
-                                         n_copies, (int32_t *)dct.p, (int64_t *)ds.p, (int64_t *)de.p, (uint8_t *)dm.p, flank,
-                                         (hite_call *)dcalls.p, (uint8_t *)dcons.p, cons_cap, stats_out, nullptr);
+    int rc = hite_flank_region_align_clip_dev(ctx, &state, te_type, plant, n_cand, (uint8_t *)dc.p, (int64_t *)dco.p, (int32_t *)dcf.p,
+                                              n_copies, (int32_t *)dct.p, (int64_t *)ds.p, (int64_t *)de.p, (uint8_t *)dm.p,
+                                              clip ? (const uint32_t *)dcl.p : nullptr, flank, (hite_call *)dcalls.p, (uint8_t *)dcons.p,
+                                              cons_cap, stats_out, nullptr);
     hipError_t es = hipDeviceSynchronize();
     if (rc == HITE_OK || rc == HITE_ECAP) {
         if (es == hipSuccess) es = hipMemcpy(calls, dcalls.p, sizeof(hite_call) * n_cand, hipMemcpyDeviceToHost);
@@ -550,4 +592,13 @@ extern "C" int hite_flank_region_align(hite_ctx *ctx, int32_t te_type, int32_t p
     hite_pipeline_release(state);
     if (es != hipSuccess) return HITE_EHIP;
     return rc;
+}
+
+extern "C" int hite_flank_region_align(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
+                                       const int64_t *cand_off, const int32_t *copy_first, int64_t n_copies,
+                                       const int32_t *contig, const int64_t *start1, const int64_t *end1,
+                                       const uint8_t *minus, int32_t flank, hite_call *calls, uint8_t *cons, int64_t cons_cap,
+                                       int64_t *stats_out) {
+    return hite_flank_region_align_clip(ctx, te_type, plant, n_cand, cand, cand_off, copy_first, n_copies, contig, start1, end1, minus,
+                                        nullptr, flank, calls, cons, cons_cap, stats_out);
 }

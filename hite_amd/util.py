@@ -1310,9 +1310,11 @@ def get_full_length_copies_minimap2(query_path, reference, temp_dir=None, max_co
     later by the longest-100 rule (ready_for_MSA.sh 100 100), so max_copy_num / temp_dir / threads have nothing to steer here."""
     ctx = set_reference(reference, device)
     names, contigs = read_fasta(query_path)
-    tab = ctx.find_copies([contigs[n] for n in names])
+    tab = ctx.find_copies([contigs[n] for n in names], clips=True)
     rev = {v: k for k, v in _PACKED["names"].items()}
-    return {n: [(rev[c], s_, e_, e_ - s_ + 1, "-" if m_ else "+") for (c, s_, e_, m_, _an) in t] for n, t in zip(names, tab) if t}
+    # (a 6th field beside the reference's five: the clip word of the record -- zero unless the records are aligned intervals,
+    # hite_copy_config(1) -- which flank_region_align_v5 hands to the star alignment)
+    return {n: [(rev[c], s_, e_, e_ - s_ + 1, "-" if m_ else "+", cl_) for (c, s_, e_, m_, _an, cl_) in t] for n, t in zip(names, tab) if t}
 
 
 def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, reference, split_ref_dir, TE_type, tmp_output_dir,
@@ -1340,7 +1342,7 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
             if key in seen:
                 continue
             seen[key] = 1
-            lst.append((idx[cp[0]], int(cp[1]), int(cp[2]), 1 if cp[4] == "-" else 0))
+            lst.append((idx[cp[0]], int(cp[1]), int(cp[2]), 1 if cp[4] == "-" else 0, 0, int(cp[5]) if len(cp) > 5 else 0))
         copies.append(lst)
     res, _stats = ctx.flank_region_align(TE_type, cands, copies, plant=int(plant), flank=int(flanking_len)) if qnames else ([], None)
     true_tes, low_copy = bucket_results(TE_type, [(q if is_te else None, cons if is_te else None, info, copy_count)

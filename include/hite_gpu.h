@@ -24,6 +24,12 @@
 extern "C" {
 #endif
 
+/* A row window handed to the star alignment may BEGIN and END with runs of this byte (never the centre, row 0 of a candidate): it
+ * takes part in the pairwise alignment as a base that matches nothing (1 per column against a centre base instead of 3 per base of a
+ * gap), and is removed afterwards -- centre positions aligned to it become gaps of the row, the ops refer to the row without the
+ * runs.  hite_flank_region_align_clip[_dev] pads the rows of copy records in the reference's coordinates with it (see there). */
+#define HITE_ROW_PAD 0x2e   /* '.' */
+
 #define HITE_OK 0
 #define HITE_EINVAL (-1)   /* bad argument */
 #define HITE_ENOMEM (-2)   /* host or device allocation failed */
@@ -344,6 +350,13 @@ int hite_find_copies_restricted_dev(hite_ctx *ctx, void **state_io, int32_t n_ca
 int hite_find_copies_restricted(hite_ctx *ctx, void **state_io, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off,
                                 int64_t cap, int32_t *copy_first, int32_t *contig, int64_t *start1, int64_t *end1, uint8_t *minus,
                                 int32_t *anchors, int64_t *n_out);
+/* The clip words of the records of the last hite_find_copies[_dev] / _restricted[_dev] call on this index, in record order: candidate
+ * bases the left | right << 16 end extension cut off (minimap2 would soft-clip them; each <= 5 % of the candidate), in the orientation
+ * of the genome.  Zero for whole-candidate intervals (the default: they are inside the interval); for aligned intervals
+ * (hite_copy_config(1)) hite_flank_region_align_clip[_dev] takes them.  _dev: *d_clip (NULL when the call found nothing) lives as long
+ * as the copy table; host form: cap >= the number of records, else HITE_ECAP. */
+int hite_copy_clips_dev(void *state, const uint32_t **d_clip, int64_t *n);
+int hite_copy_clips(void *state, int64_t cap, uint32_t *clip);
 
 /* ---- star alignment: this build's GPU-native stage where the reference runs the external
  * `mafft --preservecase --quiet --thread 1` (Util.py:10416; third-party, unpinned, absent -> parity unpinned against
@@ -429,6 +442,27 @@ int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32_t te_type,
                                 int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1, const int64_t *d_end1,
                                 const uint8_t *d_minus, int32_t flank, hite_call *d_calls, uint8_t *d_cons,
                                 int64_t cons_cap, int64_t *stats_out, void *stream);
+/* The same stage for copy records in the REFERENCE'S coordinates (hite_copy_config(1): reference_start + 1 .. reference_end of the
+ * alignment, Util.py:8026, as get_copies_minimap2 hands them to flank_region_align_v5).  Such a record covers only the part of the
+ * candidate that aligned; `clip` (per copy record, may be NULL = no pads: hite_flank_region_align) says how many candidate bases the
+ * two end extensions clipped -- left | right << 16, in the orientation of the genome (hite_copy_clips[_dev]) -- and the row's window
+ * (interval + flanks, Util.py:8110-8125) is padded by them with HITE_ROW_PAD: in front by the left clip (a minus copy: the right
+ * one, its window is reverse-complemented), behind by the other; the first500 + last500 form of a long window (Util.py:8119) is
+ * cut from the padded window; the <= 100 rows are chosen by the length of the genome window.  A padded row faces the part of the
+ * centre its copy was found with, so its path stays on the diagonal; the pads leave the alignment as gaps of the row (where mafft,
+ * which does not charge terminal gaps like internal ones, leaves such a row unaligned).  Without the pads every such row is aligned
+ * GLOBALLY at 3 per gap base to a centre that is clip_l + clip_r bases longer: on config C2 8 633 rows left the band and TE calls
+ * fell by a fifth (profiles/r04_scale_tests.txt); with them the mode calls as many TEs as the whole-candidate default
+ * (tests/test_gpu_scale.py::test_c2_reference_coordinates_with_padded_rows). */
+int hite_flank_region_align_clip(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
+                                 const int64_t *cand_off, const int32_t *copy_first, int64_t n_copies, const int32_t *contig,
+                                 const int64_t *start1, const int64_t *end1, const uint8_t *minus, const uint32_t *clip, int32_t flank,
+                                 hite_call *calls, uint8_t *cons, int64_t cons_cap, int64_t *stats_out);
+int hite_flank_region_align_clip_dev(hite_ctx *ctx, void **state_io, int32_t te_type, int32_t plant, int32_t n_cand,
+                                     const uint8_t *d_cand, const int64_t *d_cand_off, const int32_t *d_copy_first,
+                                     int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1, const int64_t *d_end1,
+                                     const uint8_t *d_minus, const uint32_t *d_clip, int32_t flank, hite_call *d_calls,
+                                     uint8_t *d_cons, int64_t cons_cap, int64_t *stats_out, void *stream);
 void hite_pipeline_release(void *state);
 
 /* ---- per-stage profiling: HIP events recorded on the launch stream around each kernel of the

@@ -146,7 +146,7 @@ static int cmp_hit(const void *a, const void *b) {
     if (x->d != y->d) return x->d < y->d ? -1 : 1;
     return 0; /* order among equal (c, rel, d) does not influence the result */
 }
-typedef struct { int32_t c, contig, minus, anch; int64_t start1, end1, gstart; } copy_t;
+typedef struct { int32_t c, contig, minus, anch; int64_t start1, end1, gstart; int32_t clip_l, clip_r; } copy_t;
 static int cmp_copy(const void *a, const void *b) {
     const copy_t *x = (const copy_t *)a, *y = (const copy_t *)b;
     if (x->c != y->c) return x->c < y->c ? -1 : 1;
@@ -244,6 +244,15 @@ void orc_find_copies_config(int aligned_interval) { g_aligned_interval = aligned
 /* seconds the last orc_find_copies call spent building its index (bench.py separates residency set-up from the lookups) */
 static double g_index_seconds = 0.0;
 double orc_find_copies_index_seconds(void) { return g_index_seconds; }
+
+/* candidate bases the two end extensions clipped (left / right in the orientation of the GENOME), per copy record of the last
+ * orc_find_copies call, in output order: what hite_find_copies hands on beside the records as `clip` (see hite_gpu.h) */
+static int32_t *g_clip = NULL;
+static int64_t g_nclip = 0;
+int64_t orc_find_copies_clips(int64_t cap, int32_t *clip_l, int32_t *clip_r) {
+    for (int64_t t = 0; t < g_nclip && t < cap; t++) { clip_l[t] = g_clip[2 * t]; clip_r[t] = g_clip[2 * t + 1]; }
+    return g_nclip;
+}
 
 /* one search of the candidates `sel[0..nsel)` (NULL: all) in the (W, K) minimizer index of the genome -> the chains kept, sorted by
  * (candidate, anchors descending, start, strand); *index_s += seconds spent building the index */
@@ -343,6 +352,10 @@ static copy_t *find_pass(const uint8_t *genome, const int64_t *contig_off, int n
                 if (ncp == ccap) { ccap *= 2; cps = (copy_t *)realloc(cps, sizeof(copy_t) * ccap); }
                 cps[ncp].c = hits[i].c; cps[ncp].contig = ctg; cps[ncp].minus = hits[i].rel; cps[ncp].anch = (int32_t)na;
                 cps[ncp].start1 = s0 - cb + 1; cps[ncp].end1 = e0 - cb; cps[ncp].gstart = s0;
+                /* aligned interval: the clipped candidate bases (in the orientation of the genome) travel beside the record; whole-candidate
+                 * interval: they are inside it */
+                cps[ncp].clip_l = g_aligned_interval ? (int32_t)(clip_l > 0xffff ? 0xffff : clip_l) : 0;
+                cps[ncp].clip_r = g_aligned_interval ? (int32_t)(clip_r > 0xffff ? 0xffff : clip_r) : 0;
                 ncp++;
             }
         }
@@ -396,6 +409,9 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
     int64_t nout = 0;
     copy_first[0] = 0;
     int64_t p = 0;
+    free(g_clip);
+    g_clip = (int32_t *)malloc(sizeof(int32_t) * 2 * (size_t)(cap > 0 ? cap : 1));
+    g_nclip = 0;
     for (int c = 0; c < ncand; c++) {
         int kept = 0;
         const int far = use2 && use2[c];
@@ -404,6 +420,7 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
                 if (nout >= cap) { free(cps); free(cps2); free(first2); free(use2); return ORC_ECAP; }
                 contig[nout] = cps2[t].contig; start1[nout] = cps2[t].start1; end1[nout] = cps2[t].end1;
                 minus[nout] = (uint8_t)cps2[t].minus; anchors[nout] = cps2[t].anch;
+                g_clip[2 * nout] = cps2[t].clip_l; g_clip[2 * nout + 1] = cps2[t].clip_r;
                 nout++;
             }
         }
@@ -412,6 +429,7 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
                 if (nout >= cap) { free(cps); free(cps2); free(first2); free(use2); return ORC_ECAP; }
                 contig[nout] = cps[p].contig; start1[nout] = cps[p].start1; end1[nout] = cps[p].end1;
                 minus[nout] = (uint8_t)cps[p].minus; anchors[nout] = cps[p].anch;
+                g_clip[2 * nout] = cps[p].clip_l; g_clip[2 * nout + 1] = cps[p].clip_r;
                 nout++; kept++;
             }
             p++;
@@ -419,6 +437,7 @@ int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int nc
         copy_first[c + 1] = (int32_t)nout;
     }
     free(cps); free(cps2); free(first2); free(use2);
+    g_nclip = nout;
     return nout;
 }
 

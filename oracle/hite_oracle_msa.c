@@ -47,6 +47,7 @@
 #define SLICE_WORDS 2     /* rows kept for the traceback (and watched by the steering): the middle 64 of the band */
 #define MARGIN 48         /* exact mode: the first wider band is the smallest with 32 NW >= U / GAP + MARGIN */
 
+#define ORC_ROW_PAD 0x2e   /* '.' */
 static inline int is_acgt(unsigned c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
 /* value of row index k (may be -1: the cell above the band, or >= W: rows that have not entered yet) of a stored column */
@@ -235,14 +236,35 @@ int orc_star_msa2(const uint8_t *win, const int64_t *win_off, int R, int *cols_o
     uint16_t *ops = (uint16_t *)calloc((size_t)R * (m + 1), sizeof(uint16_t));
     int *rowsrc = (int *)malloc(sizeof(int) * (size_t)R);
     if (!ops || !rowsrc) { free(ops); free(rowsrc); return ORC_EINVAL; }
+    /* rows that begin / end with ORC_ROW_PAD (HITE_ROW_PAD of include/hite_gpu.h; never the centre): the pads take part in the pairwise
+     * alignment as bases that match nothing and leave afterwards -- a centre position aligned to one becomes a gap of the row, the ops
+     * are rewritten for the row without them; rb / rn = every row's window as the rest of the stage sees it */
+    const uint8_t **rb = (const uint8_t **)malloc(sizeof(uint8_t *) * (size_t)R);
+    int *rn = (int *)malloc(sizeof(int) * (size_t)R);
+    if (!rb || !rn) { free(ops); free(rowsrc); free(rb); free(rn); return ORC_EINVAL; }
+    rb[0] = a; rn[0] = m;
     int K = 0;
     rowsrc[K++] = 0;
     for (int r = 1; r < R; r++) {
         int n = (int)(win_off[r + 1] - win_off[r]);
-        if (n <= 0 || n > 32767) { free(ops); free(rowsrc); return ORC_EINVAL; }
+        if (n <= 0 || n > 32767) { free(ops); free(rowsrc); free(rb); free(rn); return ORC_EINVAL; }
+        const uint8_t *b = win + win_off[r];
         int32_t o[5];
-        int rc = orc_align_pair(a, m, win + win_off[r], n, g_exact, ops + (size_t)K * (m + 1), o);
-        if (rc < 0) { free(ops); free(rowsrc); return rc; }
+        uint16_t *op = ops + (size_t)K * (m + 1);
+        int rc = orc_align_pair(a, m, b, n, g_exact, op, o);
+        if (rc < 0) { free(ops); free(rowsrc); free(rb); free(rn); return rc; }
+        int pf = 0, pb = 0;
+        while (pf < n && b[pf] == ORC_ROW_PAD) pf++;
+        while (pf + pb < n && b[n - 1 - pb] == ORC_ROW_PAD) pb++;
+        rb[r] = b + pf; rn[r] = n - pf - pb;
+        if (rc == 0 && (pf || pb)) {
+            for (int p = 0; p < m; p++) {
+                const int q = op[p] & 0x7fff;
+                if (q < pf) op[p] = 0x8000;
+                else if (q >= n - pb) op[p] = (uint16_t)(0x8000 | (n - pf - pb));
+                else op[p] = (uint16_t)((op[p] & 0x8000) | (q - pf));
+            }
+        }
         if (rc == 0) rowsrc[K++] = r;
     }
     /* ins[r][p], gap[r][p] from the ops */
@@ -250,7 +272,7 @@ int orc_star_msa2(const uint8_t *win, const int64_t *win_off, int R, int *cols_o
     int *bstart = (int *)calloc(m + 2, sizeof(int));
     for (int kr = 1; kr < K; kr++) {
         const uint16_t *o = ops + (size_t)kr * (m + 1);
-        const int n = (int)(win_off[rowsrc[kr] + 1] - win_off[rowsrc[kr]]);
+        const int n = rn[rowsrc[kr]];
         int next = 0;
         for (int p = 0; p <= m; p++) {
             int q = p < m ? (o[p] & 0x7fff) : n;
@@ -265,11 +287,11 @@ int orc_star_msa2(const uint8_t *win, const int64_t *win_off, int R, int *cols_o
     *cols_out = C;
     if (rows_out) *rows_out = K;
     if (msa) {
-        if ((int64_t)K * C > cap) { free(ops); free(insmax); free(bstart); free(rowsrc); return ORC_ECAP; }
+        if ((int64_t)K * C > cap) { free(ops); free(insmax); free(bstart); free(rowsrc); free(rb); free(rn); return ORC_ECAP; }
         memset(msa, '-', (size_t)K * C);
         for (int kr = 0; kr < K; kr++) {
-            const uint8_t *b = win + win_off[rowsrc[kr]];
-            const int n = (int)(win_off[rowsrc[kr] + 1] - win_off[rowsrc[kr]]);
+            const uint8_t *b = rb[rowsrc[kr]];
+            const int n = rn[rowsrc[kr]];
             uint8_t *row = msa + (size_t)kr * C;
             if (kr == 0) { for (int p = 0; p < m; p++) row[bstart[p] + insmax[p]] = b[p]; continue; }
             const uint16_t *o = ops + (size_t)kr * (m + 1);
@@ -284,7 +306,7 @@ int orc_star_msa2(const uint8_t *win, const int64_t *win_off, int R, int *cols_o
             }
         }
     }
-    free(ops); free(insmax); free(bstart); free(rowsrc);
+    free(ops); free(insmax); free(bstart); free(rowsrc); free(rb); free(rn);
     return 0;
 }
 

@@ -274,8 +274,9 @@ def align_pair(a, b, exact_cap=8):
     return (None if rc else ops[:len(a)]), info
 
 
-def find_copies(contigs, cands):
-    """this build's minimap2 stand-in: -> per candidate list of (contig, start1, end1, minus, anchors)"""
+def find_copies(contigs, cands, clips=False):
+    """this build's minimap2 stand-in: -> per candidate list of (contig, start1, end1, minus, anchors); clips=True: + the clip word
+    of the record (clipped candidate bases left | right << 16; zero unless find_copies_config(True)), as Context.find_copies"""
     gb = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]
     coff = np.zeros(len(gb) + 1, dtype=np.int64)
     np.cumsum([len(c) for c in gb], out=coff[1:])
@@ -294,6 +295,12 @@ def find_copies(contigs, cands):
     n = lib().orc_find_copies(_ptr(gbuf, u8p), _ptr(coff, i64p), len(gb), _ptr(qbuf, u8p), _ptr(qoff, i64p), len(cb), C.c_int64(cap),
                               _ptr(cf, i32p), _ptr(ct, i32p), _ptr(s1, i64p), _ptr(e1, i64p), _ptr(mn, u8p), _ptr(an, i32p))
     assert n >= 0, n
+    if clips:
+        cl, cr = np.zeros(n + 1, dtype=np.int32), np.zeros(n + 1, dtype=np.int32)
+        lib().orc_find_copies_clips.restype = C.c_int64
+        assert lib().orc_find_copies_clips(C.c_int64(n), _ptr(cl, i32p), _ptr(cr, i32p)) == n
+        return [[(int(ct[i]), int(s1[i]), int(e1[i]), int(mn[i]), int(an[i]), int(cl[i]) | (int(cr[i]) << 16)) for i in range(cf[c], cf[c + 1])]
+                for c in range(len(cb))]
     return [[(int(ct[i]), int(s1[i]), int(e1[i]), int(mn[i]), int(an[i])) for i in range(cf[c], cf[c + 1])] for c in range(len(cb))]
 
 

@@ -6,6 +6,7 @@ import numpy as np
 import oracle_lib as O
 
 MAXROWS = 100
+ROW_PAD = "."      # HITE_ROW_PAD (include/hite_gpu.h)
 
 
 def window_name(copy, contig_names=None):
@@ -31,8 +32,9 @@ def select_rows(lens, names=None):
     return sorted(order)
 
 
-def judge_windows(te_type, cand, windows, plant, names=None, keep_msa=None):
-    keep = select_rows([len(w) for w in windows], names)
+def judge_windows(te_type, cand, windows, plant, names=None, keep_msa=None, lens=None):
+    """lens: the lengths the row selection goes by when they are not the windows' own (padded rows: the genome window's length)"""
+    keep = select_rows(lens if lens is not None else [len(w) for w in windows], names)
     wins = [windows[i] for i in keep]
     m = O.star_msa(wins)
     if m is None:
@@ -77,14 +79,26 @@ def anchor_class(cand, msa):
 
 
 def fine_stage_candidate(te_type, cand, copies, contigs, plant=1, flank=50, contig_names=None, keep_msa=None):
-    """copies: (contig_index, start1, end1, minus) -> [is_TE, info, cons, row_num]; keep_msa: a list that receives the cleaned
-    alignment of every pass that was judged"""
-    full, trunc, fn, tn = [], [], [], []
+    """copies: (contig_index, start1, end1, minus[, anchors, clip]) -> [is_TE, info, cons, row_num]; keep_msa: a list that receives
+    the cleaned alignment of every pass that was judged.  clip (find_copies(..., clips=True); non-zero only for records in the
+    reference's coordinates): candidate bases clipped left | right << 16 in the orientation of the genome -- the window is padded by
+    them with ROW_PAD (hite_flank_region_align_clip; the first500 + last500 form is cut from the padded window), the rows are still
+    chosen by the length of the genome window"""
+    full, trunc, fn, tn, fl = [], [], [], [], []
     for cp in copies:
         (ci, s, e, mn) = cp[:4]
         w, t = O.flank_window(contigs[ci], s, e, "-" if mn else "+", flank)
         if w is None:
             continue
+        clip = int(cp[5]) if len(cp) > 5 else 0
+        fl.append(len(w))
+        if clip:
+            a, b = clip & 0xffff, clip >> 16
+            if mn:
+                a, b = b, a
+            w = ROW_PAD * a + w + ROW_PAD * b
+            if t is not None:
+                t = w[:500] + w[-500:]
         full.append(w)
         fn.append(window_name(cp, contig_names))
         if t is not None:
@@ -96,7 +110,7 @@ def fine_stage_candidate(te_type, cand, copies, contigs, plant=1, flank=50, cont
         res, _ = judge_windows(te_type, cand, trunc, plant, tn, keep_msa)
         if res[0] == "EXC" or not res[0]:
             return res if res[0] != "EXC" else [False, "EXC", "", 0]
-    res, _ = judge_windows(te_type, cand, full, plant, fn, keep_msa)
+    res, _ = judge_windows(te_type, cand, full, plant, fn, keep_msa, lens=fl)
     if res[0] == "EXC":
         return [False, "EXC", "", 0]
     return res

@@ -751,6 +751,80 @@ def test_star_msa_sparse_fused(ctx):
         assert np.array_equal(m, exp)
 
 
+def test_star_msa_padded_rows(ctx):
+    """rows that begin / end with HITE_ROW_PAD (include/hite_gpu.h): the pads are aligned as bases that match nothing and leave the
+    alignment as gaps of the row -- HIP == twin, full and sparse form; the ungapped rows are the windows WITHOUT their pads; a row
+    cut short at either end and padded by what is missing aligns like the whole row with those bases blanked"""
+    rng = np.random.default_rng(99)
+    base = _families(515, 30, rows_choices=(2, 5, 12, 40), lens=(150, 400, 1200))
+    groups = []
+    for g in base:
+        rows = [g[0]]
+        for w in g[1:]:
+            a, b = (int(x) for x in rng.integers(0, 70, 2))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                rows.append(w)                                              # no pads
+            elif kind == 1:
+                rows.append("." * a + w[min(a, len(w) // 3):] )             # cut in front, padded by what was cut (or more)
+            elif kind == 2:
+                rows.append(w[: len(w) - min(b, len(w) // 3)] + "." * b)     # cut behind
+            else:
+                rows.append("." * a + w[min(a, len(w) // 3): len(w) - min(b, len(w) // 3)] + "." * b)
+        groups.append(rows)
+    groups.append(["ACGTTGCAAGGCTTAACCGGTTAAGC" * 4, "." * 104, "." * 5 + "ACGTTGCAAGGCTTAACCGGTTAAGC"[5:] + "ACGTTGCAAGGCTTAACCGGTTAAGC" + "." * 52])     # a row of pads only
+    full = ctx.star_msa(groups)
+    sparse = ctx.star_msa(groups, sparse=True)
+    n_pad_rows = 0
+    for g, f, m in zip(groups, full, sparse):
+        exp_full = O.star_msa(g)
+        assert f is not None and f.shape == exp_full.shape and np.array_equal(f, exp_full)
+        assert not (f == ord(".")).any()
+        if f.shape[0] == len(g):                 # (a row that cannot be aligned leaves, on both sides alike)
+            for r, w in enumerate(g):
+                assert bytes(f[r][f[r] != ord("-")]) == w.strip(".").encode()
+        n_pad_rows += sum(w != w.strip(".") for w in g)
+        keep = O.sparse_cols(exp_full).astype(bool)
+        exp = np.ascontiguousarray(exp_full[:, keep])
+        assert m is not None and m.shape == exp.shape and np.array_equal(m, exp)
+    assert n_pad_rows > 100
+
+
+def test_aligned_interval_mode_pads_the_rows(ctx):
+    """Records in the reference's coordinates (hite_copy_config(1): the aligned interval of Util.py:8026) carry the candidate bases
+    the end extensions clipped; hite_flank_region_align_clip pads the rows with them.  Pinned: clip words HIP == twin, the fused
+    pipeline == the oracle chain on the padded windows -- and the calls do not fall behind the whole-candidate mode's."""
+    import oracle_pipeline as OP
+    import synth_small
+
+    g = synth_small.make(23, n_fam=24)
+    ctx.genome_pack(g["contigs"])
+    ctx.release_copy_index()
+    whole = ctx.find_copies(g["cands"], clips=True)
+    assert all(cp[5] == 0 for t in whole for cp in t)            # whole-candidate intervals: nothing to pad
+    res_whole, _ = ctx.flank_region_align("tir", g["cands"], whole, plant=1)
+    try:
+        ctx.copy_config(True)
+        O.find_copies_config(True)
+        tab = ctx.find_copies(g["cands"], clips=True)
+        assert tab == O.find_copies(g["contigs"], g["cands"], clips=True)
+    finally:
+        ctx.copy_config(False)
+        O.find_copies_config(False)
+    assert sum(cp[5] != 0 for t in tab for cp in t) > 20
+    res, _ = ctx.flank_region_align("tir", g["cands"], tab, plant=1)
+    for cand, cp, r in zip(g["cands"], tab, res):
+        assert [r[0], r[1], r[2], r[3]] == OP.fine_stage_candidate("tir", cand, cp, g["contigs"], plant=1)
+    # without the clip words the same records are aligned globally, as before (and as an external copy table would be)
+    bare = [[cp[:4] for cp in t] for t in tab]
+    res_bare, _ = ctx.flank_region_align("tir", g["cands"], bare, plant=1)
+    for cand, cp, r in zip(g["cands"], bare, res_bare):
+        assert [r[0], r[1], r[2], r[3]] == OP.fine_stage_candidate("tir", cand, cp, g["contigs"], plant=1)
+    te = lambda rr: sum(bool(r[0]) for r in rr)  # noqa: E731
+    print("TE calls: whole-candidate %d, aligned + pads %d, aligned without pads %d of %d" % (te(res_whole), te(res), te(res_bare), len(res)))
+    assert te(res) >= te(res_bare) and te(res) >= 0.9 * te(res_whole)
+
+
 def test_seed_allvsall_vs_twin(ctx):
     """all-vs-all seeding (stage 3.1, the build's blastn stand-in): HIP == twin, record for record, incl. segment splits;
     the table drives FMEA to the same intervals as the oracle's FMEA on the twin's table"""

@@ -38,6 +38,7 @@ def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",), **workload_kw):
     d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
     ctx.align_stats(reset=True)
     nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
+    p_cl = ctx.copy_clips_dev()        # zero words unless the records are aligned intervals (HITE_COPY_INTERVAL=aligned): then the rows are padded
     # the same candidates and copy table judged as Helitron / non-LTR as well (judge_Helitron_transposons.py:86-97,
     # judge_Non_LTR_transposons.py:48-51 run the same flank_region_align_v5 with another TE_type)
     other = {}
@@ -45,15 +46,16 @@ def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",), **workload_kw):
         if te == "tir":
             continue
         stats = ctx.flank_region_align_dev(te, 1, n, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
-                                           d_calls.data_ptr(), d_cons.data_ptr(), cap)
+                                           d_calls.data_ptr(), d_cons.data_ptr(), cap, d_clip=p_cl)
         torch.cuda.synchronize()
         other[te] = (d_calls.cpu().numpy().view(CALL_DTYPE).copy(), d_cons.cpu().numpy().copy())
     ctx.align_stats(reset=True)
     stats = ctx.flank_region_align_dev("tir", 1, n, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
-                                       d_calls.data_ptr(), d_cons.data_ptr(), cap)
+                                       d_calls.data_ptr(), d_cons.data_ptr(), cap, d_clip=p_cl)
     torch.cuda.synchronize()
     found = dict(copy_first=ctx.download(p_cf, n + 1, np.int32), contig=ctx.download(p_ct, nc, np.int32),
-                 start1=ctx.download(p_s1, nc, np.int64), end1=ctx.download(p_e1, nc, np.int64), minus=ctx.download(p_mn, nc, np.uint8))
+                 start1=ctx.download(p_s1, nc, np.int64), end1=ctx.download(p_e1, nc, np.int64), minus=ctx.download(p_mn, nc, np.uint8),
+                 clip=ctx.download(p_cl, nc, np.uint32) if p_cl else np.zeros(nc, dtype=np.uint32))
     return dict(w=w, ctx=ctx, n=n, calls=d_calls.cpu().numpy().view(CALL_DTYPE).copy(), cons=d_cons.cpu().numpy(), found=found,
                 other=other, stats=stats, align=ctx.align_stats(), genome=w["genome"].cpu().numpy(), seed=seed, n_tir=n_tir, n_ltr=n_ltr)
 
@@ -72,7 +74,8 @@ def _oracle_worker(job):
     out = []
     for c in cands:
         a, b = int(z["copy_first"][c]), int(z["copy_first"][c + 1])
-        copies = [(int(z["contig"][i]), int(z["start1"][i]), int(z["end1"][i]), int(z["minus"][i])) for i in range(a, b)]
+        copies = [(int(z["contig"][i]), int(z["start1"][i]), int(z["end1"][i]), int(z["minus"][i]), 0, int(z["clip"][i]) if "clip" in z else 0)
+                  for i in range(a, b)]
         cand = z["cands"][z["cand_off"][c]:z["cand_off"][c + 1]].tobytes().decode()
         out.append((int(c), OP.fine_stage_candidate(te_type, cand, copies, contigs, plant=1)))
     return out
@@ -94,7 +97,7 @@ def oracle_check(R, count, seed, te_type="tir", workers=None):
         path = os.path.join(d, "w")
         np.asarray(R["genome"], dtype=np.uint8).tofile(path + ".genome")
         np.savez(path + ".npz", contig_off=np.asarray(w["contig_off"]), cands=w["cands"], cand_off=w["cand_off"], copy_first=f["copy_first"],
-                 contig=f["contig"], start1=f["start1"], end1=f["end1"], minus=f["minus"])
+                 contig=f["contig"], start1=f["start1"], end1=f["end1"], minus=f["minus"], clip=f["clip"])
         R["oracle_files"] = (d, path)
     path = R["oracle_files"][1]
     jobs = [(path, int(len(R["genome"])), te_type, picks[k::workers]) for k in range(workers)]
@@ -211,6 +214,39 @@ def test_c2_fine_stage_matches_oracle_chain(c2):
     st = c2["align"]
     assert st["dropped"] == 0 and st["pairs"] > 50_000
     assert st["certified"] >= 0.80 * st["pairs"]            # measured r02: 0.89 (exact_cap 8)
+
+
+def test_c2_reference_coordinates_with_padded_rows(c2):
+    """C2 with the copy records in the reference's coordinates (HITE_COPY_INTERVAL=aligned: reference_start + 1 .. reference_end,
+    Util.py:8026) and the rows padded by the clipped candidate bases (hite_flank_region_align_clip_dev): the mode is usable -- hardly
+    any wide fall-back (8 633 without the pads, round 4), TE calls not behind the default mode's --, and pinned: 1 000 random
+    candidates re-judged by the oracle chain on the same records + clip words."""
+    from hite_amd import _lib as hl
+
+    base_te = int((c2["calls"]["is_te"] != 0).sum())
+    os.environ["HITE_COPY_INTERVAL"] = "aligned"
+    hl.load().hite_copy_config(-1)
+    try:
+        R = run_fine(100, 500, 0, c2["seed"])
+    finally:
+        os.environ.pop("HITE_COPY_INTERVAL", None)
+        hl.load().hite_copy_config(-1)
+    try:
+        te = int((R["calls"]["is_te"] != 0).sum())
+        n_tir, called, checked, exact, near = boundary_stats(R)
+        st = R["align"]
+        print("C2, reference coordinates + padded rows: %d copies (%d with a clip); TE calls %d (default mode %d); of %d checked: both ends exact %d, "
+              "within 3 bp %d; wide fall-backs %d, dropped %d, certified %d of %d pairs"
+              % (len(R["found"]["contig"]), int((R["found"]["clip"] != 0).sum()), te, base_te, checked, exact, near, st["fallback"], st["dropped"],
+                 st["certified"], st["pairs"]))
+        assert (R["found"]["clip"] != 0).sum() > 10000
+        assert st["fallback"] < 100 and st["dropped"] == 0
+        assert te >= 0.95 * base_te
+        bad, _n = oracle_check(R, 1000, 3)
+        assert bad == []
+    finally:
+        _release_oracle_files(R)
+        R["ctx"].close()
 
 
 def test_c2_wider_bands_never_lower_a_cost(c2):

@@ -612,3 +612,28 @@ def test_twin_far_pass_is_off_by_default_and_only_adds():
     assert O.find_copies(g["contigs"], g["cands"]) == base
     assert all(len(b) >= len(a) for a, b in zip(base, far))
     assert all(a == b for a, b in zip(base, far) if len(a) == len(b))
+
+
+def test_twin_padded_rows_and_the_aligned_interval_mode():
+    """HITE_ROW_PAD through the twins (the GPU tests pin HIP == these): a padded row leaves the star alignment without its pads, and
+    on records in the reference's coordinates (aligned intervals + clip words) the oracle chain with padded rows calls at least as
+    many candidates TE as with the bare aligned windows (where every row is globally aligned to a centre it covers only in part)."""
+    import oracle_pipeline as OP
+    import synth_small
+
+    rows = ["ACGTTGCAAGGCTTAACCGGTTAAGCAT" * 6, "." * 17 + ("ACGTTGCAAGGCTTAACCGGTTAAGCAT" * 6)[17:150] + "." * 18, "." * 168]
+    m = O.star_msa(rows)
+    assert m.shape[0] == 3 and not (m == ord(".")).any()
+    assert [bytes(r[r != ord("-")]) for r in m] == [w.strip(".").encode() for w in rows]
+    assert bytes(m[1][:17]) == b"-" * 17 and bytes(m[1][-18:]) == b"-" * 18 and bytes(m[2]) == b"-" * m.shape[1]
+    g = synth_small.make(23, n_fam=24)
+    try:
+        O.find_copies_config(True)
+        tab = O.find_copies(g["contigs"], g["cands"], clips=True)
+    finally:
+        O.find_copies_config(False)
+    whole = O.find_copies(g["contigs"], g["cands"], clips=True)
+    assert all(cp[5] == 0 for t in whole for cp in t) and sum(cp[5] != 0 for t in tab for cp in t) > 20
+    te = lambda table: sum(bool(OP.fine_stage_candidate("tir", c, t, g["contigs"], plant=1)[0]) for c, t in zip(g["cands"], table))  # noqa: E731
+    n_pad, n_bare, n_whole = te(tab), te([[cp[:4] for cp in t] for t in tab]), te(whole)
+    assert n_pad >= n_bare and n_pad >= 0.9 * n_whole, (n_pad, n_bare, n_whole)
