@@ -825,6 +825,35 @@ def test_aligned_interval_mode_pads_the_rows(ctx):
     assert te(res) >= te(res_bare) and te(res) >= 0.9 * te(res_whole)
 
 
+def test_aligned_interval_mode_through_the_host_mirror(ctx, tmp_path):
+    """util.get_full_length_copies_minimap2 -> util.flank_region_align_v5 (the reference's two functions, Util.py:7933 / 8032) in the
+    reference-coordinate mode: the clip words travel as a 6th field of the copy tuples and the stage's calls are the direct call's"""
+    import synth_small
+    from hite_amd import util
+
+    g = synth_small.make(23, n_fam=24)
+    gref = tmp_path / "g.fa"
+    gref.write_text("".join(">c%d\n%s\n" % (i, s) for i, s in enumerate(g["contigs"])))
+    cand = tmp_path / "cand.fa"
+    cand.write_text("".join(">q%d\n%s\n" % (i, s) for i, s in enumerate(g["cands"])))
+    real, low = tmp_path / "real.fa", tmp_path / "low.fa"
+    uctx = util.set_reference(str(gref))
+    try:
+        uctx.copy_config(True)
+        cps = util.get_full_length_copies_minimap2(str(cand), str(gref))
+        assert sum(cp[5] != 0 for v in cps.values() for cp in v) > 20
+        tab = uctx.find_copies(g["cands"], clips=True)
+        res, _ = uctx.flank_region_align("tir", g["cands"], tab, plant=1)
+        # (after the direct call: the low-copy rescue inside the stage packs other sequences into the context)
+        t, l = util.flank_region_align_v5(str(cand), str(real), 50, str(gref), None, "tir", str(tmp_path), 1, 0, None, "", 1, 0, 0, str(low))
+    finally:
+        uctx.copy_config(False)
+    direct = {"q%d" % i: r[2] for i, r in enumerate(res) if r[0]}
+    both = dict(t, **l)
+    assert len(direct) >= 6 and len(both) >= 3
+    assert all(n in direct and s == direct[n] for n, s in both.items())     # (TG..CA consensi and unrescued low-copy ones are dropped on the way)
+
+
 def test_seed_allvsall_vs_twin(ctx):
     """all-vs-all seeding (stage 3.1, the build's blastn stand-in): HIP == twin, record for record, incl. segment splits;
     the table drives FMEA to the same intervals as the oracle's FMEA on the twin's table"""
