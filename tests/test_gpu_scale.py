@@ -38,7 +38,9 @@ def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",), **workload_kw):
     d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
     ctx.align_stats(reset=True)
     nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
-    p_cl = ctx.copy_clips_dev()        # zero words unless the records are aligned intervals (HITE_COPY_INTERVAL=aligned): then the rows are padded
+    # zero words unless the records are aligned intervals (HITE_COPY_INTERVAL=aligned): then the rows are padded (HITE_TEST_NO_CLIP=1,
+    # tools/copy_interval_modes.py: the bare windows, as for a copy table that carries no clip words)
+    p_cl = 0 if os.environ.get("HITE_TEST_NO_CLIP") == "1" else ctx.copy_clips_dev()
     # the same candidates and copy table judged as Helitron / non-LTR as well (judge_Helitron_transposons.py:86-97,
     # judge_Non_LTR_transposons.py:48-51 run the same flank_region_align_v5 with another TE_type)
     other = {}
