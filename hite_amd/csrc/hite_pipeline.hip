@@ -205,7 +205,12 @@ __device__ __forceinline__ void emit_padded(const uint32_t *__restrict__ bases, 
     const int64_t off = ws + n1 - a;                                              // first window position wanted
     int64_t n2 = len - off; n2 = n2 < 0 ? 0 : (n2 > cnt - n1 ? cnt - n1 : n2);    // genome bytes
     for (int64_t i = lane; i < n1; i += 64) dst[i] = HITE_ROW_PAD;
-    if (n2 > 0) emit_span(bases, nmask, g_lo, len, mn, off, n2, dst + n1, lane);
+    if (n2 > 0) {       // (the pads shift the bases off the slot's alignment: up to 3 single bytes first, so that the rest goes in 16-byte stores)
+        const int64_t lead = (int64_t)((0 - (uintptr_t)(dst + n1)) & 3);
+        const int64_t l4 = lead < n2 ? lead : n2;
+        if (l4) emit_span4(bases, nmask, g_lo, len, mn, off, l4, dst + n1, lane);
+        if (n2 > l4) emit_span(bases, nmask, g_lo, len, mn, off + l4, n2 - l4, dst + n1 + l4, lane);
+    }
     for (int64_t i = n1 + n2 + lane; i < cnt; i += 64) dst[i] = HITE_ROW_PAD;
 }
 
