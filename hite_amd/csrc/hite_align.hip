@@ -71,7 +71,8 @@ __device__ __forceinline__ int wave_max_i32(int v) {
     for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
     return v;
 }
-__device__ __forceinline__ bool is_acgt_byte(unsigned c) { return c - 0x41u < 32u && ((0x00080045u >> (c - 0x41u)) & 1u); }
+// (a row byte in lower case -- a pad that carries a base, HITE_IS_ROW_PAD -- is its base: bit 5 is dropped; bits 1 and 2, the 2-bit code, are the same)
+__device__ __forceinline__ bool is_acgt_byte(unsigned c) { c &= 0xdfu; return c - 0x41u < 32u && ((0x00080045u >> (c - 0x41u)) & 1u); }
 
 // one row base as the three masks that turn the centre planes into the match vector
 struct BaseMask { uint32_t m0, m1, inv; };

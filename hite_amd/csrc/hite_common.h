@@ -62,8 +62,9 @@ struct hite_ctx {
     const int32_t *d_msa_row_map;   // per compacted row: source row (NULL: identity)
     const int32_t *d_msa_rows_eff;  // per candidate: rows that were aligned (NULL: all)
     uint32_t *d_msa_lay;             // layout words of the last sparse star alignment (hite_msa.hip)
-    const int64_t *d_msa_win_off;    // per row: its window WITHOUT the HITE_ROW_PAD bytes it began / ended with (what the ops of the
-    const int32_t *d_msa_win_len;    // last star alignment refer to: layout, fill and the judge's LDS kernels read the rows through these)
+    const int64_t *d_msa_win_off;    // per row of the last star alignment: its window, and where its back pads begin (HITE_IS_ROW_PAD;
+    const int32_t *d_msa_win_len;    // layout, fill and the judge's LDS kernels read the rows through these)
+    const uint32_t *d_msa_pads;      // per row: pad bytes in front | behind << 16
     int32_t *d_contig_rank;         // byte order of "<contig name>:" among the contigs (hite_set_contig_order; NULL: the index)
     // side streams + one fork event and a join event per stream for kernels that run beside each other inside one call (the
     // judge kernels)

@@ -54,8 +54,8 @@ __device__ __forceinline__ void fill_sparse_row(Out row, const uint8_t *__restri
                 int ins = 0, q = p;
                 if (!centre) {
                     q = p < m ? (int)(oc[u] & 0x7fffu) : nrow;
-                    const unsigned op = p > 0 ? rop[p - 1] : 0u;
-                    ins = q - (p > 0 ? (int)(op & 0x7fff) + ((op >> 15) ? 0 : 1) : 0);
+                    const unsigned op = rop[p - 1];       // (p == 0: the op "before position 0" in the spare entry of the ops row above, hite_msa.hip)
+                    ins = q - ((int)(op & 0x7fff) + ((op >> 15) ? 0 : 1));
                 }
                 const int rp = q - ins;  // first inserted base
                 for (int k = 0; k < kw; k++) row[bs + k] = k < ins ? b[rp + k] : (uint8_t)'-';

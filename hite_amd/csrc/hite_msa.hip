@@ -29,6 +29,7 @@ struct MsaParams {
     int32_t *status;           // n : 0 ok, 1 failed (alignment too wide)
     const int32_t *row_map;    // total_rows : source row of each row that was aligned (NULL: identity)
     const int32_t *rows_eff;   // n : rows that were aligned (NULL: all)
+    const uint32_t *pads;      // total_rows : pad bytes in front | behind << 16 of every row (row_pad_scan_kernel)
     uint32_t *lay;             // sparse layout, one word per centre position (0..m) of candidate c at lay[ops_base[c] / 2 + p]:
                                // kept insertion columns | keep-centre << 15 | first output column << 16  (a candidate owns
                                // (R + 1)(m + 1) >= 2 (m + 1) ops, so the halves of the ops offsets never overlap)
@@ -42,10 +43,19 @@ __device__ __forceinline__ int msa_src(const int32_t *__restrict__ row_map, int6
     return row_map ? row_map[g0 + r] - (int)g0 : r;
 }
 
-// insertions of row r before centre position p (p = 0..m), from two neighbouring ops entries
-__device__ __forceinline__ int row_ins(const uint16_t *__restrict__ rop, int p, int m, int nrow) {
-    int prev_end = 0;
+// insertions of row r before centre position p (p = 0..m), from two neighbouring ops entries.  The full (non-sparse) kernels keep their
+// column widths in the centre's ops row, spare entry included: they take the row's first base as an argument instead
+__device__ __forceinline__ int row_ins_s(const uint16_t *__restrict__ rop, int p, int m, int nrow, int start) {
+    int prev_end = start;
     if (p > 0) { unsigned o = rop[p - 1]; prev_end = (int)(o & 0x7fff) + ((o >> 15) ? 0 : 1); }
+    int q = p < m ? (int)(rop[p] & 0x7fff) : nrow;
+    return q - prev_end;
+}
+// (rop[-1], the spare entry of the ops row above, holds the op "before position 0": a gap op whose q is the row's first base --
+// 0x8000 for a row without pads, ops_pad_fix_kernel; nrow = the row's end, win_len or where its back pads begin)
+__device__ __forceinline__ int row_ins(const uint16_t *__restrict__ rop, int p, int m, int nrow) {
+    const unsigned o = rop[p - 1];
+    const int prev_end = (int)(o & 0x7fff) + ((o >> 15) ? 0 : 1);
     int q = p < m ? (int)(rop[p] & 0x7fff) : nrow;
     return q - prev_end;
 }
@@ -67,7 +77,11 @@ __global__ void __launch_bounds__(256) star_layout_kernel(MsaParams P) {
     for (int base = 0; base <= m; base += 256) {
         int p = base + threadIdx.x;
         int mx = 0;
-        if (p <= m) for (int r = 1; r < R; r++) { int v = row_ins(ops + (int64_t)r * (m + 1), p, m, P.win_len[g0 + msa_src(P.row_map, g0, r)]); mx = v > mx ? v : mx; }
+        if (p <= m) for (int r = 1; r < R; r++) {
+            const int sr = msa_src(P.row_map, g0, r);
+            int v = row_ins_s(ops + (int64_t)r * (m + 1), p, m, P.win_len[g0 + sr], P.pads ? (int)(P.pads[g0 + sr] & 0xffffu) : 0);
+            mx = v > mx ? v : mx;
+        }
         int width = p <= m ? mx + (p < m ? 1 : 0) : 0;
         int tot;
         int pre = block_excl_scan(width, s_scan, &tot);
@@ -98,6 +112,7 @@ struct FillParams {
     uint8_t *msa;
     const int32_t *row_map;    // as in MsaParams
     const int32_t *rows_eff;
+    const uint32_t *pads;
 };
 
 // fill: grid (candidate, row slice); item (r, p) owns insertion block p + centre column p of row r,
@@ -117,13 +132,14 @@ __global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
     for (int r = blockIdx.y; r < R; r += gridDim.y) {
         const uint8_t *b = P.win + P.win_off[g0 + msa_src(P.row_map, g0, r)];
         const int nrow = P.win_len[g0 + msa_src(P.row_map, g0, r)];
+        const int start = P.pads ? (int)(P.pads[g0 + msa_src(P.row_map, g0, r)] & 0xffffu) : 0;
         uint8_t *row = out + (int64_t)r * C;
         const uint16_t *rop = ops + (int64_t)r * (m + 1);
         for (int p = threadIdx.x; p <= m; p += 256) {
             int ins, gap = 0, q;
             if (r == 0) { ins = 0; q = p; }
             else {
-                ins = row_ins(rop, p, m, nrow);
+                ins = row_ins_s(rop, p, m, nrow, start);
                 if (p < m) { unsigned o = rop[p]; q = (int)(o & 0x7fff); gap = (int)(o >> 15); } else q = nrow;
             }
             const int bs = bstart[p], im = insmax[p];
@@ -183,7 +199,7 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
                 unsigned long long o4[4];
                 unsigned om[4];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { o4[u] = lay_ld8(col + (int64_t)(r + u) * rs); om[u] = col[(int64_t)(r + u) * rs - (p0 > 0 ? 1 : 0)]; }   // (p0 == 0: not used; unconditional loads fly together)
+                for (int u = 0; u < 4; u++) { o4[u] = lay_ld8(col + (int64_t)(r + u) * rs); om[u] = col[(int64_t)(r + u) * rs - 1]; }   // (p0 == 0: the op "before position 0", row_ins)
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     const int wl = r + u < MSA_MAXR ? s_wl[r + u] : P.win_len[g0 + msa_src(P.row_map, g0, r + u)];
@@ -192,7 +208,7 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
                     for (int x = 0; x < 4; x++) {
                         const int p = p0 + x;
                         const unsigned oc = p < m ? (unsigned)(o4[u] >> (16 * x)) & 0xffffu : 0u;
-                        const int pe = p > 0 ? (int)(op & 0x7fffu) + ((op >> 15) ? 0 : 1) : 0;
+                        const int pe = (int)(op & 0x7fffu) + ((op >> 15) ? 0 : 1);
                         const int q = p < m ? (int)(oc & 0x7fffu) : wl;
                         const int v = p <= m ? q - pe : 0;
                         mx[x] = v > mx[x] ? v : mx[x]; npos[x] += v > 0; gapc[x] += (int)(oc >> 15);
@@ -202,13 +218,13 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
             }
             for (; r < R; r++) {
                 const unsigned long long o4 = lay_ld8(col + (int64_t)r * rs);
-                unsigned op = col[(int64_t)r * rs - (p0 > 0 ? 1 : 0)];
+                unsigned op = col[(int64_t)r * rs - 1];
                 const int wl = r < MSA_MAXR ? s_wl[r] : P.win_len[g0 + msa_src(P.row_map, g0, r)];
 #pragma unroll
                 for (int x = 0; x < 4; x++) {
                     const int p = p0 + x;
                     const unsigned oc = p < m ? (unsigned)(o4 >> (16 * x)) & 0xffffu : 0u;
-                    const int pe = p > 0 ? (int)(op & 0x7fffu) + ((op >> 15) ? 0 : 1) : 0;
+                    const int pe = (int)(op & 0x7fffu) + ((op >> 15) ? 0 : 1);
                     const int q = p < m ? (int)(oc & 0x7fffu) : wl;
                     const int v = p <= m ? q - pe : 0;
                     mx[x] = v > mx[x] ? v : mx[x]; npos[x] += v > 0; gapc[x] += (int)(oc >> 15);
@@ -343,48 +359,59 @@ __global__ void msa_rows_out_kernel(int n, const int32_t *__restrict__ row_first
     if (c < n) rows_out[c] = rows_eff ? rows_eff[c] : row_first[c + 1] - row_first[c];
 }
 
-// ---- rows that begin / end with HITE_ROW_PAD (include/hite_gpu.h) ---------------------------------------------------------
-// per row: the pads it begins and ends with, and the window without them
+// ---- rows that begin / end with pad bytes (HITE_IS_ROW_PAD, include/hite_gpu.h) ----------------------------------------------
+// per row: the pads it begins and ends with; len2 = where its back pads begin (the row's end for layout and fill)
 __global__ void row_pad_scan_kernel(int64_t total_rows, const uint8_t *__restrict__ win, const int64_t *__restrict__ win_off,
-                                    const int32_t *__restrict__ win_len, int64_t *__restrict__ off2, int32_t *__restrict__ len2,
-                                    uint32_t *__restrict__ pads) {
+                                    const int32_t *__restrict__ win_len, int32_t *__restrict__ len2, uint32_t *__restrict__ pads) {
     const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total_rows) return;
     const uint8_t *b = win + win_off[g];
     const int n = win_len[g];
     int pf = 0, pb = 0;
-    if (n > 0 && b[0] == HITE_ROW_PAD) { pf = 1; while (pf < n && b[pf] == HITE_ROW_PAD) pf++; }
-    if (pf < n && b[n - 1] == HITE_ROW_PAD) { pb = 1; while (pf + pb < n && b[n - 1 - pb] == HITE_ROW_PAD) pb++; }
-    off2[g] = win_off[g] + pf; len2[g] = n - pf - pb;
+    if (n > 0 && HITE_IS_ROW_PAD(b[0])) { pf = 1; while (pf < n && HITE_IS_ROW_PAD(b[pf])) pf++; }
+    if (pf < n && HITE_IS_ROW_PAD(b[n - 1])) { pb = 1; while (pf + pb < n && HITE_IS_ROW_PAD(b[n - 1 - pb])) pb++; }
+    len2[g] = n - pb;
     pads[g] = (uint32_t)pf | ((uint32_t)pb << 16);
 }
-// the ops of a padded row, rewritten for the row without its pads: a centre position aligned to a pad (or facing a gap among them)
-// becomes a gap of the row before its first / after its last base
-__global__ void __launch_bounds__(256) ops_unpad_kernel(int n, const int32_t *__restrict__ row_first, const int32_t *__restrict__ win_len,
-                                                        const int64_t *__restrict__ ops_base, uint16_t *__restrict__ ops_all,
-                                                        const uint32_t *__restrict__ pads, const int64_t *__restrict__ win_off,
-                                                        int64_t *__restrict__ off2, int32_t *__restrict__ len2) {
+// The pads leave the alignment WITHOUT the ops being renumbered: the row keeps its window (bases are still b[q]), its first base is
+// b[pf] and its end is n - pb.  Monotone ops: the positions aligned to front pads (q < pf) are a prefix of the row, those aligned to
+// back pads (q >= n - pb) a suffix -- a wavefront per row rewrites just these as gaps of the row (q = pf / n - pb), and writes the
+// op "before position 0" (a gap op with q = pf) into the spare entry of the ops row above, where row_ins and the layout loops read
+// it: a few entries per row instead of a pass over all ops (which was 4 ms per C3 step).  Runs after the compaction of the rows.
+__global__ void __launch_bounds__(256) ops_pad_fix_kernel(int n, const int32_t *__restrict__ row_first, const int32_t *__restrict__ win_len,
+                                                          const int64_t *__restrict__ ops_base, uint16_t *__restrict__ ops_all,
+                                                          const uint32_t *__restrict__ pads, const int32_t *__restrict__ row_map,
+                                                          const int32_t *__restrict__ rows_eff, int32_t *__restrict__ len2) {
     const int c = blockIdx.x;
     if (c >= n) return;
-    const int g0 = row_first[c], R = row_first[c + 1] - g0;
-    if (R >= 1 && threadIdx.x == 0) { off2[g0] = win_off[g0]; len2[g0] = win_len[g0]; }     // the centre is taken as it is
+    const int g0 = row_first[c];
+    const int R = rows_eff ? rows_eff[c] : row_first[c + 1] - g0;
+    if (R >= 1 && threadIdx.x == 0) len2[g0] = win_len[g0];      // the centre is taken as it is
     if (R <= 1) return;
     const int m = win_len[g0];
     uint16_t *ops = ops_all + ops_base[c];
-    for (int r = 1; r < R; r++) {
-        const uint32_t pd = pads[g0 + r];        // uniform over the block
-        if (!pd) continue;
-        const int pf = (int)(pd & 0xffffu), pb = (int)(pd >> 16), nn = win_len[g0 + r];
-        const int hi = nn - pb, n2 = nn - pf - pb;
-        uint16_t *o = ops + (int64_t)r * (m + 1);
-        for (int p = threadIdx.x; p < m; p += 256) {
-            const unsigned v = o[p];
-            const int q = (int)(v & 0x7fffu);
-            unsigned w;
-            if (q < pf) w = 0x8000u;
-            else if (q >= hi) w = 0x8000u | (unsigned)n2;
-            else w = (v & 0x8000u) | (unsigned)(q - pf);
-            o[p] = (uint16_t)w;
+    const int lane = threadIdx.x & 63;
+    for (int k = 1 + (int)(threadIdx.x >> 6); k < R; k += 4) {
+        const int src = row_map ? row_map[g0 + k] : g0 + k;
+        const uint32_t pd = pads[src];
+        const int pf = (int)(pd & 0xffffu), pb = (int)(pd >> 16), hi = win_len[src] - pb;
+        uint16_t *o = ops + (int64_t)k * (m + 1);
+        if (lane == 0) o[-1] = (uint16_t)(0x8000u | (unsigned)pf);
+        if (pf) {
+            for (int base = 0; base < m; base += 64) {
+                const int p = base + lane;
+                const bool hit = p < m && (int)(o[p < m ? p : 0] & 0x7fffu) < pf;
+                if (hit) o[p] = (uint16_t)(0x8000u | (unsigned)pf);
+                if (__ballot(hit) != ~0ull) break;
+            }
+        }
+        if (pb) {
+            for (int top = m; top > 0; top -= 64) {
+                const int p = top - 1 - lane;
+                const bool hit = p >= 0 && (int)(o[p >= 0 ? p : 0] & 0x7fffu) >= hi;
+                if (hit) o[p] = (uint16_t)(0x8000u | (unsigned)hi);
+                if (__ballot(hit) != ~0ull) break;
+            }
         }
     }
 }
@@ -400,7 +427,7 @@ static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
     const size_t rows_bytes = ((size_t)total_rows * 4 + 255) & ~(size_t)255, cand_bytes = ((size_t)n * 4 + 255) & ~(size_t)255;
     void *opsb = nullptr;
     const size_t lay_bytes = d_new_cols ? (((size_t)ops_elems / 2 + 32768 + 16) * 4 + 255) & ~(size_t)255 : 0;
-    int rc = hite_scratch2_reserve(ctx, ops_bytes + 2 * rows_bytes + 2 * cand_bytes + lay_bytes + 4 * rows_bytes + 256, &opsb);
+    int rc = hite_scratch2_reserve(ctx, ops_bytes + 2 * rows_bytes + 2 * cand_bytes + lay_bytes + 2 * rows_bytes + 256, &opsb);
     if (rc) return rc;
     uint8_t *base = (uint8_t *)opsb;
     int32_t *row_dead = (int32_t *)(base + ops_bytes), *row_map = (int32_t *)(base + ops_bytes + rows_bytes);
@@ -417,29 +444,27 @@ static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
     rc = hite_align_stats(ctx, after, 0);
     if (rc) return rc;
     const bool dropped = after[4] > before[4];
-    // rows padded with HITE_ROW_PAD leave their pads here: from now on (compaction, layout, fill, judge) a row is its window without them
-    int64_t *off2 = (int64_t *)(base + ops_bytes + 2 * rows_bytes + 2 * cand_bytes + lay_bytes);
-    int32_t *len2 = (int32_t *)((uint8_t *)off2 + 2 * rows_bytes);
-    uint32_t *pads = (uint32_t *)((uint8_t *)off2 + 3 * rows_bytes);
-    if (total_rows > 0) {
+    // rows padded with pad bytes (HITE_IS_ROW_PAD): where each begins and ends (the ops are fixed up after the compaction below)
+    int32_t *len2 = (int32_t *)(base + ops_bytes + 2 * rows_bytes + 2 * cand_bytes + lay_bytes);
+    uint32_t *pads = (uint32_t *)((uint8_t *)len2 + rows_bytes);
+    if (total_rows > 0)
         hipLaunchKernelGGL(row_pad_scan_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, total_rows, d_win, d_win_off, d_win_len,
-                           off2, len2, pads);
-        hipLaunchKernelGGL(ops_unpad_kernel, dim3(n), dim3(256), 0, st, n, d_row_first, d_win_len, d_ops_base, (uint16_t *)opsb, pads, d_win_off,
-                           off2, len2);
-    }
-    ctx->d_msa_win_off = off2; ctx->d_msa_win_len = len2;
+                           len2, pads);
+    ctx->d_msa_win_off = d_win_off; ctx->d_msa_win_len = len2; ctx->d_msa_pads = pads;
     MsaParams P;
-    P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = off2; P.win_len = len2; P.row_first = d_row_first;
+    P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = d_win_off; P.win_len = len2; P.row_first = d_row_first;
     P.ops_base = d_ops_base; P.ops = (uint16_t *)opsb; P.cols_out = d_cols_out; P.status = d_status;
-    P.row_map = nullptr; P.rows_eff = nullptr;
+    P.row_map = nullptr; P.rows_eff = nullptr; P.pads = pads;
     P.lay = d_new_cols ? (uint32_t *)(base + ops_bytes + 2 * rows_bytes + 2 * cand_bytes) : nullptr;
     ctx->d_msa_lay = P.lay;
     if (dropped) {
-        hipLaunchKernelGGL(msa_compact_rows_kernel, dim3(n), dim3(256), 0, st, n, d_row_first, len2, d_ops_base, (uint16_t *)opsb, cand_flag,
+        hipLaunchKernelGGL(msa_compact_rows_kernel, dim3(n), dim3(256), 0, st, n, d_row_first, d_win_len, d_ops_base, (uint16_t *)opsb, cand_flag,
                            row_dead, row_map, rows_eff);
         P.row_map = row_map; P.rows_eff = rows_eff;
     }
     ctx->d_msa_row_map = P.row_map; ctx->d_msa_rows_eff = P.rows_eff;
+    hipLaunchKernelGGL(ops_pad_fix_kernel, dim3(n), dim3(256), 0, st, n, d_row_first, d_win_len, d_ops_base, (uint16_t *)opsb, pads, P.row_map,
+                       P.rows_eff, len2);
     if (d_rows_out) hipLaunchKernelGGL(msa_rows_out_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_row_first, P.rows_eff, d_rows_out);
     int tk;
     if (d_new_cols) {
@@ -488,7 +513,7 @@ extern "C" int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uin
     P.n = n; P.win = d_win; P.win_off = ctx->d_msa_win_off ? ctx->d_msa_win_off : d_win_off; P.win_len = ctx->d_msa_win_len ? ctx->d_msa_win_len : d_win_len;
     P.row_first = d_row_first; P.ops_base = d_ops_base;
     P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_new_cols; P.msa_off = d_msa_off; P.msa = d_msa;
-    P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff;
+    P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff; P.pads = ctx->d_msa_pads;
     Q.last_extra = d_last_extra; Q.lay = ctx->d_msa_lay;
     Q.cls = ctx->judge_fuse.win ? ctx->d_judge_cls : nullptr;   // set by the pipeline around this call only
     if (!Q.lay) return HITE_EINVAL;
@@ -514,7 +539,7 @@ extern "C" int hite_star_msa_fill_dev(hite_ctx *ctx, int32_t n, const uint8_t *d
     P.n = n; P.win = d_win; P.win_off = ctx->d_msa_win_off ? ctx->d_msa_win_off : d_win_off; P.win_len = ctx->d_msa_win_len ? ctx->d_msa_win_len : d_win_len;
     P.row_first = d_row_first; P.ops_base = d_ops_base;
     P.ops = (const uint16_t *)ctx->d_scratch2; P.cols = d_cols; P.msa_off = d_msa_off; P.msa = d_msa;
-    P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff;
+    P.row_map = ctx->d_msa_row_map; P.rows_eff = ctx->d_msa_rows_eff; P.pads = ctx->d_msa_pads;
     hipLaunchKernelGGL(star_fill_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, P);
     HITE_CHECK(ctx, hipGetLastError());
     return HITE_OK;

@@ -183,8 +183,8 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
         int64_t g = row_first[c] + r;
         int cp = sel[(int64_t)c * MAXROWS + r];
-        // (the rows of the first500 + last500 form are cut from the PADDED window: still 1000 bytes)
-        int L = md == 2 ? 1000 : (int)len[cp] + (clip ? (int)(clip[cp] & 0xffffu) + (int)(clip[cp] >> 16) : 0);
+        // (the rows of the first500 + last500 form are cut from the PADDED window: still 1000 bytes; the centre, row 0, is never padded)
+        int L = md == 2 ? 1000 : (int)len[cp] + (clip && r > 0 ? (int)(clip[cp] & 0xffffu) + (int)(clip[cp] >> 16) : 0);
         row_copy[g] = cp;
         row_len[g] = L;
         row_pad[g] = (L + 15) & ~15;
@@ -197,28 +197,47 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
     if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(maxlen, mx);
 }
 
-// positions [ws, ws + cnt) of a window padded by `a` bytes in front and `b` behind: HITE_ROW_PAD where the genome window is not
+// one byte of a window (position p of the window [g_lo, g_lo + wlen) read on the given strand)
+__device__ __forceinline__ unsigned window_byte(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g_lo, int64_t wlen,
+                                                bool minus, int64_t p) {
+    if (!minus) return fetch4(bases, nmask, g_lo + p) & 0xffu;
+    const unsigned c = fetch4(bases, nmask, g_lo + wlen - 1 - p) & 0xffu;
+    return c == 'A' ? 'T' : c == 'T' ? 'A' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'N';
+}
+// the centre's window, for the pads of a row: pad byte i in front = centre base i, pad byte j behind (of b) = centre base m - b + j,
+// in LOWER CASE (a pad that matches the centre base it faces: the row's path starts and ends on the centre's diagonal at no cost);
+// HITE_ROW_PAD where the centre has no such position
+struct PadSrc { int64_t g_lo, len; bool minus; };
+// positions [ws, ws + cnt) of a window padded by `a` bytes in front and `b` behind
 __device__ __forceinline__ void emit_padded(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask, int64_t g_lo, int64_t len,
-                                            bool mn, int64_t a, int64_t b, int64_t ws, int64_t cnt, uint8_t *__restrict__ dst, int lane) {
-    (void)b;
+                                            bool mn, int64_t a, int64_t b, int64_t ws, int64_t cnt, uint8_t *__restrict__ dst, int lane,
+                                            const PadSrc &C) {
     int64_t n1 = a - ws; n1 = n1 < 0 ? 0 : (n1 > cnt ? cnt : n1);                 // pad bytes in front
     const int64_t off = ws + n1 - a;                                              // first window position wanted
     int64_t n2 = len - off; n2 = n2 < 0 ? 0 : (n2 > cnt - n1 ? cnt - n1 : n2);    // genome bytes
-    for (int64_t i = lane; i < n1; i += 64) dst[i] = HITE_ROW_PAD;
+    for (int64_t i = lane; i < n1; i += 64) {
+        const int64_t cpos = ws + i;
+        dst[i] = cpos < C.len ? (uint8_t)(window_byte(bases, nmask, C.g_lo, C.len, C.minus, cpos) | 0x20u) : (uint8_t)HITE_ROW_PAD;
+    }
     if (n2 > 0) {       // (the pads shift the bases off the slot's alignment: up to 3 single bytes first, so that the rest goes in 16-byte stores)
         const int64_t lead = (int64_t)((0 - (uintptr_t)(dst + n1)) & 3);
         const int64_t l4 = lead < n2 ? lead : n2;
         if (l4) emit_span4(bases, nmask, g_lo, len, mn, off, l4, dst + n1, lane);
         if (n2 > l4) emit_span(bases, nmask, g_lo, len, mn, off + l4, n2 - l4, dst + n1 + l4, lane);
     }
-    for (int64_t i = n1 + n2 + lane; i < cnt; i += 64) dst[i] = HITE_ROW_PAD;
+    for (int64_t i = n1 + n2 + lane; i < cnt; i += 64) {
+        const int64_t j = ws + i - a - len;                                       // pad byte j of the b behind
+        const int64_t cpos = C.len - b + j;
+        dst[i] = (cpos >= 0 && cpos < C.len) ? (uint8_t)(window_byte(bases, nmask, C.g_lo, C.len, C.minus, cpos) | 0x20u) : (uint8_t)HITE_ROW_PAD;
+    }
 }
 
 // one wavefront per row: window (or its first500+last500 form) from the packed genome.  clip != NULL (copy records in the reference's
 // coordinates, the aligned interval of Util.py:8026): the window is padded by the candidate bases the copy finder's end extensions
 // clipped -- in front by the left clip (the right one for a minus copy: the window is reverse-complemented), behind by the other --
-// with HITE_ROW_PAD, a byte that matches nothing and leaves the alignment as '-': the row then faces the part of the centre it was
-// found with, and its path stays on the diagonal instead of opening a gap of the clipped length at 3 per base
+// with pad bytes (HITE_IS_ROW_PAD): the CENTRE's own first / last bases in lower case, which match the centre positions they face
+// and leave the alignment as '-'.  The row then faces the part of the centre it was found with and its path stays on the diagonal,
+// instead of opening a gap of the clipped length at 3 per base.
 __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restrict__ bases,
                                                          const uint32_t *__restrict__ nmask,
                                                          const int64_t *__restrict__ coff, int32_t ncontig,
@@ -228,7 +247,8 @@ __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restr
                                                          const int64_t *__restrict__ s1, const int64_t *__restrict__ e1,
                                                          const uint8_t *__restrict__ minus, int32_t flank,
                                                          const int64_t *__restrict__ win_off, uint8_t *__restrict__ win,
-                                                         const uint32_t *__restrict__ clip) {
+                                                         const uint32_t *__restrict__ clip, int32_t n_cand,
+                                                         const int32_t *__restrict__ copy_first, const int64_t *__restrict__ row_first) {
     int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= nrows_total) return;
     int lane = threadIdx.x & 63;
@@ -238,15 +258,27 @@ __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restr
     if (len == 0) return;
     bool mn = minus[cp] != 0;
     uint8_t *dst = win + win_off[g];
-    const uint32_t cl = clip ? clip[cp] : 0u;
+    uint32_t cl = clip ? clip[cp] : 0u;
+    int g0 = 0;
+    if (cl) {       // the centre = the first row of the candidate that owns this copy; it is never padded itself
+        int lo = 0, hi = n_cand;
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (copy_first[mid] <= cp) lo = mid; else hi = mid; }
+        g0 = (int)row_first[lo];
+        if (g == g0) cl = 0u;
+    }
     if (cl) {
         const int64_t a = mn ? (int64_t)(cl >> 16) : (int64_t)(cl & 0xffffu), b = mn ? (int64_t)(cl & 0xffffu) : (int64_t)(cl >> 16);
         const int64_t plen = a + len + b;
+        const int cp0 = row_copy[g0];
+        PadSrc C;
+        int64_t tl0;
+        window_rule(coff, ncontig, contig[cp0], s1[cp0], e1[cp0], flank, C.len, tl0, C.g_lo);
+        C.minus = minus[cp0] != 0;
         if (row_trunc[g]) {
-            emit_padded(bases, nmask, g_lo, len, mn, a, b, 0, 500, dst, lane);
-            emit_padded(bases, nmask, g_lo, len, mn, a, b, plen - 500, 500, dst + 500, lane);
+            emit_padded(bases, nmask, g_lo, len, mn, a, b, 0, 500, dst, lane, C);
+            emit_padded(bases, nmask, g_lo, len, mn, a, b, plen - 500, 500, dst + 500, lane, C);
         } else {
-            emit_padded(bases, nmask, g_lo, len, mn, a, b, 0, plen, dst, lane);
+            emit_padded(bases, nmask, g_lo, len, mn, a, b, 0, plen, dst, lane, C);
         }
         return;
     }
@@ -411,7 +443,7 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     tk = hite_prof_begin(ctx, "row_gather_kernel", st);
     hipLaunchKernelGGL(row_gather_kernel, dim3((unsigned)((total_rows + 3) / 4)), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask,
                        ctx->d_contig_off, ctx->n_contigs, total_rows, row_copy, row_trunc, d_contig, d_s1, d_e1, d_minus,
-                       flank, win_off, win, d_clip);
+                       flank, win_off, win, d_clip, n, d_copy_first, row_first);
     hite_prof_end(ctx, tk, st);
     HITE_CHECK(ctx, hipGetLastError());
 

@@ -24,11 +24,14 @@
 extern "C" {
 #endif
 
-/* A row window handed to the star alignment may BEGIN and END with runs of this byte (never the centre, row 0 of a candidate): it
- * takes part in the pairwise alignment as a base that matches nothing (1 per column against a centre base instead of 3 per base of a
- * gap), and is removed afterwards -- centre positions aligned to it become gaps of the row, the ops refer to the row without the
- * runs.  hite_flank_region_align_clip[_dev] pads the rows of copy records in the reference's coordinates with it (see there). */
+/* A row window handed to the star alignment may BEGIN and END with runs of PAD bytes (never the centre, row 0 of a candidate): bytes
+ * with bit 5 set -- HITE_ROW_PAD ('.'), which matches nothing (1 per column against a centre base instead of 3 per base of a gap), or a
+ * base in LOWER CASE (a, c, g, t), which matches its base.  Genome and candidate bytes are upper case: no pad is ever mistaken.  Pads
+ * take part in the pairwise alignment and are removed afterwards -- centre positions aligned to them become gaps of the row, the ops
+ * refer to the row without them.  hite_flank_region_align_clip[_dev] pads the rows of copy records in the reference's coordinates with
+ * the centre's own bases in lower case (see there). */
 #define HITE_ROW_PAD 0x2e   /* '.' */
+#define HITE_IS_ROW_PAD(c) (((c) & 0x20u) != 0)
 
 #define HITE_OK 0
 #define HITE_EINVAL (-1)   /* bad argument */

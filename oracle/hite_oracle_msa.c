@@ -47,7 +47,8 @@
 #define SLICE_WORDS 2     /* rows kept for the traceback (and watched by the steering): the middle 64 of the band */
 #define MARGIN 48         /* exact mode: the first wider band is the smallest with 32 NW >= U / GAP + MARGIN */
 
-#define ORC_ROW_PAD 0x2e   /* '.' */
+/* pad bytes (include/hite_gpu.h HITE_ROW_PAD / HITE_IS_ROW_PAD): bit 5 set -- '.', which matches nothing, or a base in lower case */
+#define ORC_IS_PAD(c) (((c) & 0x20u) != 0)
 static inline int is_acgt(unsigned c) { return c == 'A' || c == 'C' || c == 'G' || c == 'T'; }
 
 /* value of row index k (may be -1: the cell above the band, or >= W: rows that have not entered yet) of a stored column */
@@ -111,7 +112,7 @@ int orc_bp_pair(const uint8_t *a, int m, const uint8_t *b, int n, int NW, int fu
         ts[j] = t;
         if (t >= 1 && (long)t + 1 - j > LO) LO = (long)t + 1 - j;
         if (t + W < m && (long)t + W - j < HI) HI = (long)t + W - j;
-        const unsigned y = b[j - 1];
+        const unsigned y = b[j - 1] & 0xdfu;      /* a row byte in lower case (a pad that carries a base, ORC_ROW_PAD below) is its base */
         const int ya = is_acgt(y);
         for (int k = 0; k < W; k++) {
             const int r = t + 1 + k;
@@ -168,7 +169,7 @@ int orc_bp_pair(const uint8_t *a, int m, const uint8_t *b, int n, int NW, int fu
             const int k = i - ts[j] - 1, s = ts[j] - ts[j - 1];
             if (k < klo || k >= khi) { status = 1; break; }
             const int32_t *prev = D + (size_t)(j - 1) * W, *cur = D + (size_t)j * W;
-            const unsigned y = b[j - 1];
+            const unsigned y = b[j - 1] & 0xdfu;
             const int sub = !(is_acgt(y) && a[i - 1] == y);
             if (col_get(prev, above[j - 1], W, k + s - 1) + sub == cur[k]) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; }
             else if ((k > 0 ? cur[k - 1] : above[j]) + GAP == cur[k]) { ops[i - 1] = (uint16_t)(j | 0x8000); i--; }
@@ -236,8 +237,8 @@ int orc_star_msa2(const uint8_t *win, const int64_t *win_off, int R, int *cols_o
     uint16_t *ops = (uint16_t *)calloc((size_t)R * (m + 1), sizeof(uint16_t));
     int *rowsrc = (int *)malloc(sizeof(int) * (size_t)R);
     if (!ops || !rowsrc) { free(ops); free(rowsrc); return ORC_EINVAL; }
-    /* rows that begin / end with ORC_ROW_PAD (HITE_ROW_PAD of include/hite_gpu.h; never the centre): the pads take part in the pairwise
-     * alignment as bases that match nothing and leave afterwards -- a centre position aligned to one becomes a gap of the row, the ops
+    /* rows that begin / end with pad bytes (ORC_IS_PAD; never the centre): the pads take part in the pairwise
+     * alignment -- '.' matches nothing, a lower-case base matches its base -- and leave afterwards -- a centre position aligned to one becomes a gap of the row, the ops
      * are rewritten for the row without them; rb / rn = every row's window as the rest of the stage sees it */
     const uint8_t **rb = (const uint8_t **)malloc(sizeof(uint8_t *) * (size_t)R);
     int *rn = (int *)malloc(sizeof(int) * (size_t)R);
@@ -254,8 +255,8 @@ int orc_star_msa2(const uint8_t *win, const int64_t *win_off, int R, int *cols_o
         int rc = orc_align_pair(a, m, b, n, g_exact, op, o);
         if (rc < 0) { free(ops); free(rowsrc); free(rb); free(rn); return rc; }
         int pf = 0, pb = 0;
-        while (pf < n && b[pf] == ORC_ROW_PAD) pf++;
-        while (pf + pb < n && b[n - 1 - pb] == ORC_ROW_PAD) pb++;
+        while (pf < n && ORC_IS_PAD(b[pf])) pf++;
+        while (pf + pb < n && ORC_IS_PAD(b[n - 1 - pb])) pb++;
         rb[r] = b + pf; rn[r] = n - pf - pb;
         if (rc == 0 && (pf || pb)) {
             for (int p = 0; p < m; p++) {

@@ -11,7 +11,8 @@
  *   mismatches + 3 x (inserted + deleted bases)   (match 0, mismatch 1, linear gap ORC_GAP = 3 per base -- the same
  *   optimum as Needleman-Wunsch with match +2, mismatch -1, gap -8, since 2 (matches + mismatches) + gaps = m + n;
  *   the ratio was chosen by measurement: tools/align_cost_sweep.py);
- *   two bases match iff they are equal and one of A, C, G, T ('N' and every other byte never match);
+ *   two bases match iff they are equal and one of A, C, G, T ('N' and every other byte never match); a ROW byte in lower case
+ *   (a, c, g, t: the pads of hite_flank_region_align_clip, never a genome base) stands for its base;
  *   among co-optimal alignments the canonical one is the traceback from (m, n) that prefers
  *   diagonal, then up (centre base against a gap), then left (row base inserted).
  *
@@ -44,7 +45,7 @@ int orc_nw_distance(const uint8_t *a, int m, const uint8_t *b, int n) {
         const unsigned x = a[i - 1];
         const int xa = is_acgt(x);
         for (int j = 1; j <= n; j++) {
-            int sub = !(xa && x == b[j - 1]);
+            int sub = !(xa && x == (b[j - 1] & 0xdfu));
             int v = prev[j - 1] + sub;
             if (prev[j] + ORC_GAP < v) v = prev[j] + ORC_GAP;
             if (cur[j - 1] + ORC_GAP < v) v = cur[j - 1] + ORC_GAP;
@@ -75,7 +76,7 @@ int orc_ops_cost(const uint8_t *a, int m, const uint8_t *b, int n, const uint16_
         else {
             if (q >= n) return ORC_EINVAL;
             const unsigned x = a[p];
-            cost += !(is_acgt(x) && x == b[q]);
+            cost += !(is_acgt(x) && x == (b[q] & 0xdfu));
             next = q + 1;
         }
     }
@@ -99,7 +100,7 @@ int orc_nw_pair_cost(const uint8_t *a, int m, const uint8_t *b, int n, int mis, 
         const unsigned x = a[i - 1];
         const int xa = is_acgt(x);
         for (int j = 1; j <= n; j++) {
-            int sub = (xa && x == b[j - 1]) ? 0 : mis;
+            int sub = (xa && x == (b[j - 1] & 0xdfu)) ? 0 : mis;
             int v = up[j - 1] + sub;
             if (up[j] + gap < v) v = up[j] + gap;
             if (row[j - 1] + gap < v) v = row[j - 1] + gap;
@@ -113,7 +114,7 @@ int orc_nw_pair_cost(const uint8_t *a, int m, const uint8_t *b, int n, int mis, 
         const int32_t *up = row - ld;
         if (j > 0) {
             const unsigned x = a[i - 1];
-            int sub = (is_acgt(x) && x == b[j - 1]) ? 0 : mis;
+            int sub = (is_acgt(x) && x == (b[j - 1] & 0xdfu)) ? 0 : mis;
             if (up[j - 1] + sub == row[j]) { ops[i - 1] = (uint16_t)(j - 1); i--; j--; continue; }
             if (up[j] + gap == row[j]) { ops[i - 1] = (uint16_t)(j | 0x8000); i--; continue; }
             j--;

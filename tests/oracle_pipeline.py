@@ -78,39 +78,59 @@ def anchor_class(cand, msa):
     return "none"
 
 
+def _padded(w, clip, minus, centre):
+    """the window of a copy record in the reference's coordinates, padded by the clipped candidate bases (clip = left | right << 16 in
+    the orientation of the genome; a minus copy's window is reverse-complemented): pad byte i in front = the CENTRE's base i, pad byte j
+    of the b behind = the centre's base m - b + j, in lower case (HITE_IS_ROW_PAD: they match the centre positions they face and leave
+    the alignment as gaps of the row); ROW_PAD where the centre has no such position"""
+    a, b = clip & 0xffff, clip >> 16
+    if minus:
+        a, b = b, a
+    m = len(centre)
+    front = "".join(centre[i].lower() if i < m else ROW_PAD for i in range(a))
+    back = "".join(centre[m - b + j].lower() if 0 <= m - b + j < m else ROW_PAD for j in range(b))
+    return front + w + back
+
+
 def fine_stage_candidate(te_type, cand, copies, contigs, plant=1, flank=50, contig_names=None, keep_msa=None):
     """copies: (contig_index, start1, end1, minus[, anchors, clip]) -> [is_TE, info, cons, row_num]; keep_msa: a list that receives
     the cleaned alignment of every pass that was judged.  clip (find_copies(..., clips=True); non-zero only for records in the
-    reference's coordinates): candidate bases clipped left | right << 16 in the orientation of the genome -- the window is padded by
-    them with ROW_PAD (hite_flank_region_align_clip; the first500 + last500 form is cut from the padded window), the rows are still
-    chosen by the length of the genome window"""
-    full, trunc, fn, tn, fl = [], [], [], [], []
+    reference's coordinates): hite_flank_region_align_clip -- the rows (never the centre, the first row kept) are padded by the clipped
+    bases (_padded); the rows are chosen by the length of the genome window; the first500 + last500 form is cut from the padded window"""
+    full, trunc = [], []            # (window, name, clip, minus) per pass, in input order
     for cp in copies:
         (ci, s, e, mn) = cp[:4]
         w, t = O.flank_window(contigs[ci], s, e, "-" if mn else "+", flank)
         if w is None:
             continue
-        clip = int(cp[5]) if len(cp) > 5 else 0
-        fl.append(len(w))
-        if clip:
-            a, b = clip & 0xffff, clip >> 16
-            if mn:
-                a, b = b, a
-            w = ROW_PAD * a + w + ROW_PAD * b
-            if t is not None:
-                t = w[:500] + w[-500:]
-        full.append(w)
-        fn.append(window_name(cp, contig_names))
+        rec = (w, window_name(cp, contig_names), int(cp[5]) if len(cp) > 5 else 0, bool(mn))
+        full.append(rec)
         if t is not None:
-            trunc.append(t)
-            tn.append(fn[-1])
+            trunc.append(rec)
     if not full:
         return [False, "", "", 0]
+
+    def run(recs, cut):
+        lens = [1000 if cut else len(r[0]) for r in recs]
+        names = [r[1] for r in recs]
+        if not any(r[2] for r in recs):
+            wins = [r[0][:500] + r[0][-500:] if cut else r[0] for r in recs]
+            return judge_windows(te_type, cand, wins, plant, names, keep_msa, lens=lens)
+        keep = select_rows(lens, names)
+        centre = recs[keep[0]][0]
+        wins = []
+        for k, i in enumerate(keep):
+            w, _nm, clip, mn = recs[i]
+            if k > 0 and clip:
+                w = _padded(w, clip, mn, centre)
+            wins.append(w[:500] + w[-500:] if cut else w)
+        return judge_windows(te_type, cand, wins, plant, None, keep_msa)       # (the rows are chosen: <= 100 windows)
+
     if trunc:
-        res, _ = judge_windows(te_type, cand, trunc, plant, tn, keep_msa)
+        res, _ = run(trunc, True)
         if res[0] == "EXC" or not res[0]:
             return res if res[0] != "EXC" else [False, "EXC", "", 0]
-    res, _ = judge_windows(te_type, cand, full, plant, fn, keep_msa, lens=fl)
+    res, _ = run(full, False)
     if res[0] == "EXC":
         return [False, "EXC", "", 0]
     return res

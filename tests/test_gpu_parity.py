@@ -760,17 +760,20 @@ def test_star_msa_padded_rows(ctx):
     groups = []
     for g in base:
         rows = [g[0]]
+        c0 = g[0]
         for w in g[1:]:
             a, b = (int(x) for x in rng.integers(0, 70, 2))
             kind = int(rng.integers(0, 4))
+            # the two kinds of pad byte: '.' (matches nothing) and the centre's own bases in lower case (match what they face)
+            pa, pb = ("." * a, "." * b) if rng.random() < 0.4 else (c0[:a].lower(), c0[len(c0) - b:].lower() if b else "")
             if kind == 0:
                 rows.append(w)                                              # no pads
             elif kind == 1:
-                rows.append("." * a + w[min(a, len(w) // 3):] )             # cut in front, padded by what was cut (or more)
+                rows.append(pa + w[min(a, len(w) // 3):])                   # cut in front, padded by what was cut (or more)
             elif kind == 2:
-                rows.append(w[: len(w) - min(b, len(w) // 3)] + "." * b)     # cut behind
+                rows.append(w[: len(w) - min(b, len(w) // 3)] + pb)         # cut behind
             else:
-                rows.append("." * a + w[min(a, len(w) // 3): len(w) - min(b, len(w) // 3)] + "." * b)
+                rows.append(pa + w[min(a, len(w) // 3): len(w) - min(b, len(w) // 3)] + pb)
         groups.append(rows)
     groups.append(["ACGTTGCAAGGCTTAACCGGTTAAGC" * 4, "." * 104, "." * 5 + "ACGTTGCAAGGCTTAACCGGTTAAGC"[5:] + "ACGTTGCAAGGCTTAACCGGTTAAGC" + "." * 52])     # a row of pads only
     full = ctx.star_msa(groups)
@@ -779,11 +782,11 @@ def test_star_msa_padded_rows(ctx):
     for g, f, m in zip(groups, full, sparse):
         exp_full = O.star_msa(g)
         assert f is not None and f.shape == exp_full.shape and np.array_equal(f, exp_full)
-        assert not (f == ord(".")).any()
+        assert not (f & 0x20)[f != ord("-")].any()             # no pad byte is left ('-' itself has bit 5)
         if f.shape[0] == len(g):                 # (a row that cannot be aligned leaves, on both sides alike)
             for r, w in enumerate(g):
-                assert bytes(f[r][f[r] != ord("-")]) == w.strip(".").encode()
-        n_pad_rows += sum(w != w.strip(".") for w in g)
+                assert bytes(f[r][f[r] != ord("-")]) == w.strip(".acgtn").encode()
+        n_pad_rows += sum(w != w.strip(".acgtn") for w in g)
         keep = O.sparse_cols(exp_full).astype(bool)
         exp = np.ascontiguousarray(exp_full[:, keep])
         assert m is not None and m.shape == exp.shape and np.array_equal(m, exp)

@@ -448,8 +448,11 @@ extern "C" void host_fill(uint8_t *row, const uint8_t *b, int nrow, const uint16
             for r in range(R):
                 out = np.full(C_out + 8, 0x2a, np.uint8)
                 b = np.frombuffer(rows[r].encode() + b"\0" * 8, np.uint8)
-                rop = np.concatenate([ops[r], [0]]).astype(np.uint16) if r else np.zeros(m + 1, np.uint16)
-                lib.host_fill(out.ctypes.data_as(O.u8p), b.ctypes.data_as(O.u8p), len(rows[r]), rop.ctypes.data_as(C.POINTER(C.c_uint16)),
+                # (entry -1 of an ops row = the op "before position 0": a gap op whose q is the row's first base, 0x8000 without pads -- on
+                # the device the spare entry of the ops row above, ops_pad_fix_kernel)
+                rbuf = np.concatenate([[0x8000], ops[r], [0]]).astype(np.uint16) if r else np.zeros(m + 2, np.uint16)
+                rop = C.cast(rbuf.ctypes.data + 2, C.POINTER(C.c_uint16))
+                lib.host_fill(out.ctypes.data_as(O.u8p), b.ctypes.data_as(O.u8p), len(rows[r]), rop,
                               lay.ctypes.data_as(C.POINTER(C.c_uint32)), m, le, int(r == 0), ts)
                 assert np.array_equal(out[:C_out], exp[r]), (case, r, ts)
                 assert (out[C_out:] == 0x2a).all()

@@ -626,6 +626,12 @@ def test_twin_padded_rows_and_the_aligned_interval_mode():
     assert m.shape[0] == 3 and not (m == ord(".")).any()
     assert [bytes(r[r != ord("-")]) for r in m] == [w.strip(".").encode() for w in rows]
     assert bytes(m[1][:17]) == b"-" * 17 and bytes(m[1][-18:]) == b"-" * 18 and bytes(m[2]) == b"-" * m.shape[1]
+    # the other kind of pad byte: the centre's own bases in lower case match what they face -- same alignment, 35 less cost
+    low = rows[0][:17].lower() + rows[1].strip(".") + rows[0][150:].lower()
+    assert len(low) == len(rows[0]) and np.array_equal(O.star_msa([rows[0], low]), m[:2])
+    ops_dot, d_dot = O.nw_pair(rows[0], rows[1])
+    ops_low, d_low = O.nw_pair(rows[0], low)
+    assert d_dot - d_low == 35 and np.array_equal(ops_dot, ops_low)
     g = synth_small.make(23, n_fam=24)
     try:
         O.find_copies_config(True)
