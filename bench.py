@@ -115,7 +115,7 @@ def main():
                     help="found: copy finding (minimizer index lookup) runs inside the timed step; truth: the generator's copy table is the input")
     ap.add_argument("--verify", type=int, default=512, help="candidates re-judged with the CPU oracle chain after the timed region (0 = none)")
     ap.add_argument("--no-coarse", action="store_true", help="skip the coarse-stage block of the default line")
-    ap.add_argument("--no-modes", action="store_true", help="skip the block that re-runs the step with copy records in the reference's coordinates")
+    ap.add_argument("--no-modes", action="store_true", help="skip the block that re-runs the step in the other interval mode of the copy finder")
     ap.add_argument("--stage", choices=["fine", "coarse"], default="fine",
                     help="fine (default): BASELINE.json's metric; coarse: the companion line of stage 3.1 (all-vs-all seeding + FMEA)")
     args = ap.parse_args()
@@ -215,7 +215,7 @@ def main():
         if n_cand > 0:
             if args.copies == "found":
                 nc, p_cf, p_ct, p_s1, p_e1, p_mn, _p_an = ctx.find_copies_dev(n_cand, d_cand.data_ptr(), d_cand_off.data_ptr(), b1 - b0, sp)
-                p_cl = ctx.copy_clips_dev()      # (zero words unless HITE_COPY_INTERVAL=aligned: the rows are then padded by the clipped bases)
+                p_cl = ctx.copy_clips_dev()      # (the rows are padded by the clipped bases; zero words with HITE_COPY_INTERVAL=whole)
                 state["found"] = (nc, p_cf, p_ct, p_s1, p_e1, p_mn, p_cl)
                 state["n_copies"] = nc
                 st = ctx.flank_region_align_dev("tir", 1, n_cand, d_cand.data_ptr(), d_cand_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn,
@@ -404,12 +404,16 @@ def main():
         wv = None
         if (world == 1 and not args.no_cpu_baseline) or args.verify > 0:
             wv = host_workload(dict(w, **L), ctx, state if args.copies == "found" else None, c0, c1)
-        if world == 1 and args.copies == "found" and not args.no_modes and n_cand > 0 and os.environ.get("HITE_COPY_INTERVAL", "") != "aligned":
-            # the same step with the copy records in the REFERENCE'S coordinates (reference_start + 1 .. reference_end, Util.py:8026;
-            # hite_copy_config(1)) and the rows padded by the clipped candidate bases (hite_flank_region_align_clip_dev): outside the
-            # headline's timed region, same batch, same kernels; a sample re-judged by the oracle chain on that copy table
+        if world == 1 and args.copies == "found" and not args.no_modes and n_cand > 0:
+            # the same step in the OTHER interval mode of the copy finder, outside the headline's timed region (same batch, same
+            # kernels; a sample re-judged by the oracle chain on that copy table).  The default (and the headline): copy records in the
+            # REFERENCE'S coordinates -- reference_start + 1 .. reference_end, Util.py:8026 -- with the rows padded by the clipped
+            # candidate bases (hite_flank_region_align_clip_dev); the other: the whole-candidate intervals of rounds 2-4
+            whole_now = os.environ.get("HITE_COPY_INTERVAL", "") in ("whole", "0")
+            names = {True: "whole candidate (aligned part + the clipped ends on its diagonal; HITE_COPY_INTERVAL=whole, the default of rounds 2-4)",
+                     False: "aligned part of the candidate, as get_copies_minimap2 reports it (Util.py:8026); rows padded by the clipped bases"}
             try:
-                ctx.copy_config(True)
+                ctx.copy_config(whole_now)          # (True = aligned: the other mode of a run that was started in the whole-candidate mode)
                 step()
                 ctx.align_stats(reset=True)
                 torch.cuda.synchronize()
@@ -421,23 +425,23 @@ def main():
                 ms_m = 1000.0 * (time.perf_counter() - t_m) / k_m
                 st_m = ctx.align_stats()
                 calls_m = d_calls.cpu().numpy().view(CALL_DTYPE)[:n_cand].copy()
-                blk = {"interval": "aligned part of the candidate, as get_copies_minimap2 reports it (Util.py:8026); rows padded by the clipped bases",
-                       "ms_per_step": round(ms_m, 3), "value": round(n_cand / (ms_m * 1e-3), 2), "unit": "candidates/s", "steps": k_m,
-                       "copies": int(state["n_copies"]), "is_te": int((calls_m["is_te"] != 0).sum()),
-                       "wide_fallback_per_step": st_m["fallback"] / k_m, "dropped_per_step": st_m["dropped"] / k_m,
-                       "certified_frac": round(st_m["certified"] / max(1, st_m["pairs"]), 4),
-                       "default_mode": {"interval": "whole candidate (aligned part + the clipped ends on its diagonal)", "ms_per_step": round(ms_per_step, 3),
-                                        "is_te": n_te_all}}
+                blk = {"this_run": {"interval": names[whole_now], "ms_per_step": round(ms_per_step, 3), "is_te": n_te_all,
+                                    "wide_fallback_per_step": per_step["fallback"]},
+                       "other_mode": {"interval": names[not whole_now], "ms_per_step": round(ms_m, 3), "value": round(n_cand / (ms_m * 1e-3), 2),
+                                      "unit": "candidates/s", "steps": k_m, "copies": int(state["n_copies"]),
+                                      "is_te": int((calls_m["is_te"] != 0).sum()), "wide_fallback_per_step": st_m["fallback"] / k_m,
+                                      "dropped_per_step": st_m["dropped"] / k_m,
+                                      "certified_frac": round(st_m["certified"] / max(1, st_m["pairs"]), 4)}}
                 if args.verify > 0:
                     wv_m = host_workload(dict(w, **L), ctx, state, c0, c1)
                     v_m = verify(wv_m, calls_m, d_cons.cpu().numpy(), min(args.verify, 128))
-                    blk["verify"] = {k_: v_m[k_] for k_ in ("checked", "mismatches", "bad_candidates", "te_calls_in_sample") if k_ in v_m}
-                out["reference_coordinates"] = blk
+                    blk["other_mode"]["verify"] = {k_: v_m[k_] for k_ in ("checked", "mismatches", "bad_candidates", "te_calls_in_sample") if k_ in v_m}
+                out["copy_interval_modes"] = blk
             except Exception as e:
-                out["reference_coordinates"] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["copy_interval_modes"] = {"error": "%s: %s" % (type(e).__name__, e)}
             finally:
                 ctx.copy_config(None)
-                step()                      # the device copy table and calls are the default mode's again
+                step()                      # the device copy table and calls are this run's mode's again
                 torch.cuda.synchronize()
         if world == 1 and not args.no_coarse:
             # north_star's >= 20x target is phrased on the coarse_boundary step: measured here, after the headline's timed region, on

@@ -66,8 +66,9 @@ class Context:
         self.device = device
 
     def copy_config(self, aligned_interval):
-        """which interval copy records carry (process-wide, include/hite_gpu.h hite_copy_config): False = whole candidate
-        (default), True = the aligned interval as get_copies_minimap2 reports it (Util.py:8026), None = from HITE_COPY_INTERVAL"""
+        """which interval copy records carry (process-wide, include/hite_gpu.h hite_copy_config): True = the aligned interval as
+        get_copies_minimap2 reports it (Util.py:8026; the default), False = the whole candidate (rounds 2-4), None = from
+        HITE_COPY_INTERVAL (aligned | whole), else the default"""
         self._check(self.lib.hite_copy_config(-1 if aligned_interval is None else int(bool(aligned_interval))), "hite_copy_config")
 
     def release_copy_index(self):
@@ -409,8 +410,8 @@ class Context:
         """the copy table as arrays: (copy_first int32[n + 1], contig, start1, end1, minus, anchors) -- the copies of candidate c are
         rows copy_first[c] .. copy_first[c + 1]; needs genome_pack() first; at most FIND_COPIES_BATCH candidates.
         clips=True: a 7th array, uint32 per record: the candidate bases the end extensions clipped, left | right << 16 in the
-        orientation of the genome (hite_copy_clips) -- zero unless the records carry the reference's aligned interval
-        (hite_copy_config(1)); flank_region_align pads the rows of the star alignment with them.
+        orientation of the genome (hite_copy_clips) -- zero when the records carry the whole-candidate interval
+        (hite_copy_config(0)); flank_region_align pads the rows of the star alignment with them.
         restricted=True: the caller uses the index of this genome for THIS candidate set only (the masking step of stage 3.1):
         hite_find_copies_restricted builds the index from just the genome minimizers the candidates look up -- same table,
         a fraction of the build; any later use of the handle rebuilds the full index by itself."""

@@ -899,7 +899,9 @@ static int g_copy_interval = -1;
 static int copy_interval_mode() {
     if (g_copy_interval < 0) {
         const char *e = getenv("HITE_COPY_INTERVAL");
-        g_copy_interval = (e && (!strcmp(e, "aligned") || !strcmp(e, "1"))) ? 1 : 0;
+        // default since round 5: the reference's coordinates (the aligned interval, Util.py:8026) -- usable now that the rows are padded by
+        // the clipped bases; HITE_COPY_INTERVAL=whole: the whole-candidate interval of rounds 2-4
+        g_copy_interval = (e && (!strcmp(e, "whole") || !strcmp(e, "0"))) ? 0 : 1;
     }
     return g_copy_interval;
 }

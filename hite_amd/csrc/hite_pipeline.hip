@@ -173,7 +173,8 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
                                 const int64_t *__restrict__ len, int32_t *__restrict__ row_first32,
                                 int32_t *__restrict__ row_copy, int32_t *__restrict__ row_len,
                                 int32_t *__restrict__ row_pad, uint8_t *__restrict__ row_trunc,
-                                int32_t *__restrict__ maxlen, const uint32_t *__restrict__ clip /* per copy, or NULL */) {
+                                int32_t *__restrict__ maxlen, const uint32_t *__restrict__ clip /* per copy, or NULL */,
+                                int32_t *__restrict__ row_cp0 /* per row: the copy of its candidate's centre (clip != NULL) */) {
     int c = blockIdx.x;
     if (c >= n) return;
     if (threadIdx.x == 0) { row_first32[c] = (int32_t)row_first[c]; if (c == n - 1) row_first32[n] = (int32_t)row_first[n]; }
@@ -186,6 +187,7 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
         // (the rows of the first500 + last500 form are cut from the PADDED window: still 1000 bytes; the centre, row 0, is never padded)
         int L = md == 2 ? 1000 : (int)len[cp] + (clip && r > 0 ? (int)(clip[cp] & 0xffffu) + (int)(clip[cp] >> 16) : 0);
         row_copy[g] = cp;
+        if (clip) row_cp0[g] = sel[(int64_t)c * MAXROWS];
         row_len[g] = L;
         row_pad[g] = (L + 15) & ~15;
         row_trunc[g] = md == 2;
@@ -247,8 +249,7 @@ __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restr
                                                          const int64_t *__restrict__ s1, const int64_t *__restrict__ e1,
                                                          const uint8_t *__restrict__ minus, int32_t flank,
                                                          const int64_t *__restrict__ win_off, uint8_t *__restrict__ win,
-                                                         const uint32_t *__restrict__ clip, int32_t n_cand,
-                                                         const int32_t *__restrict__ copy_first, const int64_t *__restrict__ row_first) {
+                                                         const uint32_t *__restrict__ clip, const int32_t *__restrict__ row_cp0) {
     int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= nrows_total) return;
     int lane = threadIdx.x & 63;
@@ -258,18 +259,12 @@ __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restr
     if (len == 0) return;
     bool mn = minus[cp] != 0;
     uint8_t *dst = win + win_off[g];
-    uint32_t cl = clip ? clip[cp] : 0u;
-    int g0 = 0;
-    if (cl) {       // the centre = the first row of the candidate that owns this copy; it is never padded itself
-        int lo = 0, hi = n_cand;
-        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (copy_first[mid] <= cp) lo = mid; else hi = mid; }
-        g0 = (int)row_first[lo];
-        if (g == g0) cl = 0u;
-    }
+    // (the centre, the first row of the candidate that owns this copy, is never padded itself)
+    const int cp0 = clip ? row_cp0[g] : cp;
+    const uint32_t cl = (clip && cp != cp0) ? clip[cp] : 0u;
     if (cl) {
         const int64_t a = mn ? (int64_t)(cl >> 16) : (int64_t)(cl & 0xffffu), b = mn ? (int64_t)(cl & 0xffffu) : (int64_t)(cl >> 16);
         const int64_t plen = a + len + b;
-        const int cp0 = row_copy[g0];
         PadSrc C;
         int64_t tl0;
         window_rule(coff, ncontig, contig[cp0], s1[cp0], e1[cp0], flank, C.len, tl0, C.g_lo);
@@ -420,9 +415,11 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     ACHK(arena_alloc(ctx, T, (size_t)total_rows * 4, &p)); row_len = (int32_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)total_rows * 4, &p)); row_pad = (int32_t *)p;
     ACHK(arena_alloc(ctx, T, (size_t)total_rows, &p)); row_trunc = (uint8_t *)p;
+    int32_t *row_cp0 = nullptr;
+    if (d_clip) { ACHK(arena_alloc(ctx, T, (size_t)total_rows * 4, &p)); row_cp0 = (int32_t *)p; }
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
     hipLaunchKernelGGL(row_meta_kernel, dim3(n), dim3(128), 0, st, n, row_first, nrows, sel, d_mode, d_len, row_first32,
-                       row_copy, row_len, row_pad, row_trunc, (int32_t *)(S->d_scal + 2), d_clip);
+                       row_copy, row_len, row_pad, row_trunc, (int32_t *)(S->d_scal + 2), d_clip, row_cp0);
     ACHK(arena_alloc(ctx, T, (size_t)(total_rows + 1) * 8, &p)); win_off = (int64_t *)p;
     ACHK(scan_excl<int32_t>(ctx, T, row_pad, total_rows, win_off, st));
     ACHK(arena_alloc(ctx, T, (size_t)n * 8, &p)); ops_cnt = (int64_t *)p;
@@ -443,7 +440,7 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     tk = hite_prof_begin(ctx, "row_gather_kernel", st);
     hipLaunchKernelGGL(row_gather_kernel, dim3((unsigned)((total_rows + 3) / 4)), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask,
                        ctx->d_contig_off, ctx->n_contigs, total_rows, row_copy, row_trunc, d_contig, d_s1, d_e1, d_minus,
-                       flank, win_off, win, d_clip, n, d_copy_first, row_first);
+                       flank, win_off, win, d_clip, row_cp0);
     hite_prof_end(ctx, tk, st);
     HITE_CHECK(ctx, hipGetLastError());
 

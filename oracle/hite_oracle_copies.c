@@ -237,8 +237,8 @@ int64_t orc_ext_align(const uint8_t *qseg, int64_t n, int dir, const uint8_t *ge
     return ext_align(qseg, n, dir, genome, g0, gmin, gmax, t_out);
 }
 
-/* interval mode of the records (hite_copy_config): 0 = whole candidate (default), 1 = aligned interval (Util.py:8026) */
-static int g_aligned_interval = 0;
+/* interval mode of the records (hite_copy_config): 1 = aligned interval (Util.py:8026; the default since round 5), 0 = whole candidate */
+static int g_aligned_interval = 1;
 void orc_find_copies_config(int aligned_interval) { g_aligned_interval = aligned_interval ? 1 : 0; }
 
 /* seconds the last orc_find_copies call spent building its index (bench.py separates residency set-up from the lookups) */

@@ -276,7 +276,7 @@ def align_pair(a, b, exact_cap=8):
 
 def find_copies(contigs, cands, clips=False):
     """this build's minimap2 stand-in: -> per candidate list of (contig, start1, end1, minus, anchors); clips=True: + the clip word
-    of the record (clipped candidate bases left | right << 16; zero unless find_copies_config(True)), as Context.find_copies"""
+    of the record (clipped candidate bases left | right << 16; zero in the whole-candidate mode, find_copies_config(False)), as Context.find_copies"""
     gb = [c.encode() if isinstance(c, str) else bytes(c) for c in contigs]
     coff = np.zeros(len(gb) + 1, dtype=np.int64)
     np.cumsum([len(c) for c in gb], out=coff[1:])
@@ -305,8 +305,9 @@ def find_copies(contigs, cands, clips=False):
 
 
 def find_copies_config(aligned_interval):
-    """interval mode of the twin's records (mirror of hite_copy_config)"""
-    lib().orc_find_copies_config(int(bool(aligned_interval)))
+    """interval mode of the twin's records (mirror of hite_copy_config): True = the aligned interval (the default), False = the whole
+    candidate, None = back to the default"""
+    lib().orc_find_copies_config(1 if aligned_interval is None else int(bool(aligned_interval)))
 
 
 def find_copies_far(min_copies):

@@ -503,10 +503,9 @@ def test_find_copies_vs_twin(ctx):
     g = synth_small.make(11, n_fam=16)
     ctx.genome_pack(g["contigs"])
     ctx.release_copy_index()
-    tab = ctx.find_copies(g["cands"])
-    copies = [[x[:4] for x in t] for t in tab]
-    res, _ = ctx.flank_region_align("tir", g["cands"], copies, plant=1)
-    for cand, cp, r in zip(g["cands"], copies, res):
+    tab = ctx.find_copies(g["cands"], clips=True)
+    res, _ = ctx.flank_region_align("tir", g["cands"], tab, plant=1)
+    for cand, cp, r in zip(g["cands"], tab, res):
         assert [r[0], r[1], r[2], r[3]] == OP.fine_stage_candidate("tir", cand, cp, g["contigs"], plant=1)
 
 
@@ -541,25 +540,26 @@ def test_find_copies_restricted_index(ctx):
     assert ctx.find_copies(["ACGT", "N" * 100], restricted=True) == [[], []]
 
 
-def test_find_copies_aligned_interval_mode(ctx):
-    """hite_copy_config(1): the records carry the ALIGNED interval, reference_start + 1 .. reference_end as
-    get_copies_minimap2 reports it (Util.py:8026), instead of the interval of the whole candidate (the default; DESIGN.md
-    deviation v).  Both modes are twin-pinned; the aligned intervals lie inside the whole-candidate ones, copy for copy."""
+def test_find_copies_interval_modes(ctx):
+    """The records carry the ALIGNED interval, reference_start + 1 .. reference_end as get_copies_minimap2 reports it (Util.py:8026;
+    the default since round 5), or -- hite_copy_config(0) / HITE_COPY_INTERVAL=whole -- the interval of the whole candidate (rounds
+    2-4).  Both modes are twin-pinned; the aligned intervals lie inside the whole-candidate ones, copy for copy."""
     import synth_small
 
     g = synth_small.make(23, n_fam=24)
     ctx.genome_pack(g["contigs"])
     ctx.release_copy_index()
-    whole = ctx.find_copies(g["cands"])
+    aligned = ctx.find_copies(g["cands"])
+    assert aligned == O.find_copies(g["contigs"], g["cands"])
     try:
-        ctx.copy_config(True)
-        O.find_copies_config(True)
-        aligned = ctx.find_copies(g["cands"])
-        assert aligned == O.find_copies(g["contigs"], g["cands"])
-    finally:
         ctx.copy_config(False)
         O.find_copies_config(False)
-    assert ctx.find_copies(g["cands"]) == whole == O.find_copies(g["contigs"], g["cands"])
+        whole = ctx.find_copies(g["cands"])
+        assert whole == O.find_copies(g["contigs"], g["cands"])
+    finally:
+        ctx.copy_config(None)
+        O.find_copies_config(None)
+    assert ctx.find_copies(g["cands"]) == aligned == O.find_copies(g["contigs"], g["cands"])
     n_shorter = 0
     for w, a in zip(whole, aligned):
         assert len(w) == len(a)                    # the same chains are accepted: the two filters do not see the mode
@@ -794,26 +794,27 @@ def test_star_msa_padded_rows(ctx):
 
 
 def test_aligned_interval_mode_pads_the_rows(ctx):
-    """Records in the reference's coordinates (hite_copy_config(1): the aligned interval of Util.py:8026) carry the candidate bases
-    the end extensions clipped; hite_flank_region_align_clip pads the rows with them.  Pinned: clip words HIP == twin, the fused
-    pipeline == the oracle chain on the padded windows -- and the calls do not fall behind the whole-candidate mode's."""
+    """Records in the reference's coordinates (the aligned interval of Util.py:8026, the default) carry the candidate bases the end
+    extensions clipped; hite_flank_region_align_clip pads the rows with them.  Pinned: clip words HIP == twin, the fused pipeline ==
+    the oracle chain on the padded windows -- and the calls do not fall behind the whole-candidate mode's."""
     import oracle_pipeline as OP
     import synth_small
 
     g = synth_small.make(23, n_fam=24)
     ctx.genome_pack(g["contigs"])
     ctx.release_copy_index()
-    whole = ctx.find_copies(g["cands"], clips=True)
-    assert all(cp[5] == 0 for t in whole for cp in t)            # whole-candidate intervals: nothing to pad
-    res_whole, _ = ctx.flank_region_align("tir", g["cands"], whole, plant=1)
     try:
-        ctx.copy_config(True)
-        O.find_copies_config(True)
-        tab = ctx.find_copies(g["cands"], clips=True)
-        assert tab == O.find_copies(g["contigs"], g["cands"], clips=True)
-    finally:
         ctx.copy_config(False)
         O.find_copies_config(False)
+        whole = ctx.find_copies(g["cands"], clips=True)
+        assert whole == O.find_copies(g["contigs"], g["cands"], clips=True)
+    finally:
+        ctx.copy_config(None)
+        O.find_copies_config(None)
+    assert all(cp[5] == 0 for t in whole for cp in t)            # whole-candidate intervals: nothing to pad
+    res_whole, _ = ctx.flank_region_align("tir", g["cands"], whole, plant=1)
+    tab = ctx.find_copies(g["cands"], clips=True)
+    assert tab == O.find_copies(g["contigs"], g["cands"], clips=True)
     assert sum(cp[5] != 0 for t in tab for cp in t) > 20
     res, _ = ctx.flank_region_align("tir", g["cands"], tab, plant=1)
     for cand, cp, r in zip(g["cands"], tab, res):
@@ -842,7 +843,7 @@ def test_aligned_interval_mode_through_the_host_mirror(ctx, tmp_path):
     real, low = tmp_path / "real.fa", tmp_path / "low.fa"
     uctx = util.set_reference(str(gref))
     try:
-        uctx.copy_config(True)
+        uctx.copy_config(True)      # (the default; explicit here)
         cps = util.get_full_length_copies_minimap2(str(cand), str(gref))
         assert sum(cp[5] != 0 for v in cps.values() for cp in v) > 20
         tab = uctx.find_copies(g["cands"], clips=True)
@@ -850,7 +851,7 @@ def test_aligned_interval_mode_through_the_host_mirror(ctx, tmp_path):
         # (after the direct call: the low-copy rescue inside the stage packs other sequences into the context)
         t, l = util.flank_region_align_v5(str(cand), str(real), 50, str(gref), None, "tir", str(tmp_path), 1, 0, None, "", 1, 0, 0, str(low))
     finally:
-        uctx.copy_config(False)
+        uctx.copy_config(None)
     direct = {"q%d" % i: r[2] for i, r in enumerate(res) if r[0]}
     both = dict(t, **l)
     assert len(direct) >= 6 and len(both) >= 3

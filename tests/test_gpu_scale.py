@@ -38,7 +38,7 @@ def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",), **workload_kw):
     d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
     ctx.align_stats(reset=True)
     nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
-    # zero words unless the records are aligned intervals (HITE_COPY_INTERVAL=aligned): then the rows are padded (HITE_TEST_NO_CLIP=1,
+    # the clip words of the records (aligned intervals, the default): the rows are padded by them; zero with HITE_COPY_INTERVAL=whole (HITE_TEST_NO_CLIP=1,
     # tools/copy_interval_modes.py: the bare windows, as for a copy table that carries no clip words)
     p_cl = 0 if os.environ.get("HITE_TEST_NO_CLIP") == "1" else ctx.copy_clips_dev()
     # the same candidates and copy table judged as Helitron / non-LTR as well (judge_Helitron_transposons.py:86-97,
@@ -218,15 +218,24 @@ def test_c2_fine_stage_matches_oracle_chain(c2):
     assert st["certified"] >= 0.80 * st["pairs"]            # measured r02: 0.89 (exact_cap 8)
 
 
-def test_c2_reference_coordinates_with_padded_rows(c2):
-    """C2 with the copy records in the reference's coordinates (HITE_COPY_INTERVAL=aligned: reference_start + 1 .. reference_end,
-    Util.py:8026) and the rows padded by the clipped candidate bases (hite_flank_region_align_clip_dev): the mode is usable -- hardly
-    any wide fall-back (8 633 without the pads, round 4), TE calls not behind the default mode's --, and pinned: 1 000 random
-    candidates re-judged by the oracle chain on the same records + clip words."""
+def test_c2_whole_candidate_intervals(c2):
+    """C2 in the other interval mode (HITE_COPY_INTERVAL=whole: the whole-candidate intervals of rounds 2-4) beside the default -- copy
+    records in the reference's coordinates (reference_start + 1 .. reference_end, Util.py:8026) with the rows padded by the clipped
+    candidate bases (hite_flank_region_align_clip_dev).  The default mode is usable at size: hardly any wide fall-back (8 633 with bare
+    aligned windows, round 4), TE calls not behind the whole-candidate mode's; 1 000 random candidates of the whole-candidate run
+    re-judged by the oracle chain (test_c2_fine_stage_matches_oracle_chain re-judges all 5 000 of the default run)."""
     from hite_amd import _lib as hl
 
-    base_te = int((c2["calls"]["is_te"] != 0).sum())
-    os.environ["HITE_COPY_INTERVAL"] = "aligned"
+    te = int((c2["calls"]["is_te"] != 0).sum())
+    n_tir, called, checked, exact, near = boundary_stats(c2)
+    st = c2["align"]
+    print("C2, reference coordinates + padded rows (default): %d copies (%d with a clip); TE calls %d; of %d checked: both ends exact %d, "
+          "within 3 bp %d; wide fall-backs %d, dropped %d, certified %d of %d pairs"
+          % (len(c2["found"]["contig"]), int((c2["found"]["clip"] != 0).sum()), te, checked, exact, near, st["fallback"], st["dropped"],
+             st["certified"], st["pairs"]))
+    assert (c2["found"]["clip"] != 0).sum() > 10000
+    assert st["fallback"] < 400 and st["dropped"] == 0
+    os.environ["HITE_COPY_INTERVAL"] = "whole"
     hl.load().hite_copy_config(-1)
     try:
         R = run_fine(100, 500, 0, c2["seed"])
@@ -234,16 +243,12 @@ def test_c2_reference_coordinates_with_padded_rows(c2):
         os.environ.pop("HITE_COPY_INTERVAL", None)
         hl.load().hite_copy_config(-1)
     try:
-        te = int((R["calls"]["is_te"] != 0).sum())
-        n_tir, called, checked, exact, near = boundary_stats(R)
-        st = R["align"]
-        print("C2, reference coordinates + padded rows: %d copies (%d with a clip); TE calls %d (default mode %d); of %d checked: both ends exact %d, "
-              "within 3 bp %d; wide fall-backs %d, dropped %d, certified %d of %d pairs"
-              % (len(R["found"]["contig"]), int((R["found"]["clip"] != 0).sum()), te, base_te, checked, exact, near, st["fallback"], st["dropped"],
-                 st["certified"], st["pairs"]))
-        assert (R["found"]["clip"] != 0).sum() > 10000
-        assert st["fallback"] < 100 and st["dropped"] == 0
-        assert te >= 0.95 * base_te
+        te_w = int((R["calls"]["is_te"] != 0).sum())
+        _n, _called, checked_w, exact_w, near_w = boundary_stats(R)
+        print("C2, whole-candidate intervals: %d copies; TE calls %d; of %d checked: both ends exact %d, within 3 bp %d; wide fall-backs %d"
+              % (len(R["found"]["contig"]), te_w, checked_w, exact_w, near_w, R["align"]["fallback"]))
+        assert (R["found"]["clip"] != 0).sum() == 0
+        assert te >= 0.95 * te_w
         bad, _n = oracle_check(R, 1000, 3)
         assert bad == []
     finally:
@@ -273,7 +278,7 @@ def test_c2_wider_bands_never_lower_a_cost(c2):
             nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
             ctx.align_stats(reset=True)
             ctx.flank_region_align_dev("tir", 1, n, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
-                                       d_calls.data_ptr(), d_cons.data_ptr(), cap)
+                                       d_calls.data_ptr(), d_cons.data_ptr(), cap, d_clip=ctx.copy_clips_dev())
             torch.cuda.synchronize()
             seen[exact] = (ctx.align_stats(), d_calls.cpu().numpy().view(CALL_DTYPE).copy())
     finally:

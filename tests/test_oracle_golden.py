@@ -633,12 +633,12 @@ def test_twin_padded_rows_and_the_aligned_interval_mode():
     ops_low, d_low = O.nw_pair(rows[0], low)
     assert d_dot - d_low == 35 and np.array_equal(ops_dot, ops_low)
     g = synth_small.make(23, n_fam=24)
+    tab = O.find_copies(g["contigs"], g["cands"], clips=True)         # the default: records in the reference's coordinates
     try:
-        O.find_copies_config(True)
-        tab = O.find_copies(g["contigs"], g["cands"], clips=True)
-    finally:
         O.find_copies_config(False)
-    whole = O.find_copies(g["contigs"], g["cands"], clips=True)
+        whole = O.find_copies(g["contigs"], g["cands"], clips=True)
+    finally:
+        O.find_copies_config(None)
     assert all(cp[5] == 0 for t in whole for cp in t) and sum(cp[5] != 0 for t in tab for cp in t) > 20
     te = lambda table: sum(bool(OP.fine_stage_candidate("tir", c, t, g["contigs"], plant=1)[0]) for c, t in zip(g["cands"], table))  # noqa: E731
     n_pad, n_bare, n_whole = te(tab), te([[cp[:4] for cp in t] for t in tab]), te(whole)

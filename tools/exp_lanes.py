@@ -45,7 +45,7 @@ class Lane:
         c = self.ctx
         nc, p_cf, p_ct, p_s1, p_e1, p_mn, _ = c.find_copies_dev(self.n, self.d_cand.data_ptr(), self.d_off.data_ptr(), self.bytes, self.sp)
         c.flank_region_align_dev("tir", 1, self.n, self.d_cand.data_ptr(), self.d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
-                                 self.d_calls.data_ptr(), self.d_cons.data_ptr(), self.cap, self.sp)
+                                 self.d_calls.data_ptr(), self.d_cons.data_ptr(), self.cap, self.sp, d_clip=c.copy_clips_dev())
         self.stream.synchronize()
 
 ref = None

@@ -55,7 +55,7 @@ class Half:
     def step(self):
         nc, p_cf, p_ct, p_s1, p_e1, p_mn, _ = self.ctx.find_copies_dev(self.n, self.d_cand.data_ptr(), self.d_cand_off.data_ptr(), self.bytes, self.sp)
         self.ctx.flank_region_align_dev("tir", 1, self.n, self.d_cand.data_ptr(), self.d_cand_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn,
-                                        50, self.d_calls.data_ptr(), self.d_cons.data_ptr(), self.cons_cap, self.sp)
+                                        50, self.d_calls.data_ptr(), self.d_cons.data_ptr(), self.cons_cap, self.sp, d_clip=self.ctx.copy_clips_dev())
         self.stream.synchronize()
 
 halves = [Half(r, parts) for r in range(parts)]
