@@ -298,10 +298,11 @@ int hite_itr_search_dev(hite_ctx *ctx, int64_t n, const uint8_t *d_seqs, const i
  * hite_flank_region_align consumes (1-based inclusive coordinates).  n_cand < 2^19 per call.
  * _dev: the returned device arrays live in the index state's arena until the next call. */
 int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream);
-/* which interval the copy records of hite_find_copies[_dev] carry (process-wide): 0 = the interval of the WHOLE candidate, the
- * ends that the extension clipped extrapolated on the diagonal (default; DESIGN.md section 2, deviation v); 1 = the ALIGNED
- * interval, reference_start + 1 .. reference_end exactly as get_copies_minimap2 reports it (Util.py:8026); -1 = take the
- * setting from the environment again (HITE_COPY_INTERVAL=aligned).  Both are twin-pinned (orc_find_copies_config). */
+/* which interval the copy records of hite_find_copies[_dev] carry (process-wide): 1 = the ALIGNED interval, reference_start + 1 ..
+ * reference_end exactly as get_copies_minimap2 reports it (Util.py:8026) -- the default since round 5, with the clipped candidate
+ * bases handed on beside the records (hite_copy_clips) --; 0 = the interval of the WHOLE candidate, the ends that the extension clipped
+ * extrapolated on the diagonal (the default of rounds 2-4); -1 = take the setting from the environment again
+ * (HITE_COPY_INTERVAL=aligned | whole).  Both are twin-pinned (orc_find_copies_config). */
 int hite_copy_config(int32_t aligned_interval);
 void hite_copy_index_release(void *state);
 /* sizes of the last hite_find_copies[_dev] call on this index (diagnostics / roofline accounting):
@@ -355,8 +356,8 @@ int hite_find_copies_restricted(hite_ctx *ctx, void **state_io, int32_t n_cand, 
                                 int32_t *anchors, int64_t *n_out);
 /* The clip words of the records of the last hite_find_copies[_dev] / _restricted[_dev] call on this index, in record order: candidate
  * bases the left | right << 16 end extension cut off (minimap2 would soft-clip them; each <= 5 % of the candidate), in the orientation
- * of the genome.  Zero for whole-candidate intervals (the default: they are inside the interval); for aligned intervals
- * (hite_copy_config(1)) hite_flank_region_align_clip[_dev] takes them.  _dev: *d_clip (NULL when the call found nothing) lives as long
+ * of the genome.  For aligned intervals (the default) hite_flank_region_align_clip[_dev] takes them; zero for whole-candidate
+ * intervals (hite_copy_config(0): the clipped bases are inside the interval).  _dev: *d_clip (NULL when the call found nothing) lives as long
  * as the copy table; host form: cap >= the number of records, else HITE_ECAP. */
 int hite_copy_clips_dev(void *state, const uint32_t **d_clip, int64_t *n);
 int hite_copy_clips(void *state, int64_t cap, uint32_t *clip);
@@ -445,18 +446,19 @@ int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32_t te_type,
                                 int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1, const int64_t *d_end1,
                                 const uint8_t *d_minus, int32_t flank, hite_call *d_calls, uint8_t *d_cons,
                                 int64_t cons_cap, int64_t *stats_out, void *stream);
-/* The same stage for copy records in the REFERENCE'S coordinates (hite_copy_config(1): reference_start + 1 .. reference_end of the
- * alignment, Util.py:8026, as get_copies_minimap2 hands them to flank_region_align_v5).  Such a record covers only the part of the
+/* The same stage for copy records in the REFERENCE'S coordinates (reference_start + 1 .. reference_end of the alignment, Util.py:8026,
+ * as get_copies_minimap2 hands them to flank_region_align_v5: what hite_find_copies reports by default).  Such a record covers only the part of the
  * candidate that aligned; `clip` (per copy record, may be NULL = no pads: hite_flank_region_align) says how many candidate bases the
  * two end extensions clipped -- left | right << 16, in the orientation of the genome (hite_copy_clips[_dev]) -- and the row's window
- * (interval + flanks, Util.py:8110-8125) is padded by them with HITE_ROW_PAD: in front by the left clip (a minus copy: the right
- * one, its window is reverse-complemented), behind by the other; the first500 + last500 form of a long window (Util.py:8119) is
+ * (interval + flanks, Util.py:8110-8125) is padded by them with pad bytes (HITE_IS_ROW_PAD): the CENTRE's own first / last bases in
+ * lower case, which match the centre positions they face -- in front by the left clip (a minus copy: the right one, its window is
+ * reverse-complemented), behind by the other; the centre (the first row kept) is never padded; the first500 + last500 form of a long window (Util.py:8119) is
  * cut from the padded window; the <= 100 rows are chosen by the length of the genome window.  A padded row faces the part of the
  * centre its copy was found with, so its path stays on the diagonal; the pads leave the alignment as gaps of the row (where mafft,
  * which does not charge terminal gaps like internal ones, leaves such a row unaligned).  Without the pads every such row is aligned
  * GLOBALLY at 3 per gap base to a centre that is clip_l + clip_r bases longer: on config C2 8 633 rows left the band and TE calls
- * fell by a fifth (profiles/r04_scale_tests.txt); with them the mode calls as many TEs as the whole-candidate default
- * (tests/test_gpu_scale.py::test_c2_reference_coordinates_with_padded_rows). */
+ * fell by a fifth (profiles/r04_scale_tests.txt); with them the mode calls as many TEs as the whole-candidate mode and puts more
+ * consensus ends on the planted element (tests/test_gpu_scale.py::test_c2_whole_candidate_intervals, profiles/r05_scale_tests.txt). */
 int hite_flank_region_align_clip(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
                                  const int64_t *cand_off, const int32_t *copy_first, int64_t n_copies, const int32_t *contig,
                                  const int64_t *start1, const int64_t *end1, const uint8_t *minus, const uint32_t *clip, int32_t flank,

@@ -31,13 +31,14 @@
  *   a0 = glo - (genome bases of the left extension) .. a1 = ghi + K + (genome bases of the right one).  The chain is kept
  *   when aligned >= 95 % of Lq and aligned >= 95 % of a1 - a0: get_copies_minimap2's two filters,
  *   query_alignment_length / len(query) >= 0.95 and query_alignment_length / (M + D) >= 0.95 (Util.py:8008-8022).
- *   DEVIATION, deliberate: the reference reports the aligned interval (reference_start + 1, reference_end); this build hands
- *   on start0 = a0 - clipped_left, end0 = a1 + clipped_right (clamped to the contig), the interval of the WHOLE candidate.
- *   With the aligned interval a candidate whose ends overhang the element by more than two bases loses its 20-bp anchors in
- *   every row but its own (the overhang columns are sparse and removed, judge_boundary_v5 answers 'nb'); with the whole-
- *   candidate interval the rows keep equal extents and the boundary search walks inwards to the homology boundary: on 300
- *   candidates with ends perturbed by +-30 bp the oracle chain calls 152 TE (51 with both ends exact) on aligned intervals,
- *   209 (127) on whole-candidate intervals (round 2's finder, which extrapolated without looking at the bases: 190 (92)).
+ *   The record carries the ALIGNED interval, reference_start + 1 .. reference_end as the reference reports it (Util.py:8026): a0 + 1 ..
+ *   a1 -- the default since round 5, with the clipped candidate bases beside it (orc_find_copies_clips: the rows of the star alignment
+ *   are padded by them, hite_flank_region_align_clip) --, or (orc_find_copies_config(0), the default of rounds 2-4) the interval of
+ *   the WHOLE candidate: start0 = a0 - clipped_left, end0 = a1 + clipped_right, clamped to the contig.  History of the switch: with
+ *   bare aligned windows a candidate whose ends overhang the element loses its 20-bp anchors in every row but its own and every row
+ *   pays 3 per clipped base in the global alignment (300 candidates with ends perturbed by +-30 bp: 152 TE calls, 51 with both ends
+ *   exact, against 209 / 127 on whole-candidate intervals); with the rows padded by the clipped bases the aligned intervals call as
+ *   many TEs as the whole-candidate ones and put more consensus ends on the element (600 candidates: 388 / 248 against 381 / 234).
  *   (Round 2 accepted "anchor span >= 80 % of the candidate" with extrapolated ends: recall of the planted full-length copies
  *   0.62 -> 0.84, of those within 15 % of the candidate 0.81 -> 0.94, precision 1.000, on a 20 Mbp / 100 family sample.)
  *   Per candidate the copies are ordered by (anchors descending (capped at 4095), start ascending) and the first 300 are kept.
