@@ -7,13 +7,16 @@ TAG=${1:-r04}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-coarse --verify 0"
+BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-coarse --no-modes --verify 0"
 timeout 900 python bench.py > $OUT/${TAG}_bench_fine.json 2> $OUT/${TAG}_bench_fine.err
 timeout 600 python bench.py --config C2 > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
 timeout 900 python bench.py --config C5 --steps 3 --warmup 1 > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err
+timeout 600 python bench.py --config C4share > $OUT/${TAG}_bench_c4share.json 2> $OUT/${TAG}_bench_c4share.err
+if [ "${QUICK:-0}" != "1" ]; then      # (QUICK=1: the benches and the rocprofv3 passes only)
 timeout 600 python -m pytest tests/test_gpu_scale.py -q -m gpu -s -k "c2 or c3 or c5" > $OUT/${TAG}_scale_tests_raw.txt 2>&1
-grep -E "(copy finder|fine stage|coarse stage|C3:|C5 merge|cost sums)" $OUT/${TAG}_scale_tests_raw.txt | sed "s/^\.*//" > $OUT/${TAG}_scale_tests.txt
+grep -E "(copy finder|fine stage|coarse stage|C3:|C5 merge|cost sums|^\.*C2,)" $OUT/${TAG}_scale_tests_raw.txt | sed "s/^\.*//" > $OUT/${TAG}_scale_tests.txt
 timeout 600 python tools/copy_interval_modes.py >> $OUT/${TAG}_scale_tests.txt 2> $OUT/copy_interval_modes.err
+fi
 HITE_ALIGN_EXACT=16 timeout 600 python bench.py --no-cpu-baseline --no-coarse > $OUT/${TAG}_bench_fine_cap16.json 2> /dev/null
 HITE_ALIGN_EXACT=0 timeout 600 python bench.py --no-cpu-baseline --no-coarse > $OUT/${TAG}_bench_fine_cap0.json 2> /dev/null
 rm -rf $OUT/prof_stats $OUT/prof_sq $OUT/prof_fetch $OUT/prof_write
