@@ -217,16 +217,19 @@ __device__ __forceinline__ void emit_padded(const uint32_t *__restrict__ bases, 
     int64_t n1 = a - ws; n1 = n1 < 0 ? 0 : (n1 > cnt ? cnt : n1);                 // pad bytes in front
     const int64_t off = ws + n1 - a;                                              // first window position wanted
     int64_t n2 = len - off; n2 = n2 < 0 ? 0 : (n2 > cnt - n1 ? cnt - n1 : n2);    // genome bytes
-    for (int64_t i = lane; i < n1; i += 64) {
-        const int64_t cpos = ws + i;
-        dst[i] = cpos < C.len ? (uint8_t)(window_byte(bases, nmask, C.g_lo, C.len, C.minus, cpos) | 0x20u) : (uint8_t)HITE_ROW_PAD;
+    // the pads in front and the first bases behind them, up to the next 16-byte edge of the slot, byte by byte in ONE loop; the rest of
+    // the bases then leaves in 16-byte stores (emit_span on an aligned address)
+    int64_t lead = n2 > 0 ? (int64_t)((0 - (uintptr_t)(dst + n1)) & 15) : 0;
+    if (lead > n2) lead = n2;
+    for (int64_t i = lane; i < n1 + lead; i += 64) {
+        unsigned ch;
+        if (i < n1) {
+            const int64_t cpos = ws + i;
+            ch = cpos < C.len ? (window_byte(bases, nmask, C.g_lo, C.len, C.minus, cpos) | 0x20u) : (unsigned)HITE_ROW_PAD;
+        } else ch = window_byte(bases, nmask, g_lo, len, mn, off + (i - n1));
+        dst[i] = (uint8_t)ch;
     }
-    if (n2 > 0) {       // (the pads shift the bases off the slot's alignment: up to 3 single bytes first, so that the rest goes in 16-byte stores)
-        const int64_t lead = (int64_t)((0 - (uintptr_t)(dst + n1)) & 3);
-        const int64_t l4 = lead < n2 ? lead : n2;
-        if (l4) emit_span4(bases, nmask, g_lo, len, mn, off, l4, dst + n1, lane);
-        if (n2 > l4) emit_span(bases, nmask, g_lo, len, mn, off + l4, n2 - l4, dst + n1 + l4, lane);
-    }
+    if (n2 > lead) emit_span(bases, nmask, g_lo, len, mn, off + lead, n2 - lead, dst + n1 + lead, lane);
     for (int64_t i = n1 + n2 + lane; i < cnt; i += 64) {
         const int64_t j = ws + i - a - len;                                       // pad byte j of the b behind
         const int64_t cpos = C.len - b + j;
