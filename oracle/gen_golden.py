@@ -879,6 +879,8 @@ def gen_chain_variants(U, tmp):
         tables = {}
         for s_ in range(ns):
             tables["chr%d.fa" % s_] = [(qnames[q], "chr%d" % s2, a, b, c, e) for (q, s2, a, b, c, e) in rows if s2 == s_]
+        if ci == 1:     # a line whose subject IS the query (the library sequence among the subjects): get_copies_v1 skips it (Util.py:7045-7046)
+            tables["chr0.fa"].insert(len(tables["chr0.fa"]) // 2, (qnames[0], qnames[0], 1, qlen[0], 1, qlen[0]))
         calls = []
 
         def fake_system(cmd, _tables=tables, _calls=calls):
@@ -953,7 +955,13 @@ def gen_lib_dedup(U, tmp):
         with open(bl, "w") as fh:
             for (q, s, a, b, c, d) in rows:
                 fh.write("%s\t%s\t95.0\t%d\t0\t0\t%d\t%d\t%d\t%d\t1e-20\t200\n" % (names[q], names[s], b - a + 1, a, b, c, d))
+        if ci % 4 == 1:       # a chunk directory left by an earlier run is removed first (Util.py:12163-12164): a stale file must not come back
+            stale = os.path.join(work, "LTR_query_records_t_chunks")
+            os.makedirs(stale, exist_ok=True)
+            with open(os.path.join(stale, "chunk_999.pkl"), "wb") as fh:
+                fh.write(b"stale")
         files = U.process_blast_results_in_chunks(bl, work, "t", chunk_size=chunk_size)
+        assert not any(f.endswith("chunk_999.pkl") for f in files) and not os.path.exists(os.path.join(work, "LTR_query_records_t_chunks", "chunk_999.pkl"))
         qlens = {names[i]: lens[i] for i in range(nseq)}
         lr_dir = os.path.join(work, "lr")
         os.makedirs(lr_dir, exist_ok=True)
@@ -1069,6 +1077,17 @@ def gen_cons_v1(U, tmp):
             got = U.generate_cons_v1(0, path, cdir, 1)
             cases.append(dict(names=[n for n, _s in recs], seqs=[sq for _n, sq in recs], ninja={str(k): v for k, v in ninja.items()},
                               expected={k: v for k, v in got.items()}))
+        # Ninja writes no cluster at all: "no reliable consensus, the original sequences instead" (Util.py:12495-12498)
+        recs = [("G%d-fam0_e#LTR/Copia" % k, casegen.rand_seq(rng, 180 + 40 * k)) for k in range(3)]
+        cdir = os.path.join(tmp, "cons_v1_empty")
+        os.makedirs(cdir, exist_ok=True)
+        path = os.path.join(cdir, "0.fa")
+        write_fasta(path, [n for n, _s in recs], [sq for _n, sq in recs])
+        state["ninja"] = {}
+        state["first_call"] = True
+        got = U.generate_cons_v1(0, path, cdir, 1)
+        assert got == dict(recs)
+        cases.append(dict(names=[n for n, _s in recs], seqs=[sq for _n, sq in recs], ninja={}, expected={k: v for k, v in got.items()}))
     finally:
         U.os.system = real_system
     print("cons_v1: %d cases, %d consensus sequences" % (len(cases), sum(len(c["expected"]) for c in cases)))

@@ -457,6 +457,8 @@ def test_generate_cons_v1_golden():
             back = {i: q for q, i in enumerate(order)}
             rows = [bytes(m[back[i]]).decode() for i in range(len(seqs))]
             got[members[-1]] = O.cons_majority(rows)
+        if not c["ninja"]:          # no cluster came out of Ninja: the original sequences (Util.py:12495-12498)
+            got = seq_of
         assert got == c["expected"], ci
 
 
