@@ -193,3 +193,29 @@ def test_uncertified_rows_of_pipeline_windows_equal_the_definition():
                 exp, d = O.nw_pair(wins[0], row)
                 assert info["U"] == d and np.array_equal(ops, exp), (len(wins[0]), len(row), info, d)
     assert pairs >= 20 and unc >= 5, (pairs, unc)
+
+
+def test_twin_equals_definition_on_padded_rows():
+    """rows padded as hite_flank_region_align_clip pads them (the centre's own first / last bases in lower case, or '.'): the banded
+    twin against the band-free definition, which reads a lower-case row byte as its base -- a certified pair is the definition's
+    alignment, ops and cost; lower-case pads cost nothing on the centre's diagonal, '.' pads 1 each"""
+    rng = np.random.default_rng(8026)
+    n_cert = n_lower_free = 0
+    for it in range(80):
+        a, b = (bytes(x).decode() for x in make_pair(rng, int(rng.integers(120, 700))))
+        pf, pb = int(rng.integers(0, 60)), int(rng.integers(0, 60))
+        cut = b[min(pf, len(b) // 3): len(b) - min(pb, len(b) // 3)]
+        low = a[:pf].lower() + cut + (a[len(a) - pb:].lower() if pb else "")
+        dot = "." * pf + cut + "." * pb
+        exp_low, d_low = O.nw_pair(a, low)
+        exp_dot, d_dot = O.nw_pair(a, dot)
+        assert O.nw_pair(a, low.upper())[1] == d_low                      # a lower-case byte is its base, nothing else
+        assert d_dot >= d_low
+        n_lower_free += d_dot - d_low == pf + pb
+        for row, exp, d in ((low, exp_low, d_low), (dot, exp_dot, d_dot)):
+            ops, info = O.align_pair(a, row, 16)
+            assert ops is not None and O.ops_cost(a, row, ops) == info["U"] >= d
+            if info["cert"]:
+                assert info["U"] == d and (ops == exp).all()
+                n_cert += 1
+    assert n_cert > 100 and n_lower_free > 40
