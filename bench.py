@@ -903,9 +903,10 @@ def c5_mode(args):
 
     def step(gather):
         nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n_cand, d_cand.data_ptr(), d_off.data_ptr(), nbytes, sp)
-        state["found"], state["n_copies"] = (nc, p_cf, p_ct, p_s1, p_e1, p_mn, 0), nc
+        p_cl = ctx.copy_clips_dev()       # (records in the reference's coordinates: the rows are padded by the clipped candidate bases)
+        state["found"], state["n_copies"] = (nc, p_cf, p_ct, p_s1, p_e1, p_mn, p_cl), nc
         ctx.flank_region_align_dev("tir", 1, n_cand, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
-                                   d_calls.data_ptr(), d_cons.data_ptr(), cap, sp)
+                                   d_calls.data_ptr(), d_cons.data_ptr(), cap, sp, d_clip=p_cl)
         stream.synchronize()
         if not gather:
             return None
