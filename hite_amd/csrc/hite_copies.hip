@@ -1061,6 +1061,7 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
     CCHK(arena_alloc(ctx, S->out, (size_t)(n_cand + 2) * 4, &p)); ofirst32 = (int32_t *)p;
     *d_copy_first = ofirst32; *n_copies = 0;
     S->out_clip = nullptr; S->out_n = 0;
+    ctx->last_copy_start1 = nullptr; ctx->last_copy_clip = nullptr;
     HITE_CHECK(ctx, hipMemsetAsync(ofirst32, 0, (size_t)(n_cand + 2) * 4, st));
     *d_contig = nullptr; *d_start1 = nullptr; *d_end1 = nullptr; *d_minus = nullptr; *d_anchors = nullptr;
     if (n_cand == 0 || cand_bytes <= 0 || S->M == 0) return HITE_OK;
@@ -1300,6 +1301,7 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
     hipLaunchKernelGGL(emit_copies_kernel, CGRID(ncp), 0, st, ncp, ckey, cval, cstart, ofirst, r_contig, r_s1, r_e1, r_minus, r_anch, r_clip,
                        o_contig, o_s1, o_e1, o_minus, o_anch, o_clip);
     S->out_clip = o_clip; S->out_n = nout;
+    ctx->last_copy_start1 = o_s1; ctx->last_copy_clip = o_clip;
     HITE_CHECK(ctx, hipGetLastError());
     *d_contig = o_contig; *d_start1 = o_s1; *d_end1 = o_e1; *d_minus = o_minus; *d_anchors = o_anch;
     // if the temporaries grew into several chunks during this call, merge them NOW (they are dead; the copy table lives in

@@ -522,6 +522,10 @@ extern "C" int hite_flank_region_align_clip_dev(hite_ctx *ctx, void **state_io, 
                                                 int64_t *stats_out /* 12 x int64, host, may be NULL */, void *stream) {
     if (!ctx || !ctx->d_bases || !state_io || n_cand < 0 || n_copies < 0 || te_type < 0 || te_type > 2) return HITE_EINVAL;
     if (n_cand == 0) return HITE_OK;
+    // the table the copy finder returned last on this context, handed over without its clip words (hite_flank_region_align_dev, a
+    // caller written before round 5): they are taken from the finder -- its records are aligned intervals by default, and rows cut
+    // from those without the pads lose a fifth of the calls
+    if (!d_clip && d_start1 && (const void *)d_start1 == ctx->last_copy_start1) d_clip = ctx->last_copy_clip;
     hipStream_t st = (hipStream_t)stream;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
     PipeState *S = (PipeState *)*state_io;

@@ -459,6 +459,8 @@ int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32_t te_type,
  * GLOBALLY at 3 per gap base to a centre that is clip_l + clip_r bases longer: on config C2 8 633 rows left the band and TE calls
  * fell by a fifth (profiles/r04_scale_tests.txt); with them the mode calls as many TEs as the whole-candidate mode and puts more
  * consensus ends on the planted element (tests/test_gpu_scale.py::test_c2_whole_candidate_intervals, profiles/r05_scale_tests.txt). */
+/* (_dev forms: when d_clip is NULL and d_start1 is the very array hite_find_copies[_dev] returned last on this context, the clip words of
+ * that call are used -- a caller that passes the finder's device table straight on needs no change; host tables: pass `clip`.) */
 int hite_flank_region_align_clip(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
                                  const int64_t *cand_off, const int32_t *copy_first, int64_t n_copies, const int32_t *contig,
                                  const int64_t *start1, const int64_t *end1, const uint8_t *minus, const uint32_t *clip, int32_t flank,

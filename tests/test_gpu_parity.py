@@ -829,6 +829,44 @@ def test_aligned_interval_mode_pads_the_rows(ctx):
     assert te(res) >= te(res_bare) and te(res) >= 0.9 * te(res_whole)
 
 
+def test_finder_table_handed_on_without_clip_pointer(ctx):
+    """hite_find_copies_dev -> hite_flank_region_align_dev (the call sequence of rounds 1-4, no clip pointer): the device table of the
+    finder is recognised and its clip words are used -- the calls are those of the explicit form, not those of bare aligned windows"""
+    import synth_small
+    import torch
+    from hite_amd._lib import CALL_DTYPE
+
+    g = synth_small.make(23, n_fam=24)
+    ctx.genome_pack(g["contigs"])
+    ctx.release_copy_index()
+    ctx.copy_index_build()
+    dev = torch.device("cuda", 0)
+    cb = [c.encode() for c in g["cands"]]
+    off = np.zeros(len(cb) + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in cb], out=off[1:])
+    d_cand = torch.from_numpy(np.frombuffer(b"".join(cb) + b"\0" * 64, dtype=np.uint8).copy()).to(dev)
+    d_off = torch.from_numpy(off).to(dev)
+    n, nbytes = len(cb), int(off[-1])
+    cap = nbytes + 200 * n + 4096
+    outs = []
+    for mode in ("implicit", "explicit", "none"):
+        d_calls = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
+        d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
+        nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
+        if mode == "none":      # the table copied elsewhere: an external table, no clip words -> bare aligned windows
+            s1 = torch.from_numpy(ctx.download(p_s1, nc, np.int64)).to(dev)
+            p_s1 = s1.data_ptr()
+        ctx.flank_region_align_dev("tir", 1, n, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50, d_calls.data_ptr(),
+                                   d_cons.data_ptr(), cap, d_clip=ctx.copy_clips_dev() if mode == "explicit" else 0)
+        torch.cuda.synchronize()
+        calls = d_calls.cpu().numpy().view(CALL_DTYPE).copy()
+        cons = d_cons.cpu().numpy()
+        outs.append([(int(c["is_te"]), cons[c["cons_off"]:c["cons_off"] + c["cons_len"]].tobytes() if c["is_te"] else b"") for c in calls])
+    assert outs[0] == outs[1]
+    print("finder table without a clip pointer == explicit clip pointer; an external copy of it (bare windows) differs in %d of %d calls"
+          % (sum(a != b for a, b in zip(outs[0], outs[2])), n))
+
+
 def test_aligned_interval_mode_through_the_host_mirror(ctx, tmp_path):
     """util.get_full_length_copies_minimap2 -> util.flank_region_align_v5 (the reference's two functions, Util.py:7933 / 8032) in the
     reference-coordinate mode: the clip words travel as a 6th field of the copy tuples and the stage's calls are the direct call's"""
