@@ -41,6 +41,9 @@ def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",), **workload_kw):
     # the clip words of the records (aligned intervals, the default): the rows are padded by them; zero with HITE_COPY_INTERVAL=whole (HITE_TEST_NO_CLIP=1,
     # tools/copy_interval_modes.py: the bare windows, as for a copy table that carries no clip words)
     p_cl = 0 if os.environ.get("HITE_TEST_NO_CLIP") == "1" else ctx.copy_clips_dev()
+    if not p_cl and nc > 0:     # (an EXTERNAL table: a copy of the start array -- the finder's own device table would get its clip words anyway)
+        ext_s1 = torch.from_numpy(ctx.download(p_s1, nc, np.int64)).to(dev)
+        p_s1 = ext_s1.data_ptr()
     # the same candidates and copy table judged as Helitron / non-LTR as well (judge_Helitron_transposons.py:86-97,
     # judge_Non_LTR_transposons.py:48-51 run the same flank_region_align_v5 with another TE_type)
     other = {}
