@@ -235,6 +235,11 @@ class Context:
         certificate (default 8 or $HITE_ALIGN_EXACT)"""
         self._check(self.lib.hite_align_config(self.h, int(exact_cap)), "hite_align_config")
 
+    def align_lanes(self, min_cols):
+        """which pairs the lane-parallel kernels take (hite_align_lanes): -1 = by the size of the call (default or
+        $HITE_ALIGN_LANES), >= 0 = pairs of at least this many columns (0: all), -2 = none.  Never changes a result."""
+        self._check(self.lib.hite_align_lanes(self.h, int(min_cols)), "hite_align_lanes")
+
     def align_stats(self, reset=False):
         """-> dict(pairs, certified, wide, fallback, dropped, cost, columns, exact_cap) accumulated since the last reset"""
         o = np.zeros(8, dtype=np.int64)

@@ -42,6 +42,8 @@
 #define AL_RECB 4096          // bytes of strip records per strip and block of 64 pairs: 64 check points, then 64 boundary records
 #define AL_DEFAULT_CAP 8      // exact mode: widest band (words) tried for a certificate unless configured otherwise
 #define AL_KBINS 2048        // strips per pair <= 32767 / 16 + 1
+#define AL_LANES_MIN_STRIPS 32     // lane-parallel kernels: never for pairs shorter than 512 columns (automatic mode)
+#define AL_LANES_DIV 2500          // automatic mode: a pair is long when its strips exceed (sum of the blocks' longest strips) * 64 / this
 
 struct AlignArgs {
     const uint8_t *win;
@@ -66,6 +68,18 @@ struct AlignArgs {
 };
 
 __device__ __forceinline__ uint32_t alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return __builtin_amdgcn_alignbit(hi, lo, sh); }
+// add with the carry-out as a wave mask / add this lane's bit of a wave mask (the carry chains that run along the lanes)
+__device__ __forceinline__ uint32_t add_co_mask(uint32_t a, uint32_t b, unsigned long long &carry_mask) {
+    uint32_t r;
+    asm volatile("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(carry_mask) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t add_mask_bit(uint32_t a, unsigned long long mask) {     // a + (this lane's bit of mask)
+    uint32_t r;
+    unsigned long long dummy;
+    asm volatile("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(dummy) : "v"(a), "s"(mask));
+    return r;
+}
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d, 64); v = o > v ? o : v; }
@@ -561,6 +575,175 @@ __global__ void __launch_bounds__(64) align_fwd8_pair_kernel(AlignArgs P, const 
 }
 
 // ---------------------------------------------------------------------------------------------
+// LANE-PARALLEL forward pass for the LONGEST pairs of a run (round 6): G lanes per pair, lane q of a group = word q of the
+// band (G = 4: the 4-word level, G = 8: the 8-word level); a wavefront carries 64 / G pairs.  A kernel of thread-per-pair
+// wavefronts cannot end before the dependent instruction chain of its longest pair (an 11 000-column window at ~165
+// instructions per column = 3.7 ms, whatever the batch); in a large batch that chain hides behind the other pairs, in a
+// small one -- a rank's share of a strong-scaling run, Util.py:8141-8147 gives every candidate its own process -- it IS the
+// step.  One word per lane cuts the chain to the recurrence of ONE word + what crosses the lanes: bit 31 of vpos / h2 / h1 / h0
+// of the word below (DPP row_shr:1; the lowest lane of a group takes the band-edge constants instead), the carry of the
+// multi-word addition (carry-lookahead on two ballots, as in the 64-lane fall-back, with the chain cut at every group's
+// top lane), the words that move down when the band moves (DPP row_shl:1) and the steering count of the two middle words
+// (a butterfly over the group).  Same recurrence, same steering, same check points and boundary records, bit for bit, as
+// align_fwd_kernel<G> -- the traceback kernels read either's records.
+// ---------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_row(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true); }
+template <int G>
+__device__ __forceinline__ int grp_sum(int v) {      // sum over the G lanes of a group (G = 4 or 8, groups aligned), in every lane
+    v += (int)dpp_row<0xB1>((uint32_t)v);            // quad_perm [1,0,3,2]
+    v += (int)dpp_row<0x4E>((uint32_t)v);            // quad_perm [2,3,0,1]
+    if (G == 8) v += (int)dpp_row<0x141>((uint32_t)v);   // row_half_mirror: the other quad of the 8
+    return v;
+}
+template <int G>
+__global__ void __launch_bounds__(64) align_fwd_lanes_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    constexpr int NW = G, W = 32 * NW, H = W / 2, S0 = NW / 2 - 1, PPW = 64 / G;
+    const int q = threadIdx.x & (G - 1);
+    const int li = blockIdx.x * PPW + (int)(threadIdx.x / G);
+    const int g = li < nlist ? list[li] : -1;
+    int m = 0, n = 0, g0 = 0, c = 0;
+    if (g >= 0) {
+        c = P.row_cand[g];
+        g0 = P.row_first[c];
+        if (g != g0) { m = P.win_len[g0]; n = P.win_len[g]; }
+    }
+    const int nmax = wave_max_i32(n);
+    if (nmax == 0) return;
+    const bool bot = q == 0, top = q == G - 1, wr = q == S0;       // lowest / highest word of the band; the lane that writes the records
+    const unsigned long long TOPM = G == 4 ? 0x8888888888888888ull : 0x8080808080808080ull;
+    const uint8_t *b = P.win + (g >= 0 ? P.win_off[g] : 0);
+    const uint4 *pl = P.planes + (g >= 0 ? P.plane_off[c] : 0);
+    char *rec0 = g >= 0 ? reinterpret_cast<char *>(P.rec[g]) : nullptr;
+    uint32_t X2 = q >= NW / 2 ? 0xffffffffu : 0u, X1 = X2, X0 = 0u, A0 = 0u, A1 = 0u, AN = 0xffffffffu;
+    int t = -H;
+    bool act = n > 0;
+    if (act) { const uint4 v = pl[((t + AL_PADR) >> 5) + q]; A0 = v.x; A1 = v.y; AN = v.z; }
+    int stop = AL_GAP * H, LO = -(1 << 28), HI = 1 << 28, status = 0;     // (stop: the lowest lane's is the pair's)
+    int fq = (t + W + AL_PADR) >> 5;
+    uint4 Wa = make_uint4(0, 0, 0xffffffffu, 0), Wb = Wa, Wc = Wa, bnext = make_uint4(0, 0, 0, 0);
+    if (act) { Wa = pl[fq]; Wb = pl[fq + 1]; Wc = pl[fq + 2]; bnext = *reinterpret_cast<const uint4 *>(b); }
+    for (int k = 0; k * AL_STRIP < nmax; k++) {
+        const bool sa = act && k * AL_STRIP < n;
+        uint4 bw = make_uint4(0, 0, 0, 0);
+        uint32_t f0 = 0, f1 = 0, fn = 0;
+        uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        {   // check point: words S0 and S0 + 1 = this lane's and the lane above's
+            const uint32_t p2 = dpp_row<0x101>(X2), p1 = dpp_row<0x101>(X1), p0 = dpp_row<0x101>(X0);
+            if (sa && wr) {
+                uint4 *ck = reinterpret_cast<uint4 *>(rec0 + (size_t)k * AL_RECB);
+                ck[0] = make_uint4(X2, p2, X1, p1);
+                ck[1] = make_uint4(X0, p0, (uint32_t)(t + 32 * S0), 0u);
+            }
+        }
+        if (sa) {
+            bw = bnext;
+            if ((k + 1) * AL_STRIP < n) bnext = *reinterpret_cast<const uint4 *>(b + (k + 1) * AL_STRIP);
+            const int fx = t + W + AL_PADR;
+            if ((fx >> 5) != fq) { Wa = Wb; Wb = Wc; fq++; Wc = pl[fq + 2]; }
+            const uint32_t sh = (uint32_t)fx & 31u;
+            f0 = alignbit(Wb.x, Wa.x, sh); f1 = alignbit(Wb.y, Wa.y, sh); fn = alignbit(Wb.z, Wa.z, sh);
+        }
+#pragma unroll
+        for (int cc = 0; cc < AL_STRIP; cc++) {
+            const int j = k * AL_STRIP + cc + 1;
+            const bool on = sa && j <= n;                // (the same in every lane of a group; the cross-lane moves run for every lane)
+            if ((cc & 3) == 0) {
+                // ---- band move: steering count of words S0 and S0 + 1, the word above for the shift
+                const int ds = grp_sum<G>((q == S0 || q == S0 + 1) ? slope_count(X2, X1, X0) : 0);
+                const uint32_t i2 = dpp_row<0x102>(X2 & 0xffu), i1 = dpp_row<0x102>(X1 & 0xffu), i0 = dpp_row<0x102>(X0 & 0xffu);   // word S0 + 2's low rows
+                const uint32_t u2 = dpp_row<0x101>(X2), u1 = dpp_row<0x101>(X1), u0 = dpp_row<0x101>(X0);
+                const uint32_t ua0 = dpp_row<0x101>(A0), ua1 = dpp_row<0x101>(A1), uan = dpp_row<0x101>(AN);
+                if (on) {
+                    int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 8 : 4);
+                    const int tr = m - H;
+                    if (t + s > tr) s = (tr - t) & ~3;
+                    const int need = tr - 3 - 8 * ((n - j) >> 2) - t;
+                    if (s < need) s = (need + 3) & ~3;
+                    if (s > 8) { status = 2; act = false; s = 8; }
+                    if (bot) stop += plane_sum(X2, X1, X0, (1u << s) - 1u) - AL_GAP * s;
+                    brec[(cc >> 2) * 2] = (uint32_t)(s >> 2) | (i2 << 2) | (i1 << 10) | (i0 << 18);
+                    X2 = alignbit(top ? 0xffffffffu : u2, X2, (uint32_t)s);
+                    X1 = alignbit(top ? 0xffffffffu : u1, X1, (uint32_t)s);
+                    X0 = alignbit(top ? 0u : u0, X0, (uint32_t)s);
+                    A0 = alignbit(top ? f0 : ua0, A0, (uint32_t)s);
+                    A1 = alignbit(top ? f1 : ua1, A1, (uint32_t)s);
+                    AN = alignbit(top ? fn : uan, AN, (uint32_t)s);
+                    f0 >>= s; f1 >>= s; fn >>= s;
+                    t += s;
+                    if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
+                    if (t + W < m) { const int jl = j + 3 < n ? j + 3 : n; const int v = t + W - jl; HI = v < HI ? v : HI; }
+                }
+            }
+            // ---- column
+            const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
+            const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
+            const uint32_t eq = ~((A0 ^ bm.m0) | (A1 ^ bm.m1) | AN | bm.inv);
+            const uint32_t vpos = X2 & X1;
+            const uint32_t B = eq | ~(X2 | X1 | X0);
+            const uint32_t pvr = dpp_row<0x111>(vpos);
+            const uint32_t pv = bot ? 0u : pvr;                        // bit 31: "vertical difference +3" of the row below this word
+            const uint32_t Pp = alignbit(vpos, pv, 31);
+            const uint32_t Y = Pp | B;
+            unsigned long long Gm;
+            const uint32_t sum0 = add_co_mask(B, Y, Gm);
+            uint32_t sum;
+            {   // carries along the lanes of a group: lane w generates (its sum wrapped) or propagates (its sum is all ones); a
+                // group's top lane does neither, so no carry crosses into the next group
+                const unsigned long long Pm = __ballot(sum0 == 0xffffffffu) & ~TOPM;
+                const unsigned long long Gc = Gm & ~TOPM, Yy = Pm | Gc, ss = Gc + Yy;
+                sum = add_mask_bit(sum0, ss ^ Gc ^ Yy);
+            }
+            const uint32_t Z = B | (Pp & (sum ^ B ^ Y));
+            const uint32_t h0 = ~(Z ^ X0), b1 = Z & X0, h1 = ~(X1 ^ b1), b2 = X1 & b1, h2 = ~(X2 ^ b2);
+            const uint32_t r2 = dpp_row<0x111>(h2), r1 = dpp_row<0x111>(h1), r0 = dpp_row<0x111>(h0);
+            const uint32_t hb2 = bot ? 0x80000000u : r2, hb1 = bot ? 0x80000000u : r1, hb0 = bot ? 0u : r0;     // below the band: +3
+            if (on) {
+                const uint32_t s2 = alignbit(h2, hb2, 31), s1 = alignbit(h1, hb1, 31), s0 = alignbit(h0, hb0, 31);
+                const uint32_t c1 = Z & s0, c2 = s1 & c1;
+                X0 = ~(Z ^ s0); X1 = ~(s1 ^ c1); X2 = ~(s2 ^ c2);
+                if (bot) stop += AL_GAP;
+                // 5 carry bits that enter word S0 (kept by the lane that owns it): carry of the addition, then bit 31 of the word
+                // below's vpos, h2, h1, h0 -- shifted in one after the other
+                uint32_t c5 = alignbit(hb0 >> 31, hb1, 31);
+                c5 = alignbit(c5, hb2, 31);
+                c5 = alignbit(c5, pv, 31);
+                c5 = (c5 << 1) | (sum - sum0);
+                const int sh = 26 + 5 * (cc & 3);
+                if (sh + 5 <= 32) brec[(cc >> 2) * 2] |= c5 << sh;
+                else if (sh >= 32) brec[(cc >> 2) * 2 + 1] |= c5 << (sh - 32);
+                else { brec[(cc >> 2) * 2] |= c5 << sh; brec[(cc >> 2) * 2 + 1] |= c5 >> (32 - sh); }
+                brec[(cc >> 2) * 2 + 1] |= ((bm.m0 & 1u) | (bm.m1 & 2u) | (bm.inv & 4u)) << (14 + 3 * (cc & 3));
+            }
+        }
+        if (sa && wr) {
+            uint4 *bp = reinterpret_cast<uint4 *>(rec0 + (size_t)k * AL_RECB + AL_RECB / 2);
+            bp[0] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
+            bp[1] = make_uint4(brec[4], brec[5], brec[6], brec[7]);
+        }
+    }
+    {
+        // row m is bit H - 1 + (m - H - t_n), 0 .. 3 bits into word NW / 2
+        const int extra = m - H - t;
+        const int part = q < NW / 2 ? plane_sum(X2, X1, X0, 0xffffffffu) : (q == NW / 2 ? plane_sum(X2, X1, X0, (1u << (extra & 31)) - 1u) : 0);
+        const int tot = grp_sum<G>(part + (bot ? stop : 0));
+        if (n > 0 && wr) {
+            int U = -1, kstar = -1;
+            if (status == 0) {
+                U = tot - AL_GAP * H - AL_GAP * extra;
+                const int d = m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
+                int E = dmin - LO;
+                if (HI - dmax < E) E = HI - dmax;
+                if (E > (1 << 27)) kstar = 0x7fffffff;
+                else if (E >= 0) kstar = AL_GAP * ad + 2 * AL_GAP * E + 2 * AL_GAP - 1;
+            }
+            P.U[g] = U; P.kst[g] = kstar; P.st[g] = status; P.lvl[g] = NW;
+            if (NW == 4) P.U4[g] = U;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // traceback pass: re-compute the slice strip by strip (registers), walk it backwards
 // ---------------------------------------------------------------------------------------------
 // ops leave the traceback in descending positions, one at a time and per lane, every lane into its own row: 64 different
@@ -861,17 +1044,6 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 // of a strip are decoded by 16 lanes at once into three wave masks (one scalar bit-field extract per column and mask
 // instead of the scalar compare chain), the carry of the addition comes straight from the add's carry-out mask and goes back
 // in through an add-with-carry, and the band position is stored once per move (four columns).
-__device__ __forceinline__ uint32_t add_co_mask(uint32_t a, uint32_t b, unsigned long long &carry_mask) {
-    uint32_t r;
-    asm volatile("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(carry_mask) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t add_mask_bit(uint32_t a, unsigned long long mask) {     // a + (this lane's bit of mask)
-    uint32_t r;
-    unsigned long long dummy;
-    asm volatile("v_addc_co_u32_e64 %0, %1, %2, 0, %3" : "=v"(r), "=s"(dummy) : "v"(a), "s"(mask));
-    return r;
-}
 // lane i <- lane i-1 of v; lane 0 keeps what `keep` held before (its own fill value, written once before the loop: the
 // builtin form re-materialises the fill in front of every move).  The s_nop covers the VALU-write -> DPP-read hazard of v,
 // which the compiler does not track through an asm statement.
@@ -1095,6 +1267,129 @@ __global__ void __launch_bounds__(64) align_wide_tb_kernel(AlignArgs P, const in
 }
 
 // ---------------------------------------------------------------------------------------------
+// traceback of the LONGEST pairs (round 6): one WAVEFRONT per pair.  The re-computation of a strip needs nothing but the
+// strip's own check point and boundary record, so the 64 lanes re-compute 64 STRIPS (1024 columns) at once -- the same
+// bp_core<2> steps as align_tb_kernel, one strip per lane -- and leave the slice bits (diagonal allowed / up allowed, 64 rows
+// per column) in LDS; then the wavefront walks those 1024 columns backwards as ONE path: the 16 columns of the strip being
+// walked sit in 16 lanes, the walk reads them with v_readlane and runs on the scalar unit (the common step, a diagonal one,
+// tests one bit); ops leave 64 positions at a time, coalesced (WideOps).  The dependent chain per column is the walk's ~15
+// instructions instead of the ~190 of re-computation + walk in one lane: 5.4 -> ~0.5 ms for an 11 000-column window.
+// Same bits, same rule, same ops as align_tb_kernel.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int l) {
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l) << 32) | (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+}
+__global__ void __launch_bounds__(64) align_tb_strips_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
+    __shared__ unsigned long long s_dg[64][AL_STRIP + 1], s_up[64][AL_STRIP + 1];      // (+1: the lanes of a round write one column at a time)
+    __shared__ int s_t[64][4];                                                          // position of the slice in the strip's four column groups
+    const int pi = blockIdx.x;
+    if (pi >= nlist) return;
+    const int lane = threadIdx.x;
+    const int g = list[pi];
+    const int c = P.row_cand[g], g0 = P.row_first[c];
+    if (g == g0 || P.st[g] != 0) return;
+    const int m = P.win_len[g0], n = P.win_len[g];
+    if (n <= 0) return;
+    const uint4 *pl = P.planes + P.plane_off[c];
+    const char *rec0 = reinterpret_cast<const char *>(P.rec[g]);
+    WideOps out;
+    out.ops = P.ops + P.ops_base[c] + (int64_t)(g - g0) * (m + 1); out.m = m; out.lane = lane; out.acc = 0u;
+    const int K = (n + AL_STRIP - 1) / AL_STRIP;
+    int i = m, j = n;
+    bool fail = false;
+    for (int kb0 = K - 1; kb0 >= 0 && !fail && i > 0; kb0 -= 64) {
+        {   // ---- lane l: strip kb0 - l
+            const int k = kb0 - lane;
+            if (k >= 0) {
+                const uint4 *ck = reinterpret_cast<const uint4 *>(rec0 + (size_t)k * AL_RECB);
+                const uint4 *bp = reinterpret_cast<const uint4 *>(rec0 + (size_t)k * AL_RECB + AL_RECB / 2);
+                const uint4 ck0 = ck[0], ck1 = ck[1], bd0 = bp[0], bd1 = bp[1];
+                uint32_t X2[2] = {ck0.x, ck0.y}, X1[2] = {ck0.z, ck0.w}, X0[2] = {ck1.x, ck1.y}, A0[2], A1[2], AN[2];
+                int t = (int)ck1.z;
+                const uint32_t brec[8] = {bd0.x, bd0.y, bd0.z, bd0.w, bd1.x, bd1.y, bd1.z, bd1.w};
+                const int q0 = (t + AL_PADR) >> 5;
+                const uint4 p0 = pl[q0], p1 = pl[q0 + 1], p2 = pl[q0 + 2], p3 = pl[q0 + 3];
+                const uint32_t sh = (uint32_t)(t + AL_PADR) & 31u;
+                A0[0] = alignbit(p1.x, p0.x, sh); A1[0] = alignbit(p1.y, p0.y, sh); AN[0] = alignbit(p1.z, p0.z, sh);
+                A0[1] = alignbit(p2.x, p1.x, sh); A1[1] = alignbit(p2.y, p1.y, sh); AN[1] = alignbit(p2.z, p1.z, sh);
+                uint32_t f0 = alignbit(p3.x, p2.x, sh), f1 = alignbit(p3.y, p2.y, sh), fn = alignbit(p3.z, p2.z, sh);
+#pragma unroll
+                for (int cc = 0; cc < AL_STRIP; cc++) {
+                    const int jc = k * AL_STRIP + cc + 1;
+                    unsigned long long dgv = 0ull, upv = 0ull;
+                    if (jc <= n) {
+                        const uint32_t rlo = brec[(cc >> 2) * 2], rhi = brec[(cc >> 2) * 2 + 1];
+                        if ((cc & 3) == 0) {
+                            const uint32_t s = (rlo & 3u) << 2;
+                            const uint32_t in2 = (rlo >> 2) & 0xffu, in1 = (rlo >> 10) & 0xffu, in0 = (rlo >> 18) & 0xffu;
+                            X2[0] = alignbit(X2[1], X2[0], s); X1[0] = alignbit(X1[1], X1[0], s); X0[0] = alignbit(X0[1], X0[0], s);
+                            A0[0] = alignbit(A0[1], A0[0], s); A1[0] = alignbit(A1[1], A1[0], s); AN[0] = alignbit(AN[1], AN[0], s);
+                            X2[1] = alignbit(in2, X2[1], s); X1[1] = alignbit(in1, X1[1], s); X0[1] = alignbit(in0, X0[1], s);
+                            A0[1] = alignbit(f0, A0[1], s); A1[1] = alignbit(f1, A1[1], s); AN[1] = alignbit(fn, AN[1], s);
+                            f0 >>= s; f1 >>= s; fn >>= s;
+                            t += (int)s;
+                        }
+                        const int sh5 = 26 + 5 * (cc & 3);
+                        const uint32_t c5 = (sh5 + 5 <= 32 ? rlo >> sh5 : (sh5 >= 32 ? rhi >> (sh5 - 32) : (rlo >> sh5) | (rhi << (32 - sh5)))) & 31u;
+                        const uint32_t code = rhi >> (14 + 3 * (cc & 3));
+                        BaseMask bm;
+                        bm.m0 = 0u - (code & 1u); bm.m1 = 0u - ((code >> 1) & 1u); bm.inv = 0u - ((code >> 2) & 1u);
+                        uint32_t tap[5], dgc[2], upc[2];
+                        bp_core<2, true, -1>(X2, X1, X0, A0, A1, AN, bm, c5 & 1u, (c5 >> 1) & 1u, (c5 >> 2) & 1u, (c5 >> 3) & 1u, (c5 >> 4) & 1u, dgc, upc, tap);
+                        dgv = ((unsigned long long)dgc[1] << 32) | dgc[0];
+                        upv = ((unsigned long long)upc[1] << 32) | upc[0];
+                    }
+                    s_dg[lane][cc] = dgv; s_up[lane][cc] = upv;
+                    if ((cc & 3) == 0) s_t[lane][cc >> 2] = t;
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the walk through these strips, last to first; wave-uniform
+        const int nst = kb0 + 1 < 64 ? kb0 + 1 : 64;
+        unsigned long long dgn = s_dg[0][lane & 15], upn = s_up[0][lane & 15];
+        int tn = s_t[0][lane & 3];
+        for (int l = 0; l < nst && !fail && i > 0; l++) {
+            const unsigned long long dgl = dgn, upl = upn;
+            const int tl = tn;
+            if (l + 1 < nst) { dgn = s_dg[l + 1][lane & 15]; upn = s_up[l + 1][lane & 15]; tn = s_t[l + 1][lane & 3]; }     // (arrives while this strip is walked)
+            const int ks = kb0 - l;
+#pragma unroll
+            for (int cc = AL_STRIP - 1; cc >= 0; cc--) {
+                const int jc = ks * AL_STRIP + cc + 1;
+                if (!fail && i > 0 && j == jc) {
+                    const int kb = i - __builtin_amdgcn_readlane(tl, cc >> 2) - 1;
+                    if ((unsigned)kb >= 64u) fail = true;
+                    else {
+                        const unsigned long long dgv = readlane_u64(dgl, cc);
+                        if ((dgv >> kb) & 1ull) { out.put(i - 1, (uint32_t)(j - 1)); i--; j--; }
+                        else {
+                            const unsigned long long upv = readlane_u64(upl, cc);
+                            const unsigned long long stopm = (dgv | ~upv) & (0xffffffffffffffffull >> (63 - kb));
+                            if (stopm == 0ull) fail = true;
+                            else {
+                                const int ps = 63 - __clzll(stopm);
+                                int ups = kb - ps;
+                                if (ups > i) ups = i;
+                                out.run(i - 1, ups, (uint32_t)j | 0x8000u);
+                                i -= ups;
+                                if (i > 0) {
+                                    if ((dgv >> ps) & 1ull) { out.put(i - 1, (uint32_t)(j - 1)); i--; j--; }
+                                    else j--;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (fail) { if (lane == 0) P.st[g] = 1; }
+    else out.run(i - 1, i, 0x8000u);
+}
+
+// ---------------------------------------------------------------------------------------------
 // schedule
 // ---------------------------------------------------------------------------------------------
 // what: 0 = pairs to re-run with a band of `level` words (exact mode), 1 = pairs whose traceback left the slice,
@@ -1147,6 +1442,24 @@ __global__ void align_assign_kernel(int64_t cnt, const int32_t *__restrict__ lis
                                     unsigned long long *__restrict__ rec) {
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x < cnt) rec[list[x]] = (unsigned long long)(uintptr_t)(region + boff[x >> 6] * (int64_t)AL_RECB + (x & 63) * 32);
+}
+// how many leading blocks of 64 list entries (the lists run longest pair first, so bk never increases) go to the lane-parallel
+// kernels: those whose longest pair has >= thr strips.  thr is given (fixed_strips >= 0), or follows the size of the run:
+// the thread-per-pair kernel needs ~4 ps per pair-column of the whole list on a full machine, a lone wavefront ~0.33 us per
+// column of its longest pair -- a pair is "long" when its own chain is more than about half of what the whole list costs,
+// i.e. longer than 1 / AL_LANES_DIV of all pair-columns (C3, 1.65 G pair-columns per launch: 10 300 columns -- a handful of
+// pairs; a C4 share of an eighth: 1 300; never below AL_LANES_MIN_STRIPS)
+__global__ void align_long_blocks_kernel(int64_t nb, const int32_t *__restrict__ bk, const int64_t *__restrict__ boff, int64_t fixed_strips,
+                                         int64_t div, int64_t *__restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
+    int64_t thr = fixed_strips;
+    if (thr < 0) {
+        thr = boff[nb] * 64 / div;
+        if (thr < AL_LANES_MIN_STRIPS) thr = AL_LANES_MIN_STRIPS;
+    }
+    int64_t lo = 0, hi = nb;            // first block with bk < thr
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)bk[mid] >= thr) lo = mid + 1; else hi = mid; }
+    out[0] = lo;
 }
 // counters: [0] pairs, [1] certified, [2] kept from a band of > 4 words, [3] fall-back, [4] dropped, [5] sum of U, [6] columns
 __global__ void __launch_bounds__(256) align_stats_kernel(int64_t total_rows, const int32_t *__restrict__ strips, AlignArgs P, int32_t *__restrict__ row_dead,
@@ -1207,9 +1520,11 @@ struct AlignState {
     int64_t *h_pin = nullptr;
     int64_t *d_scal = nullptr;
     int exact_cap = -1;
+    int lanes_min = -1;            // lane-parallel kernels for pairs of >= this many columns; -1: by the size of the run; -2: never
+    int64_t lanes_div = AL_LANES_DIV;
     bool sort_attr = false;
-    hipStream_t st2 = nullptr;     // the wider bands run here, beside the traceback of the pairs that are already final
-    hipEvent_t ev = nullptr;
+    hipStream_t st2 = nullptr;     // the wider bands run here, beside the traceback of the pairs that are already final; the longest pairs' lane-parallel kernels
+    hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
@@ -1225,7 +1540,8 @@ static AlignState *align_state(hite_ctx *ctx) {
     if (!ctx->align_state) {
         AlignState *S = new AlignState();
         if (hipHostMalloc((void **)&S->h_pin, 64 * sizeof(int64_t)) != hipSuccess || hipMalloc((void **)&S->d_scal, 64 * sizeof(int64_t)) != hipSuccess ||
-            align_make_stream(&S->st2) != hipSuccess || hipEventCreateWithFlags(&S->ev, hipEventDisableTiming) != hipSuccess) {
+            align_make_stream(&S->st2) != hipSuccess || hipEventCreateWithFlags(&S->ev, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&S->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&S->ev_join, hipEventDisableTiming) != hipSuccess) {
             delete S;
             return nullptr;
         }
@@ -1233,6 +1549,10 @@ static AlignState *align_state(hite_ctx *ctx) {
         int cap = e && *e ? atoi(e) : AL_DEFAULT_CAP;
         if (cap != 0 && cap != 8 && cap != 16 && cap != 32) cap = AL_DEFAULT_CAP;
         S->exact_cap = cap;
+        const char *l = getenv("HITE_ALIGN_LANES");
+        if (l && *l) { const int v = atoi(l); S->lanes_min = v < -2 ? -1 : v; }
+        const char *d = getenv("HITE_ALIGN_LANES_DIV");
+        if (d && *d && atoll(d) > 0) S->lanes_div = atoll(d);
         ctx->align_state = S;
     }
     return (AlignState *)ctx->align_state;
@@ -1245,6 +1565,8 @@ void hite_align_release(hite_ctx *ctx) {
     if (S->d_scal) (void)hipFree(S->d_scal);
     if (S->st2) (void)hipStreamDestroy(S->st2);
     if (S->ev) (void)hipEventDestroy(S->ev);
+    if (S->ev_fork) (void)hipEventDestroy(S->ev_fork);
+    if (S->ev_join) (void)hipEventDestroy(S->ev_join);
     delete S;
     ctx->align_state = nullptr;
 }
@@ -1254,6 +1576,13 @@ extern "C" int hite_align_config(hite_ctx *ctx, int32_t exact_cap) {
     AlignState *S = align_state(ctx);
     if (!S) return HITE_ENOMEM;
     S->exact_cap = exact_cap;
+    return HITE_OK;
+}
+extern "C" int hite_align_lanes(hite_ctx *ctx, int32_t min_cols) {
+    if (!ctx || min_cols < -2 || min_cols > 32767) return HITE_EINVAL;
+    AlignState *S = align_state(ctx);
+    if (!S) return HITE_ENOMEM;
+    S->lanes_min = min_cols;
     return HITE_OK;
 }
 extern "C" int hite_align_stats(hite_ctx *ctx, int64_t *out8, int32_t reset) {
@@ -1296,16 +1625,23 @@ static int build_list(hite_ctx *ctx, AlignState *S, hipStream_t st, int64_t nrow
 }
 
 // strip records of one forward run over `list`: block sizes, their scan, the region (arena), the addresses
+// *n_long (may be NULL): how many entries at the head of the list -- whole blocks of 64 -- go to the lane-parallel kernels
 static int assign_records(hite_ctx *ctx, AlignState *S, hipStream_t st, const int32_t *list, int64_t cnt, const int32_t *strips, int32_t *bk,
-                          int64_t *boff, int64_t *scan_tmp, unsigned long long *rec, int slot) {
+                          int64_t *boff, int64_t *scan_tmp, unsigned long long *rec, int slot, int64_t *n_long = nullptr) {
+    if (n_long) *n_long = 0;
     if (cnt <= 0) return HITE_OK;
     const int64_t nb = (cnt + 63) / 64;
     hipLaunchKernelGGL(align_blockmax_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cnt, list, strips, bk);
     ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, bk, nb, boff, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + slot, boff + nb, 8, hipMemcpyDeviceToDevice, st));
-    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin + slot, S->d_scal + slot, 8, hipMemcpyDeviceToHost, st));
+    const bool lanes = n_long && S->lanes_min != -2;
+    if (lanes)
+        hipLaunchKernelGGL(align_long_blocks_kernel, dim3(1), dim3(1), 0, st, nb, bk, boff,
+                           (int64_t)(S->lanes_min < 0 ? -1 : (S->lanes_min + AL_STRIP - 1) / AL_STRIP), S->lanes_div, S->d_scal + slot + 1);
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin + slot, S->d_scal + slot, 16, hipMemcpyDeviceToHost, st));
     HITE_CHECK(ctx, hipStreamSynchronize(st));
     const int64_t block_strips = S->h_pin[slot];
+    if (lanes) { const int64_t v = S->h_pin[slot + 1] * 64; *n_long = v < cnt ? v : cnt; }
     char *region;
     ACHK(aalloc(ctx, S->arena, (size_t)block_strips * AL_RECB + 256, &region));
     hipLaunchKernelGGL(align_assign_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cnt, list, boff, region, rec);
@@ -1384,7 +1720,8 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, pwords, n_cand, plane_off, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, plane_off + n_cand, 8, hipMemcpyDeviceToDevice, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, 8, hipMemcpyDeviceToHost, st));
-    ACHK(assign_records(ctx, S, st, order, total_rows, strips, bk, boff, scan_tmp, rec, 1));     // (synchronises)
+    int64_t nl4 = 0;             // the longest pairs (a prefix of `order`): lane-parallel forward pass and traceback
+    ACHK(assign_records(ctx, S, st, order, total_rows, strips, bk, boff, scan_tmp, rec, 1, &nl4));     // (synchronises)
     const int64_t plane_words = S->h_pin[0];
     uint4 *planes;
     ACHK(aalloc(ctx, A, (size_t)plane_words + 8, &planes));
@@ -1396,9 +1733,23 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     const int nrows = (int)total_rows;
     // ---- the 4-word band for every pair
     snprintf(name, sizeof name, "align_fwd4%s", tag ? tag : "");
-    tk = hite_prof_begin(ctx, name, st);
-    hipLaunchKernelGGL(align_fwd4_kernel, dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
-    hite_prof_end(ctx, tk, st);
+    hipStream_t s2 = S->st2;
+    char lname[40];
+    if (nl4 > 0) {               // beside the other pairs, on the high-priority stream: its few wavefronts are the critical path
+        HITE_CHECK(ctx, hipEventRecord(S->ev_fork, st));
+        HITE_CHECK(ctx, hipStreamWaitEvent(s2, S->ev_fork, 0));
+        snprintf(lname, sizeof lname, "align_fwd4_lanes%s", tag ? tag : "");
+        const int tl = hite_prof_begin(ctx, lname, s2);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_lanes_kernel<4>), dim3((unsigned)((nl4 + 15) / 16)), dim3(64), 0, s2, P, order, (int)nl4);
+        hite_prof_end(ctx, tl, s2);
+        HITE_CHECK(ctx, hipEventRecord(S->ev_join, s2));
+    }
+    if (nrows > nl4) {
+        tk = hite_prof_begin(ctx, name, st);
+        hipLaunchKernelGGL(align_fwd4_kernel, dim3((unsigned)((nrows - nl4 + 63) / 64)), dim3(64), 0, st, P, order + nl4, (int)(nrows - nl4));
+        hite_prof_end(ctx, tk, st);
+    }
+    if (nl4 > 0) HITE_CHECK(ctx, hipStreamWaitEvent(st, S->ev_join, 0));
     // ---- exact mode: wider bands for the pairs without a certificate, on a second stream, beside the traceback of the pairs
     //      whose 4-word run is final (the wider bands have few, long-running waves: alone they leave most SIMDs idle)
     snprintf(name, sizeof name, "align_tb%s", tag ? tag : "");
@@ -1414,8 +1765,20 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
             int64_t cnt = 0;
             ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 0, level, cap, flag, nullptr, pos, colpos, scan_tmp, list, nullptr, &cnt, nullptr));
             if (cnt == 0) continue;
-            ACHK(assign_records(ctx, S, st, list, cnt, strips, bk, boff, scan_tmp, rec, 1));
-            hipLaunchKernelGGL(align_fwd8_pair_kernel, dim3((unsigned)((cnt + 31) / 32)), dim3(64), 0, st, P, list, (int)cnt);
+            int64_t nl8 = 0;
+            ACHK(assign_records(ctx, S, st, list, cnt, strips, bk, boff, scan_tmp, rec, 1, &nl8));
+            if (nl8 > 0) {
+                HITE_CHECK(ctx, hipEventRecord(S->ev_fork, st));
+                HITE_CHECK(ctx, hipStreamWaitEvent(s2, S->ev_fork, 0));
+                snprintf(lname, sizeof lname, "align_fwd_wide_lanes%s", tag ? tag : "");
+                const int tl = hite_prof_begin(ctx, lname, s2);
+                hipLaunchKernelGGL(HIP_KERNEL_NAME(align_fwd_lanes_kernel<8>), dim3((unsigned)((nl8 + 7) / 8)), dim3(64), 0, s2, P, list, (int)nl8);
+                hite_prof_end(ctx, tl, s2);
+                HITE_CHECK(ctx, hipEventRecord(S->ev_join, s2));
+            }
+            if (cnt > nl8)
+                hipLaunchKernelGGL(align_fwd8_pair_kernel, dim3((unsigned)((cnt - nl8 + 31) / 32)), dim3(64), 0, st, P, list + nl8, (int)(cnt - nl8));
+            if (nl8 > 0) HITE_CHECK(ctx, hipStreamWaitEvent(st, S->ev_join, 0));
         }
         hite_prof_end(ctx, tk, st);
     }
@@ -1430,7 +1793,6 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
             hipLaunchKernelGGL(align_tb_kernel, dim3((unsigned)((n_fin + 63) / 64)), dim3(64), 0, st, P, list_fin, (int)n_fin);
             hite_prof_end(ctx, tk, st);
         }
-        hipStream_t s2 = S->st2;
         tk = hite_prof_begin(ctx, wname, s2);
         for (int level = 8; level <= cap; level *= 2) {
             int64_t cnt = 0;
@@ -1450,9 +1812,21 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
         hite_prof_end(ctx, tk, st);
     } else {
         // ---- traceback on the slice of the run kept
-        tk = hite_prof_begin(ctx, name, st);
-        hipLaunchKernelGGL(align_tb_kernel, dim3((nrows + 63) / 64), dim3(64), 0, st, P, order, nrows);
-        hite_prof_end(ctx, tk, st);
+        if (nl4 > 0) {
+            HITE_CHECK(ctx, hipEventRecord(S->ev_fork, st));
+            HITE_CHECK(ctx, hipStreamWaitEvent(s2, S->ev_fork, 0));
+            snprintf(lname, sizeof lname, "align_tb_strips%s", tag ? tag : "");
+            const int tl = hite_prof_begin(ctx, lname, s2);
+            hipLaunchKernelGGL(align_tb_strips_kernel, dim3((unsigned)nl4), dim3(64), 0, s2, P, order, (int)nl4);
+            hite_prof_end(ctx, tl, s2);
+            HITE_CHECK(ctx, hipEventRecord(S->ev_join, s2));
+        }
+        if (nrows > nl4) {
+            tk = hite_prof_begin(ctx, name, st);
+            hipLaunchKernelGGL(align_tb_kernel, dim3((unsigned)((nrows - nl4 + 63) / 64)), dim3(64), 0, st, P, order + nl4, (int)(nrows - nl4));
+            hite_prof_end(ctx, tk, st);
+        }
+        if (nl4 > 0) HITE_CHECK(ctx, hipStreamWaitEvent(st, S->ev_join, 0));
     }
     HITE_CHECK(ctx, hipGetLastError());
     // ---- fall-back: the pairs whose path left the slice

@@ -389,6 +389,14 @@ int hite_copy_clips(void *state, int64_t cap, uint32_t *clip);
  * cols_out[c] = 0); d_rows_out (may be NULL) = rows per alignment.  The fill call must follow the align call on the
  * same ctx/stream. */
 int hite_align_config(hite_ctx *ctx, int32_t exact_cap);
+/* hite_align_lanes: the LONGEST pairs of a call are aligned by kernels that spread one pair over several lanes (4 or 8 lanes
+ * = the words of its band in the forward pass; a wavefront whose lanes re-compute 64 strips at once in the traceback), beside
+ * the thread-per-pair kernels of the others -- a kernel cannot end before its longest pair's dependent chain, which in a small
+ * batch (one rank's share of a sharded run; the reference gives every candidate its own process, Util.py:8141-8147) is the
+ * step.  Same recurrence, same records, same ops: which kernel takes a pair never changes a result.  min_cols = -1 (default,
+ * or the environment variable HITE_ALIGN_LANES): pairs whose row is longer than 1/160 000 of all pair-columns of the call
+ * and at least 512 columns; >= 0: pairs of at least this many columns (0: every pair -- the parity tests); -2: never. */
+int hite_align_lanes(hite_ctx *ctx, int32_t min_cols);
 int hite_align_stats(hite_ctx *ctx, int64_t *out8, int32_t reset);
 int hite_star_msa(hite_ctx *ctx, int32_t n, const uint8_t *win, const int64_t *win_off, const int32_t *row_first,
                   int32_t *cols_out, int32_t *rows_out, int64_t msa_cap, uint8_t *msa_out, int64_t *msa_off_out);

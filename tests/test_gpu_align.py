@@ -43,7 +43,21 @@ def pair_matrix(a, b, ops):
 
 
 def check_pairs(ctx, pairs, cap):
-    """pairs: list of (a, b) uint8 arrays; runs them as two-row groups with exact_cap = cap"""
+    """pairs: list of (a, b) uint8 arrays; runs them as two-row groups with exact_cap = cap -- three times: through the
+    thread-per-pair kernels alone, with EVERY pair in the lane-parallel kernels (hite_align_lanes; 4 / 8 lanes per pair in the
+    forward passes, a wavefront per pair in the traceback), and with the two kinds side by side"""
+    res = []
+    for lanes in (-2, 0, 400):
+        ctx.align_lanes(lanes)
+        try:
+            res.append(check_pairs_once(ctx, pairs, cap))
+        finally:
+            ctx.align_lanes(-1)
+    assert res[0] == res[1] == res[2]
+    return res[0]
+
+
+def check_pairs_once(ctx, pairs, cap):
     ctx.align_config(cap)
     prev = O.set_align_exact(cap)
     try:
@@ -114,6 +128,17 @@ def test_align_ragged_and_edge(ctx):
     for cap in (0, 16):
         n_cert, n_opt, n_drop = check_pairs(ctx, pairs, cap)
         assert n_drop >= 3       # (7, 1), (130, 64)-like rows shorter than half the centre are dropped
+
+
+def test_align_long_pairs_lane_kernels(ctx):
+    """windows of 2 000 - 11 000 columns -- what the automatic schedule hands to the lane-parallel kernels: several rounds of
+    64 strips per wavefront in the traceback, long runs of up steps, pairs whose path leaves the slice (fall-back), all three
+    kernel mixes of check_pairs, with and without wider bands"""
+    rng = np.random.default_rng(7006)
+    pairs = [make_pair(rng, L) for L in (1000, 1030, 2000, 2100, 3100, 5000, 8000, 11000)]
+    pairs += [make_pair(rng, L, big_indel=bi) for L, bi in ((2500, 40), (4000, 70), (6000, 150), (3000, 300))]
+    for cap in (8, 0, 16):
+        check_pairs(ctx, pairs, cap)
 
 
 def test_align_group_with_dropped_rows(ctx):
