@@ -42,8 +42,7 @@
 #define AL_RECB 4096          // bytes of strip records per strip and block of 64 pairs: 64 check points, then 64 boundary records
 #define AL_DEFAULT_CAP 8      // exact mode: widest band (words) tried for a certificate unless configured otherwise
 #define AL_KBINS 2048        // strips per pair <= 32767 / 16 + 1
-#define AL_LANES_MIN_STRIPS 32     // lane-parallel kernels: never for pairs shorter than 512 columns (automatic mode)
-#define AL_LANES_DIV 2500          // automatic mode: a pair is long when its strips exceed (sum of the blocks' longest strips) * 64 / this
+#define AL_LANES_MIN_STRIPS 32     // lane-parallel kernels: never when the longest pair has fewer than 512 columns (automatic mode)
 
 struct AlignArgs {
     const uint8_t *win;
@@ -596,6 +595,113 @@ __device__ __forceinline__ int grp_sum(int v) {      // sum over the G lanes of 
     if (G == 8) v += (int)dpp_row<0x141>((uint32_t)v);   // row_half_mirror: the other quad of the 8
     return v;
 }
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v, d, 64); v = o < v ? o : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t bit_mask(uint32_t w, int bit) { return (uint32_t)((int32_t)(w << (31 - bit)) >> 31); }    // all ones / zero (v_bfe_i32)
+template <int GI>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v) { return dpp_row<GI * 0x55>(v); }                // lane GI of this lane's quad
+struct LaneFwd {
+    uint32_t X2, X1, X0, A0, A1, AN, f0, f1, fn;
+    int t, stop, LO, HI, status;
+    bool act;
+};
+// One strip of 16 columns.  FULL: every pair of the wavefront that is still running has all 16 columns, so nothing is tested per
+// column and the state is committed unconditionally (a lane without a pair computes on garbage and writes nothing).
+// invm: bit cc = "row base cc never matches"; code12: this lane's quad position's column group as the 4 x 3 code bits of the
+// boundary record; K1: 1 in the lowest lane of a group -- bit 0 of what comes from "the word below" is the band edge there
+// (+3: a set bit for h2 / h1, a clear one for h0 / vpos), folded into the consumers' bit operations.
+template <int G, bool FULL>
+__device__ __forceinline__ void lanes_strip(LaneFwd &S, const uint4 bw, const uint32_t invm, const uint32_t code12, const bool sa, const int k,
+                                            const int m, const int n, const int q, const uint32_t K1, const unsigned long long TOPM, uint32_t (&brec)[8]) {
+    constexpr int NW = G, W = 32 * NW, H = W / 2, S0 = NW / 2 - 1;
+    const bool top = q == G - 1;
+#pragma unroll
+    for (int cc = 0; cc < AL_STRIP; cc++) {
+        const int j = k * AL_STRIP + cc + 1;
+        const bool on = FULL || (sa && j <= n);          // (the same in every lane of a group; the cross-lane moves run for every lane)
+        if ((cc & 3) == 0) {
+            // ---- band move: steering count of words S0 and S0 + 1, the word above for the shift
+            const int ds = grp_sum<G>((q == S0 || q == S0 + 1) ? slope_count(S.X2, S.X1, S.X0) : 0);
+            const uint32_t i2 = dpp_row<0x102>(S.X2) & 0xffu, i1 = dpp_row<0x102>(S.X1) & 0xffu, i0 = dpp_row<0x102>(S.X0) & 0xffu;   // word S0 + 2's low rows
+            const uint32_t u2 = dpp_row<0x101>(S.X2), u1 = dpp_row<0x101>(S.X1), u0 = dpp_row<0x101>(S.X0);
+            const uint32_t ua0 = dpp_row<0x101>(S.A0), ua1 = dpp_row<0x101>(S.A1), uan = dpp_row<0x101>(S.AN);
+            constexpr int gi = 0;
+            const uint32_t cg = (cc >> 2) == 0 ? quad_bcast<0>(code12) : ((cc >> 2) == 1 ? quad_bcast<1>(code12) : ((cc >> 2) == 2 ? quad_bcast<2>(code12) : quad_bcast<3>(code12)));
+            (void)gi;
+            if (on) {
+                int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 8 : 4);
+                const int tr = m - H;
+                if (S.t + s > tr) s = (tr - S.t) & ~3;
+                const int need = tr - 3 - 8 * ((n - j) >> 2) - S.t;
+                if (s < need) s = (need + 3) & ~3;
+                if (s > 8) { S.status = 2; S.act = false; s = 8; }
+                S.stop += plane_sum(S.X2, S.X1, S.X0, (1u << s) - 1u) - AL_GAP * s;        // (the lowest lane's is the pair's)
+                brec[(cc >> 2) * 2] = (uint32_t)(s >> 2) | (i2 << 2) | (i1 << 10) | (i0 << 18);
+                brec[(cc >> 2) * 2 + 1] = cg << 14;
+                S.X2 = alignbit(top ? 0xffffffffu : u2, S.X2, (uint32_t)s);
+                S.X1 = alignbit(top ? 0xffffffffu : u1, S.X1, (uint32_t)s);
+                S.X0 = alignbit(top ? 0u : u0, S.X0, (uint32_t)s);
+                S.A0 = alignbit(top ? S.f0 : ua0, S.A0, (uint32_t)s);
+                S.A1 = alignbit(top ? S.f1 : ua1, S.A1, (uint32_t)s);
+                S.AN = alignbit(top ? S.fn : uan, S.AN, (uint32_t)s);
+                S.f0 >>= s; S.f1 >>= s; S.fn >>= s;
+                S.t += s;
+                if (S.t >= 1) { const int v = S.t + 1 - j; S.LO = v > S.LO ? v : S.LO; }
+                if (S.t + W < m) { const int jl = j + 3 < n ? j + 3 : n; const int v = S.t + W - jl; S.HI = v < S.HI ? v : S.HI; }
+            }
+        }
+        // ---- column
+        const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
+        const uint32_t m0 = bit_mask(word, 8 * (cc & 3) + 1), m1 = bit_mask(word, 8 * (cc & 3) + 2), inv = bit_mask(invm, cc);
+        const uint32_t eq = ~((S.A0 ^ m0) | (S.A1 ^ m1) | S.AN | inv);
+        const uint32_t vpos = S.X2 & S.X1;
+        const uint32_t B = eq | ~(S.X2 | S.X1 | S.X0);
+        const uint32_t pvr = dpp_row<0x111>(vpos);                     // bit 31: "vertical difference +3" of the row below this word
+        const uint32_t Pp = alignbit(vpos, pvr, 31) & ~K1;
+        const uint32_t Y = Pp | B;
+        unsigned long long Gm;
+        const uint32_t sum0 = add_co_mask(B, Y, Gm);
+        uint32_t sum;
+        {   // carries along the lanes of a group: lane w generates (its sum wrapped) or propagates (its sum is all ones); a
+            // group's top lane does neither, so no carry crosses into the next group
+            const unsigned long long Pm = __ballot(sum0 == 0xffffffffu);
+            const unsigned long long Gc = Gm & ~TOPM, Yy = (Pm | Gm) & ~TOPM, ss = Gc + Yy;
+            sum = add_mask_bit(sum0, ss ^ Gc ^ Yy);
+        }
+        const uint32_t Z = B | (Pp & (sum ^ B ^ Y));
+        const uint32_t h0 = ~(Z ^ S.X0), b1 = Z & S.X0, h1 = ~(S.X1 ^ b1), b2 = S.X1 & b1, h2 = ~(S.X2 ^ b2);
+        const uint32_t r2 = dpp_row<0x111>(h2), r1 = dpp_row<0x111>(h1), r0 = dpp_row<0x111>(h0);
+        if (on) {
+            const uint32_t s2 = alignbit(h2, r2, 31) | K1, s1 = alignbit(h1, r1, 31) | K1, s0 = alignbit(h0, r0, 31) & ~K1;     // below the band: +3
+            const uint32_t c1 = Z & s0, c2 = s1 & c1;
+            S.X0 = ~(Z ^ s0); S.X1 = ~(s1 ^ c1); S.X2 = ~(s2 ^ c2);
+            // 5 carry bits that enter word S0 (kept by the lane that owns it: never a group's lowest): carry of the addition, then
+            // bit 31 of the word below's vpos, h2, h1, h0 -- shifted in one after the other
+            uint32_t c5 = alignbit(r0 >> 31, r1, 31);
+            c5 = alignbit(c5, r2, 31);
+            c5 = alignbit(c5, pvr, 31);
+            c5 = (c5 << 1) | (sum - sum0);
+            const int sh = 26 + 5 * (cc & 3);
+            if (sh + 5 <= 32) brec[(cc >> 2) * 2] |= c5 << sh;
+            else if (sh >= 32) brec[(cc >> 2) * 2 + 1] |= c5 << (sh - 32);
+            else { brec[(cc >> 2) * 2] |= c5 << sh; brec[(cc >> 2) * 2 + 1] |= c5 >> (32 - sh); }
+        }
+    }
+}
+// a dword of four row bases -> bits 0..3: "never matches" per base; bits 4..15: the 3 code bits per base as the boundary record holds them
+__device__ __forceinline__ uint32_t decode_bases4(uint32_t w) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int x = 0; x < 4; x++) {
+        const unsigned ch = (w >> (8 * x)) & 0xffu;
+        const uint32_t bad = is_acgt_byte(ch) ? 0u : 1u;
+        r |= (bad << x) | ((((ch >> 1) & 3u) | (bad << 2)) << (4 + 3 * x));
+    }
+    return r;
+}
 template <int G>
 __global__ void __launch_bounds__(64) align_fwd_lanes_kernel(AlignArgs P, const int32_t *__restrict__ list, int nlist) {
     constexpr int NW = G, W = 32 * NW, H = W / 2, S0 = NW / 2 - 1, PPW = 64 / G;
@@ -610,112 +716,55 @@ __global__ void __launch_bounds__(64) align_fwd_lanes_kernel(AlignArgs P, const 
     }
     const int nmax = wave_max_i32(n);
     if (nmax == 0) return;
-    const bool bot = q == 0, top = q == G - 1, wr = q == S0;       // lowest / highest word of the band; the lane that writes the records
+    const int nfull = wave_min_i32(n > 0 ? n : 0x7fffffff);        // strips below this are whole for every pair of the wavefront
+    const bool wr = q == S0;                                        // the lane that writes the records
+    const uint32_t K1 = q == 0 ? 1u : 0u;
     const unsigned long long TOPM = G == 4 ? 0x8888888888888888ull : 0x8080808080808080ull;
     const uint8_t *b = P.win + (g >= 0 ? P.win_off[g] : 0);
     const uint4 *pl = P.planes + (g >= 0 ? P.plane_off[c] : 0);
     char *rec0 = g >= 0 ? reinterpret_cast<char *>(P.rec[g]) : nullptr;
-    uint32_t X2 = q >= NW / 2 ? 0xffffffffu : 0u, X1 = X2, X0 = 0u, A0 = 0u, A1 = 0u, AN = 0xffffffffu;
-    int t = -H;
-    bool act = n > 0;
-    if (act) { const uint4 v = pl[((t + AL_PADR) >> 5) + q]; A0 = v.x; A1 = v.y; AN = v.z; }
-    int stop = AL_GAP * H, LO = -(1 << 28), HI = 1 << 28, status = 0;     // (stop: the lowest lane's is the pair's)
-    int fq = (t + W + AL_PADR) >> 5;
+    LaneFwd S;
+    S.X2 = q >= NW / 2 ? 0xffffffffu : 0u; S.X1 = S.X2; S.X0 = 0u; S.A0 = 0u; S.A1 = 0u; S.AN = 0xffffffffu;
+    S.f0 = S.f1 = S.fn = 0u;
+    S.t = -H;
+    S.act = n > 0;
+    if (S.act) { const uint4 v = pl[((S.t + AL_PADR) >> 5) + q]; S.A0 = v.x; S.A1 = v.y; S.AN = v.z; }
+    S.stop = AL_GAP * H; S.LO = -(1 << 28); S.HI = 1 << 28; S.status = 0;
+    int fq = (S.t + W + AL_PADR) >> 5;
     uint4 Wa = make_uint4(0, 0, 0xffffffffu, 0), Wb = Wa, Wc = Wa, bnext = make_uint4(0, 0, 0, 0);
-    if (act) { Wa = pl[fq]; Wb = pl[fq + 1]; Wc = pl[fq + 2]; bnext = *reinterpret_cast<const uint4 *>(b); }
+    if (S.act) { Wa = pl[fq]; Wb = pl[fq + 1]; Wc = pl[fq + 2]; bnext = *reinterpret_cast<const uint4 *>(b); }
     for (int k = 0; k * AL_STRIP < nmax; k++) {
-        const bool sa = act && k * AL_STRIP < n;
+        const bool sa = S.act && k * AL_STRIP < n;
         uint4 bw = make_uint4(0, 0, 0, 0);
-        uint32_t f0 = 0, f1 = 0, fn = 0;
         uint32_t brec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         {   // check point: words S0 and S0 + 1 = this lane's and the lane above's
-            const uint32_t p2 = dpp_row<0x101>(X2), p1 = dpp_row<0x101>(X1), p0 = dpp_row<0x101>(X0);
+            const uint32_t p2 = dpp_row<0x101>(S.X2), p1 = dpp_row<0x101>(S.X1), p0 = dpp_row<0x101>(S.X0);
             if (sa && wr) {
                 uint4 *ck = reinterpret_cast<uint4 *>(rec0 + (size_t)k * AL_RECB);
-                ck[0] = make_uint4(X2, p2, X1, p1);
-                ck[1] = make_uint4(X0, p0, (uint32_t)(t + 32 * S0), 0u);
+                ck[0] = make_uint4(S.X2, p2, S.X1, p1);
+                ck[1] = make_uint4(S.X0, p0, (uint32_t)(S.t + 32 * S0), 0u);
             }
         }
+        S.f0 = S.f1 = S.fn = 0u;
         if (sa) {
             bw = bnext;
             if ((k + 1) * AL_STRIP < n) bnext = *reinterpret_cast<const uint4 *>(b + (k + 1) * AL_STRIP);
-            const int fx = t + W + AL_PADR;
+            const int fx = S.t + W + AL_PADR;
             if ((fx >> 5) != fq) { Wa = Wb; Wb = Wc; fq++; Wc = pl[fq + 2]; }
             const uint32_t sh = (uint32_t)fx & 31u;
-            f0 = alignbit(Wb.x, Wa.x, sh); f1 = alignbit(Wb.y, Wa.y, sh); fn = alignbit(Wb.z, Wa.z, sh);
+            S.f0 = alignbit(Wb.x, Wa.x, sh); S.f1 = alignbit(Wb.y, Wa.y, sh); S.fn = alignbit(Wb.z, Wa.z, sh);
         }
-#pragma unroll
-        for (int cc = 0; cc < AL_STRIP; cc++) {
-            const int j = k * AL_STRIP + cc + 1;
-            const bool on = sa && j <= n;                // (the same in every lane of a group; the cross-lane moves run for every lane)
-            if ((cc & 3) == 0) {
-                // ---- band move: steering count of words S0 and S0 + 1, the word above for the shift
-                const int ds = grp_sum<G>((q == S0 || q == S0 + 1) ? slope_count(X2, X1, X0) : 0);
-                const uint32_t i2 = dpp_row<0x102>(X2 & 0xffu), i1 = dpp_row<0x102>(X1 & 0xffu), i0 = dpp_row<0x102>(X0 & 0xffu);   // word S0 + 2's low rows
-                const uint32_t u2 = dpp_row<0x101>(X2), u1 = dpp_row<0x101>(X1), u0 = dpp_row<0x101>(X0);
-                const uint32_t ua0 = dpp_row<0x101>(A0), ua1 = dpp_row<0x101>(A1), uan = dpp_row<0x101>(AN);
-                if (on) {
-                    int s = ds > AL_STEER ? 0 : (ds < -AL_STEER ? 8 : 4);
-                    const int tr = m - H;
-                    if (t + s > tr) s = (tr - t) & ~3;
-                    const int need = tr - 3 - 8 * ((n - j) >> 2) - t;
-                    if (s < need) s = (need + 3) & ~3;
-                    if (s > 8) { status = 2; act = false; s = 8; }
-                    if (bot) stop += plane_sum(X2, X1, X0, (1u << s) - 1u) - AL_GAP * s;
-                    brec[(cc >> 2) * 2] = (uint32_t)(s >> 2) | (i2 << 2) | (i1 << 10) | (i0 << 18);
-                    X2 = alignbit(top ? 0xffffffffu : u2, X2, (uint32_t)s);
-                    X1 = alignbit(top ? 0xffffffffu : u1, X1, (uint32_t)s);
-                    X0 = alignbit(top ? 0u : u0, X0, (uint32_t)s);
-                    A0 = alignbit(top ? f0 : ua0, A0, (uint32_t)s);
-                    A1 = alignbit(top ? f1 : ua1, A1, (uint32_t)s);
-                    AN = alignbit(top ? fn : uan, AN, (uint32_t)s);
-                    f0 >>= s; f1 >>= s; fn >>= s;
-                    t += s;
-                    if (t >= 1) { const int v = t + 1 - j; LO = v > LO ? v : LO; }
-                    if (t + W < m) { const int jl = j + 3 < n ? j + 3 : n; const int v = t + W - jl; HI = v < HI ? v : HI; }
-                }
-            }
-            // ---- column
-            const uint32_t word = cc < 4 ? bw.x : (cc < 8 ? bw.y : (cc < 12 ? bw.z : bw.w));
-            const BaseMask bm = base_mask((word >> (8 * (cc & 3))) & 0xffu);
-            const uint32_t eq = ~((A0 ^ bm.m0) | (A1 ^ bm.m1) | AN | bm.inv);
-            const uint32_t vpos = X2 & X1;
-            const uint32_t B = eq | ~(X2 | X1 | X0);
-            const uint32_t pvr = dpp_row<0x111>(vpos);
-            const uint32_t pv = bot ? 0u : pvr;                        // bit 31: "vertical difference +3" of the row below this word
-            const uint32_t Pp = alignbit(vpos, pv, 31);
-            const uint32_t Y = Pp | B;
-            unsigned long long Gm;
-            const uint32_t sum0 = add_co_mask(B, Y, Gm);
-            uint32_t sum;
-            {   // carries along the lanes of a group: lane w generates (its sum wrapped) or propagates (its sum is all ones); a
-                // group's top lane does neither, so no carry crosses into the next group
-                const unsigned long long Pm = __ballot(sum0 == 0xffffffffu) & ~TOPM;
-                const unsigned long long Gc = Gm & ~TOPM, Yy = Pm | Gc, ss = Gc + Yy;
-                sum = add_mask_bit(sum0, ss ^ Gc ^ Yy);
-            }
-            const uint32_t Z = B | (Pp & (sum ^ B ^ Y));
-            const uint32_t h0 = ~(Z ^ X0), b1 = Z & X0, h1 = ~(X1 ^ b1), b2 = X1 & b1, h2 = ~(X2 ^ b2);
-            const uint32_t r2 = dpp_row<0x111>(h2), r1 = dpp_row<0x111>(h1), r0 = dpp_row<0x111>(h0);
-            const uint32_t hb2 = bot ? 0x80000000u : r2, hb1 = bot ? 0x80000000u : r1, hb0 = bot ? 0u : r0;     // below the band: +3
-            if (on) {
-                const uint32_t s2 = alignbit(h2, hb2, 31), s1 = alignbit(h1, hb1, 31), s0 = alignbit(h0, hb0, 31);
-                const uint32_t c1 = Z & s0, c2 = s1 & c1;
-                X0 = ~(Z ^ s0); X1 = ~(s1 ^ c1); X2 = ~(s2 ^ c2);
-                if (bot) stop += AL_GAP;
-                // 5 carry bits that enter word S0 (kept by the lane that owns it): carry of the addition, then bit 31 of the word
-                // below's vpos, h2, h1, h0 -- shifted in one after the other
-                uint32_t c5 = alignbit(hb0 >> 31, hb1, 31);
-                c5 = alignbit(c5, hb2, 31);
-                c5 = alignbit(c5, pv, 31);
-                c5 = (c5 << 1) | (sum - sum0);
-                const int sh = 26 + 5 * (cc & 3);
-                if (sh + 5 <= 32) brec[(cc >> 2) * 2] |= c5 << sh;
-                else if (sh >= 32) brec[(cc >> 2) * 2 + 1] |= c5 << (sh - 32);
-                else { brec[(cc >> 2) * 2] |= c5 << sh; brec[(cc >> 2) * 2 + 1] |= c5 >> (32 - sh); }
-                brec[(cc >> 2) * 2 + 1] |= ((bm.m0 & 1u) | (bm.m1 & 2u) | (bm.inv & 4u)) << (14 + 3 * (cc & 3));
-            }
-        }
+        // the strip's 16 row bases, decoded once: lane q of a quad takes dword q (a group of 8 decodes them twice), the "never
+        // matches" bits of the four dwords are OR-ed over the quad, the code bits stay where the band move of their column
+        // group fetches them
+        const uint32_t dq = (q & 3) == 0 ? bw.x : ((q & 3) == 1 ? bw.y : ((q & 3) == 2 ? bw.z : bw.w));
+        const uint32_t dec = decode_bases4(dq);
+        uint32_t invm = (dec & 15u) << (4 * (q & 3));
+        invm |= dpp_row<0xB1>(invm);
+        invm |= dpp_row<0x4E>(invm);
+        const bool failed = __any(n > 0 && S.status != 0);
+        if ((k + 1) * AL_STRIP <= nfull && !failed) lanes_strip<G, true>(S, bw, invm, dec >> 4, sa, k, m, n, q, K1, TOPM, brec);
+        else lanes_strip<G, false>(S, bw, invm, dec >> 4, sa, k, m, n, q, K1, TOPM, brec);
         if (sa && wr) {
             uint4 *bp = reinterpret_cast<uint4 *>(rec0 + (size_t)k * AL_RECB + AL_RECB / 2);
             bp[0] = make_uint4(brec[0], brec[1], brec[2], brec[3]);
@@ -724,20 +773,20 @@ __global__ void __launch_bounds__(64) align_fwd_lanes_kernel(AlignArgs P, const 
     }
     {
         // row m is bit H - 1 + (m - H - t_n), 0 .. 3 bits into word NW / 2
-        const int extra = m - H - t;
-        const int part = q < NW / 2 ? plane_sum(X2, X1, X0, 0xffffffffu) : (q == NW / 2 ? plane_sum(X2, X1, X0, (1u << (extra & 31)) - 1u) : 0);
-        const int tot = grp_sum<G>(part + (bot ? stop : 0));
+        const int extra = m - H - S.t;
+        const int part = q < NW / 2 ? plane_sum(S.X2, S.X1, S.X0, 0xffffffffu) : (q == NW / 2 ? plane_sum(S.X2, S.X1, S.X0, (1u << (extra & 31)) - 1u) : 0);
+        const int tot = grp_sum<G>(part + (q == 0 ? S.stop : 0));
         if (n > 0 && wr) {
             int U = -1, kstar = -1;
-            if (status == 0) {
-                U = tot - AL_GAP * H - AL_GAP * extra;
+            if (S.status == 0) {
+                U = tot + AL_GAP * n - AL_GAP * H - AL_GAP * extra;          // (+ 3 per column: every column ran)
                 const int d = m - n, dmin = d < 0 ? d : 0, dmax = d > 0 ? d : 0, ad = d < 0 ? -d : d;
-                int E = dmin - LO;
-                if (HI - dmax < E) E = HI - dmax;
+                int E = dmin - S.LO;
+                if (S.HI - dmax < E) E = S.HI - dmax;
                 if (E > (1 << 27)) kstar = 0x7fffffff;
                 else if (E >= 0) kstar = AL_GAP * ad + 2 * AL_GAP * E + 2 * AL_GAP - 1;
             }
-            P.U[g] = U; P.kst[g] = kstar; P.st[g] = status; P.lvl[g] = NW;
+            P.U[g] = U; P.kst[g] = kstar; P.st[g] = S.status; P.lvl[g] = NW;
             if (NW == 4) P.U4[g] = U;
         }
     }
@@ -1181,6 +1230,16 @@ struct WideOps {
         if (lane == (pos & 63)) acc = val;
         if ((pos & 63) == 0) flush(pos);
     }
+    __device__ __forceinline__ void run_diag(int hi, int count, int delta) {   // positions hi, hi - 1, ..., hi - count + 1; position p gets p + delta
+        while (count > 0) {
+            const int base = hi & ~63;
+            const int lo = hi - count + 1 > base ? hi - count + 1 : base;
+            if (base + lane >= lo && base + lane <= hi) acc = (uint32_t)(base + lane + delta);
+            const int k = hi - lo + 1;
+            count -= k; hi -= k;
+            if (lo == base) flush(base);
+        }
+    }
     __device__ __forceinline__ void run(int hi, int count, uint32_t val) {   // positions hi, hi - 1, ..., hi - count + 1
         while (count > 0) {
             const int base = hi & ~63;
@@ -1345,40 +1404,47 @@ __global__ void __launch_bounds__(64) align_tb_strips_kernel(AlignArgs P, const 
             }
         }
         __syncthreads();
-        // ---- the walk through these strips, last to first; wave-uniform
+        // ---- the walk through these strips, last to first; wave-uniform.  Lane cc (< 16) holds column cc of the strip being
+        //      walked.  Most steps are diagonal ones, so the lanes first test, each for its own column, whether the path that
+        //      runs down the current diagonal may pass (one bit of the column's slice: row i - (columns to go) of it), a ballot
+        //      gives the length of the diagonal run, its ops leave together; only the column that ends a run takes the general rule.
         const int nst = kb0 + 1 < 64 ? kb0 + 1 : 64;
         unsigned long long dgn = s_dg[0][lane & 15], upn = s_up[0][lane & 15];
-        int tn = s_t[0][lane & 3];
+        int tn = s_t[0][(lane & 15) >> 2];
         for (int l = 0; l < nst && !fail && i > 0; l++) {
             const unsigned long long dgl = dgn, upl = upn;
             const int tl = tn;
-            if (l + 1 < nst) { dgn = s_dg[l + 1][lane & 15]; upn = s_up[l + 1][lane & 15]; tn = s_t[l + 1][lane & 3]; }     // (arrives while this strip is walked)
-            const int ks = kb0 - l;
-#pragma unroll
-            for (int cc = AL_STRIP - 1; cc >= 0; cc--) {
-                const int jc = ks * AL_STRIP + cc + 1;
-                if (!fail && i > 0 && j == jc) {
-                    const int kb = i - __builtin_amdgcn_readlane(tl, cc >> 2) - 1;
-                    if ((unsigned)kb >= 64u) fail = true;
-                    else {
-                        const unsigned long long dgv = readlane_u64(dgl, cc);
-                        if ((dgv >> kb) & 1ull) { out.put(i - 1, (uint32_t)(j - 1)); i--; j--; }
-                        else {
-                            const unsigned long long upv = readlane_u64(upl, cc);
-                            const unsigned long long stopm = (dgv | ~upv) & (0xffffffffffffffffull >> (63 - kb));
-                            if (stopm == 0ull) fail = true;
-                            else {
-                                const int ps = 63 - __clzll(stopm);
-                                int ups = kb - ps;
-                                if (ups > i) ups = i;
-                                out.run(i - 1, ups, (uint32_t)j | 0x8000u);
-                                i -= ups;
-                                if (i > 0) {
-                                    if ((dgv >> ps) & 1ull) { out.put(i - 1, (uint32_t)(j - 1)); i--; j--; }
-                                    else j--;
-                                }
-                            }
-                        }
+            if (l + 1 < nst) { dgn = s_dg[l + 1][lane & 15]; upn = s_up[l + 1][lane & 15]; tn = s_t[l + 1][(lane & 15) >> 2]; }     // (arrives while this strip is walked)
+            const int j0 = (kb0 - l) * AL_STRIP;             // columns j0 + 1 .. j0 + 16
+            while (!fail && i > 0) {
+                i = __builtin_amdgcn_readfirstlane(i); j = __builtin_amdgcn_readfirstlane(j);      // (wave-uniform by construction: keep the walk on the scalar unit)
+                const int cur = j - j0 - 1;                  // the current column, as a lane
+                if (cur < 0) break;
+                {   // diagonal run
+                    const int back = cur - (lane & 15);      // columns between the current one and this lane's
+                    const int kbl = i - back - tl - 1;
+                    const bool ok = back >= 0 && i - back >= 1 && (unsigned)kbl < 64u && ((dgl >> (kbl & 63)) & 1ull);
+                    const uint32_t okm = (uint32_t)__ballot(ok) & 0xffffu;
+                    const uint32_t bad = ~okm & ((2u << cur) - 1u);
+                    const int run = bad ? cur - (31 - __clz(bad)) : cur + 1;
+                    if (run > 0) { out.run_diag(i - 1, run, j - i); i -= run; j -= run; }
+                    if (run == cur + 1 || i <= 0) continue;  // (the strip is done -- cur < 0 next time --, or the path)
+                }
+                {   // the column that ended the run: the general rule
+                    const int cc = j - j0 - 1;
+                    const int kb = i - __builtin_amdgcn_readlane(tl, cc) - 1;
+                    if ((unsigned)kb >= 64u) { fail = true; break; }
+                    const unsigned long long dgv = readlane_u64(dgl, cc), upv = readlane_u64(upl, cc);
+                    const unsigned long long stopm = (dgv | ~upv) & (0xffffffffffffffffull >> (63 - kb));
+                    if (stopm == 0ull) { fail = true; break; }
+                    const int ps = 63 - __clzll(stopm);
+                    int ups = kb - ps;
+                    if (ups > i) ups = i;
+                    out.run(i - 1, ups, (uint32_t)j | 0x8000u);
+                    i -= ups;
+                    if (i > 0) {
+                        if ((dgv >> ps) & 1ull) { out.put(i - 1, (uint32_t)(j - 1)); i--; j--; }
+                        else j--;
                     }
                 }
             }
@@ -1443,23 +1509,48 @@ __global__ void align_assign_kernel(int64_t cnt, const int32_t *__restrict__ lis
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (x < cnt) rec[list[x]] = (unsigned long long)(uintptr_t)(region + boff[x >> 6] * (int64_t)AL_RECB + (x & 63) * 32);
 }
-// how many leading blocks of 64 list entries (the lists run longest pair first, so bk never increases) go to the lane-parallel
-// kernels: those whose longest pair has >= thr strips.  thr is given (fixed_strips >= 0), or follows the size of the run:
-// the thread-per-pair kernel needs ~4 ps per pair-column of the whole list on a full machine, a lone wavefront ~0.33 us per
-// column of its longest pair -- a pair is "long" when its own chain is more than about half of what the whole list costs,
-// i.e. longer than 1 / AL_LANES_DIV of all pair-columns (C3, 1.65 G pair-columns per launch: 10 300 columns -- a handful of
-// pairs; a C4 share of an eighth: 1 300; never below AL_LANES_MIN_STRIPS)
+// How many leading blocks of 64 list entries (the lists run longest pair first, so bk -- the strips of a block's longest pair
+// -- never increases, and boff is its running sum) go to a lane-parallel kernel.  Fixed (fixed_strips >= 0: the blocks whose
+// longest pair has at least that many strips), or by a small cost model of the two kernels running side by side on the
+// machine's 1024 SIMDs.  With k blocks in the lane-parallel kernel the launch cannot end before
+//     the lane-parallel kernel's chain over the longest pair            bk[0]  * lane_chain
+//     the thread-per-pair kernel's chain over ITS longest pair          bk[k]  * thread_chain
+//     the work of both, spread over the whole machine                   boff[k] * lane_work + (boff[nb] - boff[k]) * thread_work
+// (ns per strip of 16 columns; measured on MI355X with tools/align_chain_bench.py, profiles/r06_align_chain_bench.txt: a lone
+// wavefront needs 0.34 / 0.44 / 0.43 us per column in the 4-word forward / 8-word forward / traceback kernels whatever its
+// neighbours do, 0.20 / 0.20 / 0.033 us in the lane-parallel ones; a full machine 4.2 ps per pair-column in the thread-per-pair
+// kernels, and 12.5 / 25 / 21 ns per pair-column and SIMD -- 3 to 5 times the work -- in the lane-parallel ones.)  The first
+// term falls with k more slowly than the third one grows, so the k where they cross is the best; k = 0 unless that gains 10 %.
+// C3 (1.6 M block-strips per launch): work-bound, k = 0.  A C4 share of an eighth, full-length pass (0.3 M block-strips,
+// longest pair 690 strips): the chain of the longest pair is 2.2 x the work -> the pairs beyond ~0.75 of the longest.
+struct LaneCost { float thread_chain, lane_chain, thread_work, lane_work; };
+__device__ __forceinline__ double lane_cost_at(int64_t k, int64_t nb, const int32_t *bk, const int64_t *boff, const LaneCost c) {
+    const double chain_l = k > 0 ? (double)bk[0] * c.lane_chain : 0.0, chain_t = k < nb ? (double)bk[k] * c.thread_chain : 0.0;
+    const double work = (double)boff[k] * c.lane_work + (double)(boff[nb] - boff[k]) * c.thread_work;
+    double t = chain_l > chain_t ? chain_l : chain_t;
+    return t > work ? t : work;
+}
 __global__ void align_long_blocks_kernel(int64_t nb, const int32_t *__restrict__ bk, const int64_t *__restrict__ boff, int64_t fixed_strips,
-                                         int64_t div, int64_t *__restrict__ out) {
+                                         LaneCost cf, LaneCost ct, int64_t *__restrict__ out) {
     if (blockIdx.x || threadIdx.x) return;
-    int64_t thr = fixed_strips;
-    if (thr < 0) {
-        thr = boff[nb] * 64 / div;
-        if (thr < AL_LANES_MIN_STRIPS) thr = AL_LANES_MIN_STRIPS;
+    for (int w = 0; w < 2; w++) {
+        int64_t lo = 0, hi = nb;
+        if (fixed_strips >= 0) {            // first block with bk < fixed_strips
+            while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)bk[mid] >= fixed_strips) lo = mid + 1; else hi = mid; }
+        } else {
+            const LaneCost c = w ? ct : cf;
+            // first k where the lane-parallel side (its chain, or the work of both) is no longer below the thread-per-pair chain
+            while (lo < hi) {
+                const int64_t mid = (lo + hi) >> 1;
+                const double a = (double)bk[0] * c.lane_chain, wk = (double)boff[mid] * c.lane_work + (double)(boff[nb] - boff[mid]) * c.thread_work;
+                const double tc = mid < nb ? (double)bk[mid] * c.thread_chain : 0.0;
+                if ((a > wk ? a : wk) < tc) lo = mid + 1; else hi = mid;
+            }
+            if (lo > 0 && lane_cost_at(lo - 1, nb, bk, boff, c) <= lane_cost_at(lo, nb, bk, boff, c)) lo--;
+            if (lo > 0 && (bk[0] < AL_LANES_MIN_STRIPS || lane_cost_at(lo, nb, bk, boff, c) > 0.9 * lane_cost_at(0, nb, bk, boff, c))) lo = 0;
+        }
+        out[w] = lo;
     }
-    int64_t lo = 0, hi = nb;            // first block with bk < thr
-    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if ((int64_t)bk[mid] >= thr) lo = mid + 1; else hi = mid; }
-    out[0] = lo;
 }
 // counters: [0] pairs, [1] certified, [2] kept from a band of > 4 words, [3] fall-back, [4] dropped, [5] sum of U, [6] columns
 __global__ void __launch_bounds__(256) align_stats_kernel(int64_t total_rows, const int32_t *__restrict__ strips, AlignArgs P, int32_t *__restrict__ row_dead,
@@ -1521,7 +1612,7 @@ struct AlignState {
     int64_t *d_scal = nullptr;
     int exact_cap = -1;
     int lanes_min = -1;            // lane-parallel kernels for pairs of >= this many columns; -1: by the size of the run; -2: never
-    int64_t lanes_div = AL_LANES_DIV;
+    float lanes_scale[4] = {1.f, 1.f, 1.f, 1.f};     // measurement aid ($HITE_ALIGN_LANES_SCALE=a,b,c,d): factors on the cost model's lane-parallel work (4-word, 8-word, traceback) and forward chain
     bool sort_attr = false;
     hipStream_t st2 = nullptr;     // the wider bands run here, beside the traceback of the pairs that are already final; the longest pairs' lane-parallel kernels
     hipEvent_t ev = nullptr, ev_fork = nullptr, ev_join = nullptr;
@@ -1551,8 +1642,8 @@ static AlignState *align_state(hite_ctx *ctx) {
         S->exact_cap = cap;
         const char *l = getenv("HITE_ALIGN_LANES");
         if (l && *l) { const int v = atoi(l); S->lanes_min = v < -2 ? -1 : v; }
-        const char *d = getenv("HITE_ALIGN_LANES_DIV");
-        if (d && *d && atoll(d) > 0) S->lanes_div = atoll(d);
+        const char *sc = getenv("HITE_ALIGN_LANES_SCALE");
+        if (sc && *sc) sscanf(sc, "%f,%f,%f,%f", &S->lanes_scale[0], &S->lanes_scale[1], &S->lanes_scale[2], &S->lanes_scale[3]);
         ctx->align_state = S;
     }
     return (AlignState *)ctx->align_state;
@@ -1627,21 +1718,31 @@ static int build_list(hite_ctx *ctx, AlignState *S, hipStream_t st, int64_t nrow
 // strip records of one forward run over `list`: block sizes, their scan, the region (arena), the addresses
 // *n_long (may be NULL): how many entries at the head of the list -- whole blocks of 64 -- go to the lane-parallel kernels
 static int assign_records(hite_ctx *ctx, AlignState *S, hipStream_t st, const int32_t *list, int64_t cnt, const int32_t *strips, int32_t *bk,
-                          int64_t *boff, int64_t *scan_tmp, unsigned long long *rec, int slot, int64_t *n_long = nullptr) {
+                          int64_t *boff, int64_t *scan_tmp, unsigned long long *rec, int slot, int words = 4, int64_t *n_long = nullptr, int64_t *n_long_tb = nullptr) {
     if (n_long) *n_long = 0;
+    if (n_long_tb) *n_long_tb = 0;
     if (cnt <= 0) return HITE_OK;
     const int64_t nb = (cnt + 63) / 64;
     hipLaunchKernelGGL(align_blockmax_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cnt, list, strips, bk);
     ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, bk, nb, boff, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal + slot, boff + nb, 8, hipMemcpyDeviceToDevice, st));
     const bool lanes = n_long && S->lanes_min != -2;
-    if (lanes)
+    if (lanes) {
+        // ns per strip of 16 columns: chains of a lone wavefront, work per block of 64 pairs on the whole machine (see the kernel)
+        LaneCost fwd4 = {5440.f, 3200.f, 4.3f, 12.5f}, fwd8 = {7040.f, 3200.f, 13.75f, 25.f}, tb = {6880.f, 530.f, 4.3f, 21.5f};
+        fwd4.lane_work *= S->lanes_scale[0]; fwd8.lane_work *= S->lanes_scale[1]; tb.lane_work *= S->lanes_scale[2];
+        fwd4.lane_chain *= S->lanes_scale[3]; fwd8.lane_chain *= S->lanes_scale[3];
         hipLaunchKernelGGL(align_long_blocks_kernel, dim3(1), dim3(1), 0, st, nb, bk, boff,
-                           (int64_t)(S->lanes_min < 0 ? -1 : (S->lanes_min + AL_STRIP - 1) / AL_STRIP), S->lanes_div, S->d_scal + slot + 1);
-    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin + slot, S->d_scal + slot, 16, hipMemcpyDeviceToHost, st));
+                           (int64_t)(S->lanes_min < 0 ? -1 : (S->lanes_min + AL_STRIP - 1) / AL_STRIP), words == 4 ? fwd4 : fwd8, tb, S->d_scal + slot + 1);
+    }
+    HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin + slot, S->d_scal + slot, 24, hipMemcpyDeviceToHost, st));
     HITE_CHECK(ctx, hipStreamSynchronize(st));
     const int64_t block_strips = S->h_pin[slot];
-    if (lanes) { const int64_t v = S->h_pin[slot + 1] * 64; *n_long = v < cnt ? v : cnt; }
+    if (lanes) {
+        const int64_t v = S->h_pin[slot + 1] * 64, vt = S->h_pin[slot + 2] * 64;
+        *n_long = v < cnt ? v : cnt;
+        if (n_long_tb) *n_long_tb = vt < cnt ? vt : cnt;
+    }
     char *region;
     ACHK(aalloc(ctx, S->arena, (size_t)block_strips * AL_RECB + 256, &region));
     hipLaunchKernelGGL(align_assign_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, cnt, list, boff, region, rec);
@@ -1720,8 +1821,8 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     ACHK(scan_excl_buf<int32_t>(ctx, scan_tmp, pwords, n_cand, plane_off, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, plane_off + n_cand, 8, hipMemcpyDeviceToDevice, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->h_pin, S->d_scal, 8, hipMemcpyDeviceToHost, st));
-    int64_t nl4 = 0;             // the longest pairs (a prefix of `order`): lane-parallel forward pass and traceback
-    ACHK(assign_records(ctx, S, st, order, total_rows, strips, bk, boff, scan_tmp, rec, 1, &nl4));     // (synchronises)
+    int64_t nl4 = 0, nltb = 0;   // the longest pairs (a prefix of `order`): lane-parallel forward pass / traceback
+    ACHK(assign_records(ctx, S, st, order, total_rows, strips, bk, boff, scan_tmp, rec, 1, 4, &nl4, &nltb));     // (synchronises)
     const int64_t plane_words = S->h_pin[0];
     uint4 *planes;
     ACHK(aalloc(ctx, A, (size_t)plane_words + 8, &planes));
@@ -1735,6 +1836,7 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
     snprintf(name, sizeof name, "align_fwd4%s", tag ? tag : "");
     hipStream_t s2 = S->st2;
     char lname[40];
+    if (getenv("HITE_ALIGN_DEBUG")) fprintf(stderr, "[align%s] rows %d  block-strips %lld  lane-parallel prefix %lld forward, %lld traceback\n", tag ? tag : "", nrows, (long long)S->h_pin[1], (long long)nl4, (long long)nltb);
     if (nl4 > 0) {               // beside the other pairs, on the high-priority stream: its few wavefronts are the critical path
         HITE_CHECK(ctx, hipEventRecord(S->ev_fork, st));
         HITE_CHECK(ctx, hipStreamWaitEvent(s2, S->ev_fork, 0));
@@ -1766,7 +1868,8 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
             ACHK(build_list(ctx, S, st, total_rows, order, strips, P, 0, level, cap, flag, nullptr, pos, colpos, scan_tmp, list, nullptr, &cnt, nullptr));
             if (cnt == 0) continue;
             int64_t nl8 = 0;
-            ACHK(assign_records(ctx, S, st, list, cnt, strips, bk, boff, scan_tmp, rec, 1, &nl8));
+            ACHK(assign_records(ctx, S, st, list, cnt, strips, bk, boff, scan_tmp, rec, 1, 8, &nl8));
+            if (getenv("HITE_ALIGN_DEBUG")) fprintf(stderr, "[align%s] level %d: pairs %lld  block-strips %lld  lane-parallel prefix %lld\n", tag ? tag : "", level, (long long)cnt, (long long)S->h_pin[1], (long long)nl8);
             if (nl8 > 0) {
                 HITE_CHECK(ctx, hipEventRecord(S->ev_fork, st));
                 HITE_CHECK(ctx, hipStreamWaitEvent(s2, S->ev_fork, 0));
@@ -1812,21 +1915,21 @@ int hite_align_run(hite_ctx *ctx, int32_t n_cand, const uint8_t *d_win, const in
         hite_prof_end(ctx, tk, st);
     } else {
         // ---- traceback on the slice of the run kept
-        if (nl4 > 0) {
+        if (nltb > 0) {
             HITE_CHECK(ctx, hipEventRecord(S->ev_fork, st));
             HITE_CHECK(ctx, hipStreamWaitEvent(s2, S->ev_fork, 0));
             snprintf(lname, sizeof lname, "align_tb_strips%s", tag ? tag : "");
             const int tl = hite_prof_begin(ctx, lname, s2);
-            hipLaunchKernelGGL(align_tb_strips_kernel, dim3((unsigned)nl4), dim3(64), 0, s2, P, order, (int)nl4);
+            hipLaunchKernelGGL(align_tb_strips_kernel, dim3((unsigned)nltb), dim3(64), 0, s2, P, order, (int)nltb);
             hite_prof_end(ctx, tl, s2);
             HITE_CHECK(ctx, hipEventRecord(S->ev_join, s2));
         }
-        if (nrows > nl4) {
+        if (nrows > nltb) {
             tk = hite_prof_begin(ctx, name, st);
-            hipLaunchKernelGGL(align_tb_kernel, dim3((unsigned)((nrows - nl4 + 63) / 64)), dim3(64), 0, st, P, order + nl4, (int)(nrows - nl4));
+            hipLaunchKernelGGL(align_tb_kernel, dim3((unsigned)((nrows - nltb + 63) / 64)), dim3(64), 0, st, P, order + nltb, (int)(nrows - nltb));
             hite_prof_end(ctx, tk, st);
         }
-        if (nl4 > 0) HITE_CHECK(ctx, hipStreamWaitEvent(st, S->ev_join, 0));
+        if (nltb > 0) HITE_CHECK(ctx, hipStreamWaitEvent(st, S->ev_join, 0));
     }
     HITE_CHECK(ctx, hipGetLastError());
     // ---- fall-back: the pairs whose path left the slice

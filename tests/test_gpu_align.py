@@ -141,6 +141,16 @@ def test_align_long_pairs_lane_kernels(ctx):
         check_pairs(ctx, pairs, cap)
 
 
+def test_align_many_pairs_in_the_lane_kernels(ctx):
+    """several hundred pairs in the lane-parallel class at once: wavefronts of 16 / 8 pairs whose pairs end in different strips
+    (the whole-strip fast path of the forward kernels ends where the shortest pair of the wavefront does), lengths 40 - 2 500"""
+    rng = np.random.default_rng(7007)
+    pairs = [make_pair(rng, int(rng.integers(40, 700))) for _ in range(560)]
+    pairs += [make_pair(rng, L, big_indel=bi) for L, bi in ((2500, 0), (1800, 50), (1200, 90), (900, 200))]
+    for cap in (8, 0):
+        check_pairs(ctx, pairs, cap)
+
+
 def test_align_group_with_dropped_rows(ctx):
     """a row that cannot be aligned leaves the alignment; the other rows are unaffected (HIP == twin)"""
     rng = np.random.default_rng(7004)
