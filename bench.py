@@ -9,8 +9,9 @@ One "step" = one pass of the hot path over the whole candidate batch:
   for >1 kb windows, then the full pass), inputs resident in HBM when the timed region starts.
 Multi-GPU: `python bench.py --gpus N` starts N ranks itself (one process per GPU, RCCL); under
 torch.distributed.run it uses the ranks it is given.  The genome is replicated;
-  --scaling weak  (default): every rank judges its own candidate batch (N x the work),
-  --scaling strong: ONE batch is sharded over the ranks (config C4),
+  --scaling strong (default for --gpus N > 1): ONE batch is sharded over the ranks (BASELINE config 4); the line carries the weak
+                   form as the side block `weak`,
+  --scaling weak  (default for one GPU): every rank judges its own candidate batch (N x the work),
 and the 32-byte call records are all-gathered over RCCL inside the timed step.
 
 Prints ONE JSON line (rank 0).  See DESIGN.md section "Measurement" for the byte accounting.
@@ -103,7 +104,9 @@ def main():
     ap.add_argument("--ltr-families", type=int, default=None)
     ap.add_argument("--cands-per-family", type=int, default=10)
     ap.add_argument("--seed", type=int, default=20250927 + 3)
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong when --gpus > 1 (BASELINE config 4: ONE 1 Gbp batch sharded over the GPUs; the line then carries the "
+                         "weak form -- every rank the whole batch -- as the side block `weak`), weak otherwise")
     ap.add_argument("--share-of", type=int, default=0,
                     help="one process: judge only rank 0's strong-scaling share of this many ranks (config C4share: 8)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
@@ -157,6 +160,8 @@ def main():
     G = mbp * 1_000_000
     n_tir = args.tir_families if args.tir_families is not None else max(1, int(tir_d * mbp))
     n_ltr = args.ltr_families if args.ltr_families is not None else max(0, int(ltr_d * mbp))
+    if args.scaling is None:
+        args.scaling = "strong" if world > 1 else "weak"
     strong = args.scaling == "strong" and world > 1
     share_of = args.share_of if args.share_of > 1 else (8 if args.config == "C4share" else 0)
     if world > 1:
@@ -200,32 +205,42 @@ def main():
     def up(a):
         return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 
-    d_calls = torch.zeros(max(1, n_cand) * 32, dtype=torch.uint8, device=dev)
-    cons_cap = (b1 - b0) + 200 * n_cand + 4096
-    d_cons = torch.zeros(cons_cap + 64, dtype=torch.uint8, device=dev)
-    d_cand = up(np.concatenate([L["cands"], np.zeros(64, np.uint8)]))
-    d_cand_off = up(np.asarray(L["cand_off"], dtype=np.int64))
-    d_cf = up(np.asarray(L["copy_first"], dtype=np.int32))
-    d_ct, d_s1, d_e1 = up(L["contig"]), up(L["start1"]), up(L["end1"])
-    d_mn = up(np.concatenate([L["minus"], np.zeros(16, np.uint8)]))
+    def device_batch(Lx):
+        """the device-resident inputs and outputs of one candidate batch (CSR of candidates, copy table of the generator for --copies truth)"""
+        nc_ = len(Lx["cand_off"]) - 1
+        bases = int(Lx["cand_off"][-1])
+        Bx = {"n_cand": nc_, "bases": bases, "n_truth": len(Lx["contig"]), "cons_cap": bases + 200 * nc_ + 4096}
+        Bx["calls"] = torch.zeros(max(1, nc_) * 32, dtype=torch.uint8, device=dev)
+        Bx["cons"] = torch.zeros(Bx["cons_cap"] + 64, dtype=torch.uint8, device=dev)
+        Bx["cand"] = up(np.concatenate([Lx["cands"], np.zeros(64, np.uint8)]))
+        Bx["cand_off"] = up(np.asarray(Lx["cand_off"], dtype=np.int64))
+        Bx["cf"] = up(np.asarray(Lx["copy_first"], dtype=np.int32))
+        Bx["ct"], Bx["s1"], Bx["e1"] = up(Lx["contig"]), up(Lx["start1"]), up(Lx["end1"])
+        Bx["mn"] = up(np.concatenate([Lx["minus"], np.zeros(16, np.uint8)]))
+        return Bx
+
+    B = device_batch(L)
+    d_calls, d_cons, cons_cap = B["calls"], B["cons"], B["cons_cap"]
     state = {"found": None, "n_copies": k1 - k0}
     n_merge = n_all if strong else world * n_cand
 
+    def run_batch(Bx):
+        """one pass of the hot path over one device batch -> the pipeline's statistics"""
+        if Bx["n_cand"] <= 0:
+            return np.zeros(12, dtype=np.int64)
+        if args.copies == "found":
+            nc, p_cf, p_ct, p_s1, p_e1, p_mn, _p_an = ctx.find_copies_dev(Bx["n_cand"], Bx["cand"].data_ptr(), Bx["cand_off"].data_ptr(), Bx["bases"], sp)
+            p_cl = ctx.copy_clips_dev()      # (the rows are padded by the clipped bases; zero words with HITE_COPY_INTERVAL=whole)
+            state["found"] = (nc, p_cf, p_ct, p_s1, p_e1, p_mn, p_cl)
+            state["n_copies"] = nc
+            return ctx.flank_region_align_dev("tir", 1, Bx["n_cand"], Bx["cand"].data_ptr(), Bx["cand_off"].data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn,
+                                              50, Bx["calls"].data_ptr(), Bx["cons"].data_ptr(), Bx["cons_cap"], sp, d_clip=p_cl)
+        return ctx.flank_region_align_dev("tir", 1, Bx["n_cand"], Bx["cand"].data_ptr(), Bx["cand_off"].data_ptr(), Bx["cf"].data_ptr(), Bx["n_truth"],
+                                          Bx["ct"].data_ptr(), Bx["s1"].data_ptr(), Bx["e1"].data_ptr(), Bx["mn"].data_ptr(), 50, Bx["calls"].data_ptr(),
+                                          Bx["cons"].data_ptr(), Bx["cons_cap"], sp)
+
     def step():
-        if n_cand > 0:
-            if args.copies == "found":
-                nc, p_cf, p_ct, p_s1, p_e1, p_mn, _p_an = ctx.find_copies_dev(n_cand, d_cand.data_ptr(), d_cand_off.data_ptr(), b1 - b0, sp)
-                p_cl = ctx.copy_clips_dev()      # (the rows are padded by the clipped bases; zero words with HITE_COPY_INTERVAL=whole)
-                state["found"] = (nc, p_cf, p_ct, p_s1, p_e1, p_mn, p_cl)
-                state["n_copies"] = nc
-                st = ctx.flank_region_align_dev("tir", 1, n_cand, d_cand.data_ptr(), d_cand_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn,
-                                                50, d_calls.data_ptr(), d_cons.data_ptr(), cons_cap, sp, d_clip=p_cl)
-            else:
-                st = ctx.flank_region_align_dev("tir", 1, n_cand, d_cand.data_ptr(), d_cand_off.data_ptr(), d_cf.data_ptr(), k1 - k0,
-                                                d_ct.data_ptr(), d_s1.data_ptr(), d_e1.data_ptr(), d_mn.data_ptr(), 50, d_calls.data_ptr(),
-                                                d_cons.data_ptr(), cons_cap, sp)
-        else:
-            st = np.zeros(12, dtype=np.int64)
+        st = run_batch(B)
         stream.synchronize()
         merged = None
         if world > 1:   # merge the boundary calls (RCCL over xGMI): ONE all-gather of the 32-byte records
@@ -270,6 +285,45 @@ def main():
         assert merged_te == n_te_all, "all-gathered records disagree with the per-rank counts"
     else:
         n_te_all = n_te
+
+    weak_blk = None
+    if strong:
+        # The WEAK form as a side block of a strong-scaling line: every rank judges the whole batch (per-GPU work fixed as N grows),
+        # a few steps outside the headline's timed region, without the merge of the calls.  No collective sits inside the try
+        # blocks: a rank that fails still reaches the barrier and the reductions below.
+        ok_w, err_w, t_w, k_w = 1, "", 0.0, max(1, min(3, args.steps))
+        Bw = None
+        try:
+            Bw = device_batch({k_: w[k_] for k_ in ("cands", "cand_off", "copy_first", "contig", "start1", "end1", "minus")})
+            for _ in range(2):            # (the arenas grow to this batch's size, then are consolidated)
+                run_batch(Bw)
+                stream.synchronize()
+            torch.cuda.synchronize()
+        except Exception as e:
+            ok_w, err_w = 0, "%s: %s" % (type(e).__name__, e)
+        dist.barrier()
+        t_w0 = time.perf_counter()
+        if ok_w:
+            try:
+                for _ in range(k_w):
+                    run_batch(Bw)
+                    stream.synchronize()
+                torch.cuda.synchronize()
+            except Exception as e:
+                ok_w, err_w = 0, "%s: %s" % (type(e).__name__, e)
+        t_w = time.perf_counter() - t_w0
+        tw = torch.tensor([t_w, -float(ok_w)], dtype=torch.float64, device=dev)
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        if float(tw[1].item()) == -1.0:
+            t_w = float(tw[0].item())
+            weak_blk = {"scaling": "weak", "value": round(world * n_all * k_w / t_w, 2), "unit": "candidates/s", "steps": k_w,
+                        "ms_per_step": round(1000.0 * t_w / k_w, 3), "candidates_per_gpu": n_all,
+                        "note": "every rank judges the whole %d-candidate batch; max over ranks between barriers; the all-gather of the calls is not in this block" % n_all}
+        else:
+            weak_blk = {"scaling": "weak", "error": err_w or "another rank failed"}
+        del Bw
+        step()                            # the copy table and the calls on the device are the strong share's again
+        torch.cuda.synchronize()
 
     if rank == 0:
         steps = max(1, args.steps)
@@ -332,6 +386,37 @@ def main():
             roof = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBS, 6), "traffic": traffic,
                     "avg_launch_ms": round(avg_launch_ms, 4), "alg_bytes_per_launch": int(bytes_per_launch)}
+            if dom in ("align_fwd4", "align_tb", "align_fwd_wide"):
+                # An alignment kernel is bound by vector-instruction ISSUE (its wavefronts' dependent chains), not by HBM: the block
+                # leads with that -- wave-level vector instructions of THIS kernel (committed SQ counters of the same workload, scaled
+                # by this run's pair-columns) / its live launch time, against the measured issue rate of the 4-cycle class -- and keeps
+                # the HBM view beside it on the IRREDUCIBLE bytes (SURVEY 8(d) gives the aligner no byte formula: 1 B of row base per
+                # pair-column forward; the ops, 2 B per centre position, for the traceback); the check points / boundary records
+                # (4 B per pair-column) are the kernel's own traffic, listed as such, next to the counter traffic.
+                slow_, _fast = valu_peak()
+                cnt_file_, cnt_src_ = kept_counters()
+                e_ = cnt_file_.get({"align_fwd_wide": "align_fwd_wide8"}.get(dom, dom), {})
+                cols_file_ = cnt_file_.get("_columns_per_step", 0.0)
+                irreducible = {"align_fwd4": 1.0 * cols_step, "align_fwd_wide": 1.0 * cols_step * (per_step["wide"] / pairs_step),
+                               "align_tb": ops_bytes}[dom] * steps / max(1, cnt)
+                hbm_view = {"bound": "hbm", "achieved": round(irreducible / (avg_launch_ms * 1e-3) / 1e9, 3), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(irreducible / (avg_launch_ms * 1e-3) / 1e9 / PEAK_HBM_GBS, 6), "alg_bytes_per_launch": int(irreducible),
+                            "note": "irreducible bytes: 1 B row base per pair-column (forward) / the ops (traceback)",
+                            "with_own_records": {"alg_bytes_per_launch": int(bytes_per_launch), "achieved": round(achieved, 3),
+                                                 "frac": round(achieved / PEAK_HBM_GBS, 6),
+                                                 "note": "+ 4 B per pair-column of check points / boundary records: the kernel's own traffic, not the algorithm's"},
+                            "traffic": traffic}
+                if e_.get("valu_inst_per_step") and cols_file_ > 0 and slow_ > 0:
+                    inst_launch = e_["valu_inst_per_step"] * (cols_step / cols_file_) * steps / max(1, cnt)
+                    rate_ = inst_launch / (avg_launch_ms * 1e-3) / 1e9
+                    roof = {"kernel": dom, "bound": "valu_issue", "achieved": round(rate_, 1), "peak": round(slow_, 1), "unit": "G wave64-inst/s",
+                            "frac": round(rate_ / slow_, 4), "traffic": traffic, "avg_launch_ms": round(avg_launch_ms, 4),
+                            "wave_inst_per_launch": int(inst_launch), "wave_inst_per_pair_column": round(e_["valu_inst_per_step"] / cols_file_, 4),
+                            "peak_note": "measured issue rate of the 4-cycle instruction class at 8 waves per SIMD (tools/valu_issue_bench.hip); "
+                                         "against the 2-cycle class the fraction is %.4f" % (rate_ / _fast if _fast > 0 else 0.0),
+                            "source": cnt_src_, "hbm": hbm_view}
+                else:
+                    roof["hbm_irreducible"] = hbm_view
             # the alignment kernels are bound by vector-instruction issue, not by HBM: report the whole group against the MEASURED
             # issue rate (tools/valu_issue_bench.hip -> profiles/r02_valu_issue.txt); instructions per column from the kept counters
             align_ms = sum(ms for k, (ms, _c) in merged_prof.items() if k.startswith("align_")) / steps
@@ -394,6 +479,8 @@ def main():
             "roofline": roof,
             "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kern.items())},
         }
+        if weak_blk is not None:
+            out["weak"] = weak_blk
         if hasattr(ctx.lib, "hite_debug_judge_clocks"):   # only in a -DJUDGE_CLOCKS development build
             import ctypes
             buf = (ctypes.c_ulonglong * 16)()

@@ -66,10 +66,10 @@ class Context:
         self.device = device
 
     def copy_config(self, aligned_interval):
-        """which interval copy records carry (process-wide, include/hite_gpu.h hite_copy_config): True = the aligned interval as
-        get_copies_minimap2 reports it (Util.py:8026; the default), False = the whole candidate (rounds 2-4), None = from
-        HITE_COPY_INTERVAL (aligned | whole), else the default"""
-        self._check(self.lib.hite_copy_config(-1 if aligned_interval is None else int(bool(aligned_interval))), "hite_copy_config")
+        """which interval the copy records of THIS context carry (include/hite_gpu.h hite_copy_config_ctx): True = the aligned interval
+        as get_copies_minimap2 reports it (Util.py:8026; the default), False = the whole candidate (rounds 2-4), None = follow the
+        process-wide setting again (hite_copy_config; HITE_COPY_INTERVAL = aligned | whole, else the default)"""
+        self._check(self.lib.hite_copy_config_ctx(self.h, -1 if aligned_interval is None else int(bool(aligned_interval))), "hite_copy_config_ctx")
 
     def release_copy_index(self):
         """drops the minimizer index of the packed genome (device memory is freed); the next copy / seeding call rebuilds it"""
@@ -302,7 +302,12 @@ class Context:
         s1 = _arr([t[1] for t in flat], np.int64)
         e1 = _arr([t[2] for t in flat], np.int64)
         mn = _arr([t[3] for t in flat], np.uint8)
-        clip = _arr([t[5] if len(t) > 5 else 0 for t in flat], np.uint32) if any(len(t) > 5 and t[5] for t in flat) else None
+        # the clip words travel as the 6th field of the tuples (find_copies(clips=True)); tuples WITHOUT it -- the reference's own
+        # (chr, start, end, length, strand) records -- get theirs estimated by the library (hite_clip_probe's rule)
+        has = [len(t) > 5 for t in flat]
+        if any(has) and not all(has):
+            raise ValueError("flank_region_align: copy tuples with and without a clip field in one table")
+        clip = _arr([t[5] for t in flat], np.uint32) if flat and all(has) else None
         calls = np.zeros(n, dtype=CALL_DTYPE)
         cap = int(coff[-1]) + (2 * flank + 64) * n + 4096
         stats = np.zeros(12, dtype=np.int64)
@@ -324,10 +329,27 @@ class Context:
             out.append((bool(c["is_te"]), INFO[int(c["info"])], s, int(c["row_num"]), int(c["bstart"]), int(c["bend"])))
         return out, stats
 
+    def clip_probe(self, cands, copies):
+        """the clip words hite_flank_region_align estimates for a table without them (hite_clip_probe): copies as for
+        flank_region_align -> per candidate list of words (left | right << 16, in the orientation of the genome)"""
+        n = len(cands)
+        cb = [c.encode() if isinstance(c, str) else bytes(c) for c in cands]
+        coff = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum([len(c) for c in cb], out=coff[1:])
+        cbuf = np.frombuffer(b"".join(cb) + b"\0" * 16, dtype=np.uint8)
+        cf = np.zeros(n + 1, dtype=np.int32)
+        np.cumsum([len(c) for c in copies], out=cf[1:])
+        flat = [t for c in copies for t in c]
+        out = np.zeros(len(flat) + 1, dtype=np.uint32)
+        self._check(self.lib.hite_clip_probe(self.h, n, _p(cbuf), _p(coff), _p(cf), C.c_int64(len(flat)), _p(_arr([t[0] for t in flat], np.int32)),
+                                             _p(_arr([t[1] for t in flat], np.int64)), _p(_arr([t[2] for t in flat], np.int64)),
+                                             _p(_arr([t[3] for t in flat], np.uint8)), _p(out)), "hite_clip_probe")
+        return [[int(x) for x in out[cf[i]:cf[i + 1]]] for i in range(n)]
+
     # device-resident variant: every argument is a raw device pointer (e.g. torch tensor .data_ptr())
     def flank_region_align_dev(self, te_type, plant, n_cand, d_cand, d_cand_off, d_copy_first, n_copies, d_contig, d_start1,
                                d_end1, d_minus, flank, d_calls, d_cons, cons_cap, stream=0, d_clip=0):
-        """d_clip: device pointer of the records' clip words (copy_clips_dev()), 0: no pads"""
+        """d_clip: device pointer of the records' clip words (copy_clips_dev()), 0: the library estimates them (hite_clip_probe's rule)"""
         if not hasattr(self, "_pipe_state"):
             self._pipe_state = C.c_void_p(None)
         stats = np.zeros(12, dtype=np.int64)

@@ -65,8 +65,7 @@ struct hite_ctx {
     const int64_t *d_msa_win_off;    // per row of the last star alignment: its window, and where its back pads begin (HITE_IS_ROW_PAD;
     const int32_t *d_msa_win_len;    // layout, fill and the judge's LDS kernels read the rows through these)
     const uint32_t *d_msa_pads;      // per row: pad bytes in front | behind << 16
-    const void *last_copy_start1;    // the copy table the copy finder returned last on this context (its d_start1) and its clip words:
-    const uint32_t *last_copy_clip;  // hite_flank_region_align_dev on THAT table pads the rows even when the caller passes no clip pointer
+    int32_t copy_interval;          // hite_copy_config_ctx: 1 aligned intervals / 0 whole-candidate intervals / -1 the process default
     int32_t *d_contig_rank;         // byte order of "<contig name>:" among the contigs (hite_set_contig_order; NULL: the index)
     // side streams + one fork event and a join event per stream for kernels that run beside each other inside one call (the
     // judge kernels)

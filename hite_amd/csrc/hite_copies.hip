@@ -892,22 +892,29 @@ static int sorter_from_arena(Sorter &S, hite_ctx *ctx, Arena &A, hipStream_t st,
     return HITE_OK;
 }
 
-// which interval a copy record carries: 0 (default) = the interval of the WHOLE candidate (clipped ends extrapolated on the
-// diagonal; DESIGN.md deviation v), 1 = the ALIGNED interval, reference_start + 1 .. reference_end as get_copies_minimap2
-// reports it (Util.py:8026).  Process-wide; initialised from the environment (HITE_COPY_INTERVAL=aligned), -1 = ask the environment again.
+// which interval a copy record carries: 1 (default since round 5) = the ALIGNED interval, reference_start + 1 .. reference_end as
+// get_copies_minimap2 reports it (Util.py:8026), the clipped candidate bases beside it; 0 = the interval of the WHOLE candidate
+// (clipped ends extrapolated on the diagonal; rounds 2-4).  Per context (hite_copy_config_ctx); a context that was never
+// configured follows the process default: hite_copy_config, initialised from the environment (HITE_COPY_INTERVAL=aligned | whole).
 static int g_copy_interval = -1;
-static int copy_interval_mode() {
-    if (g_copy_interval < 0) {
+static int copy_interval_mode(const hite_ctx *ctx) {
+    if (ctx && ctx->copy_interval >= 0) return ctx->copy_interval;
+    int v = __atomic_load_n(&g_copy_interval, __ATOMIC_RELAXED);
+    if (v < 0) {
         const char *e = getenv("HITE_COPY_INTERVAL");
-        // default since round 5: the reference's coordinates (the aligned interval, Util.py:8026) -- usable now that the rows are padded by
-        // the clipped bases; HITE_COPY_INTERVAL=whole: the whole-candidate interval of rounds 2-4
-        g_copy_interval = (e && (!strcmp(e, "whole") || !strcmp(e, "0"))) ? 0 : 1;
+        v = (e && (!strcmp(e, "whole") || !strcmp(e, "0"))) ? 0 : 1;
+        __atomic_store_n(&g_copy_interval, v, __ATOMIC_RELAXED);
     }
-    return g_copy_interval;
+    return v;
 }
 extern "C" int hite_copy_config(int32_t aligned_interval) {
     if (aligned_interval < -1 || aligned_interval > 1) return HITE_EINVAL;
-    g_copy_interval = aligned_interval;
+    __atomic_store_n(&g_copy_interval, aligned_interval, __ATOMIC_RELAXED);
+    return HITE_OK;
+}
+extern "C" int hite_copy_config_ctx(hite_ctx *ctx, int32_t aligned_interval) {
+    if (!ctx || aligned_interval < -1 || aligned_interval > 1) return HITE_EINVAL;
+    ctx->copy_interval = aligned_interval;
     return HITE_OK;
 }
 
@@ -1061,7 +1068,6 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
     CCHK(arena_alloc(ctx, S->out, (size_t)(n_cand + 2) * 4, &p)); ofirst32 = (int32_t *)p;
     *d_copy_first = ofirst32; *n_copies = 0;
     S->out_clip = nullptr; S->out_n = 0;
-    ctx->last_copy_start1 = nullptr; ctx->last_copy_clip = nullptr;
     HITE_CHECK(ctx, hipMemsetAsync(ofirst32, 0, (size_t)(n_cand + 2) * 4, st));
     *d_contig = nullptr; *d_start1 = nullptr; *d_end1 = nullptr; *d_minus = nullptr; *d_anchors = nullptr;
     if (n_cand == 0 || cand_bytes <= 0 || S->M == 0) return HITE_OK;
@@ -1265,11 +1271,11 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
         const unsigned cblocks = (unsigned)(want_blocks < 8192ull ? (want_blocks ? want_blocks : 1ull) : 8192ull);
         hipLaunchKernelGGL(chain_copy_kernel<false>, dim3(cblocks), dim3(256), 0, st, d_nchain, chcap, chain_list, x_i, x_t, hkey, F, c_first, c_lo,
                            c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, r_clip, per_cand,
-                           (const int64_t *)nullptr, copy_interval_mode());
+                           (const int64_t *)nullptr, copy_interval_mode(ctx));
         CCHK(scan_excl_buf<int32_t>(ctx, bs3, per_cand, n_cand, cstart, st));
         hipLaunchKernelGGL(chain_copy_kernel<true>, dim3(cblocks), dim3(256), 0, st, d_nchain, chcap, chain_list, x_i, x_t, hkey, F, c_first, c_lo,
                            c_hi, d_cand_off, ctx->d_contig_off, ctx->n_contigs, ckey, cval, r_contig, r_s1, r_e1, r_minus, r_anch, r_clip, fill,
-                           (const int64_t *)cstart, copy_interval_mode());
+                           (const int64_t *)cstart, copy_interval_mode(ctx));
     }
     hite_prof_end(ctx, tk_cluster_copy_kernel, st);
     hipLaunchKernelGGL(cap300_kernel, CGRID((int64_t)n_cand), 0, st, n_cand, per_cand, per_cand300);
@@ -1301,7 +1307,6 @@ static int find_copies_impl(hite_ctx *ctx, void *state, int32_t n_cand, const ui
     hipLaunchKernelGGL(emit_copies_kernel, CGRID(ncp), 0, st, ncp, ckey, cval, cstart, ofirst, r_contig, r_s1, r_e1, r_minus, r_anch, r_clip,
                        o_contig, o_s1, o_e1, o_minus, o_anch, o_clip);
     S->out_clip = o_clip; S->out_n = nout;
-    ctx->last_copy_start1 = o_s1; ctx->last_copy_clip = o_clip;
     HITE_CHECK(ctx, hipGetLastError());
     *d_contig = o_contig; *d_start1 = o_s1; *d_end1 = o_e1; *d_minus = o_minus; *d_anchors = o_anch;
     // if the temporaries grew into several chunks during this call, merge them NOW (they are dead; the copy table lives in

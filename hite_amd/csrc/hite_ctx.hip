@@ -23,6 +23,7 @@ extern "C" int hite_ctx_create(int device_id, hite_ctx **out) {
     hite_ctx *c = (hite_ctx *)calloc(1, sizeof(hite_ctx));
     if (!c) return HITE_ENOMEM;
     c->device = device_id;
+    c->copy_interval = -1;
     if (hipSetDevice(device_id) != hipSuccess) { free(c); return HITE_EHIP; }
     *out = c;
     return HITE_OK;

@@ -168,12 +168,28 @@ __global__ void __launch_bounds__(256) select_rows_kernel(int n, const int32_t *
     if (threadIdx.x == 0) nrows[c] = running;
 }
 
+// Pads of a row (copy cp) of a candidate whose centre is copy cp0: the candidate bases the copy's record leaves out in front of /
+// behind its window (clip word = left | right << 16 in the orientation of the GENOME; a minus copy's window is reverse-complemented),
+// less what the CENTRE's own record leaves out on that side -- the row's first base faces centre position a_row - a_centre, and
+// that many pad bytes put it there (a row that reaches further than the centre just begins with bases the centre lacks).
+__device__ __forceinline__ void pad_lengths(const uint32_t *__restrict__ clip, const uint8_t *__restrict__ minus, int cp, int cp0, int &a, int &b) {
+    a = 0; b = 0;
+    if (!clip || cp == cp0) return;
+    const uint32_t cl = clip[cp], c0 = clip[cp0];
+    const bool mn = minus[cp] != 0, m0 = minus[cp0] != 0;
+    const int ar = mn ? (int)(cl >> 16) : (int)(cl & 0xffffu), br = mn ? (int)(cl & 0xffffu) : (int)(cl >> 16);
+    const int a0 = m0 ? (int)(c0 >> 16) : (int)(c0 & 0xffffu), b0 = m0 ? (int)(c0 & 0xffffu) : (int)(c0 >> 16);
+    a = ar > a0 ? ar - a0 : 0;
+    b = br > b0 ? br - b0 : 0;
+}
+
 __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, const int32_t *__restrict__ nrows,
                                 const int32_t *__restrict__ sel, const int32_t *__restrict__ mode,
                                 const int64_t *__restrict__ len, int32_t *__restrict__ row_first32,
                                 int32_t *__restrict__ row_copy, int32_t *__restrict__ row_len,
                                 int32_t *__restrict__ row_pad, uint8_t *__restrict__ row_trunc,
                                 int32_t *__restrict__ maxlen, const uint32_t *__restrict__ clip /* per copy, or NULL */,
+                                const uint8_t *__restrict__ minus,
                                 int32_t *__restrict__ row_cp0 /* per row: the copy of its candidate's centre (clip != NULL) */) {
     int c = blockIdx.x;
     if (c >= n) return;
@@ -185,7 +201,9 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
         int64_t g = row_first[c] + r;
         int cp = sel[(int64_t)c * MAXROWS + r];
         // (the rows of the first500 + last500 form are cut from the PADDED window: still 1000 bytes; the centre, row 0, is never padded)
-        int L = md == 2 ? 1000 : (int)len[cp] + (clip && r > 0 ? (int)(clip[cp] & 0xffffu) + (int)(clip[cp] >> 16) : 0);
+        int pa, pb;
+        pad_lengths(clip, minus, cp, sel[(int64_t)c * MAXROWS], pa, pb);
+        int L = md == 2 ? 1000 : (int)len[cp] + pa + pb;
         row_copy[g] = cp;
         if (clip) row_cp0[g] = sel[(int64_t)c * MAXROWS];
         row_len[g] = L;
@@ -264,9 +282,10 @@ __global__ void __launch_bounds__(256) row_gather_kernel(const uint32_t *__restr
     uint8_t *dst = win + win_off[g];
     // (the centre, the first row of the candidate that owns this copy, is never padded itself)
     const int cp0 = clip ? row_cp0[g] : cp;
-    const uint32_t cl = (clip && cp != cp0) ? clip[cp] : 0u;
-    if (cl) {
-        const int64_t a = mn ? (int64_t)(cl >> 16) : (int64_t)(cl & 0xffffu), b = mn ? (int64_t)(cl & 0xffffu) : (int64_t)(cl >> 16);
+    int pa, pb;
+    pad_lengths(clip, minus, cp, cp0, pa, pb);
+    if (pa | pb) {
+        const int64_t a = pa, b = pb;
         const int64_t plen = a + len + b;
         PadSrc C;
         int64_t tl0;
@@ -422,7 +441,7 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
     if (d_clip) { ACHK(arena_alloc(ctx, T, (size_t)total_rows * 4, &p)); row_cp0 = (int32_t *)p; }
     HITE_CHECK(ctx, hipMemsetAsync(S->d_scal, 0, 64, st));
     hipLaunchKernelGGL(row_meta_kernel, dim3(n), dim3(128), 0, st, n, row_first, nrows, sel, d_mode, d_len, row_first32,
-                       row_copy, row_len, row_pad, row_trunc, (int32_t *)(S->d_scal + 2), d_clip, row_cp0);
+                       row_copy, row_len, row_pad, row_trunc, (int32_t *)(S->d_scal + 2), d_clip, d_minus, row_cp0);
     ACHK(arena_alloc(ctx, T, (size_t)(total_rows + 1) * 8, &p)); win_off = (int64_t *)p;
     ACHK(scan_excl<int32_t>(ctx, T, row_pad, total_rows, win_off, st));
     ACHK(arena_alloc(ctx, T, (size_t)n * 8, &p)); ops_cnt = (int64_t *)p;
@@ -512,6 +531,93 @@ static int run_pass(hite_ctx *ctx, PipeState *S, int te_type, int plant, int n, 
 }
 
 // ---------------------------------------------------------------------------------------------
+// Clip words for a copy table that carries none -- the reference's own 5-tuples (chr, reference_start + 1, reference_end, length,
+// strand) of get_copies_minimap2, Util.py:8022-8030: minimap2's soft clips are dropped there, so nothing says which part of the
+// candidate a record covers.  The probe finds it from the sequences (definition: orc_clip_probe, oracle/hite_oracle_copies.c):
+// the first K = 21 bases of the record's interval (read on the candidate's strand) are laid on the candidate at every offset
+// d = 0 .. min(|cand| - K, |cand| / 20 + 32) -- the reference's filter leaves <= 5 % of the candidate unaligned --, the offset
+// with the fewest mismatches wins (the smallest on ties; N never matches), and is the left clip when it has <= 5 mismatches; if
+// not (an indel inside the probe), the NEXT K bases are tried the same way at the same offsets.  The right clip the same from the
+// other end.  An end that finds no offset takes what the other end's clip leaves of |cand| - |interval| (clamped to the offsets
+// tried; 0 when neither end finds one).  One thread per (record, end): the candidate slides through a 63-bit register of 3-bit codes, one XOR,
+// a fold and a population count per offset.
+// ---------------------------------------------------------------------------------------------
+#define CLIP_K 21
+#define CLIP_MM 5
+__device__ __forceinline__ unsigned long long probe_code(unsigned ch, unsigned long long nval) {     // A C G T -> 0 .. 3 (either case), else nval
+    const unsigned c = ch & 0xdfu;
+    return (c == 'A' || c == 'C' || c == 'G' || c == 'T') ? (unsigned long long)((c >> 1) & 3u) : nval;
+}
+__global__ void __launch_bounds__(256) clip_probe_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
+                                                         const int64_t *__restrict__ coff, int32_t ncontig, int64_t n_copies, int32_t n_cand,
+                                                         const int32_t *__restrict__ copy_first, const uint8_t *__restrict__ cand,
+                                                         const int64_t *__restrict__ cand_off, const int32_t *__restrict__ contig,
+                                                         const int64_t *__restrict__ s1, const int64_t *__restrict__ e1,
+                                                         const uint8_t *__restrict__ minus, uint16_t *__restrict__ clip_out /* 2 per record */) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= 2 * n_copies) return;
+    const int64_t cp = tid >> 1;
+    const int right = (int)(tid & 1);              // lanes 2 k, 2 k + 1: the two ends of record k
+    int lo = 0, hi = n_cand;                       // the candidate that owns the record: last c with copy_first[c] <= cp
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if ((int64_t)copy_first[mid] <= cp) lo = mid; else hi = mid; }
+    const uint8_t *q = cand + cand_off[lo];
+    const int64_t Lq = cand_off[lo + 1] - cand_off[lo];
+    const int ct = contig[cp];
+    int64_t ys = s1[cp] - 1, ye = e1[cp];          // the record's interval, clamped to its contig like a window
+    int clip = -1;                                  // -1: no offset within the mismatch bound
+    int64_t dmax = 0, Ly = 0;
+    bool mn = false;
+    if (ct >= 0 && ct < ncontig) {
+        const int64_t clen = coff[ct + 1] - coff[ct];
+        if (ys < 0) ys = 0;
+        if (ye > clen) ye = clen;
+        Ly = ye - ys;
+        const int64_t g_lo = coff[ct] + ys;
+        mn = minus[cp] != 0;
+        if (Ly >= CLIP_K && Lq >= CLIP_K) {
+            dmax = Lq / 20 + 32;
+            if (dmax > Lq - CLIP_K) dmax = Lq - CLIP_K;
+            if (dmax > 0xffff) dmax = 0xffff;
+            const unsigned long long M3 = 0x1249249249249249ull, M63 = 0x7fffffffffffffffull;
+            for (int att = 0; att < 2 && clip < 0; att++) {
+                const int64_t sh = (int64_t)att * CLIP_K;
+                if (Ly < sh + CLIP_K) break;
+                int64_t dm = dmax;
+                if (dm > Lq - CLIP_K - sh) dm = Lq - CLIP_K - sh;
+                if (dm < 0) break;
+                unsigned long long Y = 0, Q = 0;
+                // base i of a probe at bits 3 i
+                for (int i = 0; i < CLIP_K; i++) {
+                    const int64_t yp = right ? Ly - sh - CLIP_K + i : sh + i;
+                    Y |= probe_code(window_byte(bases, nmask, g_lo, Ly, mn, yp), 4ull) << (3 * i);
+                    const int64_t qp = right ? Lq - sh - CLIP_K + i : sh + i;
+                    Q |= probe_code(q[qp], 7ull) << (3 * i);
+                }
+                int best = CLIP_K + 1, arg = 0;
+                for (int64_t d = 0; d <= dm; d++) {
+                    if (d > 0) {
+                        if (!right) Q = (Q >> 3) | (probe_code(q[d + sh + CLIP_K - 1], 7ull) << (3 * (CLIP_K - 1)));     // the window moves up the candidate
+                        else Q = ((Q << 3) & M63) | probe_code(q[Lq - d - sh - CLIP_K], 7ull);                          // ... down
+                    }
+                    const unsigned long long x = Q ^ Y;
+                    const int mm = __popcll((x | (x >> 1) | (x >> 2)) & M3);
+                    if (mm < best) { best = mm; arg = (int)d; }
+                }
+                if (best <= CLIP_MM) clip = arg;
+            }
+        }
+    }
+    // an end without an offset takes what the other end leaves of the length difference (no net insertion / deletion assumed)
+    const int other = __shfl_xor(clip, 1, 64);
+    if (clip < 0) {
+        int64_t v = other >= 0 ? (Lq - Ly) - other : 0;
+        clip = (int)(v < 0 ? 0 : (v > dmax ? dmax : v));
+    }
+    // the word is kept in the orientation of the genome: a minus record's left clip is the candidate's right one
+    clip_out[2 * cp + ((right != 0) != mn ? 1 : 0)] = (uint16_t)clip;
+}
+
+// ---------------------------------------------------------------------------------------------
 // public entry: the fine stage for one batch of candidates
 // ---------------------------------------------------------------------------------------------
 extern "C" int hite_flank_region_align_clip_dev(hite_ctx *ctx, void **state_io, int32_t te_type, int32_t plant, int32_t n_cand,
@@ -522,10 +628,6 @@ extern "C" int hite_flank_region_align_clip_dev(hite_ctx *ctx, void **state_io, 
                                                 int64_t *stats_out /* 12 x int64, host, may be NULL */, void *stream) {
     if (!ctx || !ctx->d_bases || !state_io || n_cand < 0 || n_copies < 0 || te_type < 0 || te_type > 2) return HITE_EINVAL;
     if (n_cand == 0) return HITE_OK;
-    // the table the copy finder returned last on this context, handed over without its clip words (hite_flank_region_align_dev, a
-    // caller written before round 5): they are taken from the finder -- its records are aligned intervals by default, and rows cut
-    // from those without the pads lose a fifth of the calls
-    if (!d_clip && d_start1 && (const void *)d_start1 == ctx->last_copy_start1) d_clip = ctx->last_copy_clip;
     hipStream_t st = (hipStream_t)stream;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
     PipeState *S = (PipeState *)*state_io;
@@ -551,6 +653,19 @@ extern "C" int hite_flank_region_align_clip_dev(hite_ctx *ctx, void **state_io, 
     if (n_copies > 0)
         hipLaunchKernelGGL(flank_sizes_kernel, dim3((unsigned)((n_copies + 255) / 256)), dim3(256), 0, st, ctx->d_contig_off,
                            ctx->n_contigs, n_copies, d_contig, d_start1, d_end1, flank, len, (int64_t *)nullptr);
+    if (!d_clip && n_copies > 0) {
+        // a table without clip words (the reference's own tuples; never inferred from where the caller's arrays live): the probe
+        // supplies them, so that the rows are padded as the copy finder's own records are -- bare aligned windows, aligned globally
+        // against a longer centre, cost a fifth of the calls (profiles/r05_scale_tests.txt)
+        uint16_t *est;
+        ACHK(arena_alloc(ctx, S->keep, (size_t)n_copies * 4 + 16, &p)); est = (uint16_t *)p;
+        const int tkp = hite_prof_begin(ctx, "clip_probe_kernel", st);
+        hipLaunchKernelGGL(clip_probe_kernel, dim3((unsigned)((2 * n_copies + 255) / 256)), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask,
+                           ctx->d_contig_off, ctx->n_contigs, n_copies, n_cand, d_copy_first, d_cand, d_cand_off, d_contig, d_start1, d_end1,
+                           d_minus, est);
+        hite_prof_end(ctx, tkp, st);
+        d_clip = reinterpret_cast<const uint32_t *>(est);
+    }
     hipLaunchKernelGGL(mode_a_kernel, dim3((n_cand + 255) / 256), dim3(256), 0, st, n_cand, d_copy_first, len, mode_a);
     HITE_CHECK(ctx, hipGetLastError());
     PassOut A, B;
@@ -575,6 +690,39 @@ extern "C" int hite_flank_region_align_clip_dev(hite_ctx *ctx, void **state_io, 
     ACHK(arena_reset(ctx, S->keep, true));
     ACHK(arena_reset(ctx, S->tmp, true));
     if (cons_need > cons_cap) return HITE_ECAP;
+    return HITE_OK;
+}
+
+// the probe by itself, host buffers: what hite_flank_region_align[_clip] with clip == NULL pads the rows by (parity tests, diagnostics)
+extern "C" int hite_clip_probe(hite_ctx *ctx, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off, const int32_t *copy_first,
+                               int64_t n_copies, const int32_t *contig, const int64_t *start1, const int64_t *end1, const uint8_t *minus,
+                               uint32_t *clip_out) {
+    if (!ctx || !ctx->d_bases || n_cand < 0 || n_copies < 0 || (n_copies > 0 && (!cand || !cand_off || !copy_first || !contig || !start1 || !end1 || !minus || !clip_out)))
+        return HITE_EINVAL;
+    if (n_copies == 0 || n_cand == 0) return HITE_OK;
+    HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    uint8_t *d = nullptr;
+    const size_t cb = (size_t)cand_off[n_cand], o1 = (cb + 64 + 255) & ~(size_t)255, o2 = o1 + (((size_t)(n_cand + 1) * 8 + 255) & ~(size_t)255),
+                 o3 = o2 + (((size_t)(n_cand + 1) * 4 + 255) & ~(size_t)255), o4 = o3 + (((size_t)n_copies * 4 + 255) & ~(size_t)255),
+                 o5 = o4 + (((size_t)n_copies * 8 + 255) & ~(size_t)255), o6 = o5 + (((size_t)n_copies * 8 + 255) & ~(size_t)255),
+                 o7 = o6 + (((size_t)n_copies + 255) & ~(size_t)255), total = o7 + (size_t)n_copies * 4 + 256;
+    HITE_CHECK(ctx, hipMalloc((void **)&d, total));
+    hipError_t e = hipMemcpy(d, cand, cb, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o1, cand_off, (size_t)(n_cand + 1) * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o2, copy_first, (size_t)(n_cand + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o3, contig, (size_t)n_copies * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o4, start1, (size_t)n_copies * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o5, end1, (size_t)n_copies * 8, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + o6, minus, (size_t)n_copies, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(clip_probe_kernel, dim3((unsigned)((2 * n_copies + 255) / 256)), dim3(256), 0, 0, ctx->d_bases, ctx->d_nmask,
+                           ctx->d_contig_off, ctx->n_contigs, n_copies, n_cand, (const int32_t *)(d + o2), d, (const int64_t *)(d + o1),
+                           (const int32_t *)(d + o3), (const int64_t *)(d + o4), (const int64_t *)(d + o5), d + o6, (uint16_t *)(d + o7));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(clip_out, d + o7, (size_t)n_copies * 4, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    HITE_CHECK(ctx, e);
     return HITE_OK;
 }
 

@@ -298,12 +298,15 @@ int hite_itr_search_dev(hite_ctx *ctx, int64_t n, const uint8_t *d_seqs, const i
  * hite_flank_region_align consumes (1-based inclusive coordinates).  n_cand < 2^19 per call.
  * _dev: the returned device arrays live in the index state's arena until the next call. */
 int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream);
-/* which interval the copy records of hite_find_copies[_dev] carry (process-wide): 1 = the ALIGNED interval, reference_start + 1 ..
+/* which interval the copy records of hite_find_copies[_dev] carry (process-wide DEFAULT, for contexts without a setting of their own): 1 = the ALIGNED interval, reference_start + 1 ..
  * reference_end exactly as get_copies_minimap2 reports it (Util.py:8026) -- the default since round 5, with the clipped candidate
  * bases handed on beside the records (hite_copy_clips) --; 0 = the interval of the WHOLE candidate, the ends that the extension clipped
  * extrapolated on the diagonal (the default of rounds 2-4); -1 = take the setting from the environment again
  * (HITE_COPY_INTERVAL=aligned | whole).  Both are twin-pinned (orc_find_copies_config). */
 int hite_copy_config(int32_t aligned_interval);
+/* the same setting for ONE context (what the library's per-context thread safety covers): 1 / 0 as above, -1 = follow the process-wide
+ * setting of hite_copy_config again (the state of a new context) */
+int hite_copy_config_ctx(hite_ctx *ctx, int32_t aligned_interval);
 void hite_copy_index_release(void *state);
 /* sizes of the last hite_find_copies[_dev] call on this index (diagnostics / roofline accounting):
  * out = {candidate minimizers, index hits, diagonal clusters, copies before the 300-per-candidate cap} */
@@ -454,21 +457,30 @@ int hite_flank_region_align_dev(hite_ctx *ctx, void **state_io, int32_t te_type,
                                 int64_t n_copies, const int32_t *d_contig, const int64_t *d_start1, const int64_t *d_end1,
                                 const uint8_t *d_minus, int32_t flank, hite_call *d_calls, uint8_t *d_cons,
                                 int64_t cons_cap, int64_t *stats_out, void *stream);
-/* The same stage for copy records in the REFERENCE'S coordinates (reference_start + 1 .. reference_end of the alignment, Util.py:8026,
- * as get_copies_minimap2 hands them to flank_region_align_v5: what hite_find_copies reports by default).  Such a record covers only the part of the
- * candidate that aligned; `clip` (per copy record, may be NULL = no pads: hite_flank_region_align) says how many candidate bases the
- * two end extensions clipped -- left | right << 16, in the orientation of the genome (hite_copy_clips[_dev]) -- and the row's window
- * (interval + flanks, Util.py:8110-8125) is padded by them with pad bytes (HITE_IS_ROW_PAD): the CENTRE's own first / last bases in
- * lower case, which match the centre positions they face -- in front by the left clip (a minus copy: the right one, its window is
- * reverse-complemented), behind by the other; the centre (the first row kept) is never padded; the first500 + last500 form of a long window (Util.py:8119) is
+/* The same stage with the clip words of the copy records given.  A copy record in the REFERENCE'S coordinates (reference_start + 1 ..
+ * reference_end of the alignment, Util.py:8026, as get_copies_minimap2 hands it to flank_region_align_v5: what hite_find_copies reports
+ * by default) covers only the part of the candidate that aligned; `clip` (per record) says how many candidate bases were left out at
+ * its two ends -- left | right << 16, in the orientation of the genome (hite_copy_clips[_dev]) -- and the row's window (interval +
+ * flanks, Util.py:8110-8125) is padded with pad bytes (HITE_IS_ROW_PAD): the CENTRE's own first / last bases in lower case, which match
+ * the centre positions they face -- in front by the left clip (a minus copy: the right one, its window is reverse-complemented) LESS
+ * what the centre's own record leaves out on that side (round 6: the row's first base faces centre position clip_row - clip_centre),
+ * behind by the other; the centre (the first row kept) is never padded; the first500 + last500 form of a long window (Util.py:8119) is
  * cut from the padded window; the <= 100 rows are chosen by the length of the genome window.  A padded row faces the part of the
  * centre its copy was found with, so its path stays on the diagonal; the pads leave the alignment as gaps of the row (where mafft,
- * which does not charge terminal gaps like internal ones, leaves such a row unaligned).  Without the pads every such row is aligned
- * GLOBALLY at 3 per gap base to a centre that is clip_l + clip_r bases longer: on config C2 8 633 rows left the band and TE calls
- * fell by a fifth (profiles/r04_scale_tests.txt); with them the mode calls as many TEs as the whole-candidate mode and puts more
- * consensus ends on the planted element (tests/test_gpu_scale.py::test_c2_whole_candidate_intervals, profiles/r05_scale_tests.txt). */
-/* (_dev forms: when d_clip is NULL and d_start1 is the very array hite_find_copies[_dev] returned last on this context, the clip words of
- * that call are used -- a caller that passes the finder's device table straight on needs no change; host tables: pass `clip`.) */
+ * which does not charge terminal gaps like internal ones, leaves such a row unaligned).
+ * clip == NULL (and hite_flank_region_align[_dev], which have no such argument) -- the reference's own 5-tuples, real minimap2 records:
+ * the clip words are ESTIMATED from the sequences (round 6, clip_probe_kernel; definition orc_clip_probe in
+ * oracle/hite_oracle_copies.c): the first 21 bases of the record's interval, read on the candidate's strand, are laid on the candidate
+ * at every offset 0 .. |cand| / 20 + 32; the offset with the fewest mismatches (the smallest on ties) is the left clip when it has <= 5
+ * mismatches, else the next 21 bases are tried, else 0; the right clip the same from the other end.  A whole-candidate record probes
+ * to 0 | 0.  Nothing is inferred from where the caller's arrays live (round 5 recognised the finder's own device table by its address).
+ * Rows cut from aligned intervals WITHOUT pads are aligned globally at 3 per gap base against a centre that is clip_l + clip_r bases
+ * longer: on config C2 8 633 rows left the band and TE calls fell by a fifth (profiles/r05_scale_tests.txt, last line). */
+/* the estimate by itself (host buffers, arguments as hite_flank_region_align's table): clip_out[k] = left | right << 16 in the orientation
+ * of the genome, what a call without clip words pads the rows by */
+int hite_clip_probe(hite_ctx *ctx, int32_t n_cand, const uint8_t *cand, const int64_t *cand_off, const int32_t *copy_first,
+                    int64_t n_copies, const int32_t *contig, const int64_t *start1, const int64_t *end1, const uint8_t *minus,
+                    uint32_t *clip_out);
 int hite_flank_region_align_clip(hite_ctx *ctx, int32_t te_type, int32_t plant, int32_t n_cand, const uint8_t *cand,
                                  const int64_t *cand_off, const int32_t *copy_first, int64_t n_copies, const int32_t *contig,
                                  const int64_t *start1, const int64_t *end1, const uint8_t *minus, const uint32_t *clip, int32_t flank,

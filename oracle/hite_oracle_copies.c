@@ -376,6 +376,57 @@ static copy_t *find_pass(const uint8_t *genome, const int64_t *contig_off, int n
 #define FAR_K 13
 #define FAR_W 8
 static int g_far_min = 0;
+/* Clip words for a copy record that carries none: the reference's own tuples (chr, reference_start + 1, reference_end, length,
+ * strand) of get_copies_minimap2, /root/reference/module/Util.py:8022-8030 -- minimap2's soft clips are dropped there --, consumed at
+ * Util.py:8095-8115.  Twin of clip_probe_kernel (hite_amd/csrc/hite_pipeline.hip); THIS BUILD'S definition, not minimap2's.
+ * q: the candidate, y: the record's interval read on the candidate's strand.  The first K = 21 bases of y are laid on q at every
+ * offset d = 0 .. min(|q| - K - shift, |q| / 20 + 32, 65535); a base matches when both are the same of ACGT (either case in q); the
+ * offset with the fewest mismatches wins, the smallest on ties; it is the left clip when it has <= 5 mismatches; otherwise the same
+ * with the NEXT K bases (shift = K) against q[d + K ..].  The right clip: the same from the other end (the last K bases of y
+ * against q[|q| - d - K - shift ..]).  An end that finds no offset takes what the other end's clip leaves of |q| - |y|, clamped to
+ * 0 .. the largest offset tried; 0 when neither end finds one.  returns left | right << 16 in the CANDIDATE's orientation. */
+#define ORC_CLIP_K 21
+#define ORC_CLIP_MM 5
+static int probe_eq(uint8_t a, uint8_t b) {
+    a &= 0xdf; b &= 0xdf;
+    return a == b && (a == 'A' || a == 'C' || a == 'G' || a == 'T');
+}
+uint32_t orc_clip_probe(const uint8_t *q, int64_t Lq, const uint8_t *y, int64_t Ly) {
+    int clip[2] = {-1, -1};
+    if (Ly < ORC_CLIP_K || Lq < ORC_CLIP_K) return 0;
+    int64_t dmax = Lq / 20 + 32;
+    if (dmax > Lq - ORC_CLIP_K) dmax = Lq - ORC_CLIP_K;
+    if (dmax > 0xffff) dmax = 0xffff;
+    for (int right = 0; right < 2; right++) {
+        for (int att = 0; att < 2; att++) {
+            const int64_t sh = (int64_t)att * ORC_CLIP_K;
+            if (Ly < sh + ORC_CLIP_K) break;
+            int64_t dm = dmax;
+            if (dm > Lq - ORC_CLIP_K - sh) dm = Lq - ORC_CLIP_K - sh;
+            if (dm < 0) break;
+            int best = ORC_CLIP_K + 1, arg = 0;
+            for (int64_t d = 0; d <= dm; d++) {
+                int mm = 0;
+                for (int i = 0; i < ORC_CLIP_K; i++) {
+                    const int64_t yp = right ? Ly - sh - ORC_CLIP_K + i : sh + i;
+                    const int64_t qp = right ? Lq - d - sh - ORC_CLIP_K + i : d + sh + i;
+                    mm += !probe_eq(q[qp], y[yp]);
+                }
+                if (mm < best) { best = mm; arg = (int)d; }
+            }
+            if (best <= ORC_CLIP_MM) { clip[right] = arg; break; }
+        }
+    }
+    /* an end without an offset takes what the other end leaves of the length difference (no net insertion / deletion assumed) */
+    if (clip[0] < 0 && clip[1] < 0) return 0;
+    for (int e = 0; e < 2; e++)
+        if (clip[e] < 0) {
+            const int64_t v = (Lq - Ly) - clip[1 - e];
+            clip[e] = (int)(v < 0 ? 0 : (v > dmax ? dmax : v));
+        }
+    return (uint32_t)clip[0] | ((uint32_t)clip[1] << 16);
+}
+
 void orc_find_copies_far(int min_copies) { g_far_min = min_copies > 0 ? min_copies : 0; }
 
 int64_t orc_find_copies(const uint8_t *genome, const int64_t *contig_off, int ncontig, const uint8_t *cand,

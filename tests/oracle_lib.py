@@ -304,6 +304,14 @@ def find_copies(contigs, cands, clips=False):
     return [[(int(ct[i]), int(s1[i]), int(e1[i]), int(mn[i]), int(an[i])) for i in range(cf[c], cf[c + 1])] for c in range(len(cb))]
 
 
+def clip_probe(cand, interval_seq):
+    """clip word (left | right << 16, in the CANDIDATE's orientation) estimated for a copy record without one: twin of clip_probe_kernel"""
+    q = np.frombuffer(cand.encode() if isinstance(cand, str) else bytes(cand), dtype=np.uint8)
+    y = np.frombuffer(interval_seq.encode() if isinstance(interval_seq, str) else bytes(interval_seq), dtype=np.uint8)
+    lib().orc_clip_probe.restype = C.c_uint32
+    return int(lib().orc_clip_probe(_ptr(q, u8p), C.c_int64(len(q)), _ptr(y, u8p), C.c_int64(len(y))))
+
+
 def find_copies_config(aligned_interval):
     """interval mode of the twin's records (mirror of hite_copy_config): True = the aligned interval (the default), False = the whole
     candidate, None = back to the default"""

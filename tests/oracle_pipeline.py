@@ -78,14 +78,31 @@ def anchor_class(cand, msa):
     return "none"
 
 
-def _padded(w, clip, minus, centre):
-    """the window of a copy record in the reference's coordinates, padded by the clipped candidate bases (clip = left | right << 16 in
-    the orientation of the genome; a minus copy's window is reverse-complemented): pad byte i in front = the CENTRE's base i, pad byte j
+_COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+
+
+def _interval(contig, s, e, minus):
+    """the bases of a record's interval (1-based, inclusive, clamped to the contig) read on the record's strand; not A / C / G / T -> N"""
+    cb = contig.encode() if isinstance(contig, str) else bytes(contig)
+    iv = bytes(c if c in b"ACGT" else 78 for c in cb[max(0, s - 1):max(0, min(len(cb), e))].upper())
+    return iv.translate(_COMP)[::-1] if minus else iv
+
+
+def _front_back(clip, minus):
+    """clip word (left | right << 16 in the orientation of the genome) -> (in front of, behind) the window as it is read (a minus
+    copy's window is reverse-complemented)"""
+    a, b = clip & 0xffff, clip >> 16
+    return (b, a) if minus else (a, b)
+
+
+def _padded(w, clip, minus, centre, centre_clip=0, centre_minus=False):
+    """the window of a copy record in the reference's coordinates, padded by the candidate bases its record leaves out LESS what the
+    centre's own record leaves out on that side (pad_lengths, hite_pipeline.hip): pad byte i in front = the CENTRE's base i, pad byte j
     of the b behind = the centre's base m - b + j, in lower case (HITE_IS_ROW_PAD: they match the centre positions they face and leave
     the alignment as gaps of the row); ROW_PAD where the centre has no such position"""
-    a, b = clip & 0xffff, clip >> 16
-    if minus:
-        a, b = b, a
+    a, b = _front_back(clip, minus)
+    a0, b0 = _front_back(centre_clip, centre_minus)
+    a, b = max(0, a - a0), max(0, b - b0)
     m = len(centre)
     front = "".join(centre[i].lower() if i < m else ROW_PAD for i in range(a))
     back = "".join(centre[m - b + j].lower() if 0 <= m - b + j < m else ROW_PAD for j in range(b))
@@ -96,14 +113,21 @@ def fine_stage_candidate(te_type, cand, copies, contigs, plant=1, flank=50, cont
     """copies: (contig_index, start1, end1, minus[, anchors, clip]) -> [is_TE, info, cons, row_num]; keep_msa: a list that receives
     the cleaned alignment of every pass that was judged.  clip (find_copies(..., clips=True); non-zero only for records in the
     reference's coordinates): hite_flank_region_align_clip -- the rows (never the centre, the first row kept) are padded by the clipped
-    bases (_padded); the rows are chosen by the length of the genome window; the first500 + last500 form is cut from the padded window"""
+    bases (_padded); the rows are chosen by the length of the genome window; the first500 + last500 form is cut from the padded window.
+    A tuple WITHOUT the clip field (the reference's own 5-tuple): the clip word is estimated as hite_flank_region_align does (O.clip_probe)"""
     full, trunc = [], []            # (window, name, clip, minus) per pass, in input order
     for cp in copies:
         (ci, s, e, mn) = cp[:4]
         w, t = O.flank_window(contigs[ci], s, e, "-" if mn else "+", flank)
         if w is None:
             continue
-        rec = (w, window_name(cp, contig_names), int(cp[5]) if len(cp) > 5 else 0, bool(mn))
+        if len(cp) > 5:
+            clip = int(cp[5])
+        else:
+            # a record without a clip word (the reference's own tuples): estimated from the sequences, hite_flank_region_align's rule
+            pr = O.clip_probe(cand, _interval(contigs[ci], s, e, mn))
+            clip = ((pr >> 16) | ((pr & 0xffff) << 16)) if mn else pr      # (kept in the orientation of the genome)
+        rec = (w, window_name(cp, contig_names), clip, bool(mn))
         full.append(rec)
         if t is not None:
             trunc.append(rec)
@@ -117,12 +141,12 @@ def fine_stage_candidate(te_type, cand, copies, contigs, plant=1, flank=50, cont
             wins = [r[0][:500] + r[0][-500:] if cut else r[0] for r in recs]
             return judge_windows(te_type, cand, wins, plant, names, keep_msa, lens=lens)
         keep = select_rows(lens, names)
-        centre = recs[keep[0]][0]
+        centre, _n0, clip0, mn0 = recs[keep[0]]
         wins = []
         for k, i in enumerate(keep):
             w, _nm, clip, mn = recs[i]
             if k > 0 and clip:
-                w = _padded(w, clip, mn, centre)
+                w = _padded(w, clip, mn, centre, clip0, mn0)
             wins.append(w[:500] + w[-500:] if cut else w)
         return judge_windows(te_type, cand, wins, plant, None, keep_msa)       # (the rows are chosen: <= 100 windows)
 

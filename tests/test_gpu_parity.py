@@ -829,9 +829,10 @@ def test_aligned_interval_mode_pads_the_rows(ctx):
     assert te(res) >= te(res_bare) and te(res) >= 0.9 * te(res_whole)
 
 
-def test_finder_table_handed_on_without_clip_pointer(ctx):
-    """hite_find_copies_dev -> hite_flank_region_align_dev (the call sequence of rounds 1-4, no clip pointer): the device table of the
-    finder is recognised and its clip words are used -- the calls are those of the explicit form, not those of bare aligned windows"""
+def test_table_without_clip_words_is_probed_wherever_it_lives(ctx):
+    """hite_find_copies_dev -> hite_flank_region_align_dev without a clip pointer (the call sequence of rounds 1-4): the clip words are
+    ESTIMATED from the sequences (clip_probe_kernel) -- for the finder's own device table exactly as for a copy of it elsewhere; round
+    5 recognised the finder's table by its address and took the finder's words, which made the result depend on where an array lived"""
     import synth_small
     import torch
     from hite_amd._lib import CALL_DTYPE
@@ -849,11 +850,11 @@ def test_finder_table_handed_on_without_clip_pointer(ctx):
     n, nbytes = len(cb), int(off[-1])
     cap = nbytes + 200 * n + 4096
     outs = []
-    for mode in ("implicit", "explicit", "none"):
+    for mode in ("finder's table", "explicit", "a copy of it"):
         d_calls = torch.zeros(n * 32, dtype=torch.uint8, device=dev)
         d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
         nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
-        if mode == "none":      # the table copied elsewhere: an external table, no clip words -> bare aligned windows
+        if mode == "a copy of it":
             s1 = torch.from_numpy(ctx.download(p_s1, nc, np.int64)).to(dev)
             p_s1 = s1.data_ptr()
         ctx.flank_region_align_dev("tir", 1, n, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50, d_calls.data_ptr(),
@@ -862,9 +863,50 @@ def test_finder_table_handed_on_without_clip_pointer(ctx):
         calls = d_calls.cpu().numpy().view(CALL_DTYPE).copy()
         cons = d_cons.cpu().numpy()
         outs.append([(int(c["is_te"]), cons[c["cons_off"]:c["cons_off"] + c["cons_len"]].tobytes() if c["is_te"] else b"") for c in calls])
-    assert outs[0] == outs[1]
-    print("finder table without a clip pointer == explicit clip pointer; an external copy of it (bare windows) differs in %d of %d calls"
-          % (sum(a != b for a, b in zip(outs[0], outs[2])), n))
+    assert outs[0] == outs[2]
+    print("no clip pointer: the finder's own table == a copy of it; against the finder's clip words %d of %d calls differ (%d / %d TE calls)"
+          % (sum(a != b for a, b in zip(outs[0], outs[1])), n, sum(a[0] for a in outs[0]), sum(a[0] for a in outs[1])))
+
+
+def test_reference_tuples_clip_probe_vs_twin(ctx):
+    """A copy table in the reference's own form -- (chr, reference_start + 1, reference_end, length, strand), Util.py:8022-8030: no clip
+    words -- through hite_flank_region_align: (1) the estimated words, hite_clip_probe == orc_clip_probe record for record (both strands,
+    records at contig ends, intervals shorter than two probes); (2) they are close to what the copy finder knows (its end extensions'
+    clips); (3) the whole stage on the 5-tuples == the oracle chain, which estimates by the same rule"""
+    import oracle_pipeline as OP
+    import synth_small
+
+    g = synth_small.make(29, n_fam=20)
+    ctx.genome_pack(g["contigs"])
+    ctx.release_copy_index()
+    full = ctx.find_copies(g["cands"], clips=True)
+    assert full == O.find_copies(g["contigs"], g["cands"], clips=True)
+    # the reference's tuple: (chr, start, end, aligned length, strand) -- here with the contig as its index and the strand as 0 / 1
+    ref5 = [[(t[0], t[1], t[2], t[3], t[2] - t[1] + 1) for t in cp] for cp in full]
+    hand = [(0, 1, 30, 0, 30), (0, 5, 60, 1, 56), (len(g["contigs"]) - 1, max(1, len(g["contigs"][-1]) - 39), len(g["contigs"][-1]), 1, 40)]
+    ref5[0] = ref5[0] + hand
+    got = ctx.clip_probe(g["cands"], ref5)
+    n_rec = n_near = n_nonzero = 0
+    for cand, cps, words, cpf in zip(g["cands"], ref5, got, full):
+        for k, (t, w) in enumerate(zip(cps, words)):
+            pr = O.clip_probe(cand, OP._interval(g["contigs"][t[0]], t[1], t[2], t[3]))
+            exp = ((pr >> 16) | ((pr & 0xffff) << 16)) if t[3] else pr
+            assert w == exp, (t, w, exp)
+            if k < len(cpf):
+                n_rec += 1
+                n_nonzero += cpf[k][5] != 0
+                n_near += abs((w & 0xffff) - (cpf[k][5] & 0xffff)) <= 3 and abs((w >> 16) - (cpf[k][5] >> 16)) <= 3
+    assert n_nonzero >= 20 and n_near >= 0.85 * n_rec, (n_rec, n_nonzero, n_near)
+    ref5[0] = ref5[0][:-len(hand)]
+    res, _ = ctx.flank_region_align("tir", g["cands"], ref5, plant=1)
+    n_te = 0
+    for cand, cp, r in zip(g["cands"], ref5, res):
+        assert [r[0], r[1], r[2], r[3]] == OP.fine_stage_candidate("tir", cand, cp, g["contigs"], plant=1)
+        n_te += r[0]
+    res6, _ = ctx.flank_region_align("tir", g["cands"], full, plant=1)
+    print("reference tuples: %d records, %d with a clip, estimate within 3 bases of the finder's at both ends for %d; TE calls %d (with the finder's words: %d) of %d"
+          % (n_rec, n_nonzero, n_near, n_te, sum(r[0] for r in res6), len(res)))
+    assert n_te >= 0.9 * sum(r[0] for r in res6)
 
 
 def test_aligned_interval_mode_through_the_host_mirror(ctx, tmp_path):

@@ -39,9 +39,9 @@ def run_fine(mbp, n_tir, n_ltr, seed, te_types=("tir",), **workload_kw):
     ctx.align_stats(reset=True)
     nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n, d_cand.data_ptr(), d_off.data_ptr(), nbytes)
     # the clip words of the records (aligned intervals, the default): the rows are padded by them; zero with HITE_COPY_INTERVAL=whole (HITE_TEST_NO_CLIP=1,
-    # tools/copy_interval_modes.py: the bare windows, as for a copy table that carries no clip words)
+    # tools/copy_interval_modes.py: no clip pointer, as for a copy table in the reference's own form -- the library estimates the words)
     p_cl = 0 if os.environ.get("HITE_TEST_NO_CLIP") == "1" else ctx.copy_clips_dev()
-    if not p_cl and nc > 0:     # (an EXTERNAL table: a copy of the start array -- the finder's own device table would get its clip words anyway)
+    if not p_cl and nc > 0:     # (an EXTERNAL table: a copy of the start array)
         ext_s1 = torch.from_numpy(ctx.download(p_s1, nc, np.int64)).to(dev)
         p_s1 = ext_s1.data_ptr()
     # the same candidates and copy table judged as Helitron / non-LTR as well (judge_Helitron_transposons.py:86-97,

@@ -19,7 +19,7 @@ def main():
 
     print("# tools/copy_interval_modes.py -- config C2 (100 Mbp, 500 TIR families, 5000 candidates), the fine stage under both interval modes of the copy finder")
     for mode, name in ((0, "whole-candidate intervals (HITE_COPY_INTERVAL=whole; the default of rounds 2-4)"), (1, "aligned intervals (Util.py:8026), rows padded by the clipped bases (the default since round 5)"),
-                       (2, "aligned intervals, bare windows (no clip words: rounds 3-4, an external copy table)")):
+                       (2, "aligned intervals WITHOUT clip words (the reference's own tuples): clips estimated by the probe (round 6; rounds 3-5: bare windows)")):
         os.environ["HITE_COPY_INTERVAL"] = "aligned" if mode else "whole"
         os.environ["HITE_TEST_NO_CLIP"] = "1" if mode == 2 else "0"     # (tests/test_gpu_scale.py run_fine: hand no clip words on)
         from hite_amd import _lib as hl

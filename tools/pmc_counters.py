@@ -12,19 +12,31 @@ from pmc_traffic import per_kernel  # noqa: E402
 
 COUNTERS = ["SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_WAIT_INST_ANY", "SQ_INSTS_VMEM"]
 STAGE = {"align_fwd4_kernel": "align_fwd4", "align_fwd_kernel<4>": "align_fwd4", "align_fwd_kernel<8>": "align_fwd_wide8", "align_fwd_kernel<16>": "align_fwd_wide16",
-         "align_fwd_kernel<32>": "align_fwd_wide32", "align_tb_kernel": "align_tb", "align_wide_fwd_kernel": "align_fallback_fwd",
-         "align_wide_tb_kernel": "align_fallback_tb", "align_planes_kernel": "align_prep_planes"}
+         "align_fwd_kernel<32>": "align_fwd_wide32", "align_fwd8_pair_kernel": "align_fwd_wide8", "align_tb_kernel": "align_tb",
+         "align_fwd_lanes_kernel<4>": "align_fwd4_lanes", "align_fwd_lanes_kernel<8>": "align_fwd_wide_lanes", "align_tb_strips_kernel": "align_tb_strips",
+         "align_wide_fwd_kernel": "align_fallback_fwd", "align_wide_tb_kernel": "align_fallback_tb", "align_planes_kernel": "align_prep_planes"}
+FWD4_LAUNCHES_PER_STEP = 2      # one pipeline step = the first500 + last500 pass and the full-length pass: align_fwd4_kernel runs once in each
 
 
 def main():
     d, bj, oj, ot = sys.argv[1:5]
     hdr = sys.argv[5] if len(sys.argv) > 5 else ""
     bench = json.loads([ln for ln in open(bj) if ln.startswith("{")][-1])
-    steps_run = bench["steps"] + bench["warmup"] + 2      # bench.py makes two residency calls before the warm-up
     cols = bench["config"]["align_stats_per_step"]["columns"]
     tab = {c: per_kernel(d, c) for c in COUNTERS}
     kernels = sorted({k for c in tab.values() for k in c})
-    res = {"_columns_per_step": cols, "_steps_in_profiled_run": steps_run, "_command": hdr}
+    # The pipeline steps of the profiled run are COUNTED from the trace (launches of align_fwd4_kernel / 2), not derived from the
+    # bench line's flags: a run without --no-modes makes more steps than steps + warmup + 2 (round 5's file was normalised by 5
+    # while the trace held 9: every per-step count 1.8 x too high).  The flags' count must agree when the header says the run was
+    # --no-modes --no-coarse; anything else is refused.
+    l4 = max([tab[c].get(k, (0.0, 0))[1] for c in COUNTERS for k in kernels if "align_fwd4_kernel" in k] + [0])
+    if l4 <= 0 or l4 % FWD4_LAUNCHES_PER_STEP:
+        raise SystemExit("pmc_counters: %d launches of align_fwd4_kernel in the trace: cannot count the pipeline steps" % l4)
+    steps_run = l4 // FWD4_LAUNCHES_PER_STEP
+    by_flags = bench["steps"] + bench["warmup"] + 2      # bench.py makes two residency calls before the warm-up
+    if "--no-modes" in hdr and ("--no-coarse" in hdr or "--stage" in hdr) and by_flags != steps_run:
+        raise SystemExit("pmc_counters: the trace holds %d pipeline steps, the bench line's flags say %d" % (steps_run, by_flags))
+    res = {"_columns_per_step": cols, "_steps_in_profiled_run": steps_run, "_steps_by_bench_flags": by_flags, "_align_fwd4_launches": l4, "_command": hdr}
     lines = []
     for k in kernels:
         row = {c: tab[c].get(k, (0.0, 0))[0] for c in COUNTERS}
