@@ -244,8 +244,8 @@ def main():
         stream.synchronize()
         merged = None
         if world > 1:   # merge the boundary calls (RCCL over xGMI): ONE all-gather of the 32-byte records
-            merged = (hd.allgather_calls_balanced(d_calls[: n_cand * 32], shares) if shares is not None
-                      else hd.allgather_calls(d_calls[: n_cand * 32], n_merge))
+            merged = (hd.allgather_calls_balanced(d_calls[: n_cand * 32], shares, alias=True) if shares is not None
+                      else hd.allgather_calls(d_calls[: n_cand * 32], n_merge, alias=True))     # (a view of the merge buffer: read before the next step)
         return st, merged
 
     # residency set-up, like the index build above: the library's grow-only arenas reach their final size in the first call

@@ -104,9 +104,10 @@ def _merge_buf(key, n, dtype, device):
     return t[:n]
 
 
-def allgather_calls_balanced(local_calls, shares, group=None):
+def allgather_calls_balanced(local_calls, shares, group=None, alias=False):
     """local_calls: uint8 tensor (len(shares[rank]) * 32) in the order of shares[rank].  ONE padded all_gather_into_tensor, then
-    the inverse permutation: returns the records of all candidates in candidate order (a view of a buffer kept between steps)."""
+    the inverse permutation: returns the records of all candidates in candidate order -- a tensor of the caller's own; alias=True
+    (the bench's timed loop): a view of a buffer kept between steps, which the NEXT merge overwrites."""
     world = dist.get_world_size(group)
     dev = local_calls.device
     max_n = max(1, max(len(s) for s in shares))
@@ -115,18 +116,17 @@ def allgather_calls_balanced(local_calls, shares, group=None):
     out = _merge_buf("gathered", world * max_n * 32, torch.uint8, dev)
     dist.all_gather_into_tensor(out, pad, group=group)
     n_total = sum(len(s) for s in shares)
-    key = ("perm", id(shares))
-    cached = _MERGE_BUF.get(key)
-    if cached is None or cached[0] is not shares:
-        # row of candidate c in the gathered buffer (the shares of a run do not change between its steps)
+    cached = _MERGE_BUF.get("perm")      # ONE slot: the permutation of the shares seen last (a run's shares do not change between its steps)
+    if cached is None or cached[0] is not shares or cached[1].device != dev:
+        # row of candidate c in the gathered buffer
         src = np.empty(n_total, dtype=np.int64)
         for r, ids in enumerate(shares):
             src[ids] = r * max_n + np.arange(len(ids))
         cached = (shares, torch.from_numpy(src).to(dev))
-        _MERGE_BUF[key] = cached
+        _MERGE_BUF["perm"] = cached
     merged = _merge_buf("merged", n_total * 32, torch.uint8, dev).view(n_total, 32)
     torch.index_select(out.view(world * max_n, 32), 0, cached[1], out=merged)
-    return merged.reshape(-1)
+    return merged.reshape(-1) if alias else merged.reshape(-1).clone()
 
 
 def allgather_consensus_balanced(local_calls_np, local_cons, shares, group=None):
@@ -151,9 +151,10 @@ def allgather_consensus_balanced(local_calls_np, local_cons, shares, group=None)
     return allc, cons
 
 
-def allgather_calls(local_calls, n_total, group=None):
+def allgather_calls(local_calls, n_total, group=None, alias=False):
     """local_calls: uint8 tensor (n_local * 32) on the backend's device.  Returns the n_total records of all
-    ranks in candidate order (block partition => rank order; a view of a buffer kept between steps).  One padded all_gather_into_tensor."""
+    ranks in candidate order (block partition => rank order) -- a tensor of the caller's own; alias=True: a view of a buffer kept
+    between steps, which the next merge overwrites.  One padded all_gather_into_tensor."""
     world = dist.get_world_size(group)
     dev = local_calls.device
     b = shard_bounds(n_total, world)
@@ -166,7 +167,7 @@ def allgather_calls(local_calls, n_total, group=None):
     for r in range(world):                  # block partition: rank order is candidate order; no allocation, no concatenation
         n_r = int(b[r + 1] - b[r]) * 32
         merged[int(b[r]) * 32: int(b[r]) * 32 + n_r] = out[r * max_n * 32: r * max_n * 32 + n_r]
-    return merged
+    return merged if alias else merged.clone()
 
 
 def allgather_consensus(local_calls_np, local_cons, n_total, group=None):

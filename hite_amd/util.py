@@ -1347,7 +1347,8 @@ def flank_region_align_v5(candidate_sequence_path, real_TEs, flanking_len, refer
     res, _stats = ctx.flank_region_align(TE_type, cands, copies, plant=int(plant), flank=int(flanking_len)) if qnames else ([], None)
     true_tes, low_copy = bucket_results(TE_type, [(q if is_te else None, cons if is_te else None, info, copy_count)
                                                   for q, (is_te, info, cons, copy_count, _bs, _be) in zip(qnames, res)])
-    rescued, low_copy = rescue_low_copy(TE_type, low_copy, plant, os.path.join(tmp_output_dir, "low_copy_%s_%s" % (TE_type, ref_index)))
+    rescued, low_copy = rescue_low_copy(TE_type, low_copy, plant, os.path.join(tmp_output_dir, "low_copy_%s_%s" % (TE_type, ref_index)),
+                                        threads=max(1, int(threads)))
     true_tes.update(rescued)
     store_fasta(true_tes, real_TEs)
     with open(all_low_copy, "a") as f:
@@ -1363,11 +1364,13 @@ def rescue_low_copy(TE_type, low_copy, plant, work_dir, tandem_masker=None, ctx=
     stage where the reference runs `itrsearch -i 0.7 -l 7`) are real TEs, with their masked sequence as the tool writes it; the
     others, and the low-copy Helitron / non-LTR candidates, are searched for intact protein domains (get_domain_info: blastx
     against <library_dir>/TIRPeps.lib | HelitronPeps.lib | non_LTR.lib, a hit over >= 95 % of a protein recalls the element with
-    its unmasked sequence).  library_dir defaults to $HITE_LIBRARY_DIR; blastx is an external tool: when it or the library is
+    its unmasked sequence).  library_dir defaults to $HITE_LIBRARY_DIR, then <HiTE>/library beside the package (as scripts/judge_Other_transposons.py); blastx is an external tool: when it or the library is
     missing that recall finds nothing and the stage log says so.  -> (rescued, still low copy), both in the reference's order."""
     if not low_copy or TE_type not in _PROTEIN_LIB:
         return {}, dict(low_copy)
-    library_dir = library_dir or os.environ.get("HITE_LIBRARY_DIR")
+    # the reference always looks in <HiTE>/library (Util.py:8215-8230: cur_dir + '/library/...'); here: the argument, then
+    # $HITE_LIBRARY_DIR, then <HiTE>/library beside the package (as scripts/judge_Other_transposons.py does)
+    library_dir = library_dir or os.environ.get("HITE_LIBRARY_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "library")
     lib = os.path.join(library_dir, _PROTEIN_LIB[TE_type]) if library_dir else None
     can_search = shutil.which("blastx") is not None and lib is not None and os.path.exists(lib)
     if not can_search:
