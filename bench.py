@@ -107,6 +107,8 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
                     help="default: strong when --gpus > 1 (BASELINE config 4: ONE 1 Gbp batch sharded over the GPUs; the line then carries the "
                          "weak form -- every rank the whole batch -- as the side block `weak`), weak otherwise")
+    ap.add_argument("--genomes", type=int, default=1,
+                    help="config C5 on ONE process: this many population genomes one after another on the GPU, then the merge of all their libraries (8 = the configured size)")
     ap.add_argument("--share-of", type=int, default=0,
                     help="one process: judge only rank 0's strong-scaling share of this many ranks (config C4share: 8)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg")
@@ -965,65 +967,79 @@ def c5_mode(args):
         mbp = args.genome_mbp
     n_tir = args.tir_families if args.tir_families is not None else int(tir_d * mbp)
     n_ltr = args.ltr_families if args.ltr_families is not None else int(ltr_d * mbp)
-    w = synth.make_workload(genome_bp=mbp * 1_000_000, n_tir=n_tir, n_ltr=n_ltr, cands_per_family=args.cands_per_family,
-                            seed=args.seed + 1009 * (rank + 1), device=dev, family_seed=args.seed, family_keep=0.7)
-    n_cand = len(w["cand_off"]) - 1
-    nbytes = int(w["cand_off"][-1])
+    # --genomes G on ONE process: the G population genomes one after another on this GPU (config C5 at its configured size without a
+    # node: every genome the whole fine stage, then the real merge of G libraries); with several ranks: one genome per rank
+    n_seq_genomes = max(1, args.genomes) if world == 1 else 1
     ctx = hite_amd.Context(local_rank)
     stream = torch.cuda.Stream(device=dev)
     sp = stream.cuda_stream
-    ctx.genome_pack_dev(w["genome"].data_ptr(), w["contig_off"], sp)
-    ctx.copy_index_build(sp)
-    torch.cuda.synchronize()
-    d_cand = torch.from_numpy(np.concatenate([w["cands"], np.zeros(64, np.uint8)])).to(dev)
-    d_off = torch.from_numpy(np.ascontiguousarray(w["cand_off"])).to(dev)
-    d_calls = torch.zeros(max(1, n_cand) * 32, dtype=torch.uint8, device=dev)
-    cap = nbytes + 200 * n_cand + 4096
-    d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
+    elapsed, total_cands, per_genome = 0.0, 0, []
+    seqs_all, ranks_all = [], []
+    for gi in range(n_seq_genomes):
+        w = synth.make_workload(genome_bp=mbp * 1_000_000, n_tir=n_tir, n_ltr=n_ltr, cands_per_family=args.cands_per_family,
+                                seed=args.seed + 1009 * (rank + gi + 1), device=dev, family_seed=args.seed, family_keep=0.7)
+        n_cand = len(w["cand_off"]) - 1
+        nbytes = int(w["cand_off"][-1])
+        ctx.release_copy_index()
+        ctx.genome_pack_dev(w["genome"].data_ptr(), w["contig_off"], sp)
+        ctx.copy_index_build(sp)
+        torch.cuda.synchronize()
+        d_cand = torch.from_numpy(np.concatenate([w["cands"], np.zeros(64, np.uint8)])).to(dev)
+        d_off = torch.from_numpy(np.ascontiguousarray(w["cand_off"])).to(dev)
+        d_calls = torch.zeros(max(1, n_cand) * 32, dtype=torch.uint8, device=dev)
+        cap = nbytes + 200 * n_cand + 4096
+        d_cons = torch.zeros(cap + 64, dtype=torch.uint8, device=dev)
 
-    def library():
-        calls = d_calls.cpu().numpy().view(CALL_DTYPE)[:n_cand]
-        pool = d_cons.cpu().numpy()
-        return [pool[c["cons_off"]:c["cons_off"] + c["cons_len"]].tobytes() for c in calls if c["is_te"]]
+        def library():
+            calls = d_calls.cpu().numpy().view(CALL_DTYPE)[:n_cand]
+            pool = d_cons.cpu().numpy()
+            return [pool[c["cons_off"]:c["cons_off"] + c["cons_len"]].tobytes() for c in calls if c["is_te"]]
 
-    state = {"found": None, "n_copies": 0}
+        state = {"found": None, "n_copies": 0}
 
-    def step(gather):
-        nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n_cand, d_cand.data_ptr(), d_off.data_ptr(), nbytes, sp)
-        p_cl = ctx.copy_clips_dev()       # (records in the reference's coordinates: the rows are padded by the clipped candidate bases)
-        state["found"], state["n_copies"] = (nc, p_cf, p_ct, p_s1, p_e1, p_mn, p_cl), nc
-        ctx.flank_region_align_dev("tir", 1, n_cand, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
-                                   d_calls.data_ptr(), d_cons.data_ptr(), cap, sp, d_clip=p_cl)
-        stream.synchronize()
-        if not gather:
-            return None
-        mine = library()
+        def step(gather):
+            nc, p_cf, p_ct, p_s1, p_e1, p_mn, _an = ctx.find_copies_dev(n_cand, d_cand.data_ptr(), d_off.data_ptr(), nbytes, sp)
+            p_cl = ctx.copy_clips_dev()       # (records in the reference's coordinates: the rows are padded by the clipped candidate bases)
+            state["found"], state["n_copies"] = (nc, p_cf, p_ct, p_s1, p_e1, p_mn, p_cl), nc
+            ctx.flank_region_align_dev("tir", 1, n_cand, d_cand.data_ptr(), d_off.data_ptr(), p_cf, nc, p_ct, p_s1, p_e1, p_mn, 50,
+                                       d_calls.data_ptr(), d_cons.data_ptr(), cap, sp, d_clip=p_cl)
+            stream.synchronize()
+            if not gather:
+                return None
+            mine = library()
+            if world > 1:
+                return hd.allgather_library(mine, device=dev)
+            return mine, np.zeros(len(mine), dtype=np.int64)
+
+        for _ in range(2 + args.warmup):
+            step(False)
+        torch.cuda.synchronize()
         if world > 1:
-            return hd.allgather_library(mine, device=dev)
-        return mine, np.zeros(len(mine), dtype=np.int64)
-
-    for _ in range(2 + args.warmup):
-        step(False)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t1 = time.perf_counter()
-    lib = None
-    for _ in range(args.steps):
-        lib = step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t1
+            dist.barrier()
+        t1 = time.perf_counter()
+        lib = None
+        for _ in range(args.steps):
+            lib = step(True)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        e_g = time.perf_counter() - t1
+        elapsed += e_g
+        total_cands += n_cand
+        per_genome.append({"genome": gi, "candidates": n_cand, "ms_per_step": round(1000.0 * e_g / max(1, args.steps), 3), "library_sequences": len(lib[0])})
+        seqs_all += list(lib[0])
+        ranks_all += [int(r) + gi for r in lib[1]]
+        if gi + 1 < n_seq_genomes:       # (the last genome's workload stays: the CPU leg and the spot checks run on it)
+            del w, d_cand, d_off, d_calls, d_cons
+            torch.cuda.empty_cache()
+    lib = (seqs_all, np.asarray(ranks_all, dtype=np.int64))
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tn = torch.tensor([n_cand], dtype=torch.int64, device=dev)
+        tn = torch.tensor([total_cands], dtype=torch.int64, device=dev)
         dist.all_reduce(tn)
         total_cands = int(tn.item())
-    else:
-        total_cands = n_cand
     if rank == 0:
         seqs, ranks = lib
         tmp = tempfile.mkdtemp(prefix="hite_c5_")
@@ -1050,7 +1066,8 @@ def c5_mode(args):
         if world == 1 and not args.no_cpu_baseline:
             try:
                 cpu = cpu_baseline(wv, args.cpu_seconds, args.cpu_threads, True)
-                cpu["merge"] = c5_merge_cpu(merged, tmp, util)
+                if n_seq_genomes == 1:       # (the twins' all-vs-all of the library is super-linear: 39 s for one genome's library on one core)
+                    cpu["merge"] = c5_merge_cpu(merged, tmp, util)
             except Exception as e:   # the GPU line must not depend on the CPU leg
                 cpu = {"value": None, "unit": "candidates/s", "cores": args.cpu_threads, "kind": "port", "sample": "failed: %s: %s" % (type(e).__name__, e)}
         if args.verify > 0:
@@ -1069,13 +1086,16 @@ def c5_mode(args):
         _sh.rmtree(tmp, ignore_errors=True)
         ms = 1000.0 * elapsed / max(1, args.steps)
         print(json.dumps({
-            "metric": "candidate TE boundaries/sec, %d Mbp population genomes, one genome per GPU (config C5), + merged non-redundant TE library" % mbp,
+            "metric": "candidate TE boundaries/sec, %d Mbp population genomes, %s (config C5), + merged non-redundant TE library" %
+                      (mbp, "one genome per GPU" if n_seq_genomes == 1 else "%d genomes one after another on one GPU" % n_seq_genomes),
             "value": round(total_cands * args.steps / elapsed, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C5: %d x %d Mbp genomes (one per GPU), %d TIR + %d LTR families drawn from a shared pool (70 %% per genome), "
-                                   "%d candidates/GPU judged as TIR; step = copy finding + fine stage + all-gather of the per-genome libraries"
-                                   % (world, mbp, n_tir, n_ltr, n_cand),
+            "config": {"workload": "C5: %d x %d Mbp genomes (%s), %d TIR + %d LTR families drawn from a shared pool (70 %% per genome), "
+                                   "%d candidates in all judged as TIR; step = copy finding + fine stage + all-gather of the per-genome libraries"
+                                   % (world * n_seq_genomes, mbp, "one per GPU" if n_seq_genomes == 1 else "one after another on this GPU: ms_per_step is the SUM over the genomes",
+                                      n_tir, n_ltr, total_cands),
+                       "genomes": world * n_seq_genomes, "per_genome": per_genome,
                        "library_sequences_in": len(seqs), "library_sequences_out": n_out, "library_sequences_final": n_final,
                        "library_clusters": len(stages.get("clusters", [])), "library_hits": stages.get("hits"), "merge_seconds": round(merge_s, 2),
                        "merge": "deredundant_for_LTR_v5 on rank 0 (library-vs-library seeding, chaining, clustering, star alignments, consensus)",

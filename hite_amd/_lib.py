@@ -697,8 +697,8 @@ class Context:
         """the seeding calls of this context compute rank's share of `world` (hite_seed_shard); world <= 1: everything"""
         self._check(self.lib.hite_seed_shard(self.h, int(rank), int(world)), "hite_seed_shard")
 
-    def seed_allvsall(self, seg_len=1_000_000, max_anchors=2_000_000_000, cap=None):
-        """all-vs-all seeding of the packed genome -> dict(qseg, sseg, qs, qe, ss, se, stats): the HSP table fmea_chain takes"""
+    def _seed_allvsall_once(self, seg_len, max_anchors, cap):
+        """one hite_seed_allvsall call -> (table or None, anchors): None when the call's anchors exceed what one call sorts"""
         if getattr(self, "_copy_state", None) is None:
             self._copy_state = C.c_void_p(None)
         stats = (C.c_int64 * 4)()
@@ -713,11 +713,49 @@ class Context:
             if rc == -4 and n.value > cap:   # HITE_ECAP with the needed size known: retry once with room
                 cap = n.value + 16
                 continue
+            if rc == -4 and (int(stats[1]) > max_anchors or int(stats[1]) >= 0xffffffff):
+                return None, int(stats[1])
             self._check(rc, "hite_seed_allvsall")
             break
         k = n.value
         return {"qseg": qseg[:k].copy(), "sseg": sseg[:k].copy(), "qs": qs[:k].copy(), "qe": qe[:k].copy(), "ss": ss[:k].copy(),
-                "se": se[:k].copy(), "stats": tuple(int(x) for x in stats)}
+                "se": se[:k].copy(), "stats": tuple(int(x) for x in stats)}, int(stats[1])
+
+    def seed_allvsall(self, seg_len=1_000_000, max_anchors=2_000_000_000, cap=None):
+        """all-vs-all seeding of the packed genome -> dict(qseg, sseg, qs, qe, ss, se, stats): the HSP table fmea_chain takes.
+        A search with more anchors than one call sorts (the merged library of eight population genomes: dozens of near-identical
+        sequences per family, 5 x 10^9 anchors) runs in SHARES, one after the other -- the (strand, diagonal) ranges of hite_seed_shard,
+        whose union, put in share order and sorted stably by (query segment, subject segment), is the whole table record for record
+        (what hite_amd.dist does across ranks)."""
+        tab, anchors = self._seed_allvsall_once(seg_len, max_anchors, cap)
+        if tab is not None:
+            return tab
+        world = 2
+        while world * max_anchors < 2 * anchors:
+            world *= 2
+        while True:
+            parts = []
+            try:
+                for r in range(world):
+                    self.seed_shard(r, world)
+                    t, _a = self._seed_allvsall_once(seg_len, max_anchors, cap)
+                    if t is None:
+                        break
+                    parts.append(t)
+            finally:
+                self.seed_shard(0, 0)
+            if len(parts) == world:
+                break
+            world *= 2
+            if world > 256:
+                raise HiteError("hite_seed_allvsall: %d anchors do not fit %d shares" % (anchors, world // 2))
+        cat = {k: np.concatenate([t[k] for t in parts]) for k in ("qseg", "sseg", "qs", "qe", "ss", "se")}
+        order = np.lexsort((cat["sseg"], cat["qseg"]))          # (stable: equal keys stay in share order)
+        out = {k: v[order] for k, v in cat.items()}
+        st = np.asarray([t["stats"] for t in parts], dtype=np.int64)
+        out["stats"] = (int(st[0, 0]), int(st[:, 1].sum()), int(st[:, 2].sum()), int(st[:, 3].sum()))
+        out["shares"] = world
+        return out
 
     def coarse_stage_dev(self, seg_len, seg_chrom, seg_off, skip_gap, max_len, max_anchors=8_000_000_000):
         """all-vs-all seeding + FMEA with the HSP table kept on the device -> ((chrom ids, starts, ends), seeding stats)"""

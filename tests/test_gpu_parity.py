@@ -1801,6 +1801,13 @@ def test_seed_shard_partitions_the_hsp_table(ctx):
     oc, os_, oe = hd.coarse_stage_sharded(ctx, 50_000, 2000, 30000, base_threshold=100_000)
     tc, ts, te = hd.coarse_stage_sharded(tw, 50_000, 2000, 30000, base_threshold=100_000)
     assert (oc.tolist(), os_.tolist(), oe.tolist()) == (tc.tolist(), ts.tolist(), te.tolist()) and len(oc) >= 20
+    # a search whose anchors exceed what one call sorts (config C5's merge of eight libraries: 5 x 10^9) runs in shares by itself
+    # (Context.seed_allvsall): the same table, record for record
+    anchors = whole["stats"][1]
+    auto = ctx.seed_allvsall(seg_len=50_000, max_anchors=anchors // 5)
+    assert auto.get("shares", 1) >= 4 and auto["stats"][1] == anchors
+    for k in keys:
+        assert np.array_equal(auto[k], whole[k]), k
 
 
 def test_coarse_stage_sharded_over_rccl_world1(ctx):

@@ -380,6 +380,18 @@ def test_c5_two_population_genomes_merge_into_one_library(tmp_path):
            is replaced by its CPU twin (tests/oracle_ctx.py), and on a sub-library (the members of 150 random clusters + 100
            unclustered sequences) the two runs write byte-identical .tmp.cons and .cons files;
       (ii) the result is non-redundant: a planted family that reached the merged library comes out as ONE record."""
+    _c5_merge(tmp_path, 2, whole_library_twin=True, min_once=0.80)
+
+
+def test_c5_eight_population_genomes_merge_into_one_library(tmp_path):
+    """config C5 at its configured SIZE: eight 300 Mbp genomes one after another on the one GPU, then the real merge of eight
+    libraries (~57 000 sequences: deredundant_for_LTR_v5 takes its blocked all-vs-all path, Util.py:12202-12337).  Parity on a
+    sub-library (members of 150 random clusters of the whole-library run + 100 unclustered sequences: the twin-driven host code
+    writes the same files), and the whole library comes out non-redundant."""
+    _c5_merge(tmp_path, 8, whole_library_twin=False, min_once=0.90)       # (measured: 1 390 of 1 496 = 0.929)
+
+
+def _c5_merge(tmp_path, n_genomes, whole_library_twin, min_once):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from hite_amd import util
     from oracle_ctx import OracleCtx
@@ -387,7 +399,7 @@ def test_c5_two_population_genomes_merge_into_one_library(tmp_path):
     seed = 20250927 + 5
     names, seqs, fam_of = [], {}, {}
     ctx = None
-    for g in range(2):
+    for g in range(n_genomes):
         R = run_fine(300, 750, 750, seed + 1009 * (g + 1), family_seed=seed, family_keep=0.7)
         try:
             calls, cons, w = R["calls"], R["cons"], R["w"]
@@ -399,12 +411,13 @@ def test_c5_two_population_genomes_merge_into_one_library(tmp_path):
                 seqs[nm] = cons[r["cons_off"]:r["cons_off"] + r["cons_len"]].tobytes().decode()
                 fam_of[nm] = int(w["family"][c])
         finally:
-            if g == 0:
+            if g + 1 < n_genomes:
                 R["ctx"].close()
             else:
                 ctx = R["ctx"]
+            del R
     try:
-        assert len(names) > 8_000
+        assert len(names) > 4_000 * n_genomes
         merged = str(tmp_path / "merged.fa")
         util.store_fasta({n: seqs[n] for n in names}, merged)
         st_gpu, st_cpu = {}, {}
@@ -421,11 +434,12 @@ def test_c5_two_population_genomes_merge_into_one_library(tmp_path):
             def star_msa(self, *a, **k):
                 raise StopAfterClusters()
 
-        try:
-            util.deredundant_for_LTR_v5(twin_in, str(tmp_path), 1, "terminal", 0.95, 0, ctx=ClustersOnly(), stages=st_cpu)
-        except StopAfterClusters:
-            pass
-        assert st_cpu["hits"] == st_gpu["hits"] and st_cpu["clusters"] == st_gpu["clusters"]
+        if whole_library_twin:
+            try:
+                util.deredundant_for_LTR_v5(twin_in, str(tmp_path), 1, "terminal", 0.95, 0, ctx=ClustersOnly(), stages=st_cpu)
+            except StopAfterClusters:
+                pass
+            assert st_cpu["hits"] == st_gpu["hits"] and st_cpu["clusters"] == st_gpu["clusters"]
         clusters = st_gpu["clusters"]
         rng = np.random.default_rng(11)
         pick = [clusters[i] for i in rng.permutation(len(clusters))[:150]]
@@ -450,12 +464,12 @@ def test_c5_two_population_genomes_merge_into_one_library(tmp_path):
         once = sum(1 for f in fams_in if per_fam.get(f, 0) == 1)
         lost = sum(1 for f in fams_in if per_fam.get(f, 0) == 0)
         more = sorted((per_fam[f] for f in fams_in if per_fam.get(f, 0) > 1), reverse=True)
-        print("C5 merge: %d sequences of 2 genomes (%d families) -> %d clusters -> %d records; families with exactly one record %d, "
-              "with none %d, with more %d (largest %s); %d hits" % (len(names), len(fams_in), len(clusters), len(final_names), once, lost,
-                                                                     len(more), more[:5], st_gpu["hits"]))
+        print("C5 merge: %d sequences of %d genomes (%d families) -> %d clusters -> %d records; families with exactly one record %d (%.3f), "
+              "with none %d, with more %d (largest %s); %d hits" % (len(names), n_genomes, len(fams_in), len(clusters), len(final_names), once,
+                                                                     once / max(1, len(fams_in)), lost, len(more), more[:5], st_gpu["hits"]))
         assert os.path.exists(out) and len(final_names) < 0.3 * len(names)
         assert lost == 0
-        assert once >= 0.80 * len(fams_in)
+        assert once >= min_once * len(fams_in)
     finally:
         if ctx is not None:
             ctx.close()
