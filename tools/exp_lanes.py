@@ -17,6 +17,17 @@ torch.cuda.set_device(0)
 G = mbp * 1_000_000
 seed = 20250927 + 3
 w = synth.make_workload(genome_bp=G, n_tir=int(2.5 * mbp), n_ltr=int(2.5 * mbp), cands_per_family=10, seed=seed, device=dev, cand_seed=seed + 7919)
+share_of = int(os.environ.get("SHARE_OF", 0))        # > 1: the batch is rank 0's strong-scaling share of this many ranks (bench.py --config C4share)
+if share_of > 1:
+    ids0, _ = hd.shard_candidates_balanced(w["cand_off"], w["copy_first"], 0, share_of)
+    sub = {}
+    sub["cands"], sub["cand_off"] = hd.gather_csr(w["cands"], w["cand_off"], ids0)
+    cf64 = np.asarray(w["copy_first"], dtype=np.int64)
+    for k_ in ("contig", "start1", "end1", "minus"):
+        sub[k_], new_cf = hd.gather_csr(w[k_], cf64, ids0)
+    sub["copy_first"] = new_cf.astype(np.int32)
+    for k_, v_ in sub.items():
+        w[k_] = v_
 n_all = len(w["cand_off"]) - 1
 print("candidates", n_all, flush=True)
 
