@@ -28,7 +28,15 @@
 #define CS 12           // bytes of column statistics per column: cnt[6], first[6]
 #define SCR_PER_COL 32  // scratch bytes per column per block slot
 #define FNM_LIST 320    // 64 flagged ends x (2 k + 1 = 5) starts
-#define TILE_COLS 160   // widest column span staged in LDS for the window scans (wider spans read the alignment directly)
+#define TILE_COLS 160   // widest column span staged in LDS for the window scans (wider spans read the alignment directly): the workgroup form
+// the wavefront form: a workgroup (= one wavefront) holds 3.7 KB + its tile, and 16 of them fit a CU's 160 KB only when the tile has
+// <= 6.5 KB.  Measured in round 6 (-DJWAV_TILE_COLS, profiles/r06_judge_split.txt): 112 / 128 / 160 columns (9.4 / 9.9 / 11.4 KB per
+// wavefront; the anchor text + match records of <= 1784 / 2040 / 2544 columns fit the same bytes) give 12.1 / 11.8 / 11.9 ms of judges
+// per C3 step: the fourth wavefront per SIMD buys nothing, 160 stays
+#ifndef JWAV_TILE_COLS
+#define JWAV_TILE_COLS 160
+#endif
+#define JWAV_ANCHOR_COLS ((JWAV_TILE_COLS * 6 * 2 * 4 - 16) / 3 / 8 * 8)
 
 #ifdef JUDGE_CLOCKS
 // development aid (-DJUDGE_CLOCKS): wall-clock ticks per phase, summed over blocks by thread 0
@@ -60,6 +68,7 @@ struct JudgeParams {
     const int32_t *list;     // alignments this kernel judges
     const unsigned int *n_list;
     JudgeFuse fuse;          // LDS kernels: win != NULL -> the alignment is built from these, not copied from msa
+    int32_t *anchors;        // phase-split kernels (JT_PHASE 1 writes, 2 reads): start / end anchor column per alignment
 };
 typedef const uint8_t *jt_gptr;
 typedef const __attribute__((address_space(3))) uint8_t *jt_lptr_c;
@@ -70,6 +79,7 @@ typedef __attribute__((address_space(3))) jt_u32x4 *jt_lptr16;
 // ---- the team code, four times: {workgroup, wavefront} x {alignment in HBM, alignment built in LDS} --------------------------
 #define JW (JB / 64)
 #define JT_W32 4
+#define JT_TILE_COLS TILE_COLS
 #define ANCHOR_LDS_COLS 5104   // ungapped row (<= this many bytes) + 2 bytes of match record per text start fit the 15 KB mask area
 #define JT_KERNEL judge_kernel
 #define JT_MSA_PTR jt_gptr
@@ -79,12 +89,43 @@ typedef __attribute__((address_space(3))) jt_u32x4 *jt_lptr16;
 #define JBLK_WAVES 5
 #endif
 #define JT_WAVES_MIN JBLK_WAVES
+#define JT_PHASE 0
 namespace jblk {
+#include "hite_judge_team.inc"
+}
+#undef JT_KERNEL
+#undef JT_WAVES_MIN
+#undef JT_PHASE
+// the same judge in two kernels per class (round 6, HITE_JUDGE_SPLIT; off by default, see hite_judge_dev): the anchors (ungapped
+// rows + two fuzzy searches: 27 % of the judges' time, little state) and everything after them.  One body keeps every phase's
+// state live and is compiled to spills at the occupancy asked for; the anchor half fits its registers (64 / 86, no scratch in the
+// wavefront form), the rest keeps 176 / 64 bytes of scratch.
+#ifndef JBLK_A_WAVES
+#define JBLK_A_WAVES 8
+#endif
+#ifndef JBLK_B_WAVES
+#define JBLK_B_WAVES 5
+#endif
+#define JT_KERNEL judge_anchor_kernel
+#define JT_WAVES_MIN JBLK_A_WAVES
+#define JT_PHASE 1
+namespace jblkA {
+#include "hite_judge_team.inc"
+}
+#undef JT_KERNEL
+#undef JT_WAVES_MIN
+#undef JT_PHASE
+#define JT_KERNEL judge_rest_kernel
+#define JT_WAVES_MIN JBLK_B_WAVES
+#define JT_PHASE 2
+namespace jblkB {
 #include "hite_judge_team.inc"
 }
 #undef JT_KERNEL
 #undef JT_MSA_PTR
 #undef JT_WAVES_MIN
+#undef JT_PHASE
+#define JT_PHASE 0
 #define JT_KERNEL judge_lds_kernel
 #define JT_MSA_PTR jt_lptr_c
 #define JT_LDS_PTR jt_lptr
@@ -108,7 +149,9 @@ namespace jblds {
 #define JB 64
 #define JW 1
 #define JT_W32 2
-#define ANCHOR_LDS_COLS 2544   // 3 x 2544 + 16 <= 7680 bytes of mask tile
+#undef JT_TILE_COLS
+#define JT_TILE_COLS JWAV_TILE_COLS
+#define ANCHOR_LDS_COLS JWAV_ANCHOR_COLS   // 3 x columns + 16 <= the bytes of the mask tile
 #define JT_KERNEL judge_wave_kernel
 #define JT_MSA_PTR jt_gptr
 #ifndef JWAV_WAVES
@@ -119,8 +162,34 @@ namespace jwav {
 #include "hite_judge_team.inc"
 }
 #undef JT_KERNEL
+#undef JT_WAVES_MIN
+#undef JT_PHASE
+#ifndef JWAV_A_WAVES
+#define JWAV_A_WAVES 4
+#endif
+#ifndef JWAV_B_WAVES
+#define JWAV_B_WAVES 4
+#endif
+#define JT_KERNEL judge_wave_anchor_kernel
+#define JT_WAVES_MIN JWAV_A_WAVES
+#define JT_PHASE 1
+namespace jwavA {
+#include "hite_judge_team.inc"
+}
+#undef JT_KERNEL
+#undef JT_WAVES_MIN
+#undef JT_PHASE
+#define JT_KERNEL judge_wave_rest_kernel
+#define JT_WAVES_MIN JWAV_B_WAVES
+#define JT_PHASE 2
+namespace jwavB {
+#include "hite_judge_team.inc"
+}
+#undef JT_KERNEL
 #undef JT_MSA_PTR
 #undef JT_WAVES_MIN
+#undef JT_PHASE
+#define JT_PHASE 0
 #define JT_KERNEL judge_wave_lds_kernel
 #define JT_MSA_PTR jt_lptr_c
 #define JT_LDS_MSA 1
@@ -131,6 +200,7 @@ namespace jwav {
 namespace jwlds {
 #include "hite_judge_team.inc"
 }
+#undef JT_PHASE
 #undef JB
 #undef JW
 #undef JT_W32
@@ -476,8 +546,8 @@ static int env_int(const char *name, int dflt) {
 static JudgeLimits judge_limits(int n) {
     JudgeLimits L;
     // HITE_JUDGE_WAVE_COLS = 0 sends every alignment to the workgroup kernels; the wave kernels' LDS holds the anchor text of
-    // <= 2544 columns, wider alignments would search their anchors in global scratch
-    L.wcols = env_int("HITE_JUDGE_WAVE_COLS", 2544); L.wrows = env_int("HITE_JUDGE_WAVE_ROWS", 64);
+    // <= JWAV_ANCHOR_COLS (2040) columns, wider alignments would search their anchors in global scratch
+    L.wcols = env_int("HITE_JUDGE_WAVE_COLS", JWAV_ANCHOR_COLS); L.wrows = env_int("HITE_JUDGE_WAVE_ROWS", 64);
     if (L.wrows > 64) L.wrows = 64;
     if (L.wcols < 0 || L.wrows <= 0) L.wcols = 0;
     // one wavefront per alignment pays off when the batch keeps the machine busy for many rounds (throughput: four times the
@@ -557,13 +627,16 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
     for (int k = 0; k < JUDGE_NCLS; k++) off[k + 1] = off[k] + (size_t)grid[k] * slot[k];
     const size_t off_l = off[JUDGE_NCLS], cls_bytes = ((size_t)n + 255) & ~(size_t)255;
     void *scr = nullptr;
-    int rc = hite_scratch_reserve(ctx, off_l + (size_t)JUDGE_NCLS * n * 4 + cls_bytes + 4096, &scr);
+    const size_t anch_bytes = ((size_t)n * 8 + 255) & ~(size_t)255;
+    int rc = hite_scratch_reserve(ctx, off_l + (size_t)JUDGE_NCLS * n * 4 + cls_bytes + anch_bytes + 4096, &scr);
     if (rc) return rc;
     int32_t *lists = (int32_t *)((uint8_t *)scr + off_l);
     uint8_t *cls_own = (uint8_t *)(lists + (size_t)JUDGE_NCLS * n);
-    unsigned int *counters = (unsigned int *)(cls_own + cls_bytes);   // queue heads [0 .. JUDGE_NCLS), list lengths [JUDGE_NCLS .. 2 JUDGE_NCLS), then the class histogram
+    int32_t *anchors = (int32_t *)(cls_own + cls_bytes);
+    unsigned int *counters = (unsigned int *)((uint8_t *)anchors + anch_bytes);   // queue heads [0 .. JUDGE_NCLS), list lengths [JUDGE_NCLS .. 2 JUDGE_NCLS), the class histogram, then the queue heads of the two anchor kernels
     unsigned int *hist = counters + 2 * JUDGE_NCLS;
-    HITE_CHECK(ctx, hipMemsetAsync(counters, 0, (2 * JUDGE_NCLS + JSPLIT_SLOTS) * 4, st));
+    unsigned int *heads_a = hist + JSPLIT_SLOTS;
+    HITE_CHECK(ctx, hipMemsetAsync(counters, 0, (2 * JUDGE_NCLS + JSPLIT_SLOTS + 2) * 4, st));
     const uint8_t *cls = ctx->d_judge_cls;
     if (!cls) {
         hipLaunchKernelGGL(judge_classify_kernel, dim3((n + 255) / 256), dim3(256), 0, st, n, d_rows, d_cols, L, cls_own);
@@ -580,7 +653,14 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
         p.scratch = (uint8_t *)scr + off[k]; p.slot_bytes = slot[k]; p.maxC16 = mc16[k];
         p.counter = counters + k; p.list = lists + (size_t)k * n; p.n_list = counters + JUDGE_NCLS + k;
         p.fuse = ctx->judge_fuse;
+        p.anchors = anchors;
     }
+    // HITE_JUDGE_SPLIT (bit 0: the workgroup class, bit 1: the wavefront class): the class runs as an anchor kernel + the rest
+    // (same work list, a queue head each).  OFF by default: measured on C3 (round 6, profiles/r06_judge_split.txt) the judges
+    // take 11.84 ms per step in one kernel per class and 11.79 in two -- the anchor kernel compiles to 64 / 86 registers
+    // without a spill, the rest keeps 176 / 64 bytes of scratch, and neither the registers nor the wavefronts per SIMD were
+    // what the kernels wait for (their wavefronts issue a vector instruction in 8-16 % of their cycles)
+    const int split = env_int("HITE_JUDGE_SPLIT", 0);
     // more than 64 KB of LDS per workgroup needs the attribute: once per DEVICE (a second context on another GPU of the process
     // launches the same functions there), and only for a class that has work -- the default path (LDS classes off) asks for nothing
     static unsigned long long attr_done[2] = {0ull, 0ull};      // bit = device id (< 64)
@@ -612,10 +692,22 @@ extern "C" int hite_judge_dev(hite_ctx *ctx, int32_t te_type, int32_t plant, int
         HITE_CHECK(ctx, hipEventRecord(ev_fork, st));
         for (int i = 0; i < HITE_AUX_STREAMS; i++) if (grid[i + 1] > 0) HITE_CHECK(ctx, hipStreamWaitEvent(aux[i], ev_fork, 0));
     }
-    hipLaunchKernelGGL(jblk::judge_kernel, dim3(grid[JUDGE_CLS_BLOCK]), dim3(256), 0, st, P[JUDGE_CLS_BLOCK]);
+    if (split & 1) {
+        JudgeParams pa = P[JUDGE_CLS_BLOCK];
+        pa.counter = heads_a;
+        hipLaunchKernelGGL(jblkA::judge_anchor_kernel, dim3(grid[JUDGE_CLS_BLOCK]), dim3(256), 0, st, pa);
+        hipLaunchKernelGGL(jblkB::judge_rest_kernel, dim3(grid[JUDGE_CLS_BLOCK]), dim3(256), 0, st, P[JUDGE_CLS_BLOCK]);
+    } else
+        hipLaunchKernelGGL(jblk::judge_kernel, dim3(grid[JUDGE_CLS_BLOCK]), dim3(256), 0, st, P[JUDGE_CLS_BLOCK]);
     for (int k = JUDGE_NCLS - 1; k >= 1; k--) {
         if (grid[k] <= 0) continue;
-        if (k == JUDGE_CLS_WAVE) hipLaunchKernelGGL(jwav::judge_wave_kernel, dim3(grid[k]), dim3(64), 0, aux[k - 1], P[k]);
+        if (k == JUDGE_CLS_WAVE && (split & 2)) {
+            JudgeParams pa = P[k];
+            pa.counter = heads_a + 1;
+            hipLaunchKernelGGL(jwavA::judge_wave_anchor_kernel, dim3(grid[k]), dim3(64), 0, aux[k - 1], pa);
+            hipLaunchKernelGGL(jwavB::judge_wave_rest_kernel, dim3(grid[k]), dim3(64), 0, aux[k - 1], P[k]);
+        }
+        else if (k == JUDGE_CLS_WAVE) hipLaunchKernelGGL(jwav::judge_wave_kernel, dim3(grid[k]), dim3(64), 0, aux[k - 1], P[k]);
         else if (wave[k]) hipLaunchKernelGGL(jwlds::judge_wave_lds_kernel, dim3(grid[k]), dim3(64), (size_t)lds[k], aux[k - 1], P[k]);
         else hipLaunchKernelGGL(jblds::judge_lds_kernel, dim3(grid[k]), dim3(256), (size_t)lds[k], aux[k - 1], P[k]);
     }

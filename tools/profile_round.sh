@@ -15,7 +15,7 @@ timeout 1200 python bench.py --config C5 --genomes 8 --steps 3 --warmup 1 --no-c
 timeout 600 python bench.py --config C4share > $OUT/${TAG}_bench_c4share.json 2> $OUT/${TAG}_bench_c4share.err
 if [ "${QUICK:-0}" != "1" ]; then      # (QUICK=1: the benches and the rocprofv3 passes only)
 timeout 600 python -m pytest tests/test_gpu_scale.py -q -m gpu -s -k "c2 or c3 or c5" > $OUT/${TAG}_scale_tests_raw.txt 2>&1
-grep -E "(copy finder|fine stage|coarse stage|C3:|C5 merge|cost sums|^\.*C2,)" $OUT/${TAG}_scale_tests_raw.txt | sed "s/^\.*//" > $OUT/${TAG}_scale_tests.txt
+grep -E "(copy finder|fine stage|coarse stage|C3:|C5 merge|cost sums|anchor matches|^\.*C2,)" $OUT/${TAG}_scale_tests_raw.txt | sed "s/^\.*//" > $OUT/${TAG}_scale_tests.txt
 timeout 600 python tools/copy_interval_modes.py >> $OUT/${TAG}_scale_tests.txt 2> $OUT/copy_interval_modes.err
 fi
 HITE_ALIGN_EXACT=16 timeout 600 python bench.py --no-cpu-baseline --no-coarse > $OUT/${TAG}_bench_fine_cap16.json 2> /dev/null
