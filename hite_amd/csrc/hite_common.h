@@ -62,6 +62,7 @@ struct hite_ctx {
     const int32_t *d_msa_row_map;   // per compacted row: source row (NULL: identity)
     const int32_t *d_msa_rows_eff;  // per candidate: rows that were aligned (NULL: all)
     uint32_t *d_msa_lay;             // layout words of the last sparse star alignment (hite_msa.hip)
+    int msa_long;                    // the last star alignment held windows of more than 1 536 bases (the fill's unroll)
     const int64_t *d_msa_win_off;    // per row of the last star alignment: its window, and where its back pads begin (HITE_IS_ROW_PAD;
     const int32_t *d_msa_win_len;    // layout, fill and the judge's LDS kernels read the rows through these)
     const uint32_t *d_msa_pads;      // per row: pad bytes in front | behind << 16

@@ -159,6 +159,9 @@ __global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
 //   * the first / last column of the alignment are kept regardless (the last one may be a non-prefix column of block m).
 // Per position p one layout word (MsaParams::lay): kw | keep_centre << 15 | first kept column of the block << 16.
 // ---------------------------------------------------------------------------------------------
+#ifndef LAY_ROWS
+#define LAY_ROWS 4      // rows whose ops a thread of the layout kernel has in flight
+#endif
 __device__ __forceinline__ unsigned long long lay_ld8(const uint16_t *p) { unsigned long long v; __builtin_memcpy(&v, p, 8); return v; }
 
 __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, int32_t *__restrict__ new_cols,
@@ -195,13 +198,13 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
         if (p0 <= m) {
             const uint16_t *col = ops + p0;
             int r = 1;
-            for (; r + 3 < R; r += 4) {      // four rows in flight
-                unsigned long long o4[4];
-                unsigned om[4];
+            for (; r + LAY_ROWS - 1 < R; r += LAY_ROWS) {      // LAY_ROWS rows in flight
+                unsigned long long o4[LAY_ROWS];
+                unsigned om[LAY_ROWS];
 #pragma unroll
-                for (int u = 0; u < 4; u++) { o4[u] = lay_ld8(col + (int64_t)(r + u) * rs); om[u] = col[(int64_t)(r + u) * rs - 1]; }   // (p0 == 0: the op "before position 0", row_ins)
+                for (int u = 0; u < LAY_ROWS; u++) { o4[u] = lay_ld8(col + (int64_t)(r + u) * rs); om[u] = col[(int64_t)(r + u) * rs - 1]; }   // (p0 == 0: the op "before position 0", row_ins)
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
+                for (int u = 0; u < LAY_ROWS; u++) {
                     const int wl = r + u < MSA_MAXR ? s_wl[r + u] : P.win_len[g0 + msa_src(P.row_map, g0, r + u)];
                     unsigned op = om[u];
 #pragma unroll
@@ -286,6 +289,7 @@ struct FillSparseParams {
 
 // fill of the kept columns only: item (r, p) owns the kept prefix of insertion block p, the centre column p if kept
 // and (p == m) the extra last column; every output byte is written exactly once.
+template <int NU>
 __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams Q) {
     const FillParams &P = Q.F;
     const int c = blockIdx.x;
@@ -317,7 +321,7 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
         const uint8_t *b = P.win + woff;
         const uint16_t *rop = ops + (int64_t)r * rs;
         uint8_t *row = out + (int64_t)r * C;
-        fill_sparse_row<uint8_t *, 256>(row, b, nrow, rop, lay, m, le, r == 0 /* the centre row: position p faces its own base p */, (int)threadIdx.x);
+        fill_sparse_row<uint8_t *, 256, NU>(row, b, nrow, rop, lay, m, le, r == 0 /* the centre row: position p faces its own base p */, (int)threadIdx.x);
         r = rn; woff = woff_n; nrow = nrow_n;
     }
 }
@@ -450,7 +454,7 @@ static int star_msa_launch(hite_ctx *ctx, int32_t n, const uint8_t *d_win, const
     if (total_rows > 0)
         hipLaunchKernelGGL(row_pad_scan_kernel, dim3((unsigned)((total_rows + 255) / 256)), dim3(256), 0, st, total_rows, d_win, d_win_off, d_win_len,
                            len2, pads);
-    ctx->d_msa_win_off = d_win_off; ctx->d_msa_win_len = len2; ctx->d_msa_pads = pads;
+    ctx->d_msa_win_off = d_win_off; ctx->d_msa_win_len = len2; ctx->d_msa_pads = pads; ctx->msa_long = max_win_len > 1536;
     MsaParams P;
     P.n = n; P.total_rows = total_rows; P.win = d_win; P.win_off = d_win_off; P.win_len = len2; P.row_first = d_row_first;
     P.ops_base = d_ops_base; P.ops = (uint16_t *)opsb; P.cols_out = d_cols_out; P.status = d_status;
@@ -525,7 +529,9 @@ extern "C" int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uin
     //   * this kernel with two rows per trip (twice the bytes in flight per wavefront): 3.5 + 11.7 ms.
     // Neither instructions nor latency bound it: the two launches move 19 GB (FETCH_SIZE + WRITE_SIZE as counted; 34 GB
     // with the guide's gfx950 fetch correction) in 8 ms, 2.3 - 4 TB/s; 2 B of ops per cell are most of it.
-    hipLaunchKernelGGL(star_fill_sparse_kernel, dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
+    // (round 6: eight cells in flight per thread when the launch holds long windows, four otherwise -- hite_fill.h)
+    if (ctx->msa_long) hipLaunchKernelGGL(HIP_KERNEL_NAME(star_fill_sparse_kernel<8>), dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(star_fill_sparse_kernel<4>), dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
     HITE_CHECK(ctx, hipGetLastError());
     return HITE_OK;
 }
