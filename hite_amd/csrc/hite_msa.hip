@@ -530,8 +530,14 @@ extern "C" int hite_star_msa_fill_sparse_dev(hite_ctx *ctx, int32_t n, const uin
     // Neither instructions nor latency bound it: the two launches move 19 GB (FETCH_SIZE + WRITE_SIZE as counted; 34 GB
     // with the guide's gfx950 fetch correction) in 8 ms, 2.3 - 4 TB/s; 2 B of ops per cell are most of it.
     // (round 6: eight cells in flight per thread when the launch holds long windows, four otherwise -- hite_fill.h)
-    if (ctx->msa_long) hipLaunchKernelGGL(HIP_KERNEL_NAME(star_fill_sparse_kernel<8>), dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(star_fill_sparse_kernel<4>), dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
+#ifndef FILL_U_LONG
+#define FILL_U_LONG 8
+#endif
+#ifndef FILL_U_SHORT
+#define FILL_U_SHORT 4
+#endif
+    if (ctx->msa_long) hipLaunchKernelGGL(HIP_KERNEL_NAME(star_fill_sparse_kernel<FILL_U_LONG>), dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(star_fill_sparse_kernel<FILL_U_SHORT>), dim3(n, 4), dim3(256), 0, (hipStream_t)stream, Q);
     HITE_CHECK(ctx, hipGetLastError());
     return HITE_OK;
 }
