@@ -145,11 +145,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # HITE_BENCH_BACKEND=gloo: a FUNCTIONAL run of the N > 1 path on a box with fewer GPUs than ranks (the ranks share the GPUs,
+    # the collectives move host copies): what a one-GPU box can check of the strong-scaling line before a node runs it.  Not a
+    # measurement -- the line says so in `data`.
+    backend = os.environ.get("HITE_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    cdev = dev if backend == "nccl" else torch.device("cpu")      # where the tensors of a collective live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import hite_amd
     from hite_amd import dist as hd
@@ -192,7 +201,7 @@ def main():
     n_cand = len(L["cand_off"]) - 1
     c0, c1, b0, b1, k0, k1 = 0, n_cand, 0, int(L["cand_off"][-1]), 0, len(L["contig"])
 
-    ctx = hite_amd.Context(local_rank)
+    ctx = hite_amd.Context(gpu_index)
     stream = torch.cuda.Stream(device=dev)
     sp = stream.cuda_stream
     ctx.genome_pack_dev(w["genome"].data_ptr(), w["contig_off"], sp)
@@ -246,8 +255,9 @@ def main():
         stream.synchronize()
         merged = None
         if world > 1:   # merge the boundary calls (RCCL over xGMI): ONE all-gather of the 32-byte records
-            merged = (hd.allgather_calls_balanced(d_calls[: n_cand * 32], shares, alias=True) if shares is not None
-                      else hd.allgather_calls(d_calls[: n_cand * 32], n_merge, alias=True))     # (a view of the merge buffer: read before the next step)
+            mine = d_calls[: n_cand * 32].to(cdev)
+            merged = (hd.allgather_calls_balanced(mine, shares, alias=True) if shares is not None
+                      else hd.allgather_calls(mine, n_merge, alias=True))     # (a view of the merge buffer: read before the next step)
         return st, merged
 
     # residency set-up, like the index build above: the library's grow-only arenas reach their final size in the first call
@@ -273,14 +283,14 @@ def main():
     prof = ctx.profile(on=False)
     align_stats = ctx.align_stats()
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
     calls = d_calls.cpu().numpy().view(CALL_DTYPE)[:n_cand].copy()
     n_te = int((calls["is_te"] != 0).sum())
     if world > 1:
-        tn = torch.tensor([n_te], dtype=torch.int64, device=dev)
+        tn = torch.tensor([n_te], dtype=torch.int64, device=cdev)
         dist.all_reduce(tn)
         n_te_all = int(tn.item())
         merged_te = int((merged.cpu().numpy().view(CALL_DTYPE)["is_te"] != 0).sum())
@@ -314,7 +324,7 @@ def main():
             except Exception as e:
                 ok_w, err_w = 0, "%s: %s" % (type(e).__name__, e)
         t_w = time.perf_counter() - t_w0
-        tw = torch.tensor([t_w, -float(ok_w)], dtype=torch.float64, device=dev)
+        tw = torch.tensor([t_w, -float(ok_w)], dtype=torch.float64, device=cdev)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         if float(tw[1].item()) == -1.0:
             t_w = float(tw[0].item())
@@ -463,7 +473,7 @@ def main():
             "metric": "candidate TE boundaries/sec on %s synthetic genome (fine stage: copy finding+gather+align+vote+judge)" % ("1 Gbp" if mbp == 1000 else "%d Mbp" % mbp),
             "value": round(value, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8", "data": "synthetic" if backend == "nccl" else "synthetic; FUNCTIONAL run over %s with the ranks sharing %d GPU(s): not a measurement" % (backend, torch.cuda.device_count()),
             "config": {"workload": "%s: %d Mbp synthetic genome, %d TIR + %d LTR families, %d candidates%s judged as TIR (%s)" %
                                    (args.config if args.genome_mbp is None else "custom", mbp, n_tir, n_ltr, total_cands if strong else n_cand,
                                     " sharded over %d GPUs" % world if strong else

@@ -496,3 +496,27 @@ def _c5_merge(tmp_path, n_genomes, whole_library_twin, min_once):
     finally:
         if ctx is not None:
             ctx.close()
+
+
+def test_bench_strong_scaling_line_two_ranks_functional():
+    """The N > 1 path of bench.py as the driver launches it (--gpus 2: one C2 batch sharded over the ranks by cost, the 32-byte calls
+    all-gathered and put back in candidate order, the weak form as a side block), run FUNCTIONALLY on this one-GPU box: the two ranks
+    share the GPU and the collectives move host copies over gloo (HITE_BENCH_BACKEND=gloo; RCCL refuses two ranks on one device).
+    Checks what a node will not be asked twice: the line is printed, it is the strong form, the merged calls are the per-rank calls,
+    and the re-judged sample has no mismatch."""
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    env["HITE_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "C2", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--no-coarse", "--no-modes", "--verify", "16"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["unit"] == "candidates/s" and d["value"] > 0
+    assert "not a measurement" in d["data"]
+    assert d["config"]["candidates_per_gpu"] == 2500 and d["weak"]["candidates_per_gpu"] == 5000 and d["weak"]["value"] > 0
+    assert d["verify"]["mismatches"] == 0 and d["verify"]["checked"] == 16
