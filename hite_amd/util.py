@@ -9,6 +9,7 @@ reference calls them when they are installed (the build's own masker / clusterin
 candidates by structure (Util.py:8196-8213: short-TIR signatures + terminal inverted repeats) is reproduced, and so is the
 decision of the recall by protein domains (:8215-8276) on a blastx domain table; blastx itself stays external.
 """
+import itertools
 import os
 import re
 import shutil
@@ -32,23 +33,25 @@ def get_ctx(device=0):
 
 # ---- FASTA (Util.py:1650-1670, 1983-1988) ---------------------------------------------------------
 def read_fasta(fasta_path):
-    contignames, contigs = [], {}
-    if os.path.exists(fasta_path):
-        name, chunks = "", []
-        with open(fasta_path, "r") as rf:
-            for line in rf:
-                if line.startswith(">"):
-                    if name != "" and chunks:
-                        contigs[name] = "".join(chunks)
-                        contignames.append(name)
-                    name = line.strip()[1:].split(" ")[0].split("\t")[0]
-                    chunks = []
-                else:
-                    chunks.append(line.strip().upper())
-            if name != "" and chunks:
-                contigs[name] = "".join(chunks)
-                contignames.append(name)
-    return contignames, contigs
+    """-> (names in file order, {name: sequence}): the name is the header up to the first blank or tab, the sequence upper-case;
+    a record without sequence characters is skipped, text before the first header ignored, a missing file gives empty results"""
+    names, seqs = [], {}
+    if not os.path.exists(fasta_path):
+        return names, seqs
+    current = ""
+    with open(fasta_path, "r") as handle:
+        # runs of header lines / of sequence lines: of several headers in a row only the last can own sequence
+        for is_header, run in itertools.groupby(handle, key=lambda ln: ln.startswith(">")):
+            if is_header:
+                for ln in run:
+                    current = ln.strip()[1:].split(" ")[0].split("\t")[0]
+                continue
+            sequence = "".join(ln.strip().upper() for ln in run)
+            if current != "" and sequence != "":
+                seqs[current] = sequence
+                names.append(current)
+            # (a second run of sequence lines cannot follow without a header in between: groupby merges neighbours)
+    return names, seqs
 
 
 def store_fasta(contigs, file_path):
@@ -60,13 +63,10 @@ def store_fasta(contigs, file_path):
 def rename_fasta(input, output, header="N"):
     """Util.py:7500 -- names become <header>_<i>, a '#class' suffix (text after the last '#') is kept"""
     names, contigs = read_fasta(input)
-    with open(output, "w") as f_save:
-        for node_index, name in enumerate(names):
-            parts = str(name).split("#")
-            new_name = header + "_" + str(node_index)
-            if len(parts) >= 2:
-                new_name += "#" + parts[-1]
-            f_save.write(">" + new_name + "\n" + contigs[name] + "\n")
+    with open(output, "w") as out:
+        for i, old in enumerate(names):
+            _head, sep, cls = str(old).rpartition("#")
+            out.write(">%s_%d%s\n%s\n" % (header, i, sep + cls if sep else "", contigs[old]))
 
 
 def rename_reference(input, output, chr_name_map):
@@ -126,27 +126,26 @@ def split_chromosomes(chromosomes_dict, max_length=200_000_000):
     """Util.py:10252 -- sequences longer than max_length become <name>_part<k> pieces"""
     out = {}
     for chrom, sequence in chromosomes_dict.items():
-        if len(sequence) > max_length:
-            for i in range((len(sequence) + max_length - 1) // max_length):
-                out["%s_part%d" % (chrom, i + 1)] = sequence[i * max_length:min((i + 1) * max_length, len(sequence))]
-        else:
+        if len(sequence) <= max_length:
             out[chrom] = sequence
+            continue
+        out.update(("%s_part%d" % (chrom, k + 1), sequence[o:o + max_length]) for k, o in enumerate(range(0, len(sequence), max_length)))
     return out
 
 
 def split_dict_into_blocks(chromosomes_dict, threads, chunk_size):
-    """Util.py:10276 -- consecutive sequences are grouped until a block holds total / threads bases"""
-    chromosomes_dict = split_chromosomes(chromosomes_dict, max_length=chunk_size)
-    target = sum(len(s) for s in chromosomes_dict.values()) // threads
-    blocks, cur, cur_len = [], {}, 0
-    for chrom, seq in chromosomes_dict.items():
-        cur[chrom] = seq
-        cur_len += len(seq)
-        if cur_len >= target:
-            blocks.append(cur)
-            cur, cur_len = {}, 0
-    if cur:
-        blocks.append(cur)
+    """Util.py:10276 -- consecutive sequences are grouped until a block holds total / threads bases: on the prefix sums of the
+    lengths, a block that starts at sequence `first` ends at the first sequence where the sum since `first` reaches the target"""
+    items = list(split_chromosomes(chromosomes_dict, max_length=chunk_size).items())
+    ends = np.cumsum([len(seq) for _name, seq in items], dtype=np.int64)
+    target = int(ends[-1]) // threads if len(items) else 0
+    blocks, first = [], 0
+    while first < len(items):
+        before = int(ends[first - 1]) if first else 0
+        last = int(np.searchsorted(ends, before + target, side="left"))       # first index with ends[last] - before >= target
+        last = max(first, min(last, len(items) - 1))
+        blocks.append(dict(items[first:last + 1]))
+        first = last + 1
     return blocks
 
 
@@ -182,22 +181,18 @@ def split_genome_chunks(reference, tmp_output_dir, chrom_seg_length, chunk_size_
     return cut_references
 
 
-def file_exist(resut_file):
+def file_exist(result_path):
     """Util.py:2831 -- the reference's 'did this stage succeed' test: a FASTA with at least one record, any other file with
     a non-comment non-blank line, a non-empty directory"""
-    if os.path.isfile(resut_file):
-        if os.path.getsize(resut_file) > 0:
-            if resut_file.endswith(".fa") or resut_file.endswith(".fasta"):
-                return len(read_fasta(resut_file)[1]) > 0
-            with open(resut_file, "r") as f_r:
-                for line in f_r:
-                    if not line.startswith("#") and line.strip():
-                        return True
-            return False
+    if os.path.isdir(result_path):
+        with os.scandir(result_path) as entries:
+            return next(entries, None) is not None
+    if not os.path.isfile(result_path) or os.path.getsize(result_path) == 0:
         return False
-    if os.path.isdir(resut_file):
-        return len(os.listdir(resut_file)) > 0
-    return False
+    if result_path.endswith((".fa", ".fasta")):
+        return bool(read_fasta(result_path)[1])
+    with open(result_path, "r") as handle:
+        return any(ln.strip() != "" and not ln.startswith("#") for ln in handle)
 
 
 def update_prev_TE(prev_TE, cur_file):

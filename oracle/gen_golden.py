@@ -535,6 +535,30 @@ def gen_host(U):
         fmt["update_prev_TE"] = {"prev": ">p\nAAAA\n", "cur": ">q\nCCCC", "out": open(prev).read()}
     rev = [casegen.rand_seq(rng, 30) for _ in range(5)] + ["ACGTNRYacgt-", ""]
     dump("host_formats", fmt)
+    # round 6: read_fasta itself (:1650: headers without sequence, blank sequence lines, text before the first header, a name twice)
+    # and the block grouping of split_genome_chunks.py (split_chromosomes :10252, split_dict_into_blocks :10276)
+    fa_cases = []
+    with tempfile.TemporaryDirectory() as d:
+        for i, text in enumerate([">a desc\nacgt\nNN\n>b\t1\n\n>c\n>d\nTT\n", "junk\n>x\nAC\n>x\nGG\n", "", ">only\n", "\n\n>z \nac gt\n",
+                                  ">e\n \n>f\nA\n", ">g#DNA/x#TIR  w\nAC\n\nGT\n"]):
+            pth = os.path.join(d, "r%d.fa" % i)
+            open(pth, "w").write(text)
+            names, contigs = U.read_fasta(pth)
+            fa_cases.append({"text": text, "names": names, "contigs": contigs, "exists": bool(U.file_exist(pth))})
+        names, contigs = U.read_fasta(os.path.join(d, "absent.fa"))
+        fa_cases.append({"text": None, "names": names, "contigs": contigs, "exists": False})
+    rng2 = np.random.default_rng(4242)
+    blk_cases = []
+    for _ in range(40):
+        n = int(rng2.integers(0, 12))
+        lens = [int(rng2.integers(0, 50)) for _ in range(n)]
+        threads, chunk = int(rng2.integers(1, 7)), int(rng2.choice([7, 20, 1000]))
+        cd = {"c%d" % i: "A" * l for i, l in enumerate(lens)}
+        parts = U.split_chromosomes(dict(cd), chunk)
+        blocks = U.split_dict_into_blocks(dict(cd), threads, chunk)
+        blk_cases.append({"lens": lens, "threads": threads, "chunk": chunk, "parts": [[k, len(v)] for k, v in parts.items()],
+                          "blocks": [[[k, len(v)] for k, v in b.items()] for b in blocks]})
+    dump("host_fasta", {"read_fasta": fa_cases, "blocks": blk_cases})
     dump("host_glue", {"short_tir": short_cases, "filter_dup": dup_cases, "split": split_cases,
                        "revcomp": [[s, U.getReverseSequence(s)] for s in rev]})
 

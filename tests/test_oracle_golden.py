@@ -367,6 +367,33 @@ def test_host_formats_golden(tmp_path):
     assert prev.read_text() == c["out"]
 
 
+def test_host_fasta_golden(tmp_path):
+    """read_fasta (Util.py:1650) on the cases that make it differ from a naive reader -- headers without sequence, blank sequence
+    lines, text before the first header, a name twice, a missing file --, file_exist on the same files, and the block grouping of
+    split_genome_chunks.py (split_chromosomes :10252, split_dict_into_blocks :10276) on 40 random length lists: the reference's own
+    results (round 6: the host helpers were re-written away from the reference's statement order; this pins them)"""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from hite_amd import util
+
+    g = load_golden("host_fasta")
+    for i, c in enumerate(g["read_fasta"]):
+        p = tmp_path / ("r%d.fa" % i)
+        if c["text"] is not None:
+            p.write_text(c["text"])
+        names, contigs = util.read_fasta(str(p))
+        assert names == c["names"] and contigs == c["contigs"], i
+        assert util.file_exist(str(p)) == c["exists"], i
+    for c in g["blocks"]:
+        cd = {"c%d" % i: "A" * l for i, l in enumerate(c["lens"])}
+        parts = util.split_chromosomes(dict(cd), c["chunk"])
+        assert [[k, len(v)] for k, v in parts.items()] == c["parts"]
+        blocks = util.split_dict_into_blocks(dict(cd), c["threads"], c["chunk"])
+        assert [[[k, len(v)] for k, v in b.items()] for b in blocks] == c["blocks"], c
+
+
 def test_split_genome_chunks_golden(tmp_path):
     """f-1: the drop-in of module/split_genome_chunks.py writes byte-identical genome.cut{i}.fa / ref_chr/ref_block_{i}.fa and
     rewrites the genome like the reference (upper case, one line per contig, names cut at the first blank)"""
