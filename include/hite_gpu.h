@@ -369,8 +369,11 @@ int hite_copy_clips(void *state, int64_t cap, uint32_t *clip);
  * `mafft --preservecase --quiet --thread 1` (Util.py:10416; third-party, unpinned, absent -> parity unpinned against
  * mafft itself).  Definition of the stage: every row is aligned to the centre (first row of the candidate) by the
  * optimal global alignment under the costs mismatch 1, gap 3 per base (two bases match only when they are the same
- * upper-case A, C, G or T: callers that may hold lower-case sequence upper-case it first, as hite_amd/util.py does --
- * mafft --preservecase compares case-insensitively), canonical traceback diagonal > up > left -- the textbook full-matrix
+ * A, C, G or T; a lower-case a / c / g / t of a ROW is read as its base -- mafft --preservecase compares case-insensitively --
+ * BUT a run of bytes with bit 5 set at the BEGINNING or END of a row is a run of pad bytes, see HITE_IS_ROW_PAD above: lower
+ * case at the ends of a row is RESERVED for pads and leaves the alignment as gaps.  A caller whose windows may begin or end with
+ * soft-masked lower-case sequence upper-cases them first, as hite_amd/util.py does; the centre is compared as it is, upper
+ * case), canonical traceback diagonal > up > left -- the textbook full-matrix
  * programme of oracle/hite_oracle_nw.c; insertion blocks are left-justified.  The device computes it with a banded
  * bit-parallel aligner that CERTIFIES its result (twin: oracle/hite_oracle_msa.c, byte-exact): a certified row is the
  * alignment of the definition, a row without certificate is a valid alignment whose cost bounds the optimum from above.
