@@ -93,6 +93,30 @@ def free_port():
     return p
 
 
+def rank_devices(torch, dist, rank, local_rank, world):
+    """-> (backend, gpu index of this rank, its device, the device a collective's tensors live on); starts the process group.
+    HITE_BENCH_BACKEND=gloo: a FUNCTIONAL run of the N > 1 paths on a box with fewer GPUs than ranks (the ranks share the GPUs, the
+    collectives move host copies): what a one-GPU box can check of the multi-GPU lines before a node runs them.  Not a measurement
+    -- such a line says so in `data`."""
+    backend = os.environ.get("HITE_BENCH_BACKEND", "nccl")
+    gpu_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return backend, gpu_index, dev, cdev
+
+
+def data_note(torch, backend):
+    return "synthetic" if backend == "nccl" else ("synthetic; FUNCTIONAL run over %s with the ranks sharing %d GPU(s): not a measurement" %
+                                                  (backend, torch.cuda.device_count()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -145,20 +169,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # HITE_BENCH_BACKEND=gloo: a FUNCTIONAL run of the N > 1 path on a box with fewer GPUs than ranks (the ranks share the GPUs,
-    # the collectives move host copies): what a one-GPU box can check of the strong-scaling line before a node runs it.  Not a
-    # measurement -- the line says so in `data`.
-    backend = os.environ.get("HITE_BENCH_BACKEND", "nccl")
-    gpu_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
-    torch.cuda.set_device(gpu_index)
-    dev = torch.device("cuda", gpu_index)
-    cdev = dev if backend == "nccl" else torch.device("cpu")      # where the tensors of a collective live
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+    backend, gpu_index, dev, cdev = rank_devices(torch, dist, rank, local_rank, world)
 
     import hite_amd
     from hite_amd import dist as hd
@@ -473,7 +484,7 @@ def main():
             "metric": "candidate TE boundaries/sec on %s synthetic genome (fine stage: copy finding+gather+align+vote+judge)" % ("1 Gbp" if mbp == 1000 else "%d Mbp" % mbp),
             "value": round(value, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic" if backend == "nccl" else "synthetic; FUNCTIONAL run over %s with the ranks sharing %d GPU(s): not a measurement" % (backend, torch.cuda.device_count()),
+            "dtype": "u8", "data": data_note(torch, backend),
             "config": {"workload": "%s: %d Mbp synthetic genome, %d TIR + %d LTR families, %d candidates%s judged as TIR (%s)" %
                                    (args.config if args.genome_mbp is None else "custom", mbp, n_tir, n_ltr, total_cands if strong else n_cand,
                                     " sharded over %d GPUs" % world if strong else
@@ -960,11 +971,7 @@ def c5_mode(args):
     world = int(os.environ.get("WORLD_SIZE", 1))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    backend, gpu_index, dev, cdev = rank_devices(torch, dist, rank, local_rank, world)
     import tempfile
 
     import hite_amd
@@ -980,7 +987,7 @@ def c5_mode(args):
     # --genomes G on ONE process: the G population genomes one after another on this GPU (config C5 at its configured size without a
     # node: every genome the whole fine stage, then the real merge of G libraries); with several ranks: one genome per rank
     n_seq_genomes = max(1, args.genomes) if world == 1 else 1
-    ctx = hite_amd.Context(local_rank)
+    ctx = hite_amd.Context(gpu_index)
     stream = torch.cuda.Stream(device=dev)
     sp = stream.cuda_stream
     elapsed, total_cands, per_genome = 0.0, 0, []
@@ -1018,7 +1025,7 @@ def c5_mode(args):
                 return None
             mine = library()
             if world > 1:
-                return hd.allgather_library(mine, device=dev)
+                return hd.allgather_library(mine, device=cdev)
             return mine, np.zeros(len(mine), dtype=np.int64)
 
         for _ in range(2 + args.warmup):
@@ -1044,10 +1051,10 @@ def c5_mode(args):
             torch.cuda.empty_cache()
     lib = (seqs_all, np.asarray(ranks_all, dtype=np.int64))
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-        tn = torch.tensor([total_cands], dtype=torch.int64, device=dev)
+        tn = torch.tensor([total_cands], dtype=torch.int64, device=cdev)
         dist.all_reduce(tn)
         total_cands = int(tn.item())
     if rank == 0:
@@ -1100,7 +1107,7 @@ def c5_mode(args):
                       (mbp, "one genome per GPU" if n_seq_genomes == 1 else "%d genomes one after another on one GPU" % n_seq_genomes),
             "value": round(total_cands * args.steps / elapsed, 2), "unit": "candidates/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
+            "dtype": "u8", "data": data_note(torch, backend),
             "config": {"workload": "C5: %d x %d Mbp genomes (%s), %d TIR + %d LTR families drawn from a shared pool (70 %% per genome), "
                                    "%d candidates in all judged as TIR; step = copy finding + fine stage + all-gather of the per-genome libraries"
                                    % (world * n_seq_genomes, mbp, "one per GPU" if n_seq_genomes == 1 else "one after another on this GPU: ms_per_step is the SUM over the genomes",
@@ -1174,13 +1181,9 @@ def coarse_stage(args):
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        import torch.distributed as dist
+    import torch.distributed as dist
 
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    backend, gpu_index, dev, cdev = rank_devices(torch, dist, rank, local_rank, world)
     mbp, tir_d, ltr_d = CONFIGS[args.config]
     if args.genome_mbp is not None:
         mbp = args.genome_mbp
@@ -1189,7 +1192,7 @@ def coarse_stage(args):
     n_ltr = args.ltr_families if args.ltr_families is not None else max(0, int(ltr_d * mbp))
     # replicas: every rank searches its own genome (config 5 of BASELINE.json: one genome per GPU); no collective on the data path
     w = synth.make_workload(genome_bp=G, n_tir=n_tir, n_ltr=n_ltr, cands_per_family=1, seed=args.seed + 977 * rank, device=dev)
-    ctx = hite_amd.Context(local_rank)
+    ctx = hite_amd.Context(gpu_index)
     ctx.genome_pack_dev(w["genome"].data_ptr(), w["contig_off"])
     sc, so = ctx.seed_segments(1_000_000)
 
@@ -1213,7 +1216,7 @@ def coarse_stage(args):
         dist.barrier()
     elapsed = time.perf_counter() - t1
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     if rank == 0:
@@ -1221,7 +1224,7 @@ def coarse_stage(args):
         out = {"metric": "coarse_boundary step (stage 3.1: all-vs-all seeding + FMEA) on the %s synthetic genome" % ("1 Gbp" if mbp == 1000 else "%d Mbp" % mbp),
                "value": round(world * mbp * args.steps / elapsed, 2), "unit": "Mbp/s", "n_gpus": world, "steps": args.steps,
                "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "u8", "data": "synthetic",
+               "dtype": "u8", "data": data_note(torch, backend),
                "config": {"workload": "%s genome: %d Mbp, %d TIR + %d LTR families, 1 Mbp segments, one chunk%s" %
                                       (args.config, mbp, n_tir, n_ltr, "; one genome per GPU (replicas)" if world > 1 else ""),
                           "seeds": stats[0], "anchors": stats[1], "clusters": stats[2], "hsp_records": stats[3], "repeat_intervals": n_iv},

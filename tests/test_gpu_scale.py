@@ -520,3 +520,37 @@ def test_bench_strong_scaling_line_two_ranks_functional():
     assert "not a measurement" in d["data"]
     assert d["config"]["candidates_per_gpu"] == 2500 and d["weak"]["candidates_per_gpu"] == 5000 and d["weak"]["value"] > 0
     assert d["verify"]["mismatches"] == 0 and d["verify"]["checked"] == 16
+
+
+def _bench_two_ranks(extra, timeout=900):
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    env["HITE_BENCH_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + extra
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "not a measurement" in d["data"]
+    return d
+
+
+def test_bench_c5_line_two_ranks_functional():
+    """config C5 as a node runs it -- one population genome per rank, the per-rank libraries all-gathered (padded consensus pools +
+    lengths) and merged on rank 0 -- with two ranks sharing this GPU over gloo: the line is printed, both genomes' libraries reach
+    the merge, and the re-judged sample of rank 0 has no mismatch (genomes of 30 Mbp: a functional run)"""
+    d = _bench_two_ranks(["--config", "C5", "--genome-mbp", "30", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--verify", "16"])
+    cfg = d["config"]
+    assert d["scaling"] == "weak" and cfg["genomes"] == 2 and cfg["library_sequences_in"] > 600
+    assert 0 < cfg["library_sequences_final"] < cfg["library_sequences_in"]
+    assert d["verify"]["mismatches"] == 0
+
+
+def test_bench_coarse_line_two_ranks_functional():
+    """stage 3.1's companion line with two ranks (replicas: every rank its own genome, no collective on the data path), the ranks
+    sharing this GPU over gloo"""
+    d = _bench_two_ranks(["--stage", "coarse", "--genome-mbp", "50", "--steps", "1", "--warmup", "2", "--no-cpu-baseline"])
+    assert d["unit"] == "Mbp/s" and d["config"]["hsp_records"] > 0 and d["config"]["repeat_intervals"] > 0
