@@ -1848,6 +1848,33 @@ def test_coarse_stage_sharded_over_rccl_world1(ctx):
     assert [x.tolist() for x in shard] == [x.tolist() for x in plain] and len(plain[0]) >= 20
 
 
+def test_coarse_stage_sharded_two_ranks_on_one_gpu(ctx, tmp_path):
+    """stage 3.1 sharded over TWO ranks with the real device stages on each (hite_seed_shard's share of the anchors, the all-to-all
+    of HSP records to the owners of the query files, hite_fmea_chain per owned file, the all-gather of the interval lists): the
+    ranks share this GPU and exchange over gloo (tests/_coarse_two_ranks.py under torch.distributed.run) -- the merged intervals
+    must be the unsharded stage's.  (RCCL between two GPUs stays unmeasured: no node.)"""
+    import json
+    import subprocess
+    import sys
+    import synth_small
+    from hite_amd import dist as hd
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    g = synth_small.make(31, n_fam=14, n_chr=3, chr_len=150_000)
+    ctx.genome_pack(g["contigs"])
+    ctx.release_copy_index()
+    plain = hd.coarse_stage_sharded(ctx, 50_000, 2000, 30000, base_threshold=100_000)
+    out = tmp_path / "sharded.json"
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29500 + os.getpid() % 2000), os.path.join(root, "tests", "_coarse_two_ranks.py"), str(out)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    shard = json.load(open(out))
+    assert shard == [np.asarray(x).tolist() for x in plain] and len(plain[0]) >= 20
+
+
 def test_itr_search_tool_golden_and_twin(ctx):
     """hite_itr_search (the in-tree stage where the reference runs tools/itrsearch -i 0.7 -l 7, Util.py:216-224) against the tool's
     own output (3 300 records), then field for field against the twin on fresh records: 20 000 first-40 + last-40 records (LDS path),
