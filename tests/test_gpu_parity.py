@@ -1867,8 +1867,14 @@ def test_coarse_stage_sharded_two_ranks_on_one_gpu(ctx, tmp_path):
     out = tmp_path / "sharded.json"
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import socket
+
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29500 + os.getpid() % 2000), os.path.join(root, "tests", "_coarse_two_ranks.py"), str(out)]
+           "--master-port", str(port), os.path.join(root, "tests", "_coarse_two_ranks.py"), str(out)]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-2000:]
     shard = json.load(open(out))
