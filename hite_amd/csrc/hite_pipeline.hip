@@ -211,10 +211,12 @@ __global__ void row_meta_kernel(int n, const int64_t *__restrict__ row_first, co
         row_trunc[g] = md == 2;
         mx = L > mx ? L : mx;
     }
-    // one atomic per wavefront (one per row on a single address was half a millisecond per launch)
+    // one atomic per wavefront (one per row on a single address was half a millisecond per launch) -- and only from a wavefront
+    // whose maximum beats what the word already holds (round 6: a maximum only grows, so a stale read can at worst let a needless
+    // atomic through; 100 000 wavefronts on one address were still 0.4 ms per launch)
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d, 64); mx = o > mx ? o : mx; }
-    if ((threadIdx.x & 63) == 0 && mx > 0) atomicMax(maxlen, mx);
+    if ((threadIdx.x & 63) == 0 && mx > 0 && mx > __atomic_load_n(maxlen, __ATOMIC_RELAXED)) atomicMax(maxlen, mx);
 }
 
 // one byte of a window (position p of the window [g_lo, g_lo + wlen) read on the given strand)
@@ -313,19 +315,28 @@ __global__ void ops_count_kernel(int n, const int64_t *__restrict__ row_first, c
                                  const int32_t *__restrict__ row_len, int64_t *__restrict__ cnt,
                                  unsigned long long *__restrict__ acc) {
     int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
-    int R = nrows[c];
-    if (R <= 0) { cnt[c] = 0; return; }
-    int64_t g0 = row_first[c];
-    int64_t m = row_len[g0];
-    cnt[c] = (int64_t)(R + 1) * (m + 1);
     unsigned long long bytes = 0, steps = 0;
-    for (int r = 1; r < R; r++) {
-        int64_t nn = row_len[g0 + r];
-        bytes += (unsigned long long)(m + nn + 2 * (m + 1));
-        steps += (unsigned long long)(m + nn);
+    if (c < n) {
+        int R = nrows[c];
+        if (R <= 0) cnt[c] = 0;
+        else {
+            int64_t g0 = row_first[c];
+            int64_t m = row_len[g0];
+            cnt[c] = (int64_t)(R + 1) * (m + 1);
+            for (int r = 1; r < R; r++) {
+                int64_t nn = row_len[g0 + r];
+                bytes += (unsigned long long)(m + nn + 2 * (m + 1));
+                steps += (unsigned long long)(m + nn);
+            }
+        }
     }
-    if (bytes) { atomicAdd(&acc[0], bytes); atomicAdd(&acc[1], steps); }
+    // one pair of atomics per wavefront (round 6: two per candidate on two addresses were 100 000 per launch)
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        bytes += ((unsigned long long)(unsigned)__shfl_xor((int)(bytes >> 32), d, 64) << 32) | (unsigned)__shfl_xor((int)bytes, d, 64);
+        steps += ((unsigned long long)(unsigned)__shfl_xor((int)(steps >> 32), d, 64) << 32) | (unsigned)__shfl_xor((int)steps, d, 64);
+    }
+    if ((threadIdx.x & 63) == 0 && bytes) { atomicAdd(&acc[0], bytes); atomicAdd(&acc[1], steps); }
 }
 
 // bytes of each alignment in HBM: none for the classes whose judge kernel builds the alignment in LDS (cls may be NULL)
@@ -335,7 +346,7 @@ __global__ void msa_size_kernel(int n, const int32_t *__restrict__ nrows, const 
     if (c >= n) return;
     int64_t b = (cls && cls[c] >= JUDGE_CLS_LDS) ? 0 : (int64_t)nrows[c] * cols[c];
     bytes[c] = (b + 15) & ~(int64_t)15;
-    atomicMax(maxcols, cols[c]);
+    if (cols[c] > __atomic_load_n(maxcols, __ATOMIC_RELAXED)) atomicMax(maxcols, cols[c]);      // (a maximum only grows: a stale read lets at worst a needless atomic through)
 }
 
 // rows visible to sparse-col / judge: 0 rows where the alignment failed
