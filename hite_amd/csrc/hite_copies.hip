@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const ui
         const int64_t cb = cand_off[c];
         const int L = (int)(cand_off[c + 1] - cb);
         const int nk = L - CK + 1;
-        if (threadIdx.x == 0 && L > 0) atomicMax(max_len, (unsigned long long)L);
+        if (threadIdx.x == 0 && L > 0 && (unsigned long long)L > __atomic_load_n(max_len, __ATOMIC_RELAXED)) atomicMax(max_len, (unsigned long long)L);   // (a maximum only grows: one same-address atomic per candidate was what 50 000 blocks queued behind)
         if (nk <= 0) { if (threadIdx.x == 0) q_cnt[c] = 0; continue; }
         const int nwin = nk >= CW ? nk - CW + 1 : 1;
         const uint8_t *s = cand + cb;
