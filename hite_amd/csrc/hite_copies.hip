@@ -1630,19 +1630,25 @@ __device__ __forceinline__ long long seed_pj(unsigned long long key, unsigned pi
 }
 // does anchor i open a cluster?  (different (strand, diagonal >> 6) bucket than the anchor before it, more than SEED_GAP further
 // on, or either position in another contig)
+// (round 6: a thread walks consecutive anchors, whose positions mostly stay inside one contig -- it keeps the bounds of the contig it
+// looked up last for the query and for the subject side and searches the contig table only when a position leaves them: two binary
+// searches per anchor pair were a third of the kernel)
+struct SeedContigs { long long qlo, qhi, slo, shi; };       // [lo, hi) of the contigs looked up last; hi <= lo: none yet
 template <bool PK>
 __device__ __forceinline__ int seed_opens(int64_t i, unsigned long long ka, unsigned long long kb, const unsigned *__restrict__ aval,
-                                          int64_t G, const int64_t *__restrict__ coff, int nc) {
+                                          int64_t G, const int64_t *__restrict__ coff, int nc, SeedContigs &cb) {
     if (i == 0) return 1;
     const unsigned long long a = anc_sd<PK>(ka), b = anc_sd<PK>(kb);
     const unsigned pa = anc_pi<PK>(ka, aval, i - 1), pb = anc_pi<PK>(kb, aval, i);
     if ((a >> 6) != (b >> 6) || (long long)pb - (long long)pa > SEED_GAP) return 1;
     // same bucket, pa <= pb (position order inside a bucket): the two query positions lie in one contig iff pb is below the
     // end of pa's; likewise the two subject positions
-    const int ca = contig_of(coff, nc, pa);
+    if (!((long long)pa >= cb.qlo && (long long)pa < cb.qhi)) { const int ca = contig_of(coff, nc, pa); cb.qlo = coff[ca]; cb.qhi = coff[ca + 1]; }
+    if ((long long)pb >= cb.qhi) return 1;
     const long long sa = seed_pj(a, pa, G), sb = seed_pj(b, pb, G);
     const long long s0 = sa < sb ? sa : sb, s1 = sa < sb ? sb : sa;
-    return ((long long)pb >= coff[ca + 1] || s1 >= coff[contig_of(coff, nc, s0) + 1]) ? 1 : 0;
+    if (!(s0 >= cb.slo && s0 < cb.shi)) { const int cs = contig_of(coff, nc, s0); cb.slo = coff[cs]; cb.shi = coff[cs + 1]; }
+    return s1 >= cb.shi ? 1 : 0;
 }
 // Clusters without a flag array or a scan over the anchors: a workgroup owns SF_TILE consecutive anchors (8 per thread); pass
 // COUNT leaves the number of cluster starts of every tile, after a scan of those (one entry per 2048 anchors) pass EMIT finds the
@@ -1663,10 +1669,11 @@ __global__ void __launch_bounds__(256) seed_clusters_kernel(int64_t na, int64_t 
     for (int q = 0; q < SF_ITEMS; q++) { const int64_t i = base + q; k[q + 1] = akey[i < na ? i : na - 1]; }
     unsigned bits = 0;
     int c = 0;
+    SeedContigs cb = {0, 0, 0, 0};
 #pragma unroll
     for (int q = 0; q < SF_ITEMS; q++) {
         const int64_t i = base + q;
-        if (i < na && seed_opens<PK>(i, k[q], k[q + 1], aval, G, coff, nc)) { bits |= 1u << q; c++; }
+        if (i < na && seed_opens<PK>(i, k[q], k[q + 1], aval, G, coff, nc, cb)) { bits |= 1u << q; c++; }
     }
     int total;
     const int excl = block_excl_scan(c, s_tmp, &total);
