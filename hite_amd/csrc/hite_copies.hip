@@ -609,7 +609,8 @@ __global__ void cluster_flag_kernel(int64_t nh, const unsigned long long *__rest
         unsigned long long a = hkey[i - 1], b = hkey[i];
         long long da = hit_dbias(F, a), db = hit_dbias(F, b);
         long long ga = da - DBIAS + hit_qo(F, a, i - 1), gb = db - DBIAS + hit_qo(F, b, i);
-        f = hit_strand_key(F, a) != hit_strand_key(F, b) || db - da > C_TD || contig_of(coff, nc, ga) != contig_of(coff, nc, gb);
+        f = hit_strand_key(F, a) != hit_strand_key(F, b) || db - da > C_TD;
+        if (!f) { const int ca = contig_of(coff, nc, ga); f = gb < coff[ca] || gb >= coff[ca + 1]; }      // (one search: is gb inside ga's contig?)
     }
     flag[i] = f;
 }
