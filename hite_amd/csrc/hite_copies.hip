@@ -332,6 +332,7 @@ __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const ui
                                                              int32_t *__restrict__ q_cnt, unsigned long long *__restrict__ max_len) {
     __shared__ uint8_t sb[256 * CM_KPT + CK + 8];     // sb[q] = code of base (tile - 1 + q): 0..3, 4 = not A/C/G/T or outside
     __shared__ unsigned sh[256 * CM_KPT];             // sh[q] = hs of the k-mer starting at base (tile - 1 + q)
+    __shared__ int sm[CM_TILE + 1];                   // sm[o + 1] = minimizer position of the window that starts at tile + o
     __shared__ int s_cnt[4];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int c = blockIdx.x; c < ncand; c += gridDim.x) {
@@ -365,22 +366,48 @@ __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const ui
                 }
             }
             __syncthreads();
-#pragma unroll 1
+            // every window's minimizer ONCE (round 6, as genome_minimizer_kernel since round 5: a start used to scan its own window and
+            // its predecessor's -- 20 LDS reads, now 10 + 1): sm[o + 1] = minimizer of the window that starts at base + o, sm[0] = of the
+            // window in front of the tile
+            const int rounds = (nwin - base + 255) / 256 < CM_TILE / 256 ? (nwin - base + 255) / 256 : CM_TILE / 256;    // block-uniform
+            int mm[CM_TILE / 256];
+            unsigned hh[CM_TILE / 256];
+#pragma unroll
             for (int j = 0; j < CM_TILE / 256; j++) {
+                mm[j] = -1; hh[j] = 0;
+                if (j < rounds) {
+                    const int o = j * 256 + threadIdx.x;
+                    const int lp = base + o;
+                    if (lp < nwin) {
+                        int m = -1; unsigned h = 0;
+#pragma unroll
+                        for (int i = 0; i < CW; i++) {
+                            const unsigned v = sh[o + 1 + i];
+                            if (v != HS_INVALID && (m < 0 || (v >> 1) < (h >> 1))) { m = lp + i; h = v; }
+                        }
+                        mm[j] = m; hh[j] = h;
+                    }
+                    sm[o + 1] = mm[j];
+                }
+            }
+            if (threadIdx.x == 0) {
+                int m = -1; unsigned h = 0;
+                if (base > 0)
+                    for (int i = 0; i < CW; i++) {
+                        const unsigned u = sh[i];
+                        if (u != HS_INVALID && (m < 0 || (u >> 1) < (h >> 1))) { m = base - 1 + i; h = u; }
+                    }
+                sm[0] = m;
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int j = 0; j < rounds; j++) {
                 const int o = j * 256 + threadIdx.x;
                 const int lp = base + o;
-                bool want = false; unsigned h = 0; int m = -1;
+                bool want = false;
+                const unsigned h = hh[j]; const int m = mm[j];
                 if (lp < nwin) {
-                    // window [lp, lp + CW) = sh[o + 1 .. o + CW]; previous window = sh[o .. o + CW - 1]
-                    int mprev = -1; unsigned hprev = 0;
-#pragma unroll
-                    for (int i = 0; i < CW; i++) {
-                        const unsigned v = sh[o + 1 + i];
-                        if (v != HS_INVALID && (m < 0 || (v >> 1) < (h >> 1))) { m = lp + i; h = v; }
-                        const unsigned u = sh[o + i];
-                        if (u != HS_INVALID && (mprev < 0 || (u >> 1) < (hprev >> 1))) { mprev = lp - 1 + i; hprev = u; }
-                    }
-                    want = m >= 0 && !(lp > 0 && mprev == m);
+                    want = m >= 0 && !(lp > 0 && sm[o] == m);
                     // sampling of the candidate's minimizers (definition: cand_minimizer_kept of the twin)
                     if (want && L >= 2 * C_SUB_UNIT && m >= C_SUB_EDGE && m + CK <= L - C_SUB_EDGE) {
                         const unsigned S = L / C_SUB_UNIT > C_SUB_MAX ? C_SUB_MAX : L / C_SUB_UNIT;
@@ -395,7 +422,6 @@ __global__ void __launch_bounds__(256) cand_minimizer_kernel(int ncand, const ui
                 if (want) { r_pos[cb + off] = (unsigned)m; r_hs[cb + off] = h; }
                 run += s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
                 __syncthreads();
-                if (base + (j + 1) * 256 >= nwin) break;   // block-uniform
             }
         }
         if (threadIdx.x == 0) q_cnt[c] = run;
