@@ -1719,14 +1719,20 @@ __global__ void seed_piece_kernel(int64_t ncl, int64_t G, int64_t seg_len, const
                                   unsigned long long *__restrict__ okey, unsigned *__restrict__ oval, int32_t *__restrict__ o_qseg,
                                   int32_t *__restrict__ o_sseg, int64_t *__restrict__ o_qs, int64_t *__restrict__ o_qe,
                                   int64_t *__restrict__ o_ss, int64_t *__restrict__ o_se) {
-    int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= ncl) return;
+    // Round 6: SP_ITEMS clusters per thread, strided by the launch (coalesced).  97 % of the clusters are no HSP (fewer than three
+    // anchors, mostly): the count pass tests the anchor count before it reads a key, the emit pass reads the count pass's verdict
+    // and nothing else -- a thread per cluster was bound by the rate at which 5.7 M wavefronts can be started (4.5 ms for an emit
+    // pass that writes 11 M records).
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < ncl; k += stride) {
+    if (EMIT && pcnt[k] == 0) continue;
     const unsigned b = c_first[k], e = c_first[k + 1];
     int n = 0;
+    if (e - b < SEED_MINANCH) { if (!EMIT) pcnt[k] = 0; continue; }
     const unsigned long long kf = akey[b], kl = akey[e - 1];
     const unsigned qf = anc_pi<PK>(kf, aval, b), ql = anc_pi<PK>(kl, aval, e - 1);
     const long long q0 = qf, q1 = (long long)ql + CK;
-    if (e - b >= SEED_MINANCH && q1 - q0 >= SEED_MINSPAN) {
+    if (q1 - q0 >= SEED_MINSPAN) {
         const int rel = (int)(anc_sd<PK>(kf) >> 34);
         const long long pf = seed_pj(anc_sd<PK>(kf), qf, G), pl = seed_pj(anc_sd<PK>(kl), ql, G);
         const long long s0 = pf < pl ? pf : pl, s1 = (pf < pl ? pl : pf) + CK;
@@ -1767,7 +1773,10 @@ __global__ void seed_piece_kernel(int64_t ncl, int64_t G, int64_t seg_len, const
         }
     }
     if (!EMIT) pcnt[k] = n;
+    }
 }
+#define SP_ITEMS 8
+#define SPGRID(n) dim3((unsigned)((((n) > 0 ? (n) : 1) + 256 * SP_ITEMS - 1) / (256 * SP_ITEMS))), dim3(256)
 __global__ void seed_gather_kernel(int64_t n, const unsigned *__restrict__ perm, const int32_t *__restrict__ i_qseg,
                                    const int32_t *__restrict__ i_sseg, const int64_t *__restrict__ i_qs, const int64_t *__restrict__ i_qe,
                                    const int64_t *__restrict__ i_ss, const int64_t *__restrict__ i_se, int32_t *__restrict__ o_qseg,
@@ -1953,7 +1962,7 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); pcnt = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 8, &p)); pfirst = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(ncl) * 8, &p)); bs3 = (int64_t *)p;
-#define SEED_PIECE_COUNT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<false, PKV>), CGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
+#define SEED_PIECE_COUNT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<false, PKV>), SPGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
                        seg_base, pcnt, (const int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr, (int32_t *)nullptr, \
                        (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr)
     if (packed) SEED_PIECE_COUNT(true); else SEED_PIECE_COUNT(false);
@@ -1979,7 +1988,7 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
         CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); t_q[i] = (int64_t *)p;
         CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); f_q[i] = (int64_t *)p;
     }
-#define SEED_PIECE_EMIT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<true, PKV>), CGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
+#define SEED_PIECE_EMIT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<true, PKV>), SPGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
                        seg_base, pcnt, (const int64_t *)pfirst, okey, oval, t_qseg, t_sseg, t_q[0], t_q[1], t_q[2], t_q[3])
     int tk_hs = hite_prof_begin(ctx, "seed_hsp_emit_sort", st);
     if (packed) SEED_PIECE_EMIT(true); else SEED_PIECE_EMIT(false);
