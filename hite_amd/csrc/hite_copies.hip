@@ -1718,17 +1718,18 @@ __global__ void seed_piece_kernel(int64_t ncl, int64_t G, int64_t seg_len, const
                                   int32_t *__restrict__ pcnt, const int64_t *__restrict__ pfirst,
                                   unsigned long long *__restrict__ okey, unsigned *__restrict__ oval, int32_t *__restrict__ o_qseg,
                                   int32_t *__restrict__ o_sseg, int64_t *__restrict__ o_qs, int64_t *__restrict__ o_qe,
-                                  int64_t *__restrict__ o_ss, int64_t *__restrict__ o_se) {
-    // Round 6: SP_ITEMS clusters per thread, strided by the launch (coalesced).  97 % of the clusters are no HSP (fewer than three
-    // anchors, mostly): the count pass tests the anchor count before it reads a key, the emit pass reads the count pass's verdict
-    // and nothing else -- a thread per cluster was bound by the rate at which 5.7 M wavefronts can be started (4.5 ms for an emit
-    // pass that writes 11 M records).
+                                  int64_t *__restrict__ o_ss, int64_t *__restrict__ o_se,
+                                  const unsigned *__restrict__ list, const unsigned long long *__restrict__ n_list) {
+    // Round 6: both passes run over the DENSE list of the clusters that can be an HSP (seed_piece_select_kernel: >= 3 anchors and
+    // the query span, 3 % of them).  With a thread per cluster nearly every wavefront held one or two such clusters and walked the
+    // whole piece loop (64-bit divisions, contig searches, eight stores) for them: 3.5 + 4.5 ms for 11 M records.
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < ncl; k += stride) {
-    if (EMIT && pcnt[k] == 0) continue;
+    const int64_t nl = (int64_t)*n_list;
+    (void)ncl;
+    for (int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; li < nl; li += stride) {
+    const int64_t k = list[li];
     const unsigned b = c_first[k], e = c_first[k + 1];
     int n = 0;
-    if (e - b < SEED_MINANCH) { if (!EMIT) pcnt[k] = 0; continue; }
     const unsigned long long kf = akey[b], kl = akey[e - 1];
     const unsigned qf = anc_pi<PK>(kf, aval, b), ql = anc_pi<PK>(kl, aval, e - 1);
     const long long q0 = qf, q1 = (long long)ql + CK;
@@ -1775,8 +1776,45 @@ __global__ void seed_piece_kernel(int64_t ncl, int64_t G, int64_t seg_len, const
     if (!EMIT) pcnt[k] = n;
     }
 }
+// which clusters can be an HSP: >= SEED_MINANCH anchors and a query span >= SEED_MINSPAN (the keys are read only behind the first
+// test); their ids go to `list` in any order (one atomic per wavefront) -- the records' places come from the scan of pcnt, which
+// this kernel zeroes for everything it leaves out
 #define SP_ITEMS 8
 #define SPGRID(n) dim3((unsigned)((((n) > 0 ? (n) : 1) + 256 * SP_ITEMS - 1) / (256 * SP_ITEMS))), dim3(256)
+#define SPS_ITEMS 16
+template <bool PK>
+__global__ void __launch_bounds__(256) seed_piece_select_kernel(int64_t ncl, const unsigned long long *__restrict__ akey, const unsigned *__restrict__ aval,
+                                                                const unsigned *__restrict__ c_first, int32_t *__restrict__ pcnt, unsigned *__restrict__ list,
+                                                                unsigned long long *__restrict__ n_list) {
+    // a workgroup owns 256 x SPS_ITEMS consecutive clusters and takes its place in the list with ONE atomic (a wavefront each: 5 M
+    // same-address atomics, 34 ms)
+    __shared__ int s_tmp[8];
+    __shared__ unsigned long long s_base;
+    const int64_t tile = (int64_t)blockIdx.x * (256 * SPS_ITEMS);
+    unsigned bits = 0;
+#pragma unroll
+    for (int j = 0; j < SPS_ITEMS; j++) {
+        const int64_t k = tile + j * 256 + threadIdx.x;
+        bool want = false;
+        if (k < ncl) {
+            const unsigned b = c_first[k], e = c_first[k + 1];
+            if (e - b >= SEED_MINANCH) {
+                const unsigned qf = anc_pi<PK>(akey[b], aval, b), ql = anc_pi<PK>(akey[e - 1], aval, e - 1);
+                want = (long long)ql + CK - (long long)qf >= SEED_MINSPAN;
+            }
+            if (!want) pcnt[k] = 0;
+        }
+        bits |= (unsigned)want << j;
+    }
+    int total;
+    const int excl = block_excl_scan(__popc(bits), s_tmp, &total);
+    if (threadIdx.x == 0) s_base = total ? atomicAdd(n_list, (unsigned long long)total) : 0ull;
+    __syncthreads();
+    unsigned long long o = s_base + (unsigned long long)excl;
+#pragma unroll
+    for (int j = 0; j < SPS_ITEMS; j++)
+        if ((bits >> j) & 1u) list[o++] = (unsigned)(tile + j * 256 + threadIdx.x);
+}
 __global__ void seed_gather_kernel(int64_t n, const unsigned *__restrict__ perm, const int32_t *__restrict__ i_qseg,
                                    const int32_t *__restrict__ i_sseg, const int64_t *__restrict__ i_qs, const int64_t *__restrict__ i_qe,
                                    const int64_t *__restrict__ i_ss, const int64_t *__restrict__ i_se, int32_t *__restrict__ o_qseg,
@@ -1962,9 +2000,16 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 1) * 4, &p)); pcnt = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 8, &p)); pfirst = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(ncl) * 8, &p)); bs3 = (int64_t *)p;
-#define SEED_PIECE_COUNT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<false, PKV>), SPGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
+    unsigned *plist; unsigned long long *pn;       // the clusters that can be an HSP (each holds >= SEED_MINANCH anchors)
+    CCHK(arena_alloc(ctx, A, (size_t)(na / SEED_MINANCH + 64) * 4, &p)); plist = (unsigned *)p;
+    CCHK(arena_alloc(ctx, A, 16, &p)); pn = (unsigned long long *)p;
+    HITE_CHECK(ctx, hipMemsetAsync(pn, 0, 16, st));
+    if (packed) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_select_kernel<true>), dim3((unsigned)((ncl + 256 * SPS_ITEMS - 1) / (256 * SPS_ITEMS))), dim3(256), 0, st, ncl, akey, aval, c_first, pcnt, plist, pn);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_select_kernel<false>), dim3((unsigned)((ncl + 256 * SPS_ITEMS - 1) / (256 * SPS_ITEMS))), dim3(256), 0, st, ncl, akey, aval, c_first, pcnt, plist, pn);
+    const dim3 pgrid(8192);       // (both passes stride over the list, whose length stays on the device)
+#define SEED_PIECE_COUNT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<false, PKV>), pgrid, dim3(256), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
                        seg_base, pcnt, (const int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr, (int32_t *)nullptr, \
-                       (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr)
+                       (int32_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, (int64_t *)nullptr, plist, pn)
     if (packed) SEED_PIECE_COUNT(true); else SEED_PIECE_COUNT(false);
 #undef SEED_PIECE_COUNT
     CCHK(scan_excl_buf<int32_t>(ctx, bs3, pcnt, ncl, pfirst, st));
@@ -1988,8 +2033,8 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
         CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); t_q[i] = (int64_t *)p;
         CCHK(arena_alloc(ctx, A, (size_t)(np + 1) * 8, &p)); f_q[i] = (int64_t *)p;
     }
-#define SEED_PIECE_EMIT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<true, PKV>), SPGRID(ncl), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
-                       seg_base, pcnt, (const int64_t *)pfirst, okey, oval, t_qseg, t_sseg, t_q[0], t_q[1], t_q[2], t_q[3])
+#define SEED_PIECE_EMIT(PKV) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_piece_kernel<true, PKV>), pgrid, dim3(256), 0, st, ncl, G, seg_len, akey, aval, c_first, ctx->d_contig_off, ctx->n_contigs, \
+                       seg_base, pcnt, (const int64_t *)pfirst, okey, oval, t_qseg, t_sseg, t_q[0], t_q[1], t_q[2], t_q[3], plist, pn)
     int tk_hs = hite_prof_begin(ctx, "seed_hsp_emit_sort", st);
     if (packed) SEED_PIECE_EMIT(true); else SEED_PIECE_EMIT(false);
 #undef SEED_PIECE_EMIT
