@@ -302,8 +302,15 @@ __global__ void fm_ht_insert_kernel(int64_t nch, const Chain *__restrict__ chain
         unsigned long long key = k8[t];
         unsigned long long h = mixhash(key) & mask;
         for (;;) {
-            unsigned long long old = atomicCAS(&ht_key[h], HT_EMPTY, key);
-            if (old == HT_EMPTY || old == key) { atomicMin(&ht_val[h], (unsigned)c); break; }
+            // (round 6: a plain read first -- a slot that already holds the key needs no compare-and-swap, and a value that is
+            // already below this chain's number no atomic minimum: keys repeat, that is what the table is for, and device-scope
+            // atomics on random lines are what bounds the kernel)
+            unsigned long long old = __atomic_load_n(&ht_key[h], __ATOMIC_RELAXED);
+            if (old == HT_EMPTY) old = atomicCAS(&ht_key[h], HT_EMPTY, key);
+            if (old == HT_EMPTY || old == key) {
+                if (__atomic_load_n(&ht_val[h], __ATOMIC_RELAXED) > (unsigned)c) atomicMin(&ht_val[h], (unsigned)c);
+                break;
+            }
             h = (h + 1) & mask;
         }
     }
