@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(256) star_fill_kernel(FillParams P) {
 //   * the first / last column of the alignment are kept regardless (the last one may be a non-prefix column of block m).
 // Per position p one layout word (MsaParams::lay): kw | keep_centre << 15 | first kept column of the block << 16.
 // ---------------------------------------------------------------------------------------------
+#define LAY_KW_LIST 256  // positions of one round (1024) whose insertion block keeps columns: beyond it their lanes walk the rows themselves
 #ifndef LAY_ROWS
 #define LAY_ROWS 4      // rows whose ops a thread of the layout kernel has in flight
 #endif
@@ -178,6 +179,8 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
     uint32_t *lay = P.lay + (P.ops_base[c] >> 1);
     const int h = (R + 1) >> 1;                          // fewest rows with a base for a column to survive
     __shared__ int s_wl[MSA_MAXR];
+    __shared__ int s_nkw;
+    __shared__ unsigned short s_kwlist[LAY_KW_LIST], s_kwres[4 * 256];
     for (int r = threadIdx.x; r < R && r < MSA_MAXR; r += 256) s_wl[r] = P.win_len[g0 + msa_src(P.row_map, g0, r)];
     if (threadIdx.x == 0) s_mxm = 0;
     __syncthreads();
@@ -235,6 +238,43 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
                 }
             }
         }
+        // Positions whose insertion block keeps columns (at least h rows insert there: where the centre lacks bases of the family,
+        // ~0.5 % of them) need the h-th largest insertion length.  One lane used to walk all rows for it while the other 63 of
+        // its wavefront waited -- and nearly every wavefront of a round holds such a position: 2.2 of the kernel's 4.6 ms per C3
+        // step.  Round 6: the positions go to a list in LDS and a WAVEFRONT takes each, lanes = rows (the count of rows with a
+        // longer insertion is a ballot), the owners read the result back.
+        if (threadIdx.x == 0) s_nkw = 0;
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < 4; x++) {
+            const int p = p0 + x;
+            if (p <= m && npos[x] >= h) {
+                const int slot = atomicAdd(&s_nkw, 1);
+                if (slot < LAY_KW_LIST) s_kwlist[slot] = p - base;
+            }
+        }
+        __syncthreads();
+        {
+            const int nk = s_nkw < LAY_KW_LIST ? s_nkw : LAY_KW_LIST;
+            const int lane = threadIdx.x & 63;
+            for (int i = threadIdx.x >> 6; i < nk; i += 4) {
+                const int p = base + s_kwlist[i];
+                int kw = 1;
+                for (;;) {
+                    int cnt = 0;
+                    for (int r = 1 + lane; r - lane < R; r += 64) {            // (every lane makes every trip: the ballot below)
+                        const bool in = r < R;
+                        const int rr = in ? r : 1;
+                        const int wl = rr < MSA_MAXR ? s_wl[rr] : P.win_len[g0 + msa_src(P.row_map, g0, rr)];
+                        const bool longer = in && row_ins(ops + (int64_t)rr * (m + 1), p, m, wl) > kw;
+                        cnt += __popcll(__ballot(longer));
+                    }
+                    if (cnt >= h) kw++; else break;
+                }
+                if (lane == 0) s_kwres[s_kwlist[i]] = (unsigned short)(kw > 0xffff ? 0xffff : kw);
+            }
+        }
+        __syncthreads();
         int wnew[4], wfull[4], kws[4], sum_new = 0, sum_full = 0;
 #pragma unroll
         for (int x = 0; x < 4; x++) {
@@ -242,10 +282,14 @@ __global__ void __launch_bounds__(256) star_layout_sparse_kernel(MsaParams P, in
             int kw = 0;
             if (p <= m && npos[x] >= h) {
                 kw = 1;
-                for (;;) {
-                    int cnt = 0;
-                    for (int r = 1; r < R; r++) cnt += row_ins(ops + (int64_t)r * (m + 1), p, m, P.win_len[g0 + msa_src(P.row_map, g0, r)]) > kw;
-                    if (cnt >= h) kw++; else break;
+                if (s_nkw <= LAY_KW_LIST) kw = s_kwres[p - base];
+                else {
+                    // more such positions in one round than the list holds (it never happened on C2 / C3): the lane walks the rows
+                    for (;;) {
+                        int cnt = 0;
+                        for (int r = 1; r < R; r++) cnt += row_ins(ops + (int64_t)r * (m + 1), p, m, P.win_len[g0 + msa_src(P.row_map, g0, r)]) > kw;
+                        if (cnt >= h) kw++; else break;
+                    }
                 }
             }
             int keepc = (p < m && 2 * gapc[x] <= R) ? 1 : 0;
