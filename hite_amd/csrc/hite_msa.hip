@@ -333,6 +333,17 @@ struct FillSparseParams {
 
 // fill of the kept columns only: item (r, p) owns the kept prefix of insertion block p, the centre column p if kept
 // and (p == m) the extra last column; every output byte is written exactly once.
+// the sink star_fill_sparse_kernel hands to fill_sparse_row: (row, position) into the workgroup's list; a full list fills on the spot
+#define FILL_DEFER_CAP 1024
+struct FillDefer {
+    unsigned *list; int *count; unsigned row;
+    __device__ __forceinline__ bool push(int p) const {
+        const int slot = atomicAdd(count, 1);
+        if (slot >= FILL_DEFER_CAP) return false;
+        list[slot] = (row << 16) | (unsigned)p;
+        return true;
+    }
+};
 template <int NU>
 __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams Q) {
     const FillParams &P = Q.F;
@@ -353,6 +364,11 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
     const int rs = m + 1;
     int r = blockIdx.y;
     if (r >= R) return;
+    __shared__ unsigned s_defer[FILL_DEFER_CAP];
+    __shared__ int s_ndefer;
+    if (threadIdx.x == 0) s_ndefer = 0;
+    __syncthreads();
+    const bool can_defer = R <= 0xffff && m < 0xffff;      // (row and position share a list word)
     // the window of the NEXT row of this block is looked up while the current one is filled: row_map -> win_off / win_len are
     // two dependent scalar round trips, as long as the two or three trips over the positions that a row of 2.5 kb takes
     int src = msa_src(P.row_map, g0, r);
@@ -365,8 +381,23 @@ __global__ void __launch_bounds__(256) star_fill_sparse_kernel(FillSparseParams 
         const uint8_t *b = P.win + woff;
         const uint16_t *rop = ops + (int64_t)r * rs;
         uint8_t *row = out + (int64_t)r * C;
-        fill_sparse_row<uint8_t *, 256, NU>(row, b, nrow, rop, lay, m, le, r == 0 /* the centre row: position p faces its own base p */, (int)threadIdx.x);
+        if (can_defer) fill_sparse_row<uint8_t *, 256, NU, FillDefer>(row, b, nrow, rop, lay, m, le, r == 0 /* the centre row: position p faces its own base p */, (int)threadIdx.x,
+                                                                      FillDefer{s_defer, &s_ndefer, (unsigned)r});
+        else fill_sparse_row<uint8_t *, 256, NU>(row, b, nrow, rop, lay, m, le, r == 0, (int)threadIdx.x);
         r = rn; woff = woff_n; nrow = nrow_n;
+    }
+    // the insertion blocks and extra last columns the rows above left behind: a thread each, their load chains side by side
+    __syncthreads();
+    const int nd = s_ndefer < FILL_DEFER_CAP ? s_ndefer : FILL_DEFER_CAP;
+    for (int i = threadIdx.x; i < nd; i += 256) {
+        const int rr = (int)(s_defer[i] >> 16), p = (int)(s_defer[i] & 0xffffu);
+        const int sr = msa_src(P.row_map, g0, rr);
+        const uint8_t *b = P.win + P.win_off[g0 + sr];
+        const int nr = P.win_len[g0 + sr];
+        const uint16_t *rop = ops + (int64_t)rr * rs;
+        const unsigned w = lay[p];
+        const unsigned oc = rr == 0 ? (unsigned)p : (p < m ? (unsigned)rop[p] : 0x8000u);
+        fill_sparse_block<uint8_t *>(out + (int64_t)rr * C, b, nr, rop, m, le, rr == 0, p, w, oc);
     }
 }
 
