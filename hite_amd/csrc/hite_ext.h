@@ -16,9 +16,14 @@
 struct ExtCopyMode { static constexpr int SA = 1, SB = 3, XDROP = 40; static constexpr bool PACKEDQ = false, DIAGLIM = false; };
 struct ExtTandemMode { static constexpr int SA = 2, SB = 7, XDROP = 30; static constexpr bool PACKEDQ = true, DIAGLIM = true; };   // match 2, edit 5: oracle/hite_oracle_trf.c, "calibration"
 
+// A C G T -> 0 1 2 3 (complemented: 3 2 1 0), every other byte 4.  Without a branch: bits 1..2 of the four letters are 0 1 3 2, the
+// letters themselves bits 0, 2, 6, 19 of a mask over ch - 'A' (as a chain of comparisons the compiler made four branches of
+// it in every column of chain_extend_kernel -- a lane alone in its wavefront pays every one of them)
 __device__ __forceinline__ unsigned ext_cand_code(unsigned ch, bool comp) {
-    const unsigned c = ch == 'A' ? 0u : ch == 'C' ? 1u : ch == 'G' ? 2u : ch == 'T' ? 3u : 4u;
-    return (comp && c < 4u) ? 3u - c : c;
+    const unsigned x = ch - 'A', h = (ch >> 1) & 3u;
+    const unsigned c = (h ^ (h >> 1)) ^ (comp ? 3u : 0u);
+    const bool acgt = x < 32u && ((0x80045u >> x) & 1u);
+    return acgt ? c : 4u;
 }
 // State machine of ext_align: query bases q[p0], q[p0 + step], ... (n of them; complemented when comp) -- or, PACKEDQ, genome
 // bases p0, p0 + step, ... -- against genome bases g0, g0 + 1, ... (dir = +1) or g0 - 1, g0 - 2, ... (dir = -1), at most jmax of
@@ -58,6 +63,18 @@ __device__ __forceinline__ uint32_t ext_lut_entry(int t, int idx) {
     return (uint32_t)tc | ((uint32_t)(best + 4) << 5) | ((uint32_t)(s + 4) << 12);
 }
 
+// (device build only) the rotated words are final HERE: without it the compiler sank the rotation below the requests as selects,
+// kept the old and the new "furthest word" alive side by side, and copied one onto the other behind the load -- a wait for the
+// request just made, in every column
+#ifdef __HIP_DEVICE_COMPILE__
+#define EXT_PIN_ROTATED(E) asm volatile("" : "+v"((E).gw), "+v"((E).gwn), "+v"((E).mw), "+v"((E).qw), "+v"((E).qwn), "+v"((E).qwn2))
+// ... and a rotation stays a branch (as selects it reads the word requested last in EVERY column: a wait in every column; as a
+// branch the wait sits inside it, paid in the columns where some lane rotates)
+#define EXT_KEEP_BRANCH() asm volatile("")
+#else
+#define EXT_PIN_ROTATED(E)
+#define EXT_KEEP_BRANCH()
+#endif
 template <class M>
 struct ExtStateT {
     int D[EXT_W];
@@ -112,9 +129,10 @@ __device__ __forceinline__ void ext_fetch(ExtStateT<M> &E, const uint32_t *__res
     const int64_t qi = a >> 2;
     const bool rq = !M::PACKEDQ && qi != E.qwi;
     // rotate
-    if (rg) { E.gw = E.gwn; E.gwn = E.gwn2; E.gwi = wi; }
-    if (rm) { E.mw = E.mwn; E.mwi = mi; }
-    if (rq) { E.qw = E.qwn; E.qwn = E.qwn2; E.qwn2 = E.qwn3; E.qwi = qi; }
+    if (rg) { EXT_KEEP_BRANCH(); E.gw = E.gwn; E.gwn = E.gwn2; E.gwi = wi; }
+    if (rm) { EXT_KEEP_BRANCH(); E.mw = E.mwn; E.mwi = mi; }
+    if (rq) { EXT_KEEP_BRANCH(); E.qw = E.qwn; E.qwn = E.qwn2; E.qwn2 = E.qwn3; E.qwi = qi; }
+    EXT_PIN_ROTATED(E);
     // request
     if (rg) { const int64_t nx = wi + 2 * E.dir; E.gwn2 = bases[nx > 0 ? nx : 0]; }
     if (rm) { const int64_t nx = mi + E.dir; E.mwn = nmask[nx > 0 ? nx : 0]; }
