@@ -148,26 +148,45 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
 // (per-wave digit counts -> offsets; ballots for the rank inside a round), writes them to LDS in digit order and streams
 // the runs out: the average run of a digit is 8 consecutive elements (64 B of keys).
 // LDS: keys 64 KB | values 32 KB | per-wave digit offsets u16 [8][1024] 16 KB | run shift u32 [1024] 4 KB | scan 64 B.
+// Keys only (round 6): no values in LDS, and a tile of 14 instead of 16 rounds -- 76 KB, so that TWO workgroups share a compute unit and
+// one loads or streams out while the other ranks (with one, 116 KB, the three phases of a tile ran one behind the other).
 #define RSS_TILE 8192
 #define RSS_LDS_BYTES (RSS_TILE * 12 + 8 * 1024 * 2 + 1024 * 4 + 64)
+#ifndef RSS_KROUNDS
+#define RSS_KROUNDS 14
+#endif
+#define RSS_KTILE (512 * RSS_KROUNDS)
+#ifndef RSS_XCD_MAP
+#define RSS_XCD_MAP 1
+#endif
+#define RSS_KLDS_BYTES (RSS_KTILE * 8 + 8 * 1024 * 2 + 1024 * 4 + 64)
 template <bool VALS>
 static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const unsigned long long *__restrict__ kin, const unsigned *__restrict__ vin,
                                                                        unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
                                                                        int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
     extern __shared__ unsigned char rss_lds[];
+    constexpr int R = VALS ? 16 : RSS_KROUNDS, TILE = 512 * R, ESZ = VALS ? 12 : 8;
     unsigned long long *skey = reinterpret_cast<unsigned long long *>(rss_lds);
-    unsigned *sval = reinterpret_cast<unsigned *>(rss_lds + RSS_TILE * 8);
-    unsigned short *woff = reinterpret_cast<unsigned short *>(rss_lds + RSS_TILE * 12);           // [8][1024]
-    unsigned *delta = reinterpret_cast<unsigned *>(rss_lds + RSS_TILE * 12 + 8 * 1024 * 2);       // [1024]
-    int *wsum = reinterpret_cast<int *>(rss_lds + RSS_TILE * 12 + 8 * 1024 * 2 + 1024 * 4);      // [8] + total
+    unsigned *sval = reinterpret_cast<unsigned *>(rss_lds + TILE * 8);                            // (VALS only)
+    unsigned short *woff = reinterpret_cast<unsigned short *>(rss_lds + TILE * ESZ);              // [8][1024]
+    unsigned *delta = reinterpret_cast<unsigned *>(rss_lds + TILE * ESZ + 8 * 1024 * 2);          // [1024]
+    int *wsum = reinterpret_cast<int *>(rss_lds + TILE * ESZ + 8 * 1024 * 2 + 1024 * 4);         // [8] + total
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t tile = (int64_t)blockIdx.x * RSS_TILE;
-    unsigned long long k[16];
-    unsigned v[16];
-    unsigned info[16];   // rank inside the round (low 8 bits) | lanes with the same digit (next 8 bits) | digit << 16
+    // tile of this workgroup: the tiles that follow each other in the input finish each other's output lines (a digit's run grows by ~8
+    // keys = 64 B per tile), so they go to ONE chiplet and its L2 -- workgroup b runs on chiplet b % 8 (observed; only speed depends on
+    // it): chiplet x takes the x-th eighth of the tiles in order
+    int tb;
+    {
+        const int x = (int)(blockIdx.x & 7u), i = (int)(blockIdx.x >> 3), q = nblocks >> 3, rr = nblocks & 7;
+        tb = RSS_XCD_MAP ? x * q + (x < rr ? x : rr) + i : (int)blockIdx.x;
+    }
+    const int64_t tile = (int64_t)tb * TILE;
+    unsigned long long k[R];
+    unsigned v[R];
+    unsigned info[R];   // rank inside the round (low 8 bits) | lanes with the same digit (next 8 bits) | digit << 16
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const int64_t i = tile + w * 1024 + r * 64 + lane;
+    for (int r = 0; r < R; r++) {
+        const int64_t i = tile + w * (64 * R) + r * 64 + lane;
         const bool act = i < n;
         k[r] = act ? kin[i] : 0ull;
         v[r] = (VALS && act) ? vin[i] : 0u;
@@ -176,8 +195,8 @@ static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const uns
     __syncthreads();
     unsigned short *myoff = woff + w * 1024;
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
-        const bool act = tile + w * 1024 + r * 64 + lane < n;
+    for (int r = 0; r < R; r++) {
+        const bool act = tile + w * (64 * R) + r * 64 + lane < n;
         const int d = (int)((k[r] >> shift) & 1023ull);
         unsigned long long peers = __ballot(act);
 #pragma unroll
@@ -206,8 +225,8 @@ static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const uns
         for (int q = 0; q < w; q++) pre += wsum[q];
         // pre = local start of digit d0, pre + c0 = local start of digit d0 + 1
         int s0 = pre, s1 = pre + c0;
-        delta[d0] = (unsigned)offs[(int64_t)blockIdx.x * 1024 + d0] - (unsigned)s0;
-        delta[d0 + 1] = (unsigned)offs[(int64_t)blockIdx.x * 1024 + d0 + 1] - (unsigned)s1;
+        delta[d0] = (unsigned)offs[(int64_t)tb * 1024 + d0] - (unsigned)s0;
+        delta[d0 + 1] = (unsigned)offs[(int64_t)tb * 1024 + d0 + 1] - (unsigned)s1;
 #pragma unroll
         for (int q = 0; q < 8; q++) {
             const int a0 = woff[q * 1024 + d0], a1 = woff[q * 1024 + d0 + 1];
@@ -218,7 +237,7 @@ static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const uns
     }
     __syncthreads();
 #pragma unroll
-    for (int r = 0; r < 16; r++) {
+    for (int r = 0; r < R; r++) {
         const unsigned inf = info[r];
         const bool act = inf >> 31;
         const int d = (int)((inf >> 16) & 1023u), rank = (int)(inf & 255u), mine = (int)((inf >> 8) & 255u) + 1;
@@ -257,7 +276,7 @@ static thread_local Arena *tl_sort_arena = nullptr;
 static inline int64_t sorter_tmp_elems(int64_t hist_n) { return hist_n / RS_GROUP + 3 * 1024 + 64; }
 static inline int64_t sorter_hist_elems(int64_t n) {
     int64_t nb8 = (n + RS_TILE - 1) / RS_TILE; if (nb8 < 1) nb8 = 1;
-    int64_t nb10 = (n + 8191) / 8192; if (nb10 < 1) nb10 = 1;
+    int64_t nb10 = (n + RSS_KTILE - 1) / RSS_KTILE; if (nb10 < 1) nb10 = 1;      // (the smaller of the two 10-bit tiles)
     int64_t a = 256 * nb8, b = 1024 * nb10;
     return a > b ? a : b;
 }
@@ -267,7 +286,7 @@ static int sorter_init(Sorter &S, hite_ctx *ctx, hipStream_t st, int64_t n) {
     HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         RSS_LDS_BYTES));
     HITE_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(rs_scatter_staged_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        RSS_LDS_BYTES));
+                                        RSS_KLDS_BYTES));
     S.hist_n = sorter_hist_elems(n);
     if (tl_sort_arena) {
         void *p;
@@ -305,14 +324,15 @@ static int sorter_sort_bits_impl(Sorter &S, unsigned long long **keys_io, unsign
     static const long long wide_min = [] { const char *e = getenv("HITE_SORT_WIDE_MIN"); return e && *e ? atoll(e) : (long long)RS_WIDE_MIN; }();
     const bool wide = n >= wide_min;
     const int bits = wide ? 10 : 8;
-    const int tile = wide ? 8192 : RS_TILE;
+    const int tile = wide ? (vals ? RSS_TILE : RSS_KTILE) : RS_TILE;
     int nblocks = (int)((n + tile - 1) / tile);
     unsigned long long *ka = keys, *kb = S.k2;
     unsigned *va = vals, *vb = vals ? S.v2 : nullptr;      // vals == NULL: keys only (8 instead of 12 bytes moved per element and pass)
     int passes = (hi_bit - lo_bit + bits - 1) / bits;
     for (int p = 0; p < passes; p++) {
         const int sh = lo_bit + p * bits;
-        if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<10, 32>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
+        if (wide && vals) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<10, 32>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
+        else if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<10, RSS_KTILE / 256>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
         {
             const int ngroups = (nblocks + RS_GROUP - 1) / RS_GROUP;
@@ -330,7 +350,7 @@ static int sorter_sort_bits_impl(Sorter &S, unsigned long long **keys_io, unsign
             }
         }
         if (wide && vals) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_staged_kernel<true>), dim3(nblocks), dim3(512), RSS_LDS_BYTES, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
-        else if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_staged_kernel<false>), dim3(nblocks), dim3(512), RSS_LDS_BYTES, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
+        else if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_staged_kernel<false>), dim3(nblocks), dim3(512), RSS_KLDS_BYTES, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_scatter_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, va, kb, vb, n, sh, nblocks, S.offs);
         unsigned long long *tk = ka; ka = kb; kb = tk;
         unsigned *tv = va; va = vb; vb = tv;
