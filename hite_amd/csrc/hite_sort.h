@@ -143,14 +143,21 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
 
 // 10-bit scatter with the tile staged in LDS in output order.  The direct form above writes every element to its final
 // position as it is ranked: 256 elements per round land in up to 256 different bins and HBM sees partial-line writes
-// (PMC: 3x the algorithmic write bytes).  Here a block of 8 wavefronts owns a tile of 8192 elements (wave w: the contiguous
-// chunk [1024 w, 1024 w + 1024), 16 coalesced rounds, keys / values held in registers), ranks them stably inside the tile
+// (PMC: 3x the algorithmic write bytes).  Here a block of 8 wavefronts owns a tile of 512 R elements (wave w: the contiguous
+// chunk [64 R w, 64 R (w + 1)), R coalesced rounds, keys / values held in registers), ranks them stably inside the tile
 // (per-wave digit counts -> offsets; ballots for the rank inside a round), writes them to LDS in digit order and streams
-// the runs out: the average run of a digit is 8 consecutive elements (64 B of keys).
-// LDS: keys 64 KB | values 32 KB | per-wave digit offsets u16 [8][1024] 16 KB | run shift u32 [1024] 4 KB | scan 64 B.
-// Keys only (round 6): no values in LDS, and a tile of 14 instead of 16 rounds -- 76 KB, so that TWO workgroups share a compute unit and
-// one loads or streams out while the other ranks (with one, 116 KB, the three phases of a tile ran one behind the other).
-#define RSS_TILE 8192
+// the runs out.
+// LDS: keys 8 B x tile | values 4 B x tile | per-wave digit offsets u16 [8][1024] 16 KB | run shift u32 [1024] 4 KB | scan 64 B.
+// Round 6, two things that only pay TOGETHER (the 713 M anchor sort of stage 3.1: 21.0 ms as it was, 21.0 with the first alone,
+// 20.6 with the second alone, 14.7 with both; R = 8 / 10 keys only: 15.7 / 15.9):
+//  * two workgroups per compute unit -- keys only R = 14 (76 KB, no value area; runs of 7 keys), keys + values R = 9 (74.5 KB,
+//    runs of 4.5; 16 -> 9 took the index sort from 7.9 to 6.7 ms): one loads or streams out while the other ranks;
+//  * tiles that follow each other in the input on ONE chiplet (below): a digit's output line is finished by the next few tiles,
+//    and with those on other chiplets every L2 sent its part of the line to memory on its own.
+#ifndef RSS_VROUNDS
+#define RSS_VROUNDS 9
+#endif
+#define RSS_TILE (512 * RSS_VROUNDS)
 #define RSS_LDS_BYTES (RSS_TILE * 12 + 8 * 1024 * 2 + 1024 * 4 + 64)
 #ifndef RSS_KROUNDS
 #define RSS_KROUNDS 14
@@ -165,7 +172,7 @@ static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const uns
                                                                        unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
                                                                        int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
     extern __shared__ unsigned char rss_lds[];
-    constexpr int R = VALS ? 16 : RSS_KROUNDS, TILE = 512 * R, ESZ = VALS ? 12 : 8;
+    constexpr int R = VALS ? RSS_VROUNDS : RSS_KROUNDS, TILE = 512 * R, ESZ = VALS ? 12 : 8;
     unsigned long long *skey = reinterpret_cast<unsigned long long *>(rss_lds);
     unsigned *sval = reinterpret_cast<unsigned *>(rss_lds + TILE * 8);                            // (VALS only)
     unsigned short *woff = reinterpret_cast<unsigned short *>(rss_lds + TILE * ESZ);              // [8][1024]
@@ -276,7 +283,8 @@ static thread_local Arena *tl_sort_arena = nullptr;
 static inline int64_t sorter_tmp_elems(int64_t hist_n) { return hist_n / RS_GROUP + 3 * 1024 + 64; }
 static inline int64_t sorter_hist_elems(int64_t n) {
     int64_t nb8 = (n + RS_TILE - 1) / RS_TILE; if (nb8 < 1) nb8 = 1;
-    int64_t nb10 = (n + RSS_KTILE - 1) / RSS_KTILE; if (nb10 < 1) nb10 = 1;      // (the smaller of the two 10-bit tiles)
+    const int64_t t10 = RSS_KTILE < RSS_TILE ? RSS_KTILE : RSS_TILE;               // (the smaller of the two 10-bit tiles)
+    int64_t nb10 = (n + t10 - 1) / t10; if (nb10 < 1) nb10 = 1;
     int64_t a = 256 * nb8, b = 1024 * nb10;
     return a > b ? a : b;
 }
@@ -331,7 +339,7 @@ static int sorter_sort_bits_impl(Sorter &S, unsigned long long **keys_io, unsign
     int passes = (hi_bit - lo_bit + bits - 1) / bits;
     for (int p = 0; p < passes; p++) {
         const int sh = lo_bit + p * bits;
-        if (wide && vals) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<10, 32>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
+        if (wide && vals) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<10, RSS_TILE / 256>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
         else if (wide) hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<10, RSS_KTILE / 256>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
         else hipLaunchKernelGGL(HIP_KERNEL_NAME(rs_hist_kernel<8, 8>), dim3(nblocks), dim3(256), 0, S.st, ka, n, sh, nblocks, S.hist);
         {
