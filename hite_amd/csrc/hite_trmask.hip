@@ -23,6 +23,17 @@
 #define TR_TILE 256          // words per workgroup
 #define TR_HALO 34           // words behind the tile a period of <= 500 bases reaches (32) + the funnel's second word + 1
 
+// A seed's extension is the rare, heavy path of the scan: two banded extensions (thousands of instructions) in the ONE lane that found the
+// seed while its 63 neighbours wait, 0.3 times per wavefront and tile on random sequence -- as much as the wavefront's whole scan.  The
+// kernel therefore only LISTS the seeds (start, period), and tr_extend_kernel extends them a lane each, 64 side by side; the mask bits
+// are OR-ed, so the order does not matter.  A full list (cap entries) sends the seed down the old path.
+__device__ __forceinline__ bool tr_defer_push(unsigned long long *list, unsigned long long cap, unsigned long long *count, int64_t s, int p) {
+    const unsigned long long at = atomicAdd(count, 1ull);
+    if (at >= cap) return false;
+    list[at] = ((unsigned long long)s << 10) | (unsigned long long)p;
+    return true;
+}
+
 // >>> tr_seed (tests/test_host_compiled.py compiles this block for the host and runs it thread by thread against the twin)
 __device__ __forceinline__ int tr_contig_of(const int64_t *__restrict__ coff, int nc, int64_t g) {
     int lo = 0, hi = nc;
@@ -40,7 +51,10 @@ __device__ __forceinline__ uint32_t spread16(uint32_t x) {
 }
 __device__ __forceinline__ uint32_t tr_funnel(uint32_t hi, uint32_t lo, int sh) { return sh ? (lo >> sh) | (hi << (32 - sh)) : lo; }
 
-struct TrTile { uint32_t b[TR_TILE + TR_HALO + 2], nx[TR_TILE + TR_HALO + 2]; };   // index 0 = word w0 - 1
+struct TrTile {
+    uint32_t b[TR_TILE + TR_HALO + 2], nx[TR_TILE + TR_HALO + 2];   // index 0 = word w0 - 1
+    unsigned long long *dlist, dcap, *dcount;                        // where seeds are listed for tr_extend_kernel (null: extended on the spot)
+};
 
 // entry k of the tile of the workgroup that owns words w0 .. w0 + TR_TILE - 1
 __device__ __forceinline__ void tr_tile_load(TrTile &T, int k, int64_t w0, int64_t nwords, int64_t G, const uint32_t *__restrict__ bases,
@@ -120,6 +134,7 @@ __device__ __noinline__ void tr_seed_hit(const TrTile &T, int wl, int blk, uint3
         prev = ((pb >> (((s - st) & 8) ? 16 : 0)) & 0x5555u) == 0u;
     }
     if (prev && (s % TR_RESEED) != 0 && s - st >= coff[tr_contig_of(coff, nc, s)]) return;   // (a run may cross a contig border)
+    if (T.dlist && tr_defer_push(T.dlist, T.dcap, T.dcount, s, p)) return;
     tr_extend(s, p, bases, nmask, coff, nc, trmask);
 }
 
@@ -200,14 +215,29 @@ __device__ __forceinline__ void tr_thread(const TrTile &T, int tid, int64_t w0, 
 
 __global__ void __launch_bounds__(256) tr_seed_kernel(const uint32_t *__restrict__ bases, const uint32_t *__restrict__ nmask,
                                                       const int64_t *__restrict__ coff, int nc, int64_t G, int max_period,
-                                                      uint32_t *__restrict__ trmask) {
+                                                      uint32_t *__restrict__ trmask, unsigned long long *__restrict__ dlist,
+                                                      unsigned long long dcap, unsigned long long *__restrict__ dcount) {
     __shared__ TrTile T;
+    if (threadIdx.x == 0) { T.dlist = dlist; T.dcap = dcap; T.dcount = dcount; }
     const int64_t nwords = (G + 15) >> 4;
     for (int64_t w0 = (int64_t)blockIdx.x * TR_TILE; w0 < nwords; w0 += (int64_t)gridDim.x * TR_TILE) {
         __syncthreads();
         for (int k = threadIdx.x; k < TR_TILE + TR_HALO + 2; k += 256) tr_tile_load(T, k, w0, nwords, G, bases, nmask);
         __syncthreads();
         tr_thread(T, (int)threadIdx.x, w0, nwords, G, max_period, bases, nmask, coff, nc, trmask);
+    }
+}
+
+// the listed seeds, a lane each
+__global__ void __launch_bounds__(256) tr_extend_kernel(const unsigned long long *__restrict__ dlist, unsigned long long dcap,
+                                                        const unsigned long long *__restrict__ dcount, const uint32_t *__restrict__ bases,
+                                                        const uint32_t *__restrict__ nmask, const int64_t *__restrict__ coff, int nc,
+                                                        uint32_t *__restrict__ trmask) {
+    unsigned long long n = *dcount;
+    if (n > dcap) n = dcap;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (unsigned long long)gridDim.x * 256) {
+        const unsigned long long v = dlist[e];
+        tr_extend((int64_t)(v >> 10), (int)(v & 1023ull), bases, nmask, coff, nc, trmask);
     }
 }
 
@@ -232,9 +262,13 @@ extern "C" int hite_tr_mask(hite_ctx *ctx, int32_t max_period, uint32_t *mask_bi
     uint32_t *trmask = nullptr;
     unsigned long long *cnt = nullptr;
     const int64_t cnt_at = (nw32 + 3) & ~(int64_t)1;          // 8-byte aligned word index behind the bit map
-    HITE_CHECK(ctx, hipMalloc((void **)&trmask, (size_t)(cnt_at + 4) * 4));
+    // the seed list lives behind the bit map and its counter: one entry per 64 bases (at least 2^20); HITE_TR_DEFER=0: no list
+    static const bool defer = [] { const char *v = getenv("HITE_TR_DEFER"); return !(v && *v == '0'); }();
+    const unsigned long long dcap = defer ? (unsigned long long)((G >> 6) > (1ll << 20) ? (G >> 6) : (1ll << 20)) : 0ull;
+    HITE_CHECK(ctx, hipMalloc((void **)&trmask, (size_t)(cnt_at + 4) * 4 + (size_t)dcap * 8));
     hipError_t e = hipMemset(trmask, 0, (size_t)(cnt_at + 4) * 4);
     cnt = (unsigned long long *)(trmask + cnt_at);
+    unsigned long long *dcount = cnt + 1, *dlist = dcap ? (unsigned long long *)(trmask + cnt_at + 4) : nullptr;
     int rc = HITE_OK;
     if (e == hipSuccess) {
         const int64_t nwords = (G + 15) >> 4;
@@ -242,7 +276,9 @@ extern "C" int hite_tr_mask(hite_ctx *ctx, int32_t max_period, uint32_t *mask_bi
         if (blocks > 65536) blocks = 65536;
         if (blocks < 1) blocks = 1;
         hipLaunchKernelGGL(tr_seed_kernel, dim3((unsigned)blocks), dim3(256), 0, nullptr, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off, ctx->n_contigs, G,
-                           (int)max_period, trmask);
+                           (int)max_period, trmask, dlist, dcap, dcount);
+        if (dlist) hipLaunchKernelGGL(tr_extend_kernel, dim3(2048), dim3(256), 0, nullptr, dlist, dcap, dcount, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
+                                      ctx->n_contigs, trmask);
         hipLaunchKernelGGL(tr_apply_kernel, dim3((unsigned)((nw32 + 255) / 256)), dim3(256), 0, nullptr, nw32, trmask, ctx->d_nmask, cnt);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipDeviceSynchronize();

@@ -267,6 +267,7 @@ def test_tr_seed_kernel_logic_vs_twin(tmp_path):
 #define TR_TILE 256
 #define TR_HALO 34
 static inline void atomicOr(uint32_t *p, uint32_t v) { *p |= v; }
+static inline bool tr_defer_push(unsigned long long *, unsigned long long, unsigned long long *, int64_t, int) { return false; }   // (no list on the host)
 """ + body, r"""
 extern "C" void host_tr_mask(const uint32_t *bases, const uint32_t *nmask, const int64_t *coff, int nc, int64_t G, int max_period, uint32_t *trmask) {
     static TrTile T;
