@@ -860,8 +860,10 @@ def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
         stage_ms[name] = stage_ms.get(name, 0.0) + 1000.0 * (t1 - t0)
         return t1
 
-    def inner_step():
-        ctx.copy_index_build()
+    def inner_step(fresh=True):
+        # fresh: every step computes the genome's minimizers -- nothing kept from the step before.  Inside the end-to-end step the build
+        # follows the prev_TE step on the same packed chunk and redoes only the masked tiles (hite_copy_index_forget in include/hite_gpu.h)
+        ctx.copy_index_build(fresh=fresh)
         (oc, os_, oe), st = ctx.coarse_stage_dev(1_000_000, sc, so, 4000, 30000)
         return st, (oc, os_, oe)
 
@@ -881,7 +883,7 @@ def coarse_block(ctx, args, mbp, n_tir, n_ltr, torch, with_cpu, w=None):
             ctx.genome_mask(cc, ss, ee)
             n_masked_copies = len(cc)
         t0 = lap("prev_te_mask", t0)
-        st, (oc, os_, oe) = inner_step()    # (builds the index of the masked chunk first)
+        st, (oc, os_, oe) = inner_step(fresh=False)    # (builds the index of the masked chunk first)
         t0 = lap("index_search_fmea", t0)
         nb = ctx.flanking_seq_dev(oc, os_, oe, 50)
         t0 = lap("flank_gather", t0)
@@ -1197,7 +1199,7 @@ def coarse_stage(args):
     sc, so = ctx.seed_segments(1_000_000)
 
     def step():
-        ctx.copy_index_build()                      # the index is part of the step here (rebuilt on the same handle)
+        ctx.copy_index_build(fresh=True)            # the index is part of the step here (rebuilt on the same handle, from the genome: no kept minimizer tiles)
         (oc, _os, _oe), st = ctx.coarse_stage_dev(1_000_000, sc, so, 4000, 30000)   # the HSP table never leaves the device
         return st, len(oc)
 

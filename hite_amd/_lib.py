@@ -483,9 +483,12 @@ class Context:
         cf = cf.tolist()
         return [rows[cf[c]:cf[c + 1]] for c in range(len(cands))]
 
-    def copy_index_build(self, stream=0):
+    def copy_index_build(self, stream=0, fresh=False):
+        """fresh: the minimizer tiles the handle keeps from its last build are dropped first (hite_copy_index_forget)"""
         if getattr(self, "_copy_state", None) is None:
             self._copy_state = C.c_void_p(None)
+        if fresh:
+            self.lib.hite_copy_index_forget(self._copy_state)
         self._check(self.lib.hite_copy_index_build(self.h, C.byref(self._copy_state), C.c_void_p(stream)), "hite_copy_index_build")
 
     def find_copies_dev(self, n_cand, d_cand, d_cand_off, cand_bytes, stream=0):

@@ -43,6 +43,11 @@ struct hite_ctx {
     int64_t *h_contig_off;
     int32_t n_contigs;
     int64_t n_bases;
+    // what happened to the packed genome (hite_copies.hip keeps the minimizer tiles of an index build and redoes only those a mask touched):
+    // the epoch counts every change other than hite_genome_mask, whose intervals since then are logged (global positions, half open)
+    int64_t genome_epoch;
+    int64_t *mask_log;          // pairs
+    int64_t mask_log_n, mask_log_cap;
     // grow-only scratch
     void *d_scratch;
     size_t scratch_bytes;

@@ -49,6 +49,10 @@ struct CopyState {
     int64_t *d_scal = nullptr;
     const uint32_t *out_clip = nullptr;   // per copy record of the last call (in `out`): candidate bases clipped left | right << 16 (hite_copy_clips_dev)
     int64_t out_n = 0;
+    // the minimizer tiles of the last index build (still in the build arena): valid for THIS genome state (hite_ctx::genome_epoch) up to
+    // entry kept_log of its mask log; a build on the same state redoes only the tiles masked since (index_build_impl)
+    const void *kept_stage = nullptr, *kept_cnt = nullptr, *kept_ctx = nullptr;
+    int64_t kept_epoch = -1, kept_log = 0, kept_G = -1;
     int64_t last[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // last call: candidate minimizers, hits, clusters, copies (before the 300 cap); chains with a long / short end to extend, extension columns
 };
 
@@ -168,13 +172,15 @@ __global__ void __launch_bounds__(256) genome_minimizer_kernel(const uint32_t *_
                                                                const int64_t *__restrict__ coff, int nc, int64_t G, int64_t ntiles,
                                                                unsigned long long *__restrict__ stage /* [ntiles][GM_TILE] */,
                                                                int32_t *__restrict__ tile_cnt,
-                                                               HSet hset /* tab null: every minimizer */) {
+                                                               HSet hset /* tab null: every minimizer */,
+                                                               const int32_t *__restrict__ tile_list = nullptr /* only these tiles (ntiles = their number) */) {
     __shared__ unsigned sh[GM_TILE + CW + 8];   // sh[q] = hs of the k-mer starting at p0 - 1 + q
     __shared__ short wm[GM_TILE + 8];           // wm[q] = index into sh of the minimizer of the window starting at p0 - 1 + q (-1: none)
     constexpr int PER = GM_TILE / 256;
     __shared__ int s_cnt[PER][4];               // emitted per round and wavefront
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    for (int64_t it = blockIdx.x; it < ntiles; it += gridDim.x) {
+        const int64_t tile = tile_list ? (int64_t)tile_list[it] : it;
         const int64_t p0 = tile * GM_TILE;
         // a tile and its halo nearly always lie inside ONE contig: its bounds are looked up once (every thread, the same
         // cached words) instead of once per k-mer and once per window
@@ -276,6 +282,41 @@ __global__ void __launch_bounds__(256) genome_minimizer_pack_kernel(int64_t ntil
         const unsigned long long slot = (unsigned long long)a + (unsigned long long)r;
         if (slot < cap) { out[slot] = reg[r]; out_rank[slot] = (unsigned)slot; }
     }
+}
+
+// RESTRICTED index from kept tiles: the tiles hold every minimizer (so that the full index behind the same genome can use them again); a
+// wavefront per tile counts / moves the records whose hash is in the set (Bloom word first, then the table), in order
+template <bool WRITE>
+__global__ void __launch_bounds__(256) genome_minimizer_filter_kernel(int64_t ntiles, const unsigned long long *__restrict__ stage,
+                                                                      const int32_t *__restrict__ tile_cnt, HSet hset,
+                                                                      int32_t *__restrict__ cnt_out, const int64_t *__restrict__ first,
+                                                                      unsigned long long *__restrict__ out, unsigned *__restrict__ out_rank,
+                                                                      unsigned long long cap) {
+    const int lane = threadIdx.x & 63;
+    const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (tile >= ntiles) return;
+    const int n = tile_cnt[tile];
+    const unsigned long long *reg = stage + tile * GM_TILE;
+    unsigned long long at = WRITE ? (unsigned long long)first[tile] : 0ull;
+    int c = 0;
+    for (int r0 = 0; r0 < n; r0 += 64) {
+        const int r = r0 + lane;
+        unsigned long long rec = 0ull;
+        bool want = false;
+        if (r < n) {
+            rec = reg[r];
+            const unsigned h31 = (unsigned)(rec >> 33);
+            const unsigned b = hset_bit(hset, h31);
+            want = ((hset.bits[b >> 5] >> (b & 31)) & 1u) && hset_probe(hset, h31);
+        }
+        const unsigned long long bal = __ballot(want);
+        if (WRITE) {
+            const unsigned long long slot = at + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+            if (want && slot < cap) { out[slot] = rec; out_rank[slot] = (unsigned)slot; }
+            at += (unsigned long long)__popcll(bal);
+        } else c += __popcll(bal);
+    }
+    if (!WRITE && lane == 0) cnt_out[tile] = c;
 }
 
 // the sorted keys apart: hash | strand and position of every index entry
@@ -1014,6 +1055,7 @@ static int index_build_impl(hite_ctx *ctx, void **state_io, hipStream_t st, HSet
         S->idx_cap = (int64_t)cap;
     }
     if (!S->dir) HITE_CHECK(ctx, hipMalloc((void **)&S->dir, (size_t)((1 << DIRBITS) + 2) * 4));
+    const bool one_chunk = S->build.chunks.size() == 1;       // (more: the reset below rebuilds the arena, and what it held is gone)
     CCHK(arena_reset(ctx, S->build, true));
     Arena &B = S->build;
     void *p;
@@ -1021,26 +1063,76 @@ static int index_build_impl(hite_ctx *ctx, void **state_io, hipStream_t st, HSet
     unsigned long long *keys, *stage;
     unsigned *vals;
     int32_t *tile_cnt; int64_t *tile_first, *tbs;
+    // (kept tiles: every build on a handle allocates the same things in the same order, so the tiles of the last build are where the
+    // new ones go -- unless the arena was rebuilt, which the pointers below and the chunk count tell)
+    static const bool keep_on = [] { const char *v = getenv("HITE_KEEP_MINIMIZERS"); return !(v && *v == '0'); }();
     CCHK(arena_alloc(ctx, B, (size_t)cap * 8, &p)); keys = (unsigned long long *)p;
     CCHK(arena_alloc(ctx, B, (size_t)cap * 4, &p)); vals = (unsigned *)p;
     CCHK(arena_alloc(ctx, B, (size_t)(ntiles + 1) * 4, &p)); tile_cnt = (int32_t *)p;
     CCHK(arena_alloc(ctx, B, (size_t)(ntiles + 2) * 8, &p)); tile_first = (int64_t *)p;
     CCHK(arena_alloc(ctx, B, (size_t)scan_tmp_elems(ntiles + 1) * 8, &p)); tbs = (int64_t *)p;
     CCHK(arena_alloc(ctx, B, (size_t)(ntiles > 0 ? ntiles : 1) * GM_TILE * 8, &p)); stage = (unsigned long long *)p;
+    int32_t *tile_cnt_r = nullptr;       // restricted build from kept tiles: the filtered counts
+    if (keep_on && hset.tab) { CCHK(arena_alloc(ctx, B, (size_t)(ntiles + 1) * 4, &p)); tile_cnt_r = (int32_t *)p; }
     int64_t blocks = ntiles < 256 * 64 ? ntiles : 256 * 64;
     if (blocks < 1) blocks = 1;
     int tk_gm = hite_prof_begin(ctx, "index_minimizers", st);
-    if (hset.tab)
-        hipLaunchKernelGGL(genome_minimizer_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
-                           ctx->n_contigs, G, ntiles, stage, tile_cnt, hset);
-    else
-        hipLaunchKernelGGL(genome_minimizer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
-                           ctx->n_contigs, G, ntiles, stage, tile_cnt, hset);
+    const HSet none{nullptr, nullptr, 0, 0};
+    if (!keep_on) {
+        S->kept_epoch = -1;
+        if (hset.tab)
+            hipLaunchKernelGGL(genome_minimizer_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
+                               ctx->n_contigs, G, ntiles, stage, tile_cnt, hset, (const int32_t *)nullptr);
+        else
+            hipLaunchKernelGGL(genome_minimizer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
+                               ctx->n_contigs, G, ntiles, stage, tile_cnt, none, (const int32_t *)nullptr);
+    } else {
+        // the tiles always hold EVERY minimizer (a restricted build filters them below).  Kept from the last build on this genome state:
+        // only the tiles a mask has touched since are done again -- window starts [a - K - W - 2, b + 2] of a masked [a, b): a window
+        // reads the k-mers of W starts and a k-mer K bases, and a window's record also depends on the window before it
+        const bool kept = one_chunk && S->kept_stage == stage && S->kept_cnt == tile_cnt && S->kept_ctx == ctx && S->kept_G == G &&
+                          S->kept_epoch == ctx->genome_epoch && S->kept_log <= ctx->mask_log_n;
+        S->kept_epoch = -1;                       // (void until this build's kernels are queued)
+        if (!kept)
+            hipLaunchKernelGGL(genome_minimizer_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask, ctx->d_contig_off,
+                               ctx->n_contigs, G, ntiles, stage, tile_cnt, none, (const int32_t *)nullptr);
+        else if (S->kept_log < ctx->mask_log_n) {
+            std::vector<unsigned char> dirty((size_t)ntiles, 0);
+            for (int64_t k = S->kept_log; k < ctx->mask_log_n; k++) {
+                int64_t lo = ctx->mask_log[2 * k] - CK - CW - 2, hi = ctx->mask_log[2 * k + 1] + 2;
+                if (lo < 0) lo = 0;
+                if (hi > G - 1) hi = G - 1;
+                for (int64_t t = lo / GM_TILE; t <= hi / GM_TILE && t < ntiles; t++) dirty[(size_t)t] = 1;
+            }
+            std::vector<int32_t> list;
+            for (int64_t t = 0; t < ntiles; t++) if (dirty[(size_t)t]) list.push_back((int32_t)t);
+            if (!list.empty()) {
+                int32_t *d_list;
+                CCHK(arena_alloc(ctx, B, list.size() * 4, &p)); d_list = (int32_t *)p;
+                HITE_CHECK(ctx, hipMemcpyAsync(d_list, list.data(), list.size() * 4, hipMemcpyHostToDevice, st));
+                HITE_CHECK(ctx, hipStreamSynchronize(st));          // (the list is a local)
+                const int64_t nl = (int64_t)list.size();
+                hipLaunchKernelGGL(genome_minimizer_kernel<false>, dim3((unsigned)(nl < blocks ? nl : blocks)), dim3(256), 0, st, ctx->d_bases, ctx->d_nmask,
+                                   ctx->d_contig_off, ctx->n_contigs, G, nl, stage, tile_cnt, none, (const int32_t *)d_list);
+            }
+        }
+        S->kept_stage = stage; S->kept_cnt = tile_cnt; S->kept_ctx = ctx; S->kept_G = G;
+        S->kept_epoch = ctx->genome_epoch; S->kept_log = ctx->mask_log_n;
+    }
     int64_t M = 0;
     if (ntiles > 0) {
-        CCHK(scan_excl_buf<int32_t>(ctx, tbs, tile_cnt, ntiles, tile_first, st));
-        HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, tile_first + ntiles, 8, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(genome_minimizer_pack_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, ntiles, stage, tile_first, keys, vals, cap);
+        if (tile_cnt_r) {
+            hipLaunchKernelGGL(genome_minimizer_filter_kernel<false>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, ntiles, stage, tile_cnt, hset,
+                               tile_cnt_r, (const int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr, cap);
+            CCHK(scan_excl_buf<int32_t>(ctx, tbs, tile_cnt_r, ntiles, tile_first, st));
+            HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, tile_first + ntiles, 8, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(genome_minimizer_filter_kernel<true>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, ntiles, stage, tile_cnt, hset,
+                               (int32_t *)nullptr, tile_first, keys, vals, cap);
+        } else {
+            CCHK(scan_excl_buf<int32_t>(ctx, tbs, tile_cnt, ntiles, tile_first, st));
+            HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, tile_first + ntiles, 8, hipMemcpyDeviceToDevice, st));
+            hipLaunchKernelGGL(genome_minimizer_pack_kernel, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, ntiles, stage, tile_first, keys, vals, cap);
+        }
         hite_prof_end(ctx, tk_gm, st);
         HITE_CHECK(ctx, hipGetLastError());
         CCHK(read_back(ctx, S, st, 1));
@@ -1070,6 +1162,10 @@ static int index_build_impl(hite_ctx *ctx, void **state_io, hipStream_t st, HSet
     return HITE_OK;
 }
 
+extern "C" int hite_copy_index_forget(void *state) {
+    if (state) ((CopyState *)state)->kept_epoch = -1;
+    return HITE_OK;
+}
 extern "C" int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream) {
     return index_build_impl(ctx, state_io, (hipStream_t)stream, HSet{nullptr, nullptr, 0, 0});
 }

@@ -40,12 +40,15 @@ static void free_genome(hite_ctx *c) {
     c->h_contig_off = nullptr;
     c->n_contigs = 0;
     c->n_bases = 0;
+    c->genome_epoch++;
+    c->mask_log_n = 0;
 }
 
 extern "C" void hite_ctx_destroy(hite_ctx *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     free_genome(c);
+    free(c->mask_log);
     hite_align_release(c);
     hite_fmea_release(c);
     if (c->d_scratch) (void)hipFree(c->d_scratch);
@@ -241,6 +244,25 @@ extern "C" int hite_genome_mask(hite_ctx *ctx, int64_t n, const int32_t *contig,
     if (!ctx || !ctx->d_bases || n < 0 || (n > 0 && (!contig || !start1 || !end1))) return HITE_EINVAL;
     if (n == 0) return HITE_OK;
     HITE_CHECK(ctx, hipSetDevice(ctx->device));
+    // the log of what gets masked (the kernel's own clamping), for the index build that follows
+    if (ctx->mask_log_n + n > ctx->mask_log_cap) {
+        const int64_t cap = 2 * (ctx->mask_log_n + n) + 1024;
+        int64_t *q = (int64_t *)realloc(ctx->mask_log, (size_t)cap * 2 * sizeof(int64_t));
+        if (!q) return HITE_ENOMEM;
+        ctx->mask_log = q; ctx->mask_log_cap = cap;
+    }
+    for (int64_t k = 0; k < n; k++) {
+        const int c = contig[k];
+        if (c < 0 || c >= ctx->n_contigs) continue;
+        int64_t a = start1[k] - 1, b = end1[k];
+        const int64_t L = ctx->h_contig_off[c + 1] - ctx->h_contig_off[c];
+        if (a < 0) a = 0;
+        if (b > L) b = L;
+        if (b <= a) continue;
+        ctx->mask_log[2 * ctx->mask_log_n] = a + ctx->h_contig_off[c];
+        ctx->mask_log[2 * ctx->mask_log_n + 1] = b + ctx->h_contig_off[c];
+        ctx->mask_log_n++;
+    }
     int32_t *dc = nullptr; int64_t *ds = nullptr, *de = nullptr;
     hipError_t e = hipMalloc((void **)&dc, (size_t)n * 4);
     if (e == hipSuccess) e = hipMalloc((void **)&ds, (size_t)n * 8);

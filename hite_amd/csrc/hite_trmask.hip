@@ -287,6 +287,8 @@ extern "C" int hite_tr_mask(hite_ctx *ctx, int32_t max_period, uint32_t *mask_bi
         if (e == hipSuccess && mask_bits_host) e = hipMemcpy(mask_bits_host, trmask, (size_t)nw32 * 4, hipMemcpyDeviceToHost);
         if (masked_bases_out) *masked_bases_out = (int64_t)n;
     }
+    ctx->genome_epoch++;        // (kept minimizer tiles of an index build are void)
+    ctx->mask_log_n = 0;
     (void)hipFree(trmask);
     if (e != hipSuccess) { snprintf(ctx->err, sizeof(ctx->err), "hite_tr_mask: %s", hipGetErrorString(e)); rc = HITE_EHIP; }
     return rc;

@@ -298,6 +298,12 @@ int hite_itr_search_dev(hite_ctx *ctx, int64_t n, const uint8_t *d_seqs, const i
  * hite_flank_region_align consumes (1-based inclusive coordinates).  n_cand < 2^19 per call.
  * _dev: the returned device arrays live in the index state's arena until the next call. */
 int hite_copy_index_build(hite_ctx *ctx, void **state_io, void *stream);
+/* A build keeps the genome's minimizers (tiles of 2048 window starts, in the handle's build arena); the next build on the same handle and
+ * the same packed genome -- the restricted index of hite_find_copies_restricted, then the full index behind hite_genome_mask: stage 3.1's
+ * prev_TE step -- computes only the tiles a mask call has touched since, and gives the index a build from scratch gives (the kept tiles
+ * are void after hite_genome_pack* / hite_tr_mask; HITE_KEEP_MINIMIZERS=0 keeps nothing).  hite_copy_index_forget drops them: the next
+ * build starts from the genome (what a benchmark that times repeated builds of one genome wants).  state NULL: no-op. */
+int hite_copy_index_forget(void *state);
 /* which interval the copy records of hite_find_copies[_dev] carry (process-wide DEFAULT, for contexts without a setting of their own): 1 = the ALIGNED interval, reference_start + 1 ..
  * reference_end exactly as get_copies_minimap2 reports it (Util.py:8026) -- the default since round 5, with the clipped candidate
  * bases handed on beside the records (hite_copy_clips) --; 0 = the interval of the WHOLE candidate, the ends that the extension clipped

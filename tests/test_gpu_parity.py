@@ -544,6 +544,72 @@ def test_find_copies_restricted_index(ctx):
     assert ctx.find_copies(["ACGT", "N" * 100], restricted=True) == [[], []]
 
 
+def test_index_build_from_kept_minimizer_tiles(ctx):
+    """the index build keeps its minimizer tiles; a build on the same genome state redoes only the tiles hite_genome_mask touched since
+    (restricted index -> copies -> mask -> full index: stage 3.1's prev_TE step).  The index behind it must be the one a fresh context
+    builds from the masked genome: copy tables, all-vs-all HSP table (every index entry and its rank) -- with masks at contig starts and
+    ends, across tile borders (2048 window starts) and a second mask call on top; and HITE_KEEP_MINIMIZERS=0 (no kept tiles) agrees"""
+    import subprocess
+    import sys as _sys
+
+    import synth_small
+    from hite_amd import _lib
+
+    g = synth_small.make(31, n_fam=20)
+    contigs = list(g["contigs"])
+    cands = list(g["cands"])
+    ctx.genome_pack(contigs)
+    ctx.release_copy_index()
+    first = ctx.find_copies(cands[:8], restricted=True)          # full tile pass, tiles kept, restricted index filtered from them
+    assert first == O.find_copies(contigs, cands[:8])
+    assert ctx.find_copies(cands[4:12], restricted=True) == O.find_copies(contigs, cands[4:12])      # kept tiles, another filter
+    lens = [len(c) for c in contigs]
+    masks = [(0, 1, 30), (0, 2040, 2060), (0, 4090, 6200), (0, lens[0] - 25, lens[0]), (1, 1, 1), (1, 2047, 2049), (len(contigs) - 1, lens[-1] - 3000, lens[-1] + 50)]
+    rng = np.random.default_rng(5)
+    for _ in range(40):
+        c = int(rng.integers(0, len(contigs)))
+        a = int(rng.integers(1, lens[c]))
+        masks.append((c, a, min(lens[c], a + int(rng.integers(1, 900)))))
+
+    def masked(cs, ms):
+        arrs = [np.frombuffer(c.encode(), dtype=np.uint8).copy() for c in cs]
+        for c, s1, e1 in ms:
+            arrs[c][max(0, s1 - 1):e1] = ord("N")
+        return [a.tobytes().decode() for a in arrs]
+
+    ctx.genome_mask([m[0] for m in masks], [m[1] for m in masks], [m[2] for m in masks])
+    got_tab = ctx.find_copies(cands)                              # full index from kept tiles + the masked ones redone
+    got_hsp = ctx.seed_allvsall(seg_len=1_000_000)
+    more = [(0, 3000, 3100), (2, 1, 5000)]
+    ctx.genome_mask([m[0] for m in more], [m[1] for m in more], [m[2] for m in more])
+    got_tab2 = ctx.find_copies(cands[:6], restricted=True)        # second mask on top, restricted build from kept tiles
+    ctx.copy_index_build()
+    got_hsp2 = ctx.seed_allvsall(seg_len=1_000_000)
+    fresh = _lib.Context(0)
+    try:
+        m1 = masked(contigs, masks)
+        fresh.genome_pack(m1)
+        assert got_tab == fresh.find_copies(cands) == O.find_copies(m1, cands)
+        exp_hsp = fresh.seed_allvsall(seg_len=1_000_000)
+        m2 = masked(m1, more)
+        fresh.genome_pack(m2)
+        fresh.release_copy_index()
+        assert got_tab2 == fresh.find_copies(cands[:6]) == O.find_copies(m2, cands[:6])
+        exp_hsp2 = fresh.seed_allvsall(seg_len=1_000_000)
+    finally:
+        fresh.close()
+    for a, b in ((got_hsp, exp_hsp), (got_hsp2, exp_hsp2)):
+        for k in ("qseg", "sseg", "qs", "qe", "ss", "se"):
+            assert np.array_equal(a[k], b[k]), k
+        assert list(a["stats"]) == list(b["stats"]) and a["stats"][0] > 0
+    if os.environ.get("HITE_KEEP_MINIMIZERS") != "0":
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        rc = subprocess.run([_sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
+                             "kept_minimizer_tiles or restricted_index or mask_genome_intactTE"], env=dict(os.environ, HITE_KEEP_MINIMIZERS="0"),
+                            capture_output=True, text=True, cwd=root)
+        assert rc.returncode == 0, rc.stdout[-3000:] + rc.stderr[-2000:]
+
+
 def test_find_copies_interval_modes(ctx):
     """The records carry the ALIGNED interval, reference_start + 1 .. reference_end as get_copies_minimap2 reports it (Util.py:8026;
     the default since round 5), or -- hite_copy_config(0) / HITE_COPY_INTERVAL=whole -- the interval of the whole candidate (rounds
