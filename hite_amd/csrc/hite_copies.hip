@@ -1785,11 +1785,24 @@ __global__ void __launch_bounds__(256) seed_clusters_kernel(int64_t na, int64_t 
                                                             int32_t *__restrict__ tile_cnt, const int64_t *__restrict__ tile_first,
                                                             unsigned *__restrict__ c_first) {
     __shared__ int s_tmp[8];
-    const int64_t base = (int64_t)blockIdx.x * SF_TILE + (int64_t)threadIdx.x * SF_ITEMS;
-    unsigned long long k[SF_ITEMS + 1];
-    k[0] = base > 0 && base <= na ? akey[base - 1] : 0ull;
+    // the tile goes through LDS (round 6): a thread walks 8 CONSECUTIVE anchors, and read straight from memory that was 64 lanes 64 bytes
+    // apart in every load instruction (64 lines per instruction, each fetched 8 times).  Coalesced loads, 9-word rows against bank conflicts.
+    __shared__ unsigned long long s_k[SF_TILE + SF_TILE / 8 + 1];
+    const int64_t tile0 = (int64_t)blockIdx.x * SF_TILE;
+    const int64_t base = tile0 + (int64_t)threadIdx.x * SF_ITEMS;
 #pragma unroll
-    for (int q = 0; q < SF_ITEMS; q++) { const int64_t i = base + q; k[q + 1] = akey[i < na ? i : na - 1]; }
+    for (int q = 0; q < SF_ITEMS; q++) {
+        const int j = q * 256 + (int)threadIdx.x;
+        const int64_t i = tile0 + j;
+        s_k[1 + j + (j >> 3)] = akey[i < na ? i : na - 1];
+    }
+    if (threadIdx.x == 0) s_k[0] = tile0 > 0 && tile0 <= na ? akey[tile0 - 1] : 0ull;
+    __syncthreads();
+    unsigned long long k[SF_ITEMS + 1];
+    k[0] = s_k[threadIdx.x * 9];                    // (the anchor before the thread's first: slot 9 t is the pad behind thread t - 1's row...
+    if (threadIdx.x > 0) k[0] = s_k[threadIdx.x * 9 - 1];      //  ... so it is read from that row's last word)
+#pragma unroll
+    for (int q = 0; q < SF_ITEMS; q++) k[q + 1] = s_k[1 + threadIdx.x * 9 + q];
     unsigned bits = 0;
     int c = 0;
     SeedContigs cb = {0, 0, 0, 0};
