@@ -1622,9 +1622,15 @@ __device__ __forceinline__ bool seed_owned(const SeedShard &sh, unsigned long lo
 // large); sharded: the partners whose anchor this rank owns.  The seed's record -- index entry, place in its run, run size, partner
 // count -- goes to the seed's place in POSITION order (idx_t, left behind by the index build): the only scattered access; the
 // stages behind read it in order.
+// SPLIT (round 6, large genomes): the record stays in hash order as key = index entry << 32 | rank, value = the packed word, one radix pass
+// on the rank's top ten bits groups the records by stretches of the position order, and seed_place_kernel scatters inside such a stretch
+// -- a window of the record array that an L2 holds, so that memory sees whole lines (the direct scatter: one 32-byte sector per 8-byte
+// record, 5.7 GB written for 1.45 GB of records).
+template <bool SPLIT>
 __global__ void seed_count_kernel(int64_t M, int64_t G, const int32_t *__restrict__ rflag, const int64_t *__restrict__ rid,
                                   const unsigned *__restrict__ run_first, const unsigned long long *__restrict__ idx_key,
-                                  const unsigned *__restrict__ idx_t, SeedShard sh, uint2 *__restrict__ srec) {
+                                  const unsigned *__restrict__ idx_t, SeedShard sh, uint2 *__restrict__ srec,
+                                  unsigned long long *__restrict__ pk, unsigned *__restrict__ pv) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= M) return;
     const int64_t nrun = rid[M];
@@ -1649,7 +1655,28 @@ __global__ void seed_count_kernel(int64_t M, int64_t G, const int32_t *__restric
         }
     }
     // ONE 8-byte scatter per seed: index entry | place in its run (10 bits) | run size (10) | partners (10)
-    srec[t] = make_uint2((unsigned)i, occ <= SEED_MAXOCC ? (((unsigned)i - lo) | (occ << 10) | ((unsigned)c << 20)) : 0u);
+    const unsigned y = occ <= SEED_MAXOCC ? (((unsigned)i - lo) | (occ << 10) | ((unsigned)c << 20)) : 0u;
+    if (SPLIT) { pk[i] = ((unsigned long long)(unsigned)i << 32) | (unsigned long long)t; pv[i] = y; }
+    else srec[t] = make_uint2((unsigned)i, y);
+}
+// the grouped records to their places (and the partner counts beside them); the workgroups of a chiplet take consecutive tiles (as
+// rs_scatter_staged_kernel): the window they write into is theirs
+#define SPL_ITEMS 8
+__global__ void __launch_bounds__(256) seed_place_kernel(int64_t M, int nblocks, const unsigned long long *__restrict__ pk,
+                                                         const unsigned *__restrict__ pv, uint2 *__restrict__ srec, int32_t *__restrict__ cnt) {
+    const int x = (int)(blockIdx.x & 7u), bi = (int)(blockIdx.x >> 3), q8 = nblocks >> 3, rr = nblocks & 7;
+    const int64_t base = (int64_t)(x * q8 + (x < rr ? x : rr) + bi) * (256 * SPL_ITEMS);
+    unsigned long long k[SPL_ITEMS]; unsigned y[SPL_ITEMS];
+#pragma unroll
+    for (int q = 0; q < SPL_ITEMS; q++) {
+        const int64_t e = base + q * 256 + threadIdx.x;
+        k[q] = pk[e < M ? e : M - 1]; y[q] = pv[e < M ? e : M - 1];
+    }
+#pragma unroll
+    for (int q = 0; q < SPL_ITEMS; q++) {
+        const int64_t e = base + q * 256 + threadIdx.x;
+        if (e < M) { const unsigned t = (unsigned)k[q]; srec[t] = make_uint2((unsigned)(k[q] >> 32), y[q]); if (cnt) cnt[t] = (int32_t)(y[q] >> 20); }
+    }
 }
 __global__ void seed_cnt_kernel(int64_t M, const uint2 *__restrict__ srec, int32_t *__restrict__ cnt) {
     int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2049,8 +2076,33 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     CCHK(scan_excl_buf<int32_t>(ctx, bs, rflag, M, rid, st));
     hipLaunchKernelGGL(seed_runfirst_kernel, CGRID(M), 0, st, M, rflag, rid, run_first);
     const SeedShard shard = seed_shard_of(ctx, G);
-    hipLaunchKernelGGL(seed_count_kernel, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, srec);
-    hipLaunchKernelGGL(seed_cnt_kernel, CGRID(M), 0, st, M, srec, cnt);
+    // HITE_SEED_PLACE=0 / 1 (tests): never / always through the grouped form
+    static const int place_mode = [] { const char *e = getenv("HITE_SEED_PLACE"); return e && *e ? atoi(e) : -1; }();
+    if (place_mode == 1 || (place_mode != 0 && M >= RS_WIDE_MIN)) {
+        unsigned long long *pk; unsigned *pv;
+        CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 8, &p)); pk = (unsigned long long *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); pv = (unsigned *)p;
+        Sorter sp;
+        CCHK(sorter_from_arena(sp, ctx, A, st, M));
+        hipLaunchKernelGGL(seed_count_kernel<true>, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, srec, pk, pv);
+        int mb = 1;
+        while (mb < 32 && (1ll << mb) < M) mb++;                  // ranks < 2^mb
+        const int shift = mb > 10 ? mb - 10 : 0;
+        CCHK(sorter_sort_bits_swap(sp, &pk, &pv, M, shift, shift + (M >= RS_WIDE_MIN ? 10 : 8)));       // ONE pass
+        const int nb = (int)((M + 256 * SPL_ITEMS - 1) / (256 * SPL_ITEMS));
+        // what keeps the window inside an L2 (4 MB): two workgroups per compute unit -- 64 KB of LDS asked for, none used --, i.e. 131 k
+        // records of a chiplet in flight, half a group; and the counts NOT scattered beside the records (a second window): seed_cnt_kernel
+        // reads them back in order.  1 Gbp, 182 M seeds, seed_runs_count: direct scatter 10.7 ms; grouped 9.1; without the counts 7.8;
+        // with the LDS cap 7.1.
+        static const int place_lds = [] { const char *e = getenv("HITE_SEED_PLACE_LDS"); return e && *e ? atoi(e) : 65536; }();
+        static const bool place_cnt = [] { const char *e = getenv("HITE_SEED_PLACE_CNT"); return e && *e == '1'; }();
+        hipLaunchKernelGGL(seed_place_kernel, dim3((unsigned)nb), dim3(256), (size_t)place_lds, st, M, nb, pk, pv, srec, place_cnt ? cnt : (int32_t *)nullptr);
+        if (!place_cnt) hipLaunchKernelGGL(seed_cnt_kernel, CGRID(M), 0, st, M, srec, cnt);
+    } else {
+        hipLaunchKernelGGL(seed_count_kernel<false>, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, srec,
+                           (unsigned long long *)nullptr, (unsigned *)nullptr);
+        hipLaunchKernelGGL(seed_cnt_kernel, CGRID(M), 0, st, M, srec, cnt);
+    }
     CCHK(scan_excl_buf<int32_t>(ctx, bs, cnt, M, aoff, st));
     hite_prof_end(ctx, tk_rc, st);
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, aoff + M, 8, hipMemcpyDeviceToDevice, st));

@@ -1475,7 +1475,10 @@ def test_seed_anchor_record_forms(tmp_path):
     import sys as _sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for extra in ({"HITE_SEED_PACK": "0"}, {"HITE_SEED_PACK": "0", "HITE_SORT_WIDE_MIN": "2"}):
+    # HITE_SEED_PLACE=1: the seeds' records reach position order through one radix pass + a scatter inside L2-sized windows (the form of
+    # genomes with >= 4 M minimizers) also at test sizes, with both radix-sort forms and with the counts scattered beside the records
+    for extra in ({"HITE_SEED_PACK": "0"}, {"HITE_SEED_PACK": "0", "HITE_SORT_WIDE_MIN": "2"}, {"HITE_SEED_PLACE": "1"},
+                  {"HITE_SEED_PLACE": "1", "HITE_SORT_WIDE_MIN": "2", "HITE_SEED_PLACE_CNT": "1", "HITE_SEED_PLACE_LDS": "0"}):
         rc = subprocess.run([_sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-x", "-q", "-m", "gpu", "-k",
                              "seed_allvsall or seed_shard or coarse_boundary"], env=dict(os.environ, **extra), capture_output=True, text=True, cwd=root)
         assert rc.returncode == 0, rc.stdout[-3000:] + rc.stderr[-2000:]
