@@ -11,7 +11,9 @@ BENCH="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-coarse --no-m
 timeout 900 python bench.py > $OUT/${TAG}_bench_fine.json 2> $OUT/${TAG}_bench_fine.err
 timeout 600 python bench.py --config C2 > $OUT/${TAG}_bench_c2.json 2> $OUT/${TAG}_bench_c2.err
 timeout 900 python bench.py --config C5 --steps 3 --warmup 1 > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err
+if [ "${SKIP_C5X8:-0}" != "1" ]; then
 timeout 1200 python bench.py --config C5 --genomes 8 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_c5x8.json 2> $OUT/${TAG}_bench_c5x8.err
+fi
 timeout 600 python bench.py --config C4share > $OUT/${TAG}_bench_c4share.json 2> $OUT/${TAG}_bench_c4share.err
 if [ "${QUICK:-0}" != "1" ]; then      # (QUICK=1: the benches and the rocprofv3 passes only)
 timeout 600 python -m pytest tests/test_gpu_scale.py -q -m gpu -s -k "c2 or c3 or c5" > $OUT/${TAG}_scale_tests_raw.txt 2>&1
