@@ -954,8 +954,8 @@ static int sorter_from_arena(Sorter &S, hite_ctx *ctx, Arena &A, hipStream_t st,
     CCHK(arena_alloc(ctx, A, (size_t)(n + 1) * 8, &p)); S.k2 = (unsigned long long *)p;
     S.v2 = nullptr;
     if (with_vals) { CCHK(arena_alloc(ctx, A, (size_t)(n + 1) * 4, &p)); S.v2 = (unsigned *)p; }
-    CCHK(arena_alloc(ctx, A, (size_t)S.hist_n * 4, &p)); S.hist = (int32_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(S.hist_n + 1) * 8, &p)); S.offs = (int64_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)S.hist_n * sizeof(rs_cnt_t), &p)); S.hist = (rs_cnt_t *)p;
+    CCHK(arena_alloc(ctx, A, (size_t)(S.hist_n + 1) * sizeof(rs_off_t), &p)); S.offs = (rs_off_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)sorter_tmp_elems(S.hist_n) * 8, &p)); S.bs = (int64_t *)p;
     return HITE_OK;
 }

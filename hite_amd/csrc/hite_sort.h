@@ -12,13 +12,17 @@
 // stable LSD radix sort of (u64 key, u32 value).  Two digit widths: 8 bits (tile = 256 threads x 8 items) for small
 // inputs, 10 bits (tile = 256 threads x 32 items, 1024 bins) for large ones: a 50-bit key takes 5 passes instead of 7.
 // ---------------------------------------------------------------------------------------------
+// the [tile][digit] matrices beside the keys: counts fit 16 bits (a tile holds at most 8192 elements), offsets 32 (every caller sorts
+// < 2^32 elements) -- as int32 / int64 they were 2.9 GB per pass of the 713 M anchor sort against 11.4 GB of keys
+typedef unsigned short rs_cnt_t;
+typedef unsigned rs_off_t;
 #define RS_ITEMS 8
 #define RS_TILE (256 * RS_ITEMS)
 #define RS_WIDE_MIN (1 << 22)   // element count from which the 10-bit form is used
 
 template <int BITS, int ITEMS>
 static __global__ void __launch_bounds__(256) rs_hist_kernel(const unsigned long long *__restrict__ keys, int64_t n, int shift,
-                                                             int nblocks, int32_t *__restrict__ hist /* [bins][nblocks] */) {
+                                                             int nblocks, rs_cnt_t *__restrict__ hist /* [nblocks][bins] */) {
     constexpr int BINS = 1 << BITS;
     __shared__ int h[BINS];
     for (int b = threadIdx.x; b < BINS; b += 256) h[b] = 0;
@@ -38,7 +42,7 @@ static __global__ void __launch_bounds__(256) rs_hist_kernel(const unsigned long
         if (i < n) atomicAdd(&h[(int)((kk[it] >> shift) & (unsigned long long)(BINS - 1))], 1);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < BINS; b += 256) hist[(int64_t)blockIdx.x * BINS + b] = h[b];      // tile-major: one coalesced run per tile
+    for (int b = threadIdx.x; b < BINS; b += 256) hist[(int64_t)blockIdx.x * BINS + b] = (rs_cnt_t)h[b];      // tile-major: one coalesced run per tile
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -50,7 +54,7 @@ static __global__ void __launch_bounds__(256) rs_hist_kernel(const unsigned long
 // ---------------------------------------------------------------------------------------------
 #define RS_GROUP 64
 template <int BINS>
-static __global__ void __launch_bounds__(256) rs_colsum_kernel(const int32_t *__restrict__ hist, int nblocks, long long *__restrict__ gsum /* [groups][BINS] */) {
+static __global__ void __launch_bounds__(256) rs_colsum_kernel(const rs_cnt_t *__restrict__ hist, int nblocks, long long *__restrict__ gsum /* [groups][BINS] */) {
     const int d = blockIdx.y * 256 + threadIdx.x, g = blockIdx.x;
     const int t0 = g * RS_GROUP, t1 = t0 + RS_GROUP < nblocks ? t0 + RS_GROUP : nblocks;
     long long acc = 0;
@@ -89,18 +93,18 @@ static __global__ void __launch_bounds__(BINS > 1024 ? 1024 : BINS) rs_digitscan
     dtot[threadIdx.x] = pre + x - v;
 }
 template <int BINS>
-static __global__ void __launch_bounds__(256) rs_coloffs_kernel(const int32_t *__restrict__ hist, int nblocks, const long long *__restrict__ gsum,
-                                                                const long long *__restrict__ dbase, int64_t *__restrict__ offs) {
+static __global__ void __launch_bounds__(256) rs_coloffs_kernel(const rs_cnt_t *__restrict__ hist, int nblocks, const long long *__restrict__ gsum,
+                                                                const long long *__restrict__ dbase, rs_off_t *__restrict__ offs) {
     const int d = blockIdx.y * 256 + threadIdx.x, g = blockIdx.x;
     const int t0 = g * RS_GROUP, t1 = t0 + RS_GROUP < nblocks ? t0 + RS_GROUP : nblocks;
     long long run = gsum[(int64_t)g * BINS + d] + dbase[d];
-    for (int t = t0; t < t1; t++) { offs[(int64_t)t * BINS + d] = run; run += hist[(int64_t)t * BINS + d]; }
+    for (int t = t0; t < t1; t++) { offs[(int64_t)t * BINS + d] = (rs_off_t)run; run += hist[(int64_t)t * BINS + d]; }
 }
 
 template <int BITS, int ITEMS>
 static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned long long *__restrict__ kin, const unsigned *__restrict__ vin,
                                                                 unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
-                                                                int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
+                                                                int64_t n, int shift, int nblocks, const rs_off_t *__restrict__ offs) {
     constexpr int BINS = 1 << BITS;
     __shared__ unsigned base[BINS];   // global positions fit 32 bits (every caller sorts < 2^32 elements)
     __shared__ int cnt[4][BINS];
@@ -170,7 +174,7 @@ static __global__ void __launch_bounds__(256) rs_scatter_kernel(const unsigned l
 template <bool VALS>
 static __global__ void __launch_bounds__(512) rs_scatter_staged_kernel(const unsigned long long *__restrict__ kin, const unsigned *__restrict__ vin,
                                                                        unsigned long long *__restrict__ kout, unsigned *__restrict__ vout,
-                                                                       int64_t n, int shift, int nblocks, const int64_t *__restrict__ offs) {
+                                                                       int64_t n, int shift, int nblocks, const rs_off_t *__restrict__ offs) {
     extern __shared__ unsigned char rss_lds[];
     constexpr int R = VALS ? RSS_VROUNDS : RSS_KROUNDS, TILE = 512 * R, ESZ = VALS ? 12 : 8;
     unsigned long long *skey = reinterpret_cast<unsigned long long *>(rss_lds);
@@ -270,8 +274,9 @@ struct Sorter {
     int64_t cap = 0;
     unsigned long long *k2 = nullptr;
     unsigned *v2 = nullptr;
-    int32_t *hist = nullptr;
-    int64_t *offs = nullptr, *bs = nullptr;
+    rs_cnt_t *hist = nullptr;
+    rs_off_t *offs = nullptr;
+    int64_t *bs = nullptr;
     int64_t hist_n = 0;
     bool owned = true;      // false: the buffers belong to an arena (sorter_free leaves them alone)
 };
@@ -302,15 +307,15 @@ static int sorter_init(Sorter &S, hite_ctx *ctx, hipStream_t st, int64_t n) {
         int rc;
         if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)(n + 1) * 8, &p))) return rc; S.k2 = (unsigned long long *)p;
         if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)(n + 1) * 4, &p))) return rc; S.v2 = (unsigned *)p;
-        if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)S.hist_n * 4, &p))) return rc; S.hist = (int32_t *)p;
-        if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)(S.hist_n + 1) * 8, &p))) return rc; S.offs = (int64_t *)p;
+        if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)S.hist_n * sizeof(rs_cnt_t), &p))) return rc; S.hist = (rs_cnt_t *)p;
+        if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)(S.hist_n + 1) * sizeof(rs_off_t), &p))) return rc; S.offs = (rs_off_t *)p;
         if ((rc = arena_alloc(ctx, *tl_sort_arena, (size_t)sorter_tmp_elems(S.hist_n) * 8, &p))) return rc; S.bs = (int64_t *)p;
         return HITE_OK;
     }
     HITE_CHECK(ctx, hipMalloc((void **)&S.k2, (size_t)(n + 1) * 8));
     HITE_CHECK(ctx, hipMalloc((void **)&S.v2, (size_t)(n + 1) * 4));
-    HITE_CHECK(ctx, hipMalloc((void **)&S.hist, (size_t)S.hist_n * 4));
-    HITE_CHECK(ctx, hipMalloc((void **)&S.offs, (size_t)(S.hist_n + 1) * 8));
+    HITE_CHECK(ctx, hipMalloc((void **)&S.hist, (size_t)S.hist_n * sizeof(rs_cnt_t)));
+    HITE_CHECK(ctx, hipMalloc((void **)&S.offs, (size_t)(S.hist_n + 1) * sizeof(rs_off_t)));
     HITE_CHECK(ctx, hipMalloc((void **)&S.bs, (size_t)sorter_tmp_elems(S.hist_n) * 8));
     return HITE_OK;
 }
