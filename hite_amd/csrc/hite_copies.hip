@@ -1810,7 +1810,7 @@ template <bool PK, bool EMIT>
 __global__ void __launch_bounds__(256) seed_clusters_kernel(int64_t na, int64_t G, const unsigned long long *__restrict__ akey,
                                                             const unsigned *__restrict__ aval, const int64_t *__restrict__ coff, int nc,
                                                             int32_t *__restrict__ tile_cnt, const int64_t *__restrict__ tile_first,
-                                                            unsigned *__restrict__ c_first) {
+                                                            unsigned *__restrict__ c_first, uint8_t *__restrict__ start_bits = nullptr) {
     __shared__ int s_tmp[8];
     // the tile goes through LDS (round 6): a thread walks 8 CONSECUTIVE anchors, and read straight from memory that was 64 lanes 64 bytes
     // apart in every load instruction (64 lines per instruction, each fetched 8 times).  Coalesced loads, 9-word rows against bank conflicts.
@@ -1840,11 +1840,29 @@ __global__ void __launch_bounds__(256) seed_clusters_kernel(int64_t na, int64_t 
     }
     int total;
     const int excl = block_excl_scan(c, s_tmp, &total);
-    if (!EMIT) { if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total; return; }
+    if (!EMIT) {
+        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+        if (start_bits) start_bits[(int64_t)blockIdx.x * 256 + threadIdx.x] = (uint8_t)bits;      // (for seed_cluster_emit_kernel)
+        return;
+    }
     int64_t o = tile_first[blockIdx.x] + excl;
 #pragma unroll
     for (int q = 0; q < SF_ITEMS; q++) if ((bits >> q) & 1u) c_first[o++] = (unsigned)(base + q);
     if (base <= na - 1 && na - 1 < base + SF_ITEMS) c_first[tile_first[gridDim.x]] = (unsigned)na;   // (the thread of the last anchor closes the list)
+}
+// pass EMIT from the start bits pass COUNT left (a byte per thread: 1/64 of the keys; round 6: the second reading of the 713 M keys and
+// of their cluster tests was half of the stage's 7.5 ms)
+__global__ void __launch_bounds__(256) seed_cluster_emit_kernel(int64_t na, const uint8_t *__restrict__ start_bits, const int64_t *__restrict__ tile_first,
+                                                                unsigned *__restrict__ c_first) {
+    __shared__ int s_tmp[8];
+    const int64_t base = (int64_t)blockIdx.x * SF_TILE + (int64_t)threadIdx.x * SF_ITEMS;
+    const unsigned bits = start_bits[(int64_t)blockIdx.x * 256 + threadIdx.x];
+    int total;
+    const int excl = block_excl_scan(__popc(bits), s_tmp, &total);
+    int64_t o = tile_first[blockIdx.x] + excl;
+#pragma unroll
+    for (int q = 0; q < SF_ITEMS; q++) if ((bits >> q) & 1u) c_first[o++] = (unsigned)(base + q);
+    if (base <= na - 1 && na - 1 < base + SF_ITEMS) c_first[tile_first[gridDim.x]] = (unsigned)na;
 }
 // one thread per cluster; EMIT = false counts the pieces, EMIT = true writes them at pfirst[cluster]
 template <bool EMIT, bool PK>
@@ -2144,16 +2162,17 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     CCHK(arena_alloc(ctx, A, (size_t)(ntile + 1) * 4, &p)); tcnt = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(ntile + 2) * 8, &p)); tfirst = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(ntile) * 8, &p)); bs2 = (int64_t *)p;
-    if (packed) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<true, false>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)nullptr, (unsigned *)nullptr);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<false, false>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)nullptr, (unsigned *)nullptr);
+    uint8_t *sbits;
+    CCHK(arena_alloc(ctx, A, (size_t)ntile * 256, &p)); sbits = (uint8_t *)p;
+    if (packed) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<true, false>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)nullptr, (unsigned *)nullptr, sbits);
+    else hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<false, false>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)nullptr, (unsigned *)nullptr, sbits);
     CCHK(scan_excl_buf<int32_t>(ctx, bs2, tcnt, ntile, tfirst, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, tfirst + ntile, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
     const int64_t ncl = S->h_pin[0];
     if (stats_out) stats_out[2] = ncl;
     CCHK(arena_alloc(ctx, A, (size_t)(ncl + 2) * 4, &p)); c_first = (unsigned *)p;
-    if (packed) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<true, true>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)tfirst, c_first);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<false, true>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)tfirst, c_first);
+    hipLaunchKernelGGL(seed_cluster_emit_kernel, dim3((unsigned)ntile), dim3(256), 0, st, na, sbits, (const int64_t *)tfirst, c_first);
     hite_prof_end(ctx, tk_cl, st);
     // pieces: count, scan, emit
     int tk_pc = hite_prof_begin(ctx, "seed_pieces", st);
