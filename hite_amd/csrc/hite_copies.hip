@@ -291,25 +291,36 @@ __global__ void __launch_bounds__(256) genome_minimizer_filter_kernel(int64_t nt
                                                                       const int32_t *__restrict__ tile_cnt, HSet hset,
                                                                       int32_t *__restrict__ cnt_out, const int64_t *__restrict__ first,
                                                                       unsigned long long *__restrict__ out, unsigned *__restrict__ out_rank,
-                                                                      unsigned long long cap) {
+                                                                      unsigned long long cap,
+                                                                      unsigned long long *__restrict__ wmask /* [ntiles][GM_TILE / 64]: pass COUNT's ballots, which pass WRITE reads instead of probing again */) {
     const int lane = threadIdx.x & 63;
     const int64_t tile = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (tile >= ntiles) return;
     const int n = tile_cnt[tile];
     const unsigned long long *reg = stage + tile * GM_TILE;
     unsigned long long at = WRITE ? (unsigned long long)first[tile] : 0ull;
+    if (WRITE && first[tile + 1] == first[tile]) return;          // (nothing of this tile is in the set)
     int c = 0;
     for (int r0 = 0; r0 < n; r0 += 64) {
         const int r = r0 + lane;
         unsigned long long rec = 0ull;
         bool want = false;
-        if (r < n) {
-            rec = reg[r];
-            const unsigned h31 = (unsigned)(rec >> 33);
-            const unsigned b = hset_bit(hset, h31);
-            want = ((hset.bits[b >> 5] >> (b & 31)) & 1u) && hset_probe(hset, h31);
+        unsigned long long bal;
+        if (WRITE) {
+            bal = wmask[tile * (GM_TILE / 64) + (r0 >> 6)];
+            if (bal == 0ull) continue;
+            want = (bal >> lane) & 1ull;
+            if (want) rec = reg[r];
+        } else {
+            if (r < n) {
+                rec = reg[r];
+                const unsigned h31 = (unsigned)(rec >> 33);
+                const unsigned b = hset_bit(hset, h31);
+                want = ((hset.bits[b >> 5] >> (b & 31)) & 1u) && hset_probe(hset, h31);
+            }
+            bal = __ballot(want);
+            if (lane == 0) wmask[tile * (GM_TILE / 64) + (r0 >> 6)] = bal;
         }
-        const unsigned long long bal = __ballot(want);
         if (WRITE) {
             const unsigned long long slot = at + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
             if (want && slot < cap) { out[slot] = rec; out_rank[slot] = (unsigned)slot; }
@@ -1073,7 +1084,11 @@ static int index_build_impl(hite_ctx *ctx, void **state_io, hipStream_t st, HSet
     CCHK(arena_alloc(ctx, B, (size_t)scan_tmp_elems(ntiles + 1) * 8, &p)); tbs = (int64_t *)p;
     CCHK(arena_alloc(ctx, B, (size_t)(ntiles > 0 ? ntiles : 1) * GM_TILE * 8, &p)); stage = (unsigned long long *)p;
     int32_t *tile_cnt_r = nullptr;       // restricted build from kept tiles: the filtered counts
-    if (keep_on && hset.tab) { CCHK(arena_alloc(ctx, B, (size_t)(ntiles + 1) * 4, &p)); tile_cnt_r = (int32_t *)p; }
+    unsigned long long *wmask = nullptr;
+    if (keep_on && hset.tab) {
+        CCHK(arena_alloc(ctx, B, (size_t)(ntiles + 1) * 4, &p)); tile_cnt_r = (int32_t *)p;
+        CCHK(arena_alloc(ctx, B, (size_t)(ntiles + 1) * (GM_TILE / 64) * 8, &p)); wmask = (unsigned long long *)p;
+    }
     int64_t blocks = ntiles < 256 * 64 ? ntiles : 256 * 64;
     if (blocks < 1) blocks = 1;
     int tk_gm = hite_prof_begin(ctx, "index_minimizers", st);
@@ -1123,11 +1138,11 @@ static int index_build_impl(hite_ctx *ctx, void **state_io, hipStream_t st, HSet
     if (ntiles > 0) {
         if (tile_cnt_r) {
             hipLaunchKernelGGL(genome_minimizer_filter_kernel<false>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, ntiles, stage, tile_cnt, hset,
-                               tile_cnt_r, (const int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr, cap);
+                               tile_cnt_r, (const int64_t *)nullptr, (unsigned long long *)nullptr, (unsigned *)nullptr, cap, wmask);
             CCHK(scan_excl_buf<int32_t>(ctx, tbs, tile_cnt_r, ntiles, tile_first, st));
             HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, tile_first + ntiles, 8, hipMemcpyDeviceToDevice, st));
             hipLaunchKernelGGL(genome_minimizer_filter_kernel<true>, dim3((unsigned)((ntiles + 3) / 4)), dim3(256), 0, st, ntiles, stage, tile_cnt, hset,
-                               (int32_t *)nullptr, tile_first, keys, vals, cap);
+                               (int32_t *)nullptr, tile_first, keys, vals, cap, wmask);
         } else {
             CCHK(scan_excl_buf<int32_t>(ctx, tbs, tile_cnt, ntiles, tile_first, st));
             HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, tile_first + ntiles, 8, hipMemcpyDeviceToDevice, st));
