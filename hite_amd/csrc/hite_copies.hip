@@ -1815,17 +1815,17 @@ __device__ __forceinline__ int seed_opens(int64_t i, unsigned long long ka, unsi
     if (!(s0 >= cb.slo && s0 < cb.shi)) { const int cs = contig_of(coff, nc, s0); cb.slo = coff[cs]; cb.shi = coff[cs + 1]; }
     return s1 >= cb.shi ? 1 : 0;
 }
-// Clusters without a flag array or a scan over the anchors: a workgroup owns SF_TILE consecutive anchors (8 per thread); pass
-// COUNT leaves the number of cluster starts of every tile, after a scan of those (one entry per 2048 anchors) pass EMIT finds the
-// starts again and writes the index of the k-th one of the tile to c_first[first[tile] + k].  The keys are read twice (16 B per
-// anchor) where flags + scan + scatter moved 42.
+// Clusters without a scan over the anchors: a workgroup owns SF_TILE consecutive anchors (8 per thread); this pass leaves the number
+// of cluster starts of every tile and a byte of start bits per thread; after a scan of the tile counts (one entry per 2048 anchors)
+// seed_cluster_emit_kernel writes the index of the k-th start of the tile to c_first[first[tile] + k] from the bits.  The keys are
+// read once (8 B + 1 bit per anchor; until late in round 6 the emit pass read and tested them again: 16 B; flags + scan + scatter of
+// round 4 moved 42).
 #define SF_ITEMS 8
 #define SF_TILE (256 * SF_ITEMS)
-template <bool PK, bool EMIT>
+template <bool PK>
 __global__ void __launch_bounds__(256) seed_clusters_kernel(int64_t na, int64_t G, const unsigned long long *__restrict__ akey,
                                                             const unsigned *__restrict__ aval, const int64_t *__restrict__ coff, int nc,
-                                                            int32_t *__restrict__ tile_cnt, const int64_t *__restrict__ tile_first,
-                                                            unsigned *__restrict__ c_first, uint8_t *__restrict__ start_bits = nullptr) {
+                                                            int32_t *__restrict__ tile_cnt, uint8_t *__restrict__ start_bits) {
     __shared__ int s_tmp[8];
     // the tile goes through LDS (round 6): a thread walks 8 CONSECUTIVE anchors, and read straight from memory that was 64 lanes 64 bytes
     // apart in every load instruction (64 lines per instruction, each fetched 8 times).  Coalesced loads, 9-word rows against bank conflicts.
@@ -1854,16 +1854,9 @@ __global__ void __launch_bounds__(256) seed_clusters_kernel(int64_t na, int64_t 
         if (i < na && seed_opens<PK>(i, k[q], k[q + 1], aval, G, coff, nc, cb)) { bits |= 1u << q; c++; }
     }
     int total;
-    const int excl = block_excl_scan(c, s_tmp, &total);
-    if (!EMIT) {
-        if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
-        if (start_bits) start_bits[(int64_t)blockIdx.x * 256 + threadIdx.x] = (uint8_t)bits;      // (for seed_cluster_emit_kernel)
-        return;
-    }
-    int64_t o = tile_first[blockIdx.x] + excl;
-#pragma unroll
-    for (int q = 0; q < SF_ITEMS; q++) if ((bits >> q) & 1u) c_first[o++] = (unsigned)(base + q);
-    if (base <= na - 1 && na - 1 < base + SF_ITEMS) c_first[tile_first[gridDim.x]] = (unsigned)na;   // (the thread of the last anchor closes the list)
+    (void)block_excl_scan(c, s_tmp, &total);
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = total;
+    start_bits[(int64_t)blockIdx.x * 256 + threadIdx.x] = (uint8_t)bits;      // (for seed_cluster_emit_kernel)
 }
 // pass EMIT from the start bits pass COUNT left (a byte per thread: 1/64 of the keys; round 6: the second reading of the 713 M keys and
 // of their cluster tests was half of the stage's 7.5 ms)
@@ -1877,7 +1870,7 @@ __global__ void __launch_bounds__(256) seed_cluster_emit_kernel(int64_t na, cons
     int64_t o = tile_first[blockIdx.x] + excl;
 #pragma unroll
     for (int q = 0; q < SF_ITEMS; q++) if ((bits >> q) & 1u) c_first[o++] = (unsigned)(base + q);
-    if (base <= na - 1 && na - 1 < base + SF_ITEMS) c_first[tile_first[gridDim.x]] = (unsigned)na;
+    if (base <= na - 1 && na - 1 < base + SF_ITEMS) c_first[tile_first[gridDim.x]] = (unsigned)na;   // (the thread of the last anchor closes the list)
 }
 // one thread per cluster; EMIT = false counts the pieces, EMIT = true writes them at pfirst[cluster]
 template <bool EMIT, bool PK>
@@ -2179,8 +2172,8 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(ntile) * 8, &p)); bs2 = (int64_t *)p;
     uint8_t *sbits;
     CCHK(arena_alloc(ctx, A, (size_t)ntile * 256, &p)); sbits = (uint8_t *)p;
-    if (packed) hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<true, false>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)nullptr, (unsigned *)nullptr, sbits);
-    else hipLaunchKernelGGL(HIP_KERNEL_NAME(seed_clusters_kernel<false, false>), dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, (const int64_t *)nullptr, (unsigned *)nullptr, sbits);
+    if (packed) hipLaunchKernelGGL(seed_clusters_kernel<true>, dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, sbits);
+    else hipLaunchKernelGGL(seed_clusters_kernel<false>, dim3((unsigned)ntile), dim3(256), 0, st, na, G, akey, aval, ctx->d_contig_off, ctx->n_contigs, tcnt, sbits);
     CCHK(scan_excl_buf<int32_t>(ctx, bs2, tcnt, ntile, tfirst, st));
     HITE_CHECK(ctx, hipMemcpyAsync(S->d_scal, tfirst + ntile, 8, hipMemcpyDeviceToDevice, st));
     CCHK(read_back(ctx, S, st, 1));
