@@ -1,5 +1,5 @@
 // hite_sort.h -- hand-written stable LSD radix sort of (u64 key, u32 value) pairs, shared by FMEA, the copy finder and the
-// seeding stage.  Per pass: per-tile digit histogram (LDS atomics), three-phase scan of the [digit][tile] matrix, stable
+// seeding stage.  Per pass: per-tile digit histogram (LDS atomics), three-phase scan of the [tile][digit] matrix, stable
 // scatter.  Two forms: 8-bit digits with a direct scatter (rank from wave ballots + per-wave digit counts) for small
 // inputs; 10-bit digits with the tile ranked and staged in LDS in output order (rs_scatter_staged_kernel) from 4 M elements
 // on.  HBM streaming: 8 B (histogram) + 12 B read and 12 B written per element per pass.
@@ -10,7 +10,8 @@
 
 // ---------------------------------------------------------------------------------------------
 // stable LSD radix sort of (u64 key, u32 value).  Two digit widths: 8 bits (tile = 256 threads x 8 items) for small
-// inputs, 10 bits (tile = 256 threads x 32 items, 1024 bins) for large ones: a 50-bit key takes 5 passes instead of 7.
+// inputs, 10 bits (1024 bins; tile = 7168 keys, or 4608 keys + values: RSS_KTILE / RSS_TILE below) for large ones: a 50-bit key
+// takes 5 passes instead of 7.
 // ---------------------------------------------------------------------------------------------
 // the [tile][digit] matrices beside the keys: counts fit 16 bits (a tile holds at most 8192 elements), offsets 32 (every caller sorts
 // < 2^32 elements) -- as int32 / int64 they were 2.9 GB per pass of the 713 M anchor sort against 11.4 GB of keys
