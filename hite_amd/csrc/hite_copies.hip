@@ -1674,6 +1674,80 @@ __global__ void seed_count_kernel(int64_t M, int64_t G, const int32_t *__restric
     if (SPLIT) { pk[i] = ((unsigned long long)(unsigned)i << 32) | (unsigned long long)t; pv[i] = y; }
     else srec[t] = make_uint2((unsigned)i, y);
 }
+// The same records without the run arrays (late round 6): flag array, scan of the flags and first-of-run array were three passes over
+// the index (2.1 ms per Gbp) to tell an entry where its run begins and ends.  A workgroup owns SC_TILE consecutive entries, puts the run
+// starts of its tile and of SC_HALO entries either side into a bit map in LDS (a ballot per 64 entries) and finds the start at or before
+// an entry and the next one behind it with two bit searches.  A run that begins or ends outside the halo is longer than SEED_MAXOCC (the
+// halo is larger), which is all the record needs to know about it.
+#define SC_TILE 2048
+#define SC_HALO 1024
+#define SC_WORDS ((SC_TILE + 2 * SC_HALO) / 64 + 1)
+template <bool SPLIT>
+__global__ void __launch_bounds__(256) seed_count2_kernel(int64_t M, int64_t G, const unsigned *__restrict__ idx_hs,
+                                                          const unsigned long long *__restrict__ idx_key, const unsigned *__restrict__ idx_t,
+                                                          SeedShard sh, uint2 *__restrict__ srec, unsigned long long *__restrict__ pk,
+                                                          unsigned *__restrict__ pv) {
+    static_assert(SC_HALO > SEED_MAXOCC + 1, "the halo must hold a whole countable run");
+    __shared__ unsigned long long s_bits[SC_WORDS + 3];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t t0 = (int64_t)blockIdx.x * SC_TILE, P0 = t0 - SC_HALO;
+    // bit x of the map = entry P0 + x opens a run (entry 0 does; entry M, the end of the index, counts as one)
+    for (int k = 0; k * 4 < SC_WORDS; k++) {
+        const int x = k * 256 + (int)threadIdx.x;
+        const int64_t e = P0 + x;
+        bool f = false;
+        if (e >= 0 && e <= M) f = e == 0 || e == M || (idx_hs[e] >> 1) != (idx_hs[e - 1] >> 1);
+        const unsigned long long bal = __ballot(f);
+        if (lane == 0 && k * 4 + w < SC_WORDS) s_bits[k * 4 + w] = bal;
+    }
+    __syncthreads();
+#pragma unroll 2
+    for (int q = 0; q < SC_TILE / 256; q++) {
+        const int64_t i = t0 + q * 256 + threadIdx.x;
+        if (i >= M) continue;
+        const int b = SC_HALO + q * 256 + (int)threadIdx.x;
+        // the run start at or before b, the next start behind b (each at most SC_HALO away, else: not found)
+        int lo_b = -1, hi_b = -1;
+        {
+            int wi = b >> 6;
+            unsigned long long m = s_bits[wi] & (0xffffffffffffffffull >> (63 - (b & 63)));
+            const int wmin = (b - SC_HALO) >> 6;
+            while (m == 0ull && wi > wmin) { wi--; m = s_bits[wi]; }
+            if (m != 0ull) lo_b = wi * 64 + 63 - __clzll((long long)m);
+        }
+        {
+            const int b1 = b + 1;
+            int wi = b1 >> 6;
+            unsigned long long m = s_bits[wi] & (0xffffffffffffffffull << (b1 & 63));
+            const int wmax = (b + SC_HALO) >> 6 < SC_WORDS - 1 ? (b + SC_HALO) >> 6 : SC_WORDS - 1;
+            while (m == 0ull && wi < wmax) { wi++; m = s_bits[wi]; }
+            if (m != 0ull) hi_b = wi * 64 + __ffsll((long long)m) - 1;
+        }
+        const bool countable = lo_b >= 0 && hi_b >= 0 && hi_b - lo_b <= SEED_MAXOCC;
+        const unsigned lo = (unsigned)(P0 + lo_b), hi = (unsigned)(P0 + hi_b);       // (used only when countable)
+        const unsigned occ = hi - lo;
+        const unsigned t = idx_t[i];
+        int c = 0;
+        if (countable) {
+            if (!sh.sharded) c = (int)(occ - 1);
+            else {
+                const unsigned long long ki = idx_key[i];
+                const unsigned hq = (unsigned)(ki >> 32);
+                const long long pi = (long long)(unsigned)ki;
+                for (unsigned j = lo; j < hi; j++) {
+                    if (j == (unsigned)i) continue;
+                    const unsigned long long kj = idx_key[j];
+                    const unsigned long long rel = (hq ^ (unsigned)(kj >> 32)) & 1u;
+                    const long long pj = (long long)(unsigned)kj;
+                    c += seed_owned(sh, rel, rel ? (unsigned long long)(pi + pj) : (unsigned long long)(pj - pi + G));
+                }
+            }
+        }
+        const unsigned y = countable ? (((unsigned)i - lo) | (occ << 10) | ((unsigned)c << 20)) : 0u;
+        if (SPLIT) { pk[i] = ((unsigned long long)(unsigned)i << 32) | (unsigned long long)t; pv[i] = y; }
+        else srec[t] = make_uint2((unsigned)i, y);
+    }
+}
 // the grouped records to their places (and the partner counts beside them); the workgroups of a chiplet take consecutive tiles (as
 // rs_scatter_staged_kernel): the window they write into is theirs
 #define SPL_ITEMS 8
@@ -2090,17 +2164,24 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
     int tk_rc = hite_prof_begin(ctx, "seed_runs_count", st);
     // runs of equal hs >> 1 in the index; per seed -- in position order, the rank the index build left in idx_t -- its partner count
     // and its record (index entry, place in its run)
-    int32_t *rflag, *cnt; int64_t *rid, *bs, *aoff; unsigned *run_first; uint2 *srec;
-    CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); rflag = (int32_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 8, &p)); rid = (int64_t *)p;
+    // HITE_SEED_COUNT2=0: the run arrays (flags, scan, first-of-run) and the thread-per-entry kernel of round 5
+    static const bool count2 = [] { const char *e = getenv("HITE_SEED_COUNT2"); return !(e && *e == '0'); }();
+    int32_t *rflag = nullptr, *cnt; int64_t *rid = nullptr, *bs, *aoff; unsigned *run_first = nullptr; uint2 *srec;
+    if (!count2) {
+        CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); rflag = (int32_t *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 8, &p)); rid = (int64_t *)p;
+        CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 4, &p)); run_first = (unsigned *)p;
+    }
     CCHK(arena_alloc(ctx, A, (size_t)scan_tmp_elems(M) * 8, &p)); bs = (int64_t *)p;
-    CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 4, &p)); run_first = (unsigned *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); cnt = (int32_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(M + 2) * 8, &p)); aoff = (int64_t *)p;
     CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 8, &p)); srec = (uint2 *)p;
-    hipLaunchKernelGGL(seed_runflag_kernel, CGRID(M), 0, st, M, S->idx_hs, rflag);
-    CCHK(scan_excl_buf<int32_t>(ctx, bs, rflag, M, rid, st));
-    hipLaunchKernelGGL(seed_runfirst_kernel, CGRID(M), 0, st, M, rflag, rid, run_first);
+    const dim3 c2grid((unsigned)((M + SC_TILE - 1) / SC_TILE));
+    if (!count2) {
+        hipLaunchKernelGGL(seed_runflag_kernel, CGRID(M), 0, st, M, S->idx_hs, rflag);
+        CCHK(scan_excl_buf<int32_t>(ctx, bs, rflag, M, rid, st));
+        hipLaunchKernelGGL(seed_runfirst_kernel, CGRID(M), 0, st, M, rflag, rid, run_first);
+    }
     const SeedShard shard = seed_shard_of(ctx, G);
     // HITE_SEED_PLACE=0 / 1 (tests): never / always through the grouped form
     static const int place_mode = [] { const char *e = getenv("HITE_SEED_PLACE"); return e && *e ? atoi(e) : -1; }();
@@ -2110,7 +2191,8 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
         CCHK(arena_alloc(ctx, A, (size_t)(M + 1) * 4, &p)); pv = (unsigned *)p;
         Sorter sp;
         CCHK(sorter_from_arena(sp, ctx, A, st, M));
-        hipLaunchKernelGGL(seed_count_kernel<true>, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, srec, pk, pv);
+        if (count2) hipLaunchKernelGGL(seed_count2_kernel<true>, c2grid, dim3(256), 0, st, M, G, S->idx_hs, S->idx_key, S->idx_t, shard, srec, pk, pv);
+        else hipLaunchKernelGGL(seed_count_kernel<true>, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, srec, pk, pv);
         int mb = 1;
         while (mb < 32 && (1ll << mb) < M) mb++;                  // ranks < 2^mb
         const int shift = mb > 10 ? mb - 10 : 0;
@@ -2125,8 +2207,10 @@ static int seed_allvsall_impl(hite_ctx *ctx, void **state_io, int64_t seg_len, i
         hipLaunchKernelGGL(seed_place_kernel, dim3((unsigned)nb), dim3(256), (size_t)place_lds, st, M, nb, pk, pv, srec, place_cnt ? cnt : (int32_t *)nullptr);
         if (!place_cnt) hipLaunchKernelGGL(seed_cnt_kernel, CGRID(M), 0, st, M, srec, cnt);
     } else {
-        hipLaunchKernelGGL(seed_count_kernel<false>, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, srec,
-                           (unsigned long long *)nullptr, (unsigned *)nullptr);
+        if (count2) hipLaunchKernelGGL(seed_count2_kernel<false>, c2grid, dim3(256), 0, st, M, G, S->idx_hs, S->idx_key, S->idx_t, shard, srec,
+                                       (unsigned long long *)nullptr, (unsigned *)nullptr);
+        else hipLaunchKernelGGL(seed_count_kernel<false>, CGRID(M), 0, st, M, G, rflag, rid, run_first, S->idx_key, S->idx_t, shard, srec,
+                                (unsigned long long *)nullptr, (unsigned *)nullptr);
         hipLaunchKernelGGL(seed_cnt_kernel, CGRID(M), 0, st, M, srec, cnt);
     }
     CCHK(scan_excl_buf<int32_t>(ctx, bs, cnt, M, aoff, st));

@@ -1164,7 +1164,12 @@ def test_seed_allvsall_edge_cases(ctx):
     g3 = [base[:10_000] + fam + base[10_000:29_400] + fam[:700] + "N" * 50 + fam[750:] + base[29_400:45_000] +
           casegen.revcomp(fam) + base[45_000:]]                                             # direct, N-broken and inverted copies
     g4 = [casegen.rand_seq(rng, 3000) + unit * 6 + casegen.rand_seq(rng, 3000), "N" * 2000 + casegen.rand_seq(rng, 4000)]  # tandem array
-    for contigs, seg in ((g1, 10_000), (g2, 1000), (g3, 20_000), (g3, 1_000_000), (g4, 2_500)):
+    # hashes that occur about SEED_MAXOCC = 1000 times (a run of the index that long is not seeded from: the kernel finds a run's ends
+    # with bit searches inside a halo of 1024 entries): arrays of 998 .. 1003 and 1100 copies of a 41-base unit, behind / before other runs
+    u41, v43 = casegen.rand_seq(rng, 41), casegen.rand_seq(rng, 43)
+    g5 = [[casegen.rand_seq(rng, 1500) + u41 * n + casegen.rand_seq(rng, 700)] for n in (998, 1000, 1001, 1003)]
+    g5.append([u41 * 999 + casegen.rand_seq(rng, 100), v43 * 1002, casegen.rand_seq(rng, 300) + v43[::-1] * 1100])
+    for contigs, seg in ((g1, 10_000), (g2, 1000), (g3, 20_000), (g3, 1_000_000), (g4, 2_500)) + tuple((g, 1_000_000) for g in g5):
         ctx.genome_pack(contigs)
         ctx.release_copy_index()
         got = ctx.seed_allvsall(seg_len=seg)
